@@ -1,0 +1,323 @@
+"""Write the golden fixtures by running the REAL reference (janosh/torch-mnf).
+
+Run in the build container only (needs /root/reference; it never travels):
+
+    python tests/golden/gen_golden.py
+
+Every fixture is data: inputs, masks/noise, the reference's outputs, and -- where they
+cannot be rebuilt from ``recipes.py`` -- parameter values.  No reference source text is
+stored.  Fixture list follows SURVEY.md section 8c (G1..G9).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("MNF_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from sklearn.datasets import make_moons  # noqa: E402
+from torch.distributions import MultivariateNormal  # noqa: E402
+
+import recipes  # noqa: E402
+import torch_mnf.flows as nf  # noqa: E402  (the reference)
+from torch_mnf.flows import spline_flow as ref_spline  # noqa: E402
+from torch_mnf.layers import MNFLinear  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  keys={len(arrays)}")
+
+
+def moons(n):
+    """== torch_mnf.data.sample_moons(n) (data.py:21-24); data.py itself needs seaborn."""
+    pts, _ = make_moons(n, noise=0.05, random_state=0)
+    return torch.as_tensor(pts).float()
+
+
+def sd_arrays(prefix, sd):
+    return {f"{prefix}{k}": npy(v) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_c1_stack():
+    """9 x AffineHalfFlow(d=2) on half-moons, default-init (seed 0) and trained."""
+    x = moons(4096)
+    base = MultivariateNormal(torch.zeros(2), torch.eye(2))
+    for tag, steps in (("init", 0), ("trained", 300)):
+        torch.manual_seed(0)
+        flows = [nf.AffineHalfFlow(dim=2, parity=bool(i % 2)) for i in range(9)]
+        model = nf.NormalizingFlowModel(base, flows)
+        if steps:
+            opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=1e-5)
+            for _ in range(steps):
+                xb = x[torch.randperm(4096)[:512]]  # minibatches of the evaluated points
+                _, ld = model.inverse(xb)
+                loss = -(ld + model.base_log_prob(xb)).sum() / 512
+                model.zero_grad()
+                loss.backward()
+                opt.step()
+        with torch.no_grad():
+            zs, ld_inv = model.inverse(x)
+            blp = model.base_log_prob(x)
+            xs, ld_fwd = model.forward(zs[-1])
+        out = {"x": npy(x), "ld_inv": npy(ld_inv), "base_log_prob": npy(blp),
+               "ld_fwd": npy(ld_fwd),
+               "mean_log_prob": np.float64((ld_inv + blp).double().mean().item())}
+        # keep every 3rd intermediate + the last to stay small; index list is stored
+        keep = [0, 3, 6, 9]
+        out["keep"] = np.array(keep)
+        for i in keep:
+            out[f"zs{i}"] = npy(zs[i])
+            out[f"xs{i}"] = npy(xs[i])
+        for li, f in enumerate(flows):
+            out.update(sd_arrays(f"L{li}.", f.state_dict()))
+        save(f"g1_c1_stack_{tag}", **out)
+
+
+# ----------------------------------------------------------------------------- G2
+def g2_affine_half_single():
+    out = {}
+    for dim in (64, 256):
+        for parity in (False, True):
+            seed = 200 + dim + int(parity)
+            f = nf.AffineHalfFlow(dim, parity)
+            f.load_state_dict(recipes.affine_half_params(seed, dim))
+            z = recipes.gaussian(seed + 1, 256 if dim == 64 else 64, dim)
+            with torch.no_grad():
+                x_f, ld_f = f.forward(z)
+                x_i, ld_i = f.inverse(z)
+            tag = f"d{dim}_p{int(parity)}"
+            out.update({f"{tag}.z": npy(z), f"{tag}.fwd": npy(x_f), f"{tag}.ld_fwd": npy(ld_f),
+                        f"{tag}.inv": npy(x_i), f"{tag}.ld_inv": npy(ld_i)})
+    # NICE variants and odd hidden sizes (scale/shift flags, h_sizes of other lengths)
+    for tag, kw in (("nice", dict(scale=False)), ("noshift", dict(shift=False)),
+                    ("h2", dict(h_sizes=(16, 40))), ("h1", dict(h_sizes=(7,)))):
+        dim, seed = 10, 290
+        f = nf.AffineHalfFlow(dim, True, **kw)
+        f.load_state_dict(recipes.affine_half_params(seed, dim, **kw))
+        z = recipes.gaussian(seed + 1, 64, dim)
+        with torch.no_grad():
+            x_f, ld_f = f.forward(z)
+            x_i, ld_i = f.inverse(z)
+        out.update({f"{tag}.z": npy(z), f"{tag}.fwd": npy(x_f), f"{tag}.ld_fwd": npy(ld_f),
+                    f"{tag}.inv": npy(x_i), f"{tag}.ld_inv": npy(ld_i)})
+    save("g2_affine_half_single", **out)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3_c2_stack():
+    """9 x AffineHalfFlow d=64 (the benchmark stack's weights) on 256 rows, plus d=256."""
+    out = {}
+    for dim in (64, 256):
+        sds = recipes.c2_stack_params(dim)
+        flows = []
+        for i, sd in enumerate(sds):
+            f = nf.AffineHalfFlow(dim, parity=bool(i % 2))
+            f.load_state_dict(sd)
+            flows.append(f)
+        base = MultivariateNormal(torch.zeros(dim), torch.eye(dim))
+        model = nf.NormalizingFlowModel(base, flows)
+        x = recipes.gaussian(300 + dim, 256 if dim == 64 else 64, dim)
+        with torch.no_grad():
+            zs, ld = model.inverse(x)
+            blp = model.base_log_prob(x)
+            incr, cur = [], x
+            for f in reversed(flows):
+                cur, l1 = f.inverse(cur)
+                incr.append(npy(l1))
+            xs, ld_f = model.forward(x)
+            z64, ld64 = nf.NormalizingFlowModel(base, flows).double().inverse(x.double())
+        out.update({f"d{dim}.x": npy(x), f"d{dim}.z_last": npy(zs[-1]), f"d{dim}.z_mid": npy(zs[4]),
+                    f"d{dim}.ld_inv": npy(ld), f"d{dim}.ld_incr": np.stack(incr),
+                    f"d{dim}.base_log_prob": npy(blp),
+                    f"d{dim}.mean_log_prob": np.float64((ld + blp).double().mean().item()),
+                    f"d{dim}.x_fwd_last": npy(xs[-1]), f"d{dim}.ld_fwd": npy(ld_f),
+                    f"d{dim}.z_last_f64": npy(z64[-1]), f"d{dim}.ld_inv_f64": npy(ld64)})
+    save("g3_c2_stack", **out)
+
+
+# ----------------------------------------------------------------------------- G4
+def g4_rqs_direct():
+    """unconstrained_RQS called directly, edge inputs included."""
+    out = {}
+    T = 3.0
+    for K in (5, 8):
+        rng = np.random.default_rng(400 + K)
+        n = 512
+        v = (2.2 * rng.standard_normal(n)).astype(np.float32)
+        edge = np.array([0.0, T, -T, np.nextafter(np.float32(T), np.float32(10)),
+                         np.nextafter(np.float32(-T), np.float32(-10)), 3.5, -7.0, np.nan,
+                         np.nextafter(np.float32(T), np.float32(0)), 1e-30, -1e-30, 2.9999],
+                        dtype=np.float32)
+        v[: len(edge)] = edge
+        W = (2.0 * rng.standard_normal((n, K))).astype(np.float32)
+        H = (2.0 * rng.standard_normal((n, K))).astype(np.float32)
+        D = (2.0 * rng.standard_normal((n, K - 1))).astype(np.float32)
+        D[20:24] = 30.0  # softplus linear branch (threshold 20)
+        out.update({f"K{K}.v": v, f"K{K}.W": W, f"K{K}.H": H, f"K{K}.D": D})
+        for inv in (False, True):
+            y, lad = ref_spline.unconstrained_RQS(
+                torch.from_numpy(v), torch.from_numpy(W), torch.from_numpy(H),
+                torch.from_numpy(D), inverse=inv, tail_bound=T)
+            out[f"K{K}.out_{'inv' if inv else 'fwd'}"] = npy(y)
+            out[f"K{K}.lad_{'inv' if inv else 'fwd'}"] = npy(lad)
+    save("g4_rqs_direct", **out)
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_nsf_cl_layer():
+    out = {}
+    for dim, K, n_h, rows in ((32, 8, 8, 256), (32, 8, 16, 256), (2, 8, 16, 256), (6, 5, 8, 128)):
+        seed = 500 + dim + n_h
+        f = nf.NSF_CL(dim, K=K, B=3, n_h=n_h)
+        f.load_state_dict(recipes.nsf_cl_params(seed, dim, K, n_h))
+        z = recipes.gaussian(seed + 1, rows, dim, scale=1.4)
+        z[0, :] = 3.0
+        z[1, :] = -3.0
+        z[2, 0] = 3.5  # one element outside, rest of the row inside
+        z[3, :] = 5.0  # whole row outside
+        with torch.no_grad():
+            x_f, ld_f = f.forward(z)
+            x_i, ld_i = f.inverse(z)
+        tag = f"d{dim}_K{K}_h{n_h}"
+        out.update({f"{tag}.z": npy(z), f"{tag}.fwd": npy(x_f), f"{tag}.ld_fwd": npy(ld_f),
+                    f"{tag}.inv": npy(x_i), f"{tag}.ld_inv": npy(ld_i)})
+    save("g5_nsf_cl_layer", **out)
+
+
+# ----------------------------------------------------------------------------- G6
+def g6_c3_stack():
+    """3 x [ActNorm, Glow, NSF_CL] d=32 K=8 n_h=8 after ActNorm's data-dependent init."""
+    dim, rows = 32, 256
+    torch.manual_seed(6)
+    flows = []
+    for i in range(3):
+        an = nf.ActNormFlow(dim)
+        gl = nf.Glow(dim)
+        gp = recipes.glow_params(600 + i, dim)
+        gl.P = gp["P"]
+        gl.load_state_dict({"L": gp["L"], "S": gp["S"], "U": gp["U"]})
+        sp = nf.NSF_CL(dim, K=8, B=3, n_h=8)
+        sp.load_state_dict(recipes.nsf_cl_params(610 + i, dim, 8, 8))
+        flows += [an, gl, sp]
+    model = nf.NormalizingFlow(flows)
+    x = recipes.gaussian(620, rows, dim, scale=1.2)
+    out = {"x": npy(x)}
+    with torch.no_grad():
+        zs, ld = model.inverse(x)  # first inverse call initialises the three ActNorms
+        for i in range(3):
+            out[f"actnorm{i}.s"] = npy(flows[3 * i].s)
+            out[f"actnorm{i}.t"] = npy(flows[3 * i].t)
+        zs2, ld2 = model.inverse(x)  # now data-independent
+        xs, ld_f = model.forward(x)
+        shapes = [tuple(f.inverse(x)[1].shape) for f in flows[:3]]
+    out.update({"z_last_first_call": npy(zs[-1]), "ld_first_call": npy(ld),
+                "z_last": npy(zs2[-1]), "ld_inv": npy(ld2), "z_mid": npy(zs2[5]),
+                "x_fwd_last": npy(xs[-1]), "ld_fwd": npy(ld_f),
+                "ld_shape_actnorm": np.array(shapes[0], dtype=np.int64),
+                "ld_shape_glow": np.array(shapes[1], dtype=np.int64),
+                "ld_shape_nsf": np.array(shapes[2], dtype=np.int64)})
+    save("g6_c3_stack", **out)
+
+
+# ----------------------------------------------------------------------------- G7
+def g7_rnvp():
+    out = {}
+    for dim, rows in ((50, 128), (800, 32), (784, 16)):
+        seed = 700 + dim
+        f = nf.RNVP(dim, h_sizes=(50,))
+        f.load_state_dict(recipes.rnvp_params(seed, dim, 50))
+        z = recipes.gaussian(seed + 1, rows, dim)
+        torch.manual_seed(seed)
+        mask = torch.bernoulli(0.5 * torch.ones_like(z))
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            x, ld = f.forward(z)
+        out.update({f"d{dim}.z": npy(z), f"d{dim}.mask_bits": np.packbits(npy(mask).astype(np.uint8), axis=1),
+                    f"d{dim}.x": npy(x), f"d{dim}.ld": npy(ld)})
+    save("g7_rnvp", **out)
+
+
+# ----------------------------------------------------------------------------- G8
+def g8_sample_z():
+    """MNFLinear(800, 50).sample_z(64) with the noise and both masks captured."""
+    torch.manual_seed(8)
+    layer = MNFLinear(800, 50)
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(800 + i, 800, 50))
+    captured = {"eps": [], "mask": []}
+    real_randn_like, real_bernoulli = torch.randn_like, torch.bernoulli
+
+    def randn_like(t, *a, **k):
+        r = real_randn_like(t, *a, **k)
+        captured["eps"].append(r.clone())
+        return r
+
+    def bernoulli(t, *a, **k):
+        r = real_bernoulli(t, *a, **k)
+        captured["mask"].append(r.clone())
+        return r
+
+    torch.randn_like, torch.bernoulli = randn_like, bernoulli
+    try:
+        with torch.no_grad():
+            z, ld = layer.sample_z(64)
+    finally:
+        torch.randn_like, torch.bernoulli = real_randn_like, real_bernoulli
+    assert len(captured["eps"]) == 1 and len(captured["mask"]) == 2
+    save("g8_sample_z", q0_mean=npy(layer.q0_mean), q0_log_var=npy(layer.q0_log_var),
+         eps=npy(captured["eps"][0]),
+         mask0_bits=np.packbits(npy(captured["mask"][0]).astype(np.uint8), axis=1),
+         mask1_bits=np.packbits(npy(captured["mask"][1]).astype(np.uint8), axis=1),
+         z=npy(z), log_det=npy(ld))
+
+
+# ----------------------------------------------------------------------------- G9
+def g9_logdet_shapes():
+    x = recipes.gaussian(900, 8, 4)
+    mods = {"affine_half": nf.AffineHalfFlow(4, False), "nsf_cl": nf.NSF_CL(4, K=5),
+            "actnorm": nf.ActNormFlow(4), "affine_const": nf.AffineConstantFlow(4),
+            "glow": nf.Glow(4), "rnvp": nf.RNVP(4)}
+    out = {}
+    with torch.no_grad():
+        for name, m in mods.items():
+            out[f"{name}.fwd"] = np.array(tuple(m.forward(x)[1].shape), dtype=np.int64)
+            if hasattr(m, "inverse"):
+                out[f"{name}.inv"] = np.array(tuple(m.inverse(x)[1].shape), dtype=np.int64)
+        out["rnvp.has_inverse"] = np.array(int(hasattr(mods["rnvp"], "inverse")))
+        zs, ld = nf.NormalizingFlow([mods["actnorm"], mods["glow"], mods["nsf_cl"]]).forward(x)
+        out["stack.ld_shape"] = np.array(tuple(ld.shape), dtype=np.int64)
+        out["stack.first_is_input"] = np.array(int(zs[0] is x))
+        out["stack.n_intermediates"] = np.array(len(zs))
+    save("g9_logdet_shapes", **out)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    g1_c1_stack()
+    g2_affine_half_single()
+    g3_c2_stack()
+    g4_rqs_direct()
+    g5_nsf_cl_layer()
+    g6_c3_stack()
+    g7_rnvp()
+    g8_sample_z()
+    g9_logdet_shapes()

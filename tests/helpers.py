@@ -1,0 +1,71 @@
+"""Shared test helpers: tolerance rule, fixture -> oracle layer specs."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import recipes
+
+# SURVEY.md 8c / BASELINE.json north_star: "1e-5 rel fp32", read normwise:
+# max|a - b| <= RTOL * max|b| per output tensor.
+RTOL = 1e-5
+
+
+def normwise_err(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    same_nan = np.isnan(a) == np.isnan(b)
+    assert same_nan.all(), "NaN pattern differs"
+    m = ~np.isnan(b)
+    if not m.any():
+        return 0.0
+    scale = max(np.abs(b[m]).max(), 1e-30)
+    return float(np.abs(a[m] - b[m]).max() / scale)
+
+
+def assert_close(a, b, rtol: float = RTOL, what: str = ""):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().cpu().numpy()
+    err = normwise_err(a, b)
+    assert err <= rtol, f"{what}: normwise error {err:.3e} > {rtol:.1e}"
+    return err
+
+
+def t(a) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def unpack_mask(bits, dim: int) -> torch.Tensor:
+    return t(np.unpackbits(bits, axis=1)[:, :dim].astype(np.float32))
+
+
+def g1_layers(fx) -> list[dict]:
+    layers = []
+    for i in range(9):
+        pre = f"L{i}."
+        sd = {k[len(pre):]: t(v) for k, v in fx.items() if k.startswith(pre)}
+        layers.append({"kind": "affine_half", "parity": bool(i % 2), "params": sd})
+    return layers
+
+
+def c2_layers(dim: int = 64, n_layers: int = 9) -> list[dict]:
+    return [{"kind": "affine_half", "parity": bool(i % 2), "params": sd}
+            for i, sd in enumerate(recipes.c2_stack_params(dim, n_layers))]
+
+
+def c3_layers(fx=None, dim: int = 32, K: int = 8, n_h: int = 8) -> list[dict]:
+    """3 x [ActNorm, Glow, NSF_CL]; ActNorm (s, t) from the G6 fixture when given."""
+    layers = []
+    for i in range(3):
+        if fx is not None:
+            an = {"s": t(fx[f"actnorm{i}.s"]), "t": t(fx[f"actnorm{i}.t"])}
+        else:
+            an = recipes.actnorm_params(630 + i, dim)
+        layers.append({"kind": "affine_const", "params": an})
+        layers.append({"kind": "glow", "params": recipes.glow_params(600 + i, dim)})
+        layers.append({"kind": "nsf_cl", "K": K, "B": 3.0,
+                       "params": recipes.nsf_cl_params(610 + i, dim, K, n_h)})
+    return layers

@@ -1,0 +1,206 @@
+"""Pin the CPU oracle to the reference: every fixture under tests/golden/ was written by
+the real reference (tests/golden/gen_golden.py); the oracle must reproduce it.
+
+Where the oracle issues the reference's own ATen op sequence the match is required
+bit-for-bit; the spline path (evaluated in place instead of on a gathered subset) and
+the closed-form base log-prob are held to 1e-6 normwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from helpers import assert_close, c2_layers, c3_layers, g1_layers, t, unpack_mask
+from oracle import flow_oracle as O
+
+torch.set_num_threads(4)
+
+
+def same(a, b, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == np.asarray(b).shape, what
+    assert np.array_equal(a, b, equal_nan=True), f"{what}: not bit-identical, max diff {np.nanmax(np.abs(a - b))}"
+
+
+@pytest.mark.parametrize("tag", ["init", "trained"])
+def test_g1_c1_stack(golden, tag):
+    fx = golden(f"g1_c1_stack_{tag}")
+    layers = g1_layers(fx)
+    x = t(fx["x"])
+    zs, ld = O.flow_stack(x, layers, inverse=True)
+    assert zs[0] is x and len(zs) == 10
+    same(ld, fx["ld_inv"], "ld_inv")
+    for i in fx["keep"]:
+        same(zs[i], fx[f"zs{i}"], f"zs{i}")
+    xs, ld_f = O.flow_stack(zs[-1], layers, inverse=False)
+    same(ld_f, fx["ld_fwd"], "ld_fwd")
+    for i in fx["keep"]:
+        same(xs[i], fx[f"xs{i}"], f"xs{i}")
+    assert_close(O.std_normal_log_prob(zs[-1]), fx["base_log_prob"], 1e-6, "base_log_prob")
+    mean_lp, _ = O.mean_log_prob(x, layers)
+    assert abs(mean_lp - float(fx["mean_log_prob"])) <= 1e-6 * abs(float(fx["mean_log_prob"]))
+    # round trip sanity (~7e-7 abs in the reference)
+    assert (xs[-1] - x).abs().max() < 5e-5
+
+
+def test_g2_affine_half_single(golden):
+    fx = golden("g2_affine_half_single")
+    for dim in (64, 256):
+        for parity in (False, True):
+            sd = recipes.affine_half_params(200 + dim + int(parity), dim)
+            tag = f"d{dim}_p{int(parity)}"
+            z = t(fx[f"{tag}.z"])
+            x, ld = O.affine_half(z, sd, parity, inverse=False)
+            same(x, fx[f"{tag}.fwd"], tag + ".fwd")
+            same(ld, fx[f"{tag}.ld_fwd"], tag + ".ld_fwd")
+            x, ld = O.affine_half(z, sd, parity, inverse=True)
+            same(x, fx[f"{tag}.inv"], tag + ".inv")
+            same(ld, fx[f"{tag}.ld_inv"], tag + ".ld_inv")
+            assert np.abs(fx[f"{tag}.ld_fwd"]).max() > 1.0  # fixture exercises exp() away from 1
+    for tag, kw in (("nice", dict(scale=False)), ("noshift", dict(shift=False)),
+                    ("h2", dict(h_sizes=(16, 40))), ("h1", dict(h_sizes=(7,)))):
+        sd = recipes.affine_half_params(290, 10, **kw)
+        flags = {k: v for k, v in kw.items() if k in ("scale", "shift")}
+        z = t(fx[f"{tag}.z"])
+        for inv, name in ((False, "fwd"), (True, "inv")):
+            x, ld = O.affine_half(z, sd, True, inverse=inv, **flags)
+            same(x, fx[f"{tag}.{name}"], f"{tag}.{name}")
+            same(ld, fx[f"{tag}.ld_{name}"], f"{tag}.ld_{name}")
+
+
+@pytest.mark.parametrize("dim", [64, 256])
+def test_g3_c2_stack(golden, dim):
+    fx = golden("g3_c2_stack")
+    layers = c2_layers(dim)
+    x = t(fx[f"d{dim}.x"])
+    zs, ld = O.flow_stack(x, layers, inverse=True)
+    same(zs[-1], fx[f"d{dim}.z_last"], "z_last")
+    same(zs[4], fx[f"d{dim}.z_mid"], "z_mid")
+    same(ld, fx[f"d{dim}.ld_inv"], "ld_inv")
+    cur = x
+    for i, spec in enumerate(reversed(layers)):
+        cur, l1 = O.apply_layer(spec, cur, inverse=True)
+        same(l1, fx[f"d{dim}.ld_incr"][i], f"ld_incr[{i}]")
+    xs, ld_f = O.flow_stack(x, layers, inverse=False)
+    same(xs[-1], fx[f"d{dim}.x_fwd_last"], "x_fwd_last")
+    same(ld_f, fx[f"d{dim}.ld_fwd"], "ld_fwd")
+    assert_close(O.std_normal_log_prob(zs[-1]), fx[f"d{dim}.base_log_prob"], 1e-6)
+    mean_lp, _ = O.mean_log_prob(x, layers)
+    ref = float(fx[f"d{dim}.mean_log_prob"])
+    assert abs(mean_lp - ref) <= 1e-6 * abs(ref)
+    # fp64 run of the oracle against the reference's own fp64 run: the error budget
+    layers64 = [{**s, "params": {k: v.double() for k, v in s["params"].items()}} for s in layers]
+    zs64, ld64 = O.flow_stack(x.double(), layers64, inverse=True)
+    assert_close(zs64[-1], fx[f"d{dim}.z_last_f64"], 1e-12)
+    # the reference accumulates log_det in an fp32 buffer even for fp64 inputs (core.py:29)
+    assert_close(ld64, fx[f"d{dim}.ld_inv_f64"], 5e-7)
+    # the fp32 reference sits within 1e-5 normwise of its own fp64 run (tolerance is meaningful)
+    assert_close(fx[f"d{dim}.z_last"], fx[f"d{dim}.z_last_f64"].astype(np.float32), 1e-5)
+
+
+@pytest.mark.parametrize("K", [5, 8])
+def test_g4_rqs_direct(golden, K):
+    fx = golden("g4_rqs_direct")
+    v, W, H, D = (t(fx[f"K{K}.{n}"]) for n in "vWHD")
+    for inv, name in ((False, "fwd"), (True, "inv")):
+        out, lad = O.unconstrained_rqs(v, W, H, D, inverse=inv, tail_bound=3.0)
+        assert_close(out, fx[f"K{K}.out_{name}"], 1e-6, f"out_{name}")
+        assert_close(lad, fx[f"K{K}.lad_{name}"], 1e-6, f"lad_{name}")
+    # identity tails, NaN passes through, +-T are inside
+    out, lad = O.unconstrained_rqs(v, W, H, D, inverse=False, tail_bound=3.0)
+    assert out[5] == 3.5 and lad[5] == 0 and out[6] == -7.0 and torch.isnan(out[7]) and lad[7] == 0
+    assert abs(float(out[1]) - 3.0) < 1e-5 and abs(float(out[2]) + 3.0) < 1e-5
+
+
+def test_rqs_all_outside_returns_identity():
+    v = torch.tensor([4.0, -5.0, float("nan")])
+    W = torch.zeros(3, 5)
+    out, lad = O.unconstrained_rqs(v, W, W.clone(), torch.zeros(3, 4), inverse=False, tail_bound=3.0)
+    assert torch.equal(out[:2], v[:2]) and torch.isnan(out[2]) and (lad == 0).all()
+
+
+def test_rqs_too_many_bins_raises():
+    v = torch.zeros(2)
+    W = torch.zeros(2, 1001)
+    with pytest.raises(ValueError):
+        O.unconstrained_rqs(v, W, W.clone(), torch.zeros(2, 1000), inverse=False, tail_bound=3.0)
+
+
+@pytest.mark.parametrize("cfg", [(32, 8, 8), (32, 8, 16), (2, 8, 16), (6, 5, 8)])
+def test_g5_nsf_cl_layer(golden, cfg):
+    dim, K, n_h = cfg
+    fx = golden("g5_nsf_cl_layer")
+    tag = f"d{dim}_K{K}_h{n_h}"
+    sd = recipes.nsf_cl_params(500 + dim + n_h, dim, K, n_h)
+    z = t(fx[f"{tag}.z"])
+    for inv, name in ((False, "fwd"), (True, "inv")):
+        x, ld = O.nsf_cl(z, sd, K, 3.0, inverse=inv)
+        assert_close(x, fx[f"{tag}.{name}"], 1e-6, f"{tag}.{name}")
+        assert_close(ld, fx[f"{tag}.ld_{name}"], 2e-6, f"{tag}.ld_{name}")
+
+
+def test_g6_c3_stack(golden):
+    fx = golden("g6_c3_stack")
+    x = t(fx["x"])
+    # ActNorm's data-dependent init, replayed layer by layer as the first inverse call does
+    layers = c3_layers(fx)
+    cur = x
+    for i in reversed(range(3)):
+        nsf, glow, _ = layers[3 * i + 2], layers[3 * i + 1], layers[3 * i]
+        cur, _ = O.apply_layer(nsf, cur, True)
+        cur, _ = O.apply_layer(glow, cur, True)
+        s, tt = O.actnorm_init(cur)
+        assert_close(s, fx[f"actnorm{i}.s"], 1e-5, f"actnorm{i}.s")
+        assert_close(tt, fx[f"actnorm{i}.t"], 1e-5, f"actnorm{i}.t")
+        cur, _ = O.affine_const(cur, t(fx[f"actnorm{i}.s"]), t(fx[f"actnorm{i}.t"]), True)
+    assert_close(cur, fx["z_last_first_call"], 2e-6)
+    zs, ld = O.flow_stack(x, layers, inverse=True)
+    assert_close(zs[-1], fx["z_last"], 2e-6, "z_last")
+    assert_close(zs[5], fx["z_mid"], 2e-6, "z_mid")
+    assert_close(ld, fx["ld_inv"], 2e-6, "ld_inv")
+    xs, ld_f = O.flow_stack(x, layers, inverse=False)
+    assert_close(xs[-1], fx["x_fwd_last"], 2e-6, "x_fwd_last")
+    assert_close(ld_f, fx["ld_fwd"], 2e-6, "ld_fwd")
+
+
+@pytest.mark.parametrize("dim", [50, 800, 784])
+def test_g7_rnvp(golden, dim):
+    fx = golden("g7_rnvp")
+    sd = recipes.rnvp_params(700 + dim, dim, 50)
+    z = t(fx[f"d{dim}.z"])
+    mask = unpack_mask(fx[f"d{dim}.mask_bits"], dim)
+    x, ld = O.rnvp(z, sd, mask)
+    # K=800 GEMMs: MKL's summation order moves with the thread count, so not bitwise
+    assert_close(x, fx[f"d{dim}.x"], 1e-6, "x")
+    assert_close(ld, fx[f"d{dim}.ld"], 1e-6, "ld")
+
+
+def test_g8_sample_z(golden):
+    fx = golden("g8_sample_z")
+    layers = [{"kind": "rnvp", "params": recipes.rnvp_params(800 + i, 800, 50),
+               "mask": unpack_mask(fx[f"mask{i}_bits"], 800)} for i in range(2)]
+    z, ld = O.sample_z(t(fx["q0_mean"]), t(fx["q0_log_var"]), t(fx["eps"]), layers)
+    assert_close(z, fx["z"], 1e-6, "z")
+    assert_close(ld, fx["log_det"], 1e-6, "log_det")
+
+
+def test_g9_logdet_shapes(golden):
+    fx = golden("g9_logdet_shapes")
+    x = recipes.gaussian(900, 8, 4)
+    specs = {
+        "affine_half": {"kind": "affine_half", "parity": False, "params": recipes.affine_half_params(1, 4)},
+        "nsf_cl": {"kind": "nsf_cl", "K": 5, "B": 3.0, "params": recipes.nsf_cl_params(2, 4, 5, 8)},
+        "actnorm": {"kind": "affine_const", "params": recipes.actnorm_params(3, 4)},
+        "affine_const": {"kind": "affine_const", "params": recipes.actnorm_params(4, 4)},
+        "glow": {"kind": "glow", "params": recipes.glow_params(5, 4)},
+    }
+    for name, spec in specs.items():
+        for inv, d in ((False, "fwd"), (True, "inv")):
+            _, ld = O.apply_layer(spec, x, inv)
+            assert tuple(ld.shape) == tuple(fx[f"{name}.{d}"]), name
+    assert int(fx["rnvp.has_inverse"]) == 0
+    with pytest.raises(AttributeError):
+        O.apply_layer({"kind": "rnvp", "params": {}, "mask": None}, x, True)
+    zs, ld = O.flow_stack(x, [specs["actnorm"], specs["glow"], specs["nsf_cl"]], False)
+    assert tuple(ld.shape) == tuple(fx["stack.ld_shape"]) and zs[0] is x
+    assert len(zs) == int(fx["stack.n_intermediates"])
