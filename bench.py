@@ -1,0 +1,205 @@
+"""Benchmark of the coupling-flow hot path on MI355X (contract: see the round brief).
+
+Metric (BASELINE.json): samples/s + mean-log-prob error vs CPU on configs[1]:
+9 x AffineHalfFlow ("RNVP"), d=64, batch 2^20 synthetic Gaussian, fp32.
+
+A step = one density evaluation of one batch resident in HBM, through the drop-in API:
+    zs, log_det = NormalizingFlow.inverse(x)        (9 fused coupling kernels, log_det += ld)
+    log p = log_det + N(0,I).log_prob(zs[-1])       (epilogue kernel, fp64 sum over rows)
+followed, when N > 1, by one RCCL all-reduce of (sum, count).  Every rank holds its own 2^20
+rows (weak scaling); value = rows of all ranks / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (dim, rows per GPU, description)
+    "c2": (64, 1 << 20, "9xAffineHalfFlow d=64 batch=2^20 inverse+log_prob (BASELINE configs[1])"),
+    "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3] shard)"),
+}
+
+
+def build_model(dim: int, device):
+    import recipes
+    import torch_mnf_amd as amd
+
+    flows = []
+    sds = recipes.c2_stack_params(dim)
+    for i, sd in enumerate(sds):
+        f = amd.AffineHalfFlow(dim, parity=bool(i % 2))
+        f.load_state_dict(sd)
+        flows.append(f)
+    model = amd.NormalizingFlowModel(amd.StandardNormal(dim, device), flows).to(device)
+    layers = [{"kind": "affine_half", "parity": bool(i % 2), "params": sd} for i, sd in enumerate(sds)]
+    return model, layers
+
+
+def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float = 12.0) -> tuple[dict, float, int]:
+    """Time the CPU oracle (the restated reference path: stock PyTorch CPU ops, all host
+    threads) on a bounded sample of the same workload.  Checker and baseline only."""
+    from oracle import flow_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    probe = 1 << 14
+    x = x_sample_gpu[:probe].cpu()
+    with torch.no_grad():
+        O.mean_log_prob(x[:2048], layers)  # warm the thread pool
+        t0 = time.perf_counter()
+        O.mean_log_prob(x, layers)
+        dt = time.perf_counter() - t0
+    rate = probe / dt
+    rows = int(min(x_sample_gpu.shape[0], max(probe, 1 << int(max(14, (rate * budget_s)).bit_length() - 1))))
+    x = x_sample_gpu[:rows].cpu()
+    best = float("inf")
+    mean = None
+    with torch.no_grad():
+        t_start = time.perf_counter()
+        for _ in range(3):
+            t0 = time.perf_counter()
+            mean, _ = O.mean_log_prob(x, layers)
+            best = min(best, time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 2.5 * budget_s:
+                break
+    info = {
+        "value": rows / best,
+        "unit": "samples/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle (PyTorch-CPU restatement of the reference path), first {rows} rows of the "
+                  f"rank-0 batch, one inverse pass + base log-prob, best of <=3, {best:.3f} s",
+    }
+    return info, mean, rows
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import torch_mnf_amd as amd
+    from torch_mnf_amd.dist import reduce_sum_count
+
+    dim, rows, desc = WORKLOADS[args.workload]
+    model, layers = build_model(dim, device)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
+    n_layers = len(model.flows)
+
+    def step():
+        lp, total = model.log_prob(x, return_sum=True)
+        s, c = reduce_sum_count(total, rows)  # RCCL all-reduce of 16 bytes when world > 1
+        return s / c
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            mean = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        model.layer_events = []  # (start, end) HIP events around every coupling kernel
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mean = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        events, model.layer_events = model.layer_events, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    gpu_mean = float(mean.item())
+
+    if rank == 0:
+        kern_ms = [a.elapsed_time(b) for a, b in events]
+        avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
+        algo_bytes = (8 * dim + 8) * rows  # per launch: read 4d, write 4d, log_det read+write
+        achieved = algo_bytes / avg_kernel_s / 1e9
+        out = {
+            "metric": "samples/s, 9xRNVP(AffineHalfFlow) d=64 batch=2^20 inverse+log-prob" if args.workload == "c2"
+            else f"samples/s, {desc}",
+            "value": world * rows * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": n_layers,
+                       "hidden": [24, 24, 24], "intermediates": "all kept (reference API)"},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": f"ahf_mfma_kernel<{dim // 2},24,inverse>",
+                "avg_kernel_us": avg_kernel_s * 1e6,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "launches_timed": len(kern_ms),
+                "frac_of_achievable_6300": achieved / 6300.0,
+                "fp32_tflops": 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24) * rows / avg_kernel_s / 1e12,
+            },
+            "mean_log_prob": gpu_mean,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            info, cpu_mean, n = cpu_baseline(layers, dim, x)
+            with torch.no_grad():
+                _, tot = model.log_prob(x[:n].contiguous(), return_sum=True)
+            gpu_sample_mean = float(tot.item()) / n
+            out["cpu_baseline"] = info
+            out["parity"] = {"rows": n, "mean_log_prob_gpu": gpu_sample_mean, "mean_log_prob_cpu": cpu_mean,
+                             "rel_err": abs(gpu_sample_mean - cpu_mean) / abs(cpu_mean), "tolerance": 1e-5}
+            out["speedup_vs_cpu"] = out["value"] / info["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * mnf_hip.h -- C ABI of libmnf_hip.so: the coupling-flow hot path of janosh/torch-mnf
+ * as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference is pure Python on PyTorch and has no FFI of its own; the interface each
+ * entry point replaces is the duck-typed Flow module method it computes
+ * (paths below /root/reference):
+ *
+ *   mnf_affine_half      AffineHalfFlow.forward / .inverse      torch_mnf/flows/affine_half_flow.py:44-66
+ *   mnf_nsf_cl           NSF_CL.forward / .inverse              torch_mnf/flows/spline_flow.py:249-285
+ *   mnf_rqs              unconstrained_RQS                      torch_mnf/flows/spline_flow.py:29-68
+ *   mnf_rnvp             RNVP.forward                           torch_mnf/flows/rnvp.py:25-39
+ *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
+ *   mnf_linear_rows      Glow.forward / .inverse (x @ W)        torch_mnf/flows/glow.py:26-37
+ *   mnf_gauss_logprob    base.log_prob + the callers' mean      torch_mnf/flows/core.py:46-49,
+ *                                                               examples/half_moons.ipynb:183-186
+ *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
+ *   log_det accumulation NormalizingFlow.forward / .inverse     torch_mnf/flows/core.py:17-35
+ *                        (the `accumulate` flag of every layer entry point: log_det += ld)
+ *
+ * Contract:
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all
+ *     buffers; the library allocates nothing and keeps no state between calls;
+ *   - all tensors are fp32, row-major contiguous: x, y are (rows, dim); log_det is (rows,);
+ *   - y must not alias x (layers are out-of-place, as in the reference);
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*); no host
+ *     synchronisation inside, so calls can be captured into a hipGraph;
+ *   - return value: MNF_OK or a negative MNF_ERR_* code; nothing is thrown across the ABI;
+ *   - re-entrant and thread-safe.
+ *
+ * Parameter layouts
+ *   "flat": the module's state_dict tensors concatenated in state_dict order, each in its
+ *   own row-major layout (nn.Linear weight is (out, in)).  For AffineHalfFlow: s_net then
+ *   t_net (an absent net contributes nothing); NSF_CL: f1 then f2; RNVP: net, t, s.
+ *   "image": the same numbers rearranged into per-lane MFMA A-operand order for the
+ *   specialised kernels; built on the device by mnf_pack_gather from an index table that
+ *   mnf_*_image_index fills on the host once per configuration.
+ */
+#ifndef MNF_HIP_H
+#define MNF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNF_OK 0
+#define MNF_ERR_INVALID_ARG (-1) /* null pointer, odd dim, negative size, ...                     */
+#define MNF_ERR_UNSUPPORTED (-2) /* shape outside what the kernels cover (e.g. layer too wide)    */
+#define MNF_ERR_LAUNCH (-3)      /* hipLaunchKernel reported an error; see mnf_last_hip_error()   */
+#define MNF_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                                      */
+#define MNF_ERR_DOMAIN (-5)      /* spline: min bin width/height * K > 1 (ValueError in reference) */
+
+#define MNF_MAX_LINEAR 8 /* Linear layers per conditioner net (hidden layers + 1) */
+
+int mnf_abi_version(void);
+const char* mnf_error_string(int code);
+/* hipError_t of the last failed launch on the calling thread (0 if none). */
+int mnf_last_hip_error(void);
+/* Number of visible devices whose gcnArchName starts with gfx950 (0 = none / no driver). */
+int mnf_device_count(void);
+
+/* ---------------------------------------------------------------- AffineHalfFlow */
+/* hidden: n_hidden sizes of the hidden layers (reference default {24,24,24}).
+ * image: NULL, or the MFMA operand image (mnf_affine_half_image_floats() floats); when it is
+ * given and the configuration has a specialised kernel, that kernel runs, otherwise the
+ * generic one reads `flat`.  log_det may be NULL (not computed). accumulate != 0: log_det += ld.
+ * force_generic != 0 selects the generic kernel (used by tests to compare the two). */
+int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
+                    const float* flat, const float* image,
+                    int64_t rows, int dim, int parity, int inverse,
+                    int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                    int force_generic, void* stream);
+/* 0 when the configuration has no specialised (MFMA) kernel. */
+int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden_host,
+                                     int has_scale, int has_shift);
+/* idx_host[i] = index into `flat` feeding image[i], or -1 for a structural zero. */
+int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden_host,
+                                int has_scale, int has_shift, int32_t* idx_host);
+int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden_host,
+                                    int has_scale, int has_shift);
+
+/* image[i] = idx[i] < 0 ? 0 : flat[idx[i]]  (device-side repack after a weight update). */
+int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------ NSF_CL */
+/* f1, f2 = MLP(dim/2, n_h, n_h, n_h, (3K-1)*dim/2); `hidden` generalises (n_h,n_h,n_h). */
+int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
+               const float* flat, const float* image,
+               int64_t rows, int dim, int K, float tail_bound, int inverse,
+               int n_hidden, const int* hidden_host, int force_generic, void* stream);
+int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);
+int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden_host);
+int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden_host, int32_t* idx_host);
+
+/* Elementwise unconstrained rational-quadratic spline: inputs (n,), W,H (n,K), D (n,K-1). */
+int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D,
+            float* outputs, float* logabsdet, int64_t n, int K, float tail_bound,
+            int inverse, void* stream);
+
+/* -------------------------------------------------------------- RNVP (masked/gated) */
+/* mask: (rows, dim) floats in {0,1}, supplied by the caller (the reference draws
+ * torch.bernoulli per call, rnvp.py:28).  net = MLP(dim, hidden...); t, s = Linear(h_last, dim). */
+int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+             const float* flat, const float* image,
+             int64_t rows, int dim, int n_hidden, const int* hidden_host,
+             int force_generic, void* stream);
+int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden_host);
+int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden_host);
+int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);
+
+/* ------------------------------------------------------- data-independent layers */
+/* forward: y = x*exp(s)+t ; inverse: y = (x-t)*exp(-s).  s, t: (dim,) device vectors.
+ * The (1,)-shaped log_det = +-sum(s) is a parameter-only scalar; ld_scalar (device, may be
+ * NULL) receives it, and when log_det != NULL it is added to (accumulate) or broadcast
+ * into (otherwise) every row. */
+int mnf_affine_const(const float* x, float* y, const float* s, const float* t,
+                     float* log_det, int accumulate, float* ld_scalar,
+                     int64_t rows, int dim, int inverse, void* stream);
+/* y = x @ W, W (dim, dim) row-major on the device (Glow's assembled matrix or its inverse). */
+int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int dim, void* stream);
+
+/* --------------------------------------------------------- base log-prob epilogue */
+/* log_prob[r] = (log_det ? log_det[r] : 0) - |z_r|^2/2 - dim/2*log(2 pi)   (standard normal base)
+ * sum_out (device double, may be NULL) += sum_r log_prob[r]; the caller zeroes it first. */
+int mnf_gauss_logprob(const float* z, const float* log_det, float* log_prob, double* sum_out,
+                      int64_t rows, int dim, void* stream);
+
+/* z0 = q0_mean + exp(q0_log_var)^(1/2) * eps   (rows, dim); mean, log_var: (dim,). */
+int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
+                  int64_t rows, int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNF_HIP_H */

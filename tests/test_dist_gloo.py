@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the sharded mean log-prob (the N>1 path of bench.py).
+
+The per-rank evaluation here is the CPU oracle (this is a CPU test of the sharding and the
+reduction, not of the kernels); on the GPU box the same driver gets the HIP epilogue's sum."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import recipes
+from helpers import c2_layers
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, rows, out):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import flow_oracle as O
+    from torch_mnf_amd.dist import shard_bounds, sharded_mean_log_prob
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    layers = c2_layers(64, 3)
+    x = recipes.gaussian(99, rows, 64)
+    lo, hi = shard_bounds(rows, world, rank)
+
+    def local_sum(xl):
+        _, lp = O.mean_log_prob(xl, layers)
+        return lp.double().sum().reshape(1)
+
+    mean = sharded_mean_log_prob(local_sum, x[lo:hi])
+    if rank == 0:
+        out.put((float(mean), lo, hi))
+    dist.destroy_process_group()
+
+
+def test_sharded_mean_matches_single_process():
+    from oracle import flow_oracle as O
+
+    rows, world = 1001, 2  # odd: uneven shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mean, lo, hi = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, _ = O.mean_log_prob(recipes.gaussian(99, rows, 64), c2_layers(64, 3))
+    assert (lo, hi) == (0, 501)
+    assert abs(mean - ref) <= 1e-9 * abs(ref)
+
+
+def test_shard_bounds_cover_rows_exactly():
+    from torch_mnf_amd.dist import shard_bounds
+
+    for rows in (0, 1, 7, 1 << 20, (1 << 22) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(rows, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == rows
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

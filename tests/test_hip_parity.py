@@ -1,0 +1,401 @@
+"""GPU parity tests: the HIP path (through the C ABI, via torch_mnf_amd) against
+(1) the golden fixtures written by the real reference and (2) the CPU oracle on seeded inputs,
+plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance (BASELINE.json north_star "1e-5 rel fp32"): normwise
+max|a-b| <= 1e-5 * max|b| per output tensor; scalar mean log-prob to 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from helpers import RTOL, assert_close, c2_layers, c3_layers, g1_layers, t, unpack_mask
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch_mnf_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    torch_mnf_amd._lib.load()
+    return torch_mnf_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import flow_oracle
+
+    return flow_oracle
+
+
+def cuda(a):
+    return (a if isinstance(a, torch.Tensor) else t(a)).to(DEV)
+
+
+def ahf_module(amd, sd, dim, parity, **kw):
+    f = amd.AffineHalfFlow(dim, parity, **kw)
+    f.load_state_dict(sd)
+    return f.to(DEV)
+
+
+# ------------------------------------------------------------------ AffineHalfFlow
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("dim", [64, 256])
+@pytest.mark.parametrize("parity", [False, True])
+def test_g2_affine_half_golden(amd, golden, dim, parity, generic):
+    fx = golden("g2_affine_half_single")
+    tag = f"d{dim}_p{int(parity)}"
+    f = ahf_module(amd, recipes.affine_half_params(200 + dim + int(parity), dim), dim, parity)
+    f.force_generic = generic
+    z = cuda(fx[f"{tag}.z"])
+    x, ld = f.forward(z)
+    assert_close(x, fx[f"{tag}.fwd"], RTOL, "fwd")
+    assert_close(ld, fx[f"{tag}.ld_fwd"], RTOL, "ld_fwd")
+    x, ld = f.inverse(z)
+    assert_close(x, fx[f"{tag}.inv"], RTOL, "inv")
+    assert_close(ld, fx[f"{tag}.ld_inv"], RTOL, "ld_inv")
+    x2, ld2 = f.forward(z, inverse=True)  # the reference's extra keyword (:44)
+    assert torch.equal(x, x2) and torch.equal(ld, ld2)
+
+
+def test_mfma_kernel_is_selected(amd):
+    """The d=64 / d=256 default configuration must run the specialised kernel (image exists)."""
+    lib = amd._lib.load()
+    hid = amd._lib.int_array([24, 24, 24])
+    for dim in (32, 64, 128, 256):
+        assert lib.mnf_affine_half_image_floats(dim, 3, hid, 1, 1) > 0
+    assert lib.mnf_affine_half_image_floats(2, 3, hid, 1, 1) == 0
+
+
+@pytest.mark.parametrize("tag,kw", [("nice", dict(scale=False)), ("noshift", dict(shift=False)),
+                                    ("h2", dict(h_sizes=(16, 40))), ("h1", dict(h_sizes=(7,)))])
+def test_g2_affine_half_variants(amd, golden, tag, kw):
+    fx = golden("g2_affine_half_single")
+    f = ahf_module(amd, recipes.affine_half_params(290, 10, **kw), 10, True, **kw)
+    z = cuda(fx[f"{tag}.z"])
+    for name, fn in (("fwd", f.forward), ("inv", f.inverse)):
+        x, ld = fn(z)
+        assert_close(x, fx[f"{tag}.{name}"], RTOL, f"{tag}.{name}")
+        assert_close(ld, fx[f"{tag}.ld_{name}"], RTOL, f"{tag}.ld_{name}")
+
+
+@pytest.mark.parametrize("rows", [1, 15, 17, 1000, 4099])
+@pytest.mark.parametrize("dim", [32, 64, 128])
+def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim):
+    """Tiles are 16 rows: partial last tile, single row, and a grid-stride wrap."""
+    sd = recipes.affine_half_params(77 + dim, dim)
+    x = recipes.gaussian(rows + dim, rows, dim)
+    for parity in (False, True):
+        f = ahf_module(amd, sd, dim, parity)
+        for inverse in (False, True):
+            ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
+            y, ld = f.forward(cuda(x), inverse=inverse)
+            assert_close(y, ref_y, RTOL, "y")
+            assert_close(ld, ref_ld, RTOL, "ld")
+
+
+def test_affine_half_empty_batch(amd):
+    f = ahf_module(amd, recipes.affine_half_params(1, 64), 64, False)
+    y, ld = f.forward(torch.empty(0, 64, device=DEV))
+    assert y.shape == (0, 64) and ld.shape == (0,)
+
+
+def test_affine_half_overflow_matches_reference_semantics(amd, O):
+    """s is unbounded (no clamp): huge weights overflow to inf/NaN exactly like the reference."""
+    sd = recipes.affine_half_params(5, 64, s_last_gain=4000.0)
+    x = recipes.gaussian(6, 64, 64)
+    ref_y, ref_ld = O.affine_half(x, sd, False, False)
+    f = ahf_module(amd, sd, 64, False)
+    y, _ = f.forward(cuda(x))
+    assert torch.isinf(ref_y).any()
+    assert torch.equal(torch.isfinite(y).cpu(), torch.isfinite(ref_y))
+
+
+# ------------------------------------------------------------------ stacks (C1, C2, C4)
+def build_ahf_stack(amd, layers, dim):
+    flows = []
+    for spec in layers:
+        flows.append(ahf_module(amd, spec["params"], dim, spec["parity"]))
+    return amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["init", "trained"])
+def test_g1_c1_stack(amd, golden, tag):
+    """Config 1: 9 x AffineHalfFlow d=2 on half-moons (generic kernel: h = 1)."""
+    fx = golden(f"g1_c1_stack_{tag}")
+    model = build_ahf_stack(amd, g1_layers(fx), 2)
+    x = cuda(fx["x"])
+    zs, ld = model.inverse(x)
+    assert zs[0] is x and len(zs) == 10
+    assert_close(ld, fx["ld_inv"], RTOL, "ld_inv")
+    for i in fx["keep"]:
+        assert_close(zs[i], fx[f"zs{i}"], RTOL, f"zs{i}")
+    assert_close(model.base_log_prob(x), fx["base_log_prob"], RTOL, "base_log_prob")
+    xs, ld_f = model.forward(zs[-1])
+    assert_close(ld_f, fx["ld_fwd"], RTOL, "ld_fwd")
+    assert_close(xs[-1], fx["xs9"], RTOL, "xs9")
+    lp, total = model.log_prob(x, return_sum=True)
+    mean = float(total.item()) / x.shape[0]
+    ref = float(fx["mean_log_prob"])
+    assert abs(mean - ref) <= RTOL * abs(ref)
+
+
+@pytest.mark.parametrize("dim", [64, 256])
+def test_g3_c2_stack(amd, golden, dim):
+    """Configs 2 / 4: the benchmark stack's weights on the fixture rows."""
+    fx = golden("g3_c2_stack")
+    model = build_ahf_stack(amd, c2_layers(dim), dim)
+    x = cuda(fx[f"d{dim}.x"])
+    zs, ld = model.inverse(x)
+    assert_close(zs[-1], fx[f"d{dim}.z_last"], RTOL, "z_last")
+    assert_close(zs[4], fx[f"d{dim}.z_mid"], RTOL, "z_mid")
+    assert_close(ld, fx[f"d{dim}.ld_inv"], RTOL, "ld_inv")
+    cur = x
+    for i, f in enumerate(reversed(model.flows)):
+        cur, l1 = f.inverse(cur)
+        assert_close(l1, fx[f"d{dim}.ld_incr"][i], RTOL, f"ld_incr[{i}]")
+    xs, ld_f = model.forward(x)
+    assert_close(xs[-1], fx[f"d{dim}.x_fwd_last"], RTOL, "x_fwd_last")
+    assert_close(ld_f, fx[f"d{dim}.ld_fwd"], RTOL, "ld_fwd")
+    lp, total = model.log_prob(x, return_sum=True)
+    assert_close(lp, fx[f"d{dim}.ld_inv"] + fx[f"d{dim}.base_log_prob"], RTOL, "log_prob")
+    ref = float(fx[f"d{dim}.mean_log_prob"])
+    assert abs(float(total.item()) / x.shape[0] - ref) <= RTOL * abs(ref)
+    # against the reference's fp64 run: the HIP fp32 path is as close to it as the reference's own fp32
+    assert_close(zs[-1], fx[f"d{dim}.z_last_f64"].astype(np.float32), RTOL, "vs fp64")
+
+
+def test_c2_full_size_properties(amd, O):
+    """BASELINE configs[1] at full size (2^20 x 64): properties that need no CPU reference, plus
+    a 4096-row slice against the oracle."""
+    dim, rows = 64, 1 << 20
+    model = build_ahf_stack(amd, c2_layers(dim), dim)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(rows, dim, device=DEV, generator=g)
+    zs, ld = model.inverse(x)
+    xs, ld_f = model.forward(zs[-1])
+    # forward(inverse(x)) == x ; the two log-dets cancel
+    assert float((xs[-1] - x).abs().max()) <= 2e-4 * float(x.abs().max())
+    assert float((ld + ld_f).abs().max()) <= 1e-4 * float(ld.abs().max())
+    assert torch.isfinite(zs[-1]).all() and torch.isfinite(ld).all()
+    # MFMA kernel == generic kernel on the full batch (first layer of the inverse pass)
+    f = model.flows[-1]
+    y_fast, ld_fast = f.inverse(x)
+    f.force_generic = True
+    y_gen, ld_gen = f.inverse(x)
+    f.force_generic = False
+    assert_close(y_fast, y_gen, RTOL, "mfma vs generic y")
+    assert_close(ld_fast, ld_gen, RTOL, "mfma vs generic ld")
+    # mean log-prob: fused epilogue (fp64 sum) vs the oracle on a slice, rows chosen across the batch
+    sel = torch.arange(0, rows, rows // 4096, device=DEV)[:4096]
+    xo = x[sel].cpu()
+    ref_mean, ref_lp = O.mean_log_prob(xo, c2_layers(dim))
+    lp, total = model.log_prob(x[sel].contiguous(), return_sum=True)
+    assert_close(lp, ref_lp, RTOL, "log_prob slice")
+    assert abs(float(total.item()) / 4096 - ref_mean) <= RTOL * abs(ref_mean)
+    # sum of the per-row log-probs over the whole batch == the epilogue's fp64 sum
+    lp_all, total_all = model.log_prob(x, return_sum=True)
+    assert abs(float(total_all.item()) - float(lp_all.double().sum())) <= 1e-9 * abs(float(total_all.item()))
+
+
+def test_log_det_accumulates_in_layer_order(amd):
+    """NormalizingFlow's fused `log_det += ld` equals summing the per-layer log-dets."""
+    dim = 64
+    model = build_ahf_stack(amd, c2_layers(dim, 4), dim)
+    x = cuda(recipes.gaussian(11, 333, dim))
+    zs, ld = model.inverse(x)
+    acc = torch.zeros(333, device=DEV)
+    cur = x
+    for f in reversed(model.flows):
+        cur, l1 = f.inverse(cur)
+        acc += l1
+    assert torch.equal(cur, zs[-1])
+    assert_close(ld, acc, 1e-6, "accumulated log_det")
+
+
+# ------------------------------------------------------------------------- splines
+@pytest.mark.parametrize("K", [5, 8])
+def test_g4_rqs_direct(amd, golden, K):
+    fx = golden("g4_rqs_direct")
+    v, W, H, D = (cuda(fx[f"K{K}.{n}"]) for n in "vWHD")
+    for inv, name in ((False, "fwd"), (True, "inv")):
+        out, lad = amd.rqs(v, W, H, D, inverse=inv, tail_bound=3.0)
+        assert_close(out, fx[f"K{K}.out_{name}"], RTOL, f"out_{name}")
+        # log-derivatives: normwise over the batch (max |lad| ~ 5)
+        assert_close(lad, fx[f"K{K}.lad_{name}"], RTOL, f"lad_{name}")
+    out, lad = amd.rqs(v, W, H, D, inverse=False, tail_bound=3.0)
+    out, lad = out.cpu(), lad.cpu()
+    assert out[5] == 3.5 and lad[5] == 0 and out[6] == -7.0 and torch.isnan(out[7]) and lad[7] == 0
+
+
+def test_rqs_all_outside_is_identity_and_too_many_bins_raises(amd):
+    v = torch.tensor([4.0, -5.0, float("nan")], device=DEV)
+    W = torch.zeros(3, 5, device=DEV)
+    out, lad = amd.rqs(v, W, W.clone(), torch.zeros(3, 4, device=DEV), tail_bound=3.0)
+    assert torch.equal(out[:2], v[:2]) and torch.isnan(out[2]) and (lad == 0).all()
+    Wbig = torch.zeros(2, 1001, device=DEV)
+    with pytest.raises(ValueError):
+        amd.rqs(torch.zeros(2, device=DEV), Wbig, Wbig.clone(), torch.zeros(2, 1000, device=DEV), tail_bound=3.0)
+
+
+@pytest.mark.parametrize("cfg", [(32, 8, 8), (32, 8, 16), (2, 8, 16), (6, 5, 8)])
+@pytest.mark.parametrize("generic", [False, True])
+def test_g5_nsf_cl_layer(amd, golden, cfg, generic):
+    dim, K, n_h = cfg
+    fx = golden("g5_nsf_cl_layer")
+    tag = f"d{dim}_K{K}_h{n_h}"
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(recipes.nsf_cl_params(500 + dim + n_h, dim, K, n_h))
+    f = f.to(DEV)
+    f.force_generic = generic
+    z = cuda(fx[f"{tag}.z"])
+    for name, fn in (("fwd", f.forward), ("inv", f.inverse)):
+        x, ld = fn(z)
+        assert_close(x, fx[f"{tag}.{name}"], RTOL, f"{tag}.{name}")
+        assert_close(ld, fx[f"{tag}.ld_{name}"], RTOL, f"{tag}.ld_{name}")
+    assert ld.device.type == "cuda"  # the reference allocates log_det on the CPU (:250); fixed here
+
+
+def build_c3(amd, fx=None):
+    flows = []
+    for i in range(3):
+        an = amd.ActNormFlow(32)
+        if fx is not None:
+            an.load_state_dict({"s": t(fx[f"actnorm{i}.s"]), "t": t(fx[f"actnorm{i}.t"])})
+            an.data_dep_init_done = True
+        gl = amd.Glow(32)
+        gp = recipes.glow_params(600 + i, 32)
+        gl.P = gp["P"]
+        gl.load_state_dict({"L": gp["L"], "S": gp["S"], "U": gp["U"]})
+        sp = amd.NSF_CL(32, K=8, B=3, n_h=8)
+        sp.load_state_dict(recipes.nsf_cl_params(610 + i, 32, 8, 8))
+        flows += [an, gl, sp]
+    return amd.NormalizingFlowModel(amd.StandardNormal(32), flows).to(DEV)
+
+
+def test_g6_c3_stack(amd, golden):
+    """Config 3: 3 x [ActNorm, Glow, NSF_CL] d=32 K=8."""
+    fx = golden("g6_c3_stack")
+    x = cuda(fx["x"])
+    model = build_c3(amd, fx)
+    zs, ld = model.inverse(x)
+    assert_close(zs[-1], fx["z_last"], RTOL, "z_last")
+    assert_close(zs[5], fx["z_mid"], RTOL, "z_mid")
+    assert_close(ld, fx["ld_inv"], RTOL, "ld_inv")
+    xs, ld_f = model.forward(x)
+    assert_close(xs[-1], fx["x_fwd_last"], RTOL, "x_fwd_last")
+    assert_close(ld_f, fx["ld_fwd"], RTOL, "ld_fwd")
+
+
+def test_g6_actnorm_data_dependent_init(amd, golden):
+    """First inverse call initialises each ActNorm from the batch it sees (affine_constant_flow.py:42-50)."""
+    fx = golden("g6_c3_stack")
+    torch.manual_seed(6)
+    model = build_c3(amd, None)
+    x = cuda(fx["x"])
+    zs, ld = model.inverse(x)
+    for i in range(3):
+        an = model.flows[3 * i]
+        assert an.data_dep_init_done is True
+        assert_close(an.s, fx[f"actnorm{i}.s"], 2e-5, f"actnorm{i}.s")
+        assert_close(an.t, fx[f"actnorm{i}.t"], 2e-5, f"actnorm{i}.t")
+    assert_close(zs[-1], fx["z_last_first_call"], 2e-5, "first call z")
+    assert_close(ld, fx["ld_first_call"], 2e-5, "first call ld")
+
+
+def test_c3_full_size_round_trip(amd):
+    """Config 3 at 2^20 rows: inverse(forward(x)) == x and log-dets cancel (reference: ~7e-6 abs)."""
+    rows = 1 << 20
+    model = build_c3(amd, None)
+    for i in range(3):
+        model.flows[3 * i].load_state_dict(recipes.actnorm_params(630 + i, 32))
+        model.flows[3 * i].data_dep_init_done = True
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(rows, 32, device=DEV, generator=g)
+    xs, ld_f = model.forward(x)
+    zs, ld_i = model.inverse(xs[-1])
+    assert float((zs[-1] - x).abs().max()) <= 5e-4
+    assert float((ld_f + ld_i).abs().max()) <= 5e-4 * max(1.0, float(ld_f.abs().max()))
+    outside = (x.abs() > 3).float().mean().item()
+    assert 0.001 < outside < 0.005  # ~0.27 % of N(0,1) falls in the identity tails
+
+
+# --------------------------------------------------------------------------- RNVP
+@pytest.mark.parametrize("dim", [50, 800, 784])
+@pytest.mark.parametrize("generic", [False, True])
+def test_g7_rnvp(amd, golden, dim, generic):
+    fx = golden("g7_rnvp")
+    f = amd.RNVP(dim, h_sizes=(50,))
+    f.load_state_dict(recipes.rnvp_params(700 + dim, dim, 50))
+    f = f.to(DEV)
+    f.force_generic = generic
+    z = cuda(fx[f"d{dim}.z"])
+    mask = unpack_mask(fx[f"d{dim}.mask_bits"], dim).to(DEV)
+    x, ld = f.forward(z, mask=mask)
+    assert_close(x, fx[f"d{dim}.x"], RTOL, "x")
+    assert_close(ld, fx[f"d{dim}.ld"], RTOL, "ld")
+    assert not hasattr(f, "inverse")
+    # without a mask argument a Bernoulli(0.5) mask is drawn per element per call
+    x1, _ = f.forward(z)
+    x2, _ = f.forward(z)
+    assert not torch.equal(x1, x2)
+
+
+# ------------------------------------------------------- contracts of the boundary
+def test_g9_log_det_shapes(amd, golden):
+    fx = golden("g9_logdet_shapes")
+    x = cuda(recipes.gaussian(900, 8, 4))
+    mods = {"affine_half": amd.AffineHalfFlow(4, False), "nsf_cl": amd.NSF_CL(4, K=5),
+            "actnorm": amd.ActNormFlow(4), "affine_const": amd.AffineConstantFlow(4),
+            "glow": amd.Glow(4), "rnvp": amd.RNVP(4)}
+    for name, m in mods.items():
+        m.to(DEV)
+        assert tuple(m.forward(x)[1].shape) == tuple(fx[f"{name}.fwd"]), name
+        if name != "rnvp":
+            assert tuple(m.inverse(x)[1].shape) == tuple(fx[f"{name}.inv"]), name
+    stack = amd.NormalizingFlow([mods["actnorm"], mods["glow"], mods["nsf_cl"]])
+    zs, ld = stack.forward(x)
+    assert tuple(ld.shape) == tuple(fx["stack.ld_shape"]) and zs[0] is x
+    assert len(zs) == int(fx["stack.n_intermediates"])
+
+
+def test_state_dict_keys_match_reference(amd):
+    assert list(amd.AffineHalfFlow(64, False).state_dict()) == list(recipes.affine_half_params(0, 64))
+    assert list(amd.NSF_CL(32, K=8).state_dict()) == list(recipes.nsf_cl_params(0, 32, 8, 8))
+    assert list(amd.RNVP(800, (50,)).state_dict()) == list(recipes.rnvp_params(0, 800, 50))
+    assert list(amd.Glow(4).state_dict()) == ["L", "S", "U"]
+    assert list(amd.ActNormFlow(4).state_dict()) == ["s", "t"]
+
+
+def test_cpu_input_is_an_error_not_a_fallback(amd):
+    f = amd.AffineHalfFlow(64, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f.forward(torch.zeros(4, 64))
+    with pytest.raises(ValueError):
+        f.to(DEV).forward(torch.zeros(4, 32, device=DEV))
+
+
+def test_foreign_duck_typed_flow_in_stack(amd):
+    """NormalizingFlow calls unknown flows by name and adds their (possibly scalar) log_det."""
+
+    class Shift(torch.nn.Module):
+        def forward(self, z):
+            return z + 1.0, torch.tensor(0.5, device=z.device)
+
+        def inverse(self, x):
+            return x - 1.0, torch.tensor(-0.5, device=x.device)
+
+    f = ahf_module(amd, recipes.affine_half_params(3, 64), 64, False)
+    stack = amd.NormalizingFlow([Shift(), f])
+    x = cuda(recipes.gaussian(4, 20, 64))
+    xs, ld = stack.forward(x)
+    y, l1 = f.forward(x + 1.0)
+    assert torch.equal(xs[-1], y)
+    assert_close(ld, l1 + 0.5, 1e-6)
+    zs, ldi = stack.inverse(xs[-1])
+    assert float((zs[-1] - x).abs().max()) < 1e-4

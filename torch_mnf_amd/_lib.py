@@ -1,0 +1,102 @@
+"""ctypes binding of libmnf_hip.so (the C ABI declared in include/mnf_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, this module raises.
+PyTorch is used by the callers only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmnf_hip.so")
+
+MNF_OK = 0
+MNF_ERR_INVALID_ARG = -1
+MNF_ERR_UNSUPPORTED = -2
+MNF_ERR_LAUNCH = -3
+MNF_ERR_NO_DEVICE = -4
+MNF_ERR_DOMAIN = -5
+
+_intp = POINTER(c_int)
+_i32p = POINTER(c_int32)
+
+# name -> (restype, argtypes); mirrors include/mnf_hip.h one to one
+SIGNATURES = {
+    "mnf_abi_version": (c_int, []),
+    "mnf_error_string": (c_char_p, [c_int]),
+    "mnf_last_hip_error": (c_int, []),
+    "mnf_device_count": (c_int, []),
+    "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
+    "mnf_affine_half_image_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
+    "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
+    "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
+    "mnf_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_nsf_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+                           c_float, c_int, c_int, _intp, c_int, c_void_p]),
+    "mnf_nsf_cl_flat_floats": (c_int64, [c_int, c_int, c_int, _intp]),
+    "mnf_nsf_cl_image_floats": (c_int64, [c_int, c_int, c_int, _intp]),
+    "mnf_nsf_cl_image_index": (c_int, [c_int, c_int, c_int, _intp, _i32p]),
+    "mnf_rqs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                        c_int, c_void_p]),
+    "mnf_rnvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
+                         c_int, _intp, c_int, c_void_p]),
+    "mnf_rnvp_flat_floats": (c_int64, [c_int, c_int, _intp]),
+    "mnf_rnvp_image_floats": (c_int64, [c_int, c_int, _intp]),
+    "mnf_rnvp_image_index": (c_int, [c_int, c_int, _intp, _i32p]),
+    "mnf_affine_const": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
+                                 c_int, c_int, c_void_p]),
+    "mnf_linear_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_gauss_logprob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class MnfHipError(RuntimeError):
+    """A libmnf_hip.so call returned a negative MNF_ERR_* code."""
+
+    def __init__(self, fn: str, code: int, message: str):
+        super().__init__(f"{fn} failed: {message} (code {code})")
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load libmnf_hip.so (once) and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C torch_mnf_amd/csrc). "
+            "torch_mnf_amd has no CPU or PyTorch fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(fn: str, code: int) -> None:
+    if code == MNF_OK:
+        return
+    lib = load()
+    msg = lib.mnf_error_string(code).decode()
+    if code == MNF_ERR_LAUNCH:
+        msg += f" (hipError_t {lib.mnf_last_hip_error()})"
+    if code == MNF_ERR_DOMAIN:
+        # same exception type and text as the reference (spline_flow.py:90-93)
+        raise ValueError("Minimal bin width too large for the number of bins")
+    raise MnfHipError(fn, code, msg)
+
+
+def int_array(values) -> ctypes.Array:
+    values = [int(v) for v in values]
+    return (c_int * max(len(values), 1))(*values)

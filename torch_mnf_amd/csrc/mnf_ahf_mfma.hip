@@ -1,0 +1,351 @@
+// AffineHalfFlow coupling layer on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// One wave owns a tile of 16 consecutive rows (samples).  Everything is computed transposed,
+// activations^T = W . x^T, so that the batch sits on the MFMA's N axis (lane & 15) and the
+// accumulator of one Linear is, register for register, the B operand of the next one:
+//
+//   D layout of 16x16x4:  lane (j = lane & 15, q = lane >> 4), reg r  holds  D[row 4q + r][col j]
+//   B operand of a K-step: lane (j, q) supplies B[k = q][col j]
+//   => register r of an accumulator tile IS a K-step operand whose four k's are the rows
+//      {r, 4 + r, 8 + r, 12 + r} of that tile.  Hidden units are therefore numbered so that
+//      "quad" c (= K-step) of the concatenated [s_net ; t_net] hidden vector holds units
+//      4c .. 4c+3, quad c lives in register c % 4 of tile c / 4, and no lane shuffle or LDS
+//      round trip is needed between layers: bias is the initial accumulator, LeakyReLU is two
+//      VALU ops on the accumulator registers.
+//
+// s_net and t_net share their input, so layer 1 is one (2*HID x H) product; the hidden layers
+// are block diagonal and only the K-steps of the nets present in an output tile are issued
+// (for HID = 24: 6 + 12 + 6 MFMAs instead of 32 for two padded nets).  The last layer produces
+// s and t for 16 output dims at a time in two accumulators with the same lane layout as a
+// float4 of the row, so the affine transform, the store and the log|det J| partial sum run
+// straight out of registers; the per-row sum is finished with two cross-lane adds.
+//
+// Weights: the host builds an "image" in MFMA A-operand order ([group of 4 MFMAs][lane][4]
+// floats, then biases); each workgroup copies it to LDS once and every wave re-reads it with
+// conflict-free ds_read_b128 (one read feeds four MFMAs).  Workgroups are persistent and
+// stride over the tiles.
+//
+// HBM traffic per row: read 4*dim, write 4*dim, log_det 4 (+4 when accumulating): the
+// algorithmic minimum for an out-of-place layer (8d + 8 bytes).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int HID>
+struct AhfShape {
+  static_assert(H % 16 == 0, "conditioner width must be a multiple of 16");
+  static_assert(HID % 4 == 0, "hidden width must be a multiple of 4");
+  static constexpr int G = H / 16;             // float4 groups per half row == output tiles per net
+  static constexpr int QN = HID / 4;           // quads (K-steps) per net
+  static constexpr int NQ = 2 * QN;            // quads of the concatenated hidden vector
+  static constexpr int NT = (NQ + 3) / 4;      // 16-row tiles of the concatenated hidden vector
+  static constexpr bool tile_has_net(int m, int net) {
+    for (int c = 4 * m; c < 4 * m + 4 && c < NQ; ++c)
+      if ((c >= QN) == (net == 1)) return true;
+    return false;
+  }
+  static constexpr int hidden_mfmas() {
+    int n = 0;
+    for (int c = 0; c < NQ; ++c)
+      for (int m = 0; m < NT; ++m)
+        if (tile_has_net(m, c >= QN ? 1 : 0)) ++n;
+    return n;
+  }
+  static constexpr int N_MFMA = (H / 4) * NT + 2 * hidden_mfmas() + G * 2 * QN;
+  static constexpr int A_FLOATS = ((N_MFMA + 3) / 4) * 256;
+  static constexpr int N_BIAS_TILES = 3 * NT + 2 * G;
+  static constexpr int IMAGE_FLOATS = A_FLOATS + N_BIAS_TILES * 16;
+};
+
+constexpr int kAhfWaves = 8;  // 512-thread workgroups
+
+template <int H, int HID, bool INV>
+__global__ void __launch_bounds__(kAhfWaves * 64)
+ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
+                const float* __restrict__ image, int64_t rows, int parity, int accumulate) {
+  using S = AhfShape<H, HID>;
+  constexpr int G = S::G, QN = S::QN, NQ = S::NQ, NT = S::NT;
+  constexpr int dim = 2 * H;
+  __shared__ __attribute__((aligned(16))) float lds[S::IMAGE_FLOATS];
+
+  {  // stage the operand image (L2-resident) into LDS
+    const float4* src = reinterpret_cast<const float4*>(image);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < S::IMAGE_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
+  const f32x4* A4_base = reinterpret_cast<const f32x4*>(lds) + lane;        // + 64 * group
+  const f32x4* B4_base = reinterpret_cast<const f32x4*>(lds + S::A_FLOATS) + q;  // + 4 * tile
+
+  const int64_t n_tiles = (rows + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * kAhfWaves + wave; tile < n_tiles;
+       tile += (int64_t)gridDim.x * kAhfWaves) {
+    const int64_t row = tile * 16 + j;
+    const bool live = row < rows;
+    const int64_t rowc = live ? row : rows - 1;
+    const float* xr = x + rowc * dim;
+    float* yr = y + rowc * dim;
+
+    f32x4 cnd[G], act[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g + 4 * q);
+#pragma unroll
+    for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g + 4 * q);
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g + 4 * q) = cnd[g];
+    }
+
+    int n = 0;       // MFMA sequence number (compile-time after unrolling)
+    int btile = 0;   // bias tile number
+    f32x4 a4;
+    // The operand image never changes, so hipcc would hoist all ~100 A-operand reads out of
+    // the tile loop into VGPRs (2 waves/SIMD).  Re-reading them from LDS costs one
+    // ds_read_b128 per four MFMAs and keeps the kernel at 8 waves/SIMD, which is what hides
+    // the HBM latency here; making the base pointers opaque per tile blocks the hoist.
+    const f32x4* A4 = A4_base;
+    const f32x4* B4 = B4_base;
+    asm volatile("" : "+v"(A4), "+v"(B4));
+
+    // ---- layer 1: [s;t] hidden (2*HID) <- cond (H)
+    f32x4 h1[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) h1[m] = B4[4 * (btile++)];
+#pragma unroll
+    for (int c1 = 0; c1 < H / 4; ++c1) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
+        ++n;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[m][r] = leaky(h1[m][r]);
+
+    // ---- layers 2 and 3: block-diagonal (HID <- HID) per net
+    f32x4 h2[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) h2[m] = B4[4 * (btile++)];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+          if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+          h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
+          ++n;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[m][r] = leaky(h2[m][r]);
+
+    f32x4 h3[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) h3[m] = B4[4 * (btile++)];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+          if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+          h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
+          ++n;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h3[m][r] = leaky(h3[m][r]);
+
+    // ---- layer 4 + affine transform, 16 output dims per step
+    float ld = 0.f;
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      f32x4 s4 = B4[4 * (btile++)];
+      f32x4 t4 = B4[4 * (btile++)];
+#pragma unroll
+      for (int c = 0; c < QN; ++c) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], s4, 0, 0, 0);
+        ++n;
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4, 0, 0, 0);
+        ++n;
+      }
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(s4[r]);
+        o[r] = INV ? (act[m][r] - t4[r]) / e : e * act[m][r] + t4[r];
+        ld += s4[r];
+      }
+      if (live) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m + 4 * q) = o;
+    }
+    if (log_det) {
+      ld = sum_over_q(ld);
+      if (INV) ld = -ld;
+      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host: image index table
+template <int H, int HID>
+static void build_index(int32_t* idx) {
+  using S = AhfShape<H, HID>;
+  constexpr int QN = S::QN, NQ = S::NQ, NT = S::NT, G = S::G;
+  int sizes[5] = {H, HID, HID, HID, H};
+  NetDesc net[2];
+  int64_t off = fill_net(net[0], 5, sizes, 0);
+  fill_net(net[1], 5, sizes, off);
+  for (int64_t i = 0; i < S::IMAGE_FLOATS; ++i) idx[i] = -1;
+  int n = 0;
+  auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
+  // hidden-vector unit of accumulator row i of tile m
+  auto unit_of = [&](int m, int i) { return 16 * m + 4 * (i & 3) + (i >> 2); };
+
+  for (int c1 = 0; c1 < H / 4; ++c1) {
+    const int g = c1 >> 2, e = c1 & 3;
+    for (int m = 0; m < NT; ++m) {
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
+        if (u < 2 * HID) {
+          const int nn = u / HID, unit = u % HID;
+          put(lane, net[nn].w_off[0] + unit * H + 16 * g + 4 * kq + e);
+        }
+      }
+      ++n;
+    }
+  }
+  for (int l = 1; l <= 2; ++l) {
+    for (int c = 0; c < NQ; ++c) {
+      const int cn = c >= QN ? 1 : 0;
+      for (int m = 0; m < NT; ++m) {
+        if (!S::tile_has_net(m, cn)) continue;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
+          if (u < 2 * HID && u / HID == cn)
+            put(lane, net[cn].w_off[l] + (u % HID) * HID + (4 * c + kq - cn * HID));
+        }
+        ++n;
+      }
+    }
+  }
+  for (int m = 0; m < G; ++m) {
+    for (int c = 0; c < QN; ++c) {
+      for (int nn = 0; nn < 2; ++nn) {
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4;
+          put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
+        }
+        ++n;
+      }
+    }
+  }
+  // biases: [tile][row i]
+  int32_t* b = idx + S::A_FLOATS;
+  int bt = 0;
+  for (int l = 0; l < 3; ++l)
+    for (int m = 0; m < NT; ++m, ++bt)
+      for (int i = 0; i < 16; ++i) {
+        const int u = unit_of(m, i);
+        if (u < 2 * HID) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
+      }
+  for (int m = 0; m < G; ++m)
+    for (int nn = 0; nn < 2; ++nn, ++bt)
+      for (int i = 0; i < 16; ++i) b[bt * 16 + i] = net[nn].b_off[3] + 16 * m + i;
+}
+
+template <int H, int HID>
+static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                  int64_t rows, int parity, int inverse, hipStream_t stream) {
+  const int64_t n_tiles = (rows + 15) / 16;
+  int64_t blocks = (n_tiles + kAhfWaves - 1) / kAhfWaves;
+  const int64_t cap = 256 * 4;  // persistent: 4 workgroups per CU
+  if (blocks > cap) blocks = cap;
+  if (inverse)
+    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true>), dim3((unsigned)blocks), dim3(kAhfWaves * 64), 0,
+                       stream, x, y, log_det, image, rows, parity, accumulate);
+  else
+    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false>), dim3((unsigned)blocks), dim3(kAhfWaves * 64), 0,
+                       stream, x, y, log_det, image, rows, parity, accumulate);
+  return check_launch();
+}
+
+// (H, HID) pairs with an instantiated kernel
+#define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24)
+
+static bool uniform_hidden(int n_hidden, const int* hidden, int& hid) {
+  if (n_hidden != 3) return false;
+  hid = hidden[0];
+  return hidden[1] == hid && hidden[2] == hid;
+}
+
+int ahf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                    int64_t rows, int dim, int parity, int inverse, int n_hidden, const int* hidden,
+                    int has_scale, int has_shift, hipStream_t stream) {
+  int hid = 0;
+  if (!has_scale || !has_shift || !uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+       reinterpret_cast<uintptr_t>(image)) & 15)
+    return MNF_ERR_UNSUPPORTED;  // float4 accesses need 16-byte aligned bases
+#define X(HH, HD) \
+  if (dim == 2 * HH && hid == HD) \
+    return launch<HH, HD>(x, y, log_det, accumulate, image, rows, parity != 0, inverse != 0, stream);
+  MNF_AHF_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden, int has_scale,
+                                     int has_shift) {
+  int hid = 0;
+  if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) ||
+      !mnf::uniform_hidden(n_hidden, hidden, hid))
+    return 0;
+#define X(HH, HD) \
+  if (dim == 2 * HH && hid == HD) return mnf::AhfShape<HH, HD>::IMAGE_FLOATS;
+  MNF_AHF_SHAPES(X)
+#undef X
+  return 0;
+}
+
+int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                                int32_t* idx_host) {
+  int hid = 0;
+  if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  if (!has_scale || !has_shift || !mnf::uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+#define X(HH, HD)                        \
+  if (dim == 2 * HH && hid == HD) {      \
+    mnf::build_index<HH, HD>(idx_host);  \
+    return MNF_OK;                       \
+  }
+  MNF_AHF_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

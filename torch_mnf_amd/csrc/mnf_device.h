@@ -1,0 +1,158 @@
+// Device-side helpers shared by the generic and the MFMA kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mnf_hip.h"
+
+namespace mnf {
+
+constexpr float kLeakySlope = 0.2f;  // models/mlp.py:7
+constexpr float kMinBin = 1e-3f;     // spline_flow.py:17-18 (width and height share it)
+constexpr float kMinDeriv = 1e-3f;   // spline_flow.py:19
+// log(exp(1 - 1e-3) - 1) evaluated in float64 then rounded (spline_flow.py:47-49)
+constexpr float kEdgeDerivConst = 0.53974241439865964f;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+// Shapes of one conditioner net: n_lin Linear layers, sizes[0..n_lin], and the float
+// offset of each weight / bias inside the flat parameter buffer.
+struct NetDesc {
+  int n_lin;
+  int sizes[MNF_MAX_LINEAR + 1];
+  int w_off[MNF_MAX_LINEAR];
+  int b_off[MNF_MAX_LINEAR];
+  int max_width;  // max over sizes
+};
+
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, kLeakySlope * v); }
+
+// F.softplus with beta=1, threshold=20 (linear above the threshold).
+__device__ __forceinline__ float softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ------------------------------------------------------------------------------------
+// Rational-quadratic spline for ONE element, streaming over the K bins so that no
+// per-bin array is needed: `get(k)` returns the k-th raw value of a parameter group.
+//
+//   DOUBLE = true  : raw net outputs; NSF_CL's first normalisation (2T*softmax, softplus,
+//                    spline_flow.py:254-256) is applied and then RQS's own (:95-113)
+//   DOUBLE = false : inputs are what unconstrained_RQS receives (mnf_rqs entry point)
+//
+// Knots follow the reference: fractions 1e-3 + (1 - 1e-3 K) softmax, sequential cumsum,
+// 2T*c - T, first/last knot forced to -T / +T, bin sizes re-derived by differencing.
+// The bin is count(v >= knot) - 1 over K+1 knots with the last one nudged by 1e-6; for an
+// inside element that is the last k < K with v >= knot_k.
+// ------------------------------------------------------------------------------------
+template <bool DOUBLE, typename GetW, typename GetH, typename GetD>
+__device__ __forceinline__ void rqs_element(float v, int K, float T, bool inverse, GetW getW,
+                                            GetH getH, GetD getD, float& out, float& lad) {
+  const bool inside = (v >= -T) && (v <= T);  // NaN -> outside -> identity
+  if (!inside) {
+    out = v;
+    lad = 0.f;
+    return;
+  }
+  const float twoT = 2.f * T;
+  const float c1 = 1.f - kMinBin * (float)K;  // (1 - min_bin * K)
+
+  // softmax normalisers.  First level (DOUBLE): p = exp(u - max u) / sum; u' = 2T p.
+  float mW = -INFINITY, mH = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    mW = fmaxf(mW, getW(k));
+    mH = fmaxf(mH, getH(k));
+  }
+  float sW = 0.f, sH = 0.f;
+  for (int k = 0; k < K; ++k) {
+    sW += expf(getW(k) - mW);
+    sH += expf(getH(k) - mH);
+  }
+  // Second level max/sum (or the only level when !DOUBLE: m2 = max, s2 = sum above).
+  float m2W, m2H, s2W, s2H;
+  if (DOUBLE) {
+    m2W = twoT * (1.f / sW);  // the max element has exp(0) = 1
+    m2H = twoT * (1.f / sH);
+    s2W = 0.f;
+    s2H = 0.f;
+    for (int k = 0; k < K; ++k) {
+      s2W += expf(twoT * (expf(getW(k) - mW) / sW) - m2W);
+      s2H += expf(twoT * (expf(getH(k) - mH) / sH) - m2H);
+    }
+  } else {
+    m2W = mW;
+    m2H = mH;
+    s2W = sW;
+    s2H = sH;
+  }
+
+  // stream over the bins: running cumsum for both axes, remember the selected bin
+  float cw = 0.f, ch = 0.f;      // cumulative fractions
+  float xk_prev = -T, yk_prev = -T;
+  float x_k = -T, w_k = 1.f, y_k = -T, h_k = 1.f;
+  int bin = 0;
+  for (int k = 0; k < K; ++k) {
+    float uW = getW(k), uH = getH(k);
+    if (DOUBLE) {
+      uW = twoT * (expf(uW - mW) / sW);
+      uH = twoT * (expf(uH - mH) / sH);
+    }
+    const float fw = kMinBin + c1 * (expf(uW - m2W) / s2W);
+    const float fh = kMinBin + c1 * (expf(uH - m2H) / s2H);
+    cw += fw;
+    ch += fh;
+    const float xk_next = (k == K - 1) ? T : twoT * cw + (-T);
+    const float yk_next = (k == K - 1) ? T : twoT * ch + (-T);
+    const float probe = inverse ? yk_prev : xk_prev;
+    if (v >= probe) {  // knots increase, so the last hit is the bin
+      bin = k;
+      x_k = xk_prev;
+      w_k = xk_next - xk_prev;
+      y_k = yk_prev;
+      h_k = yk_next - yk_prev;
+    }
+    xk_prev = xk_next;
+    yk_prev = yk_next;
+  }
+  // derivatives at the two knots of the bin: index 0 and K carry the edge constant
+  float d_k, d_k1;
+  {
+    float r0 = (bin == 0) ? kEdgeDerivConst : (DOUBLE ? softplus(getD(bin - 1)) : getD(bin - 1));
+    float r1 = (bin == K - 1) ? kEdgeDerivConst : (DOUBLE ? softplus(getD(bin)) : getD(bin));
+    d_k = kMinDeriv + softplus(r0);
+    d_k1 = kMinDeriv + softplus(r1);
+  }
+  const float delta = h_k / w_k;
+  if (inverse) {
+    const float dy = v - y_k;
+    const float curv = d_k + d_k1 - 2.f * delta;
+    const float a = dy * curv + h_k * (delta - d_k);
+    const float b = h_k * d_k - dy * curv;
+    const float c = -delta * dy;
+    const float disc = b * b - 4.f * a * c;
+    const float root = (2.f * c) / (-b - sqrtf(disc));
+    out = root * w_k + x_k;
+    const float tomt = root * (1.f - root);
+    const float denom = delta + curv * tomt;
+    const float omr = 1.f - root;
+    const float dnum = (delta * delta) * (d_k1 * (root * root) + 2.f * delta * tomt + d_k * (omr * omr));
+    lad = -(logf(dnum) - 2.f * logf(denom));
+  } else {
+    const float theta = (v - x_k) / w_k;
+    const float tomt = theta * (1.f - theta);
+    const float numer = h_k * (delta * (theta * theta) + d_k * tomt);
+    const float denom = delta + (d_k + d_k1 - 2.f * delta) * tomt;
+    out = y_k + numer / denom;
+    const float omt = 1.f - theta;
+    const float dnum = (delta * delta) * (d_k1 * (theta * theta) + 2.f * delta * tomt + d_k * (omt * omt));
+    lad = logf(dnum) - 2.f * logf(denom);
+  }
+}
+
+// sum over the 4 lanes {j, j+16, j+32, j+48} that share a sample in the 16x16 MFMA layout
+__device__ __forceinline__ float sum_over_q(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+}  // namespace mnf

@@ -1,0 +1,711 @@
+// Generic (any-shape) kernels for every layer on the hot path, plus the C-ABI entry points.
+//
+// These cover every configuration the reference accepts (odd hidden sizes, d = 2, NICE
+// variants, any K); the specialised MFMA kernels in mnf_ahf_mfma.hip / mnf_nsf_mfma.hip /
+// mnf_rnvp_mfma.hip take over for the shapes that matter for throughput.
+//
+// Structure of a generic coupling kernel: one 256-thread workgroup owns R consecutive rows
+// (R chosen on the host so that everything fits in 64 KiB of LDS); the conditioner's
+// activations live in LDS as [R][width]; every thread computes (row, unit) pairs of a
+// Linear layer with an fmaf chain in k order; the transform and the per-row log|det J|
+// reduction run out of LDS.  Global traffic is coalesced: rows are read and written once.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+
+constexpr int kThreads = 256;
+constexpr int kLdsBudgetFloats = 15 * 1024;  // 60 KiB of dynamic LDS per workgroup
+
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+// One Linear (+ optional LeakyReLU) over R rows held in LDS.
+// in: [R][ld_in], out: [R][ld_out]; weights (n_out, n_in) row-major in global memory.
+__device__ __forceinline__ void block_linear(const float* __restrict__ W, const float* __restrict__ b,
+                                             const float* in, int ld_in, float* out, int ld_out,
+                                             int n_in, int n_out, int R, bool act) {
+  for (int idx = threadIdx.x; idx < R * n_out; idx += blockDim.x) {
+    const int r = idx / n_out, o = idx - r * n_out;
+    const float* w = W + (size_t)o * n_in;
+    const float* a = in + r * ld_in;
+    float acc = b[o];
+    for (int k = 0; k < n_in; ++k) acc = fmaf(w[k], a[k], acc);
+    out[r * ld_out + o] = act ? leaky(acc) : acc;
+  }
+  __syncthreads();
+}
+
+// Whole MLP.  `in` holds the input [R][ld_in]; bufA/bufB are ping-pong scratch [R][ldw];
+// the last layer writes to `dst` [R][ld_dst].
+__device__ __forceinline__ void block_mlp(const float* __restrict__ flat, const NetDesc& nd,
+                                          const float* in, int ld_in, float* bufA, float* bufB,
+                                          int ldw, float* dst, int ld_dst, int R) {
+  const float* cur = in;
+  int ld_cur = ld_in;
+  for (int l = 0; l < nd.n_lin; ++l) {
+    const bool last = (l == nd.n_lin - 1);
+    float* o = last ? dst : ((l & 1) ? bufB : bufA);
+    const int ld_o = last ? ld_dst : ldw;
+    block_linear(flat + nd.w_off[l], flat + nd.b_off[l], cur, ld_cur, o, ld_o, nd.sizes[l],
+                 nd.sizes[l + 1], R, !last);
+    cur = o;
+    ld_cur = ld_o;
+  }
+}
+
+// ------------------------------------------------------------------ AffineHalfFlow
+struct AhfArgs {
+  const float* x;
+  float* y;
+  float* log_det;
+  const float* flat;
+  int64_t rows;
+  int dim, parity, inverse, accumulate, has_scale, has_shift;
+  int R;    // rows per workgroup
+  int ldw;  // scratch row stride (max hidden width)
+  NetDesc s_net, t_net;
+};
+
+__global__ void __launch_bounds__(kThreads) ahf_generic_kernel(AhfArgs a) {
+  const int H = a.dim / 2;
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* cond = smem;                 // [R][H]
+  float* s_out = cond + a.R * H;      // [R][H]
+  float* t_out = s_out + a.R * H;     // [R][H]
+  float* bufA = t_out + a.R * H;      // [R][ldw]
+  float* bufB = bufA + a.R * a.ldw;   // [R][ldw]
+  const int cond_off = a.parity ? H : 0, act_off = a.parity ? 0 : H;
+
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const float c = a.x[(row0 + r) * a.dim + cond_off + j];
+    cond[idx] = c;
+    a.y[(row0 + r) * a.dim + cond_off + j] = c;  // untouched half keeps its place
+    s_out[idx] = 0.f;                            // scale=False / shift=False -> zeros (:38)
+    t_out[idx] = 0.f;
+  }
+  __syncthreads();
+  if (a.has_scale) block_mlp(a.flat, a.s_net, cond, H, bufA, bufB, a.ldw, s_out, H, R);
+  if (a.has_shift) block_mlp(a.flat, a.t_net, cond, H, bufA, bufB, a.ldw, t_out, H, R);
+
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const float v = a.x[(row0 + r) * a.dim + act_off + j];
+    const float s = s_out[idx], t = t_out[idx];
+    a.y[(row0 + r) * a.dim + act_off + j] = a.inverse ? (v - t) / expf(s) : expf(s) * v + t;
+  }
+  if (a.log_det) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float acc = 0.f;
+      for (int j = 0; j < H; ++j) acc += a.inverse ? -s_out[r * H + j] : s_out[r * H + j];
+      float* p = a.log_det + row0 + r;
+      *p = a.accumulate ? *p + acc : acc;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------- NSF_CL
+struct NsfArgs {
+  const float* x;
+  float* y;
+  float* log_det;
+  const float* flat;
+  int64_t rows;
+  int dim, K, inverse, accumulate;
+  float T;
+  int R, ldw, ldp;  // ldp = (3K-1)*H, the spline-parameter row stride
+  NetDesc f1, f2;
+};
+
+// spline for all (row, element) pairs of one half; params [R][ldp] in LDS
+__device__ __forceinline__ void block_spline(const float* params, int ldp, float* vals /*[R][H] in/out*/,
+                                             float* lad_sum /*[R]*/, float* lad_tmp /*[R][H]*/, int H,
+                                             int K, float T, bool inverse, int R) {
+  const int P = 3 * K - 1;
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const float* p = params + r * ldp + j * P;
+    float out, lad;
+    rqs_element<true>(
+        vals[idx], K, T, inverse, [&](int k) { return p[k]; }, [&](int k) { return p[K + k]; },
+        [&](int k) { return p[2 * K + k]; }, out, lad);
+    vals[idx] = out;
+    lad_tmp[idx] = lad;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < H; ++j) acc += lad_tmp[r * H + j];
+    lad_sum[r] += acc;  // log_det += sum(ld, dim=1) per half-step (spline_flow.py:258,265)
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kThreads) nsf_generic_kernel(NsfArgs a) {
+  const int H = a.dim / 2;
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* lower = smem;                  // [R][H]
+  float* upper = lower + a.R * H;       // [R][H]
+  float* lad_tmp = upper + a.R * H;     // [R][H]
+  float* lad_sum = lad_tmp + a.R * H;   // [R]
+  float* bufA = lad_sum + a.R;          // [R][ldw]
+  float* bufB = bufA + a.R * a.ldw;     // [R][ldw]
+  float* params = bufB + a.R * a.ldw;   // [R][ldp]
+
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    lower[idx] = a.x[(row0 + r) * a.dim + j];
+    upper[idx] = a.x[(row0 + r) * a.dim + H + j];
+  }
+  for (int r = threadIdx.x; r < R; r += blockDim.x) lad_sum[r] = 0.f;
+  __syncthreads();
+
+  if (!a.inverse) {  // f1(lower) moves upper, then f2(upper') moves lower (:249-266)
+    block_mlp(a.flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_spline(params, a.ldp, upper, lad_sum, lad_tmp, H, a.K, a.T, false, R);
+    block_mlp(a.flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_spline(params, a.ldp, lower, lad_sum, lad_tmp, H, a.K, a.T, false, R);
+  } else {  // (:268-285)
+    block_mlp(a.flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_spline(params, a.ldp, lower, lad_sum, lad_tmp, H, a.K, a.T, true, R);
+    block_mlp(a.flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_spline(params, a.ldp, upper, lad_sum, lad_tmp, H, a.K, a.T, true, R);
+  }
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    a.y[(row0 + r) * a.dim + j] = lower[idx];
+    a.y[(row0 + r) * a.dim + H + j] = upper[idx];
+  }
+  if (a.log_det) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float* p = a.log_det + row0 + r;
+      *p = a.accumulate ? *p + lad_sum[r] : lad_sum[r];
+    }
+  }
+}
+
+// elementwise unconstrained_RQS on caller-supplied (W, H, D)
+__global__ void rqs_kernel(const float* __restrict__ v, const float* __restrict__ W,
+                           const float* __restrict__ Hh, const float* __restrict__ D,
+                           float* __restrict__ out, float* __restrict__ lad, int64_t n, int K, float T,
+                           int inverse) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* w = W + i * K;
+  const float* h = Hh + i * K;
+  const float* d = D + i * (K - 1);
+  float o, l;
+  rqs_element<false>(
+      v[i], K, T, inverse != 0, [&](int k) { return w[k]; }, [&](int k) { return h[k]; },
+      [&](int k) { return d[k]; }, o, l);
+  out[i] = o;
+  lad[i] = l;
+}
+
+// ------------------------------------------------------------------- RNVP (gated)
+struct RnvpArgs {
+  const float* z;
+  const float* mask;
+  float* x;
+  float* log_det;
+  const float* flat;
+  int64_t rows;
+  int dim, accumulate;
+  int R, ldw;
+  int t_w, t_b, s_w, s_b;  // float offsets of t.weight, t.bias, s.weight, s.bias
+  NetDesc net;
+};
+
+__global__ void __launch_bounds__(kThreads) rnvp_generic_kernel(RnvpArgs a) {
+  const int d = a.dim, hl = a.net.sizes[a.net.n_lin];
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* kept = smem;                // [R][d]  mask * z
+  float* y = kept + a.R * d;         // [R][hl]
+  float* lad = y + a.R * hl;         // [R][d]
+  float* bufA = lad + a.R * d;       // [R][ldw]
+  float* bufB = bufA + a.R * a.ldw;  // [R][ldw]
+
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    const int r = idx / d, j = idx - r * d;
+    const int64_t g = (row0 + r) * d + j;
+    kept[idx] = a.mask[g] * a.z[g];
+  }
+  __syncthreads();
+  block_mlp(a.flat, a.net, kept, d, bufA, bufB, a.ldw, y, hl, R);
+
+  const float* Wt = a.flat + a.t_w;
+  const float* bt = a.flat + a.t_b;
+  const float* Ws = a.flat + a.s_w;
+  const float* bs = a.flat + a.s_b;
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    const int r = idx / d, j = idx - r * d;
+    const int64_t g = (row0 + r) * d + j;
+    const float* yr = y + r * hl;
+    float shift = bt[j], scale = bs[j];
+    for (int k = 0; k < hl; ++k) {
+      shift = fmaf(Wt[(size_t)j * hl + k], yr[k], shift);
+      scale = fmaf(Ws[(size_t)j * hl + k], yr[k], scale);
+    }
+    const float m = a.mask[g], zz = a.z[g];
+    const float gate = sigmoidf(scale);
+    // x = z1*gate + (1-gate)*shift + z2, every position (rnvp.py:37)
+    a.x[g] = ((1.f - m) * zz * gate + (1.f - gate) * shift) + m * zz;
+    lad[idx] = (1.f - m) * logf(gate);  // 0 * -inf = NaN, as in the reference (:36)
+  }
+  __syncthreads();
+  if (a.log_det) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float acc = 0.f;
+      for (int j = 0; j < d; ++j) acc += lad[r * d + j];
+      float* p = a.log_det + row0 + r;
+      *p = a.accumulate ? *p + acc : acc;
+    }
+  }
+}
+
+// ----------------------------------------------------------- data-independent layers
+__global__ void sum_vec_kernel(const float* __restrict__ s, int dim, int negate, float* __restrict__ out) {
+  // one wave; sequential-per-lane then shuffle tree (order fixed -> deterministic)
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < dim; j += 64) acc += s[j];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) *out = negate ? -acc : acc;
+}
+
+__global__ void affine_const_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                    const float* __restrict__ s, const float* __restrict__ t,
+                                    int64_t n, int dim, int inverse) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int j = (int)(i % dim);
+    y[i] = inverse ? (x[i] - t[j]) * expf(-s[j]) : x[i] * expf(s[j]) + t[j];
+  }
+}
+
+__global__ void add_scalar_rows_kernel(float* __restrict__ log_det, const float* __restrict__ scalar,
+                                       int64_t rows, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float v = *scalar;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride)
+    log_det[i] = accumulate ? log_det[i] + v : v;
+}
+
+// y = x @ W for small dim: W in LDS, R rows per workgroup, thread per (row, column)
+__global__ void __launch_bounds__(kThreads) linear_rows_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ W,
+                                                               float* __restrict__ y, int64_t rows,
+                                                               int dim, int R) {
+  float* Wl = smem;             // [dim][dim]
+  float* xl = Wl + dim * dim;   // [R][dim]
+  for (int i = threadIdx.x; i < dim * dim; i += blockDim.x) Wl[i] = W[i];
+  const int64_t n_groups = (rows + R - 1) / R;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t row0 = grp * R;
+    const int Rn = (int)min((int64_t)R, rows - row0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < Rn * dim; i += blockDim.x) xl[i] = x[row0 * dim + i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Rn * dim; idx += blockDim.x) {
+      const int r = idx / dim, j = idx - r * dim;
+      float acc = 0.f;
+      for (int k = 0; k < dim; ++k) acc = fmaf(xl[r * dim + k], Wl[k * dim + j], acc);
+      y[row0 * dim + idx] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------- base log-prob epilogue
+// One wave per row group; lanes stride the row, shuffle-reduce |z|^2, fp64 block sum.
+__global__ void __launch_bounds__(kThreads) gauss_logprob_kernel(const float* __restrict__ z,
+                                                                 const float* __restrict__ log_det,
+                                                                 float* __restrict__ log_prob,
+                                                                 double* __restrict__ sum_out,
+                                                                 int64_t rows, int dim) {
+  __shared__ double wave_sums[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n_waves = (int64_t)gridDim.x * (kThreads / 64);
+  const float cst = (float)dim * kHalfLog2Pi;
+  double local = 0.0;
+  // lanes_per_row = smallest power of two >= dim/4 capped at 64; rows_per_wave = 64 / lanes_per_row
+  int lpr = 1;
+  while (lpr < 64 && lpr * 4 < dim) lpr <<= 1;
+  const int rpw = 64 / lpr;
+  const int sub = lane / lpr, l = lane % lpr;
+  for (int64_t base = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * rpw; base < rows;
+       base += n_waves * rpw) {
+    const int64_t row = base + sub;
+    float acc = 0.f;
+    if (row < rows) {
+      const float* zr = z + row * dim;
+      for (int j = l; j < dim; j += lpr) acc = fmaf(zr[j], zr[j], acc);
+    }
+    for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (row < rows && l == 0) {
+      const float lp = (log_det ? log_det[row] : 0.f) + (-0.5f * acc - cst);
+      if (log_prob) log_prob[row] = lp;
+      local += (double)lp;
+    }
+  }
+  if (sum_out) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) wave_sums[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kThreads / 64; ++w) tot += wave_sums[w];
+      atomicAdd(sum_out, tot);
+    }
+  }
+}
+
+__global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __restrict__ log_var,
+                                 const float* __restrict__ eps, float* __restrict__ z0, int64_t n,
+                                 int dim) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int j = (int)(i % dim);
+    z0[i] = mean[j] + sqrtf(expf(log_var[j])) * eps[i];  // mnf_linear.py:59-62
+  }
+}
+
+__global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
+                                   float* __restrict__ image, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t s = idx[i];
+    image[i] = s < 0 ? 0.f : flat[s];
+  }
+}
+
+}  // namespace mnf
+
+// =====================================================================================
+// host side: argument checking, descriptors, launches
+// =====================================================================================
+using namespace mnf;
+
+namespace mnf {
+thread_local int g_last_hip_error = 0;
+
+int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return MNF_ERR_LAUNCH;
+  }
+  return MNF_OK;
+}
+
+// Fill a NetDesc for MLP(sizes...) whose parameters start at float offset `base` of the flat
+// buffer (weight then bias per Linear, state_dict order).  Returns floats consumed.
+int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base) {
+  nd.n_lin = n_sizes - 1;
+  nd.max_width = 0;
+  int64_t off = base;
+  for (int i = 0; i < n_sizes; ++i) {
+    nd.sizes[i] = sizes[i];
+    if (sizes[i] > nd.max_width) nd.max_width = sizes[i];
+  }
+  for (int l = 0; l < nd.n_lin; ++l) {
+    nd.w_off[l] = (int)off;
+    off += (int64_t)sizes[l] * sizes[l + 1];
+    nd.b_off[l] = (int)off;
+    off += sizes[l + 1];
+  }
+  return off - base;
+}
+
+bool hidden_ok(int n_hidden, const int* hidden) {
+  if (n_hidden < 0 || n_hidden + 1 > MNF_MAX_LINEAR) return false;
+  if (n_hidden > 0 && !hidden) return false;
+  for (int i = 0; i < n_hidden; ++i)
+    if (hidden[i] <= 0) return false;
+  return true;
+}
+
+static int grid_for(int64_t n, int threads, int cap = 256 * 8) {
+  int64_t g = (n + threads - 1) / threads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+}  // namespace mnf
+
+extern "C" {
+
+int mnf_abi_version(void) { return 1; }
+
+const char* mnf_error_string(int code) {
+  switch (code) {
+    case MNF_OK: return "ok";
+    case MNF_ERR_INVALID_ARG: return "invalid argument";
+    case MNF_ERR_UNSUPPORTED: return "shape not supported by the HIP kernels";
+    case MNF_ERR_LAUNCH: return "HIP kernel launch failed";
+    case MNF_ERR_NO_DEVICE: return "no gfx950 device";
+    case MNF_ERR_DOMAIN: return "minimal bin width/height too large for the number of bins";
+    default: return "unknown error";
+  }
+}
+
+int mnf_last_hip_error(void) { return g_last_hip_error; }
+
+int mnf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+// ------------------------------------------------------------------ AffineHalfFlow
+int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden, int has_scale,
+                                    int has_shift) {
+  if (dim < 2 || (dim & 1) || !hidden_ok(n_hidden, hidden)) return -1;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = dim / 2;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  sizes[n_hidden + 1] = dim / 2;
+  NetDesc nd;
+  const int64_t one = fill_net(nd, n_hidden + 2, sizes, 0);
+  return one * ((has_scale ? 1 : 0) + (has_shift ? 1 : 0));
+}
+
+int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate, const float* flat,
+                    const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
+                    const int* hidden, int has_scale, int has_shift, int force_generic, void* stream) {
+  if (!x || !y || x == y || rows < 0 || dim < 2 || (dim & 1) || !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if ((has_scale || has_shift) && !flat && !image) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (image && !force_generic) {
+    const int rc = ahf_mfma_launch(x, y, log_det, accumulate, image, rows, dim, parity, inverse,
+                                   n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
+  if ((has_scale || has_shift) && !flat) return MNF_ERR_INVALID_ARG;
+
+  AhfArgs a;
+  a.x = x; a.y = y; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim;
+  a.parity = parity != 0; a.inverse = inverse != 0; a.accumulate = accumulate != 0;
+  a.has_scale = has_scale != 0; a.has_shift = has_shift != 0;
+  const int H = dim / 2;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = H;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  sizes[n_hidden + 1] = H;
+  int64_t off = 0;
+  memset(&a.s_net, 0, sizeof(NetDesc));
+  memset(&a.t_net, 0, sizeof(NetDesc));
+  if (has_scale) off += fill_net(a.s_net, n_hidden + 2, sizes, off);
+  if (has_shift) off += fill_net(a.t_net, n_hidden + 2, sizes, off);
+  int ldw = 1;
+  for (int i = 0; i < n_hidden; ++i) ldw = hidden[i] > ldw ? hidden[i] : ldw;
+  a.ldw = ldw;
+  const int per_row = 3 * H + 2 * ldw;
+  int R = kLdsBudgetFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 64) R = 64;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ahf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
+                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream) {
+  if (!flat || !idx || !image || n < 0) return MNF_ERR_INVALID_ARG;
+  if (n == 0) return MNF_OK;
+  hipLaunchKernelGGL(pack_gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     flat, idx, image, n);
+  return check_launch();
+}
+
+// -------------------------------------------------------------------------- NSF_CL
+static int nsf_sizes(int dim, int K, int n_hidden, const int* hidden, int* sizes) {
+  sizes[0] = dim / 2;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  sizes[n_hidden + 1] = ((3 * K - 1) * dim) / 2;  // spline_flow.py:246
+  return n_hidden + 2;
+}
+
+int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden) {
+  if (dim < 2 || (dim & 1) || K < 1 || !hidden_ok(n_hidden, hidden)) return -1;
+  int sizes[MNF_MAX_LINEAR + 1];
+  const int n = nsf_sizes(dim, K, n_hidden, hidden, sizes);
+  NetDesc nd;
+  return 2 * fill_net(nd, n, sizes, 0);
+}
+
+int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const float* flat,
+               const float* image, int64_t rows, int dim, int K, float tail_bound, int inverse,
+               int n_hidden, const int* hidden, int force_generic, void* stream) {
+  if (!x || !y || x == y || rows < 0 || dim < 2 || (dim & 1) || K < 1 || !(tail_bound > 0.f) ||
+      !hidden_ok(n_hidden, hidden) || (!flat && !image))
+    return MNF_ERR_INVALID_ARG;
+  if (1e-3 * K > 1.0) return MNF_ERR_DOMAIN;  // spline_flow.py:90-93
+  if (rows == 0) return MNF_OK;
+  if (image && !force_generic) {
+    const int rc = nsf_mfma_launch(x, y, log_det, accumulate, image, rows, dim, K, tail_bound, inverse,
+                                   n_hidden, hidden, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
+  if (!flat) return MNF_ERR_INVALID_ARG;
+  NsfArgs a;
+  a.x = x; a.y = y; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim; a.K = K;
+  a.inverse = inverse != 0; a.accumulate = accumulate != 0; a.T = tail_bound;
+  const int H = dim / 2;
+  int sizes[MNF_MAX_LINEAR + 1];
+  const int n = nsf_sizes(dim, K, n_hidden, hidden, sizes);
+  int64_t off = fill_net(a.f1, n, sizes, 0);
+  fill_net(a.f2, n, sizes, off);
+  int ldw = 1;
+  for (int i = 0; i < n_hidden; ++i) ldw = hidden[i] > ldw ? hidden[i] : ldw;
+  a.ldw = ldw;
+  a.ldp = sizes[n - 1];
+  const int per_row = 3 * H + 1 + 2 * ldw + a.ldp;
+  int R = kLdsBudgetFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 64) R = 64;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nsf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
+                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D, float* outputs,
+            float* logabsdet, int64_t n, int K, float tail_bound, int inverse, void* stream) {
+  if (!inputs || !W || !H || (!D && K > 1) || !outputs || !logabsdet || n < 0 || K < 1 ||
+      !(tail_bound > 0.f))
+    return MNF_ERR_INVALID_ARG;
+  if (1e-3 * K > 1.0) return MNF_ERR_DOMAIN;
+  if (n == 0) return MNF_OK;
+  const int64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rqs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, inputs, W, H,
+                     D, outputs, logabsdet, n, K, tail_bound, inverse);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------- RNVP
+int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden) {
+  if (dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden)) return -1;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = dim;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  NetDesc nd;
+  const int64_t net = fill_net(nd, n_hidden + 1, sizes, 0);
+  return net + 2 * ((int64_t)hidden[n_hidden - 1] * dim + dim);
+}
+
+int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+             const float* flat, const float* image, int64_t rows, int dim, int n_hidden,
+             const int* hidden, int force_generic, void* stream) {
+  if (!z || !mask || !x || z == x || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden) ||
+      (!flat && !image))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (image && !force_generic) {
+    const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, rows, dim, n_hidden, hidden,
+                                    (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
+  if (!flat) return MNF_ERR_INVALID_ARG;
+  RnvpArgs a;
+  a.z = z; a.mask = mask; a.x = x; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim;
+  a.accumulate = accumulate != 0;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = dim;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  int64_t off = fill_net(a.net, n_hidden + 1, sizes, 0);
+  const int hl = hidden[n_hidden - 1];
+  a.t_w = (int)off; off += (int64_t)hl * dim;
+  a.t_b = (int)off; off += dim;
+  a.s_w = (int)off; off += (int64_t)hl * dim;
+  a.s_b = (int)off;
+  int ldw = 1;
+  for (int i = 0; i + 1 < n_hidden; ++i) ldw = hidden[i] > ldw ? hidden[i] : ldw;
+  a.ldw = ldw;
+  const int per_row = 2 * dim + hl + 2 * ldw;
+  int R = kLdsBudgetFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 32) R = 32;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rnvp_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
+                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+  return check_launch();
+}
+
+// ----------------------------------------------------------- data-independent layers
+int mnf_affine_const(const float* x, float* y, const float* s, const float* t, float* log_det,
+                     int accumulate, float* ld_scalar, int64_t rows, int dim, int inverse, void* stream) {
+  if (!x || !y || !s || !t || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (log_det && !ld_scalar) return MNF_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (ld_scalar) {
+    hipLaunchKernelGGL(sum_vec_kernel, dim3(1), dim3(64), 0, st, s, dim, inverse != 0, ld_scalar);
+    if (int rc = check_launch()) return rc;
+  }
+  if (rows == 0) return MNF_OK;
+  const int64_t n = rows * dim;
+  hipLaunchKernelGGL(affine_const_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, s, t, n, dim,
+                     inverse != 0);
+  if (int rc = check_launch()) return rc;
+  if (log_det) {
+    hipLaunchKernelGGL(add_scalar_rows_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, st, log_det,
+                       ld_scalar, rows, accumulate != 0);
+    return check_launch();
+  }
+  return MNF_OK;
+}
+
+int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int dim, void* stream) {
+  if (!x || !W || !y || x == y || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  const int64_t wf = (int64_t)dim * dim;
+  if (wf + dim > kLdsBudgetFloats) return MNF_ERR_UNSUPPORTED;
+  int R = (int)((kLdsBudgetFloats - wf) / dim);
+  if (R > 256) R = 256;
+  const int64_t groups = (rows + R - 1) / R;
+  const int grid = (int)(groups < 2048 ? groups : 2048);
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(grid), dim3(kThreads), (size_t)(wf + (int64_t)R * dim) * 4,
+                     (hipStream_t)stream, x, W, y, rows, dim, R);
+  return check_launch();
+}
+
+int mnf_gauss_logprob(const float* z, const float* log_det, float* log_prob, double* sum_out,
+                      int64_t rows, int dim, void* stream) {
+  if (!z || rows < 0 || dim < 1 || (!log_prob && !sum_out)) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(gauss_logprob_kernel, dim3(grid_for(rows, 16, 2048)), dim3(kThreads), 0,
+                     (hipStream_t)stream, z, log_det, log_prob, sum_out, rows, dim);
+  return check_launch();
+}
+
+int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0, int64_t rows,
+                  int dim, void* stream) {
+  if (!q0_mean || !q0_log_var || !eps || !z0 || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  const int64_t n = rows * dim;
+  hipLaunchKernelGGL(sample_z0_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, q0_mean,
+                     q0_log_var, eps, z0, n, dim);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+"""Flow modules with the reference's API, computed by libmnf_hip.so on MI355X.
+
+Drop-in boundary: each class keeps the reference's constructor
+signature, attribute names and ``state_dict`` keys, and the duck-typed Flow interface
+
+    flow.forward(z) -> (x, log_det)        flow.inverse(x) -> (z, log_det)
+
+so they slot into ``NormalizingFlow`` / ``NormalizingFlowModel`` (here or the reference's)
+and into MNF layers unchanged.  The arithmetic is a C-ABI call on raw device pointers and
+the current HIP stream; PyTorch only owns the memory.  Inputs must be fp32 tensors on the
+GPU -- there is no CPU path (the CPU restatement lives in ``oracle/`` and is test-only).
+
+Reference classes (below /root/reference/torch_mnf):
+  AffineHalfFlow  flows/affine_half_flow.py:20-66     NSF_CL   flows/spline_flow.py:238-285
+  RNVP            flows/rnvp.py:7-39                  Glow     flows/glow.py:5-37
+  AffineConstantFlow / ActNormFlow  flows/affine_constant_flow.py:7-50
+  NormalizingFlow / NormalizingFlowModel  flows/core.py:10-55     MLP  models/mlp.py:4-12
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import warnings
+from collections.abc import Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+__all__ = [
+    "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
+    "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "rqs",
+]
+
+
+class MLP(nn.Sequential):
+    """Linear / LeakyReLU(0.2) chain, last activation dropped (models/mlp.py:4-12).
+
+    Holds the conditioner's parameters under the reference's key names
+    (``0.weight``, ``0.bias``, ``2.weight`` ...).  The HIP kernels read the parameters
+    directly; this module's own ``forward`` is never on the hot path."""
+
+    def __init__(self, *layer_sizes: int, leaky_a: float = 0.2) -> None:
+        layers: list[nn.Module] = []
+        for s1, s2 in zip(layer_sizes, layer_sizes[1:]):
+            layers.append(nn.Linear(s1, s2))
+            layers.append(nn.LeakyReLU(leaky_a))
+        super().__init__(*layers[:-1])
+        self.layer_sizes = tuple(int(s) for s in layer_sizes)
+
+
+def _ptr(t: Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _device_input(t: Tensor, what: str) -> Tensor:
+    if not isinstance(t, Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"torch_mnf_amd: {what} must be a GPU tensor (got {getattr(t, 'device', type(t))}); "
+            "the HIP path has no CPU fallback"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"torch_mnf_amd: {what} must be float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"torch_mnf_amd: {what} must be (rows, dim), got {tuple(t.shape)}")
+    return t.detach().contiguous()
+
+
+_warned_autograd = False
+
+
+def _note_no_autograd(module: nn.Module, x: Tensor) -> None:
+    global _warned_autograd
+    if _warned_autograd or not torch.is_grad_enabled():
+        return
+    if x.requires_grad or any(p.requires_grad for p in module.parameters()):
+        _warned_autograd = True
+        warnings.warn(
+            "torch_mnf_amd: the HIP coupling kernels do not record an autograd graph yet "
+            "(forward/inverse values only); wrap evaluation in torch.no_grad().",
+            stacklevel=3,
+        )
+
+
+class _HipFlow(nn.Module):
+    """Shared plumbing: packed-parameter caches keyed on parameter versions."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._cache_key = None
+        self._flat: Tensor | None = None
+        self._image: Tensor | None = None
+        self._index: Tensor | None = None  # device int32 gather table, built once
+        self.force_generic = False  # tests: run the generic kernel even if an MFMA one exists
+
+    # subclasses: ordered parameter list == state_dict order
+    def _packed_params(self) -> list[Tensor]:
+        return [p for p in self.parameters()]
+
+    def _image_index_host(self):  # -> ctypes int32 array or None
+        return None
+
+    def _buffers(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
+        params = self._packed_params()
+        if not params:
+            return None, None
+        key = (device, tuple((p.data_ptr(), p._version) for p in params))
+        if key != self._cache_key:
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
+            self._flat = flat.contiguous()
+            if self._index is None or self._index.device != device:
+                host = self._image_index_host()
+                self._index = None if host is None else torch.frombuffer(
+                    host, dtype=torch.int32).clone().to(device)
+            if self._index is not None:
+                image = torch.empty(self._index.numel(), dtype=torch.float32, device=device)
+                _lib.check("mnf_pack_gather", _lib.load().mnf_pack_gather(
+                    self._flat.data_ptr(), self._index.data_ptr(), image.data_ptr(),
+                    self._index.numel(), _stream()))
+                self._image = image
+            else:
+                self._image = None
+            self._cache_key = key
+        return self._flat, self._image
+
+    # out-of-place layer on raw buffers; accum: (rows,) tensor receiving ``+= log_det`` or None
+    def _run(self, x: Tensor, inverse: bool, accum: Tensor | None) -> tuple[Tensor, Tensor | None]:
+        raise NotImplementedError
+
+
+
+class _TwoWayFlow(_HipFlow):
+    """Flows with both directions (everything except the forward-only RNVP)."""
+
+    def forward(self, z: Tensor) -> tuple[Tensor, Tensor]:
+        return self._run(z, False, None)
+
+    def inverse(self, x: Tensor) -> tuple[Tensor, Tensor]:
+        return self._run(x, True, None)
+
+
+class AffineHalfFlow(_TwoWayFlow):
+    """RealNVP / NICE half coupling (flows/affine_half_flow.py:20-66)."""
+
+    def __init__(self, dim: int, parity: bool, h_sizes: Sequence[int] = (24, 24, 24),
+                 scale: bool = True, shift: bool = True) -> None:
+        super().__init__()
+        if dim % 2:
+            raise ValueError("AffineHalfFlow needs an even dim")
+        self.dim = int(dim)
+        self.parity = parity
+        self.h_sizes = tuple(int(h) for h in h_sizes)
+        self.scale, self.shift = bool(scale), bool(shift)
+        # absent nets return zeros in the reference (:38); here the kernels take flags
+        if scale:
+            self.s_net = MLP(dim // 2, *self.h_sizes, dim // 2)
+        if shift:
+            self.t_net = MLP(dim // 2, *self.h_sizes, dim // 2)
+        self._hid = _lib.int_array(self.h_sizes)
+
+    def _packed_params(self) -> list[Tensor]:
+        out: list[Tensor] = []
+        if self.scale:
+            out += list(self.s_net.parameters())
+        if self.shift:
+            out += list(self.t_net.parameters())
+        return out
+
+    def _image_index_host(self):
+        lib = _lib.load()
+        n = lib.mnf_affine_half_image_floats(self.dim, len(self.h_sizes), self._hid, self.scale, self.shift)
+        if n <= 0:
+            return None
+        idx = (ctypes.c_int32 * n)()
+        _lib.check("mnf_affine_half_image_index", lib.mnf_affine_half_image_index(
+            self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
+        return idx
+
+    def _run(self, x, inverse, accum):
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        _note_no_autograd(self, x)
+        flat, image = self._buffers(x.device)
+        y = torch.empty_like(x)
+        ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_affine_half", _lib.load().mnf_affine_half(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
+            x.shape[0], self.dim, int(bool(self.parity)), int(inverse), len(self.h_sizes), self._hid,
+            int(self.scale), int(self.shift), int(self.force_generic), _stream()))
+        return y, (None if accum is not None else ld)
+
+    def forward(self, z: Tensor, inverse: bool = False) -> tuple[Tensor, Tensor]:
+        return self._run(z, inverse, None)
+
+
+class NSF_CL(_TwoWayFlow):
+    """Neural-spline coupling layer (flows/spline_flow.py:238-285)."""
+
+    def __init__(self, dim: int, K: int = 5, B: float = 3, n_h: int = 8, net_class=MLP) -> None:
+        super().__init__()
+        if dim % 2:
+            raise ValueError("NSF_CL needs an even dim")
+        self.dim, self.K, self.B = int(dim), int(K), B
+        self.f1 = net_class(dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2)
+        self.f2 = net_class(dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2)
+        sizes = getattr(self.f1, "layer_sizes", (dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2))
+        self.h_sizes = tuple(int(s) for s in sizes[1:-1])
+        self._hid = _lib.int_array(self.h_sizes)
+
+    def _packed_params(self) -> list[Tensor]:
+        return list(self.f1.parameters()) + list(self.f2.parameters())
+
+    def _image_index_host(self):
+        lib = _lib.load()
+        n = lib.mnf_nsf_cl_image_floats(self.dim, self.K, len(self.h_sizes), self._hid)
+        if n <= 0:
+            return None
+        idx = (ctypes.c_int32 * n)()
+        _lib.check("mnf_nsf_cl_image_index", lib.mnf_nsf_cl_image_index(
+            self.dim, self.K, len(self.h_sizes), self._hid, idx))
+        return idx
+
+    def _run(self, x, inverse, accum):
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        _note_no_autograd(self, x)
+        flat, image = self._buffers(x.device)
+        y = torch.empty_like(x)
+        ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
+            x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
+            int(self.force_generic), _stream()))
+        return y, (None if accum is not None else ld)
+
+
+def rqs(inputs: Tensor, W: Tensor, H: Tensor, D: Tensor, inverse: bool = False,
+        tail_bound: float = 1.0) -> tuple[Tensor, Tensor]:
+    """``unconstrained_RQS`` (flows/spline_flow.py:29-68) elementwise on the GPU.
+
+    inputs (...,), W/H (..., K), D (..., K-1).  An all-outside batch returns the identity
+    (the reference raises there)."""
+    shape = inputs.shape
+    K = W.shape[-1]
+    v = _device_input(inputs.reshape(-1, 1), "inputs").reshape(-1)
+    w = _device_input(W.reshape(-1, K), "W")
+    h = _device_input(H.reshape(-1, K), "H")
+    d = _device_input(D.reshape(-1, max(K - 1, 1)) if K > 1 else D.reshape(-1, 1), "D")
+    out, lad = torch.empty_like(v), torch.empty_like(v)
+    _lib.check("mnf_rqs", _lib.load().mnf_rqs(
+        v.data_ptr(), w.data_ptr(), h.data_ptr(), d.data_ptr(), out.data_ptr(), lad.data_ptr(),
+        v.numel(), K, float(tail_bound), int(inverse), _stream()))
+    return out.reshape(shape), lad.reshape(shape)
+
+
+class RNVP(_HipFlow):
+    """Forward-only masked/gated coupling used by the MNF layers (flows/rnvp.py:7-39).
+
+    ``forward(z)`` draws a fresh Bernoulli(0.5) mask per element like the reference (:28);
+    ``forward(z, mask=m)`` takes the mask as an input (parity tests, reproducible runs)."""
+
+    def __init__(self, dim: int, h_sizes: Sequence[int] = (30,)) -> None:
+        super().__init__()
+        self.dim = int(dim)
+        self.h_sizes = tuple(int(h) for h in h_sizes)
+        self.net = MLP(dim, *self.h_sizes)
+        self.t = nn.Linear(self.h_sizes[-1], dim)
+        self.s = nn.Linear(self.h_sizes[-1], dim)
+        self._hid = _lib.int_array(self.h_sizes)
+
+    def _packed_params(self) -> list[Tensor]:
+        return list(self.net.parameters()) + list(self.t.parameters()) + list(self.s.parameters())
+
+    def _image_index_host(self):
+        lib = _lib.load()
+        n = lib.mnf_rnvp_image_floats(self.dim, len(self.h_sizes), self._hid)
+        if n <= 0:
+            return None
+        idx = (ctypes.c_int32 * n)()
+        _lib.check("mnf_rnvp_image_index", lib.mnf_rnvp_image_index(self.dim, len(self.h_sizes), self._hid, idx))
+        return idx
+
+    def _run(self, z, inverse, accum, mask: Tensor | None = None):
+        if inverse:
+            raise AttributeError("RNVP has no inverse (flows/rnvp.py defines forward only)")
+        z = _device_input(z, "input")
+        if z.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {z.shape[1]}")
+        _note_no_autograd(self, z)
+        if mask is None:
+            mask = torch.bernoulli(0.5 * torch.ones_like(z))
+        mask = _device_input(mask, "mask")
+        if mask.shape != z.shape:
+            raise ValueError("mask must have the shape of z")
+        flat, image = self._buffers(z.device)
+        x = torch.empty_like(z)
+        ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        _lib.check("mnf_rnvp", _lib.load().mnf_rnvp(
+            z.data_ptr(), mask.data_ptr(), x.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat),
+            _ptr(image), z.shape[0], self.dim, len(self.h_sizes), self._hid, int(self.force_generic),
+            _stream()))
+        return x, (None if accum is not None else ld)
+
+    def forward(self, z: Tensor, mask: Tensor | None = None) -> tuple[Tensor, Tensor]:
+        return self._run(z, False, None, mask)
+
+
+class AffineConstantFlow(_TwoWayFlow):
+    """Per-dimension learned affine; log_det has shape (1,) (flows/affine_constant_flow.py:7-26)."""
+
+    def __init__(self, dim: int, scale: bool = True, shift: bool = True) -> None:
+        super().__init__()
+        self.dim = int(dim)
+        if scale:
+            self.s = nn.Parameter(torch.randn(1, dim))
+        else:
+            self.register_buffer("s", torch.zeros(1, dim), persistent=False)
+        if shift:
+            self.t = nn.Parameter(torch.randn(1, dim))
+        else:
+            self.register_buffer("t", torch.zeros(1, dim), persistent=False)
+
+    def _run(self, x, inverse, accum):
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        _note_no_autograd(self, x)
+        s = self.s.detach().to(x.device, torch.float32).contiguous()
+        t = self.t.detach().to(x.device, torch.float32).contiguous()
+        y = torch.empty_like(x)
+        ld1 = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.check("mnf_affine_const", _lib.load().mnf_affine_const(
+            x.data_ptr(), y.data_ptr(), s.data_ptr(), t.data_ptr(), _ptr(accum), int(accum is not None),
+            ld1.data_ptr(), x.shape[0], self.dim, int(inverse), _stream()))
+        return y, (None if accum is not None else ld1)
+
+
+class ActNormFlow(AffineConstantFlow):
+    """AffineConstantFlow with a data-dependent initialisation on the first ``inverse`` call
+    (flows/affine_constant_flow.py:29-50): s <- log std(x, 0), t <- mean(x * exp(s), 0)."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.data_dep_init_done = False
+
+    def inverse(self, x: Tensor) -> tuple[Tensor, Tensor]:
+        self._maybe_init(x)
+        return super().inverse(x)
+
+    def _maybe_init(self, x: Tensor) -> None:
+        if self.data_dep_init_done is False:
+            with torch.no_grad():  # one-off, cross-row statistics: plain device ops
+                if not bool((self.s.squeeze() == 0).all()):
+                    self.s.data = x.std(dim=0, keepdim=True).log().detach()
+                if not bool((self.t.squeeze() == 0).all()):
+                    self.t.data = (x * self.s.exp()).mean(dim=0, keepdim=True).detach()
+            self.data_dep_init_done = True
+
+    def _run(self, x, inverse, accum):
+        if inverse:
+            self._maybe_init(x)
+        return super()._run(x, inverse, accum)
+
+
+class Glow(_TwoWayFlow):
+    """Invertible d x d linear map, PLU-parametrised (flows/glow.py:5-37).
+
+    ``P`` is a plain attribute (not in the state_dict), as in the reference.  W (and, for
+    ``inverse``, its dense inverse) is d x d parameter preparation and is cached until a
+    parameter changes -- the reference rebuilds both on every call (:20-24, :33-34); the
+    row transform x @ W runs in the HIP library."""
+
+    def __init__(self, dim: int) -> None:
+        super().__init__()
+        self.dim = int(dim)
+        q, _ = torch.linalg.qr(torch.randn(dim, dim))
+        P, L, U = torch.linalg.lu(q)
+        self.P = P
+        self.L = nn.Parameter(L)
+        self.S = nn.Parameter(U.diag().clone())
+        self.U = nn.Parameter(torch.triu(U, diagonal=1))
+        self._w_key = None
+        self._w: Tensor | None = None
+        self._w_inv: Tensor | None = None
+
+    def _assemble_W(self, device=None) -> Tensor:
+        device = self.L.device if device is None else device
+        L = torch.tril(self.L.detach(), diagonal=-1) + torch.eye(self.dim, device=self.L.device)
+        U = torch.triu(self.U.detach(), diagonal=1)
+        W = self.P.to(self.L.device) @ L @ (U + self.S.detach().diag())
+        return W.to(device=device, dtype=torch.float32).contiguous()
+
+    def _weights(self, device, inverse: bool) -> Tensor:
+        key = (device, tuple((p.data_ptr(), p._version) for p in (self.L, self.S, self.U)), id(self.P))
+        if key != self._w_key:
+            self._w = self._assemble_W(device)
+            self._w_inv = None
+            self._w_key = key
+        if inverse:
+            if self._w_inv is None:
+                self._w_inv = torch.inverse(self._w).contiguous()
+            return self._w_inv
+        return self._w
+
+    def _run(self, x, inverse, accum):
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        _note_no_autograd(self, x)
+        W = self._weights(x.device, inverse)
+        y = torch.empty_like(x)
+        _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
+            x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
+        ld = self.S.detach().abs().log().sum().to(x.device)  # 0-dim, parameter-only
+        if inverse:
+            ld = -ld
+        if accum is not None:
+            accum += ld
+            return y, None
+        return y, ld
+
+
+class NormalizingFlow(nn.Module):
+    """Runs flows in order (forward) or reversed (inverse), summing log|det J| and keeping every
+    intermediate (flows/core.py:10-35).  Layers from this package accumulate ``log_det`` inside
+    their kernel; any other duck-typed flow is called by name and added like the reference does."""
+
+    def __init__(self, flows: Sequence[nn.Module]) -> None:
+        super().__init__()
+        self.flows = nn.ModuleList(flows)
+        # bench.py: set to a list to collect a (start, end) HIP event pair around every layer,
+        # recorded on the stream the kernels are launched on
+        self.layer_events: list | None = None
+
+    def _pass(self, x: Tensor, inverse: bool) -> tuple[list[Tensor], Tensor]:
+        log_det = torch.zeros(x.size(0), device=x.device)
+        seen = [x]
+        timed = self.layer_events is not None and x.is_cuda
+        for flow in (reversed(self.flows) if inverse else self.flows):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
+                x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
+            else:
+                x, ld = flow.inverse(x) if inverse else flow.forward(x)
+                log_det += ld
+            if timed:
+                e1.record()
+                self.layer_events.append((e0, e1))
+            seen.append(x)
+        return seen, log_det
+
+    def forward(self, z: Tensor) -> tuple[list[Tensor], Tensor]:  # z -> x
+        return self._pass(z, False)
+
+    def inverse(self, x: Tensor) -> tuple[list[Tensor], Tensor]:  # x -> z
+        return self._pass(x, True)
+
+
+class StandardNormal:
+    """N(0, I_dim) base distribution whose ``log_prob`` is the HIP epilogue kernel.
+
+    Equivalent to the ``MultivariateNormal(zeros(d), eye(d))`` the reference's tests and
+    notebooks pair with the flows (tests/test_flows.py:38)."""
+
+    def __init__(self, dim: int, device: torch.device | str = "cuda") -> None:
+        self.dim = int(dim)
+        self.device = torch.device(device)
+
+    def log_prob(self, z: Tensor) -> Tensor:
+        z = _device_input(z, "z")
+        lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
+            z.data_ptr(), None, lp.data_ptr(), None, z.shape[0], self.dim, _stream()))
+        return lp
+
+    def sample(self, sample_shape=torch.Size()) -> Tensor:
+        if isinstance(sample_shape, int):
+            sample_shape = (sample_shape,)
+        return torch.randn(*sample_shape, self.dim, device=self.device)
+
+
+class NormalizingFlowModel(NormalizingFlow):
+    """(base distribution, flows) pair (flows/core.py:38-55), plus a fused ``log_prob``."""
+
+    def __init__(self, base, flows: Sequence[nn.Module]) -> None:
+        super().__init__(flows)
+        self.base = base
+
+    def base_log_prob(self, x: Tensor) -> Tensor:
+        zs, _ = self.inverse(x)
+        return self.base.log_prob(zs[-1])
+
+    def sample(self, *num_samples: int) -> Tensor:
+        z = self.base.sample(*num_samples)
+        xs, _ = self.forward(z)
+        return xs[-1]
+
+    def log_prob(self, x: Tensor, return_sum: bool = False):
+        """log p(x) = log_det + base.log_prob(z) with ONE inverse pass (the reference's callers
+        run two, core.py:46-49 vs examples/half_moons.ipynb:183-184).  With a StandardNormal
+        base the epilogue kernel also produces the fp64 sum over rows."""
+        zs, log_det = self.inverse(x)
+        z = zs[-1]
+        if isinstance(self.base, StandardNormal):
+            lp = torch.empty_like(log_det)
+            total = torch.zeros(1, dtype=torch.float64, device=z.device) if return_sum else None
+            _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
+                z.data_ptr(), log_det.data_ptr(), lp.data_ptr(), _ptr(total), z.shape[0], z.shape[1],
+                _stream()))
+            return (lp, total) if return_sum else lp
+        lp = log_det + self.base.log_prob(z)
+        return (lp, lp.double().sum().reshape(1)) if return_sum else lp
