@@ -56,17 +56,25 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
     threads) on a bounded sample of the same workload.  Checker and baseline only."""
     from oracle import flow_oracle as O
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # Pick the ATen thread count the way a user of the reference would tune it on this host:
+    # the op sequence is many small ops, so "all cores" is rarely the fastest setting.
+    host = os.cpu_count() or 1
     probe = 1 << 14
-    x = x_sample_gpu[:probe].cpu()
+    xp = x_sample_gpu[:probe].cpu()
+    best_rate, cores = 0.0, 1
     with torch.no_grad():
-        O.mean_log_prob(x[:2048], layers)  # warm the thread pool
-        t0 = time.perf_counter()
-        O.mean_log_prob(x, layers)
-        dt = time.perf_counter() - t0
-    rate = probe / dt
-    rows = int(min(x_sample_gpu.shape[0], max(probe, 1 << int(max(14, (rate * budget_s)).bit_length() - 1))))
+        for n in sorted({c for c in (8, 16, 32, 64, host) if c <= host}):
+            torch.set_num_threads(n)
+            O.mean_log_prob(xp[:2048], layers)  # warm the pool
+            t0 = time.perf_counter()
+            O.mean_log_prob(xp, layers)
+            r = probe / (time.perf_counter() - t0)
+            if r > best_rate:
+                best_rate, cores = r, n
+            if probe / r > 3.0:  # this setting is already hopeless; larger pools only get worse
+                break
+    torch.set_num_threads(cores)
+    rows = int(min(x_sample_gpu.shape[0], max(probe, 1 << (int(best_rate * budget_s).bit_length() - 1))))
     x = x_sample_gpu[:rows].cpu()
     best = float("inf")
     mean = None
@@ -76,15 +84,17 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
             t0 = time.perf_counter()
             mean, _ = O.mean_log_prob(x, layers)
             best = min(best, time.perf_counter() - t0)
-            if time.perf_counter() - t_start > 2.5 * budget_s:
+            if time.perf_counter() - t_start > 2.0 * budget_s:
                 break
     info = {
         "value": rows / best,
         "unit": "samples/s",
-        "cores": torch.get_num_threads(),
+        "cores": cores,
+        "host_cores": host,
         "kind": "port",
         "sample": f"oracle (PyTorch-CPU restatement of the reference path), first {rows} rows of the "
-                  f"rank-0 batch, one inverse pass + base log-prob, best of <=3, {best:.3f} s",
+                  f"rank-0 batch, one inverse pass + base log-prob, best of <=3, {best:.3f} s, "
+                  f"{cores} ATen threads (fastest of 8/16/32/64/{host} on a probe)",
     }
     return info, mean, rows
 

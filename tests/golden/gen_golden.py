@@ -175,27 +175,39 @@ def g4_rqs_direct():
                 torch.from_numpy(D), inverse=inv, tail_bound=T)
             out[f"K{K}.out_{'inv' if inv else 'fwd'}"] = npy(y)
             out[f"K{K}.lad_{'inv' if inv else 'fwd'}"] = npy(lad)
+            y64, lad64 = ref_spline.unconstrained_RQS(
+                torch.from_numpy(v).double(), torch.from_numpy(W).double(), torch.from_numpy(H).double(),
+                torch.from_numpy(D).double(), inverse=inv, tail_bound=T)
+            out[f"K{K}.out64_{'inv' if inv else 'fwd'}"] = npy(y64)
+            out[f"K{K}.lad64_{'inv' if inv else 'fwd'}"] = npy(lad64)
     save("g4_rqs_direct", **out)
 
 
 # ----------------------------------------------------------------------------- G5
 def g5_nsf_cl_layer():
     out = {}
-    for dim, K, n_h, rows in ((32, 8, 8, 256), (32, 8, 16, 256), (2, 8, 16, 256), (6, 5, 8, 128)):
+    for dim, K, n_h, rows, gain in ((32, 8, 8, 256, 1.0), (32, 8, 16, 256, 1.0), (2, 8, 16, 256, 1.0),
+                                   (6, 5, 8, 128, 1.0), (32, 8, 8, 256, 2.0), (2, 8, 16, 256, 2.0)):
         seed = 500 + dim + n_h
         f = nf.NSF_CL(dim, K=K, B=3, n_h=n_h)
-        f.load_state_dict(recipes.nsf_cl_params(seed, dim, K, n_h))
+        f.load_state_dict(recipes.nsf_cl_params(seed, dim, K, n_h, gain=gain))
         z = recipes.gaussian(seed + 1, rows, dim, scale=1.4)
         z[0, :] = 3.0
         z[1, :] = -3.0
         z[2, 0] = 3.5  # one element outside, rest of the row inside
         z[3, :] = 5.0  # whole row outside
+        f64 = nf.NSF_CL(dim, K=K, B=3, n_h=n_h).double()
+        f64.load_state_dict({k: v.double() for k, v in f.state_dict().items()})
         with torch.no_grad():
             x_f, ld_f = f.forward(z)
             x_i, ld_i = f.inverse(z)
-        tag = f"d{dim}_K{K}_h{n_h}"
+            x_f64, ld_f64 = f64.forward(z.double())
+            x_i64, ld_i64 = f64.inverse(z.double())
+        tag = f"d{dim}_K{K}_h{n_h}" + ("" if gain == 1.0 else "_stress")
         out.update({f"{tag}.z": npy(z), f"{tag}.fwd": npy(x_f), f"{tag}.ld_fwd": npy(ld_f),
-                    f"{tag}.inv": npy(x_i), f"{tag}.ld_inv": npy(ld_i)})
+                    f"{tag}.inv": npy(x_i), f"{tag}.ld_inv": npy(ld_i),
+                    f"{tag}.fwd64": npy(x_f64).astype(np.float32), f"{tag}.ld_fwd64": npy(ld_f64).astype(np.float32),
+                    f"{tag}.inv64": npy(x_i64).astype(np.float32), f"{tag}.ld_inv64": npy(ld_i64).astype(np.float32)})
     save("g5_nsf_cl_layer", **out)
 
 
@@ -225,6 +237,30 @@ def g6_c3_stack():
         zs2, ld2 = model.inverse(x)  # now data-independent
         xs, ld_f = model.forward(x)
         shapes = [tuple(f.inverse(x)[1].shape) for f in flows[:3]]
+    # the same stack in float64 (ActNorm values copied from the fp32 run): the error budget
+    flows64 = []
+    for i in range(3):
+        an = nf.ActNormFlow(dim).double()
+        an.load_state_dict({"s": flows[3 * i].s.double(), "t": flows[3 * i].t.double()})
+        an.data_dep_init_done = True
+        gl = nf.Glow(dim).double()
+        gl.P = flows[3 * i + 1].P.double()
+        gl.load_state_dict({k: v.double() for k, v in flows[3 * i + 1].state_dict().items()})
+        sp = nf.NSF_CL(dim, K=8, B=3, n_h=8).double()
+        sp.load_state_dict({k: v.double() for k, v in flows[3 * i + 2].state_dict().items()})
+        flows64 += [an, gl, sp]
+    with torch.no_grad():
+        # NSF_CL/NormalizingFlow keep log_det in an fp32 buffer; sum the float64 terms here instead
+        def run64(xx, inverse):
+            ld = torch.zeros(rows, dtype=torch.float64)
+            for f in (reversed(flows64) if inverse else flows64):
+                xx, l1 = f.inverse(xx) if inverse else f.forward(xx)
+                ld = ld + l1.double()
+            return xx, ld
+        z64, ld64 = run64(x.double(), True)
+        x64, ldf64 = run64(x.double(), False)
+    out.update({"z_last64": npy(z64).astype(np.float32), "ld_inv64": npy(ld64).astype(np.float32),
+                "x_fwd_last64": npy(x64).astype(np.float32), "ld_fwd64": npy(ldf64).astype(np.float32)})
     out.update({"z_last_first_call": npy(zs[-1]), "ld_first_call": npy(ld),
                 "z_last": npy(zs2[-1]), "ld_inv": npy(ld2), "z_mid": npy(zs2[5]),
                 "x_fwd_last": npy(xs[-1]), "ld_fwd": npy(ld_f),

@@ -126,12 +126,13 @@ def test_rqs_too_many_bins_raises():
         O.unconstrained_rqs(v, W, W.clone(), torch.zeros(2, 1000), inverse=False, tail_bound=3.0)
 
 
-@pytest.mark.parametrize("cfg", [(32, 8, 8), (32, 8, 16), (2, 8, 16), (6, 5, 8)])
+@pytest.mark.parametrize("cfg", [(32, 8, 8, 1.0), (32, 8, 16, 1.0), (2, 8, 16, 1.0), (6, 5, 8, 1.0),
+                                 (32, 8, 8, 2.0), (2, 8, 16, 2.0)])
 def test_g5_nsf_cl_layer(golden, cfg):
-    dim, K, n_h = cfg
+    dim, K, n_h, gain = cfg
     fx = golden("g5_nsf_cl_layer")
-    tag = f"d{dim}_K{K}_h{n_h}"
-    sd = recipes.nsf_cl_params(500 + dim + n_h, dim, K, n_h)
+    tag = f"d{dim}_K{K}_h{n_h}" + ("" if gain == 1.0 else "_stress")
+    sd = recipes.nsf_cl_params(500 + dim + n_h, dim, K, n_h, gain=gain)
     z = t(fx[f"{tag}.z"])
     for inv, name in ((False, "fwd"), (True, "inv")):
         x, ld = O.nsf_cl(z, sd, K, 3.0, inverse=inv)

@@ -86,8 +86,6 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
-  const f32x4* A4_base = reinterpret_cast<const f32x4*>(lds) + lane;        // + 64 * group
-  const f32x4* B4_base = reinterpret_cast<const f32x4*>(lds + S::A_FLOATS) + q;  // + 4 * tile
 
   const int64_t n_tiles = (rows + 15) >> 4;
   for (int64_t tile = (int64_t)blockIdx.x * kAhfWaves + wave; tile < n_tiles;
@@ -115,9 +113,12 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     // the tile loop into VGPRs (2 waves/SIMD).  Re-reading them from LDS costs one
     // ds_read_b128 per four MFMAs and keeps the kernel at 8 waves/SIMD, which is what hides
     // the HBM latency here; making the base pointers opaque per tile blocks the hoist.
-    const f32x4* A4 = A4_base;
-    const f32x4* B4 = B4_base;
-    asm volatile("" : "+v"(A4), "+v"(B4));
+    // (the opaque value is an integer offset, not the pointer: an opaque pointer loses its LDS
+    // address space and turns every read into a flat_load that also waits on vmcnt.)
+    int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
+    asm volatile("" : "+v"(a_off), "+v"(b_off));
+    const f32x4* A4 = reinterpret_cast<const f32x4*>(lds + a_off);  // + 64 * group
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + b_off);  // + 4 * tile
 
     // ---- layer 1: [s;t] hidden (2*HID) <- cond (H)
     f32x4 h1[NT];

@@ -47,6 +47,10 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 template <bool DOUBLE, typename GetW, typename GetH, typename GetD>
 __device__ __forceinline__ void rqs_element(float v, int K, float T, bool inverse, GetW getW,
                                             GetH getH, GetD getD, float& out, float& lad) {
+// ATen evaluates the reference's formulas one op at a time, each rounded to fp32; keep the
+// same roundings (no fused multiply-add) so that ill-conditioned elements near a knot land
+// on the same side as the reference as often as possible.
+#pragma clang fp contract(off)
   const bool inside = (v >= -T) && (v <= T);  // NaN -> outside -> identity
   if (!inside) {
     out = v;
@@ -68,15 +72,17 @@ __device__ __forceinline__ void rqs_element(float v, int K, float T, bool invers
     sH += expf(getH(k) - mH);
   }
   // Second level max/sum (or the only level when !DOUBLE: m2 = max, s2 = sum above).
-  float m2W, m2H, s2W, s2H;
+  float m2W, m2H, s2W, s2H, rW = 1.f, rH = 1.f;
   if (DOUBLE) {
-    m2W = twoT * (1.f / sW);  // the max element has exp(0) = 1
-    m2H = twoT * (1.f / sH);
+    rW = 1.f / sW;  // ATen's softmax multiplies by the reciprocal of the sum
+    rH = 1.f / sH;
+    m2W = twoT * rW;  // the max element has exp(0) = 1
+    m2H = twoT * rH;
     s2W = 0.f;
     s2H = 0.f;
     for (int k = 0; k < K; ++k) {
-      s2W += expf(twoT * (expf(getW(k) - mW) / sW) - m2W);
-      s2H += expf(twoT * (expf(getH(k) - mH) / sH) - m2H);
+      s2W += expf(twoT * (expf(getW(k) - mW) * rW) - m2W);
+      s2H += expf(twoT * (expf(getH(k) - mH) * rH) - m2H);
     }
   } else {
     m2W = mW;
@@ -85,6 +91,7 @@ __device__ __forceinline__ void rqs_element(float v, int K, float T, bool invers
     s2H = sH;
   }
 
+  const float r2W = 1.f / s2W, r2H = 1.f / s2H;
   // stream over the bins: running cumsum for both axes, remember the selected bin
   float cw = 0.f, ch = 0.f;      // cumulative fractions
   float xk_prev = -T, yk_prev = -T;
@@ -93,11 +100,11 @@ __device__ __forceinline__ void rqs_element(float v, int K, float T, bool invers
   for (int k = 0; k < K; ++k) {
     float uW = getW(k), uH = getH(k);
     if (DOUBLE) {
-      uW = twoT * (expf(uW - mW) / sW);
-      uH = twoT * (expf(uH - mH) / sH);
+      uW = twoT * (expf(uW - mW) * rW);
+      uH = twoT * (expf(uH - mH) * rH);
     }
-    const float fw = kMinBin + c1 * (expf(uW - m2W) / s2W);
-    const float fh = kMinBin + c1 * (expf(uH - m2H) / s2H);
+    const float fw = kMinBin + c1 * (expf(uW - m2W) * r2W);
+    const float fh = kMinBin + c1 * (expf(uH - m2H) * r2H);
     cw += fw;
     ch += fh;
     const float xk_next = (k == K - 1) ? T : twoT * cw + (-T);

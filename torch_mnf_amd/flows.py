@@ -71,6 +71,11 @@ def _device_input(t: Tensor, what: str) -> Tensor:
     return t.detach().contiguous()
 
 
+def _empty_result(x: Tensor, accum: Tensor | None):
+    """rows == 0: nothing to launch (an empty tensor has no device pointer to hand over)."""
+    return torch.empty_like(x), (None if accum is not None else x.new_empty(0))
+
+
 _warned_autograd = False
 
 
@@ -105,7 +110,7 @@ class _HipFlow(nn.Module):
     def _image_index_host(self):  # -> ctypes int32 array or None
         return None
 
-    def _buffers(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
+    def _packed(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
         params = self._packed_params()
         if not params:
             return None, None
@@ -186,7 +191,9 @@ class AffineHalfFlow(_TwoWayFlow):
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         _note_no_autograd(self, x)
-        flat, image = self._buffers(x.device)
+        if x.shape[0] == 0:
+            return _empty_result(x, accum)
+        flat, image = self._packed(x.device)
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_half", _lib.load().mnf_affine_half(
@@ -231,7 +238,9 @@ class NSF_CL(_TwoWayFlow):
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         _note_no_autograd(self, x)
-        flat, image = self._buffers(x.device)
+        if x.shape[0] == 0:
+            return _empty_result(x, accum)
+        flat, image = self._packed(x.device)
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
@@ -294,12 +303,14 @@ class RNVP(_HipFlow):
         if z.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {z.shape[1]}")
         _note_no_autograd(self, z)
+        if z.shape[0] == 0:
+            return _empty_result(z, accum)
         if mask is None:
             mask = torch.bernoulli(0.5 * torch.ones_like(z))
         mask = _device_input(mask, "mask")
         if mask.shape != z.shape:
             raise ValueError("mask must have the shape of z")
-        flat, image = self._buffers(z.device)
+        flat, image = self._packed(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         _lib.check("mnf_rnvp", _lib.load().mnf_rnvp(
@@ -334,6 +345,9 @@ class AffineConstantFlow(_TwoWayFlow):
         _note_no_autograd(self, x)
         s = self.s.detach().to(x.device, torch.float32).contiguous()
         t = self.t.detach().to(x.device, torch.float32).contiguous()
+        if x.shape[0] == 0:
+            ld1 = (-s if inverse else s).sum(dim=1)
+            return torch.empty_like(x), (None if accum is not None else ld1)
         y = torch.empty_like(x)
         ld1 = torch.empty(1, dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_const", _lib.load().mnf_affine_const(
@@ -416,8 +430,9 @@ class Glow(_TwoWayFlow):
         _note_no_autograd(self, x)
         W = self._weights(x.device, inverse)
         y = torch.empty_like(x)
-        _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
-            x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
+        if x.shape[0] > 0:
+            _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
+                x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
         ld = self.S.detach().abs().log().sum().to(x.device)  # 0-dim, parameter-only
         if inverse:
             ld = -ld
@@ -478,6 +493,8 @@ class StandardNormal:
     def log_prob(self, z: Tensor) -> Tensor:
         z = _device_input(z, "z")
         lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        if z.shape[0] == 0:
+            return lp
         _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
             z.data_ptr(), None, lp.data_ptr(), None, z.shape[0], self.dim, _stream()))
         return lp
