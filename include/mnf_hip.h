@@ -12,7 +12,7 @@
  *   mnf_rnvp             RNVP.forward                           torch_mnf/flows/rnvp.py:25-39
  *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
  *   mnf_linear_rows      Glow.forward / .inverse (x @ W)        torch_mnf/flows/glow.py:26-37
- *   mnf_gauss_logprob    base.log_prob + the callers' mean      torch_mnf/flows/core.py:46-49,
+ *   mnf_gauss_logprob(_sq) base.log_prob + the callers' mean    torch_mnf/flows/core.py:46-49,
  *                                                               examples/half_moons.ipynb:183-186
  *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
  *   log_det accumulation NormalizingFlow.forward / .inverse     torch_mnf/flows/core.py:17-35
@@ -72,6 +72,15 @@ int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
                     int64_t rows, int dim, int parity, int inverse,
                     int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                     int force_generic, void* stream);
+/* Same layer, additionally writing y_sqnorm[r] = |y_r|^2 (rows,) so that the base log-prob of
+ * a standard-normal base needs no second pass over y.  Only the
+ * specialised kernel produces it: MNF_ERR_UNSUPPORTED otherwise (callers then run
+ * mnf_gauss_logprob on y). */
+int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
+                       const float* flat, const float* image,
+                       int64_t rows, int dim, int parity, int inverse,
+                       int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                       int force_generic, void* stream);
 /* 0 when the configuration has no specialised (MFMA) kernel. */
 int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden_host,
                                      int has_scale, int has_shift);
@@ -126,6 +135,10 @@ int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int 
  * sum_out (device double, may be NULL) += sum_r log_prob[r]; the caller zeroes it first. */
 int mnf_gauss_logprob(const float* z, const float* log_det, float* log_prob, double* sum_out,
                       int64_t rows, int dim, void* stream);
+
+/* The same from precomputed z_sqnorm[r] = |z_r|^2 (see mnf_affine_half_sq). */
+int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log_prob, double* sum_out,
+                         int64_t rows, int dim, void* stream);
 
 /* z0 = q0_mean + exp(q0_log_var)^(1/2) * eps   (rows, dim); mean, log_var: (dim,). */
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,

@@ -30,6 +30,8 @@ SIGNATURES = {
     "mnf_device_count": (c_int, []),
     "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
+    "mnf_affine_half_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                   c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
     "mnf_affine_half_image_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
     "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
@@ -50,6 +52,7 @@ SIGNATURES = {
                                  c_int, c_int, c_void_p]),
     "mnf_linear_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_gauss_logprob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_gauss_logprob_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 

@@ -38,6 +38,35 @@ namespace mnf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// On gfx950 the fp32 MFMA runs at the fp32 VALU rate and does NOT overlap with VALU work of
+// other waves on the same SIMD (measured: kernel time = 32 cycles per MFMA + 4 cycles per VALU
+// instruction, tools/ahf_microbench.hip), so every vector instruction in the tile loop costs
+// ~0.1 % of the layer.  The two helpers below exist to keep that count down.
+
+// LeakyReLU(0.2) = max(v, 0.2 v) in two instructions.  fmaxf() would add a canonicalising
+// v_max per MFMA output; the median of (v, 0.2 v, +inf) is the same value without it.
+__device__ __forceinline__ float leaky2(float v) {
+  return __builtin_amdgcn_fmed3f(v, kLeakySlope * v, __builtin_inff());
+}
+
+// exp(x) in six instructions, <= 1.5 ulp: x*log2(e) as a two-term product, v_exp_f32 on the
+// head, first-order correction for the tail.  Overflow gives +inf, underflow 0, NaN stays NaN
+// (same as expf; ocml's expf is about twice as long because of its explicit range checks).
+__device__ __forceinline__ float exp6(float x) {
+  const float c_hi = 1.44269502162933349609375f;    // fl32(log2 e)
+  const float c_lo = 1.925963033500011e-08f;        // log2 e - c_hi
+  const float ln2 = 0.693147182464599609375f;
+  const float t = x * c_hi;
+  const float err = __builtin_fmaf(x, c_hi, -t);
+  const float tl = __builtin_fmaf(x, c_lo, err);
+  const float e1 = __builtin_amdgcn_exp2f(t);
+  return e1 * __builtin_fmaf(tl, ln2, 1.0f);
+}
+
+// (ablation builds replace the MFMA by a pass-through of the accumulator)
+#define MNF_MFMA(a, b, c, x0, x1, x2) \
+  ((ABL == 1) ? (c) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), (x0), (x1), (x2)))
+
 template <int H, int HID>
 struct AhfShape {
   static_assert(H % 16 == 0, "conditioner width must be a multiple of 16");
@@ -64,12 +93,15 @@ struct AhfShape {
   static constexpr int IMAGE_FLOATS = A_FLOATS + N_BIAS_TILES * 16;
 };
 
-constexpr int kAhfWaves = 8;  // 512-thread workgroups
+constexpr int kAhfWaves = 4;  // 256-thread workgroups: one wave per SIMD, so residency moves in steps of one wave/SIMD
 
-template <int H, int HID, bool INV>
+// ABL != 0 only in tools/ahf_microbench.hip (ablation builds: 1 = no MFMA chain, 2 = no HBM
+// traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS); the library uses ABL = 0.
+template <int H, int HID, bool INV, bool PREFETCH, int ABL = 0>
 __global__ void __launch_bounds__(kAhfWaves * 64)
 ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
-                const float* __restrict__ image, int64_t rows, int parity, int accumulate) {
+                float* __restrict__ ysq, const float* __restrict__ image, int64_t rows, int parity,
+                int accumulate) {
   using S = AhfShape<H, HID>;
   constexpr int G = S::G, QN = S::QN, NQ = S::NQ, NT = S::NT;
   constexpr int dim = 2 * H;
@@ -87,23 +119,55 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   const int j = lane & 15, q = lane >> 4;
   const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
 
-  const int64_t n_tiles = (rows + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * kAhfWaves + wave; tile < n_tiles;
-       tile += (int64_t)gridDim.x * kAhfWaves) {
-    const int64_t row = tile * 16 + j;
-    const bool live = row < rows;
-    const int64_t rowc = live ? row : rows - 1;
-    const float* xr = x + rowc * dim;
-    float* yr = y + rowc * dim;
+  // tiles are counted in 32 bits (rows < 2^35); only the row offset is 64-bit
+  const int n_tiles = (int)((rows + 15) >> 4);
+  const int tile_stride = (int)gridDim.x * kAhfWaves;
+  int tile = (int)blockIdx.x * kAhfWaves + wave;
 
-    f32x4 cnd[G], act[G];
+  // rows past the end are clamped to the last row for loads and masked for stores
+  auto row_ptr = [&](int t) -> const float* {
+    if (ABL == 2) t = blockIdx.x * kAhfWaves + wave;  // ablation: stay on one cached tile
+    const int64_t r = (int64_t)t * 16 + j;
+    return x + (r < rows ? r : rows - 1) * dim + 4 * q;
+  };
+
+  f32x4 cnd[G], act[G];
+  if (PREFETCH && tile < n_tiles) {
+    const float* xr = row_ptr(tile);
 #pragma unroll
-    for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g + 4 * q);
+    for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
 #pragma unroll
-    for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g + 4 * q);
+    for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g);
+  }
+
+  for (; tile < n_tiles; tile += tile_stride) {
+    const int64_t row = (int64_t)tile * 16 + j;
+    bool live = row < rows;
+    if (ABL == 2) live = live && (cnd[0][0] == 1.2345e30f);  // ablation: never true, keeps the math alive
+    const int64_t rowc = live ? row : rows - 1;
+    float* yr = y + rowc * dim + 4 * q;
+    // PREFETCH: the next tile's rows are requested into the SAME registers as soon as their
+    // last reader of this tile has issued (cnd: after layer 1; act[m]: after output step m), so
+    // the loads fly under the remaining MFMA chain at no register cost.  One tile past the end
+    // re-reads the last tile: harmless, and keeps the loop branch-free.
+    const float* xn = PREFETCH ? row_ptr(tile + tile_stride < n_tiles ? tile + tile_stride : n_tiles - 1)
+                               : row_ptr(tile);
+    if (!PREFETCH) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xn + cond_off + 16 * g);
+#pragma unroll
+      for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * g);
+    }
     if (live) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g + 4 * q) = cnd[g];
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g) = cnd[g];
+    }
+    float ld = 0.f, sq = 0.f;
+    if (ysq) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = fmaf(cnd[g][r], cnd[g][r], sq);
     }
 
     int n = 0;       // MFMA sequence number (compile-time after unrolling)
@@ -128,15 +192,19 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     for (int c1 = 0; c1 < H / 4; ++c1) {
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
-        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-        h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
+        if ((n & 3) == 0 && (ABL != 4 || n == 0)) a4 = A4[64 * (n >> 2)];
+        h1[m] = MNF_MFMA(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
         ++n;
       }
+    }
+    if (PREFETCH) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xn + cond_off + 16 * g);
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h1[m][r] = leaky(h1[m][r]);
+      for (int r = 0; r < 4; ++r) h1[m][r] = leaky2(h1[m][r]);
 
     // ---- layers 2 and 3: block-diagonal (HID <- HID) per net
     f32x4 h2[NT];
@@ -147,8 +215,8 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
         if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
-          if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-          h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
+          if ((n & 3) == 0 && (ABL != 4 || n == 0)) a4 = A4[64 * (n >> 2)];
+          h2[m] = MNF_MFMA(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
           ++n;
         }
       }
@@ -156,7 +224,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h2[m][r] = leaky(h2[m][r]);
+      for (int r = 0; r < 4; ++r) h2[m][r] = leaky2(h2[m][r]);
 
     f32x4 h3[NT];
 #pragma unroll
@@ -166,8 +234,8 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
         if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
-          if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-          h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
+          if ((n & 3) == 0 && (ABL != 4 || n == 0)) a4 = A4[64 * (n >> 2)];
+          h3[m] = MNF_MFMA(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
           ++n;
         }
       }
@@ -175,36 +243,43 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h3[m][r] = leaky(h3[m][r]);
+      for (int r = 0; r < 4; ++r) h3[m][r] = leaky2(h3[m][r]);
 
     // ---- layer 4 + affine transform, 16 output dims per step
-    float ld = 0.f;
 #pragma unroll
     for (int m = 0; m < G; ++m) {
       f32x4 s4 = B4[4 * (btile++)];
       f32x4 t4 = B4[4 * (btile++)];
 #pragma unroll
       for (int c = 0; c < QN; ++c) {
-        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-        s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], s4, 0, 0, 0);
+        if ((n & 3) == 0 && (ABL != 4 || n == 0)) a4 = A4[64 * (n >> 2)];
+        s4 = MNF_MFMA(a4[n & 3], h3[c >> 2][c & 3], s4, 0, 0, 0);
         ++n;
-        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-        t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4, 0, 0, 0);
+        if ((n & 3) == 0 && (ABL != 4 || n == 0)) a4 = A4[64 * (n >> 2)];
+        t4 = MNF_MFMA(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4, 0, 0, 0);
         ++n;
       }
       f32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = expf(s4[r]);
-        o[r] = INV ? (act[m][r] - t4[r]) / e : e * act[m][r] + t4[r];
+        // inverse: (v - t) / exp(s) evaluated as (v - t) * exp(-s): one multiply instead of a
+        // ~10-instruction IEEE divide; same limits (0, inf, NaN) and <= 2 ulp from the quotient
+        const float e = (ABL == 3) ? s4[r] : exp6(INV ? -s4[r] : s4[r]);
+        o[r] = (ABL == 3) ? (act[m][r] - t4[r]) + e : INV ? (act[m][r] - t4[r]) * e : __builtin_fmaf(e, act[m][r], t4[r]);
         ld += s4[r];
+        sq = fmaf(o[r], o[r], sq);
       }
-      if (live) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m + 4 * q) = o;
+      if (live) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
+      if (PREFETCH) act[m] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * m);
     }
     if (log_det) {
       ld = sum_over_q(ld);
       if (INV) ld = -ld;
       if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+    if (ysq) {  // |y_row|^2 for the base log-prob epilogue: saves re-reading y (4*dim bytes/row)
+      sq = sum_over_q(sq);
+      if (live && q == 0) ysq[row] = sq;
     }
   }
 }
@@ -277,18 +352,32 @@ static void build_index(int32_t* idx) {
 }
 
 template <int H, int HID>
-static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                  int64_t rows, int parity, int inverse, hipStream_t stream) {
+static int launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+                  const float* image, int64_t rows, int parity, int inverse, hipStream_t stream) {
+  // Measured (tools/ahf_microbench.hip, d = 64, 6 workgroups/CU): 139.5 us without the in-place
+  // prefetch, 145 us with it -- six resident waves per SIMD already cover the HBM latency.
+  constexpr bool kPrefetch = false;
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kAhfWaves - 1) / kAhfWaves;
-  const int64_t cap = 256 * 4;  // persistent: 4 workgroups per CU
-  if (blocks > cap) blocks = cap;
+  // persistent grid: as many workgroups as are resident at once (registers and the LDS image
+  // bound it), each striding over the tiles
+  static const int resident = [] {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, ahf_mfma_kernel<H, HID, true, kPrefetch>, kAhfWaves * 64, 0) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    return per_cu * cus;
+  }();
+  if (blocks > resident) blocks = resident;
   if (inverse)
-    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true>), dim3((unsigned)blocks), dim3(kAhfWaves * 64), 0,
-                       stream, x, y, log_det, image, rows, parity, accumulate);
+    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true, kPrefetch>), dim3((unsigned)blocks),
+                       dim3(kAhfWaves * 64), 0, stream, x, y, log_det, ysq, image, rows, parity, accumulate);
   else
-    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false>), dim3((unsigned)blocks), dim3(kAhfWaves * 64), 0,
-                       stream, x, y, log_det, image, rows, parity, accumulate);
+    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false, kPrefetch>), dim3((unsigned)blocks),
+                       dim3(kAhfWaves * 64), 0, stream, x, y, log_det, ysq, image, rows, parity, accumulate);
   return check_launch();
 }
 
@@ -301,9 +390,9 @@ static bool uniform_hidden(int n_hidden, const int* hidden, int& hid) {
   return hidden[1] == hid && hidden[2] == hid;
 }
 
-int ahf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                    int64_t rows, int dim, int parity, int inverse, int n_hidden, const int* hidden,
-                    int has_scale, int has_shift, hipStream_t stream) {
+int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+                    const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
+                    const int* hidden, int has_scale, int has_shift, hipStream_t stream) {
   int hid = 0;
   if (!has_scale || !has_shift || !uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
@@ -311,7 +400,7 @@ int ahf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
     return MNF_ERR_UNSUPPORTED;  // float4 accesses need 16-byte aligned bases
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) \
-    return launch<HH, HD>(x, y, log_det, accumulate, image, rows, parity != 0, inverse != 0, stream);
+    return launch<HH, HD>(x, y, log_det, ysq, accumulate, image, rows, parity != 0, inverse != 0, stream);
   MNF_AHF_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

@@ -367,6 +367,34 @@ __global__ void __launch_bounds__(kThreads) gauss_logprob_kernel(const float* __
   }
 }
 
+// log-prob from the per-row |z|^2 the last coupling kernel already produced
+__global__ void __launch_bounds__(kThreads) gauss_logprob_sq_kernel(const float* __restrict__ zsq,
+                                                                    const float* __restrict__ log_det,
+                                                                    float* __restrict__ log_prob,
+                                                                    double* __restrict__ sum_out,
+                                                                    int64_t rows, int dim) {
+  __shared__ double wave_sums[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float cst = (float)dim * kHalfLog2Pi;
+  double local = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+    const float lp = (log_det ? log_det[r] : 0.f) + (-0.5f * zsq[r] - cst);
+    if (log_prob) log_prob[r] = lp;
+    local += (double)lp;
+  }
+  if (sum_out) {
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) wave_sums[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kThreads / 64; ++w) tot += wave_sums[w];
+      atomicAdd(sum_out, tot);
+    }
+  }
+}
+
 __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __restrict__ log_var,
                                  const float* __restrict__ eps, float* __restrict__ z0, int64_t n,
                                  int dim) {
@@ -485,15 +513,24 @@ int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden, in
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate, const float* flat,
                     const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
                     const int* hidden, int has_scale, int has_shift, int force_generic, void* stream) {
+  return mnf_affine_half_sq(x, y, log_det, nullptr, accumulate, flat, image, rows, dim, parity, inverse,
+                            n_hidden, hidden, has_scale, has_shift, force_generic, stream);
+}
+
+int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
+                       const float* flat, const float* image, int64_t rows, int dim, int parity,
+                       int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                       int force_generic, void* stream) {
   if (!x || !y || x == y || rows < 0 || dim < 2 || (dim & 1) || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if ((has_scale || has_shift) && !flat && !image) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (image && !force_generic) {
-    const int rc = ahf_mfma_launch(x, y, log_det, accumulate, image, rows, dim, parity, inverse,
+    const int rc = ahf_mfma_launch(x, y, log_det, y_sqnorm, accumulate, image, rows, dim, parity, inverse,
                                    n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
+  if (y_sqnorm) return MNF_ERR_UNSUPPORTED;  // only the specialised kernel emits |y|^2
   if ((has_scale || has_shift) && !flat) return MNF_ERR_INVALID_ARG;
 
   AhfArgs a;
@@ -695,6 +732,15 @@ int mnf_gauss_logprob(const float* z, const float* log_det, float* log_prob, dou
   if (rows == 0) return MNF_OK;
   hipLaunchKernelGGL(gauss_logprob_kernel, dim3(grid_for(rows, 16, 2048)), dim3(kThreads), 0,
                      (hipStream_t)stream, z, log_det, log_prob, sum_out, rows, dim);
+  return check_launch();
+}
+
+int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log_prob, double* sum_out,
+                         int64_t rows, int dim, void* stream) {
+  if (!z_sqnorm || rows < 0 || dim < 1 || (!log_prob && !sum_out)) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(gauss_logprob_sq_kernel, dim3(grid_for(rows, 256, 1024)), dim3(kThreads), 0,
+                     (hipStream_t)stream, z_sqnorm, log_det, log_prob, sum_out, rows, dim);
   return check_launch();
 }
 

@@ -186,7 +186,7 @@ class AffineHalfFlow(_TwoWayFlow):
             self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
         return idx
 
-    def _run(self, x, inverse, accum):
+    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
@@ -196,11 +196,15 @@ class AffineHalfFlow(_TwoWayFlow):
         flat, image = self._packed(x.device)
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        _lib.check("mnf_affine_half", _lib.load().mnf_affine_half(
-            x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
-            x.shape[0], self.dim, int(bool(self.parity)), int(inverse), len(self.h_sizes), self._hid,
-            int(self.scale), int(self.shift), int(self.force_generic), _stream()))
+        _lib.check("mnf_affine_half_sq", _lib.load().mnf_affine_half_sq(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), _ptr(flat),
+            _ptr(image), x.shape[0], self.dim, int(bool(self.parity)), int(inverse), len(self.h_sizes),
+            self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
+
+    def emits_sqnorm(self, device) -> bool:
+        """True when this layer's kernel can also write |y_row|^2 (the specialised kernel only)."""
+        return (not self.force_generic) and self._packed(device)[1] is not None
 
     def forward(self, z: Tensor, inverse: bool = False) -> tuple[Tensor, Tensor]:
         return self._run(z, inverse, None)
@@ -453,16 +457,24 @@ class NormalizingFlow(nn.Module):
         # bench.py: set to a list to collect a (start, end) HIP event pair around every layer,
         # recorded on the stream the kernels are launched on
         self.layer_events: list | None = None
+        self._last_sqnorm: Tensor | None = None
 
-    def _pass(self, x: Tensor, inverse: bool) -> tuple[list[Tensor], Tensor]:
+    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False):
         log_det = torch.zeros(x.size(0), device=x.device)
         seen = [x]
         timed = self.layer_events is not None and x.is_cuda
-        for flow in (reversed(self.flows) if inverse else self.flows):
+        order = list(reversed(self.flows)) if inverse else list(self.flows)
+        self._last_sqnorm = None
+        for i, flow in enumerate(order):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
+            if (want_sqnorm and i == len(order) - 1 and isinstance(flow, AffineHalfFlow) and x.is_cuda
+                    and x.shape[0] > 0 and flow.emits_sqnorm(x.device)):
+                # last layer also emits |z|^2 per row for the standard-normal epilogue
+                self._last_sqnorm = torch.empty(x.size(0), device=x.device)
+                x, _ = flow._run(x, inverse, log_det, self._last_sqnorm)
+            elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
                 x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
             else:
                 x, ld = flow.inverse(x) if inverse else flow.forward(x)
@@ -525,14 +537,22 @@ class NormalizingFlowModel(NormalizingFlow):
         """log p(x) = log_det + base.log_prob(z) with ONE inverse pass (the reference's callers
         run two, core.py:46-49 vs examples/half_moons.ipynb:183-184).  With a StandardNormal
         base the epilogue kernel also produces the fp64 sum over rows."""
-        zs, log_det = self.inverse(x)
+        std = isinstance(self.base, StandardNormal)
+        zs, log_det = self._pass(x, True, want_sqnorm=std)
         z = zs[-1]
-        if isinstance(self.base, StandardNormal):
+        if std:
             lp = torch.empty_like(log_det)
             total = torch.zeros(1, dtype=torch.float64, device=z.device) if return_sum else None
-            _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
-                z.data_ptr(), log_det.data_ptr(), lp.data_ptr(), _ptr(total), z.shape[0], z.shape[1],
-                _stream()))
+            if z.shape[0] == 0:
+                return (lp, total) if return_sum else lp
+            if self._last_sqnorm is not None:  # |z|^2 came out of the last coupling kernel
+                _lib.check("mnf_gauss_logprob_sq", _lib.load().mnf_gauss_logprob_sq(
+                    self._last_sqnorm.data_ptr(), log_det.data_ptr(), lp.data_ptr(), _ptr(total),
+                    z.shape[0], z.shape[1], _stream()))
+            else:
+                _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
+                    z.data_ptr(), log_det.data_ptr(), lp.data_ptr(), _ptr(total), z.shape[0], z.shape[1],
+                    _stream()))
             return (lp, total) if return_sum else lp
         lp = log_det + self.base.log_prob(z)
         return (lp, lp.double().sum().reshape(1)) if return_sum else lp
