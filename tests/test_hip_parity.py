@@ -356,6 +356,28 @@ def test_g7_rnvp(amd, golden, dim, generic):
     assert not torch.equal(x1, x2)
 
 
+def test_g8_mnf_linear_sample_z(amd, golden):
+    """MNFLinear(800, 50).sample_z(64) with the reference's captured noise and masks (row a14)."""
+    fx = golden("g8_sample_z")
+    layer = amd.MNFLinear(800, 50)
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(800 + i, 800, 50))
+    layer.load_state_dict({"q0_mean": t(fx["q0_mean"]), "q0_log_var": t(fx["q0_log_var"])}, strict=False)
+    layer.to(DEV)
+    masks = [unpack_mask(fx[f"mask{i}_bits"], 800).to(DEV) for i in range(2)]
+    z, ld = layer.sample_z(64, eps=cuda(fx["eps"]), masks=masks)
+    assert_close(z, fx["z"], RTOL, "z")
+    assert_close(ld, fx["log_det"], RTOL, "log_det")
+    # default path: noise and masks drawn on the device; shapes and finiteness
+    z2, ld2 = layer.sample_z(32)
+    assert z2.shape == (32, 800) and ld2.shape == (32,) and torch.isfinite(z2).all()
+    out = layer.forward(torch.randn(16, 800, device=DEV))
+    assert out.shape == (16, 50) and torch.isfinite(out).all()
+    assert torch.isfinite(layer.kl_div())
+    ref_keys = ["W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"]
+    assert list(layer.state_dict())[:9] == ref_keys
+
+
 # ------------------------------------------------------- contracts of the boundary
 def test_g9_log_det_shapes(amd, golden):
     fx = golden("g9_logdet_shapes")

@@ -8,6 +8,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 (The directory is ``torch_mnf_amd``: ``torch-mnf_amd`` is not an importable name.)
 """
 from . import _lib
+from .layers import MNFLinear
 from .flows import (
     MLP,
     ActNormFlow,
@@ -24,7 +25,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "rqs", "library_path",
+    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "rqs", "MNFLinear", "library_path",
 ]
 
 

@@ -1,0 +1,85 @@
+"""The MNF caller of the path: ``MNFLinear`` (torch_mnf/layers/mnf_linear.py:7-90).
+
+Only ``sample_z`` is on the hot path: it draws the multiplicative noise
+``z0 = q0_mean + sigma * eps`` for every row of the batch and pushes it through ``flow_q``
+(a stack of masked/gated ``RNVP`` layers) -- at MNF-LeNet's 512 images x 500 MC samples that is
+256,000 rows of 800 dims.  Both steps run in libmnf_hip.so.  The two GEMMs of ``forward`` and the
+closed-form KL terms of ``kl_div`` are the reference's own formulas on device tensors
+(stock PyTorch-ROCm); they are callers, not the path.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .flows import RNVP, NormalizingFlow, _stream
+
+
+class MNFLinear(nn.Module):
+    """Bayesian linear layer with multiplicative normalizing-flow noise.
+
+    Same constructor, parameter names and state_dict keys as the reference."""
+
+    def __init__(self, n_in: int, n_out: int, n_flows_q: int = 2, n_flows_r: int = 2, h_sizes=(50,)) -> None:
+        super().__init__()
+        self.n_in, self.n_out = int(n_in), int(n_out)
+        small = lambda *shape: 0.1 * torch.randn(*shape)            # noqa: E731
+        log_var = lambda *shape: -9 + 0.1 * torch.randn(*shape)     # noqa: E731
+        self.W_mean = nn.Parameter(small(n_out, n_in))
+        self.W_log_var = nn.Parameter(log_var(n_out, n_in))
+        self.b_mean = nn.Parameter(torch.zeros(n_out))
+        self.b_log_var = nn.Parameter(log_var(n_out))
+        self.q0_mean = nn.Parameter(small(n_in))
+        self.q0_log_var = nn.Parameter(log_var(n_in))
+        self.r0_c = nn.Parameter(small(n_in))
+        self.r0_b1 = nn.Parameter(small(n_in))
+        self.r0_b2 = nn.Parameter(small(n_in))
+        self.flow_q = NormalizingFlow([RNVP(n_in, h_sizes=h_sizes) for _ in range(n_flows_q)])
+        self.flow_r = NormalizingFlow([RNVP(n_in, h_sizes=h_sizes) for _ in range(n_flows_r)])
+
+    # ------------------------------------------------------------------ hot path
+    def sample_z(self, batch_size: int = 1, eps: Tensor | None = None, masks=None) -> tuple[Tensor, Tensor]:
+        """(mnf_linear.py:58-64).  ``eps`` (batch, n_in) and ``masks`` (one per flow_q layer) may be
+        injected for reproducible runs; by default both are drawn on the device."""
+        dev = self.q0_mean.device
+        if eps is None:
+            eps = torch.randn(batch_size, self.n_in, device=dev)
+        eps = eps.to(dev, torch.float32).contiguous()
+        z0 = torch.empty_like(eps)
+        if eps.shape[0] > 0:
+            _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
+                self.q0_mean.detach().contiguous().data_ptr(), self.q0_log_var.detach().contiguous().data_ptr(),
+                eps.data_ptr(), z0.data_ptr(), eps.shape[0], self.n_in, _stream()))
+        if masks is None:
+            zs, log_det = self.flow_q.forward(z0)
+        else:  # same loop as NormalizingFlow.forward with the masks handed to each RNVP
+            log_det = torch.zeros(z0.shape[0], device=dev)
+            zs = [z0]
+            for flow, m in zip(self.flow_q.flows, masks):
+                z, _ = flow._run(zs[-1], False, log_det, m)
+                zs.append(z)
+        return zs[-1], log_det.squeeze()
+
+    # ------------------------------------------------------------------ callers (stock PyTorch-ROCm)
+    def forward(self, x: Tensor) -> Tensor:  # algorithm 1 of the MNF paper; mnf_linear.py:46-56
+        z, _ = self.sample_z(x.size(0))
+        mean = (x * z) @ self.W_mean.T + self.b_mean
+        var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
+        return mean + var.sqrt() * torch.randn_like(var)
+
+    def kl_div(self) -> Tensor:  # mnf_linear.py:66-90
+        z, log_det_q = self.sample_z()
+        W_mean = z * self.W_mean
+        W_var = self.W_log_var.exp()
+        weight = W_mean + W_var.sqrt() * torch.randn_like(W_var)
+        kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean.pow(2) - 1)
+        kl_b = 0.5 * torch.sum(-self.b_log_var + self.b_log_var.exp() + self.b_mean.pow(2) - 1)
+        log_q = -log_det_q - 0.5 * self.q0_log_var.sum()
+        act = torch.tanh(self.r0_c @ weight.T)
+        mean_r = torch.outer(self.r0_b1, act).mean(1)       # eq. (9)
+        log_var_r = torch.outer(self.r0_b2, act).mean(1)    # eq. (10)
+        zs, log_det_r = self.flow_r.forward(z)
+        (log_det_r,) = log_det_r                            # relies on shape (1,), as the reference does
+        log_r = log_det_r + 0.5 * torch.sum(-log_var_r.exp() * (zs[-1] - mean_r).pow(2) + log_var_r)
+        return kl_W + kl_b + log_q - log_r
