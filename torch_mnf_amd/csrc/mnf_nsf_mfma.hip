@@ -1,15 +1,443 @@
-// NSF_CL specialised kernel (placeholder until the MFMA spline kernel lands: every shape
-// reports "unsupported", so mnf_nsf_cl runs the generic kernel).
+// NSF_CL (neural-spline coupling layer) with the conditioner on the fp32 matrix cores and the
+// rational-quadratic spline evaluated out of accumulator registers, gfx950.
+//
+// One wave owns 16 rows; lane (j = lane & 15, q = lane >> 4) holds, as float4s, the elements
+// {16 gg + 4 q + g'} of both halves of row j.  The conditioner MLP(H, NH, NH, NH, (3K-1) H) runs
+// transposed on v_mfma_f32_16x16x4_f32 exactly like the AffineHalfFlow kernel (accumulator
+// register r of a tile is the next layer's K-step operand; bias = initial accumulator).  Its
+// last layer is arranged so that the tile for "slot" s = (gg, g') and parameter block kb puts
+// parameter 4 kb + r of element 16 gg + 4 q + g' of row j into register r of lane (j, q):
+// after ceil((3K-1)/4) tiles a lane owns all 3K-1 spline parameters of one of ITS OWN elements,
+// and evaluates the spline on it with every index a compile-time constant -- no LDS traffic for
+// parameters, no cross-lane movement, all 64 lanes busy in the transcendental part.
+//
+// The spline reproduces the reference's double normalisation and knot construction
+// (spline_flow.py:254-256, :95-113); see rqs_regs below.  This kernel is VALU/transcendental
+// bound by construction (~36 v_exp per element at K = 8): SURVEY.md 8d.
+#include <hip/hip_runtime.h>
+
+#include "mnf_device.h"
 #include "mnf_host.h"
 
 namespace mnf {
-int nsf_mfma_launch(const float*, float*, float*, int, const float*, int64_t, int, int, float, int, int,
-                    const int*, hipStream_t) {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int NH, int K>
+struct NsfShape {
+  static_assert(H % 16 == 0 && NH % 4 == 0 && K >= 2, "unsupported NSF_CL shape");
+  static constexpr int G = H / 16;            // float4 groups per half row
+  static constexpr int QH = NH / 4;           // K-steps (quads) of a hidden layer
+  static constexpr int NTH = (QH + 3) / 4;    // 16-row tiles of a hidden layer
+  static constexpr int P = 3 * K - 1;         // spline parameters per element
+  static constexpr int NB = (P + 3) / 4;      // parameter blocks (tiles) per slot
+  static constexpr int S = H / 4;             // slots = elements per lane per half
+  static constexpr int N_L1 = (H / 4) * NTH;
+  static constexpr int N_L23 = QH * NTH;
+  static constexpr int N_L4 = S * NB * QH;
+  static constexpr int N_MFMA = N_L1 + 2 * N_L23 + N_L4;
+  static constexpr int A_FLOATS = ((N_MFMA + 3) / 4) * 256;
+  static constexpr int BIAS_TILES = 3 * NTH + S * NB;
+  static constexpr int NET_FLOATS = A_FLOATS + BIAS_TILES * 16;
+  static constexpr int IMAGE_FLOATS = 2 * NET_FLOATS;  // f1 then f2
+};
+
+// exp for softmax terms (argument <= 0 after the max is subtracted): v_exp_f32 on x*log2(e).
+// Relative error ~ |x| * 4e-8, and a term's weight in the sum is exp(x) itself, so the error
+// it contributes to a normalised fraction is far below one ulp.
+__device__ __forceinline__ float exp_sm(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+// softplus(x) = max(x, 0) + log(1 + exp(-|x|)); threshold 20 as F.softplus
+__device__ __forceinline__ float softplus_fast(float x) {
+  const float t = log_fast(1.f + exp_sm(-__builtin_fabsf(x)));
+  return x > 20.f ? x : __builtin_fmaxf(x, 0.f) + t;
+}
+
+// K+1 knots on [-T, T] from K raw (first-level) parameters: 2T*softmax -> softmax again ->
+// 1e-3 + (1 - 1e-3 K) p -> sequential cumsum -> 2T c - T -> ends forced (spline_flow.py:254-255,
+// :95-101).  u[] is consumed.
+template <int K>
+__device__ __forceinline__ void knots_from_raw(const float (&u)[K], float T, float (&knot)[K + 1]) {
+  const float twoT = 2.f * T;
+  const float c1 = 1.f - kMinBin * (float)K;
+  float m = u[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) m = __builtin_fmaxf(m, u[k]);
+  float e[K];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    e[k] = exp_sm(u[k] - m);
+    s += e[k];
+  }
+  const float r = rcp_fast(s);
+  const float m2 = twoT * r;  // second-level max: the max element has e = 1
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    e[k] = exp_sm(twoT * (e[k] * r) - m2);
+    s2 += e[k];
+  }
+  const float r2 = rcp_fast(s2);
+  float c = 0.f;
+  knot[0] = -T;
+#pragma unroll
+  for (int k = 0; k < K - 1; ++k) {
+    c += kMinBin + c1 * (e[k] * r2);
+    knot[k + 1] = twoT * c - T;
+  }
+  knot[K] = T;
+}
+
+// Spline for one element with all 3K-1 raw parameters in registers: p[0..K) widths, p[K..2K)
+// heights, p[2K..3K-1) derivatives.  Same maths as rqs_element<true> (mnf_device.h).
+template <int K, bool INV, int NP>
+__device__ __forceinline__ void rqs_regs(float v, float T, const float (&p)[NP], float& out, float& lad) {
+  const bool inside = (v >= -T) && (v <= T);  // NaN -> outside -> identity
+  float uw[K], uh[K], xk[K + 1], yk[K + 1];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    uw[k] = p[k];
+    uh[k] = p[K + k];
+  }
+  knots_from_raw<K>(uw, T, xk);
+  knots_from_raw<K>(uh, T, yk);
+  // bin = count(v >= knot) - 1 over the K+1 knots (last one nudged by 1e-6): the last k with
+  // v >= knot_k.  Select the bin's quantities with compile-time indices.
+  const float vs = inside ? v : 0.f;
+  float x_k = xk[0], x_k1 = xk[1], y_k = yk[0], y_k1 = yk[1];
+  // raw derivative parameters at the bin's two knots: D[bin-1] and D[bin]; the outermost knots
+  // carry the edge constant instead (spline_flow.py:46-49)
+  float r0 = 0.f, r1 = p[2 * K];
+  bool bin0 = true, binlast = false;
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool hit = vs >= (INV ? yk[k] : xk[k]);  // knots increase: hits are a prefix of k
+    x_k = hit ? xk[k] : x_k;
+    x_k1 = hit ? xk[k + 1] : x_k1;
+    y_k = hit ? yk[k] : y_k;
+    y_k1 = hit ? yk[k + 1] : y_k1;
+    r0 = hit ? p[2 * K + k - 1] : r0;
+    if (k < K - 1) r1 = hit ? p[2 * K + k] : r1;
+    if (k == 1) bin0 = !hit;
+    if (k == K - 1) binlast = hit;
+  }
+  // first-level softplus for interior knots (:256), then 1e-3 + softplus(padded value) (:104)
+  const float dk_in = bin0 ? kEdgeDerivConst : softplus_fast(r0);
+  const float dk1_in = binlast ? kEdgeDerivConst : softplus_fast(r1);
+  const float d_k = kMinDeriv + softplus_fast(dk_in);
+  const float d_k1 = kMinDeriv + softplus_fast(dk1_in);
+
+  const float w_k = x_k1 - x_k, h_k = y_k1 - y_k;
+  const float rw = rcp_fast(w_k);
+  const float delta = h_k * rw;
+  float o, l;
+  if (INV) {
+    const float dy = vs - y_k;
+    const float curv = d_k + d_k1 - 2.f * delta;
+    const float a = dy * curv + h_k * (delta - d_k);
+    const float b = h_k * d_k - dy * curv;
+    const float c = -delta * dy;
+    const float disc = b * b - 4.f * a * c;
+    const float root = (2.f * c) * rcp_fast(-b - __builtin_amdgcn_sqrtf(disc));
+    o = root * w_k + x_k;
+    const float tomt = root * (1.f - root);
+    const float denom = delta + curv * tomt;
+    const float omr = 1.f - root;
+    const float dnum = (delta * delta) * (d_k1 * (root * root) + 2.f * delta * tomt + d_k * (omr * omr));
+    l = 2.f * log_fast(denom) - log_fast(dnum);
+  } else {
+    const float theta = (vs - x_k) * rw;
+    const float tomt = theta * (1.f - theta);
+    const float numer = h_k * (delta * (theta * theta) + d_k * tomt);
+    const float denom = delta + (d_k + d_k1 - 2.f * delta) * tomt;
+    o = y_k + numer * rcp_fast(denom);
+    const float omt = 1.f - theta;
+    const float dnum = (delta * delta) * (d_k1 * (theta * theta) + 2.f * delta * tomt + d_k * (omt * omt));
+    l = log_fast(dnum) - 2.f * log_fast(denom);
+  }
+  out = inside ? o : v;
+  lad = inside ? l : 0.f;
+}
+
+constexpr int kNsfWaves = 4;
+
+// One half-step: params = net(cond); act <- spline(act; params); returns this lane's sum of
+// log-derivatives over its S elements.
+template <int H, int NH, int K, bool INV>
+__device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, int q, const f32x4 (&cond)[H / 16],
+                                               f32x4 (&act)[H / 16], float T) {
+  using S_ = NsfShape<H, NH, K>;
+  constexpr int G = S_::G, QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
+  int a_off = lane * 4, b_off = S_::A_FLOATS + q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop (see mnf_ahf_mfma.hip)
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(lds_net + a_off);
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(lds_net + b_off);
+  int n = 0, bt = 0;
+  f32x4 a4;
+
+  f32x4 h1[NTH];
+#pragma unroll
+  for (int m = 0; m < NTH; ++m) h1[m] = B4[4 * (bt++)];
+#pragma unroll
+  for (int c1 = 0; c1 < H / 4; ++c1)
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cond[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
+      ++n;
+    }
+  f32x4 h2[NTH], h3[NTH];
+#pragma unroll
+  for (int m = 0; m < NTH; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[m][r] = __builtin_fmaxf(h1[m][r], kLeakySlope * h1[m][r]);
+    h2[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < QH; ++c)
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+  for (int m = 0; m < NTH; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[m][r] = __builtin_fmaxf(h2[m][r], kLeakySlope * h2[m][r]);
+    h3[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < QH; ++c)
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+  for (int m = 0; m < NTH; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h3[m][r] = __builtin_fmaxf(h3[m][r], kLeakySlope * h3[m][r]);
+
+  float lad_sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    f32x4 prm[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) prm[kb] = B4[4 * (bt++)];
+#pragma unroll
+    for (int c = 0; c < QH; ++c)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        prm[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], prm[kb], 0, 0, 0);
+        ++n;
+      }
+    float p[4 * NB];
+#pragma unroll
+    for (int i = 0; i < 4 * NB; ++i) p[i] = prm[i >> 2][i & 3];
+    float o, l;
+    rqs_regs<K, INV, 4 * NB>(act[s >> 2][s & 3], T, p, o, l);
+    act[s >> 2][s & 3] = o;
+    lad_sum += l;
+  }
+  (void)P;
+  return lad_sum;
+}
+
+template <int H, int NH, int K, bool INV>
+__global__ void __launch_bounds__(kNsfWaves * 64)
+nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
+                const float* __restrict__ image, int64_t rows, float T, int accumulate) {
+  using S_ = NsfShape<H, NH, K>;
+  constexpr int G = S_::G, dim = 2 * H;
+  static_assert(G >= 1, "");
+  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS];
+  {
+    const float4* src = reinterpret_cast<const float4*>(image);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < S_::IMAGE_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* f1 = lds;
+  const float* f2 = lds + S_::NET_FLOATS;
+
+  const int n_tiles = (int)((rows + 15) >> 4);
+  for (int tile = (int)blockIdx.x * kNsfWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kNsfWaves) {
+    const int64_t row = (int64_t)tile * 16 + j;
+    const bool live = row < rows;
+    const int64_t rowc = live ? row : rows - 1;
+    const float* xr = x + rowc * dim + 4 * q;
+    float* yr = y + rowc * dim + 4 * q;
+    f32x4 lo[G], up[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+    float ld;
+    if (!INV) {  // f1(lower) moves upper, then f2(upper') moves lower (spline_flow.py:249-266)
+      ld = nsf_half_step<H, NH, K, false>(f1, lane, q, lo, up, T);
+      ld += nsf_half_step<H, NH, K, false>(f2, lane, q, up, lo, T);
+    } else {     // (:268-285)
+      ld = nsf_half_step<H, NH, K, true>(f2, lane, q, up, lo, T);
+      ld += nsf_half_step<H, NH, K, true>(f1, lane, q, lo, up, T);
+    }
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = up[g];
+    }
+    if (log_det) {
+      ld = sum_over_q(ld);
+      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host: image index table
+template <int H, int NH, int K>
+static void build_index(int32_t* idx) {
+  using S_ = NsfShape<H, NH, K>;
+  constexpr int QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
+  int sizes[5] = {H, NH, NH, NH, P * H};
+  NetDesc net[2];
+  int64_t off = fill_net(net[0], 5, sizes, 0);
+  fill_net(net[1], 5, sizes, off);
+  for (int64_t i = 0; i < S_::IMAGE_FLOATS; ++i) idx[i] = -1;
+  auto unit_of = [&](int m, int i) { return 16 * m + 4 * (i & 3) + (i >> 2); };  // hidden unit of acc row i
+  for (int nn = 0; nn < 2; ++nn) {
+    int32_t* A = idx + (int64_t)nn * S_::NET_FLOATS;
+    int32_t* B = A + S_::A_FLOATS;
+    int n = 0, bt = 0;
+    auto put = [&](int lane, int32_t src) { A[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
+    for (int m = 0; m < NTH; ++m, ++bt)
+      for (int i = 0; i < 16; ++i)
+        if (unit_of(m, i) < NH) B[bt * 16 + i] = net[nn].b_off[0] + unit_of(m, i);
+    for (int c1 = 0; c1 < H / 4; ++c1) {
+      const int g = c1 >> 2, e = c1 & 3;
+      for (int m = 0; m < NTH; ++m) {
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
+          if (u < NH) put(lane, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
+        }
+        ++n;
+      }
+    }
+    for (int l = 1; l <= 2; ++l) {
+      for (int m = 0; m < NTH; ++m, ++bt)
+        for (int i = 0; i < 16; ++i)
+          if (unit_of(m, i) < NH) B[bt * 16 + i] = net[nn].b_off[l] + unit_of(m, i);
+      for (int c = 0; c < QH; ++c)
+        for (int m = 0; m < NTH; ++m) {
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
+            if (u < NH) put(lane, net[nn].w_off[l] + u * NH + 4 * c + kq);
+          }
+          ++n;
+        }
+    }
+    for (int s = 0; s < SL; ++s) {
+      // accumulator row i = 4 q' + r of tile (s, kb): element 16 (s/4) + 4 q' + (s%4), parameter 4 kb + r
+      auto out_of = [&](int kb, int i) {
+        const int elem = 16 * (s >> 2) + 4 * (i >> 2) + (s & 3), prm = 4 * kb + (i & 3);
+        return prm < P ? elem * P + prm : -1;
+      };
+      for (int kb = 0; kb < NB; ++kb, ++bt)
+        for (int i = 0; i < 16; ++i)
+          if (out_of(kb, i) >= 0) B[bt * 16 + i] = net[nn].b_off[3] + out_of(kb, i);
+      for (int c = 0; c < QH; ++c)
+        for (int kb = 0; kb < NB; ++kb) {
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, o = out_of(kb, i);
+            if (o >= 0) put(lane, net[nn].w_off[3] + o * NH + 4 * c + kq);
+          }
+          ++n;
+        }
+    }
+  }
+}
+
+template <int H, int NH, int K>
+static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
+                  float T, int inverse, hipStream_t stream) {
+  const int64_t n_tiles = (rows + 15) / 16;
+  int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
+  static const int resident = [] {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsf_mfma_kernel<H, NH, K, true>, kNsfWaves * 64,
+                                                     0) != hipSuccess || per_cu < 1)
+      per_cu = 2;
+    return per_cu * cus;
+  }();
+  if (blocks > resident) blocks = resident;
+  if (inverse)
+    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true>), dim3((unsigned)blocks), dim3(kNsfWaves * 64), 0, stream,
+                       x, y, log_det, image, rows, T, accumulate);
+  else
+    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false>), dim3((unsigned)blocks), dim3(kNsfWaves * 64), 0, stream,
+                       x, y, log_det, image, rows, T, accumulate);
+  return check_launch();
+}
+
+// (H, NH, K) triples with an instantiated kernel
+#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8)
+
+static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
+  if (n_hidden != 3) return false;
+  nh = hidden[0];
+  return hidden[1] == nh && hidden[2] == nh;
+}
+
+int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
+                    int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
+                    hipStream_t stream) {
+  int nh = 0;
+  if (!uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+#define X(HH, NHH, KK) \
+  if (dim == 2 * HH && nh == NHH && K == KK) \
+    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream);
+  MNF_NSF_SHAPES(X)
+#undef X
   return MNF_ERR_UNSUPPORTED;
 }
+
 }  // namespace mnf
 
 extern "C" {
-int64_t mnf_nsf_cl_image_floats(int, int, int, const int*) { return 0; }
-int mnf_nsf_cl_image_index(int, int, int, const int*, int32_t*) { return MNF_ERR_UNSUPPORTED; }
+
+int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden) {
+  int nh = 0;
+  if (!mnf::hidden_ok(n_hidden, hidden) || !mnf::uniform_hidden3(n_hidden, hidden, nh)) return 0;
+#define X(HH, NHH, KK) \
+  if (dim == 2 * HH && nh == NHH && K == KK) return mnf::NsfShape<HH, NHH, KK>::IMAGE_FLOATS;
+  MNF_NSF_SHAPES(X)
+#undef X
+  return 0;
 }
+
+int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden, int32_t* idx_host) {
+  int nh = 0;
+  if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+#define X(HH, NHH, KK)                            \
+  if (dim == 2 * HH && nh == NHH && K == KK) {    \
+    mnf::build_index<HH, NHH, KK>(idx_host);      \
+    return MNF_OK;                                \
+  }
+  MNF_NSF_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"
