@@ -30,13 +30,14 @@ static float run(const float* x, float* y, float* ld, const float* img, int64_t 
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int blocks = 256 * blocks_per_cu;
+  const int acc = WAVES_CAP ? 0 : 1;  // (template slot reused: 1 = run with accumulate = 0)
   for (int i = 0; i < 3; ++i)
     hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(kAhfWaves * 64), 0, 0, x, y, ld,
-                       nullptr, img, rows, 0, 1);
+                       nullptr, img, rows, 0, acc);
   hipEventRecord(e0);
   for (int i = 0; i < iters; ++i)
     hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(kAhfWaves * 64), 0, 0, x, y, ld,
-                       nullptr, img, rows, 0, 1);
+                       nullptr, img, rows, 0, acc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -58,17 +59,30 @@ int main() {
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(img, hi.data(), hi.size() * 4, hipMemcpyHostToDevice);
   hipMemset(ld, 0, rows * 4);
-  int occ = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ahf_mfma_kernel<32, 24, true, true, 0>, kAhfWaves * 64, 0);
-  printf("occupancy (prefetch build): %d blocks/CU of %d waves\n", occ, kAhfWaves);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ahf_mfma_kernel<32, 24, true, false, 0>, kAhfWaves * 64, 0);
-  printf("occupancy (no-prefetch build): %d blocks/CU\n", occ);
-  for (int bpc : {2, 3, 4, 5, 6, 8}) {
-    printf("blocks/CU %d | full pf %.1f  nopf %.1f | noMFMA pf %.1f nopf %.1f | noHBM pf %.1f nopf %.1f | noExpDiv pf %.1f | noLDS pf %.1f  [us]\n", bpc,
-           run<true, 0, 0>(x, y, ld, img, rows, bpc, 20), run<false, 0, 0>(x, y, ld, img, rows, bpc, 20),
-           run<true, 1, 0>(x, y, ld, img, rows, bpc, 20), run<false, 1, 0>(x, y, ld, img, rows, bpc, 20),
-           run<true, 2, 0>(x, y, ld, img, rows, bpc, 20), run<false, 2, 0>(x, y, ld, img, rows, bpc, 20),
-           run<true, 3, 0>(x, y, ld, img, rows, bpc, 20), run<true, 4, 0>(x, y, ld, img, rows, bpc, 20));
+  // interleaved rounds in one process (rule: never rank variants from separate or one-shot runs)
+  struct V { const char* name; float (*fn)(const float*, float*, float*, const float*, int64_t, int, int); };
+  const V vs[] = {
+      {"full", run<false, 0, 0>},          {"full+prefetch", run<true, 0, 0>},
+      {"accumulate=0", run<false, 0, 1>},  {"no-logdet-rmw", run<false, 7, 0>},
+      {"no-cnd-store", run<false, 8, 0>},  {"no-act-store", run<false, 9, 0>},
+      {"no-stores", run<false, 6, 0>},     {"compute-only", run<false, 2, 0>},
+      {"copy-only", run<false, 5, 0>},     {"no-mfma", run<false, 1, 0>},
+      {"no-exp", run<false, 3, 0>},        {"no-lds-reads", run<false, 4, 0>},
+      {"contiguous-io", run<false, 10, 0>},
+  };
+  const int nv = sizeof(vs) / sizeof(vs[0]);
+  for (int bpc : {4, 6}) {
+    float best[32], sum[32];
+    for (int v = 0; v < nv; ++v) { best[v] = 1e9f; sum[v] = 0.f; }
+    const int rounds = 5;
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < nv; ++v) {
+        const float t = vs[v].fn(x, y, ld, img, rows, bpc, 10);
+        best[v] = t < best[v] ? t : best[v];
+        sum[v] += t;
+      }
+    printf("== %d workgroups/CU (us per launch: min / mean of %d interleaved rounds)\n", bpc, rounds);
+    for (int v = 0; v < nv; ++v) printf("  %-16s %7.1f / %7.1f\n", vs[v].name, best[v], sum[v] / rounds);
   }
   return 0;
 }

@@ -65,7 +65,7 @@ __device__ __forceinline__ float exp6(float x) {
 
 // (ablation builds replace the MFMA by a pass-through of the accumulator)
 #define MNF_MFMA(a, b, c, x0, x1, x2) \
-  ((ABL == 1) ? (c) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), (x0), (x1), (x2)))
+  ((ABL == 1 || ABL == 5) ? (c) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), (x0), (x1), (x2)))
 
 template <int H, int HID>
 struct AhfShape {
@@ -96,7 +96,8 @@ struct AhfShape {
 constexpr int kAhfWaves = 4;  // 256-thread workgroups: one wave per SIMD, so residency moves in steps of one wave/SIMD
 
 // ABL != 0 only in tools/ahf_microbench.hip (ablation builds: 1 = no MFMA chain, 2 = no HBM
-// traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS); the library uses ABL = 0.
+// traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS, 5 = copy only, 6 = no stores);
+// the library uses ABL = 0.
 template <int H, int HID, bool INV, bool PREFETCH, int ABL = 0>
 __global__ void __launch_bounds__(kAhfWaves * 64)
 ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
@@ -128,6 +129,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   auto row_ptr = [&](int t) -> const float* {
     if (ABL == 2) t = blockIdx.x * kAhfWaves + wave;  // ablation: stay on one cached tile
     const int64_t r = (int64_t)t * 16 + j;
+    if (ABL == 10) return x + (int64_t)t * 16 * dim + lane * 4 - cond_off;  // ablation: contiguous 1-KiB accesses (wrong data)
     return x + (r < rows ? r : rows - 1) * dim + 4 * q;
   };
 
@@ -143,9 +145,10 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   for (; tile < n_tiles; tile += tile_stride) {
     const int64_t row = (int64_t)tile * 16 + j;
     bool live = row < rows;
-    if (ABL == 2) live = live && (cnd[0][0] == 1.2345e30f);  // ablation: never true, keeps the math alive
+    if (ABL == 2 || ABL == 6) live = live && (cnd[0][0] == 1.2345e30f);  // ablation: never true, keeps the math alive
     const int64_t rowc = live ? row : rows - 1;
     float* yr = y + rowc * dim + 4 * q;
+    if (ABL == 10) yr = y + (int64_t)tile * 16 * dim + lane * 4 - cond_off;
     // PREFETCH: the next tile's rows are requested into the SAME registers as soon as their
     // last reader of this tile has issued (cnd: after layer 1; act[m]: after output step m), so
     // the loads fly under the remaining MFMA chain at no register cost.  One tile past the end
@@ -158,7 +161,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
       for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * g);
     }
-    if (live) {
+    if (live && ABL != 8) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g) = cnd[g];
     }
@@ -264,18 +267,18 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       for (int r = 0; r < 4; ++r) {
         // inverse: (v - t) / exp(s) evaluated as (v - t) * exp(-s): one multiply instead of a
         // ~10-instruction IEEE divide; same limits (0, inf, NaN) and <= 2 ulp from the quotient
-        const float e = (ABL == 3) ? s4[r] : exp6(INV ? -s4[r] : s4[r]);
-        o[r] = (ABL == 3) ? (act[m][r] - t4[r]) + e : INV ? (act[m][r] - t4[r]) * e : __builtin_fmaf(e, act[m][r], t4[r]);
+        const float e = (ABL == 3 || ABL == 5) ? s4[r] : exp6(INV ? -s4[r] : s4[r]);
+        o[r] = (ABL == 3 || ABL == 5) ? (act[m][r] - t4[r]) + e : INV ? (act[m][r] - t4[r]) * e : __builtin_fmaf(e, act[m][r], t4[r]);
         ld += s4[r];
         sq = fmaf(o[r], o[r], sq);
       }
-      if (live) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
+      if (live && (ABL != 9 || o[0] == 1.2345e30f)) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
       if (PREFETCH) act[m] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * m);
     }
     if (log_det) {
       ld = sum_over_q(ld);
       if (INV) ld = -ld;
-      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+      if (live && q == 0 && (ABL != 7 || ld == 1.2345e30f)) log_det[row] = accumulate ? log_det[row] + ld : ld;
     }
     if (ysq) {  // |y_row|^2 for the base log-prob epilogue: saves re-reading y (4*dim bytes/row)
       sq = sum_over_q(sq);
