@@ -77,6 +77,18 @@ def build_model(dim: int, device):
     return model, layers
 
 
+def pmc_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/r1/<workload>_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 rule,
+    plus WRITE_SIZE).  None when no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r1", f"{workload}_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float = 12.0) -> tuple[dict, float, int]:
     """Time the CPU oracle (the restated reference path: stock PyTorch CPU ops, all host
     threads) on a bounded sample of the same workload.  Checker and baseline only."""
@@ -216,7 +228,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload),
                 "kernel": "nsf_cl kernel (inverse)" if args.workload == "c3" else f"ahf_mfma_kernel<{dim // 2},24,inverse>",
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "algorithmic_bytes_per_launch": algo_bytes,

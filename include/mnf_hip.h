@@ -144,6 +144,22 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
                   int64_t rows, int dim, void* stream);
 
+/* ------------------------------------------------------------------ gradients (autograd)
+ * What torch.autograd.Function.backward needs so the modules train like the reference's
+ * (tests/test_flows.py:14-31 trains through forward/inverse).  grad_flat has the `flat` layout and
+ * is ADDED to (the caller zeroes it); grad_y / grad_ld may be NULL (treated as zero). */
+int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                        float* grad_flat, const float* flat, int64_t rows, int dim, int parity,
+                        int inverse, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                        void* stream);
+/* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
+int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
+                         float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,
+                         int inverse, void* stream);
+/* Glow: grad_W (dim, dim) += x^T grad_y   (grad_x is mnf_linear_rows with W^T). */
+int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_W, int64_t rows, int dim,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""Gradients of the HIP Flow modules against torch.autograd through the CPU
+oracle, and the reference's own training contracts (tests/test_flows.py:14-31,53-55,76-86)."""
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from helpers import assert_close, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GTOL = 2e-5  # parameter gradients are sums over rows accumulated with fp32 atomics
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch_mnf_amd
+
+    return torch_mnf_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import flow_oracle
+
+    return flow_oracle
+
+
+def leaf(sd):
+    return {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("dim,kw", [(64, {}), (10, dict(h_sizes=(16, 40))), (2, {}), (10, dict(scale=False)),
+                                    (10, dict(shift=False))])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_half_gradients(amd, O, dim, kw, inverse):
+    sd = recipes.affine_half_params(31 + dim, dim, s_last_gain=2.0, **kw)
+    rows = 300
+    x_cpu = recipes.gaussian(32 + dim, rows, dim).requires_grad_(True)
+    w_y = recipes.gaussian(33, rows, dim)     # random cotangents
+    w_l = recipes.gaussian(34, rows, 1)[:, 0]
+    flags = {k: v for k, v in kw.items() if k in ("scale", "shift")}
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, True, inverse, **flags)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+
+    f = amd.AffineHalfFlow(dim, True, **kw)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = f.forward(x, inverse=inverse)
+    assert yg.requires_grad and ldg.requires_grad
+    ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    assert_close(yg, y.detach(), 1e-5, "y")
+    assert_close(x.grad, x_cpu.grad, GTOL, "grad_x")
+    for name, prm in f.named_parameters():
+        assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
+
+
+def test_stack_gradients_through_normalizing_flow(amd, O):
+    """NLL of a 3-layer stack + ActNorm + Glow: d loss / d parameters vs the oracle's autograd."""
+    dim, rows = 8, 257
+    x_cpu = recipes.gaussian(50, rows, dim)
+    specs, mods = [], []
+    for i in range(2):
+        an = recipes.actnorm_params(60 + i, dim)
+        gl = recipes.glow_params(62 + i, dim)
+        ah = recipes.affine_half_params(64 + i, dim, s_last_gain=2.0)
+        specs += [{"kind": "affine_const", "params": leaf(an)},
+                  {"kind": "glow", "params": {**{k: v.clone().requires_grad_(True) for k, v in gl.items() if k != "P"},
+                                              "P": gl["P"]}},
+                  {"kind": "affine_half", "parity": bool(i % 2), "params": leaf(ah)}]
+        m_an = amd.ActNormFlow(dim); m_an.load_state_dict(an); m_an.data_dep_init_done = True
+        m_gl = amd.Glow(dim); m_gl.P = gl["P"]; m_gl.load_state_dict({k: gl[k] for k in "LSU"})
+        m_ah = amd.AffineHalfFlow(dim, bool(i % 2)); m_ah.load_state_dict(ah)
+        mods += [m_an, m_gl, m_ah]
+    zs, ld = O.flow_stack(x_cpu, specs, inverse=True)
+    loss_ref = -(ld + O.std_normal_log_prob(zs[-1])).sum()
+    loss_ref.backward()
+
+    model = amd.NormalizingFlowModel(amd.StandardNormal(dim), mods).to(DEV)
+    lp = model.log_prob(x_cpu.to(DEV))
+    loss = -lp.sum()
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    for i, (spec, mod) in enumerate(zip(specs, mods)):
+        for name, prm in mod.named_parameters():
+            ref = spec["params"][name].grad
+            assert_close(prm.grad, ref, 5e-5, f"layer {i} grad {name}")
+
+
+def moons(n):
+    sk = pytest.importorskip("sklearn.datasets")
+    pts, _ = sk.make_moons(n, noise=0.05, random_state=0)
+    return torch.as_tensor(pts).float()
+
+
+def train(model, optim, samples, steps):
+    for _ in range(steps):
+        _, log_det = model.inverse(samples)
+        base_log_prob = model.base_log_prob(samples)
+        loss = -(log_det + base_log_prob).sum()
+        model.zero_grad()
+        loss.backward()
+        optim.step()
+    return float(loss)
+
+
+@pytest.mark.parametrize("name,bound", [("rnvp", 236), ("glow", 308), ("glow_actnorm", 246)])
+def test_reference_training_contracts(amd, name, bound):
+    """The reference's e2e tests: Adam, 1 step then 70 steps on 128 half-moon points; the loss must
+    fall and end below the reference's bound (tests/test_flows.py:41-50, :53-55, :76-86)."""
+    torch.manual_seed(0)
+    samples = moons(128).to(DEV)
+    if name == "rnvp":
+        flows = [amd.AffineHalfFlow(dim=2, parity=i % 2 == 0) for i in range(2)]
+    else:
+        flows = [amd.Glow(dim=2) for _ in range(2)]
+        if name == "glow_actnorm":
+            for idx in reversed(range(len(flows))):
+                flows.insert(idx, amd.ActNormFlow(dim=2))
+    base = torch.distributions.MultivariateNormal(torch.zeros(2, device=DEV), torch.eye(2, device=DEV))
+    model = amd.NormalizingFlowModel(base, flows).to(DEV)
+    adam = torch.optim.Adam(model.parameters())
+    loss1 = train(model, adam, samples, 1)
+    loss2 = train(model, adam, samples, 70)
+    assert loss1 > loss2
+    assert loss2 < bound, f"{loss2=:.4} > {bound=}"

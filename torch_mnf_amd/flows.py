@@ -71,6 +71,12 @@ def _device_input(t: Tensor, what: str) -> Tensor:
     return t.detach().contiguous()
 
 
+def _grad_input(t: Tensor) -> Tensor:
+    """Same checks as _device_input but keeps the autograd link (training path)."""
+    _device_input(t, "input")
+    return t.contiguous()
+
+
 def _empty_result(x: Tensor, accum: Tensor | None):
     """rows == 0: nothing to launch (an empty tensor has no device pointer to hand over)."""
     return torch.empty_like(x), (None if accum is not None else x.new_empty(0))
@@ -86,10 +92,97 @@ def _note_no_autograd(module: nn.Module, x: Tensor) -> None:
     if x.requires_grad or any(p.requires_grad for p in module.parameters()):
         _warned_autograd = True
         warnings.warn(
-            "torch_mnf_amd: the HIP coupling kernels do not record an autograd graph yet "
-            "(forward/inverse values only); wrap evaluation in torch.no_grad().",
+            f"torch_mnf_amd: {type(module).__name__} has no backward kernel yet (AffineHalfFlow, "
+            "AffineConstantFlow/ActNormFlow and Glow do); its outputs are detached from autograd.",
             stacklevel=3,
         )
+
+
+def _wants_grad(module: nn.Module, x: Tensor) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+class _AffineHalfFn(torch.autograd.Function):
+    """AffineHalfFlow with gradients: forward = the usual kernel, backward = mnf_affine_half_bwd
+    (recomputes the conditioner, returns grad wrt x and wrt the flat parameter vector; autograd's
+    own cat-backward then scatters that vector onto s_net / t_net parameters)."""
+
+    @staticmethod
+    def forward(ctx, x, flat_with_grad, module, inverse):
+        flat, image = module._packed(x.device)
+        y = torch.empty_like(x)
+        ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_affine_half", _lib.load().mnf_affine_half(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), x.shape[0], module.dim,
+            int(bool(module.parity)), int(inverse), len(module.h_sizes), module._hid, int(module.scale),
+            int(module.shift), int(module.force_generic), _stream()))
+        ctx.module, ctx.inverse = module, inverse
+        ctx.save_for_backward(x, flat if flat is not None else x.new_empty(0))
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_ld):
+        x, flat = ctx.saved_tensors
+        m = ctx.module
+        gy = None if grad_y is None else grad_y.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_x = torch.empty_like(x)
+        grad_flat = torch.zeros_like(flat)
+        _lib.check("mnf_affine_half_bwd", _lib.load().mnf_affine_half_bwd(
+            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), _ptr(grad_flat) if flat.numel() else None,
+            _ptr(flat) if flat.numel() else None, x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse),
+            len(m.h_sizes), m._hid, int(m.scale), int(m.shift), _stream()))
+        return grad_x, (grad_flat if flat.numel() else None), None, None
+
+
+class _AffineConstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, t, inverse):
+        y = torch.empty_like(x)
+        _lib.check("mnf_affine_const", _lib.load().mnf_affine_const(
+            x.data_ptr(), y.data_ptr(), s.contiguous().data_ptr(), t.contiguous().data_ptr(), None, 0, None,
+            x.shape[0], x.shape[1], int(inverse), _stream()))
+        ctx.inverse = inverse
+        ctx.save_for_backward(x, y, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, y, s = ctx.saved_tensors
+        gy = grad_y.contiguous()
+        gx = torch.empty_like(x)
+        gs, gt = torch.zeros_like(s), torch.zeros_like(s)
+        _lib.check("mnf_affine_const_bwd", _lib.load().mnf_affine_const_bwd(
+            x.data_ptr(), y.data_ptr(), gy.data_ptr(), s.contiguous().data_ptr(), gx.data_ptr(), gs.data_ptr(),
+            gt.data_ptr(), x.shape[0], x.shape[1], int(ctx.inverse), _stream()))
+        return gx, gs, gt, None
+
+
+class _LinearRowsFn(torch.autograd.Function):
+    """y = x @ W with both gradients from the HIP library."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        W = W.contiguous()
+        y = torch.empty_like(x)
+        _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
+            x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()))
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, W = ctx.saved_tensors
+        gy = grad_y.contiguous()
+        gx = torch.empty_like(x)
+        Wt = W.t().contiguous()
+        lib = _lib.load()
+        _lib.check("mnf_linear_rows", lib.mnf_linear_rows(gy.data_ptr(), Wt.data_ptr(), gx.data_ptr(), x.shape[0],
+                                                          x.shape[1], _stream()))
+        gW = torch.zeros_like(W)
+        _lib.check("mnf_linear_rows_bwd_weight", lib.mnf_linear_rows_bwd_weight(
+            x.data_ptr(), gy.data_ptr(), gW.data_ptr(), x.shape[0], x.shape[1], _stream()))
+        return gx, gW
 
 
 class _HipFlow(nn.Module):
@@ -187,10 +280,17 @@ class AffineHalfFlow(_TwoWayFlow):
         return idx
 
     def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
+        if accum is None and sqnorm is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 \
+                and _wants_grad(self, x):
+            xg = _grad_input(x)
+            if xg.shape[1] != self.dim:
+                raise ValueError(f"expected dim {self.dim}, got {xg.shape[1]}")
+            params = self._packed_params()
+            flat = torch.cat([p.reshape(-1) for p in params]) if params else xg.new_empty(0)
+            return _AffineHalfFn.apply(xg, flat, self, bool(inverse))
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
-        _note_no_autograd(self, x)
         if x.shape[0] == 0:
             return _empty_result(x, accum)
         flat, image = self._packed(x.device)
@@ -343,10 +443,13 @@ class AffineConstantFlow(_TwoWayFlow):
             self.register_buffer("t", torch.zeros(1, dim), persistent=False)
 
     def _run(self, x, inverse, accum):
+        if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            xg = _grad_input(x)
+            y = _AffineConstFn.apply(xg, self.s.to(xg.device), self.t.to(xg.device), bool(inverse))
+            return y, torch.sum(-self.s if inverse else self.s, dim=1).to(xg.device)
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
-        _note_no_autograd(self, x)
         s = self.s.detach().to(x.device, torch.float32).contiguous()
         t = self.t.detach().to(x.device, torch.float32).contiguous()
         if x.shape[0] == 0:
@@ -428,10 +531,18 @@ class Glow(_TwoWayFlow):
         return self._w
 
     def _run(self, x, inverse, accum):
+        if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            xg = _grad_input(x)
+            eye = torch.eye(self.dim, device=self.L.device)
+            W = self.P.to(self.L.device) @ (torch.tril(self.L, diagonal=-1) + eye) @ (
+                torch.triu(self.U, diagonal=1) + self.S.diag())  # glow.py:20-24, differentiable
+            ld = self.S.abs().log().sum()
+            if inverse:
+                return _LinearRowsFn.apply(xg, torch.inverse(W).to(xg.device)), -ld.to(xg.device)
+            return _LinearRowsFn.apply(xg, W.to(xg.device)), ld.to(xg.device)
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
-        _note_no_autograd(self, x)
         W = self._weights(x.device, inverse)
         y = torch.empty_like(x)
         if x.shape[0] > 0:
@@ -470,10 +581,13 @@ class NormalizingFlow(nn.Module):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if (want_sqnorm and i == len(order) - 1 and isinstance(flow, AffineHalfFlow) and x.is_cuda
-                    and x.shape[0] > 0 and flow.emits_sqnorm(x.device)):
+                    and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
                 # last layer also emits |z|^2 per row for the standard-normal epilogue
                 self._last_sqnorm = torch.empty(x.size(0), device=x.device)
                 x, _ = flow._run(x, inverse, log_det, self._last_sqnorm)
+            elif isinstance(flow, (AffineHalfFlow, AffineConstantFlow, Glow)) and _wants_grad(flow, x):
+                x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
+                log_det = log_det + ld
             elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
                 x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
             else:
@@ -503,6 +617,8 @@ class StandardNormal:
         self.device = torch.device(device)
 
     def log_prob(self, z: Tensor) -> Tensor:
+        if torch.is_grad_enabled() and z.requires_grad:  # training: keep the autograd link
+            return -0.5 * z.pow(2).sum(1) - 0.5 * self.dim * math.log(2 * math.pi)
         z = _device_input(z, "z")
         lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         if z.shape[0] == 0:
@@ -540,7 +656,7 @@ class NormalizingFlowModel(NormalizingFlow):
         std = isinstance(self.base, StandardNormal)
         zs, log_det = self._pass(x, True, want_sqnorm=std)
         z = zs[-1]
-        if std:
+        if std and not (torch.is_grad_enabled() and (z.requires_grad or log_det.requires_grad)):
             lp = torch.empty_like(log_det)
             total = torch.zeros(1, dtype=torch.float64, device=z.device) if return_sum else None
             if z.shape[0] == 0:
