@@ -130,6 +130,12 @@ int mnf_affine_const(const float* x, float* y, const float* s, const float* t,
 /* y = x @ W, W (dim, dim) row-major on the device (Glow's assembled matrix or its inverse). */
 int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int dim, void* stream);
 
+/* The same product with W pre-arranged as an MFMA operand image (dim in {16,32,64,128}):
+ * image[i] = W_flat[idx[i]] with idx from mnf_linear_rows_image_index (dim*dim entries). */
+int64_t mnf_linear_rows_image_floats(int dim);
+int mnf_linear_rows_image_index(int dim, int32_t* idx_host);
+int mnf_linear_rows_img(const float* x, const float* image, float* y, int64_t rows, int dim, void* stream);
+
 /* --------------------------------------------------------- base log-prob epilogue */
 /* log_prob[r] = (log_det ? log_det[r] : 0) - |z_r|^2/2 - dim/2*log(2 pi)   (standard normal base)
  * sum_out (device double, may be NULL) += sum_r log_prob[r]; the caller zeroes it first. */

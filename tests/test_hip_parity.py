@@ -335,6 +335,38 @@ def test_c3_full_size_round_trip(amd):
     assert 0.001 < outside < 0.005  # ~0.27 % of N(0,1) falls in the identity tails
 
 
+@pytest.mark.parametrize("dim", [4, 16, 32, 64, 128])
+def test_glow_and_actnorm_layers_vs_oracle(amd, O, dim):
+    """Glow (MFMA kernel for d in {16,32,64,128}, generic otherwise) and AffineConstantFlow."""
+    gp = recipes.glow_params(40 + dim, dim)
+    gl = amd.Glow(dim)
+    gl.P = gp["P"]
+    gl.load_state_dict({k: gp[k] for k in "LSU"})
+    gl.to(DEV)
+    x = recipes.gaussian(41 + dim, 1037, dim)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.glow(x, gp["P"], gp["L"], gp["S"], gp["U"], inverse)
+        y, ld = (gl.inverse if inverse else gl.forward)(cuda(x))
+        assert_close(y, ref_y, 2e-5 if inverse else RTOL, "glow y")  # inverse: dense torch.inverse on both sides
+        assert abs(float(ld) - float(ref_ld)) <= 1e-5 * max(1.0, abs(float(ref_ld))) and ld.dim() == 0
+        gl.force_generic = True
+        gl._w_img = {}
+        y_gen, _ = (gl.inverse if inverse else gl.forward)(cuda(x))
+        gl.force_generic = False
+        gl._w_img = {}
+        assert_close(y, y_gen, RTOL, "mfma vs generic")
+    ap = recipes.actnorm_params(42 + dim, dim)
+    an = amd.AffineConstantFlow(dim)
+    an.load_state_dict(ap)
+    an.to(DEV)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.affine_const(x, ap["s"], ap["t"], inverse)
+        y, ld = (an.inverse if inverse else an.forward)(cuda(x))
+        assert_close(y, ref_y, RTOL, "affine_const y")
+        assert_close(ld, ref_ld, RTOL, "affine_const ld")
+        assert tuple(ld.shape) == (1,)
+
+
 # --------------------------------------------------------------------------- RNVP
 @pytest.mark.parametrize("dim", [50, 800, 784])
 @pytest.mark.parametrize("generic", [False, True])

@@ -51,6 +51,9 @@ SIGNATURES = {
     "mnf_affine_const": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
                                  c_int, c_int, c_void_p]),
     "mnf_linear_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_linear_rows_image_floats": (c_int64, [c_int]),
+    "mnf_linear_rows_image_index": (c_int, [c_int, _i32p]),
+    "mnf_linear_rows_img": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_gauss_logprob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_gauss_logprob_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_affine_half_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,

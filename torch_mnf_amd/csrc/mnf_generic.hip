@@ -291,6 +291,27 @@ __global__ void affine_const_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// float4 variant (dim % 4 == 0, 16-byte aligned rows): each thread owns 4 consecutive dims
+__global__ void affine_const_kernel_v4(const float4* __restrict__ x, float4* __restrict__ y,
+                                       const float* __restrict__ s, const float* __restrict__ t, int64_t n4,
+                                       int dim4, int inverse) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int j = (int)(i % dim4) * 4;
+    const float4 v = x[i];
+    const float4 sv = *reinterpret_cast<const float4*>(s + j), tv = *reinterpret_cast<const float4*>(t + j);
+    float4 o;
+    if (inverse) {
+      o.x = (v.x - tv.x) * expf(-sv.x); o.y = (v.y - tv.y) * expf(-sv.y);
+      o.z = (v.z - tv.z) * expf(-sv.z); o.w = (v.w - tv.w) * expf(-sv.w);
+    } else {
+      o.x = v.x * expf(sv.x) + tv.x; o.y = v.y * expf(sv.y) + tv.y;
+      o.z = v.z * expf(sv.z) + tv.z; o.w = v.w * expf(sv.w) + tv.w;
+    }
+    y[i] = o;
+  }
+}
+
 __global__ void add_scalar_rows_kernel(float* __restrict__ log_det, const float* __restrict__ scalar,
                                        int64_t rows, int accumulate) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -303,10 +324,16 @@ __global__ void add_scalar_rows_kernel(float* __restrict__ log_det, const float*
 __global__ void __launch_bounds__(kThreads) linear_rows_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ W,
                                                                float* __restrict__ y, int64_t rows,
-                                                               int dim, int R) {
-  float* Wl = smem;             // [dim][dim]
-  float* xl = Wl + dim * dim;   // [R][dim]
-  for (int i = threadIdx.x; i < dim * dim; i += blockDim.x) Wl[i] = W[i];
+                                                               int dim, int R, int w_lds) {
+  // W is staged in LDS when it fits (w_lds != 0); otherwise it is read through L1/L2
+  const float* Wl = W;
+  float* xl = smem;
+  if (w_lds) {
+    float* Ws = smem;           // [dim][dim]
+    xl = Ws + dim * dim;        // [R][dim]
+    for (int i = threadIdx.x; i < dim * dim; i += blockDim.x) Ws[i] = W[i];
+    Wl = Ws;
+  }
   const int64_t n_groups = (rows + R - 1) / R;
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int64_t row0 = grp * R;
@@ -701,8 +728,15 @@ int mnf_affine_const(const float* x, float* y, const float* s, const float* t, f
   }
   if (rows == 0) return MNF_OK;
   const int64_t n = rows * dim;
-  hipLaunchKernelGGL(affine_const_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, s, t, n, dim,
-                     inverse != 0);
+  const bool vec = (dim % 4 == 0) && !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                        reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(t)) & 15);
+  if (vec)
+    hipLaunchKernelGGL(affine_const_kernel_v4, dim3(grid_for(n / 4, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), s, t, n / 4, dim / 4,
+                       inverse != 0);
+  else
+    hipLaunchKernelGGL(affine_const_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, s, t, n, dim,
+                       inverse != 0);
   if (int rc = check_launch()) return rc;
   if (log_det) {
     hipLaunchKernelGGL(add_scalar_rows_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, st, log_det,
@@ -715,14 +749,16 @@ int mnf_affine_const(const float* x, float* y, const float* s, const float* t, f
 int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int dim, void* stream) {
   if (!x || !W || !y || x == y || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  const int64_t wf = (int64_t)dim * dim;
-  if (wf + dim > kLdsBudgetFloats) return MNF_ERR_UNSUPPORTED;
+  int64_t wf = (int64_t)dim * dim;
+  const int w_lds = wf + 8 * (int64_t)dim <= kLdsBudgetFloats;
+  if (!w_lds) wf = 0;
+  if (dim > kLdsBudgetFloats) return MNF_ERR_UNSUPPORTED;
   int R = (int)((kLdsBudgetFloats - wf) / dim);
   if (R > 256) R = 256;
   const int64_t groups = (rows + R - 1) / R;
   const int grid = (int)(groups < 2048 ? groups : 2048);
   hipLaunchKernelGGL(linear_rows_kernel, dim3(grid), dim3(kThreads), (size_t)(wf + (int64_t)R * dim) * 4,
-                     (hipStream_t)stream, x, W, y, rows, dim, R);
+                     (hipStream_t)stream, x, W, y, rows, dim, R, w_lds);
   return check_launch();
 }
 

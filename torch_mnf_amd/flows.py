@@ -510,6 +510,9 @@ class Glow(_TwoWayFlow):
         self._w_key = None
         self._w: Tensor | None = None
         self._w_inv: Tensor | None = None
+        self._w_ld: Tensor | None = None      # sum(log|S|), cached with W
+        self._w_img: dict = {}                # inverse? -> MFMA operand image of W / W^-1
+        self._w_index: Tensor | None = None
 
     def _assemble_W(self, device=None) -> Tensor:
         device = self.L.device if device is None else device
@@ -523,12 +526,33 @@ class Glow(_TwoWayFlow):
         if key != self._w_key:
             self._w = self._assemble_W(device)
             self._w_inv = None
+            self._w_img = {}
+            self._w_ld = self.S.detach().abs().log().sum().to(device)  # 0-dim, parameter-only (glow.py:29)
             self._w_key = key
         if inverse:
             if self._w_inv is None:
                 self._w_inv = torch.inverse(self._w).contiguous()
             return self._w_inv
         return self._w
+
+    def _w_image(self, device, inverse: bool) -> Tensor | None:
+        """W (or W^-1) in MFMA operand order, or None when dim has no specialised kernel."""
+        W = self._weights(device, inverse)
+        if inverse not in self._w_img:
+            lib = _lib.load()
+            n = lib.mnf_linear_rows_image_floats(self.dim)
+            if n <= 0 or self.force_generic:
+                self._w_img[inverse] = None
+            else:
+                if self._w_index is None or self._w_index.device != device:
+                    idx = (ctypes.c_int32 * n)()
+                    _lib.check("mnf_linear_rows_image_index", lib.mnf_linear_rows_image_index(self.dim, idx))
+                    self._w_index = torch.frombuffer(idx, dtype=torch.int32).clone().to(device)
+                img = torch.empty(n, dtype=torch.float32, device=device)
+                _lib.check("mnf_pack_gather", lib.mnf_pack_gather(
+                    W.data_ptr(), self._w_index.data_ptr(), img.data_ptr(), n, _stream()))
+                self._w_img[inverse] = img
+        return self._w_img[inverse]
 
     def _run(self, x, inverse, accum):
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
@@ -544,13 +568,16 @@ class Glow(_TwoWayFlow):
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         W = self._weights(x.device, inverse)
+        img = self._w_image(x.device, inverse)
         y = torch.empty_like(x)
         if x.shape[0] > 0:
-            _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
-                x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
-        ld = self.S.detach().abs().log().sum().to(x.device)  # 0-dim, parameter-only
-        if inverse:
-            ld = -ld
+            if img is not None:
+                _lib.check("mnf_linear_rows_img", _lib.load().mnf_linear_rows_img(
+                    x.data_ptr(), img.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
+            else:
+                _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
+                    x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
+        ld = -self._w_ld if inverse else self._w_ld
         if accum is not None:
             accum += ld
             return y, None
