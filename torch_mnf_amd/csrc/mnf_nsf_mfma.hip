@@ -59,33 +59,39 @@ __device__ __forceinline__ float softplus_fast(float x) {
 // :95-101).  u[] is consumed.
 template <int K>
 __device__ __forceinline__ void knots_from_raw(const float (&u)[K], float T, float (&knot)[K + 1]) {
+  // Instruction diet (this kernel is VALU bound): every exp argument is one fma with the scale
+  // and the subtracted maximum folded into constants.  A rounding error in a folded constant
+  // multiplies all K terms alike and cancels in the normalisation.
+  constexpr float L2E = 1.44269504088896341f;
   const float twoT = 2.f * T;
   const float c1 = 1.f - kMinBin * (float)K;
   float m = u[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) m = __builtin_fmaxf(m, u[k]);
+  const float mb = m * L2E;
   float e[K];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    e[k] = exp_sm(u[k] - m);
+    e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(u[k], L2E, -mb));  // exp(u - max u)
     s += e[k];
   }
   const float r = rcp_fast(s);
-  const float m2 = twoT * r;  // second-level max: the max element has e = 1
+  // second level: exp(2T p_k - 2T p_max), p_k = e_k r, p_max = r (the max element has e = 1)
+  const float a2 = (twoT * r) * L2E;
   float s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    e[k] = exp_sm(twoT * (e[k] * r) - m2);
+    e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[k], a2, -a2));
     s2 += e[k];
   }
-  const float r2 = rcp_fast(s2);
+  const float g = c1 * rcp_fast(s2);
   float c = 0.f;
   knot[0] = -T;
 #pragma unroll
   for (int k = 0; k < K - 1; ++k) {
-    c += kMinBin + c1 * (e[k] * r2);
-    knot[k + 1] = twoT * c - T;
+    c += __builtin_fmaf(e[k], g, kMinBin);    // 1e-3 + (1 - 1e-3 K) p2_k, cumulative
+    knot[k + 1] = __builtin_fmaf(twoT, c, -T);
   }
   knot[K] = T;
 }
