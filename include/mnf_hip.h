@@ -115,6 +115,15 @@ int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int ac
              const float* flat, const float* image,
              int64_t rows, int dim, int n_hidden, const int* hidden_host,
              int force_generic, void* stream);
+/* Same layer with the mask generated inside the kernel when mask == NULL: element (r, j) is bit
+ * (j & 31) of a 32-bit hash of (seed, r, j >> 5) -- a stateless Bernoulli(0.5) stream owned by
+ * this library.  mnf_rnvp_mask writes exactly that mask as floats, so a
+ * seeded call can be reproduced with an explicit mask (and by the CPU oracle). */
+int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, float* log_det,
+                    int accumulate, const float* flat, const float* image,
+                    int64_t rows, int dim, int n_hidden, const int* hidden_host,
+                    int force_generic, void* stream);
+int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
 int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden_host);
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden_host);
 int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);

@@ -386,6 +386,30 @@ def test_g7_rnvp(amd, golden, dim, generic):
     x1, _ = f.forward(z)
     x2, _ = f.forward(z)
     assert not torch.equal(x1, x2)
+    # ... from the library's counter-based generator: reproducible under torch.manual_seed, and a
+    # seeded call equals an explicit-mask call with the mask mask_for() reports
+    torch.manual_seed(5)
+    xa, lda = f.forward(z)
+    torch.manual_seed(5)
+    xb, ldb = f.forward(z)
+    assert torch.equal(xa, xb) and torch.equal(lda, ldb)
+    xs, lds = f.forward(z, seed=1234)
+    m = f.mask_for(1234, z.shape[0])
+    xm, ldm = f.forward(z, mask=m)
+    assert torch.equal(xs, xm) and torch.equal(lds, ldm)
+    assert set(m.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_rnvp_in_kernel_mask_statistics(amd):
+    """The generated mask is Bernoulli(0.5) per element: mean, per-column and per-row balance, and
+    no correlation between neighbouring rows / columns or between seeds."""
+    f = amd.RNVP(800, h_sizes=(50,)).to(DEV)
+    m = f.mask_for(99, 4096)
+    assert abs(float(m.mean()) - 0.5) < 2e-3
+    assert float((m.mean(0) - 0.5).abs().max()) < 0.05 and float((m.mean(1) - 0.5).abs().max()) < 0.09
+    c = lambda a, b: float(((a - 0.5) * (b - 0.5)).mean() * 4)  # noqa: E731
+    assert abs(c(m[1:], m[:-1])) < 5e-3 and abs(c(m[:, 1:], m[:, :-1])) < 5e-3
+    assert abs(c(m, f.mask_for(100, 4096))) < 5e-3
 
 
 def test_g8_mnf_linear_sample_z(amd, golden):

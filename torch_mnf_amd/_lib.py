@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmnf_hip.so")
@@ -45,6 +45,9 @@ SIGNATURES = {
                         c_int, c_void_p]),
     "mnf_rnvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
                          c_int, _intp, c_int, c_void_p]),
+    "mnf_rnvp_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                c_int64, c_int, c_int, _intp, c_int, c_void_p]),
+    "mnf_rnvp_mask": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_rnvp_flat_floats": (c_int64, [c_int, c_int, _intp]),
     "mnf_rnvp_image_floats": (c_int64, [c_int, c_int, _intp]),
     "mnf_rnvp_image_index": (c_int, [c_int, c_int, _intp, _i32p]),

@@ -155,6 +155,22 @@ __device__ __forceinline__ void rqs_element(float v, int K, float T, bool invers
   }
 }
 
+// Counter-based Bernoulli(0.5) mask for RNVP (the reference draws torch.bernoulli per call,
+// rnvp.py:28): bit (dim & 31) of a 32-bit hash of (seed, row, dim >> 5).  Stateless, so the
+// GEMM-1 operand pass and the epilogue of the same kernel regenerate identical bits, and
+// mnf_rnvp_mask() can materialise exactly the mask a seeded call used.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t rnvp_mask_word(uint64_t seed, int64_t row, int word) {
+  const uint32_t a = mix32((uint32_t)row * 0x9e3779b1u + (uint32_t)((uint64_t)row >> 32) + (uint32_t)(seed >> 32));
+  return mix32(a ^ ((uint32_t)word * 0x85ebca77u + (uint32_t)seed));
+}
+__device__ __forceinline__ float rnvp_mask_bit(uint64_t seed, int64_t row, int dim) {
+  return (float)((rnvp_mask_word(seed, row, dim >> 5) >> (dim & 31)) & 1u);
+}
+
 // sum over the 4 lanes {j, j+16, j+32, j+48} that share a sample in the 16x16 MFMA layout
 __device__ __forceinline__ float sum_over_q(float v) {
   v += __shfl_xor(v, 16, 64);

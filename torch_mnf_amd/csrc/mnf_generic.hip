@@ -221,6 +221,7 @@ struct RnvpArgs {
   int dim, accumulate;
   int R, ldw;
   int t_w, t_b, s_w, s_b;  // float offsets of t.weight, t.bias, s.weight, s.bias
+  uint64_t seed;           // used when mask == nullptr
   NetDesc net;
 };
 
@@ -237,7 +238,8 @@ __global__ void __launch_bounds__(kThreads) rnvp_generic_kernel(RnvpArgs a) {
   for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
     const int r = idx / d, j = idx - r * d;
     const int64_t g = (row0 + r) * d + j;
-    kept[idx] = a.mask[g] * a.z[g];
+    const float m = a.mask ? a.mask[g] : rnvp_mask_bit(a.seed, row0 + r, j);
+    kept[idx] = m * a.z[g];
   }
   __syncthreads();
   block_mlp(a.flat, a.net, kept, d, bufA, bufB, a.ldw, y, hl, R);
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(kThreads) rnvp_generic_kernel(RnvpArgs a) {
       shift = fmaf(Wt[(size_t)j * hl + k], yr[k], shift);
       scale = fmaf(Ws[(size_t)j * hl + k], yr[k], scale);
     }
-    const float m = a.mask[g], zz = a.z[g];
+    const float m = a.mask ? a.mask[g] : rnvp_mask_bit(a.seed, row0 + r, j), zz = a.z[g];
     const float gate = sigmoidf(scale);
     // x = z1*gate + (1-gate)*shift + z2, every position (rnvp.py:37)
     a.x[g] = ((1.f - m) * zz * gate + (1.f - gate) * shift) + m * zz;
@@ -679,19 +681,41 @@ int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden) {
 int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
              const float* flat, const float* image, int64_t rows, int dim, int n_hidden,
              const int* hidden, int force_generic, void* stream) {
-  if (!z || !mask || !x || z == x || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden) ||
+  if (!mask) return MNF_ERR_INVALID_ARG;
+  return mnf_rnvp_seeded(z, mask, 0, x, log_det, accumulate, flat, image, rows, dim, n_hidden, hidden,
+                         force_generic, stream);
+}
+
+__global__ void rnvp_mask_kernel(uint64_t seed, float* __restrict__ mask, int64_t rows, int dim) {
+  const int64_t n = rows * dim, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    mask[i] = rnvp_mask_bit(seed, i / dim, (int)(i % dim));
+}
+
+int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream) {
+  if (!mask || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(rnvp_mask_kernel, dim3(grid_for(rows * dim, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                     mask, rows, dim);
+  return check_launch();
+}
+
+int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
+                    const float* flat, const float* image, int64_t rows, int dim, int n_hidden,
+                    const int* hidden, int force_generic, void* stream) {
+  if (!z || !x || z == x || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden) ||
       (!flat && !image))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (image && !force_generic) {
-    const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, rows, dim, n_hidden, hidden,
+    const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, rows, dim, n_hidden, hidden, seed,
                                     (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (!flat) return MNF_ERR_INVALID_ARG;
   RnvpArgs a;
   a.z = z; a.mask = mask; a.x = x; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim;
-  a.accumulate = accumulate != 0;
+  a.accumulate = accumulate != 0; a.seed = seed;
   int sizes[MNF_MAX_LINEAR + 1];
   sizes[0] = dim;
   for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];

@@ -20,8 +20,9 @@ int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int ac
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                     int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
                     const int* hidden, hipStream_t stream);
+// mask == nullptr: the mask is generated in-kernel from `seed`
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, int64_t rows, int dim, int n_hidden, const int* hidden,
-                     hipStream_t stream);
+                     uint64_t seed, hipStream_t stream);
 
 }  // namespace mnf

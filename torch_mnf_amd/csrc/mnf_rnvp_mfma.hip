@@ -54,11 +54,13 @@ __device__ __forceinline__ float exp6r(float x) {
   return __builtin_amdgcn_exp2f(t) * __builtin_fmaf(tl, ln2, 1.0f);
 }
 
-template <int HN>
+// SEEDED: the mask is not read from memory but regenerated from (seed, row, dim) wherever it
+// is needed -- 8d fewer bytes per row (the mask is otherwise read twice).
+template <int HN, bool SEEDED>
 __global__ void __launch_bounds__(kRnvpWaves * 64)
 rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                  float* __restrict__ log_det, const float* __restrict__ image, int64_t rows, int d,
-                 int accumulate) {
+                 int accumulate, uint64_t seed) {
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT, G2 = S::G2;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
@@ -77,7 +79,14 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
     const float* zr = z + rowc * d + 4 * q;
-    const float* mr = mask + rowc * d + 4 * q;
+    const float* mr = SEEDED ? nullptr : mask + rowc * d + 4 * q;
+    // four consecutive dims 16 g + 4 q .. + 3 share one 32-bit mask word
+    auto mask4 = [&](int dim0) -> f32x4 {
+      if (!SEEDED) return *reinterpret_cast<const f32x4*>(mr + dim0);
+      const int dd = dim0 + 4 * q;
+      const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
+      return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
+    };
     float* xr = x + rowc * d + 4 * q;
 
     // ---------------- GEMM 1: y^T (64 x 16) = Wn . (m*z)^T, K = d
@@ -97,7 +106,7 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
       for (int g = 0; g < nk / 4; ++g) {  // 16 dims = 4 K-steps per float4
         const int dim0 = (k0 + 4 * g) * 4;
         f32x4 zz = *reinterpret_cast<const f32x4*>(zr + dim0);
-        const f32x4 mm = *reinterpret_cast<const f32x4*>(mr + dim0);
+        const f32x4 mm = mask4(dim0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float b = mm[e] * zz[e];
@@ -126,7 +135,7 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
         f32x4 t4 = *reinterpret_cast<const f32x4*>(bias_ts + m * 32 + 4 * q);
         f32x4 s4 = *reinterpret_cast<const f32x4*>(bias_ts + m * 32 + 16 + 4 * q);
         const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 16 * m);
-        const f32x4 mm = *reinterpret_cast<const f32x4*>(mr + 16 * m);
+        const f32x4 mm = mask4(16 * m);
         f32x4 a4;
 #pragma unroll
         for (int c = 0; c < KQ; ++c) {
@@ -206,7 +215,7 @@ static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
 
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, int64_t rows, int dim, int n_hidden, const int* hidden,
-                     hipStream_t stream) {
+                     uint64_t seed, hipStream_t stream) {
   if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) |
        reinterpret_cast<uintptr_t>(image)) & 15)
@@ -217,14 +226,18 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rnvp_mfma_kernel<50>, kRnvpWaves * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rnvp_mfma_kernel<50, false>, kRnvpWaves * 64, 0) !=
             hipSuccess || per_cu < 1)
       per_cu = 2;
     return per_cu * cus;
   }();
   const int64_t blocks = n_groups < resident ? n_groups : resident;
-  hipLaunchKernelGGL((rnvp_mfma_kernel<50>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z, mask, x,
-                     log_det, image, rows, dim, accumulate);
+  if (mask)
+    hipLaunchKernelGGL((rnvp_mfma_kernel<50, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed);
+  else
+    hipLaunchKernelGGL((rnvp_mfma_kernel<50, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed);
   return check_launch();
 }
 

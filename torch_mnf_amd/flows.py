@@ -376,8 +376,11 @@ def rqs(inputs: Tensor, W: Tensor, H: Tensor, D: Tensor, inverse: bool = False,
 class RNVP(_HipFlow):
     """Forward-only masked/gated coupling used by the MNF layers (flows/rnvp.py:7-39).
 
-    ``forward(z)`` draws a fresh Bernoulli(0.5) mask per element like the reference (:28);
-    ``forward(z, mask=m)`` takes the mask as an input (parity tests, reproducible runs)."""
+    ``forward(z)`` uses a fresh Bernoulli(0.5) mask per element per call like the reference (:28);
+    the bits come from the library's counter-based generator, keyed by a seed drawn from torch's
+    global RNG (so ``torch.manual_seed`` makes runs reproducible) and never touch memory.
+    ``forward(z, mask=m)`` takes an explicit float mask; ``forward(z, seed=k)`` a fixed seed, and
+    ``mask_for(seed, rows)`` returns the mask such a call used."""
 
     def __init__(self, dim: int, h_sizes: Sequence[int] = (30,)) -> None:
         super().__init__()
@@ -400,7 +403,13 @@ class RNVP(_HipFlow):
         _lib.check("mnf_rnvp_image_index", lib.mnf_rnvp_image_index(self.dim, len(self.h_sizes), self._hid, idx))
         return idx
 
-    def _run(self, z, inverse, accum, mask: Tensor | None = None):
+    def mask_for(self, seed: int, rows: int, device="cuda") -> Tensor:
+        m = torch.empty(rows, self.dim, dtype=torch.float32, device=device)
+        if rows:
+            _lib.check("mnf_rnvp_mask", _lib.load().mnf_rnvp_mask(int(seed), m.data_ptr(), rows, self.dim, _stream()))
+        return m
+
+    def _run(self, z, inverse, accum, mask: Tensor | None = None, seed: int | None = None):
         if inverse:
             raise AttributeError("RNVP has no inverse (flows/rnvp.py defines forward only)")
         z = _device_input(z, "input")
@@ -409,22 +418,23 @@ class RNVP(_HipFlow):
         _note_no_autograd(self, z)
         if z.shape[0] == 0:
             return _empty_result(z, accum)
-        if mask is None:
-            mask = torch.bernoulli(0.5 * torch.ones_like(z))
-        mask = _device_input(mask, "mask")
-        if mask.shape != z.shape:
-            raise ValueError("mask must have the shape of z")
+        if mask is not None:
+            mask = _device_input(mask, "mask")
+            if mask.shape != z.shape:
+                raise ValueError("mask must have the shape of z")
+        elif seed is None:  # one draw from torch's global generator per call
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
         flat, image = self._packed(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
-        _lib.check("mnf_rnvp", _lib.load().mnf_rnvp(
-            z.data_ptr(), mask.data_ptr(), x.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat),
-            _ptr(image), z.shape[0], self.dim, len(self.h_sizes), self._hid, int(self.force_generic),
-            _stream()))
+        _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
+            z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
+            int(accum is not None), _ptr(flat), _ptr(image), z.shape[0], self.dim, len(self.h_sizes), self._hid,
+            int(self.force_generic), _stream()))
         return x, (None if accum is not None else ld)
 
-    def forward(self, z: Tensor, mask: Tensor | None = None) -> tuple[Tensor, Tensor]:
-        return self._run(z, False, None, mask)
+    def forward(self, z: Tensor, mask: Tensor | None = None, seed: int | None = None) -> tuple[Tensor, Tensor]:
+        return self._run(z, False, None, mask, seed)
 
 
 class AffineConstantFlow(_TwoWayFlow):
