@@ -68,7 +68,7 @@ int main() {
       {"no-stores", run<false, 6, 0>},     {"compute-only", run<false, 2, 0>},
       {"copy-only", run<false, 5, 0>},     {"no-mfma", run<false, 1, 0>},
       {"no-exp", run<false, 3, 0>},        {"no-lds-reads", run<false, 4, 0>},
-      {"contiguous-io", run<false, 10, 0>},
+      {"wide-stores", run<false, 12, 0>},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   for (int bpc : {4, 6}) {

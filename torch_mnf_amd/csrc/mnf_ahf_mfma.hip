@@ -63,6 +63,33 @@ __device__ __forceinline__ float exp6(float x) {
   return e1 * __builtin_fmaf(tl, ln2, 1.0f);
 }
 
+// Full-line stores.  In the operand layout one store instruction writes 64 bytes of each of 16
+// rows, i.e. it touches 16 cache lines, and store cost on this chip goes with the number of lines
+// an instruction touches (about 9 cycles each; tools/ahf_microbench.hip: the stores cost 20 us of
+// a 140 us layer).  Rows j and j^8 sit in the same 16-lane DPP row, so one row_ror:8 exchange per
+// register turns two float4 slots (g, g+1) of 16 rows into  A: rows 0-7, 128 contiguous bytes
+// each  and  B: rows 8-15  -- 8 lines per instruction instead of 16, same bytes.
+__device__ __forceinline__ float dpp_ror8(float keep, float src, int bank_mask_hi) {
+  // lanes 8..15 of every 16-lane row (bank_mask 0xC) or lanes 0..7 (0x3) take src from lane j^8
+  const int r = bank_mask_hi
+                    ? __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, src), 0x128, 0xF, 0xC, false)
+                    : __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, src), 0x128, 0xF, 0x3, false);
+  return __builtin_bit_cast(float, r);
+}
+// v0 = this lane's float4 of slot g, v1 = of slot g+1 (row j, floats 16g+4q.. and 16(g+1)+4q..).
+// ya / yb: this lane's destination in instruction A (row j&7) / B (row 8 + (j&7)).
+__device__ __forceinline__ void store_pair_wide(float* ya, float* yb, bool live_a, bool live_b, const f32x4& v0,
+                                                const f32x4& v1) {
+  f32x4 a, b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a[r] = dpp_ror8(v0[r], v1[r], 1);  // j < 8: own slot g ; j >= 8: slot g+1 of row j-8
+    b[r] = dpp_ror8(v1[r], v0[r], 0);  // j < 8: slot g of row j+8 ; j >= 8: own slot g+1
+  }
+  if (live_a) *reinterpret_cast<f32x4*>(ya) = a;
+  if (live_b) *reinterpret_cast<f32x4*>(yb) = b;
+}
+
 // (ablation builds replace the MFMA by a pass-through of the accumulator)
 #define MNF_MFMA(a, b, c, x0, x1, x2) \
   ((ABL == 1 || ABL == 5) ? (c) : __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), (x0), (x1), (x2)))
@@ -96,7 +123,8 @@ struct AhfShape {
 constexpr int kAhfWaves = 4;  // 256-thread workgroups: one wave per SIMD, so residency moves in steps of one wave/SIMD
 
 // ABL != 0 only in tools/ahf_microbench.hip (ablation builds: 1 = no MFMA chain, 2 = no HBM
-// traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS, 5 = copy only, 6 = no stores);
+// traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS, 5 = copy only, 6 = no stores,
+// 7-9 = single stores off, 12 = full-line stores through a DPP row exchange);
 // the library uses ABL = 0.
 template <int H, int HID, bool INV, bool PREFETCH, int ABL = 0>
 __global__ void __launch_bounds__(kAhfWaves * 64)
@@ -149,6 +177,15 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     const int64_t rowc = live ? row : rows - 1;
     float* yr = y + rowc * dim + 4 * q;
     if (ABL == 10) yr = y + (int64_t)tile * 16 * dim + lane * 4 - cond_off;
+    // wide stores: instruction A serves row (j & 7) of the tile, B row 8 + (j & 7); the lanes with
+    // j >= 8 carry the second 64 bytes of the line
+    // Measured (interleaved rounds, d = 64): wide 141.7 us vs narrow 135.4 us -- the extra DPP moves
+    // cost more than the halved line count saves, so the library uses the narrow form (ABL 12 = wide).
+    constexpr bool WIDE = (G % 2 == 0) && ABL == 12;
+    const int64_t row_a = (int64_t)tile * 16 + (j & 7), row_b = row_a + 8;
+    const bool live_a = row_a < rows && (ABL != 2 && ABL != 6), live_b = row_b < rows && (ABL != 2 && ABL != 6);
+    float* ya = y + (live_a ? row_a : rows - 1) * dim + 16 * (j >> 3) + 4 * q;
+    float* yb = y + (live_b ? row_b : rows - 1) * dim + 16 * (j >> 3) + 4 * q;
     // PREFETCH: the next tile's rows are requested into the SAME registers as soon as their
     // last reader of this tile has issued (cnd: after layer 1; act[m]: after output step m), so
     // the loads fly under the remaining MFMA chain at no register cost.  One tile past the end
@@ -161,7 +198,13 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
       for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * g);
     }
-    if (live && ABL != 8) {
+    if (WIDE) {
+      if (ABL != 8) {
+#pragma unroll
+        for (int g = 0; g + 1 < G; g += 2)
+          store_pair_wide(ya + cond_off + 16 * g, yb + cond_off + 16 * g, live_a, live_b, cnd[g], cnd[g + 1]);
+      }
+    } else if (live && ABL != 8) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g) = cnd[g];
     }
@@ -249,6 +292,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       for (int r = 0; r < 4; ++r) h3[m][r] = leaky2(h3[m][r]);
 
     // ---- layer 4 + affine transform, 16 output dims per step
+    f32x4 o_even = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < G; ++m) {
       f32x4 s4 = B4[4 * (btile++)];
@@ -272,7 +316,17 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
         ld += s4[r];
         sq = fmaf(o[r], o[r], sq);
       }
-      if (live && (ABL != 9 || o[0] == 1.2345e30f)) *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
+      if (WIDE) {
+        if (m & 1) {
+          const bool keep = (ABL != 9 || o[0] == 1.2345e30f);
+          store_pair_wide(ya + act_off + 16 * (m - 1), yb + act_off + 16 * (m - 1), live_a && keep, live_b && keep,
+                          o_even, o);
+        } else {
+          o_even = o;
+        }
+      } else if (live && (ABL != 9 || o[0] == 1.2345e30f)) {
+        *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
+      }
       if (PREFETCH) act[m] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * m);
     }
     if (log_det) {
