@@ -167,6 +167,13 @@ int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_l
                         float* grad_flat, const float* flat, int64_t rows, int dim, int parity,
                         int inverse, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                         void* stream);
+int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                   float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
+                   int inverse, int n_hidden, const int* hidden_host, void* stream);
+/* mask == NULL: the mask of the seeded forward call is regenerated from `seed`. */
+int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x,
+                 const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,
+                 int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
 /* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
 int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,

@@ -57,6 +57,83 @@ def test_affine_half_gradients(amd, O, dim, kw, inverse):
         assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
 
 
+@pytest.mark.parametrize("cfg", [(32, 8, 8), (6, 5, 8), (2, 8, 16)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_gradients(amd, O, cfg, inverse):
+    dim, K, n_h = cfg
+    sd = recipes.nsf_cl_params(71 + dim, dim, K, n_h)
+    rows = 200
+    x_cpu = recipes.gaussian(72 + dim, rows, dim, scale=1.3)
+    x_cpu[0, :] = 5.0          # a row in the identity tails: gradient 1, no parameter gradient
+    x_cpu.requires_grad_(True)
+    w_y = recipes.gaussian(73, rows, dim)
+    w_l = recipes.gaussian(74, rows, 1)[:, 0]
+    p = leaf(sd)
+    y, ld = O.nsf_cl(x_cpu, p, K, 3.0, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = (f.inverse if inverse else f.forward)(x)
+    assert yg.requires_grad and ldg.requires_grad
+    ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    assert_close(x.grad, x_cpu.grad, 1e-4, "grad_x")
+    for name, prm in f.named_parameters():
+        assert_close(prm.grad, p[name].grad, 1e-4, f"grad {name}")
+
+
+@pytest.mark.parametrize("dim", [50, 800])
+def test_rnvp_gradients(amd, O, dim):
+    sd = recipes.rnvp_params(81 + dim, dim, 50)
+    rows = 70
+    z_cpu = recipes.gaussian(82 + dim, rows, dim).requires_grad_(True)
+    mask = recipes.bernoulli_mask(83, rows, dim)
+    w_x = recipes.gaussian(84, rows, dim)
+    w_l = recipes.gaussian(85, rows, 1)[:, 0]
+    p = leaf(sd)
+    xr, ld = O.rnvp(z_cpu, p, mask)
+    ((xr * w_x).sum() + (ld * w_l).sum()).backward()
+
+    f = amd.RNVP(dim, h_sizes=(50,))
+    f.load_state_dict(sd)
+    f.to(DEV)
+    z = z_cpu.detach().to(DEV).requires_grad_(True)
+    xg, ldg = f.forward(z, mask=mask.to(DEV))
+    ((xg * w_x.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    assert_close(z.grad, z_cpu.grad, 5e-5, "grad_z")
+    for name, prm in f.named_parameters():
+        assert_close(prm.grad, p[name].grad, 5e-5, f"grad {name}")
+    # seeded call: backward regenerates the same mask
+    z2 = z_cpu.detach().to(DEV).requires_grad_(True)
+    f.zero_grad()
+    x2, ld2 = f.forward(z2, seed=77)
+    (x2.sum() + ld2.sum()).backward()
+    m77 = f.mask_for(77, rows)
+    z3 = z_cpu.detach().to(DEV).requires_grad_(True)
+    g_seeded = {n: q.grad.clone() for n, q in f.named_parameters()}
+    f.zero_grad()
+    x3, ld3 = f.forward(z3, mask=m77)
+    (x3.sum() + ld3.sum()).backward()
+    assert_close(z2.grad, z3.grad, 1e-6, "seeded grad_z")
+    for n, q in f.named_parameters():
+        assert_close(g_seeded[n], q.grad, 2e-5, f"seeded grad {n}")
+
+
+def test_mnf_linear_kl_and_forward_are_differentiable(amd):
+    """The MNF caller trains: gradients reach q0, the RNVP flows and the weights."""
+    torch.manual_seed(1)
+    layer = amd.MNFLinear(32, 10, h_sizes=(50,)).to(DEV)
+    xin = torch.randn(64, 32, device=DEV)
+    loss = layer.forward(xin).pow(2).mean() + 1e-3 * layer.kl_div()
+    loss.backward()
+    for name, prm in layer.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+    assert float(layer.flow_q.flows[0].s.weight.grad.abs().sum()) > 0
+    assert float(layer.flow_r.flows[0].net[0].weight.grad.abs().sum()) > 0
+
+
 def test_stack_gradients_through_normalizing_flow(amd, O):
     """NLL of a 3-layer stack + ActNorm + Glow: d loss / d parameters vs the oracle's autograd."""
     dim, rows = 8, 257
@@ -106,14 +183,20 @@ def train(model, optim, samples, steps):
     return float(loss)
 
 
-@pytest.mark.parametrize("name,bound", [("rnvp", 236), ("glow", 308), ("glow_actnorm", 246)])
+@pytest.mark.parametrize("name,bound", [("rnvp", 236), ("glow", 308), ("glow_actnorm", 246), ("nsfcl", 207),
+                                        ("nsfcl_actnorm", 184)])
 def test_reference_training_contracts(amd, name, bound):
     """The reference's e2e tests: Adam, 1 step then 70 steps on 128 half-moon points; the loss must
-    fall and end below the reference's bound (tests/test_flows.py:41-50, :53-55, :76-86)."""
+    fall and end below the reference's bound (tests/test_flows.py:41-50, :53-55, :76-99)."""
     torch.manual_seed(0)
     samples = moons(128).to(DEV)
     if name == "rnvp":
         flows = [amd.AffineHalfFlow(dim=2, parity=i % 2 == 0) for i in range(2)]
+    elif name.startswith("nsfcl"):  # tests/test_flows.py:89-99
+        flows = [amd.NSF_CL(dim=2, K=8, B=3, n_h=16) for _ in range(2)]
+        if name == "nsfcl_actnorm":
+            for idx in reversed(range(len(flows))):
+                flows.insert(idx, amd.ActNormFlow(dim=2))
     else:
         flows = [amd.Glow(dim=2) for _ in range(2)]
         if name == "glow_actnorm":

@@ -290,3 +290,412 @@ int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_
 }
 
 }  // extern "C"
+
+// =====================================================================================
+// NSF_CL and RNVP gradients (generic kernels)
+// =====================================================================================
+namespace mnf {
+
+constexpr int kMaxBins = 32;  // spline backward keeps per-bin arrays in private memory
+
+__device__ __forceinline__ float sigmoid_of_softplus_arg(float x) {  // d softplus / dx, threshold 20
+  return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+}
+
+// forward of one spline axis keeping both softmax levels: p1, p2, knots[0..K]
+__device__ __forceinline__ void axis_forward(const float* u, int K, float T, float* p1, float* p2, float* knot) {
+  const float twoT = 2.f * T, c1 = 1.f - kMinBin * (float)K;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, u[k]);
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) { p1[k] = expf(u[k] - m); s += p1[k]; }
+  const float r = 1.f / s;
+  float m2 = -INFINITY;
+  for (int k = 0; k < K; ++k) { p1[k] *= r; m2 = fmaxf(m2, twoT * p1[k]); }
+  float s2 = 0.f;
+  for (int k = 0; k < K; ++k) { p2[k] = expf(twoT * p1[k] - m2); s2 += p2[k]; }
+  const float r2 = 1.f / s2;
+  float c = 0.f;
+  knot[0] = -T;
+  for (int k = 0; k < K; ++k) {
+    p2[k] *= r2;
+    c += kMinBin + c1 * p2[k];
+    knot[k + 1] = (k == K - 1) ? T : twoT * c - T;
+  }
+}
+
+// gradient wrt the K raw parameters of an axis, given the gradients of knot_b and knot_{b+1}
+__device__ __forceinline__ void axis_backward(const float* p1, const float* p2, int K, float T, int b, float g_lo,
+                                              float g_hi, float* g_u) {
+  const float twoT = 2.f * T, c1 = 1.f - kMinBin * (float)K;
+  // knot_i = 2T cum_{i-1} - T for 1 <= i <= K-1 (knot_0, knot_K are constants)
+  float dot2 = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float gf = 0.f;
+    if (b >= 1 && k < b) gf += g_lo;
+    if (b + 1 <= K - 1 && k <= b) gf += g_hi;
+    g_u[k] = c1 * twoT * gf;  // g_p2
+    dot2 += p2[k] * g_u[k];
+  }
+  float dot1 = 0.f;
+  for (int k = 0; k < K; ++k) {
+    g_u[k] = twoT * (p2[k] * (g_u[k] - dot2));  // g_p1 = 2T g_w1
+    dot1 += p1[k] * g_u[k];
+  }
+  for (int k = 0; k < K; ++k) g_u[k] = p1[k] * (g_u[k] - dot1);
+}
+
+// Reverse-mode derivative of rqs_element<true> for one element.  p: 3K-1 raw parameters;
+// g_o, g_l: cotangents of (output, log-derivative); writes g_v and g_p[0..3K-1).
+__device__ void rqs_element_bwd(float v, int K, float T, bool inverse, const float* p, float g_o, float g_l,
+                                float& g_v, float* g_p) {
+  const int P = 3 * K - 1;
+  for (int i = 0; i < P; ++i) g_p[i] = 0.f;
+  if (!((v >= -T) && (v <= T))) {  // identity tails
+    g_v = g_o;
+    return;
+  }
+  float uw[kMaxBins], uh[kMaxBins], p1w[kMaxBins], p2w[kMaxBins], p1h[kMaxBins], p2h[kMaxBins];
+  float xk[kMaxBins + 1], yk[kMaxBins + 1];
+  for (int k = 0; k < K; ++k) { uw[k] = p[k]; uh[k] = p[K + k]; }
+  axis_forward(uw, K, T, p1w, p2w, xk);
+  axis_forward(uh, K, T, p1h, p2h, yk);
+  int b = 0;
+  for (int k = 1; k < K; ++k)
+    if (v >= (inverse ? yk[k] : xk[k])) b = k;
+  const float x0 = xk[b], x1 = xk[b + 1], y0 = yk[b], y1 = yk[b + 1];
+  const float raw0 = (b == 0) ? 0.f : p[2 * K + b - 1], raw1 = (b == K - 1) ? 0.f : p[2 * K + b];
+  const float pad0 = (b == 0) ? kEdgeDerivConst : softplus(raw0);
+  const float pad1 = (b == K - 1) ? kEdgeDerivConst : softplus(raw1);
+  const float d0 = kMinDeriv + softplus(pad0), d1 = kMinDeriv + softplus(pad1);
+  const float w = x1 - x0, h = y1 - y0, delta = h / w;
+  float g_x0 = 0.f, g_x1 = 0.f, g_y0 = 0.f, g_y1 = 0.f, g_d0 = 0.f, g_d1 = 0.f;
+  float g_w = 0.f, g_h = 0.f, g_delta = 0.f;
+  if (!inverse) {
+    const float th = (v - x0) / w, t1 = th * (1.f - th), omt = 1.f - th;
+    const float B = delta * th * th + d0 * t1, N = h * B;
+    const float cv = d0 + d1 - 2.f * delta, Dn = delta + cv * t1;
+    const float A = d1 * th * th + 2.f * delta * t1 + d0 * omt * omt, dn = delta * delta * A;
+    const float gN = g_o / Dn, gDn = -g_o * N / (Dn * Dn) - 2.f * g_l / Dn, g_dn = g_l / dn;
+    g_y0 += g_o;
+    float g_th = 0.f, g_t1 = 0.f;
+    g_delta += g_dn * (2.f * delta * A + delta * delta * 2.f * t1);
+    const float gA = g_dn * delta * delta;
+    g_d1 += gA * th * th; g_d0 += gA * omt * omt; g_th += gA * (2.f * d1 * th - 2.f * d0 * omt); g_t1 += gA * 2.f * delta;
+    g_delta += gDn * (1.f - 2.f * t1); g_d0 += gDn * t1; g_d1 += gDn * t1; g_t1 += gDn * cv;
+    g_h += gN * B;
+    const float gB = gN * h;
+    g_delta += gB * th * th; g_th += gB * 2.f * delta * th; g_d0 += gB * t1; g_t1 += gB * d0;
+    g_th += g_t1 * (1.f - 2.f * th);
+    g_v = g_th / w; g_x0 -= g_th / w; g_w -= g_th * th / w;
+  } else {
+    const float dy = v - y0, cv = d0 + d1 - 2.f * delta;
+    const float a = dy * cv + h * (delta - d0), bb = h * d0 - dy * cv, c = -delta * dy;
+    const float disc = bb * bb - 4.f * a * c, sq = sqrtf(disc), den = -bb - sq, xi = 2.f * c / den;
+    const float t1 = xi * (1.f - xi), omx = 1.f - xi, Dn = delta + cv * t1;
+    const float A = d1 * xi * xi + 2.f * delta * t1 + d0 * omx * omx, dn = delta * delta * A;
+    float g_xi = g_o * w, g_t1 = 0.f, g_cv = 0.f;
+    g_w += g_o * xi; g_x0 += g_o;
+    const float gDn = 2.f * g_l / Dn, g_dn = -g_l / dn;
+    g_delta += g_dn * (2.f * delta * A + 2.f * delta * delta * t1);
+    const float gA = g_dn * delta * delta;
+    g_d1 += gA * xi * xi; g_d0 += gA * omx * omx; g_xi += gA * (2.f * d1 * xi - 2.f * d0 * omx); g_t1 += gA * 2.f * delta;
+    g_delta += gDn; g_cv += gDn * t1; g_t1 += gDn * cv;
+    g_xi += g_t1 * (1.f - 2.f * xi);
+    float g_c = 2.f * g_xi / den;
+    const float g_den = -g_xi * xi / den;
+    float g_b = -g_den;
+    const float g_disc = -g_den / (2.f * sq);
+    g_b += 2.f * bb * g_disc;
+    const float g_a = -4.f * c * g_disc;
+    g_c += -4.f * a * g_disc;
+    float g_dy = 0.f;
+    g_delta += -dy * g_c; g_dy += -delta * g_c;
+    g_h += d0 * g_b; g_d0 += h * g_b; g_dy += -cv * g_b; g_cv += -dy * g_b;
+    g_dy += cv * g_a; g_cv += dy * g_a; g_h += (delta - d0) * g_a; g_delta += h * g_a; g_d0 += -h * g_a;
+    g_d0 += g_cv; g_d1 += g_cv; g_delta += -2.f * g_cv;
+    g_v = g_dy; g_y0 -= g_dy;
+  }
+  g_h += g_delta / w; g_w -= g_delta * delta / w;
+  g_y1 += g_h; g_y0 -= g_h; g_x1 += g_w; g_x0 -= g_w;
+  // derivative parameters
+  if (b > 0) g_p[2 * K + b - 1] = g_d0 * sigmoid_of_softplus_arg(pad0) * sigmoid_of_softplus_arg(raw0);
+  if (b < K - 1) g_p[2 * K + b] = g_d1 * sigmoid_of_softplus_arg(pad1) * sigmoid_of_softplus_arg(raw1);
+  axis_backward(p1w, p2w, K, T, b, g_x0, g_x1, g_p);
+  axis_backward(p1h, p2h, K, T, b, g_y0, g_y1, g_p + K);
+}
+
+struct NsfBwdArgs {
+  const float* x;
+  const float* grad_y;
+  const float* grad_ld;
+  float* grad_x;
+  float* grad_flat;
+  const float* flat;
+  int64_t rows;
+  int dim, K, inverse;
+  float T;
+  int R, maxw, act_floats, ldp;
+  int act_off[MNF_MAX_LINEAR];
+  NetDesc f1, f2;
+};
+
+// one half-step forward on LDS rows: vals <- spline(vals; net(cond)); acts keeps the net's layers
+__device__ __forceinline__ void nsf_half_forward(const float* flat, const NetDesc& nd, const float* cond, float* vals,
+                                                 float* acts, const int* act_off, int H, int K, float T, bool inverse,
+                                                 int R) {
+  mlp_forward_keep(flat, nd, cond, H, acts, act_off, R);
+  const float* params = acts + act_off[nd.n_lin - 1] * R;  // [R][(3K-1) H]
+  const int P = 3 * K - 1;
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const float* p = params + r * (P * H) + j * P;
+    float o, l;
+    rqs_element<true>(vals[idx], K, T, inverse, [&](int k) { return p[k]; }, [&](int k) { return p[K + k]; },
+                      [&](int k) { return p[2 * K + k]; }, o, l);
+    vals[idx] = o;
+  }
+  __syncthreads();
+}
+
+// backward of one half-step.  vals_in: the half BEFORE the spline; g_vals: cotangent of the half
+// AFTER it (in/out: becomes the cotangent of vals_in); g_cond += through the net.
+__device__ __forceinline__ void nsf_half_backward(const float* flat, float* grad_flat, const NetDesc& nd,
+                                                  const float* cond, const float* vals_in, float* g_vals, float* g_cond,
+                                                  const float* g_ld_rows, float* acts, const int* act_off, float* dA,
+                                                  float* dB, int H, int K, float T, bool inverse, int R) {
+  const int P = 3 * K - 1;
+  const float* params = acts + act_off[nd.n_lin - 1] * R;
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    float gv;
+    rqs_element_bwd(vals_in[idx], K, T, inverse, params + r * (P * H) + j * P, g_vals[idx], g_ld_rows[r], gv,
+                    dA + r * (P * H) + j * P);
+    g_vals[idx] = gv;
+  }
+  __syncthreads();
+  mlp_backward(flat, grad_flat, nd, cond, H, acts, act_off, dA, dB, g_cond, R);
+}
+
+__global__ void __launch_bounds__(kBwdThreads) nsf_bwd_kernel(NsfBwdArgs a) {
+  const int H = a.dim / 2;
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* lo0 = bsmem;                 // lower half, input
+  float* up0 = lo0 + a.R * H;         // upper half, input
+  float* mid = up0 + a.R * H;         // the half after the first half-step
+  float* g_lo = mid + a.R * H;
+  float* g_up = g_lo + a.R * H;
+  float* g_ldr = g_up + a.R * H;      // [R]
+  float* acts = g_ldr + a.R;          // [act_floats][R]
+  float* dA = acts + a.R * a.act_floats;
+  float* dB = dA + a.R * a.maxw;
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const int64_t g = (row0 + r) * a.dim;
+    lo0[idx] = a.x[g + j];
+    up0[idx] = a.x[g + H + j];
+    mid[idx] = a.inverse ? a.x[g + j] : a.x[g + H + j];
+    g_lo[idx] = a.grad_y ? a.grad_y[g + j] : 0.f;
+    g_up[idx] = a.grad_y ? a.grad_y[g + H + j] : 0.f;
+  }
+  for (int r = threadIdx.x; r < R; r += blockDim.x) g_ldr[r] = a.grad_ld ? a.grad_ld[row0 + r] : 0.f;
+  __syncthreads();
+  if (!a.inverse) {
+    // forward: up1 = S(up0; f1(lo0)); lo1 = S(lo0; f2(up1)).  Reverse: f2 step first.
+    nsf_half_forward(a.flat, a.f1, lo0, mid, acts, a.act_off, H, a.K, a.T, false, R);        // mid = up1
+    mlp_forward_keep(a.flat, a.f2, mid, H, acts, a.act_off, R);
+    nsf_half_backward(a.flat, a.grad_flat, a.f2, mid, lo0, g_lo, g_up, g_ldr, acts, a.act_off, dA, dB, H, a.K, a.T,
+                      false, R);                                                              // g_lo -> wrt lo0 (direct); g_up += via f2
+    mlp_forward_keep(a.flat, a.f1, lo0, H, acts, a.act_off, R);
+    nsf_half_backward(a.flat, a.grad_flat, a.f1, lo0, up0, g_up, g_lo, g_ldr, acts, a.act_off, dA, dB, H, a.K, a.T,
+                      false, R);
+  } else {
+    // inverse: lo1 = S^-1(lo0; f2(up0)); up1 = S^-1(up0; f1(lo1)).  Reverse: f1 step first.
+    nsf_half_forward(a.flat, a.f2, up0, mid, acts, a.act_off, H, a.K, a.T, true, R);         // mid = lo1
+    mlp_forward_keep(a.flat, a.f1, mid, H, acts, a.act_off, R);
+    nsf_half_backward(a.flat, a.grad_flat, a.f1, mid, up0, g_up, g_lo, g_ldr, acts, a.act_off, dA, dB, H, a.K, a.T,
+                      true, R);
+    mlp_forward_keep(a.flat, a.f2, up0, H, acts, a.act_off, R);
+    nsf_half_backward(a.flat, a.grad_flat, a.f2, up0, lo0, g_lo, g_up, g_ldr, acts, a.act_off, dA, dB, H, a.K, a.T,
+                      true, R);
+  }
+  for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
+    const int r = idx / H, j = idx - r * H;
+    const int64_t g = (row0 + r) * a.dim;
+    a.grad_x[g + j] = g_lo[idx];
+    a.grad_x[g + H + j] = g_up[idx];
+  }
+}
+
+struct RnvpBwdArgs {
+  const float* z;
+  const float* mask;
+  const float* grad_x;
+  const float* grad_ld;
+  float* grad_z;
+  float* grad_flat;
+  const float* flat;
+  int64_t rows;
+  int dim, R, maxw, act_floats;
+  int t_w, t_b, s_w, s_b;
+  uint64_t seed;
+  int act_off[MNF_MAX_LINEAR];
+  NetDesc net;
+};
+
+__global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
+  const int d = a.dim, hl = a.net.sizes[a.net.n_lin];
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* kept = bsmem;                 // [R][d]  m z
+  float* g_t = kept + a.R * d;         // [R][d]
+  float* g_s = g_t + a.R * d;          // [R][d]
+  float* g_kept = g_s + a.R * d;       // [R][d]
+  float* acts = g_kept + a.R * d;      // [act_floats][R]
+  float* dA = acts + a.R * a.act_floats;
+  float* dB = dA + a.R * a.maxw;
+  auto mask_of = [&](int r, int j) {
+    return a.mask ? a.mask[(row0 + r) * d + j] : rnvp_mask_bit(a.seed, row0 + r, j);
+  };
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    const int r = idx / d, j = idx - r * d;
+    kept[idx] = mask_of(r, j) * a.z[(row0 + r) * d + j];
+    g_kept[idx] = 0.f;
+  }
+  __syncthreads();
+  mlp_forward_keep(a.flat, a.net, kept, d, acts, a.act_off, R);
+  const float* y = acts + a.act_off[a.net.n_lin - 1] * R;  // [R][hl]
+  const float* Wt = a.flat + a.t_w;
+  const float* Ws = a.flat + a.s_w;
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    const int r = idx / d, j = idx - r * d;
+    const int64_t gi = (row0 + r) * d + j;
+    float shift = a.flat[a.t_b + j], scale = a.flat[a.s_b + j];
+    for (int k = 0; k < hl; ++k) {
+      shift = fmaf(Wt[(size_t)j * hl + k], y[r * hl + k], shift);
+      scale = fmaf(Ws[(size_t)j * hl + k], y[r * hl + k], scale);
+    }
+    const float m = mask_of(r, j), zz = a.z[gi], gate = sigmoidf(scale);
+    const float G = a.grad_x ? a.grad_x[gi] : 0.f, gl = a.grad_ld ? a.grad_ld[row0 + r] : 0.f;
+    // x = (1-m) z g + (1-g) t + m z ; ld = sum (1-m) log g
+    g_t[idx] = G * (1.f - gate);
+    g_s[idx] = (G * ((1.f - m) * zz - shift) * gate + gl * (1.f - m)) * (1.f - gate);
+    a.grad_z[gi] = G * ((1.f - m) * gate + m);
+  }
+  __syncthreads();
+  if (a.grad_flat) {
+    for (int idx = threadIdx.x; idx < d * hl; idx += blockDim.x) {
+      const int j = idx / hl, k = idx - j * hl;
+      float at = 0.f, as = 0.f;
+      for (int r = 0; r < R; ++r) {
+        at = fmaf(g_t[r * d + j], y[r * hl + k], at);
+        as = fmaf(g_s[r * d + j], y[r * hl + k], as);
+      }
+      atomicAdd(a.grad_flat + a.t_w + idx, at);
+      atomicAdd(a.grad_flat + a.s_w + idx, as);
+    }
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+      float at = 0.f, as = 0.f;
+      for (int r = 0; r < R; ++r) { at += g_t[r * d + j]; as += g_s[r * d + j]; }
+      atomicAdd(a.grad_flat + a.t_b + j, at);
+      atomicAdd(a.grad_flat + a.s_b + j, as);
+    }
+  }
+  for (int idx = threadIdx.x; idx < R * hl; idx += blockDim.x) {  // g_y -> dA [R][hl]
+    const int r = idx / hl, k = idx - r * hl;
+    float acc = 0.f;
+    for (int j = 0; j < d; ++j) {
+      acc = fmaf(Wt[(size_t)j * hl + k], g_t[r * d + j], acc);
+      acc = fmaf(Ws[(size_t)j * hl + k], g_s[r * d + j], acc);
+    }
+    dA[idx] = acc;
+  }
+  __syncthreads();
+  mlp_backward(a.flat, a.grad_flat, a.net, kept, d, acts, a.act_off, dA, dB, g_kept, R);
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    const int r = idx / d, j = idx - r * d;
+    a.grad_z[(row0 + r) * d + j] += mask_of(r, j) * g_kept[idx];
+  }
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                   const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                   const int* hidden, void* stream) {
+  if (!x || !grad_x || !flat || rows < 0 || dim < 2 || (dim & 1) || K < 2 || K > kMaxBins || !(tail_bound > 0.f) ||
+      !hidden_ok(n_hidden, hidden))
+    return K > kMaxBins ? MNF_ERR_UNSUPPORTED : MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  NsfBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat; a.flat = flat;
+  a.rows = rows; a.dim = dim; a.K = K; a.inverse = inverse != 0; a.T = tail_bound;
+  const int H = dim / 2;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = H;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  sizes[n_hidden + 1] = ((3 * K - 1) * dim) / 2;
+  int64_t off = fill_net(a.f1, n_hidden + 2, sizes, 0);
+  fill_net(a.f2, n_hidden + 2, sizes, off);
+  int act = 0, maxw = H;
+  for (int l = 0; l <= n_hidden; ++l) {
+    a.act_off[l] = act;
+    act += sizes[l + 1];
+    if (sizes[l + 1] > maxw) maxw = sizes[l + 1];
+  }
+  a.act_floats = act; a.maxw = maxw; a.ldp = sizes[n_hidden + 1];
+  const int per_row = 5 * H + 1 + act + 2 * maxw;
+  int R = kBwdLdsFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 32) R = 32;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nsf_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
+                     (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                 float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
+                 const int* hidden, void* stream) {
+  if (!z || !grad_z || !flat || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  RnvpBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = z; a.mask = mask; a.seed = seed; a.grad_x = grad_x; a.grad_ld = grad_ld; a.grad_z = grad_z;
+  a.grad_flat = grad_flat; a.flat = flat; a.rows = rows; a.dim = dim;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = dim;
+  for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
+  int64_t off = fill_net(a.net, n_hidden + 1, sizes, 0);
+  const int hl = hidden[n_hidden - 1];
+  a.t_w = (int)off; off += (int64_t)hl * dim;
+  a.t_b = (int)off; off += dim;
+  a.s_w = (int)off; off += (int64_t)hl * dim;
+  a.s_b = (int)off;
+  int act = 0, maxw = dim;
+  for (int l = 0; l < n_hidden; ++l) {
+    a.act_off[l] = act;
+    act += sizes[l + 1];
+    if (sizes[l + 1] > maxw) maxw = sizes[l + 1];
+  }
+  a.act_floats = act; a.maxw = maxw;
+  const int per_row = 4 * dim + act + 2 * maxw;
+  int R = kBwdLdsFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 32) R = 32;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
+                     (hipStream_t)stream, a);
+  return check_launch();
+}
+
+}  // extern "C"

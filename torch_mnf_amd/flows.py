@@ -82,22 +82,6 @@ def _empty_result(x: Tensor, accum: Tensor | None):
     return torch.empty_like(x), (None if accum is not None else x.new_empty(0))
 
 
-_warned_autograd = False
-
-
-def _note_no_autograd(module: nn.Module, x: Tensor) -> None:
-    global _warned_autograd
-    if _warned_autograd or not torch.is_grad_enabled():
-        return
-    if x.requires_grad or any(p.requires_grad for p in module.parameters()):
-        _warned_autograd = True
-        warnings.warn(
-            f"torch_mnf_amd: {type(module).__name__} has no backward kernel yet (AffineHalfFlow, "
-            "AffineConstantFlow/ActNormFlow and Glow do); its outputs are detached from autograd.",
-            stacklevel=3,
-        )
-
-
 def _wants_grad(module: nn.Module, x: Tensor) -> bool:
     return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
@@ -133,6 +117,66 @@ class _AffineHalfFn(torch.autograd.Function):
             _ptr(flat) if flat.numel() else None, x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse),
             len(m.h_sizes), m._hid, int(m.scale), int(m.shift), _stream()))
         return grad_x, (grad_flat if flat.numel() else None), None, None
+
+
+class _NsfFn(torch.autograd.Function):
+    """NSF_CL with gradients (mnf_nsf_cl_bwd: recompute both half-steps, reverse-mode through the
+    spline and the conditioner nets)."""
+
+    @staticmethod
+    def forward(ctx, x, flat_with_grad, module, inverse):
+        flat, image = module._packed(x.device)
+        y = torch.empty_like(x)
+        ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), x.shape[0], module.dim,
+            module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
+            int(module.force_generic), _stream()))
+        ctx.module, ctx.inverse = module, inverse
+        ctx.save_for_backward(x, flat)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_ld):
+        x, flat = ctx.saved_tensors
+        m = ctx.module
+        gy = None if grad_y is None else grad_y.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_x = torch.empty_like(x)
+        grad_flat = torch.zeros_like(flat)
+        _lib.check("mnf_nsf_cl_bwd", _lib.load().mnf_nsf_cl_bwd(
+            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
+            x.shape[0], m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid, _stream()))
+        return grad_x, grad_flat, None, None
+
+
+class _RnvpFn(torch.autograd.Function):
+    """RNVP with gradients; the backward pass sees the same mask (explicit or regenerated from the seed)."""
+
+    @staticmethod
+    def forward(ctx, z, flat_with_grad, module, mask, seed):
+        flat, image = module._packed(z.device)
+        x = torch.empty_like(z)
+        ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
+            z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), z.shape[0],
+            module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _stream()))
+        ctx.module, ctx.seed, ctx.mask = module, seed, mask
+        ctx.save_for_backward(z, flat)
+        return x, ld
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_ld):
+        z, flat = ctx.saved_tensors
+        m = ctx.module
+        gx = None if grad_x is None else grad_x.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_z = torch.empty_like(z)
+        grad_flat = torch.zeros_like(flat)
+        _lib.check("mnf_rnvp_bwd", _lib.load().mnf_rnvp_bwd(
+            z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
+            flat.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
+        return grad_z, grad_flat, None, None, None
 
 
 class _AffineConstFn(torch.autograd.Function):
@@ -338,10 +382,15 @@ class NSF_CL(_TwoWayFlow):
         return idx
 
     def _run(self, x, inverse, accum):
+        if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            xg = _grad_input(x)
+            if xg.shape[1] != self.dim:
+                raise ValueError(f"expected dim {self.dim}, got {xg.shape[1]}")
+            flat = torch.cat([p.reshape(-1) for p in self._packed_params()])
+            return _NsfFn.apply(xg, flat, self, bool(inverse))
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
-        _note_no_autograd(self, x)
         if x.shape[0] == 0:
             return _empty_result(x, accum)
         flat, image = self._packed(x.device)
@@ -412,10 +461,11 @@ class RNVP(_HipFlow):
     def _run(self, z, inverse, accum, mask: Tensor | None = None, seed: int | None = None):
         if inverse:
             raise AttributeError("RNVP has no inverse (flows/rnvp.py defines forward only)")
+        want_grad = accum is None and isinstance(z, Tensor) and z.is_cuda and z.shape[0] > 0 and _wants_grad(self, z)
+        zin = z
         z = _device_input(z, "input")
         if z.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {z.shape[1]}")
-        _note_no_autograd(self, z)
         if z.shape[0] == 0:
             return _empty_result(z, accum)
         if mask is not None:
@@ -424,6 +474,9 @@ class RNVP(_HipFlow):
                 raise ValueError("mask must have the shape of z")
         elif seed is None:  # one draw from torch's global generator per call
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        if want_grad:
+            flat_g = torch.cat([p.reshape(-1) for p in self._packed_params()])
+            return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF)
         flat, image = self._packed(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
@@ -622,7 +675,8 @@ class NormalizingFlow(nn.Module):
                 # last layer also emits |z|^2 per row for the standard-normal epilogue
                 self._last_sqnorm = torch.empty(x.size(0), device=x.device)
                 x, _ = flow._run(x, inverse, log_det, self._last_sqnorm)
-            elif isinstance(flow, (AffineHalfFlow, AffineConstantFlow, Glow)) and _wants_grad(flow, x):
+            elif isinstance(flow, _HipFlow) and (inverse is False or isinstance(flow, _TwoWayFlow)) \
+                    and _wants_grad(flow, x):
                 x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
                 log_det = log_det + ld
             elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):

@@ -46,18 +46,26 @@ class MNFLinear(nn.Module):
         if eps is None:
             eps = torch.randn(batch_size, self.n_in, device=dev)
         eps = eps.to(dev, torch.float32).contiguous()
-        z0 = torch.empty_like(eps)
-        if eps.shape[0] > 0:
-            _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
-                self.q0_mean.detach().contiguous().data_ptr(), self.q0_log_var.detach().contiguous().data_ptr(),
-                eps.data_ptr(), z0.data_ptr(), eps.shape[0], self.n_in, _stream()))
+        if torch.is_grad_enabled() and (self.q0_mean.requires_grad or self.q0_log_var.requires_grad):
+            # training: the two-parameter prologue stays on autograd (it is O(rows*n_in) elementwise)
+            z0 = self.q0_mean + self.q0_log_var.exp().sqrt() * eps
+        else:
+            z0 = torch.empty_like(eps)
+            if eps.shape[0] > 0:
+                _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
+                    self.q0_mean.detach().contiguous().data_ptr(), self.q0_log_var.detach().contiguous().data_ptr(),
+                    eps.data_ptr(), z0.data_ptr(), eps.shape[0], self.n_in, _stream()))
         if masks is None:
             zs, log_det = self.flow_q.forward(z0)
         else:  # same loop as NormalizingFlow.forward with the masks handed to each RNVP
             log_det = torch.zeros(z0.shape[0], device=dev)
             zs = [z0]
             for flow, m in zip(self.flow_q.flows, masks):
-                z, _ = flow._run(zs[-1], False, log_det, m)
+                if torch.is_grad_enabled() and z0.requires_grad:
+                    z, ld = flow._run(zs[-1], False, None, m)
+                    log_det = log_det + ld
+                else:
+                    z, _ = flow._run(zs[-1], False, log_det, m)
                 zs.append(z)
         return zs[-1], log_det.squeeze()
 
