@@ -192,6 +192,16 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         events, model.layer_events = model.layer_events, None
 
+    # the other direction (sampling: z -> x), outside the timed region, for the record
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.steps // 2)):
+            xs_fwd, _ = model.forward(x)
+        torch.cuda.synchronize()
+        fwd_rate = rows * max(1, args.steps // 2) / (time.perf_counter() - t1)
+        del xs_fwd
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,6 +248,7 @@ def main() -> None:
                 * rows / avg_kernel_s / 1e12,
             },
             "mean_log_prob": gpu_mean,
+            "forward_direction_samples_per_s_per_gpu": fwd_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
             info, cpu_mean, n = cpu_baseline(layers, dim, x)

@@ -119,6 +119,47 @@ def test_affine_half_overflow_matches_reference_semantics(amd, O):
     assert torch.equal(torch.isfinite(y).cpu(), torch.isfinite(ref_y))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_generic_kernels_random_shapes_vs_oracle(amd, O, seed):
+    """Seeded sweep over shapes only the generic kernels serve: odd dims, 0-3 hidden layers of
+    assorted widths, K from 2 to 12, row counts around the workgroup tile."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([2, 4, 6, 10, 18, 34, 50]))
+    rows = int(rng.choice([1, 3, 63, 64, 65, 257]))
+    h_sizes = tuple(int(v) for v in rng.integers(1, 40, size=int(rng.integers(0, 4))))
+    sd = recipes.affine_half_params(2000 + seed, dim, h_sizes=h_sizes, s_last_gain=2.0)
+    x = recipes.gaussian(3000 + seed, rows, dim)
+    parity = bool(seed % 2)
+    f = ahf_module(amd, sd, dim, parity, h_sizes=h_sizes)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
+        y, ld = f.forward(cuda(x), inverse=inverse)
+        assert_close(y, ref_y, RTOL, f"ahf d={dim} h={h_sizes} rows={rows}")
+        assert_close(ld, ref_ld, RTOL, "ahf ld")
+    K = int(rng.choice([2, 3, 5, 8, 12]))
+    n_h = int(rng.choice([3, 8, 13]))
+    sdn = recipes.nsf_cl_params(4000 + seed, dim, K, n_h)
+    g = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    g.load_state_dict(sdn)
+    g.to(DEV)
+    xs = recipes.gaussian(5000 + seed, rows, dim, scale=1.5)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.nsf_cl(xs, sdn, K, 3.0, inverse)
+        y, ld = (g.inverse if inverse else g.forward)(cuda(xs))
+        assert_close(y, ref_y, 2e-5, f"nsf d={dim} K={K} n_h={n_h} rows={rows}")
+        assert_close(ld, ref_ld, 2e-5 if abs(float(ref_ld.abs().max())) > 1e-3 else 1.0, "nsf ld")
+    hq = int(rng.choice([7, 30, 50]))
+    sdr = recipes.rnvp_params(6000 + seed, dim, hq)
+    r = amd.RNVP(dim, h_sizes=(hq,))
+    r.load_state_dict(sdr)
+    r.to(DEV)
+    mask = recipes.bernoulli_mask(7000 + seed, rows, dim)
+    ref_x, ref_ld = O.rnvp(x, sdr, mask)
+    xg, ldg = r.forward(cuda(x), mask=cuda(mask))
+    assert_close(xg, ref_x, RTOL, f"rnvp d={dim} h={hq}")
+    assert_close(ldg, ref_ld, RTOL, "rnvp ld")
+
+
 # ------------------------------------------------------------------ stacks (C1, C2, C4)
 def build_ahf_stack(amd, layers, dim):
     flows = []
