@@ -32,11 +32,11 @@ static float run(const float* x, float* y, float* ld, const float* img, int64_t 
   const int blocks = 256 * blocks_per_cu;
   const int acc = WAVES_CAP ? 0 : 1;  // (template slot reused: 1 = run with accumulate = 0)
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(kAhfWaves * 64), 0, 0, x, y, ld,
+    hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(ahf_waves<32>() * 64), 0, 0, x, y, ld,
                        nullptr, img, rows, 0, acc);
   hipEventRecord(e0);
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(kAhfWaves * 64), 0, 0, x, y, ld,
+    hipLaunchKernelGGL((ahf_mfma_kernel<32, 24, true, PF, ABL>), dim3(blocks), dim3(ahf_waves<32>() * 64), 0, 0, x, y, ld,
                        nullptr, img, rows, 0, acc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);

@@ -120,14 +120,19 @@ struct AhfShape {
   static constexpr int IMAGE_FLOATS = A_FLOATS + N_BIAS_TILES * 16;
 };
 
-constexpr int kAhfWaves = 4;  // 256-thread workgroups: one wave per SIMD, so residency moves in steps of one wave/SIMD
+// Waves per workgroup.  Up to d = 64 the 25 KB image allows six 256-thread workgroups per CU (one
+// wave per SIMD each, so residency moves in steps of one wave/SIMD).  From d = 128 the image is
+// 38-63 KB and LDS, not registers, caps residency: 512-thread workgroups share one image between
+// twice as many waves.
+template <int H>
+constexpr int ahf_waves() { return H >= 64 ? 8 : 4; }
 
 // ABL != 0 only in tools/ahf_microbench.hip (ablation builds: 1 = no MFMA chain, 2 = no HBM
 // traffic, 3 = no exp/divide, 4 = A operands not re-read from LDS, 5 = copy only, 6 = no stores,
 // 7-9 = single stores off, 12 = full-line stores through a DPP row exchange);
 // the library uses ABL = 0.
 template <int H, int HID, bool INV, bool PREFETCH, int ABL = 0>
-__global__ void __launch_bounds__(kAhfWaves * 64)
+__global__ void __launch_bounds__(ahf_waves<H>() * 64)
 ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
                 float* __restrict__ ysq, const float* __restrict__ image, int64_t rows, int parity,
                 int accumulate) {
@@ -150,6 +155,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 
   // tiles are counted in 32 bits (rows < 2^35); only the row offset is 64-bit
   const int n_tiles = (int)((rows + 15) >> 4);
+  constexpr int kAhfWaves = ahf_waves<H>();
   const int tile_stride = (int)gridDim.x * kAhfWaves;
   int tile = (int)blockIdx.x * kAhfWaves + wave;
 
@@ -414,6 +420,7 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
   // Measured (tools/ahf_microbench.hip, d = 64, 6 workgroups/CU): 139.5 us without the in-place
   // prefetch, 145 us with it -- six resident waves per SIMD already cover the HBM latency.
   constexpr bool kPrefetch = false;
+  constexpr int kAhfWaves = ahf_waves<H>();
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kAhfWaves - 1) / kAhfWaves;
   // persistent grid: as many workgroups as are resident at once (registers and the LDS image

@@ -48,11 +48,13 @@ struct NsfShape {
 __device__ __forceinline__ float exp_sm(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
-// softplus(x) = max(x, 0) + log(1 + exp(-|x|)); threshold 20 as F.softplus
+// softplus(x) = max(x, 0) + log(1 + exp(-|x|)).  F.softplus switches to the identity above 20;
+// there this form differs from x by log1p(e^-20) = 2e-9 < ulp(20)/2, i.e. it rounds to x as well.
 __device__ __forceinline__ float softplus_fast(float x) {
-  const float t = log_fast(1.f + exp_sm(-__builtin_fabsf(x)));
-  return x > 20.f ? x : __builtin_fmaxf(x, 0.f) + t;
+  return __builtin_fmaxf(x, 0.f) + log_fast(1.f + exp_sm(-__builtin_fabsf(x)));
 }
+// the same for x >= 0 (second level: its argument is a softplus value or the edge constant)
+__device__ __forceinline__ float softplus_pos(float x) { return x + log_fast(1.f + exp_sm(-x)); }
 
 // K+1 knots on [-T, T] from K raw (first-level) parameters: 2T*softmax -> softmax again ->
 // 1e-3 + (1 - 1e-3 K) p -> sequential cumsum -> 2T c - T -> ends forced (spline_flow.py:254-255,
@@ -85,14 +87,11 @@ __device__ __forceinline__ void knots_from_raw(const float (&u)[K], float T, flo
     e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[k], a2, -a2));
     s2 += e[k];
   }
-  const float g = c1 * rcp_fast(s2);
-  float c = 0.f;
+  // knot_{k+1} = knot_k + 2T (1e-3 + (1 - 1e-3 K) p2_k): the cumulative sum carried in knot units
+  const float g = (twoT * c1) * rcp_fast(s2), w0 = twoT * kMinBin;
   knot[0] = -T;
 #pragma unroll
-  for (int k = 0; k < K - 1; ++k) {
-    c += __builtin_fmaf(e[k], g, kMinBin);    // 1e-3 + (1 - 1e-3 K) p2_k, cumulative
-    knot[k + 1] = __builtin_fmaf(twoT, c, -T);
-  }
+  for (int k = 0; k < K - 1; ++k) knot[k + 1] = knot[k] + __builtin_fmaf(e[k], g, w0);
   knot[K] = T;
 }
 
@@ -132,8 +131,8 @@ __device__ __forceinline__ void rqs_regs(float v, float T, const float (&p)[NP],
   // first-level softplus for interior knots (:256), then 1e-3 + softplus(padded value) (:104)
   const float dk_in = bin0 ? kEdgeDerivConst : softplus_fast(r0);
   const float dk1_in = binlast ? kEdgeDerivConst : softplus_fast(r1);
-  const float d_k = kMinDeriv + softplus_fast(dk_in);
-  const float d_k1 = kMinDeriv + softplus_fast(dk1_in);
+  const float d_k = kMinDeriv + softplus_pos(dk_in);
+  const float d_k1 = kMinDeriv + softplus_pos(dk1_in);
 
   const float w_k = x_k1 - x_k, h_k = y_k1 - y_k;
   const float rw = rcp_fast(w_k);
