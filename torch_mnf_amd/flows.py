@@ -740,6 +740,34 @@ class NormalizingFlowModel(NormalizingFlow):
         xs, _ = self.forward(z)
         return xs[-1]
 
+    def graphed_log_prob(self, example: Tensor):
+        """Capture one ``log_prob(x, return_sum=True)`` pass (every coupling kernel + the epilogue)
+        into a HIP graph and return ``replay(x) -> (log_prob, sum)``.
+
+        The C ABI never allocates or synchronises, so the whole pass is capturable; replaying it
+        removes the per-launch host work for small batches (at 4,096 rows the nine-layer pass is
+        launch-bound).  The returned tensors are the graph's static outputs: they are overwritten
+        by the next replay.  Parameters must not change between capture and replay."""
+        static_x = example.detach().clone()
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up: packs the parameter images outside the capture
+                    self.log_prob(static_x, return_sum=True)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.log_prob(static_x, return_sum=True)
+
+        def replay(x: Tensor):
+            static_x.copy_(x)
+            graph.replay()
+            return out
+
+        replay.graph = graph
+        return replay
+
     def log_prob(self, x: Tensor, return_sum: bool = False):
         """log p(x) = log_det + base.log_prob(z) with ONE inverse pass (the reference's callers
         run two, core.py:46-49 vs examples/half_moons.ipynb:183-184).  With a StandardNormal
