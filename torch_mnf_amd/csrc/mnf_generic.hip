@@ -59,6 +59,25 @@ __device__ __forceinline__ void block_mlp(const float* __restrict__ flat, const 
   }
 }
 
+// Small parameter sets (<= kParamLdsFloats) are copied into LDS once per workgroup so the fmaf
+// chains read weights at LDS latency instead of L2 latency; `w_lds` = floats to stage (0 = none).
+constexpr int kParamLdsFloats = 8192;
+
+__device__ __forceinline__ const float* stage_params(const float* __restrict__ flat, float* lds_dst, int n) {
+  if (n <= 0) return flat;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds_dst[i] = flat[i];
+  __syncthreads();
+  return lds_dst;
+}
+
+// rows per workgroup: fill the chip first (>= 2 workgroups per CU), then grow up to `cap`
+static int pick_rows_per_group(int64_t rows, int cap) {
+  int64_t r = (rows + 511) / 512;
+  if (r < 4) r = 4;
+  if (r > cap) r = cap;
+  return (int)r;
+}
+
 // ------------------------------------------------------------------ AffineHalfFlow
 struct AhfArgs {
   const float* x;
@@ -69,6 +88,7 @@ struct AhfArgs {
   int dim, parity, inverse, accumulate, has_scale, has_shift;
   int R;    // rows per workgroup
   int ldw;  // scratch row stride (max hidden width)
+  int w_lds;
   NetDesc s_net, t_net;
 };
 
@@ -82,6 +102,7 @@ __global__ void __launch_bounds__(kThreads) ahf_generic_kernel(AhfArgs a) {
   float* bufA = t_out + a.R * H;      // [R][ldw]
   float* bufB = bufA + a.R * a.ldw;   // [R][ldw]
   const int cond_off = a.parity ? H : 0, act_off = a.parity ? 0 : H;
+  const float* flat = stage_params(a.flat, bufB + a.R * a.ldw, a.w_lds);
 
   for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
     const int r = idx / H, j = idx - r * H;
@@ -92,8 +113,8 @@ __global__ void __launch_bounds__(kThreads) ahf_generic_kernel(AhfArgs a) {
     t_out[idx] = 0.f;
   }
   __syncthreads();
-  if (a.has_scale) block_mlp(a.flat, a.s_net, cond, H, bufA, bufB, a.ldw, s_out, H, R);
-  if (a.has_shift) block_mlp(a.flat, a.t_net, cond, H, bufA, bufB, a.ldw, t_out, H, R);
+  if (a.has_scale) block_mlp(flat, a.s_net, cond, H, bufA, bufB, a.ldw, s_out, H, R);
+  if (a.has_shift) block_mlp(flat, a.t_net, cond, H, bufA, bufB, a.ldw, t_out, H, R);
 
   for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
     const int r = idx / H, j = idx - r * H;
@@ -121,6 +142,7 @@ struct NsfArgs {
   int dim, K, inverse, accumulate;
   float T;
   int R, ldw, ldp;  // ldp = (3K-1)*H, the spline-parameter row stride
+  int w_lds;
   NetDesc f1, f2;
 };
 
@@ -159,6 +181,7 @@ __global__ void __launch_bounds__(kThreads) nsf_generic_kernel(NsfArgs a) {
   float* bufA = lad_sum + a.R;          // [R][ldw]
   float* bufB = bufA + a.R * a.ldw;     // [R][ldw]
   float* params = bufB + a.R * a.ldw;   // [R][ldp]
+  const float* flat = stage_params(a.flat, params + a.R * a.ldp, a.w_lds);
 
   for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
     const int r = idx / H, j = idx - r * H;
@@ -169,14 +192,14 @@ __global__ void __launch_bounds__(kThreads) nsf_generic_kernel(NsfArgs a) {
   __syncthreads();
 
   if (!a.inverse) {  // f1(lower) moves upper, then f2(upper') moves lower (:249-266)
-    block_mlp(a.flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_mlp(flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
     block_spline(params, a.ldp, upper, lad_sum, lad_tmp, H, a.K, a.T, false, R);
-    block_mlp(a.flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_mlp(flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
     block_spline(params, a.ldp, lower, lad_sum, lad_tmp, H, a.K, a.T, false, R);
   } else {  // (:268-285)
-    block_mlp(a.flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_mlp(flat, a.f2, upper, H, bufA, bufB, a.ldw, params, a.ldp, R);
     block_spline(params, a.ldp, lower, lad_sum, lad_tmp, H, a.K, a.T, true, R);
-    block_mlp(a.flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
+    block_mlp(flat, a.f1, lower, H, bufA, bufB, a.ldw, params, a.ldp, R);
     block_spline(params, a.ldp, upper, lad_sum, lad_tmp, H, a.K, a.T, true, R);
   }
   for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
@@ -222,6 +245,7 @@ struct RnvpArgs {
   int R, ldw;
   int t_w, t_b, s_w, s_b;  // float offsets of t.weight, t.bias, s.weight, s.bias
   uint64_t seed;           // used when mask == nullptr
+  int w_lds;
   NetDesc net;
 };
 
@@ -234,6 +258,7 @@ __global__ void __launch_bounds__(kThreads) rnvp_generic_kernel(RnvpArgs a) {
   float* lad = y + a.R * hl;         // [R][d]
   float* bufA = lad + a.R * d;       // [R][ldw]
   float* bufB = bufA + a.R * a.ldw;  // [R][ldw]
+  const float* flat = stage_params(a.flat, bufB + a.R * a.ldw, a.w_lds);
 
   for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
     const int r = idx / d, j = idx - r * d;
@@ -242,12 +267,12 @@ __global__ void __launch_bounds__(kThreads) rnvp_generic_kernel(RnvpArgs a) {
     kept[idx] = m * a.z[g];
   }
   __syncthreads();
-  block_mlp(a.flat, a.net, kept, d, bufA, bufB, a.ldw, y, hl, R);
+  block_mlp(flat, a.net, kept, d, bufA, bufB, a.ldw, y, hl, R);
 
-  const float* Wt = a.flat + a.t_w;
-  const float* bt = a.flat + a.t_b;
-  const float* Ws = a.flat + a.s_w;
-  const float* bs = a.flat + a.s_b;
+  const float* Wt = flat + a.t_w;
+  const float* bt = flat + a.t_b;
+  const float* Ws = flat + a.s_w;
+  const float* bs = flat + a.s_b;
   for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
     const int r = idx / d, j = idx - r * d;
     const int64_t g = (row0 + r) * d + j;
@@ -580,14 +605,16 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
   for (int i = 0; i < n_hidden; ++i) ldw = hidden[i] > ldw ? hidden[i] : ldw;
   a.ldw = ldw;
   const int per_row = 3 * H + 2 * ldw;
-  int R = kLdsBudgetFloats / per_row;
+  a.w_lds = (off <= kParamLdsFloats && off + 4 * per_row <= kLdsBudgetFloats) ? (int)off : 0;
+  int R = (kLdsBudgetFloats - a.w_lds) / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
-  if (R > 64) R = 64;
+  const int want = pick_rows_per_group(rows, 64);
+  if (R > want) R = want;
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ahf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
-                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+                     ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
 }
 
@@ -642,14 +669,17 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const f
   a.ldw = ldw;
   a.ldp = sizes[n - 1];
   const int per_row = 3 * H + 1 + 2 * ldw + a.ldp;
-  int R = kLdsBudgetFloats / per_row;
+  const int64_t n_par = mnf_nsf_cl_flat_floats(dim, K, n_hidden, hidden);
+  a.w_lds = (n_par <= kParamLdsFloats && n_par + 4 * per_row <= kLdsBudgetFloats) ? (int)n_par : 0;
+  int R = (kLdsBudgetFloats - a.w_lds) / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
-  if (R > 64) R = 64;
+  const int want = pick_rows_per_group(rows, 64);
+  if (R > want) R = want;
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(nsf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
-                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+                     ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
 }
 
@@ -729,14 +759,17 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
   for (int i = 0; i + 1 < n_hidden; ++i) ldw = hidden[i] > ldw ? hidden[i] : ldw;
   a.ldw = ldw;
   const int per_row = 2 * dim + hl + 2 * ldw;
-  int R = kLdsBudgetFloats / per_row;
+  const int64_t n_par = (int64_t)a.s_b + dim;
+  a.w_lds = (n_par <= kParamLdsFloats && n_par + 4 * per_row <= kLdsBudgetFloats) ? (int)n_par : 0;
+  int R = (kLdsBudgetFloats - a.w_lds) / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
-  if (R > 32) R = 32;
+  const int want = pick_rows_per_group(rows, 32);
+  if (R > want) R = want;
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rnvp_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
-                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+                     ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
 }
 
