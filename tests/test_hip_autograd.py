@@ -159,7 +159,7 @@ def test_stack_gradients_through_normalizing_flow(amd, O):
     lp = model.log_prob(x_cpu.to(DEV))
     loss = -lp.sum()
     loss.backward()
-    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
     for i, (spec, mod) in enumerate(zip(specs, mods)):
         for name, prm in mod.named_parameters():
             ref = spec["params"][name].grad

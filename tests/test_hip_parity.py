@@ -99,6 +99,41 @@ def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim):
             assert_close(ld, ref_ld, RTOL, "ld")
 
 
+@pytest.mark.parametrize("dim,hid", [(32, 16), (64, 16), (32, 32), (64, 32), (128, 32), (32, 24), (128, 24)])
+def test_affine_half_mfma_shape_matrix(amd, O, dim, hid):
+    """Every (dim, hidden width) pair with a specialised kernel: MFMA result vs the oracle, and the
+    library must actually have picked that kernel (an operand image exists)."""
+    h_sizes = (hid, hid, hid)
+    lib = amd._lib.load()
+    assert lib.mnf_affine_half_image_floats(dim, 3, amd._lib.int_array(h_sizes), 1, 1) > 0
+    sd = recipes.affine_half_params(90 + dim + hid, dim, h_sizes=h_sizes, s_last_gain=3.0)
+    x = recipes.gaussian(91 + dim, 531, dim)
+    for parity in (False, True):
+        f = ahf_module(amd, sd, dim, parity, h_sizes=h_sizes)
+        assert f._packed(torch.device(DEV, 0))[1] is not None
+        for inverse in (False, True):
+            ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
+            y, ld = f.forward(cuda(x), inverse=inverse)
+            assert_close(y, ref_y, RTOL, "y")
+            assert_close(ld, ref_ld, RTOL, "ld")
+
+
+@pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50)])
+def test_rnvp_mfma_shape_matrix(amd, O, dim, hid):
+    sd = recipes.rnvp_params(95 + dim + hid, dim, hid)
+    f = amd.RNVP(dim, h_sizes=(hid,))
+    f.load_state_dict(sd)
+    f.to(DEV)
+    assert f._packed(torch.device(DEV, 0))[1] is not None
+    rows = 131
+    z = recipes.gaussian(96 + dim, rows, dim)
+    mask = recipes.bernoulli_mask(97, rows, dim)
+    ref_x, ref_ld = O.rnvp(z, sd, mask)
+    x, ld = f.forward(cuda(z), mask=cuda(mask))
+    assert_close(x, ref_x, RTOL, "x")
+    assert_close(ld, ref_ld, RTOL, "ld")
+
+
 def test_empty_batches(amd):
     f = ahf_module(amd, recipes.affine_half_params(1, 64), 64, False)
     y, ld = f.forward(torch.empty(0, 64, device=DEV))

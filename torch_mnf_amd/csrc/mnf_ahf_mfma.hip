@@ -446,7 +446,8 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
 }
 
 // (H, HID) pairs with an instantiated kernel
-#define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24)
+// reference default hidden width 24 at d = 32..256, plus widths 16 and 32 at the small dims
+#define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24) X(16, 16) X(32, 16) X(16, 32) X(32, 32) X(64, 32)
 
 static bool uniform_hidden(int n_hidden, const int* hidden, int& hid) {
   if (n_hidden != 3) return false;

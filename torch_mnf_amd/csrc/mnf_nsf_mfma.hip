@@ -174,7 +174,7 @@ template <int H, int NH, int K, bool INV>
 __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, int q, const f32x4 (&cond)[H / 16],
                                                f32x4 (&act)[H / 16], float T) {
   using S_ = NsfShape<H, NH, K>;
-  constexpr int G = S_::G, QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
+  constexpr int QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S;
   int a_off = lane * 4, b_off = S_::A_FLOATS + q * 4;
   asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop (see mnf_ahf_mfma.hip)
   const f32x4* A4 = reinterpret_cast<const f32x4*>(lds_net + a_off);
@@ -249,7 +249,6 @@ __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, i
     act[s >> 2][s & 3] = o;
     lad_sum += l;
   }
-  (void)P;
   return lad_sum;
 }
 

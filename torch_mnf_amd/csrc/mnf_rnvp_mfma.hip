@@ -34,7 +34,7 @@ template <int HN>
 struct RnvpShape {
   static constexpr int KQ = (HN + 3) / 4;       // K-steps of GEMM 2 (quads of y units)
   static constexpr int YT = (KQ + 3) / 4;       // 16-row tiles of y
-  static_assert(YT == 4, "the GEMM-1 operand groups assume four y tiles (49..64 hidden units)");
+  static_assert(YT >= 1 && YT <= 4, "GEMM-1 operand groups hold up to four y tiles (hidden width <= 64)");
   static constexpr int G2 = (2 * KQ + 3) / 4;   // operand groups (of 4 MFMAs) per GEMM-2 output tile
   static constexpr int TILE2_FLOATS = G2 * 256;
   static constexpr int64_t part1_floats(int d) { return (int64_t)(d / 4) * 256; }         // one group per K-step
@@ -62,7 +62,7 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
                  float* __restrict__ log_det, const float* __restrict__ image, int64_t rows, int d,
                  int accumulate, uint64_t seed) {
   using S = RnvpShape<HN>;
-  constexpr int KQ = S::KQ, YT = S::YT, G2 = S::G2;
+  constexpr int KQ = S::KQ, YT = S::YT;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
@@ -155,7 +155,6 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
         if (live) *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
       }
     }
-    (void)G2;
     if (log_det) {
       ld = sum_over_q(ld);
       if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
@@ -208,9 +207,39 @@ static void build_index(int d, int32_t* idx) {
     }
 }
 
+// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default)
+#define MNF_RNVP_HIDDEN(X) X(50) X(30)
+
+template <int HN>
+static int launch_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                       const float* image, int64_t rows, int dim, uint64_t seed, hipStream_t stream) {
+  const int64_t n_groups = (rows + 63) / 64;
+  static const int resident = [] {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rnvp_mfma_kernel<HN, false>, kRnvpWaves * 64, 0) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 2;
+    return per_cu * cus;
+  }();
+  const int64_t blocks = n_groups < resident ? n_groups : resident;
+  if (mask)
+    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed);
+  else
+    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed);
+  return check_launch();
+}
+
 static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
-  return n_hidden == 1 && hidden && hidden[0] == 50 && dim >= 64 && dim % 16 == 0 &&
-         (int64_t)dim * 50 * 3 < (1ll << 30);
+  if (n_hidden != 1 || !hidden || dim < 64 || dim % 16 != 0 || (int64_t)dim * 64 * 3 >= (1ll << 30)) return false;
+#define X(HN) if (hidden[0] == HN) return true;
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return false;
 }
 
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
@@ -220,25 +249,11 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) |
        reinterpret_cast<uintptr_t>(image)) & 15)
     return MNF_ERR_UNSUPPORTED;
-  const int64_t n_groups = (rows + 63) / 64;
-  static const int resident = [] {
-    int per_cu = 0, cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rnvp_mfma_kernel<50, false>, kRnvpWaves * 64, 0) !=
-            hipSuccess || per_cu < 1)
-      per_cu = 2;
-    return per_cu * cus;
-  }();
-  const int64_t blocks = n_groups < resident ? n_groups : resident;
-  if (mask)
-    hipLaunchKernelGGL((rnvp_mfma_kernel<50, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, image, rows, dim, accumulate, seed);
-  else
-    hipLaunchKernelGGL((rnvp_mfma_kernel<50, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, image, rows, dim, accumulate, seed);
-  return check_launch();
+#define X(HN) \
+  if (hidden[0] == HN) return launch_rnvp<HN>(z, mask, x, log_det, accumulate, image, rows, dim, seed, stream);
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
 }
 
 }  // namespace mnf
@@ -247,14 +262,23 @@ extern "C" {
 
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden) {
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return 0;
-  return mnf::RnvpShape<50>::image_floats(dim);
+#define X(HN) if (hidden[0] == HN) return mnf::RnvpShape<HN>::image_floats(dim);
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return 0;
 }
 
 int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden, int32_t* idx_host) {
   if (!idx_host) return MNF_ERR_INVALID_ARG;
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
-  mnf::build_index<50>(dim, idx_host);
-  return MNF_OK;
+#define X(HN)                               \
+  if (hidden[0] == HN) {                    \
+    mnf::build_index<HN>(dim, idx_host);    \
+    return MNF_OK;                          \
+  }
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"
