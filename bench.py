@@ -163,6 +163,14 @@ def main() -> None:
     import torch_mnf_amd as amd
     from torch_mnf_amd.dist import reduce_sum_count
 
+    if not os.path.exists(amd.library_path()):  # normally prebuilt in-tree by __graft_entry__.build()
+        if rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
+
     dim, rows, desc = WORKLOADS[args.workload]
     model, layers = build_c3(device) if args.workload == "c3" else build_model(dim, device)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)

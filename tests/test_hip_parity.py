@@ -5,6 +5,8 @@ plus size-independent properties at BASELINE.json's full sizes.
 Tolerance (BASELINE.json north_star "1e-5 rel fp32"): normwise
 max|a-b| <= 1e-5 * max|b| per output tensor; scalar mean log-prob to 1e-5 relative.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,6 +24,10 @@ def amd():
     import torch_mnf_amd
 
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    if not os.path.exists(torch_mnf_amd.library_path()):  # normally prebuilt by __graft_entry__.build()
+        import __graft_entry__
+
+        __graft_entry__.build()
     torch_mnf_amd._lib.load()
     return torch_mnf_amd
 
