@@ -68,7 +68,8 @@ int main() {
       {"no-stores", run<false, 6, 0>},     {"compute-only", run<false, 2, 0>},
       {"copy-only", run<false, 5, 0>},     {"no-mfma", run<false, 1, 0>},
       {"no-exp", run<false, 3, 0>},        {"no-lds-reads", run<false, 4, 0>},
-      {"wide-stores", run<false, 12, 0>},
+      {"wide-stores", run<false, 12, 0>},   {"nt-stores", run<false, 13, 0>},
+      {"nt-loads+stores", run<false, 14, 0>}, {"nt-loads", run<false, 15, 0>},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
   for (int bpc : {4, 6}) {

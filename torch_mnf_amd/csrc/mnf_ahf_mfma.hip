@@ -29,6 +29,7 @@
 // algorithmic minimum for an out-of-place layer (8d + 8 bytes).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "mnf_device.h"
@@ -88,6 +89,17 @@ __device__ __forceinline__ void store_pair_wide(float* ya, float* yb, bool live_
   }
   if (live_a) *reinterpret_cast<f32x4*>(ya) = a;
   if (live_b) *reinterpret_cast<f32x4*>(yb) = b;
+}
+
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, const f32x4& v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return *reinterpret_cast<const f32x4*>(p);
 }
 
 // (ablation builds replace the MFMA by a pass-through of the accumulator)
@@ -200,9 +212,9 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
                                : row_ptr(tile);
     if (!PREFETCH) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xn + cond_off + 16 * g);
+      for (int g = 0; g < G; ++g) cnd[g] = ld4<ABL == 14 || ABL == 15>(xn + cond_off + 16 * g);
 #pragma unroll
-      for (int g = 0; g < G; ++g) act[g] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * g);
+      for (int g = 0; g < G; ++g) act[g] = ld4<ABL == 14 || ABL == 15>(xn + act_off + 16 * g);
     }
     if (WIDE) {
       if (ABL != 8) {
@@ -212,7 +224,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       }
     } else if (live && ABL != 8) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + cond_off + 16 * g) = cnd[g];
+      for (int g = 0; g < G; ++g) st4<ABL == 13 || ABL == 14>(yr + cond_off + 16 * g, cnd[g]);
     }
     float ld = 0.f, sq = 0.f;
     if (ysq) {
@@ -331,7 +343,7 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
           o_even = o;
         }
       } else if (live && (ABL != 9 || o[0] == 1.2345e30f)) {
-        *reinterpret_cast<f32x4*>(yr + act_off + 16 * m) = o;
+        st4<ABL == 13 || ABL == 14>(yr + act_off + 16 * m, o);
       }
       if (PREFETCH) act[m] = *reinterpret_cast<const f32x4*>(xn + act_off + 16 * m);
     }
@@ -436,12 +448,27 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
     return per_cu * cus;
   }();
   if (blocks > resident) blocks = resident;
-  if (inverse)
-    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true, kPrefetch>), dim3((unsigned)blocks),
-                       dim3(kAhfWaves * 64), 0, stream, x, y, log_det, ysq, image, rows, parity, accumulate);
-  else
-    hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false, kPrefetch>), dim3((unsigned)blocks),
-                       dim3(kAhfWaves * 64), 0, stream, x, y, log_det, ysq, image, rows, parity, accumulate);
+  // Non-temporal loads/stores (MNF_AHF_NT=1) are an experiment switch, off by default: in the
+  // isolated microbench they gain 5 % at d = 64, but inside the 9-layer pass (each layer re-reads
+  // what the previous one just wrote) they are neutral at d = 64 and cost 13 % at d = 256.
+  static const bool nt = [] { const char* e = getenv("MNF_AHF_NT"); return e && e[0] == '1'; }();
+  constexpr int kNt = 14;  // loads + stores non-temporal (see the ABL list above the kernel)
+  const dim3 grid((unsigned)blocks), block(kAhfWaves * 64);
+  if (nt) {
+    if (inverse)
+      hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true, kPrefetch, kNt>), grid, block, 0, stream, x, y, log_det,
+                         ysq, image, rows, parity, accumulate);
+    else
+      hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false, kPrefetch, kNt>), grid, block, 0, stream, x, y, log_det,
+                         ysq, image, rows, parity, accumulate);
+  } else {
+    if (inverse)
+      hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true, kPrefetch>), grid, block, 0, stream, x, y, log_det, ysq,
+                         image, rows, parity, accumulate);
+    else
+      hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, false, kPrefetch>), grid, block, 0, stream, x, y, log_det, ysq,
+                         image, rows, parity, accumulate);
+  }
   return check_launch();
 }
 
