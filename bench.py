@@ -140,8 +140,11 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prime-ms", type=float, default=60.0,
+                    help="untimed device priming before the warm-up steps: the GPU leaves its idle power "
+                         "state only after tens of ms of load, and the first ~25 passes run ~10 %% slower")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -183,13 +186,24 @@ def main() -> None:
         return s / c
 
     with torch.no_grad():
+        # setup: pack parameter images, let the caching allocator reach its steady state and bring
+        # the device out of its idle power state (reported as config.primed_ms; not a timed step)
+        step()  # first call: lazy library load, parameter packing, allocator growth
+        torch.cuda.synchronize()
+        t_prime = time.perf_counter()
+        primed = 0
+        while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+            step()
+            torch.cuda.synchronize()
+            primed += 1
         for _ in range(args.warmup):
             mean = step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        model.layer_events = []  # (start, end) HIP events around every coupling kernel
+        # (start, end) HIP events around every coupling kernel of the timed steps
+        model.layer_events = None if os.environ.get("MNF_BENCH_NO_EVENTS") else []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             mean = step()
@@ -199,6 +213,12 @@ def main() -> None:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         events, model.layer_events = model.layer_events, None
+        if events is None:  # experiment mode: time the kernels in a separate pass instead
+            model.layer_events = []
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            events, model.layer_events = model.layer_events, None
 
     # the other direction (sampling: z -> x), outside the timed region, for the record
     with torch.no_grad():
@@ -239,7 +259,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": n_layers,
                        "hidden": [8, 8, 8] if args.workload == "c3" else [24, 24, 24],
-                       "intermediates": "all kept (reference API)"},
+                       "intermediates": "all kept (reference API)", "primed_ms": args.prime_ms,
+                       "primed_steps": primed},
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

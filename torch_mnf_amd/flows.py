@@ -655,8 +655,8 @@ class NormalizingFlow(nn.Module):
     def __init__(self, flows: Sequence[nn.Module]) -> None:
         super().__init__()
         self.flows = nn.ModuleList(flows)
-        # bench.py: set to a list to collect a (start, end) HIP event pair around every layer,
-        # recorded on the stream the kernels are launched on
+        # bench.py: set to a list to collect a (start, end) HIP event pair per layer, recorded on
+        # the stream the kernels are launched on (consecutive layers share the boundary event)
         self.layer_events: list | None = None
         self._last_sqnorm: Tensor | None = None
 
@@ -666,10 +666,10 @@ class NormalizingFlow(nn.Module):
         timed = self.layer_events is not None and x.is_cuda
         order = list(reversed(self.flows)) if inverse else list(self.flows)
         self._last_sqnorm = None
+        if timed:  # one event per layer boundary: layer i runs between marks i and i+1
+            e_prev = torch.cuda.Event(enable_timing=True)
+            e_prev.record()
         for i, flow in enumerate(order):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             if (want_sqnorm and i == len(order) - 1 and isinstance(flow, AffineHalfFlow) and x.is_cuda
                     and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
                 # last layer also emits |z|^2 per row for the standard-normal epilogue
@@ -685,8 +685,10 @@ class NormalizingFlow(nn.Module):
                 x, ld = flow.inverse(x) if inverse else flow.forward(x)
                 log_det += ld
             if timed:
-                e1.record()
-                self.layer_events.append((e0, e1))
+                e_next = torch.cuda.Event(enable_timing=True)
+                e_next.record()
+                self.layer_events.append((e_prev, e_next))
+                e_prev = e_next
             seen.append(x)
         return seen, log_det
 
