@@ -437,8 +437,9 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
   int64_t blocks = (n_tiles + kAhfWaves - 1) / kAhfWaves;
   // persistent grid: as many workgroups as are resident at once (registers and the LDS image
   // bound it), each striding over the tiles
+  static int cus = 256;
   static const int resident = [] {
-    int per_cu = 0, cus = 256, dev = 0;
+    int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
@@ -447,7 +448,7 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
       per_cu = 4;
     return per_cu * cus;
   }();
-  if (blocks > resident) blocks = resident;
+  blocks = balanced_grid(n_tiles, kAhfWaves, resident, cus);
   // Non-temporal loads/stores (MNF_AHF_NT=1) are an experiment switch, off by default: in the
   // isolated microbench they gain 5 % at d = 64, but inside the 9-layer pass (each layer re-reads
   // what the previous one just wrote) they are neutral at d = 64 and cost 13 % at d = 256.

@@ -12,6 +12,27 @@ int check_launch();
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base);
 bool hidden_ok(int n_hidden, const int* hidden);
 
+// Persistent-grid sizing: among grids of whole workgroups-per-CU steps between resident/2 and
+// resident, pick the one whose static tile striding wastes the fewest wave-rounds
+// (tiles / (rounds * waves)); e.g. 65,536 tiles on 1,536 resident 4-wave workgroups run 11 rounds at
+// 97 % fill, on 1,024 workgroups 16 rounds at 100 %.
+inline int64_t balanced_grid(int64_t n_tiles, int waves_per_block, int resident_blocks, int cus) {
+  const int64_t need = (n_tiles + waves_per_block - 1) / waves_per_block;
+  if (need <= resident_blocks) return need;
+  int64_t best = resident_blocks;
+  double best_fill = 0.0;
+  for (int64_t b = resident_blocks; b >= resident_blocks / 2 && b >= cus; b -= cus) {
+    const int64_t waves = b * waves_per_block;
+    const int64_t rounds = (n_tiles + waves - 1) / waves;
+    const double fill = (double)n_tiles / (double)(rounds * waves);
+    if (fill > best_fill + 1e-9) {
+      best_fill = fill;
+      best = b;
+    }
+  }
+  return best;
+}
+
 // Specialised launchers: return MNF_ERR_UNSUPPORTED when the shape has no MFMA kernel, in
 // which case the caller falls through to the generic kernel.
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
