@@ -15,6 +15,7 @@ rows (weak scaling); value = rows of all ranks / max-over-ranks time.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -196,6 +197,11 @@ def main() -> None:
             step()
             torch.cuda.synchronize()
             primed += 1
+        # CPython's cyclic collector fires at a fixed allocation count, i.e. at the same layer of the
+        # same step in every run, and a full collection of a process that has imported torch takes
+        # ~70 ms: collect now and keep it off for the warm-up and timed steps.
+        gc.collect()
+        gc.disable()
         for _ in range(args.warmup):
             mean = step()
         torch.cuda.synchronize()
@@ -212,6 +218,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         events, model.layer_events = model.layer_events, None
         if events is None:  # experiment mode: time the kernels in a separate pass instead
             model.layer_events = []
@@ -238,6 +245,10 @@ def main() -> None:
 
     if rank == 0:
         kern_ms = [a.elapsed_time(b) for a, b in events]
+        per_layer_us = [1e3 * sum(kern_ms[i::n_layers]) / len(kern_ms[i::n_layers]) for i in range(n_layers)]
+        if os.environ.get("MNF_BENCH_DEBUG"):
+            for i in range(n_layers):
+                print(f"layer {i} per step (us):", [round(v * 1e3) for v in kern_ms[i::n_layers]], file=sys.stderr)
         if args.workload == "c3":  # dominant kernel = the NSF_CL layer (first of every 3 in the inverse order)
             kern_ms = [k for i, k in enumerate(kern_ms) if i % 3 == 0]
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
@@ -272,6 +283,7 @@ def main() -> None:
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launches_timed": len(kern_ms),
+                "per_layer_us": [round(v, 1) for v in per_layer_us],
                 "frac_of_achievable_6300": achieved / 6300.0,
                 "fp32_tflops": (12800 if args.workload == "c3" else 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24))
                 * rows / avg_kernel_s / 1e12,

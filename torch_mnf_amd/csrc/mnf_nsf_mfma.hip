@@ -16,6 +16,8 @@
 // bound by construction (~36 v_exp per element at K = 8): SURVEY.md 8d.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mnf_device.h"
 #include "mnf_host.h"
 
@@ -380,6 +382,7 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsf_mfma_kernel<H, NH, K, true>, kNsfWaves * 64,
                                                      0) != hipSuccess || per_cu < 1)
       per_cu = 2;
+    if (const char* e = getenv("MNF_NSF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // experiment switch
     return per_cu * cus;
   }();
   if (blocks > resident) blocks = resident;
