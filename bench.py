@@ -35,7 +35,9 @@ WORKLOADS = {
     "c2": (64, 1 << 20, "9xAffineHalfFlow d=64 batch=2^20 inverse+log_prob (BASELINE configs[1])"),
     "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3] shard)"),
     "c3": (32, 1 << 20, "3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob (BASELINE configs[2])"),
+    "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
 }
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 
 
 def build_c3(device):
@@ -138,6 +140,98 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
     return info, mean, rows
 
 
+def main_c5(args, rank, world, device, dim, rows, desc) -> None:
+    """Config 5: the flow_q of MNFLinear(800, 50) on 256,000 MC rows.  A step = one sample_z call
+    (prologue kernel + two seeded RNVP kernels, log-det accumulated in-kernel); fp32-MFMA bound."""
+    import recipes
+    import torch_mnf_amd as amd
+
+    layer = amd.MNFLinear(dim, 50)
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(800 + i, dim, 50))
+    layer.to(device)
+    gen = torch.Generator(device=device).manual_seed(4321 + rank)
+    eps = torch.randn(rows, dim, device=device, generator=gen)  # noise resident in HBM; masks are generated in-kernel
+
+    def step():
+        return layer.sample_z(rows, eps=eps)
+
+    with torch.no_grad():
+        step()
+        torch.cuda.synchronize()
+        t_prime = time.perf_counter()
+        while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+            step()
+            torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        layer.flow_q.layer_events = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+        events, layer.flow_q.layer_events = layer.flow_q.layer_events, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        kern_ms = [a.elapsed_time(b) for a, b in events]
+        avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+        flops = 2 * (dim * 50 + 2 * 50 * dim) * rows  # 240,000 per row (SURVEY 8d)
+        tf = flops / avg_s / 1e12
+        out = {
+            "metric": f"rows/s, {desc}", "value": world * rows * args.steps / elapsed, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "hidden": [50], "mask": "in-kernel (seeded)",
+                       "primed_ms": args.prime_ms},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "rnvp_mfma_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
+                         "algorithmic_flops_per_launch": flops, "launches_timed": len(kern_ms),
+                         "algorithmic_GBps": (12 * dim + 8) * rows / avg_s / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import flow_oracle as O
+
+            n = 8192
+            torch.set_num_threads(min(32, os.cpu_count() or 1))
+            q0m, q0v = layer.q0_mean.detach().cpu(), layer.q0_log_var.detach().cpu()
+            e_cpu = eps[:n].cpu()
+            seeds = (11, 12)
+            masks = [layer.flow_q.flows[i].mask_for(seeds[i], n, device).cpu() for i in range(2)]
+            specs = [{"kind": "rnvp", "params": recipes.rnvp_params(800 + i, dim, 50), "mask": masks[i]} for i in range(2)]
+            best = float("inf")
+            with torch.no_grad():
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    z_cpu, ld_cpu = O.sample_z(q0m, q0v, e_cpu, specs)
+                    best = min(best, time.perf_counter() - t1)
+                z_gpu, ld_gpu = layer.sample_z(n, eps=eps[:n].contiguous(), masks=[m.to(device) for m in masks])
+            err = float((z_gpu.cpu() - z_cpu).abs().max() / z_cpu.abs().max())
+            out["cpu_baseline"] = {"value": n / best, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"oracle sample_z on the first {n} rows (masks materialised from the "
+                                             f"library's generator), best of 3, {best:.3f} s"}
+            out["parity"] = {"rows": n, "z_normwise_err": err,
+                             "log_det_normwise_err": float((ld_gpu.cpu() - ld_cpu).abs().max() / ld_cpu.abs().max()),
+                             "tolerance": 1e-5}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +270,8 @@ def main() -> None:
             dist.barrier()
 
     dim, rows, desc = WORKLOADS[args.workload]
+    if args.workload == "c5":
+        return main_c5(args, rank, world, device, dim, rows, desc)
     model, layers = build_c3(device) if args.workload == "c3" else build_model(dim, device)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
