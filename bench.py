@@ -206,7 +206,7 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         if world == 1 and not args.no_cpu_baseline:
             from oracle import flow_oracle as O
 
-            n = 8192
+            n = 1 << 17
             torch.set_num_threads(min(32, os.cpu_count() or 1))
             q0m, q0v = layer.q0_mean.detach().cpu(), layer.q0_log_var.detach().cpu()
             e_cpu = eps[:n].cpu()
