@@ -12,7 +12,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <cstdio>
 #include <cstring>
 
 #include "mnf_device.h"

@@ -20,7 +20,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import warnings
 from collections.abc import Sequence
 
 import torch
