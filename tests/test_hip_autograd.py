@@ -1,11 +1,10 @@
 """Gradients of the HIP Flow modules against torch.autograd through the CPU
 oracle, and the reference's own training contracts (tests/test_flows.py:14-31,53-55,76-86)."""
-import numpy as np
 import pytest
 import torch
 
 import recipes
-from helpers import assert_close, t
+from helpers import assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

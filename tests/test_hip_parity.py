@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import recipes
-from helpers import RTOL, assert_close, assert_parity, c2_layers, c3_layers, g1_layers, t, unpack_mask
+from helpers import RTOL, assert_close, assert_parity, c2_layers, g1_layers, t, unpack_mask
 
 pytestmark = pytest.mark.gpu
 

@@ -46,7 +46,15 @@ __device__ __forceinline__ void mlp_forward_keep(const float* __restrict__ flat,
 
 // backward of one MLP: delta (in dA, [R][n_last]) is the gradient wrt the net's output.
 // Adds dW, db into grad_flat, and the gradient wrt the net's input into g_in [R][sizes[0]].
-__device__ __forceinline__ void mlp_backward(const float* __restrict__ flat, float* __restrict__ grad_flat,
+// `grad_dst` has the flat layout.  lds_acc: it is this workgroup's private LDS accumulator (each
+// (layer, unit) slot is always visited by the same thread, so a plain += is race free) and is
+// flushed to global memory once per workgroup; otherwise it is the global buffer itself.
+__device__ __forceinline__ void grad_add(float* dst, float v, bool lds_acc) {
+  if (lds_acc) *dst += v;
+  else atomicAdd(dst, v);
+}
+
+__device__ __forceinline__ void mlp_backward(const float* __restrict__ flat, float* grad_flat, bool lds_acc,
                                              const NetDesc& nd, const float* in, int ld_in, const float* acts,
                                              const int* act_off, float* dA, float* dB, float* g_in, int R) {
   float* delta = dA;
@@ -61,12 +69,12 @@ __device__ __forceinline__ void mlp_backward(const float* __restrict__ flat, flo
         const int o = idx / n_in, k = idx - o * n_in;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(delta[r * n_out + o], hin[r * ld_h + k], acc);
-        atomicAdd(grad_flat + nd.w_off[l] + idx, acc);
+        grad_add(grad_flat + nd.w_off[l] + idx, acc, lds_acc);
       }
       for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += delta[r * n_out + o];
-        atomicAdd(grad_flat + nd.b_off[l] + o, acc);
+        grad_add(grad_flat + nd.b_off[l] + o, acc, lds_acc);
       }
     }
     for (int idx = threadIdx.x; idx < R * n_in; idx += blockDim.x) {
@@ -97,13 +105,23 @@ struct AhfBwdArgs {
   int64_t rows;
   int dim, parity, inverse, has_scale, has_shift;
   int R, maxw, act_floats;  // act_floats = sum of layer output widths of one net
+  int n_params;             // > 0: parameter gradients are accumulated in LDS and flushed once
   int act_off[MNF_MAX_LINEAR];
   NetDesc s_net, t_net;
 };
 
 __global__ void __launch_bounds__(kBwdThreads) ahf_bwd_kernel(AhfBwdArgs a) {
   const int H = a.dim / 2;
-  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const bool lds_acc = a.n_params > 0 && a.grad_flat;
+  float* gacc = bsmem + (size_t)a.R * (2 * H + 2 * a.act_floats + 2 * a.maxw);
+  if (lds_acc) {
+    for (int i = threadIdx.x; i < a.n_params; i += blockDim.x) gacc[i] = 0.f;
+    __syncthreads();
+  }
+  float* gdst = lds_acc ? gacc : a.grad_flat;
+  const int64_t n_groups = (a.rows + a.R - 1) / a.R;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  const int64_t row0 = grp * a.R;
   const int R = (int)min((int64_t)a.R, a.rows - row0);
   float* cond = bsmem;                       // [R][H]
   float* g_cond = cond + a.R * H;            // [R][H]
@@ -157,17 +175,23 @@ __global__ void __launch_bounds__(kBwdThreads) ahf_bwd_kernel(AhfBwdArgs a) {
     float* park = acts_s + a.act_off[last] * R;  // s_out is no longer needed
     for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) park[idx] = dB[(idx / H) * a.maxw + idx % H];
     __syncthreads();
-    mlp_backward(a.flat, a.grad_flat, a.s_net, cond, H, acts_s, a.act_off, dA, dB, g_cond, R);
+    mlp_backward(a.flat, gdst, lds_acc, a.s_net, cond, H, acts_s, a.act_off, dA, dB, g_cond, R);
     for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) dA[idx] = park[idx];
     __syncthreads();
   } else {
     for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) dA[idx] = dB[(idx / H) * a.maxw + idx % H];
     __syncthreads();
   }
-  if (a.has_shift) mlp_backward(a.flat, a.grad_flat, a.t_net, cond, H, acts_t, a.act_off, dA, dB, g_cond, R);
+  if (a.has_shift) mlp_backward(a.flat, gdst, lds_acc, a.t_net, cond, H, acts_t, a.act_off, dA, dB, g_cond, R);
   for (int idx = threadIdx.x; idx < R * H; idx += blockDim.x) {
     const int r = idx / H, j = idx - r * H;
     a.grad_x[(row0 + r) * a.dim + cond_off + j] = g_cond[idx];
+  }
+  __syncthreads();  // LDS rows are reused by the next group
+  }
+  if (lds_acc) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_params; i += blockDim.x) atomicAdd(a.grad_flat + i, gacc[i]);
   }
 }
 
@@ -241,14 +265,17 @@ int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_l
   a.act_floats = act;
   a.maxw = maxw;
   const int per_row = 2 * H + 2 * act + 2 * maxw;
-  int R = kBwdLdsFloats / per_row;
+  // parameter-gradient accumulator in LDS when it leaves room for >= 8 rows
+  a.n_params = (grad_flat && off + 8 * per_row <= kBwdLdsFloats) ? (int)off : 0;
+  int R = (kBwdLdsFloats - a.n_params) / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
   if (R > 64) R = 64;
   a.R = R;
-  const int64_t blocks = (rows + R - 1) / R;
+  int64_t blocks = (rows + R - 1) / R;
+  if (a.n_params > 0 && blocks > 1024) blocks = 1024;  // persistent: 4 workgroups per CU, one flush each
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ahf_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads),
-                     (size_t)R * per_row * sizeof(float), (hipStream_t)stream, a);
+                     ((size_t)R * per_row + a.n_params) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
 }
 
@@ -474,7 +501,7 @@ __device__ __forceinline__ void nsf_half_backward(const float* flat, float* grad
     g_vals[idx] = gv;
   }
   __syncthreads();
-  mlp_backward(flat, grad_flat, nd, cond, H, acts, act_off, dA, dB, g_cond, R);
+  mlp_backward(flat, grad_flat, false, nd, cond, H, acts, act_off, dA, dB, g_cond, R);
 }
 
 __global__ void __launch_bounds__(kBwdThreads) nsf_bwd_kernel(NsfBwdArgs a) {
@@ -612,7 +639,7 @@ __global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
     dA[idx] = acc;
   }
   __syncthreads();
-  mlp_backward(a.flat, a.grad_flat, a.net, kept, d, acts, a.act_off, dA, dB, g_kept, R);
+  mlp_backward(a.flat, a.grad_flat, false, a.net, kept, d, acts, a.act_off, dA, dB, g_kept, R);
   for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
     const int r = idx / d, j = idx - r * d;
     a.grad_z[(row0 + r) * d + j] += mask_of(r, j) * g_kept[idx];
