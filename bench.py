@@ -182,7 +182,8 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         elapsed = time.perf_counter() - t0
         gc.enable()
         events, layer.flow_q.layer_events = layer.flow_q.layer_events, None
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64,
+                     device=device if os.environ.get("MNF_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -252,11 +253,19 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    # Self-test switches (not used by the driver): MNF_BENCH_BACKEND=gloo + MNF_BENCH_SHARE_GPU=1 run
+    # the N > 1 control flow with every rank on GPU 0 of a one-GPU box.
+    backend = os.environ.get("MNF_BENCH_BACKEND", "nccl")
+    if os.environ.get("MNF_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import torch_mnf_amd as amd
     from torch_mnf_amd.dist import reduce_sum_count
@@ -333,7 +342,7 @@ def main() -> None:
         fwd_rate = rows * max(1, args.steps // 2) / (time.perf_counter() - t1)
         del xs_fwd
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

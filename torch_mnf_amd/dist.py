@@ -27,7 +27,12 @@ def reduce_sum_count(local_sum: torch.Tensor, local_rows: int, group=None) -> tu
     pair[0] = local_sum.reshape(-1)[0].to(torch.float64)
     pair[1] = float(local_rows)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        if pair.is_cuda and dist.get_backend(group) == "gloo":  # CPU-side test backend: reduce on the host
+            host = pair.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            pair.copy_(host)
+        else:
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
     return pair[0], pair[1]
 
 
