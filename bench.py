@@ -35,6 +35,8 @@ WORKLOADS = {
     "c2": (64, 1 << 20, "9xAffineHalfFlow d=64 batch=2^20 inverse+log_prob (BASELINE configs[1])"),
     "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3] shard)"),
     "c3": (32, 1 << 20, "3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob (BASELINE configs[2])"),
+    "c3f": (32, 1 << 20, "3xFusedSplineBlock[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob "
+                         "(opt-in fusion: block intermediates not materialised; reported separately from c3)"),
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
@@ -281,7 +283,16 @@ def main() -> None:
     dim, rows, desc = WORKLOADS[args.workload]
     if args.workload == "c5":
         return main_c5(args, rank, world, device, dim, rows, desc)
-    model, layers = build_c3(device) if args.workload == "c3" else build_model(dim, device)
+    if args.workload in ("c3", "c3f"):
+        model, layers = build_c3(device)
+        if args.workload == "c3f":
+            import torch_mnf_amd as _amd
+
+            fl = list(model.flows)
+            model = _amd.NormalizingFlowModel(model.base, [_amd.FusedSplineBlock(*fl[3 * i:3 * i + 3])
+                                                           for i in range(3)]).to(device)
+    else:
+        model, layers = build_model(dim, device)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
     n_layers = len(model.flows)
@@ -374,7 +385,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": n_layers,
-                       "hidden": [8, 8, 8] if args.workload == "c3" else [24, 24, 24],
+                       "hidden": [8, 8, 8] if args.workload in ("c3", "c3f") else [24, 24, 24],
                        "intermediates": "all kept (reference API)", "primed_ms": args.prime_ms,
                        "primed_steps": primed},
             "roofline": {
@@ -384,13 +395,14 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.workload),
-                "kernel": "nsf_cl kernel (inverse)" if args.workload == "c3" else f"ahf_mfma_kernel<{dim // 2},24,inverse>",
+                "kernel": ("nsf_cl kernel (inverse)" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"
+                           if args.workload == "c3f" else f"ahf_mfma_kernel<{dim // 2},24,inverse>"),
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launches_timed": len(kern_ms),
                 "per_layer_us": [round(v, 1) for v in per_layer_us],
                 "frac_of_achievable_6300": achieved / 6300.0,
-                "fp32_tflops": (12800 if args.workload == "c3" else 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24))
+                "fp32_tflops": (12800 if args.workload in ("c3", "c3f") else 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24))
                 * rows / avg_kernel_s / 1e12,
             },
             "mean_log_prob": gpu_mean,

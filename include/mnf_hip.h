@@ -99,6 +99,17 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
                const float* flat, const float* image,
                int64_t rows, int dim, int K, float tail_bound, int inverse,
                int n_hidden, const int* hidden_host, int force_generic, void* stream);
+/* Opt-in fusion of the reference's [ActNorm, Glow, NSF_CL] block into one kernel (SURVEY.md 8f
+ * rank 3; drops the block's two intermediate tensors, so it is not what NormalizingFlow.forward
+ * returns by default).  ActNorm and Glow collapse to  row @ A + b  (A: dim x dim, given as the
+ * MFMA operand image of mnf_linear_rows_image_index followed by the dim bias values) and the
+ * row-independent log-det constant ld_const:
+ *   forward:  y = NSF_CL(x @ A + b)            A = diag(e^s) W,      b = t @ W
+ *   inverse:  y = NSF_CL^-1(x) @ A + b         A = W^-1 diag(e^-s),  b = -t e^-s
+ * MNF_ERR_UNSUPPORTED when the shape has no fused kernel (callers run the three layers). */
+int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound,
+                     int inverse, int n_hidden, const int* hidden_host, void* stream);
 int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden_host);
 int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden_host, int32_t* idx_host);

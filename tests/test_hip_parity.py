@@ -384,6 +384,36 @@ def test_g6_c3_stack(amd, golden):
     assert_parity(ld_f, fx["ld_fwd"], fx["ld_fwd64"], "ld_fwd")
 
 
+def test_fused_spline_block_matches_the_three_layers(amd, golden):
+    """Opt-in [ActNorm, Glow, NSF_CL] fusion: same numbers as the three modules (and as the
+    reference's C3 stack), in one launch per block and direction."""
+    fx = golden("g6_c3_stack")
+    x = cuda(fx["x"])
+    plain = build_c3(amd, fx)
+    fused = amd.NormalizingFlowModel(amd.StandardNormal(32), [
+        amd.FusedSplineBlock(plain.flows[3 * i], plain.flows[3 * i + 1], plain.flows[3 * i + 2]) for i in range(3)
+    ]).to(DEV)
+    zs, ld = fused.inverse(x)
+    assert len(zs) == 4  # one tensor per block: the intermediates inside a block are gone
+    assert_parity(zs[-1], fx["z_last"], fx["z_last64"], "fused z_last")
+    assert_parity(ld, fx["ld_inv"], fx["ld_inv64"], "fused ld_inv")
+    xs, ld_f = fused.forward(x)
+    assert_parity(xs[-1], fx["x_fwd_last"], fx["x_fwd_last64"], "fused x_fwd_last")
+    assert_parity(ld_f, fx["ld_fwd"], fx["ld_fwd64"], "fused ld_fwd")
+    zs_p, ld_p = plain.inverse(x)
+    assert_close(zs[-1], zs_p[-1], 2e-6, "fused vs unfused")
+    assert_close(ld, ld_p, 2e-6, "fused vs unfused log_det")
+    # a parameter update invalidates the folded affine map
+    with torch.no_grad():
+        plain.flows[0].t.add_(0.25)
+    zs2, _ = fused.inverse(x)
+    zs2_p, _ = plain.inverse(x)
+    assert_close(zs2[-1], zs2_p[-1], 2e-6, "after update")
+    assert not torch.equal(zs2[-1], zs[-1])
+    # state_dict nests the three modules
+    assert list(fused.flows[0].state_dict())[:5] == ["actnorm.s", "actnorm.t", "glow.L", "glow.S", "glow.U"]
+
+
 def test_g6_actnorm_data_dependent_init(amd, golden):
     """First inverse call initialises each ActNorm from the batch it sees (affine_constant_flow.py:42-50)."""
     fx = golden("g6_c3_stack")

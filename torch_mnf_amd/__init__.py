@@ -14,6 +14,7 @@ from .flows import (
     ActNormFlow,
     AffineConstantFlow,
     AffineHalfFlow,
+    FusedSplineBlock,
     Glow,
     NormalizingFlow,
     NormalizingFlowModel,
@@ -25,7 +26,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "rqs", "MNFLinear", "library_path",
+    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "rqs", "MNFLinear", "library_path",
 ]
 
 

@@ -254,18 +254,60 @@ __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, i
   return lad_sum;
 }
 
-template <int H, int NH, int K, bool INV>
+// row <- row @ A + b for the whole (lower | upper) row held as float4s, on the same MFMA scheme as
+// mnf_linear_mfma.hip: `aff` = [D*D operand image][D bias], D = 2H.
+template <int H>
+__device__ __forceinline__ void affine_rows(const float* aff, int lane, int q, f32x4 (&lo)[H / 16],
+                                            f32x4 (&up)[H / 16]) {
+  constexpr int G = H / 16, D = 2 * H, NK = D / 4;
+  int a_off = lane * 4, b_off = D * D + q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(aff + a_off);
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(aff + b_off);
+  f32x4 acc[2 * G];
+#pragma unroll
+  for (int m = 0; m < 2 * G; ++m) acc[m] = B4[4 * m];  // bias of dims 16 m + 4 q .. + 3
+  int n = 0;
+  f32x4 a4;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int m = 0; m < 2 * G; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      const float b = (kk >> 2) < G ? lo[kk >> 2][kk & 3] : up[(kk >> 2) - G][kk & 3];
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], b, acc[m], 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    lo[g] = acc[g];
+    up[g] = acc[G + g];
+  }
+}
+
+// AFF: 0 = plain NSF_CL.  Opt-in fusion of the reference's [ActNorm, Glow, NSF_CL] block (SURVEY.md
+// 8f rank 3): 1 = the affine map runs before the spline steps (forward: z e^s + t, then @ W),
+// 2 = after them (inverse: @ W^-1, then (. - t) e^-s); both collapse to one  row @ A + b  and a
+// row-independent log-det constant.  The block's two intermediate tensors are never written.
+template <int H, int NH, int K, bool INV, int AFF = 0>
 __global__ void __launch_bounds__(kNsfWaves * 64)
 nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
-                const float* __restrict__ image, int64_t rows, float T, int accumulate) {
+                const float* __restrict__ image, int64_t rows, float T, int accumulate,
+                const float* __restrict__ aff_image, float ld_const) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int G = S_::G, dim = 2 * H;
   static_assert(G >= 1, "");
-  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS];
+  constexpr int AFF_FLOATS = AFF ? dim * dim + dim : 0;
+  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS + AFF_FLOATS];
   {
     const float4* src = reinterpret_cast<const float4*>(image);
     float4* dst = reinterpret_cast<float4*>(lds);
     for (int i = threadIdx.x; i < S_::IMAGE_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    if (AFF) {
+      const float4* asrc = reinterpret_cast<const float4*>(aff_image);
+      float4* adst = reinterpret_cast<float4*>(lds + S_::IMAGE_FLOATS);
+      for (int i = threadIdx.x; i < AFF_FLOATS / 4; i += blockDim.x) adst[i] = asrc[i];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -286,6 +328,7 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
     for (int g = 0; g < G; ++g) up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
     float ld;
+    if (AFF == 1) affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
     if (!INV) {  // f1(lower) moves upper, then f2(upper') moves lower (spline_flow.py:249-266)
       ld = nsf_half_step<H, NH, K, false>(f1, lane, q, lo, up, T);
       ld += nsf_half_step<H, NH, K, false>(f2, lane, q, up, lo, T);
@@ -293,6 +336,7 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       ld = nsf_half_step<H, NH, K, true>(f2, lane, q, up, lo, T);
       ld += nsf_half_step<H, NH, K, true>(f1, lane, q, lo, up, T);
     }
+    if (AFF == 2) affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
     if (live) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
@@ -300,7 +344,7 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = up[g];
     }
     if (log_det) {
-      ld = sum_over_q(ld);
+      ld = sum_over_q(ld) + ld_const;
       if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
     }
   }
@@ -371,7 +415,7 @@ static void build_index(int32_t* idx) {
 
 template <int H, int NH, int K>
 static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
-                  float T, int inverse, hipStream_t stream) {
+                  float T, int inverse, hipStream_t stream, const float* aff = nullptr, float ld_const = 0.f) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
   static const int resident = [] {
@@ -386,17 +430,29 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
     return per_cu * cus;
   }();
   if (blocks > resident) blocks = resident;
-  if (inverse)
-    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true>), dim3((unsigned)blocks), dim3(kNsfWaves * 64), 0, stream,
-                       x, y, log_det, image, rows, T, accumulate);
-  else
-    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false>), dim3((unsigned)blocks), dim3(kNsfWaves * 64), 0, stream,
-                       x, y, log_det, image, rows, T, accumulate);
+  const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
+  if (aff) {  // fused [ActNorm, Glow, NSF_CL] block
+    if (inverse)
+      hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true, 2>), grid, block, 0, stream, x, y, log_det, image, rows, T,
+                         accumulate, aff, ld_const);
+    else
+      hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false, 1>), grid, block, 0, stream, x, y, log_det, image, rows, T,
+                         accumulate, aff, ld_const);
+  } else if (inverse) {
+    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true>), grid, block, 0, stream, x, y, log_det, image, rows, T,
+                       accumulate, aff, 0.f);
+  } else {
+    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false>), grid, block, 0, stream, x, y, log_det, image, rows, T,
+                       accumulate, aff, 0.f);
+  }
   return check_launch();
 }
 
 // (H, NH, K) triples with an instantiated kernel
 #define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8)
+// ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (dim = 32: the
+// affine image must be one the Glow MFMA kernel supports)
+#define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8)
 
 static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
   if (n_hidden != 3) return false;
@@ -419,9 +475,38 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
   return MNF_ERR_UNSUPPORTED;
 }
 
+int nsf_fused_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound, int inverse,
+                     int n_hidden, const int* hidden, hipStream_t stream) {
+  int nh = 0;
+  if (!uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image) |
+       reinterpret_cast<uintptr_t>(aff)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+#define X(HH, NHH, KK) \
+  if (dim == 2 * HH && nh == NHH && K == KK) \
+    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream, aff, ld_const);
+  MNF_NSF_FUSED_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
 }  // namespace mnf
 
 extern "C" {
+
+// Opt-in fused [ActNorm, Glow, NSF_CL] block: forward y = NSF(x @ A + b), inverse y = NSF^-1(x) @ A + b,
+// log_det = spline terms + ld_const.  aff = [dim*dim operand image of A (mnf_linear_rows_image_index)][dim bias].
+int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound,
+                     int inverse, int n_hidden, const int* hidden, void* stream) {
+  if (!x || !y || x == y || !image || !aff || rows < 0 || dim < 2 || (dim & 1) || K < 2 || !(tail_bound > 0.f) ||
+      !mnf::hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, aff, ld_const, rows, dim, K, tail_bound, inverse,
+                               n_hidden, hidden, (hipStream_t)stream);
+}
 
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden) {
   int nh = 0;

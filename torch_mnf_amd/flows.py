@@ -29,7 +29,7 @@ from . import _lib
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
-    "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "rqs",
+    "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "FusedSplineBlock", "rqs",
 ]
 
 
@@ -640,6 +640,103 @@ class Glow(_TwoWayFlow):
                 _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
                     x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], self.dim, _stream()))
         ld = -self._w_ld if inverse else self._w_ld
+        if accum is not None:
+            accum += ld
+            return y, None
+        return y, ld
+
+
+class FusedSplineBlock(_TwoWayFlow):
+    """Opt-in fusion of the reference's ``[ActNormFlow, Glow, NSF_CL]`` block (readme.md:67-73) into one
+    kernel launch per direction.
+
+    The three sub-modules keep their parameters (``state_dict`` keys ``actnorm.*``, ``glow.*``,
+    ``nsf.*``); ActNorm and Glow are folded into one ``row @ A + b`` that the spline kernel applies
+    to the rows while they are in registers, so the block's two intermediate tensors are never
+    written -- which is exactly why this is an explicit opt-in and not what ``NormalizingFlow`` does
+    with the three separate modules.  Falls back to running the three modules in sequence when a
+    graph is being recorded, for ActNorm's data-dependent first ``inverse`` call, and for shapes
+    without a fused kernel."""
+
+    def __init__(self, actnorm: ActNormFlow, glow: Glow, nsf: NSF_CL) -> None:
+        super().__init__()
+        if not (actnorm.dim == glow.dim == nsf.dim):
+            raise ValueError("the three layers must share dim")
+        self.actnorm, self.glow, self.nsf = actnorm, glow, nsf
+        self.dim = nsf.dim
+        self._aff_key = None
+        self._aff: dict = {}
+        self._lin_index: Tensor | None = None
+
+    def _packed_params(self) -> list[Tensor]:
+        return []
+
+    def _sequence(self, x: Tensor, inverse: bool):
+        order = (self.nsf, self.glow, self.actnorm) if inverse else (self.actnorm, self.glow, self.nsf)
+        ld = 0
+        for m in order:
+            x, l1 = m._run(x, inverse, None)
+            ld = ld + l1
+        return x, ld
+
+    def _affine(self, device, inverse: bool):
+        """(aff buffer = [operand image of A | b], log-det constant) for one direction, cached."""
+        an, gl = self.actnorm, self.glow
+        key = (device, tuple((p.data_ptr(), p._version) for p in (an.s, an.t, gl.L, gl.S, gl.U)), id(gl.P))
+        if key != self._aff_key:
+            self._aff, self._aff_key = {}, key
+        if inverse not in self._aff:
+            lib = _lib.load()
+            n = lib.mnf_linear_rows_image_floats(self.dim)
+            if n <= 0:
+                self._aff[inverse] = None
+                return None
+            s = an.s.detach().to(device, torch.float32).reshape(-1)
+            t = an.t.detach().to(device, torch.float32).reshape(-1)
+            W = gl._weights(device, inverse)  # W (forward) or W^-1 (inverse), cached by Glow
+            if inverse:   # z = (y @ W^-1 - t) e^-s
+                A, b = W * torch.exp(-s)[None, :], -t * torch.exp(-s)
+                ldc = -(s.sum() + gl._w_ld)
+            else:         # x = (z e^s + t) @ W
+                A, b = torch.exp(s)[:, None] * W, t @ W
+                ldc = s.sum() + gl._w_ld
+            if self._lin_index is None or self._lin_index.device != device:
+                idx = (ctypes.c_int32 * n)()
+                _lib.check("mnf_linear_rows_image_index", lib.mnf_linear_rows_image_index(self.dim, idx))
+                self._lin_index = torch.frombuffer(idx, dtype=torch.int32).clone().to(device)
+            aff = torch.empty(n + self.dim, dtype=torch.float32, device=device)
+            _lib.check("mnf_pack_gather", lib.mnf_pack_gather(
+                A.contiguous().data_ptr(), self._lin_index.data_ptr(), aff.data_ptr(), n, _stream()))
+            aff[n:] = b
+            self._aff[inverse] = (aff, float(ldc))  # one host read per parameter update
+        return self._aff[inverse]
+
+    def _run(self, x, inverse, accum):
+        nsf = self.nsf
+        needs_init = inverse and self.actnorm.data_dep_init_done is False
+        if (not isinstance(x, Tensor)) or (not x.is_cuda) or x.shape[0] == 0 or needs_init or any(
+                _wants_grad(m, x) for m in (self.actnorm, self.glow, nsf)):
+            y, ld = self._sequence(x, inverse)
+            if accum is not None:
+                accum += ld
+                return y, None
+            return y, ld
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        packed = self._affine(x.device, inverse)
+        _, image = nsf._packed(x.device)
+        if packed is not None and image is not None:
+            aff, ldc = packed
+            y = torch.empty_like(x)
+            ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            rc = _lib.load().mnf_nsf_cl_fused(
+                x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), image.data_ptr(), aff.data_ptr(),
+                ldc, x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_nsf_cl_fused", rc)
+                return y, (None if accum is not None else ld)
+        y, ld = self._sequence(x, inverse)
         if accum is not None:
             accum += ld
             return y, None
