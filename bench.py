@@ -35,6 +35,8 @@ WORKLOADS = {
     "c2": (64, 1 << 20, "9xAffineHalfFlow d=64 batch=2^20 inverse+log_prob (BASELINE configs[1])"),
     "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3] shard)"),
     "c3": (32, 1 << 20, "3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob (BASELINE configs[2])"),
+    "c2f": (64, 1 << 20, "FusedAffineStack(9xAffineHalfFlow) d=64 batch=2^20 inverse+log_prob (opt-in whole-stack "
+                         "fusion: no intermediates; reported separately from c2)"),
     "c3f": (32, 1 << 20, "3xFusedSplineBlock[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob "
                          "(opt-in fusion: block intermediates not materialised; reported separately from c3)"),
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
@@ -293,6 +295,10 @@ def main() -> None:
                                                            for i in range(3)]).to(device)
     else:
         model, layers = build_model(dim, device)
+        if args.workload == "c2f":
+            import torch_mnf_amd as _amd
+
+            model = _amd.NormalizingFlowModel(model.base, [_amd.FusedAffineStack(list(model.flows))]).to(device)
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
     n_layers = len(model.flows)
@@ -369,6 +375,7 @@ def main() -> None:
             kern_ms = [k for i, k in enumerate(kern_ms) if i % 3 == 0]
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
         algo_bytes = (8 * dim + 8) * rows  # per launch: read 4d, write 4d, log_det read+write
+        n_fused = 9 if args.workload == "c2f" else 1  # layers per launch (flop accounting)
         achieved = algo_bytes / avg_kernel_s / 1e9
         out = {
             "metric": "samples/s, 9xRNVP(AffineHalfFlow) d=64 batch=2^20 inverse+log-prob" if args.workload == "c2"
@@ -396,14 +403,15 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.workload),
                 "kernel": ("nsf_cl kernel (inverse)" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"
-                           if args.workload == "c3f" else f"ahf_mfma_kernel<{dim // 2},24,inverse>"),
+                           if args.workload == "c3f" else "ahf_stack_kernel<32,24,inverse> (9 layers per launch)"
+                           if args.workload == "c2f" else f"ahf_mfma_kernel<{dim // 2},24,inverse>"),
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launches_timed": len(kern_ms),
                 "per_layer_us": [round(v, 1) for v in per_layer_us],
                 "frac_of_achievable_6300": achieved / 6300.0,
-                "fp32_tflops": (12800 if args.workload in ("c3", "c3f") else 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24))
-                * rows / avg_kernel_s / 1e12,
+                "fp32_tflops": (12800 if args.workload in ("c3", "c3f") else
+                                n_fused * 2 * 2 * (2 * (dim // 2) * 24 + 2 * 24 * 24)) * rows / avg_kernel_s / 1e12,
             },
             "mean_log_prob": gpu_mean,
             "forward_direction_samples_per_s_per_gpu": fwd_rate,

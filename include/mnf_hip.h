@@ -81,6 +81,16 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
                        int64_t rows, int dim, int parity, int inverse,
                        int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                        int force_generic, void* stream);
+/* Opt-in whole-stack fusion: n_layers AffineHalfFlow layers of one shape in
+ * ONE launch, rows kept in registers across layers; no intermediate tensor is written, so this is
+ * not what NormalizingFlow.forward/inverse return by default.  images = the layers' operand
+ * images back to back (layer 0 first); layers are applied 0..L-1 (forward) or L-1..0 (inverse).
+ * HBM traffic: 8*dim + 8 bytes per row for the whole stack.  MNF_ERR_UNSUPPORTED for shapes
+ * without a fused kernel (dim in {32, 64}, hidden (24,24,24) or (16,16,16)). */
+int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
+                          const float* images, const int* parity_host, int n_layers,
+                          int64_t rows, int dim, int inverse,
+                          int n_hidden, const int* hidden_host, void* stream);
 /* 0 when the configuration has no specialised (MFMA) kernel. */
 int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden_host,
                                      int has_scale, int has_shift);

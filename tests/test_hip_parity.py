@@ -288,6 +288,36 @@ def test_c2_full_size_properties(amd, O):
     assert abs(float(total_all.item()) - float(lp_all.double().sum())) <= 1e-9 * abs(float(total_all.item()))
 
 
+@pytest.mark.parametrize("dim", [64, 32])
+def test_fused_affine_stack_matches_layer_by_layer(amd, golden, O, dim):
+    """Opt-in whole-stack fusion: one launch for all nine layers, same numbers as the layer-by-layer
+    pass and as the reference (G3 fixture at d=64)."""
+    layers = c2_layers(dim)
+    plain = build_ahf_stack(amd, layers, dim)
+    fused = amd.NormalizingFlowModel(amd.StandardNormal(dim), [amd.FusedAffineStack(list(plain.flows))]).to(DEV)
+    x = cuda(golden("g3_c2_stack")["d64.x"]) if dim == 64 else cuda(recipes.gaussian(8, 300, dim))
+    zs, ld = fused.inverse(x)
+    assert len(zs) == 2  # input and output only
+    zs_p, ld_p = plain.inverse(x)
+    assert_close(zs[-1], zs_p[-1], 1e-6, "fused vs layer-by-layer z")
+    assert_close(ld, ld_p, 1e-6, "fused vs layer-by-layer log_det")
+    xs, ld_f = fused.forward(x)
+    xs_p, ld_fp = plain.forward(x)
+    assert_close(xs[-1], xs_p[-1], 1e-6, "forward")
+    assert_close(ld_f, ld_fp, 1e-6, "forward log_det")
+    if dim == 64:
+        fx = golden("g3_c2_stack")
+        assert_close(zs[-1], fx["d64.z_last"], RTOL, "vs reference z")
+        assert_close(ld, fx["d64.ld_inv"], RTOL, "vs reference log_det")
+    lp, total = fused.log_prob(x, return_sum=True)       # fused |z|^2 epilogue too
+    lp_p, total_p = plain.log_prob(x, return_sum=True)
+    assert_close(lp, lp_p, 1e-6, "log_prob")
+    # ragged rows + big batch
+    xr = cuda(recipes.gaussian(9, 1000 + 77, dim))
+    assert_close(fused.inverse(xr)[0][-1], plain.inverse(xr)[0][-1], 1e-6, "ragged")
+    assert list(fused.flows[0].state_dict())[0] == "layers.0.s_net.0.weight"
+
+
 def test_log_det_accumulates_in_layer_order(amd):
     """NormalizingFlow's fused `log_det += ld` equals summing the per-layer log-dets."""
     dim = 64

@@ -14,6 +14,7 @@ from .flows import (
     ActNormFlow,
     AffineConstantFlow,
     AffineHalfFlow,
+    FusedAffineStack,
     FusedSplineBlock,
     Glow,
     NormalizingFlow,
@@ -26,7 +27,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "rqs", "MNFLinear", "library_path",
+    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "library_path",
 ]
 
 

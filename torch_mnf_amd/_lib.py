@@ -32,6 +32,8 @@ SIGNATURES = {
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
     "mnf_affine_half_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                    c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
+    "mnf_affine_half_stack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, _intp, c_int, c_int64,
+                                      c_int, c_int, c_int, _intp, c_void_p]),
     "mnf_affine_half_image_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
     "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),

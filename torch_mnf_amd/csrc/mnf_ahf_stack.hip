@@ -1,0 +1,238 @@
+// Opt-in whole-stack fusion of consecutive AffineHalfFlow layers.
+//
+// mnf_affine_half_stack runs L coupling layers in ONE launch: a wave keeps its 16 rows in
+// registers across all layers, so HBM sees the rows once in and once out (8d + 8 bytes per row
+// for the whole stack instead of per layer) and the stack becomes compute bound.  The per-layer
+// operand images (25 KB each at d = 64) are streamed from L2 through a double-buffered LDS window
+// shared by the eight waves of a workgroup: the image of layer l+1 is requested into registers
+// before layer l is computed and handed over at one barrier per layer.
+//
+// This drops every intermediate tensor, so it is NOT what NormalizingFlow.forward/inverse return
+// (the reference's API keeps all L+1 tensors, core.py:20-24); callers opt in through
+// torch_mnf_amd.FusedAffineStack and the number is reported separately from the headline metric.
+#include <hip/hip_runtime.h>
+
+#include "mnf_ahf_shape.h"
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+
+constexpr int kStackWaves = 8;
+
+// one coupling layer on rows held in registers: act <- exp(s) act + t (or its inverse), returns sum_j s_j
+template <int H, int HID, bool INV>
+__device__ __forceinline__ float ahf_layer_regs(const float* img, int lane, int q, const f32x4 (&cnd)[H / 16],
+                                                f32x4 (&act)[H / 16]) {
+  using S = AhfShape<H, HID>;
+  constexpr int G = S::G, QN = S::QN, NQ = S::NQ, NT = S::NT;
+  int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(img + a_off);
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(img + b_off);
+  int n = 0, bt = 0;
+  f32x4 a4;
+  f32x4 h1[NT], h2[NT], h3[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) h1[m] = B4[4 * (bt++)];
+#pragma unroll
+  for (int c1 = 0; c1 < H / 4; ++c1)
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[m][r] = leaky2(h1[m][r]);
+    h2[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < NQ; ++c)
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
+        ++n;
+      }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[m][r] = leaky2(h2[m][r]);
+    h3[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < NQ; ++c)
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
+        ++n;
+      }
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h3[m][r] = leaky2(h3[m][r]);
+  float ld = 0.f;
+#pragma unroll
+  for (int m = 0; m < G; ++m) {
+    f32x4 s4 = B4[4 * (bt++)];
+    f32x4 t4 = B4[4 * (bt++)];
+#pragma unroll
+    for (int c = 0; c < QN; ++c) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], s4, 0, 0, 0);
+      ++n;
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4, 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = exp6(INV ? -s4[r] : s4[r]);
+      act[m][r] = INV ? (act[m][r] - t4[r]) * e : __builtin_fmaf(e, act[m][r], t4[r]);
+      ld += s4[r];
+    }
+  }
+  return ld;
+}
+
+template <int H, int HID, bool INV>
+__global__ void __launch_bounds__(kStackWaves * 64, 6)  // three 8-wave workgroups per CU: <= 80 VGPRs
+ahf_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
+                 float* __restrict__ ysq, const float* __restrict__ images, uint32_t parity_bits, int n_layers,
+                 int64_t rows, int accumulate) {
+  using S = AhfShape<H, HID>;
+  constexpr int G = S::G, dim = 2 * H;
+  constexpr int IMG4 = S::IMAGE_FLOATS / 4;
+  constexpr int STAGE = (IMG4 + kStackWaves * 64 - 1) / (kStackWaves * 64);
+  __shared__ __attribute__((aligned(16))) float lds[2][S::IMAGE_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float4* img4 = reinterpret_cast<const float4*>(images);
+  auto layer_at = [&](int li) { return INV ? n_layers - 1 - li : li; };  // application order
+
+  const int n_groups = (int)((rows + 16 * kStackWaves - 1) / (16 * kStackWaves));
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t row = (int64_t)grp * (16 * kStackWaves) + wave * 16 + j;
+    const bool live = row < rows;
+    const int64_t rowc = live ? row : rows - 1;
+    const float* xr = x + rowc * dim + 4 * q;
+    f32x4 lo[G], hi[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) hi[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+    __syncthreads();  // the previous group's last layer is fully consumed
+    {
+      const float4* src = img4 + (int64_t)layer_at(0) * IMG4;
+      float4* dst = reinterpret_cast<float4*>(lds[0]);
+      for (int k = threadIdx.x; k < IMG4; k += kStackWaves * 64) dst[k] = src[k];
+    }
+    __syncthreads();
+    float ld = 0.f;
+    for (int li = 0; li < n_layers; ++li) {
+      const int layer = layer_at(li);
+      // request the next layer's image (after the last layer: the same one again, branch-free)
+      const float4* src = img4 + (int64_t)layer_at(li + 1 < n_layers ? li + 1 : li) * IMG4;
+      float4 st[STAGE];
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) {
+        const int k = threadIdx.x + i * (kStackWaves * 64);
+        st[i] = src[k < IMG4 ? k : 0];
+      }
+      const float* img = lds[li & 1];
+      if ((parity_bits >> layer) & 1u)  // conditioner = upper half
+        ld += ahf_layer_regs<H, HID, INV>(img, lane, q, hi, lo);
+      else
+        ld += ahf_layer_regs<H, HID, INV>(img, lane, q, lo, hi);
+      float4* dst = reinterpret_cast<float4*>(lds[(li + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < STAGE; ++i) {
+        const int k = threadIdx.x + i * (kStackWaves * 64);
+        if (k < IMG4) dst[k] = st[i];
+      }
+      __syncthreads();
+    }
+    if (live) {
+      float* yr = y + rowc * dim + 4 * q;
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = hi[g];
+    }
+    if (log_det) {
+      ld = sum_over_q(ld);
+      if (INV) ld = -ld;
+      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+    if (ysq) {
+      float sq = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = fmaf(lo[g][r], lo[g][r], fmaf(hi[g][r], hi[g][r], sq));
+      sq = sum_over_q(sq);
+      if (live && q == 0) ysq[row] = sq;
+    }
+  }
+}
+
+template <int H, int HID>
+static int launch_stack(const float* x, float* y, float* log_det, float* ysq, int accumulate, const float* images,
+                        uint32_t parity_bits, int n_layers, int64_t rows, int inverse, hipStream_t stream) {
+  const int64_t n_groups = (rows + 16 * kStackWaves - 1) / (16 * kStackWaves);
+  static const int resident = [] {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ahf_stack_kernel<H, HID, true>, kStackWaves * 64, 0) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 1;
+    return per_cu * cus;
+  }();
+  const int64_t blocks = n_groups < resident ? n_groups : resident;
+  const dim3 grid((unsigned)blocks), block(kStackWaves * 64);
+  if (inverse)
+    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, log_det, ysq, images,
+                       parity_bits, n_layers, rows, accumulate);
+  else
+    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, log_det, ysq, images,
+                       parity_bits, n_layers, rows, accumulate);
+  return check_launch();
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+// images: n_layers operand images (mnf_affine_half_image_floats each) back to back, layer 0 first;
+// parity_host[l] as in mnf_affine_half.  Layers are applied 0..L-1 (forward) or L-1..0 (inverse).
+int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
+                          const float* images, const int* parity_host, int n_layers, int64_t rows, int dim,
+                          int inverse, int n_hidden, const int* hidden, void* stream) {
+  if (!x || !y || x == y || !images || !parity_host || n_layers < 1 || n_layers > 32 || rows < 0 || dim < 2 ||
+      (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (n_hidden != 3 || hidden[0] != hidden[1] || hidden[1] != hidden[2]) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(images)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+  uint32_t bits = 0;
+  for (int l = 0; l < n_layers; ++l) bits |= (parity_host[l] ? 1u : 0u) << l;
+  const int hid = hidden[0];
+#define X(HH, HD) \
+  if (dim == 2 * HH && hid == HD) \
+    return mnf::launch_stack<HH, HD>(x, y, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, inverse != 0, \
+                                     (hipStream_t)stream);
+  X(16, 24) X(32, 24) X(16, 16) X(32, 16)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

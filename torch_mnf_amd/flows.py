@@ -29,7 +29,7 @@ from . import _lib
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
-    "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "FusedSplineBlock", "rqs",
+    "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs",
 ]
 
 
@@ -743,6 +743,76 @@ class FusedSplineBlock(_TwoWayFlow):
         return y, ld
 
 
+class FusedAffineStack(_TwoWayFlow):
+    """Opt-in whole-stack fusion of consecutive ``AffineHalfFlow`` layers of one shape (SURVEY.md 8f
+    rank 3): all of them in ONE kernel launch per direction, the rows held in registers across
+    layers -- HBM sees each row once in and once out.  No intermediate tensor exists, so as a member
+    of a ``NormalizingFlow`` it contributes ONE entry to the returned list instead of one per layer;
+    that change of what ``forward``/``inverse`` return is why this is an explicit opt-in.
+
+    ``state_dict`` keys are ``layers.{i}.s_net...``; falls back to running the layers one by one when
+    a graph is being recorded or the shape has no fused kernel."""
+
+    def __init__(self, layers: Sequence[AffineHalfFlow]) -> None:
+        super().__init__()
+        layers = list(layers)
+        if not layers or any(not isinstance(f, AffineHalfFlow) for f in layers):
+            raise TypeError("FusedAffineStack takes AffineHalfFlow layers")
+        f0 = layers[0]
+        if any((f.dim, f.h_sizes, f.scale, f.shift) != (f0.dim, f0.h_sizes, f0.scale, f0.shift) for f in layers):
+            raise ValueError("all layers must share dim, h_sizes and the scale/shift flags")
+        self.layers = nn.ModuleList(layers)
+        self.dim = f0.dim
+        self._img_key = None
+        self._images: Tensor | None = None
+
+    def _packed_params(self) -> list[Tensor]:
+        return []
+
+    def _sequence(self, x, inverse, sqnorm=None):
+        ld = 0
+        order = list(reversed(self.layers)) if inverse else list(self.layers)
+        for i, f in enumerate(order):
+            x, l1 = f._run(x, inverse, None, sqnorm if i == len(order) - 1 else None)
+            ld = ld + l1
+        return x, ld
+
+    def _stack_images(self, device) -> Tensor | None:
+        key = (device, tuple((p.data_ptr(), p._version) for f in self.layers for p in f._packed_params()))
+        if key != self._img_key:
+            imgs = [f._packed(device)[1] for f in self.layers]
+            self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
+            self._img_key = key
+        return self._images
+
+    def emits_sqnorm(self, device) -> bool:
+        return self._stack_images(device) is not None
+
+    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
+        f0 = self.layers[0]
+        fused_ok = isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and not any(
+            _wants_grad(f, x) for f in self.layers) and not any(f.force_generic for f in self.layers)
+        images = self._stack_images(x.device) if fused_ok else None
+        if images is not None:
+            x = _device_input(x, "input")
+            if x.shape[1] != self.dim:
+                raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+            y = torch.empty_like(x)
+            ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
+            rc = _lib.load().mnf_affine_half_stack(
+                x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), images.data_ptr(),
+                par, len(self.layers), x.shape[0], self.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_affine_half_stack", rc)
+                return y, (None if accum is not None else ld)
+        y, ld = self._sequence(x, inverse, sqnorm)
+        if accum is not None:
+            accum += ld
+            return y, None
+        return y, ld
+
+
 class NormalizingFlow(nn.Module):
     """Runs flows in order (forward) or reversed (inverse), summing log|det J| and keeping every
     intermediate (flows/core.py:10-35).  Layers from this package accumulate ``log_det`` inside
@@ -766,8 +836,8 @@ class NormalizingFlow(nn.Module):
             e_prev = torch.cuda.Event(enable_timing=True)
             e_prev.record()
         for i, flow in enumerate(order):
-            if (want_sqnorm and i == len(order) - 1 and isinstance(flow, AffineHalfFlow) and x.is_cuda
-                    and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
+            if (want_sqnorm and i == len(order) - 1 and isinstance(flow, (AffineHalfFlow, FusedAffineStack))
+                    and x.is_cuda and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
                 # last layer also emits |z|^2 per row for the standard-normal epilogue
                 self._last_sqnorm = torch.empty(x.size(0), device=x.device)
                 x, _ = flow._run(x, inverse, log_det, self._last_sqnorm)
