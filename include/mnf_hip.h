@@ -63,12 +63,17 @@ int mnf_device_count(void);
 
 /* ---------------------------------------------------------------- AffineHalfFlow */
 /* hidden: n_hidden sizes of the hidden layers (reference default {24,24,24}).
- * image: NULL, or the MFMA operand image (mnf_affine_half_image_floats() floats); when it is
- * given and the configuration has a specialised kernel, that kernel runs, otherwise the
- * generic one reads `flat`.  log_det may be NULL (not computed). accumulate != 0: log_det += ld.
- * force_generic != 0 selects the generic kernel (used by tests to compare the two). */
+ * Three kernels, fastest first:
+ *   split   image and split_image given, shape supported: conditioner nets on the f16 matrix pipe in
+ *           split (hi + lo) fp32 arithmetic -- three f16 MFMAs per fp32 product, fp32 accumulation,
+ *           ~22 significant bits per product; tiles whose operands leave the f16 range are recomputed
+ *           on the fp32 MFMA path inside the same launch (needs `image`)
+ *   fp32    image given (mnf_affine_half_image_floats() floats), split_image NULL: fp32 MFMAs
+ *   generic otherwise: reads `flat`, any shape
+ * log_det may be NULL (not computed). accumulate != 0: log_det += ld.
+ * force_generic != 0 selects the generic kernel (used by tests to compare the kernels). */
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
-                    const float* flat, const float* image,
+                    const float* flat, const float* image, const void* split_image,
                     int64_t rows, int dim, int parity, int inverse,
                     int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                     int force_generic, void* stream);
@@ -77,20 +82,31 @@ int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
  * specialised kernel produces it: MNF_ERR_UNSUPPORTED otherwise (callers then run
  * mnf_gauss_logprob on y). */
 int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
-                       const float* flat, const float* image,
+                       const float* flat, const float* image, const void* split_image,
                        int64_t rows, int dim, int parity, int inverse,
                        int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                        int force_generic, void* stream);
 /* Opt-in whole-stack fusion: n_layers AffineHalfFlow layers of one shape in
  * ONE launch, rows kept in registers across layers; no intermediate tensor is written, so this is
  * not what NormalizingFlow.forward/inverse return by default.  images = the layers' operand
- * images back to back (layer 0 first); layers are applied 0..L-1 (forward) or L-1..0 (inverse).
+ * images back to back (layer 0 first); split_images = their split images back to back, or NULL for
+ * the fp32 MFMA kernel; layers are applied 0..L-1 (forward) or L-1..0 (inverse).
  * HBM traffic: 8*dim + 8 bytes per row for the whole stack.  MNF_ERR_UNSUPPORTED for shapes
  * without a fused kernel (dim in {32, 64}, hidden (24,24,24) or (16,16,16)). */
 int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
-                          const float* images, const int* parity_host, int n_layers,
+                          const float* images, const void* split_images, const int* parity_host, int n_layers,
                           int64_t rows, int dim, int inverse,
                           int n_hidden, const int* hidden_host, void* stream);
+/* Split image of one layer: n_split_words 32-bit words of packed f16 (hi | scaled lo) operands, then
+ * n_plain_words fp32 words (biases), then MNF_SPLIT_TAIL_WORDS words written by the pack call (word 0
+ * = bit pattern of max |weight|: the kernels take the fp32 path when it leaves the f16 range).
+ * _split_index fills 2 * n_split_words + n_plain_words entries for mnf_pack_gather_split.
+ * MNF_ERR_UNSUPPORTED when the configuration has no split kernel. */
+#define MNF_SPLIT_TAIL_WORDS 4
+int mnf_affine_half_split_layout(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                                 int64_t* n_split_words, int64_t* n_plain_words);
+int mnf_affine_half_split_index(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                                int32_t* idx_host);
 /* 0 when the configuration has no specialised (MFMA) kernel. */
 int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden_host,
                                      int has_scale, int has_shift);
@@ -101,6 +117,12 @@ int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden_hos
                                     int has_scale, int has_shift);
 
 /* image[i] = idx[i] < 0 ? 0 : flat[idx[i]]  (device-side repack after a weight update). */
+/* Split-image pack (device): split word w = two f16 halves, half h from entry e = idx[2 w + h]:
+ * e < 0 -> 0; else v = flat[e & 0x3fffffff], hi = f16(v), and the half is hi, or f16((v - hi) * 2^11)
+ * when bit 30 of e is set.  Plain word w = flat[idx[2 n_split_words + w]] (or 0).  Also writes the
+ * MNF_SPLIT_TAIL_WORDS tail.  image holds n_split_words + n_plain_words + MNF_SPLIT_TAIL_WORDS words. */
+int mnf_pack_gather_split(const float* flat, const int32_t* idx_dev, void* image, int64_t n_split_words,
+                          int64_t n_plain_words, void* stream);
 int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------ NSF_CL */

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.mnf_abi_version() == 1
+    assert lib.mnf_abi_version() == 2
     assert lib.mnf_error_string(0) == b"ok"
     assert b"unsupported" in lib.mnf_error_string(-2).lower() or b"not supported" in lib.mnf_error_string(-2)
 
@@ -90,14 +90,14 @@ def test_argument_checking_without_a_gpu(lib):
     from torch_mnf_amd._lib import int_array
 
     hid = int_array([24, 24, 24])
-    assert lib.mnf_affine_half(None, None, None, 0, None, None, 4, 64, 0, 0, 3, hid, 1, 1, 0, None) == -1
+    assert lib.mnf_affine_half(None, None, None, 0, None, None, None, 4, 64, 0, 0, 3, hid, 1, 1, 0, None) == -1
     buf = (ctypes.c_float * 256)()
     p = ctypes.addressof(buf)
-    assert lib.mnf_affine_half(p, p, None, 0, p, None, 4, 64, 0, 0, 3, hid, 1, 1, 0, None) == -1  # aliasing
-    assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, 4, 63, 0, 0, 3, hid, 1, 1, 0, None) == -1  # odd dim
+    assert lib.mnf_affine_half(p, p, None, 0, p, None, None, 4, 64, 0, 0, 3, hid, 1, 1, 0, None) == -1  # aliasing
+    assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, None, 4, 63, 0, 0, 3, hid, 1, 1, 0, None) == -1  # odd dim
     assert lib.mnf_nsf_cl(p, p + 512, None, 0, p, None, 4, 32, 2000, 3.0, 0, 3, hid, 0, None) == -5  # K too large
     assert lib.mnf_rqs(p, p, p, p, p, p, 4, 1001, 3.0, 0, None) == -5
-    assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, 0, 64, 0, 0, 3, hid, 1, 1, 0, None) == 0  # empty batch
+    assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, None, 0, 64, 0, 0, 3, hid, 1, 1, 0, None) == 0  # empty batch
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import recipes
-from helpers import RTOL, assert_close, assert_parity, c2_layers, g1_layers, t, unpack_mask
+from helpers import RTOL, normwise_err, assert_close, assert_parity, c2_layers, g1_layers, t, unpack_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -43,21 +43,29 @@ def cuda(a):
     return (a if isinstance(a, torch.Tensor) else t(a)).to(DEV)
 
 
-def ahf_module(amd, sd, dim, parity, **kw):
+def ahf_module(amd, sd, dim, parity, kernel="split", **kw):
     f = amd.AffineHalfFlow(dim, parity, **kw)
     f.load_state_dict(sd)
-    return f.to(DEV)
+    return select_kernel(f.to(DEV), kernel)
+
+
+KERNELS = ["split", "fp32", "generic"]  # f16 hi+lo MFMA (default) / fp32 MFMA / shape-generic
+
+
+def select_kernel(f, kernel):
+    f.force_generic = kernel == "generic"
+    f.force_fp32_mfma = kernel == "fp32"
+    return f
 
 
 # ------------------------------------------------------------------ AffineHalfFlow
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dim", [64, 256])
 @pytest.mark.parametrize("parity", [False, True])
-def test_g2_affine_half_golden(amd, golden, dim, parity, generic):
+def test_g2_affine_half_golden(amd, golden, dim, parity, kernel):
     fx = golden("g2_affine_half_single")
     tag = f"d{dim}_p{int(parity)}"
-    f = ahf_module(amd, recipes.affine_half_params(200 + dim + int(parity), dim), dim, parity)
-    f.force_generic = generic
+    f = ahf_module(amd, recipes.affine_half_params(200 + dim + int(parity), dim), dim, parity, kernel)
     z = cuda(fx[f"{tag}.z"])
     x, ld = f.forward(z)
     assert_close(x, fx[f"{tag}.fwd"], RTOL, "fwd")
@@ -75,6 +83,10 @@ def test_mfma_kernel_is_selected(amd):
     hid = amd._lib.int_array([24, 24, 24])
     for dim in (32, 64, 128, 256):
         assert lib.mnf_affine_half_image_floats(dim, 3, hid, 1, 1) > 0
+        f = amd.AffineHalfFlow(dim, False).to(DEV)
+        assert f._split_image(torch.device(DEV, 0)) is not None  # the split kernel is the default
+        f.force_fp32_mfma = True
+        assert f._split_image(torch.device(DEV, 0)) is None
     assert lib.mnf_affine_half_image_floats(2, 3, hid, 1, 1) == 0
 
 
@@ -90,14 +102,15 @@ def test_g2_affine_half_variants(amd, golden, tag, kw):
         assert_close(ld, fx[f"{tag}.ld_{name}"], RTOL, f"{tag}.ld_{name}")
 
 
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
 @pytest.mark.parametrize("rows", [1, 15, 17, 1000, 4099])
 @pytest.mark.parametrize("dim", [32, 64, 128])
-def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim):
+def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim, kernel):
     """Tiles are 16 rows: partial last tile, single row, and a grid-stride wrap."""
     sd = recipes.affine_half_params(77 + dim, dim)
     x = recipes.gaussian(rows + dim, rows, dim)
     for parity in (False, True):
-        f = ahf_module(amd, sd, dim, parity)
+        f = ahf_module(amd, sd, dim, parity, kernel)
         for inverse in (False, True):
             ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
             y, ld = f.forward(cuda(x), inverse=inverse)
@@ -105,8 +118,9 @@ def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim):
             assert_close(ld, ref_ld, RTOL, "ld")
 
 
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
 @pytest.mark.parametrize("dim,hid", [(32, 16), (64, 16), (32, 32), (64, 32), (128, 32), (32, 24), (128, 24)])
-def test_affine_half_mfma_shape_matrix(amd, O, dim, hid):
+def test_affine_half_mfma_shape_matrix(amd, O, dim, hid, kernel):
     """Every (dim, hidden width) pair with a specialised kernel: MFMA result vs the oracle, and the
     library must actually have picked that kernel (an operand image exists)."""
     h_sizes = (hid, hid, hid)
@@ -115,8 +129,9 @@ def test_affine_half_mfma_shape_matrix(amd, O, dim, hid):
     sd = recipes.affine_half_params(90 + dim + hid, dim, h_sizes=h_sizes, s_last_gain=3.0)
     x = recipes.gaussian(91 + dim, 531, dim)
     for parity in (False, True):
-        f = ahf_module(amd, sd, dim, parity, h_sizes=h_sizes)
+        f = ahf_module(amd, sd, dim, parity, kernel, h_sizes=h_sizes)
         assert f._packed(torch.device(DEV, 0))[1] is not None
+        assert (f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split")
         for inverse in (False, True):
             ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
             y, ld = f.forward(cuda(x), inverse=inverse)
@@ -138,6 +153,94 @@ def test_rnvp_mfma_shape_matrix(amd, O, dim, hid):
     x, ld = f.forward(cuda(z), mask=cuda(mask))
     assert_close(x, ref_x, RTOL, "x")
     assert_close(ld, ref_ld, RTOL, "ld")
+
+
+def _f64_affine_half(x, sd, parity, inverse):
+    """float64 evaluation of the layer (affine_half_flow.py:44-66) as the accuracy yardstick."""
+    import numpy as np
+
+    x = np.asarray(x, np.float64)
+    h = x.shape[1] // 2
+    x0, x1 = (x[:, h:], x[:, :h]) if parity else (x[:, :h], x[:, h:])
+
+    def mlp(prefix, v):
+        n = len([k for k in sd if k.startswith(prefix) and k.endswith("weight")])
+        for i, li in enumerate(sorted({int(k.split(".")[1]) for k in sd if k.startswith(prefix)})):
+            v = v @ np.asarray(sd[f"{prefix}.{li}.weight"], np.float64).T + np.asarray(sd[f"{prefix}.{li}.bias"], np.float64)
+            if i < n - 1:
+                v = np.where(v > 0, v, 0.2 * v)
+        return v
+
+    sv, tv = mlp("s_net", x0), mlp("t_net", x0)
+    y1 = (x1 - tv) * np.exp(-sv) if inverse else np.exp(sv) * x1 + tv
+    y = np.concatenate([y1, x0] if parity else [x0, y1], axis=1)
+    return y, (-sv.sum(1) if inverse else sv.sum(1))
+
+
+@pytest.mark.parametrize("dim", [32, 64, 256])
+def test_split_kernel_accuracy_against_float64(amd, O, dim):
+    """The split (f16 hi + lo) kernel is as close to the float64 value of the layer as fp32 arithmetic is:
+    its error is of the size of the reference's own fp32 rounding error, far inside the 1e-5 bar."""
+    sd = recipes.affine_half_params(300 + dim, dim, s_last_gain=2.0)
+    x = recipes.gaussian(301 + dim, 2048, dim)
+    errs = {}
+    for inverse in (False, True):
+        y64, ld64 = _f64_affine_half(x, sd, True, inverse)
+        ref_y, ref_ld = O.affine_half(x, sd, True, inverse)  # the reference's fp32 arithmetic
+        for kernel in ("split", "fp32"):
+            with torch.no_grad():
+                y, ld = ahf_module(amd, sd, dim, True, kernel).forward(cuda(x), inverse=inverse)
+            errs[kernel, inverse] = max(normwise_err(y.cpu().numpy(), y64), normwise_err(ld.cpu().numpy(), ld64))
+        errs["reference", inverse] = max(normwise_err(ref_y.numpy(), y64), normwise_err(ref_ld.numpy(), ld64))
+        assert errs["split", inverse] < 1e-6, errs
+        assert errs["split", inverse] < 4 * errs["reference", inverse] + 2e-7, errs
+
+
+@pytest.mark.parametrize("case", ["big_inputs", "big_weights", "inf_input", "tiny_inputs", "one_big_row"])
+def test_split_kernel_range_guard(amd, O, case):
+    """Operands outside the f16 range (|v| >= 3e4) send the tile to the fp32 path inside the same launch:
+    results must not depend on the input range."""
+    import numpy as np
+
+    dim = 64
+    sd = recipes.affine_half_params(310, dim)
+    x = recipes.gaussian(311, 333, dim)
+    if case == "big_inputs":
+        x = x * 1.0e5
+        sd = {k: (v * 1e-5 if k.endswith(".0.weight") else v) for k, v in sd.items()}  # keeps s moderate
+    elif case == "big_weights":
+        sd = {k: (v * 1e5 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+        x = x * 1e-5
+    elif case == "inf_input":
+        x = x.clone()
+        x[7, 3] = float("inf")
+        x[100, 40] = -float("inf")
+    elif case == "tiny_inputs":
+        x = x * 1e-6
+    elif case == "one_big_row":
+        x = x.clone()
+        x[200] *= 5e4
+        sd = {k: (v * 1e-3 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+    for parity in (False, True):
+        for inverse in (False, True):
+            ref_y, ref_ld = O.affine_half(x, sd, parity, inverse)
+            y, ld = ahf_module(amd, sd, dim, parity, "split").forward(cuda(x), inverse=inverse)
+            fin = torch.isfinite(ref_y)
+            assert torch.equal(torch.isfinite(y).cpu(), fin)
+            rows_ok = fin.all(1)
+            assert_close(y[rows_ok.to(DEV)], ref_y[rows_ok], RTOL, f"{case} y")
+            assert_close(ld[rows_ok.to(DEV)], ref_ld[rows_ok], RTOL, f"{case} ld")
+    # the stack kernel shares the guard
+    flows = [ahf_module(amd, sd, dim, bool(i % 2), "split") for i in range(3)]
+    fused = amd.FusedAffineStack(flows).to(DEV)
+    z, ld = fused.inverse(cuda(x))
+    ref_z, ref_ld = x, 0
+    for i in reversed(range(3)):
+        ref_z, l1 = O.affine_half(ref_z, sd, bool(i % 2), True)
+        ref_ld = ref_ld + l1
+    rows_ok = torch.isfinite(ref_z).all(1)
+    assert_close(z[rows_ok.to(DEV)], ref_z[rows_ok], 3 * RTOL, f"{case} stack z")
+    assert_close(ld[rows_ok.to(DEV)], ref_ld[rows_ok], 3 * RTOL, f"{case} stack ld")
 
 
 def test_empty_batches(amd):

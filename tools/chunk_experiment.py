@@ -28,7 +28,7 @@ def run(chunk):
             f = flows[fi]; flat, image = packed[fi]
             src, dst = bufs[li], bufs[li + 1]
             rc = lib.mnf_affine_half(src.data_ptr() + r0 * dim * 4, dst.data_ptr() + r0 * dim * 4, ld.data_ptr() + r0 * 4, 1,
-                                     flat.data_ptr(), image.data_ptr(), n, dim, int(f.parity), 1, 3, f._hid, 1, 1, 0, _stream())
+                                     flat.data_ptr(), image.data_ptr(), None, n, dim, int(f.parity), 1, 3, f._hid, 1, 1, 0, _stream())
             assert rc == 0
 
 def timed(chunk, n=10):

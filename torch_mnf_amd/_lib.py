@@ -21,6 +21,8 @@ MNF_ERR_DOMAIN = -5
 
 _intp = POINTER(c_int)
 _i32p = POINTER(c_int32)
+_i64p = POINTER(c_int64)
+MNF_SPLIT_TAIL_WORDS = 4
 
 # name -> (restype, argtypes); mirrors include/mnf_hip.h one to one
 SIGNATURES = {
@@ -28,12 +30,15 @@ SIGNATURES = {
     "mnf_error_string": (c_char_p, [c_int]),
     "mnf_last_hip_error": (c_int, []),
     "mnf_device_count": (c_int, []),
-    "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
+    "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
-    "mnf_affine_half_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
-                                   c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
-    "mnf_affine_half_stack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, _intp, c_int, c_int64,
-                                      c_int, c_int, c_int, _intp, c_void_p]),
+    "mnf_affine_half_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
+    "mnf_affine_half_stack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, _intp, c_int,
+                                      c_int64, c_int, c_int, c_int, _intp, c_void_p]),
+    "mnf_affine_half_split_layout": (c_int, [c_int, c_int, _intp, c_int, c_int, _i64p, _i64p]),
+    "mnf_affine_half_split_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
+    "mnf_pack_gather_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mnf_affine_half_image_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
     "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),

@@ -60,4 +60,96 @@ struct AhfShape {
   static constexpr int IMAGE_FLOATS = A_FLOATS + N_BIAS_TILES * 16;
 };
 
+// The two conditioner nets on fp32 MFMAs (16x16x4): cnd (accumulator layout: lane (j, q) reg r <-> dim
+// 16 g + 4 q + r) -> raw s and t in the same layout.  img is the fp32 operand image, in LDS (hot path
+// of the fp32 kernels) or in global memory (cold path of the split kernels).
+template <int H, int HID>
+__device__ __forceinline__ void ahf_cond_f32(const float* img, int lane, int q, const f32x4 (&cnd)[H / 16],
+                                             f32x4 (&s4)[H / 16], f32x4 (&t4)[H / 16]) {
+  using S = AhfShape<H, HID>;
+  constexpr int G = S::G, QN = S::QN, NQ = S::NQ, NT = S::NT;
+  int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(img + a_off);
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(img + b_off);
+  int n = 0, bt = 0;
+  f32x4 a4;
+  f32x4 h1[NT], h2[NT], h3[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) h1[m] = B4[4 * (bt++)];
+#pragma unroll
+  for (int c1 = 0; c1 < H / 4; ++c1)
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
+      ++n;
+    }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[m][r] = leaky2(h1[m][r]);
+    h2[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < NQ; ++c)
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
+        ++n;
+      }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[m][r] = leaky2(h2[m][r]);
+    h3[m] = B4[4 * (bt++)];
+  }
+#pragma unroll
+  for (int c = 0; c < NQ; ++c)
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
+        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+        h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
+        ++n;
+      }
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h3[m][r] = leaky2(h3[m][r]);
+#pragma unroll
+  for (int m = 0; m < G; ++m) {
+    s4[m] = B4[4 * (bt++)];
+    t4[m] = B4[4 * (bt++)];
+#pragma unroll
+    for (int c = 0; c < QN; ++c) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      s4[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], s4[m], 0, 0, 0);
+      ++n;
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      t4[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4[m], 0, 0, 0);
+      ++n;
+    }
+  }
+}
+
+// act <- exp(s) act + t, or its inverse (act - t) exp(-s): one multiply instead of a ~10-instruction
+// IEEE divide, same limits (0, inf, NaN), <= 2 ulp from the quotient.  Returns this lane's sum of s.
+template <int H, bool INV>
+__device__ __forceinline__ float ahf_transform(const f32x4 (&s4)[H / 16], const f32x4 (&t4)[H / 16],
+                                               f32x4 (&act)[H / 16]) {
+  float ld = 0.f;
+#pragma unroll
+  for (int m = 0; m < H / 16; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = exp6(INV ? -s4[m][r] : s4[m][r]);
+      act[m][r] = INV ? (act[m][r] - t4[m][r]) * e : __builtin_fmaf(e, act[m][r], t4[m][r]);
+      ld += s4[m][r];
+    }
+  return ld;
+}
+
 }  // namespace mnf

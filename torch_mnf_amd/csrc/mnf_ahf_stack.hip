@@ -24,81 +24,9 @@ constexpr int kStackWaves = 8;
 template <int H, int HID, bool INV>
 __device__ __forceinline__ float ahf_layer_regs(const float* img, int lane, int q, const f32x4 (&cnd)[H / 16],
                                                 f32x4 (&act)[H / 16]) {
-  using S = AhfShape<H, HID>;
-  constexpr int G = S::G, QN = S::QN, NQ = S::NQ, NT = S::NT;
-  int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
-  asm volatile("" : "+v"(a_off), "+v"(b_off));
-  const f32x4* A4 = reinterpret_cast<const f32x4*>(img + a_off);
-  const f32x4* B4 = reinterpret_cast<const f32x4*>(img + b_off);
-  int n = 0, bt = 0;
-  f32x4 a4;
-  f32x4 h1[NT], h2[NT], h3[NT];
-#pragma unroll
-  for (int m = 0; m < NT; ++m) h1[m] = B4[4 * (bt++)];
-#pragma unroll
-  for (int c1 = 0; c1 < H / 4; ++c1)
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-      h1[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], cnd[c1 >> 2][c1 & 3], h1[m], 0, 0, 0);
-      ++n;
-    }
-#pragma unroll
-  for (int m = 0; m < NT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h1[m][r] = leaky2(h1[m][r]);
-    h2[m] = B4[4 * (bt++)];
-  }
-#pragma unroll
-  for (int c = 0; c < NQ; ++c)
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
-        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-        h2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h1[c >> 2][c & 3], h2[m], 0, 0, 0);
-        ++n;
-      }
-#pragma unroll
-  for (int m = 0; m < NT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h2[m][r] = leaky2(h2[m][r]);
-    h3[m] = B4[4 * (bt++)];
-  }
-#pragma unroll
-  for (int c = 0; c < NQ; ++c)
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-      if (S::tile_has_net(m, c >= QN ? 1 : 0)) {
-        if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-        h3[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h2[c >> 2][c & 3], h3[m], 0, 0, 0);
-        ++n;
-      }
-#pragma unroll
-  for (int m = 0; m < NT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h3[m][r] = leaky2(h3[m][r]);
-  float ld = 0.f;
-#pragma unroll
-  for (int m = 0; m < G; ++m) {
-    f32x4 s4 = B4[4 * (bt++)];
-    f32x4 t4 = B4[4 * (bt++)];
-#pragma unroll
-    for (int c = 0; c < QN; ++c) {
-      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-      s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[c >> 2][c & 3], s4, 0, 0, 0);
-      ++n;
-      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
-      t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], h3[(QN + c) >> 2][(QN + c) & 3], t4, 0, 0, 0);
-      ++n;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = exp6(INV ? -s4[r] : s4[r]);
-      act[m][r] = INV ? (act[m][r] - t4[r]) * e : __builtin_fmaf(e, act[m][r], t4[r]);
-      ld += s4[r];
-    }
-  }
-  return ld;
+  f32x4 s4[H / 16], t4[H / 16];
+  ahf_cond_f32<H, HID>(img, lane, q, cnd, s4, t4);
+  return ahf_transform<H, INV>(s4, t4, act);
 }
 
 template <int H, int HID, bool INV>
@@ -214,8 +142,8 @@ extern "C" {
 // images: n_layers operand images (mnf_affine_half_image_floats each) back to back, layer 0 first;
 // parity_host[l] as in mnf_affine_half.  Layers are applied 0..L-1 (forward) or L-1..0 (inverse).
 int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
-                          const float* images, const int* parity_host, int n_layers, int64_t rows, int dim,
-                          int inverse, int n_hidden, const int* hidden, void* stream) {
+                          const float* images, const void* split_images, const int* parity_host, int n_layers,
+                          int64_t rows, int dim, int inverse, int n_hidden, const int* hidden, void* stream) {
   if (!x || !y || x == y || !images || !parity_host || n_layers < 1 || n_layers > 32 || rows < 0 || dim < 2 ||
       (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
@@ -226,6 +154,11 @@ int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqn
   uint32_t bits = 0;
   for (int l = 0; l < n_layers; ++l) bits |= (parity_host[l] ? 1u : 0u) << l;
   const int hid = hidden[0];
+  if (split_images) {
+    const int rc = mnf::ahf_split_stack_launch(x, y, log_det, y_sqnorm, accumulate, split_images, images, bits,
+                                               n_layers, rows, dim, inverse, hid, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) \
     return mnf::launch_stack<HH, HD>(x, y, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, inverse != 0, \

@@ -16,6 +16,7 @@
 
 #include "mnf_device.h"
 #include "mnf_host.h"
+#include "mnf_split.h"
 
 namespace mnf {
 
@@ -467,6 +468,33 @@ __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t
   }
 }
 
+// ---------------------------------------------------------------- pack: flat fp32 -> split image
+__global__ void pack_gather_split_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
+                                         uint32_t* __restrict__ image, int64_t n_split, int64_t n_plain) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float mx = 0.f;
+  if (w < n_split) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int32_t e = idx[2 * w + h];
+      if (e < 0) continue;
+      const float v = flat[e & (kSplitLoBit - 1)];
+      const _Float16 hi = (_Float16)v;
+      const _Float16 part = (e & kSplitLoBit) ? (_Float16)((v - (float)hi) * kSplitScale) : hi;
+      word |= (uint32_t)__builtin_bit_cast(uint16_t, part) << (16 * h);
+      mx = fmaxf(mx, fabsf(v));  // NaN weights: fmaxf drops them here, the MFMAs propagate them
+      if (!(fabsf(v) <= 3.0e38f)) mx = __builtin_inff();  // inf or NaN weight: always take the fp32 path
+    }
+    image[w] = word;
+  } else if (w < n_split + n_plain) {
+    const int32_t e = idx[2 * n_split + (w - n_split)];
+    image[w] = e < 0 ? 0u : __builtin_bit_cast(uint32_t, flat[e]);
+  }
+  // non-negative floats order like their bit patterns
+  if (mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));
+}
+
 }  // namespace mnf
 
 // =====================================================================================
@@ -523,7 +551,7 @@ static int grid_for(int64_t n, int threads, int cap = 256 * 8) {
 
 extern "C" {
 
-int mnf_abi_version(void) { return 1; }
+int mnf_abi_version(void) { return 2; }
 
 const char* mnf_error_string(int code) {
   switch (code) {
@@ -564,20 +592,26 @@ int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden, in
 }
 
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate, const float* flat,
-                    const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
-                    const int* hidden, int has_scale, int has_shift, int force_generic, void* stream) {
-  return mnf_affine_half_sq(x, y, log_det, nullptr, accumulate, flat, image, rows, dim, parity, inverse,
+                    const float* image, const void* split_image, int64_t rows, int dim, int parity, int inverse,
+                    int n_hidden, const int* hidden, int has_scale, int has_shift, int force_generic,
+                    void* stream) {
+  return mnf_affine_half_sq(x, y, log_det, nullptr, accumulate, flat, image, split_image, rows, dim, parity, inverse,
                             n_hidden, hidden, has_scale, has_shift, force_generic, stream);
 }
 
 int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
-                       const float* flat, const float* image, int64_t rows, int dim, int parity,
-                       int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                       const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
+                       int parity, int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
                        int force_generic, void* stream) {
   if (!x || !y || x == y || rows < 0 || dim < 2 || (dim & 1) || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if ((has_scale || has_shift) && !flat && !image) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
+  if (image && split_image && !force_generic) {
+    const int rc = ahf_split_launch(x, y, log_det, y_sqnorm, accumulate, split_image, image, rows, dim, parity,
+                                    inverse, n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
   if (image && !force_generic) {
     const int rc = ahf_mfma_launch(x, y, log_det, y_sqnorm, accumulate, image, rows, dim, parity, inverse,
                                    n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
@@ -614,6 +648,19 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ahf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
                      ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
+  return check_launch();
+}
+
+int mnf_pack_gather_split(const float* flat, const int32_t* idx, void* image, int64_t n_split_words,
+                          int64_t n_plain_words, void* stream) {
+  if (!flat || !idx || !image || n_split_words < 0 || n_plain_words < 0) return MNF_ERR_INVALID_ARG;
+  uint32_t* img = static_cast<uint32_t*>(image);
+  const int64_t n = n_split_words + n_plain_words;
+  if (hipMemsetAsync(img + n, 0, MNF_SPLIT_TAIL_WORDS * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return check_launch();
+  if (n == 0) return MNF_OK;
+  hipLaunchKernelGGL(pack_gather_split_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, flat,
+                     idx, img, n_split_words, n_plain_words);
   return check_launch();
 }
 

@@ -38,6 +38,12 @@ inline int64_t balanced_grid(int64_t n_tiles, int waves_per_block, int resident_
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
                     const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
                     const int* hidden, int has_scale, int has_shift, hipStream_t stream);
+int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate, const void* split_image,
+                     const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
+                     const int* hidden, int has_scale, int has_shift, hipStream_t stream);
+int ahf_split_stack_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+                           const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
+                           int64_t rows, int dim, int inverse, int hid, hipStream_t stream);
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                     int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
                     const int* hidden, hipStream_t stream);

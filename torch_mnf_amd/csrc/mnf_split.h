@@ -1,0 +1,291 @@
+// fp32 products on the f16 matrix pipe ("split" arithmetic), shared by the kernels that use it.
+//
+// gfx950 runs v_mfma_f32_16x16x4_f32 at the fp32 VALU rate (32 cycles per 2,048 MACs... i.e. 256
+// flop/cycle/CU) and it does not overlap with VALU work, which is what bounds the conditioner nets
+// of the coupling layers.  v_mfma_f32_16x16x32_f16 does 8x the MACs in half the cycles and leaves
+// the vector issue port free for half of them.  A fp32 value v is carried as two f16 numbers
+//
+//     hi = f16(v)                       (11 significant bits)
+//     lo = f16((v - f32(hi)) * 2^11)    (the next 11 bits, pre-scaled so it stays a normal f16)
+//
+// and a fp32 product sum  sum_k w_k v_k  is evaluated as three f16 MFMAs with fp32 accumulation
+//
+//     main = sum w_hi v_hi           corr = sum (w_hi v_lo + w_lo v_hi)         result = main + corr * 2^-11
+//
+// Every f16 x f16 product is exact in fp32; the dropped w_lo v_lo term is 2^-22 relative, so the
+// result carries ~22 significant bits per product (fp32: 24) -- measured against float64 the split
+// MLP is 1.7e-7 normwise where the fp32 MLP is 0.7e-7 (tests/test_hip_parity.py, tools/split_error.py);
+// the parity bar is 1e-5.  16 x fewer matrix-pipe cycles per MAC x 3 products = 5.3 x fewer cycles.
+//
+// Range: f16 tops out at 65,504 and lo is scaled by 2^11, so the scheme needs |v| < 2^15 for every
+// operand.  The kernels track max|v| per 16-row tile (one v_max3 per two values) and recompute a tile
+// that exceeds kSplitLimit -- or whose weights do, flagged by the pack kernel -- on the fp32 MFMA path,
+// so results do not depend on the input range.  Values below 2^-14 lose low bits of hi to f16
+// subnormals; their absolute error is < 2^-25 and lo still carries the residual.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mnf_ahf_shape.h"
+
+namespace mnf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kSplitScale = 2048.f;          // 2^11
+constexpr float kSplitInvScale = 1.f / 2048.f;
+constexpr float kSplitLimit = 30000.f;         // < 2^15 with headroom for the round-toward-zero residual
+constexpr int kSplitTailWords = 4;             // [max|w| bits, 0, 0, 0] after the plain words
+constexpr int32_t kSplitLoBit = 1 << 30;       // index-table entry: take the lo part of the source value
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// v - f32(low / high half of hp), exact, in one instruction (the compiler emits cvt + sub for the C form)
+__device__ __forceinline__ float residual_lo(uint32_t hp, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+  return r;
+}
+__device__ __forceinline__ float residual_hi(uint32_t hp, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+  return r;
+}
+
+// two fp32 values -> packed f16 hi pair and packed scaled-residual pair; mx tracks max|v|.
+// Six vector instructions: cvt_pkrtz, 2 x fma_mix, pk_mul, cvt_pkrtz, max3.
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t& hi, uint32_t& lo, float& mx) {
+  hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+  f32x2 r = f32x2{residual_lo(hi, v0), residual_hi(hi, v1)};
+  r = r * kSplitScale;
+  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r[0], r[1]));
+  mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v0)), __builtin_fabsf(v1));
+}
+
+// the four accumulator rows of one 16x16 tile (rows 4q..4q+3) -> two words of hi, two of lo
+__device__ __forceinline__ void split_tile(const f32x4& v, u32x2& hi, u32x2& lo, float& mx) {
+  uint32_t h0, l0, h1, l1;
+  split_pair(v[0], v[1], h0, l0, mx);
+  split_pair(v[2], v[3], h1, l1, mx);
+  hi = u32x2{h0, h1};
+  lo = u32x2{l0, l1};
+}
+
+// B operand of one K = 32 step: slots 8q..8q+3 <- tile a rows 4q..4q+3, slots 8q+4..8q+7 <- tile b
+__device__ __forceinline__ f16x8 pair_operand(const u32x2& a, const u32x2& b) {
+  return __builtin_bit_cast(f16x8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
+__device__ __forceinline__ f32x4 mfma_h(const f16x8& a, const f16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// main += Ah Bh ; corr += Ah Bl + Al Bh
+__device__ __forceinline__ void split_mac(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                          f32x4& main, f32x4& corr) {
+  main = mfma_h(ah, bh, main);
+  corr = mfma_h(ah, bl, corr);
+  corr = mfma_h(al, bh, corr);
+}
+
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// ------------------------------------------------------------------------------------------------
+// Tiling of a coupling layer's two conditioner nets (s and t, HID hidden units each, evaluated as
+// one concatenated net with block-diagonal hidden layers) for 16x16x32 MFMAs.
+//   hidden vector u in [0, 2 HID): u < HID is s-net unit u, else t-net unit u - HID; tile m holds
+//   u = 16 m + i in accumulator row i.  A hidden K-step pairs two tiles (the accumulator registers
+//   of tiles a, b ARE the B operand after the split -- no data movement between layers).
+// ------------------------------------------------------------------------------------------------
+template <int H, int HID>
+struct SplitShape {
+  static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported conditioner shape");
+  static constexpr int G = H / 16;                 // 16-dim groups per half row = output tiles per net
+  static constexpr int KS1 = (G + 1) / 2;          // K-steps of the first layer
+  static constexpr int NT = (2 * HID + 15) / 16;   // tiles of the concatenated hidden vector
+  static constexpr int NKS = (NT + 1) / 2;         // hidden K-steps
+  static constexpr int ks_a(int ks) { return (NT > 1 && (NT & 1) && ks == NKS - 1) ? NT - 2 : 2 * ks; }
+  static constexpr int ks_b(int ks) { return ks_a(ks) + 1 < NT ? ks_a(ks) + 1 : -1; }
+  static constexpr bool ks_has(int ks, int tile) { return ks_a(ks) == tile || ks_b(ks) == tile; }
+  // nets: bit 0 = s, bit 1 = t
+  static constexpr bool tile_needed(int nets, int tile) {
+    for (int i = 0; i < 16; ++i) {
+      const int u = 16 * tile + i;
+      if (u < 2 * HID && ((nets >> (u / HID)) & 1)) return true;
+    }
+    return false;
+  }
+  static constexpr int tile_nets(int tile) {  // nets with a unit in this tile
+    int nets = 0;
+    for (int i = 0; i < 16; ++i)
+      if (16 * tile + i < 2 * HID) nets |= 1 << ((16 * tile + i) / HID);
+    return nets;
+  }
+  static constexpr int single_cover(int nets) {
+    for (int ks = 0; ks < NKS; ++ks) {
+      bool all = true;
+      for (int t = 0; t < NT; ++t)
+        if (tile_needed(nets, t) && !ks_has(ks, t)) all = false;
+      if (all) return ks;
+    }
+    return -1;
+  }
+  // the K-step through which input tile `tile` feeds an output that depends on `nets`
+  static constexpr int assigned_ks(int nets, int tile) {
+    const int sc = single_cover(nets);
+    if (sc >= 0) return sc;
+    for (int ks = 0; ks < NKS; ++ks)
+      if (ks_has(ks, tile)) return ks;
+    return -1;
+  }
+  static constexpr bool uses(int nets, int ks) {
+    for (int t = 0; t < NT; ++t)
+      if (tile_needed(nets, t) && assigned_ks(nets, t) == ks) return true;
+    return false;
+  }
+  static constexpr int count_ops() {
+    int n = NT * KS1;
+    for (int m = 0; m < NT; ++m)
+      for (int ks = 0; ks < NKS; ++ks)
+        if (uses(tile_nets(m), ks)) n += 2;
+    for (int net = 0; net < 2; ++net)
+      for (int ks = 0; ks < NKS; ++ks)
+        if (uses(1 << net, ks)) n += G;
+    return n;
+  }
+  static constexpr int N_OPS = count_ops();              // (hi, lo) A-operand pairs = MFMA triples
+  static constexpr int SPLIT_WORDS = N_OPS * 2 * 256;    // [op][hi|lo][lane][4 words]
+  static constexpr int N_BIAS_TILES = 3 * NT + 2 * G;
+  static constexpr int PLAIN_WORDS = N_BIAS_TILES * 16;
+  static constexpr int IMAGE_WORDS = SPLIT_WORDS + PLAIN_WORDS + kSplitTailWords;
+};
+
+// The conditioner on the split path: cnd (G groups of the conditioning half, accumulator layout
+// lane (j, q) reg r <-> dim 16 g + 4 q + r) -> raw s and t of the same layout.  `img` points at the
+// LDS copy of the split image.  mx accumulates max|operand| (see kSplitLimit).
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// after_split() runs once cnd has been turned into MFMA operands (cnd is dead from there on: the
+// single-layer kernel issues its prefetch of the next tile there).
+// ABL != 0 only in tools/split_microbench.hip (1 = MFMAs skipped, 3 = operand splitting skipped).
+template <int H, int HID, typename Hook = NoHook, int ABL = 0>
+__device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane, int q, const f32x4 (&cnd)[H / 16],
+                                                  f32x4 (&s4)[H / 16], f32x4 (&t4)[H / 16], float& mx,
+                                                  Hook after_split = Hook()) {
+  using S = SplitShape<H, HID>;
+  constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
+  // opaque offsets: keep the (loop-invariant) operand reads inside the tile loop instead of in VGPRs
+  int a_off = lane * 4, b_off = S::SPLIT_WORDS + q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));
+  const f16x8* A8 = reinterpret_cast<const f16x8*>(img + a_off);  // + 64 * (2 op + part)
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(img + b_off);  // + 4 * tile
+  int op = 0, bt = 0;
+  const u32x2 zero2 = u32x2{0u, 0u};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto split_tile = [&](const f32x4& v, u32x2& hi, u32x2& lo, float& m) {
+    if (ABL == 3) {
+      hi = u32x2{__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])};
+      lo = u32x2{__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])};
+    } else {
+      mnf::split_tile(v, hi, lo, m);
+    }
+  };
+  auto split_mac = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
+    if (ABL == 1) {
+      mn += __builtin_bit_cast(f32x4, ah) * __builtin_bit_cast(f32x4, bh);
+      cr += __builtin_bit_cast(f32x4, al) * __builtin_bit_cast(f32x4, bl);
+    } else {
+      mnf::split_mac(ah, al, bh, bl, mn, cr);
+    }
+  };
+  u32x2 xh[G], xl[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) split_tile(cnd[g], xh[g], xl[g], mx);
+  after_split();
+
+  // ---- layer 1
+  f32x4 main[NT], corr[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    main[m] = B4[4 * (bt++)];
+    corr[m] = zero4;
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) {
+    const f16x8 bh = pair_operand(xh[2 * ks], 2 * ks + 1 < G ? xh[2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
+    const f16x8 bl = pair_operand(xl[2 * ks], 2 * ks + 1 < G ? xl[2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, main[m], corr[m]);
+      ++op;
+    }
+  }
+  u32x2 hh[NT], hl[NT];
+  auto activate = [&]() {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      // pre-activation = main + corr 2^-11, LeakyReLU = max(p, 0.2 p): vector forms so that the
+      // multiply-adds go out as packed fp32 instructions (two values each)
+      const f32x4 p = corr[m] * kSplitInvScale + main[m];
+      const f32x4 v = __builtin_elementwise_max(p, p * kLeakySlope);
+      split_tile(v, hh[m], hl[m], mx);
+    }
+  };
+  activate();
+
+  // ---- hidden layers 2 and 3 (block diagonal)
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      main[m] = B4[4 * (bt++)];
+      corr[m] = zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ta = S::ks_a(ks), tb = S::ks_b(ks);
+      const f16x8 bh = pair_operand(hh[ta], tb >= 0 ? hh[tb >= 0 ? tb : 0] : zero2);
+      const f16x8 bl = pair_operand(hl[ta], tb >= 0 ? hl[tb >= 0 ? tb : 0] : zero2);
+#pragma unroll
+      for (int m = 0; m < NT; ++m)
+        if (S::uses(S::tile_nets(m), ks)) {
+          split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, main[m], corr[m]);
+          ++op;
+        }
+    }
+    activate();
+  }
+
+  // ---- output layer: s from the s-net units, t from the t-net units
+#pragma unroll
+  for (int net = 0; net < 2; ++net) {
+    f32x4(&out)[G] = net ? t4 : s4;
+    f32x4 oc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      out[g] = B4[4 * (bt++)];
+      oc[g] = zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      if (S::uses(1 << net, ks)) {
+        const int ta = S::ks_a(ks), tb = S::ks_b(ks);
+        const f16x8 bh = pair_operand(hh[ta], tb >= 0 ? hh[tb >= 0 ? tb : 0] : zero2);
+        const f16x8 bl = pair_operand(hl[ta], tb >= 0 ? hl[tb >= 0 ? tb : 0] : zero2);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, out[g], oc[g]);
+          ++op;
+        }
+      }
+#pragma unroll
+    for (int g = 0; g < G; ++g) out[g] = oc[g] * kSplitInvScale + out[g];
+  }
+}
+
+}  // namespace mnf

@@ -25,7 +25,12 @@ from collections.abc import Sequence
 import torch
 from torch import Tensor, nn
 
+import os
+
 from . import _lib
+
+# MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
+_FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
@@ -96,7 +101,8 @@ class _AffineHalfFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_half", _lib.load().mnf_affine_half(
-            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), x.shape[0], module.dim,
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), _ptr(module._split_image(x.device)),
+            x.shape[0], module.dim,
             int(bool(module.parity)), int(inverse), len(module.h_sizes), module._hid, int(module.scale),
             int(module.shift), int(module.force_generic), _stream()))
         ctx.module, ctx.inverse = module, inverse
@@ -237,7 +243,10 @@ class _HipFlow(nn.Module):
         self._flat: Tensor | None = None
         self._image: Tensor | None = None
         self._index: Tensor | None = None  # device int32 gather table, built once
+        self._split: Tensor | None = None  # split (f16 hi + lo) operand image, see csrc/mnf_split.h
+        self._split_index = None           # (device int32 table, n_split_words, n_plain_words) or False
         self.force_generic = False  # tests: run the generic kernel even if an MFMA one exists
+        self.force_fp32_mfma = False  # tests / MNF_FP32_MFMA=1: fp32 MFMA kernel instead of the split one
 
     # subclasses: ordered parameter list == state_dict order
     def _packed_params(self) -> list[Tensor]:
@@ -245,6 +254,16 @@ class _HipFlow(nn.Module):
 
     def _image_index_host(self):  # -> ctypes int32 array or None
         return None
+
+    def _split_index_host(self):  # -> (ctypes int32 array, n_split_words, n_plain_words) or None
+        return None
+
+    def _split_image(self, device: torch.device) -> Tensor | None:
+        """The split operand image for the current parameters, or None (no split kernel / switched off)."""
+        if self.force_fp32_mfma or _FP32_MFMA_ENV:
+            return None
+        self._packed(device)
+        return self._split
 
     def _packed(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
         params = self._packed_params()
@@ -266,6 +285,18 @@ class _HipFlow(nn.Module):
                 self._image = image
             else:
                 self._image = None
+            if self._split_index is None or (self._split_index and self._split_index[0].device != device):
+                host = self._split_index_host()
+                self._split_index = False if host is None else (
+                    torch.frombuffer(host[0], dtype=torch.int32).clone().to(device), host[1], host[2])
+            if self._split_index:
+                sidx, n_split, n_plain = self._split_index
+                split = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=device)
+                _lib.check("mnf_pack_gather_split", _lib.load().mnf_pack_gather_split(
+                    self._flat.data_ptr(), sidx.data_ptr(), split.data_ptr(), n_split, n_plain, _stream()))
+                self._split = split
+            else:
+                self._split = None
             self._cache_key = key
         return self._flat, self._image
 
@@ -322,6 +353,19 @@ class AffineHalfFlow(_TwoWayFlow):
             self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
         return idx
 
+    def _split_index_host(self):
+        lib = _lib.load()
+        n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = lib.mnf_affine_half_split_layout(self.dim, len(self.h_sizes), self._hid, self.scale, self.shift,
+                                              ctypes.byref(n_split), ctypes.byref(n_plain))
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            return None
+        _lib.check("mnf_affine_half_split_layout", rc)
+        idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+        _lib.check("mnf_affine_half_split_index", lib.mnf_affine_half_split_index(
+            self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
+        return idx, n_split.value, n_plain.value
+
     def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
         if accum is None and sqnorm is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 \
                 and _wants_grad(self, x):
@@ -341,7 +385,8 @@ class AffineHalfFlow(_TwoWayFlow):
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_half_sq", _lib.load().mnf_affine_half_sq(
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), _ptr(flat),
-            _ptr(image), x.shape[0], self.dim, int(bool(self.parity)), int(inverse), len(self.h_sizes),
+            _ptr(image), _ptr(self._split_image(x.device)), x.shape[0], self.dim, int(bool(self.parity)),
+            int(inverse), len(self.h_sizes),
             self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
 
@@ -765,6 +810,7 @@ class FusedAffineStack(_TwoWayFlow):
         self.dim = f0.dim
         self._img_key = None
         self._images: Tensor | None = None
+        self._splits: Tensor | None = None
 
     def _packed_params(self) -> list[Tensor]:
         return []
@@ -782,6 +828,8 @@ class FusedAffineStack(_TwoWayFlow):
         if key != self._img_key:
             imgs = [f._packed(device)[1] for f in self.layers]
             self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
+            splits = [f._split_image(device) for f in self.layers]
+            self._splits = None if any(i is None for i in splits) else torch.cat(splits).contiguous()
             self._img_key = key
         return self._images
 
@@ -802,7 +850,7 @@ class FusedAffineStack(_TwoWayFlow):
             par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
             rc = _lib.load().mnf_affine_half_stack(
                 x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), images.data_ptr(),
-                par, len(self.layers), x.shape[0], self.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
+                _ptr(None if any(f.force_fp32_mfma for f in self.layers) else self._splits), par, len(self.layers), x.shape[0], self.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_affine_half_stack", rc)
                 return y, (None if accum is not None else ld)
