@@ -192,7 +192,7 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     if rank == 0:
-        kern_ms = [a.elapsed_time(b) for a, b in events]
+        kern_ms = [a.elapsed_time(b) for a, b, _ in events]
         avg_s = sum(kern_ms) / len(kern_ms) / 1e3
         flops = 2 * (dim * 50 + 2 * 50 * dim) * rows  # 240,000 per row
         tf = flops / avg_s / 1e12
@@ -332,8 +332,14 @@ def main() -> None:
         torch.cuda.synchronize()
         # (start, end) HIP events around every coupling kernel of the timed steps
         model.layer_events = None if os.environ.get("MNF_BENCH_NO_EVENTS") else []
+        # layers of the inverse pass that get timed: all of them, except for c3 where only the dominant
+        # kernel (the NSF_CL layer, first of every 3 in the inverse order) is
+        timed_layers = [i for i in range(n_layers) if args.workload != "c3" or i % 3 == 0]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(args.steps):
+            # one layer per step carries the (start, end) marks, rotating: every mark costs a few us of
+            # stream time, and ten of them per step would be ~4 % of the step they are measuring
+            model.layer_event_pick = timed_layers[k % len(timed_layers)]
             mean = step()
         torch.cuda.synchronize()
         if world > 1:
@@ -344,10 +350,12 @@ def main() -> None:
         events, model.layer_events = model.layer_events, None
         if events is None:  # experiment mode: time the kernels in a separate pass instead
             model.layer_events = []
-            for _ in range(args.steps):
+            for k in range(args.steps):
+                model.layer_event_pick = timed_layers[k % len(timed_layers)]
                 step()
             torch.cuda.synchronize()
             events, model.layer_events = model.layer_events, None
+        model.layer_event_pick = None
 
     # the other direction (sampling: z -> x), outside the timed region, for the record
     with torch.no_grad():
@@ -366,13 +374,14 @@ def main() -> None:
     gpu_mean = float(mean.item())
 
     if rank == 0:
-        kern_ms = [a.elapsed_time(b) for a, b in events]
-        per_layer_us = [1e3 * sum(kern_ms[i::n_layers]) / len(kern_ms[i::n_layers]) for i in range(n_layers)]
+        by_layer = {}
+        for a, b, i in events:
+            by_layer.setdefault(i, []).append(a.elapsed_time(b))
+        per_layer_us = [round(1e3 * sum(v) / len(v), 1) for _, v in sorted(by_layer.items())]
         if os.environ.get("MNF_BENCH_DEBUG"):
-            for i in range(n_layers):
-                print(f"layer {i} per step (us):", [round(v * 1e3) for v in kern_ms[i::n_layers]], file=sys.stderr)
-        if args.workload == "c3":  # dominant kernel = the NSF_CL layer (first of every 3 in the inverse order)
-            kern_ms = [k for i, k in enumerate(kern_ms) if i % 3 == 0]
+            for i, v in sorted(by_layer.items()):
+                print(f"layer {i} per step (us):", [round(t * 1e3) for t in v], file=sys.stderr)
+        kern_ms = [t for v in by_layer.values() for t in v]
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
         algo_bytes = (8 * dim + 8) * rows  # per launch: read 4d, write 4d, log_det read+write
         n_fused = 9 if args.workload == "c2f" else 1  # layers per launch (flop accounting)

@@ -878,7 +878,8 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
                          int64_t rows, int dim, void* stream) {
   if (!z_sqnorm || rows < 0 || dim < 1 || (!log_prob && !sum_out)) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL(gauss_logprob_sq_kernel, dim3(grid_for(rows, 256, 1024)), dim3(kThreads), 0,
+  // 8 MB in, 4 MB out: one workgroup per CU is enough, and keeps the fp64 atomics on sum_out to 256
+  hipLaunchKernelGGL(gauss_logprob_sq_kernel, dim3(grid_for(rows, 4 * kThreads, 256)), dim3(kThreads), 0,
                      (hipStream_t)stream, z_sqnorm, log_det, log_prob, sum_out, rows, dim);
   return check_launch();
 }

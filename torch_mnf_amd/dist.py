@@ -22,11 +22,16 @@ def shard_bounds(total_rows: int, world_size: int, rank: int) -> tuple[int, int]
 
 
 def reduce_sum_count(local_sum: torch.Tensor, local_rows: int, group=None) -> tuple[torch.Tensor, torch.Tensor]:
-    """All-reduce (sum, count) as one 2-element float64 tensor on local_sum's device."""
-    pair = torch.empty(2, dtype=torch.float64, device=local_sum.device)
-    pair[0] = local_sum.reshape(-1)[0].to(torch.float64)
-    pair[1] = float(local_rows)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    """All-reduce (sum, count) as one 2-element float64 tensor on local_sum's device.
+
+    Single process: no device work at all (sum stays where it is, count is a host scalar tensor), so a
+    caller's ``sum / count`` is one small kernel instead of four."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return local_sum.reshape(-1)[0].to(torch.float64), torch.tensor(float(local_rows), dtype=torch.float64)
+    pair = torch.cat((local_sum.reshape(-1)[:1].to(torch.float64),
+                      torch.tensor([float(local_rows)], dtype=torch.float64).to(local_sum.device, non_blocking=True)))
+    if multi:
         if pair.is_cuda and dist.get_backend(group) == "gloo":  # CPU-side test backend: reduce on the host
             host = pair.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -366,7 +366,8 @@ class AffineHalfFlow(_TwoWayFlow):
             self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
         return idx, n_split.value, n_plain.value
 
-    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
+    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None, overwrite: bool = False):
+        # overwrite: accum receives ld instead of += ld (first layer of a pass: saves zero-filling it)
         if accum is None and sqnorm is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 \
                 and _wants_grad(self, x):
             xg = _grad_input(x)
@@ -384,8 +385,8 @@ class AffineHalfFlow(_TwoWayFlow):
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_half_sq", _lib.load().mnf_affine_half_sq(
-            x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), _ptr(flat),
-            _ptr(image), _ptr(self._split_image(x.device)), x.shape[0], self.dim, int(bool(self.parity)),
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None and not overwrite),
+            _ptr(flat), _ptr(image), _ptr(self._split_image(x.device)), x.shape[0], self.dim, int(bool(self.parity)),
             int(inverse), len(self.h_sizes),
             self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
@@ -836,7 +837,7 @@ class FusedAffineStack(_TwoWayFlow):
     def emits_sqnorm(self, device) -> bool:
         return self._stack_images(device) is not None
 
-    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None):
+    def _run(self, x, inverse, accum, sqnorm: Tensor | None = None, overwrite: bool = False):
         f0 = self.layers[0]
         fused_ok = isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and not any(
             _wants_grad(f, x) for f in self.layers) and not any(f.force_generic for f in self.layers)
@@ -849,14 +850,18 @@ class FusedAffineStack(_TwoWayFlow):
             ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
             par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
             rc = _lib.load().mnf_affine_half_stack(
-                x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None), images.data_ptr(),
+                x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None and not overwrite),
+                images.data_ptr(),
                 _ptr(None if any(f.force_fp32_mfma for f in self.layers) else self._splits), par, len(self.layers), x.shape[0], self.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_affine_half_stack", rc)
                 return y, (None if accum is not None else ld)
         y, ld = self._sequence(x, inverse, sqnorm)
         if accum is not None:
-            accum += ld
+            if overwrite:
+                accum.copy_(ld)
+            else:
+                accum += ld
             return y, None
         return y, ld
 
@@ -872,27 +877,37 @@ class NormalizingFlow(nn.Module):
         # bench.py: set to a list to collect a (start, end) HIP event pair per layer, recorded on
         # the stream the kernels are launched on (consecutive layers share the boundary event)
         self.layer_events: list | None = None
+        self.layer_event_pick: int | None = None
         self._last_sqnorm: Tensor | None = None
 
     def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False):
-        log_det = torch.zeros(x.size(0), device=x.device)
-        seen = [x]
-        timed = self.layer_events is not None and x.is_cuda
         order = list(reversed(self.flows)) if inverse else list(self.flows)
+        # a first layer whose kernel writes log_det for every row saves zero-filling it
+        fresh = (bool(order) and isinstance(order[0], (AffineHalfFlow, FusedAffineStack)) and isinstance(x, Tensor)
+                 and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and not _wants_grad(order[0], x))
+        log_det = torch.empty(x.size(0), device=x.device) if fresh else torch.zeros(x.size(0), device=x.device)
+        seen = [x]
         self._last_sqnorm = None
-        if timed:  # one event per layer boundary: layer i runs between marks i and i+1
-            e_prev = torch.cuda.Event(enable_timing=True)
-            e_prev.record()
+        # layer_events: list receiving (start, end) HIP events per layer; layer_event_pick = i restricts
+        # the marks to layer i of this pass (a mark costs a few us of stream time, bench.py rotates i)
+        pick = self.layer_event_pick
+        events_on = self.layer_events is not None and x.is_cuda
         for i, flow in enumerate(order):
+            timed = events_on and (pick is None or pick == i)
+            if timed and (pick is not None or i == 0):
+                e_prev = torch.cuda.Event(enable_timing=True)
+                e_prev.record()
             if (want_sqnorm and i == len(order) - 1 and isinstance(flow, (AffineHalfFlow, FusedAffineStack))
                     and x.is_cuda and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
                 # last layer also emits |z|^2 per row for the standard-normal epilogue
                 self._last_sqnorm = torch.empty(x.size(0), device=x.device)
-                x, _ = flow._run(x, inverse, log_det, self._last_sqnorm)
+                x, _ = flow._run(x, inverse, log_det, self._last_sqnorm, overwrite=fresh and i == 0)
             elif isinstance(flow, _HipFlow) and (inverse is False or isinstance(flow, _TwoWayFlow)) \
                     and _wants_grad(flow, x):
                 x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
                 log_det = log_det + ld
+            elif fresh and i == 0:
+                x, _ = flow._run(x, inverse, log_det, overwrite=True)  # log_det = ld inside the kernel
             elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
                 x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
             else:
@@ -901,7 +916,7 @@ class NormalizingFlow(nn.Module):
             if timed:
                 e_next = torch.cuda.Event(enable_timing=True)
                 e_next.record()
-                self.layer_events.append((e_prev, e_next))
+                self.layer_events.append((e_prev, e_next, i))
                 e_prev = e_next
             seen.append(x)
         return seen, log_det
