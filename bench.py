@@ -144,6 +144,14 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
     return info, mean, rows
 
 
+# the coupling kernels evaluate fp32 products on the f16 matrix pipe (hi + lo split, three MFMAs per product,
+# fp32 accumulation; csrc/mnf_split.h); MNF_FP32_MFMA=1 switches to the fp32 MFMA kernels for A/B runs
+SPLIT = os.environ.get("MNF_FP32_MFMA", "0") != "1"
+ARITHMETIC = ("fp32 via split f16 MFMA (hi+lo, 3 products per fp32 product, fp32 accumulate; fp32-MFMA fallback for "
+              "operands outside the f16 range)") if SPLIT else "fp32 MFMA"
+AHF_KERNEL = "ahf_split_kernel" if SPLIT else "ahf_mfma_kernel"
+
+
 def main_c5(args, rank, world, device, dim, rows, desc) -> None:
     """Config 5: the flow_q of MNFLinear(800, 50) on 256,000 MC rows.  A step = one sample_z call
     (prologue kernel + two seeded RNVP kernels, log-det accumulated in-kernel); fp32-MFMA bound."""
@@ -201,13 +209,26 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "hidden": [50], "mask": "in-kernel (seeded)",
-                       "primed_ms": args.prime_ms},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "rnvp_mfma_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
-                         "algorithmic_flops_per_launch": flops, "launches_timed": len(kern_ms),
-                         "algorithmic_GBps": (12 * dim + 8) * rows / avg_s / 1e9},
+                       "primed_ms": args.prime_ms, "arithmetic": ARITHMETIC},
         }
+        # Algorithmic bytes per row with the in-kernel mask: read z (4d), write x (4d), log_det RMW (8).  The
+        # kernel reads z a second time for the gate epilogue (it cannot stay on chip: 410 KB per 128-row
+        # group), so its own traffic is 12d + 8.
+        algo_bytes = (8 * dim + 8) * rows
+        if SPLIT:  # memory-path bound (tools ablations: no MFMAs -> same time), priced against HBM
+            gbs = algo_bytes / avg_s / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("c5"),
+                               "kernel": "rnvp_split_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
+                               "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(kern_ms),
+                               "kernel_GBps_incl_second_z_read": (12 * dim + 8) * rows / avg_s / 1e9,
+                               "fp32_equivalent_tflops": tf}
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "rnvp_mfma_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
+                               "algorithmic_flops_per_launch": flops, "launches_timed": len(kern_ms),
+                               "algorithmic_GBps": (12 * dim + 8) * rows / avg_s / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import flow_oracle as O
 
@@ -403,7 +424,7 @@ def main() -> None:
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": n_layers,
                        "hidden": [8, 8, 8] if args.workload in ("c3", "c3f") else [24, 24, 24],
                        "intermediates": "all kept (reference API)", "primed_ms": args.prime_ms,
-                       "primed_steps": primed},
+                       "primed_steps": primed, "arithmetic": ARITHMETIC},
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -412,8 +433,8 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.workload),
                 "kernel": ("nsf_cl kernel (inverse)" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"
-                           if args.workload == "c3f" else "ahf_stack_kernel<32,24,inverse> (9 layers per launch)"
-                           if args.workload == "c2f" else f"ahf_mfma_kernel<{dim // 2},24,inverse>"),
+                           if args.workload == "c3f" else f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<32,24,inverse> (9 layers per launch)"
+                           if args.workload == "c2f" else f"{AHF_KERNEL}<{dim // 2},24,inverse>"),
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launches_timed": len(kern_ms),

@@ -155,7 +155,7 @@ int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D,
 /* mask: (rows, dim) floats in {0,1}, supplied by the caller (the reference draws
  * torch.bernoulli per call, rnvp.py:28).  net = MLP(dim, hidden...); t, s = Linear(h_last, dim). */
 int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
-             const float* flat, const float* image,
+             const float* flat, const float* image, const void* split_image,
              int64_t rows, int dim, int n_hidden, const int* hidden_host,
              int force_generic, void* stream);
 /* Same layer with the mask generated inside the kernel when mask == NULL: element (r, j) is bit
@@ -163,13 +163,19 @@ int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int ac
  * this library.  mnf_rnvp_mask writes exactly that mask as floats, so a
  * seeded call can be reproduced with an explicit mask (and by the CPU oracle). */
 int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, float* log_det,
-                    int accumulate, const float* flat, const float* image,
+                    int accumulate, const float* flat, const float* image, const void* split_image,
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
 int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden_host);
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden_host);
 int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);
+/* Split image (see mnf_affine_half_split_layout): with image AND split_image given, both GEMMs run on
+ * the f16 matrix pipe in split fp32 arithmetic; 128-row groups whose operands leave the f16 range are
+ * recomputed with fp32 MFMAs inside the same launch. */
+int mnf_rnvp_split_layout(int dim, int n_hidden, const int* hidden_host, int64_t* n_split_words,
+                          int64_t* n_plain_words);
+int mnf_rnvp_split_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);
 
 /* ------------------------------------------------------- data-independent layers */
 /* forward: y = x*exp(s)+t ; inverse: y = (x-t)*exp(-s).  s, t: (dim,) device vectors.

@@ -139,20 +139,57 @@ def test_affine_half_mfma_shape_matrix(amd, O, dim, hid, kernel):
             assert_close(ld, ref_ld, RTOL, "ld")
 
 
-@pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50)])
-def test_rnvp_mfma_shape_matrix(amd, O, dim, hid):
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
+@pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50), (784, 50), (80, 30)])
+def test_rnvp_mfma_shape_matrix(amd, O, dim, hid, kernel):
     sd = recipes.rnvp_params(95 + dim + hid, dim, hid)
     f = amd.RNVP(dim, h_sizes=(hid,))
     f.load_state_dict(sd)
-    f.to(DEV)
+    select_kernel(f.to(DEV), kernel)
     assert f._packed(torch.device(DEV, 0))[1] is not None
-    rows = 131
-    z = recipes.gaussian(96 + dim, rows, dim)
-    mask = recipes.bernoulli_mask(97, rows, dim)
+    assert (f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split")
+    for rows in (131, 1000):
+        z = recipes.gaussian(96 + dim, rows, dim)
+        mask = recipes.bernoulli_mask(97, rows, dim)
+        ref_x, ref_ld = O.rnvp(z, sd, mask)
+        x, ld = f.forward(cuda(z), mask=cuda(mask))
+        assert_close(x, ref_x, RTOL, "x")
+        assert_close(ld, ref_ld, RTOL, "ld")
+
+
+@pytest.mark.parametrize("case", ["big_inputs", "big_weights", "inf_input", "one_big_row", "tiny_inputs"])
+def test_rnvp_split_range_guard(amd, O, case):
+    """RNVP on the split path: a 128-row group whose operands leave the f16 range is recomputed with fp32
+    MFMAs inside the same launch; the other groups stay on the split path."""
+    dim, hid, rows = 800, 50, 700
+    sd = recipes.rnvp_params(140, dim, hid)
+    z = recipes.gaussian(141, rows, dim)
+    if case == "big_inputs":
+        z = z * 1.0e5
+        sd = {k: (v * 1e-5 if k == "net.0.weight" else v) for k, v in sd.items()}
+    elif case == "big_weights":
+        sd = {k: (v * 1e5 if k == "net.0.weight" else v) for k, v in sd.items()}
+        z = z * 1e-5
+    elif case == "inf_input":
+        z = z.clone()
+        z[300, 17] = float("inf")
+    elif case == "one_big_row":
+        z = z.clone()
+        z[5] *= 1e5
+        z[650] *= 1e5
+        sd = {k: (v * 1e-3 if k == "net.0.weight" else v) for k, v in sd.items()}
+    elif case == "tiny_inputs":
+        z = z * 1e-6
+    mask = recipes.bernoulli_mask(142, rows, dim)
     ref_x, ref_ld = O.rnvp(z, sd, mask)
+    f = amd.RNVP(dim, h_sizes=(hid,))
+    f.load_state_dict(sd)
+    f.to(DEV)
     x, ld = f.forward(cuda(z), mask=cuda(mask))
-    assert_close(x, ref_x, RTOL, "x")
-    assert_close(ld, ref_ld, RTOL, "ld")
+    ok = torch.isfinite(ref_x).all(1)
+    assert torch.equal(torch.isfinite(x).all(1).cpu(), ok)
+    assert_close(x[ok.to(DEV)], ref_x[ok], RTOL, f"{case} x")
+    assert_close(ld[ok.to(DEV)], ref_ld[ok], RTOL, f"{case} ld")
 
 
 def _f64_affine_half(x, sd, parity, inverse):
@@ -614,13 +651,14 @@ def test_glow_and_actnorm_layers_vs_oracle(amd, O, dim):
 
 # --------------------------------------------------------------------------- RNVP
 @pytest.mark.parametrize("dim", [50, 800, 784])
-@pytest.mark.parametrize("generic", [False, True])
-def test_g7_rnvp(amd, golden, dim, generic):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_g7_rnvp(amd, golden, dim, kernel):
     fx = golden("g7_rnvp")
     f = amd.RNVP(dim, h_sizes=(50,))
     f.load_state_dict(recipes.rnvp_params(700 + dim, dim, 50))
-    f = f.to(DEV)
-    f.force_generic = generic
+    f = select_kernel(f.to(DEV), kernel)
+    if dim >= 64 and kernel != "generic":
+        assert (f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split")
     z = cuda(fx[f"d{dim}.z"])
     mask = unpack_mask(fx[f"d{dim}.mask_bits"], dim).to(DEV)
     x, ld = f.forward(z, mask=mask)

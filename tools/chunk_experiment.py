@@ -18,6 +18,7 @@ bufs = [x] + [torch.empty_like(x) for _ in flows]
 ld = torch.zeros(rows, device=dev)
 lib = _lib.load()
 packed = [f._packed(torch.device(dev, 0)) for f in flows]
+splits = [f._split_image(torch.device(dev, 0)) for f in flows]
 
 def run(chunk):
     ld.zero_()
@@ -28,7 +29,7 @@ def run(chunk):
             f = flows[fi]; flat, image = packed[fi]
             src, dst = bufs[li], bufs[li + 1]
             rc = lib.mnf_affine_half(src.data_ptr() + r0 * dim * 4, dst.data_ptr() + r0 * dim * 4, ld.data_ptr() + r0 * 4, 1,
-                                     flat.data_ptr(), image.data_ptr(), None, n, dim, int(f.parity), 1, 3, f._hid, 1, 1, 0, _stream())
+                                     flat.data_ptr(), image.data_ptr(), splits[fi].data_ptr(), n, dim, int(f.parity), 1, 3, f._hid, 1, 1, 0, _stream())
             assert rc == 0
 
 def timed(chunk, n=10):
@@ -38,7 +39,7 @@ def timed(chunk, n=10):
 
 run(rows); ref = bufs[-1].clone(); ref_ld = ld.clone()
 for rnd in range(4):
-    for chunk in (rows, 1 << 19, 393216, 1 << 18, 196608):
+    for chunk in (rows, 1 << 19, 1 << 18, 1 << 17, 1 << 16):
         t = timed(chunk, 60)
         run(chunk)
         ok = torch.equal(bufs[-1], ref) and torch.equal(ld, ref_ld)

@@ -75,7 +75,7 @@ int main() {
       {"no-guard", run<5>},      {"copy-only", run<6>}, {"no-prefetch", run<7>},
   };
   const int nv = sizeof(vs) / sizeof(vs[0]);
-  for (int bpc : {1, 2, 3}) {
+  for (int bpc : {2, 4, 8, 16, 32}) {
     float best[32], sum[32];
     for (int v = 0; v < nv; ++v) { best[v] = 1e9f; sum[v] = 0.f; }
     const int rounds = 5;

@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmnf_hip.so")
+LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
@@ -52,10 +52,12 @@ SIGNATURES = {
     "mnf_nsf_cl_image_index": (c_int, [c_int, c_int, c_int, _intp, _i32p]),
     "mnf_rqs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
                         c_int, c_void_p]),
-    "mnf_rnvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int,
+    "mnf_rnvp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                          c_int, _intp, c_int, c_void_p]),
     "mnf_rnvp_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                c_int64, c_int, c_int, _intp, c_int, c_void_p]),
+                                c_void_p, c_int64, c_int, c_int, _intp, c_int, c_void_p]),
+    "mnf_rnvp_split_layout": (c_int, [c_int, c_int, _intp, _i64p, _i64p]),
+    "mnf_rnvp_split_index": (c_int, [c_int, c_int, _intp, _i32p]),
     "mnf_rnvp_mask": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_rnvp_flat_floats": (c_int64, [c_int, c_int, _intp]),
     "mnf_rnvp_image_floats": (c_int64, [c_int, c_int, _intp]),

@@ -755,10 +755,10 @@ int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden) {
 }
 
 int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
-             const float* flat, const float* image, int64_t rows, int dim, int n_hidden,
-             const int* hidden, int force_generic, void* stream) {
+             const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
+             int n_hidden, const int* hidden, int force_generic, void* stream) {
   if (!mask) return MNF_ERR_INVALID_ARG;
-  return mnf_rnvp_seeded(z, mask, 0, x, log_det, accumulate, flat, image, rows, dim, n_hidden, hidden,
+  return mnf_rnvp_seeded(z, mask, 0, x, log_det, accumulate, flat, image, split_image, rows, dim, n_hidden, hidden,
                          force_generic, stream);
 }
 
@@ -777,15 +777,15 @@ int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* strea
 }
 
 int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
-                    const float* flat, const float* image, int64_t rows, int dim, int n_hidden,
-                    const int* hidden, int force_generic, void* stream) {
+                    const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
+                    int n_hidden, const int* hidden, int force_generic, void* stream) {
   if (!z || !x || z == x || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden) ||
       (!flat && !image))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (image && !force_generic) {
-    const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, rows, dim, n_hidden, hidden, seed,
-                                    (hipStream_t)stream);
+    const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, split_image, rows, dim, n_hidden, hidden,
+                                    seed, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (!flat) return MNF_ERR_INVALID_ARG;

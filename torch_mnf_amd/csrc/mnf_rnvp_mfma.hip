@@ -22,10 +22,9 @@
 
 #include "mnf_device.h"
 #include "mnf_host.h"
+#include "mnf_split.h"
 
 namespace mnf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRnvpWaves = 8;    // 512-thread workgroups: 128 rows share every staged operand chunk
 constexpr int kRnvpChunkK = 16;  // GEMM-1 K-steps per chunk (64 dims): 16 x 4 tiles x 256 B = 16 KiB
@@ -65,14 +64,14 @@ __device__ __forceinline__ float exp6r(float x) {
 // SEEDED: the mask is regenerated from (seed, row, dim) wherever it is needed instead of being
 // read -- 8d fewer bytes per row (a float mask is otherwise read twice).
 template <int HN, bool SEEDED>
-__global__ void __launch_bounds__(kRnvpWaves * 64, 4)  // two 8-wave workgroups per CU: <= 128 VGPRs
-rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
-                 float* __restrict__ log_det, const float* __restrict__ image, int64_t rows, int d,
-                 int accumulate, uint64_t seed) {
+__device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CHUNK_FLOATS], int grp,
+                                               const float* __restrict__ z, const float* __restrict__ mask,
+                                               float* __restrict__ x, float* __restrict__ log_det,
+                                               const float* __restrict__ image, int64_t rows, int d, int accumulate,
+                                               uint64_t seed) {
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT, KC = kRnvpChunkK, MC = kRnvpChunkM;
   constexpr int NROW = (KC / 4 > MC ? KC / 4 : MC);  // float4 row loads per chunk
-  __shared__ __attribute__((aligned(16))) float lds[2][S::CHUNK_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n_k = d / 4;    // GEMM-1 K-steps
@@ -98,8 +97,7 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
     return dim0 < d ? dim0 : 0;
   };
 
-  const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  {
     const int64_t row = (int64_t)grp * (16 * kRnvpWaves) + wave * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
@@ -227,6 +225,390 @@ rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, fl
   }
 }
 
+template <int HN, bool SEEDED>
+__global__ void __launch_bounds__(kRnvpWaves * 64, 4)  // two 8-wave workgroups per CU: <= 128 VGPRs
+rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
+                 float* __restrict__ log_det, const float* __restrict__ image, int64_t rows, int d,
+                 int accumulate, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) float lds[2][RnvpShape<HN>::CHUNK_FLOATS];
+  const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
+    rnvp_group_f32<HN, SEEDED>(lds, grp, z, mask, x, log_det, image, rows, d, accumulate, seed);
+}
+
+// ================================================================================================
+// The same layer with both GEMMs on the f16 matrix pipe in split (hi + lo) fp32 arithmetic
+// (mnf_split.h): per 16 rows at d = 800, h = 50: 900 v_mfma_f32_16x16x32_f16 of 16 cycles instead of
+// 2,100 v_mfma_f32_16x16x4_f32 of 32 cycles.  Same streaming scheme (double-buffered LDS window,
+// one barrier per chunk).  A 128-row group whose operands leave the f16 range -- detected after
+// GEMM 1, before anything is stored -- is recomputed by rnvp_group_f32 inside the same launch.
+// ================================================================================================
+#ifndef MNF_RNVP_NT
+#define MNF_RNVP_NT 0
+#endif
+constexpr bool kRnvpNtStore = (MNF_RNVP_NT & 1) != 0, kRnvpNtLoad2 = (MNF_RNVP_NT & 2) != 0;
+#ifndef MNF_RNVP_ABL
+#define MNF_RNVP_ABL 0  // experiments only: 1 no x stores, 2 no phase-2 row loads, 3 no phase-1 row loads, 4 no MFMAs
+#endif
+constexpr int kRnvpAbl = MNF_RNVP_ABL;
+
+template <int HN>
+struct RnvpSplitShape {
+  static constexpr int YT = (HN + 15) / 16;            // 16-unit tiles of y (unit u = 16 m + i)
+  static constexpr int NKS2 = (YT + 1) / 2;            // K = 32 steps of GEMM 2
+  static constexpr int KS1_WORDS = YT * 512;           // one GEMM-1 K-step: YT x (hi, lo) operands
+  static constexpr int TILE2_WORDS = 2 * NKS2 * 512;   // one GEMM-2 output tile: (t, s) x NKS2 x (hi, lo)
+  static constexpr int KC = 2, MC = 2;                 // K-steps / output tiles per chunk
+  static constexpr int CHUNK_WORDS = KC * KS1_WORDS > MC * TILE2_WORDS ? KC * KS1_WORDS : MC * TILE2_WORDS;
+  static constexpr int NROW = 2 * KC > MC ? 2 * KC : MC;  // 16-dim row groups per chunk
+  static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);
+  static constexpr int64_t n_ks1(int d) { return (d / 16 + 1) / 2; }
+  static constexpr int64_t part1_words(int d) { return n_ks1(d) * KS1_WORDS; }
+  static constexpr int64_t part2_words(int d) { return (int64_t)(d / 16) * TILE2_WORDS; }
+  static constexpr int64_t split_words(int d) { return part1_words(d) + part2_words(d); }
+  static constexpr int64_t plain_words(int d) { return (int64_t)(d / 16) * 32 + YT * 16; }  // (bt, bs) per tile, then bn
+};
+
+// returns false (block-uniform) when the group has to be recomputed on the fp32 path
+template <int HN, bool SEEDED>
+__device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
+                                                 const float* __restrict__ mask, float* __restrict__ x,
+                                                 float* __restrict__ log_det, const uint32_t* __restrict__ simage,
+                                                 int64_t rows, int d, int accumulate, uint64_t seed) {
+  using S = RnvpSplitShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC, NROW = S::NROW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int G = d / 16;                  // 16-dim groups of a row = GEMM-2 output tiles
+  const int n_ks1 = (G + 1) / 2;         // GEMM-1 K-steps (two groups each)
+  const int nc1 = (n_ks1 + KC - 1) / KC, nc2 = (G + MC - 1) / MC, nc = nc1 + nc2;
+  const uint32_t* img1 = simage;
+  const uint32_t* img2 = simage + S::part1_words(d);
+  const float* bias2 = reinterpret_cast<const float*>(simage + S::split_words(d));
+  const float* bias_y = bias2 + (int64_t)G * 32;
+
+  auto chunk_src = [&](int c, int& n4) -> const uint4* {
+    if (c < nc1) {
+      n4 = min(KC, n_ks1 - c * KC) * (S::KS1_WORDS / 4);
+      return reinterpret_cast<const uint4*>(img1 + (int64_t)c * KC * S::KS1_WORDS);
+    }
+    const int m0 = (c - nc1) * MC;
+    n4 = min(MC, G - m0) * (S::TILE2_WORDS / 4);
+    return reinterpret_cast<const uint4*>(img2 + (int64_t)m0 * S::TILE2_WORDS);
+  };
+  // the i-th 16-dim group chunk c works on, or -1 past the end of the row
+  auto row_group = [&](int c, int i) -> int {
+    const int g = c < nc1 ? 2 * (c * KC) + i : (c - nc1) * MC + i;
+    return g < G ? g : -1;
+  };
+
+  const int64_t row = (int64_t)grp * (16 * kRnvpWaves) + wave * 16 + j;
+  const bool live = row < rows;
+  const int64_t rowc = live ? row : rows - 1;
+  const float* zr = z + rowc * d + 4 * q;
+  const float* mr = SEEDED ? nullptr : mask + rowc * d + 4 * q;
+  float* xr = x + rowc * d + 4 * q;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mask4 = [&](int g) -> f32x4 {  // mask of dims 16 g + 4 q .. + 3; groups past the row end read as 0
+    if (g < 0) return zero4;
+    if (!SEEDED) return *reinterpret_cast<const f32x4*>(mr + 16 * g);
+    const int dd = 16 * g + 4 * q;
+    const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
+    return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
+  };
+  auto z4 = [&](int g) -> f32x4 { return *reinterpret_cast<const f32x4*>(zr + 16 * (g < 0 ? 0 : g)); };
+  const f32x4 fake4 = f32x4{0.25f, -0.5f, 0.125f, 1.f};
+
+  // Row data (z, and the mask when it is an input) comes from HBM with ~2 us of latency under load, while
+  // a chunk of split MFMAs takes well under 1 us: rows are therefore requested D chunks ahead into a ring
+  // of register sets (the chunk loops are unrolled by D so that the ring index is static).  A set is
+  // re-requested as soon as it has been turned into MFMA operands.  With an explicit float mask the ring
+  // would need twice the registers, so that variant keeps a depth of one.
+  constexpr int D1 = SEEDED ? 2 : 1;  // GEMM 1: 2 KC groups per set
+  constexpr int D2 = SEEDED ? 3 : 1;  // GEMM 2: MC groups per set
+  uint4 st[S::STAGE_U4];
+  auto request_operands = [&](int c, int& n4) {
+    const uint4* src = chunk_src(c < nc ? c : nc - 1, n4);
+#pragma unroll
+    for (int i = 0; i < S::STAGE_U4; ++i) {
+      const int k = threadIdx.x + i * (kRnvpWaves * 64);
+      st[i] = src[k < n4 ? k : 0];
+    }
+  };
+  auto hand_over = [&](uint32_t* buf, int n4) {
+    uint4* dst = reinterpret_cast<uint4*>(buf);
+#pragma unroll
+    for (int i = 0; i < S::STAGE_U4; ++i) {
+      const int k = threadIdx.x + i * (kRnvpWaves * 64);
+      if (k < n4) dst[k] = st[i];
+    }
+  };
+  f32x4 z1[D1][2 * KC], m1[SEEDED ? 1 : D1][2 * KC];
+  auto request_rows1 = [&](int c, int u) {
+#pragma unroll
+    for (int i = 0; i < 2 * KC; ++i) {
+      z1[u][i] = (kRnvpAbl == 3 || kRnvpAbl >= 5) ? fake4 : z4(row_group(c < nc1 ? c : nc1 - 1, i));
+      if (!SEEDED) m1[u][i] = mask4(row_group(c < nc1 ? c : nc1 - 1, i));
+    }
+  };
+  __syncthreads();  // the previous group's last chunk is fully consumed
+  {
+    int n4;
+#pragma unroll
+    for (int u = 0; u < D1; ++u) request_rows1(u, u);
+    request_operands(0, n4);
+    hand_over(lds0, n4);
+  }
+  __syncthreads();
+
+  auto split_mac = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
+    if (kRnvpAbl == 4 || kRnvpAbl == 6) {
+      mn += __builtin_bit_cast(f32x4, ah) * __builtin_bit_cast(f32x4, bh);
+      cr += __builtin_bit_cast(f32x4, al) * __builtin_bit_cast(f32x4, bl);
+    } else {
+      mnf::split_mac(ah, al, bh, bl, mn, cr);
+    }
+  };
+  f32x4 ym[YT], yc[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) {
+    ym[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
+    yc[m] = zero4;
+  }
+  float mx = 0.f;
+  // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step
+  for (int c0 = 0; c0 < nc1; c0 += D1) {
+#pragma unroll
+    for (int u = 0; u < D1; ++u) {
+      const int c = c0 + u;
+      if (c < nc1) {
+        f16x8 bh[KC], bl[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          u32x2 h0, l0, h1, l1;
+          const f32x4 ma = SEEDED ? mask4(row_group(c, 2 * kk)) : m1[SEEDED ? 0 : u][2 * kk];
+          const f32x4 mb = SEEDED ? mask4(row_group(c, 2 * kk + 1)) : m1[SEEDED ? 0 : u][2 * kk + 1];
+          split_tile(ma * z1[u][2 * kk], h0, l0, mx);
+          split_tile(mb * z1[u][2 * kk + 1], h1, l1, mx);
+          bh[kk] = pair_operand(h0, h1);
+          bl[kk] = pair_operand(l0, l1);
+        }
+        int n4_next = 0;
+        request_rows1(c + D1, u);
+        request_operands(c + 1, n4_next);  // c + 1 == nc1: the first GEMM-2 chunk
+        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;  // + 64 * operand
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          if (c * KC + kk < n_ks1) {
+#pragma unroll
+            for (int m = 0; m < YT; ++m)
+              split_mac(A8[64 * (2 * (kk * YT + m))], A8[64 * (2 * (kk * YT + m) + 1)], bh[kk], bl[kk], ym[m], yc[m]);
+          }
+        }
+        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        if (c < nc1 - 1) __syncthreads();
+      }
+    }
+  }
+  // rows of the first GEMM-2 chunks: their latency overlaps the y split and the group-wide verdict
+  f32x4 z2[D2][MC], m2[SEEDED ? 1 : D2][MC];
+  auto request_rows2 = [&](int c, int u) {
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+      const int g2 = row_group(c < nc ? c : nc - 1, i);
+      z2[u][i] = (kRnvpAbl == 2 || kRnvpAbl >= 5) ? fake4 : kRnvpNtLoad2 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zr + 16 * (g2 < 0 ? 0 : g2)))
+                              : z4(g2);
+      if (!SEEDED) m2[u][i] = mask4(row_group(c < nc ? c : nc - 1, i));
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < D2; ++u) request_rows2(nc1 + u, u);
+  // y complete: operands of GEMM 2, and the range verdict for the whole 128-row group
+  u32x2 yh[YT], yl[YT];
+  const u32x2 zero2 = u32x2{0u, 0u};
+#pragma unroll
+  for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
+  if (__syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0)) return false;  // nothing has been stored yet
+
+  // ---- GEMM 2 + gate, 16 output dims per tile
+  float ld = 0.f;
+  for (int c0 = nc1; c0 < nc; c0 += D2) {
+#pragma unroll
+    for (int u = 0; u < D2; ++u) {
+      const int c = c0 + u;
+      if (c < nc) {
+        int n4_next = 0;
+        request_operands(c + 1, n4_next);  // past the last chunk: the same chunk again (branch-free)
+        const int m0 = (c - nc1) * MC;
+        f32x4 bt[MC], bs[MC];
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const int m = m0 + mi < G ? m0 + mi : G - 1;
+          bt[mi] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 4 * q);
+          bs[mi] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 16 + 4 * q);
+        }
+        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
+#pragma unroll
+        for (int mi = 0; mi < MC; ++mi) {
+          const int m = m0 + mi;
+          if (m < G) {
+            const f16x8* T8 = A8 + 64 * (mi * (S::TILE2_WORDS / 256));
+            f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+#pragma unroll
+            for (int ks = 0; ks < NKS2; ++ks) {
+              const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+              const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+              split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
+              split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
+            }
+            const f32x4 t4 = tc * kSplitInvScale + tm + bt[mi];
+            const f32x4 s4 = sc * kSplitInvScale + sm + bs[mi];
+            const f32x4 mk = SEEDED ? mask4(m) : m2[SEEDED ? 0 : u][mi];
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float zz = z2[u][mi][r], mm = mk[r];
+              const float gate = __builtin_amdgcn_rcpf(1.f + exp6r(-s4[r]));
+              const float keep = mm * zz;                            // z2 = m z
+              const float gated = (1.f - mm) * zz;                   // z1 = (1-m) z
+              o[r] = (gated * gate + (1.f - gate) * t4[r]) + keep;   // rnvp.py:37
+              ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);  // :36
+            }
+            if (live && ((kRnvpAbl != 1 && kRnvpAbl < 5) || o[0] == 1.2345e30f)) {
+              if (kRnvpNtStore) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xr + 16 * m));
+              else *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+            }
+          }
+        }
+        request_rows2(c + D2, u);
+        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        __syncthreads();
+      }
+    }
+  }
+  if (log_det) {
+    ld = sum_over_q(ld);
+    if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+  }
+  return true;
+}
+
+// out-of-line on purpose: inlined next to the split path the two bodies compete for the 128 VGPRs of
+// a 4-waves/SIMD kernel and the hot path spills
+template <int HN, bool SEEDED>
+__device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int grp, const float* z, const float* mask,
+                                                             float* x, float* log_det, const float* image,
+                                                             int64_t rows, int d, int accumulate, uint64_t seed) {
+  rnvp_group_f32<HN, SEEDED>(*reinterpret_cast<float(*)[2][RnvpShape<HN>::CHUNK_FLOATS]>(lds), grp, z, mask, x,
+                             log_det, image, rows, d, accumulate, seed);
+}
+
+template <int HN, bool SEEDED>
+__global__ void __launch_bounds__(kRnvpWaves * 64, 4)
+rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
+                  float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
+                  int64_t rows, int d, int accumulate, uint64_t seed) {
+  using S = RnvpSplitShape<HN>;
+  using F = RnvpShape<HN>;
+  constexpr int WORDS = S::CHUNK_WORDS > F::CHUNK_FLOATS ? S::CHUNK_WORDS : F::CHUNK_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2][WORDS];
+  // weights outside the f16 range (flagged by the pack kernel): every group on the fp32 path
+  const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
+  const bool split_ok = wmax <= kSplitLimit;
+  const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    if (split_ok && rnvp_group_split<HN, SEEDED>(reinterpret_cast<uint32_t*>(lds[0]), reinterpret_cast<uint32_t*>(lds[1]),
+                                                 grp, z, mask, x, log_det, simage, rows, d, accumulate, seed))
+      continue;
+#ifndef MNF_NO_COLD
+    rnvp_group_f32_cold<HN, SEEDED>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed);
+#endif
+  }
+}
+
+// 2 entries per split word (low half, high half), then 1 entry per plain word -- see mnf_pack_gather_split
+template <int HN>
+static void build_split_index(int d, int32_t* idx) {
+  using S = RnvpSplitShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  const int G = d / 16;
+  const int64_t wn = 0, bn = wn + (int64_t)HN * d, wt = bn + HN, bt = wt + (int64_t)d * HN, ws = bt + d,
+                bs = ws + (int64_t)d * HN;
+  const int64_t n_entries = 2 * S::split_words(d) + S::plain_words(d);
+  for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
+  // element e of lane (i, kq) of operand `op` (hi at 2 op, lo at 2 op + 1), base = first word of the region
+  auto put = [&](int64_t base_words, int op, int lane, int e, int64_t src) {
+    for (int part = 0; part < 2; ++part)
+      idx[2 * base_words + (((int64_t)(2 * op + part) * 64 + lane) * 4 + (e >> 1)) * 2 + (e & 1)] =
+          (int32_t)src | (part ? kSplitLoBit : 0);
+  };
+  // part 1: K-step ks covers groups 2 ks (slots 8 kq + 0..3) and 2 ks + 1 (slots 8 kq + 4..7)
+  for (int ks = 0; ks < S::n_ks1(d); ++ks)
+    for (int m = 0; m < YT; ++m)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+        if (u >= HN) continue;
+        for (int e = 0; e < 8; ++e) {
+          const int g = 2 * ks + (e >> 2);
+          if (g < G) put(0, ks * YT + m, lane, e, wn + (int64_t)u * d + 16 * g + 4 * kq + (e & 3));
+        }
+      }
+  // part 2: per output tile m: t operands for K-steps 0..NKS2-1, then s operands
+  for (int m = 0; m < G; ++m)
+    for (int which = 0; which < 2; ++which)
+      for (int ks = 0; ks < NKS2; ++ks)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4;
+          for (int e = 0; e < 8; ++e) {
+            const int tile = 2 * ks + (e >> 2), unit = 16 * tile + 4 * kq + (e & 3);
+            if (tile < YT && unit < HN)
+              put(S::part1_words(d) + (int64_t)m * S::TILE2_WORDS, which * NKS2 + ks, lane, e,
+                  (which ? ws : wt) + (int64_t)(16 * m + i) * HN + unit);
+          }
+        }
+  int32_t* pl = idx + 2 * S::split_words(d);
+  for (int m = 0; m < G; ++m)
+    for (int i = 0; i < 16; ++i) {
+      pl[(int64_t)m * 32 + i] = (int32_t)(bt + 16 * m + i);
+      pl[(int64_t)m * 32 + 16 + i] = (int32_t)(bs + 16 * m + i);
+    }
+  for (int m = 0; m < YT; ++m)
+    for (int i = 0; i < 16; ++i)
+      if (16 * m + i < HN) pl[(int64_t)G * 32 + m * 16 + i] = (int32_t)(bn + 16 * m + i);
+}
+
+template <int HN>
+static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                             const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
+                             hipStream_t stream) {
+  const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
+  auto resident_of = [](auto kernel) {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRnvpWaves * 64, 0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    return per_cu * cus;
+  };
+  static const int resident_mask = resident_of(rnvp_split_kernel<HN, false>);
+  static const int resident_seed = resident_of(rnvp_split_kernel<HN, true>);
+  // experiment switch: MNF_RNVP_BLOCKS_PER_CU=n caps the persistent grid at n workgroups per CU
+  static const int cap = [] { const char* e = getenv("MNF_RNVP_BLOCKS_PER_CU"); return e ? atoi(e) * 256 : 1 << 30; }();
+  const int resident0 = mask ? resident_mask : resident_seed;
+  const int resident = resident0 < cap ? resident0 : cap;
+  const int64_t blocks = n_groups < resident ? n_groups : resident;
+  if (mask)
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, simage, image, rows, dim, accumulate, seed);
+  else
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, simage, image, rows, dim, accumulate, seed);
+  return check_launch();
+}
+
 // ---------------------------------------------------------------- host: image index table
 template <int HN>
 static void build_index(int d, int32_t* idx) {
@@ -309,12 +691,20 @@ static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
 }
 
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
-                     const float* image, int64_t rows, int dim, int n_hidden, const int* hidden,
-                     uint64_t seed, hipStream_t stream) {
+                     const float* image, const void* split_image, int64_t rows, int dim, int n_hidden,
+                     const int* hidden, uint64_t seed, hipStream_t stream) {
   if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) |
-       reinterpret_cast<uintptr_t>(image)) & 15)
+       reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(split_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
+  if (split_image) {
+#define X(HN)            \
+  if (hidden[0] == HN)   \
+    return launch_rnvp_split<HN>(z, mask, x, log_det, accumulate, static_cast<const uint32_t*>(split_image), image, \
+                                 rows, dim, seed, stream);
+    MNF_RNVP_HIDDEN(X)
+#undef X
+  }
 #define X(HN) \
   if (hidden[0] == HN) return launch_rnvp<HN>(z, mask, x, log_det, accumulate, image, rows, dim, seed, stream);
   MNF_RNVP_HIDDEN(X)
@@ -332,6 +722,33 @@ int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden) {
   MNF_RNVP_HIDDEN(X)
 #undef X
   return 0;
+}
+
+int mnf_rnvp_split_layout(int dim, int n_hidden, const int* hidden, int64_t* n_split_words, int64_t* n_plain_words) {
+  if (!n_split_words || !n_plain_words) return MNF_ERR_INVALID_ARG;
+  if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+#define X(HN)                                                        \
+  if (hidden[0] == HN) {                                             \
+    *n_split_words = mnf::RnvpSplitShape<HN>::split_words(dim);      \
+    *n_plain_words = mnf::RnvpSplitShape<HN>::plain_words(dim);      \
+    return MNF_OK;                                                   \
+  }
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_rnvp_split_index(int dim, int n_hidden, const int* hidden, int32_t* idx_host) {
+  if (!idx_host) return MNF_ERR_INVALID_ARG;
+  if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+#define X(HN)                                      \
+  if (hidden[0] == HN) {                           \
+    mnf::build_split_index<HN>(dim, idx_host);     \
+    return MNF_OK;                                 \
+  }
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
 }
 
 int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden, int32_t* idx_host) {

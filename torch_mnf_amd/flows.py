@@ -164,7 +164,8 @@ class _RnvpFn(torch.autograd.Function):
         x = torch.empty_like(z)
         ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
-            z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), z.shape[0],
+            z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image),
+            _ptr(module._split_image(z.device)), z.shape[0],
             module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _stream()))
         ctx.module, ctx.seed, ctx.mask = module, seed, mask
         ctx.save_for_backward(z, flat)
@@ -497,6 +498,18 @@ class RNVP(_HipFlow):
         _lib.check("mnf_rnvp_image_index", lib.mnf_rnvp_image_index(self.dim, len(self.h_sizes), self._hid, idx))
         return idx
 
+    def _split_index_host(self):
+        lib = _lib.load()
+        n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = lib.mnf_rnvp_split_layout(self.dim, len(self.h_sizes), self._hid, ctypes.byref(n_split),
+                                       ctypes.byref(n_plain))
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            return None
+        _lib.check("mnf_rnvp_split_layout", rc)
+        idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+        _lib.check("mnf_rnvp_split_index", lib.mnf_rnvp_split_index(self.dim, len(self.h_sizes), self._hid, idx))
+        return idx, n_split.value, n_plain.value
+
     def mask_for(self, seed: int, rows: int, device="cuda") -> Tensor:
         m = torch.empty(rows, self.dim, dtype=torch.float32, device=device)
         if rows:
@@ -527,8 +540,8 @@ class RNVP(_HipFlow):
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
             z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
-            int(accum is not None), _ptr(flat), _ptr(image), z.shape[0], self.dim, len(self.h_sizes), self._hid,
-            int(self.force_generic), _stream()))
+            int(accum is not None), _ptr(flat), _ptr(image), _ptr(self._split_image(z.device)), z.shape[0], self.dim,
+            len(self.h_sizes), self._hid, int(self.force_generic), _stream()))
         return x, (None if accum is not None else ld)
 
     def forward(self, z: Tensor, mask: Tensor | None = None, seed: int | None = None) -> tuple[Tensor, Tensor]:
