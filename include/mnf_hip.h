@@ -91,9 +91,14 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
  * not what NormalizingFlow.forward/inverse return by default.  images = the layers' operand
  * images back to back (layer 0 first); split_images = their split images back to back, or NULL for
  * the fp32 MFMA kernel; layers are applied 0..L-1 (forward) or L-1..0 (inverse).
- * HBM traffic: 8*dim + 8 bytes per row for the whole stack.  MNF_ERR_UNSUPPORTED for shapes
+ * intermediates: NULL, or a (n_layers - 1, rows, dim) buffer that receives the output of every layer but
+ * the last in application order -- each intermediate tensor is then written once and never re-read
+ * (4*dim*(n_layers+1) + 8 bytes per row for the stack instead of (8*dim+8)*n_layers), which is how
+ * NormalizingFlow.forward/inverse run a chain of equal AffineHalfFlow layers while still returning all
+ * of them.  HBM traffic with intermediates == NULL: 8*dim + 8 bytes per row for the whole stack.  MNF_ERR_UNSUPPORTED for shapes
  * without a fused kernel (dim in {32, 64}, hidden (24,24,24) or (16,16,16)). */
-int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
+int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float* log_det, float* y_sqnorm,
+                          int accumulate,
                           const float* images, const void* split_images, const int* parity_host, int n_layers,
                           int64_t rows, int dim, int inverse,
                           int n_hidden, const int* hidden_host, void* stream);

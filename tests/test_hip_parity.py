@@ -458,6 +458,63 @@ def test_fused_affine_stack_matches_layer_by_layer(amd, golden, O, dim):
     assert list(fused.flows[0].state_dict())[0] == "layers.0.s_net.0.weight"
 
 
+@pytest.mark.parametrize("dim", [64, 32, 128])
+def test_run_fusion_keeps_every_intermediate(amd, dim):
+    """NormalizingFlow sends a run of equal AffineHalfFlow layers out as ONE launch that still writes every
+    intermediate: same list of tensors, same log_det as launching the layers one by one."""
+    layers = c2_layers(dim)
+    model = build_ahf_stack(amd, layers, dim)
+    assert model.fuse_affine_runs
+    x = cuda(recipes.gaussian(21, 1000 + 13, dim))
+    with torch.no_grad():
+        for direction in ("inverse", "forward"):
+            model.fuse_affine_runs = True
+            zs_f, ld_f = getattr(model, direction)(x)
+            model.fuse_affine_runs = False
+            zs_u, ld_u = getattr(model, direction)(x)
+            assert len(zs_f) == len(zs_u) == len(layers) + 1
+            if dim <= 64:  # one buffer holds the run's outputs
+                assert zs_f[1].data_ptr() + zs_f[1].numel() * 4 == zs_f[2].data_ptr()
+            for i, (a, b) in enumerate(zip(zs_f, zs_u)):
+                assert_close(a, b, 1e-6, f"{direction} tensor {i}")
+            assert_close(ld_f, ld_u, 1e-6, f"{direction} log_det")
+        model.fuse_affine_runs = True
+        lp_f, tot_f = model.log_prob(x, return_sum=True)
+        model.fuse_affine_runs = False
+        lp_u, tot_u = model.log_prob(x, return_sum=True)
+    assert_close(lp_f, lp_u, 1e-6, "log_prob")
+    assert abs(float(tot_f) - float(tot_u)) <= 1e-6 * abs(float(tot_u))
+
+
+def test_run_fusion_in_mixed_stacks(amd):
+    """Runs are found between other layers, split where the shape changes, and skipped for layers that want
+    gradients; a single AffineHalfFlow is not a run."""
+    dim = 64
+    mk = lambda i, **kw: ahf_module(amd, recipes.affine_half_params(400 + i, dim, **kw), dim, bool(i % 2), **kw)
+    flows = [mk(0), mk(1), mk(2), amd.ActNormFlow(dim).to(DEV), mk(3), mk(4, h_sizes=(16, 16, 16)),
+             mk(5, h_sizes=(16, 16, 16)), amd.Glow(dim).to(DEV), mk(6)]
+    flows[3].load_state_dict(recipes.actnorm_params(410, dim))
+    flows[3].data_dep_init_done = True
+    model = amd.NormalizingFlow(flows).to(DEV)
+    runs = model._affine_runs()
+    assert sorted((s, len(r.layers)) for s, r in runs.items()) == [(0, 3), (5, 2)]
+    x = cuda(recipes.gaussian(22, 777, dim))
+    with torch.no_grad():
+        for direction in ("forward", "inverse"):
+            model.fuse_affine_runs = True
+            zs_f, ld_f = getattr(model, direction)(x)
+            model.fuse_affine_runs = False
+            zs_u, ld_u = getattr(model, direction)(x)
+            assert len(zs_f) == len(zs_u) == len(flows) + 1
+            for i, (a, b) in enumerate(zip(zs_f, zs_u)):
+                assert_close(a, b, 2e-6, f"{direction} tensor {i}")
+            assert_close(ld_f, ld_u, 2e-6, f"{direction} log_det")
+    # with gradients requested the layers run one by one through their autograd functions
+    model.fuse_affine_runs = True
+    zs, ld = model.inverse(x)
+    assert ld.requires_grad and zs[-1].requires_grad
+
+
 def test_log_det_accumulates_in_layer_order(amd):
     """NormalizingFlow's fused `log_det += ld` equals summing the per-layer log-dets."""
     dim = 64

@@ -27,15 +27,49 @@ __device__ __forceinline__ void stage_split_image(uint32_t* lds, const uint32_t*
   for (int i = threadIdx.x; i < S::IMAGE_WORDS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
-// s, t for one tile: split path, then the fp32 path if any operand was out of range
+// fp32 conditioner for one tile, out of line: the stack kernel's layer loop must stay free of ordinary
+// global loads -- with the cold path inlined the compiler puts a vmcnt(0) at the join of the two paths,
+// which on the hot path waits for the previous layer's intermediate-tensor stores (an HBM write latency
+// per layer).  A call is a clean boundary for the wait-count tracking.
+template <int G>
+struct CondOut {
+  f32x4 s[G], t[G];
+};
+template <int G>
+struct CondIn {
+  f32x4 c[G];
+};
+// (arguments and result by value: by reference the rows would have to live in scratch memory)
 template <int H, int HID>
+__device__ __attribute__((noinline)) CondOut<H / 16> ahf_cond_f32_cold(const float* image_f32, int lane, int q,
+                                                                      CondIn<H / 16> in) {
+  CondOut<H / 16> out;
+  ahf_cond_f32<H, HID>(image_f32, lane, q, in.c, out.s, out.t);
+  return out;
+}
+
+// s, t for NTL tiles: split path, then the fp32 path if any operand was out of range
+template <int H, int HID, int NTL>
 __device__ __forceinline__ void ahf_cond_guarded(const uint32_t* lds, const float* image_f32, int lane, int q,
-                                                 const f32x4 (&cnd)[H / 16], f32x4 (&s4)[H / 16],
-                                                 f32x4 (&t4)[H / 16]) {
+                                                 const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
+                                                 f32x4 (&t4)[NTL][H / 16]) {
   using S = SplitShape<H, HID>;
   float mx = __builtin_bit_cast(float, lds[S::SPLIT_WORDS + S::PLAIN_WORDS]);  // max |weight|
-  split_conditioner<H, HID>(lds, lane, q, cnd, s4, t4, mx);
-  if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) ahf_cond_f32<H, HID>(image_f32, lane, q, cnd, s4, t4);
+  split_conditioner<H, HID, NTL>(lds, lane, q, cnd, s4, t4, mx);
+  if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      CondIn<H / 16> in;
+#pragma unroll
+      for (int g = 0; g < H / 16; ++g) in.c[g] = cnd[t][g];
+      const CondOut<H / 16> out = ahf_cond_f32_cold<H, HID>(image_f32, lane, q, in);
+#pragma unroll
+      for (int g = 0; g < H / 16; ++g) {
+        s4[t][g] = out.s[g];
+        t4[t][g] = out.t[g];
+      }
+    }
+  }
 }
 
 // ABL != 0 only in tools/split_microbench.hip (2 = no HBM traffic, 5 = no range guard, 6 = copy only,
@@ -99,11 +133,11 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
     // soon as this tile's has been split into MFMA operands, and flies under the conditioner (at
     // 4 waves/SIMD the other waves alone do not cover the HBM latency).  One tile past the end
     // re-reads the last tile: harmless, and keeps the loop branch-free.
-    f32x4 cur[G];
+    f32x4 cur[1][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) cur[g] = cnd[g];
+    for (int g = 0; g < G; ++g) cur[0][g] = cnd[g];
     const float* xn = row_ptr(tile + tile_stride < n_tiles ? tile + tile_stride : n_tiles - 1);
-    f32x4 s4[G], t4[G];
+    f32x4 s4[1][G], t4[1][G];
     {
       using SS = SplitShape<H, HID>;
       float mx = __builtin_bit_cast(float, lds[SS::SPLIT_WORDS + SS::PLAIN_WORDS]);  // max |weight|
@@ -115,18 +149,18 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
       if (ABL == 6) {
         prefetch();
 #pragma unroll
-        for (int g = 0; g < G; ++g) s4[g] = t4[g] = cur[g];
+        for (int g = 0; g < G; ++g) s4[0][g] = t4[0][g] = cur[0][g];
       } else {
-        split_conditioner<H, HID, decltype(prefetch), ABL>(lds, lane, q, cur, s4, t4, mx, prefetch);
+        split_conditioner<H, HID, 1, decltype(prefetch), ABL>(lds, lane, q, cur, s4, t4, mx, prefetch);
       }
       if (ABL != 5 && ABL != 6 && __builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {  // out of f16 range: fp32 MFMAs, operands from L2
         f32x4 again[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) again[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
-        ahf_cond_f32<H, HID>(image_f32, lane, q, again, s4, t4);
+        ahf_cond_f32<H, HID>(image_f32, lane, q, again, s4[0], t4[0]);
       }
     }
-    float ld = ahf_transform<H, INV>(s4, t4, act);
+    float ld = ahf_transform<H, INV>(s4[0], t4[0], act);
     if (live) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + act_off + 16 * g) = act[g];
@@ -147,93 +181,137 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
   }
 }
 
-// L layers per launch; the split images are streamed through a double-buffered LDS window: the
-// image of layer l+1 is requested into registers before layer l is computed and handed over at
-// one barrier per layer.
+// ------------------------------------------------------------------------------------------------
+// L layers per launch, rows kept in registers across layers.  Compute bound (no per-layer HBM read), and
+// inside the conditioner the co-bottleneck is LDS: a wave re-reads 30 KB of operands per 16 rows per
+// layer.  So a wave owns kStackTiles (2) row tiles that share every operand read, a workgroup has
+// kStackWaves (4) waves -- one per SIMD, two workgroups per CU -- and the next layer's split image is
+// copied L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into the other half of
+// a double buffer while the current layer computes; one barrier per layer.
+// mid != nullptr: the output of every layer but the last goes to mid[li] (application order): each
+// intermediate tensor is written once and never re-read.
+// ------------------------------------------------------------------------------------------------
+#ifndef MNF_STACK_SAME_SLOT
+#define MNF_STACK_SAME_SLOT 0  // experiment: every intermediate into slot 0 (store issue cost without HBM traffic)
+#endif
+constexpr int kStackWaves = 4;
+constexpr int kStackTiles = 2;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// Image copy L2 -> LDS by LDS-DMA (no staging registers).  One wave-instruction copies 64 x 16 B; the LDS
+// destination is the wave-uniform base + lane * 16.  Completion: s_waitcnt vmcnt(0) by the issuing wave,
+// then a barrier.
+template <int IMG4, int WAVES>
+__device__ __forceinline__ void image_to_lds_async(const uint4* src, uint32_t* dst, int lane, int wave) {
+  constexpr int PIECES = (IMG4 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
+    const int piece = i * WAVES + wave;  // wave-uniform
+    if (piece < PIECES && piece * 64 + lane < IMG4)
+      __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, (lds_void_ptr)(dst + piece * 256), 16, 0, 0);
+  }
+}
+
 template <int H, int HID, bool INV>
-__global__ void __launch_bounds__(kSplitWaves * 64)
-ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
-                       float* __restrict__ ysq, const uint32_t* __restrict__ simages,
+__global__ void __launch_bounds__(kStackWaves * 64, 2)
+ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
+                       float* __restrict__ log_det, float* __restrict__ ysq, const uint32_t* __restrict__ simages,
                        const float* __restrict__ images_f32, uint32_t parity_bits, int n_layers, int64_t rows,
                        int accumulate) {
   using S = SplitShape<H, HID>;
-  constexpr int G = S::G, dim = 2 * H;
+  constexpr int G = S::G, dim = 2 * H, NTL = kStackTiles;
   constexpr int IMG4 = S::IMAGE_WORDS / 4;
-  constexpr int STAGE = (IMG4 + kSplitWaves * 64 - 1) / (kSplitWaves * 64);
   constexpr int F32_FLOATS = AhfShape<H, HID>::IMAGE_FLOATS;
+  constexpr int GROUP_ROWS = 16 * NTL * kStackWaves;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][S::IMAGE_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const uint4* img4 = reinterpret_cast<const uint4*>(simages);
   auto layer_at = [&](int li) { return INV ? n_layers - 1 - li : li; };  // application order
 
-  const int n_groups = (int)((rows + 16 * kSplitWaves - 1) / (16 * kSplitWaves));
+  const int n_groups = (int)((rows + GROUP_ROWS - 1) / GROUP_ROWS);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int64_t row = (int64_t)grp * (16 * kSplitWaves) + wave * 16 + j;
-    const bool live = row < rows;
-    const int64_t rowc = live ? row : rows - 1;
-    const float* xr = x + rowc * dim + 4 * q;
-    f32x4 lo[G], hi[G];
+    int64_t row[NTL], rowc[NTL];
+    bool live[NTL];
+    f32x4 lo[NTL][G], hi[NTL][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+    for (int t = 0; t < NTL; ++t) {
+      row[t] = (int64_t)grp * GROUP_ROWS + (wave * NTL + t) * 16 + j;
+      live[t] = row[t] < rows;
+      rowc[t] = live[t] ? row[t] : rows - 1;  // rows past the end: clamped loads, masked stores
+      const float* xr = x + rowc[t] * dim + 4 * q;
 #pragma unroll
-    for (int g = 0; g < G; ++g) hi[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
-    __syncthreads();  // the previous group's last layer is fully consumed
-    {
-      const uint4* src = img4 + (int64_t)layer_at(0) * IMG4;
-      uint4* dst = reinterpret_cast<uint4*>(lds[0]);
-      for (int k = threadIdx.x; k < IMG4; k += kSplitWaves * 64) dst[k] = src[k];
+      for (int g = 0; g < G; ++g) lo[t][g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+#pragma unroll
+      for (int g = 0; g < G; ++g) hi[t][g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
     }
-    __syncthreads();
-    float ld = 0.f;
+    __syncthreads();  // the previous group's last layer is fully consumed
+    image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(0) * IMG4, lds[0], lane, wave);
+    __syncthreads();  // (hipcc drains vmcnt before a barrier: image and rows have landed)
+    float ld[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) ld[t] = 0.f;
     for (int li = 0; li < n_layers; ++li) {
       const int layer = layer_at(li);
-      // request the next layer's image (after the last layer: the same one again, branch-free)
-      const uint4* src = img4 + (int64_t)layer_at(li + 1 < n_layers ? li + 1 : li) * IMG4;
-      uint4 st[STAGE];
-#pragma unroll
-      for (int i = 0; i < STAGE; ++i) {
-        const int k = threadIdx.x + i * (kSplitWaves * 64);
-        st[i] = src[k < IMG4 ? k : 0];
-      }
+      if (li + 1 < n_layers)  // next layer's image into the other buffer, in flight under this layer's math
+        image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(li + 1) * IMG4, lds[(li + 1) & 1], lane, wave);
       const uint32_t* img = lds[li & 1];
       const float* f32img = images_f32 + (int64_t)layer * F32_FLOATS;
-      f32x4 s4[G], t4[G];
+      f32x4 s4[NTL][G], t4[NTL][G];
       if ((parity_bits >> layer) & 1u) {  // conditioner = upper half
-        ahf_cond_guarded<H, HID>(img, f32img, lane, q, hi, s4, t4);
-        ld += ahf_transform<H, INV>(s4, t4, lo);
+        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, hi, s4, t4);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], lo[t]);
       } else {
-        ahf_cond_guarded<H, HID>(img, f32img, lane, q, lo, s4, t4);
-        ld += ahf_transform<H, INV>(s4, t4, hi);
+        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, lo, s4, t4);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], hi[t]);
       }
-      uint4* dst = reinterpret_cast<uint4*>(lds[(li + 1) & 1]);
+      if (li + 1 < n_layers) {
+        // End of layer.  The next image (LDS-DMA, issued before this layer's math) must have landed before
+        // the barrier; the intermediate stores need not have.  A counted wait cannot single out the DMA
+        // (loads and stores retire out of order with each other), so: drain BEFORE the stores -- all that is
+        // outstanding then is the DMA and the previous layer's stores, both issued a whole layer of math
+        // ago -- then store, and meet at a bare s_barrier (a __syncthreads() after the stores would put a
+        // vmcnt(0) behind them and expose one HBM write latency per layer).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mid != nullptr) {
 #pragma unroll
-      for (int i = 0; i < STAGE; ++i) {
-        const int k = threadIdx.x + i * (kSplitWaves * 64);
-        if (k < IMG4) dst[k] = st[i];
+          for (int t = 0; t < NTL; ++t)
+            if (live[t]) {
+              float* mr = mid + ((int64_t)(MNF_STACK_SAME_SLOT ? 0 : li) * rows + rowc[t]) * dim + 4 * q;
+#pragma unroll
+              for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + 16 * g) = lo[t][g];
+#pragma unroll
+              for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = hi[t][g];
+            }
+        }
+        __builtin_amdgcn_s_barrier();
       }
-      __syncthreads();
     }
-    if (live) {
-      float* yr = y + rowc * dim + 4 * q;
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
+    for (int t = 0; t < NTL; ++t) {
+      if (live[t]) {
+        float* yr = y + rowc[t] * dim + 4 * q;
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = hi[g];
-    }
-    if (log_det) {
-      ld = sum_over_q(ld);
-      if (INV) ld = -ld;
-      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
-    }
-    if (ysq) {
-      float sq = 0.f;
+        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[t][g];
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = hi[t][g];
+      }
+      if (log_det) {
+        float l = sum_over_q(ld[t]);
+        if (INV) l = -l;
+        if (live[t] && q == 0) log_det[row[t]] = accumulate ? log_det[row[t]] + l : l;
+      }
+      if (ysq) {
+        float sq = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sq = fmaf(lo[g][r], lo[g][r], fmaf(hi[g][r], hi[g][r], sq));
-      sq = sum_over_q(sq);
-      if (live && q == 0) ysq[row] = sq;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq = fmaf(lo[t][g][r], lo[t][g][r], fmaf(hi[t][g][r], hi[t][g][r], sq));
+        sq = sum_over_q(sq);
+        if (live[t] && q == 0) ysq[row[t]] = sq;
+      }
     }
   }
 }
@@ -346,19 +424,28 @@ static int launch_split(const float* x, float* y, float* log_det, float* ysq, in
 }
 
 template <int H, int HID>
-static int launch_split_stack(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+static int launch_split_stack(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                               const uint32_t* simages, const float* images, uint32_t parity_bits, int n_layers,
                               int64_t rows, int inverse, hipStream_t stream) {
-  static int cus = 256;
-  static const int resident = resident_blocks(ahf_split_stack_kernel<H, HID, true>, cus);
-  const int64_t n_groups = (rows + 16 * kSplitWaves - 1) / (16 * kSplitWaves);
-  const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kSplitWaves * 64);
+  static const int resident = [] {
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ahf_split_stack_kernel<H, HID, true>, kStackWaves * 64,
+                                                     0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    return per_cu * cus;
+  }();
+  constexpr int GROUP_ROWS = 16 * kStackTiles * kStackWaves;
+  const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
+  const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);
   if (inverse)
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, log_det, ysq, simages,
-                       images, parity_bits, n_layers, rows, accumulate);
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, mid, log_det, ysq,
+                       simages, images, parity_bits, n_layers, rows, accumulate);
   else
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, log_det, ysq, simages,
-                       images, parity_bits, n_layers, rows, accumulate);
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, mid, log_det, ysq,
+                       simages, images, parity_bits, n_layers, rows, accumulate);
   return check_launch();
 }
 
@@ -393,13 +480,14 @@ int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int a
   return MNF_ERR_UNSUPPORTED;
 }
 
-int ahf_split_stack_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
                            int64_t rows, int dim, int inverse, int hid, hipStream_t stream) {
-  if (!split_images || !images || !aligned16(x, y, split_images, images)) return MNF_ERR_UNSUPPORTED;
+  if (!split_images || !images || !aligned16(x, y, split_images, images) || (reinterpret_cast<uintptr_t>(mid) & 15))
+    return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                                                                                               \
   if (dim == 2 * HH && hid == HD)                                                                               \
-    return launch_split_stack<HH, HD>(x, y, log_det, ysq, accumulate, static_cast<const uint32_t*>(split_images), \
+    return launch_split_stack<HH, HD>(x, y, mid, log_det, ysq, accumulate, static_cast<const uint32_t*>(split_images), \
                                       images, parity_bits, n_layers, rows, inverse != 0, stream);
   MNF_AHF_SPLIT_STACK_SHAPES(X)
 #undef X

@@ -31,8 +31,8 @@ __device__ __forceinline__ float ahf_layer_regs(const float* img, int lane, int 
 
 template <int H, int HID, bool INV>
 __global__ void __launch_bounds__(kStackWaves * 64, 6)  // three 8-wave workgroups per CU: <= 80 VGPRs
-ahf_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
-                 float* __restrict__ ysq, const float* __restrict__ images, uint32_t parity_bits, int n_layers,
+ahf_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
+                 float* __restrict__ log_det, float* __restrict__ ysq, const float* __restrict__ images, uint32_t parity_bits, int n_layers,
                  int64_t rows, int accumulate) {
   using S = AhfShape<H, HID>;
   constexpr int G = S::G, dim = 2 * H;
@@ -78,6 +78,13 @@ ahf_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
         ld += ahf_layer_regs<H, HID, INV>(img, lane, q, hi, lo);
       else
         ld += ahf_layer_regs<H, HID, INV>(img, lane, q, lo, hi);
+      if (mid && li + 1 < n_layers && live) {  // the intermediate tensor after this layer
+        float* mr = mid + ((int64_t)li * rows + rowc) * dim + 4 * q;
+#pragma unroll
+        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + 16 * g) = lo[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = hi[g];
+      }
       float4* dst = reinterpret_cast<float4*>(lds[(li + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < STAGE; ++i) {
@@ -111,7 +118,8 @@ ahf_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
 }
 
 template <int H, int HID>
-static int launch_stack(const float* x, float* y, float* log_det, float* ysq, int accumulate, const float* images,
+static int launch_stack(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
+                        const float* images,
                         uint32_t parity_bits, int n_layers, int64_t rows, int inverse, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kStackWaves - 1) / (16 * kStackWaves);
   static const int resident = [] {
@@ -127,10 +135,10 @@ static int launch_stack(const float* x, float* y, float* log_det, float* ysq, in
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   const dim3 grid((unsigned)blocks), block(kStackWaves * 64);
   if (inverse)
-    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, log_det, ysq, images,
+    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, mid, log_det, ysq, images,
                        parity_bits, n_layers, rows, accumulate);
   else
-    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, log_det, ysq, images,
+    hipLaunchKernelGGL((ahf_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, mid, log_det, ysq, images,
                        parity_bits, n_layers, rows, accumulate);
   return check_launch();
 }
@@ -141,27 +149,29 @@ extern "C" {
 
 // images: n_layers operand images (mnf_affine_half_image_floats each) back to back, layer 0 first;
 // parity_host[l] as in mnf_affine_half.  Layers are applied 0..L-1 (forward) or L-1..0 (inverse).
-int mnf_affine_half_stack(const float* x, float* y, float* log_det, float* y_sqnorm, int accumulate,
-                          const float* images, const void* split_images, const int* parity_host, int n_layers,
+int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float* log_det, float* y_sqnorm,
+                          int accumulate, const float* images, const void* split_images, const int* parity_host, int n_layers,
                           int64_t rows, int dim, int inverse, int n_hidden, const int* hidden, void* stream) {
   if (!x || !y || x == y || !images || !parity_host || n_layers < 1 || n_layers > 32 || rows < 0 || dim < 2 ||
       (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (n_hidden != 3 || hidden[0] != hidden[1] || hidden[1] != hidden[2]) return MNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(images)) & 15)
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(images) |
+       reinterpret_cast<uintptr_t>(intermediates)) & 15)
     return MNF_ERR_UNSUPPORTED;
   uint32_t bits = 0;
   for (int l = 0; l < n_layers; ++l) bits |= (parity_host[l] ? 1u : 0u) << l;
   const int hid = hidden[0];
   if (split_images) {
-    const int rc = mnf::ahf_split_stack_launch(x, y, log_det, y_sqnorm, accumulate, split_images, images, bits,
+    const int rc = mnf::ahf_split_stack_launch(x, y, intermediates, log_det, y_sqnorm, accumulate, split_images, images, bits,
                                                n_layers, rows, dim, inverse, hid, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) \
-    return mnf::launch_stack<HH, HD>(x, y, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, inverse != 0, \
+    return mnf::launch_stack<HH, HD>(x, y, intermediates, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, \
+                                     inverse != 0, \
                                      (hipStream_t)stream);
   X(16, 24) X(32, 24) X(16, 16) X(32, 16)
 #undef X

@@ -41,7 +41,7 @@ int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int ac
 int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate, const void* split_image,
                      const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
                      const int* hidden, int has_scale, int has_shift, hipStream_t stream);
-int ahf_split_stack_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
+int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
                            int64_t rows, int dim, int inverse, int hid, hipStream_t stream);
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,

@@ -169,13 +169,15 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 
-// after_split() runs once cnd has been turned into MFMA operands (cnd is dead from there on: the
-// single-layer kernel issues its prefetch of the next tile there).
+// NTL row tiles (16 rows each) share every A-operand read: the weights come out of LDS once per NTL
+// tiles (LDS bandwidth, not the matrix pipe, is the co-bottleneck of the conditioner: 30 KB of operands
+// per tile per layer).  after_split() runs once cnd has been turned into MFMA operands (cnd is dead from
+// there on: the single-layer kernel issues its prefetch of the next tile there).
 // ABL != 0 only in tools/split_microbench.hip (1 = MFMAs skipped, 3 = operand splitting skipped).
-template <int H, int HID, typename Hook = NoHook, int ABL = 0>
-__device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane, int q, const f32x4 (&cnd)[H / 16],
-                                                  f32x4 (&s4)[H / 16], f32x4 (&t4)[H / 16], float& mx,
-                                                  Hook after_split = Hook()) {
+template <int H, int HID, int NTL = 1, typename Hook = NoHook, int ABL = 0>
+__device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane, int q,
+                                                  const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
+                                                  f32x4 (&t4)[NTL][H / 16], float& mx, Hook after_split = Hook()) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
   // opaque offsets: keep the (loop-invariant) operand reads inside the tile loop instead of in VGPRs
@@ -203,38 +205,52 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
       mnf::split_mac(ah, al, bh, bl, mn, cr);
     }
   };
-  u32x2 xh[G], xl[G];
+  u32x2 xh[NTL][G], xl[NTL][G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) split_tile(cnd[g], xh[g], xl[g], mx);
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int g = 0; g < G; ++g) split_tile(cnd[t][g], xh[t][g], xl[t][g], mx);
   after_split();
 
   // ---- layer 1
-  f32x4 main[NT], corr[NT];
+  f32x4 main[NTL][NT], corr[NTL][NT];
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
-    main[m] = B4[4 * (bt++)];
-    corr[m] = zero4;
+    const f32x4 bias = B4[4 * (bt++)];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      main[t][m] = bias;
+      corr[t][m] = zero4;
+    }
   }
 #pragma unroll
   for (int ks = 0; ks < KS1; ++ks) {
-    const f16x8 bh = pair_operand(xh[2 * ks], 2 * ks + 1 < G ? xh[2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
-    const f16x8 bl = pair_operand(xl[2 * ks], 2 * ks + 1 < G ? xl[2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
+    f16x8 bh[NTL], bl[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      bh[t] = pair_operand(xh[t][2 * ks], 2 * ks + 1 < G ? xh[t][2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
+      bl[t] = pair_operand(xl[t][2 * ks], 2 * ks + 1 < G ? xl[t][2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
+    }
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-      split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, main[m], corr[m]);
+      const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], main[t][m], corr[t][m]);
       ++op;
     }
   }
-  u32x2 hh[NT], hl[NT];
+  u32x2 hh[NTL][NT], hl[NTL][NT];
   auto activate = [&]() {
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      // pre-activation = main + corr 2^-11, LeakyReLU = max(p, 0.2 p): vector forms so that the
-      // multiply-adds go out as packed fp32 instructions (two values each)
-      const f32x4 p = corr[m] * kSplitInvScale + main[m];
-      const f32x4 v = __builtin_elementwise_max(p, p * kLeakySlope);
-      split_tile(v, hh[m], hl[m], mx);
-    }
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        // pre-activation = main + corr 2^-11, LeakyReLU = max(p, 0.2 p): vector forms so that the
+        // multiply-adds go out as packed fp32 instructions (two values each)
+        const f32x4 p = corr[t][m] * kSplitInvScale + main[t][m];
+        const f32x4 v = __builtin_elementwise_max(p, p * kLeakySlope);
+        split_tile(v, hh[t][m], hl[t][m], mx);
+      }
   };
   activate();
 
@@ -243,18 +259,28 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   for (int layer = 0; layer < 2; ++layer) {
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-      main[m] = B4[4 * (bt++)];
-      corr[m] = zero4;
+      const f32x4 bias = B4[4 * (bt++)];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        main[t][m] = bias;
+        corr[t][m] = zero4;
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int ta = S::ks_a(ks), tb = S::ks_b(ks);
-      const f16x8 bh = pair_operand(hh[ta], tb >= 0 ? hh[tb >= 0 ? tb : 0] : zero2);
-      const f16x8 bl = pair_operand(hl[ta], tb >= 0 ? hl[tb >= 0 ? tb : 0] : zero2);
+      f16x8 bh[NTL], bl[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        bh[t] = pair_operand(hh[t][ta], tb >= 0 ? hh[t][tb >= 0 ? tb : 0] : zero2);
+        bl[t] = pair_operand(hl[t][ta], tb >= 0 ? hl[t][tb >= 0 ? tb : 0] : zero2);
+      }
 #pragma unroll
       for (int m = 0; m < NT; ++m)
         if (S::uses(S::tile_nets(m), ks)) {
-          split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, main[m], corr[m]);
+          const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], main[t][m], corr[t][m]);
           ++op;
         }
     }
@@ -264,27 +290,39 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   // ---- output layer: s from the s-net units, t from the t-net units
 #pragma unroll
   for (int net = 0; net < 2; ++net) {
-    f32x4(&out)[G] = net ? t4 : s4;
-    f32x4 oc[G];
+    f32x4(&out)[NTL][G] = net ? t4 : s4;
+    f32x4 oc[NTL][G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      out[g] = B4[4 * (bt++)];
-      oc[g] = zero4;
+      const f32x4 bias = B4[4 * (bt++)];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        out[t][g] = bias;
+        oc[t][g] = zero4;
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       if (S::uses(1 << net, ks)) {
         const int ta = S::ks_a(ks), tb = S::ks_b(ks);
-        const f16x8 bh = pair_operand(hh[ta], tb >= 0 ? hh[tb >= 0 ? tb : 0] : zero2);
-        const f16x8 bl = pair_operand(hl[ta], tb >= 0 ? hl[tb >= 0 ? tb : 0] : zero2);
+        f16x8 bh[NTL], bl[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          bh[t] = pair_operand(hh[t][ta], tb >= 0 ? hh[t][tb >= 0 ? tb : 0] : zero2);
+          bl[t] = pair_operand(hl[t][ta], tb >= 0 ? hl[t][tb >= 0 ? tb : 0] : zero2);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          split_mac(A8[64 * (2 * op)], A8[64 * (2 * op + 1)], bh, bl, out[g], oc[g]);
+          const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], out[t][g], oc[t][g]);
           ++op;
         }
       }
 #pragma unroll
-    for (int g = 0; g < G; ++g) out[g] = oc[g] * kSplitInvScale + out[g];
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int g = 0; g < G; ++g) out[t][g] = oc[t][g] * kSplitInvScale + out[t][g];
   }
 }
 

@@ -31,6 +31,8 @@ from . import _lib
 
 # MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
 _FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
+# MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
+_NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
@@ -802,12 +804,66 @@ class FusedSplineBlock(_TwoWayFlow):
         return y, ld
 
 
+class _AffineRun:
+    """Consecutive ``AffineHalfFlow`` layers of one shape, in MODEL order, as one ``mnf_affine_half_stack``
+    launch.  A plain object (not a Module): it only caches the concatenated operand images."""
+
+    def __init__(self, layers: Sequence["AffineHalfFlow"]) -> None:
+        self.layers = list(layers)
+        self._key = None
+        self._images: Tensor | None = None
+        self._splits: Tensor | None = None
+        self._unsupported = False  # set once the library reports that the shape has no stack kernel
+
+    @staticmethod
+    def compatible(a: "AffineHalfFlow", b: "AffineHalfFlow") -> bool:
+        return (a.dim, a.h_sizes, a.scale, a.shift) == (b.dim, b.h_sizes, b.scale, b.shift)
+
+    def images(self, device):
+        key = (device, tuple(f.force_fp32_mfma for f in self.layers),
+               tuple((p.data_ptr(), p._version) for f in self.layers for p in f._packed_params()))
+        if key != self._key:
+            imgs = [f._packed(device)[1] for f in self.layers]
+            self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
+            splits = [f._split_image(device) for f in self.layers]
+            self._splits = None if any(i is None for i in splits) else torch.cat(splits).contiguous()
+            self._key = key
+        return self._images, self._splits
+
+    def usable(self, x) -> bool:
+        return (not self._unsupported and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+                and x.shape[1] == self.layers[0].dim and not any(f.force_generic for f in self.layers)
+                and not any(_wants_grad(f, x) for f in self.layers) and self.images(x.device)[0] is not None)
+
+    def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, sqnorm: Tensor | None,
+               keep: bool) -> list[Tensor] | None:
+        """Runs the layers (model order reversed when ``inverse``).  Returns the output tensors in
+        application order -- all of them when ``keep`` (views of one buffer: each intermediate is written
+        once and never re-read), else just the last -- or None when the shape has no stack kernel."""
+        f0, n = self.layers[0], len(self.layers)
+        images, splits = self.images(x.device)
+        x = _device_input(x, "input")
+        buf = torch.empty((n if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
+        rc = _lib.load().mnf_affine_half_stack(
+            x.data_ptr(), buf[-1].data_ptr(), buf.data_ptr() if keep and n > 1 else None, log_det.data_ptr(),
+            _ptr(sqnorm), int(accumulate), images.data_ptr(), _ptr(splits), par, n, x.shape[0], f0.dim, int(inverse),
+            len(f0.h_sizes), f0._hid, _stream())
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            self._unsupported = True
+            return None
+        _lib.check("mnf_affine_half_stack", rc)
+        return list(buf.unbind(0))
+
+
 class FusedAffineStack(_TwoWayFlow):
     """Opt-in whole-stack fusion of consecutive ``AffineHalfFlow`` layers of one shape (SURVEY.md 8f
     rank 3): all of them in ONE kernel launch per direction, the rows held in registers across
     layers -- HBM sees each row once in and once out.  No intermediate tensor exists, so as a member
     of a ``NormalizingFlow`` it contributes ONE entry to the returned list instead of one per layer;
     that change of what ``forward``/``inverse`` return is why this is an explicit opt-in.
+    (``NormalizingFlow`` itself fuses runs of equal AffineHalfFlow layers while KEEPING every
+    intermediate; this class is for callers that do not want them.)
 
     ``state_dict`` keys are ``layers.{i}.s_net...``; falls back to running the layers one by one when
     a graph is being recorded or the shape has no fused kernel."""
@@ -818,13 +874,11 @@ class FusedAffineStack(_TwoWayFlow):
         if not layers or any(not isinstance(f, AffineHalfFlow) for f in layers):
             raise TypeError("FusedAffineStack takes AffineHalfFlow layers")
         f0 = layers[0]
-        if any((f.dim, f.h_sizes, f.scale, f.shift) != (f0.dim, f0.h_sizes, f0.scale, f0.shift) for f in layers):
+        if any(not _AffineRun.compatible(f, f0) for f in layers):
             raise ValueError("all layers must share dim, h_sizes and the scale/shift flags")
         self.layers = nn.ModuleList(layers)
         self.dim = f0.dim
-        self._img_key = None
-        self._images: Tensor | None = None
-        self._splits: Tensor | None = None
+        self.__dict__["_run_helper"] = _AffineRun(layers)  # not a Module: keep it out of the module tree
 
     def _packed_params(self) -> list[Tensor]:
         return []
@@ -837,38 +891,18 @@ class FusedAffineStack(_TwoWayFlow):
             ld = ld + l1
         return x, ld
 
-    def _stack_images(self, device) -> Tensor | None:
-        key = (device, tuple((p.data_ptr(), p._version) for f in self.layers for p in f._packed_params()))
-        if key != self._img_key:
-            imgs = [f._packed(device)[1] for f in self.layers]
-            self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
-            splits = [f._split_image(device) for f in self.layers]
-            self._splits = None if any(i is None for i in splits) else torch.cat(splits).contiguous()
-            self._img_key = key
-        return self._images
-
     def emits_sqnorm(self, device) -> bool:
-        return self._stack_images(device) is not None
+        return self._run_helper.images(device)[0] is not None
 
     def _run(self, x, inverse, accum, sqnorm: Tensor | None = None, overwrite: bool = False):
-        f0 = self.layers[0]
-        fused_ok = isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and not any(
-            _wants_grad(f, x) for f in self.layers) and not any(f.force_generic for f in self.layers)
-        images = self._stack_images(x.device) if fused_ok else None
-        if images is not None:
-            x = _device_input(x, "input")
-            if x.shape[1] != self.dim:
-                raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
-            y = torch.empty_like(x)
+        run = self._run_helper
+        if run.usable(x):
             ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-            par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
-            rc = _lib.load().mnf_affine_half_stack(
-                x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None and not overwrite),
-                images.data_ptr(),
-                _ptr(None if any(f.force_fp32_mfma for f in self.layers) else self._splits), par, len(self.layers), x.shape[0], self.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
-            if rc != _lib.MNF_ERR_UNSUPPORTED:
-                _lib.check("mnf_affine_half_stack", rc)
-                return y, (None if accum is not None else ld)
+            out = run.launch(x, inverse, ld, accum is not None and not overwrite, sqnorm, keep=False)
+            if out is not None:
+                return out[-1], (None if accum is not None else ld)
+        elif isinstance(x, Tensor) and x.dim() == 2 and x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         y, ld = self._sequence(x, inverse, sqnorm)
         if accum is not None:
             if overwrite:
@@ -891,47 +925,91 @@ class NormalizingFlow(nn.Module):
         # the stream the kernels are launched on (consecutive layers share the boundary event)
         self.layer_events: list | None = None
         self.layer_event_pick: int | None = None
+        # runs of equal AffineHalfFlow layers go out as ONE launch that still writes every intermediate
+        self.fuse_affine_runs = True
         self._last_sqnorm: Tensor | None = None
 
+    def _affine_runs(self) -> dict:
+        """start index (model order) -> _AffineRun for every maximal run of >= 2 consecutive AffineHalfFlow
+        layers of one shape; rebuilt when the module list changes."""
+        ids = tuple(id(f) for f in self.flows)
+        cache = self.__dict__.get("_runs_cache")
+        if cache is None or cache[0] != ids:
+            runs, flows, i = {}, list(self.flows), 0
+            while i < len(flows):
+                j = i + 1
+                if type(flows[i]) is AffineHalfFlow:
+                    while j < len(flows) and type(flows[j]) is AffineHalfFlow and _AffineRun.compatible(flows[i], flows[j]):
+                        j += 1
+                    if j - i >= 2:
+                        runs[i] = _AffineRun(flows[i:j])
+                i = j
+            cache = (ids, runs)
+            self.__dict__["_runs_cache"] = cache
+        return cache[1]
+
     def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False):
+        n = len(self.flows)
         order = list(reversed(self.flows)) if inverse else list(self.flows)
+        runs = self._affine_runs() if self.fuse_affine_runs and not _NO_RUN_FUSION_ENV else {}
+        # position in `order` -> run that starts there
+        run_at = {(n - (start + len(r.layers)) if inverse else start): r for start, r in runs.items()}
         # a first layer whose kernel writes log_det for every row saves zero-filling it
         fresh = (bool(order) and isinstance(order[0], (AffineHalfFlow, FusedAffineStack)) and isinstance(x, Tensor)
                  and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and not _wants_grad(order[0], x))
         log_det = torch.empty(x.size(0), device=x.device) if fresh else torch.zeros(x.size(0), device=x.device)
         seen = [x]
         self._last_sqnorm = None
-        # layer_events: list receiving (start, end) HIP events per layer; layer_event_pick = i restricts
-        # the marks to layer i of this pass (a mark costs a few us of stream time, bench.py rotates i)
+        # layer_events: list receiving (start, end, index) HIP events per launch; layer_event_pick = i restricts
+        # the marks to the launch at position i of this pass (a mark costs a few us of stream time)
         pick = self.layer_event_pick
         events_on = self.layer_events is not None and x.is_cuda
-        for i, flow in enumerate(order):
+        i = 0
+        while i < n:
+            flow = order[i]
+            run = run_at.get(i)
+            if run is not None and not run.usable(x):
+                run = None
+            span = len(run.layers) if run is not None else 1
+            last = i + span == n
             timed = events_on and (pick is None or pick == i)
-            if timed and (pick is not None or i == 0):
+            if timed:
                 e_prev = torch.cuda.Event(enable_timing=True)
                 e_prev.record()
-            if (want_sqnorm and i == len(order) - 1 and isinstance(flow, (AffineHalfFlow, FusedAffineStack))
-                    and x.is_cuda and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
-                # last layer also emits |z|^2 per row for the standard-normal epilogue
-                self._last_sqnorm = torch.empty(x.size(0), device=x.device)
-                x, _ = flow._run(x, inverse, log_det, self._last_sqnorm, overwrite=fresh and i == 0)
-            elif isinstance(flow, _HipFlow) and (inverse is False or isinstance(flow, _TwoWayFlow)) \
-                    and _wants_grad(flow, x):
-                x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
-                log_det = log_det + ld
-            elif fresh and i == 0:
-                x, _ = flow._run(x, inverse, log_det, overwrite=True)  # log_det = ld inside the kernel
-            elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
-                x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
-            else:
-                x, ld = flow.inverse(x) if inverse else flow.forward(x)
-                log_det += ld
+            outs = None
+            if run is not None:
+                # one launch for the whole run; every intermediate is written once and never re-read
+                sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
+                outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True)
+                if outs is not None:
+                    self._last_sqnorm = sq
+                    seen.extend(outs)
+                    x = outs[-1]
+                else:
+                    span, last = 1, i + 1 == n
+            if outs is None:
+                if (want_sqnorm and last and isinstance(flow, (AffineHalfFlow, FusedAffineStack))
+                        and x.is_cuda and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
+                    # last layer also emits |z|^2 per row for the standard-normal epilogue
+                    self._last_sqnorm = torch.empty(x.size(0), device=x.device)
+                    x, _ = flow._run(x, inverse, log_det, self._last_sqnorm, overwrite=fresh and i == 0)
+                elif isinstance(flow, _HipFlow) and (inverse is False or isinstance(flow, _TwoWayFlow)) \
+                        and _wants_grad(flow, x):
+                    x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
+                    log_det = log_det + ld
+                elif fresh and i == 0:
+                    x, _ = flow._run(x, inverse, log_det, overwrite=True)  # log_det = ld inside the kernel
+                elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):
+                    x, _ = flow._run(x, inverse, log_det)  # log_det += ld inside the kernel
+                else:
+                    x, ld = flow.inverse(x) if inverse else flow.forward(x)
+                    log_det += ld
+                seen.append(x)
             if timed:
                 e_next = torch.cuda.Event(enable_timing=True)
                 e_next.record()
-                self.layer_events.append((e_prev, e_next, i))
-                e_prev = e_next
-            seen.append(x)
+                self.layer_events.append((e_prev, e_next, i, span))
+            i += span
         return seen, log_det
 
     def forward(self, z: Tensor) -> tuple[list[Tensor], Tensor]:  # z -> x
