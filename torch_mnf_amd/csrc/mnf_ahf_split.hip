@@ -75,7 +75,7 @@ __device__ __forceinline__ void ahf_cond_guarded(const uint32_t* lds, const floa
 // ABL != 0 only in tools/split_microbench.hip (2 = no HBM traffic, 5 = no range guard, 6 = copy only,
 // 7 = no prefetch; 1 and 3: see split_conditioner); the library uses ABL = 0.
 template <int H, int HID, bool INV, int ABL = 0>
-__global__ void __launch_bounds__(kSplitWaves * 64)
+__global__ void __launch_bounds__(kSplitWaves * 64, H <= 32 ? 4 : 1)  // d <= 64: 4 waves/SIMD (<= 128 VGPRs)
 ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
                  float* __restrict__ ysq, const uint32_t* __restrict__ simage, const float* __restrict__ image_f32,
                  int64_t rows, int parity, int accumulate) {
@@ -286,7 +286,9 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
               for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = hi[t][g];
             }
         }
-        __builtin_amdgcn_s_barrier();
+        // (inline asm with a memory clobber, not __builtin_amdgcn_s_barrier(): the builtin is no compiler
+        // barrier for memory operations, and the next layer's first operand reads must not be hoisted above it)
+        asm volatile("s_barrier" ::: "memory");
       }
     }
 #pragma unroll

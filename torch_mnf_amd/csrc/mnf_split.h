@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mnf_ahf_shape.h"
 
 namespace mnf {
@@ -197,32 +199,74 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
       mnf::split_tile(v, hi, lo, m);
     }
   };
-  auto split_mac = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
-    if (ABL == 1) {
-      mn += __builtin_bit_cast(f32x4, ah) * __builtin_bit_cast(f32x4, bh);
-      cr += __builtin_bit_cast(f32x4, al) * __builtin_bit_cast(f32x4, bl);
-    } else {
-      mnf::split_mac(ah, al, bh, bl, mn, cr);
-    }
+  // the three products of every (output tile, row tile) pair, issued product by product: an accumulator's
+  // two dependent MFMAs (corr) are then NM * NTL - 1 independent MFMAs apart instead of back to back
+  auto split_mac_phased_impl = [&](auto nm_tag, const auto& ah, const auto& al, const f16x8 (&bh)[NTL],
+                                   const f16x8 (&bl)[NTL], auto& mn, auto& cr, auto used, int m0 = 0) {
+    constexpr int NM = decltype(nm_tag)::value;
+#pragma unroll
+    for (int phase = 0; phase < 3; ++phase)
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        if (used(m)) {
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) {
+            if (ABL == 1) {
+              if (phase == 0) mn[t][m0 + m] += __builtin_bit_cast(f32x4, ah[m]) * __builtin_bit_cast(f32x4, bh[t]);
+              if (phase == 1) cr[t][m0 + m] += __builtin_bit_cast(f32x4, al[m]) * __builtin_bit_cast(f32x4, bl[t]);
+            } else if (phase == 0) {
+              mn[t][m0 + m] = mfma_h(ah[m], bh[t], mn[t][m0 + m]);
+            } else if (phase == 1) {
+              cr[t][m0 + m] = mfma_h(ah[m], bl[t], cr[t][m0 + m]);
+            } else {
+              cr[t][m0 + m] = mfma_h(al[m], bh[t], cr[t][m0 + m]);
+            }
+          }
+        }
   };
+  // With two or more row tiles per wave there are registers to spare (the kernel runs at 2 waves/SIMD
+  // anyway): a layer's operands are then requested from LDS BEFORE the vector work on the previous layer's
+  // results and consumed after it, so the LDS latency is covered (left alone, hipcc sinks every ds_read to
+  // just in front of its MFMA to save registers and exposes ~100 cycles per operand).  sched_barrier(0)
+  // pins the three blocks [reads][vector work][MFMAs] in that order.
+  constexpr bool PRE = NTL >= 2;
+  auto fence = [] {
+    if (PRE) __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- layer 1
+  f16x8 a1h[KS1][NT], a1l[KS1][NT];
+  f32x4 bias1[NT];
+  auto read_layer1 = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        a1h[ks][m] = A8[64 * (2 * op)];
+        a1l[ks][m] = A8[64 * (2 * op + 1)];
+        ++op;
+      }
+#pragma unroll
+    for (int m = 0; m < NT; ++m) bias1[m] = B4[4 * (bt++)];
+  };
+  if (PRE) read_layer1();
+  fence();
   u32x2 xh[NTL][G], xl[NTL][G];
 #pragma unroll
   for (int t = 0; t < NTL; ++t)
 #pragma unroll
     for (int g = 0; g < G; ++g) split_tile(cnd[t][g], xh[t][g], xl[t][g], mx);
   after_split();
-
-  // ---- layer 1
+  fence();
+  if (!PRE) read_layer1();  // one tile per wave: reads stay next to their MFMAs (registers are what is scarce)
   f32x4 main[NTL][NT], corr[NTL][NT];
 #pragma unroll
-  for (int m = 0; m < NT; ++m) {
-    const f32x4 bias = B4[4 * (bt++)];
+  for (int m = 0; m < NT; ++m)
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
-      main[t][m] = bias;
+      main[t][m] = bias1[m];
       corr[t][m] = zero4;
     }
-  }
 #pragma unroll
   for (int ks = 0; ks < KS1; ++ks) {
     f16x8 bh[NTL], bl[NTL];
@@ -231,13 +275,8 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
       bh[t] = pair_operand(xh[t][2 * ks], 2 * ks + 1 < G ? xh[t][2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
       bl[t] = pair_operand(xl[t][2 * ks], 2 * ks + 1 < G ? xl[t][2 * ks + 1 < G ? 2 * ks + 1 : 0] : zero2);
     }
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], main[t][m], corr[t][m]);
-      ++op;
-    }
+    split_mac_phased_impl(std::integral_constant<int, NT>{}, a1h[ks], a1l[ks], bh, bl, main, corr,
+                          [](int) { return true; });
   }
   u32x2 hh[NTL][NT], hl[NTL][NT];
   auto activate = [&]() {
@@ -252,71 +291,112 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
         split_tile(v, hh[t][m], hl[t][m], mx);
       }
   };
-  activate();
+  auto hidden_operand = [&](const u32x2 (&h)[NTL][NT], int ks, f16x8 (&b)[NTL]) {
+    const int ta = S::ks_a(ks), tb = S::ks_b(ks);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) b[t] = pair_operand(h[t][ta], tb >= 0 ? h[t][tb >= 0 ? tb : 0] : zero2);
+  };
 
   // ---- hidden layers 2 and 3 (block diagonal)
 #pragma unroll
   for (int layer = 0; layer < 2; ++layer) {
+    f16x8 ah[NKS][NT], al[NKS][NT];
+    f32x4 bias[NT];
+    auto read_hidden = [&]() {
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const f32x4 bias = B4[4 * (bt++)];
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          if (S::uses(S::tile_nets(m), ks)) {
+            ah[ks][m] = A8[64 * (2 * op)];
+            al[ks][m] = A8[64 * (2 * op + 1)];
+            ++op;
+          }
+#pragma unroll
+      for (int m = 0; m < NT; ++m) bias[m] = B4[4 * (bt++)];
+    };
+    if (PRE) read_hidden();
+    fence();
+    activate();  // the previous layer's accumulators -> this layer's B operands
+    fence();
+    if (!PRE) read_hidden();
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
-        main[t][m] = bias;
+        main[t][m] = bias[m];
         corr[t][m] = zero4;
       }
-    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const int ta = S::ks_a(ks), tb = S::ks_b(ks);
       f16x8 bh[NTL], bl[NTL];
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        bh[t] = pair_operand(hh[t][ta], tb >= 0 ? hh[t][tb >= 0 ? tb : 0] : zero2);
-        bl[t] = pair_operand(hl[t][ta], tb >= 0 ? hl[t][tb >= 0 ? tb : 0] : zero2);
-      }
-#pragma unroll
-      for (int m = 0; m < NT; ++m)
-        if (S::uses(S::tile_nets(m), ks)) {
-          const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
-#pragma unroll
-          for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], main[t][m], corr[t][m]);
-          ++op;
-        }
+      hidden_operand(hh, ks, bh);
+      hidden_operand(hl, ks, bl);
+      split_mac_phased_impl(std::integral_constant<int, NT>{}, ah[ks], al[ks], bh, bl, main, corr,
+                            [ks](int m) { return S::uses(S::tile_nets(m), ks); });
     }
-    activate();
   }
 
-  // ---- output layer: s from the s-net units, t from the t-net units
+  // ---- output layer: s from the s-net units, t from the t-net units; output tiles in chunks of GC so that
+  // at d = 256 (G = 8) not all sixteen operands of a K-step are live at once
+  constexpr int GC = G < 4 ? G : 4;
+  static_assert(G % GC == 0, "output tiles come in whole chunks");
+  f16x8 aoh[2][NKS][G], aol[2][NKS][G];
+  f32x4 biaso[2][G];
+  auto read_bias_out = [&](int net) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) biaso[net][g] = B4[4 * (bt++)];
+  };
+  auto read_output = [&](int net, int ks, int g0) {
+#pragma unroll
+    for (int g = 0; g < GC; ++g) {
+      aoh[net][ks][g0 + g] = A8[64 * (2 * op)];
+      aol[net][ks][g0 + g] = A8[64 * (2 * op + 1)];
+      ++op;
+    }
+  };
+  if (PRE) {
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      read_bias_out(net);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        if (S::uses(1 << net, ks))
+#pragma unroll
+          for (int g0 = 0; g0 < G; g0 += GC) read_output(net, ks, g0);
+    }
+  }
+  fence();
+  activate();
+  fence();
 #pragma unroll
   for (int net = 0; net < 2; ++net) {
+    if (!PRE) read_bias_out(net);
     f32x4(&out)[NTL][G] = net ? t4 : s4;
     f32x4 oc[NTL][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const f32x4 bias = B4[4 * (bt++)];
+    for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
-        out[t][g] = bias;
+        out[t][g] = biaso[net][g];
         oc[t][g] = zero4;
       }
-    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       if (S::uses(1 << net, ks)) {
-        const int ta = S::ks_a(ks), tb = S::ks_b(ks);
         f16x8 bh[NTL], bl[NTL];
+        hidden_operand(hh, ks, bh);
+        hidden_operand(hl, ks, bl);
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-          bh[t] = pair_operand(hh[t][ta], tb >= 0 ? hh[t][tb >= 0 ? tb : 0] : zero2);
-          bl[t] = pair_operand(hl[t][ta], tb >= 0 ? hl[t][tb >= 0 ? tb : 0] : zero2);
-        }
+        for (int g0 = 0; g0 < G; g0 += GC) {
+          if (!PRE) read_output(net, ks, g0);
+          f16x8 ah[GC], al[GC];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const f16x8 ah = A8[64 * (2 * op)], al = A8[64 * (2 * op + 1)];
-#pragma unroll
-          for (int t = 0; t < NTL; ++t) split_mac(ah, al, bh[t], bl[t], out[t][g], oc[t][g]);
-          ++op;
+          for (int g = 0; g < GC; ++g) {
+            ah[g] = aoh[net][ks][g0 + g];
+            al[g] = aol[net][ks][g0 + g];
+          }
+          split_mac_phased_impl(std::integral_constant<int, GC>{}, ah, al, bh, bl, out, oc, [](int) { return true; }, g0);
         }
       }
 #pragma unroll
