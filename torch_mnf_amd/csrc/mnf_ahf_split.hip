@@ -49,13 +49,13 @@ __device__ __attribute__((noinline)) CondOut<H / 16> ahf_cond_f32_cold(const flo
 }
 
 // s, t for NTL tiles: split path, then the fp32 path if any operand was out of range
-template <int H, int HID, int NTL>
+template <int H, int HID, int NTL, typename Hook>
 __device__ __forceinline__ void ahf_cond_guarded(const uint32_t* lds, const float* image_f32, int lane, int q,
                                                  const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
-                                                 f32x4 (&t4)[NTL][H / 16]) {
+                                                 f32x4 (&t4)[NTL][H / 16], Hook at_stage) {
   using S = SplitShape<H, HID>;
   float mx = __builtin_bit_cast(float, lds[S::SPLIT_WORDS + S::PLAIN_WORDS]);  // max |weight|
-  split_conditioner<H, HID, NTL>(lds, lane, q, cnd, s4, t4, mx);
+  split_conditioner<H, HID, NTL, Hook>(lds, lane, q, cnd, s4, t4, mx, at_stage);
   if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
@@ -141,8 +141,8 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
     {
       using SS = SplitShape<H, HID>;
       float mx = __builtin_bit_cast(float, lds[SS::SPLIT_WORDS + SS::PLAIN_WORDS]);  // max |weight|
-      auto prefetch = [&]() {
-        if (ABL == 7) return;
+      auto prefetch = [&](int stage = 0) {
+        if (ABL == 7 || stage != 0) return;
 #pragma unroll
         for (int g = 0; g < G; ++g) cnd[g] = *reinterpret_cast<const f32x4*>(xn + cond_off + 16 * g);
       };
@@ -191,9 +191,6 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
 // mid != nullptr: the output of every layer but the last goes to mid[li] (application order): each
 // intermediate tensor is written once and never re-read.
 // ------------------------------------------------------------------------------------------------
-#ifndef MNF_STACK_SAME_SLOT
-#define MNF_STACK_SAME_SLOT 0  // experiment: every intermediate into slot 0 (store issue cost without HBM traffic)
-#endif
 constexpr int kStackWaves = 4;
 constexpr int kStackTiles = 2;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -258,37 +255,38 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
       const uint32_t* img = lds[li & 1];
       const float* f32img = images_f32 + (int64_t)layer * F32_FLOATS;
       f32x4 s4[NTL][G], t4[NTL][G];
+      // The rows as they stand at the top of this layer are the previous layer's output, i.e. intermediate
+      // tensor li - 1.  Its NTL * 2G stores are spread over the four stages of this layer's conditioner
+      // (the registers change only in the transform after it): issued as one burst in front of the layer
+      // barrier they held up both workgroups of the CU at the same moment.
+      auto store_previous = [&](int stage) {
+        if (mid == nullptr || li == 0) return;
+        constexpr int TOTAL = NTL * 2 * G, PER = (TOTAL + 3) / 4;
+#pragma unroll
+        for (int k = stage * PER; k < (stage + 1) * PER && k < TOTAL; ++k) {
+          const int t = k / (2 * G), half = (k / G) & 1, g = k % G;
+          if (live[t]) {
+            float* mr = mid + ((int64_t)(li - 1) * rows + rowc[t]) * dim + 4 * q + (half ? H : 0) + 16 * g;
+            *reinterpret_cast<f32x4*>(mr) = half ? hi[t][g] : lo[t][g];
+          }
+        }
+      };
       if ((parity_bits >> layer) & 1u) {  // conditioner = upper half
-        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, hi, s4, t4);
+        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, hi, s4, t4, store_previous);
 #pragma unroll
         for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], lo[t]);
       } else {
-        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, lo, s4, t4);
+        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, lo, s4, t4, store_previous);
 #pragma unroll
         for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], hi[t]);
       }
       if (li + 1 < n_layers) {
-        // End of layer.  The next image (LDS-DMA, issued before this layer's math) must have landed before
-        // the barrier; the intermediate stores need not have.  A counted wait cannot single out the DMA
-        // (loads and stores retire out of order with each other), so: drain BEFORE the stores -- all that is
-        // outstanding then is the DMA and the previous layer's stores, both issued a whole layer of math
-        // ago -- then store, and meet at a bare s_barrier (a __syncthreads() after the stores would put a
-        // vmcnt(0) behind them and expose one HBM write latency per layer).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (mid != nullptr) {
-#pragma unroll
-          for (int t = 0; t < NTL; ++t)
-            if (live[t]) {
-              float* mr = mid + ((int64_t)(MNF_STACK_SAME_SLOT ? 0 : li) * rows + rowc[t]) * dim + 4 * q;
-#pragma unroll
-              for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + 16 * g) = lo[t][g];
-#pragma unroll
-              for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = hi[t][g];
-            }
-        }
-        // (inline asm with a memory clobber, not __builtin_amdgcn_s_barrier(): the builtin is no compiler
-        // barrier for memory operations, and the next layer's first operand reads must not be hoisted above it)
-        asm volatile("s_barrier" ::: "memory");
+        // End of layer: the next image (LDS-DMA, issued before this layer's math) must have landed before the
+        // barrier.  vmcnt(0) also covers this layer's staged stores; the last of them was issued a quarter of
+        // a layer ago.  (Inline asm with a memory clobber, not __builtin_amdgcn_s_barrier(): the builtin is no
+        // compiler barrier for memory operations, and the next layer's first operand reads must not be
+        // hoisted above it.)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
 #pragma unroll

@@ -30,6 +30,10 @@
 
 #include "mnf_ahf_shape.h"
 
+#ifndef MNF_SPLIT_PRE_OUT
+#define MNF_SPLIT_PRE_OUT 0  // preloading the output-layer operands too spills at 256 VGPRs (measured: slower)
+#endif
+
 namespace mnf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -168,18 +172,19 @@ struct SplitShape {
 // lane (j, q) reg r <-> dim 16 g + 4 q + r) -> raw s and t of the same layout.  `img` points at the
 // LDS copy of the split image.  mx accumulates max|operand| (see kSplitLimit).
 struct NoHook {
-  __device__ __forceinline__ void operator()() const {}
+  __device__ __forceinline__ void operator()(int) const {}
 };
 
 // NTL row tiles (16 rows each) share every A-operand read: the weights come out of LDS once per NTL
 // tiles (LDS bandwidth, not the matrix pipe, is the co-bottleneck of the conditioner: 30 KB of operands
-// per tile per layer).  after_split() runs once cnd has been turned into MFMA operands (cnd is dead from
-// there on: the single-layer kernel issues its prefetch of the next tile there).
+// per tile per layer).  at_stage(0) runs once cnd has been turned into MFMA operands (cnd is dead from
+// there on: the single-layer kernel issues its prefetch of the next tile there); at_stage(1..3) after each
+// of the three activation blocks (the stack kernel spreads its intermediate-tensor stores over them).
 // ABL != 0 only in tools/split_microbench.hip (1 = MFMAs skipped, 3 = operand splitting skipped).
 template <int H, int HID, int NTL = 1, typename Hook = NoHook, int ABL = 0>
 __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane, int q,
                                                   const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
-                                                  f32x4 (&t4)[NTL][H / 16], float& mx, Hook after_split = Hook()) {
+                                                  f32x4 (&t4)[NTL][H / 16], float& mx, Hook at_stage = Hook()) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
   // opaque offsets: keep the (loop-invariant) operand reads inside the tile loop instead of in VGPRs
@@ -230,6 +235,7 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   // just in front of its MFMA to save registers and exposes ~100 cycles per operand).  sched_barrier(0)
   // pins the three blocks [reads][vector work][MFMAs] in that order.
   constexpr bool PRE = NTL >= 2;
+  constexpr bool PRE_OUT = PRE && MNF_SPLIT_PRE_OUT;  // output layer operands too
   auto fence = [] {
     if (PRE) __builtin_amdgcn_sched_barrier(0);
   };
@@ -256,7 +262,7 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   for (int t = 0; t < NTL; ++t)
 #pragma unroll
     for (int g = 0; g < G; ++g) split_tile(cnd[t][g], xh[t][g], xl[t][g], mx);
-  after_split();
+  at_stage(0);
   fence();
   if (!PRE) read_layer1();  // one tile per wave: reads stay next to their MFMAs (registers are what is scarce)
   f32x4 main[NTL][NT], corr[NTL][NT];
@@ -318,6 +324,7 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
     if (PRE) read_hidden();
     fence();
     activate();  // the previous layer's accumulators -> this layer's B operands
+    at_stage(1 + layer);
     fence();
     if (!PRE) read_hidden();
 #pragma unroll
@@ -355,7 +362,7 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
       ++op;
     }
   };
-  if (PRE) {
+  if (PRE_OUT) {
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
       read_bias_out(net);
@@ -368,10 +375,11 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   }
   fence();
   activate();
+  at_stage(3);
   fence();
 #pragma unroll
   for (int net = 0; net < 2; ++net) {
-    if (!PRE) read_bias_out(net);
+    if (!PRE_OUT) read_bias_out(net);
     f32x4(&out)[NTL][G] = net ? t4 : s4;
     f32x4 oc[NTL][G];
 #pragma unroll
@@ -389,7 +397,7 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
         hidden_operand(hl, ks, bl);
 #pragma unroll
         for (int g0 = 0; g0 < G; g0 += GC) {
-          if (!PRE) read_output(net, ks, g0);
+          if (!PRE_OUT) read_output(net, ks, g0);
           f16x8 ah[GC], al[GC];
 #pragma unroll
           for (int g = 0; g < GC; ++g) {
