@@ -450,7 +450,9 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.workload),
-                "kernel": ("nsf_cl kernel (inverse)" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"
+                "kernel": ("nsf_mfma_kernel<16,8,8,inverse,block> ([NSF_CL, Glow, ActNorm] inverse in one launch, both "
+                           "intermediates written)" if args.workload == "c3" and span_dom > 1 else
+                           "nsf_mfma_kernel<16,8,8,inverse>" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"
                            if args.workload == "c3f" else f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<32,24,inverse> (9 layers per launch)"
                            if args.workload == "c2f" else
                            f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<{dim // 2},24,inverse> ({span_dom} layers per launch, "

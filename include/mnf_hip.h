@@ -143,9 +143,14 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
  * row-independent log-det constant ld_const:
  *   forward:  y = NSF_CL(x @ A + b)            A = diag(e^s) W,      b = t @ W
  *   inverse:  y = NSF_CL^-1(x) @ A + b         A = W^-1 diag(e^-s),  b = -t e^-s
+ * mid1, mid2 (both NULL, or (rows, dim) buffers): the block's two intermediate tensors in application order,
+ * written once from registers and never re-read -- forward ActNorm(x) and Glow(ActNorm(x)), inverse
+ * NSF_CL^-1(x) and Glow^-1 of it; this is how NormalizingFlow runs the block as one launch while still
+ * returning every tensor.  They need scale_shift = [exp(s) (dim), t (dim)] of the ActNorm layer.
  * MNF_ERR_UNSUPPORTED when the shape has no fused kernel (callers run the three layers). */
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound,
+                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     int64_t rows, int dim, int K, float tail_bound,
                      int inverse, int n_hidden, const int* hidden_host, void* stream);
 int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden_host);

@@ -515,6 +515,26 @@ def test_run_fusion_in_mixed_stacks(amd):
     assert ld.requires_grad and zs[-1].requires_grad
 
 
+def test_spline_block_run_keeps_every_intermediate(amd, golden):
+    """[ActNorm, Glow, NSF_CL] blocks go out as one launch each that still writes both intermediates."""
+    fx = golden("g6_c3_stack")
+    model = build_c3(amd, fx)
+    runs = model._affine_runs()
+    assert sorted(runs) == [0, 3, 6] and all(type(r).__name__ == "_SplineBlockRun" for r in runs.values())
+    x = cuda(fx["x"])
+    with torch.no_grad():
+        for direction in ("inverse", "forward"):
+            model.fuse_affine_runs = True
+            zs_f, ld_f = getattr(model, direction)(x)
+            model.fuse_affine_runs = False
+            zs_u, ld_u = getattr(model, direction)(x)
+            assert len(zs_f) == len(zs_u) == 10
+            for i, (a, b) in enumerate(zip(zs_f, zs_u)):
+                assert_close(a, b, 3e-6, f"{direction} tensor {i}")
+            assert_close(ld_f, ld_u, 3e-6, f"{direction} log_det")
+    model.fuse_affine_runs = True
+
+
 def test_log_det_accumulates_in_layer_order(amd):
     """NormalizingFlow's fused `log_det += ld` equals summing the per-layer log-dets."""
     dim = 64

@@ -45,7 +45,8 @@ SIGNATURES = {
     "mnf_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_nsf_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
                            c_float, c_int, c_int, _intp, c_int, c_void_p]),
-    "mnf_nsf_cl_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int64, c_int,
+    "mnf_nsf_cl_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_int,
                                  c_int, c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_nsf_cl_flat_floats": (c_int64, [c_int, c_int, c_int, _intp]),
     "mnf_nsf_cl_image_floats": (c_int64, [c_int, c_int, c_int, _intp]),

@@ -293,12 +293,14 @@ template <int H, int NH, int K, bool INV, int AFF = 0>
 __global__ void __launch_bounds__(kNsfWaves * 64)
 nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
                 const float* __restrict__ image, int64_t rows, float T, int accumulate,
-                const float* __restrict__ aff_image, float ld_const) {
+                const float* __restrict__ aff_image, float ld_const, const float* __restrict__ scale_shift,
+                float* __restrict__ mid1, float* __restrict__ mid2) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int G = S_::G, dim = 2 * H;
   static_assert(G >= 1, "");
   constexpr int AFF_FLOATS = AFF ? dim * dim + dim : 0;
-  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS + AFF_FLOATS];
+  constexpr int SS_FLOATS = AFF ? 2 * dim : 0;  // ActNorm's exp(s) and t, for the block's intermediate tensors
+  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS + AFF_FLOATS + SS_FLOATS];
   {
     const float4* src = reinterpret_cast<const float4*>(image);
     float4* dst = reinterpret_cast<float4*>(lds);
@@ -307,6 +309,8 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       const float4* asrc = reinterpret_cast<const float4*>(aff_image);
       float4* adst = reinterpret_cast<float4*>(lds + S_::IMAGE_FLOATS);
       for (int i = threadIdx.x; i < AFF_FLOATS / 4; i += blockDim.x) adst[i] = asrc[i];
+      if (scale_shift)
+        for (int i = threadIdx.x; i < SS_FLOATS; i += blockDim.x) lds[S_::IMAGE_FLOATS + AFF_FLOATS + i] = scale_shift[i];
     }
   }
   __syncthreads();
@@ -328,7 +332,33 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 #pragma unroll
     for (int g = 0; g < G; ++g) up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
     float ld;
-    if (AFF == 1) affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+    // the block's two intermediate tensors (mid1, mid2 in application order), written once from registers:
+    //   forward: ActNorm(x) = x e^s + t elementwise, then the affine result = Glow(ActNorm(x))
+    //   inverse: NSF^-1(x), then Glow^-1 of it = (final) e^s + t elementwise from the affine result
+    const float* ss = lds + S_::IMAGE_FLOATS + AFF_FLOATS + 4 * q;
+    auto store_row = [&](float* base, const f32x4 (&a)[G], const f32x4 (&b)[G]) {
+      if (!live) return;
+      float* mr = base + rowc * dim + 4 * q;
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + 16 * g) = a[g];
+#pragma unroll
+      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = b[g];
+    };
+    auto store_actnorm_of = [&](float* base) {  // rows e^s + t
+      f32x4 a[G], b[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        a[g] = lo[g] * *reinterpret_cast<const f32x4*>(ss + 16 * g) + *reinterpret_cast<const f32x4*>(ss + dim + 16 * g);
+        b[g] = up[g] * *reinterpret_cast<const f32x4*>(ss + H + 16 * g) +
+               *reinterpret_cast<const f32x4*>(ss + dim + H + 16 * g);
+      }
+      store_row(base, a, b);
+    };
+    if (AFF == 1) {
+      if (mid1) store_actnorm_of(mid1);
+      affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+      if (mid2) store_row(mid2, lo, up);
+    }
     if (!INV) {  // f1(lower) moves upper, then f2(upper') moves lower (spline_flow.py:249-266)
       ld = nsf_half_step<H, NH, K, false>(f1, lane, q, lo, up, T);
       ld += nsf_half_step<H, NH, K, false>(f2, lane, q, up, lo, T);
@@ -336,7 +366,11 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       ld = nsf_half_step<H, NH, K, true>(f2, lane, q, up, lo, T);
       ld += nsf_half_step<H, NH, K, true>(f1, lane, q, lo, up, T);
     }
-    if (AFF == 2) affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+    if (AFF == 2) {
+      if (mid1) store_row(mid1, lo, up);
+      affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+      if (mid2) store_actnorm_of(mid2);
+    }
     if (live) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
@@ -415,7 +449,8 @@ static void build_index(int32_t* idx) {
 
 template <int H, int NH, int K>
 static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
-                  float T, int inverse, hipStream_t stream, const float* aff = nullptr, float ld_const = 0.f) {
+                  float T, int inverse, hipStream_t stream, const float* aff = nullptr, float ld_const = 0.f,
+                  const float* scale_shift = nullptr, float* mid1 = nullptr, float* mid2 = nullptr) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
   static const int resident = [] {
@@ -434,16 +469,16 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
   if (aff) {  // fused [ActNorm, Glow, NSF_CL] block
     if (inverse)
       hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true, 2>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                         accumulate, aff, ld_const);
+                         accumulate, aff, ld_const, scale_shift, mid1, mid2);
     else
       hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false, 1>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                         accumulate, aff, ld_const);
+                         accumulate, aff, ld_const, scale_shift, mid1, mid2);
   } else if (inverse) {
     hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                       accumulate, aff, 0.f);
+                       accumulate, aff, 0.f, nullptr, nullptr, nullptr);
   } else {
     hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                       accumulate, aff, 0.f);
+                       accumulate, aff, 0.f, nullptr, nullptr, nullptr);
   }
   return check_launch();
 }
@@ -476,16 +511,18 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
 }
 
 int nsf_fused_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound, int inverse,
-                     int n_hidden, const int* hidden, hipStream_t stream) {
+                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
+                     hipStream_t stream) {
   int nh = 0;
   if (!uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image) |
-       reinterpret_cast<uintptr_t>(aff)) & 15)
+       reinterpret_cast<uintptr_t>(aff) | reinterpret_cast<uintptr_t>(mid1) | reinterpret_cast<uintptr_t>(mid2)) & 15)
     return MNF_ERR_UNSUPPORTED;
 #define X(HH, NHH, KK) \
   if (dim == 2 * HH && nh == NHH && K == KK) \
-    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream, aff, ld_const);
+    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream, aff, ld_const, \
+                               scale_shift, mid1, mid2);
   MNF_NSF_FUSED_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -498,14 +535,16 @@ extern "C" {
 // Opt-in fused [ActNorm, Glow, NSF_CL] block: forward y = NSF(x @ A + b), inverse y = NSF^-1(x) @ A + b,
 // log_det = spline terms + ld_const.  aff = [dim*dim operand image of A (mnf_linear_rows_image_index)][dim bias].
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, int64_t rows, int dim, int K, float tail_bound,
-                     int inverse, int n_hidden, const int* hidden, void* stream) {
+                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
+                     void* stream) {
   if (!x || !y || x == y || !image || !aff || rows < 0 || dim < 2 || (dim & 1) || K < 2 || !(tail_bound > 0.f) ||
-      !mnf::hidden_ok(n_hidden, hidden))
+      !mnf::hidden_ok(n_hidden, hidden) || ((mid1 || mid2) && !scale_shift) || (mid1 && (mid1 == y || mid1 == x)) ||
+      (mid2 && (mid2 == y || mid2 == x || mid2 == mid1)))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, aff, ld_const, rows, dim, K, tail_bound, inverse,
-                               n_hidden, hidden, (hipStream_t)stream);
+  return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, aff, ld_const, scale_shift, mid1, mid2, rows, dim, K,
+                               tail_bound, inverse, n_hidden, hidden, (hipStream_t)stream);
 }
 
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden) {

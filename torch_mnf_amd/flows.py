@@ -707,41 +707,21 @@ class Glow(_TwoWayFlow):
         return y, ld
 
 
-class FusedSplineBlock(_TwoWayFlow):
-    """Opt-in fusion of the reference's ``[ActNormFlow, Glow, NSF_CL]`` block (readme.md:67-73) into one
-    kernel launch per direction.
+class _SplineBlockRun:
+    """One ``[ActNormFlow, Glow, NSF_CL]`` block (readme.md:67-73) as one ``mnf_nsf_cl_fused`` launch: ActNorm
+    and Glow are folded into one ``row @ A + b`` that the spline kernel applies to the rows while they are in
+    registers.  A plain object (not a Module): it caches the folded operand image per direction."""
 
-    The three sub-modules keep their parameters (``state_dict`` keys ``actnorm.*``, ``glow.*``,
-    ``nsf.*``); ActNorm and Glow are folded into one ``row @ A + b`` that the spline kernel applies
-    to the rows while they are in registers, so the block's two intermediate tensors are never
-    written -- which is exactly why this is an explicit opt-in and not what ``NormalizingFlow`` does
-    with the three separate modules.  Falls back to running the three modules in sequence when a
-    graph is being recorded, for ActNorm's data-dependent first ``inverse`` call, and for shapes
-    without a fused kernel."""
-
-    def __init__(self, actnorm: ActNormFlow, glow: Glow, nsf: NSF_CL) -> None:
-        super().__init__()
-        if not (actnorm.dim == glow.dim == nsf.dim):
-            raise ValueError("the three layers must share dim")
+    def __init__(self, actnorm: "ActNormFlow", glow: "Glow", nsf: "NSF_CL") -> None:
         self.actnorm, self.glow, self.nsf = actnorm, glow, nsf
         self.dim = nsf.dim
         self._aff_key = None
         self._aff: dict = {}
         self._lin_index: Tensor | None = None
-
-    def _packed_params(self) -> list[Tensor]:
-        return []
-
-    def _sequence(self, x: Tensor, inverse: bool):
-        order = (self.nsf, self.glow, self.actnorm) if inverse else (self.actnorm, self.glow, self.nsf)
-        ld = 0
-        for m in order:
-            x, l1 = m._run(x, inverse, None)
-            ld = ld + l1
-        return x, ld
+        self._unsupported = False
 
     def _affine(self, device, inverse: bool):
-        """(aff buffer = [operand image of A | b], log-det constant) for one direction, cached."""
+        """(aff buffer = [operand image of A | b], log-det constant, [exp(s) | t]) for one direction, cached."""
         an, gl = self.actnorm, self.glow
         key = (device, tuple((p.data_ptr(), p._version) for p in (an.s, an.t, gl.L, gl.S, gl.U)), id(gl.P))
         if key != self._aff_key:
@@ -769,34 +749,79 @@ class FusedSplineBlock(_TwoWayFlow):
             _lib.check("mnf_pack_gather", lib.mnf_pack_gather(
                 A.contiguous().data_ptr(), self._lin_index.data_ptr(), aff.data_ptr(), n, _stream()))
             aff[n:] = b
-            self._aff[inverse] = (aff, float(ldc))  # one host read per parameter update
+            scale_shift = torch.cat((torch.exp(s), t)).contiguous()
+            self._aff[inverse] = (aff, float(ldc), scale_shift)  # one host read per parameter update
         return self._aff[inverse]
 
-    def _run(self, x, inverse, accum):
-        nsf = self.nsf
+    def usable(self, x, inverse: bool) -> bool:
         needs_init = inverse and self.actnorm.data_dep_init_done is False
-        if (not isinstance(x, Tensor)) or (not x.is_cuda) or x.shape[0] == 0 or needs_init or any(
-                _wants_grad(m, x) for m in (self.actnorm, self.glow, nsf)):
-            y, ld = self._sequence(x, inverse)
-            if accum is not None:
-                accum += ld
-                return y, None
-            return y, ld
-        x = _device_input(x, "input")
-        if x.shape[1] != self.dim:
-            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        return (not self._unsupported and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+                and x.shape[1] == self.dim and not needs_init and not self.nsf.force_generic
+                and not self.glow.force_generic
+                and not any(_wants_grad(m, x) for m in (self.actnorm, self.glow, self.nsf)))
+
+    def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, keep: bool) -> list[Tensor] | None:
+        """Returns the output tensors in application order -- all three when ``keep`` (each written once from
+        registers, never re-read), else just the last -- or None when the shape has no fused kernel."""
+        nsf = self.nsf
         packed = self._affine(x.device, inverse)
         _, image = nsf._packed(x.device)
-        if packed is not None and image is not None:
-            aff, ldc = packed
-            y = torch.empty_like(x)
+        if packed is None or image is None:
+            self._unsupported = True
+            return None
+        aff, ldc, scale_shift = packed
+        x = _device_input(x, "input")
+        buf = torch.empty((3 if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        rc = _lib.load().mnf_nsf_cl_fused(
+            x.data_ptr(), buf[-1].data_ptr(), log_det.data_ptr(), int(accumulate), image.data_ptr(), aff.data_ptr(),
+            ldc, scale_shift.data_ptr(), buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
+            x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            self._unsupported = True
+            return None
+        _lib.check("mnf_nsf_cl_fused", rc)
+        return list(buf.unbind(0))
+
+
+class FusedSplineBlock(_TwoWayFlow):
+    """Opt-in fusion of the reference's ``[ActNormFlow, Glow, NSF_CL]`` block (readme.md:67-73) into one
+    kernel launch per direction that writes NO intermediate tensor.
+
+    The three sub-modules keep their parameters (``state_dict`` keys ``actnorm.*``, ``glow.*``,
+    ``nsf.*``).  As a member of a ``NormalizingFlow`` the block contributes one entry to the returned list
+    instead of three, which is why this is an explicit opt-in (``NormalizingFlow`` itself runs such a block
+    as one launch too, but still writes both intermediates).  Falls back to running the three modules in
+    sequence when a graph is being recorded, for ActNorm's data-dependent first ``inverse`` call, and for
+    shapes without a fused kernel."""
+
+    def __init__(self, actnorm: ActNormFlow, glow: Glow, nsf: NSF_CL) -> None:
+        super().__init__()
+        if not (actnorm.dim == glow.dim == nsf.dim):
+            raise ValueError("the three layers must share dim")
+        self.actnorm, self.glow, self.nsf = actnorm, glow, nsf
+        self.dim = nsf.dim
+        self.__dict__["_run_helper"] = _SplineBlockRun(actnorm, glow, nsf)
+
+    def _packed_params(self) -> list[Tensor]:
+        return []
+
+    def _sequence(self, x: Tensor, inverse: bool):
+        order = (self.nsf, self.glow, self.actnorm) if inverse else (self.actnorm, self.glow, self.nsf)
+        ld = 0
+        for m in order:
+            x, l1 = m._run(x, inverse, None)
+            ld = ld + l1
+        return x, ld
+
+    def _run(self, x, inverse, accum):
+        run = self._run_helper
+        if run.usable(x, inverse):
             ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-            rc = _lib.load().mnf_nsf_cl_fused(
-                x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), image.data_ptr(), aff.data_ptr(),
-                ldc, x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
-            if rc != _lib.MNF_ERR_UNSUPPORTED:
-                _lib.check("mnf_nsf_cl_fused", rc)
-                return y, (None if accum is not None else ld)
+            out = run.launch(x, inverse, ld, accum is not None, keep=False)
+            if out is not None:
+                return out[-1], (None if accum is not None else ld)
+        elif isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         y, ld = self._sequence(x, inverse)
         if accum is not None:
             accum += ld
@@ -930,8 +955,9 @@ class NormalizingFlow(nn.Module):
         self._last_sqnorm: Tensor | None = None
 
     def _affine_runs(self) -> dict:
-        """start index (model order) -> _AffineRun for every maximal run of >= 2 consecutive AffineHalfFlow
-        layers of one shape; rebuilt when the module list changes."""
+        """start index (model order) -> run object for every group of layers that goes out as one launch:
+        maximal runs of >= 2 consecutive AffineHalfFlow layers of one shape (_AffineRun) and
+        [ActNormFlow, Glow, NSF_CL] blocks (_SplineBlockRun); rebuilt when the module list changes."""
         ids = tuple(id(f) for f in self.flows)
         cache = self.__dict__.get("_runs_cache")
         if cache is None or cache[0] != ids:
@@ -943,6 +969,10 @@ class NormalizingFlow(nn.Module):
                         j += 1
                     if j - i >= 2:
                         runs[i] = _AffineRun(flows[i:j])
+                elif (i + 2 < len(flows) and type(flows[i]) is ActNormFlow and type(flows[i + 1]) is Glow
+                      and type(flows[i + 2]) is NSF_CL and flows[i].dim == flows[i + 1].dim == flows[i + 2].dim):
+                    runs[i] = _SplineBlockRun(flows[i], flows[i + 1], flows[i + 2])
+                    j = i + 3
                 i = j
             cache = (ids, runs)
             self.__dict__["_runs_cache"] = cache
@@ -953,7 +983,8 @@ class NormalizingFlow(nn.Module):
         order = list(reversed(self.flows)) if inverse else list(self.flows)
         runs = self._affine_runs() if self.fuse_affine_runs and not _NO_RUN_FUSION_ENV else {}
         # position in `order` -> run that starts there
-        run_at = {(n - (start + len(r.layers)) if inverse else start): r for start, r in runs.items()}
+        span_of = lambda r: len(r.layers) if isinstance(r, _AffineRun) else 3
+        run_at = {(n - (start + span_of(r)) if inverse else start): r for start, r in runs.items()}
         # a first layer whose kernel writes log_det for every row saves zero-filling it
         fresh = (bool(order) and isinstance(order[0], (AffineHalfFlow, FusedAffineStack)) and isinstance(x, Tensor)
                  and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and not _wants_grad(order[0], x))
@@ -968,9 +999,9 @@ class NormalizingFlow(nn.Module):
         while i < n:
             flow = order[i]
             run = run_at.get(i)
-            if run is not None and not run.usable(x):
+            if run is not None and not (run.usable(x) if isinstance(run, _AffineRun) else run.usable(x, inverse)):
                 run = None
-            span = len(run.layers) if run is not None else 1
+            span = span_of(run) if run is not None else 1
             last = i + span == n
             timed = events_on and (pick is None or pick == i)
             if timed:
@@ -979,8 +1010,12 @@ class NormalizingFlow(nn.Module):
             outs = None
             if run is not None:
                 # one launch for the whole run; every intermediate is written once and never re-read
-                sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
-                outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True)
+                if isinstance(run, _AffineRun):
+                    sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
+                    outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True)
+                else:
+                    sq = None
+                    outs = run.launch(x, inverse, log_det, True, keep=True)
                 if outs is not None:
                     self._last_sqnorm = sq
                     seen.extend(outs)
