@@ -133,7 +133,7 @@ int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t
 /* ------------------------------------------------------------------------ NSF_CL */
 /* f1, f2 = MLP(dim/2, n_h, n_h, n_h, (3K-1)*dim/2); `hidden` generalises (n_h,n_h,n_h). */
 int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
-               const float* flat, const float* image,
+               const float* flat, const float* image, const void* split_image,
                int64_t rows, int dim, int K, float tail_bound, int inverse,
                int n_hidden, const int* hidden_host, int force_generic, void* stream);
 /* Opt-in fusion of the reference's [ActNorm, Glow, NSF_CL] block into one kernel (SURVEY.md 8f
@@ -149,12 +149,19 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
  * returning every tensor.  They need scale_shift = [exp(s) (dim), t (dim)] of the ActNorm layer.
  * MNF_ERR_UNSUPPORTED when the shape has no fused kernel (callers run the three layers). */
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     const void* split_image, const float* aff, float ld_const, const float* scale_shift,
+                     float* mid1, float* mid2,
                      int64_t rows, int dim, int K, float tail_bound,
                      int inverse, int n_hidden, const int* hidden_host, void* stream);
 int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden_host);
 int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden_host, int32_t* idx_host);
+/* Split image (see mnf_affine_half_split_layout): with image AND split_image the conditioner nets run on
+ * v_mfma_f32_16x16x16_f16 in split fp32 arithmetic; a half step whose operands leave the f16 range is
+ * redone with fp32 MFMAs inside the same launch. */
+int mnf_nsf_cl_split_layout(int dim, int K, int n_hidden, const int* hidden_host, int64_t* n_split_words,
+                            int64_t* n_plain_words);
+int mnf_nsf_cl_split_index(int dim, int K, int n_hidden, const int* hidden_host, int32_t* idx_host);
 
 /* Elementwise unconstrained rational-quadratic spline: inputs (n,), W,H (n,K), D (n,K-1). */
 int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D,

@@ -95,7 +95,7 @@ def test_argument_checking_without_a_gpu(lib):
     p = ctypes.addressof(buf)
     assert lib.mnf_affine_half(p, p, None, 0, p, None, None, 4, 64, 0, 0, 3, hid, 1, 1, 0, None) == -1  # aliasing
     assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, None, 4, 63, 0, 0, 3, hid, 1, 1, 0, None) == -1  # odd dim
-    assert lib.mnf_nsf_cl(p, p + 512, None, 0, p, None, 4, 32, 2000, 3.0, 0, 3, hid, 0, None) == -5  # K too large
+    assert lib.mnf_nsf_cl(p, p + 512, None, 0, p, None, None, 4, 32, 2000, 3.0, 0, 3, hid, 0, None) == -5  # K too large
     assert lib.mnf_rqs(p, p, p, p, p, p, 4, 1001, 3.0, 0, None) == -5
     assert lib.mnf_affine_half(p, p + 512, None, 0, p, None, None, 0, 64, 0, 0, 3, hid, 1, 1, 0, None) == 0  # empty batch
 

@@ -515,6 +515,47 @@ def test_run_fusion_in_mixed_stacks(amd):
     assert ld.requires_grad and zs[-1].requires_grad
 
 
+@pytest.mark.parametrize("case", ["big_inputs", "big_weights", "one_big_row", "tiny_inputs"])
+def test_nsf_split_range_guard(amd, O, case):
+    """NSF_CL on the split path: a half step whose conditioner operands leave the f16 range is redone with
+    fp32 MFMAs in the same launch (inputs inside the tails still go through the spline)."""
+    dim, K, n_h, rows = 32, 8, 8, 555
+    sd = recipes.nsf_cl_params(150, dim, K, n_h)
+    x = recipes.gaussian(151, rows, dim)
+    if case == "big_inputs":      # far outside the tail bound: identity there, but the conditioner sees 1e5
+        x = x * 1.0e5
+        sd = {k: (v * 1e-5 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+    elif case == "big_weights":
+        sd = {k: (v * 1e5 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+        x = x * 1e-5
+    elif case == "one_big_row":
+        x = x.clone()
+        x[77] *= 3e4
+        x[400] *= 3e4
+        sd = {k: (v * 1e-3 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+    elif case == "tiny_inputs":
+        x = x * 1e-6
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    with torch.no_grad():
+        for inverse in (False, True):
+            ref_y, ref_ld = O.nsf_cl(x, sd, K, 3.0, inverse)
+            y, ld = (f.inverse if inverse else f.forward)(cuda(x))
+            select_kernel(f, "fp32")
+            y32, ld32 = (f.inverse if inverse else f.forward)(cuda(x))
+            select_kernel(f, "split")
+            ok = torch.isfinite(ref_y).all(1) & torch.isfinite(ref_ld)
+            assert torch.equal((torch.isfinite(y).all(1) & torch.isfinite(ld)).cpu(), ok)
+            # ill-conditioned on purpose (1e5-scale products feeding a spline): the yardstick is the fp32 MFMA
+            # kernel on the same inputs, which the guarded split path must reproduce, and the oracle loosely
+            tol32 = 1e-5 if case == "tiny_inputs" else 2e-6  # tiny: not guarded, 2^-36 absolute operand error
+            assert_close(y[ok.to(DEV)], y32[ok.to(DEV)], tol32, f"{case} y vs fp32 kernel")
+            assert_close(ld[ok.to(DEV)], ld32[ok.to(DEV)], tol32, f"{case} ld vs fp32 kernel")
+            assert_close(y[ok.to(DEV)], ref_y[ok], 2e-3 if case == "big_weights" else 2e-5, f"{case} y")
+            assert_close(ld[ok.to(DEV)], ref_ld[ok], 2e-3 if case == "big_weights" else 2e-5, f"{case} ld")
+
+
 def test_spline_block_run_keeps_every_intermediate(amd, golden):
     """[ActNorm, Glow, NSF_CL] blocks go out as one launch each that still writes both intermediates."""
     fx = golden("g6_c3_stack")
@@ -577,15 +618,16 @@ def test_rqs_all_outside_is_identity_and_too_many_bins_raises(amd):
 
 @pytest.mark.parametrize("cfg", [(32, 8, 8, 1.0), (32, 8, 16, 1.0), (2, 8, 16, 1.0), (6, 5, 8, 1.0),
                                  (32, 8, 8, 2.0), (2, 8, 16, 2.0)])
-@pytest.mark.parametrize("generic", [False, True])
-def test_g5_nsf_cl_layer(amd, golden, cfg, generic):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_g5_nsf_cl_layer(amd, golden, cfg, kernel):
     dim, K, n_h, gain = cfg
     fx = golden("g5_nsf_cl_layer")
     tag = f"d{dim}_K{K}_h{n_h}" + ("" if gain == 1.0 else "_stress")
     f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
     f.load_state_dict(recipes.nsf_cl_params(500 + dim + n_h, dim, K, n_h, gain=gain))
-    f = f.to(DEV)
-    f.force_generic = generic
+    f = select_kernel(f.to(DEV), kernel)
+    if dim == 32 and kernel != "generic":
+        assert (f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split")
     z = cuda(fx[f"{tag}.z"])
     for name, fn in (("fwd", f.forward), ("inv", f.inverse)):
         x, ld = fn(z)

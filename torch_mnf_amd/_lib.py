@@ -43,11 +43,13 @@ SIGNATURES = {
     "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
     "mnf_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "mnf_nsf_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int,
+    "mnf_nsf_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                            c_float, c_int, c_int, _intp, c_int, c_void_p]),
-    "mnf_nsf_cl_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+    "mnf_nsf_cl_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_int,
                                  c_int, c_float, c_int, c_int, _intp, c_void_p]),
+    "mnf_nsf_cl_split_layout": (c_int, [c_int, c_int, c_int, _intp, _i64p, _i64p]),
+    "mnf_nsf_cl_split_index": (c_int, [c_int, c_int, c_int, _intp, _i32p]),
     "mnf_nsf_cl_flat_floats": (c_int64, [c_int, c_int, c_int, _intp]),
     "mnf_nsf_cl_image_floats": (c_int64, [c_int, c_int, c_int, _intp]),
     "mnf_nsf_cl_image_index": (c_int, [c_int, c_int, c_int, _intp, _i32p]),

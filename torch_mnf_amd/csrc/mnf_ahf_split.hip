@@ -54,7 +54,7 @@ __device__ __forceinline__ void ahf_cond_guarded(const uint32_t* lds, const floa
                                                  const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
                                                  f32x4 (&t4)[NTL][H / 16], Hook at_stage) {
   using S = SplitShape<H, HID>;
-  float mx = __builtin_bit_cast(float, lds[S::SPLIT_WORDS + S::PLAIN_WORDS]);  // max |weight|
+  float mx = split_guard_seed(__builtin_bit_cast(float, lds[S::SPLIT_WORDS + S::PLAIN_WORDS]));  // max |weight|
   split_conditioner<H, HID, NTL, Hook>(lds, lane, q, cnd, s4, t4, mx, at_stage);
   if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {
 #pragma unroll
@@ -140,7 +140,7 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
     f32x4 s4[1][G], t4[1][G];
     {
       using SS = SplitShape<H, HID>;
-      float mx = __builtin_bit_cast(float, lds[SS::SPLIT_WORDS + SS::PLAIN_WORDS]);  // max |weight|
+      float mx = split_guard_seed(__builtin_bit_cast(float, lds[SS::SPLIT_WORDS + SS::PLAIN_WORDS]));  // max |weight|
       auto prefetch = [&](int stage = 0) {
         if (ABL == 7 || stage != 0) return;
 #pragma unroll

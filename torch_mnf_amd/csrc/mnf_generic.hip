@@ -689,15 +689,15 @@ int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden) 
 }
 
 int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const float* flat,
-               const float* image, int64_t rows, int dim, int K, float tail_bound, int inverse,
-               int n_hidden, const int* hidden, int force_generic, void* stream) {
+               const float* image, const void* split_image, int64_t rows, int dim, int K, float tail_bound,
+               int inverse, int n_hidden, const int* hidden, int force_generic, void* stream) {
   if (!x || !y || x == y || rows < 0 || dim < 2 || (dim & 1) || K < 1 || !(tail_bound > 0.f) ||
       !hidden_ok(n_hidden, hidden) || (!flat && !image))
     return MNF_ERR_INVALID_ARG;
   if (1e-3 * K > 1.0) return MNF_ERR_DOMAIN;  // spline_flow.py:90-93
   if (rows == 0) return MNF_OK;
   if (image && !force_generic) {
-    const int rc = nsf_mfma_launch(x, y, log_det, accumulate, image, rows, dim, K, tail_bound, inverse,
+    const int rc = nsf_mfma_launch(x, y, log_det, accumulate, image, split_image, rows, dim, K, tail_bound, inverse,
                                    n_hidden, hidden, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }

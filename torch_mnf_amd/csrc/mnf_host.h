@@ -45,8 +45,8 @@ int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
                            int64_t rows, int dim, int inverse, int hid, hipStream_t stream);
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                    int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
-                    const int* hidden, hipStream_t stream);
+                    const void* split_image, int64_t rows, int dim, int K, float tail_bound, int inverse,
+                    int n_hidden, const int* hidden, hipStream_t stream);
 // mask == nullptr: the mask is generated in-kernel from `seed`
 // split_image != nullptr: the split (f16 hi + lo) kernel, with `image` behind it for out-of-range groups
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,

@@ -20,10 +20,9 @@
 
 #include "mnf_device.h"
 #include "mnf_host.h"
+#include "mnf_split.h"
 
 namespace mnf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int H, int NH, int K>
 struct NsfShape {
@@ -254,6 +253,166 @@ __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, i
   return lad_sum;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The conditioner in split (hi + lo) fp32 arithmetic on v_mfma_f32_16x16x16_f16 (mnf_split.h; K = 16
+// covers the hidden widths 8 and 16 without the 4x zero padding a K = 32 step would carry in LDS):
+// 81 f16 MFMAs per half step at (16, 8, 8) instead of 64 fp32 MFMAs that cost 32 non-overlapping cycles
+// each.  Same tiling as the fp32 version (slot s / parameter block kb output tiles), hidden unit u of
+// tile m in accumulator row u - 16 m.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int NH, int K>
+struct NsfSplitShape {
+  using F = NsfShape<H, NH, K>;
+  static constexpr int G = H / 16;
+  static constexpr int NTH = (NH + 15) / 16;
+  static constexpr int NB = F::NB, S = F::S, P = F::P;
+  static constexpr int N_OPS = G * NTH + 2 * NTH * NTH + S * NTH * NB;
+  static constexpr int OP_WORDS = 256;                       // [hi: 64 lanes x 2 words][lo: 64 lanes x 2 words]
+  static constexpr int SPLIT_WORDS_NET = N_OPS * OP_WORDS;
+  static constexpr int BIAS_TILES = 3 * NTH + S * NB;
+  static constexpr int PLAIN_WORDS_NET = BIAS_TILES * 16;
+  // image: [f1 operands][f2 operands][f1 biases][f2 biases][tail]
+  static constexpr int SPLIT_WORDS = 2 * SPLIT_WORDS_NET;
+  static constexpr int PLAIN_WORDS = 2 * PLAIN_WORDS_NET;
+  static constexpr int IMAGE_WORDS = SPLIT_WORDS + PLAIN_WORDS + kSplitTailWords;
+};
+
+__device__ __forceinline__ f32x4 mfma_h16(const u32x2& a, const u32x2& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+
+// ops: this net's operand words (in LDS), bias: this net's bias tiles (in LDS); mx: max |operand| so far
+template <int H, int NH, int K, bool INV>
+__device__ __forceinline__ float nsf_half_step_split(const uint32_t* ops, const float* bias, int lane, int q,
+                                                     const f32x4 (&cond)[H / 16], f32x4 (&act)[H / 16], float T,
+                                                     float& mx) {
+  using S_ = NsfSplitShape<H, NH, K>;
+  constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S;
+  int a_off = lane * 2, b_off = q * 4;
+  asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop
+  const u32x2* A2 = reinterpret_cast<const u32x2*>(ops + a_off);   // + 64 * (2 op + part)
+  const f32x4* B4 = reinterpret_cast<const f32x4*>(bias + b_off);  // + 4 * tile
+  int op = 0, bt = 0;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mac = [&](const u32x2& bh, const u32x2& bl, f32x4& main, f32x4& corr) {
+    const u32x2 ah = A2[64 * (2 * op)], al = A2[64 * (2 * op + 1)];
+    main = mfma_h16(ah, bh, main);
+    corr = mfma_h16(ah, bl, corr);
+    corr = mfma_h16(al, bh, corr);
+    ++op;
+  };
+  u32x2 xh[G], xl[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) split_tile(cond[g], xh[g], xl[g], mx);
+  f32x4 main[NTH], corr[NTH];
+  u32x2 hh[NTH], hl[NTH];
+  auto activate = [&]() {
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) {
+      const f32x4 p = corr[m] * kSplitInvScale + main[m];
+      split_tile(__builtin_elementwise_max(p, p * kLeakySlope), hh[m], hl[m], mx);
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < NTH; ++m) {
+    main[m] = B4[4 * (bt++)];
+    corr[m] = zero4;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) mac(xh[g], xl[g], main[m], corr[m]);
+  activate();
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+    u32x2 ph[NTH], pl[NTH];
+#pragma unroll
+    for (int m = 0; m < NTH; ++m) {
+      ph[m] = hh[m];
+      pl[m] = hl[m];
+      main[m] = B4[4 * (bt++)];
+      corr[m] = zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NTH; ++ks)
+#pragma unroll
+      for (int m = 0; m < NTH; ++m) mac(ph[ks], pl[ks], main[m], corr[m]);
+    activate();
+  }
+  float lad_sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    f32x4 prm[NB], prc[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      prm[kb] = B4[4 * (bt++)];
+      prc[kb] = zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NTH; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) mac(hh[ks], hl[ks], prm[kb], prc[kb]);
+    float p[4 * NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const f32x4 v = prc[kb] * kSplitInvScale + prm[kb];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[4 * kb + r] = v[r];
+    }
+    float o, l;
+    rqs_regs<K, INV, 4 * NB>(act[s >> 2][s & 3], T, p, o, l);
+    act[s >> 2][s & 3] = o;
+    lad_sum += l;
+  }
+  return lad_sum;
+}
+
+// fp32 half step from the fp32 image in global memory, out of line: the range-guard path of the split kernel
+template <int G>
+struct HalfStepIO {
+  f32x4 act[G];
+  float lad;
+};
+template <int H, int NH, int K, bool INV>
+__device__ __attribute__((noinline)) HalfStepIO<H / 16> nsf_half_step_cold(const float* net_f32, int lane, int q,
+                                                                          HalfStepIO<H / 16> cond_in,
+                                                                          HalfStepIO<H / 16> act_in, float T) {
+  HalfStepIO<H / 16> out = act_in;
+  out.lad = nsf_half_step<H, NH, K, INV>(net_f32, lane, q, cond_in.act, out.act, T);
+  return out;
+}
+
+// one guarded half step: split path on a copy, redone in fp32 if an operand left the f16 range
+template <int H, int NH, int K, bool INV>
+__device__ __forceinline__ float nsf_half_step_guarded(const uint32_t* ops, const float* bias, const float* net_f32,
+                                                       float wmax, int lane, int q, const f32x4 (&cond)[H / 16],
+                                                       f32x4 (&act)[H / 16], float T) {
+  constexpr int G = H / 16;
+  f32x4 trial[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) trial[g] = act[g];
+  float mx = split_guard_seed(wmax);
+  float lad = nsf_half_step_split<H, NH, K, INV>(ops, bias, lane, q, cond, trial, T, mx);
+  if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {
+    HalfStepIO<G> c, a;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      c.act[g] = cond[g];
+      a.act[g] = act[g];
+    }
+    c.lad = a.lad = 0.f;
+    const HalfStepIO<G> r = nsf_half_step_cold<H, NH, K, INV>(net_f32, lane, q, c, a, T);
+#pragma unroll
+    for (int g = 0; g < G; ++g) trial[g] = r.act[g];
+    lad = r.lad;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) act[g] = trial[g];
+  return lad;
+}
+
 // row <- row @ A + b for the whole (lower | upper) row held as float4s, on the same MFMA scheme as
 // mnf_linear_mfma.hip: `aff` = [D*D operand image][D bias], D = 2H.
 template <int H>
@@ -289,10 +448,13 @@ __device__ __forceinline__ void affine_rows(const float* aff, int lane, int q, f
 // 8f rank 3): 1 = the affine map runs before the spline steps (forward: z e^s + t, then @ W),
 // 2 = after them (inverse: @ W^-1, then (. - t) e^-s); both collapse to one  row @ A + b  and a
 // row-independent log-det constant.  The block's two intermediate tensors are never written.
-template <int H, int NH, int K, bool INV, int AFF = 0>
+// SPLIT: the conditioner on f16 MFMAs in split arithmetic (`simage`), with `image` (fp32, read from global
+// memory) behind it for tiles whose operands leave the f16 range.
+template <int H, int NH, int K, bool INV, int AFF = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(kNsfWaves * 64)
 nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
-                const float* __restrict__ image, int64_t rows, float T, int accumulate,
+                const float* __restrict__ image, const uint32_t* __restrict__ simage, int64_t rows, float T,
+                int accumulate,
                 const float* __restrict__ aff_image, float ld_const, const float* __restrict__ scale_shift,
                 float* __restrict__ mid1, float* __restrict__ mid2) {
   using S_ = NsfShape<H, NH, K>;
@@ -300,17 +462,19 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   static_assert(G >= 1, "");
   constexpr int AFF_FLOATS = AFF ? dim * dim + dim : 0;
   constexpr int SS_FLOATS = AFF ? 2 * dim : 0;  // ActNorm's exp(s) and t, for the block's intermediate tensors
-  __shared__ __attribute__((aligned(16))) float lds[S_::IMAGE_FLOATS + AFF_FLOATS + SS_FLOATS];
+  using SS_ = NsfSplitShape<H, NH, K>;
+  constexpr int NET_IMAGE = SPLIT ? SS_::IMAGE_WORDS : S_::IMAGE_FLOATS;  // words of LDS for the conditioner nets
+  __shared__ __attribute__((aligned(16))) float lds[NET_IMAGE + AFF_FLOATS + SS_FLOATS];
   {
-    const float4* src = reinterpret_cast<const float4*>(image);
+    const float4* src = SPLIT ? reinterpret_cast<const float4*>(simage) : reinterpret_cast<const float4*>(image);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < S_::IMAGE_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < NET_IMAGE / 4; i += blockDim.x) dst[i] = src[i];
     if (AFF) {
       const float4* asrc = reinterpret_cast<const float4*>(aff_image);
-      float4* adst = reinterpret_cast<float4*>(lds + S_::IMAGE_FLOATS);
+      float4* adst = reinterpret_cast<float4*>(lds + NET_IMAGE);
       for (int i = threadIdx.x; i < AFF_FLOATS / 4; i += blockDim.x) adst[i] = asrc[i];
       if (scale_shift)
-        for (int i = threadIdx.x; i < SS_FLOATS; i += blockDim.x) lds[S_::IMAGE_FLOATS + AFF_FLOATS + i] = scale_shift[i];
+        for (int i = threadIdx.x; i < SS_FLOATS; i += blockDim.x) lds[NET_IMAGE + AFF_FLOATS + i] = scale_shift[i];
     }
   }
   __syncthreads();
@@ -318,6 +482,18 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   const int j = lane & 15, q = lane >> 4;
   const float* f1 = lds;
   const float* f2 = lds + S_::NET_FLOATS;
+  // split image: [f1 operands][f2 operands][f1 biases][f2 biases][tail: max |weight|]
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(lds);
+  const float wmax = SPLIT ? lds[SS_::SPLIT_WORDS + SS_::PLAIN_WORDS] : 0.f;
+  auto half_step = [&](auto inv_tag, int net, const f32x4 (&cond)[G], f32x4 (&act)[G]) -> float {
+    constexpr bool kInv = decltype(inv_tag)::value;
+    if constexpr (SPLIT)
+      return nsf_half_step_guarded<H, NH, K, kInv>(sw + net * SS_::SPLIT_WORDS_NET,
+                                                   lds + SS_::SPLIT_WORDS + net * SS_::PLAIN_WORDS_NET,
+                                                   image + net * S_::NET_FLOATS, wmax, lane, q, cond, act, T);
+    else
+      return nsf_half_step<H, NH, K, kInv>(net ? f2 : f1, lane, q, cond, act, T);
+  };
 
   const int n_tiles = (int)((rows + 15) >> 4);
   for (int tile = (int)blockIdx.x * kNsfWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kNsfWaves) {
@@ -335,7 +511,7 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     // the block's two intermediate tensors (mid1, mid2 in application order), written once from registers:
     //   forward: ActNorm(x) = x e^s + t elementwise, then the affine result = Glow(ActNorm(x))
     //   inverse: NSF^-1(x), then Glow^-1 of it = (final) e^s + t elementwise from the affine result
-    const float* ss = lds + S_::IMAGE_FLOATS + AFF_FLOATS + 4 * q;
+    const float* ss = lds + NET_IMAGE + AFF_FLOATS + 4 * q;
     auto store_row = [&](float* base, const f32x4 (&a)[G], const f32x4 (&b)[G]) {
       if (!live) return;
       float* mr = base + rowc * dim + 4 * q;
@@ -356,19 +532,19 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     };
     if (AFF == 1) {
       if (mid1) store_actnorm_of(mid1);
-      affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+      affine_rows<H>(lds + NET_IMAGE, lane, q, lo, up);
       if (mid2) store_row(mid2, lo, up);
     }
     if (!INV) {  // f1(lower) moves upper, then f2(upper') moves lower (spline_flow.py:249-266)
-      ld = nsf_half_step<H, NH, K, false>(f1, lane, q, lo, up, T);
-      ld += nsf_half_step<H, NH, K, false>(f2, lane, q, up, lo, T);
+      ld = half_step(std::false_type{}, 0, lo, up);
+      ld += half_step(std::false_type{}, 1, up, lo);
     } else {     // (:268-285)
-      ld = nsf_half_step<H, NH, K, true>(f2, lane, q, up, lo, T);
-      ld += nsf_half_step<H, NH, K, true>(f1, lane, q, lo, up, T);
+      ld = half_step(std::true_type{}, 1, up, lo);
+      ld += half_step(std::true_type{}, 0, lo, up);
     }
     if (AFF == 2) {
       if (mid1) store_row(mid1, lo, up);
-      affine_rows<H>(lds + S_::IMAGE_FLOATS, lane, q, lo, up);
+      affine_rows<H>(lds + NET_IMAGE, lane, q, lo, up);
       if (mid2) store_actnorm_of(mid2);
     }
     if (live) {
@@ -447,39 +623,111 @@ static void build_index(int32_t* idx) {
   }
 }
 
+// 2 entries per split word (low half, high half), then 1 entry per plain (bias) word -- mnf_pack_gather_split
 template <int H, int NH, int K>
-static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
-                  float T, int inverse, hipStream_t stream, const float* aff = nullptr, float ld_const = 0.f,
-                  const float* scale_shift = nullptr, float* mid1 = nullptr, float* mid2 = nullptr) {
+static void build_split_index(int32_t* idx) {
+  using S_ = NsfSplitShape<H, NH, K>;
+  constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
+  int sizes[5] = {H, NH, NH, NH, P * H};
+  NetDesc net[2];
+  int64_t off = fill_net(net[0], 5, sizes, 0);
+  fill_net(net[1], 5, sizes, off);
+  const int64_t n_entries = 2 * (int64_t)S_::SPLIT_WORDS + S_::PLAIN_WORDS;
+  for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
+  for (int nn = 0; nn < 2; ++nn) {
+    int op = 0, bt = 0;
+    int32_t* B = idx + 2 * (int64_t)S_::SPLIT_WORDS + (int64_t)nn * S_::PLAIN_WORDS_NET;
+    // element e (0..3) of lane (i, kq) of operand op: weight(row i of the output tile, input slot 4 kq + e)
+    auto put = [&](int lane, int e, int32_t src) {
+      for (int part = 0; part < 2; ++part)
+        idx[2 * ((int64_t)nn * S_::SPLIT_WORDS_NET) +
+            (((int64_t)(2 * op + part) * 64 + lane) * 2 + (e >> 1)) * 2 + (e & 1)] = src | (part ? kSplitLoBit : 0);
+    };
+    for (int m = 0; m < NTH; ++m, ++bt)
+      for (int i = 0; i < 16; ++i)
+        if (16 * m + i < NH) B[bt * 16 + i] = net[nn].b_off[0] + 16 * m + i;
+    for (int g = 0; g < G; ++g)
+      for (int m = 0; m < NTH; ++m, ++op)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+          if (u >= NH) continue;
+          for (int e = 0; e < 4; ++e) put(lane, e, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
+        }
+    for (int l = 1; l <= 2; ++l) {
+      for (int m = 0; m < NTH; ++m, ++bt)
+        for (int i = 0; i < 16; ++i)
+          if (16 * m + i < NH) B[bt * 16 + i] = net[nn].b_off[l] + 16 * m + i;
+      for (int ks = 0; ks < NTH; ++ks)
+        for (int m = 0; m < NTH; ++m, ++op)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+            if (u >= NH) continue;
+            for (int e = 0; e < 4; ++e) {
+              const int ui = 16 * ks + 4 * kq + e;
+              if (ui < NH) put(lane, e, net[nn].w_off[l] + u * NH + ui);
+            }
+          }
+    }
+    for (int s = 0; s < SL; ++s) {
+      // accumulator row i = 4 q' + r of tile (s, kb): element 16 (s/4) + 4 q' + (s%4), parameter 4 kb + r
+      auto out_of = [&](int kb, int i) {
+        const int elem = 16 * (s >> 2) + 4 * (i >> 2) + (s & 3), prm = 4 * kb + (i & 3);
+        return prm < P ? elem * P + prm : -1;
+      };
+      for (int kb = 0; kb < NB; ++kb, ++bt)
+        for (int i = 0; i < 16; ++i)
+          if (out_of(kb, i) >= 0) B[bt * 16 + i] = net[nn].b_off[3] + out_of(kb, i);
+      for (int ks = 0; ks < NTH; ++ks)
+        for (int kb = 0; kb < NB; ++kb, ++op)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, o = out_of(kb, i);
+            if (o < 0) continue;
+            for (int e = 0; e < 4; ++e) {
+              const int ui = 16 * ks + 4 * kq + e;
+              if (ui < NH) put(lane, e, net[nn].w_off[3] + o * NH + ui);
+            }
+          }
+    }
+  }
+}
+
+template <int H, int NH, int K>
+static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                  const uint32_t* simage, int64_t rows, float T, int inverse, hipStream_t stream,
+                  const float* aff = nullptr, float ld_const = 0.f, const float* scale_shift = nullptr,
+                  float* mid1 = nullptr, float* mid2 = nullptr) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
-  static const int resident = [] {
+  auto resident_of = [](auto kernel) {
     int per_cu = 0, cus = 256, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsf_mfma_kernel<H, NH, K, true>, kNsfWaves * 64,
-                                                     0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kNsfWaves * 64, 0) != hipSuccess || per_cu < 1)
       per_cu = 2;
     if (const char* e = getenv("MNF_NSF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // experiment switch
     return per_cu * cus;
-  }();
+  };
+  static const int resident_f32 = resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>);
+  static const int resident_split = resident_of(nsf_mfma_kernel<H, NH, K, true, 2, true>);
+  const int resident = simage ? resident_split : resident_f32;
   if (blocks > resident) blocks = resident;
   const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
-  if (aff) {  // fused [ActNorm, Glow, NSF_CL] block
-    if (inverse)
-      hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true, 2>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                         accumulate, aff, ld_const, scale_shift, mid1, mid2);
-    else
-      hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false, 1>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                         accumulate, aff, ld_const, scale_shift, mid1, mid2);
-  } else if (inverse) {
-    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, true>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                       accumulate, aff, 0.f, nullptr, nullptr, nullptr);
+#define MNF_NSF_LAUNCH(INVV, AFFV, SPL)                                                                          \
+  hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, INVV, AFFV, SPL>), grid, block, 0, stream, x, y, log_det, image, \
+                     simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2)
+  if (simage) {
+    if (aff) {
+      if (inverse) MNF_NSF_LAUNCH(true, 2, true); else MNF_NSF_LAUNCH(false, 1, true);
+    } else {
+      if (inverse) MNF_NSF_LAUNCH(true, 0, true); else MNF_NSF_LAUNCH(false, 0, true);
+    }
+  } else if (aff) {  // fused [ActNorm, Glow, NSF_CL] block
+    if (inverse) MNF_NSF_LAUNCH(true, 2, false); else MNF_NSF_LAUNCH(false, 1, false);
   } else {
-    hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, false>), grid, block, 0, stream, x, y, log_det, image, rows, T,
-                       accumulate, aff, 0.f, nullptr, nullptr, nullptr);
+    if (inverse) MNF_NSF_LAUNCH(true, 0, false); else MNF_NSF_LAUNCH(false, 0, false);
   }
+#undef MNF_NSF_LAUNCH
   return check_launch();
 }
 
@@ -495,34 +743,38 @@ static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
   return hidden[1] == nh && hidden[2] == nh;
 }
 
-int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image, int64_t rows,
-                    int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
-                    hipStream_t stream) {
+int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
+                    const void* split_image, int64_t rows, int dim, int K, float tail_bound, int inverse,
+                    int n_hidden, const int* hidden, hipStream_t stream) {
   int nh = 0;
   if (!uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image)) & 15)
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image) |
+       reinterpret_cast<uintptr_t>(split_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
 #define X(HH, NHH, KK) \
   if (dim == 2 * HH && nh == NHH && K == KK) \
-    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream);
+    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, static_cast<const uint32_t*>(split_image), rows, \
+                               tail_bound, inverse != 0, stream);
   MNF_NSF_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
 }
 
 int nsf_fused_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     const void* split_image, const float* aff, float ld_const, const float* scale_shift,
+                     float* mid1, float* mid2,
                      int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
                      hipStream_t stream) {
   int nh = 0;
   if (!uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image) |
-       reinterpret_cast<uintptr_t>(aff) | reinterpret_cast<uintptr_t>(mid1) | reinterpret_cast<uintptr_t>(mid2)) & 15)
+       reinterpret_cast<uintptr_t>(aff) | reinterpret_cast<uintptr_t>(mid1) | reinterpret_cast<uintptr_t>(mid2) |
+       reinterpret_cast<uintptr_t>(split_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
 #define X(HH, NHH, KK) \
   if (dim == 2 * HH && nh == NHH && K == KK) \
-    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, rows, tail_bound, inverse != 0, stream, aff, ld_const, \
-                               scale_shift, mid1, mid2);
+    return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, static_cast<const uint32_t*>(split_image), rows, \
+                               tail_bound, inverse != 0, stream, aff, ld_const, scale_shift, mid1, mid2);
   MNF_NSF_FUSED_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -535,7 +787,8 @@ extern "C" {
 // Opt-in fused [ActNorm, Glow, NSF_CL] block: forward y = NSF(x @ A + b), inverse y = NSF^-1(x) @ A + b,
 // log_det = spline terms + ld_const.  aff = [dim*dim operand image of A (mnf_linear_rows_image_index)][dim bias].
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
-                     const float* aff, float ld_const, const float* scale_shift, float* mid1, float* mid2,
+                     const void* split_image, const float* aff, float ld_const, const float* scale_shift,
+                     float* mid1, float* mid2,
                      int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
                      void* stream) {
   if (!x || !y || x == y || !image || !aff || rows < 0 || dim < 2 || (dim & 1) || K < 2 || !(tail_bound > 0.f) ||
@@ -543,8 +796,39 @@ int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, c
       (mid2 && (mid2 == y || mid2 == x || mid2 == mid1)))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, aff, ld_const, scale_shift, mid1, mid2, rows, dim, K,
+  return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, split_image, aff, ld_const, scale_shift, mid1, mid2,
+                               rows, dim, K,
                                tail_bound, inverse, n_hidden, hidden, (hipStream_t)stream);
+}
+
+int mnf_nsf_cl_split_layout(int dim, int K, int n_hidden, const int* hidden, int64_t* n_split_words,
+                            int64_t* n_plain_words) {
+  int nh = 0;
+  if (!n_split_words || !n_plain_words || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+#define X(HH, NHH, KK)                                                   \
+  if (dim == 2 * HH && nh == NHH && K == KK) {                           \
+    *n_split_words = mnf::NsfSplitShape<HH, NHH, KK>::SPLIT_WORDS;       \
+    *n_plain_words = mnf::NsfSplitShape<HH, NHH, KK>::PLAIN_WORDS;       \
+    return MNF_OK;                                                       \
+  }
+  MNF_NSF_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_nsf_cl_split_index(int dim, int K, int n_hidden, const int* hidden, int32_t* idx_host) {
+  int nh = 0;
+  if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+#define X(HH, NHH, KK)                                     \
+  if (dim == 2 * HH && nh == NHH && K == KK) {             \
+    mnf::build_split_index<HH, NHH, KK>(idx_host);         \
+    return MNF_OK;                                         \
+  }
+  MNF_NSF_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
 }
 
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden) {

@@ -516,7 +516,7 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   __shared__ __attribute__((aligned(16))) float lds[2][WORDS];
   // weights outside the f16 range (flagged by the pack kernel): every group on the fp32 path
   const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
-  const bool split_ok = wmax <= kSplitLimit;
+  const bool split_ok = wmax <= kSplitWeightLimit;
   const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     if (split_ok && rnvp_group_split<HN, SEEDED>(reinterpret_cast<uint32_t*>(lds[0]), reinterpret_cast<uint32_t*>(lds[1]),

@@ -19,9 +19,11 @@
 //
 // Range: f16 tops out at 65,504 and lo is scaled by 2^11, so the scheme needs |v| < 2^15 for every
 // operand.  The kernels track max|v| per 16-row tile (one v_max3 per two values) and recompute a tile
-// that exceeds kSplitLimit -- or whose weights do, flagged by the pack kernel -- on the fp32 MFMA path,
-// so results do not depend on the input range.  Values below 2^-14 lose low bits of hi to f16
-// subnormals; their absolute error is < 2^-25 and lo still carries the residual.
+// that reaches kSplitLimit -- or, for the whole launch, whose weights exceed kSplitWeightLimit, flagged by
+// the pack kernel -- on the fp32 MFMA path, so results do not depend on the input range.  An operand
+// below 2^-14 is carried with an ABSOLUTE error of at most 2^-36 (hi and lo are f16 subnormals there,
+// which the MFMA honours); the two limits keep the other factor of such a product small enough for that
+// to stay below fp32's own rounding of the sum.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,7 +44,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kSplitScale = 2048.f;          // 2^11
 constexpr float kSplitInvScale = 1.f / 2048.f;
-constexpr float kSplitLimit = 30000.f;         // < 2^15 with headroom for the round-toward-zero residual
+constexpr float kSplitLimit = 8192.f;           // operands at or above 2^13 go to the fp32 path (f16 ends at 65,504;
+                                               // keeping |v| small also bounds |v| 2^-36, the absolute error a
+                                               // sub-2^-14 weight contributes per product)
+constexpr float kSplitWeightLimit = 256.f;     // likewise for weights: a larger one sends the launch to fp32
 constexpr int kSplitTailWords = 4;             // [max|w| bits, 0, 0, 0] after the plain words
 constexpr int32_t kSplitLoBit = 1 << 30;       // index-table entry: take the lo part of the source value
 
@@ -60,13 +65,19 @@ __device__ __forceinline__ float residual_hi(uint32_t hp, float v) {
   return r;
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 // two fp32 values -> packed f16 hi pair and packed scaled-residual pair; mx tracks max|v|.
-// Six vector instructions: cvt_pkrtz, 2 x fma_mix, pk_mul, cvt_pkrtz, max3.
+// Six vector instructions: v_cvt_pk_f16_f32 (round to nearest even, gfx950), 2 x fma_mix, pk_mul,
+// v_cvt_pk_f16_f32, max3.  With round-to-nearest |v - hi| <= 2^-12 |v| and the residual is itself rounded
+// to 11 bits, so hi + lo 2^-11 carries v to 2^-24 relative -- fp32's own precision -- as long as hi is a
+// normal f16; below 2^-14 the ABSOLUTE error is bounded by 2^-36 instead (f16 subnormals are honoured by
+// the MFMA, measured), which is why the guard also has a lower-than-overflow weight limit.
 __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t& hi, uint32_t& lo, float& mx) {
-  hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v0, v1}, f16x2));
   f32x2 r = f32x2{residual_lo(hi, v0), residual_hi(hi, v1)};
   r = r * kSplitScale;
-  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r[0], r[1]));
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
   mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v0)), __builtin_fabsf(v1));
 }
 
@@ -97,6 +108,9 @@ __device__ __forceinline__ void split_mac(const f16x8& ah, const f16x8& al, cons
 }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// initial value of a tile's running max|operand|: the weights' verdict (image tail word = max |weight| bits)
+__device__ __forceinline__ float split_guard_seed(float wmax) { return wmax <= kSplitWeightLimit ? 0.f : __builtin_inff(); }
 
 // ------------------------------------------------------------------------------------------------
 // Tiling of a coupling layer's two conditioner nets (s and t, HID hidden units each, evaluated as

@@ -136,7 +136,8 @@ class _NsfFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
-            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), x.shape[0], module.dim,
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), _ptr(module._split_image(x.device)),
+            x.shape[0], module.dim,
             module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
             int(module.force_generic), _stream()))
         ctx.module, ctx.inverse = module, inverse
@@ -429,6 +430,19 @@ class NSF_CL(_TwoWayFlow):
             self.dim, self.K, len(self.h_sizes), self._hid, idx))
         return idx
 
+    def _split_index_host(self):
+        lib = _lib.load()
+        n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = lib.mnf_nsf_cl_split_layout(self.dim, self.K, len(self.h_sizes), self._hid, ctypes.byref(n_split),
+                                         ctypes.byref(n_plain))
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            return None
+        _lib.check("mnf_nsf_cl_split_layout", rc)
+        idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+        _lib.check("mnf_nsf_cl_split_index", lib.mnf_nsf_cl_split_index(
+            self.dim, self.K, len(self.h_sizes), self._hid, idx))
+        return idx, n_split.value, n_plain.value
+
     def _run(self, x, inverse, accum):
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
             xg = _grad_input(x)
@@ -446,6 +460,7 @@ class NSF_CL(_TwoWayFlow):
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
+            _ptr(self._split_image(x.device)),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
             int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
@@ -773,8 +788,8 @@ class _SplineBlockRun:
         x = _device_input(x, "input")
         buf = torch.empty((3 if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         rc = _lib.load().mnf_nsf_cl_fused(
-            x.data_ptr(), buf[-1].data_ptr(), log_det.data_ptr(), int(accumulate), image.data_ptr(), aff.data_ptr(),
-            ldc, scale_shift.data_ptr(), buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
+            x.data_ptr(), buf[-1].data_ptr(), log_det.data_ptr(), int(accumulate), image.data_ptr(),
+            _ptr(nsf._split_image(x.device)), aff.data_ptr(), ldc, scale_shift.data_ptr(), buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
             x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
         if rc == _lib.MNF_ERR_UNSUPPORTED:
             self._unsupported = True
