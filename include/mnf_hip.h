@@ -233,6 +233,16 @@ int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_l
                         float* grad_flat, const float* flat, int64_t rows, int dim, int parity,
                         int inverse, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                         void* stream);
+/* The same gradients at matrix-pipe rate (fp32 MFMAs; d in {32, 64}, hidden (24,24,24) or (16,16,16), scale and
+ * shift nets both present).  index_dev: device copy of the mnf_affine_half_bwd_index table
+ * (mnf_affine_half_bwd_index_ints() int32s, built once per shape; 0 = no such kernel).  Same contract as
+ * mnf_affine_half_bwd: grad_x is written, grad_flat is ADDED to; MNF_ERR_UNSUPPORTED otherwise. */
+int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift);
+int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                              int32_t* idx_host);
+int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                             float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                             int parity, int inverse, int n_hidden, const int* hidden_host, void* stream);
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);

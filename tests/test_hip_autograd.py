@@ -56,6 +56,40 @@ def test_affine_half_gradients(amd, O, dim, kw, inverse):
         assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
 
 
+@pytest.mark.parametrize("dim,hid", [(64, 24), (32, 24), (64, 16), (32, 16)])
+@pytest.mark.parametrize("parity", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_half_mfma_gradient_kernel(amd, O, dim, hid, parity, inverse):
+    """The fp32-MFMA gradient kernel (every shape it exists for, ragged row count, both parities) against
+    autograd through the oracle and against the generic gradient kernel."""
+    h_sizes = (hid, hid, hid)
+    sd = recipes.affine_half_params(61 + dim + hid, dim, h_sizes=h_sizes, s_last_gain=2.0)
+    rows = 1000 + 7
+    x_cpu = recipes.gaussian(62 + dim, rows, dim).requires_grad_(True)
+    w_y = recipes.gaussian(63, rows, dim)
+    w_l = recipes.gaussian(64, rows, 1)[:, 0]
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, parity, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    grads = {}
+    for generic in (False, True):
+        f = amd.AffineHalfFlow(dim, parity, h_sizes=h_sizes)
+        f.load_state_dict(sd)
+        f.to(DEV)
+        assert f._bwd_index(torch.device(DEV, 0)) is not None
+        f.force_generic = generic
+        x = x_cpu.detach().to(DEV).requires_grad_(True)
+        yg, ldg = f.forward(x, inverse=inverse)
+        ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+        grads[generic] = {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+        if not generic:
+            assert_close(x.grad, x_cpu.grad, GTOL, "grad_x")
+            for name, prm in f.named_parameters():
+                assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
+    for k in grads[False]:
+        assert_close(grads[False][k], grads[True][k], GTOL, f"mfma vs generic {k}")
+
+
 @pytest.mark.parametrize("cfg", [(32, 8, 8), (6, 5, 8), (2, 8, 16)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_gradients(amd, O, cfg, inverse):

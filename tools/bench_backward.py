@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch, recipes
 import torch_mnf_amd as amd
-for dim, rows in ((2, 128), (2, 4096), (64, 4096), (64, 1 << 16), (64, 1 << 18)):
+for dim, rows in ((2, 128), (2, 4096), (64, 4096), (64, 1 << 16), (64, 1 << 18), (64, 1 << 20)):
     flows = []
     for i, sd in enumerate(recipes.c2_stack_params(dim)):
         f = amd.AffineHalfFlow(dim, parity=bool(i % 2)); f.load_state_dict(sd); flows.append(f)

@@ -75,6 +75,10 @@ SIGNATURES = {
     "mnf_gauss_logprob_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_affine_half_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                     c_int, c_int, c_int, _intp, c_int, c_int, c_void_p]),
+    "mnf_affine_half_bwd_index_ints": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
+    "mnf_affine_half_bwd_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
+    "mnf_affine_half_bwd_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_int, c_int, c_int, c_int, _intp, c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

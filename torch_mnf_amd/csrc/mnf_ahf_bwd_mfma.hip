@@ -1,0 +1,557 @@
+// AffineHalfFlow gradients on fp32 MFMAs (SURVEY.md 8f rank 1 at matrix-pipe rate).
+//
+// One wave owns 16 rows at a time.  Per tile it
+//   1. recomputes the two conditioner nets (as one concatenated net, block-diagonal hidden layers) with
+//      v_mfma_f32_16x16x4_f32, parking every activation tile in LDS,
+//   2. forms the output deltas from grad_y / grad_ld and the transform,
+//   3. back-propagates them through the transposed weights (same MFMA scheme: the accumulator layout of
+//      one product is the B-operand layout of the next), and
+//   4. accumulates the weight gradients dW_l += delta_l^T h_{l-1} with the 16 rows on the MFMA K axis.
+//      That product needs rows on K where everything else has them on N, so delta and h tiles go through
+//      a per-wave LDS scratch ([row][unit], 20-float pitch: conflict-free float4 writes) and are read back
+//      transposed; the bias gradients are the sums of those same operand reads.
+// The 28 weight-gradient tiles (112 VGPRs at d = 64) stay in registers across all tiles of a wave; at the
+// end the four waves of a workgroup add them up in LDS and issue one atomic add per parameter.
+// Operand images (forward and transposed weights, 57 KB) are gathered from `flat` into LDS by every
+// workgroup through an index table the caller builds once per shape (mnf_affine_half_bwd_index).
+#include <hip/hip_runtime.h>
+
+#include "mnf_ahf_shape.h"
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+
+constexpr int kBwdWaves = 4;
+constexpr int kTilePitch = 20;                     // floats per row of an LDS scratch tile
+constexpr int kTileFloats = 16 * kTilePitch;
+
+template <int H, int HID>
+struct BwdShape {
+  static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported shape");
+  static constexpr int G = H / 16;
+  static constexpr int NT = (2 * HID + 15) / 16;
+  static constexpr int tile_nets(int m) {  // bit 0 = s, bit 1 = t
+    int nets = 0;
+    for (int i = 0; i < 16; ++i)
+      if (16 * m + i < 2 * HID) nets |= 1 << ((16 * m + i) / HID);
+    return nets;
+  }
+  static constexpr bool needs(int m, int mt) { return (tile_nets(m) & tile_nets(mt)) != 0; }
+  static constexpr int pairs() {
+    int n = 0;
+    for (int m = 0; m < NT; ++m)
+      for (int mt = 0; mt < NT; ++mt) n += needs(m, mt) ? 1 : 0;
+    return n;
+  }
+  static constexpr int net_tiles() {  // (hidden tile, net) incidences
+    int n = 0;
+    for (int m = 0; m < NT; ++m) n += (tile_nets(m) & 1) + ((tile_nets(m) >> 1) & 1);
+    return n;
+  }
+  static constexpr int PAIRS = pairs(), NET_TILES = net_tiles();
+  // MFMA operand counts (one op = 64 floats), in image order
+  static constexpr int N_F1 = NT * G * 4, N_FH = PAIRS * 4, N_F4 = NET_TILES * G * 4;
+  static constexpr int N_B4 = NET_TILES * G * 4, N_BH = PAIRS * 4, N_B1 = G * NT * 4;
+  static constexpr int N_OPS = N_F1 + 2 * N_FH + N_F4 + N_B4 + 2 * N_BH + N_B1;
+  static constexpr int A_FLOATS = ((N_OPS + 3) / 4) * 256;
+  static constexpr int BIAS_TILES = 3 * NT + 2 * G;
+  static constexpr int IMAGE_FLOATS = A_FLOATS + BIAS_TILES * 16;
+  // weight-gradient tiles: layer 1 (NT x G), hidden x 2 (PAIRS each), output (NET_TILES x G)
+  static constexpr int DW_TILES = NT * G + 2 * PAIRS + NET_TILES * G;
+  static constexpr int DB_TILES = 3 * NT + 2 * G;
+  // LDS scratch tiles per wave: x0 (G), h1..h3 (3 NT), deltas (max(NT, 2 G))
+  static constexpr int D_TILES = NT > 2 * G ? NT : 2 * G;
+  static constexpr int SCRATCH_TILES = G + 3 * NT + D_TILES;
+  // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
+  static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
+  static constexpr int LDS_FLOATS = IMAGE_FLOATS + kBwdWaves * SCRATCH_TILES * kTileFloats;
+};
+
+// D-layout tile (lane (j, q) holds units 4q..4q+3 of row j) -> LDS scratch [row][unit]
+__device__ __forceinline__ void tile_to_lds(float* tile, int j, int q, const f32x4& v) {
+  *reinterpret_cast<f32x4*>(tile + j * kTilePitch + 4 * q) = v;
+}
+__device__ __forceinline__ f32x4 tile_from_lds(const float* tile, int j, int q) {
+  return *reinterpret_cast<const f32x4*>(tile + j * kTilePitch + 4 * q);
+}
+// transposed read: element [row 4 s + kq][unit i] for the four K-steps s (rows on the MFMA K axis)
+__device__ __forceinline__ void tile_rows_on_k(const float* tile, int i, int kq, float (&out)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) out[s] = tile[(4 * s + kq) * kTilePitch + i];
+}
+
+template <int H, int HID, bool INV>
+__global__ void __launch_bounds__(kBwdWaves * 64, 1)
+ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
+                    float* __restrict__ grad_x, float* __restrict__ grad_flat, const float* __restrict__ flat,
+                    const int32_t* __restrict__ index, int64_t rows, int parity) {
+  using S = BwdShape<H, HID>;
+  constexpr int G = S::G, NT = S::NT, dim = 2 * H;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < S::IMAGE_FLOATS; i += blockDim.x) {
+    const int32_t src = index[i];
+    lds[i] = src < 0 ? 0.f : flat[src];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
+  float* scratch = lds + S::IMAGE_FLOATS + wave * S::SCRATCH_TILES * kTileFloats;
+  float* TX = scratch;                             // x0: G tiles
+  float* TH = TX + G * kTileFloats;                // h1, h2, h3: 3 NT tiles
+  float* TD = TH + 3 * NT * kTileFloats;           // deltas of the layer in flight
+
+  f32x4 dW[S::DW_TILES];
+  float db[S::DB_TILES];
+#pragma unroll
+  for (int t = 0; t < S::DW_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < S::DB_TILES; ++t) db[t] = 0.f;
+
+  const int n_tiles = (int)((rows + 15) >> 4);
+  for (int tile = (int)blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kBwdWaves) {
+    const int64_t row = (int64_t)tile * 16 + j;
+    const bool live = row < rows;
+    const int64_t rowc = live ? row : rows - 1;
+    const float* xr = x + rowc * dim + 4 * q;
+    f32x4 cnd[G], act[G], gc[G], ga[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
+      act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g);
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      gc[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + cond_off + 16 * g) : zero;
+      ga[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + act_off + 16 * g) : zero;
+    }
+    const float gl = (grad_ld && live) ? grad_ld[rowc] : 0.f;
+
+    int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
+    asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop
+    const f32x4* A4 = reinterpret_cast<const f32x4*>(lds + a_off);
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + b_off);
+    int n = 0, bt = 0, dwt = 0, dbt = 0;
+    f32x4 a4;
+    auto mfma = [&](float b, f32x4& acc) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], b, acc, 0, 0, 0);
+      ++n;
+    };
+
+    // ------------------------------------------------------------------ forward recompute
+#pragma unroll
+    for (int g = 0; g < G; ++g) tile_to_lds(TX + g * kTileFloats, j, q, cnd[g]);
+    f32x4 h[3][NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      h[0][m] = B4[4 * (bt++)];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mfma(cnd[g][r], h[0][m]);
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[l][m][r] = leaky2(h[l][m][r]);
+        tile_to_lds(TH + (l * NT + m) * kTileFloats, j, q, h[l][m]);
+      }
+      if (l < 2) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          h[l + 1][m] = B4[4 * (bt++)];
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt)
+            if (S::needs(m, mt))
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mfma(h[l][mt][r], h[l + 1][m]);
+        }
+      }
+    }
+    f32x4 st[2][G];  // raw s (net 0) and t (net 1) in the row's float4 layout
+#pragma unroll
+    for (int net = 0; net < 2; ++net)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        st[net][g] = B4[4 * (bt++)];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+          if ((S::tile_nets(mt) >> net) & 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mfma(h[2][mt][r], st[net][g]);
+      }
+
+    // ------------------------------------------------------------------ output deltas, grad of the transformed half
+    //   forward: y = e^s v + t          g_v = g e^s      g_s = g e^s v + g_ld      g_t = g
+    //   inverse: y = (v - t) e^-s       g_v = g e^-s     g_s = -g y - g_ld         g_t = -g e^-s
+    f32x4 d4[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      f32x4 gv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = st[0][g][r], t = st[1][g][r], gy = ga[g][r], v = act[g][r];
+        const float e = exp6(INV ? -s : s);
+        gv[r] = gy * e;
+        d4[0][g][r] = live ? (INV ? -gy * ((v - t) * e) - gl : gy * e * v + gl) : 0.f;
+        d4[1][g][r] = INV ? -gy * e : gy;
+      }
+      if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + act_off + 16 * g) = gv;
+    }
+
+    // weight gradients of one layer: out tiles' deltas in TD[0..n_out), in tiles at `tin`; (mo, mi) pairs by `used`
+    auto weight_grads = [&](int n_out, int n_in, const float* tin, auto used) {
+      float aop[S::D_TILES][4], bop[NT > G ? NT : G][4];
+#pragma unroll
+      for (int mo = 0; mo < S::D_TILES; ++mo)
+        if (mo < n_out) {
+          tile_rows_on_k(TD + mo * kTileFloats, j, q, aop[mo]);
+          db[dbt++] += (aop[mo][0] + aop[mo][1]) + (aop[mo][2] + aop[mo][3]);
+        }
+#pragma unroll
+      for (int mi = 0; mi < (NT > G ? NT : G); ++mi)
+        if (mi < n_in) tile_rows_on_k(tin + mi * kTileFloats, j, q, bop[mi]);
+#pragma unroll
+      for (int mo = 0; mo < S::D_TILES; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < (NT > G ? NT : G); ++mi)
+          if (mo < n_out && mi < n_in && used(mo, mi)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              dW[dwt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mo][s], bop[mi][s], dW[dwt], 0, 0, 0);
+            ++dwt;
+          }
+    };
+
+    // ------------------------------------------------------------------ output layer: dW4, then delta3 = W4^T delta4
+    // (dW tile order: layer 1, hidden 1, hidden 2, output -- the flush table follows the same order, so the
+    //  counters are set per layer instead of running)
+    constexpr int DW_L1 = 0, DW_H1 = NT * G, DW_H2 = DW_H1 + S::PAIRS, DW_OUT = DW_H2 + S::PAIRS;
+    constexpr int DB_L1 = 0, DB_H1 = NT, DB_H2 = 2 * NT, DB_OUT = 3 * NT;
+#pragma unroll
+    for (int net = 0; net < 2; ++net)
+#pragma unroll
+      for (int g = 0; g < G; ++g) tile_to_lds(TD + (net * G + g) * kTileFloats, j, q, d4[net][g]);
+    dwt = DW_OUT;
+    dbt = DB_OUT;
+    weight_grads(2 * G, NT, TH + 2 * NT * kTileFloats,
+                 [](int mo, int mi) { return ((S::tile_nets(mi) >> (mo / G)) & 1) != 0; });
+    f32x4 dl[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      dl[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int net = 0; net < 2; ++net)
+        if ((S::tile_nets(m) >> net) & 1)
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mfma(d4[net][g][r], dl[m]);
+    }
+    // ------------------------------------------------------------------ hidden layers 3 and 2
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        const f32x4 hv = tile_from_lds(TH + (l * NT + m) * kTileFloats, j, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dl[m][r] = hv[r] > 0.f ? dl[m][r] : kLeakySlope * dl[m][r];
+        tile_to_lds(TD + m * kTileFloats, j, q, dl[m]);
+      }
+      dwt = l == 2 ? DW_H2 : DW_H1;
+      dbt = l == 2 ? DB_H2 : DB_H1;
+      weight_grads(NT, NT, TH + (l - 1) * NT * kTileFloats, [](int mo, int mi) { return S::needs(mo, mi); });
+      f32x4 dn[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        dn[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+          if (S::needs(m, mt))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mfma(dl[mt][r], dn[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < NT; ++m) dl[m] = dn[m];
+    }
+    // ------------------------------------------------------------------ layer 1
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const f32x4 hv = tile_from_lds(TH + m * kTileFloats, j, q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dl[m][r] = hv[r] > 0.f ? dl[m][r] : kLeakySlope * dl[m][r];
+      tile_to_lds(TD + m * kTileFloats, j, q, dl[m]);
+    }
+    dwt = DW_L1;
+    dbt = DB_L1;
+    weight_grads(NT, G, TX, [](int, int) { return true; });
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      f32x4 gx0 = gc[g];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mfma(dl[mt][r], gx0);
+      if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + cond_off + 16 * g) = gx0;
+    }
+  }
+
+  // ------------------------------------------------------------------ flush: sum over the waves in LDS, one atomic per parameter
+  if (grad_flat == nullptr) return;
+  __syncthreads();
+  float* red = lds;  // the images are no longer needed
+  constexpr int DW_FLOATS = S::DW_TILES * 256, DB_FLOATS = S::DB_TILES * 64;
+  for (int w = 0; w < kBwdWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < S::DW_TILES; ++t) {
+        f32x4* p = reinterpret_cast<f32x4*>(red + t * 256 + lane * 4);
+        *p = w == 0 ? dW[t] : *p + dW[t];
+      }
+#pragma unroll
+      for (int t = 0; t < S::DB_TILES; ++t) {
+        float* p = red + DW_FLOATS + t * 64 + lane;
+        *p = w == 0 ? db[t] : *p + db[t];
+      }
+    }
+    __syncthreads();
+  }
+  const int32_t* flush_w = index + S::IMAGE_FLOATS;
+  const int32_t* flush_b = flush_w + DW_FLOATS;
+  for (int i = threadIdx.x; i < DW_FLOATS; i += blockDim.x) {
+    const int32_t dst = flush_w[i];
+    if (dst >= 0) atomicAdd(grad_flat + dst, red[i]);
+  }
+  // db: lane (i = unit, kq) holds a quarter of the rows' sum
+  for (int i = threadIdx.x; i < S::DB_TILES * 16; i += blockDim.x) {
+    const int t = i >> 4, u = i & 15;
+    const int32_t dst = flush_b[i];
+    if (dst >= 0) {
+      const float* p = red + DW_FLOATS + t * 64 + u;
+      atomicAdd(grad_flat + dst, (p[0] + p[16]) + (p[32] + p[48]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host: index table
+template <int H, int HID>
+static void build_bwd_index(int32_t* idx) {
+  using S = BwdShape<H, HID>;
+  constexpr int G = S::G, NT = S::NT;
+  int sizes[5] = {H, HID, HID, HID, H};
+  NetDesc net[2];
+  int64_t off = fill_net(net[0], 5, sizes, 0);
+  fill_net(net[1], 5, sizes, off);
+  for (int i = 0; i < S::INDEX_INTS; ++i) idx[i] = -1;
+  auto netof = [&](int u) { return u / HID; };
+  auto valid = [&](int u) { return u < 2 * HID; };
+  int n = 0;
+  auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
+  // forward operands: A[i][kq] = W[out unit of row i][input behind K slot kq of step r]
+  for (int m = 0; m < NT; ++m)
+    for (int g = 0; g < G; ++g)
+      for (int r = 0; r < 4; ++r, ++n)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+          if (valid(u)) put(lane, net[netof(u)].w_off[0] + (u % HID) * H + 16 * g + 4 * kq + r);
+        }
+  for (int l = 1; l <= 2; ++l)
+    for (int m = 0; m < NT; ++m)
+      for (int mt = 0; mt < NT; ++mt) {
+        if (!S::needs(m, mt)) continue;
+        for (int r = 0; r < 4; ++r, ++n)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, uo = 16 * m + i, ui = 16 * mt + 4 * kq + r;
+            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
+              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+          }
+      }
+  for (int nn = 0; nn < 2; ++nn)
+    for (int g = 0; g < G; ++g)
+      for (int mt = 0; mt < NT; ++mt) {
+        if (!((S::tile_nets(mt) >> nn) & 1)) continue;
+        for (int r = 0; r < 4; ++r, ++n)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, ui = 16 * mt + 4 * kq + r;
+            if (valid(ui) && netof(ui) == nn) put(lane, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+          }
+      }
+  // transposed operands
+  for (int m = 0; m < NT; ++m)  // delta3[unit 16 m + i] += W4[dim 16 g + 4 kq + r][unit] delta4[dim]
+    for (int nn = 0; nn < 2; ++nn) {
+      if (!((S::tile_nets(m) >> nn) & 1)) continue;
+      for (int g = 0; g < G; ++g)
+        for (int r = 0; r < 4; ++r, ++n)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+            if (valid(u) && netof(u) == nn) put(lane, net[nn].w_off[3] + (16 * g + 4 * kq + r) * HID + u % HID);
+          }
+    }
+  for (int l = 2; l >= 1; --l)  // delta_{l}[unit 16 m + i] += W_{l+1}... here: W_l[out 16 mt + 4 kq + r][in unit]
+    for (int m = 0; m < NT; ++m)
+      for (int mt = 0; mt < NT; ++mt) {
+        if (!S::needs(m, mt)) continue;
+        for (int r = 0; r < 4; ++r, ++n)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4, ui = 16 * m + i, uo = 16 * mt + 4 * kq + r;
+            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
+              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+          }
+      }
+  for (int g = 0; g < G; ++g)  // grad x0[dim 16 g + i] += W1[unit 16 mt + 4 kq + r][dim] delta1[unit]
+    for (int mt = 0; mt < NT; ++mt)
+      for (int r = 0; r < 4; ++r, ++n)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = 16 * mt + 4 * kq + r;
+          if (valid(u)) put(lane, net[netof(u)].w_off[0] + (u % HID) * H + 16 * g + i);
+        }
+  // biases of the forward recompute
+  int32_t* b = idx + S::A_FLOATS;
+  int bt = 0;
+  for (int l = 0; l < 3; ++l)
+    for (int m = 0; m < NT; ++m, ++bt)
+      for (int i = 0; i < 16; ++i)
+        if (valid(16 * m + i)) b[bt * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
+  for (int nn = 0; nn < 2; ++nn)
+    for (int g = 0; g < G; ++g, ++bt)
+      for (int i = 0; i < 16; ++i) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+
+  // flush tables.  dW tile (mo, mi): lane (j = in index b, q), reg r <-> out index a = 4 q + r
+  int32_t* fw = idx + S::IMAGE_FLOATS;
+  int t = 0;
+  auto put_w = [&](int lane, int r, int32_t dst) { fw[t * 256 + lane * 4 + r] = dst; };
+  for (int mo = 0; mo < NT; ++mo)  // layer 1: W1[unit 16 mo + a][dim 16 mi + b]
+    for (int mi = 0; mi < G; ++mi, ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int bq = lane & 15, a = 4 * (lane >> 4) + r, u = 16 * mo + a;
+          if (valid(u)) put_w(lane, r, net[netof(u)].w_off[0] + (u % HID) * H + 16 * mi + bq);
+        }
+  for (int l = 1; l <= 2; ++l)
+    for (int mo = 0; mo < NT; ++mo)
+      for (int mi = 0; mi < NT; ++mi) {
+        if (!S::needs(mo, mi)) continue;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            const int bq = lane & 15, a = 4 * (lane >> 4) + r, uo = 16 * mo + a, ui = 16 * mi + bq;
+            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
+              put_w(lane, r, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+          }
+        ++t;
+      }
+  for (int mo = 0; mo < 2 * G; ++mo)  // output: delta tile mo = net * G + g
+    for (int mi = 0; mi < NT; ++mi) {
+      const int nn = mo / G, g = mo % G;
+      if (!((S::tile_nets(mi) >> nn) & 1)) continue;
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int bq = lane & 15, a = 4 * (lane >> 4) + r, ui = 16 * mi + bq;
+          if (valid(ui) && netof(ui) == nn) put_w(lane, r, net[nn].w_off[3] + (16 * g + a) * HID + ui % HID);
+        }
+      ++t;
+    }
+  int32_t* fb = fw + S::DW_TILES * 256;
+  t = 0;
+  for (int l = 0; l < 3; ++l)
+    for (int m = 0; m < NT; ++m, ++t)
+      for (int i = 0; i < 16; ++i)
+        if (valid(16 * m + i)) fb[t * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
+  for (int nn = 0; nn < 2; ++nn)
+    for (int g = 0; g < G; ++g, ++t)
+      for (int i = 0; i < 16; ++i) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+}
+
+// shapes: hidden (24,24,24) / (16,16,16) at d = 32, 64
+#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16)
+
+template <int H, int HID>
+static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                      const float* flat, const int32_t* index, int64_t rows, int parity, int inverse,
+                      hipStream_t stream) {
+  using S = BwdShape<H, HID>;
+  constexpr size_t lds_bytes = S::LDS_FLOATS * sizeof(float);
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      return prop.multiProcessorCount;
+    return 256;
+  }();
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  }();
+  if (!attr_ok) return MNF_ERR_UNSUPPORTED;
+  const int64_t n_tiles = (rows + 15) / 16;
+  int64_t blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
+  if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)
+  const dim3 grid((unsigned)blocks), block(kBwdWaves * 64);
+  if (inverse)
+    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
+                       grad_flat, flat, index, rows, parity);
+  else
+    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
+                       grad_x, grad_flat, flat, index, rows, parity);
+  return check_launch();
+}
+
+static bool bwd_uniform3(int n_hidden, const int* hidden, int& hid) {
+  if (n_hidden != 3 || !hidden) return false;
+  hid = hidden[0];
+  return hidden[1] == hid && hidden[2] == hid;
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden, int has_scale, int has_shift) {
+  int hid = 0;
+  if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
+    return 0;
+#define X(HH, HD) \
+  if (dim == 2 * HH && hid == HD) return mnf::BwdShape<HH, HD>::INDEX_INTS;
+  MNF_AHF_BWD_SHAPES(X)
+#undef X
+  return 0;
+}
+
+int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                              int32_t* idx_host) {
+  int hid = 0;
+  if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  if (!has_scale || !has_shift || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+#define X(HH, HD)                              \
+  if (dim == 2 * HH && hid == HD) {            \
+    mnf::build_bwd_index<HH, HD>(idx_host);    \
+    return MNF_OK;                             \
+  }
+  MNF_AHF_BWD_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                             float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                             int parity, int inverse, int n_hidden, const int* hidden, void* stream) {
+  int hid = 0;
+  if (!x || !grad_x || !flat || !index_dev || rows < 0 || dim < 2 || (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (!mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+#define X(HH, HD)                                                                                              \
+  if (dim == 2 * HH && hid == HD)                                                                              \
+    return mnf::launch_bwd<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows, parity != 0, \
+                                   inverse != 0, (hipStream_t)stream);
+  MNF_AHF_BWD_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

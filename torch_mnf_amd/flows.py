@@ -119,6 +119,15 @@ class _AffineHalfFn(torch.autograd.Function):
         gl = None if grad_ld is None else grad_ld.contiguous()
         grad_x = torch.empty_like(x)
         grad_flat = torch.zeros_like(flat)
+        index = m._bwd_index(x.device) if flat.numel() and not m.force_generic else None
+        if index is not None:  # fp32-MFMA gradient kernel
+            rc = _lib.load().mnf_affine_half_bwd_mfma(
+                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
+                index.data_ptr(), x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse), len(m.h_sizes), m._hid,
+                _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_affine_half_bwd_mfma", rc)
+                return grad_x, grad_flat, None, None
         _lib.check("mnf_affine_half_bwd", _lib.load().mnf_affine_half_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), _ptr(grad_flat) if flat.numel() else None,
             _ptr(flat) if flat.numel() else None, x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse),
@@ -356,6 +365,22 @@ class AffineHalfFlow(_TwoWayFlow):
         _lib.check("mnf_affine_half_image_index", lib.mnf_affine_half_image_index(
             self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
         return idx
+
+    def _bwd_index(self, device) -> Tensor | None:
+        """Device index table of the MFMA gradient kernel (built once per module), or None."""
+        cached = self.__dict__.get("_bwd_index_cache")
+        if cached is None or (cached[0] is not None and cached[0].device != device):
+            lib = _lib.load()
+            n = lib.mnf_affine_half_bwd_index_ints(self.dim, len(self.h_sizes), self._hid, self.scale, self.shift)
+            table = None
+            if n > 0:
+                idx = (ctypes.c_int32 * n)()
+                _lib.check("mnf_affine_half_bwd_index", lib.mnf_affine_half_bwd_index(
+                    self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
+                table = torch.frombuffer(idx, dtype=torch.int32).clone().to(device)
+            cached = (table,)
+            self.__dict__["_bwd_index_cache"] = cached
+        return cached[0]
 
     def _split_index_host(self):
         lib = _lib.load()
