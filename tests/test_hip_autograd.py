@@ -90,6 +90,48 @@ def test_affine_half_mfma_gradient_kernel(amd, O, dim, hid, parity, inverse):
         assert_close(grads[False][k], grads[True][k], GTOL, f"mfma vs generic {k}")
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_run_is_one_autograd_node(amd, O, inverse):
+    """With gradients wanted, a run of equal AffineHalfFlow layers is one autograd node (stack kernel forward,
+    MFMA gradient kernel per layer backward): same gradients as layer-by-layer autograd and as autograd through
+    the oracle, including a loss term on an intermediate tensor."""
+    dim, n, rows = 64, 4, 777
+    sds = [recipes.affine_half_params(71 + i, dim, s_last_gain=1.5) for i in range(n)]
+    x_cpu = recipes.gaussian(72, rows, dim).requires_grad_(True)
+    w_z, w_mid, w_l = recipes.gaussian(73, rows, dim), recipes.gaussian(74, rows, dim), recipes.gaussian(75, rows, 1)[:, 0]
+    ps = [leaf(sd) for sd in sds]
+    z, ld, mids = x_cpu, 0, []
+    for i in (reversed(range(n)) if inverse else range(n)):
+        z, l1 = O.affine_half(z, ps[i], bool(i % 2), inverse)
+        ld = ld + l1
+        mids.append(z)
+    ((z * w_z).sum() + (mids[1] * w_mid).sum() + (ld * w_l).sum()).backward()
+
+    results = {}
+    for fused in (True, False):
+        flows = []
+        for i, sd in enumerate(sds):
+            f = amd.AffineHalfFlow(dim, bool(i % 2))
+            f.load_state_dict(sd)
+            flows.append(f)
+        model = amd.NormalizingFlow(flows).to(DEV)
+        model.fuse_affine_runs = fused
+        x = x_cpu.detach().to(DEV).requires_grad_(True)
+        zs, ldg = model.inverse(x) if inverse else model.forward(x)
+        assert len(zs) == n + 1 and ldg.requires_grad
+        if fused:
+            assert type(zs[-1].grad_fn).__name__.startswith("_AffineRunFn")
+        ((zs[-1] * w_z.to(DEV)).sum() + (zs[2] * w_mid.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+        results[fused] = {"x": x.grad, **{k: q.grad for k, q in model.named_parameters()}}
+        assert_close(zs[-1], z.detach(), 1e-5, "z")
+    assert_close(results[True]["x"], x_cpu.grad, GTOL, "grad_x vs oracle")
+    for i in range(n):
+        for k, v in ps[i].items():
+            assert_close(results[True][f"flows.{i}.{k}"], v.grad, GTOL, f"grad flows.{i}.{k} vs oracle")
+    for k in results[True]:
+        assert_close(results[True][k], results[False][k], GTOL, f"fused vs layer-by-layer {k}")
+
+
 @pytest.mark.parametrize("cfg", [(32, 8, 8), (6, 5, 8), (2, 8, 16)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_gradients(amd, O, cfg, inverse):

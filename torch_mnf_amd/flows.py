@@ -28,6 +28,7 @@ from torch import Tensor, nn
 import os
 
 from . import _lib
+from ._lib import MnfHipError
 
 # MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
 _FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
@@ -245,6 +246,53 @@ class _LinearRowsFn(torch.autograd.Function):
         _lib.check("mnf_linear_rows_bwd_weight", lib.mnf_linear_rows_bwd_weight(
             x.data_ptr(), gy.data_ptr(), gW.data_ptr(), x.shape[0], x.shape[1], _stream()))
         return gx, gW
+
+
+class _AffineRunFn(torch.autograd.Function):
+    """A run of equal AffineHalfFlow layers as ONE autograd node: forward = the stack kernel (every
+    intermediate written once), backward = the fp32-MFMA gradient kernel layer by layer on the saved
+    intermediates.  One parameter cat / one grad scatter for the whole run instead of one per layer."""
+
+    @staticmethod
+    def forward(ctx, x, flat_with_grad, run, inverse):
+        n = len(run.layers)
+        ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        outs = run.launch(x, inverse, ld, False, None, keep=True)
+        if outs is None:
+            raise MnfHipError("mnf_affine_half_stack", _lib.MNF_ERR_UNSUPPORTED, "no stack kernel for this shape")
+        ctx.run, ctx.inverse = run, inverse
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, flat_with_grad.detach(), *outs[:-1])
+        ctx.n = n
+        return (*outs, ld)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        run, inverse, n = ctx.run, ctx.inverse, ctx.n
+        x, flat, *mids = ctx.saved_tensors
+        inputs = [x] + list(mids)                     # input of the li-th applied layer
+        order = list(reversed(run.layers)) if inverse else list(run.layers)
+        grad_ld = grads[-1]
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_flat = torch.zeros_like(flat)
+        # offset of every layer's parameters inside the run's flat vector (model order)
+        sizes = [sum(p.numel() for p in f._packed_params()) for f in run.layers]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        lib = _lib.load()
+        g = grads[n - 1]
+        for li in range(n - 1, -1, -1):
+            f = order[li]
+            k = run.layers.index(f)
+            gy = None if g is None else g.contiguous()
+            gx = torch.empty_like(x)
+            _lib.check("mnf_affine_half_bwd_mfma", lib.mnf_affine_half_bwd_mfma(
+                inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
+                flat.data_ptr() + 4 * offs[k], f._bwd_index(x.device).data_ptr(), x.shape[0], f.dim,
+                int(bool(f.parity)), int(inverse), len(f.h_sizes), f._hid, _stream()))
+            g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
+        return g, grad_flat, None, None
 
 
 class _HipFlow(nn.Module):
@@ -900,6 +948,22 @@ class _AffineRun:
                 and x.shape[1] == self.layers[0].dim and not any(f.force_generic for f in self.layers)
                 and not any(_wants_grad(f, x) for f in self.layers) and self.images(x.device)[0] is not None)
 
+    def trainable(self, x) -> bool:
+        """Gradients wanted and the whole run can go through one autograd node (stack kernel forward, fp32-MFMA
+        gradient kernel per layer backward)."""
+        return (not self._unsupported and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+                and x.shape[1] == self.layers[0].dim and not any(f.force_generic for f in self.layers)
+                and any(_wants_grad(f, x) for f in self.layers) and self.images(x.device)[0] is not None
+                and self.layers[0]._bwd_index(x.device) is not None)
+
+    def launch_grad(self, x: Tensor, inverse: bool):
+        """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
+        flat = torch.cat([p.reshape(-1) for f in self.layers for p in f._packed_params()])
+        out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
+        if out is None:
+            return None
+        return list(out[:-1]), out[-1]
+
     def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, sqnorm: Tensor | None,
                keep: bool) -> list[Tensor] | None:
         """Runs the layers (model order reversed when ``inverse``).  Returns the output tensors in
@@ -1039,7 +1103,9 @@ class NormalizingFlow(nn.Module):
         while i < n:
             flow = order[i]
             run = run_at.get(i)
-            if run is not None and not (run.usable(x) if isinstance(run, _AffineRun) else run.usable(x, inverse)):
+            train_run = run is not None and isinstance(run, _AffineRun) and run.trainable(x)
+            if run is not None and not train_run and not (
+                    run.usable(x) if isinstance(run, _AffineRun) else run.usable(x, inverse)):
                 run = None
             span = span_of(run) if run is not None else 1
             last = i + span == n
@@ -1050,7 +1116,13 @@ class NormalizingFlow(nn.Module):
             outs = None
             if run is not None:
                 # one launch for the whole run; every intermediate is written once and never re-read
-                if isinstance(run, _AffineRun):
+                if train_run:  # one autograd node for the whole run
+                    sq = None
+                    res = run.launch_grad(x, inverse)
+                    if res is not None:
+                        outs, ld_run = res
+                        log_det = ld_run if (fresh and i == 0) else log_det + ld_run
+                elif isinstance(run, _AffineRun):
                     sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
                     outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True)
                 else:
