@@ -121,3 +121,94 @@ def test_product_path_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), fn
                 assert "flow_oracle" not in text, fn
+
+
+# ------------------------------------------------------------------ operand-image index tables (host logic)
+def _split_table(lib, layout_fn, index_fn, head_args):
+    n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = layout_fn(*head_args, ctypes.byref(n_split), ctypes.byref(n_plain))
+    assert rc == 0, rc
+    idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+    assert index_fn(*head_args, idx) == 0
+    a = np.frombuffer(idx, dtype=np.int32)
+    return a[: 2 * n_split.value], a[2 * n_split.value:]
+
+
+def _check_split_table(halves, plain, n_weights, n_params):
+    """Every weight appears as a hi half and, with the same multiplicity, as a lo half; every bias appears in
+    the plain (fp32) words; nothing points outside the flat parameter vector."""
+    LO = 1 << 30
+    used = halves[halves >= 0]
+    src = used & (LO - 1)
+    assert src.max() < n_params and plain.max() < n_params
+    hi = np.bincount(src[(used & LO) == 0], minlength=n_params)
+    lo = np.bincount(src[(used & LO) != 0], minlength=n_params)
+    assert np.array_equal(hi, lo)
+    biases = np.setdiff1d(np.arange(n_params), np.nonzero(hi)[0])
+    assert (hi > 0).sum() == n_weights and len(biases) == n_params - n_weights
+    assert np.array_equal(np.unique(plain[plain >= 0]), biases)
+
+
+@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (128, 24), (256, 24), (32, 16), (64, 16), (32, 32), (128, 32)])
+def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
+    from torch_mnf_amd._lib import int_array
+
+    sd = recipes.affine_half_params(0, dim, h_sizes=(hid,) * 3)
+    n_params = sum(v.numel() for v in sd.values())
+    n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
+    halves, plain = _split_table(lib, lib.mnf_affine_half_split_layout, lib.mnf_affine_half_split_index,
+                                 (dim, 3, int_array([hid] * 3), 1, 1))
+    _check_split_table(halves, plain, n_weights, n_params)
+
+
+@pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30)])
+def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
+    from torch_mnf_amd._lib import int_array
+
+    sd = recipes.rnvp_params(0, dim, hid)
+    n_params = sum(v.numel() for v in sd.values())
+    n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
+    halves, plain = _split_table(lib, lib.mnf_rnvp_split_layout, lib.mnf_rnvp_split_index, (dim, 1, int_array([hid])))
+    _check_split_table(halves, plain, n_weights, n_params)
+
+
+@pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8)])
+def test_nsf_split_index_covers_every_parameter(lib, dim, K, nh):
+    from torch_mnf_amd._lib import int_array
+
+    sd = recipes.nsf_cl_params(0, dim, K, nh)
+    n_params = sum(v.numel() for v in sd.values())
+    n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
+    halves, plain = _split_table(lib, lib.mnf_nsf_cl_split_layout, lib.mnf_nsf_cl_split_index,
+                                 (dim, K, 3, int_array([nh] * 3)))
+    _check_split_table(halves, plain, n_weights, n_params)
+
+
+@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (32, 16), (64, 16)])
+def test_affine_half_gradient_index_tables(lib, dim, hid):
+    """The MFMA gradient kernel's tables: the operand gather stays inside the flat vector and uses every
+    parameter; the flush table sends exactly one accumulator element to every parameter."""
+    from torch_mnf_amd._lib import int_array
+
+    hid3 = int_array([hid] * 3)
+    sd = recipes.affine_half_params(0, dim, h_sizes=(hid,) * 3)
+    n_params = sum(v.numel() for v in sd.values())
+    n = lib.mnf_affine_half_bwd_index_ints(dim, 3, hid3, 1, 1)
+    assert n > 0 and lib.mnf_affine_half_bwd_index_ints(256, 3, hid3, 1, 1) == 0
+    idx = (ctypes.c_int32 * n)()
+    assert lib.mnf_affine_half_bwd_index(dim, 3, hid3, 1, 1, idx) == 0
+    a = np.frombuffer(idx, dtype=np.int32)
+    assert a.max() < n_params and a.min() >= -1
+    # the flush part is the tail: [dW tiles x 256][db tiles x 16]; find it as the suffix in which every parameter
+    # occurs exactly once
+    G, NT = dim // 32, (2 * hid + 15) // 16
+    pairs = sum(1 for m in range(NT) for mt in range(NT)
+                if {(16 * m + i) // hid for i in range(16) if 16 * m + i < 2 * hid}
+                & {(16 * mt + i) // hid for i in range(16) if 16 * mt + i < 2 * hid})
+    net_tiles = sum(len({(16 * m + i) // hid for i in range(16) if 16 * m + i < 2 * hid}) for m in range(NT))
+    flush = (NT * G + 2 * pairs + net_tiles * G) * 256 + (3 * NT + 2 * G) * 16
+    tail = a[-flush:]
+    counts = np.bincount(tail[tail >= 0], minlength=n_params)
+    assert np.array_equal(counts, np.ones(n_params, dtype=counts.dtype))
+    head = a[:-flush]
+    assert np.array_equal(np.unique(head[head >= 0]), np.arange(n_params))
