@@ -184,6 +184,14 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
+/* MNFLinear.sample_z's prologue fused into its first flow (torch_mnf/layers/mnf_linear.py:58-64):
+ * x = RNVP(q0_mean + sqrt(exp(q0_log_var)) * eps); z0 is formed in the kernel's loads and never stored.
+ * mask == NULL: in-kernel mask from `seed`.  Needs image and split_image (split MFMA kernel) and dim <= 1024;
+ * MNF_ERR_UNSUPPORTED otherwise (callers then run mnf_sample_z0 followed by mnf_rnvp_seeded). */
+int mnf_rnvp_sample(const float* eps, const float* q0_mean, const float* q0_log_var, const float* mask,
+                    uint64_t seed, float* x, float* log_det, int accumulate, const float* image,
+                    const void* split_image, int64_t rows, int dim, int n_hidden, const int* hidden_host,
+                    void* stream);
 int64_t mnf_rnvp_flat_floats(int dim, int n_hidden, const int* hidden_host);
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden_host);
 int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);

@@ -33,3 +33,13 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch():
+    """Every test starts from the same torch generator state: module constructors (Glow, nn.Linear) and the
+    default RNVP masks draw from it, and a test must not depend on which tests ran before it."""
+    import torch
+
+    torch.manual_seed(1234)
+    yield

@@ -458,12 +458,15 @@ def test_fused_affine_stack_matches_layer_by_layer(amd, golden, O, dim):
     assert list(fused.flows[0].state_dict())[0] == "layers.0.s_net.0.weight"
 
 
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
 @pytest.mark.parametrize("dim", [64, 32, 128])
-def test_run_fusion_keeps_every_intermediate(amd, dim):
+def test_run_fusion_keeps_every_intermediate(amd, dim, kernel):
     """NormalizingFlow sends a run of equal AffineHalfFlow layers out as ONE launch that still writes every
     intermediate: same list of tensors, same log_det as launching the layers one by one."""
     layers = c2_layers(dim)
     model = build_ahf_stack(amd, layers, dim)
+    for f in model.flows:
+        select_kernel(f, kernel)
     assert model.fuse_affine_runs
     x = cuda(recipes.gaussian(21, 1000 + 13, dim))
     with torch.no_grad():
@@ -491,8 +494,12 @@ def test_run_fusion_in_mixed_stacks(amd):
     gradients; a single AffineHalfFlow is not a run."""
     dim = 64
     mk = lambda i, **kw: ahf_module(amd, recipes.affine_half_params(400 + i, dim, **kw), dim, bool(i % 2), **kw)
+    gl = amd.Glow(dim)  # fixed parameters: Glow's own init draws from torch's global generator
+    gp = recipes.glow_params(411, dim)
+    gl.P = gp["P"]
+    gl.load_state_dict({k: gp[k] for k in "LSU"})
     flows = [mk(0), mk(1), mk(2), amd.ActNormFlow(dim).to(DEV), mk(3), mk(4, h_sizes=(16, 16, 16)),
-             mk(5, h_sizes=(16, 16, 16)), amd.Glow(dim).to(DEV), mk(6)]
+             mk(5, h_sizes=(16, 16, 16)), gl.to(DEV), mk(6)]
     flows[3].load_state_dict(recipes.actnorm_params(410, dim))
     flows[3].data_dep_init_done = True
     model = amd.NormalizingFlow(flows).to(DEV)
@@ -826,6 +833,22 @@ def test_g8_mnf_linear_sample_z(amd, golden):
     z, ld = layer.sample_z(64, eps=cuda(fx["eps"]), masks=masks)
     assert_close(z, fx["z"], RTOL, "z")
     assert_close(ld, fx["log_det"], RTOL, "log_det")
+    # the prologue fused into the first flow's kernel (the default) against mnf_sample_z0 + the flows
+    with torch.no_grad():
+        assert layer._fused_prologue_ok(layer.flow_q.flows[0], cuda(fx["eps"]))
+        layer.fuse_prologue = False
+        z_u, ld_u = layer.sample_z(64, eps=cuda(fx["eps"]), masks=masks)
+        torch.manual_seed(7)
+        zs_u, lds_u = layer.sample_z(500, eps=cuda(recipes.gaussian(88, 500, 800)))
+        layer.fuse_prologue = True
+        z_f, ld_f = layer.sample_z(64, eps=cuda(fx["eps"]), masks=masks)
+        torch.manual_seed(7)
+        zs_f, lds_f = layer.sample_z(500, eps=cuda(recipes.gaussian(88, 500, 800)))
+    assert_close(z_f, fx["z"], RTOL, "fused z vs reference")
+    assert_close(z_f, z_u, 1e-6, "fused vs unfused z")
+    assert_close(ld_f, ld_u, 1e-6, "fused vs unfused log_det")
+    assert_close(zs_f, zs_u, 1e-6, "fused vs unfused z (in-kernel masks)")
+    assert_close(lds_f, lds_u, 1e-6, "fused vs unfused log_det (in-kernel masks)")
     # default path: noise and masks drawn on the device; shapes and finiteness
     z2, ld2 = layer.sample_z(32)
     assert z2.shape == (32, 800) and ld2.shape == (32,) and torch.isfinite(z2).all()

@@ -61,6 +61,8 @@ SIGNATURES = {
                                 c_void_p, c_int64, c_int, c_int, _intp, c_int, c_void_p]),
     "mnf_rnvp_split_layout": (c_int, [c_int, c_int, _intp, _i64p, _i64p]),
     "mnf_rnvp_split_index": (c_int, [c_int, c_int, _intp, _i32p]),
+    "mnf_rnvp_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p, c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_mask": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_rnvp_flat_floats": (c_int64, [c_int, c_int, _intp]),
     "mnf_rnvp_image_floats": (c_int64, [c_int, c_int, _intp]),

@@ -762,6 +762,20 @@ int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int ac
                          force_generic, stream);
 }
 
+// MNFLinear.sample_z with its prologue fused into the first flow (mnf_linear.py:58-64): z0 = q0_mean +
+// sqrt(exp(q0_log_var)) * eps is formed in the RNVP kernel's loads, so z0 is neither written nor re-read.
+int mnf_rnvp_sample(const float* eps, const float* q0_mean, const float* q0_log_var, const float* mask,
+                    uint64_t seed, float* x, float* log_det, int accumulate, const float* image,
+                    const void* split_image, int64_t rows, int dim, int n_hidden, const int* hidden, void* stream) {
+  if (!eps || !q0_mean || !q0_log_var || !x || eps == x || rows < 0 || dim < 1 || n_hidden < 1 ||
+      !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (!image || !split_image) return MNF_ERR_UNSUPPORTED;  // only the split MFMA kernel has the fused prologue
+  if (rows == 0) return MNF_OK;
+  return rnvp_mfma_launch(eps, mask, x, log_det, accumulate, image, split_image, rows, dim, n_hidden, hidden, seed,
+                          (hipStream_t)stream, q0_mean, q0_log_var);
+}
+
 __global__ void rnvp_mask_kernel(uint64_t seed, float* __restrict__ mask, int64_t rows, int dim) {
   const int64_t n = rows * dim, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

@@ -51,6 +51,7 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
 // split_image != nullptr: the split (f16 hi + lo) kernel, with `image` behind it for out-of-range groups
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, const void* split_image, int64_t rows, int dim, int n_hidden,
-                     const int* hidden, uint64_t seed, hipStream_t stream);
+                     const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean = nullptr,
+                     const float* q0_log_var = nullptr);
 
 }  // namespace mnf

@@ -68,7 +68,7 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
                                                const float* __restrict__ z, const float* __restrict__ mask,
                                                float* __restrict__ x, float* __restrict__ log_det,
                                                const float* __restrict__ image, int64_t rows, int d, int accumulate,
-                                               uint64_t seed) {
+                                               uint64_t seed, const float* zprm = nullptr) {
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT, KC = kRnvpChunkK, MC = kRnvpChunkM;
   constexpr int NROW = (KC / 4 > MC ? KC / 4 : MC);  // float4 row loads per chunk
@@ -104,6 +104,13 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
     const float* zr = z + rowc * d + 4 * q;
     const float* mr = SEEDED ? nullptr : mask + rowc * d + 4 * q;
     float* xr = x + rowc * d + 4 * q;
+    // zprm: the sample_z prologue fused into the loads, z = q0_mean + q0_std * eps (mnf_linear.py:59-62)
+    auto load_z = [&](int dim0) -> f32x4 {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + dim0);
+      if (zprm == nullptr) return v;
+      return v * *reinterpret_cast<const f32x4*>(zprm + d + dim0 + 4 * q) +
+             *reinterpret_cast<const f32x4*>(zprm + dim0 + 4 * q);
+    };
     auto mask4 = [&](int dim0) -> f32x4 {  // four consecutive dims share one 32-bit mask word
       if (!SEEDED) return *reinterpret_cast<const f32x4*>(mr + dim0);
       const int dd = dim0 + 4 * q;
@@ -120,7 +127,7 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
       const float4* src = chunk_src(0, n4);
 #pragma unroll
       for (int i = 0; i < NROW; ++i) {
-        zc[i] = *reinterpret_cast<const f32x4*>(zr + row_dim(0, i));
+        zc[i] = load_z(row_dim(0, i));
         mc[i] = mask4(row_dim(0, i));
       }
 #pragma unroll
@@ -145,7 +152,7 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
       const float4* src_next = chunk_src(cn, n4_next);
 #pragma unroll
       for (int i = 0; i < NROW; ++i) {
-        zn[i] = *reinterpret_cast<const f32x4*>(zr + row_dim(cn, i));
+        zn[i] = load_z(row_dim(cn, i));
         mn[i] = mask4(row_dim(cn, i));
       }
 #pragma unroll
@@ -252,6 +259,8 @@ constexpr bool kRnvpNtStore = (MNF_RNVP_NT & 1) != 0, kRnvpNtLoad2 = (MNF_RNVP_N
 #endif
 constexpr int kRnvpAbl = MNF_RNVP_ABL;
 
+constexpr int kRnvpMaxPrologueDim = 1024;  // fused sample_z prologue: mean and std of up to this many dims in LDS
+
 template <int HN>
 struct RnvpSplitShape {
   static constexpr int YT = (HN + 15) / 16;            // 16-unit tiles of y (unit u = 16 m + i)
@@ -274,7 +283,8 @@ template <int HN, bool SEEDED>
 __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
                                                  const float* __restrict__ mask, float* __restrict__ x,
                                                  float* __restrict__ log_det, const uint32_t* __restrict__ simage,
-                                                 int64_t rows, int d, int accumulate, uint64_t seed) {
+                                                 int64_t rows, int d, int accumulate, uint64_t seed,
+                                                 const float* zprm) {
   using S = RnvpSplitShape<HN>;
   constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC, NROW = S::NROW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -316,7 +326,13 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
     const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
     return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
   };
-  auto z4 = [&](int g) -> f32x4 { return *reinterpret_cast<const f32x4*>(zr + 16 * (g < 0 ? 0 : g)); };
+  // zprm != nullptr: the sample_z prologue fused into the loads, z = q0_mean + q0_std * eps
+  auto z_of = [&](const f32x4& v, int g) -> f32x4 {
+    if (zprm == nullptr) return v;
+    const int dd = 16 * (g < 0 ? 0 : g) + 4 * q;
+    return v * *reinterpret_cast<const f32x4*>(zprm + d + dd) + *reinterpret_cast<const f32x4*>(zprm + dd);
+  };
+  auto z4 = [&](int g) -> f32x4 { return z_of(*reinterpret_cast<const f32x4*>(zr + 16 * (g < 0 ? 0 : g)), g); };
   const f32x4 fake4 = f32x4{0.25f, -0.5f, 0.125f, 1.f};
 
   // Row data (z, and the mask when it is an input) comes from HBM with ~2 us of latency under load, while
@@ -417,7 +433,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
     for (int i = 0; i < MC; ++i) {
       const int g2 = row_group(c < nc ? c : nc - 1, i);
-      z2[u][i] = (kRnvpAbl == 2 || kRnvpAbl >= 5) ? fake4 : kRnvpNtLoad2 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zr + 16 * (g2 < 0 ? 0 : g2)))
+      z2[u][i] = (kRnvpAbl == 2 || kRnvpAbl >= 5) ? fake4 : kRnvpNtLoad2 ? z_of(__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zr + 16 * (g2 < 0 ? 0 : g2))), g2)
                               : z4(g2);
       if (!SEEDED) m2[u][i] = mask4(row_group(c < nc ? c : nc - 1, i));
     }
@@ -500,31 +516,42 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 template <int HN, bool SEEDED>
 __device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int grp, const float* z, const float* mask,
                                                              float* x, float* log_det, const float* image,
-                                                             int64_t rows, int d, int accumulate, uint64_t seed) {
+                                                             int64_t rows, int d, int accumulate, uint64_t seed,
+                                                             const float* zprm) {
   rnvp_group_f32<HN, SEEDED>(*reinterpret_cast<float(*)[2][RnvpShape<HN>::CHUNK_FLOATS]>(lds), grp, z, mask, x,
-                             log_det, image, rows, d, accumulate, seed);
+                             log_det, image, rows, d, accumulate, seed, zprm);
 }
 
 template <int HN, bool SEEDED>
 __global__ void __launch_bounds__(kRnvpWaves * 64, 4)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
-                  int64_t rows, int d, int accumulate, uint64_t seed) {
+                  int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
+                  const float* __restrict__ q0_log_var) {
   using S = RnvpSplitShape<HN>;
   using F = RnvpShape<HN>;
   constexpr int WORDS = S::CHUNK_WORDS > F::CHUNK_FLOATS ? S::CHUNK_WORDS : F::CHUNK_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[2][WORDS];
+  // fused sample_z prologue (q0_mean != nullptr: `z` holds eps): mean and std = sqrt(exp(log_var)) per dim
+  __shared__ __attribute__((aligned(16))) float zprm_lds[2 * kRnvpMaxPrologueDim];
+  const float* zprm = nullptr;
+  if (q0_mean != nullptr) {
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      zprm_lds[i] = q0_mean[i];
+      zprm_lds[d + i] = sqrtf(expf(q0_log_var[i]));  // mnf_linear.py:60
+    }
+    zprm = zprm_lds;
+    __syncthreads();
+  }
   // weights outside the f16 range (flagged by the pack kernel): every group on the fp32 path
   const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
   const bool split_ok = wmax <= kSplitWeightLimit;
   const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     if (split_ok && rnvp_group_split<HN, SEEDED>(reinterpret_cast<uint32_t*>(lds[0]), reinterpret_cast<uint32_t*>(lds[1]),
-                                                 grp, z, mask, x, log_det, simage, rows, d, accumulate, seed))
+                                                 grp, z, mask, x, log_det, simage, rows, d, accumulate, seed, zprm))
       continue;
-#ifndef MNF_NO_COLD
-    rnvp_group_f32_cold<HN, SEEDED>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed);
-#endif
+    rnvp_group_f32_cold<HN, SEEDED>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm);
   }
 }
 
@@ -582,7 +609,7 @@ static void build_split_index(int d, int32_t* idx) {
 template <int HN>
 static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
-                             hipStream_t stream) {
+                             const float* q0_mean, const float* q0_log_var, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
   auto resident_of = [](auto kernel) {
     int per_cu = 0, cus = 256, dev = 0;
@@ -602,10 +629,10 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)
     hipLaunchKernelGGL((rnvp_split_kernel<HN, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, simage, image, rows, dim, accumulate, seed);
+                       mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var);
   else
     hipLaunchKernelGGL((rnvp_split_kernel<HN, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, simage, image, rows, dim, accumulate, seed);
+                       mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var);
   return check_launch();
 }
 
@@ -692,8 +719,10 @@ static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
 
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, const void* split_image, int64_t rows, int dim, int n_hidden,
-                     const int* hidden, uint64_t seed, hipStream_t stream) {
+                     const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean,
+                     const float* q0_log_var) {
   if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+  if (q0_mean && (!split_image || !q0_log_var || dim > kRnvpMaxPrologueDim)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) |
        reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(split_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
@@ -701,7 +730,7 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 #define X(HN)            \
   if (hidden[0] == HN)   \
     return launch_rnvp_split<HN>(z, mask, x, log_det, accumulate, static_cast<const uint32_t*>(split_image), image, \
-                                 rows, dim, seed, stream);
+                                 rows, dim, seed, q0_mean, q0_log_var, stream);
     MNF_RNVP_HIDDEN(X)
 #undef X
   }

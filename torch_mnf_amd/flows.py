@@ -606,7 +606,9 @@ class RNVP(_HipFlow):
             _lib.check("mnf_rnvp_mask", _lib.load().mnf_rnvp_mask(int(seed), m.data_ptr(), rows, self.dim, _stream()))
         return m
 
-    def _run(self, z, inverse, accum, mask: Tensor | None = None, seed: int | None = None):
+    def _run(self, z, inverse, accum, mask: Tensor | None = None, seed: int | None = None, prologue=None):
+        """prologue = (q0_mean, q0_log_var): ``z`` holds eps and the layer runs on q0_mean + q0_std * eps formed
+        inside the kernel (MNFLinear.sample_z); returns None when that fused form is not available."""
         if inverse:
             raise AttributeError("RNVP has no inverse (flows/rnvp.py defines forward only)")
         want_grad = accum is None and isinstance(z, Tensor) and z.is_cuda and z.shape[0] > 0 and _wants_grad(self, z)
@@ -622,12 +624,27 @@ class RNVP(_HipFlow):
                 raise ValueError("mask must have the shape of z")
         elif seed is None:  # one draw from torch's global generator per call
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        if want_grad and prologue is not None:
+            return None
         if want_grad:
             flat_g = torch.cat([p.reshape(-1) for p in self._packed_params()])
             return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF)
         flat, image = self._packed(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        if prologue is not None:
+            split = self._split_image(z.device)
+            if image is None or split is None or self.force_generic:
+                return None
+            mean, log_var = prologue
+            rc = _lib.load().mnf_rnvp_sample(
+                z.data_ptr(), mean.data_ptr(), log_var.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF,
+                x.data_ptr(), ld.data_ptr(), int(accum is not None), image.data_ptr(), split.data_ptr(), z.shape[0],
+                self.dim, len(self.h_sizes), self._hid, _stream())
+            if rc == _lib.MNF_ERR_UNSUPPORTED:
+                return None
+            _lib.check("mnf_rnvp_sample", rc)
+            return x, (None if accum is not None else ld)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
             z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
             int(accum is not None), _ptr(flat), _ptr(image), _ptr(self._split_image(z.device)), z.shape[0], self.dim,
@@ -1082,7 +1099,8 @@ class NormalizingFlow(nn.Module):
             self.__dict__["_runs_cache"] = cache
         return cache[1]
 
-    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False):
+    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None):
+        """prologue (forward only, first flow an RNVP): see RNVP._run; the returned list then starts with eps."""
         n = len(self.flows)
         order = list(reversed(self.flows)) if inverse else list(self.flows)
         runs = self._affine_runs() if self.fuse_affine_runs and not _NO_RUN_FUSION_ENV else {}
@@ -1144,6 +1162,12 @@ class NormalizingFlow(nn.Module):
                         and _wants_grad(flow, x):
                     x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
                     log_det = log_det + ld
+                elif prologue is not None and i == 0:
+                    res = flow._run(x, inverse, log_det, prologue=prologue)
+                    if res is None:  # no fused kernel after all: z0 by the formula, then the layer as usual
+                        z0 = prologue[0] + prologue[1].exp().sqrt() * x
+                        res = flow._run(z0, inverse, log_det)
+                    x = res[0]
                 elif fresh and i == 0:
                     x, _ = flow._run(x, inverse, log_det, overwrite=True)  # log_det = ld inside the kernel
                 elif isinstance(flow, _TwoWayFlow) or (isinstance(flow, RNVP) and not inverse):

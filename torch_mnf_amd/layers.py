@@ -37,6 +37,14 @@ class MNFLinear(nn.Module):
         self.r0_b2 = nn.Parameter(small(n_in))
         self.flow_q = NormalizingFlow([RNVP(n_in, h_sizes=h_sizes) for _ in range(n_flows_q)])
         self.flow_r = NormalizingFlow([RNVP(n_in, h_sizes=h_sizes) for _ in range(n_flows_r)])
+        self.fuse_prologue = True  # sample_z: form z0 inside the first flow's kernel when that kernel exists
+
+    def _fused_prologue_ok(self, flow, eps) -> bool:
+        """The first flow's split MFMA kernel can form z0 in its loads (d % 16 == 0, 64 <= d <= 1024, h in {30, 50})."""
+        if self.fuse_prologue is False or torch.is_grad_enabled() and any(p.requires_grad for p in flow.parameters()):
+            return False
+        return (not flow.force_generic and self.n_in <= 1024 and flow._packed(eps.device)[1] is not None
+                and flow._split_image(eps.device) is not None)
 
     # ------------------------------------------------------------------ hot path
     def sample_z(self, batch_size: int = 1, eps: Tensor | None = None, masks=None) -> tuple[Tensor, Tensor]:
@@ -46,7 +54,23 @@ class MNFLinear(nn.Module):
         if eps is None:
             eps = torch.randn(batch_size, self.n_in, device=dev)
         eps = eps.to(dev, torch.float32).contiguous()
-        if torch.is_grad_enabled() and (self.q0_mean.requires_grad or self.q0_log_var.requires_grad):
+        training = torch.is_grad_enabled() and (self.q0_mean.requires_grad or self.q0_log_var.requires_grad)
+        flows = list(self.flow_q.flows)
+        if (not training and eps.shape[0] > 0 and flows and isinstance(flows[0], RNVP)
+                and self._fused_prologue_ok(flows[0], eps)):
+            # the prologue z0 = q0_mean + q0_std eps is formed inside the first flow's kernel: z0 is never stored
+            prologue = (self.q0_mean.detach().contiguous(), self.q0_log_var.detach().contiguous())
+            if masks is None:
+                zs, log_det = self.flow_q._pass(eps, False, prologue=prologue)
+                return zs[-1], log_det.squeeze()
+            log_det = torch.zeros(eps.shape[0], device=dev)
+            res = flows[0]._run(eps, False, log_det, masks[0], prologue=prologue)
+            if res is not None:
+                z = res[0]
+                for flow, m in zip(flows[1:], masks[1:]):
+                    z, _ = flow._run(z, False, log_det, m)
+                return z, log_det.squeeze()
+        if training:
             # training: the two-parameter prologue stays on autograd (it is O(rows*n_in) elementwise)
             z0 = self.q0_mean + self.q0_log_var.exp().sqrt() * eps
         else:
