@@ -805,7 +805,10 @@ def test_g7_rnvp(amd, golden, dim, kernel):
     xs, lds = f.forward(z, seed=1234)
     m = f.mask_for(1234, z.shape[0])
     xm, ldm = f.forward(z, mask=m)
-    assert torch.equal(xs, xm) and torch.equal(lds, ldm)
+    # (the in-kernel-mask path evaluates the same formula in its binary-mask form,
+    #  x = (1 - gate) t + (m ? z : gate z), so the two agree to rounding, not bit for bit)
+    assert_close(xs, xm, 1e-6, "seeded vs explicit mask x")
+    assert_close(lds, ldm, 1e-6, "seeded vs explicit mask log_det")
     assert set(m.unique().tolist()) <= {0.0, 1.0}
 
 

@@ -326,6 +326,19 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
     const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
     return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
   };
+  // in-kernel mask as all-ones / all-zeros words (element r of the lane's float4): one v_bfe_i32 each, so that
+  // m z is an AND and the  m ? z : gated  choice a v_bfi -- the float form costs a convert and a multiply more
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  auto mask_bits = [&](int g) -> i32x4 {
+    if (g < 0) return i32x4{0, 0, 0, 0};
+    const int dd = 16 * g + 4 * q;
+    const int32_t w = (int32_t)(rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31));
+    return i32x4{(int32_t)__builtin_amdgcn_sbfe(w, 0, 1), (int32_t)__builtin_amdgcn_sbfe(w, 1, 1),
+                 (int32_t)__builtin_amdgcn_sbfe(w, 2, 1), (int32_t)__builtin_amdgcn_sbfe(w, 3, 1)};
+  };
+  auto and_bits = [](const f32x4& v, const i32x4& m) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & m);
+  };
   // zprm != nullptr: the sample_z prologue fused into the loads, z = q0_mean + q0_std * eps
   auto z_of = [&](const f32x4& v, int g) -> f32x4 {
     if (zprm == nullptr) return v;
@@ -402,10 +415,13 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
           u32x2 h0, l0, h1, l1;
-          const f32x4 ma = SEEDED ? mask4(row_group(c, 2 * kk)) : m1[SEEDED ? 0 : u][2 * kk];
-          const f32x4 mb = SEEDED ? mask4(row_group(c, 2 * kk + 1)) : m1[SEEDED ? 0 : u][2 * kk + 1];
-          split_tile(ma * z1[u][2 * kk], h0, l0, mx);
-          split_tile(mb * z1[u][2 * kk + 1], h1, l1, mx);
+          if (SEEDED) {
+            split_tile(and_bits(z1[u][2 * kk], mask_bits(row_group(c, 2 * kk))), h0, l0, mx);
+            split_tile(and_bits(z1[u][2 * kk + 1], mask_bits(row_group(c, 2 * kk + 1))), h1, l1, mx);
+          } else {
+            split_tile(m1[SEEDED ? 0 : u][2 * kk] * z1[u][2 * kk], h0, l0, mx);
+            split_tile(m1[SEEDED ? 0 : u][2 * kk + 1] * z1[u][2 * kk + 1], h1, l1, mx);
+          }
           bh[kk] = pair_operand(h0, h1);
           bl[kk] = pair_operand(l0, l1);
         }
@@ -448,7 +464,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
   if (__syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0)) return false;  // nothing has been stored yet
 
   // ---- GEMM 2 + gate, 16 output dims per tile
-  float ld = 0.f;
+  float ld = 0.f, ld2 = 0.f;  // ld2: sum of log2(1 + e^-s) over the gated elements (seeded path)
   for (int c0 = nc1; c0 < nc; c0 += D2) {
 #pragma unroll
     for (int u = 0; u < D2; ++u) {
@@ -481,16 +497,33 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
             }
             const f32x4 t4 = tc * kSplitInvScale + tm + bt[mi];
             const f32x4 s4 = sc * kSplitInvScale + sm + bs[mi];
-            const f32x4 mk = SEEDED ? mask4(m) : m2[SEEDED ? 0 : u][mi];
             f32x4 o;
+            if (SEEDED) {
+              // binary mask: x = (1 - gate) t + (m ? z : gate z);  log_det -= (1 - m) ln(1 + e^-s)   (rnvp.py:36-37;
+              // the shift term reaches the kept elements too)
+              const i32x4 mb = mask_bits(m);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float zz = z2[u][mi][r], mm = mk[r];
-              const float gate = __builtin_amdgcn_rcpf(1.f + exp6r(-s4[r]));
-              const float keep = mm * zz;                            // z2 = m z
-              const float gated = (1.f - mm) * zz;                   // z1 = (1-m) z
-              o[r] = (gated * gate + (1.f - gate) * t4[r]) + keep;   // rnvp.py:37
-              ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);  // :36
+              for (int r = 0; r < 4; ++r) {
+                const float zz = z2[u][mi][r];
+                const float den = 1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f);
+                const float gate = __builtin_amdgcn_rcpf(den);
+                const int32_t mr_ = mb[r];
+                const float zsel = __builtin_bit_cast(float, (mr_ & __builtin_bit_cast(int32_t, zz)) |
+                                                                 (~mr_ & __builtin_bit_cast(int32_t, zz * gate)));
+                o[r] = __builtin_fmaf(-gate, t4[r], t4[r]) + zsel;
+                ld2 += __builtin_bit_cast(float, ~mr_ & __builtin_bit_cast(int32_t, __builtin_amdgcn_logf(den)));
+              }
+            } else {
+              const f32x4 mk = m2[SEEDED ? 0 : u][mi];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float zz = z2[u][mi][r], mm = mk[r];
+                const float gate = __builtin_amdgcn_rcpf(1.f + exp6r(-s4[r]));
+                const float keep = mm * zz;                            // z2 = m z
+                const float gated = (1.f - mm) * zz;                   // z1 = (1-m) z
+                o[r] = (gated * gate + (1.f - gate) * t4[r]) + keep;   // rnvp.py:37
+                ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);  // :36
+              }
             }
             if (live && ((kRnvpAbl != 1 && kRnvpAbl < 5) || o[0] == 1.2345e30f)) {
               if (kRnvpNtStore) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xr + 16 * m));
@@ -505,7 +538,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
     }
   }
   if (log_det) {
-    ld = sum_over_q(ld);
+    ld = sum_over_q(ld - 0.693147180559945309f * ld2);
     if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
   }
   return true;
