@@ -336,10 +336,14 @@ def main() -> None:
         torch.cuda.synchronize()
         t_prime = time.perf_counter()
         primed = 0
+        # (time-based, so ranks may run different numbers of passes: the priming pass is the local work only,
+        #  WITHOUT the all-reduce of step() -- a collective here would deadlock ranks that disagree on the count)
         while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
-            step()
+            model.log_prob(x, return_sum=True)
             torch.cuda.synchronize()
             primed += 1
+        if world > 1:
+            dist.barrier()
         # CPython's cyclic collector fires at a fixed allocation count, i.e. at the same layer of the
         # same step in every run, and a full collection of a process that has imported torch takes
         # ~70 ms: collect now and keep it off for the warm-up and timed steps.
