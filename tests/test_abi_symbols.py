@@ -212,3 +212,24 @@ def test_affine_half_gradient_index_tables(lib, dim, hid):
     assert np.array_equal(counts, np.ones(n_params, dtype=counts.dtype))
     head = a[:-flush]
     assert np.array_equal(np.unique(head[head >= 0]), np.arange(n_params))
+
+
+def test_cached_parameter_walk_matches_module_parameters():
+    """_HipFlow._net_params caches the module walk; it must return exactly list(net.parameters()) and notice a
+    replaced layer or parameter."""
+    import torch
+    from torch import nn
+    import torch_mnf_amd as amd
+
+    f = amd.AffineHalfFlow(8, True)
+    want = lambda: list(f.s_net.parameters()) + list(f.t_net.parameters())  # noqa: E731
+    assert [id(p) for p in f._packed_params()] == [id(p) for p in want()]
+    f.s_net[0] = nn.Linear(4, 24)                       # replaced child module
+    assert [id(p) for p in f._packed_params()] == [id(p) for p in want()]
+    f.t_net[2].weight = nn.Parameter(torch.zeros(24, 24))  # replaced parameter
+    assert [id(p) for p in f._packed_params()] == [id(p) for p in want()]
+    r = amd.RNVP(16, h_sizes=(30,))
+    assert [id(p) for p in r._packed_params()] == [id(p) for p in
+                                                   list(r.net.parameters()) + list(r.t.parameters()) + list(r.s.parameters())]
+    n = amd.NSF_CL(4, K=5, n_h=8)
+    assert [id(p) for p in n._packed_params()] == [id(p) for p in list(n.f1.parameters()) + list(n.f2.parameters())]

@@ -313,6 +313,20 @@ class _HipFlow(nn.Module):
     def _packed_params(self) -> list[Tensor]:
         return [p for p in self.parameters()]
 
+    def _net_params(self, nets: Sequence[nn.Module]) -> list[Tensor]:
+        """``[p for net in nets for p in net.parameters()]`` without walking the module tree on every call (a
+        small-batch pass otherwise spends most of its host time in nn.Module.parameters()).  The walk is cached
+        per set of nets and their direct children -- the MLP / Linear conditioners of this package; any other
+        module type takes the plain walk."""
+        if not all(type(n) in (MLP, nn.Linear) for n in nets):
+            return [p for n in nets for p in n.parameters()]
+        sig = tuple(id(c) for n in nets for c in (n, *n._modules.values()))
+        cache = self.__dict__.get("_net_param_cache")
+        if cache is None or cache[0] != sig:
+            cache = (sig, [m for n in nets for m in n.modules()])
+            self.__dict__["_net_param_cache"] = cache
+        return [p for m in cache[1] for p in m._parameters.values() if p is not None]
+
     def _image_index_host(self):  # -> ctypes int32 array or None
         return None
 
@@ -325,6 +339,12 @@ class _HipFlow(nn.Module):
             return None
         self._packed(device)
         return self._split
+
+    def _packed3(self, device: torch.device):
+        """(flat, image, split image) with ONE walk over the parameters (the walk is what a small-batch call
+        spends its host time on)."""
+        flat, image = self._packed(device)
+        return flat, image, (None if (self.force_fp32_mfma or _FP32_MFMA_ENV) else self._split)
 
     def _packed(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
         params = self._packed_params()
@@ -397,12 +417,7 @@ class AffineHalfFlow(_TwoWayFlow):
         self._hid = _lib.int_array(self.h_sizes)
 
     def _packed_params(self) -> list[Tensor]:
-        out: list[Tensor] = []
-        if self.scale:
-            out += list(self.s_net.parameters())
-        if self.shift:
-            out += list(self.t_net.parameters())
-        return out
+        return self._net_params(([self.s_net] if self.scale else []) + ([self.t_net] if self.shift else []))
 
     def _image_index_host(self):
         lib = _lib.load()
@@ -458,12 +473,12 @@ class AffineHalfFlow(_TwoWayFlow):
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         if x.shape[0] == 0:
             return _empty_result(x, accum)
-        flat, image = self._packed(x.device)
+        flat, image, split = self._packed3(x.device)
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_affine_half_sq", _lib.load().mnf_affine_half_sq(
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None and not overwrite),
-            _ptr(flat), _ptr(image), _ptr(self._split_image(x.device)), x.shape[0], self.dim, int(bool(self.parity)),
+            _ptr(flat), _ptr(image), _ptr(split), x.shape[0], self.dim, int(bool(self.parity)),
             int(inverse), len(self.h_sizes),
             self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
@@ -491,7 +506,7 @@ class NSF_CL(_TwoWayFlow):
         self._hid = _lib.int_array(self.h_sizes)
 
     def _packed_params(self) -> list[Tensor]:
-        return list(self.f1.parameters()) + list(self.f2.parameters())
+        return self._net_params([self.f1, self.f2])
 
     def _image_index_host(self):
         lib = _lib.load()
@@ -528,12 +543,12 @@ class NSF_CL(_TwoWayFlow):
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         if x.shape[0] == 0:
             return _empty_result(x, accum)
-        flat, image = self._packed(x.device)
+        flat, image, split = self._packed3(x.device)
         y = torch.empty_like(x)
         ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         _lib.check("mnf_nsf_cl", _lib.load().mnf_nsf_cl(
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
-            _ptr(self._split_image(x.device)),
+            _ptr(split),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
             int(self.force_generic), _stream()))
         return y, (None if accum is not None else ld)
@@ -577,7 +592,7 @@ class RNVP(_HipFlow):
         self._hid = _lib.int_array(self.h_sizes)
 
     def _packed_params(self) -> list[Tensor]:
-        return list(self.net.parameters()) + list(self.t.parameters()) + list(self.s.parameters())
+        return self._net_params([self.net, self.t, self.s])
 
     def _image_index_host(self):
         lib = _lib.load()
@@ -629,11 +644,10 @@ class RNVP(_HipFlow):
         if want_grad:
             flat_g = torch.cat([p.reshape(-1) for p in self._packed_params()])
             return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF)
-        flat, image = self._packed(z.device)
+        flat, image, split = self._packed3(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         if prologue is not None:
-            split = self._split_image(z.device)
             if image is None or split is None or self.force_generic:
                 return None
             mean, log_var = prologue
@@ -647,7 +661,7 @@ class RNVP(_HipFlow):
             return x, (None if accum is not None else ld)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
             z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
-            int(accum is not None), _ptr(flat), _ptr(image), _ptr(self._split_image(z.device)), z.shape[0], self.dim,
+            int(accum is not None), _ptr(flat), _ptr(image), _ptr(split), z.shape[0], self.dim,
             len(self.h_sizes), self._hid, int(self.force_generic), _stream()))
         return x, (None if accum is not None else ld)
 
@@ -958,6 +972,8 @@ class _AffineRun:
             splits = [f._split_image(device) for f in self.layers]
             self._splits = None if any(i is None for i in splits) else torch.cat(splits).contiguous()
             self._key = key
+            if self._images is None:  # the shape has no specialised kernel at all: a static property
+                self._unsupported = True
         return self._images, self._splits
 
     def usable(self, x) -> bool:
