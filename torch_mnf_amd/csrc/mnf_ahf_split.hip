@@ -184,15 +184,20 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
 // ------------------------------------------------------------------------------------------------
 // L layers per launch, rows kept in registers across layers.  Compute bound (no per-layer HBM read), and
 // inside the conditioner the co-bottleneck is LDS: a wave re-reads 30 KB of operands per 16 rows per
-// layer.  So a wave owns kStackTiles (2) row tiles that share every operand read, a workgroup has
-// kStackWaves (4) waves -- one per SIMD, two workgroups per CU -- and the next layer's split image is
+// layer.  So (d <= 64) a wave owns two row tiles that share every operand read, a workgroup has
+// four waves -- one per SIMD, two workgroups per CU -- and the next layer's split image is
 // copied L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into the other half of
 // a double buffer while the current layer computes; one barrier per layer.
 // mid != nullptr: the output of every layer but the last goes to mid[li] (application order): each
 // intermediate tensor is written once and never re-read.
 // ------------------------------------------------------------------------------------------------
-constexpr int kStackWaves = 4;
-constexpr int kStackTiles = 2;
+// d <= 64: two row tiles per wave (shared operand reads), four waves, two workgroups per CU.
+// d >= 128: the rows of ONE tile already take 32-64 VGPRs and the double-buffered image 90-150 KB of LDS:
+// one tile per wave, eight waves sharing the image, one workgroup per CU (still two waves per SIMD).
+template <int H>
+constexpr int stack_tiles() { return H <= 32 ? 2 : 1; }
+template <int H>
+constexpr int stack_waves() { return H <= 32 ? 4 : 8; }
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // Image copy L2 -> LDS by LDS-DMA (no staging registers).  One wave-instruction copies 64 x 16 B; the LDS
@@ -210,17 +215,23 @@ __device__ __forceinline__ void image_to_lds_async(const uint4* src, uint32_t* d
 }
 
 template <int H, int HID, bool INV>
-__global__ void __launch_bounds__(kStackWaves * 64, 2)
+__global__ void __launch_bounds__(stack_waves<H>() * 64, 2)
 ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
                        float* __restrict__ log_det, float* __restrict__ ysq, const uint32_t* __restrict__ simages,
                        const float* __restrict__ images_f32, uint32_t parity_bits, int n_layers, int64_t rows,
                        int accumulate) {
   using S = SplitShape<H, HID>;
-  constexpr int G = S::G, dim = 2 * H, NTL = kStackTiles;
+  constexpr int G = S::G, dim = 2 * H, NTL = stack_tiles<H>(), kStackWaves = stack_waves<H>();
   constexpr int IMG4 = S::IMAGE_WORDS / 4;
   constexpr int F32_FLOATS = AhfShape<H, HID>::IMAGE_FLOATS;
   constexpr int GROUP_ROWS = 16 * NTL * kStackWaves;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2][S::IMAGE_WORDS];
+  // two images: static LDS while they fit the 64 KB static limit (the compiler folds constant LDS addresses
+  // into the operand reads: measured 755 vs 900 us for the d = 64 pass), dynamic LDS above it
+  constexpr bool kStaticLds = 2 * S::IMAGE_WORDS * sizeof(uint32_t) <= 64 * 1024;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_static[kStaticLds ? 2 * S::IMAGE_WORDS : 4];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  uint32_t* const lds_base = kStaticLds ? lds_static : lds_dyn;
+  auto lds_buf = [&](int k) -> uint32_t* { return lds_base + (k & 1) * S::IMAGE_WORDS; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const uint4* img4 = reinterpret_cast<const uint4*>(simages);
@@ -243,7 +254,7 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
       for (int g = 0; g < G; ++g) hi[t][g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
     }
     __syncthreads();  // the previous group's last layer is fully consumed
-    image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(0) * IMG4, lds[0], lane, wave);
+    image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(0) * IMG4, lds_buf(0), lane, wave);
     __syncthreads();  // (hipcc drains vmcnt before a barrier: image and rows have landed)
     float ld[NTL];
 #pragma unroll
@@ -251,8 +262,8 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
     for (int li = 0; li < n_layers; ++li) {
       const int layer = layer_at(li);
       if (li + 1 < n_layers)  // next layer's image into the other buffer, in flight under this layer's math
-        image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(li + 1) * IMG4, lds[(li + 1) & 1], lane, wave);
-      const uint32_t* img = lds[li & 1];
+        image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(li + 1) * IMG4, lds_buf(li + 1), lane, wave);
+      const uint32_t* img = lds_buf(li);
       const float* f32img = images_f32 + (int64_t)layer * F32_FLOATS;
       f32x4 s4[NTL][G], t4[NTL][G];
       // The rows as they stand at the top of this layer are the previous layer's output, i.e. intermediate
@@ -427,25 +438,35 @@ template <int H, int HID>
 static int launch_split_stack(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                               const uint32_t* simages, const float* images, uint32_t parity_bits, int n_layers,
                               int64_t rows, int inverse, hipStream_t stream) {
+  constexpr int kStackWaves = stack_waves<H>(), kStackTiles = stack_tiles<H>();
+  constexpr size_t image_bytes = 2 * SplitShape<H, HID>::IMAGE_WORDS * sizeof(uint32_t);
+  constexpr size_t lds_bytes = image_bytes <= 64 * 1024 ? 0 : image_bytes;  // dynamic part (see the kernel)
   static const int resident = [] {
     int per_cu = 0, cus = 256, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ahf_split_stack_kernel<H, HID, true>, kStackWaves * 64,
-                                                     0) != hipSuccess || per_cu < 1)
-      per_cu = 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return 0;
+    // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
+    // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
+    per_cu = 8 / kStackWaves;
+    while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
     return per_cu * cus;
   }();
+  if (resident == 0) return MNF_ERR_UNSUPPORTED;
   constexpr int GROUP_ROWS = 16 * kStackTiles * kStackWaves;
   const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
   const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);
   if (inverse)
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, mid, log_det, ysq,
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, y, mid, log_det, ysq,
                        simages, images, parity_bits, n_layers, rows, accumulate);
   else
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, 0, stream, x, y, mid, log_det, ysq,
-                       simages, images, parity_bits, n_layers, rows, accumulate);
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, y, mid, log_det,
+                       ysq, simages, images, parity_bits, n_layers, rows, accumulate);
   return check_launch();
 }
 
