@@ -378,20 +378,21 @@ static void build_split_index(int32_t* idx) {
         }
         ++op;
       }
-  for (int nn = 0; nn < 2; ++nn)
-    for (int ks = 0; ks < NKS; ++ks) {
-      if (!S::uses(1 << nn, ks)) continue;
-      for (int g = 0; g < G; ++g, ++op)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int i = lane & 15, kq = lane >> 4;
-          for (int e = 0; e < 8; ++e) {
-            int tile;
-            const int ui = unit_in(ks, kq, e, tile);
-            if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks) continue;
-            put(lane, e, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+  for (int g0 = 0; g0 < G; g0 += S::GC)  // output operands: chunk, net, K-step, tile (split_conditioner's order)
+    for (int nn = 0; nn < 2; ++nn)
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (!S::uses(1 << nn, ks)) continue;
+        for (int g = g0; g < g0 + S::GC; ++g, ++op)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kq = lane >> 4;
+            for (int e = 0; e < 8; ++e) {
+              int tile;
+              const int ui = unit_in(ks, kq, e, tile);
+              if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks) continue;
+              put(lane, e, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+            }
           }
-        }
-    }
+      }
   // biases: [tile][row i], fp32
   int32_t* b = idx + 2 * (int64_t)S::SPLIT_WORDS;
   int bt = 0;

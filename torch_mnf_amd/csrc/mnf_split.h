@@ -32,10 +32,6 @@
 
 #include "mnf_ahf_shape.h"
 
-#ifndef MNF_SPLIT_PRE_OUT
-#define MNF_SPLIT_PRE_OUT 0  // preloading the output-layer operands too spills at 256 VGPRs (measured: slower)
-#endif
-
 namespace mnf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -123,6 +119,8 @@ template <int H, int HID>
 struct SplitShape {
   static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported conditioner shape");
   static constexpr int G = H / 16;                 // 16-dim groups per half row = output tiles per net
+  static constexpr int GC = G < 4 ? G : 4;         // output tiles per chunk (operand order: chunk, net, K-step, tile)
+  static_assert(G % GC == 0, "output tiles come in whole chunks");
   static constexpr int KS1 = (G + 1) / 2;          // K-steps of the first layer
   static constexpr int NT = (2 * HID + 15) / 16;   // tiles of the concatenated hidden vector
   static constexpr int NKS = (NT + 1) / 2;         // hidden K-steps
@@ -188,6 +186,9 @@ struct SplitShape {
 struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
+struct NoEmit {
+  static constexpr bool enabled = false;
+};
 
 // NTL row tiles (16 rows each) share every A-operand read: the weights come out of LDS once per NTL
 // tiles (LDS bandwidth, not the matrix pipe, is the co-bottleneck of the conditioner: 30 KB of operands
@@ -195,10 +196,11 @@ struct NoHook {
 // there on: the single-layer kernel issues its prefetch of the next tile there); at_stage(1..3) after each
 // of the three activation blocks (the stack kernel spreads its intermediate-tensor stores over them).
 // ABL != 0 only in tools/split_microbench.hip (1 = MFMAs skipped, 3 = operand splitting skipped).
-template <int H, int HID, int NTL = 1, typename Hook = NoHook, int ABL = 0>
+template <int H, int HID, int NTL = 1, typename Hook = NoHook, int ABL = 0, typename Emit = NoEmit>
 __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane, int q,
                                                   const f32x4 (&cnd)[NTL][H / 16], f32x4 (&s4)[NTL][H / 16],
-                                                  f32x4 (&t4)[NTL][H / 16], float& mx, Hook at_stage = Hook()) {
+                                                  f32x4 (&t4)[NTL][H / 16], float& mx, Hook at_stage = Hook(),
+                                                  Emit emit = Emit()) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
   // opaque offsets: keep the (loop-invariant) operand reads inside the tile loop instead of in VGPRs
@@ -249,7 +251,6 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
   // just in front of its MFMA to save registers and exposes ~100 cycles per operand).  sched_barrier(0)
   // pins the three blocks [reads][vector work][MFMAs] in that order.
   constexpr bool PRE = NTL >= 2;
-  constexpr bool PRE_OUT = PRE && MNF_SPLIT_PRE_OUT;  // output layer operands too
   auto fence = [] {
     if (PRE) __builtin_amdgcn_sched_barrier(0);
   };
@@ -358,73 +359,66 @@ __device__ __forceinline__ void split_conditioner(const uint32_t* img, int lane,
     }
   }
 
-  // ---- output layer: s from the s-net units, t from the t-net units; output tiles in chunks of GC so that
-  // at d = 256 (G = 8) not all sixteen operands of a K-step are live at once
-  constexpr int GC = G < 4 ? G : 4;
-  static_assert(G % GC == 0, "output tiles come in whole chunks");
-  f16x8 aoh[2][NKS][G], aol[2][NKS][G];
-  f32x4 biaso[2][G];
-  auto read_bias_out = [&](int net) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) biaso[net][g] = B4[4 * (bt++)];
-  };
-  auto read_output = [&](int net, int ks, int g0) {
-#pragma unroll
-    for (int g = 0; g < GC; ++g) {
-      aoh[net][ks][g0 + g] = A8[64 * (2 * op)];
-      aol[net][ks][g0 + g] = A8[64 * (2 * op + 1)];
-      ++op;
-    }
-  };
-  if (PRE_OUT) {
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
-      read_bias_out(net);
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        if (S::uses(1 << net, ks))
-#pragma unroll
-          for (int g0 = 0; g0 < G; g0 += GC) read_output(net, ks, g0);
-    }
-  }
+  // ---- output layer: s from the s-net units, t from the t-net units, in chunks of GC output tiles (operand
+  // order in the image: chunk, net, K-step, tile).  With an Emit consumer (d = 256: the sixteen s/t tiles of a
+  // row would take 128 VGPRs) a chunk's s and t are handed over as soon as they are complete and s4 / t4
+  // are not written; emit.abort(mx) is asked first, with the final max|operand|, whether the caller wants
+  // the fp32 path instead (the range guard has to be settled before anything is consumed).
+  constexpr int GC = S::GC;
   fence();
   activate();
   at_stage(3);
   fence();
+  if constexpr (Emit::enabled) {
+    if (emit.abort(mx)) return;
+  }
 #pragma unroll
-  for (int net = 0; net < 2; ++net) {
-    if (!PRE_OUT) read_bias_out(net);
-    f32x4(&out)[NTL][G] = net ? t4 : s4;
-    f32x4 oc[NTL][G];
+  for (int g0 = 0; g0 < G; g0 += GC) {
+    f32x4 chunk[2][NTL][GC];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int net = 0; net < 2; ++net) {
+      f32x4 oc[NTL][GC];
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) {
-        out[t][g] = biaso[net][g];
-        oc[t][g] = zero4;
-      }
+      for (int g = 0; g < GC; ++g) {
+        const f32x4 bias = B4[4 * (3 * NT + net * G + g0 + g)];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      if (S::uses(1 << net, ks)) {
-        f16x8 bh[NTL], bl[NTL];
-        hidden_operand(hh, ks, bh);
-        hidden_operand(hl, ks, bl);
-#pragma unroll
-        for (int g0 = 0; g0 < G; g0 += GC) {
-          if (!PRE_OUT) read_output(net, ks, g0);
-          f16x8 ah[GC], al[GC];
-#pragma unroll
-          for (int g = 0; g < GC; ++g) {
-            ah[g] = aoh[net][ks][g0 + g];
-            al[g] = aol[net][ks][g0 + g];
-          }
-          split_mac_phased_impl(std::integral_constant<int, GC>{}, ah, al, bh, bl, out, oc, [](int) { return true; }, g0);
+        for (int t = 0; t < NTL; ++t) {
+          chunk[net][t][g] = bias;
+          oc[t][g] = zero4;
         }
       }
 #pragma unroll
-    for (int t = 0; t < NTL; ++t)
+      for (int ks = 0; ks < NKS; ++ks)
+        if (S::uses(1 << net, ks)) {
+          f16x8 bh[NTL], bl[NTL];
+          hidden_operand(hh, ks, bh);
+          hidden_operand(hl, ks, bl);
+          f16x8 ah[GC], al[GC];
 #pragma unroll
-      for (int g = 0; g < G; ++g) out[t][g] = oc[t][g] * kSplitInvScale + out[t][g];
+          for (int g = 0; g < GC; ++g) {
+            ah[g] = A8[64 * (2 * op)];
+            al[g] = A8[64 * (2 * op + 1)];
+            ++op;
+          }
+          split_mac_phased_impl(std::integral_constant<int, GC>{}, ah, al, bh, bl, chunk[net], oc,
+                                [](int) { return true; });
+        }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int g = 0; g < GC; ++g) chunk[net][t][g] = oc[t][g] * kSplitInvScale + chunk[net][t][g];
+    }
+    if constexpr (Emit::enabled) {
+      emit(g0, chunk[0], chunk[1]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int g = 0; g < GC; ++g) {
+          s4[t][g0 + g] = chunk[0][t][g];
+          t4[t][g0 + g] = chunk[1][t][g];
+        }
+    }
   }
 }
 
