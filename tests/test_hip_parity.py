@@ -280,6 +280,29 @@ def test_split_kernel_range_guard(amd, O, case):
     assert_close(ld[rows_ok.to(DEV)], ref_ld[rows_ok], 3 * RTOL, f"{case} stack ld")
 
 
+@pytest.mark.parametrize("dim", [128, 256])
+def test_wide_stack_kernel_range_guard(amd, O, dim):
+    """d = 128 / 256 runs (one tile per wave; at 256 s and t are consumed chunk by chunk): rows outside the
+    f16 range take the fp32 path inside the same launch."""
+    sd = recipes.affine_half_params(320 + dim, dim)
+    sd = {k: (v * 1e-3 if k.endswith(".0.weight") else v) for k, v in sd.items()}
+    x = recipes.gaussian(321, 300, dim).clone()
+    x[17] *= 5e4
+    x[200:216] *= 2e4
+    flows = [ahf_module(amd, sd, dim, bool(i % 2), "split") for i in range(3)]
+    model = amd.NormalizingFlow(flows).to(DEV)
+    with torch.no_grad():
+        zs, ld = model.inverse(cuda(x))
+    assert zs[1].data_ptr() + zs[1].numel() * 4 == zs[2].data_ptr()  # one launch wrote all three
+    ref, ref_ld = x, 0
+    for i in reversed(range(3)):
+        ref, l1 = O.affine_half(ref, sd, bool(i % 2), True)
+        ref_ld = ref_ld + l1
+    ok = torch.isfinite(ref).all(1)
+    assert_close(zs[-1][ok.to(DEV)], ref[ok], 3 * RTOL, "z")
+    assert_close(ld[ok.to(DEV)], ref_ld[ok], 3 * RTOL, "log_det")
+
+
 def test_empty_batches(amd):
     f = ahf_module(amd, recipes.affine_half_params(1, 64), 64, False)
     y, ld = f.forward(torch.empty(0, 64, device=DEV))
@@ -459,7 +482,7 @@ def test_fused_affine_stack_matches_layer_by_layer(amd, golden, O, dim):
 
 
 @pytest.mark.parametrize("kernel", ["split", "fp32"])
-@pytest.mark.parametrize("dim", [64, 32, 128])
+@pytest.mark.parametrize("dim", [64, 32, 128, 256])
 def test_run_fusion_keeps_every_intermediate(amd, dim, kernel):
     """NormalizingFlow sends a run of equal AffineHalfFlow layers out as ONE launch that still writes every
     intermediate: same list of tensors, same log_det as launching the layers one by one."""
@@ -476,7 +499,7 @@ def test_run_fusion_keeps_every_intermediate(amd, dim, kernel):
             model.fuse_affine_runs = False
             zs_u, ld_u = getattr(model, direction)(x)
             assert len(zs_f) == len(zs_u) == len(layers) + 1
-            if dim <= 64:  # one buffer holds the run's outputs
+            if kernel == "split" or dim <= 64:  # one launch: one buffer holds the run's outputs
                 assert zs_f[1].data_ptr() + zs_f[1].numel() * 4 == zs_f[2].data_ptr()
             for i, (a, b) in enumerate(zip(zs_f, zs_u)):
                 assert_close(a, b, 1e-6, f"{direction} tensor {i}")

@@ -282,15 +282,48 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
           }
         }
       };
-      if ((parity_bits >> layer) & 1u) {  // conditioner = upper half
-        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, hi, s4, t4, store_previous);
+      // one coupling layer on the rows in registers: cnd_rows condition, act_rows are transformed
+      auto run_layer = [&](const f32x4 (&cnd_rows)[NTL][G], f32x4 (&act_rows)[NTL][G]) {
+        if constexpr (G > S::GC) {
+          // d = 256: s and t are consumed chunk by chunk (all sixteen tiles of a row would take 128 VGPRs)
+          bool cold = false;
+          float mx = split_guard_seed(__builtin_bit_cast(float, img[S::SPLIT_WORDS + S::PLAIN_WORDS]));
+          auto emit = make_chunk_emit(
+              [&](float m) { return cold = wave_any(!(m <= kSplitLimit)); },
+              [&](int g0, const f32x4 (&sc)[NTL][S::GC], const f32x4 (&tc)[NTL][S::GC]) {
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], lo[t]);
-      } else {
-        ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, lo, s4, t4, store_previous);
+                for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], hi[t]);
-      }
+                  for (int g = 0; g < S::GC; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                      const float sv = sc[t][g][r], tv = tc[t][g][r];
+                      const float e = exp6(INV ? -sv : sv);
+                      const float a = act_rows[t][g0 + g][r];
+                      act_rows[t][g0 + g][r] = INV ? (a - tv) * e : __builtin_fmaf(e, a, tv);
+                      ld[t] += sv;
+                    }
+              });
+          split_conditioner<H, HID, NTL, decltype(store_previous), 0, decltype(emit)>(img, lane, q, cnd_rows, s4, t4, mx,
+                                                                                   store_previous, emit);
+          if (__builtin_expect(cold, 0)) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+              CondIn<G> in;
+#pragma unroll
+              for (int g = 0; g < G; ++g) in.c[g] = cnd_rows[t][g];
+              const CondOut<G> out = ahf_cond_f32_cold<H, HID>(f32img, lane, q, in);
+              ld[t] += ahf_transform<H, INV>(out.s, out.t, act_rows[t]);
+            }
+          }
+        } else {
+          ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, cnd_rows, s4, t4, store_previous);
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], act_rows[t]);
+        }
+      };
+      if ((parity_bits >> layer) & 1u) run_layer(hi, lo);  // conditioner = upper half
+      else run_layer(lo, hi);
       if (li + 1 < n_layers) {
         // End of layer: the next image (LDS-DMA, issued before this layer's math) must have landed before the
         // barrier.  vmcnt(0) also covers this layer's staged stores; the last of them was issued a quarter of
@@ -473,7 +506,7 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
 
 // (H, HID) pairs with a split kernel; the stack kernel exists for the first four
 #define MNF_AHF_SPLIT_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
-#define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16)
+#define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24)
 
 static bool uniform3(int n_hidden, const int* hidden, int& hid) {
   if (n_hidden != 3 || !hidden) return false;

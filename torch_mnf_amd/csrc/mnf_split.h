@@ -189,6 +189,21 @@ struct NoHook {
 struct NoEmit {
   static constexpr bool enabled = false;
 };
+// per-chunk consumer of the output layer: abort_fn(mx) -> true = the caller takes the fp32 path instead;
+// fn(g0, s_chunk, t_chunk) gets the raw s and t of output tiles g0 .. g0 + GC - 1
+template <typename AbortFn, typename Fn>
+struct ChunkEmit {
+  static constexpr bool enabled = true;
+  AbortFn abort_fn;
+  Fn fn;
+  __device__ __forceinline__ bool abort(float mx) { return abort_fn(mx); }
+  template <typename SC, typename TC>
+  __device__ __forceinline__ void operator()(int g0, const SC& s, const TC& t) { fn(g0, s, t); }
+};
+template <typename AbortFn, typename Fn>
+__device__ __forceinline__ ChunkEmit<AbortFn, Fn> make_chunk_emit(AbortFn a, Fn f) {
+  return ChunkEmit<AbortFn, Fn>{a, f};
+}
 
 // NTL row tiles (16 rows each) share every A-operand read: the weights come out of LDS once per NTL
 // tiles (LDS bandwidth, not the matrix pipe, is the co-bottleneck of the conditioner: 30 KB of operands
