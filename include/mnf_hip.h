@@ -95,10 +95,13 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
  * the last in application order -- each intermediate tensor is then written once and never re-read
  * (4*dim*(n_layers+1) + 8 bytes per row for the stack instead of (8*dim+8)*n_layers), which is how
  * NormalizingFlow.forward/inverse run a chain of equal AffineHalfFlow layers while still returning all
- * of them.  HBM traffic with intermediates == NULL: 8*dim + 8 bytes per row for the whole stack.  MNF_ERR_UNSUPPORTED for shapes
+ * of them.  HBM traffic with intermediates == NULL: 8*dim + 8 bytes per row for the whole stack.
+ * log_prob (rows,) / log_prob_sum (device double, ADDED to; caller zeroes it), both optional (split kernel only,
+ * need log_det): the standard-normal base log-prob epilogue log_det - |y|^2/2 - dim/2 log(2 pi) of
+ * mnf_gauss_logprob fused into the same launch (when the stack is the whole inverse pass of a model).  MNF_ERR_UNSUPPORTED for shapes
  * without a fused kernel (dim in {32, 64}, hidden (24,24,24) or (16,16,16)). */
 int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float* log_det, float* y_sqnorm,
-                          int accumulate,
+                          float* log_prob, double* log_prob_sum, int accumulate,
                           const float* images, const void* split_images, const int* parity_host, int n_layers,
                           int64_t rows, int dim, int inverse,
                           int n_hidden, const int* hidden_host, void* stream);

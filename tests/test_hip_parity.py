@@ -506,10 +506,16 @@ def test_run_fusion_keeps_every_intermediate(amd, dim, kernel):
             assert_close(ld_f, ld_u, 1e-6, f"{direction} log_det")
         model.fuse_affine_runs = True
         lp_f, tot_f = model.log_prob(x, return_sum=True)
+        # the split stack kernel also does the standard-normal epilogue (log p and its fp64 sum) in the same launch
+        assert model._logprob_done == (kernel == "split")
+        lp_only = model.log_prob(x)
         model.fuse_affine_runs = False
         lp_u, tot_u = model.log_prob(x, return_sum=True)
+        assert not model._logprob_done
     assert_close(lp_f, lp_u, 1e-6, "log_prob")
+    assert torch.equal(lp_only, lp_f)
     assert abs(float(tot_f) - float(tot_u)) <= 1e-6 * abs(float(tot_u))
+    assert abs(float(tot_f) - float(lp_f.double().sum())) <= 1e-9 * abs(float(tot_f))
 
 
 def test_run_fusion_in_mixed_stacks(amd):

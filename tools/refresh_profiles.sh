@@ -13,6 +13,7 @@ python bench.py --workload c2f --no-cpu-baseline > "$OUT/c2_fused_stack_optin_be
 python bench.py --workload c3f --no-cpu-baseline > "$OUT/c3_fused_optin_bench.json" 2>/dev/null
 MNF_NO_RUN_FUSION=1 python bench.py --no-cpu-baseline > "$OUT/c2_layer_by_layer_bench.json" 2>/dev/null
 MNF_NO_RUN_FUSION=1 python bench.py --workload c3 --no-cpu-baseline > "$OUT/c3_layer_by_layer_bench.json" 2>/dev/null
+MNF_NO_RUN_FUSION=1 python bench.py --workload c4 --no-cpu-baseline > "$OUT/c4_layer_by_layer_bench.json" 2>/dev/null
 MNF_FP32_MFMA=1 python bench.py --no-cpu-baseline > "$OUT/fp32_mfma/c2_bench_same_build.json" 2>/dev/null
 MNF_FP32_MFMA=1 MNF_NO_RUN_FUSION=1 python bench.py --no-cpu-baseline > "$OUT/fp32_mfma/c2_layer_by_layer_bench_same_build.json" 2>/dev/null
 MNF_FP32_MFMA=1 python bench.py --workload c5 --no-cpu-baseline > "$OUT/fp32_mfma/c5_bench_same_build.json" 2>/dev/null

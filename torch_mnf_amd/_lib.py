@@ -34,7 +34,7 @@ SIGNATURES = {
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
     "mnf_affine_half_sq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
-    "mnf_affine_half_stack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, _intp, c_int,
+    "mnf_affine_half_stack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, _intp, c_int,
                                       c_int64, c_int, c_int, c_int, _intp, c_void_p]),
     "mnf_affine_half_split_layout": (c_int, [c_int, c_int, _intp, c_int, c_int, _i64p, _i64p]),
     "mnf_affine_half_split_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),

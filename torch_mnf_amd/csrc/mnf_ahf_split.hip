@@ -15,6 +15,10 @@
 #include "mnf_host.h"
 #include "mnf_split.h"
 
+#ifndef MNF_LP_EPILOGUE
+#define MNF_LP_EPILOGUE 1  // experiment switch: 0 compiles the fused log-prob epilogue out of the stack kernel
+#endif
+
 namespace mnf {
 
 constexpr int kSplitWaves = 8;
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(stack_waves<H>() * 64, 2)
 ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
                        float* __restrict__ log_det, float* __restrict__ ysq, const uint32_t* __restrict__ simages,
                        const float* __restrict__ images_f32, uint32_t parity_bits, int n_layers, int64_t rows,
-                       int accumulate) {
+                       int accumulate, float* __restrict__ log_prob, double* __restrict__ log_prob_sum) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, dim = 2 * H, NTL = stack_tiles<H>(), kStackWaves = stack_waves<H>();
   constexpr int IMG4 = S::IMAGE_WORDS / 4;
@@ -237,6 +241,7 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
   const uint4* img4 = reinterpret_cast<const uint4*>(simages);
   auto layer_at = [&](int li) { return INV ? n_layers - 1 - li : li; };  // application order
 
+  double lp_acc = 0.0;
   const int n_groups = (int)((rows + GROUP_ROWS - 1) / GROUP_ROWS);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     int64_t row[NTL], rowc[NTL];
@@ -342,21 +347,34 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 #pragma unroll
         for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = hi[t][g];
       }
+      float ld_row = 0.f;
       if (log_det) {
         float l = sum_over_q(ld[t]);
         if (INV) l = -l;
-        if (live[t] && q == 0) log_det[row[t]] = accumulate ? log_det[row[t]] + l : l;
+        ld_row = (accumulate && live[t]) ? log_det[row[t]] + l : l;
+        if (live[t] && q == 0) log_det[row[t]] = ld_row;
       }
-      if (ysq) {
+      if (ysq || (MNF_LP_EPILOGUE && log_prob)) {
         float sq = 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sq = fmaf(lo[t][g][r], lo[t][g][r], fmaf(hi[t][g][r], hi[t][g][r], sq));
         sq = sum_over_q(sq);
-        if (live[t] && q == 0) ysq[row[t]] = sq;
+        if (ysq && live[t] && q == 0) ysq[row[t]] = sq;
+        if (MNF_LP_EPILOGUE && log_prob) {  // standard-normal base: log p = log_det - |z|^2 / 2 - d/2 log(2 pi)   (core.py:46-49)
+          const float lp = ld_row + (-0.5f * sq - (float)dim * kHalfLog2Pi);
+          if (live[t] && q == 0) {
+            log_prob[row[t]] = lp;
+            lp_acc += (double)lp;
+          }
+        }
       }
     }
+  }
+  if (MNF_LP_EPILOGUE && log_prob_sum) {  // fp64 sum over the rows: wave shuffle, one native fp64 atomic per wave
+    for (int off = 32; off > 0; off >>= 1) lp_acc += __shfl_down(lp_acc, off, 64);
+    if (lane == 0) atomicAdd(log_prob_sum, lp_acc);
   }
 }
 
@@ -471,7 +489,7 @@ static int launch_split(const float* x, float* y, float* log_det, float* ysq, in
 template <int H, int HID>
 static int launch_split_stack(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                               const uint32_t* simages, const float* images, uint32_t parity_bits, int n_layers,
-                              int64_t rows, int inverse, hipStream_t stream) {
+                              int64_t rows, int inverse, float* log_prob, double* log_prob_sum, hipStream_t stream) {
   constexpr int kStackWaves = stack_waves<H>(), kStackTiles = stack_tiles<H>();
   constexpr size_t image_bytes = 2 * SplitShape<H, HID>::IMAGE_WORDS * sizeof(uint32_t);
   constexpr size_t lds_bytes = image_bytes <= 64 * 1024 ? 0 : image_bytes;  // dynamic part (see the kernel)
@@ -497,10 +515,10 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);
   if (inverse)
     hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, y, mid, log_det, ysq,
-                       simages, images, parity_bits, n_layers, rows, accumulate);
+                       simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum);
   else
     hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, y, mid, log_det,
-                       ysq, simages, images, parity_bits, n_layers, rows, accumulate);
+                       ysq, simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum);
   return check_launch();
 }
 
@@ -537,13 +555,14 @@ int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int a
 
 int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
-                           int64_t rows, int dim, int inverse, int hid, hipStream_t stream) {
+                           int64_t rows, int dim, int inverse, int hid, float* log_prob, double* log_prob_sum,
+                           hipStream_t stream) {
   if (!split_images || !images || !aligned16(x, y, split_images, images) || (reinterpret_cast<uintptr_t>(mid) & 15))
     return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                                                                                               \
   if (dim == 2 * HH && hid == HD)                                                                               \
     return launch_split_stack<HH, HD>(x, y, mid, log_det, ysq, accumulate, static_cast<const uint32_t*>(split_images), \
-                                      images, parity_bits, n_layers, rows, inverse != 0, stream);
+                                      images, parity_bits, n_layers, rows, inverse != 0, log_prob, log_prob_sum, stream);
   MNF_AHF_SPLIT_STACK_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

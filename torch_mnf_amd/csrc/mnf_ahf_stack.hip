@@ -150,10 +150,10 @@ extern "C" {
 // images: n_layers operand images (mnf_affine_half_image_floats each) back to back, layer 0 first;
 // parity_host[l] as in mnf_affine_half.  Layers are applied 0..L-1 (forward) or L-1..0 (inverse).
 int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float* log_det, float* y_sqnorm,
-                          int accumulate, const float* images, const void* split_images, const int* parity_host, int n_layers,
+                          float* log_prob, double* log_prob_sum, int accumulate, const float* images, const void* split_images, const int* parity_host, int n_layers,
                           int64_t rows, int dim, int inverse, int n_hidden, const int* hidden, void* stream) {
   if (!x || !y || x == y || !images || !parity_host || n_layers < 1 || n_layers > 32 || rows < 0 || dim < 2 ||
-      (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
+      (dim & 1) || !mnf::hidden_ok(n_hidden, hidden) || ((log_prob || log_prob_sum) && !log_det))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (n_hidden != 3 || hidden[0] != hidden[1] || hidden[1] != hidden[2]) return MNF_ERR_UNSUPPORTED;
@@ -165,9 +165,11 @@ int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float*
   const int hid = hidden[0];
   if (split_images) {
     const int rc = mnf::ahf_split_stack_launch(x, y, intermediates, log_det, y_sqnorm, accumulate, split_images, images, bits,
-                                               n_layers, rows, dim, inverse, hid, (hipStream_t)stream);
+                                               n_layers, rows, dim, inverse, hid, log_prob, log_prob_sum,
+                                               (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
+  if (log_prob || log_prob_sum) return MNF_ERR_UNSUPPORTED;  // only the split kernel has the fused log-prob epilogue
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) \
     return mnf::launch_stack<HH, HD>(x, y, intermediates, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, \

@@ -43,7 +43,8 @@ int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int a
                      const int* hidden, int has_scale, int has_shift, hipStream_t stream);
 int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
-                           int64_t rows, int dim, int inverse, int hid, hipStream_t stream);
+                           int64_t rows, int dim, int inverse, int hid, float* log_prob, double* log_prob_sum,
+                           hipStream_t stream);
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                     const void* split_image, int64_t rows, int dim, int K, float tail_bound, int inverse,
                     int n_hidden, const int* hidden, hipStream_t stream);

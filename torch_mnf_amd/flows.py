@@ -34,6 +34,8 @@ from ._lib import MnfHipError
 _FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
+# MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
+_NO_FUSED_LOGPROB_ENV = os.environ.get("MNF_NO_FUSED_LOGPROB", "") not in ("", "0")
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
@@ -958,6 +960,8 @@ class _AffineRun:
         self._images: Tensor | None = None
         self._splits: Tensor | None = None
         self._unsupported = False  # set once the library reports that the shape has no stack kernel
+        self._no_fused_logprob = False  # set once the library reports that the shape has no fused log-prob epilogue
+        self.logprob_fused = False
 
     @staticmethod
     def compatible(a: "AffineHalfFlow", b: "AffineHalfFlow") -> bool:
@@ -998,19 +1002,32 @@ class _AffineRun:
         return list(out[:-1]), out[-1]
 
     def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, sqnorm: Tensor | None,
-               keep: bool) -> list[Tensor] | None:
+               keep: bool, logprob: tuple | None = None) -> list[Tensor] | None:
         """Runs the layers (model order reversed when ``inverse``).  Returns the output tensors in
         application order -- all of them when ``keep`` (views of one buffer: each intermediate is written
-        once and never re-read), else just the last -- or None when the shape has no stack kernel."""
+        once and never re-read), else just the last -- or None when the shape has no stack kernel.
+
+        ``logprob`` = (log_prob (rows,), fp64 sum (1,) zeroed, or None): ask the kernel for the
+        standard-normal log-prob epilogue too; ``self.logprob_fused`` says whether it did (only the split
+        kernel can -- otherwise ``sqnorm`` is filled as usual and the caller runs the epilogue kernel)."""
         f0, n = self.layers[0], len(self.layers)
         images, splits = self.images(x.device)
         x = _device_input(x, "input")
         buf = torch.empty((n if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
-        rc = _lib.load().mnf_affine_half_stack(
-            x.data_ptr(), buf[-1].data_ptr(), buf.data_ptr() if keep and n > 1 else None, log_det.data_ptr(),
-            _ptr(sqnorm), int(accumulate), images.data_ptr(), _ptr(splits), par, n, x.shape[0], f0.dim, int(inverse),
-            len(f0.h_sizes), f0._hid, _stream())
+
+        def go(lp, total, sq):
+            return _lib.load().mnf_affine_half_stack(
+                x.data_ptr(), buf[-1].data_ptr(), buf.data_ptr() if keep and n > 1 else None, log_det.data_ptr(),
+                _ptr(sq), _ptr(lp), _ptr(total), int(accumulate), images.data_ptr(), _ptr(splits), par, n, x.shape[0],
+                f0.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
+
+        self.logprob_fused = (logprob is not None and splits is not None and not self._no_fused_logprob
+                              and not _NO_FUSED_LOGPROB_ENV)
+        rc = go(logprob[0], logprob[1], None) if self.logprob_fused else go(None, None, sqnorm)
+        if rc == _lib.MNF_ERR_UNSUPPORTED and self.logprob_fused:  # shape runs on the fp32 stack kernel: no epilogue
+            self._no_fused_logprob, self.logprob_fused = True, False
+            rc = go(None, None, sqnorm)
         if rc == _lib.MNF_ERR_UNSUPPORTED:
             self._unsupported = True
             return None
@@ -1115,8 +1132,10 @@ class NormalizingFlow(nn.Module):
             self.__dict__["_runs_cache"] = cache
         return cache[1]
 
-    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None):
-        """prologue (forward only, first flow an RNVP): see RNVP._run; the returned list then starts with eps."""
+    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None, want_logprob=None):
+        """prologue (forward only, first flow an RNVP): see RNVP._run; the returned list then starts with eps.
+        want_logprob = (lp, total-or-None): when the LAST launch is an affine run whose kernel can add the
+        standard-normal epilogue, it fills them and ``self._logprob_done`` is set."""
         n = len(self.flows)
         order = list(reversed(self.flows)) if inverse else list(self.flows)
         runs = self._affine_runs() if self.fuse_affine_runs and not _NO_RUN_FUSION_ENV else {}
@@ -1129,6 +1148,7 @@ class NormalizingFlow(nn.Module):
         log_det = torch.empty(x.size(0), device=x.device) if fresh else torch.zeros(x.size(0), device=x.device)
         seen = [x]
         self._last_sqnorm = None
+        self._logprob_done = False
         # layer_events: list receiving (start, end, index) HIP events per launch; layer_event_pick = i restricts
         # the marks to the launch at position i of this pass (a mark costs a few us of stream time)
         pick = self.layer_event_pick
@@ -1158,7 +1178,10 @@ class NormalizingFlow(nn.Module):
                         log_det = ld_run if (fresh and i == 0) else log_det + ld_run
                 elif isinstance(run, _AffineRun):
                     sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
-                    outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True)
+                    outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True,
+                                      logprob=want_logprob if last else None)
+                    if outs is not None and last and want_logprob is not None and run.logprob_fused:
+                        self._logprob_done, sq = True, None
                 else:
                     sq = None
                     outs = run.launch(x, inverse, log_det, True, keep=True)
@@ -1282,11 +1305,18 @@ class NormalizingFlowModel(NormalizingFlow):
         run two, core.py:46-49 vs examples/half_moons.ipynb:183-184).  With a StandardNormal
         base the epilogue kernel also produces the fp64 sum over rows."""
         std = isinstance(self.base, StandardNormal)
-        zs, log_det = self._pass(x, True, want_sqnorm=std)
+        lp = total = None
+        if std and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0:
+            lp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            total = torch.zeros(1, dtype=torch.float64, device=x.device) if return_sum else None
+        zs, log_det = self._pass(x, True, want_sqnorm=std, want_logprob=(lp, total) if lp is not None else None)
         z = zs[-1]
+        if self._logprob_done:  # the last coupling launch already produced log p and its sum
+            return (lp, total) if return_sum else lp
         if std and not (torch.is_grad_enabled() and (z.requires_grad or log_det.requires_grad)):
-            lp = torch.empty_like(log_det)
-            total = torch.zeros(1, dtype=torch.float64, device=z.device) if return_sum else None
+            if lp is None:
+                lp = torch.empty_like(log_det)
+                total = torch.zeros(1, dtype=torch.float64, device=z.device) if return_sum else None
             if z.shape[0] == 0:
                 return (lp, total) if return_sum else lp
             if self._last_sqnorm is not None:  # |z|^2 came out of the last coupling kernel
