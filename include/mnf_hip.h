@@ -54,6 +54,9 @@ extern "C" {
 
 #define MNF_MAX_LINEAR 8 /* Linear layers per conditioner net (hidden layers + 1) */
 
+/* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
+ * library was built with, so a binding can refuse a stale build. */
+#define MNF_ABI_VERSION 3
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */

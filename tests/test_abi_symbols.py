@@ -40,7 +40,11 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.mnf_abi_version() == 2
+    import re
+    header = open(os.path.join(ROOT, "include", "mnf_hip.h")).read()
+    import torch_mnf_amd
+    declared = int(re.search(r"#define MNF_ABI_VERSION (\d+)", header).group(1))
+    assert lib.mnf_abi_version() == declared == torch_mnf_amd._lib.ABI_VERSION
     assert lib.mnf_error_string(0) == b"ok"
     assert b"unsupported" in lib.mnf_error_string(-2).lower() or b"not supported" in lib.mnf_error_string(-2)
 

@@ -12,6 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
+ABI_VERSION = 3  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -118,6 +119,9 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here == header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.mnf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.mnf_abi_version()}, this package binds version "
+                           f"{ABI_VERSION}: rebuild it (make -C torch_mnf_amd/csrc)")
     _lib = lib
     return lib
 

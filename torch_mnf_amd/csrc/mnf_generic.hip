@@ -551,7 +551,7 @@ static int grid_for(int64_t n, int threads, int cap = 256 * 8) {
 
 extern "C" {
 
-int mnf_abi_version(void) { return 2; }
+int mnf_abi_version(void) { return MNF_ABI_VERSION; }
 
 const char* mnf_error_string(int code) {
   switch (code) {
