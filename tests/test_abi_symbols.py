@@ -64,9 +64,10 @@ def test_flat_sizes_match_state_dicts(lib):
     assert lib.mnf_affine_half_flat_floats(3, 3, hid, 1, 1) == -1  # odd dim
 
 
-@pytest.mark.parametrize("dim", [32, 64, 128, 256])
+@pytest.mark.parametrize("dim", [32, 64, 128, 256, 2, 6, 30, 50, 100, 250])
 def test_affine_half_image_index_is_a_permutation_plus_zeros(lib, dim):
-    """Every parameter appears exactly once in the MFMA operand image; the rest is structural zero."""
+    """Every parameter appears exactly once in the MFMA operand image; the rest is structural zero
+    (a half narrower than its 16/32/64/128-column tile is zero-padded: the stack kernel's ragged variant)."""
     from torch_mnf_amd._lib import int_array
 
     hid = int_array([24, 24, 24])
@@ -84,7 +85,12 @@ def test_affine_half_image_index_is_a_permutation_plus_zeros(lib, dim):
 def test_unsupported_shapes_report_no_image(lib):
     from torch_mnf_amd._lib import int_array
 
-    assert lib.mnf_affine_half_image_floats(2, 3, int_array([24, 24, 24]), 1, 1) == 0
+    assert lib.mnf_affine_half_image_floats(258, 3, int_array([24, 24, 24]), 1, 1) == 0  # half wider than 128
+    assert lib.mnf_affine_half_image_floats(2, 3, int_array([24, 24, 24]), 1, 1) > 0     # padded to a 16-column tile
+    n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+    # a ragged half only has the stack kernel, which exists for hidden widths 24 and 16
+    assert lib.mnf_affine_half_split_layout(6, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
+                                            ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_image_floats(64, 2, int_array([24, 24]), 1, 1) == 0
     assert lib.mnf_affine_half_image_floats(64, 3, int_array([24, 24, 24]), 0, 1) == 0
 
@@ -153,7 +159,8 @@ def _check_split_table(halves, plain, n_weights, n_params):
     assert np.array_equal(np.unique(plain[plain >= 0]), biases)
 
 
-@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (128, 24), (256, 24), (32, 16), (64, 16), (32, 32), (128, 32)])
+@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (128, 24), (256, 24), (32, 16), (64, 16), (32, 32), (128, 32),
+                                     (2, 24), (6, 24), (30, 16), (50, 24), (100, 24), (250, 24)])
 def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
     from torch_mnf_amd._lib import int_array
 

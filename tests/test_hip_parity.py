@@ -87,7 +87,10 @@ def test_mfma_kernel_is_selected(amd):
         assert f._split_image(torch.device(DEV, 0)) is not None  # the split kernel is the default
         f.force_fp32_mfma = True
         assert f._split_image(torch.device(DEV, 0)) is None
-    assert lib.mnf_affine_half_image_floats(2, 3, hid, 1, 1) == 0
+    # d = 2 (config 1): a one-column half padded to a 16-column tile, served by the stack kernel's ragged variant
+    assert lib.mnf_affine_half_image_floats(2, 3, hid, 1, 1) > 0
+    assert amd.AffineHalfFlow(2, False).to(DEV)._split_image(torch.device(DEV, 0)) is not None
+    assert lib.mnf_affine_half_image_floats(258, 3, hid, 1, 1) == 0
 
 
 @pytest.mark.parametrize("tag,kw", [("nice", dict(scale=False)), ("noshift", dict(shift=False)),
@@ -116,6 +119,65 @@ def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim, kernel):
             y, ld = f.forward(cuda(x), inverse=inverse)
             assert_close(y, ref_y, RTOL, "y")
             assert_close(ld, ref_ld, RTOL, "ld")
+
+
+@pytest.mark.parametrize("rows", [1, 17, 1000, 4099])
+@pytest.mark.parametrize("dim,hid", [(2, 24), (4, 24), (6, 16), (10, 24), (24, 24), (30, 16), (40, 24), (50, 24), (62, 24),
+                                     (100, 24), (58, 16), (130, 24), (200, 24), (250, 24)])
+def test_affine_half_narrow_halves_vs_oracle(amd, O, rows, dim, hid):
+    """A coupling half that does not fill its 16/32/64/128-column MFMA tile (any even d <= 256, e.g. config 1's
+    d = 2): zero-padded operand image, masked row accesses (16-byte when d % 8 == 0, else element by element).
+    One layer and a 3-layer run, both directions, against the oracle and the shape-generic kernel."""
+    h_sizes = (hid,) * 3
+    sds = [recipes.affine_half_params(700 + dim + i, dim, h_sizes=h_sizes, s_last_gain=2.0) for i in range(3)]
+    x = recipes.gaussian(rows + dim, rows, dim)
+    flows = [ahf_module(amd, sd, dim, bool(i % 2), h_sizes=h_sizes) for i, sd in enumerate(sds)]
+    assert all(f._split_image(torch.device(DEV, 0)) is not None for f in flows)
+    for inverse in (False, True):
+        f = flows[1]
+        ref_y, ref_ld = O.affine_half(x, sds[1], True, inverse)
+        y, ld = f.forward(cuda(x), inverse=inverse)
+        assert_close(y, ref_y, RTOL, "y")
+        assert_close(ld, ref_ld, RTOL, "ld")
+        f.force_generic = True
+        y_g, ld_g = f.forward(cuda(x), inverse=inverse)
+        f.force_generic = False
+        assert_close(y, y_g, RTOL, "vs generic y")
+        assert_close(ld, ld_g, RTOL, "vs generic ld")
+    model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
+    layers = [{"kind": "affine_half", "parity": bool(i % 2), "params": sd} for i, sd in enumerate(sds)]
+    with torch.no_grad():
+        zs, ld = model.inverse(cuda(x))
+        assert zs[1].data_ptr() + zs[1].numel() * 4 == zs[2].data_ptr()  # one launch, one buffer
+        cur, ld_ref = x, 0
+        for i in (2, 1, 0):
+            cur, l1 = O.affine_half(cur, sds[i], bool(i % 2), True)
+            ld_ref = ld_ref + l1
+            assert_close(zs[3 - i], cur, RTOL, f"z after layer {i}")
+        assert_close(ld, ld_ref, RTOL, "run log_det")
+        xs, ld_f = model.forward(zs[-1])
+        assert_close(xs[-1], x, 1e-4, "round trip")
+        lp, total = model.log_prob(cuda(x), return_sum=True)
+        assert model._logprob_done
+        ref_mean, ref_lp = O.mean_log_prob(x, layers)
+        assert_close(lp, ref_lp, RTOL, "log_prob")
+        assert abs(float(total) / rows - ref_mean) <= RTOL * abs(ref_mean)
+
+
+def test_narrow_half_unaligned_view(amd, O):
+    """Row bases that are not 16-byte aligned (a column-offset view made contiguous at an odd float offset)."""
+    dim = 8
+    sd = recipes.affine_half_params(801, dim)
+    f = ahf_module(amd, sd, dim, False)
+    x = recipes.gaussian(802, 100, dim)
+    buf = torch.empty(100 * dim + 1, device=DEV)
+    xv = buf[1:].view(100, dim)
+    xv.copy_(cuda(x))
+    assert xv.data_ptr() % 16 != 0
+    y, ld = f.forward(xv)
+    ref_y, ref_ld = O.affine_half(x, sd, False, False)
+    assert_close(y, ref_y, RTOL, "y")
+    assert_close(ld, ref_ld, RTOL, "ld")
 
 
 @pytest.mark.parametrize("kernel", ["split", "fp32"])
@@ -374,7 +436,7 @@ def build_ahf_stack(amd, layers, dim):
 
 @pytest.mark.parametrize("tag", ["init", "trained"])
 def test_g1_c1_stack(amd, golden, tag):
-    """Config 1: 9 x AffineHalfFlow d=2 on half-moons (generic kernel: h = 1)."""
+    """Config 1: 9 x AffineHalfFlow d=2 on half-moons (h = 1: the stack kernel's ragged variant, one launch)."""
     fx = golden(f"g1_c1_stack_{tag}")
     model = build_ahf_stack(amd, g1_layers(fx), 2)
     x = cuda(fx["x"])

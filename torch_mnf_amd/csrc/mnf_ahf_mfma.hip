@@ -309,11 +309,12 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 }
 
 // ---------------------------------------------------------------- host: image index table
+// h <= H: real half width (the image is zero in the padded input columns / output rows)
 template <int H, int HID>
-static void build_index(int32_t* idx) {
+static void build_index(int32_t* idx, int h) {
   using S = AhfShape<H, HID>;
   constexpr int QN = S::QN, NQ = S::NQ, NT = S::NT, G = S::G;
-  int sizes[5] = {H, HID, HID, HID, H};
+  int sizes[5] = {h, HID, HID, HID, h};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -330,7 +331,8 @@ static void build_index(int32_t* idx) {
         const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
         if (u < 2 * HID) {
           const int nn = u / HID, unit = u % HID;
-          put(lane, net[nn].w_off[0] + unit * H + 16 * g + 4 * kq + e);
+          const int col = 16 * g + 4 * kq + e;
+          if (col < h) put(lane, net[nn].w_off[0] + unit * h + col);
         }
       }
       ++n;
@@ -355,7 +357,7 @@ static void build_index(int32_t* idx) {
       for (int nn = 0; nn < 2; ++nn) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4;
-          put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
+          if (16 * m + i < h) put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
         }
         ++n;
       }
@@ -372,7 +374,8 @@ static void build_index(int32_t* idx) {
       }
   for (int m = 0; m < G; ++m)
     for (int nn = 0; nn < 2; ++nn, ++bt)
-      for (int i = 0; i < 16; ++i) b[bt * 16 + i] = net[nn].b_off[3] + 16 * m + i;
+      for (int i = 0; i < 16; ++i)
+        if (16 * m + i < h) b[bt * 16 + i] = net[nn].b_off[3] + 16 * m + i;
 }
 
 template <int H, int HID>
@@ -458,8 +461,9 @@ int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden, i
   if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) ||
       !mnf::uniform_hidden(n_hidden, hidden, hid))
     return 0;
+  const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
 #define X(HH, HD) \
-  if (dim == 2 * HH && hid == HD) return mnf::AhfShape<HH, HD>::IMAGE_FLOATS;
+  if (hp == HH && hid == HD) return mnf::AhfShape<HH, HD>::IMAGE_FLOATS;
   MNF_AHF_SHAPES(X)
 #undef X
   return 0;
@@ -470,10 +474,11 @@ int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden, int ha
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-#define X(HH, HD)                        \
-  if (dim == 2 * HH && hid == HD) {      \
-    mnf::build_index<HH, HD>(idx_host);  \
-    return MNF_OK;                       \
+  const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
+#define X(HH, HD)                           \
+  if (hp == HH && hid == HD) {              \
+    mnf::build_index<HH, HD>(idx_host, h);  \
+    return MNF_OK;                          \
   }
   MNF_AHF_SHAPES(X)
 #undef X

@@ -218,14 +218,49 @@ __device__ __forceinline__ void image_to_lds_async(const uint4* src, uint32_t* d
   }
 }
 
-template <int H, int HID, bool INV>
+// Row accesses of the stack kernel: four columns col..col+3 of a coupling half that is `h` columns wide.
+// RAG = false: h == H, one 16-byte access.  RAG = true (h < H): columns >= h are zero on load and skipped on
+// store; `vec` (h % 4 == 0 and 16-byte aligned bases) keeps the 16-byte access, else element by element.
+template <bool RAG>
+__device__ __forceinline__ f32x4 half_load4(const float* p, int col, int h, bool vec) {
+  if (!RAG) return *reinterpret_cast<const f32x4*>(p + col);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if (col < h) v = *reinterpret_cast<const f32x4*>(p + col);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float e = 0.f;
+      if (col + r < h) e = p[col + r];
+      v[r] = e;
+    }
+  }
+  return v;
+}
+template <bool RAG>
+__device__ __forceinline__ void half_store4(float* p, int col, int h, bool vec, f32x4 v) {
+  if (!RAG) {
+    *reinterpret_cast<f32x4*>(p + col) = v;
+  } else if (vec) {
+    if (col < h) *reinterpret_cast<f32x4*>(p + col) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + r < h) p[col + r] = v[r];
+  }
+}
+
+template <int H, int HID, bool INV, bool RAG>
 __global__ void __launch_bounds__(stack_waves<H>() * 64, 2)
 ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
                        float* __restrict__ log_det, float* __restrict__ ysq, const uint32_t* __restrict__ simages,
                        const float* __restrict__ images_f32, uint32_t parity_bits, int n_layers, int64_t rows,
-                       int accumulate, float* __restrict__ log_prob, double* __restrict__ log_prob_sum) {
+                       int accumulate, float* __restrict__ log_prob, double* __restrict__ log_prob_sum, int h_ragged,
+                       int vec_ok) {
   using S = SplitShape<H, HID>;
-  constexpr int G = S::G, dim = 2 * H, NTL = stack_tiles<H>(), kStackWaves = stack_waves<H>();
+  constexpr int G = S::G, NTL = stack_tiles<H>(), kStackWaves = stack_waves<H>();
+  const int h = RAG ? h_ragged : H, dim = 2 * h;  // the rows in memory are 2 h wide; the tiles H
+  const bool vec = vec_ok != 0;
   constexpr int IMG4 = S::IMAGE_WORDS / 4;
   constexpr int F32_FLOATS = AhfShape<H, HID>::IMAGE_FLOATS;
   constexpr int GROUP_ROWS = 16 * NTL * kStackWaves;
@@ -252,11 +287,11 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
       row[t] = (int64_t)grp * GROUP_ROWS + (wave * NTL + t) * 16 + j;
       live[t] = row[t] < rows;
       rowc[t] = live[t] ? row[t] : rows - 1;  // rows past the end: clamped loads, masked stores
-      const float* xr = x + rowc[t] * dim + 4 * q;
+      const float* xr = x + rowc[t] * dim;
 #pragma unroll
-      for (int g = 0; g < G; ++g) lo[t][g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+      for (int g = 0; g < G; ++g) lo[t][g] = half_load4<RAG>(xr, 16 * g + 4 * q, h, vec);
 #pragma unroll
-      for (int g = 0; g < G; ++g) hi[t][g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+      for (int g = 0; g < G; ++g) hi[t][g] = half_load4<RAG>(xr + h, 16 * g + 4 * q, h, vec);
     }
     __syncthreads();  // the previous group's last layer is fully consumed
     image_to_lds_async<IMG4, kStackWaves>(img4 + (int64_t)layer_at(0) * IMG4, lds_buf(0), lane, wave);
@@ -282,8 +317,8 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
         for (int k = stage * PER; k < (stage + 1) * PER && k < TOTAL; ++k) {
           const int t = k / (2 * G), half = (k / G) & 1, g = k % G;
           if (live[t]) {
-            float* mr = mid + ((int64_t)(li - 1) * rows + rowc[t]) * dim + 4 * q + (half ? H : 0) + 16 * g;
-            *reinterpret_cast<f32x4*>(mr) = half ? hi[t][g] : lo[t][g];
+            float* mr = mid + ((int64_t)(li - 1) * rows + rowc[t]) * dim + (half ? h : 0);
+            half_store4<RAG>(mr, 16 * g + 4 * q, h, vec, half ? hi[t][g] : lo[t][g]);
           }
         }
       };
@@ -341,11 +376,11 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
       if (live[t]) {
-        float* yr = y + rowc[t] * dim + 4 * q;
+        float* yr = y + rowc[t] * dim;
 #pragma unroll
-        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[t][g];
+        for (int g = 0; g < G; ++g) half_store4<RAG>(yr, 16 * g + 4 * q, h, vec, lo[t][g]);
 #pragma unroll
-        for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = hi[t][g];
+        for (int g = 0; g < G; ++g) half_store4<RAG>(yr + h, 16 * g + 4 * q, h, vec, hi[t][g]);
       }
       float ld_row = 0.f;
       if (log_det) {
@@ -380,11 +415,12 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 
 // ---------------------------------------------------------------- host: split image index table
 // 2 entries per split word (low half, high half), then 1 entry per plain (fp32 bias) word.
+// h <= H: real half width (zero operands in the padded input columns / output rows)
 template <int H, int HID>
-static void build_split_index(int32_t* idx) {
+static void build_split_index(int32_t* idx, int h) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
-  int sizes[5] = {H, HID, HID, HID, H};
+  int sizes[5] = {h, HID, HID, HID, h};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -409,8 +445,8 @@ static void build_split_index(int32_t* idx) {
         const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
         if (u >= 2 * HID) continue;
         for (int e = 0; e < 8; ++e) {
-          const int g = 2 * ks + (e >> 2);
-          if (g < G) put(lane, e, net[u / HID].w_off[0] + (u % HID) * H + 16 * g + 4 * kq + (e & 3));
+          const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
+          if (g < G && col < h) put(lane, e, net[u / HID].w_off[0] + (u % HID) * h + col);
         }
       }
   for (int l = 1; l <= 2; ++l)
@@ -439,7 +475,7 @@ static void build_split_index(int32_t* idx) {
             for (int e = 0; e < 8; ++e) {
               int tile;
               const int ui = unit_in(ks, kq, e, tile);
-              if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks) continue;
+              if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks || 16 * g + i >= h) continue;
               put(lane, e, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
             }
           }
@@ -455,7 +491,8 @@ static void build_split_index(int32_t* idx) {
       }
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
-      for (int i = 0; i < 16; ++i) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+      for (int i = 0; i < 16; ++i)
+        if (16 * g + i < h) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
 template <typename K>
@@ -486,10 +523,11 @@ static int launch_split(const float* x, float* y, float* log_det, float* ysq, in
   return check_launch();
 }
 
-template <int H, int HID>
+template <int H, int HID, bool RAG>
 static int launch_split_stack(const float* x, float* y, float* mid, float* log_det, float* ysq, int accumulate,
                               const uint32_t* simages, const float* images, uint32_t parity_bits, int n_layers,
-                              int64_t rows, int inverse, float* log_prob, double* log_prob_sum, hipStream_t stream) {
+                              int64_t rows, int inverse, float* log_prob, double* log_prob_sum, int h, int vec_ok,
+                              hipStream_t stream) {
   constexpr int kStackWaves = stack_waves<H>(), kStackTiles = stack_tiles<H>();
   constexpr size_t image_bytes = 2 * SplitShape<H, HID>::IMAGE_WORDS * sizeof(uint32_t);
   constexpr size_t lds_bytes = image_bytes <= 64 * 1024 ? 0 : image_bytes;  // dynamic part (see the kernel)
@@ -498,9 +536,9 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, true, RAG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, false, RAG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return 0;
     // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
@@ -514,11 +552,11 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
   const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);
   if (inverse)
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, y, mid, log_det, ysq,
-                       simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum);
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true, RAG>), grid, block, lds_bytes, stream, x, y, mid, log_det,
+                       ysq, simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum, h, vec_ok);
   else
-    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, y, mid, log_det,
-                       ysq, simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum);
+    hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, false, RAG>), grid, block, lds_bytes, stream, x, y, mid, log_det,
+                       ysq, simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum, h, vec_ok);
   return check_launch();
 }
 
@@ -557,12 +595,21 @@ int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det,
                            const void* split_images, const float* images, uint32_t parity_bits, int n_layers,
                            int64_t rows, int dim, int inverse, int hid, float* log_prob, double* log_prob_sum,
                            hipStream_t stream) {
-  if (!split_images || !images || !aligned16(x, y, split_images, images) || (reinterpret_cast<uintptr_t>(mid) & 15))
+  if (!split_images || !images || (dim & 1) || !aligned16(split_images, images, nullptr, nullptr))
     return MNF_ERR_UNSUPPORTED;
-#define X(HH, HD)                                                                                               \
-  if (dim == 2 * HH && hid == HD)                                                                               \
-    return launch_split_stack<HH, HD>(x, y, mid, log_det, ysq, accumulate, static_cast<const uint32_t*>(split_images), \
-                                      images, parity_bits, n_layers, rows, inverse != 0, log_prob, log_prob_sum, stream);
+  const int h = dim / 2, hp = ahf_padded_half(h);
+  const bool rows_aligned = aligned16(x, y, mid, nullptr);
+  if (h == hp && !rows_aligned) return MNF_ERR_UNSUPPORTED;
+  const int vec_ok = rows_aligned && (h & 3) == 0;
+  const uint32_t* simages = static_cast<const uint32_t*>(split_images);
+#define X(HH, HD)                                                                                                    \
+  if (hp == HH && hid == HD)                                                                                         \
+    return h == HH ? launch_split_stack<HH, HD, false>(x, y, mid, log_det, ysq, accumulate, simages, images,         \
+                                                       parity_bits, n_layers, rows, inverse != 0, log_prob,         \
+                                                       log_prob_sum, h, vec_ok, stream)                              \
+                   : launch_split_stack<HH, HD, true>(x, y, mid, log_det, ysq, accumulate, simages, images,          \
+                                                      parity_bits, n_layers, rows, inverse != 0, log_prob,          \
+                                                      log_prob_sum, h, vec_ok, stream);
   MNF_AHF_SPLIT_STACK_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -577,13 +624,18 @@ int mnf_affine_half_split_layout(int dim, int n_hidden, const int* hidden, int h
   int hid = 0;
   if (!n_split_words || !n_plain_words || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
 #define X(HH, HD)                                            \
-  if (dim == 2 * HH && hid == HD) {                          \
+  if (hp == HH && hid == HD) {                               \
     *n_split_words = mnf::SplitShape<HH, HD>::SPLIT_WORDS;   \
     *n_plain_words = mnf::SplitShape<HH, HD>::PLAIN_WORDS;   \
     return MNF_OK;                                           \
   }
-  MNF_AHF_SPLIT_SHAPES(X)
+  if (h == hp) {  // full tiles: every split shape; a ragged half: the shapes of the stack kernel (its only kernel)
+    MNF_AHF_SPLIT_SHAPES(X)
+  } else {
+    MNF_AHF_SPLIT_STACK_SHAPES(X)
+  }
 #undef X
   return MNF_ERR_UNSUPPORTED;
 }
@@ -593,12 +645,17 @@ int mnf_affine_half_split_index(int dim, int n_hidden, const int* hidden, int ha
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-#define X(HH, HD)                              \
-  if (dim == 2 * HH && hid == HD) {            \
-    mnf::build_split_index<HH, HD>(idx_host);  \
-    return MNF_OK;                             \
+  const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
+#define X(HH, HD)                                 \
+  if (hp == HH && hid == HD) {                    \
+    mnf::build_split_index<HH, HD>(idx_host, h);  \
+    return MNF_OK;                                \
   }
-  MNF_AHF_SPLIT_SHAPES(X)
+  if (h == hp) {
+    MNF_AHF_SPLIT_SHAPES(X)
+  } else {
+    MNF_AHF_SPLIT_STACK_SHAPES(X)
+  }
 #undef X
   return MNF_ERR_UNSUPPORTED;
 }

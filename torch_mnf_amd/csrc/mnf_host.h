@@ -12,6 +12,11 @@ int check_launch();
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base);
 bool hidden_ok(int n_hidden, const int* hidden);
 
+// Half width the AffineHalfFlow MFMA kernels pad a coupling half of `h` columns to (0: none).  A layer
+// whose half is narrower than its tile runs on the stack kernel's ragged variant: zero operands in the
+// padded columns, element-wise masked row accesses.
+inline int ahf_padded_half(int h) { return h < 1 ? 0 : h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : h <= 128 ? 128 : 0; }
+
 // Persistent-grid sizing: among grids of whole workgroups-per-CU steps between resident/2 and
 // resident, pick the one whose static tile striding wastes the fewest wave-rounds
 // (tiles / (rounds * waves)); e.g. 65,536 tiles on 1,536 resident 4-wave workgroups run 11 rounds at

@@ -959,6 +959,8 @@ class _AffineRun:
         self._key = None
         self._images: Tensor | None = None
         self._splits: Tensor | None = None
+        self._plist = None
+        self._checked = None  # (images, splits) validated by usable(), consumed by the launch that follows
         self._unsupported = False  # set once the library reports that the shape has no stack kernel
         self._no_fused_logprob = False  # set once the library reports that the shape has no fused log-prob epilogue
         self.logprob_fused = False
@@ -967,9 +969,17 @@ class _AffineRun:
     def compatible(a: "AffineHalfFlow", b: "AffineHalfFlow") -> bool:
         return (a.dim, a.h_sizes, a.scale, a.shift) == (b.dim, b.h_sizes, b.scale, b.shift)
 
+    def _params(self) -> list[Tensor]:
+        """Every layer's packed parameters in order; the walk is redone only when a conditioner (or one of its
+        Linear children) has been replaced."""
+        nets = [n for f in self.layers for n in (f._modules.get("s_net"), f._modules.get("t_net")) if n is not None]
+        sig = [id(c) for n in nets for c in n._modules.values()] + [id(n) for n in nets]
+        if self._plist is None or self._plist[0] != sig:
+            self._plist = (sig, [p for f in self.layers for p in f._packed_params()])
+        return self._plist[1]
+
     def images(self, device):
-        key = (device, tuple(f.force_fp32_mfma for f in self.layers),
-               tuple((p.data_ptr(), p._version) for f in self.layers for p in f._packed_params()))
+        key = (device, [f.force_fp32_mfma for f in self.layers], [(p.data_ptr(), p._version) for p in self._params()])
         if key != self._key:
             imgs = [f._packed(device)[1] for f in self.layers]
             self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
@@ -981,9 +991,16 @@ class _AffineRun:
         return self._images, self._splits
 
     def usable(self, x) -> bool:
-        return (not self._unsupported and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
-                and x.shape[1] == self.layers[0].dim and not any(f.force_generic for f in self.layers)
-                and not any(_wants_grad(f, x) for f in self.layers) and self.images(x.device)[0] is not None)
+        self._checked = None
+        if (self._unsupported or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.shape[0] == 0
+                or x.shape[1] != self.layers[0].dim or any(f.force_generic for f in self.layers)
+                or any(_wants_grad(f, x) for f in self.layers)):
+            return False
+        imgs = self.images(x.device)
+        if imgs[0] is None:
+            return False
+        self._checked = (x.device, imgs)  # the launch right after this check does not validate the cache again
+        return True
 
     def trainable(self, x) -> bool:
         """Gradients wanted and the whole run can go through one autograd node (stack kernel forward, fp32-MFMA
@@ -1011,7 +1028,8 @@ class _AffineRun:
         standard-normal log-prob epilogue too; ``self.logprob_fused`` says whether it did (only the split
         kernel can -- otherwise ``sqnorm`` is filled as usual and the caller runs the epilogue kernel)."""
         f0, n = self.layers[0], len(self.layers)
-        images, splits = self.images(x.device)
+        checked, self._checked = self._checked, None
+        images, splits = checked[1] if checked is not None and checked[0] == x.device else self.images(x.device)
         x = _device_input(x, "input")
         buf = torch.empty((n if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
