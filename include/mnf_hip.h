@@ -135,6 +135,14 @@ int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden_hos
 int mnf_pack_gather_split(const float* flat, const int32_t* idx_dev, void* image, int64_t n_split_words,
                           int64_t n_plain_words, void* stream);
 int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream);
+/* The same for n_images layers of ONE shape in one launch each: image k (back to back in `images`) is built from
+ * flat + k * flat_stride with the shared index table.  A run of equal AffineHalfFlow layers repacks all its
+ * operand images after a weight update with one parameter concatenation and two launches (a training step
+ * otherwise spends more time launching per-layer packs than computing). */
+int mnf_pack_gather_batch(const float* flat, const int32_t* idx, float* images, int64_t n, int n_images,
+                          int64_t flat_stride, void* stream);
+int mnf_pack_gather_split_batch(const float* flat, const int32_t* idx_dev, void* images, int64_t n_split_words,
+                                int64_t n_plain_words, int n_images, int64_t flat_stride, void* stream);
 
 /* ------------------------------------------------------------------------ NSF_CL */
 /* f1, f2 = MLP(dim/2, n_h, n_h, n_h, (3K-1)*dim/2); `hidden` generalises (n_h,n_h,n_h). */

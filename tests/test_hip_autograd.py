@@ -90,12 +90,14 @@ def test_affine_half_mfma_gradient_kernel(amd, O, dim, hid, parity, inverse):
         assert_close(grads[False][k], grads[True][k], GTOL, f"mfma vs generic {k}")
 
 
+@pytest.mark.parametrize("dim", [64, 2, 10, 256])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_affine_run_is_one_autograd_node(amd, O, inverse):
-    """With gradients wanted, a run of equal AffineHalfFlow layers is one autograd node (stack kernel forward,
-    MFMA gradient kernel per layer backward): same gradients as layer-by-layer autograd and as autograd through
-    the oracle, including a loss term on an intermediate tensor."""
-    dim, n, rows = 64, 4, 777
+def test_affine_run_is_one_autograd_node(amd, O, inverse, dim):
+    """With gradients wanted, a run of equal AffineHalfFlow layers is one autograd node (stack kernel forward;
+    backward per layer on the saved intermediates: MFMA gradient kernel at d = 64, the generic one for the narrow
+    halves of d = 2 / 10 and for d = 256): same gradients as layer-by-layer autograd and as autograd through the
+    oracle, including a loss term on an intermediate tensor."""
+    n, rows = 4, 777
     sds = [recipes.affine_half_params(71 + i, dim, s_last_gain=1.5) for i in range(n)]
     x_cpu = recipes.gaussian(72, rows, dim).requires_grad_(True)
     w_z, w_mid, w_l = recipes.gaussian(73, rows, dim), recipes.gaussian(74, rows, dim), recipes.gaussian(75, rows, 1)[:, 0]

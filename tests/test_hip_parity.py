@@ -121,7 +121,7 @@ def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim, kernel):
             assert_close(ld, ref_ld, RTOL, "ld")
 
 
-@pytest.mark.parametrize("rows", [1, 17, 1000, 4099])
+@pytest.mark.parametrize("rows", [1, 17, 777, 1000, 4099])
 @pytest.mark.parametrize("dim,hid", [(2, 24), (4, 24), (6, 16), (10, 24), (24, 24), (30, 16), (40, 24), (50, 24), (62, 24),
                                      (100, 24), (58, 16), (130, 24), (200, 24), (250, 24)])
 def test_affine_half_narrow_halves_vs_oracle(amd, O, rows, dim, hid):

@@ -44,6 +44,8 @@ SIGNATURES = {
     "mnf_affine_half_image_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_flat_floats": (c_int64, [c_int, c_int, _intp, c_int, c_int]),
     "mnf_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_pack_gather_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "mnf_pack_gather_split_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p]),
     "mnf_nsf_cl": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                            c_float, c_int, c_int, _intp, c_int, c_void_p]),
     "mnf_nsf_cl_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,

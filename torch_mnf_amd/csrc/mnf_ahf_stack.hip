@@ -157,9 +157,6 @@ int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float*
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (n_hidden != 3 || hidden[0] != hidden[1] || hidden[1] != hidden[2]) return MNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(images) |
-       reinterpret_cast<uintptr_t>(intermediates)) & 15)
-    return MNF_ERR_UNSUPPORTED;
   uint32_t bits = 0;
   for (int l = 0; l < n_layers; ++l) bits |= (parity_host[l] ? 1u : 0u) << l;
   const int hid = hidden[0];
@@ -170,6 +167,9 @@ int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float*
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (log_prob || log_prob_sum) return MNF_ERR_UNSUPPORTED;  // only the split kernel has the fused log-prob epilogue
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(images) |
+       reinterpret_cast<uintptr_t>(intermediates)) & 15)
+    return MNF_ERR_UNSUPPORTED;  // 16-byte row accesses (the split launcher has its own check: narrow halves need none)
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) \
     return mnf::launch_stack<HH, HD>(x, y, intermediates, log_det, y_sqnorm, accumulate, images, bits, n_layers, rows, \

@@ -459,8 +459,12 @@ __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __
   }
 }
 
+// blockIdx.y = image number: the k-th image is gathered from flat + k * flat_stride (layers of one shape whose
+// parameters sit back to back share the index table)
 __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
-                                   float* __restrict__ image, int64_t n) {
+                                   float* __restrict__ image, int64_t n, int64_t flat_stride) {
+  flat += (int64_t)blockIdx.y * flat_stride;
+  image += (int64_t)blockIdx.y * n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t s = idx[i];
@@ -470,7 +474,10 @@ __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t
 
 // ---------------------------------------------------------------- pack: flat fp32 -> split image
 __global__ void pack_gather_split_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
-                                         uint32_t* __restrict__ image, int64_t n_split, int64_t n_plain) {
+                                         uint32_t* __restrict__ image, int64_t n_split, int64_t n_plain,
+                                         int64_t flat_stride) {
+  flat += (int64_t)blockIdx.y * flat_stride;
+  image += (int64_t)blockIdx.y * (n_split + n_plain + MNF_SPLIT_TAIL_WORDS);
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float mx = 0.f;
   if (w < n_split) {
@@ -661,25 +668,40 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
   return check_launch();
 }
 
-int mnf_pack_gather_split(const float* flat, const int32_t* idx, void* image, int64_t n_split_words,
-                          int64_t n_plain_words, void* stream) {
-  if (!flat || !idx || !image || n_split_words < 0 || n_plain_words < 0) return MNF_ERR_INVALID_ARG;
-  uint32_t* img = static_cast<uint32_t*>(image);
-  const int64_t n = n_split_words + n_plain_words;
-  if (hipMemsetAsync(img + n, 0, MNF_SPLIT_TAIL_WORDS * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+int mnf_pack_gather_split_batch(const float* flat, const int32_t* idx, void* images, int64_t n_split_words,
+                                int64_t n_plain_words, int n_images, int64_t flat_stride, void* stream) {
+  if (!flat || !idx || !images || n_split_words < 0 || n_plain_words < 0 || n_images < 1 || n_images > 65535 ||
+      flat_stride < 0)
+    return MNF_ERR_INVALID_ARG;
+  uint32_t* img = static_cast<uint32_t*>(images);
+  const int64_t n = n_split_words + n_plain_words, image_words = n + MNF_SPLIT_TAIL_WORDS;
+  // the tail words collect max |weight| by atomicMax: zero them first (one memset over the tails' span)
+  if (hipMemsetAsync(img + n, 0, ((n_images - 1) * image_words + MNF_SPLIT_TAIL_WORDS) * sizeof(uint32_t),
+                     (hipStream_t)stream) != hipSuccess)
     return check_launch();
   if (n == 0) return MNF_OK;
-  hipLaunchKernelGGL(pack_gather_split_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, flat,
-                     idx, img, n_split_words, n_plain_words);
+  hipLaunchKernelGGL(pack_gather_split_kernel, dim3(grid_for(n, 256), n_images), dim3(256), 0, (hipStream_t)stream,
+                     flat, idx, img, n_split_words, n_plain_words, flat_stride);
+  return check_launch();
+}
+
+int mnf_pack_gather_split(const float* flat, const int32_t* idx, void* image, int64_t n_split_words,
+                          int64_t n_plain_words, void* stream) {
+  return mnf_pack_gather_split_batch(flat, idx, image, n_split_words, n_plain_words, 1, 0, stream);
+}
+
+int mnf_pack_gather_batch(const float* flat, const int32_t* idx, float* images, int64_t n, int n_images,
+                          int64_t flat_stride, void* stream) {
+  if (!flat || !idx || !images || n < 0 || n_images < 1 || n_images > 65535 || flat_stride < 0)
+    return MNF_ERR_INVALID_ARG;
+  if (n == 0) return MNF_OK;
+  hipLaunchKernelGGL(pack_gather_kernel, dim3(grid_for(n, 256), n_images), dim3(256), 0, (hipStream_t)stream,
+                     flat, idx, images, n, flat_stride);
   return check_launch();
 }
 
 int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream) {
-  if (!flat || !idx || !image || n < 0) return MNF_ERR_INVALID_ARG;
-  if (n == 0) return MNF_OK;
-  hipLaunchKernelGGL(pack_gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     flat, idx, image, n);
-  return check_launch();
+  return mnf_pack_gather_batch(flat, idx, image, n, 1, 0, stream);
 }
 
 // -------------------------------------------------------------------------- NSF_CL

@@ -259,12 +259,15 @@ class _AffineRunFn(torch.autograd.Function):
     def forward(ctx, x, flat_with_grad, run, inverse):
         n = len(run.layers)
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        outs = run.launch(x, inverse, ld, False, None, keep=True)
+        flat = flat_with_grad.detach()
+        imgs = run.images(x.device, flat)  # after a weight update: repacked from this one concatenation
+        run._checked = (x.device, imgs)
+        outs = run.launch(x, inverse, ld, False, None, keep=True) if imgs[0] is not None else None
         if outs is None:
             raise MnfHipError("mnf_affine_half_stack", _lib.MNF_ERR_UNSUPPORTED, "no stack kernel for this shape")
         ctx.run, ctx.inverse = run, inverse
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x, flat_with_grad.detach(), *outs[:-1])
+        ctx.save_for_backward(x, flat, *outs[:-1])
         ctx.n = n
         return (*outs, ld)
 
@@ -289,10 +292,19 @@ class _AffineRunFn(torch.autograd.Function):
             k = run.layers.index(f)
             gy = None if g is None else g.contiguous()
             gx = torch.empty_like(x)
-            _lib.check("mnf_affine_half_bwd_mfma", lib.mnf_affine_half_bwd_mfma(
-                inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
-                flat.data_ptr() + 4 * offs[k], f._bwd_index(x.device).data_ptr(), x.shape[0], f.dim,
-                int(bool(f.parity)), int(inverse), len(f.h_sizes), f._hid, _stream()))
+            index = f._bwd_index(x.device)
+            rc = _lib.MNF_ERR_UNSUPPORTED
+            if index is not None:
+                rc = lib.mnf_affine_half_bwd_mfma(
+                    inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
+                    flat.data_ptr() + 4 * offs[k], index.data_ptr(), x.shape[0], f.dim,
+                    int(bool(f.parity)), int(inverse), len(f.h_sizes), f._hid, _stream())
+            if rc == _lib.MNF_ERR_UNSUPPORTED:  # no MFMA gradient kernel for this shape (e.g. a narrow half)
+                rc = lib.mnf_affine_half_bwd(
+                    inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
+                    flat.data_ptr() + 4 * offs[k], x.shape[0], f.dim, int(bool(f.parity)), int(inverse),
+                    len(f.h_sizes), f._hid, int(f.scale), int(f.shift), _stream())
+            _lib.check("mnf_affine_half_bwd", rc)
             g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
         return g, grad_flat, None, None
 
@@ -348,6 +360,21 @@ class _HipFlow(nn.Module):
         flat, image = self._packed(device)
         return flat, image, (None if (self.force_fp32_mfma or _FP32_MFMA_ENV) else self._split)
 
+    def _device_index(self, device: torch.device) -> Tensor | None:
+        """Device copy of the fp32 operand-image index table (built once), or None."""
+        if self._index is None or self._index.device != device:
+            host = self._image_index_host()
+            self._index = None if host is None else torch.frombuffer(host, dtype=torch.int32).clone().to(device)
+        return self._index
+
+    def _device_split_index(self, device: torch.device):
+        """(device index table, n_split_words, n_plain_words) of the split operand image, or False."""
+        if self._split_index is None or (self._split_index and self._split_index[0].device != device):
+            host = self._split_index_host()
+            self._split_index = False if host is None else (
+                torch.frombuffer(host[0], dtype=torch.int32).clone().to(device), host[1], host[2])
+        return self._split_index
+
     def _packed(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
         params = self._packed_params()
         if not params:
@@ -356,10 +383,7 @@ class _HipFlow(nn.Module):
         if key != self._cache_key:
             flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
             self._flat = flat.contiguous()
-            if self._index is None or self._index.device != device:
-                host = self._image_index_host()
-                self._index = None if host is None else torch.frombuffer(
-                    host, dtype=torch.int32).clone().to(device)
+            self._device_index(device)
             if self._index is not None:
                 image = torch.empty(self._index.numel(), dtype=torch.float32, device=device)
                 _lib.check("mnf_pack_gather", _lib.load().mnf_pack_gather(
@@ -368,10 +392,7 @@ class _HipFlow(nn.Module):
                 self._image = image
             else:
                 self._image = None
-            if self._split_index is None or (self._split_index and self._split_index[0].device != device):
-                host = self._split_index_host()
-                self._split_index = False if host is None else (
-                    torch.frombuffer(host[0], dtype=torch.int32).clone().to(device), host[1], host[2])
+            self._device_split_index(device)
             if self._split_index:
                 sidx, n_split, n_plain = self._split_index
                 split = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=device)
@@ -978,16 +999,35 @@ class _AffineRun:
             self._plist = (sig, [p for f in self.layers for p in f._packed_params()])
         return self._plist[1]
 
-    def images(self, device):
-        key = (device, [f.force_fp32_mfma for f in self.layers], [(p.data_ptr(), p._version) for p in self._params()])
+    def images(self, device, flat: Tensor | None = None):
+        """(fp32 operand images, split operand images) of all layers, back to back; repacked after a weight update
+        with ONE parameter concatenation (``flat``: the caller's, if it already has one) and one launch per kind."""
+        params = self._params()
+        key = (device, [f.force_fp32_mfma for f in self.layers], [(p.data_ptr(), p._version) for p in params])
         if key != self._key:
-            imgs = [f._packed(device)[1] for f in self.layers]
-            self._images = None if any(i is None for i in imgs) else torch.cat(imgs).contiguous()
-            splits = [f._split_image(device) for f in self.layers]
-            self._splits = None if any(i is None for i in splits) else torch.cat(splits).contiguous()
-            self._key = key
-            if self._images is None:  # the shape has no specialised kernel at all: a static property
+            f0, n = self.layers[0], len(self.layers)
+            index = f0._device_index(device)
+            self._images = self._splits = None
+            if index is None:  # the shape has no specialised kernel at all: a static property
                 self._unsupported = True
+            else:
+                lib = _lib.load()
+                if flat is None:
+                    flat = torch.cat([p.detach().reshape(-1) for p in params])
+                flat = flat.to(device=device, dtype=torch.float32).contiguous()
+                stride = flat.numel() // n
+                self._images = torch.empty(n * index.numel(), dtype=torch.float32, device=device)
+                _lib.check("mnf_pack_gather_batch", lib.mnf_pack_gather_batch(
+                    flat.data_ptr(), index.data_ptr(), self._images.data_ptr(), index.numel(), n, stride, _stream()))
+                sidx = f0._device_split_index(device)
+                if sidx and not _FP32_MFMA_ENV and not any(f.force_fp32_mfma for f in self.layers):
+                    table, n_split, n_plain = sidx
+                    self._splits = torch.empty(n * (n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS), dtype=torch.int32,
+                                               device=device)
+                    _lib.check("mnf_pack_gather_split_batch", lib.mnf_pack_gather_split_batch(
+                        flat.data_ptr(), table.data_ptr(), self._splits.data_ptr(), n_split, n_plain, n, stride,
+                        _stream()))
+            self._key = key
         return self._images, self._splits
 
     def usable(self, x) -> bool:
@@ -1003,16 +1043,17 @@ class _AffineRun:
         return True
 
     def trainable(self, x) -> bool:
-        """Gradients wanted and the whole run can go through one autograd node (stack kernel forward, fp32-MFMA
-        gradient kernel per layer backward)."""
+        """Gradients wanted and the whole run can go through one autograd node (stack kernel forward; backward
+        layer by layer on the saved intermediates: the fp32-MFMA gradient kernel, or the generic one for shapes
+        it does not cover)."""
         return (not self._unsupported and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
                 and x.shape[1] == self.layers[0].dim and not any(f.force_generic for f in self.layers)
-                and any(_wants_grad(f, x) for f in self.layers) and self.images(x.device)[0] is not None
-                and self.layers[0]._bwd_index(x.device) is not None)
+                and any(_wants_grad(f, x) for f in self.layers)
+                and self.layers[0]._device_index(x.device) is not None)
 
     def launch_grad(self, x: Tensor, inverse: bool):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
-        flat = torch.cat([p.reshape(-1) for f in self.layers for p in f._packed_params()])
+        flat = torch.cat([p.reshape(-1) for p in self._params()])
         out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
         if out is None:
             return None
