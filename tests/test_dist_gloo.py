@@ -25,7 +25,7 @@ def _worker(rank, world, port, rows, out):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from oracle import flow_oracle as O
-    from torch_mnf_amd.dist import shard_bounds, sharded_mean_log_prob
+    from torch_mnf_amd.dist import shard_bounds, sharded_mean_log_prob, sharded_mean_log_prob_async
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,8 +39,12 @@ def _worker(rank, world, port, rows, out):
         return lp.double().sum().reshape(1)
 
     mean = sharded_mean_log_prob(local_sum, x[lo:hi])
+    # pipelined form (bench.py's N > 1 step): the reduction of batch k is collected after batch k + 1 is enqueued
+    first = sharded_mean_log_prob_async(local_sum, x[lo:hi])
+    second = sharded_mean_log_prob_async(local_sum, 2 * x[lo:hi])
+    piped = (float(first.result()), float(second.result()))
     if rank == 0:
-        out.put((float(mean), lo, hi))
+        out.put((float(mean), lo, hi, piped))
     dist.destroy_process_group()
 
 
@@ -54,13 +58,15 @@ def test_sharded_mean_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, rows, q)) for r in range(world)]
     for p in procs:
         p.start()
-    mean, lo, hi = q.get(timeout=120)
+    mean, lo, hi, piped = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     ref, _ = O.mean_log_prob(recipes.gaussian(99, rows, 64), c2_layers(64, 3))
     assert (lo, hi) == (0, 501)
     assert abs(mean - ref) <= 1e-9 * abs(ref)
+    ref2, _ = O.mean_log_prob(2 * recipes.gaussian(99, rows, 64), c2_layers(64, 3))
+    assert abs(piped[0] - ref) <= 1e-9 * abs(ref) and abs(piped[1] - ref2) <= 1e-9 * abs(ref2)
 
 
 def test_shard_bounds_cover_rows_exactly():

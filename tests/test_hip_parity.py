@@ -1034,3 +1034,34 @@ def test_foreign_duck_typed_flow_in_stack(amd):
     assert_close(ld, l1 + 0.5, 1e-6)
     zs, ldi = stack.inverse(xs[-1])
     assert float((zs[-1] - x).abs().max()) < 1e-4
+
+
+def test_pipelined_all_reduce_on_rccl(amd):
+    """The N > 1 step of bench.py on RCCL itself (a one-rank group on this one-GPU box): the 16-byte all-reduce is
+    left in flight (async_op) while the next pass is enqueued, and collected afterwards."""
+    import socket
+
+    import torch.distributed as dist
+    from torch_mnf_amd.dist import reduce_sum_count
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV, 0))
+    try:
+        dim, rows = 64, 5000
+        model = build_ahf_stack(amd, c2_layers(dim), dim)
+        x = cuda(recipes.gaussian(31, rows, dim))
+        with torch.no_grad():
+            lp, total = model.log_prob(x, return_sum=True)
+            first = reduce_sum_count(total, rows, async_op=True, force_collective=True)
+            lp2, total2 = model.log_prob(2 * x, return_sum=True)  # enqueued while the reduction is in flight
+            second = reduce_sum_count(total2, rows, async_op=True, force_collective=True)
+            m1, m2 = float(first.result()), float(second.result())
+            s_sync, c_sync = reduce_sum_count(total, rows, force_collective=True)
+        assert abs(m1 - float(lp.double().mean())) <= 1e-9 * abs(m1)
+        assert abs(m2 - float(lp2.double().mean())) <= 1e-9 * abs(m2)
+        assert float(c_sync) == rows and abs(float(s_sync) / rows - m1) <= 1e-12 * abs(m1)
+    finally:
+        dist.destroy_process_group()

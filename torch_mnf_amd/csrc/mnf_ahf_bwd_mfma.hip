@@ -302,7 +302,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   if (grad_flat == nullptr) return;
   __syncthreads();
   float* red = lds;  // the images are no longer needed
-  constexpr int DW_FLOATS = S::DW_TILES * 256, DB_FLOATS = S::DB_TILES * 64;
+  constexpr int DW_FLOATS = S::DW_TILES * 256;
   for (int w = 0; w < kBwdWaves; ++w) {
     if (wave == w) {
 #pragma unroll

@@ -4,8 +4,10 @@
 // Per 16-row tile at d = 64: 45 v_mfma_f32_16x16x32_f16 (16 cycles each, half of them free for
 // VALU issue) instead of 96 v_mfma_f32_16x16x4_f32 (32 cycles each, none free), which moves the
 // layer from issue bound to HBM bound.  Two kernels share the conditioner:
-//   ahf_split_kernel        one coupling layer per launch (the default AffineHalfFlow path)
-//   ahf_split_stack_kernel  L layers per launch, rows kept in registers (opt-in, FusedAffineStack)
+//   ahf_split_kernel        one coupling layer per launch (a single AffineHalfFlow call)
+//   ahf_split_stack_kernel  L layers per launch, rows kept in registers, every intermediate written once
+//                           (what NormalizingFlow does with a run of equal layers; FusedAffineStack: no
+//                           intermediates); its ragged variant also serves halves narrower than an MFMA tile
 // A tile whose operands leave the f16 range is recomputed with fp32 MFMAs from the fp32 operand image
 // (read from global memory: the cold path is about correctness, not speed).
 #include <hip/hip_runtime.h>
@@ -202,6 +204,8 @@ template <int H>
 constexpr int stack_tiles() { return H <= 32 ? 2 : 1; }
 template <int H>
 constexpr int stack_waves() { return H <= 32 ? 4 : 8; }
+template <int H>
+constexpr int stack_waves_per_simd() { return 2; }
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // Image copy L2 -> LDS by LDS-DMA (no staging registers).  One wave-instruction copies 64 x 16 B; the LDS
@@ -251,7 +255,7 @@ __device__ __forceinline__ void half_store4(float* p, int col, int h, bool vec, 
 }
 
 template <int H, int HID, bool INV, bool RAG>
-__global__ void __launch_bounds__(stack_waves<H>() * 64, 2)
+__global__ void __launch_bounds__(stack_waves<H>() * 64, stack_waves_per_simd<H>())
 ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mid,
                        float* __restrict__ log_det, float* __restrict__ ysq, const uint32_t* __restrict__ simages,
                        const float* __restrict__ images_f32, uint32_t parity_bits, int n_layers, int64_t rows,
@@ -543,7 +547,7 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
       return 0;
     // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
     // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
-    per_cu = 8 / kStackWaves;
+    per_cu = 4 * stack_waves_per_simd<H>() / kStackWaves;
     while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
     return per_cu * cus;
   }();

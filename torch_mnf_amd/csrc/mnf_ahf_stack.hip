@@ -1,4 +1,6 @@
-// Opt-in whole-stack fusion of consecutive AffineHalfFlow layers.
+// Whole-stack fusion of consecutive AffineHalfFlow layers: the C entry point
+// mnf_affine_half_stack (which tries the split kernel of mnf_ahf_split.hip first) and the fp32-MFMA
+// stack kernel behind it.
 //
 // mnf_affine_half_stack runs L coupling layers in ONE launch: a wave keeps its 16 rows in
 // registers across all layers, so HBM sees the rows once in and once out (8d + 8 bytes per row
@@ -7,9 +9,10 @@
 // shared by the eight waves of a workgroup: the image of layer l+1 is requested into registers
 // before layer l is computed and handed over at one barrier per layer.
 //
-// This drops every intermediate tensor, so it is NOT what NormalizingFlow.forward/inverse return
-// (the reference's API keeps all L+1 tensors, core.py:20-24); callers opt in through
-// torch_mnf_amd.FusedAffineStack and the number is reported separately from the headline metric.
+// With `intermediates` the output of every layer is written once (never re-read): that is what
+// NormalizingFlow.forward/inverse return (the reference's API keeps all L+1 tensors, core.py:20-24).
+// Without it every intermediate tensor is dropped: callers opt in through torch_mnf_amd.FusedAffineStack
+// and that number is reported separately from the headline metric.
 #include <hip/hip_runtime.h>
 
 #include "mnf_ahf_shape.h"

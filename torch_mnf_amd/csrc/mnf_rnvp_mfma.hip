@@ -286,7 +286,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
                                                  int64_t rows, int d, int accumulate, uint64_t seed,
                                                  const float* zprm) {
   using S = RnvpSplitShape<HN>;
-  constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC, NROW = S::NROW;
+  constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int G = d / 16;                  // 16-dim groups of a row = GEMM-2 output tiles
