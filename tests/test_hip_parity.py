@@ -1065,3 +1065,23 @@ def test_pipelined_all_reduce_on_rccl(amd):
         assert float(c_sync) == rows and abs(float(s_sync) / rows - m1) <= 1e-12 * abs(m1)
     finally:
         dist.destroy_process_group()
+
+
+def test_every_even_width_up_to_256_matches_the_generic_kernel(amd):
+    """Sweep of all 128 even dims: the MFMA path (full tiles, or the ragged variant for a narrow half) against the
+    shape-generic kernel, one layer, both directions, a row count that leaves a partial tile."""
+    worst = 0.0
+    for dim in range(2, 257, 2):
+        sd = recipes.affine_half_params(900 + dim, dim, s_last_gain=1.5)
+        f = ahf_module(amd, sd, dim, bool((dim // 2) % 2))
+        assert f._split_image(torch.device(DEV, 0)) is not None, dim
+        x = cuda(recipes.gaussian(dim, 37, dim))
+        for inverse in (False, True):
+            y, ld = f.forward(x, inverse=inverse)
+            f.force_generic = True
+            y_g, ld_g = f.forward(x, inverse=inverse)
+            f.force_generic = False
+            err = max(float((y - y_g).abs().max() / y_g.abs().max()), float((ld - ld_g).abs().max() / ld_g.abs().max()))
+            worst = max(worst, err)
+            assert err <= RTOL, (dim, inverse, err)
+    assert worst > 0.0  # two different kernels, not the same one twice
