@@ -127,7 +127,8 @@ int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden_host,
 int64_t mnf_affine_half_flat_floats(int dim, int n_hidden, const int* hidden_host,
                                     int has_scale, int has_shift);
 
-/* image[i] = idx[i] < 0 ? 0 : flat[idx[i]]  (device-side repack after a weight update). */
+/* image[i] = flat[idx[i]] for idx[i] >= 0, 0 for -1, the constant 80.0 for -2 (the scale bias of an RNVP output
+ * dim that only exists as padding: gate 1, log gate 0)  (device-side repack after a weight update). */
 /* Split-image pack (device): split word w = two f16 halves, half h from entry e = idx[2 w + h]:
  * e < 0 -> 0; else v = flat[e & 0x3fffffff], hi = f16(v), and the half is hi, or f16((v - hi) * 2^11)
  * when bit 30 of e is set.  Plain word w = flat[idx[2 n_split_words + w]] (or 0).  Also writes the

@@ -172,7 +172,7 @@ def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
     _check_split_table(halves, plain, n_weights, n_params)
 
 
-@pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30)])
+@pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30), (50, 50), (49, 30), (100, 30), (790, 50)])
 def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
     from torch_mnf_amd._lib import int_array
 
@@ -181,6 +181,14 @@ def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
     n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
     halves, plain = _split_table(lib, lib.mnf_rnvp_split_layout, lib.mnf_rnvp_split_index, (dim, 1, int_array([hid])))
     _check_split_table(halves, plain, n_weights, n_params)
+    # dims that only exist as padding (dim % 16 != 0) get the "big" scale bias: gate 1, log gate 0
+    assert (plain == -2).sum() == (-dim) % 16
+    n = lib.mnf_rnvp_image_floats(dim, 1, int_array([hid]))
+    idx = (ctypes.c_int32 * n)()
+    assert lib.mnf_rnvp_image_index(dim, 1, int_array([hid]), idx) == 0
+    a = np.frombuffer(idx, dtype=np.int32)
+    used = a[a >= 0]
+    assert len(used) == n_params and len(np.unique(used)) == n_params and (a == -2).sum() == (-dim) % 16
 
 
 @pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8)])

@@ -202,8 +202,12 @@ def test_affine_half_mfma_shape_matrix(amd, O, dim, hid, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["split", "fp32"])
-@pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50), (784, 50), (80, 30)])
+@pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50), (784, 50), (80, 30),
+                                     (50, 50), (49, 30), (70, 50), (100, 50), (130, 30), (500, 50), (790, 50)])
 def test_rnvp_mfma_shape_matrix(amd, O, dim, hid, kernel):
+    """(dim, hidden width) pairs of the MFMA kernels; dim % 16 != 0 (MNFLinear(50, 10)'s flow, MNFFeedForward's
+    100 / 500-wide layers) runs the ragged variants: zero-padded operand image, masked row accesses (16-byte
+    when dim % 4 == 0, else element by element), padded scale bias such that nothing reaches log_det."""
     sd = recipes.rnvp_params(95 + dim + hid, dim, hid)
     f = amd.RNVP(dim, h_sizes=(hid,))
     f.load_state_dict(sd)
@@ -217,13 +221,20 @@ def test_rnvp_mfma_shape_matrix(amd, O, dim, hid, kernel):
         x, ld = f.forward(cuda(z), mask=cuda(mask))
         assert_close(x, ref_x, RTOL, "x")
         assert_close(ld, ref_ld, RTOL, "ld")
+        # the in-kernel mask: same bits as mnf_rnvp_mask materialises
+        m_seed = f.mask_for(77, rows)
+        x_s, ld_s = f.forward(cuda(z), seed=77)
+        ref_x, ref_ld = O.rnvp(z, sd, m_seed.cpu())
+        assert_close(x_s, ref_x, RTOL, "x (seeded)")
+        assert_close(ld_s, ref_ld, RTOL, "ld (seeded)")
 
 
+@pytest.mark.parametrize("dim", [800, 50, 100])
 @pytest.mark.parametrize("case", ["big_inputs", "big_weights", "inf_input", "one_big_row", "tiny_inputs"])
-def test_rnvp_split_range_guard(amd, O, case):
+def test_rnvp_split_range_guard(amd, O, case, dim):
     """RNVP on the split path: a 128-row group whose operands leave the f16 range is recomputed with fp32
-    MFMAs inside the same launch; the other groups stay on the split path."""
-    dim, hid, rows = 800, 50, 700
+    MFMAs inside the same launch; the other groups stay on the split path (dim 50 / 100: ragged variants)."""
+    hid, rows = 50, 700
     sd = recipes.rnvp_params(140, dim, hid)
     z = recipes.gaussian(141, rows, dim)
     if case == "big_inputs":
@@ -951,6 +962,35 @@ def test_g8_mnf_linear_sample_z(amd, golden):
     assert torch.isfinite(layer.kl_div())
     ref_keys = ["W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"]
     assert list(layer.state_dict())[:9] == ref_keys
+
+
+def test_mnf_linear_50_10_sample_z_vs_oracle(amd, O):
+    """Config 5's second workload: MNFLinear(50, 10) -- its flow is 50 wide, i.e. not a multiple of the kernels'
+    16-dim groups: the ragged RNVP variants, with the sample_z prologue fused into the first one."""
+    n_in, rows = 50, 777
+    layer = amd.MNFLinear(n_in, 10)
+    sds = [recipes.rnvp_params(850 + i, n_in, 50) for i in range(2)]
+    for f, sd in zip(layer.flow_q.flows, sds):
+        f.load_state_dict(sd)
+    q0_mean, q0_log_var = recipes.gaussian(851, 1, n_in)[0], recipes.gaussian(852, 1, n_in)[0] * 0.3 - 2.0
+    layer.load_state_dict({"q0_mean": q0_mean, "q0_log_var": q0_log_var}, strict=False)
+    layer.to(DEV)
+    eps = recipes.gaussian(853, rows, n_in)
+    masks = [recipes.bernoulli_mask(854 + i, rows, n_in) for i in range(2)]
+    z = q0_mean + q0_log_var.exp().sqrt() * eps   # mnf_linear.py:59-62
+    ld_ref = 0
+    for sd, m in zip(sds, masks):
+        z, l1 = O.rnvp(z, sd, m)
+        ld_ref = ld_ref + l1
+    with torch.no_grad():
+        assert layer._fused_prologue_ok(layer.flow_q.flows[0], cuda(eps))
+        z_f, ld_f = layer.sample_z(rows, eps=cuda(eps), masks=[cuda(m) for m in masks])
+        layer.fuse_prologue = False
+        z_u, ld_u = layer.sample_z(rows, eps=cuda(eps), masks=[cuda(m) for m in masks])
+    assert_close(z_f, z, RTOL, "z")
+    assert_close(ld_f, ld_ref, RTOL, "log_det")
+    assert_close(z_u, z_f, 1e-6, "fused vs unfused z")
+    assert_close(ld_u, ld_f, 1e-6, "fused vs unfused log_det")
 
 
 # ------------------------------------------------------- contracts of the boundary

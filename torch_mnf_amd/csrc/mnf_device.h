@@ -13,6 +13,10 @@ constexpr float kMinDeriv = 1e-3f;   // spline_flow.py:19
 // log(exp(1 - 1e-3) - 1) evaluated in float64 then rounded (spline_flow.py:47-49)
 constexpr float kEdgeDerivConst = 0.53974241439865964f;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+// Index-table entries of the pack kernels: >= 0 a flat-parameter offset, -1 zero, kPackBigBias the constant
+// kPackBigBiasValue (a padded RNVP output dim's scale bias: sigmoid = 1 and its log = 0 exactly in fp32).
+constexpr int32_t kPackBigBias = -2;
+constexpr float kPackBigBiasValue = 80.f;
 
 // Shapes of one conditioner net: n_lin Linear layers, sizes[0..n_lin], and the float
 // offset of each weight / bias inside the flat parameter buffer.

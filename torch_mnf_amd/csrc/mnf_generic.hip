@@ -468,7 +468,7 @@ __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t s = idx[i];
-    image[i] = s < 0 ? 0.f : flat[s];
+    image[i] = s >= 0 ? flat[s] : (s == kPackBigBias ? kPackBigBiasValue : 0.f);
   }
 }
 
@@ -496,7 +496,7 @@ __global__ void pack_gather_split_kernel(const float* __restrict__ flat, const i
     image[w] = word;
   } else if (w < n_split + n_plain) {
     const int32_t e = idx[2 * n_split + (w - n_split)];
-    image[w] = e < 0 ? 0u : __builtin_bit_cast(uint32_t, flat[e]);
+    image[w] = __builtin_bit_cast(uint32_t, e >= 0 ? flat[e] : (e == kPackBigBias ? kPackBigBiasValue : 0.f));
   }
   // non-negative floats order like their bit patterns
   if (mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));

@@ -16,8 +16,8 @@
 // z and the mask are read twice (once as the GEMM-1 operand, once in the epilogue; the second
 // read mostly hits L2 / Infinity Cache) and x is written once.
 //
-// Supported here: one hidden layer (net is a bare Linear, as MNFLinear uses it), d % 16 == 0;
-// everything else runs the generic kernel.
+// Supported here: one hidden layer (net is a bare Linear, as MNFLinear uses it) of width 50 or 30, d >= 49
+// (d % 16 != 0: the ragged variants, see row_load4); everything else runs the generic kernel.
 #include <hip/hip_runtime.h>
 
 #include "mnf_device.h"
@@ -46,6 +46,40 @@ struct RnvpShape {
   static constexpr int STAGE_F4 = (CHUNK_FLOATS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);  // float4 per thread
 };
 
+// Ragged rows (RAG): the row in memory is `dm` floats wide, the kernels work on d = dm rounded up to a multiple of
+// 16 -- the operand images are zero in the padded columns (and carry kPackBigBias as the padded scale bias, so
+// gate = 1 and log gate = 0 there: nothing reaches log_det).  Loads return 0 past the row end, stores skip it;
+// `vec`: dm % 4 == 0 and 16-byte aligned bases keep the 16-byte access, else element by element.
+// (`rowq` = row start + 4 q, the lane's own float4 column inside a 16-dim group; `col` = 16 g; `q4` = 4 q)
+template <bool RAG>
+__device__ __forceinline__ f32x4 row_load4(const float* rowq, int col, int q4, int dm, bool vec) {
+  if (!RAG) return *reinterpret_cast<const f32x4*>(rowq + col);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if (col + q4 < dm) v = *reinterpret_cast<const f32x4*>(rowq + col);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float e = 0.f;
+      if (col + q4 + r < dm) e = rowq[col + r];
+      v[r] = e;
+    }
+  }
+  return v;
+}
+template <bool RAG>
+__device__ __forceinline__ void row_store4(float* rowq, int col, int q4, int dm, bool vec, const f32x4& v) {
+  if (!RAG) {
+    *reinterpret_cast<f32x4*>(rowq + col) = v;
+  } else if (vec) {
+    if (col + q4 < dm) *reinterpret_cast<f32x4*>(rowq + col) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + q4 + r < dm) rowq[col + r] = v[r];
+  }
+}
+
 // 1/(1+exp(-v)) with the 6-instruction exp of the AffineHalfFlow kernel
 __device__ __forceinline__ float exp6r(float x) {
   const float c_hi = 1.44269502162933349609375f, c_lo = 1.925963033500011e-08f, ln2 = 0.693147182464599609375f;
@@ -63,12 +97,14 @@ __device__ __forceinline__ float exp6r(float x) {
 // So neither HBM/L2 latency (rows, operands) nor the LDS fill is on the MFMA chain's critical path.
 // SEEDED: the mask is regenerated from (seed, row, dim) wherever it is needed instead of being
 // read -- 8d fewer bytes per row (a float mask is otherwise read twice).
-template <int HN, bool SEEDED>
+template <int HN, bool SEEDED, bool RAG = false>
 __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CHUNK_FLOATS], int grp,
                                                const float* __restrict__ z, const float* __restrict__ mask,
                                                float* __restrict__ x, float* __restrict__ log_det,
                                                const float* __restrict__ image, int64_t rows, int d, int accumulate,
-                                               uint64_t seed, const float* zprm = nullptr) {
+                                               uint64_t seed, const float* zprm = nullptr, int dm_ragged = 0,
+                                               bool vec = true) {
+  const int dm = RAG ? dm_ragged : d;  // row width in memory
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT, KC = kRnvpChunkK, MC = kRnvpChunkM;
   constexpr int NROW = (KC / 4 > MC ? KC / 4 : MC);  // float4 row loads per chunk
@@ -101,18 +137,18 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
     const int64_t row = (int64_t)grp * (16 * kRnvpWaves) + wave * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
-    const float* zr = z + rowc * d + 4 * q;
-    const float* mr = SEEDED ? nullptr : mask + rowc * d + 4 * q;
-    float* xr = x + rowc * d + 4 * q;
+    const float* zr = z + rowc * dm + 4 * q;
+    const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
+    float* xr = x + rowc * dm + 4 * q;
     // zprm: the sample_z prologue fused into the loads, z = q0_mean + q0_std * eps (mnf_linear.py:59-62)
     auto load_z = [&](int dim0) -> f32x4 {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + dim0);
+      const f32x4 v = row_load4<RAG>(zr, dim0, 4 * q, dm, vec);
       if (zprm == nullptr) return v;
       return v * *reinterpret_cast<const f32x4*>(zprm + d + dim0 + 4 * q) +
              *reinterpret_cast<const f32x4*>(zprm + dim0 + 4 * q);
     };
     auto mask4 = [&](int dim0) -> f32x4 {  // four consecutive dims share one 32-bit mask word
-      if (!SEEDED) return *reinterpret_cast<const f32x4*>(mr + dim0);
+      if (!SEEDED) return row_load4<RAG>(mr, dim0, 4 * q, dm, vec);
       const int dd = dim0 + 4 * q;
       const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
       return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
@@ -205,7 +241,7 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
               o[r] = (gated * gate + (1.f - gate) * t4[r]) + keep;   // rnvp.py:37
               ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);  // :36
             }
-            if (live) *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+            if (live) row_store4<RAG>(xr, 16 * m, 4 * q, dm, vec, o);
           }
         }
       }
@@ -232,15 +268,16 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
   }
 }
 
-template <int HN, bool SEEDED>
+template <int HN, bool SEEDED, bool RAG>
 __global__ void __launch_bounds__(kRnvpWaves * 64, 4)  // two 8-wave workgroups per CU: <= 128 VGPRs
 rnvp_mfma_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                  float* __restrict__ log_det, const float* __restrict__ image, int64_t rows, int d,
-                 int accumulate, uint64_t seed) {
+                 int accumulate, uint64_t seed, int dm, int vec) {
   __shared__ __attribute__((aligned(16))) float lds[2][RnvpShape<HN>::CHUNK_FLOATS];
   const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
-    rnvp_group_f32<HN, SEEDED>(lds, grp, z, mask, x, log_det, image, rows, d, accumulate, seed);
+    rnvp_group_f32<HN, SEEDED, RAG>(lds, grp, z, mask, x, log_det, image, rows, d, accumulate, seed, nullptr, dm,
+                                    vec != 0);
 }
 
 // ================================================================================================
@@ -279,13 +316,14 @@ struct RnvpSplitShape {
 };
 
 // returns false (block-uniform) when the group has to be recomputed on the fp32 path
-template <int HN, bool SEEDED>
+template <int HN, bool SEEDED, bool RAG>
 __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
                                                  const float* __restrict__ mask, float* __restrict__ x,
                                                  float* __restrict__ log_det, const uint32_t* __restrict__ simage,
                                                  int64_t rows, int d, int accumulate, uint64_t seed,
-                                                 const float* zprm) {
+                                                 const float* zprm, int dm_ragged, bool vec) {
   using S = RnvpSplitShape<HN>;
+  const int dm = RAG ? dm_ragged : d;  // row width in memory (d: rounded up to whole 16-dim groups)
   constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
@@ -315,13 +353,13 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
   const int64_t row = (int64_t)grp * (16 * kRnvpWaves) + wave * 16 + j;
   const bool live = row < rows;
   const int64_t rowc = live ? row : rows - 1;
-  const float* zr = z + rowc * d + 4 * q;
-  const float* mr = SEEDED ? nullptr : mask + rowc * d + 4 * q;
-  float* xr = x + rowc * d + 4 * q;
+  const float* zr = z + rowc * dm + 4 * q;
+  const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
+  float* xr = x + rowc * dm + 4 * q;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mask4 = [&](int g) -> f32x4 {  // mask of dims 16 g + 4 q .. + 3; groups past the row end read as 0
     if (g < 0) return zero4;
-    if (!SEEDED) return *reinterpret_cast<const f32x4*>(mr + 16 * g);
+    if (!SEEDED) return row_load4<RAG>(mr, 16 * g, 4 * q, dm, vec);
     const int dd = 16 * g + 4 * q;
     const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
     return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
@@ -345,7 +383,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
     const int dd = 16 * (g < 0 ? 0 : g) + 4 * q;
     return v * *reinterpret_cast<const f32x4*>(zprm + d + dd) + *reinterpret_cast<const f32x4*>(zprm + dd);
   };
-  auto z4 = [&](int g) -> f32x4 { return z_of(*reinterpret_cast<const f32x4*>(zr + 16 * (g < 0 ? 0 : g)), g); };
+  auto z4 = [&](int g) -> f32x4 { return z_of(row_load4<RAG>(zr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec), g); };
   const f32x4 fake4 = f32x4{0.25f, -0.5f, 0.125f, 1.f};
 
   // Row data (z, and the mask when it is an input) comes from HBM with ~2 us of latency under load, while
@@ -449,8 +487,10 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
     for (int i = 0; i < MC; ++i) {
       const int g2 = row_group(c < nc ? c : nc - 1, i);
-      z2[u][i] = (kRnvpAbl == 2 || kRnvpAbl >= 5) ? fake4 : kRnvpNtLoad2 ? z_of(__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zr + 16 * (g2 < 0 ? 0 : g2))), g2)
-                              : z4(g2);
+      z2[u][i] = (kRnvpAbl == 2 || kRnvpAbl >= 5) ? fake4
+                 : (kRnvpNtLoad2 && !RAG)
+                     ? z_of(__builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zr + 16 * (g2 < 0 ? 0 : g2))), g2)
+                     : z4(g2);
       if (!SEEDED) m2[u][i] = mask4(row_group(c < nc ? c : nc - 1, i));
     }
   };
@@ -526,8 +566,8 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
               }
             }
             if (live && ((kRnvpAbl != 1 && kRnvpAbl < 5) || o[0] == 1.2345e30f)) {
-              if (kRnvpNtStore) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xr + 16 * m));
-              else *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+              if (kRnvpNtStore && !RAG) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(xr + 16 * m));
+              else row_store4<RAG>(xr, 16 * m, 4 * q, dm, vec, o);
             }
           }
         }
@@ -546,21 +586,23 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 
 // out-of-line on purpose: inlined next to the split path the two bodies compete for the 128 VGPRs of
 // a 4-waves/SIMD kernel and the hot path spills
-template <int HN, bool SEEDED>
+template <int HN, bool SEEDED, bool RAG>
 __device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int grp, const float* z, const float* mask,
                                                              float* x, float* log_det, const float* image,
                                                              int64_t rows, int d, int accumulate, uint64_t seed,
-                                                             const float* zprm) {
-  rnvp_group_f32<HN, SEEDED>(*reinterpret_cast<float(*)[2][RnvpShape<HN>::CHUNK_FLOATS]>(lds), grp, z, mask, x,
-                             log_det, image, rows, d, accumulate, seed, zprm);
+                                                             const float* zprm, int dm, bool vec) {
+  rnvp_group_f32<HN, SEEDED, RAG>(*reinterpret_cast<float(*)[2][RnvpShape<HN>::CHUNK_FLOATS]>(lds), grp, z, mask, x,
+                                  log_det, image, rows, d, accumulate, seed, zprm, dm, vec);
 }
 
-template <int HN, bool SEEDED>
+template <int HN, bool SEEDED, bool RAG>
 __global__ void __launch_bounds__(kRnvpWaves * 64, 4)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
                   int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
-                  const float* __restrict__ q0_log_var) {
+                  const float* __restrict__ q0_log_var, int dm_ragged, int vec_ok) {
+  const int dm = RAG ? dm_ragged : d;
+  const bool vec = vec_ok != 0;
   using S = RnvpSplitShape<HN>;
   using F = RnvpShape<HN>;
   constexpr int WORDS = S::CHUNK_WORDS > F::CHUNK_FLOATS ? S::CHUNK_WORDS : F::CHUNK_FLOATS;
@@ -570,8 +612,8 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   const float* zprm = nullptr;
   if (q0_mean != nullptr) {
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
-      zprm_lds[i] = q0_mean[i];
-      zprm_lds[d + i] = sqrtf(expf(q0_log_var[i]));  // mnf_linear.py:60
+      zprm_lds[i] = i < dm ? q0_mean[i] : 0.f;
+      zprm_lds[d + i] = i < dm ? sqrtf(expf(q0_log_var[i])) : 0.f;  // mnf_linear.py:60
     }
     zprm = zprm_lds;
     __syncthreads();
@@ -581,21 +623,24 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   const bool split_ok = wmax <= kSplitWeightLimit;
   const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    if (split_ok && rnvp_group_split<HN, SEEDED>(reinterpret_cast<uint32_t*>(lds[0]), reinterpret_cast<uint32_t*>(lds[1]),
-                                                 grp, z, mask, x, log_det, simage, rows, d, accumulate, seed, zprm))
+    if (split_ok && rnvp_group_split<HN, SEEDED, RAG>(reinterpret_cast<uint32_t*>(lds[0]),
+                                                      reinterpret_cast<uint32_t*>(lds[1]), grp, z, mask, x, log_det,
+                                                      simage, rows, d, accumulate, seed, zprm, dm, vec))
       continue;
-    rnvp_group_f32_cold<HN, SEEDED>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm);
+    rnvp_group_f32_cold<HN, SEEDED, RAG>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm,
+                                         dm, vec);
   }
 }
 
 // 2 entries per split word (low half, high half), then 1 entry per plain word -- see mnf_pack_gather_split
+// dm: the layer's real width (flat-parameter offsets, valid columns / rows); d: dm rounded up to 16
 template <int HN>
-static void build_split_index(int d, int32_t* idx) {
+static void build_split_index(int dm, int d, int32_t* idx) {
   using S = RnvpSplitShape<HN>;
   constexpr int YT = S::YT, NKS2 = S::NKS2;
   const int G = d / 16;
-  const int64_t wn = 0, bn = wn + (int64_t)HN * d, wt = bn + HN, bt = wt + (int64_t)d * HN, ws = bt + d,
-                bs = ws + (int64_t)d * HN;
+  const int64_t wn = 0, bn = wn + (int64_t)HN * dm, wt = bn + HN, bt = wt + (int64_t)dm * HN, ws = bt + dm,
+                bs = ws + (int64_t)dm * HN;
   const int64_t n_entries = 2 * S::split_words(d) + S::plain_words(d);
   for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
   // element e of lane (i, kq) of operand `op` (hi at 2 op, lo at 2 op + 1), base = first word of the region
@@ -611,8 +656,8 @@ static void build_split_index(int d, int32_t* idx) {
         const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
         if (u >= HN) continue;
         for (int e = 0; e < 8; ++e) {
-          const int g = 2 * ks + (e >> 2);
-          if (g < G) put(0, ks * YT + m, lane, e, wn + (int64_t)u * d + 16 * g + 4 * kq + (e & 3));
+          const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
+          if (g < G && col < dm) put(0, ks * YT + m, lane, e, wn + (int64_t)u * dm + col);
         }
       }
   // part 2: per output tile m: t operands for K-steps 0..NKS2-1, then s operands
@@ -623,7 +668,7 @@ static void build_split_index(int d, int32_t* idx) {
           const int i = lane & 15, kq = lane >> 4;
           for (int e = 0; e < 8; ++e) {
             const int tile = 2 * ks + (e >> 2), unit = 16 * tile + 4 * kq + (e & 3);
-            if (tile < YT && unit < HN)
+            if (tile < YT && unit < HN && 16 * m + i < dm)
               put(S::part1_words(d) + (int64_t)m * S::TILE2_WORDS, which * NKS2 + ks, lane, e,
                   (which ? ws : wt) + (int64_t)(16 * m + i) * HN + unit);
           }
@@ -631,18 +676,19 @@ static void build_split_index(int d, int32_t* idx) {
   int32_t* pl = idx + 2 * S::split_words(d);
   for (int m = 0; m < G; ++m)
     for (int i = 0; i < 16; ++i) {
-      pl[(int64_t)m * 32 + i] = (int32_t)(bt + 16 * m + i);
-      pl[(int64_t)m * 32 + 16 + i] = (int32_t)(bs + 16 * m + i);
+      const bool real = 16 * m + i < dm;  // padded output dims: shift 0, scale bias "big" (gate 1, log gate 0)
+      pl[(int64_t)m * 32 + i] = real ? (int32_t)(bt + 16 * m + i) : -1;
+      pl[(int64_t)m * 32 + 16 + i] = real ? (int32_t)(bs + 16 * m + i) : kPackBigBias;
     }
   for (int m = 0; m < YT; ++m)
     for (int i = 0; i < 16; ++i)
       if (16 * m + i < HN) pl[(int64_t)G * 32 + m * 16 + i] = (int32_t)(bn + 16 * m + i);
 }
 
-template <int HN>
+template <int HN, bool RAG>
 static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
-                             const float* q0_mean, const float* q0_log_var, hipStream_t stream) {
+                             const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
   auto resident_of = [](auto kernel) {
     int per_cu = 0, cus = 256, dev = 0;
@@ -653,30 +699,30 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
       per_cu = 1;
     return per_cu * cus;
   };
-  static const int resident_mask = resident_of(rnvp_split_kernel<HN, false>);
-  static const int resident_seed = resident_of(rnvp_split_kernel<HN, true>);
+  static const int resident_mask = resident_of(rnvp_split_kernel<HN, false, RAG>);
+  static const int resident_seed = resident_of(rnvp_split_kernel<HN, true, RAG>);
   // experiment switch: MNF_RNVP_BLOCKS_PER_CU=n caps the persistent grid at n workgroups per CU
   static const int cap = [] { const char* e = getenv("MNF_RNVP_BLOCKS_PER_CU"); return e ? atoi(e) * 256 : 1 << 30; }();
   const int resident0 = mask ? resident_mask : resident_seed;
   const int resident = resident0 < cap ? resident0 : cap;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)
-    hipLaunchKernelGGL((rnvp_split_kernel<HN, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var);
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, false, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
+                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec);
   else
-    hipLaunchKernelGGL((rnvp_split_kernel<HN, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var);
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, true, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
+                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec);
   return check_launch();
 }
 
 // ---------------------------------------------------------------- host: image index table
 template <int HN>
-static void build_index(int d, int32_t* idx) {
+static void build_index(int dm, int d, int32_t* idx) {
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT;
-  // flat layout: net.0.weight (HN, d), net.0.bias (HN), t.weight (d, HN), t.bias (d), s.weight (d, HN), s.bias (d)
-  const int64_t wn = 0, bn = wn + (int64_t)HN * d, wt = bn + HN, bt = wt + (int64_t)d * HN, ws = bt + d,
-                bs = ws + (int64_t)d * HN;
+  // flat layout: net.0.weight (HN, dm), net.0.bias (HN), t.weight (dm, HN), t.bias (dm), s.weight (dm, HN), s.bias (dm)
+  const int64_t wn = 0, bn = wn + (int64_t)HN * dm, wt = bn + HN, bt = wt + (int64_t)dm * HN, ws = bt + dm,
+                bs = ws + (int64_t)dm * HN;
   const int64_t total = S::image_floats(d);
   for (int64_t i = 0; i < total; ++i) idx[i] = -1;
   auto unit_of = [&](int m, int i) { return 16 * m + 4 * (i & 3) + (i >> 2); };
@@ -686,7 +732,8 @@ static void build_index(int d, int32_t* idx) {
     for (int m = 0; m < YT; ++m)
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-        if (u < HN) idx[(int64_t)kk * 256 + lane * 4 + m] = (int32_t)(wn + (int64_t)u * d + 16 * g + 4 * kq + e);
+        const int col = 16 * g + 4 * kq + e;
+        if (u < HN && col < dm) idx[(int64_t)kk * 256 + lane * 4 + m] = (int32_t)(wn + (int64_t)u * dm + col);
       }
   }
   // part 2: per output tile m: sequence n = 2 c + which
@@ -697,15 +744,16 @@ static void build_index(int d, int32_t* idx) {
         const int n = 2 * c + which;
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, unit = 4 * c + kq;
-          if (unit < HN)
+          if (unit < HN && 16 * m + i < dm)
             p2[(int64_t)m * S::TILE2_FLOATS + (n >> 2) * 256 + lane * 4 + (n & 3)] =
                 (int32_t)((which ? ws : wt) + (int64_t)(16 * m + i) * HN + unit);
         }
       }
   for (int m = 0; m < d / 16; ++m)
     for (int i = 0; i < 16; ++i) {
-      p2[(int64_t)m * S::TILE2_FLOATS + S::G2 * 256 + i] = (int32_t)(bt + 16 * m + i);
-      p2[(int64_t)m * S::TILE2_FLOATS + S::G2 * 256 + 16 + i] = (int32_t)(bs + 16 * m + i);
+      const bool real = 16 * m + i < dm;
+      p2[(int64_t)m * S::TILE2_FLOATS + S::G2 * 256 + i] = real ? (int32_t)(bt + 16 * m + i) : -1;
+      p2[(int64_t)m * S::TILE2_FLOATS + S::G2 * 256 + 16 + i] = real ? (int32_t)(bs + 16 * m + i) : kPackBigBias;
     }
   int32_t* pb = p2 + S::part2_floats(d);
   for (int m = 0; m < YT; ++m)
@@ -716,9 +764,9 @@ static void build_index(int d, int32_t* idx) {
 // hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default)
 #define MNF_RNVP_HIDDEN(X) X(50) X(30)
 
-template <int HN>
+template <int HN, bool RAG>
 static int launch_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
-                       const float* image, int64_t rows, int dim, uint64_t seed, hipStream_t stream) {
+                       const float* image, int64_t rows, int dim, uint64_t seed, int dm, int vec, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
   auto resident_of = [](auto kernel) {
     int per_cu = 0, cus = 256, dev = 0;
@@ -729,21 +777,25 @@ static int launch_rnvp(const float* z, const float* mask, float* x, float* log_d
       per_cu = 1;
     return per_cu * cus;
   };
-  static const int resident_mask = resident_of(rnvp_mfma_kernel<HN, false>);
-  static const int resident_seed = resident_of(rnvp_mfma_kernel<HN, true>);
+  static const int resident_mask = resident_of(rnvp_mfma_kernel<HN, false, RAG>);
+  static const int resident_seed = resident_of(rnvp_mfma_kernel<HN, true, RAG>);
   const int resident = mask ? resident_mask : resident_seed;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)
-    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, false>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, image, rows, dim, accumulate, seed);
+    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, false, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed, dm, vec);
   else
-    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, true>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
-                       mask, x, log_det, image, rows, dim, accumulate, seed);
+    hipLaunchKernelGGL((rnvp_mfma_kernel<HN, true, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
+                       mask, x, log_det, image, rows, dim, accumulate, seed, dm, vec);
   return check_launch();
 }
 
+// dim rounded up to whole 16-dim groups (the kernels' d); a layer with dim % 16 != 0 runs the ragged variants
+static int rnvp_padded_dim(int dim) { return (dim + 15) & ~15; }
+
 static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
-  if (n_hidden != 1 || !hidden || dim < 64 || dim % 16 != 0 || (int64_t)dim * 64 * 3 >= (1ll << 30)) return false;
+  const int d = rnvp_padded_dim(dim);
+  if (n_hidden != 1 || !hidden || dim < 1 || d < 64 || (int64_t)d * 64 * 3 >= (1ll << 30)) return false;
 #define X(HN) if (hidden[0] == HN) return true;
   MNF_RNVP_HIDDEN(X)
 #undef X
@@ -755,20 +807,29 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
                      const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean,
                      const float* q0_log_var) {
   if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
-  if (q0_mean && (!split_image || !q0_log_var || dim > kRnvpMaxPrologueDim)) return MNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x) |
-       reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(split_image)) & 15)
-    return MNF_ERR_UNSUPPORTED;
+  const int d = rnvp_padded_dim(dim);
+  if (q0_mean && (!split_image || !q0_log_var || d > kRnvpMaxPrologueDim)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(split_image)) & 15) return MNF_ERR_UNSUPPORTED;
+  const bool rows_aligned =
+      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  const bool ragged = d != dim;
+  if (!ragged && !rows_aligned) return MNF_ERR_UNSUPPORTED;
+  const int vec = rows_aligned && (dim & 3) == 0;
   if (split_image) {
-#define X(HN)            \
-  if (hidden[0] == HN)   \
-    return launch_rnvp_split<HN>(z, mask, x, log_det, accumulate, static_cast<const uint32_t*>(split_image), image, \
-                                 rows, dim, seed, q0_mean, q0_log_var, stream);
+    const uint32_t* simage = static_cast<const uint32_t*>(split_image);
+#define X(HN)                                                                                                        \
+  if (hidden[0] == HN)                                                                                               \
+    return ragged ? launch_rnvp_split<HN, true>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,       \
+                                                q0_mean, q0_log_var, dim, vec, stream)                               \
+                  : launch_rnvp_split<HN, false>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,      \
+                                                 q0_mean, q0_log_var, dim, vec, stream);
     MNF_RNVP_HIDDEN(X)
 #undef X
   }
-#define X(HN) \
-  if (hidden[0] == HN) return launch_rnvp<HN>(z, mask, x, log_det, accumulate, image, rows, dim, seed, stream);
+#define X(HN)                                                                                                        \
+  if (hidden[0] == HN)                                                                                               \
+    return ragged ? launch_rnvp<HN, true>(z, mask, x, log_det, accumulate, image, rows, d, seed, dim, vec, stream)   \
+                  : launch_rnvp<HN, false>(z, mask, x, log_det, accumulate, image, rows, d, seed, dim, vec, stream);
   MNF_RNVP_HIDDEN(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -780,7 +841,7 @@ extern "C" {
 
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden) {
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return 0;
-#define X(HN) if (hidden[0] == HN) return mnf::RnvpShape<HN>::image_floats(dim);
+#define X(HN) if (hidden[0] == HN) return mnf::RnvpShape<HN>::image_floats(mnf::rnvp_padded_dim(dim));
   MNF_RNVP_HIDDEN(X)
 #undef X
   return 0;
@@ -791,8 +852,8 @@ int mnf_rnvp_split_layout(int dim, int n_hidden, const int* hidden, int64_t* n_s
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                                                        \
   if (hidden[0] == HN) {                                             \
-    *n_split_words = mnf::RnvpSplitShape<HN>::split_words(dim);      \
-    *n_plain_words = mnf::RnvpSplitShape<HN>::plain_words(dim);      \
+    *n_split_words = mnf::RnvpSplitShape<HN>::split_words(mnf::rnvp_padded_dim(dim));  \
+    *n_plain_words = mnf::RnvpSplitShape<HN>::plain_words(mnf::rnvp_padded_dim(dim));  \
     return MNF_OK;                                                   \
   }
   MNF_RNVP_HIDDEN(X)
@@ -805,7 +866,7 @@ int mnf_rnvp_split_index(int dim, int n_hidden, const int* hidden, int32_t* idx_
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                                      \
   if (hidden[0] == HN) {                           \
-    mnf::build_split_index<HN>(dim, idx_host);     \
+    mnf::build_split_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host);  \
     return MNF_OK;                                 \
   }
   MNF_RNVP_HIDDEN(X)
@@ -818,7 +879,7 @@ int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden, int32_t* idx_
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                               \
   if (hidden[0] == HN) {                    \
-    mnf::build_index<HN>(dim, idx_host);    \
+    mnf::build_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host);  \
     return MNF_OK;                          \
   }
   MNF_RNVP_HIDDEN(X)

@@ -40,7 +40,7 @@ class MNFLinear(nn.Module):
         self.fuse_prologue = True  # sample_z: form z0 inside the first flow's kernel when that kernel exists
 
     def _fused_prologue_ok(self, flow, eps) -> bool:
-        """The first flow's split MFMA kernel can form z0 in its loads (d % 16 == 0, 64 <= d <= 1024, h in {30, 50})."""
+        """The first flow's split MFMA kernel can form z0 in its loads (49 <= d <= 1024, h in {30, 50})."""
         if self.fuse_prologue is False or torch.is_grad_enabled() and any(p.requires_grad for p in flow.parameters()):
             return False
         return (not flow.force_generic and self.n_in <= 1024 and flow._packed(eps.device)[1] is not None
