@@ -89,6 +89,7 @@ def test_unsupported_shapes_report_no_image(lib):
     assert lib.mnf_affine_half_image_floats(2, 3, int_array([24, 24, 24]), 1, 1) > 0     # padded to a 16-column tile
     n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
     # a ragged half only has the stack kernel, which exists for hidden widths 24 and 16
+    assert lib.mnf_affine_half_image_floats(6, 3, int_array([32, 32, 32]), 1, 1) == 0
     assert lib.mnf_affine_half_split_layout(6, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
                                             ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_image_floats(64, 2, int_array([24, 24]), 1, 1) == 0

@@ -319,3 +319,33 @@ def test_reference_training_contracts(amd, name, bound):
     loss2 = train(model, adam, samples, 70)
     assert loss1 > loss2
     assert loss2 < bound, f"{loss2=:.4} > {bound=}"
+
+
+@pytest.mark.parametrize("dim,hid", [(64, 32), (6, 32), (6, 24), (40, 16)])
+def test_runs_without_a_stack_kernel_fall_back_layer_by_layer(amd, O, dim, hid):
+    """Shapes whose run cannot go out as one launch (hidden width 32 has no stack kernel; a narrow half with it has
+    no MFMA kernel at all) still evaluate and train: same log-prob as the oracle, same gradients with and without
+    run fusion.  (6, 24) and (40, 16) do have the ragged stack kernel: the fused path itself.)"""
+    h_sizes = (hid,) * 3
+    sds = [recipes.affine_half_params(610 + dim + i, dim, h_sizes=h_sizes) for i in range(3)]
+    layers = [{"kind": "affine_half", "parity": bool(i % 2), "params": sd} for i, sd in enumerate(sds)]
+    x_cpu = recipes.gaussian(611, 300, dim)
+    ref_mean, ref_lp = O.mean_log_prob(x_cpu, layers)
+    grads = {}
+    for fused in (True, False):
+        flows = []
+        for i, sd in enumerate(sds):
+            f = amd.AffineHalfFlow(dim, bool(i % 2), h_sizes=h_sizes)
+            f.load_state_dict(sd)
+            flows.append(f)
+        model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
+        model.fuse_affine_runs = fused
+        with torch.no_grad():
+            lp = model.log_prob(x_cpu.to(DEV))
+        assert_close(lp, ref_lp, 1e-5, "log_prob")
+        loss = -model.log_prob(x_cpu.to(DEV)).mean()
+        loss.backward()
+        grads[fused] = {k: p.grad for k, p in model.named_parameters()}
+        assert abs(float(loss) + ref_mean) <= 1e-5 * abs(ref_mean)
+    for k in grads[True]:
+        assert_close(grads[True][k], grads[False][k], GTOL, k)

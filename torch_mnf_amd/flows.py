@@ -1054,8 +1054,12 @@ class _AffineRun:
     def launch_grad(self, x: Tensor, inverse: bool):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
         flat = torch.cat([p.reshape(-1) for p in self._params()])
-        out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
-        if out is None:
+        try:
+            out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
+        except MnfHipError as err:  # an image exists but no stack kernel (e.g. hidden width 32): layer by layer
+            if err.code != _lib.MNF_ERR_UNSUPPORTED:
+                raise
+            self._unsupported = True
             return None
         return list(out[:-1]), out[-1]
 
