@@ -56,7 +56,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 3
+#define MNF_ABI_VERSION 4
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -162,10 +162,13 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
  * written once from registers and never re-read -- forward ActNorm(x) and Glow(ActNorm(x)), inverse
  * NSF_CL^-1(x) and Glow^-1 of it; this is how NormalizingFlow runs the block as one launch while still
  * returning every tensor.  They need scale_shift = [exp(s) (dim), t (dim)] of the ActNorm layer.
+ * log_prob (rows,) / log_prob_sum (device double, ADDED to; caller zeroes it), both optional (need log_det): the
+ * standard-normal base log-prob epilogue log_det - |y|^2/2 - dim/2 log(2 pi) and its fp64 sum over rows in the
+ * same launch (when the block is the last launch of a density pass), as in mnf_affine_half_stack.
  * MNF_ERR_UNSUPPORTED when the shape has no fused kernel (callers run the three layers). */
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
                      const void* split_image, const float* aff, float ld_const, const float* scale_shift,
-                     float* mid1, float* mid2,
+                     float* mid1, float* mid2, float* log_prob, double* log_prob_sum,
                      int64_t rows, int dim, int K, float tail_bound,
                      int inverse, int n_hidden, const int* hidden_host, void* stream);
 int64_t mnf_nsf_cl_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);

@@ -682,6 +682,16 @@ def test_spline_block_run_keeps_every_intermediate(amd, golden):
             for i, (a, b) in enumerate(zip(zs_f, zs_u)):
                 assert_close(a, b, 3e-6, f"{direction} tensor {i}")
             assert_close(ld_f, ld_u, 3e-6, f"{direction} log_det")
+        # density pass: the last block's launch also does the standard-normal log-prob epilogue and its fp64 sum
+        model.fuse_affine_runs = True
+        lp_f, tot_f = model.log_prob(x, return_sum=True)
+        assert model._logprob_done
+        model.fuse_affine_runs = False
+        lp_u, tot_u = model.log_prob(x, return_sum=True)
+        assert not model._logprob_done
+    assert_close(lp_f, lp_u, 3e-6, "log_prob")
+    assert abs(float(tot_f) - float(tot_u)) <= 3e-6 * abs(float(tot_u))
+    assert abs(float(tot_f) - float(lp_f.double().sum())) <= 1e-9 * abs(float(tot_f))
     model.fuse_affine_runs = True
 
 

@@ -456,7 +456,8 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
                 const float* __restrict__ image, const uint32_t* __restrict__ simage, int64_t rows, float T,
                 int accumulate,
                 const float* __restrict__ aff_image, float ld_const, const float* __restrict__ scale_shift,
-                float* __restrict__ mid1, float* __restrict__ mid2) {
+                float* __restrict__ mid1, float* __restrict__ mid2, float* __restrict__ log_prob,
+                double* __restrict__ log_prob_sum) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int G = S_::G, dim = 2 * H;
   static_assert(G >= 1, "");
@@ -495,6 +496,7 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       return nsf_half_step<H, NH, K, kInv>(net ? f2 : f1, lane, q, cond, act, T);
   };
 
+  double lp_acc = 0.0;
   const int n_tiles = (int)((rows + 15) >> 4);
   for (int tile = (int)blockIdx.x * kNsfWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kNsfWaves) {
     const int64_t row = (int64_t)tile * 16 + j;
@@ -555,8 +557,26 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     }
     if (log_det) {
       ld = sum_over_q(ld) + ld_const;
-      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+      if (accumulate && live) ld += log_det[row];
+      if (live && q == 0) log_det[row] = ld;
+      if (log_prob) {  // last launch of a density pass: log p = log_det - |y|^2 / 2 - d/2 log(2 pi)  (core.py:46-49)
+        float sq = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq = fmaf(lo[g][r], lo[g][r], fmaf(up[g][r], up[g][r], sq));
+        sq = sum_over_q(sq);
+        const float lp = ld + (-0.5f * sq - (float)dim * kHalfLog2Pi);
+        if (live && q == 0) {
+          log_prob[row] = lp;
+          lp_acc += (double)lp;
+        }
+      }
     }
+  }
+  if (log_prob_sum) {  // fp64 sum over the rows: wave shuffle, one native fp64 atomic per wave
+    for (int off = 32; off > 0; off >>= 1) lp_acc += __shfl_down(lp_acc, off, 64);
+    if (lane == 0) atomicAdd(log_prob_sum, lp_acc);
   }
 }
 
@@ -695,7 +715,8 @@ template <int H, int NH, int K>
 static int launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                   const uint32_t* simage, int64_t rows, float T, int inverse, hipStream_t stream,
                   const float* aff = nullptr, float ld_const = 0.f, const float* scale_shift = nullptr,
-                  float* mid1 = nullptr, float* mid2 = nullptr) {
+                  float* mid1 = nullptr, float* mid2 = nullptr, float* log_prob = nullptr,
+                  double* log_prob_sum = nullptr) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
   auto resident_of = [](auto kernel) {
@@ -715,7 +736,7 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
   const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
 #define MNF_NSF_LAUNCH(INVV, AFFV, SPL)                                                                          \
   hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, INVV, AFFV, SPL>), grid, block, 0, stream, x, y, log_det, image, \
-                     simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2)
+                     simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2, log_prob, log_prob_sum)
   if (simage) {
     if (aff) {
       if (inverse) MNF_NSF_LAUNCH(true, 2, true); else MNF_NSF_LAUNCH(false, 1, true);
@@ -762,7 +783,7 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
 
 int nsf_fused_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                      const void* split_image, const float* aff, float ld_const, const float* scale_shift,
-                     float* mid1, float* mid2,
+                     float* mid1, float* mid2, float* log_prob, double* log_prob_sum,
                      int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
                      hipStream_t stream) {
   int nh = 0;
@@ -774,7 +795,8 @@ int nsf_fused_launch(const float* x, float* y, float* log_det, int accumulate, c
 #define X(HH, NHH, KK) \
   if (dim == 2 * HH && nh == NHH && K == KK) \
     return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, static_cast<const uint32_t*>(split_image), rows, \
-                               tail_bound, inverse != 0, stream, aff, ld_const, scale_shift, mid1, mid2);
+                               tail_bound, inverse != 0, stream, aff, ld_const, scale_shift, mid1, mid2, log_prob,    \
+                               log_prob_sum);
   MNF_NSF_FUSED_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -788,16 +810,17 @@ extern "C" {
 // log_det = spline terms + ld_const.  aff = [dim*dim operand image of A (mnf_linear_rows_image_index)][dim bias].
 int mnf_nsf_cl_fused(const float* x, float* y, float* log_det, int accumulate, const float* image,
                      const void* split_image, const float* aff, float ld_const, const float* scale_shift,
-                     float* mid1, float* mid2,
+                     float* mid1, float* mid2, float* log_prob, double* log_prob_sum,
                      int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden, const int* hidden,
                      void* stream) {
   if (!x || !y || x == y || !image || !aff || rows < 0 || dim < 2 || (dim & 1) || K < 2 || !(tail_bound > 0.f) ||
       !mnf::hidden_ok(n_hidden, hidden) || ((mid1 || mid2) && !scale_shift) || (mid1 && (mid1 == y || mid1 == x)) ||
-      (mid2 && (mid2 == y || mid2 == x || mid2 == mid1)))
+      (mid2 && (mid2 == y || mid2 == x || mid2 == mid1)) || ((log_prob || log_prob_sum) && !log_det) ||
+      (log_prob_sum && !log_prob))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   return mnf::nsf_fused_launch(x, y, log_det, accumulate, image, split_image, aff, ld_const, scale_shift, mid1, mid2,
-                               rows, dim, K,
+                               log_prob, log_prob_sum, rows, dim, K,
                                tail_bound, inverse, n_hidden, hidden, (hipStream_t)stream);
 }
 

@@ -902,9 +902,12 @@ class _SplineBlockRun:
                 and not self.glow.force_generic
                 and not any(_wants_grad(m, x) for m in (self.actnorm, self.glow, self.nsf)))
 
-    def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, keep: bool) -> list[Tensor] | None:
+    def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, keep: bool,
+               logprob: tuple | None = None) -> list[Tensor] | None:
         """Returns the output tensors in application order -- all three when ``keep`` (each written once from
-        registers, never re-read), else just the last -- or None when the shape has no fused kernel."""
+        registers, never re-read), else just the last -- or None when the shape has no fused kernel.
+        ``logprob`` = (log_prob (rows,), zeroed fp64 sum (1,) or None): the kernel also does the standard-normal
+        log-prob epilogue (the block is the last launch of a density pass)."""
         nsf = self.nsf
         packed = self._affine(x.device, inverse)
         _, image = nsf._packed(x.device)
@@ -916,8 +919,9 @@ class _SplineBlockRun:
         buf = torch.empty((3 if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         rc = _lib.load().mnf_nsf_cl_fused(
             x.data_ptr(), buf[-1].data_ptr(), log_det.data_ptr(), int(accumulate), image.data_ptr(),
-            _ptr(nsf._split_image(x.device)), aff.data_ptr(), ldc, scale_shift.data_ptr(), buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
-            x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
+            _ptr(nsf._split_image(x.device)), aff.data_ptr(), ldc, scale_shift.data_ptr(),
+            buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
+            _ptr(logprob[0]) if logprob else None, _ptr(logprob[1]) if logprob else None, x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
         if rc == _lib.MNF_ERR_UNSUPPORTED:
             self._unsupported = True
             return None
@@ -1247,7 +1251,10 @@ class NormalizingFlow(nn.Module):
                         self._logprob_done, sq = True, None
                 else:
                     sq = None
-                    outs = run.launch(x, inverse, log_det, True, keep=True)
+                    outs = run.launch(x, inverse, log_det, True, keep=True,
+                                      logprob=want_logprob if (last and not _NO_FUSED_LOGPROB_ENV) else None)
+                    if outs is not None and last and want_logprob is not None and not _NO_FUSED_LOGPROB_ENV:
+                        self._logprob_done = True
                 if outs is not None:
                     self._last_sqnorm = sq
                     seen.extend(outs)
