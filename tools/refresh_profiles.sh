@@ -19,6 +19,8 @@ MNF_FP32_MFMA=1 MNF_NO_RUN_FUSION=1 python bench.py --no-cpu-baseline > "$OUT/fp
 MNF_FP32_MFMA=1 python bench.py --workload c5 --no-cpu-baseline > "$OUT/fp32_mfma/c5_bench_same_build.json" 2>/dev/null
 python tools/bench_backward.py > "$OUT/training_step.txt" 2>&1
 python tools/bench_c1.py > "$OUT/c1_latency.txt" 2>&1
+python tools/bench_c5.py 2>/dev/null | grep MNFLinear > "$OUT/c5_sample_z.txt"
+python tools/mnf_lenet_harness.py 2>/dev/null | grep MNF-LeNet > "$OUT/c5_mnf_lenet_forward.txt"
 for w in c2 c3 c5; do
   tools/profile_bench.sh r1_$w --workload $w > /dev/null 2>&1
   cp "$REPO/gpurun_out/prof_r1_$w/summary.txt" "$OUT/${w}_rocprofv3_summary.txt"
