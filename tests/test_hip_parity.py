@@ -1135,3 +1135,20 @@ def test_every_even_width_up_to_256_matches_the_generic_kernel(amd):
             worst = max(worst, err)
             assert err <= RTOL, (dim, inverse, err)
     assert worst > 0.0  # two different kernels, not the same one twice
+
+
+def test_rnvp_every_width_from_49_to_130_matches_the_generic_kernel(amd):
+    """Sweep over 82 consecutive widths (every residue mod 16, both access modes of the ragged variants) with the
+    in-kernel mask: MFMA path against the shape-generic kernel."""
+    for dim in range(49, 131):
+        f = amd.RNVP(dim, h_sizes=(50,))
+        f.load_state_dict(recipes.rnvp_params(1200 + dim, dim, 50))
+        f.to(DEV)
+        assert f._split_image(torch.device(DEV, 0)) is not None, dim
+        z = cuda(recipes.gaussian(dim, 141, dim))
+        x, ld = f.forward(z, seed=dim)
+        f.force_generic = True
+        x_g, ld_g = f.forward(z, seed=dim)
+        f.force_generic = False
+        assert_close(x, x_g, RTOL, f"x d={dim}")
+        assert_close(ld, ld_g, RTOL, f"ld d={dim}")
