@@ -88,9 +88,13 @@ def test_unsupported_shapes_report_no_image(lib):
     assert lib.mnf_affine_half_image_floats(258, 3, int_array([24, 24, 24]), 1, 1) == 0  # half wider than 128
     assert lib.mnf_affine_half_image_floats(2, 3, int_array([24, 24, 24]), 1, 1) > 0     # padded to a 16-column tile
     n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
-    # a ragged half only has the stack kernel, which exists for hidden widths 24 and 16
-    assert lib.mnf_affine_half_image_floats(6, 3, int_array([32, 32, 32]), 1, 1) == 0
+    # a ragged half only has the stack kernel, which exists for hidden widths 16, 24 and 32 (not at d > 128 for 32)
+    assert lib.mnf_affine_half_image_floats(6, 3, int_array([40, 40, 40]), 1, 1) == 0
+    assert lib.mnf_affine_half_split_layout(6, 3, int_array([40, 40, 40]), 1, 1, ctypes.byref(n_split),
+                                            ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_split_layout(6, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
+                                            ctypes.byref(n_plain)) == 0
+    assert lib.mnf_affine_half_split_layout(200, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
                                             ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_image_floats(64, 2, int_array([24, 24]), 1, 1) == 0
     assert lib.mnf_affine_half_image_floats(64, 3, int_array([24, 24, 24]), 0, 1) == 0
@@ -161,7 +165,7 @@ def _check_split_table(halves, plain, n_weights, n_params):
 
 
 @pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (128, 24), (256, 24), (32, 16), (64, 16), (32, 32), (128, 32),
-                                     (2, 24), (6, 24), (30, 16), (50, 24), (100, 24), (250, 24)])
+                                     (2, 24), (6, 24), (30, 16), (50, 24), (100, 24), (250, 24), (6, 32), (50, 32), (100, 32)])
 def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
     from torch_mnf_amd._lib import int_array
 

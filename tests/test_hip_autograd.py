@@ -323,9 +323,9 @@ def test_reference_training_contracts(amd, name, bound):
 
 @pytest.mark.parametrize("dim,hid", [(64, 32), (6, 32), (6, 24), (40, 16)])
 def test_runs_without_a_stack_kernel_fall_back_layer_by_layer(amd, O, dim, hid):
-    """Shapes whose run cannot go out as one launch (hidden width 32 has no stack kernel; a narrow half with it has
-    no MFMA kernel at all) still evaluate and train: same log-prob as the oracle, same gradients with and without
-    run fusion.  (6, 24) and (40, 16) do have the ragged stack kernel: the fused path itself.)"""
+    """Shapes whose run does not go out as one launch (hidden width 32 at d = 64: the stack kernel declines, it would
+    be no faster) still evaluate and train: same log-prob as the oracle, same gradients with and without run
+    fusion.  (6, 32), (6, 24) and (40, 16) have the ragged stack kernel: the fused path itself."""
     h_sizes = (hid,) * 3
     sds = [recipes.affine_half_params(610 + dim + i, dim, h_sizes=h_sizes) for i in range(3)]
     layers = [{"kind": "affine_half", "parity": bool(i % 2), "params": sd} for i, sd in enumerate(sds)]

@@ -123,7 +123,7 @@ def test_affine_half_ragged_rows_vs_oracle(amd, O, rows, dim, kernel):
 
 @pytest.mark.parametrize("rows", [1, 17, 777, 1000, 4099])
 @pytest.mark.parametrize("dim,hid", [(2, 24), (4, 24), (6, 16), (10, 24), (24, 24), (30, 16), (40, 24), (50, 24), (62, 24),
-                                     (100, 24), (58, 16), (130, 24), (200, 24), (250, 24)])
+                                     (100, 24), (58, 16), (130, 24), (200, 24), (250, 24), (6, 32), (20, 32), (50, 32), (100, 32)])
 def test_affine_half_narrow_halves_vs_oracle(amd, O, rows, dim, hid):
     """A coupling half that does not fill its 16/32/64/128-column MFMA tile (any even d <= 256, e.g. config 1's
     d = 2): zero-padded operand image, masked row accesses (16-byte when d % 8 == 0, else element by element).

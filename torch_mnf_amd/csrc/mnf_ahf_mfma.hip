@@ -462,7 +462,7 @@ int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden, i
       !mnf::uniform_hidden(n_hidden, hidden, hid))
     return 0;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
-  if (h != hp && hid != 24 && hid != 16) return 0;  // a narrow half only has the stack kernel (hidden width 24 / 16)
+  if (h != hp && hid != 24 && hid != 16 && hid != 32) return 0;  // a narrow half only has the stack kernel
 #define X(HH, HD) \
   if (hp == HH && hid == HD) return mnf::AhfShape<HH, HD>::IMAGE_FLOATS;
   MNF_AHF_SHAPES(X)
@@ -476,7 +476,7 @@ int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden, int ha
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
-  if (h != hp && hid != 24 && hid != 16) return MNF_ERR_UNSUPPORTED;
+  if (h != hp && hid != 24 && hid != 16 && hid != 32) return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                           \
   if (hp == HH && hid == HD) {              \
     mnf::build_index<HH, HD>(idx_host, h);  \

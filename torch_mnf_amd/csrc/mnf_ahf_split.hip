@@ -564,9 +564,10 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   return check_launch();
 }
 
-// (H, HID) pairs with a split kernel; the stack kernel exists for the first four
+// (H, HID) pairs with a split kernel, and those of the stack kernel (hidden width 32 at d <= 64 spills at two tiles
+// per wave and gains nothing over nine single-layer launches: there it only serves narrow halves, see below)
 #define MNF_AHF_SPLIT_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
-#define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24)
+#define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
 
 static bool uniform3(int n_hidden, const int* hidden, int& hid) {
   if (n_hidden != 3 || !hidden) return false;
@@ -605,6 +606,7 @@ int ahf_split_stack_launch(const float* x, float* y, float* mid, float* log_det,
   const bool rows_aligned = aligned16(x, y, mid, nullptr);
   if (h == hp && !rows_aligned) return MNF_ERR_UNSUPPORTED;
   const int vec_ok = rows_aligned && (h & 3) == 0;
+  if (hid == 32 && h == hp && hp <= 32 && n_layers > 1) return MNF_ERR_UNSUPPORTED;  // measured: no faster than layer by layer
   const uint32_t* simages = static_cast<const uint32_t*>(split_images);
 #define X(HH, HD)                                                                                                    \
   if (hp == HH && hid == HD)                                                                                         \
