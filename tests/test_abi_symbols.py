@@ -97,7 +97,8 @@ def test_unsupported_shapes_report_no_image(lib):
     assert lib.mnf_affine_half_split_layout(200, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
                                             ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_image_floats(64, 2, int_array([24, 24]), 1, 1) == 0
-    assert lib.mnf_affine_half_image_floats(64, 3, int_array([24, 24, 24]), 0, 1) == 0
+    assert lib.mnf_affine_half_image_floats(64, 3, int_array([24, 24, 24]), 0, 0) == 0  # neither net: nothing to pack
+    assert lib.mnf_affine_half_image_floats(64, 3, int_array([24, 24, 24]), 0, 1) > 0   # NICE: zero operands for s
 
 
 def test_argument_checking_without_a_gpu(lib):
@@ -169,12 +170,23 @@ def _check_split_table(halves, plain, n_weights, n_params):
 def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
     from torch_mnf_amd._lib import int_array
 
-    sd = recipes.affine_half_params(0, dim, h_sizes=(hid,) * 3)
-    n_params = sum(v.numel() for v in sd.values())
-    n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
-    halves, plain = _split_table(lib, lib.mnf_affine_half_split_layout, lib.mnf_affine_half_split_index,
-                                 (dim, 3, int_array([hid] * 3), 1, 1))
-    _check_split_table(halves, plain, n_weights, n_params)
+    # both nets, then the NICE (scale=False) and shift=False variants: one net's parameters only, the absent net's
+    # operands structural zeros
+    for kw, flags in ((dict(), (1, 1)), (dict(scale=False), (0, 1)), (dict(shift=False), (1, 0))):
+        sd = recipes.affine_half_params(0, dim, h_sizes=(hid,) * 3, **kw)
+        n_params = sum(v.numel() for v in sd.values())
+        n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
+        assert lib.mnf_affine_half_flat_floats(dim, 3, int_array([hid] * 3), *flags) == n_params
+        halves, plain = _split_table(lib, lib.mnf_affine_half_split_layout, lib.mnf_affine_half_split_index,
+                                     (dim, 3, int_array([hid] * 3), *flags))
+        _check_split_table(halves, plain, n_weights, n_params)
+        n = lib.mnf_affine_half_image_floats(dim, 3, int_array([hid] * 3), *flags)
+        if n > 0:  # (the fp32 image exists for d <= 128 at hidden width 32)
+            idx = (ctypes.c_int32 * n)()
+            assert lib.mnf_affine_half_image_index(dim, 3, int_array([hid] * 3), *flags, idx) == 0
+            used = np.frombuffer(idx, dtype=np.int32)
+            used = used[used >= 0]
+            assert len(used) == n_params and len(np.unique(used)) == n_params
 
 
 @pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30), (50, 50), (49, 30), (100, 30), (790, 50)])

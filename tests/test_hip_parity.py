@@ -1152,3 +1152,36 @@ def test_rnvp_every_width_from_49_to_130_matches_the_generic_kernel(amd):
         f.force_generic = False
         assert_close(x, x_g, RTOL, f"x d={dim}")
         assert_close(ld, ld_g, RTOL, f"ld d={dim}")
+
+
+@pytest.mark.parametrize("kw", [dict(scale=False), dict(shift=False)], ids=["nice", "noshift"])
+@pytest.mark.parametrize("dim", [2, 10, 64, 256])
+def test_nice_and_no_shift_variants_on_the_mfma_path(amd, O, dim, kw):
+    """scale=False (NICE, readme.md) / shift=False: the absent net is the zero function in the reference
+    (affine_half_flow.py:38); here its operands are structural zeros of the same MFMA kernels -- s = 0 (log_det
+    exactly 0) or t = 0.  Single layers and a 3-layer run, both directions, vs the oracle."""
+    sds = [recipes.affine_half_params(1300 + dim + i, dim, s_last_gain=2.0, **kw) for i in range(3)]
+    flows = [ahf_module(amd, sd, dim, bool(i % 2), **kw) for i, sd in enumerate(sds)]
+    assert all(f._split_image(torch.device(DEV, 0)) is not None for f in flows)
+    x = recipes.gaussian(1301 + dim, 333, dim)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.affine_half(x, sds[0], False, inverse, **kw)
+        y, ld = flows[0].forward(cuda(x), inverse=inverse)
+        assert_close(y, ref_y, RTOL, "y")
+        if kw.get("scale", True):
+            assert_close(ld, ref_ld, RTOL, "ld")
+        else:
+            assert float(ld.abs().max()) == 0.0 and float(torch.as_tensor(ref_ld).abs().max()) == 0.0
+    model = amd.NormalizingFlow(flows).to(DEV)
+    with torch.no_grad():
+        zs, ld = model.inverse(cuda(x))
+        assert zs[1].data_ptr() + zs[1].numel() * 4 == zs[2].data_ptr()  # one launch
+        cur, ld_ref = x, 0
+        for i in (2, 1, 0):
+            cur, l1 = O.affine_half(cur, sds[i], bool(i % 2), True, **kw)
+            ld_ref = ld_ref + l1
+        assert_close(zs[-1], cur, RTOL, "run z")
+        if kw.get("scale", True):
+            assert_close(ld, ld_ref, RTOL, "run log_det")
+        else:
+            assert float(ld.abs().max()) == 0.0

@@ -310,14 +310,18 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 
 // ---------------------------------------------------------------- host: image index table
 // h <= H: real half width (the image is zero in the padded input columns / output rows)
+// has[0] / has[1]: the s / t net exists (scale=False / shift=False, affine_half_flow.py:38: an absent net is the
+// zero function -- here an all-zero operand set, so s = 0 or t = 0 exactly)
 template <int H, int HID>
-static void build_index(int32_t* idx, int h) {
+static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = true) {
   using S = AhfShape<H, HID>;
   constexpr int QN = S::QN, NQ = S::NQ, NT = S::NT, G = S::G;
   int sizes[5] = {h, HID, HID, HID, h};
   NetDesc net[2];
-  int64_t off = fill_net(net[0], 5, sizes, 0);
-  fill_net(net[1], 5, sizes, off);
+  const bool has[2] = {has_s, has_t};
+  int64_t off = 0;
+  if (has_s) off += fill_net(net[0], 5, sizes, off);
+  if (has_t) off += fill_net(net[1], 5, sizes, off);
   for (int64_t i = 0; i < S::IMAGE_FLOATS; ++i) idx[i] = -1;
   int n = 0;
   auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
@@ -332,7 +336,7 @@ static void build_index(int32_t* idx, int h) {
         if (u < 2 * HID) {
           const int nn = u / HID, unit = u % HID;
           const int col = 16 * g + 4 * kq + e;
-          if (col < h) put(lane, net[nn].w_off[0] + unit * h + col);
+          if (col < h && has[nn]) put(lane, net[nn].w_off[0] + unit * h + col);
         }
       }
       ++n;
@@ -345,7 +349,7 @@ static void build_index(int32_t* idx, int h) {
         if (!S::tile_has_net(m, cn)) continue;
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-          if (u < 2 * HID && u / HID == cn)
+          if (u < 2 * HID && u / HID == cn && has[cn])
             put(lane, net[cn].w_off[l] + (u % HID) * HID + (4 * c + kq - cn * HID));
         }
         ++n;
@@ -357,7 +361,7 @@ static void build_index(int32_t* idx, int h) {
       for (int nn = 0; nn < 2; ++nn) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4;
-          if (16 * m + i < h) put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
+          if (16 * m + i < h && has[nn]) put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
         }
         ++n;
       }
@@ -370,12 +374,12 @@ static void build_index(int32_t* idx, int h) {
     for (int m = 0; m < NT; ++m, ++bt)
       for (int i = 0; i < 16; ++i) {
         const int u = unit_of(m, i);
-        if (u < 2 * HID) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
+        if (u < 2 * HID && has[u / HID]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
       }
   for (int m = 0; m < G; ++m)
     for (int nn = 0; nn < 2; ++nn, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (16 * m + i < h) b[bt * 16 + i] = net[nn].b_off[3] + 16 * m + i;
+        if (16 * m + i < h && has[nn]) b[bt * 16 + i] = net[nn].b_off[3] + 16 * m + i;
 }
 
 template <int H, int HID>
@@ -439,7 +443,7 @@ int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int ac
                     const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
                     const int* hidden, int has_scale, int has_shift, hipStream_t stream) {
   int hid = 0;
-  if (!has_scale || !has_shift || !uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((!has_scale && !has_shift) || !uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
        reinterpret_cast<uintptr_t>(image)) & 15)
     return MNF_ERR_UNSUPPORTED;  // float4 accesses need 16-byte aligned bases
@@ -458,7 +462,7 @@ extern "C" {
 int64_t mnf_affine_half_image_floats(int dim, int n_hidden, const int* hidden, int has_scale,
                                      int has_shift) {
   int hid = 0;
-  if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) ||
+  if ((!has_scale && !has_shift) || !mnf::hidden_ok(n_hidden, hidden) ||
       !mnf::uniform_hidden(n_hidden, hidden, hid))
     return 0;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
@@ -474,12 +478,12 @@ int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden, int ha
                                 int32_t* idx_host) {
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
-  if (!has_scale || !has_shift || !mnf::uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((!has_scale && !has_shift) || !mnf::uniform_hidden(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
   if (h != hp && hid != 24 && hid != 16 && hid != 32) return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                           \
   if (hp == HH && hid == HD) {              \
-    mnf::build_index<HH, HD>(idx_host, h);  \
+    mnf::build_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0);  \
     return MNF_OK;                          \
   }
   MNF_AHF_SHAPES(X)

@@ -421,13 +421,15 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 // 2 entries per split word (low half, high half), then 1 entry per plain (fp32 bias) word.
 // h <= H: real half width (zero operands in the padded input columns / output rows)
 template <int H, int HID>
-static void build_split_index(int32_t* idx, int h) {
+static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t = true) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
   int sizes[5] = {h, HID, HID, HID, h};
   NetDesc net[2];
-  int64_t off = fill_net(net[0], 5, sizes, 0);
-  fill_net(net[1], 5, sizes, off);
+  const bool has[2] = {has_s, has_t};  // an absent net (scale=False / shift=False) is an all-zero operand set
+  int64_t off = 0;
+  if (has_s) off += fill_net(net[0], 5, sizes, off);
+  if (has_t) off += fill_net(net[1], 5, sizes, off);
   const int64_t n_entries = 2 * (int64_t)S::SPLIT_WORDS + S::PLAIN_WORDS;
   for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
   int op = 0;
@@ -450,7 +452,7 @@ static void build_split_index(int32_t* idx, int h) {
         if (u >= 2 * HID) continue;
         for (int e = 0; e < 8; ++e) {
           const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
-          if (g < G && col < h) put(lane, e, net[u / HID].w_off[0] + (u % HID) * h + col);
+          if (g < G && col < h && has[u / HID]) put(lane, e, net[u / HID].w_off[0] + (u % HID) * h + col);
         }
       }
   for (int l = 1; l <= 2; ++l)
@@ -463,7 +465,7 @@ static void build_split_index(int32_t* idx, int h) {
           for (int e = 0; e < 8; ++e) {
             int tile;
             const int ui = unit_in(ks, kq, e, tile);
-            if (ui < 0 || ui / HID != u / HID || S::assigned_ks(S::tile_nets(m), tile) != ks) continue;
+            if (ui < 0 || ui / HID != u / HID || S::assigned_ks(S::tile_nets(m), tile) != ks || !has[u / HID]) continue;
             put(lane, e, net[u / HID].w_off[l] + (u % HID) * HID + ui % HID);
           }
         }
@@ -479,7 +481,7 @@ static void build_split_index(int32_t* idx, int h) {
             for (int e = 0; e < 8; ++e) {
               int tile;
               const int ui = unit_in(ks, kq, e, tile);
-              if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks || 16 * g + i >= h) continue;
+              if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks || 16 * g + i >= h || !has[nn]) continue;
               put(lane, e, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
             }
           }
@@ -491,12 +493,12 @@ static void build_split_index(int32_t* idx, int h) {
     for (int m = 0; m < NT; ++m, ++bt)
       for (int i = 0; i < 16; ++i) {
         const int u = 16 * m + i;
-        if (u < 2 * HID) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
+        if (u < 2 * HID && has[u / HID]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
       }
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (16 * g + i < h) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+        if (16 * g + i < h && has[nn]) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
 template <typename K>
@@ -584,7 +586,7 @@ int ahf_split_launch(const float* x, float* y, float* log_det, float* ysq, int a
                      const float* image, int64_t rows, int dim, int parity, int inverse, int n_hidden,
                      const int* hidden, int has_scale, int has_shift, hipStream_t stream) {
   int hid = 0;
-  if (!split_image || !image || !has_scale || !has_shift || !uniform3(n_hidden, hidden, hid))
+  if (!split_image || !image || (!has_scale && !has_shift) || !uniform3(n_hidden, hidden, hid))
     return MNF_ERR_UNSUPPORTED;
   if (!aligned16(x, y, split_image, image)) return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                                                                                            \
@@ -629,7 +631,7 @@ int mnf_affine_half_split_layout(int dim, int n_hidden, const int* hidden, int h
                                  int64_t* n_split_words, int64_t* n_plain_words) {
   int hid = 0;
   if (!n_split_words || !n_plain_words || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
-  if (!has_scale || !has_shift || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((!has_scale && !has_shift) || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
 #define X(HH, HD)                                            \
   if (hp == HH && hid == HD) {                               \
@@ -650,11 +652,11 @@ int mnf_affine_half_split_index(int dim, int n_hidden, const int* hidden, int ha
                                 int32_t* idx_host) {
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
-  if (!has_scale || !has_shift || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((!has_scale && !has_shift) || !mnf::uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
 #define X(HH, HD)                                 \
   if (hp == HH && hid == HD) {                    \
-    mnf::build_split_index<HH, HD>(idx_host, h);  \
+    mnf::build_split_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0);  \
     return MNF_OK;                                \
   }
   if (h == hp) {

@@ -618,7 +618,7 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
     const int rc = ahf_split_launch(x, y, log_det, y_sqnorm, accumulate, split_image, image, rows, dim, parity,
                                     inverse, n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
-    if (dim / 2 != ahf_padded_half(dim / 2) && has_scale && has_shift && n_hidden == 3 && hidden[1] == hidden[0] &&
+    if (dim / 2 != ahf_padded_half(dim / 2) && (has_scale || has_shift) && n_hidden == 3 && hidden[1] == hidden[0] &&
         hidden[2] == hidden[0]) {
       // a half narrower than its MFMA tile (d = 2, 6, 50 ...): the stack kernel's ragged variant, one layer
       const int rc1 = ahf_split_stack_launch(x, y, nullptr, log_det, y_sqnorm, accumulate, split_image, image,
