@@ -89,7 +89,7 @@ def test_unsupported_shapes_report_no_image(lib):
     assert lib.mnf_affine_half_image_floats(2, 3, int_array([24, 24, 24]), 1, 1) > 0     # padded to a 16-column tile
     n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
     # a ragged half only has the stack kernel, which exists for hidden widths 16, 24 and 32 (not at d > 128 for 32)
-    assert lib.mnf_affine_half_image_floats(6, 3, int_array([40, 40, 40]), 1, 1) == 0
+    assert lib.mnf_affine_half_image_floats(6, 3, int_array([40, 40, 40]), 1, 1) == 0   # wider than 32
     assert lib.mnf_affine_half_split_layout(6, 3, int_array([40, 40, 40]), 1, 1, ctypes.byref(n_split),
                                             ctypes.byref(n_plain)) == -2
     assert lib.mnf_affine_half_split_layout(6, 3, int_array([32, 32, 32]), 1, 1, ctypes.byref(n_split),
@@ -187,6 +187,30 @@ def test_affine_half_split_index_covers_every_parameter(lib, dim, hid):
             used = np.frombuffer(idx, dtype=np.int32)
             used = used[used >= 0]
             assert len(used) == n_params and len(np.unique(used)) == n_params
+
+
+@pytest.mark.parametrize("dim", [64, 6, 256])
+@pytest.mark.parametrize("h_sizes", [(20, 20, 20), (8, 24, 16), (30, 12, 32), (1, 1, 1)])
+def test_affine_half_index_tables_for_padded_hidden_widths(lib, dim, h_sizes):
+    """Three hidden layers of any widths <= 32 run at the next of 16 / 24 / 32: every real parameter appears once
+    (fp32 image) / as hi and lo (split image), the padded units are structural zeros."""
+    from torch_mnf_amd._lib import int_array
+
+    if dim == 256 and not 16 < max(h_sizes) <= 24:
+        pytest.skip("d = 256 only has the kernels that run the hidden layers at 24 units")
+    sd = recipes.affine_half_params(0, dim, h_sizes=h_sizes)
+    n_params = sum(v.numel() for v in sd.values())
+    n_weights = sum(v.numel() for k, v in sd.items() if k.endswith("weight"))
+    hid = int_array(list(h_sizes))
+    halves, plain = _split_table(lib, lib.mnf_affine_half_split_layout, lib.mnf_affine_half_split_index, (dim, 3, hid, 1, 1))
+    _check_split_table(halves, plain, n_weights, n_params)
+    n = lib.mnf_affine_half_image_floats(dim, 3, hid, 1, 1)
+    assert n > 0
+    idx = (ctypes.c_int32 * n)()
+    assert lib.mnf_affine_half_image_index(dim, 3, hid, 1, 1, idx) == 0
+    used = np.frombuffer(idx, dtype=np.int32)
+    used = used[used >= 0]
+    assert len(used) == n_params and len(np.unique(used)) == n_params
 
 
 @pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30), (50, 50), (49, 30), (100, 30), (790, 50)])

@@ -313,10 +313,11 @@ ahf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 // has[0] / has[1]: the s / t net exists (scale=False / shift=False, affine_half_flow.py:38: an absent net is the
 // zero function -- here an all-zero operand set, so s = 0 or t = 0 exactly)
 template <int H, int HID>
-static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = true) {
+static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = true, const int* widths = nullptr) {
   using S = AhfShape<H, HID>;
   constexpr int QN = S::QN, NQ = S::NQ, NT = S::NT, G = S::G;
-  int sizes[5] = {h, HID, HID, HID, h};
+  const int w[3] = {widths ? widths[0] : HID, widths ? widths[1] : HID, widths ? widths[2] : HID};  // real widths <= HID
+  int sizes[5] = {h, w[0], w[1], w[2], h};
   NetDesc net[2];
   const bool has[2] = {has_s, has_t};
   int64_t off = 0;
@@ -336,7 +337,7 @@ static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = tru
         if (u < 2 * HID) {
           const int nn = u / HID, unit = u % HID;
           const int col = 16 * g + 4 * kq + e;
-          if (col < h && has[nn]) put(lane, net[nn].w_off[0] + unit * h + col);
+          if (col < h && has[nn] && unit < w[0]) put(lane, net[nn].w_off[0] + unit * h + col);
         }
       }
       ++n;
@@ -349,8 +350,9 @@ static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = tru
         if (!S::tile_has_net(m, cn)) continue;
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-          if (u < 2 * HID && u / HID == cn && has[cn])
-            put(lane, net[cn].w_off[l] + (u % HID) * HID + (4 * c + kq - cn * HID));
+          const int in_unit = 4 * c + kq - cn * HID;
+          if (u < 2 * HID && u / HID == cn && has[cn] && u % HID < w[l] && in_unit < w[l - 1])
+            put(lane, net[cn].w_off[l] + (u % HID) * w[l - 1] + in_unit);
         }
         ++n;
       }
@@ -361,7 +363,7 @@ static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = tru
       for (int nn = 0; nn < 2; ++nn) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4;
-          if (16 * m + i < h && has[nn]) put(lane, net[nn].w_off[3] + (16 * m + i) * HID + 4 * c + kq);
+          if (16 * m + i < h && has[nn] && 4 * c + kq < w[2]) put(lane, net[nn].w_off[3] + (16 * m + i) * w[2] + 4 * c + kq);
         }
         ++n;
       }
@@ -374,7 +376,7 @@ static void build_index(int32_t* idx, int h, bool has_s = true, bool has_t = tru
     for (int m = 0; m < NT; ++m, ++bt)
       for (int i = 0; i < 16; ++i) {
         const int u = unit_of(m, i);
-        if (u < 2 * HID && has[u / HID]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
+        if (u < 2 * HID && has[u / HID] && u % HID < w[l]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
       }
   for (int m = 0; m < G; ++m)
     for (int nn = 0; nn < 2; ++nn, ++bt)
@@ -433,10 +435,10 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
 // reference default hidden width 24 at d = 32..256, plus widths 16 and 32 at the small dims
 #define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24) X(16, 16) X(32, 16) X(16, 32) X(32, 32) X(64, 32)
 
+// three hidden layers of at most 32 units: hid = the width the kernels run them at (see ahf_padded_hidden)
 static bool uniform_hidden(int n_hidden, const int* hidden, int& hid) {
-  if (n_hidden != 3) return false;
-  hid = hidden[0];
-  return hidden[1] == hid && hidden[2] == hid;
+  hid = ahf_padded_hidden(n_hidden, hidden);
+  return hid != 0;
 }
 
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
@@ -483,7 +485,7 @@ int mnf_affine_half_image_index(int dim, int n_hidden, const int* hidden, int ha
   if (h != hp && hid != 24 && hid != 16 && hid != 32) return MNF_ERR_UNSUPPORTED;
 #define X(HH, HD)                           \
   if (hp == HH && hid == HD) {              \
-    mnf::build_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0);  \
+    mnf::build_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0, hidden);  \
     return MNF_OK;                          \
   }
   MNF_AHF_SHAPES(X)

@@ -421,10 +421,12 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 // 2 entries per split word (low half, high half), then 1 entry per plain (fp32 bias) word.
 // h <= H: real half width (zero operands in the padded input columns / output rows)
 template <int H, int HID>
-static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t = true) {
+static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t = true, const int* widths = nullptr) {
   using S = SplitShape<H, HID>;
   constexpr int G = S::G, NT = S::NT, NKS = S::NKS, KS1 = S::KS1;
-  int sizes[5] = {h, HID, HID, HID, h};
+  // real widths of the three hidden layers (<= HID: the rest of a tile's units are structural zeros)
+  const int w[3] = {widths ? widths[0] : HID, widths ? widths[1] : HID, widths ? widths[2] : HID};
+  int sizes[5] = {h, w[0], w[1], w[2], h};
   NetDesc net[2];
   const bool has[2] = {has_s, has_t};  // an absent net (scale=False / shift=False) is an all-zero operand set
   int64_t off = 0;
@@ -452,7 +454,8 @@ static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t
         if (u >= 2 * HID) continue;
         for (int e = 0; e < 8; ++e) {
           const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
-          if (g < G && col < h && has[u / HID]) put(lane, e, net[u / HID].w_off[0] + (u % HID) * h + col);
+          if (g < G && col < h && has[u / HID] && u % HID < w[0])
+            put(lane, e, net[u / HID].w_off[0] + (u % HID) * h + col);
         }
       }
   for (int l = 1; l <= 2; ++l)
@@ -466,7 +469,8 @@ static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t
             int tile;
             const int ui = unit_in(ks, kq, e, tile);
             if (ui < 0 || ui / HID != u / HID || S::assigned_ks(S::tile_nets(m), tile) != ks || !has[u / HID]) continue;
-            put(lane, e, net[u / HID].w_off[l] + (u % HID) * HID + ui % HID);
+            if (u % HID >= w[l] || ui % HID >= w[l - 1]) continue;
+            put(lane, e, net[u / HID].w_off[l] + (u % HID) * w[l - 1] + ui % HID);
           }
         }
         ++op;
@@ -482,7 +486,8 @@ static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t
               int tile;
               const int ui = unit_in(ks, kq, e, tile);
               if (ui < 0 || ui / HID != nn || S::assigned_ks(1 << nn, tile) != ks || 16 * g + i >= h || !has[nn]) continue;
-              put(lane, e, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+              if (ui % HID >= w[2]) continue;
+              put(lane, e, net[nn].w_off[3] + (16 * g + i) * w[2] + ui % HID);
             }
           }
       }
@@ -493,7 +498,7 @@ static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t
     for (int m = 0; m < NT; ++m, ++bt)
       for (int i = 0; i < 16; ++i) {
         const int u = 16 * m + i;
-        if (u < 2 * HID && has[u / HID]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
+        if (u < 2 * HID && has[u / HID] && u % HID < w[l]) b[bt * 16 + i] = net[u / HID].b_off[l] + u % HID;
       }
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
@@ -571,10 +576,10 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
 #define MNF_AHF_SPLIT_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
 #define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
 
+// three hidden layers of at most 32 units: hid = the width the kernels run them at (see ahf_padded_hidden)
 static bool uniform3(int n_hidden, const int* hidden, int& hid) {
-  if (n_hidden != 3 || !hidden) return false;
-  hid = hidden[0];
-  return hidden[1] == hid && hidden[2] == hid;
+  hid = ahf_padded_hidden(n_hidden, hidden);
+  return hid != 0;
 }
 
 static bool aligned16(const void* a, const void* b, const void* c, const void* d) {
@@ -656,7 +661,7 @@ int mnf_affine_half_split_index(int dim, int n_hidden, const int* hidden, int ha
   const int h = dim / 2, hp = (dim & 1) ? 0 : mnf::ahf_padded_half(h);
 #define X(HH, HD)                                 \
   if (hp == HH && hid == HD) {                    \
-    mnf::build_split_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0);  \
+    mnf::build_split_index<HH, HD>(idx_host, h, has_scale != 0, has_shift != 0, hidden);  \
     return MNF_OK;                                \
   }
   if (h == hp) {

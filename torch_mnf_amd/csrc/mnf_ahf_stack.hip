@@ -159,10 +159,10 @@ int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float*
       (dim & 1) || !mnf::hidden_ok(n_hidden, hidden) || ((log_prob || log_prob_sum) && !log_det))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  if (n_hidden != 3 || hidden[0] != hidden[1] || hidden[1] != hidden[2]) return MNF_ERR_UNSUPPORTED;
+  const int hid = mnf::ahf_padded_hidden(n_hidden, hidden);  // three hidden layers of <= 32 units, run at 16 / 24 / 32
+  if (hid == 0) return MNF_ERR_UNSUPPORTED;
   uint32_t bits = 0;
   for (int l = 0; l < n_layers; ++l) bits |= (parity_host[l] ? 1u : 0u) << l;
-  const int hid = hidden[0];
   if (split_images) {
     const int rc = mnf::ahf_split_stack_launch(x, y, intermediates, log_det, y_sqnorm, accumulate, split_images, images, bits,
                                                n_layers, rows, dim, inverse, hid, log_prob, log_prob_sum,

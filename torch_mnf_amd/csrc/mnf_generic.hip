@@ -618,11 +618,10 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
     const int rc = ahf_split_launch(x, y, log_det, y_sqnorm, accumulate, split_image, image, rows, dim, parity,
                                     inverse, n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
-    if (dim / 2 != ahf_padded_half(dim / 2) && (has_scale || has_shift) && n_hidden == 3 && hidden[1] == hidden[0] &&
-        hidden[2] == hidden[0]) {
+    if (dim / 2 != ahf_padded_half(dim / 2) && (has_scale || has_shift) && ahf_padded_hidden(n_hidden, hidden)) {
       // a half narrower than its MFMA tile (d = 2, 6, 50 ...): the stack kernel's ragged variant, one layer
       const int rc1 = ahf_split_stack_launch(x, y, nullptr, log_det, y_sqnorm, accumulate, split_image, image,
-                                             parity ? 1u : 0u, 1, rows, dim, inverse, hidden[0], nullptr, nullptr,
+                                             parity ? 1u : 0u, 1, rows, dim, inverse, ahf_padded_hidden(n_hidden, hidden), nullptr, nullptr,
                                              (hipStream_t)stream);
       if (rc1 != MNF_ERR_UNSUPPORTED) return rc1;
     }
