@@ -1187,16 +1187,18 @@ def test_nice_and_no_shift_variants_on_the_mfma_path(amd, O, dim, kw):
             assert float(ld.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
 @pytest.mark.parametrize("dim", [64, 6, 256])
 @pytest.mark.parametrize("h_sizes", [(20, 20, 20), (8, 24, 17), (30, 12, 32), (3, 1, 2)])
-def test_affine_half_any_three_hidden_widths_up_to_32(amd, O, dim, h_sizes):
+def test_affine_half_any_three_hidden_widths_up_to_32(amd, O, dim, h_sizes, kernel):
     """Three hidden layers of any widths <= 32 run on the MFMA kernels at the next of 16 / 24 / 32 (structural-zero
     units): single layer and 3-layer run vs the oracle and the generic kernel."""
     if dim == 256 and not 16 < max(h_sizes) <= 24:
         pytest.skip("d = 256 only has the kernels that run the hidden layers at 24 units")
     sds = [recipes.affine_half_params(1400 + dim + i, dim, h_sizes=h_sizes, s_last_gain=2.0) for i in range(3)]
-    flows = [ahf_module(amd, sd, dim, bool(i % 2), h_sizes=h_sizes) for i, sd in enumerate(sds)]
-    assert all(f._split_image(torch.device(DEV, 0)) is not None for f in flows)
+    flows = [ahf_module(amd, sd, dim, bool(i % 2), kernel, h_sizes=h_sizes) for i, sd in enumerate(sds)]
+    assert all((f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split") for f in flows)
+    assert all(f._packed(torch.device(DEV, 0))[1] is not None for f in flows)
     x = recipes.gaussian(1401 + dim, 333, dim)
     for inverse in (False, True):
         ref_y, ref_ld = O.affine_half(x, sds[1], True, inverse)

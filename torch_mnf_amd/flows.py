@@ -507,8 +507,12 @@ class AffineHalfFlow(_TwoWayFlow):
         return y, (None if accum is not None else ld)
 
     def emits_sqnorm(self, device) -> bool:
-        """True when this layer's kernel can also write |y_row|^2 (the specialised kernel only)."""
-        return (not self.force_generic) and self._packed(device)[1] is not None
+        """True when this layer's kernel can also write |y_row|^2 (the specialised kernels only; a half narrower than
+        its MFMA tile only has the split stack kernel, so not when that one is switched off)."""
+        if self.force_generic:
+            return False
+        _, image, split = self._packed3(device)
+        return image is not None and (split is not None or self.dim // 2 in (16, 32, 64, 128))
 
     def forward(self, z: Tensor, inverse: bool = False) -> tuple[Tensor, Tensor]:
         return self._run(z, inverse, None)
