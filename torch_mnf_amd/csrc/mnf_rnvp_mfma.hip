@@ -634,13 +634,14 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
 
 // 2 entries per split word (low half, high half), then 1 entry per plain word -- see mnf_pack_gather_split
 // dm: the layer's real width (flat-parameter offsets, valid columns / rows); d: dm rounded up to 16
+// hn <= HN: the layer's real hidden width (units hn .. HN-1 are structural zeros: y = 0 there)
 template <int HN>
-static void build_split_index(int dm, int d, int32_t* idx) {
+static void build_split_index(int dm, int d, int32_t* idx, int hn = HN) {
   using S = RnvpSplitShape<HN>;
   constexpr int YT = S::YT, NKS2 = S::NKS2;
   const int G = d / 16;
-  const int64_t wn = 0, bn = wn + (int64_t)HN * dm, wt = bn + HN, bt = wt + (int64_t)dm * HN, ws = bt + dm,
-                bs = ws + (int64_t)dm * HN;
+  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, bt = wt + (int64_t)dm * hn, ws = bt + dm,
+                bs = ws + (int64_t)dm * hn;
   const int64_t n_entries = 2 * S::split_words(d) + S::plain_words(d);
   for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
   // element e of lane (i, kq) of operand `op` (hi at 2 op, lo at 2 op + 1), base = first word of the region
@@ -654,7 +655,7 @@ static void build_split_index(int dm, int d, int32_t* idx) {
     for (int m = 0; m < YT; ++m)
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-        if (u >= HN) continue;
+        if (u >= hn) continue;
         for (int e = 0; e < 8; ++e) {
           const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
           if (g < G && col < dm) put(0, ks * YT + m, lane, e, wn + (int64_t)u * dm + col);
@@ -668,9 +669,9 @@ static void build_split_index(int dm, int d, int32_t* idx) {
           const int i = lane & 15, kq = lane >> 4;
           for (int e = 0; e < 8; ++e) {
             const int tile = 2 * ks + (e >> 2), unit = 16 * tile + 4 * kq + (e & 3);
-            if (tile < YT && unit < HN && 16 * m + i < dm)
+            if (tile < YT && unit < hn && 16 * m + i < dm)
               put(S::part1_words(d) + (int64_t)m * S::TILE2_WORDS, which * NKS2 + ks, lane, e,
-                  (which ? ws : wt) + (int64_t)(16 * m + i) * HN + unit);
+                  (which ? ws : wt) + (int64_t)(16 * m + i) * hn + unit);
           }
         }
   int32_t* pl = idx + 2 * S::split_words(d);
@@ -682,7 +683,7 @@ static void build_split_index(int dm, int d, int32_t* idx) {
     }
   for (int m = 0; m < YT; ++m)
     for (int i = 0; i < 16; ++i)
-      if (16 * m + i < HN) pl[(int64_t)G * 32 + m * 16 + i] = (int32_t)(bn + 16 * m + i);
+      if (16 * m + i < hn) pl[(int64_t)G * 32 + m * 16 + i] = (int32_t)(bn + 16 * m + i);
 }
 
 template <int HN, bool RAG>
@@ -717,12 +718,12 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
 
 // ---------------------------------------------------------------- host: image index table
 template <int HN>
-static void build_index(int dm, int d, int32_t* idx) {
+static void build_index(int dm, int d, int32_t* idx, int hn = HN) {
   using S = RnvpShape<HN>;
   constexpr int KQ = S::KQ, YT = S::YT;
-  // flat layout: net.0.weight (HN, dm), net.0.bias (HN), t.weight (dm, HN), t.bias (dm), s.weight (dm, HN), s.bias (dm)
-  const int64_t wn = 0, bn = wn + (int64_t)HN * dm, wt = bn + HN, bt = wt + (int64_t)dm * HN, ws = bt + dm,
-                bs = ws + (int64_t)dm * HN;
+  // flat layout: net.0.weight (hn, dm), net.0.bias (hn), t.weight (dm, hn), t.bias (dm), s.weight (dm, hn), s.bias (dm)
+  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, bt = wt + (int64_t)dm * hn, ws = bt + dm,
+                bs = ws + (int64_t)dm * hn;
   const int64_t total = S::image_floats(d);
   for (int64_t i = 0; i < total; ++i) idx[i] = -1;
   auto unit_of = [&](int m, int i) { return 16 * m + 4 * (i & 3) + (i >> 2); };
@@ -733,7 +734,7 @@ static void build_index(int dm, int d, int32_t* idx) {
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
         const int col = 16 * g + 4 * kq + e;
-        if (u < HN && col < dm) idx[(int64_t)kk * 256 + lane * 4 + m] = (int32_t)(wn + (int64_t)u * dm + col);
+        if (u < hn && col < dm) idx[(int64_t)kk * 256 + lane * 4 + m] = (int32_t)(wn + (int64_t)u * dm + col);
       }
   }
   // part 2: per output tile m: sequence n = 2 c + which
@@ -744,9 +745,9 @@ static void build_index(int dm, int d, int32_t* idx) {
         const int n = 2 * c + which;
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, unit = 4 * c + kq;
-          if (unit < HN && 16 * m + i < dm)
+          if (unit < hn && 16 * m + i < dm)
             p2[(int64_t)m * S::TILE2_FLOATS + (n >> 2) * 256 + lane * 4 + (n & 3)] =
-                (int32_t)((which ? ws : wt) + (int64_t)(16 * m + i) * HN + unit);
+                (int32_t)((which ? ws : wt) + (int64_t)(16 * m + i) * hn + unit);
         }
       }
   for (int m = 0; m < d / 16; ++m)
@@ -758,11 +759,16 @@ static void build_index(int dm, int d, int32_t* idx) {
   int32_t* pb = p2 + S::part2_floats(d);
   for (int m = 0; m < YT; ++m)
     for (int i = 0; i < 16; ++i)
-      if (unit_of(m, i) < HN) pb[m * 16 + i] = (int32_t)(bn + unit_of(m, i));
+      if (unit_of(m, i) < hn) pb[m * 16 + i] = (int32_t)(bn + unit_of(m, i));
 }
 
-// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default)
+// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default); any other width up
+// to 50 runs at the next one up with structural-zero units (rnvp_padded_hidden)
 #define MNF_RNVP_HIDDEN(X) X(50) X(30)
+static int rnvp_padded_hidden(int n_hidden, const int* hidden) {
+  if (n_hidden != 1 || !hidden || hidden[0] < 1) return 0;
+  return hidden[0] <= 30 ? 30 : hidden[0] <= 50 ? 50 : 0;
+}
 
 template <int HN, bool RAG>
 static int launch_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
@@ -796,7 +802,7 @@ static int rnvp_padded_dim(int dim) { return (dim + 15) & ~15; }
 static bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
   const int d = rnvp_padded_dim(dim);
   if (n_hidden != 1 || !hidden || dim < 1 || d < 64 || (int64_t)d * 64 * 3 >= (1ll << 30)) return false;
-#define X(HN) if (hidden[0] == HN) return true;
+#define X(HN) if (rnvp_padded_hidden(n_hidden, hidden) == HN) return true;
   MNF_RNVP_HIDDEN(X)
 #undef X
   return false;
@@ -813,12 +819,13 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   const bool rows_aligned =
       ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   const bool ragged = d != dim;
+  const int hn_pad = rnvp_padded_hidden(n_hidden, hidden);
   if (!ragged && !rows_aligned) return MNF_ERR_UNSUPPORTED;
   const int vec = rows_aligned && (dim & 3) == 0;
   if (split_image) {
     const uint32_t* simage = static_cast<const uint32_t*>(split_image);
 #define X(HN)                                                                                                        \
-  if (hidden[0] == HN)                                                                                               \
+  if (hn_pad == HN)                                                                                                  \
     return ragged ? launch_rnvp_split<HN, true>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,       \
                                                 q0_mean, q0_log_var, dim, vec, stream)                               \
                   : launch_rnvp_split<HN, false>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,      \
@@ -827,7 +834,7 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 #undef X
   }
 #define X(HN)                                                                                                        \
-  if (hidden[0] == HN)                                                                                               \
+  if (hn_pad == HN)                                                                                                  \
     return ragged ? launch_rnvp<HN, true>(z, mask, x, log_det, accumulate, image, rows, d, seed, dim, vec, stream)   \
                   : launch_rnvp<HN, false>(z, mask, x, log_det, accumulate, image, rows, d, seed, dim, vec, stream);
   MNF_RNVP_HIDDEN(X)
@@ -841,7 +848,7 @@ extern "C" {
 
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden) {
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return 0;
-#define X(HN) if (hidden[0] == HN) return mnf::RnvpShape<HN>::image_floats(mnf::rnvp_padded_dim(dim));
+#define X(HN) if (mnf::rnvp_padded_hidden(n_hidden, hidden) == HN) return mnf::RnvpShape<HN>::image_floats(mnf::rnvp_padded_dim(dim));
   MNF_RNVP_HIDDEN(X)
 #undef X
   return 0;
@@ -851,7 +858,7 @@ int mnf_rnvp_split_layout(int dim, int n_hidden, const int* hidden, int64_t* n_s
   if (!n_split_words || !n_plain_words) return MNF_ERR_INVALID_ARG;
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                                                        \
-  if (hidden[0] == HN) {                                             \
+  if (mnf::rnvp_padded_hidden(n_hidden, hidden) == HN) {             \
     *n_split_words = mnf::RnvpSplitShape<HN>::split_words(mnf::rnvp_padded_dim(dim));  \
     *n_plain_words = mnf::RnvpSplitShape<HN>::plain_words(mnf::rnvp_padded_dim(dim));  \
     return MNF_OK;                                                   \
@@ -865,8 +872,8 @@ int mnf_rnvp_split_index(int dim, int n_hidden, const int* hidden, int32_t* idx_
   if (!idx_host) return MNF_ERR_INVALID_ARG;
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                                      \
-  if (hidden[0] == HN) {                           \
-    mnf::build_split_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host);  \
+  if (mnf::rnvp_padded_hidden(n_hidden, hidden) == HN) {  \
+    mnf::build_split_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host, hidden[0]);  \
     return MNF_OK;                                 \
   }
   MNF_RNVP_HIDDEN(X)
@@ -878,8 +885,8 @@ int mnf_rnvp_image_index(int dim, int n_hidden, const int* hidden, int32_t* idx_
   if (!idx_host) return MNF_ERR_INVALID_ARG;
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
 #define X(HN)                               \
-  if (hidden[0] == HN) {                    \
-    mnf::build_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host);  \
+  if (mnf::rnvp_padded_hidden(n_hidden, hidden) == HN) {  \
+    mnf::build_index<HN>(dim, mnf::rnvp_padded_dim(dim), idx_host, hidden[0]);  \
     return MNF_OK;                          \
   }
   MNF_RNVP_HIDDEN(X)
