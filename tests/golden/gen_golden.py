@@ -6,7 +6,7 @@ Run in the build container only (needs /root/reference; it never travels):
 
 Every fixture is data: inputs, masks/noise, the reference's outputs, and -- where they
 cannot be rebuilt from ``recipes.py`` -- parameter values.  No reference source text is
-stored.  Fixture list follows SURVEY.md section 8c (G1..G9).
+stored.  Fixture list follows SURVEY.md section 8c (G1..G9); G10 adds the shapes the kernels run padded.
 """
 from __future__ import annotations
 
@@ -288,6 +288,36 @@ def g7_rnvp():
     save("g7_rnvp", **out)
 
 
+# ----------------------------------------------------------------------------- G10
+def g10_padded_shapes():
+    """Layers whose widths do not fill the kernels' tiles: AffineHalfFlow with narrow halves / odd hidden widths /
+    an absent net, RNVP with dim % 16 != 0 and hidden widths other than 30 / 50."""
+    out = {}
+    for k, (tag, (dim, kw)) in enumerate(recipes.G10_AHF.items()):
+        seed = 1000 + 10 * k
+        f = nf.AffineHalfFlow(dim, bool(k % 2), **kw)
+        f.load_state_dict(recipes.affine_half_params(seed, dim, s_last_gain=2.0, **kw))
+        z = recipes.gaussian(seed + 1, 96, dim)
+        with torch.no_grad():
+            x_f, ld_f = f.forward(z)
+            x_i, ld_i = f.inverse(z)
+        out.update({f"ahf.{tag}.z": npy(z), f"ahf.{tag}.fwd": npy(x_f), f"ahf.{tag}.ld_fwd": npy(ld_f),
+                    f"ahf.{tag}.inv": npy(x_i), f"ahf.{tag}.ld_inv": npy(ld_i)})
+    for k, (tag, (dim, hid)) in enumerate(recipes.G10_RNVP.items()):
+        seed = 1100 + 10 * k
+        f = nf.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(recipes.rnvp_params(seed, dim, hid))
+        z = recipes.gaussian(seed + 1, 80, dim)
+        torch.manual_seed(seed)
+        mask = torch.bernoulli(0.5 * torch.ones_like(z))
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            x, ld = f.forward(z)
+        out.update({f"rnvp.{tag}.z": npy(z), f"rnvp.{tag}.mask_bits": np.packbits(npy(mask).astype(np.uint8), axis=1),
+                    f"rnvp.{tag}.x": npy(x), f"rnvp.{tag}.ld": npy(ld)})
+    save("g10_padded_shapes", **out)
+
+
 # ----------------------------------------------------------------------------- G8
 def g8_sample_z():
     """MNFLinear(800, 50).sample_z(64) with the noise and both masks captured."""
@@ -356,4 +386,5 @@ if __name__ == "__main__":
     g6_c3_stack()
     g7_rnvp()
     g8_sample_z()
+    g10_padded_shapes()
     g9_logdet_shapes()

@@ -103,3 +103,17 @@ def c2_stack_params(dim: int = 64, n_layers: int = 9, base_seed: int = 1000) -> 
     = bool(i % 2) as in examples/half_moons.ipynb:90.  s_last_gain 2 keeps a 9-layer
     pass finite while exercising exp() away from 1."""
     return [affine_half_params(base_seed + i, dim, s_last_gain=2.0) for i in range(n_layers)]
+
+
+# Fixture G10 (gen_golden.g10_padded_shapes): k-th entry uses seed 1000 + 10 k (AffineHalfFlow, parity = k odd)
+# or 1100 + 10 k (RNVP)
+G10_AHF = {  # tag -> (dim, constructor keywords): shapes the MFMA kernels run padded (narrow halves, hidden widths)
+    "d6_h8_24_17": (6, dict(h_sizes=(8, 24, 17))),
+    "d64_h20": (64, dict(h_sizes=(20, 20, 20))),
+    "d50": (50, dict()),
+    "d2": (2, dict()),
+    "d64_nice": (64, dict(scale=False)),
+    "d130_noshift": (130, dict(shift=False)),
+    "d100_h32": (100, dict(h_sizes=(32, 32, 32))),
+}
+G10_RNVP = {"d100_h41": (100, 41), "d70_h50": (70, 50), "d49_h7": (49, 7)}

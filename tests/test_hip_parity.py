@@ -1217,3 +1217,28 @@ def test_affine_half_any_three_hidden_widths_up_to_32(amd, O, dim, h_sizes, kern
     ref_mean, ref_lp = O.mean_log_prob(x, layers)
     assert_close(lp, ref_lp, RTOL, "log_prob")
     assert abs(float(total) / 333 - ref_mean) <= RTOL * abs(ref_mean)
+
+
+def test_g10_padded_shapes_vs_reference(amd, golden):
+    """Reference-generated fixture for the shapes the kernels run padded: AffineHalfFlow with narrow halves, odd hidden
+    widths or an absent net, RNVP with dim % 16 != 0 / other hidden widths -- every one on an MFMA kernel."""
+    fx = golden("g10_padded_shapes")
+    for k, (tag, (dim, kw)) in enumerate(recipes.G10_AHF.items()):
+        f = ahf_module(amd, recipes.affine_half_params(1000 + 10 * k, dim, s_last_gain=2.0, **kw), dim, bool(k % 2), **kw)
+        assert f._split_image(torch.device(DEV, 0)) is not None, tag
+        z = cuda(fx[f"ahf.{tag}.z"])
+        for name, fn in (("fwd", f.forward), ("inv", f.inverse)):
+            y, ld = fn(z)
+            assert_close(y, fx[f"ahf.{tag}.{name}"], RTOL, f"{tag}.{name}")
+            if kw.get("scale", True):
+                assert_close(ld, fx[f"ahf.{tag}.ld_{name}"], RTOL, f"{tag}.ld_{name}")
+            else:
+                assert float(ld.abs().max()) == 0.0
+    for k, (tag, (dim, hid)) in enumerate(recipes.G10_RNVP.items()):
+        f = amd.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(recipes.rnvp_params(1100 + 10 * k, dim, hid))
+        f.to(DEV)
+        assert f._split_image(torch.device(DEV, 0)) is not None, tag
+        x, ld = f.forward(cuda(fx[f"rnvp.{tag}.z"]), mask=unpack_mask(fx[f"rnvp.{tag}.mask_bits"], dim).to(DEV))
+        assert_close(x, fx[f"rnvp.{tag}.x"], RTOL, f"{tag}.x")
+        assert_close(ld, fx[f"rnvp.{tag}.ld"], RTOL, f"{tag}.ld")

@@ -205,3 +205,22 @@ def test_g9_logdet_shapes(golden):
     zs, ld = O.flow_stack(x, [specs["actnorm"], specs["glow"], specs["nsf_cl"]], False)
     assert tuple(ld.shape) == tuple(fx["stack.ld_shape"]) and zs[0] is x
     assert len(zs) == int(fx["stack.n_intermediates"])
+
+
+def test_g10_padded_shapes(golden):
+    """The shapes the HIP kernels run padded (narrow halves, odd hidden widths, an absent net; RNVP widths that are
+    not multiples of 16 / hidden widths other than 30, 50): the oracle against the real reference."""
+    fx = golden("g10_padded_shapes")
+    for k, (tag, (dim, kw)) in enumerate(recipes.G10_AHF.items()):
+        sd = recipes.affine_half_params(1000 + 10 * k, dim, s_last_gain=2.0, **kw)
+        z = t(fx[f"ahf.{tag}.z"])
+        flags = {key: kw[key] for key in ("scale", "shift") if key in kw}
+        for name, inverse in (("fwd", False), ("inv", True)):
+            y, ld = O.affine_half(z, sd, bool(k % 2), inverse, **flags)
+            assert_close(y, fx[f"ahf.{tag}.{name}"], 1e-6, f"{tag}.{name}")
+            assert_close(ld, fx[f"ahf.{tag}.ld_{name}"], 1e-6 if flags.get("scale", True) else 1.0, f"{tag}.ld_{name}")
+    for k, (tag, (dim, hid)) in enumerate(recipes.G10_RNVP.items()):
+        sd = recipes.rnvp_params(1100 + 10 * k, dim, hid)
+        x, ld = O.rnvp(t(fx[f"rnvp.{tag}.z"]), sd, unpack_mask(fx[f"rnvp.{tag}.mask_bits"], dim))
+        assert_close(x, fx[f"rnvp.{tag}.x"], 1e-6, f"{tag}.x")
+        assert_close(ld, fx[f"rnvp.{tag}.ld"], 1e-6, f"{tag}.ld")
