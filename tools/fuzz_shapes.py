@@ -1,0 +1,110 @@
+"""Randomised shape fuzz: runs of 1-4 AffineHalfFlow layers (any even d <= 256, any three hidden widths <= 32, NICE /
+no-shift variants, random row counts, both directions) and RNVP layers (49 <= d <= 900, hidden <= 50) on the MFMA
+kernels against the shape-generic kernels.  Not a pytest (minutes of GPU time); exits non-zero on a mismatch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import numpy as np, torch, recipes
+import torch_mnf_amd as amd
+
+
+
+def f64_layer(x, sd, parity, inverse, scale=True, shift=True):
+    """One AffineHalfFlow layer in float64 (affine_half_flow.py:44-66), the referee when two fp32 kernels disagree."""
+    import torch.nn.functional as F
+    h = x.shape[1] // 2
+    x0, x1 = x[:, :h], x[:, h:]
+    if parity: x0, x1 = x1, x0
+    def net(pre):
+        a, i = x0, 0
+        while f"{pre}.{i}.weight" in sd:
+            a = F.linear(a, sd[f"{pre}.{i}.weight"].double(), sd[f"{pre}.{i}.bias"].double())
+            if f"{pre}.{i + 2}.weight" in sd: a = F.leaky_relu(a, 0.2)
+            i += 2
+        return a
+    s_ = net("s_net") if scale else torch.zeros_like(x0)
+    t_ = net("t_net") if shift else torch.zeros_like(x0)
+    y1 = (x1 - t_) * torch.exp(-s_) if inverse else torch.exp(s_) * x1 + t_
+    y0, y1 = (y1, x0) if parity else (x0, y1)
+    return torch.cat([y0, y1], 1), (-s_.sum(1) if inverse else s_.sum(1))
+
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev, tol, bad, mfma = "cuda", 1e-5, 0, 0
+
+
+def close(a, b, t=tol):
+    d = float((a - b).abs().max())
+    return d <= t * max(float(b.abs().max()), 1e-30) or (d == 0.0)
+
+
+# log_det is a sum of up to 128 scale outputs that may nearly cancel: two fp32 kernels that are each within 1e-5 of a
+# float64 run can sit 1e-5 apart relative to max |log_det| (seen: 1.1e-5 with a one-unit hidden layer), hence 5e-5 there
+LD_TOL = 5e-5
+
+
+for case in range(n_cases):
+    if rng.random() < 0.75:
+        dim = int(rng.integers(1, 129)) * 2
+        h = tuple(int(v) for v in rng.integers(1, 33, size=3)) if rng.random() < 0.5 else (24, 24, 24)
+        if dim > 128 and max(h) > 24 or dim > 128 and max(h) <= 16:
+            h = (24, 24, 24)
+        kw = {}
+        r = rng.random()
+        if r < 0.15: kw["scale"] = False
+        elif r < 0.3: kw["shift"] = False
+        n_layers, rows, inverse = int(rng.integers(1, 5)), int(rng.integers(1, 5000)), bool(rng.integers(0, 2))
+        flows = []
+        for i in range(n_layers):
+            f = amd.AffineHalfFlow(dim, bool(rng.integers(0, 2)), h_sizes=h, **kw)
+            f.load_state_dict(recipes.affine_half_params(int(rng.integers(1 << 30)), dim, h_sizes=h, s_last_gain=1.5, **kw))
+            flows.append(f)
+        sds = [{k: v.detach().cpu() for k, v in f.state_dict().items()} for f in flows]
+        model = amd.NormalizingFlow(flows).to(dev)
+        x = torch.randn(rows, dim, device=dev) * float(rng.choice([0.1, 1.0, 3.0]))
+        with torch.no_grad():
+            zs, ld = model.inverse(x) if inverse else model.forward(x)
+            mfma += int(flows[0]._split_image(torch.device(dev, 0)) is not None)
+            for f in flows: f.force_generic = True
+            zs_g, ld_g = model.inverse(x) if inverse else model.forward(x)
+        ok = all(close(a, b) for a, b in zip(zs, zs_g)) and close(ld, ld_g, LD_TOL)
+        if not ok:  # referee: float64.  An ill-conditioned draw (e.g. a one-unit hidden layer) is no kernel bug if the
+            cur, ldr = x.double().cpu(), 0  # MFMA result is as close to float64 as the generic kernel's
+            order = range(n_layers - 1, -1, -1) if inverse else range(n_layers)
+            for i in order:
+                cur, l1 = f64_layer(cur, sds[i], bool(flows[i].parity), inverse, **kw)
+                ldr = ldr + l1
+            e = lambda a, b: float((a.double().cpu() - b).abs().max() / max(float(b.abs().max()), 1e-30))
+            if not (torch.isfinite(cur).all() and torch.isfinite(ldr).all()):
+                print("   (the draw overflows in float64 too: skipped)")
+                ok = True
+            else:
+                em, eg = max(e(zs[-1], cur), e(ld, ldr)), max(e(zs_g[-1], cur), e(ld_g, ldr))
+                print(f"   disagreement; vs float64: mfma {em:.1e}, generic {eg:.1e}")
+                # the split path carries ~22 bits per product (mnf_split.h): through a one-unit hidden layer and a few
+                # exp(s) it can end a few 1e-6 further from float64 than an fp32 kernel; beyond 5e-5 it is a bug
+                ok = em <= max(2 * eg, 5e-5)
+                if ok: print("   ill-conditioned draw, within the split format's error:", end=" ")
+        desc = f"ahf d={dim} h={h} {kw} layers={n_layers} rows={rows} inv={inverse}"
+    else:
+        dim, hid, rows = int(rng.integers(49, 901)), int(rng.integers(1, 51)), int(rng.integers(1, 3000))
+        f = amd.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(recipes.rnvp_params(int(rng.integers(1 << 30)), dim, hid))
+        f.to(dev)
+        z = torch.randn(rows, dim, device=dev)
+        seed = int(rng.integers(1 << 40))
+        with torch.no_grad():
+            x1, l1 = f.forward(z, seed=seed)
+            mfma += int(f._split_image(torch.device(dev, 0)) is not None)
+            f.force_generic = True
+            x2, l2 = f.forward(z, seed=seed)
+        ok = close(x1, x2) and close(l1, l2, LD_TOL)
+        desc = f"rnvp d={dim} hid={hid} rows={rows}"
+    if not ok:
+        bad += 1
+        print("MISMATCH:", desc)
+    elif "ill-conditioned" in locals().get("_note", ""):
+        pass
+print(f"{n_cases} cases, {mfma} on MFMA kernels, {bad} mismatches")
+sys.exit(1 if bad else 0)
