@@ -261,8 +261,7 @@ class _AffineRunFn(torch.autograd.Function):
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         flat = flat_with_grad.detach()
         imgs = run.images(x.device, flat)  # after a weight update: repacked from this one concatenation
-        run._checked = (x.device, imgs)
-        outs = run.launch(x, inverse, ld, False, None, keep=True) if imgs[0] is not None else None
+        outs = run.launch(x, inverse, ld, False, None, keep=True, images=imgs) if imgs[0] is not None else None
         if outs is None:
             raise MnfHipError("mnf_affine_half_stack", _lib.MNF_ERR_UNSUPPORTED, "no stack kernel for this shape")
         ctx.run, ctx.inverse = run, inverse
@@ -989,7 +988,6 @@ class _AffineRun:
         self._images: Tensor | None = None
         self._splits: Tensor | None = None
         self._plist = None
-        self._checked = None  # (images, splits) validated by usable(), consumed by the launch that follows
         self._unsupported = False  # set once the library reports that the shape has no stack kernel
         self._no_fused_logprob = False  # set once the library reports that the shape has no fused log-prob epilogue
         self.logprob_fused = False
@@ -1038,17 +1036,18 @@ class _AffineRun:
             self._key = key
         return self._images, self._splits
 
-    def usable(self, x) -> bool:
-        self._checked = None
+    def ready(self, x):
+        """The run's (fp32 images, split images) if ``x`` can go through the stack kernel without gradients, else
+        None.  Hand the result to ``launch(images=...)``: the cache is then validated once per pass, not twice."""
         if (self._unsupported or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.shape[0] == 0
                 or x.shape[1] != self.layers[0].dim or any(f.force_generic for f in self.layers)
                 or any(_wants_grad(f, x) for f in self.layers)):
-            return False
+            return None
         imgs = self.images(x.device)
-        if imgs[0] is None:
-            return False
-        self._checked = (x.device, imgs)  # the launch right after this check does not validate the cache again
-        return True
+        return imgs if imgs[0] is not None else None
+
+    def usable(self, x) -> bool:
+        return self.ready(x) is not None
 
     def trainable(self, x) -> bool:
         """Gradients wanted and the whole run can go through one autograd node (stack kernel forward; backward
@@ -1072,7 +1071,7 @@ class _AffineRun:
         return list(out[:-1]), out[-1]
 
     def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, sqnorm: Tensor | None,
-               keep: bool, logprob: tuple | None = None) -> list[Tensor] | None:
+               keep: bool, logprob: tuple | None = None, images: tuple | None = None) -> list[Tensor] | None:
         """Runs the layers (model order reversed when ``inverse``).  Returns the output tensors in
         application order -- all of them when ``keep`` (views of one buffer: each intermediate is written
         once and never re-read), else just the last -- or None when the shape has no stack kernel.
@@ -1081,8 +1080,7 @@ class _AffineRun:
         standard-normal log-prob epilogue too; ``self.logprob_fused`` says whether it did (only the split
         kernel can -- otherwise ``sqnorm`` is filled as usual and the caller runs the epilogue kernel)."""
         f0, n = self.layers[0], len(self.layers)
-        checked, self._checked = self._checked, None
-        images, splits = checked[1] if checked is not None and checked[0] == x.device else self.images(x.device)
+        images, splits = images if images is not None else self.images(x.device)  # (``images``: from ready())
         x = _device_input(x, "input")
         buf = torch.empty((n if keep else 1, x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         par = _lib.int_array([int(bool(f.parity)) for f in self.layers])
@@ -1146,9 +1144,10 @@ class FusedAffineStack(_TwoWayFlow):
 
     def _run(self, x, inverse, accum, sqnorm: Tensor | None = None, overwrite: bool = False):
         run = self._run_helper
-        if run.usable(x):
+        imgs = run.ready(x)
+        if imgs is not None:
             ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-            out = run.launch(x, inverse, ld, accum is not None and not overwrite, sqnorm, keep=False)
+            out = run.launch(x, inverse, ld, accum is not None and not overwrite, sqnorm, keep=False, images=imgs)
             if out is not None:
                 return out[-1], (None if accum is not None else ld)
         elif isinstance(x, Tensor) and x.dim() == 2 and x.shape[1] != self.dim:
@@ -1229,9 +1228,14 @@ class NormalizingFlow(nn.Module):
             flow = order[i]
             run = run_at.get(i)
             train_run = run is not None and isinstance(run, _AffineRun) and run.trainable(x)
-            if run is not None and not train_run and not (
-                    run.usable(x) if isinstance(run, _AffineRun) else run.usable(x, inverse)):
-                run = None
+            run_images = None  # an affine run's validated operand images, handed on to its launch
+            if run is not None and not train_run:
+                if isinstance(run, _AffineRun):
+                    run_images = run.ready(x)
+                    if run_images is None:
+                        run = None
+                elif not run.usable(x, inverse):
+                    run = None
             span = span_of(run) if run is not None else 1
             last = i + span == n
             timed = events_on and (pick is None or pick == i)
@@ -1250,7 +1254,7 @@ class NormalizingFlow(nn.Module):
                 elif isinstance(run, _AffineRun):
                     sq = torch.empty(x.size(0), device=x.device) if (want_sqnorm and last) else None
                     outs = run.launch(x, inverse, log_det, not (fresh and i == 0), sq, keep=True,
-                                      logprob=want_logprob if last else None)
+                                      logprob=want_logprob if last else None, images=run_images)
                     if outs is not None and last and want_logprob is not None and run.logprob_fused:
                         self._logprob_done, sq = True, None
                 else:
