@@ -542,22 +542,29 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   constexpr int kStackWaves = stack_waves<H>(), kStackTiles = stack_tiles<H>();
   constexpr size_t image_bytes = 2 * SplitShape<H, HID>::IMAGE_WORDS * sizeof(uint32_t);
   constexpr size_t lds_bytes = image_bytes <= 64 * 1024 ? 0 : image_bytes;  // dynamic part (see the kernel)
-  static const int resident = [] {
-    int per_cu = 0, cus = 256, dev = 0;
+  // per device (the dynamic-LDS attribute is a per-device setting of the function; a process may drive several GPUs):
+  // 0 = not set up yet, -1 = the attribute could not be set, else the number of resident workgroups
+  static int resident_of_device[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (resident_of_device[dev] == 0) {  // (idempotent: two threads racing here compute the same value)
+    int per_cu = 0, cus = 256;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, true, RAG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, false, RAG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-      return 0;
-    // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
-    // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
-    per_cu = 4 * stack_waves_per_simd<H>() / kStackWaves;
-    while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
-    return per_cu * cus;
-  }();
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+      resident_of_device[dev] = -1;
+    } else {
+      // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
+      // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
+      per_cu = 4 * stack_waves_per_simd<H>() / kStackWaves;
+      while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
+      resident_of_device[dev] = per_cu * cus;
+    }
+  }
+  const int resident = resident_of_device[dev] > 0 ? resident_of_device[dev] : 0;
   if (resident == 0) return MNF_ERR_UNSUPPORTED;
   constexpr int GROUP_ROWS = 16 * kStackTiles * kStackWaves;
   const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
