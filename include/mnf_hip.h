@@ -73,6 +73,10 @@ int mnf_device_count(void);
  *           on the fp32 MFMA path inside the same launch (needs `image`)
  *   fp32    image given (mnf_affine_half_image_floats() floats), split_image NULL: fp32 MFMAs
  *   generic otherwise: reads `flat`, any shape
+ * Shapes with operand images (mnf_affine_half_image_floats() > 0): three hidden layers of at most 32 units each
+ * (run at 16 / 24 / 32 units with structural zeros), any even dim <= 256 (a half narrower than its 16/32/64/128-
+ * column tile is zero-padded in the image and runs the stack kernel's ragged variant with one layer; hidden width 32
+ * up to dim 128), has_scale / has_shift (an absent net is an all-zero operand set: s = 0 or t = 0 exactly).
  * log_det may be NULL (not computed). accumulate != 0: log_det += ld.
  * force_generic != 0 selects the generic kernel (used by tests to compare the kernels). */
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
@@ -89,9 +93,8 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
                        int64_t rows, int dim, int parity, int inverse,
                        int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                        int force_generic, void* stream);
-/* Opt-in whole-stack fusion: n_layers AffineHalfFlow layers of one shape in
- * ONE launch, rows kept in registers across layers; no intermediate tensor is written, so this is
- * not what NormalizingFlow.forward/inverse return by default.  images = the layers' operand
+/* Whole-stack fusion: n_layers AffineHalfFlow layers of one shape in ONE launch, rows kept
+ * in registers across layers.  images = the layers' operand
  * images back to back (layer 0 first); split_images = their split images back to back, or NULL for
  * the fp32 MFMA kernel; layers are applied 0..L-1 (forward) or L-1..0 (inverse).
  * intermediates: NULL, or a (n_layers - 1, rows, dim) buffer that receives the output of every layer but
@@ -101,8 +104,10 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
  * of them.  HBM traffic with intermediates == NULL: 8*dim + 8 bytes per row for the whole stack.
  * log_prob (rows,) / log_prob_sum (device double, ADDED to; caller zeroes it), both optional (split kernel only,
  * need log_det): the standard-normal base log-prob epilogue log_det - |y|^2/2 - dim/2 log(2 pi) of
- * mnf_gauss_logprob fused into the same launch (when the stack is the whole inverse pass of a model).  MNF_ERR_UNSUPPORTED for shapes
- * without a fused kernel (dim in {32, 64}, hidden (24,24,24) or (16,16,16)). */
+ * mnf_gauss_logprob fused into the same launch (when the stack is the whole inverse pass of a model).
+ * MNF_ERR_UNSUPPORTED for shapes without a fused kernel: the split kernel covers every shape that has a split image
+ * except hidden width 32 at full-tile dim <= 64 with n_layers > 1 (no faster than one launch per layer); the fp32
+ * kernel behind it dim in {32, 64} with hidden width 24 or 16. */
 int mnf_affine_half_stack(const float* x, float* y, float* intermediates, float* log_det, float* y_sqnorm,
                           float* log_prob, double* log_prob_sum, int accumulate,
                           const float* images, const void* split_images, const int* parity_host, int n_layers,
