@@ -193,7 +193,10 @@ int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D,
 
 /* -------------------------------------------------------------- RNVP (masked/gated) */
 /* mask: (rows, dim) floats in {0,1}, supplied by the caller (the reference draws
- * torch.bernoulli per call, rnvp.py:28).  net = MLP(dim, hidden...); t, s = Linear(h_last, dim). */
+ * torch.bernoulli per call, rnvp.py:28).  net = MLP(dim, hidden...); t, s = Linear(h_last, dim).
+ * MFMA kernels (image / split_image given): one hidden layer of at most 50 units (run at 30 or 50 with structural
+ * zeros), any dim >= 49 (dim % 16 != 0: zero-padded operand images, masked row accesses; the padded dims' scale bias
+ * is the constant 80 so that they add nothing to log_det); the generic kernel (flat) otherwise. */
 int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
              const float* flat, const float* image, const void* split_image,
              int64_t rows, int dim, int n_hidden, const int* hidden_host,
