@@ -51,4 +51,22 @@ eps2 = torch.randn(256000, 50, device=dev)
 masks2 = [f.mask_for(21 + i, 256000) for i, f in enumerate(layer2.flow_q.flows)]
 total += check("MNFLinear(50,10).sample_z", lambda: list(layer2.sample_z(256000, eps=eps2, masks=masks2)), iters)
 print("TOTAL mismatches:", total)
-sys.exit(1 if total else 0)
+
+# two streams at once: workgroups of different launches share CUs, which shifts every timing the double-buffered
+# LDS images and their LDS-DMA hand-over depend on
+model_a, model_b = ahf_model(64), ahf_model(256)
+xa, xb = torch.randn(1 << 19, 64, device=dev), torch.randn(1 << 17, 256, device=dev)
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+with torch.no_grad():
+    ref_a, ref_b = model_a.log_prob(xa).clone(), model_b.log_prob(xb).clone()
+    torch.cuda.synchronize()
+    bad2 = 0
+    for _ in range(iters // 2):
+        with torch.cuda.stream(sa):
+            la = model_a.log_prob(xa)
+        with torch.cuda.stream(sb):
+            lb = model_b.log_prob(xb)
+        torch.cuda.synchronize()
+        bad2 += int(not torch.equal(la, ref_a)) + int(not torch.equal(lb, ref_b))
+print(f"two concurrent streams (d=64 and d=256 stacks): {iters // 2} rounds, {bad2} mismatching tensors")
+sys.exit(1 if (total + bad2) else 0)
