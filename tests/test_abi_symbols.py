@@ -233,7 +233,7 @@ def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
     assert len(used) == n_params and len(np.unique(used)) == n_params and (a == -2).sum() == (-dim) % 16
 
 
-@pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8)])
+@pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8), (64, 5, 8), (64, 8, 16), (32, 5, 16)])
 def test_nsf_split_index_covers_every_parameter(lib, dim, K, nh):
     from torch_mnf_amd._lib import int_array
 

@@ -1242,3 +1242,22 @@ def test_g10_padded_shapes_vs_reference(amd, golden):
         x, ld = f.forward(cuda(fx[f"rnvp.{tag}.z"]), mask=unpack_mask(fx[f"rnvp.{tag}.mask_bits"], dim).to(DEV))
         assert_close(x, fx[f"rnvp.{tag}.x"], RTOL, f"{tag}.x")
         assert_close(ld, fx[f"rnvp.{tag}.ld"], RTOL, f"{tag}.ld")
+
+
+@pytest.mark.parametrize("kernel", ["split", "fp32"])
+@pytest.mark.parametrize("dim,K,n_h", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (32, 5, 16), (64, 8, 8), (64, 5, 8), (64, 8, 16)])
+def test_nsf_cl_mfma_shape_matrix(amd, O, dim, K, n_h, kernel):
+    """Every (dim, K, n_h) triple with an MFMA spline kernel -- incl. the reference's default K = 5 and the n_h = 16 of
+    its tests at both dims: result vs the oracle, both directions, a row count with a partial tile."""
+    sd = recipes.nsf_cl_params(1500 + dim + K + n_h, dim, K, n_h)
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f = select_kernel(f.to(DEV), kernel)
+    assert f._packed(torch.device(DEV, 0))[1] is not None
+    assert (f._split_image(torch.device(DEV, 0)) is not None) == (kernel == "split")
+    x = recipes.gaussian(1501 + dim, 531, dim, scale=1.5)
+    for inverse in (False, True):
+        ref_y, ref_ld = O.nsf_cl(x, sd, K, 3.0, inverse)
+        y, ld = (f.inverse if inverse else f.forward)(cuda(x))
+        assert_close(y, ref_y, 2e-5, "y")
+        assert_close(ld, ref_ld, 2e-5, "ld")
