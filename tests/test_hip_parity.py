@@ -1261,3 +1261,35 @@ def test_nsf_cl_mfma_shape_matrix(amd, O, dim, K, n_h, kernel):
         y, ld = (f.inverse if inverse else f.forward)(cuda(x))
         assert_close(y, ref_y, 2e-5, "y")
         assert_close(ld, ref_ld, 2e-5, "ld")
+
+
+@pytest.mark.parametrize("dim,K,n_h", [(64, 8, 8), (64, 5, 8), (64, 8, 16), (32, 5, 8), (32, 5, 16)])
+def test_spline_block_run_at_other_shapes(amd, dim, K, n_h):
+    """[ActNorm, Glow, NSF_CL] blocks as one launch each for the other MFMA spline shapes (d = 64; K = 5): same
+    tensors, log_det and log-prob as running the nine layers one by one."""
+    torch.manual_seed(5)
+    flows = []
+    for i in range(3):
+        a = amd.ActNormFlow(dim)
+        a.load_state_dict({"s": 0.1 * torch.randn(1, dim), "t": 0.1 * torch.randn(1, dim)}, strict=False)
+        a.data_dep_init_done = True
+        nsf = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+        nsf.load_state_dict(recipes.nsf_cl_params(1600 + dim + i, dim, K, n_h))
+        flows += [a, amd.Glow(dim), nsf]
+    model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
+    x = cuda(recipes.gaussian(1601 + dim, 700, dim))
+    with torch.no_grad():
+        for direction in ("inverse", "forward"):
+            model.fuse_affine_runs = True
+            zs_f, ld_f = getattr(model, direction)(x)
+            assert zs_f[1].data_ptr() + zs_f[1].numel() * 4 == zs_f[2].data_ptr()  # one launch, one buffer
+            model.fuse_affine_runs = False
+            zs_u, ld_u = getattr(model, direction)(x)
+            for i, (a, b) in enumerate(zip(zs_f, zs_u)):
+                assert_close(a, b, 5e-6, f"{direction} tensor {i}")
+            assert_close(ld_f, ld_u, 5e-6, f"{direction} log_det")
+        model.fuse_affine_runs = True
+        lp_f = model.log_prob(x)
+        assert model._logprob_done
+        model.fuse_affine_runs = False
+        assert_close(lp_f, model.log_prob(x), 5e-6, "log_prob")

@@ -754,9 +754,9 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
 
 // (H, NH, K) triples with an instantiated kernel
 #define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5)
-// ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (dim = 32: the
-// affine image must be one the Glow MFMA kernel supports)
-#define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8)
+// ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (the affine image must be one the Glow
+// MFMA kernel supports: dim 32 and 64 are; (32, 16, 5) is not instantiated)
+#define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)
 
 static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
   if (n_hidden != 3) return false;
