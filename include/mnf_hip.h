@@ -151,7 +151,9 @@ int mnf_pack_gather_split_batch(const float* flat, const int32_t* idx_dev, void*
                                 int64_t n_plain_words, int n_images, int64_t flat_stride, void* stream);
 
 /* ------------------------------------------------------------------------ NSF_CL */
-/* f1, f2 = MLP(dim/2, n_h, n_h, n_h, (3K-1)*dim/2); `hidden` generalises (n_h,n_h,n_h). */
+/* f1, f2 = MLP(dim/2, n_h, n_h, n_h, (3K-1)*dim/2); `hidden` generalises (n_h,n_h,n_h).
+ * MFMA kernels (image given): dim 32 or 64, K 8 or 5, three hidden layers of at most 16 units (run at 8 or 16 with
+ * structural zeros; at dim 64 with K = 5 at most 8); the generic kernel (flat) otherwise. */
 int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate,
                const float* flat, const float* image, const void* split_image,
                int64_t rows, int dim, int K, float tail_bound, int inverse,

@@ -233,7 +233,8 @@ def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
     assert len(used) == n_params and len(np.unique(used)) == n_params and (a == -2).sum() == (-dim) % 16
 
 
-@pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8), (64, 5, 8), (64, 8, 16), (32, 5, 16)])
+@pytest.mark.parametrize("dim,K,nh", [(32, 8, 8), (32, 8, 16), (32, 5, 8), (64, 8, 8), (64, 5, 8), (64, 8, 16), (32, 5, 16),
+                                       (32, 8, 12), (32, 5, 3), (64, 8, 10)])
 def test_nsf_split_index_covers_every_parameter(lib, dim, K, nh):
     from torch_mnf_amd._lib import int_array
 
@@ -243,6 +244,13 @@ def test_nsf_split_index_covers_every_parameter(lib, dim, K, nh):
     halves, plain = _split_table(lib, lib.mnf_nsf_cl_split_layout, lib.mnf_nsf_cl_split_index,
                                  (dim, K, 3, int_array([nh] * 3)))
     _check_split_table(halves, plain, n_weights, n_params)
+    # (a hidden width other than 8 / 16 runs at the next one up: the fp32 image covers every real parameter once too)
+    n = lib.mnf_nsf_cl_image_floats(dim, K, 3, int_array([nh] * 3))
+    idx = (ctypes.c_int32 * n)()
+    assert n > 0 and lib.mnf_nsf_cl_image_index(dim, K, 3, int_array([nh] * 3), idx) == 0
+    used = np.frombuffer(idx, dtype=np.int32)
+    used = used[used >= 0]
+    assert len(used) == n_params and len(np.unique(used)) == n_params
 
 
 @pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (32, 16), (64, 16)])

@@ -582,10 +582,12 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 
 // ---------------------------------------------------------------- host: image index table
 template <int H, int NH, int K>
-static void build_index(int32_t* idx) {
+static void build_index(int32_t* idx, const int* widths = nullptr) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
-  int sizes[5] = {H, NH, NH, NH, P * H};
+  // real widths of the three hidden layers (<= NH; the other units are structural zeros: LeakyReLU(0) = 0)
+  const int w[3] = {widths ? widths[0] : NH, widths ? widths[1] : NH, widths ? widths[2] : NH};
+  int sizes[5] = {H, w[0], w[1], w[2], P * H};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -598,13 +600,13 @@ static void build_index(int32_t* idx) {
     auto put = [&](int lane, int32_t src) { A[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
     for (int m = 0; m < NTH; ++m, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (unit_of(m, i) < NH) B[bt * 16 + i] = net[nn].b_off[0] + unit_of(m, i);
+        if (unit_of(m, i) < w[0]) B[bt * 16 + i] = net[nn].b_off[0] + unit_of(m, i);
     for (int c1 = 0; c1 < H / 4; ++c1) {
       const int g = c1 >> 2, e = c1 & 3;
       for (int m = 0; m < NTH; ++m) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-          if (u < NH) put(lane, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
+          if (u < w[0]) put(lane, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
         }
         ++n;
       }
@@ -612,12 +614,12 @@ static void build_index(int32_t* idx) {
     for (int l = 1; l <= 2; ++l) {
       for (int m = 0; m < NTH; ++m, ++bt)
         for (int i = 0; i < 16; ++i)
-          if (unit_of(m, i) < NH) B[bt * 16 + i] = net[nn].b_off[l] + unit_of(m, i);
+          if (unit_of(m, i) < w[l]) B[bt * 16 + i] = net[nn].b_off[l] + unit_of(m, i);
       for (int c = 0; c < QH; ++c)
         for (int m = 0; m < NTH; ++m) {
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-            if (u < NH) put(lane, net[nn].w_off[l] + u * NH + 4 * c + kq);
+            if (u < w[l] && 4 * c + kq < w[l - 1]) put(lane, net[nn].w_off[l] + u * w[l - 1] + 4 * c + kq);
           }
           ++n;
         }
@@ -635,7 +637,7 @@ static void build_index(int32_t* idx) {
         for (int kb = 0; kb < NB; ++kb) {
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, o = out_of(kb, i);
-            if (o >= 0) put(lane, net[nn].w_off[3] + o * NH + 4 * c + kq);
+            if (o >= 0 && 4 * c + kq < w[2]) put(lane, net[nn].w_off[3] + o * w[2] + 4 * c + kq);
           }
           ++n;
         }
@@ -645,10 +647,11 @@ static void build_index(int32_t* idx) {
 
 // 2 entries per split word (low half, high half), then 1 entry per plain (bias) word -- mnf_pack_gather_split
 template <int H, int NH, int K>
-static void build_split_index(int32_t* idx) {
+static void build_split_index(int32_t* idx, const int* widths = nullptr) {
   using S_ = NsfSplitShape<H, NH, K>;
   constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
-  int sizes[5] = {H, NH, NH, NH, P * H};
+  const int w[3] = {widths ? widths[0] : NH, widths ? widths[1] : NH, widths ? widths[2] : NH};  // real widths <= NH
+  int sizes[5] = {H, w[0], w[1], w[2], P * H};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -665,26 +668,26 @@ static void build_split_index(int32_t* idx) {
     };
     for (int m = 0; m < NTH; ++m, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (16 * m + i < NH) B[bt * 16 + i] = net[nn].b_off[0] + 16 * m + i;
+        if (16 * m + i < w[0]) B[bt * 16 + i] = net[nn].b_off[0] + 16 * m + i;
     for (int g = 0; g < G; ++g)
       for (int m = 0; m < NTH; ++m, ++op)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-          if (u >= NH) continue;
+          if (u >= w[0]) continue;
           for (int e = 0; e < 4; ++e) put(lane, e, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
         }
     for (int l = 1; l <= 2; ++l) {
       for (int m = 0; m < NTH; ++m, ++bt)
         for (int i = 0; i < 16; ++i)
-          if (16 * m + i < NH) B[bt * 16 + i] = net[nn].b_off[l] + 16 * m + i;
+          if (16 * m + i < w[l]) B[bt * 16 + i] = net[nn].b_off[l] + 16 * m + i;
       for (int ks = 0; ks < NTH; ++ks)
         for (int m = 0; m < NTH; ++m, ++op)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-            if (u >= NH) continue;
+            if (u >= w[l]) continue;
             for (int e = 0; e < 4; ++e) {
               const int ui = 16 * ks + 4 * kq + e;
-              if (ui < NH) put(lane, e, net[nn].w_off[l] + u * NH + ui);
+              if (ui < w[l - 1]) put(lane, e, net[nn].w_off[l] + u * w[l - 1] + ui);
             }
           }
     }
@@ -704,7 +707,7 @@ static void build_split_index(int32_t* idx) {
             if (o < 0) continue;
             for (int e = 0; e < 4; ++e) {
               const int ui = 16 * ks + 4 * kq + e;
-              if (ui < NH) put(lane, e, net[nn].w_off[3] + o * NH + ui);
+              if (ui < w[2]) put(lane, e, net[nn].w_off[3] + o * w[2] + ui);
             }
           }
     }
@@ -758,10 +761,17 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
 // MFMA kernel supports: dim 32 and 64 are; (32, 16, 5) is not instantiated)
 #define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)
 
+// three hidden layers of at most 16 units: nh = the width the kernels run them at (8 or 16; narrower layers get
+// structural-zero units)
 static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
-  if (n_hidden != 3) return false;
-  nh = hidden[0];
-  return hidden[1] == nh && hidden[2] == nh;
+  if (n_hidden != 3 || !hidden) return false;
+  int mx = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (hidden[i] < 1) return false;
+    mx = hidden[i] > mx ? hidden[i] : mx;
+  }
+  nh = mx <= 8 ? 8 : mx <= 16 ? 16 : 0;
+  return nh != 0;
 }
 
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
@@ -846,7 +856,7 @@ int mnf_nsf_cl_split_index(int dim, int K, int n_hidden, const int* hidden, int3
   if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
 #define X(HH, NHH, KK)                                     \
   if (dim == 2 * HH && nh == NHH && K == KK) {             \
-    mnf::build_split_index<HH, NHH, KK>(idx_host);         \
+    mnf::build_split_index<HH, NHH, KK>(idx_host, hidden); \
     return MNF_OK;                                         \
   }
   MNF_NSF_SHAPES(X)
@@ -870,7 +880,7 @@ int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden, int3
   if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
 #define X(HH, NHH, KK)                            \
   if (dim == 2 * HH && nh == NHH && K == KK) {    \
-    mnf::build_index<HH, NHH, KK>(idx_host);      \
+    mnf::build_index<HH, NHH, KK>(idx_host, hidden); \
     return MNF_OK;                                \
   }
   MNF_NSF_SHAPES(X)
