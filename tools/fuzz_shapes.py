@@ -1,5 +1,6 @@
 """Randomised shape fuzz: runs of 1-4 AffineHalfFlow layers (any even d <= 256, any three hidden widths <= 32, NICE /
-no-shift variants, random row counts, both directions) and RNVP layers (49 <= d <= 900, hidden <= 50) on the MFMA
+no-shift variants, random row counts, both directions), RNVP layers (49 <= d <= 900, hidden <= 50) and NSF_CL layers
+(d 32 / 64, K 5 / 8, n_h <= 16) on the MFMA
 kernels against the shape-generic kernels.  Not a pytest (minutes of GPU time); exits non-zero on a mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +48,23 @@ LD_TOL = 5e-5
 
 
 for case in range(n_cases):
-    if rng.random() < 0.75:
+    if rng.random() < 0.15:  # NSF_CL on the MFMA spline kernels: d in {32, 64}, K in {5, 8}, any n_h <= 16
+        dim, K, n_h = int(rng.choice([32, 64])), int(rng.choice([5, 8])), int(rng.integers(1, 17))
+        if dim == 64 and K == 5 and n_h > 8:
+            n_h = 8
+        rows, inverse = int(rng.integers(1, 3000)), bool(rng.integers(0, 2))
+        f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+        f.load_state_dict(recipes.nsf_cl_params(int(rng.integers(1 << 30)), dim, K, n_h))
+        f.to(dev)
+        x = torch.randn(rows, dim, device=dev) * 1.5
+        with torch.no_grad():
+            y1, l1 = f.inverse(x) if inverse else f.forward(x)
+            mfma += int(f._split_image(torch.device(dev, 0)) is not None)
+            f.force_generic = True
+            y2, l2 = f.inverse(x) if inverse else f.forward(x)
+        ok = close(y1, y2, 2e-5) and close(l1, l2, LD_TOL)
+        desc = f"nsf d={dim} K={K} n_h={n_h} rows={rows} inv={inverse}"
+    elif rng.random() < 0.75:
         dim = int(rng.integers(1, 129)) * 2
         h = tuple(int(v) for v in rng.integers(1, 33, size=3)) if rng.random() < 0.5 else (24, 24, 24)
         if dim > 128 and max(h) > 24 or dim > 128 and max(h) <= 16:
