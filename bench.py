@@ -23,7 +23,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -33,7 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achi
 WORKLOADS = {
     # name: (dim, rows per GPU, description)
     "c2": (64, 1 << 20, "9xAffineHalfFlow d=64 batch=2^20 inverse+log_prob (BASELINE configs[1])"),
-    "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3] shard)"),
+    "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3]: 2^22 rows over "
+                         "8 GPUs = this shard per GPU; at --gpus 8 the line IS configs[3])"),
     "c3": (32, 1 << 20, "3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob (BASELINE configs[2])"),
     "c2f": (64, 1 << 20, "FusedAffineStack(9xAffineHalfFlow) d=64 batch=2^20 inverse+log_prob (opt-in whole-stack "
                          "fusion: no intermediates; reported separately from c2)"),
@@ -46,7 +46,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 
 def build_c3(device):
     """3 x [ActNorm, Glow, NSF_CL(32, K=8, B=3, n_h=8)] with fixture-recipe parameters."""
-    import recipes
+    from torch_mnf_amd import synthetic as recipes
     import torch_mnf_amd as amd
 
     flows, layers = [], []
@@ -70,7 +70,7 @@ def build_c3(device):
 
 
 def build_model(dim: int, device):
-    import recipes
+    from torch_mnf_amd import synthetic as recipes
     import torch_mnf_amd as amd
 
     flows = []
@@ -84,16 +84,30 @@ def build_model(dim: int, device):
     return model, layers
 
 
-def pmc_traffic(workload: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/r1/<workload>_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 rule,
-    plus WRITE_SIZE).  None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r1", f"{workload}_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic(workload: str) -> tuple[float | None, str | None]:
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The counters cannot be
+    collected inside a timed run (rocprofv3 PMC passes serialise the kernels), so this is READ from the committed
+    PMC profile of this same command -- profiles/r<N>/<workload>_pmc_traffic.json, newest round first: FETCH_SIZE
+    doubled per the gfx950 rule, plus WRITE_SIZE -- and `traffic_source` in the JSON line says so.  (None, None)
+    when no such profile is committed."""
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()),
+                    key=lambda d: -int(d[1:])) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    for r in rounds:
+        path = os.path.join(ROOT, "profiles", r, f"{workload}_pmc_traffic.json")
+        try:
+            with open(path) as fh:
+                return json.load(fh)["traffic_bytes_per_launch"], f"committed rocprofv3 --pmc profile profiles/{r}/{workload}_pmc_traffic.json (not measured in this run)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def physical(traffic, avg_kernel_s: float) -> dict:
+    """The HBM fraction by bytes that actually cross the interface (PMC), next to the SURVEY 8(d) algorithmic one."""
+    if not traffic:
+        return {"achieved_physical": None, "frac_physical": None}
+    gbs = traffic / avg_kernel_s / 1e9
+    return {"achieved_physical": gbs, "frac_physical": gbs / HBM_PEAK_GBS}
 
 
 def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float = 12.0) -> tuple[dict, float, int]:
@@ -155,7 +169,7 @@ AHF_KERNEL = "ahf_split_kernel" if SPLIT else "ahf_mfma_kernel"
 def main_c5(args, rank, world, device, dim, rows, desc) -> None:
     """Config 5: the flow_q of MNFLinear(800, 50) on 256,000 MC rows.  A step = one sample_z call
     (prologue kernel + two seeded RNVP kernels, log-det accumulated in-kernel); fp32-MFMA bound."""
-    import recipes
+    from torch_mnf_amd import synthetic as recipes
     import torch_mnf_amd as amd
 
     layer = amd.MNFLinear(dim, 50)
@@ -194,11 +208,8 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         elapsed = time.perf_counter() - t0
         gc.enable()
         events, layer.flow_q.layer_events = layer.flow_q.layer_events, None
-    t = torch.tensor([elapsed], dtype=torch.float64,
-                     device=device if os.environ.get("MNF_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    backend = os.environ.get("MNF_BENCH_BACKEND", "nccl")
+    elapsed, per_rank_s = rank_times(elapsed, world, device, backend)
     if rank == 0:
         kern_ms = [a.elapsed_time(b) for a, b, *_ in events]
         avg_s = sum(kern_ms) / len(kern_ms) / 1e3
@@ -209,7 +220,8 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "hidden": [50], "mask": "in-kernel (seeded)",
-                       "primed_ms": args.prime_ms, "arithmetic": ARITHMETIC},
+                       "primed_ms": args.prime_ms, "arithmetic": ARITHMETIC, "total_rows": world * rows},
+            "distributed": dist_info(world, backend, per_rank_s, args.steps),
         }
         # Algorithmic bytes per row with the in-kernel mask: read z (4d), write x (4d), log_det RMW (8).  The
         # kernel reads z a second time for the gate epilogue (it cannot stay on chip: 410 KB per 128-row
@@ -217,8 +229,10 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         algo_bytes = (8 * dim + 8) * rows
         if SPLIT:  # memory-path bound (tools ablations: no MFMAs -> same time), priced against HBM
             gbs = algo_bytes / avg_s / 1e9
+            traffic, source = pmc_traffic("c5")
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("c5"),
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                               **physical(traffic, avg_s),
                                "kernel": "rnvp_split_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
                                "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(kern_ms),
                                "kernel_GBps_incl_second_z_read": (12 * dim + 8) * rows / avg_s / 1e9,
@@ -258,6 +272,44 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         dist.destroy_process_group()
 
 
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without torchrun: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process
+    (one rank per GPU) and return its exit code.  Called before anything in this process touches the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_times(elapsed: float, world: int, device, backend: str) -> tuple[float, list[float]]:
+    """(max over ranks, every rank's own time) of the timed region."""
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world == 1:
+        return elapsed, [elapsed]
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    per_rank = [float(e.item()) for e in every]
+    return max(per_rank), per_rank
+
+
+def dist_info(world: int, backend: str, per_rank_s: list[float], steps: int) -> dict:
+    """What the N > 1 line says about the ranks behind it (size of the process group the all-reduce ran on, the
+    backend -- "nccl" is RCCL on ROCm --, every rank's own ms per step; `value` uses the slowest)."""
+    return {"rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else (1 if world == 1 else 0)),
+            "ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": backend if world > 1 else None,
+            "ms_per_step_per_rank": [round(t / steps * 1e3, 4) for t in per_rank_s]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,12 +322,16 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # No launcher around us: start the N ranks ourselves, as CHILD processes, before this process has
+        # made any GPU call (a process that has initialised the GPU must never be replaced by another
+        # program); rank 0's JSON line reaches our stdout through the launcher, its exit code becomes ours.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     # Self-test switches (not used by the driver): MNF_BENCH_BACKEND=gloo + MNF_BENCH_SHARE_GPU=1 run
@@ -417,10 +473,7 @@ def main() -> None:
         fwd_rate = rows * max(1, args.steps // 2) / (time.perf_counter() - t1)
         del xs_fwd
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, per_rank_s = rank_times(elapsed, world, device, backend)
     gpu_mean = float(mean.item())
 
     if rank == 0:
@@ -443,6 +496,9 @@ def main() -> None:
         algo_bytes = (8 * dim + 8) * rows * span_dom
         n_fused = 9 if args.workload == "c2f" else span_dom  # layers per launch (flop accounting)
         achieved = algo_bytes / avg_kernel_s / 1e9
+        # (the committed PMC passes are of the default path; the layer-by-layer c2 kernel has its own file)
+        traffic, traffic_source = pmc_traffic("c2_layer_by_layer" if args.workload == "c2" and span_dom == 1
+                                              else args.workload)
         out = {
             "metric": "samples/s, 9xRNVP(AffineHalfFlow) d=64 batch=2^20 inverse+log-prob" if args.workload == "c2"
             else f"samples/s, {desc}",
@@ -460,15 +516,21 @@ def main() -> None:
             "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": n_layers,
                        "hidden": [8, 8, 8] if args.workload in ("c3", "c3f") else [24, 24, 24],
                        "intermediates": "all kept (reference API)", "primed_ms": args.prime_ms,
-                       "primed_steps": primed, "arithmetic": ARITHMETIC},
+                       "primed_steps": primed, "arithmetic": ARITHMETIC, "total_rows": world * rows},
+            "distributed": dist_info(world, backend, per_rank_s, args.steps),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # (the committed PMC passes are of the default path; the layer-by-layer c2 kernel has its own file)
-                "traffic": pmc_traffic("c2_layer_by_layer" if args.workload == "c2" and span_dom == 1 else args.workload),
+                # `achieved` / `frac` price the launch at SURVEY 8(d)'s ALGORITHMIC bytes: (8d + 8) per row per LAYER,
+                # times the layers one launch covers.  A fused run moves fewer bytes than that (every intermediate is
+                # written once, none is re-read): `traffic` (PMC) and `frac_physical` say what crosses the HBM
+                # interface, so `frac` can exceed the physical utilisation -- never mix the two.
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                **physical(traffic, avg_kernel_s),
                 "kernel": ("nsf_mfma_kernel<16,8,8,inverse,block> ([NSF_CL, Glow, ActNorm] inverse in one launch, both "
                            "intermediates written)" if args.workload == "c3" and span_dom > 1 else
                            "nsf_mfma_kernel<16,8,8,inverse>" if args.workload == "c3" else "fused actnorm+glow+nsf_cl kernel (inverse)"

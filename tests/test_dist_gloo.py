@@ -79,3 +79,24 @@ def test_shard_bounds_cover_rows_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_spawns_its_ranks_as_child_processes():
+    """`python bench.py --gpus 2` with no launcher: the parent must start the ranks itself (torch.distributed.run as
+    a child process, before any GPU call) and pass the ranks' failure on as its own exit code.  On this CPU-only
+    container every rank stops at "needs an MI355X" -- that message next to the launcher's per-rank failure report
+    proves the ranks were started by torch.distributed.run (the launcher ends the other rank as soon as one has
+    failed); the full run is the -m gpu test tests/test_hip_round2.py::test_bench_starts_its_own_ranks."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("CPU-container check; the GPU box runs the real thing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("needs an MI355X") >= 1 and "local_rank" in out.stderr, out.stderr[-1500:]

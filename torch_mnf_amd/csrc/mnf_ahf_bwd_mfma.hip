@@ -472,20 +472,15 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
                       hipStream_t stream) {
   using S = BwdShape<H, HID>;
   constexpr size_t lds_bytes = S::LDS_FLOATS * sizeof(float);
-  static const int cus = [] {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      return prop.multiProcessorCount;
-    return 256;
-  }();
-  static const bool attr_ok = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  }();
-  if (!attr_ok) return MNF_ERR_UNSUPPORTED;
+  static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
+  const int cus = memo.get([](int dev) {
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+    return ok ? device_cus(dev) : -1;
+  });
+  if (cus <= 0) return MNF_ERR_UNSUPPORTED;
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)

@@ -395,17 +395,11 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
   int64_t blocks = (n_tiles + kAhfWaves - 1) / kAhfWaves;
   // persistent grid: as many workgroups as are resident at once (registers and the LDS image
   // bound it), each striding over the tiles
-  static int cus = 256;
-  static const int resident = [] {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, ahf_mfma_kernel<H, HID, true, kPrefetch>, kAhfWaves * 64, 0) != hipSuccess || per_cu < 1)
-      per_cu = 4;
-    return per_cu * cus;
-  }();
+  static DeviceMemo memo;
+  const int resident = memo.get([](int dev) {
+    return resident_by_occupancy(ahf_mfma_kernel<H, HID, true, kPrefetch>, kAhfWaves * 64, dev, 4);
+  });
+  const int cus = device_cus(current_device());
   blocks = balanced_grid(n_tiles, kAhfWaves, resident, cus);
   // Non-temporal loads/stores (MNF_AHF_NT=1) are an experiment switch, off by default: in the
   // isolated microbench they gain 5 % at d = 64, but inside the 9-layer pass (each layer re-reads

@@ -506,23 +506,14 @@ static void build_split_index(int32_t* idx, int h, bool has_s = true, bool has_t
         if (16 * g + i < h && has[nn]) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
-template <typename K>
-static int resident_blocks(K kernel, int& cus) {
-  int per_cu = 0, dev = 0;
-  cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kSplitWaves * 64, 0) != hipSuccess || per_cu < 1)
-    per_cu = 1;
-  return per_cu * cus;
-}
-
 template <int H, int HID>
 static int launch_split(const float* x, float* y, float* log_det, float* ysq, int accumulate, const uint32_t* simage,
                         const float* image, int64_t rows, int parity, int inverse, hipStream_t stream) {
-  static int cus = 256;
-  static const int resident = resident_blocks(ahf_split_kernel<H, HID, true>, cus);
+  static DeviceMemo memo;
+  const int resident = memo.get([](int dev) {
+    return resident_by_occupancy(ahf_split_kernel<H, HID, true>, kSplitWaves * 64, dev, 1);
+  });
+  const int cus = device_cus(current_device());
   const int64_t n_tiles = (rows + 15) / 16;
   const dim3 grid((unsigned)balanced_grid(n_tiles, kSplitWaves, resident, cus)), block(kSplitWaves * 64);
   if (inverse)
@@ -544,28 +535,20 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   constexpr size_t lds_bytes = image_bytes <= 64 * 1024 ? 0 : image_bytes;  // dynamic part (see the kernel)
   // per device (the dynamic-LDS attribute is a per-device setting of the function; a process may drive several GPUs):
   // 0 = not set up yet, -1 = the attribute could not be set, else the number of resident workgroups
-  static int resident_of_device[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (resident_of_device[dev] == 0) {  // (idempotent: two threads racing here compute the same value)
-    int per_cu = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  static DeviceMemo memo;
+  const int resident = memo.get([](int dev) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, true, RAG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_split_stack_kernel<H, HID, false, RAG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-      resident_of_device[dev] = -1;
-    } else {
-      // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
-      // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
-      per_cu = 4 * stack_waves_per_simd<H>() / kStackWaves;
-      while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
-      resident_of_device[dev] = per_cu * cus;
-    }
-  }
-  const int resident = resident_of_device[dev] > 0 ? resident_of_device[dev] : 0;
-  if (resident == 0) return MNF_ERR_UNSUPPORTED;
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return -1;
+    // two waves per SIMD by registers (launch bounds), i.e. 8 waves per CU; the double-buffered image fits twice
+    // for d <= 64 (the occupancy query under-reports kernels with dynamic LDS, so this is computed here)
+    int per_cu = 4 * stack_waves_per_simd<H>() / kStackWaves;
+    while (per_cu > 1 && per_cu * image_bytes > 160 * 1024) --per_cu;
+    return per_cu * device_cus(dev);
+  });
+  if (resident <= 0) return MNF_ERR_UNSUPPORTED;
   constexpr int GROUP_ROWS = 16 * kStackTiles * kStackWaves;
   const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
   const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);

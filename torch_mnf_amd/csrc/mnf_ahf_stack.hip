@@ -125,16 +125,10 @@ static int launch_stack(const float* x, float* y, float* mid, float* log_det, fl
                         const float* images,
                         uint32_t parity_bits, int n_layers, int64_t rows, int inverse, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kStackWaves - 1) / (16 * kStackWaves);
-  static const int resident = [] {
-    int per_cu = 0, cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ahf_stack_kernel<H, HID, true>, kStackWaves * 64, 0) !=
-            hipSuccess || per_cu < 1)
-      per_cu = 1;
-    return per_cu * cus;
-  }();
+  static DeviceMemo memo;
+  const int resident = memo.get([](int dev) {
+    return resident_by_occupancy(ahf_stack_kernel<H, HID, true>, kStackWaves * 64, dev, 1);
+  });
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   const dim3 grid((unsigned)blocks), block(kStackWaves * 64);
   if (inverse)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "mnf_device.h"
 
 namespace mnf {
@@ -28,6 +30,48 @@ inline int ahf_padded_hidden(int n_hidden, const int* hidden) {
   return mx <= 16 ? 16 : mx <= 24 ? 24 : mx <= 32 ? 32 : 0;
 }
 inline int ahf_padded_half(int h) { return h < 1 ? 0 : h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : h <= 128 ? 128 : 0; }
+
+// Launch parameters that depend on the device (CU count, occupancy, "dynamic-LDS attribute set") are cached PER
+// DEVICE: a process may drive several GPUs, and hipFuncSetAttribute is a per-device setting of the function.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+inline int device_cus(int dev) {
+  static std::atomic<int> cus[kMaxDevices];
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    v = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+// One non-zero int per device, computed on first use on that device by `compute(dev)` (idempotent: two threads racing
+// here compute the same value).  Every call site owns one static DeviceMemo.
+struct DeviceMemo {
+  std::atomic<int> v[kMaxDevices];
+  template <typename F>
+  int get(F compute) {
+    const int dev = current_device();
+    int r = v[dev].load(std::memory_order_relaxed);
+    if (r == 0) {
+      r = compute(dev);
+      v[dev].store(r, std::memory_order_relaxed);
+    }
+    return r;
+  }
+};
+// resident workgroups of `kernel` on device `dev` by the occupancy query (`fallback` per CU if it fails)
+template <typename K>
+inline int resident_by_occupancy(K kernel, int threads, int dev, int fallback) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1)
+    per_cu = fallback;
+  return per_cu * device_cus(dev);
+}
 
 // Persistent-grid sizing: among grids of whole workgroups-per-CU steps between resident/2 and
 // resident, pick the one whose static tile striding wastes the fewest wave-rounds

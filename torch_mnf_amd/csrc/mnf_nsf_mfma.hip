@@ -722,19 +722,15 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
                   double* log_prob_sum = nullptr) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
-  auto resident_of = [](auto kernel) {
-    int per_cu = 0, cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kNsfWaves * 64, 0) != hipSuccess || per_cu < 1)
-      per_cu = 2;
-    if (const char* e = getenv("MNF_NSF_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // experiment switch
-    return per_cu * cus;
+  auto resident_of = [](auto kernel, int dev) {
+    if (const char* e = getenv("MNF_NSF_BLOCKS_PER_CU"))  // experiment switch
+      if (atoi(e) > 0) return atoi(e) * device_cus(dev);
+    return resident_by_occupancy(kernel, kNsfWaves * 64, dev, 2);
   };
-  static const int resident_f32 = resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>);
-  static const int resident_split = resident_of(nsf_mfma_kernel<H, NH, K, true, 2, true>);
-  const int resident = simage ? resident_split : resident_f32;
+  static DeviceMemo memo_f32, memo_split;
+  const int resident =
+      simage ? memo_split.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, true>, dev); })
+             : memo_f32.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>, dev); });
   if (blocks > resident) blocks = resident;
   const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
 #define MNF_NSF_LAUNCH(INVV, AFFV, SPL)                                                                          \

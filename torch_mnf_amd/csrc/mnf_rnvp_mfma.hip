@@ -691,17 +691,11 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
                              const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
-  auto resident_of = [](auto kernel) {
-    int per_cu = 0, cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRnvpWaves * 64, 0) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    return per_cu * cus;
-  };
-  static const int resident_mask = resident_of(rnvp_split_kernel<HN, false, RAG>);
-  static const int resident_seed = resident_of(rnvp_split_kernel<HN, true, RAG>);
+  static DeviceMemo memo_mask, memo_seed;
+  const int resident_mask = memo_mask.get(
+      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, false, RAG>, kRnvpWaves * 64, dev, 1); });
+  const int resident_seed = memo_seed.get(
+      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, true, RAG>, kRnvpWaves * 64, dev, 1); });
   // experiment switch: MNF_RNVP_BLOCKS_PER_CU=n caps the persistent grid at n workgroups per CU
   static const int cap = [] { const char* e = getenv("MNF_RNVP_BLOCKS_PER_CU"); return e ? atoi(e) * 256 : 1 << 30; }();
   const int resident0 = mask ? resident_mask : resident_seed;
@@ -774,17 +768,11 @@ template <int HN, bool RAG>
 static int launch_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                        const float* image, int64_t rows, int dim, uint64_t seed, int dm, int vec, hipStream_t stream) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
-  auto resident_of = [](auto kernel) {
-    int per_cu = 0, cus = 256, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRnvpWaves * 64, 0) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    return per_cu * cus;
-  };
-  static const int resident_mask = resident_of(rnvp_mfma_kernel<HN, false, RAG>);
-  static const int resident_seed = resident_of(rnvp_mfma_kernel<HN, true, RAG>);
+  static DeviceMemo memo_mask, memo_seed;
+  const int resident_mask = memo_mask.get(
+      [](int dev) { return resident_by_occupancy(rnvp_mfma_kernel<HN, false, RAG>, kRnvpWaves * 64, dev, 1); });
+  const int resident_seed = memo_seed.get(
+      [](int dev) { return resident_by_occupancy(rnvp_mfma_kernel<HN, true, RAG>, kRnvpWaves * 64, dev, 1); });
   const int resident = mask ? resident_mask : resident_seed;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)

@@ -59,6 +59,18 @@ class MLP(nn.Sequential):
         self.layer_sizes = tuple(int(s) for s in layer_sizes)
 
 
+def _require_mlp(*nets: nn.Module) -> None:
+    """The kernels evaluate the conditioner themselves: Linear / LeakyReLU(0.2) chains (the reference's MLP with its
+    default slope, models/mlp.py:4-12).  Any other conditioner class or slope cannot run on them -- say so instead of
+    packing a parameter buffer of the wrong shape."""
+    for net in nets:
+        acts = [m for m in net.modules() if isinstance(m, nn.LeakyReLU)] if isinstance(net, nn.Module) else []
+        if not isinstance(net, MLP) or any(abs(a.negative_slope - 0.2) > 1e-12 for a in acts):
+            raise NotImplementedError(
+                "torch_mnf_amd kernels implement the reference's MLP conditioner with LeakyReLU(0.2) only; "
+                f"got {type(net).__name__}" + (f" with slopes {[a.negative_slope for a in acts]}" if acts else ""))
+
+
 def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -322,6 +334,19 @@ class _HipFlow(nn.Module):
         self.force_generic = False  # tests: run the generic kernel even if an MFMA one exists
         self.force_fp32_mfma = False  # tests / MNF_FP32_MFMA=1: fp32 MFMA kernel instead of the split one
 
+    def invalidate(self) -> None:
+        """Drop the packed operand images; the next call repacks them from the parameters.
+
+        The caches are keyed on every parameter's ``(data_ptr, _version)``, which optimizers, ``load_state_dict``,
+        ``copy_`` and every other in-place op on the parameter itself bump.  Writes THROUGH ``p.data``
+        (``p.data.clamp_()``, ``p.data.copy_()`` -- weight clipping, EMA, some init code) do not bump the
+        parameter's version counter, so after such a write call ``invalidate()`` (on the layer, or on the
+        ``NormalizingFlow`` for all of its layers), or write with ``torch.no_grad(): p.clamp_()`` instead."""
+        self._cache_key = None
+        for attr in ("_w_key", ):
+            if hasattr(self, attr):
+                setattr(self, attr, None)
+
     # subclasses: ordered parameter list == state_dict order
     def _packed_params(self) -> list[Tensor]:
         return [p for p in self.parameters()]
@@ -527,7 +552,8 @@ class NSF_CL(_TwoWayFlow):
         self.dim, self.K, self.B = int(dim), int(K), B
         self.f1 = net_class(dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2)
         self.f2 = net_class(dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2)
-        sizes = getattr(self.f1, "layer_sizes", (dim // 2, n_h, n_h, n_h, (3 * K - 1) * dim // 2))
+        _require_mlp(self.f1, self.f2)
+        sizes = self.f1.layer_sizes
         self.h_sizes = tuple(int(s) for s in sizes[1:-1])
         self._hid = _lib.int_array(self.h_sizes)
 
@@ -954,6 +980,10 @@ class FusedSplineBlock(_TwoWayFlow):
     def _packed_params(self) -> list[Tensor]:
         return []
 
+    def invalidate(self) -> None:
+        super().invalidate()
+        self._run_helper._aff_key = None
+
     def _sequence(self, x: Tensor, inverse: bool):
         order = (self.nsf, self.glow, self.actnorm) if inverse else (self.actnorm, self.glow, self.nsf)
         ld = 0
@@ -982,8 +1012,12 @@ class _AffineRun:
     """Consecutive ``AffineHalfFlow`` layers of one shape, in MODEL order, as one ``mnf_affine_half_stack``
     launch.  A plain object (not a Module): it only caches the concatenated operand images."""
 
+    MAX_LAYERS = 32  # mnf_affine_half_stack takes the layers' parities as one 32-bit word
+
     def __init__(self, layers: Sequence["AffineHalfFlow"]) -> None:
         self.layers = list(layers)
+        if len(self.layers) > self.MAX_LAYERS:
+            raise ValueError(f"one stack launch covers at most {self.MAX_LAYERS} layers")
         self._key = None
         self._images: Tensor | None = None
         self._splits: Tensor | None = None
@@ -1126,10 +1160,17 @@ class FusedAffineStack(_TwoWayFlow):
             raise ValueError("all layers must share dim, h_sizes and the scale/shift flags")
         self.layers = nn.ModuleList(layers)
         self.dim = f0.dim
-        self.__dict__["_run_helper"] = _AffineRun(layers)  # not a Module: keep it out of the module tree
+        # not Modules: keep them out of the module tree.  One launch per chunk of at most 32 layers.
+        m = _AffineRun.MAX_LAYERS
+        self.__dict__["_run_helpers"] = [_AffineRun(layers[k:k + m]) for k in range(0, len(layers), m)]
 
     def _packed_params(self) -> list[Tensor]:
         return []
+
+    def invalidate(self) -> None:
+        super().invalidate()
+        for r in self._run_helpers:
+            r._key = None
 
     def _sequence(self, x, inverse, sqnorm=None):
         ld = 0
@@ -1140,16 +1181,22 @@ class FusedAffineStack(_TwoWayFlow):
         return x, ld
 
     def emits_sqnorm(self, device) -> bool:
-        return self._run_helper.images(device)[0] is not None
+        return all(r.images(device)[0] is not None for r in self._run_helpers)
 
     def _run(self, x, inverse, accum, sqnorm: Tensor | None = None, overwrite: bool = False):
-        run = self._run_helper
-        imgs = run.ready(x)
-        if imgs is not None:
+        runs = list(reversed(self._run_helpers)) if inverse else list(self._run_helpers)
+        imgs = [r.ready(x) for r in runs]
+        if all(i is not None for i in imgs):
             ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-            out = run.launch(x, inverse, ld, accum is not None and not overwrite, sqnorm, keep=False, images=imgs)
-            if out is not None:
-                return out[-1], (None if accum is not None else ld)
+            y, done = x, 0
+            for k, (run, im) in enumerate(zip(runs, imgs)):
+                out = run.launch(y, inverse, ld, k > 0 or (accum is not None and not overwrite),
+                                 sqnorm if k == len(runs) - 1 else None, keep=False, images=im)
+                if out is None:
+                    break
+                y, done = out[-1], k + 1
+            if done == len(runs):
+                return y, (None if accum is not None else ld)
         elif isinstance(x, Tensor) and x.dim() == 2 and x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
         y, ld = self._sequence(x, inverse, sqnorm)
@@ -1178,6 +1225,13 @@ class NormalizingFlow(nn.Module):
         self.fuse_affine_runs = True
         self._last_sqnorm: Tensor | None = None
 
+    def invalidate(self) -> None:
+        """Drop every layer's packed operand images and the fused runs' (see ``_HipFlow.invalidate``)."""
+        for f in self.modules():
+            if f is not self and hasattr(f, "invalidate"):
+                f.invalidate()
+        self.__dict__.pop("_runs_cache", None)
+
     def _affine_runs(self) -> dict:
         """start index (model order) -> run object for every group of layers that goes out as one launch:
         maximal runs of >= 2 consecutive AffineHalfFlow layers of one shape (_AffineRun) and
@@ -1191,8 +1245,10 @@ class NormalizingFlow(nn.Module):
                 if type(flows[i]) is AffineHalfFlow:
                     while j < len(flows) and type(flows[j]) is AffineHalfFlow and _AffineRun.compatible(flows[i], flows[j]):
                         j += 1
-                    if j - i >= 2:
-                        runs[i] = _AffineRun(flows[i:j])
+                    # (one launch covers at most _AffineRun.MAX_LAYERS layers: longer runs go out in chunks)
+                    for k in range(i, j, _AffineRun.MAX_LAYERS):
+                        if min(j, k + _AffineRun.MAX_LAYERS) - k >= 2:
+                            runs[k] = _AffineRun(flows[k:min(j, k + _AffineRun.MAX_LAYERS)])
                 elif (i + 2 < len(flows) and type(flows[i]) is ActNormFlow and type(flows[i + 1]) is Glow
                       and type(flows[i + 2]) is NSF_CL and flows[i].dim == flows[i + 1].dim == flows[i + 2].dim):
                     runs[i] = _SplineBlockRun(flows[i], flows[i + 1], flows[i + 2])

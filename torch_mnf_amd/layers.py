@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib
-from .flows import RNVP, NormalizingFlow, _stream
+from .flows import RNVP, NormalizingFlow, _stream, _wants_grad
 
 
 class MNFLinear(nn.Module):
@@ -40,8 +40,10 @@ class MNFLinear(nn.Module):
         self.fuse_prologue = True  # sample_z: form z0 inside the first flow's kernel when that kernel exists
 
     def _fused_prologue_ok(self, flow, eps) -> bool:
-        """The first flow's split MFMA kernel can form z0 in its loads (49 <= d <= 1024, h in {30, 50})."""
-        if self.fuse_prologue is False or torch.is_grad_enabled() and any(p.requires_grad for p in flow.parameters()):
+        """The first flow's split MFMA kernel can form z0 in its loads (49 <= d <= 1024, h in {30, 50}).  Inference
+        only: when any flow_q layer wants gradients the pass goes through the layers' autograd functions."""
+        if self.fuse_prologue is False or (torch.is_grad_enabled()
+                                           and any(p.requires_grad for p in self.flow_q.parameters())):
             return False
         return (not flow.force_generic and self.n_in <= 1024 and flow._packed(eps.device)[1] is not None
                 and flow._split_image(eps.device) is not None)
@@ -56,6 +58,8 @@ class MNFLinear(nn.Module):
         eps = eps.to(dev, torch.float32).contiguous()
         training = torch.is_grad_enabled() and (self.q0_mean.requires_grad or self.q0_log_var.requires_grad)
         flows = list(self.flow_q.flows)
+        if masks is not None and len(masks) != len(flows):
+            raise ValueError(f"sample_z got {len(masks)} masks for {len(flows)} flow_q layers")
         if (not training and eps.shape[0] > 0 and flows and isinstance(flows[0], RNVP)
                 and self._fused_prologue_ok(flows[0], eps)):
             # the prologue z0 = q0_mean + q0_std eps is formed inside the first flow's kernel: z0 is never stored
@@ -85,7 +89,7 @@ class MNFLinear(nn.Module):
             log_det = torch.zeros(z0.shape[0], device=dev)
             zs = [z0]
             for flow, m in zip(self.flow_q.flows, masks):
-                if torch.is_grad_enabled() and z0.requires_grad:
+                if _wants_grad(flow, zs[-1]):  # autograd path: flow_q gradients from the *_bwd kernels
                     z, ld = flow._run(zs[-1], False, None, m)
                     log_det = log_det + ld
                 else:
