@@ -116,4 +116,10 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
                      const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean = nullptr,
                      const float* q0_log_var = nullptr);
 
+// the register-resident kernel (mnf_rnvp_resident.hip): in-kernel mask only, selected shapes; MNF_ERR_UNSUPPORTED
+// sends the caller on to the streaming kernels
+int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
+                         const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
+                         const float* q0_log_var, int vec, hipStream_t stream);
+
 }  // namespace mnf

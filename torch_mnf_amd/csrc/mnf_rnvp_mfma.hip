@@ -23,250 +23,9 @@
 #include "mnf_device.h"
 #include "mnf_host.h"
 #include "mnf_split.h"
+#include "mnf_rnvp_common.h"
 
 namespace mnf {
-
-constexpr int kRnvpWaves = 8;    // 512-thread workgroups: 128 rows share every staged operand chunk
-constexpr int kRnvpChunkK = 16;  // GEMM-1 K-steps per chunk (64 dims): 16 x 4 tiles x 256 B = 16 KiB
-constexpr int kRnvpChunkM = 2;   // GEMM-2 output tiles per chunk
-
-template <int HN>
-struct RnvpShape {
-  static constexpr int KQ = (HN + 3) / 4;       // K-steps of GEMM 2 (quads of y units)
-  static constexpr int YT = (KQ + 3) / 4;       // 16-row tiles of y
-  static_assert(YT >= 1 && YT <= 4, "GEMM-1 operand groups hold up to four y tiles (hidden width <= 64)");
-  static constexpr int G2 = (2 * KQ + 3) / 4;   // operand groups (of 4 MFMAs) per GEMM-2 output tile
-  static constexpr int TILE2_FLOATS = G2 * 256 + 32;  // operands, then the tile's t and s biases (16 + 16)
-  static constexpr int64_t part1_floats(int d) { return (int64_t)(d / 4) * 256; }         // one group per K-step
-  static constexpr int64_t part2_floats(int d) { return (int64_t)(d / 16) * TILE2_FLOATS; }
-  static constexpr int64_t bias_floats(int) { return YT * 16; }
-  static constexpr int64_t image_floats(int d) { return part1_floats(d) + part2_floats(d) + bias_floats(d); }
-  static constexpr int CHUNK_FLOATS =
-      (kRnvpChunkK * 256 > kRnvpChunkM * TILE2_FLOATS ? kRnvpChunkK * 256 : kRnvpChunkM * TILE2_FLOATS);
-  static constexpr int STAGE_F4 = (CHUNK_FLOATS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);  // float4 per thread
-};
-
-// Ragged rows (RAG): the row in memory is `dm` floats wide, the kernels work on d = dm rounded up to a multiple of
-// 16 -- the operand images are zero in the padded columns (and carry kPackBigBias as the padded scale bias, so
-// gate = 1 and log gate = 0 there: nothing reaches log_det).  Loads return 0 past the row end, stores skip it;
-// `vec`: dm % 4 == 0 and 16-byte aligned bases keep the 16-byte access, else element by element.
-// (`rowq` = row start + 4 q, the lane's own float4 column inside a 16-dim group; `col` = 16 g; `q4` = 4 q)
-template <bool RAG>
-__device__ __forceinline__ f32x4 row_load4(const float* rowq, int col, int q4, int dm, bool vec) {
-  if (!RAG) return *reinterpret_cast<const f32x4*>(rowq + col);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (vec) {
-    if (col + q4 < dm) v = *reinterpret_cast<const f32x4*>(rowq + col);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float e = 0.f;
-      if (col + q4 + r < dm) e = rowq[col + r];
-      v[r] = e;
-    }
-  }
-  return v;
-}
-template <bool RAG>
-__device__ __forceinline__ void row_store4(float* rowq, int col, int q4, int dm, bool vec, const f32x4& v) {
-  if (!RAG) {
-    *reinterpret_cast<f32x4*>(rowq + col) = v;
-  } else if (vec) {
-    if (col + q4 < dm) *reinterpret_cast<f32x4*>(rowq + col) = v;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (col + q4 + r < dm) rowq[col + r] = v[r];
-  }
-}
-
-// 1/(1+exp(-v)) with the 6-instruction exp of the AffineHalfFlow kernel
-__device__ __forceinline__ float exp6r(float x) {
-  const float c_hi = 1.44269502162933349609375f, c_lo = 1.925963033500011e-08f, ln2 = 0.693147182464599609375f;
-  const float t = x * c_hi;
-  const float err = __builtin_fmaf(x, c_hi, -t);
-  const float tl = __builtin_fmaf(x, c_lo, err);
-  return __builtin_amdgcn_exp2f(t) * __builtin_fmaf(tl, ln2, 1.0f);
-}
-
-// The operand image is streamed through a double-buffered LDS window.  Per chunk c every thread
-//   1. requests the rows' z (and mask) values chunk c+1 will need and its share of chunk c+1's
-//      operands into registers,
-//   2. computes chunk c out of LDS buffer c&1 with the z values requested one chunk earlier,
-//   3. writes the staged operands into buffer (c+1)&1 and meets the others at ONE barrier.
-// So neither HBM/L2 latency (rows, operands) nor the LDS fill is on the MFMA chain's critical path.
-// SEEDED: the mask is regenerated from (seed, row, dim) wherever it is needed instead of being
-// read -- 8d fewer bytes per row (a float mask is otherwise read twice).
-template <int HN, bool SEEDED, bool RAG = false>
-__device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CHUNK_FLOATS], int grp,
-                                               const float* __restrict__ z, const float* __restrict__ mask,
-                                               float* __restrict__ x, float* __restrict__ log_det,
-                                               const float* __restrict__ image, int64_t rows, int d, int accumulate,
-                                               uint64_t seed, const float* zprm = nullptr, int dm_ragged = 0,
-                                               bool vec = true) {
-  const int dm = RAG ? dm_ragged : d;  // row width in memory
-  using S = RnvpShape<HN>;
-  constexpr int KQ = S::KQ, YT = S::YT, KC = kRnvpChunkK, MC = kRnvpChunkM;
-  constexpr int NROW = (KC / 4 > MC ? KC / 4 : MC);  // float4 row loads per chunk
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int n_k = d / 4;    // GEMM-1 K-steps
-  const int n_m = d / 16;   // GEMM-2 output tiles
-  const int nc1 = (n_k + KC - 1) / KC, nc2 = (n_m + MC - 1) / MC, nc = nc1 + nc2;
-  const float* img1 = image;
-  const float* img2 = image + S::part1_floats(d);
-  const float* bias_y = img2 + S::part2_floats(d);
-
-  // operands of chunk c: source and number of float4s
-  auto chunk_src = [&](int c, int& n4) -> const float4* {
-    if (c < nc1) {
-      n4 = min(KC, n_k - c * KC) * 64;
-      return reinterpret_cast<const float4*>(img1 + (int64_t)c * KC * 256);
-    }
-    const int m0 = (c - nc1) * MC;
-    n4 = min(MC, n_m - m0) * (S::TILE2_FLOATS / 4);
-    return reinterpret_cast<const float4*>(img2 + (int64_t)m0 * S::TILE2_FLOATS);
-  };
-  // first dim of the i-th float4 of row data chunk c needs (clamped inside the row)
-  auto row_dim = [&](int c, int i) -> int {
-    const int dim0 = (c < nc1) ? (c * KC + 4 * i) * 4 : 16 * ((c - nc1) * MC + i);
-    return dim0 < d ? dim0 : 0;
-  };
-
-  {
-    const int64_t row = (int64_t)grp * (16 * kRnvpWaves) + wave * 16 + j;
-    const bool live = row < rows;
-    const int64_t rowc = live ? row : rows - 1;
-    const float* zr = z + rowc * dm + 4 * q;
-    const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
-    float* xr = x + rowc * dm + 4 * q;
-    // zprm: the sample_z prologue fused into the loads, z = q0_mean + q0_std * eps (mnf_linear.py:59-62)
-    auto load_z = [&](int dim0) -> f32x4 {
-      const f32x4 v = row_load4<RAG>(zr, dim0, 4 * q, dm, vec);
-      if (zprm == nullptr) return v;
-      return v * *reinterpret_cast<const f32x4*>(zprm + d + dim0 + 4 * q) +
-             *reinterpret_cast<const f32x4*>(zprm + dim0 + 4 * q);
-    };
-    auto mask4 = [&](int dim0) -> f32x4 {  // four consecutive dims share one 32-bit mask word
-      if (!SEEDED) return row_load4<RAG>(mr, dim0, 4 * q, dm, vec);
-      const int dd = dim0 + 4 * q;
-      const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
-      return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
-    };
-
-    f32x4 zc[NROW], mc[NROW], zn[NROW], mn[NROW];
-    float4 st[S::STAGE_F4];
-    // prologue: rows + operands of chunk 0 (the only exposed latency of the group)
-    __syncthreads();  // the previous group's last chunk is fully consumed
-    {
-      int n4;
-      const float4* src = chunk_src(0, n4);
-#pragma unroll
-      for (int i = 0; i < NROW; ++i) {
-        zc[i] = load_z(row_dim(0, i));
-        mc[i] = mask4(row_dim(0, i));
-      }
-#pragma unroll
-      for (int i = 0; i < S::STAGE_F4; ++i) {
-        const int k = threadIdx.x + i * (kRnvpWaves * 64);
-        if (k < n4) reinterpret_cast<float4*>(lds[0])[k] = src[k];
-      }
-    }
-    __syncthreads();
-
-    f32x4 yacc[YT];
-#pragma unroll
-    for (int m = 0; m < YT; ++m) yacc[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
-    float ld = 0.f;
-
-    for (int c = 0; c < nc; ++c) {
-      // 1. request what chunk c+1 needs.  Branch-free on purpose: after the last chunk the same
-      //    chunk is simply requested again (a conditional here makes hipcc park st[] in scratch
-      //    behind a vmcnt wait, which serialises the prefetch).
-      const int cn = c + 1 < nc ? c + 1 : c;
-      int n4_next = 0;
-      const float4* src_next = chunk_src(cn, n4_next);
-#pragma unroll
-      for (int i = 0; i < NROW; ++i) {
-        zn[i] = load_z(row_dim(cn, i));
-        mn[i] = mask4(row_dim(cn, i));
-      }
-#pragma unroll
-      for (int i = 0; i < S::STAGE_F4; ++i) {
-        const int k = threadIdx.x + i * (kRnvpWaves * 64);
-        st[i] = src_next[k < n4_next ? k : 0];
-      }
-      // 2. compute chunk c
-      const float* buf = lds[c & 1];
-      if (c < nc1) {  // GEMM 1: y^T (64 x 16) += Wn[:, chunk] . (m*z)^T[chunk]
-        const int nk = min(KC, n_k - c * KC);
-        const f32x4* A4 = reinterpret_cast<const f32x4*>(buf) + lane;
-#pragma unroll
-        for (int g = 0; g < KC / 4; ++g) {
-          if (4 * g < nk) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float b = mc[g][e] * zc[g][e];
-              const f32x4 a4 = A4[64 * (4 * g + e)];
-#pragma unroll
-              for (int m = 0; m < YT; ++m)
-                yacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m], b, yacc[m], 0, 0, 0);
-            }
-          }
-        }
-      } else {  // GEMM 2 + gate, 16 output dims per tile
-        const int m0 = (c - nc1) * MC;
-#pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          const int m = m0 + mi;
-          if (m < n_m) {
-            const float* tile = buf + mi * S::TILE2_FLOATS;
-            const f32x4* A4 = reinterpret_cast<const f32x4*>(tile) + lane;
-            f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + S::G2 * 256 + 4 * q);
-            f32x4 s4 = *reinterpret_cast<const f32x4*>(tile + S::G2 * 256 + 16 + 4 * q);
-            f32x4 a4;
-#pragma unroll
-            for (int cc = 0; cc < KQ; ++cc) {
-              if (((2 * cc) & 3) == 0) a4 = A4[64 * ((2 * cc) >> 2)];
-              t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(2 * cc) & 3], yacc[cc >> 2][cc & 3], t4, 0, 0, 0);
-              s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(2 * cc + 1) & 3], yacc[cc >> 2][cc & 3], s4, 0, 0, 0);
-            }
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float zz = zc[mi][r], mm = mc[mi][r];
-              const float gate = __builtin_amdgcn_rcpf(1.f + exp6r(-s4[r]));
-              const float keep = mm * zz;                            // z2 = m z
-              const float gated = (1.f - mm) * zz;                   // z1 = (1-m) z
-              o[r] = (gated * gate + (1.f - gate) * t4[r]) + keep;   // rnvp.py:37
-              ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);  // :36
-            }
-            if (live) row_store4<RAG>(xr, 16 * m, 4 * q, dm, vec, o);
-          }
-        }
-      }
-      // 3. hand chunk c+1 over
-      {
-        float4* dst = reinterpret_cast<float4*>(lds[(c + 1) & 1]);
-#pragma unroll
-        for (int i = 0; i < S::STAGE_F4; ++i) {
-          const int k = threadIdx.x + i * (kRnvpWaves * 64);
-          if (k < n4_next) dst[k] = st[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NROW; ++i) {
-          zc[i] = zn[i];
-          mc[i] = mn[i];
-        }
-      }
-      __syncthreads();
-    }
-    if (log_det) {
-      ld = sum_over_q(ld);
-      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
-    }
-  }
-}
 
 template <int HN, bool SEEDED, bool RAG>
 __global__ void __launch_bounds__(kRnvpWaves * 64, 4)  // two 8-wave workgroups per CU: <= 128 VGPRs
@@ -298,22 +57,6 @@ constexpr int kRnvpAbl = MNF_RNVP_ABL;
 
 constexpr int kRnvpMaxPrologueDim = 1024;  // fused sample_z prologue: mean and std of up to this many dims in LDS
 
-template <int HN>
-struct RnvpSplitShape {
-  static constexpr int YT = (HN + 15) / 16;            // 16-unit tiles of y (unit u = 16 m + i)
-  static constexpr int NKS2 = (YT + 1) / 2;            // K = 32 steps of GEMM 2
-  static constexpr int KS1_WORDS = YT * 512;           // one GEMM-1 K-step: YT x (hi, lo) operands
-  static constexpr int TILE2_WORDS = 2 * NKS2 * 512;   // one GEMM-2 output tile: (t, s) x NKS2 x (hi, lo)
-  static constexpr int KC = 2, MC = 2;                 // K-steps / output tiles per chunk
-  static constexpr int CHUNK_WORDS = KC * KS1_WORDS > MC * TILE2_WORDS ? KC * KS1_WORDS : MC * TILE2_WORDS;
-  static constexpr int NROW = 2 * KC > MC ? 2 * KC : MC;  // 16-dim row groups per chunk
-  static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);
-  static constexpr int64_t n_ks1(int d) { return (d / 16 + 1) / 2; }
-  static constexpr int64_t part1_words(int d) { return n_ks1(d) * KS1_WORDS; }
-  static constexpr int64_t part2_words(int d) { return (int64_t)(d / 16) * TILE2_WORDS; }
-  static constexpr int64_t split_words(int d) { return part1_words(d) + part2_words(d); }
-  static constexpr int64_t plain_words(int d) { return (int64_t)(d / 16) * 32 + YT * 16; }  // (bt, bs) per tile, then bn
-};
 
 // returns false (block-uniform) when the group has to be recomputed on the fp32 path
 template <int HN, bool SEEDED, bool RAG>
@@ -810,6 +553,11 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   const int hn_pad = rnvp_padded_hidden(n_hidden, hidden);
   if (!ragged && !rows_aligned) return MNF_ERR_UNSUPPORTED;
   const int vec = rows_aligned && (dim & 3) == 0;
+  if (split_image && !mask && rows_aligned) {  // in-kernel mask: the register-resident kernel where it exists
+    const int rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
+                                        q0_log_var, vec, stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
   if (split_image) {
     const uint32_t* simage = static_cast<const uint32_t*>(split_image);
 #define X(HN)                                                                                                        \

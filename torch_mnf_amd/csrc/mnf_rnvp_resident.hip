@@ -1,0 +1,439 @@
+// Masked / gated RNVP coupling (flows/rnvp.py:25-39) with the rows RESIDENT IN REGISTERS, gfx950.
+//
+//   y      = Wn (m * z) + bn                 GEMM 1, K = d          (needs every z of the row)
+//   shift  = Wt y + bt ; scale = Ws y + bs   GEMM 2, K = h
+//   x      = (1 - gate) shift + (m ? z : gate z) ;  log_det = sum_j (1 - m_j) log gate_j     (needs z again)
+//
+// z is needed twice with all of GEMM 1 in between.  The streaming kernels (mnf_rnvp_mfma.hip) read it from
+// memory twice: 12 d + 8 bytes per row against 8 d + 8 algorithmic (PMC: 1.70 x).  Here a wave keeps its 16
+// rows -- d / 4 registers per lane, 200 at d = 800 -- in the register file from the one load to the gate
+// epilogue, so every z is read ONCE.  That takes the whole 512-entry file: one wave per SIMD, one 4-wave
+// workgroup per CU (`__launch_bounds__(256, 1)`).  The loops over the row are fully unrolled (G = d / 16 is a
+// template parameter), so every register index is static.
+//
+// Latency is hidden inside the wave instead of by other waves: as soon as the epilogue has consumed the 16 dims
+// of group g (x stored), the registers of that group are re-loaded with the same dims of the wave's NEXT 16 rows;
+// those loads are in flight under the rest of the epilogue and land long before GEMM 1 of the next row tile reads
+// them.  HBM therefore sees one load and one store per 64 B of row, interleaved, all through the epilogue.
+//
+// Both GEMMs run in split arithmetic (mnf_split.h) on v_mfma_f32_16x16x32_f16 from the same operand image as the
+// streaming split kernel; the image (600 KB at d = 800, h = 50) is streamed L2 -> registers -> LDS in 32 KB chunks
+// shared by the four waves (64 rows per pass), double buffered, one barrier per chunk.  A 64-row group whose
+// operands leave the f16 range (verdict after GEMM 1, before anything is stored) is recomputed by the fp32 body.
+// The mask is the in-kernel counter-based one (`seed`): its 32-bit words are hashed once per row tile and kept
+// (d / 32 registers) for the epilogue.  Explicit float masks stay on the streaming kernels.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include <utility>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+#include "mnf_rnvp_common.h"
+#include "mnf_split.h"
+
+namespace mnf {
+
+constexpr int kResWaves = 4;   // one wave per SIMD
+constexpr int kResKC = 4;      // GEMM-1 K-steps (32 dims each) per operand chunk
+constexpr int kResMC = 4;      // GEMM-2 output tiles (16 dims each) per operand chunk
+constexpr int kResColdWords = 64;  // one bit per row group of a workgroup that has to be redone in fp32 (2,048 groups)
+
+template <int HN>
+struct ResShape {
+  using S = RnvpSplitShape<HN>;
+  static constexpr int CHUNK_WORDS =
+      kResKC * S::KS1_WORDS > kResMC * S::TILE2_WORDS ? kResKC * S::KS1_WORDS : kResMC * S::TILE2_WORDS;
+  static constexpr int F32_WORDS = RnvpShape<HN, kResWaves>::CHUNK_FLOATS;  // the fp32 body's window
+  static constexpr int BUF_WORDS = CHUNK_WORDS > F32_WORDS ? CHUNK_WORDS : F32_WORDS;
+  static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kResWaves * 64 - 1) / (kResWaves * 64);
+  // LDS: two operand buffers, the fp32 biases ((bt, bs) per tile, then bn), mean / std of the sample_z prologue
+  static constexpr size_t lds_bytes(int d) {
+    return sizeof(uint32_t) * (2 * (size_t)BUF_WORDS + S::plain_words(d) + 2 * (size_t)d + kResColdWords);
+  }
+};
+
+template <int HN, bool RAG>
+__device__ __attribute__((noinline)) void rnvp_resident_f32_cold(float* lds, int grp, const float* z, float* x,
+                                                                float* log_det, const float* image, int64_t rows, int d,
+                                                                int accumulate, uint64_t seed, const float* zprm, int dm,
+                                                                bool vec) {
+  using F = RnvpShape<HN, kResWaves>;
+  rnvp_group_f32<HN, true, RAG, kResWaves>(*reinterpret_cast<float(*)[2][F::CHUNK_FLOATS]>(lds), grp, z, nullptr, x,
+                                           log_det, image, rows, d, accumulate, seed, zprm, dm, vec);
+}
+
+// ---- compile-time loops: every register index and every instruction offset below is a constant
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- the resident rows live in the ACCUMULATOR half of the register file, in registers this file assigns itself:
+// group g of the row tile is a[4 g : 4 g + 3].  hipcc allocates at most 256 ordinary VGPRs and treats everything
+// above as spills (a plain `f32x4 zr[50]` put 800 dwords per lane in scratch), and values it allocates itself -- also
+// "a"-constrained asm operands -- may be copied or spilled by the register allocator at any point, e.g. at the
+// loop back-edge, WHILE the asynchronous load that fills them is still in flight.  So the compiler never sees these
+// registers as values: reserve_agprs() marks them used (clobbers) so that it neither allocates them nor uses them as
+// spill slots, and every access is an asm statement with the register number as an immediate.  All of them are
+// volatile: they keep their program order among themselves.
+// The loads are asm, so the compiler's s_waitcnt insertion does not know them: row_wait<N> is the explicit wait
+// (vector-memory operations complete in issue order; the compiler's own counted waits stay correct with extra
+// operations in flight -- they only become stricter).
+constexpr int kResAgprs = 208;  // a0 .. a207 (G <= 52); the other 48 stay with the compiler
+#define MNF_A4(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__device__ __forceinline__ void reserve_agprs() {
+  asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", MNF_A4(1), MNF_A4(2), MNF_A4(3),
+               MNF_A4(4), MNF_A4(5), MNF_A4(6), MNF_A4(7), MNF_A4(8), MNF_A4(9), MNF_A4(10), MNF_A4(11), MNF_A4(12),
+               MNF_A4(13), MNF_A4(14), MNF_A4(15), MNF_A4(16), MNF_A4(17), MNF_A4(18), MNF_A4(19), "a200", "a201",
+               "a202", "a203", "a204", "a205", "a206", "a207");
+}
+#undef MNF_A4
+template <int GRP>
+__device__ __forceinline__ void row_load(const float* p) {  // a[4 GRP : 4 GRP + 3] <- 16 bytes at p + 64 GRP
+  asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(4 * GRP), "n"(4 * GRP + 3), "n"(64 * GRP)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void row_wait() {  // at most N vector-memory operations still in flight
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int GRP>
+__device__ __forceinline__ f32x4 row_read() {
+  f32x4 v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\t"
+               "v_accvgpr_read_b32 %3, a[%7]"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3])
+               : "n"(4 * GRP), "n"(4 * GRP + 1), "n"(4 * GRP + 2), "n"(4 * GRP + 3));
+  return v;
+}
+template <int GRP>
+__device__ __forceinline__ void row_write(const f32x4& v) {
+  asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\tv_accvgpr_write_b32 a[%6], %2\n\t"
+               "v_accvgpr_write_b32 a[%7], %3" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]),
+               "n"(4 * GRP), "n"(4 * GRP + 1), "n"(4 * GRP + 2), "n"(4 * GRP + 3));
+}
+
+template <int HN, int G, bool SAMPLE>
+__global__ void __launch_bounds__(kResWaves * 64, 1)
+rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* __restrict__ log_det,
+                     const uint32_t* __restrict__ simage, const float* __restrict__ image, int64_t rows, int accumulate,
+                     uint64_t seed, const float* __restrict__ q0_mean, const float* __restrict__ q0_log_var) {
+  using S = RnvpSplitShape<HN>;
+  using R = ResShape<HN>;
+  constexpr int d = 16 * G;
+  constexpr int YT = S::YT, NKS2 = S::NKS2, KC = kResKC, MC = kResMC;
+  constexpr int NKS1 = (G + 1) / 2;
+  constexpr int NC1 = (NKS1 + KC - 1) / KC, NC2 = (G + MC - 1) / MC, NC = NC1 + NC2;
+  static_assert(NC % 2 == 0, "the operand ring keeps its buffer parity from one row group to the next");
+  static_assert(64 * (G - 1) < 4096, "row offsets are instruction immediates");
+  static_assert(4 * G <= kResAgprs, "resident rows fit the reserved accumulator registers");
+  reserve_agprs();
+  constexpr int GROUP_ROWS = 16 * kResWaves;
+  constexpr int NSTAGE = R::STAGE_U4;  // uint4 per thread per (full) operand chunk
+  // loads per thread that fetch chunk c (the last chunk of either GEMM may be short; whole 4 KB pieces)
+  auto chunk_loads = [](int c) constexpr -> int {
+    const int words = c < NC1 ? ((NKS1 - c * KC) < KC ? (NKS1 - c * KC) : KC) * S::KS1_WORDS
+                              : ((G - (c - NC1) * MC) < MC ? (G - (c - NC1) * MC) : MC) * S::TILE2_WORDS;
+    return (words / 4 + kResWaves * 64 - 1) / (kResWaves * 64);
+  };
+  // operand loads issued at the tops of GEMM-1 chunks 0 .. c (each requests chunk c' + 1)
+  auto loads_since_rows = [chunk_loads](int c) constexpr -> int {
+    int n = 0;
+    for (int k = 0; k <= c; ++k) n += chunk_loads((k + 1) % NC);
+    return n;
+  };
+  static_assert(S::KS1_WORDS % (kResWaves * 64 * 4) == 0 && S::TILE2_WORDS % (kResWaves * 64 * 4) == 0,
+                "chunks are whole 4 KB pieces (one uint4 per thread)");
+
+  // LDS: [two operand buffers][(bt | bs) per tile, then bn][mean | std of the sample_z prologue][cold-group flags]
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  float* const bias_lds = reinterpret_cast<float*>(lds_dyn + 2 * R::BUF_WORDS);
+  float* const zprm_lds = bias_lds + S::plain_words(d);
+  uint32_t* const cold_flags = reinterpret_cast<uint32_t*>(zprm_lds + 2 * d);  // kResColdWords words
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+
+  // once per workgroup: biases (and the prologue's mean / std) into LDS
+  if (threadIdx.x < kResColdWords) cold_flags[threadIdx.x] = 0u;
+  {
+    const float* bias_src = reinterpret_cast<const float*>(simage + S::split_words(d));
+    for (int i = threadIdx.x; i < (int)S::plain_words(d); i += kResWaves * 64) bias_lds[i] = bias_src[i];
+  }
+  // SAMPLE: `z` holds eps; the layer runs on q0_mean + q0_std * eps (MNFLinear.sample_z, mnf_linear.py:58-64)
+  if (SAMPLE) {
+    for (int i = threadIdx.x; i < d; i += kResWaves * 64) {
+      zprm_lds[i] = q0_mean[i];
+      zprm_lds[d + i] = sqrtf(expf(q0_log_var[i]));  // mnf_linear.py:60
+    }
+  }
+  const float* zprm = SAMPLE ? zprm_lds : nullptr;
+  const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
+  const bool split_ok = wmax <= kSplitWeightLimit;  // else every group takes the fp32 body
+  __syncthreads();
+  // byte offsets of the LDS regions as opaque registers: every LDS access below is then one of these + an
+  // instruction immediate (left constant, hipcc materialises one address register per access for the regions above
+  // 64 KB -- the limit of the immediate -- and hoists all of them out of the group loop)
+  uint32_t bias_off = 2 * R::BUF_WORDS * 4 + q * 16, buf_off0 = lane * 16, buf_off1 = R::BUF_WORDS * 4 + lane * 16;
+  uint32_t zprm_off = (2 * R::BUF_WORDS + (uint32_t)S::plain_words(d)) * 4 + q * 16;
+  asm volatile("" : "+v"(bias_off), "+v"(buf_off0), "+v"(buf_off1), "+v"(zprm_off));
+  auto lds_f4 = [&](uint32_t byte_off) -> const f32x4& {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds_dyn) + byte_off);
+  };
+  auto lds_h8 = [&](uint32_t byte_off) -> const f16x8& {
+    return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(lds_dyn) + byte_off);
+  };
+
+  // ---- operand ring.  Chunk c (mod NC) of the image: GEMM-1 K-steps for c < NC1, GEMM-2 tiles after.  The chunks
+  // do not depend on the rows, so the ring runs on across row groups: at the top of chunk c the wave requests chunk
+  // c + 1 into registers, at its end it writes them into LDS buffer (c + 1) & 1 and meets the others at the chunk's
+  // one barrier.
+  u32x4 st[NSTAGE];
+  uint32_t img_off = 0;  // always 0, but opaque and re-declared at the top of every row group: see there
+  uint32_t toff[NSTAGE];              // byte offset of this thread's i-th uint4 inside a chunk
+#pragma unroll
+  for (int i = 0; i < NSTAGE; ++i) toff[i] = (threadIdx.x + i * (kResWaves * 64)) * 16u;
+  auto request = [&](auto cc) {
+    constexpr int c = decltype(cc)::value % NC;
+    constexpr int64_t word0 = c < NC1 ? (int64_t)c * KC * S::KS1_WORDS
+                                      : S::part1_words(d) + (int64_t)(c - NC1) * MC * S::TILE2_WORDS;
+    const char* src = reinterpret_cast<const char*>(simage + word0) + img_off;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i)
+      if (i < chunk_loads(c)) st[i] = *reinterpret_cast<const u32x4*>(src + toff[i]);
+  };
+  auto hand_over = [&](auto bufc) {  // registers -> LDS buffer u (whole chunk; a short last chunk copies padding)
+    constexpr int u = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_dyn) + u * (R::BUF_WORDS * 4) + toff[i]) = st[i];
+  };
+  using I0 = std::integral_constant<int, 0>;
+
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  // the mask of element r of group g as all-ones / all-zeros (wq = the row's mask word g >> 1, pre-shifted by 4 q).
+  // asm on purpose: left to itself hipcc turns  sext(bit) & v  into compare + select through an SGPR pair per
+  // element, and a fully unrolled row then spills SGPRs through v_writelane.
+  auto mask_bits = [&](uint32_t wq, auto gc) -> i32x4 {
+    constexpr int o = 16 * (decltype(gc)::value & 1);
+    i32x4 m;
+    asm("v_bfe_i32 %0, %4, %5, 1\n\tv_bfe_i32 %1, %4, %6, 1\n\tv_bfe_i32 %2, %4, %7, 1\n\tv_bfe_i32 %3, %4, %8, 1"
+        : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
+        : "v"(wq), "n"(o), "n"(o + 1), "n"(o + 2), "n"(o + 3));
+    return m;
+  };
+  auto and_bits = [](const f32x4& v, const i32x4& m) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & m);
+  };
+  auto bfi = [](int32_t m, float a, float b) -> float {  // m ? a : b, bitwise
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+  };
+  // resident rows: a[4 g : 4 g + 3] of lane (j, q) holds dims 16 g + 4 q .. + 3 of row j of the wave's 16 rows
+  uint32_t mw[NKS1];  // the rows' mask words (32 dims each), pre-shifted by 4 q
+  bool primed = false;  // rows resident and the operand ring running (false at the start and after an fp32 group)
+  const int n_groups = (int)((rows + GROUP_ROWS - 1) / GROUP_ROWS);
+
+  for (int grp = blockIdx.x, it = 0; grp < n_groups; grp += gridDim.x, ++it) {
+    const int64_t row = (int64_t)grp * GROUP_ROWS + wave * 16 + j;  // (every row of a hot-path group exists)
+    const int64_t rowc = row < rows ? row : rows - 1;
+    float* xr = x + rowc * d + 4 * q;
+    // Groups for the fp32 body -- weights outside the f16 range, the one group that may be short of 64 rows, and
+    // (below) operands outside the f16 range -- are only FLAGGED here and redone after the loop: a call inside this
+    // loop would have the 200 resident registers live across it.
+    if (!split_ok || (int64_t)(grp + 1) * GROUP_ROWS > rows) {
+      if (threadIdx.x == 0) cold_flags[it >> 5] |= 1u << (it & 31);
+      primed = false;
+      continue;
+    }
+    // opaque per group: the 20 x 8 operand addresses of a pass are formed where they are used (scalar base + 32-bit
+    // thread offset) instead of being hoisted out of the group loop into 300 registers
+    asm volatile("" : "+s"(img_off));
+    // rows of the NEXT group, loaded in place while this group's epilogue frees the registers; past the last group
+    // every lane re-reads 16 bytes of row 0 instead (a cache hit, no branch in the unrolled epilogue)
+    const bool has_next = grp + (int)gridDim.x < n_groups;
+    const float* zn;
+    {
+      const int64_t rn = (int64_t)(grp + (int)gridDim.x) * GROUP_ROWS + wave * 16 + j;
+      zn = z + (has_next ? (rn < rows ? rn : rows - 1) : 0) * d + 4 * q;
+    }
+    if (!primed) {  // the only exposed loads: operand chunk 0, then the group's rows
+      __syncthreads();  // (LDS may still be in use by an fp32 group)
+      request(I0{});
+      hand_over(I0{});
+      const float* zq = z + rowc * d + 4 * q;
+      static_for<G>([&](auto gc) { row_load<decltype(gc)::value>(zq); });
+      __syncthreads();
+      primed = true;
+    }
+
+    // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step
+    f32x4 ym[YT], yc[YT];
+#pragma unroll
+    for (int m = 0; m < YT; ++m) {
+      ym[m] = lds_f4(bias_off + (G * 32 + m * 16) * 4);
+      yc[m] = zero4;
+    }
+    float mx = 0.f;
+    const uint32_t row_hash =
+        mix32((uint32_t)rowc * 0x9e3779b1u + (uint32_t)((uint64_t)rowc >> 32) + (uint32_t)(seed >> 32));
+    static_for<NKS1>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value, c = ks / KC, kk = ks % KC;
+      constexpr int g0 = 2 * ks, g1 = 2 * ks + 1 < G ? 2 * ks + 1 : 2 * ks;
+      if constexpr (kk == 0) request(std::integral_constant<int, c + 1>{});
+      // rows: groups g0, g1 have landed once at most this many vector-memory operations are in flight -- the row
+      // loads issued after them (groups g1 + 1 .. G - 1) and the operand requests issued since (NSTAGE per chunk)
+      constexpr int n_after = (G - 1 - g1) + loads_since_rows(c);
+      row_wait<(n_after < 63 ? n_after : 63)>();
+      f32x4 v0 = row_read<g0>(), v1 = row_read<g1>();
+      if constexpr (SAMPLE) {  // the sample_z prologue, once per row: z = q0_mean + q0_std * eps, kept for the epilogue
+        v0 = v0 * lds_f4(zprm_off + (d + 16 * g0) * 4) + lds_f4(zprm_off + 16 * g0 * 4);
+        row_write<g0>(v0);
+        if constexpr (g1 != g0) {
+          v1 = v1 * lds_f4(zprm_off + (d + 16 * g1) * 4) + lds_f4(zprm_off + 16 * g1 * 4);
+          row_write<g1>(v1);
+        }
+      }
+      // mask word of dims 32 ks .. 32 ks + 31 (rnvp_mask_word), kept for the epilogue
+      mw[ks] = mix32(row_hash ^ ((uint32_t)ks * 0x85ebca77u + (uint32_t)seed)) >> (4 * q);
+      u32x2 h0, l0, h1 = zero2, l1 = zero2;
+      split_tile(and_bits(v0, mask_bits(mw[ks], std::integral_constant<int, g0>{})), h0, l0, mx);
+      if constexpr (g1 != g0) split_tile(and_bits(v1, mask_bits(mw[ks], std::integral_constant<int, g1>{})), h1, l1, mx);
+      const f16x8 bh = pair_operand(h0, h1), bl = pair_operand(l0, l1);
+      const uint32_t a_off = (c & 1) ? buf_off1 : buf_off0;  // operand o of the chunk at + 1024 o
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+        split_mac(lds_h8(a_off + 1024 * (2 * (kk * YT + m))), lds_h8(a_off + 1024 * (2 * (kk * YT + m) + 1)), bh, bl,
+                  ym[m], yc[m]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the scheduler inside one K-step
+      if constexpr (kk == KC - 1 || ks == NKS1 - 1) {
+        hand_over(std::integral_constant<int, (c + 1) & 1>{});
+        if constexpr (ks < NKS1 - 1) __syncthreads();  // (the last chunk's barrier is the verdict below)
+      }
+    });
+    // y complete: operands of GEMM 2, and the range verdict for the whole 64-row group
+    u32x2 yh[YT], yl[YT];
+#pragma unroll
+    for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
+    if (__syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0)) {  // nothing has been stored yet
+      if (threadIdx.x == 0) cold_flags[it >> 5] |= 1u << (it & 31);
+      primed = false;
+      continue;
+    }
+    f16x8 ybh[NKS2], ybl[NKS2];
+#pragma unroll
+    for (int ks = 0; ks < NKS2; ++ks) {
+      ybh[ks] = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+      ybl[ks] = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+    }
+
+    // ---- GEMM 2 + gate, 16 output dims per tile; the tile's z registers are re-loaded for the next group
+    float ld2 = 0.f;  // sum of log2(1 + e^-s) over the gated elements
+    static_for<G>([&](auto mc_) {
+      constexpr int m = decltype(mc_)::value, c = NC1 + m / MC, mi = m % MC;
+      if constexpr (mi == 0) request(std::integral_constant<int, c + 1>{});
+      const uint32_t t_off = ((c & 1) ? buf_off1 : buf_off0) + mi * (S::TILE2_WORDS * 4);  // operand o at + 1024 o
+      f32x4 tm = lds_f4(bias_off + m * 128);
+      f32x4 sm = lds_f4(bias_off + m * 128 + 64);
+      f32x4 tc = zero4, sc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < NKS2; ++ks) {
+        split_mac(lds_h8(t_off + 1024 * (2 * ks)), lds_h8(t_off + 1024 * (2 * ks + 1)), ybh[ks], ybl[ks], tm, tc);
+        split_mac(lds_h8(t_off + 1024 * (2 * (NKS2 + ks))), lds_h8(t_off + 1024 * (2 * (NKS2 + ks) + 1)), ybh[ks],
+                  ybl[ks], sm, sc);
+      }
+      const f32x4 t4 = tc * kSplitInvScale + tm;
+      const f32x4 s4 = sc * kSplitInvScale + sm;
+      // binary mask: x = (1 - gate) t + (m ? z : gate z);  log_det -= (1 - m) ln(1 + e^-s)   (rnvp.py:36-37; the shift
+      // term reaches the kept elements too)
+      const i32x4 mb = mask_bits(mw[m >> 1], mc_);
+      const f32x4 zv = row_read<m>();
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float zz = zv[r];
+        const float den = 1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f);
+        const float gate = __builtin_amdgcn_rcpf(den);
+        o[r] = __builtin_fmaf(-gate, t4[r], t4[r]) + bfi(mb[r], zz, zz * gate);
+        // kept elements contribute log2(1) = 0.  (The mask goes on BEFORE the logarithm: an asm statement must not
+        // read the result of a transcendental instruction directly -- gfx950 needs a wait state there that hipcc
+        // only inserts for instructions it has selected itself; log2 of the masked value feeds a plain add.)
+        ld2 += __builtin_amdgcn_logf(bfi(mb[r], 1.f, den));
+      }
+      *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+      row_load<m>(zn);  // the same dims of the next group's row
+      __builtin_amdgcn_sched_barrier(0);  // keep the scheduler inside one tile
+      if constexpr (mi == MC - 1 || m == G - 1) {
+        hand_over(std::integral_constant<int, (c + 1) & 1>{});
+        __syncthreads();
+      }
+    });
+    {  // (log_det is never null here: a conditional use would let the compiler sink the 4 G adds of ld2 down to it)
+      const float ld = sum_over_q(-0.693147180559945309f * ld2);
+      if (q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+  }
+  // the flagged groups, on the fp32 MFMA body (reads its rows from memory itself)
+  __syncthreads();
+  for (int grp = blockIdx.x, it = 0; grp < n_groups; grp += gridDim.x, ++it)
+    if ((cold_flags[it >> 5] >> (it & 31)) & 1u)
+      rnvp_resident_f32_cold<HN, false>(reinterpret_cast<float*>(lds_dyn), grp, z, x, log_det, image, rows, d,
+                                        accumulate, seed, zprm, d, true);
+}
+
+// ---------------------------------------------------------------- host
+template <int HN, int G, bool SAMPLE>
+static int launch_resident(const float* z, float* x, float* log_det, int accumulate, const uint32_t* simage,
+                           const float* image, int64_t rows, uint64_t seed, const float* q0_mean,
+                           const float* q0_log_var, hipStream_t stream) {
+  constexpr size_t lds_bytes = ResShape<HN>::lds_bytes(16 * G);
+  static_assert(lds_bytes <= 160 * 1024, "operand window + biases must fit the CU's LDS");
+  static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
+  const int cus = memo.get([](int dev) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(rnvp_resident_kernel<HN, G, SAMPLE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess
+               ? device_cus(dev)
+               : -1;
+  });
+  if (cus <= 0) return MNF_ERR_UNSUPPORTED;
+  const int64_t n_groups = (rows + 16 * kResWaves - 1) / (16 * kResWaves);
+  const int64_t blocks = n_groups < cus ? n_groups : cus;  // one persistent workgroup per CU
+  if ((n_groups + blocks - 1) / (blocks > 0 ? blocks : 1) > 32 * kResColdWords) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((rnvp_resident_kernel<HN, G, SAMPLE>), dim3((unsigned)blocks), dim3(kResWaves * 64), lds_bytes,
+                     stream, z, x, log_det, simage, image, rows, accumulate, seed, q0_mean, q0_log_var);
+  return check_launch();
+}
+
+// (hidden width the layer runs at, padded dim / 16) pairs with an instantiated kernel: MNFLinear(800, 50)'s flow_q
+// (BASELINE configs[4]) and MNFFeedForward's 784-wide first layer
+#define MNF_RNVP_RESIDENT_SHAPES(X) X(50, 50)
+
+// MNF_ERR_UNSUPPORTED: no resident kernel for this shape -- the caller runs the streaming split kernel
+int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
+                         const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
+                         const float* q0_log_var, int vec, hipStream_t stream) {
+  // MNF_RNVP_RESIDENT=0 (read per call: tests and A/B runs flip it): the streaming kernels only
+  const char* env = getenv("MNF_RNVP_RESIDENT");
+  if ((env && env[0] == '0') || !split_image || !image || !log_det) return MNF_ERR_UNSUPPORTED;
+  if ((dim & 15) || !vec) return MNF_ERR_UNSUPPORTED;  // whole 16-dim groups, 16-byte aligned rows
+  const uint32_t* simage = static_cast<const uint32_t*>(split_image);
+#define X(HN, GG)                                                                                                  \
+  if (hn_pad == HN && dim == 16 * GG)                                                                              \
+    return q0_mean ? launch_resident<HN, GG, true>(z, x, log_det, accumulate, simage, image, rows, seed, q0_mean,   \
+                                                   q0_log_var, stream)                                             \
+                   : launch_resident<HN, GG, false>(z, x, log_det, accumulate, simage, image, rows, seed, q0_mean,  \
+                                                    q0_log_var, stream);
+  MNF_RNVP_RESIDENT_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // namespace mnf
