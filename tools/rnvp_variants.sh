@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B libraries of the register-resident RNVP kernel: recompiles mnf_rnvp_resident.hip with experiment switches and
+# links it with the other objects into tools/bin/libmnf_<tag>.so (run here; the .so files travel to the GPU box).
+# usage: tools/rnvp_variants.sh tag1:"-DMNF_RES_ABL=1" tag2:"-DMNF_RES_KC=2 -DMNF_RES_MC=2" ...
+set -e
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+C=$REPO/torch_mnf_amd/csrc
+mkdir -p $REPO/tools/bin
+OBJS=$(ls $C/*.o | grep -v mnf_rnvp_resident.o)
+for spec in "$@"; do
+  tag=${spec%%:*}; flags=${spec#*:}
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-spill-vgpr-to-agpr=0 $flags \
+      -c $C/mnf_rnvp_resident.hip -o /tmp/res_$tag.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/tools/bin/libmnf_$tag.so $OBJS /tmp/res_$tag.o
+  echo "built tools/bin/libmnf_$tag.so ($flags)"
+done

@@ -34,9 +34,24 @@
 
 namespace mnf {
 
-constexpr int kResWaves = 4;   // one wave per SIMD
-constexpr int kResKC = 4;      // GEMM-1 K-steps (32 dims each) per operand chunk
-constexpr int kResMC = 4;      // GEMM-2 output tiles (16 dims each) per operand chunk
+// experiment switches (tools/rnvp_variants.sh builds A/B libraries with them; the defaults are the product)
+#ifndef MNF_RES_KC
+#define MNF_RES_KC 4
+#endif
+#ifndef MNF_RES_MC
+#define MNF_RES_MC 4
+#endif
+#ifndef MNF_RES_ABL
+#define MNF_RES_ABL 0  // timing only, results wrong: 1 no x stores, 2 no row re-loads, 3 no MFMAs, 4 no gate math,
+                       // 5 no operand requests, 6 = 1 + 2, 7 = 1 + 2 + 5
+#endif
+#ifndef MNF_RES_SCHED
+#define MNF_RES_SCHED 1  // sched_barrier after every K-step / tile
+#endif
+constexpr int kResWaves = 4;        // one wave per SIMD
+constexpr int kResKC = MNF_RES_KC;  // GEMM-1 K-steps (32 dims each) per operand chunk
+constexpr int kResMC = MNF_RES_MC;  // GEMM-2 output tiles (16 dims each) per operand chunk
+constexpr int kResAbl = MNF_RES_ABL;
 constexpr int kResColdWords = 64;  // one bit per row group of a workgroup that has to be redone in fp32 (2,048 groups)
 
 template <int HN>
@@ -78,19 +93,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // above as spills (a plain `f32x4 zr[50]` put 800 dwords per lane in scratch), and values it allocates itself -- also
 // "a"-constrained asm operands -- may be copied or spilled by the register allocator at any point, e.g. at the
 // loop back-edge, WHILE the asynchronous load that fills them is still in flight.  So the compiler never sees these
-// registers as values: reserve_agprs() marks them used (clobbers) so that it neither allocates them nor uses them as
-// spill slots, and every access is an asm statement with the register number as an immediate.  All of them are
+// registers as values: reserve_agprs() marks them used (clobbers) so that they are part of the kernel's register
+// allocation, the file is compiled with -mllvm -amdgpu-spill-vgpr-to-agpr=0 (the one way hipcc would otherwise touch
+// the accumulator half here: as spill space for VGPRs -- a clobber does not keep it from picking the same registers;
+// MFMA results are in VGPRs, -amdgpu-mfma-vgpr-form), and every access is an asm statement with the register number as
+// an immediate.  All of them are
 // volatile: they keep their program order among themselves.
 // The loads are asm, so the compiler's s_waitcnt insertion does not know them: row_wait<N> is the explicit wait
 // (vector-memory operations complete in issue order; the compiler's own counted waits stay correct with extra
 // operations in flight -- they only become stricter).
-constexpr int kResAgprs = 208;  // a0 .. a207 (G <= 52); the other 48 stay with the compiler
+constexpr int kResAgprs = 208;   // a0 .. a207: the rows (G <= 52)
+constexpr int kResMaskAgpr = 208;  // a208 .. a239: the rows' mask words (one per 32 dims)
 #define MNF_A4(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 __device__ __forceinline__ void reserve_agprs() {
   asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", MNF_A4(1), MNF_A4(2), MNF_A4(3),
                MNF_A4(4), MNF_A4(5), MNF_A4(6), MNF_A4(7), MNF_A4(8), MNF_A4(9), MNF_A4(10), MNF_A4(11), MNF_A4(12),
-               MNF_A4(13), MNF_A4(14), MNF_A4(15), MNF_A4(16), MNF_A4(17), MNF_A4(18), MNF_A4(19), "a200", "a201",
-               "a202", "a203", "a204", "a205", "a206", "a207");
+               MNF_A4(13), MNF_A4(14), MNF_A4(15), MNF_A4(16), MNF_A4(17), MNF_A4(18), MNF_A4(19), MNF_A4(20),
+               MNF_A4(21), MNF_A4(22), MNF_A4(23));
 }
 #undef MNF_A4
 template <int GRP>
@@ -111,6 +130,16 @@ __device__ __forceinline__ f32x4 row_read() {
                : "n"(4 * GRP), "n"(4 * GRP + 1), "n"(4 * GRP + 2), "n"(4 * GRP + 3));
   return v;
 }
+template <int REG>
+__device__ __forceinline__ uint32_t agpr_get() {
+  uint32_t v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v) : "n"(REG));
+  return v;
+}
+template <int REG>
+__device__ __forceinline__ void agpr_put(uint32_t v) {
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(v), "n"(REG));
+}
 template <int GRP>
 __device__ __forceinline__ void row_write(const f32x4& v) {
   asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\tv_accvgpr_write_b32 a[%6], %2\n\t"
@@ -129,22 +158,23 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   constexpr int YT = S::YT, NKS2 = S::NKS2, KC = kResKC, MC = kResMC;
   constexpr int NKS1 = (G + 1) / 2;
   constexpr int NC1 = (NKS1 + KC - 1) / KC, NC2 = (G + MC - 1) / MC, NC = NC1 + NC2;
-  static_assert(NC % 2 == 0, "the operand ring keeps its buffer parity from one row group to the next");
+  static_assert(NC % 2 == 0, "the operand ring keeps its buffer / register-set parity from one row group to the next");
   static_assert(64 * (G - 1) < 4096, "row offsets are instruction immediates");
-  static_assert(4 * G <= kResAgprs, "resident rows fit the reserved accumulator registers");
+  static_assert(4 * G <= kResAgprs && (G + 1) / 2 <= 32, "resident rows and mask words fit the reserved registers");
   reserve_agprs();
   constexpr int GROUP_ROWS = 16 * kResWaves;
   constexpr int NSTAGE = R::STAGE_U4;  // uint4 per thread per (full) operand chunk
+  constexpr int OPS1 = 2 * YT, OPS2 = 4 * NKS2;  // 1 KB A operands per GEMM-1 K-step / per GEMM-2 tile
   // loads per thread that fetch chunk c (the last chunk of either GEMM may be short; whole 4 KB pieces)
   auto chunk_loads = [](int c) constexpr -> int {
     const int words = c < NC1 ? ((NKS1 - c * KC) < KC ? (NKS1 - c * KC) : KC) * S::KS1_WORDS
                               : ((G - (c - NC1) * MC) < MC ? (G - (c - NC1) * MC) : MC) * S::TILE2_WORDS;
     return (words / 4 + kResWaves * 64 - 1) / (kResWaves * 64);
   };
-  // operand loads issued at the tops of GEMM-1 chunks 0 .. c (each requests chunk c' + 1)
+  // operand loads issued at the tops of GEMM-1 chunks 0 .. c (each requests chunk c' + 2)
   auto loads_since_rows = [chunk_loads](int c) constexpr -> int {
     int n = 0;
-    for (int k = 0; k <= c; ++k) n += chunk_loads((k + 1) % NC);
+    for (int k = 0; k <= c; ++k) n += chunk_loads((k + 2) % NC);
     return n;
   };
   static_assert(S::KS1_WORDS % (kResWaves * 64 * 4) == 0 && S::TILE2_WORDS % (kResWaves * 64 * 4) == 0,
@@ -182,39 +212,50 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   uint32_t bias_off = 2 * R::BUF_WORDS * 4 + q * 16, buf_off0 = lane * 16, buf_off1 = R::BUF_WORDS * 4 + lane * 16;
   uint32_t zprm_off = (2 * R::BUF_WORDS + (uint32_t)S::plain_words(d)) * 4 + q * 16;
   asm volatile("" : "+v"(bias_off), "+v"(buf_off0), "+v"(buf_off1), "+v"(zprm_off));
-  auto lds_f4 = [&](uint32_t byte_off) -> const f32x4& {
+  auto lds_f4 = [&](uint32_t byte_off) -> f32x4 {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds_dyn) + byte_off);
   };
-  auto lds_h8 = [&](uint32_t byte_off) -> const f16x8& {
+  auto lds_h8 = [&](uint32_t byte_off) -> f16x8 {
     return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(lds_dyn) + byte_off);
   };
 
   // ---- operand ring.  Chunk c (mod NC) of the image: GEMM-1 K-steps for c < NC1, GEMM-2 tiles after.  The chunks
-  // do not depend on the rows, so the ring runs on across row groups: at the top of chunk c the wave requests chunk
-  // c + 1 into registers, at its end it writes them into LDS buffer (c + 1) & 1 and meets the others at the chunk's
-  // one barrier.
-  u32x4 st[NSTAGE];
+  // do not depend on the rows, so the ring runs on across row groups.  At the top of chunk c the wave requests chunk
+  // c + 2 into register set c & 1; at the end of chunk c it writes chunk c + 1 (set (c + 1) & 1, requested a whole
+  // chunk earlier) into LDS buffer (c + 1) & 1 and meets the others at the chunk's one barrier.  Two chunks of
+  // distance, because vector-memory operations complete in order: waiting for an operand load also waits for every
+  // row load and store issued before it, and those need a couple of microseconds under load.
+  u32x4 st[2][NSTAGE];
   uint32_t img_off = 0;  // always 0, but opaque and re-declared at the top of every row group: see there
-  uint32_t toff[NSTAGE];              // byte offset of this thread's i-th uint4 inside a chunk
+  uint32_t toff[NSTAGE];  // byte offset of this thread's i-th uint4 inside a chunk
 #pragma unroll
   for (int i = 0; i < NSTAGE; ++i) toff[i] = (threadIdx.x + i * (kResWaves * 64)) * 16u;
   auto request = [&](auto cc) {
-    constexpr int c = decltype(cc)::value % NC;
+    constexpr int c = decltype(cc)::value % NC, u = decltype(cc)::value & 1;
     constexpr int64_t word0 = c < NC1 ? (int64_t)c * KC * S::KS1_WORDS
                                       : S::part1_words(d) + (int64_t)(c - NC1) * MC * S::TILE2_WORDS;
     const char* src = reinterpret_cast<const char*>(simage + word0) + img_off;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i)
-      if (i < chunk_loads(c)) st[i] = *reinterpret_cast<const u32x4*>(src + toff[i]);
+      if (i < chunk_loads(c) && kResAbl != 5 && kResAbl != 7) st[u][i] = *reinterpret_cast<const u32x4*>(src + toff[i]);
   };
-  auto hand_over = [&](auto bufc) {  // registers -> LDS buffer u (whole chunk; a short last chunk copies padding)
-    constexpr int u = decltype(bufc)::value;
+  auto hand_over = [&](auto cc) {  // register set u -> LDS buffer u (whole chunk; a short last chunk copies padding)
+    constexpr int u = decltype(cc)::value & 1;
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_dyn) + u * (R::BUF_WORDS * 4) + toff[i]) = st[i];
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_dyn) + u * (R::BUF_WORDS * 4) + toff[i]) = st[u][i];
   };
   using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
 
+  auto mfma3 = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
+    if (kResAbl == 3) {
+      mn += __builtin_bit_cast(f32x4, ah) * __builtin_bit_cast(f32x4, bh);
+      cr += __builtin_bit_cast(f32x4, al) * __builtin_bit_cast(f32x4, bl);
+    } else {
+      mnf::split_mac(ah, al, bh, bl, mn, cr);
+    }
+  };
   typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x2 zero2 = u32x2{0u, 0u};
@@ -237,9 +278,12 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
     return r;
   };
+  auto fence = [] {
+    if (MNF_RES_SCHED) __builtin_amdgcn_sched_barrier(0);
+  };
   // resident rows: a[4 g : 4 g + 3] of lane (j, q) holds dims 16 g + 4 q .. + 3 of row j of the wave's 16 rows
-  uint32_t mw[NKS1];  // the rows' mask words (32 dims each), pre-shifted by 4 q
-  bool primed = false;  // rows resident and the operand ring running (false at the start and after an fp32 group)
+  // their mask words (32 dims each, pre-shifted by 4 q): a[208 + k]
+  bool primed = false;  // rows resident and the operand ring running (false at the start and after a flagged group)
   const int n_groups = (int)((rows + GROUP_ROWS - 1) / GROUP_ROWS);
 
   for (int grp = blockIdx.x, it = 0; grp < n_groups; grp += gridDim.x, ++it) {
@@ -254,7 +298,7 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       primed = false;
       continue;
     }
-    // opaque per group: the 20 x 8 operand addresses of a pass are formed where they are used (scalar base + 32-bit
+    // opaque per group: the operand addresses of a pass are formed where they are used (scalar base + 32-bit
     // thread offset) instead of being hoisted out of the group loop into 300 registers
     asm volatile("" : "+s"(img_off));
     // rows of the NEXT group, loaded in place while this group's epilogue frees the registers; past the last group
@@ -265,9 +309,10 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       const int64_t rn = (int64_t)(grp + (int)gridDim.x) * GROUP_ROWS + wave * 16 + j;
       zn = z + (has_next ? (rn < rows ? rn : rows - 1) : 0) * d + 4 * q;
     }
-    if (!primed) {  // the only exposed loads: operand chunk 0, then the group's rows
-      __syncthreads();  // (LDS may still be in use by an fp32 group)
+    if (!primed) {  // the only exposed loads: operand chunks 0 and 1, then the group's rows
+      __syncthreads();  // (the previous group may still be reading the buffers)
       request(I0{});
+      request(I1{});
       hand_over(I0{});
       const float* zq = z + rowc * d + 4 * q;
       static_for<G>([&](auto gc) { row_load<decltype(gc)::value>(zq); });
@@ -275,7 +320,10 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       primed = true;
     }
 
-    // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step
+    // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step.  Software pipeline, one K-step per
+    // slot (one wave per SIMD: nothing else hides a latency): slot k issues the MFMAs of K-step k - 1 (operands read
+    // one slot earlier), then the LDS reads of K-step k's operands into the same registers, then -- under those MFMAs
+    // and reads -- turns the rows of K-step k into B operands (mask, split).
     f32x4 ym[YT], yc[YT];
 #pragma unroll
     for (int m = 0; m < YT; ++m) {
@@ -285,38 +333,49 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     float mx = 0.f;
     const uint32_t row_hash =
         mix32((uint32_t)rowc * 0x9e3779b1u + (uint32_t)((uint64_t)rowc >> 32) + (uint32_t)(seed >> 32));
-    static_for<NKS1>([&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value, c = ks / KC, kk = ks % KC;
-      constexpr int g0 = 2 * ks, g1 = 2 * ks + 1 < G ? 2 * ks + 1 : 2 * ks;
-      if constexpr (kk == 0) request(std::integral_constant<int, c + 1>{});
-      // rows: groups g0, g1 have landed once at most this many vector-memory operations are in flight -- the row
-      // loads issued after them (groups g1 + 1 .. G - 1) and the operand requests issued since (NSTAGE per chunk)
-      constexpr int n_after = (G - 1 - g1) + loads_since_rows(c);
-      row_wait<(n_after < 63 ? n_after : 63)>();
-      f32x4 v0 = row_read<g0>(), v1 = row_read<g1>();
-      if constexpr (SAMPLE) {  // the sample_z prologue, once per row: z = q0_mean + q0_std * eps, kept for the epilogue
-        v0 = v0 * lds_f4(zprm_off + (d + 16 * g0) * 4) + lds_f4(zprm_off + 16 * g0 * 4);
-        row_write<g0>(v0);
-        if constexpr (g1 != g0) {
-          v1 = v1 * lds_f4(zprm_off + (d + 16 * g1) * 4) + lds_f4(zprm_off + 16 * g1 * 4);
-          row_write<g1>(v1);
-        }
-      }
-      // mask word of dims 32 ks .. 32 ks + 31 (rnvp_mask_word), kept for the epilogue
-      mw[ks] = mix32(row_hash ^ ((uint32_t)ks * 0x85ebca77u + (uint32_t)seed)) >> (4 * q);
-      u32x2 h0, l0, h1 = zero2, l1 = zero2;
-      split_tile(and_bits(v0, mask_bits(mw[ks], std::integral_constant<int, g0>{})), h0, l0, mx);
-      if constexpr (g1 != g0) split_tile(and_bits(v1, mask_bits(mw[ks], std::integral_constant<int, g1>{})), h1, l1, mx);
-      const f16x8 bh = pair_operand(h0, h1), bl = pair_operand(l0, l1);
-      const uint32_t a_off = (c & 1) ? buf_off1 : buf_off0;  // operand o of the chunk at + 1024 o
+    f16x8 a1[OPS1], b1h, b1l;
+    static_for<NKS1 + 1>([&](auto kc_) {
+      constexpr int k = decltype(kc_)::value;
+      if constexpr (k >= 1) {  // M(k - 1)
 #pragma unroll
-      for (int m = 0; m < YT; ++m)
-        split_mac(lds_h8(a_off + 1024 * (2 * (kk * YT + m))), lds_h8(a_off + 1024 * (2 * (kk * YT + m) + 1)), bh, bl,
-                  ym[m], yc[m]);
-      __builtin_amdgcn_sched_barrier(0);  // keep the scheduler inside one K-step
-      if constexpr (kk == KC - 1 || ks == NKS1 - 1) {
-        hand_over(std::integral_constant<int, (c + 1) & 1>{});
-        if constexpr (ks < NKS1 - 1) __syncthreads();  // (the last chunk's barrier is the verdict below)
+        for (int m = 0; m < YT; ++m) mfma3(a1[2 * m], a1[2 * m + 1], b1h, b1l, ym[m], yc[m]);
+      }
+      if constexpr (k < NKS1) {  // R(k): into the registers the MFMAs above have just been issued from
+        constexpr int c = k / KC, kk = k % KC;
+        if constexpr (kk == 0) request(std::integral_constant<int, c + 2>{});
+        const uint32_t a_off = ((c & 1) ? buf_off1 : buf_off0) + kk * (S::KS1_WORDS * 4);  // operand o at + 1024 o
+#pragma unroll
+        for (int o = 0; o < OPS1; ++o) a1[o] = lds_h8(a_off + 1024 * o);
+      }
+      if constexpr (k < NKS1) {  // P(k)
+        constexpr int c = k / KC;
+        constexpr int g0 = 2 * k, g1 = 2 * k + 1 < G ? 2 * k + 1 : 2 * k;
+        // rows: groups g0, g1 have landed once at most this many vector-memory operations are in flight -- the row
+        // loads issued after them (groups g1 + 1 .. G - 1) and the operand requests issued since (tops of chunks 0..c)
+        constexpr int n_after = (G - 1 - g1) + loads_since_rows(c);
+        row_wait<(n_after < 63 ? n_after : 63)>();
+        f32x4 v0 = row_read<g0>(), v1 = row_read<g1>();
+        if constexpr (SAMPLE) {  // the sample_z prologue, once per row: z = q0_mean + q0_std * eps, kept for the epilogue
+          v0 = v0 * lds_f4(zprm_off + (d + 16 * g0) * 4) + lds_f4(zprm_off + 16 * g0 * 4);
+          row_write<g0>(v0);
+          if constexpr (g1 != g0) {
+            v1 = v1 * lds_f4(zprm_off + (d + 16 * g1) * 4) + lds_f4(zprm_off + 16 * g1 * 4);
+            row_write<g1>(v1);
+          }
+        }
+        // mask word of dims 32 k .. 32 k + 31 (rnvp_mask_word), kept for the epilogue
+        const uint32_t mwk = mix32(row_hash ^ ((uint32_t)k * 0x85ebca77u + (uint32_t)seed)) >> (4 * q);
+        agpr_put<kResMaskAgpr + k>(mwk);
+        u32x2 h0, l0, h1 = zero2, l1 = zero2;
+        split_tile(and_bits(v0, mask_bits(mwk, std::integral_constant<int, g0>{})), h0, l0, mx);
+        if constexpr (g1 != g0) split_tile(and_bits(v1, mask_bits(mwk, std::integral_constant<int, g1>{})), h1, l1, mx);
+        b1h = pair_operand(h0, h1);
+        b1l = pair_operand(l0, l1);
+        fence();
+        if constexpr (k % KC == KC - 1 || k == NKS1 - 1) {  // end of chunk c
+          hand_over(std::integral_constant<int, c + 1>{});
+          if constexpr (k < NKS1 - 1) __syncthreads();  // (the last chunk's barrier is the verdict below)
+        }
       }
     });
     // y complete: operands of GEMM 2, and the range verdict for the whole 64-row group
@@ -335,44 +394,67 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       ybl[ks] = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
     }
 
-    // ---- GEMM 2 + gate, 16 output dims per tile; the tile's z registers are re-loaded for the next group
+    // ---- GEMM 2 + gate, 16 output dims per tile, three-stage software pipeline: slot m issues the MFMAs of tile m - 1,
+    // then the LDS reads of tile m's operands (into the registers those MFMAs were issued from), then -- under both --
+    // the gate epilogue of tile m - 2: x stored, and the tile's row registers re-loaded with the same dims of the NEXT
+    // group's rows.
     float ld2 = 0.f;  // sum of log2(1 + e^-s) over the gated elements
-    static_for<G>([&](auto mc_) {
-      constexpr int m = decltype(mc_)::value, c = NC1 + m / MC, mi = m % MC;
-      if constexpr (mi == 0) request(std::integral_constant<int, c + 1>{});
-      const uint32_t t_off = ((c & 1) ? buf_off1 : buf_off0) + mi * (S::TILE2_WORDS * 4);  // operand o at + 1024 o
-      f32x4 tm = lds_f4(bias_off + m * 128);
-      f32x4 sm = lds_f4(bias_off + m * 128 + 64);
-      f32x4 tc = zero4, sc = zero4;
+    f16x8 a2[OPS2];
+    f32x4 tm[2], tc[2], sm[2], sc[2], tb, sb;  // (tb, sb: the biases of the tile whose operands are in a2)
+    static_for<G + 2>([&](auto mc_) {
+      constexpr int s = decltype(mc_)::value;
+      if constexpr (s >= 1 && s - 1 < G) {  // M(s - 1)
+        constexpr int u = (s - 1) & 1;
+        tm[u] = tb;
+        sm[u] = sb;
+        tc[u] = zero4;
+        sc[u] = zero4;
 #pragma unroll
-      for (int ks = 0; ks < NKS2; ++ks) {
-        split_mac(lds_h8(t_off + 1024 * (2 * ks)), lds_h8(t_off + 1024 * (2 * ks + 1)), ybh[ks], ybl[ks], tm, tc);
-        split_mac(lds_h8(t_off + 1024 * (2 * (NKS2 + ks))), lds_h8(t_off + 1024 * (2 * (NKS2 + ks) + 1)), ybh[ks],
-                  ybl[ks], sm, sc);
+        for (int ks = 0; ks < NKS2; ++ks) {
+          mfma3(a2[2 * ks], a2[2 * ks + 1], ybh[ks], ybl[ks], tm[u], tc[u]);
+          mfma3(a2[2 * (NKS2 + ks)], a2[2 * (NKS2 + ks) + 1], ybh[ks], ybl[ks], sm[u], sc[u]);
+        }
       }
-      const f32x4 t4 = tc * kSplitInvScale + tm;
-      const f32x4 s4 = sc * kSplitInvScale + sm;
-      // binary mask: x = (1 - gate) t + (m ? z : gate z);  log_det -= (1 - m) ln(1 + e^-s)   (rnvp.py:36-37; the shift
-      // term reaches the kept elements too)
-      const i32x4 mb = mask_bits(mw[m >> 1], mc_);
-      const f32x4 zv = row_read<m>();
-      f32x4 o;
+      if constexpr (s < G) {  // R(s): into the registers the MFMAs above have just been issued from
+        constexpr int c = NC1 + s / MC, mi = s % MC;
+        if constexpr (mi == 0) request(std::integral_constant<int, c + 2>{});
+        const uint32_t t_off = ((c & 1) ? buf_off1 : buf_off0) + mi * (S::TILE2_WORDS * 4);  // operand o at + 1024 o
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float zz = zv[r];
-        const float den = 1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f);
-        const float gate = __builtin_amdgcn_rcpf(den);
-        o[r] = __builtin_fmaf(-gate, t4[r], t4[r]) + bfi(mb[r], zz, zz * gate);
-        // kept elements contribute log2(1) = 0.  (The mask goes on BEFORE the logarithm: an asm statement must not
-        // read the result of a transcendental instruction directly -- gfx950 needs a wait state there that hipcc
-        // only inserts for instructions it has selected itself; log2 of the masked value feeds a plain add.)
-        ld2 += __builtin_amdgcn_logf(bfi(mb[r], 1.f, den));
+        for (int o = 0; o < OPS2; ++o) a2[o] = lds_h8(t_off + 1024 * o);
+        tb = lds_f4(bias_off + s * 128);
+        sb = lds_f4(bias_off + s * 128 + 64);
       }
-      *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
-      row_load<m>(zn);  // the same dims of the next group's row
-      __builtin_amdgcn_sched_barrier(0);  // keep the scheduler inside one tile
-      if constexpr (mi == MC - 1 || m == G - 1) {
-        hand_over(std::integral_constant<int, (c + 1) & 1>{});
+      if constexpr (s >= 2) {  // E(s - 2)
+        constexpr int m = s - 2, u = m & 1;
+        const f32x4 t4 = tc[u] * kSplitInvScale + tm[u];
+        const f32x4 s4 = sc[u] * kSplitInvScale + sm[u];
+        // binary mask: x = (1 - gate) t + (m ? z : gate z);  log_det -= (1 - m) ln(1 + e^-s)   (rnvp.py:36-37; the
+        // shift term reaches the kept elements too)
+        const i32x4 mb = mask_bits(agpr_get<kResMaskAgpr + (m >> 1)>(), std::integral_constant<int, m>{});
+        const f32x4 zv = row_read<m>();
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zz = zv[r];
+          if (kResAbl == 4) {
+            o[r] = zz + t4[r] + s4[r];
+            continue;
+          }
+          const float den = 1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f);
+          const float gate = __builtin_amdgcn_rcpf(den);
+          o[r] = __builtin_fmaf(-gate, t4[r], t4[r]) + bfi(mb[r], zz, zz * gate);
+          // kept elements contribute log2(1) = 0.  (The mask goes on BEFORE the logarithm: an asm statement must not
+          // read the result of a transcendental instruction directly -- gfx950 needs a wait state there that hipcc
+          // only inserts for instructions it has selected itself; log2 of the masked value feeds a plain add.)
+          ld2 += __builtin_amdgcn_logf(bfi(mb[r], 1.f, den));
+        }
+        if ((kResAbl != 1 && kResAbl < 6) || o[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+        if (kResAbl != 2 && kResAbl < 6) row_load<m>(zn);  // the same dims of the next group's row
+      }
+      fence();
+      if constexpr (s < G && (s % MC == MC - 1 || s == G - 1)) {  // end of chunk c (its last tile's reads are issued)
+        constexpr int c = NC1 + s / MC;
+        hand_over(std::integral_constant<int, c + 1>{});
         __syncthreads();
       }
     });
