@@ -224,18 +224,21 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
             "distributed": dist_info(world, backend, per_rank_s, args.steps),
         }
         # Algorithmic bytes per row with the in-kernel mask: read z (4d), write x (4d), log_det RMW (8).  The
-        # kernel reads z a second time for the gate epilogue (it cannot stay on chip: 410 KB per 128-row
-        # group), so its own traffic is 12d + 8.
+        # register-resident kernel moves exactly that; the streaming kernel (MNF_RNVP_RESIDENT=0) reads z a second
+        # time for the gate epilogue: 12d + 8.
         algo_bytes = (8 * dim + 8) * rows
+        resident = SPLIT and os.environ.get("MNF_RNVP_RESIDENT", "1") != "0"  # rows held in registers: z read once
         if SPLIT:  # memory-path bound (tools ablations: no MFMAs -> same time), priced against HBM
             gbs = algo_bytes / avg_s / 1e9
-            traffic, source = pmc_traffic("c5")
+            traffic, source = pmc_traffic("c5" if resident else "c5_streaming")
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                                **physical(traffic, avg_s),
-                               "kernel": "rnvp_split_kernel<50,seeded>", "avg_kernel_us": avg_s * 1e6,
+                               "kernel": ("rnvp_resident_kernel<50,50> (rows resident in the register file, z read once)"
+                                          if resident else "rnvp_split_kernel<50,seeded> (z read twice)"),
+                               "avg_kernel_us": avg_s * 1e6,
                                "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(kern_ms),
-                               "kernel_GBps_incl_second_z_read": (12 * dim + 8) * rows / avg_s / 1e9,
+                               "bytes_moved_per_launch_by_design": (8 if resident else 12) * dim * rows + 8 * rows,
                                "fp32_equivalent_tflops": tf}
         else:
             out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1,4 +1,4 @@
-"""profiles/r1/<workload>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh.
+"""profiles/rN/<workload>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh.
 usage: make_traffic_json.py <gpurun_out/prof_TAG> <workload> <kernel substring> <out.json>"""
 import csv, glob, json, os, sys
 d, workload, kern, out = sys.argv[1:5]

@@ -34,6 +34,8 @@
 
 namespace mnf {
 
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
 // experiment switches (tools/rnvp_variants.sh builds A/B libraries with them; the defaults are the product)
 #ifndef MNF_RES_KC
 #define MNF_RES_KC 4
@@ -43,10 +45,11 @@ namespace mnf {
 #endif
 #ifndef MNF_RES_ABL
 #define MNF_RES_ABL 0  // timing only, results wrong: 1 no x stores, 2 no row re-loads, 3 no MFMAs, 4 no gate math,
-                       // 5 no operand requests, 6 = 1 + 2, 7 = 1 + 2 + 5
+                       // 5 no operand requests, 6 = 1 + 2, 7 = 1 + 2 + 5, 8 stores all to the row's first 64 B,
+                       // 9 row re-loads all from the row's first 64 B, 10 = 8 + 9, 11 no chunk waits / barriers
 #endif
 #ifndef MNF_RES_SCHED
-#define MNF_RES_SCHED 1  // sched_barrier after every K-step / tile
+#define MNF_RES_SCHED 1  // sched_barrier after every n-th K-step / tile (0: none)
 #endif
 constexpr int kResWaves = 4;        // one wave per SIMD
 constexpr int kResKC = MNF_RES_KC;  // GEMM-1 K-steps (32 dims each) per operand chunk
@@ -54,17 +57,18 @@ constexpr int kResMC = MNF_RES_MC;  // GEMM-2 output tiles (16 dims each) per op
 constexpr int kResAbl = MNF_RES_ABL;
 constexpr int kResColdWords = 64;  // one bit per row group of a workgroup that has to be redone in fp32 (2,048 groups)
 
+constexpr int kResBufs = 4;     // LDS operand buffers: a chunk is requested kResBufs - 1 chunks before it is used
 template <int HN>
 struct ResShape {
   using S = RnvpSplitShape<HN>;
   static constexpr int CHUNK_WORDS =
       kResKC * S::KS1_WORDS > kResMC * S::TILE2_WORDS ? kResKC * S::KS1_WORDS : kResMC * S::TILE2_WORDS;
-  static constexpr int F32_WORDS = RnvpShape<HN, kResWaves>::CHUNK_FLOATS;  // the fp32 body's window
-  static constexpr int BUF_WORDS = CHUNK_WORDS > F32_WORDS ? CHUNK_WORDS : F32_WORDS;
-  static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kResWaves * 64 - 1) / (kResWaves * 64);
-  // LDS: two operand buffers, the fp32 biases ((bt, bs) per tile, then bn), mean / std of the sample_z prologue
+  static constexpr int F32_WORDS = 2 * RnvpShape<HN, kResWaves>::CHUNK_FLOATS;  // the fp32 body's double buffer
+  static_assert(kResBufs * CHUNK_WORDS >= F32_WORDS, "the fp32 body's window fits the operand buffers");
+  // LDS: the operand buffers, the fp32 biases ((bt, bs) per tile, then bn), mean / std of the sample_z prologue,
+  // the flags of the groups to redo in fp32
   static constexpr size_t lds_bytes(int d) {
-    return sizeof(uint32_t) * (2 * (size_t)BUF_WORDS + S::plain_words(d) + 2 * (size_t)d + kResColdWords);
+    return sizeof(uint32_t) * (kResBufs * (size_t)CHUNK_WORDS + S::plain_words(d) + 2 * (size_t)d + kResColdWords);
   }
 };
 
@@ -117,6 +121,11 @@ __device__ __forceinline__ void row_load(const float* p) {  // a[4 GRP : 4 GRP +
   asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(4 * GRP), "n"(4 * GRP + 3), "n"(64 * GRP)
                : "memory");
 }
+template <int GRP, int BYTE_OFFSET>
+__device__ __forceinline__ void row_load_at(const float* p) {  // (experiments)
+  asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(4 * GRP), "n"(4 * GRP + 3), "n"(BYTE_OFFSET)
+               : "memory");
+}
 template <int N>
 __device__ __forceinline__ void row_wait() {  // at most N vector-memory operations still in flight
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -147,6 +156,60 @@ __device__ __forceinline__ void row_write(const f32x4& v) {
                "n"(4 * GRP), "n"(4 * GRP + 1), "n"(4 * GRP + 2), "n"(4 * GRP + 3));
 }
 
+// ---- the wave's stream of vector-memory operations per row group, known at compile time (the waits are counted):
+//   GEMM-1 slot k :  [k % KC == 0: the LDS-DMA pieces of chunk c + D]
+//   GEMM-2 slot s :  [s % MC == 0: the pieces of chunk c + D]  [s >= 2: store x of tile s - 2, load of its next row]
+// (the log_det update at the end of a group is not counted: the counts are lower bounds of what is in flight)
+template <int HN, int G>
+struct ResPlan {
+  using S = RnvpSplitShape<HN>;
+  static constexpr int KC = kResKC, MC = kResMC, D = kResBufs - 1;
+  static constexpr int NKS1 = (G + 1) / 2;
+  static constexpr int NC1 = (NKS1 + KC - 1) / KC, NC2 = (G + MC - 1) / MC, NC = NC1 + NC2;
+  // 1 KB LDS-DMA pieces per wave that fetch chunk c (the last chunk of either GEMM may be short)
+  static constexpr int chunk_pieces(int c) {
+    c %= NC;
+    const int words = c < NC1 ? ((NKS1 - c * KC) < KC ? (NKS1 - c * KC) : KC) * S::KS1_WORDS
+                              : ((G - (c - NC1) * MC) < MC ? (G - (c - NC1) * MC) : MC) * S::TILE2_WORDS;
+    return words / 256 / kResWaves;
+  }
+  // operations issued from the start of a group up to: the end of the request block of GEMM-1 slot k ...
+  static constexpr int ops_g1(int k) {
+    int n = 0;
+    for (int kk = 0; kk <= k && kk < NKS1; kk += KC) n += chunk_pieces(kk / KC + D);
+    return n;
+  }
+  // ... the end of the request block of GEMM-2 slot s (before its epilogue's store) ...
+  static constexpr int ops_g2(int s) {
+    int n = ops_g1(NKS1);
+    for (int ss = 0; ss <= s && ss < G; ss += MC) n += chunk_pieces(NC1 + ss / MC + D);
+    return n + 2 * (s - 2 > 0 ? s - 2 : 0);  // epilogues of slots 2 .. s - 1
+  }
+  static constexpr int ops_group() { return ops_g2(G + 1) + 2; }
+  // ... and after the row load of tile m (slot m + 2)
+  static constexpr int ops_after_rowload(int m) { return ops_g2(m + 2) + 2; }
+  // operations issued by the end of chunk e (e < NC1: GEMM 1; else GEMM 2, its last slot's epilogue included)
+  static constexpr int ops_chunk_end(int e) {
+    if (e < NC1) return ops_g1(((e + 1) * KC < NKS1 ? (e + 1) * KC : NKS1) - 1);
+    const int s = ((e - NC1 + 1) * MC < G ? (e - NC1 + 1) * MC : G) - 1;
+    return ops_g2(s) + (s >= 2 ? 2 : 0);
+  }
+  // operations issued by the end of the request block at the top of chunk c
+  static constexpr int ops_chunk_top(int c) { return c < NC1 ? ops_g1(c * KC) : ops_g2((c - NC1) * MC); }
+  // in flight behind the pieces of chunk e + 1 at the end of chunk e (they were requested at the top of chunk
+  // e + 1 - D, possibly in the previous group)
+  static constexpr int dma_wait_count(int e) {
+    const int top = e + 1 - D;
+    const int n = top >= 0 ? ops_chunk_end(e) - ops_chunk_top(top) : ops_chunk_end(e) + ops_group() - ops_chunk_top(top + NC);
+    return n < 63 ? n : 63;
+  }
+  // in flight behind the row load of group g (issued by the previous row group) when GEMM-1 slot k wants it
+  static constexpr int row_wait_count(int g, int k) {
+    const int n = ops_group() - ops_after_rowload(g) + ops_g1(k);
+    return n < 63 ? n : 63;
+  }
+};
+
 template <int HN, int G, bool SAMPLE>
 __global__ void __launch_bounds__(kResWaves * 64, 1)
 rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* __restrict__ log_det,
@@ -163,26 +226,16 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   static_assert(4 * G <= kResAgprs && (G + 1) / 2 <= 32, "resident rows and mask words fit the reserved registers");
   reserve_agprs();
   constexpr int GROUP_ROWS = 16 * kResWaves;
-  constexpr int NSTAGE = R::STAGE_U4;  // uint4 per thread per (full) operand chunk
+  constexpr int NB = kResBufs, D = NB - 1;
+  static_assert(NC % NB == 0, "the operand ring keeps its buffer assignment from one row group to the next");
   constexpr int OPS1 = 2 * YT, OPS2 = 4 * NKS2;  // 1 KB A operands per GEMM-1 K-step / per GEMM-2 tile
-  // loads per thread that fetch chunk c (the last chunk of either GEMM may be short; whole 4 KB pieces)
-  auto chunk_loads = [](int c) constexpr -> int {
-    const int words = c < NC1 ? ((NKS1 - c * KC) < KC ? (NKS1 - c * KC) : KC) * S::KS1_WORDS
-                              : ((G - (c - NC1) * MC) < MC ? (G - (c - NC1) * MC) : MC) * S::TILE2_WORDS;
-    return (words / 4 + kResWaves * 64 - 1) / (kResWaves * 64);
-  };
-  // operand loads issued at the tops of GEMM-1 chunks 0 .. c (each requests chunk c' + 2)
-  auto loads_since_rows = [chunk_loads](int c) constexpr -> int {
-    int n = 0;
-    for (int k = 0; k <= c; ++k) n += chunk_loads((k + 2) % NC);
-    return n;
-  };
-  static_assert(S::KS1_WORDS % (kResWaves * 64 * 4) == 0 && S::TILE2_WORDS % (kResWaves * 64 * 4) == 0,
-                "chunks are whole 4 KB pieces (one uint4 per thread)");
+  using P = ResPlan<HN, G>;
+  static_assert(S::KS1_WORDS % (256 * kResWaves) == 0 && S::TILE2_WORDS % (256 * kResWaves) == 0,
+                "every wave copies the same number of 1 KB pieces of a chunk");
 
-  // LDS: [two operand buffers][(bt | bs) per tile, then bn][mean | std of the sample_z prologue][cold-group flags]
+  // LDS: [NB operand buffers][(bt | bs) per tile, then bn][mean | std of the sample_z prologue][cold-group flags]
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  float* const bias_lds = reinterpret_cast<float*>(lds_dyn + 2 * R::BUF_WORDS);
+  float* const bias_lds = reinterpret_cast<float*>(lds_dyn + NB * R::CHUNK_WORDS);
   float* const zprm_lds = bias_lds + S::plain_words(d);
   uint32_t* const cold_flags = reinterpret_cast<uint32_t*>(zprm_lds + 2 * d);  // kResColdWords words
 
@@ -209,9 +262,16 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   // byte offsets of the LDS regions as opaque registers: every LDS access below is then one of these + an
   // instruction immediate (left constant, hipcc materialises one address register per access for the regions above
   // 64 KB -- the limit of the immediate -- and hoists all of them out of the group loop)
-  uint32_t bias_off = 2 * R::BUF_WORDS * 4 + q * 16, buf_off0 = lane * 16, buf_off1 = R::BUF_WORDS * 4 + lane * 16;
-  uint32_t zprm_off = (2 * R::BUF_WORDS + (uint32_t)S::plain_words(d)) * 4 + q * 16;
-  asm volatile("" : "+v"(bias_off), "+v"(buf_off0), "+v"(buf_off1), "+v"(zprm_off));
+  uint32_t bias_off = NB * R::CHUNK_WORDS * 4 + q * 16, buf_off = lane * 16;
+  uint32_t zprm_off = (NB * R::CHUNK_WORDS + (uint32_t)S::plain_words(d)) * 4 + q * 16;
+  asm volatile("" : "+v"(bias_off), "+v"(buf_off), "+v"(zprm_off));
+  // (a second base for the upper buffers: the immediate of an LDS instruction ends at 64 KB)
+  uint32_t buf_off_hi = buf_off + 2 * R::CHUNK_WORDS * 4;
+  asm volatile("" : "+v"(buf_off_hi));
+  auto buf_base = [&](int c) -> uint32_t {  // byte offset of this lane's 16 bytes in the buffer of chunk c
+    const int u = c % NB;
+    return u < 2 ? buf_off + u * (R::CHUNK_WORDS * 4) : buf_off_hi + (u - 2) * (R::CHUNK_WORDS * 4);
+  };
   auto lds_f4 = [&](uint32_t byte_off) -> f32x4 {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds_dyn) + byte_off);
   };
@@ -220,33 +280,37 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   };
 
   // ---- operand ring.  Chunk c (mod NC) of the image: GEMM-1 K-steps for c < NC1, GEMM-2 tiles after.  The chunks
-  // do not depend on the rows, so the ring runs on across row groups.  At the top of chunk c the wave requests chunk
-  // c + 2 into register set c & 1; at the end of chunk c it writes chunk c + 1 (set (c + 1) & 1, requested a whole
-  // chunk earlier) into LDS buffer (c + 1) & 1 and meets the others at the chunk's one barrier.  Two chunks of
-  // distance, because vector-memory operations complete in order: waiting for an operand load also waits for every
-  // row load and store issued before it, and those need a couple of microseconds under load.
-  u32x4 st[2][NSTAGE];
+  // do not depend on the rows, so the ring runs on across row groups.  At the top of chunk c the wave requests its
+  // pieces of chunk c + D by LDS-DMA (global_load_lds_dwordx4: L2 -> LDS, no staging registers) into buffer
+  // (c + D) % NB -- last read during chunk c - 1, which every wave has left --; at the end of chunk c it waits until
+  // its pieces of chunk c + 1 have landed and meets the others at the chunk's one barrier.  Vector-memory operations
+  // complete in issue order and the wait is a count of operations still in flight, so it is exact only if every
+  // operation of the loop is accounted for (dma_wait_count): a wait that is stricter than necessary makes the wave
+  // stand until row loads and stores issued long after the pieces have completed too -- a couple of microseconds each
+  // under load -- and with it the three other waves at the barrier.
   uint32_t img_off = 0;  // always 0, but opaque and re-declared at the top of every row group: see there
-  uint32_t toff[NSTAGE];  // byte offset of this thread's i-th uint4 inside a chunk
-#pragma unroll
-  for (int i = 0; i < NSTAGE; ++i) toff[i] = (threadIdx.x + i * (kResWaves * 64)) * 16u;
   auto request = [&](auto cc) {
-    constexpr int c = decltype(cc)::value % NC, u = decltype(cc)::value & 1;
+    constexpr int c = decltype(cc)::value % NC;
     constexpr int64_t word0 = c < NC1 ? (int64_t)c * KC * S::KS1_WORDS
                                       : S::part1_words(d) + (int64_t)(c - NC1) * MC * S::TILE2_WORDS;
-    const char* src = reinterpret_cast<const char*>(simage + word0) + img_off;  // wave-uniform
+    const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(simage + word0) + img_off) + lane;
+    uint32_t* dst = lds_dyn + (c % NB) * R::CHUNK_WORDS;
+    if (kResAbl != 5 && kResAbl != 7) {
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i)
-      if (i < chunk_loads(c) && kResAbl != 5 && kResAbl != 7) st[u][i] = *reinterpret_cast<const u32x4*>(src + toff[i]);
+      for (int i = 0; i < P::chunk_pieces(c); ++i) {
+        const int piece = i * kResWaves + wave;  // wave-uniform
+        __builtin_amdgcn_global_load_lds(src + piece * 64, (lds_void_ptr)(dst + piece * 256), 16, 0, 0);
+      }
+    }
+    asm volatile("" ::: "memory");  // (keeps the stores of the epilogue behind the pieces: the counts assume it)
   };
-  auto hand_over = [&](auto cc) {  // register set u -> LDS buffer u (whole chunk; a short last chunk copies padding)
-    constexpr int u = decltype(cc)::value & 1;
-#pragma unroll
-    for (int i = 0; i < NSTAGE; ++i)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_dyn) + u * (R::BUF_WORDS * 4) + toff[i]) = st[u][i];
+  auto landed = [&](auto ec) {  // end of chunk e: this wave's pieces of chunk e + 1 are in LDS
+    constexpr int e = decltype(ec)::value;
+    if (kResAbl != 11 && kResAbl != 13) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::dma_wait_count(e)) : "memory");
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
+  auto chunk_barrier = [] {
+    if (kResAbl != 11 && kResAbl != 13) __syncthreads();
+  };
 
   auto mfma3 = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
     if (kResAbl == 3) {
@@ -278,8 +342,8 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
     return r;
   };
-  auto fence = [] {
-    if (MNF_RES_SCHED) __builtin_amdgcn_sched_barrier(0);
+  auto fence = [](int slot) {  // MNF_RES_SCHED = n: the scheduler may mix n consecutive slots (0: everything)
+    if (MNF_RES_SCHED && (slot + 1) % MNF_RES_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
   };
   // resident rows: a[4 g : 4 g + 3] of lane (j, q) holds dims 16 g + 4 q .. + 3 of row j of the wave's 16 rows
   // their mask words (32 dims each, pre-shifted by 4 q): a[208 + k]
@@ -309,16 +373,18 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       const int64_t rn = (int64_t)(grp + (int)gridDim.x) * GROUP_ROWS + wave * 16 + j;
       zn = z + (has_next ? (rn < rows ? rn : rows - 1) : 0) * d + 4 * q;
     }
-    if (!primed) {  // the only exposed loads: operand chunks 0 and 1, then the group's rows
+    if (!primed) {  // the only exposed loads: operand chunks 0 .. D - 1, then the group's rows
       __syncthreads();  // (the previous group may still be reading the buffers)
-      request(I0{});
-      request(I1{});
-      hand_over(I0{});
+      static_for<D>([&](auto cc) { request(cc); });
       const float* zq = z + rowc * d + 4 * q;
       static_for<G>([&](auto gc) { row_load<decltype(gc)::value>(zq); });
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everything has landed: the counted waits below assume
+      __syncthreads();                                   // the steady state, where MORE is in flight behind a load
       primed = true;
     }
+    // log_det of the rows, read early: its wait must not be the one that drains the loop's loads at the end
+    float ld_prev = 0.f;
+    if (accumulate && q == 0) ld_prev = log_det[row];
 
     // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step.  Software pipeline, one K-step per
     // slot (one wave per SIMD: nothing else hides a latency): slot k issues the MFMAs of K-step k - 1 (operands read
@@ -342,18 +408,17 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       }
       if constexpr (k < NKS1) {  // R(k): into the registers the MFMAs above have just been issued from
         constexpr int c = k / KC, kk = k % KC;
-        if constexpr (kk == 0) request(std::integral_constant<int, c + 2>{});
-        const uint32_t a_off = ((c & 1) ? buf_off1 : buf_off0) + kk * (S::KS1_WORDS * 4);  // operand o at + 1024 o
+        if constexpr (kk == 0) request(std::integral_constant<int, c + D>{});
+        const uint32_t a_off = buf_base(c) + kk * (S::KS1_WORDS * 4);  // operand o at + 1024 o
 #pragma unroll
         for (int o = 0; o < OPS1; ++o) a1[o] = lds_h8(a_off + 1024 * o);
       }
       if constexpr (k < NKS1) {  // P(k)
         constexpr int c = k / KC;
         constexpr int g0 = 2 * k, g1 = 2 * k + 1 < G ? 2 * k + 1 : 2 * k;
-        // rows: groups g0, g1 have landed once at most this many vector-memory operations are in flight -- the row
-        // loads issued after them (groups g1 + 1 .. G - 1) and the operand requests issued since (tops of chunks 0..c)
-        constexpr int n_after = (G - 1 - g1) + loads_since_rows(c);
-        row_wait<(n_after < 63 ? n_after : 63)>();
+        // rows: groups g0, g1 have landed once at most this many vector-memory operations are in flight (everything
+        // the previous group's epilogue issued after the load of group g1, and this group's requests so far)
+        if (kResAbl != 12 && kResAbl != 13) row_wait<P::row_wait_count(g1, k)>();
         f32x4 v0 = row_read<g0>(), v1 = row_read<g1>();
         if constexpr (SAMPLE) {  // the sample_z prologue, once per row: z = q0_mean + q0_std * eps, kept for the epilogue
           v0 = v0 * lds_f4(zprm_off + (d + 16 * g0) * 4) + lds_f4(zprm_off + 16 * g0 * 4);
@@ -371,10 +436,10 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
         if constexpr (g1 != g0) split_tile(and_bits(v1, mask_bits(mwk, std::integral_constant<int, g1>{})), h1, l1, mx);
         b1h = pair_operand(h0, h1);
         b1l = pair_operand(l0, l1);
-        fence();
+        fence(k);
         if constexpr (k % KC == KC - 1 || k == NKS1 - 1) {  // end of chunk c
-          hand_over(std::integral_constant<int, c + 1>{});
-          if constexpr (k < NKS1 - 1) __syncthreads();  // (the last chunk's barrier is the verdict below)
+          landed(std::integral_constant<int, c>{});
+          if constexpr (k < NKS1 - 1) chunk_barrier();  // (the last chunk's barrier is the verdict below)
         }
       }
     });
@@ -382,7 +447,7 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     u32x2 yh[YT], yl[YT];
 #pragma unroll
     for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
-    if (__syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0)) {  // nothing has been stored yet
+    if (__syncthreads_or(!(mx <= kSplitLimit) && kResAbl == 0 ? 1 : 0)) {  // nothing has been stored yet
       if (threadIdx.x == 0) cold_flags[it >> 5] |= 1u << (it & 31);
       primed = false;
       continue;
@@ -417,8 +482,8 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       }
       if constexpr (s < G) {  // R(s): into the registers the MFMAs above have just been issued from
         constexpr int c = NC1 + s / MC, mi = s % MC;
-        if constexpr (mi == 0) request(std::integral_constant<int, c + 2>{});
-        const uint32_t t_off = ((c & 1) ? buf_off1 : buf_off0) + mi * (S::TILE2_WORDS * 4);  // operand o at + 1024 o
+        if constexpr (mi == 0) request(std::integral_constant<int, c + D>{});
+        const uint32_t t_off = buf_base(c) + mi * (S::TILE2_WORDS * 4);  // operand o at + 1024 o
 #pragma unroll
         for (int o = 0; o < OPS2; ++o) a2[o] = lds_h8(t_off + 1024 * o);
         tb = lds_f4(bias_off + s * 128);
@@ -448,19 +513,21 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
           // only inserts for instructions it has selected itself; log2 of the masked value feeds a plain add.)
           ld2 += __builtin_amdgcn_logf(bfi(mb[r], 1.f, den));
         }
-        if ((kResAbl != 1 && kResAbl < 6) || o[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
-        if (kResAbl != 2 && kResAbl < 6) row_load<m>(zn);  // the same dims of the next group's row
+        if (kResAbl == 8 || kResAbl == 10) *reinterpret_cast<f32x4*>(xr) = o;
+        else if ((kResAbl != 1 && kResAbl != 6 && kResAbl != 7) || o[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(xr + 16 * m) = o;
+        if (kResAbl == 9 || kResAbl == 10) row_load_at<m, 0>(zn);
+        else if (kResAbl != 2 && kResAbl != 6 && kResAbl != 7) row_load<m>(zn);  // the same dims of the next group's row
       }
-      fence();
+      fence(s);
       if constexpr (s < G && (s % MC == MC - 1 || s == G - 1)) {  // end of chunk c (its last tile's reads are issued)
         constexpr int c = NC1 + s / MC;
-        hand_over(std::integral_constant<int, c + 1>{});
-        __syncthreads();
+        landed(std::integral_constant<int, c>{});
+        chunk_barrier();
       }
     });
     {  // (log_det is never null here: a conditional use would let the compiler sink the 4 G adds of ld2 down to it)
       const float ld = sum_over_q(-0.693147180559945309f * ld2);
-      if (q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+      if (q == 0) log_det[row] = ld_prev + ld;
     }
   }
   // the flagged groups, on the fp32 MFMA body (reads its rows from memory itself)
