@@ -225,3 +225,180 @@ def test_sample_z_on_the_resident_kernel(amd, O):
     z_ref, ld_ref = O.sample_z(layer.q0_mean.detach().cpu(), layer.q0_log_var.detach().cpu(), eps, specs)
     assert_close(z, z_ref, RTOL, "z")
     assert_close(ld, ld_ref, RTOL, "log_det")
+
+
+# ------------------------------------------------------------------ seeded fuzz slice (tools/fuzz_shapes.py, promoted)
+def f64(sd):
+    return {k: v.double() for k, v in sd.items()}
+
+
+def rel(a, b):
+    return normwise_err(a.detach().double().cpu().numpy(), b.numpy())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_seeded_fuzz_slice_against_float64(amd, O, seed):
+    """A fixed-seed slice of tools/fuzz_shapes.py inside the driver-run suite: random shapes on the MFMA kernels
+    (AffineHalfFlow runs of 1-4 layers with any even d <= 256, any three hidden widths <= 32, NICE / no-shift; RNVP
+    49 <= d <= 900, any hidden <= 50; NSF_CL d in {32, 64}, K in {5, 8}, any n_h <= 16), every draw against the oracle
+    evaluated in FLOAT64 at the plain 1e-5 normwise bar -- no draw may exceed it (round 1 had one: a one-unit hidden
+    layer on the split path, now routed to the fp32 MFMA kernels)."""
+    rng = np.random.default_rng(1000 + seed)
+    torch.manual_seed(seed)
+    worst = 0.0
+    for case in range(150):
+        u = rng.random()
+        if u < 0.2:
+            dim, K, n_h = int(rng.choice([32, 64])), int(rng.choice([5, 8])), int(rng.integers(1, 17))
+            if dim == 64 and K == 5 and n_h > 8:
+                n_h = 8
+            rows, inverse = int(rng.integers(1, 1500)), bool(rng.integers(0, 2))
+            sd = recipes.nsf_cl_params(int(rng.integers(1 << 30)), dim, K, n_h)
+            f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+            f.load_state_dict(sd)
+            f.to(DEV)
+            x = torch.randn(rows, dim) * 1.5
+            with torch.no_grad():
+                y, ld = (f.inverse if inverse else f.forward)(x.to(DEV))
+            y64, ld64 = O.nsf_cl(x.double(), f64(sd), K, 3.0, inverse)
+            y32, ld32 = O.nsf_cl(x, sd, K, 3.0, inverse)
+            # the spline's bin search is discontinuous in rounding: an element a few ulps from a knot lands in the
+            # neighbouring bin in one fp32 evaluation and not in another.  Budget as in helpers.assert_parity: 1e-5 +
+            # twice the fp32 oracle's own distance from float64 on this draw.
+            budget_y = RTOL + 2 * normwise_err(y32.numpy(), y64.numpy())
+            budget_ld = RTOL + 2 * normwise_err(ld32.numpy(), ld64.numpy())
+            assert rel(y, y64) <= budget_y and rel(ld, ld64) <= budget_ld, (case, "nsf", dim, K, n_h, rows, inverse)
+            continue
+        if u < 0.8:
+            dim = int(rng.integers(1, 129)) * 2
+            h = tuple(int(v) for v in rng.integers(1, 33, size=3)) if rng.random() < 0.6 else (24, 24, 24)
+            if dim > 128 and (max(h) > 24 or max(h) <= 16):
+                h = (24, 24, 24)
+            kw = {}
+            r = rng.random()
+            if r < 0.15:
+                kw["scale"] = False
+            elif r < 0.3:
+                kw["shift"] = False
+            n_layers, rows, inverse = int(rng.integers(1, 5)), int(rng.integers(1, 3000)), bool(rng.integers(0, 2))
+            flows, specs = [], []
+            for i in range(n_layers):
+                parity = bool(rng.integers(0, 2))
+                sd = recipes.affine_half_params(int(rng.integers(1 << 30)), dim, h_sizes=h, s_last_gain=1.5, **kw)
+                f = amd.AffineHalfFlow(dim, parity, h_sizes=h, **kw)
+                f.load_state_dict(sd)
+                flows.append(f)
+                specs.append({"kind": "affine_half", "parity": parity, "params": f64(sd), **kw})
+            model = amd.NormalizingFlow(flows).to(DEV)
+            x = torch.randn(rows, dim) * float(rng.choice([0.1, 1.0, 3.0]))
+            with torch.no_grad():
+                zs, ld = (model.inverse if inverse else model.forward)(x.to(DEV))
+            z64, ld64 = O.flow_stack(x.double(), specs, inverse)
+            if not (torch.isfinite(z64[-1]).all() and torch.isfinite(ld64).all()):
+                continue  # the draw overflows in float64 too
+            e = max(rel(zs[-1], z64[-1]), rel(ld, ld64))
+            worst = max(worst, e)
+            assert e <= RTOL, (case, "ahf", dim, h, kw, n_layers, rows, inverse, e)
+            continue
+        dim, hid, rows = int(rng.integers(49, 901)), int(rng.integers(1, 51)), int(rng.integers(1, 2000))
+        sd = recipes.rnvp_params(int(rng.integers(1 << 30)), dim, hid)
+        f = amd.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(sd)
+        f.to(DEV)
+        z = torch.randn(rows, dim)
+        s = int(rng.integers(1 << 40))
+        with torch.no_grad():
+            x1, l1 = f.forward(z.to(DEV), seed=s)
+            mask = f.mask_for(s, rows).cpu()
+        x64, l64 = O.rnvp(z.double(), f64(sd), mask.double())
+        e = max(rel(x1, x64), rel(l1, l64))
+        worst = max(worst, e)
+        assert e <= RTOL, (case, "rnvp", dim, hid, rows, e)
+    assert worst > 0.0
+
+
+def test_narrow_hidden_layers_take_the_fp32_kernels(amd, O):
+    """The round-1 fuzz draw that ended 1.2e-5 from float64 on the split path: three layers through a ONE-unit hidden
+    layer, inputs scaled by 3.  Such conditioners now run on the fp32 MFMA kernels by themselves (_MIN_SPLIT_HIDDEN)."""
+    dim, h = 64, (20, 1, 9)
+    flows, specs = [], []
+    for i in range(3):
+        sd = recipes.affine_half_params(7000 + i, dim, h_sizes=h, s_last_gain=1.5)
+        f = amd.AffineHalfFlow(dim, bool(i % 2), h_sizes=h)
+        f.load_state_dict(sd)
+        flows.append(f)
+        specs.append({"kind": "affine_half", "parity": bool(i % 2), "params": f64(sd)})
+    model = amd.NormalizingFlow(flows).to(DEV)
+    assert all(f._split_image(torch.device(DEV, 0)) is None and f._packed(torch.device(DEV, 0))[1] is not None
+               for f in flows)
+    x = recipes.gaussian(7003, 2000, dim, scale=3.0)
+    with torch.no_grad():
+        zs, ld = model.forward(x.to(DEV))
+    z64, ld64 = O.flow_stack(x.double(), specs, False)
+    assert rel(zs[-1], z64[-1]) <= RTOL and rel(ld, ld64) <= RTOL
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] / [4] at full size
+def test_c4_full_size_properties(amd, O):
+    """BASELINE configs[3], one GPU's shard at full size (2^19 x 256, 9 layers, 4.8 GB of intermediates; the 8-wave
+    wide stack kernel with a persistent grid that wraps): the same checks as test_c2_full_size_properties."""
+    dim, rows = 256, 1 << 19
+    model, specs = ahf_stack(amd, dim, 9)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(rows, dim, device=DEV, generator=g)
+    with torch.no_grad():
+        zs, ld = model.inverse(x)
+        assert len(zs) == 10 and torch.isfinite(zs[-1]).all() and torch.isfinite(ld).all()
+        z_last = zs[-1].clone()
+        mids = [z[:: rows // 2048][:2048].cpu() for z in zs]  # a 2,048-row slice of every intermediate
+        del zs
+        xs, ld_f = model.forward(z_last)
+        # forward(inverse(x)) == x ; the two log-dets cancel
+        assert float((xs[-1] - x).abs().max()) <= 5e-4 * float(x.abs().max())
+        assert float((ld + ld_f).abs().max()) <= 2e-4 * float(ld.abs().max())
+        del xs
+        # the slice against the oracle: every intermediate tensor and log_det
+        sel = torch.arange(0, rows, rows // 2048, device=DEV)[:2048]
+        ref_zs, ref_ld = O.flow_stack(x[sel].cpu(), specs, True)
+        for i, (a, b) in enumerate(zip(mids, ref_zs)):
+            assert_close(a, b, RTOL, f"intermediate {i}")
+        assert_close(ld[sel], ref_ld, RTOL, "log_det slice")
+        # log-prob: fused epilogue, fp64 sum identity over the whole shard, slice mean vs the oracle
+        lp_all, total_all = model.log_prob(x, return_sum=True)
+        assert model._logprob_done
+        assert abs(float(total_all.item()) - float(lp_all.double().sum())) <= 1e-9 * abs(float(total_all.item()))
+        ref_mean, ref_lp = O.mean_log_prob(x[sel].cpu(), specs)
+        assert_close(lp_all[sel], ref_lp, RTOL, "log_prob slice")
+        # the split stack kernel == layer-by-layer launches on the full shard (last tensor, log_det)
+        model.fuse_affine_runs = False
+        zs_u, ld_u = model.inverse(x)
+        assert_close(zs_u[-1][sel], z_last[sel], 1e-6, "run fusion vs layer by layer")
+        assert_close(ld_u[sel], ld[sel], 1e-6, "run fusion vs layer by layer (log_det)")
+
+
+def test_c5_full_size_sample_z(amd, O):
+    """BASELINE configs[4] at full size: MNFLinear(800, 50).sample_z on 512 x 500 = 256,000 rows with the in-kernel
+    masks (the register-resident RNVP kernel, prologue fused): finite everywhere, a 4,096-row slice spread over the
+    batch against the oracle (masks materialised from the same seeds), and MNFLinear(50, 10)'s ragged flow too."""
+    rows = 512 * 500
+    for n_in, n_out in ((800, 50), (50, 10)):
+        layer = amd.MNFLinear(n_in, n_out)
+        for i, fl in enumerate(layer.flow_q.flows):
+            fl.load_state_dict(recipes.rnvp_params(800 + i, n_in, 50))
+        layer.to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        eps = torch.randn(rows, n_in, device=DEV, generator=g)
+        torch.manual_seed(4242)
+        with torch.no_grad():
+            z, ld = layer.sample_z(rows, eps=eps)
+            assert z.shape == (rows, n_in) and ld.shape == (rows,)
+            assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+            torch.manual_seed(4242)
+            seeds = [int(torch.empty((), dtype=torch.int64).random_().item()) for _ in layer.flow_q.flows]
+            sel = torch.arange(0, rows, rows // 4096, device=DEV)[:4096]
+            masks = [fl.mask_for(s, rows)[sel].cpu() for fl, s in zip(layer.flow_q.flows, seeds)]
+        specs = [{"kind": "rnvp", "params": recipes.rnvp_params(800 + i, n_in, 50), "mask": masks[i]} for i in range(2)]
+        z_ref, ld_ref = O.sample_z(layer.q0_mean.detach().cpu(), layer.q0_log_var.detach().cpu(), eps[sel].cpu(), specs)
+        assert_close(z[sel], z_ref, RTOL, f"z ({n_in})")
+        assert_close(ld[sel], ld_ref, RTOL, f"log_det ({n_in})")
+        del z, ld, eps

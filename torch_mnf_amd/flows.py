@@ -71,6 +71,17 @@ def _require_mlp(*nets: nn.Module) -> None:
                 f"got {type(net).__name__}" + (f" with slopes {[a.negative_slope for a in acts]}" if acts else ""))
 
 
+# The split (f16 hi + lo) kernels carry ~22 bits per product (csrc/mnf_split.h).  In sums over 16-32 terms that
+# averages out to 1-2e-7; through a hidden layer of one or two units a sum IS one or two products, and a few exp(s)
+# later the result can sit 1e-5 from float64 (seeded fuzz, round 1: 1.2e-5 with a one-unit layer).  Conditioners with a
+# hidden layer narrower than this run on the fp32 MFMA kernels instead.
+_MIN_SPLIT_HIDDEN = 4
+
+
+def _narrow_hidden(h_sizes) -> bool:
+    return len(h_sizes) > 0 and min(h_sizes) < _MIN_SPLIT_HIDDEN
+
+
 def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -333,6 +344,9 @@ class _HipFlow(nn.Module):
         self._split_index = None           # (device int32 table, n_split_words, n_plain_words) or False
         self.force_generic = False  # tests: run the generic kernel even if an MFMA one exists
         self.force_fp32_mfma = False  # tests / MNF_FP32_MFMA=1: fp32 MFMA kernel instead of the split one
+        # False: this conditioner always takes the fp32 MFMA kernels (set by layers whose hidden layers are so narrow
+        # that a product sum has too few terms to average the split format's 2^-22 per product out, see _narrow_hidden)
+        self._split_ok = True
 
     def invalidate(self) -> None:
         """Drop the packed operand images; the next call repacks them from the parameters.
@@ -373,7 +387,7 @@ class _HipFlow(nn.Module):
 
     def _split_image(self, device: torch.device) -> Tensor | None:
         """The split operand image for the current parameters, or None (no split kernel / switched off)."""
-        if self.force_fp32_mfma or _FP32_MFMA_ENV:
+        if self.force_fp32_mfma or _FP32_MFMA_ENV or not self._split_ok:
             return None
         self._packed(device)
         return self._split
@@ -382,7 +396,7 @@ class _HipFlow(nn.Module):
         """(flat, image, split image) with ONE walk over the parameters (the walk is what a small-batch call
         spends its host time on)."""
         flat, image = self._packed(device)
-        return flat, image, (None if (self.force_fp32_mfma or _FP32_MFMA_ENV) else self._split)
+        return flat, image, (None if (self.force_fp32_mfma or _FP32_MFMA_ENV or not self._split_ok) else self._split)
 
     def _device_index(self, device: torch.device) -> Tensor | None:
         """Device copy of the fp32 operand-image index table (built once), or None."""
@@ -462,6 +476,7 @@ class AffineHalfFlow(_TwoWayFlow):
         if shift:
             self.t_net = MLP(dim // 2, *self.h_sizes, dim // 2)
         self._hid = _lib.int_array(self.h_sizes)
+        self._split_ok = not _narrow_hidden(self.h_sizes)
 
     def _packed_params(self) -> list[Tensor]:
         return self._net_params(([self.s_net] if self.scale else []) + ([self.t_net] if self.shift else []))
@@ -556,6 +571,7 @@ class NSF_CL(_TwoWayFlow):
         sizes = self.f1.layer_sizes
         self.h_sizes = tuple(int(s) for s in sizes[1:-1])
         self._hid = _lib.int_array(self.h_sizes)
+        self._split_ok = not _narrow_hidden(self.h_sizes)
 
     def _packed_params(self) -> list[Tensor]:
         return self._net_params([self.f1, self.f2])
@@ -1043,7 +1059,8 @@ class _AffineRun:
         """(fp32 operand images, split operand images) of all layers, back to back; repacked after a weight update
         with ONE parameter concatenation (``flat``: the caller's, if it already has one) and one launch per kind."""
         params = self._params()
-        key = (device, [f.force_fp32_mfma for f in self.layers], [(p.data_ptr(), p._version) for p in params])
+        key = (device, [f.force_fp32_mfma or not f._split_ok for f in self.layers],
+               [(p.data_ptr(), p._version) for p in params])
         if key != self._key:
             f0, n = self.layers[0], len(self.layers)
             index = f0._device_index(device)
@@ -1060,7 +1077,7 @@ class _AffineRun:
                 _lib.check("mnf_pack_gather_batch", lib.mnf_pack_gather_batch(
                     flat.data_ptr(), index.data_ptr(), self._images.data_ptr(), index.numel(), n, stride, _stream()))
                 sidx = f0._device_split_index(device)
-                if sidx and not _FP32_MFMA_ENV and not any(f.force_fp32_mfma for f in self.layers):
+                if sidx and not _FP32_MFMA_ENV and not any(f.force_fp32_mfma or not f._split_ok for f in self.layers):
                     table, n_split, n_plain = sidx
                     self._splits = torch.empty(n * (n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS), dtype=torch.int32,
                                                device=device)
