@@ -15,6 +15,7 @@
  *   mnf_gauss_logprob(_sq) base.log_prob + the callers' mean    torch_mnf/flows/core.py:46-49,
  *                                                               examples/half_moons.ipynb:183-186
  *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
+ *   mnf_mnf_linear_fwd   MNFLinear.forward behind sample_z      torch_mnf/layers/mnf_linear.py:46-56
  *   log_det accumulation NormalizingFlow.forward / .inverse     torch_mnf/flows/core.py:17-35
  *                        (the `accumulate` flag of every layer entry point: log_det += ld)
  *
@@ -56,7 +57,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 4
+#define MNF_ABI_VERSION 5
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -260,6 +261,22 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
 /* z0 = q0_mean + exp(q0_log_var)^(1/2) * eps   (rows, dim); mean, log_var: (dim,). */
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
                   int64_t rows, int dim, void* stream);
+
+/* ------------------------------------------------ MNFLinear.forward behind the flow path
+ * torch_mnf/layers/mnf_linear.py:46-56 with z (rows, n_in) = what sample_z's last flow wrote:
+ *   out = (x * z) W_mean^T + b_mean + sqrt(x^2 exp(W_log_var)^T + exp(b_log_var)) * eps       (rows, n_out), n_out <= 64
+ * one pass, x and z read once.  eps (rows, n_out): the layer's N(0,1) noise, or NULL to have it
+ * generated in-kernel from `seed` (mnf_mnf_linear_noise writes exactly those numbers).
+ * flat (device): W_mean (n_out, n_in) | exp(W_log_var) * var_scale (n_out, n_in) | b_mean (n_out) | exp(b_log_var)
+ * (n_out); var_scale a power of two that brings exp(W_log_var) into the f16 normal range, var_unscale = 1 / var_scale.
+ * split_image: mnf_pack_gather_split of `flat` through the table of mnf_mnf_linear_split_index.
+ * workspace: (rows + 127) / 128 int32 (written by the call: 128-row groups recomputed in fp32 by its fix-up launch). */
+int mnf_mnf_linear_split_layout(int n_in, int n_out, int64_t* n_split_words, int64_t* n_plain_words);
+int mnf_mnf_linear_split_index(int n_in, int n_out, int32_t* idx_host);
+int mnf_mnf_linear_fwd(const float* x, const float* z, const float* eps, uint64_t seed, float* out, const float* flat,
+                       const void* split_image, float var_unscale, int32_t* workspace, int64_t rows, int n_in, int n_out,
+                       void* stream);
+int mnf_mnf_linear_noise(uint64_t seed, float* eps, int64_t rows, int n_out, void* stream);
 
 /* ------------------------------------------------------------------ gradients (autograd)
  * What torch.autograd.Function.backward needs so the modules train like the reference's

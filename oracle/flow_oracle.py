@@ -353,3 +353,13 @@ def sample_z(q0_mean: Tensor, q0_log_var: Tensor, eps: Tensor, layers: Sequence[
     z = q0_mean + q0_std * eps
     zs, log_det = flow_stack(z, layers, inverse=False)
     return zs[-1], log_det.squeeze()
+
+
+def mnf_linear_forward(x: Tensor, z: Tensor, W_mean: Tensor, W_log_var: Tensor, b_mean: Tensor, b_log_var: Tensor,
+                       eps: Tensor) -> Tensor:
+    """MNFLinear.forward behind sample_z, with the output noise injected.  torch_mnf/layers/mnf_linear.py:46-56:
+    ``mean = x * z @ W_mean.T + b_mean``; ``var = x**2 @ exp(W_log_var).T + exp(b_log_var)``;
+    ``mean + var.sqrt() * epsilon``."""
+    mean = x * z @ W_mean.T + b_mean
+    var = x**2 @ W_log_var.exp().T + b_log_var.exp()
+    return mean + var.sqrt() * eps

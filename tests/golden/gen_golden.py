@@ -352,6 +352,48 @@ def g8_sample_z():
          z=npy(z), log_det=npy(ld))
 
 
+# ----------------------------------------------------------------------------- G11
+def g11_mnf_linear_forward():
+    """MNFLinear.forward (mnf_linear.py:46-56) with every random draw captured: the sample_z noise, both flow masks and
+    the output noise -- for MNFLinear(800, 50) (MNF-LeNet's first dense layer) and MNFLinear(50, 10) (its second)."""
+    out = {}
+    for tag, (n_in, n_out, rows, seed) in {"l800": (800, 50, 96, 11), "l50": (50, 10, 200, 12)}.items():
+        torch.manual_seed(seed)
+        layer = MNFLinear(n_in, n_out)
+        for i, f in enumerate(layer.flow_q.flows):
+            f.load_state_dict(recipes.rnvp_params(1100 + seed + i, n_in, 50))
+        x = recipes.gaussian(1100 + seed, rows, n_in, scale=1.5).abs()  # post-ReLU-like activations
+        captured = {"eps": [], "mask": []}
+        real_randn_like, real_bernoulli = torch.randn_like, torch.bernoulli
+
+        def randn_like(t, *a, **k):
+            r = real_randn_like(t, *a, **k)
+            captured["eps"].append(r.clone())
+            return r
+
+        def bernoulli(t, *a, **k):
+            r = real_bernoulli(t, *a, **k)
+            captured["mask"].append(r.clone())
+            return r
+
+        torch.randn_like, torch.bernoulli = randn_like, bernoulli
+        try:
+            with torch.no_grad():
+                y = layer.forward(x)
+        finally:
+            torch.randn_like, torch.bernoulli = real_randn_like, real_bernoulli
+        assert len(captured["eps"]) == 2 and len(captured["mask"]) == 2
+        for k in ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var"):
+            out[f"{tag}.{k}"] = npy(getattr(layer, k))
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.eps_z"] = npy(captured["eps"][0])
+        out[f"{tag}.eps_out"] = npy(captured["eps"][1])
+        out[f"{tag}.mask0_bits"] = np.packbits(npy(captured["mask"][0]).astype(np.uint8), axis=1)
+        out[f"{tag}.mask1_bits"] = np.packbits(npy(captured["mask"][1]).astype(np.uint8), axis=1)
+        out[f"{tag}.y"] = npy(y)
+    save("g11_mnf_linear_forward", **out)
+
+
 # ----------------------------------------------------------------------------- G9
 def g9_logdet_shapes():
     x = recipes.gaussian(900, 8, 4)
@@ -387,4 +429,5 @@ if __name__ == "__main__":
     g7_rnvp()
     g8_sample_z()
     g10_padded_shapes()
+    g11_mnf_linear_forward()
     g9_logdet_shapes()

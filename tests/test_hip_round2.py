@@ -402,3 +402,105 @@ def test_c5_full_size_sample_z(amd, O):
         assert_close(z[sel], z_ref, RTOL, f"z ({n_in})")
         assert_close(ld[sel], ld_ref, RTOL, f"log_det ({n_in})")
         del z, ld, eps
+
+
+# ------------------------------------------------------------------ MNFLinear.forward behind the flow path
+def g11_layer(amd, fx, tag):
+    from test_oracle_golden import G11_CASES
+
+    n_in, n_out, seed = G11_CASES[tag]
+    layer = amd.MNFLinear(n_in, n_out)
+    sd = {k: torch.from_numpy(fx[f"{tag}.{k}"]) for k in ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var")}
+    layer.load_state_dict(sd, strict=False)
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(1100 + seed + i, n_in, 50))
+    return layer.to(DEV), n_in, n_out
+
+
+@pytest.mark.parametrize("tag", ["l800", "l50"])
+def test_g11_mnf_linear_forward_vs_reference(amd, golden, tag):
+    """Fixture G11: the reference's MNFLinear.forward with its three random draws captured.  Here: sample_z with the
+    captured noise and masks, then mnf_mnf_linear_fwd (both products in split arithmetic + the noise epilogue, one
+    launch) with the captured output noise."""
+    from helpers import unpack_mask
+
+    fx = golden("g11_mnf_linear_forward")
+    layer, n_in, n_out = g11_layer(amd, fx, tag)
+    x = torch.from_numpy(fx[f"{tag}.x"]).to(DEV)
+    masks = [unpack_mask(fx[f"{tag}.mask{i}_bits"], n_in).to(DEV) for i in range(2)]
+    eps_z, eps_out = torch.from_numpy(fx[f"{tag}.eps_z"]).to(DEV), torch.from_numpy(fx[f"{tag}.eps_out"]).to(DEV)
+    with torch.no_grad():
+        z, _ = layer.sample_z(x.shape[0], eps=eps_z, masks=masks)
+        # forward() draws its own z; the kernel is the part under test: call it on the fixture's z
+        real = layer.sample_z
+        layer.sample_z = lambda n: (z, None)
+        try:
+            y = layer.forward(x, eps=eps_out)
+        finally:
+            layer.sample_z = real
+    assert layer._forward_operands(torch.device(DEV, 0)) is not None
+    assert_close(y, fx[f"{tag}.y"], RTOL, "y vs the reference")
+
+
+@pytest.mark.parametrize("n_in,n_out,rows", [(800, 50, 1000), (800, 50, 128 * 40 + 3), (50, 10, 777), (784, 64, 300),
+                                             (100, 33, 129), (30, 7, 50), (500, 1, 200)])
+def test_mnf_linear_forward_kernel_vs_oracle(amd, O, n_in, n_out, rows):
+    """mnf_mnf_linear_fwd on seeded inputs against the oracle (mnf_linear.py:46-56): widths with partial K-steps and
+    output tiles, ragged rows, trained-like tiny variances, injected and in-kernel noise."""
+    torch.manual_seed(n_in + n_out)
+    layer = amd.MNFLinear(n_in, n_out).to(DEV)
+    with torch.no_grad():
+        layer.W_log_var.add_(-3.0)  # exp(-12) ~ 6e-6: below the f16 normal range before the pack-time scaling
+        layer.b_mean.normal_(0, 0.3)
+    x = recipes.gaussian(5, rows, n_in, scale=1.2).abs().to(DEV)
+    z = (1.0 + 0.3 * recipes.gaussian(6, rows, n_in)).to(DEV)
+    eps = recipes.gaussian(7, rows, n_out).to(DEV)
+    real = layer.sample_z
+    layer.sample_z = lambda n: (z, None)
+    try:
+        with torch.no_grad():
+            y = layer.forward(x, eps=eps)
+            torch.manual_seed(31)
+            y_seeded = layer.forward(x)
+            torch.manual_seed(31)
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    finally:
+        layer.sample_z = real
+    p = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    ref = O.mnf_linear_forward(x.cpu(), z.cpu(), p["W_mean"], p["W_log_var"], p["b_mean"], p["b_log_var"], eps.cpu())
+    assert_close(y, ref, RTOL, "y (injected noise)")
+    e2 = layer.noise_for(seed, rows)
+    ref2 = O.mnf_linear_forward(x.cpu(), z.cpu(), p["W_mean"], p["W_log_var"], p["b_mean"], p["b_log_var"], e2.cpu())
+    assert_close(y_seeded, ref2, RTOL, "y (in-kernel noise)")
+    # the in-kernel stream is standard normal
+    if rows * n_out >= 20000:
+        assert abs(float(e2.mean())) < 0.03 and abs(float(e2.std()) - 1.0) < 0.03
+
+
+def test_mnf_linear_forward_range_guard_and_training_path(amd, O):
+    """Activations whose squares leave the f16 range: the 128-row groups concerned are redone in fp32 by the fix-up
+    launch.  With gradients wanted the layer runs the reference's composition under autograd."""
+    torch.manual_seed(3)
+    layer = amd.MNFLinear(800, 50).to(DEV)
+    rows = 128 * 5
+    x = recipes.gaussian(8, rows, 800).abs()
+    x[130] *= 400.0   # x^2 ~ 1e6 in group 1
+    x[600, 7] = 3.0e4
+    z = 1.0 + 0.3 * recipes.gaussian(9, rows, 800)
+    eps = recipes.gaussian(10, rows, 50)
+    real = layer.sample_z
+    layer.sample_z = lambda n: (z.to(DEV), None)
+    try:
+        with torch.no_grad():
+            y = layer.forward(x.to(DEV), eps=eps.to(DEV))
+        y_train = layer.forward(x.to(DEV), eps=eps.to(DEV))
+    finally:
+        layer.sample_z = real
+    p = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    ref = O.mnf_linear_forward(x, z, p["W_mean"], p["W_log_var"], p["b_mean"], p["b_log_var"], eps)
+    for lo in range(0, rows, 128):  # per group: the guarded rows dominate the norm otherwise
+        assert_close(y[lo:lo + 128], ref[lo:lo + 128], RTOL, f"rows {lo}..")
+    assert y_train.requires_grad
+    assert_close(y_train, ref, RTOL, "autograd path")
+    y_train.sum().backward()
+    assert layer.W_mean.grad is not None and layer.W_log_var.grad is not None

@@ -185,6 +185,28 @@ def test_g8_sample_z(golden):
     assert_close(ld, fx["log_det"], 1e-6, "log_det")
 
 
+G11_CASES = {"l800": (800, 50, 11), "l50": (50, 10, 12)}
+
+
+def g11_oracle(fx, tag):
+    """The oracle's MNFLinear.forward on fixture G11's captured noise: sample_z, then the layer."""
+    n_in, n_out, seed = G11_CASES[tag]
+    layers = [{"kind": "rnvp", "params": recipes.rnvp_params(1100 + seed + i, n_in, 50),
+               "mask": unpack_mask(fx[f"{tag}.mask{i}_bits"], n_in)} for i in range(2)]
+    z, _ = O.sample_z(t(fx[f"{tag}.q0_mean"]), t(fx[f"{tag}.q0_log_var"]), t(fx[f"{tag}.eps_z"]), layers)
+    y = O.mnf_linear_forward(t(fx[f"{tag}.x"]), z, t(fx[f"{tag}.W_mean"]), t(fx[f"{tag}.W_log_var"]),
+                             t(fx[f"{tag}.b_mean"]), t(fx[f"{tag}.b_log_var"]), t(fx[f"{tag}.eps_out"]))
+    return z, y
+
+
+@pytest.mark.parametrize("tag", sorted(G11_CASES))
+def test_g11_mnf_linear_forward(golden, tag):
+    """MNFLinear.forward of the reference with every random draw captured (mnf_linear.py:46-56)."""
+    fx = golden("g11_mnf_linear_forward")
+    _, y = g11_oracle(fx, tag)
+    assert_close(y, fx[f"{tag}.y"], 1e-6, "y")
+
+
 def test_g9_logdet_shapes(golden):
     fx = golden("g9_logdet_shapes")
     x = recipes.gaussian(900, 8, 4)

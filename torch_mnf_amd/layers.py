@@ -1,13 +1,17 @@
 """The MNF caller of the path: ``MNFLinear`` (torch_mnf/layers/mnf_linear.py:7-90).
 
-Only ``sample_z`` is on the hot path: it draws the multiplicative noise
+``sample_z`` is on the hot path: it draws the multiplicative noise
 ``z0 = q0_mean + sigma * eps`` for every row of the batch and pushes it through ``flow_q``
 (a stack of masked/gated ``RNVP`` layers) -- at MNF-LeNet's 512 images x 500 MC samples that is
-256,000 rows of 800 dims.  Both steps run in libmnf_hip.so.  The two GEMMs of ``forward`` and the
-closed-form KL terms of ``kl_div`` are the reference's own formulas on device tensors
-(stock PyTorch-ROCm); they are callers, not the path.
+256,000 rows of 800 dims.  Both steps run in libmnf_hip.so, and so does what ``forward`` does with the
+result: the two products of the local reparametrisation and the noise epilogue are one
+launch that reads x and z once (``mnf_mnf_linear_fwd``).  The closed-form KL terms of ``kl_div`` are the
+reference's own formulas on device tensors (stock PyTorch-ROCm): a caller, not the path.
 """
 from __future__ import annotations
+
+import ctypes
+import math
 
 import torch
 from torch import Tensor, nn
@@ -97,12 +101,89 @@ class MNFLinear(nn.Module):
                 zs.append(z)
         return zs[-1], log_det.squeeze()
 
-    # ------------------------------------------------------------------ callers (stock PyTorch-ROCm)
-    def forward(self, x: Tensor) -> Tensor:  # algorithm 1 of the MNF paper; mnf_linear.py:46-56
+    # ------------------------------------------------------------------ forward behind the flow path
+    def _forward_operands(self, device):
+        """(flat parameters, split operand image, var_unscale) of mnf_mnf_linear_fwd for the current parameters, or
+        None when the shape has no kernel (n_out > 64).  Repacked when a parameter changes."""
+        params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
+        key = (device, tuple((p.data_ptr(), p._version) for p in params))
+        cache = self.__dict__.get("_fwd_cache")
+        if cache is None or cache[0] != key:
+            lib = _lib.load()
+            n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = lib.mnf_mnf_linear_split_layout(self.n_in, self.n_out, ctypes.byref(n_split), ctypes.byref(n_plain))
+            if rc == _lib.MNF_ERR_UNSUPPORTED:
+                cache = (key, None)
+            else:
+                _lib.check("mnf_mnf_linear_split_layout", rc)
+                index = self.__dict__.get("_fwd_index")
+                if index is None or index.device != device:
+                    idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+                    _lib.check("mnf_mnf_linear_split_index", lib.mnf_mnf_linear_split_index(self.n_in, self.n_out, idx))
+                    index = torch.frombuffer(idx, dtype=torch.int32).clone().to(device)
+                    self.__dict__["_fwd_index"] = index
+                with torch.no_grad():
+                    w_var = self.W_log_var.detach().to(device, torch.float32).exp()
+                    # exp(W_log_var) is ~1e-4 at init and shrinks in training: times a power of two that puts its
+                    # largest entry in [0.5, 1), so that the f16 halves of the image are normal numbers
+                    top = float(w_var.max())
+                    shift = -math.frexp(top)[1] if top > 0.0 and math.isfinite(top) else 0
+                    shift = max(min(shift, 100), -100)
+                    flat = torch.cat([self.W_mean.detach().to(device, torch.float32).reshape(-1),
+                                      (w_var * (2.0 ** shift)).reshape(-1),
+                                      self.b_mean.detach().to(device, torch.float32),
+                                      self.b_log_var.detach().to(device, torch.float32).exp()]).contiguous()
+                image = torch.empty(n_split.value + n_plain.value + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32,
+                                    device=device)
+                _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
+                    flat.data_ptr(), index.data_ptr(), image.data_ptr(), n_split.value, n_plain.value, _stream()))
+                cache = (key, (flat, image, 2.0 ** -shift))
+            self.__dict__["_fwd_cache"] = cache
+        return cache[1]
+
+    def forward(self, x: Tensor, eps: Tensor | None = None) -> Tensor:
+        """Algorithm 1 of the MNF paper (mnf_linear.py:46-56): ``mean + sqrt(var) * eps`` with
+        ``mean = (x * z) @ W_mean.T + b_mean`` and ``var = x**2 @ exp(W_log_var).T + exp(b_log_var)``.
+
+        Without gradients both products and the noise epilogue are ONE HIP launch behind ``sample_z`` (x and z read
+        once; ``eps`` (rows, n_out) may be injected, by default it is generated inside the kernel from a seed drawn
+        from torch's generator).  With gradients the reference's formulas run on device tensors (autograd)."""
         z, _ = self.sample_z(x.size(0))
-        mean = (x * z) @ self.W_mean.T + self.b_mean
-        var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
-        return mean + var.sqrt() * torch.randn_like(var)
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        ops = None
+        if not training and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32:
+            ops = self._forward_operands(x.device)
+        if ops is None:  # training, or a shape without a kernel: the reference's composition (stock PyTorch-ROCm)
+            mean = (x * z) @ self.W_mean.T + self.b_mean
+            var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
+            return mean + var.sqrt() * (torch.randn_like(var) if eps is None else eps)
+        flat, image, var_unscale = ops
+        xc, zc = x.detach().contiguous(), z.detach().contiguous()
+        rows = xc.shape[0]
+        out = torch.empty(rows, self.n_out, dtype=torch.float32, device=x.device)
+        work = torch.empty((rows + 127) // 128, dtype=torch.int32, device=x.device)
+        seed = 0
+        if eps is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            eps = eps.detach().to(x.device, torch.float32).contiguous()
+            if eps.shape != out.shape:
+                raise ValueError(f"eps must be {tuple(out.shape)}, got {tuple(eps.shape)}")
+        _lib.check("mnf_mnf_linear_fwd", _lib.load().mnf_mnf_linear_fwd(
+            xc.data_ptr(), zc.data_ptr(), None if eps is None else eps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF,
+            out.data_ptr(), flat.data_ptr(), image.data_ptr(), var_unscale, work.data_ptr(), rows, self.n_in,
+            self.n_out, _stream()))
+        return out
+
+    def noise_for(self, seed: int, rows: int, device="cuda") -> Tensor:
+        """The (rows, n_out) noise an in-kernel-noise ``forward`` call with this seed used (tests)."""
+        e = torch.empty(rows, self.n_out, dtype=torch.float32, device=device)
+        if rows:
+            _lib.check("mnf_mnf_linear_noise", _lib.load().mnf_mnf_linear_noise(
+                int(seed) & 0xFFFFFFFFFFFFFFFF, e.data_ptr(), rows, self.n_out, _stream()))
+        return e
+
+    # ------------------------------------------------------------------ caller (stock PyTorch-ROCm)
 
     def kl_div(self) -> Tensor:  # mnf_linear.py:66-90
         z, log_det_q = self.sample_z()
