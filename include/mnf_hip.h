@@ -8,6 +8,7 @@
  *
  *   mnf_affine_half      AffineHalfFlow.forward / .inverse      torch_mnf/flows/affine_half_flow.py:44-66
  *   mnf_nsf_cl           NSF_CL.forward / .inverse              torch_mnf/flows/spline_flow.py:249-285
+ *   mnf_nsf_ar           NSF_AR.forward / .inverse              torch_mnf/flows/spline_flow.py:201-235
  *   mnf_rqs              unconstrained_RQS                      torch_mnf/flows/spline_flow.py:29-68
  *   mnf_rnvp             RNVP.forward                           torch_mnf/flows/rnvp.py:25-39
  *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
@@ -261,6 +262,18 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
 /* z0 = q0_mean + exp(q0_log_var)^(1/2) * eps   (rows, dim); mean, log_var: (dim,). */
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
                   int64_t rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------ NSF_AR (reuse of the spline device function)
+ * torch_mnf/flows/spline_flow.py:182-235.  Element i is moved by a spline whose 3K-1 parameters come from
+ * MLP_i(first i elements) -- of the OUTPUT in forward (inverse = 0; sequential in i; the spline runs inverted, :213-215)
+ * and of the INPUT in inverse (:231-233); element 0 uses `init_param`.  log_det as for mnf_nsf_cl.
+ * flat: init_param (3K-1), then the state_dict tensors of layers[0 .. dim-2] (layers[i-1] = MLP(i, hidden..., 3K-1)). */
+int mnf_nsf_ar(const float* x, float* y, float* log_det, int accumulate, const float* flat, int64_t rows, int dim, int K,
+               float tail_bound, int inverse, int n_hidden, const int* hidden_host, void* stream);
+int64_t mnf_nsf_ar_flat_floats(int dim, int K, int n_hidden, const int* hidden_host);
+int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                   const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                   const int* hidden_host, void* stream);
 
 /* ------------------------------------------------ MNFLinear.forward behind the flow path
  * torch_mnf/layers/mnf_linear.py:46-56 with z (rows, n_in) = what sample_z's last flow wrote:

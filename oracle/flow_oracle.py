@@ -243,6 +243,31 @@ def nsf_cl(x: Tensor, params: Params, K: int, T: float, inverse: bool) -> tuple[
     return torch.cat([lower, upper], dim=1), log_det
 
 
+def nsf_ar(x: Tensor, params: Params, K: int, T: float, inverse: bool) -> tuple[Tensor, Tensor]:
+    """Neural-spline autoregressive layer.  spline_flow.py:201-235.
+
+    ``params``: ``init_param`` (3K-1,) and ``layers.{i-1}.{0,2,4,6}.{weight,bias}`` for the conditioner of element i.
+    forward (:201-218) conditions element i on the first i OUTPUT elements and runs the spline inverted;
+    inverse (:220-235) conditions on the INPUT and runs it forward.
+    """
+    dim = x.shape[1]
+    out = torch.zeros_like(x)
+    log_det = torch.zeros(x.shape[0], dtype=x.dtype)
+    for i in range(dim):
+        if i == 0:
+            raw = params["init_param"].expand(x.shape[0], 3 * K - 1)
+        else:
+            raw = mlp((x if inverse else out)[:, :i], params, f"layers.{i - 1}")
+        W, H, D = torch.split(raw, K, dim=1)
+        W, H = torch.softmax(W, dim=1), torch.softmax(H, dim=1)
+        W, H = 2 * T * W, 2 * T * H
+        D = F.softplus(D)
+        col, ld = unconstrained_rqs(x[:, i], W, H, D, inverse=not inverse, tail_bound=T)
+        out = torch.cat([out[:, :i], col[:, None], out[:, i + 1:]], dim=1)  # (out-of-place: autograd friendly)
+        log_det = log_det + ld
+    return out, log_det
+
+
 # ------------------------------------------------------------- masked/gated RNVP
 def rnvp(z: Tensor, params: Params, mask: Tensor) -> tuple[Tensor, Tensor]:
     """Forward-only gated coupling with an explicit Bernoulli mask.  rnvp.py:25-39.
@@ -303,6 +328,8 @@ def apply_layer(spec: dict, x: Tensor, inverse: bool) -> tuple[Tensor, Tensor]:
         )
     if kind == "nsf_cl":
         return nsf_cl(x, p, spec["K"], spec["B"], inverse)
+    if kind == "nsf_ar":
+        return nsf_ar(x, p, spec["K"], spec["B"], inverse)
     if kind == "affine_const":
         return affine_const(x, p["s"], p["t"], inverse)
     if kind == "glow":

@@ -394,6 +394,37 @@ def g11_mnf_linear_forward():
     save("g11_mnf_linear_forward", **out)
 
 
+# ----------------------------------------------------------------------------- G12
+def g12_nsf_ar():
+    """NSF_AR (spline_flow.py:182-235) forward and inverse: K in {5, 8}, dims 2 (the reference's tests), 6 and 16."""
+    out = {}
+    for tag, (dim, K, n_h, rows, gain) in {"d2_k8": (2, 8, 16, 300, 1.0), "d6_k5": (6, 5, 8, 257, 1.0),
+                                           "d16_k8": (16, 8, 8, 128, 1.5)}.items():
+        sd = recipes.nsf_ar_params(1200 + dim + K, dim, K, n_h, gain=gain)
+        layer = nf.NSF_AR(dim, K=K, B=3, n_h=n_h)
+        layer.load_state_dict(sd)
+        x = recipes.gaussian(1201 + dim, rows, dim, scale=1.6)  # a few percent of the elements outside +-3
+        with torch.no_grad():
+            y_f, ld_f = layer.forward(x)
+            y_i, ld_i = layer.inverse(x)
+            back, _ = layer.inverse(y_f)
+        assert float((back - x).abs().max()) < 1e-3
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.fwd"], out[f"{tag}.ld_fwd"] = npy(y_f), npy(ld_f)
+        out[f"{tag}.inv"], out[f"{tag}.ld_inv"] = npy(y_i), npy(ld_i)
+        layer64 = nf.NSF_AR(dim, K=K, B=3, n_h=n_h).double()
+        layer64.load_state_dict({k: v.double() for k, v in sd.items()})
+        with torch.no_grad():
+            # (the reference allocates log_det as float32 zeros: its float64 run returns float64 outputs only)
+            y64_f, _ = layer64.forward(x.double())
+            y64_i, _ = layer64.inverse(x.double())
+        out[f"{tag}.fwd64"], out[f"{tag}.inv64"] = npy(y64_f), npy(y64_i)
+    save("g12_nsf_ar", **out)
+
+
+G12_CASES = {"d2_k8": (2, 8, 16), "d6_k5": (6, 5, 8), "d16_k8": (16, 8, 8)}
+
+
 # ----------------------------------------------------------------------------- G9
 def g9_logdet_shapes():
     x = recipes.gaussian(900, 8, 4)
@@ -430,4 +461,5 @@ if __name__ == "__main__":
     g8_sample_z()
     g10_padded_shapes()
     g11_mnf_linear_forward()
+    g12_nsf_ar()
     g9_logdet_shapes()

@@ -294,7 +294,7 @@ def train(model, optim, samples, steps):
 
 
 @pytest.mark.parametrize("name,bound", [("rnvp", 236), ("glow", 308), ("glow_actnorm", 246), ("nsfcl", 207),
-                                        ("nsfcl_actnorm", 184)])
+                                        ("nsfcl_actnorm", 184), ("nsfar", 318), ("nsfar_actnorm", 213)])
 def test_reference_training_contracts(amd, name, bound):
     """The reference's e2e tests: Adam, 1 step then 70 steps on 128 half-moon points; the loss must
     fall and end below the reference's bound (tests/test_flows.py:41-50, :53-55, :76-99)."""
@@ -302,6 +302,11 @@ def test_reference_training_contracts(amd, name, bound):
     samples = moons(128).to(DEV)
     if name == "rnvp":
         flows = [amd.AffineHalfFlow(dim=2, parity=i % 2 == 0) for i in range(2)]
+    elif name.startswith("nsfar"):  # tests/test_flows.py:102-112
+        flows = [amd.NSF_AR(dim=2, K=8, B=3, n_h=16) for _ in range(2)]
+        if name == "nsfar_actnorm":
+            for idx in reversed(range(len(flows))):
+                flows.insert(idx, amd.ActNormFlow(dim=2))
     elif name.startswith("nsfcl"):  # tests/test_flows.py:89-99
         flows = [amd.NSF_CL(dim=2, K=8, B=3, n_h=16) for _ in range(2)]
         if name == "nsfcl_actnorm":

@@ -504,3 +504,92 @@ def test_mnf_linear_forward_range_guard_and_training_path(amd, O):
     assert_close(y_train, ref, RTOL, "autograd path")
     y_train.sum().backward()
     assert layer.W_mean.grad is not None and layer.W_log_var.grad is not None
+
+
+# ------------------------------------------------------------------ NSF_AR on the spline device function
+G12_CASES = {"d2_k8": (2, 8, 16, 1.0), "d6_k5": (6, 5, 8, 1.0), "d16_k8": (16, 8, 8, 1.5)}  # dim, K, n_h, gain
+
+
+def nsf_ar_layer(amd, sd, dim, K, n_h):
+    f = amd.NSF_AR(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    return f.to(DEV)
+
+
+@pytest.mark.parametrize("tag", sorted(G12_CASES))
+def test_g12_nsf_ar_vs_reference(amd, golden, tag):
+    """Fixture G12: the reference's NSF_AR.forward / .inverse (spline_flow.py:182-235)."""
+    from helpers import assert_parity
+
+    fx = golden("g12_nsf_ar")
+    dim, K, n_h, gain = G12_CASES[tag]
+    sd = recipes.nsf_ar_params(1200 + dim + K, dim, K, n_h, gain=gain)
+    f = nsf_ar_layer(amd, sd, dim, K, n_h)
+    assert list(f.state_dict()) == list(sd)  # init_param, layers.{i}.{0,2,4,6}.{weight,bias}
+    x = torch.from_numpy(fx[f"{tag}.x"]).to(DEV)
+    with torch.no_grad():
+        for direction, fn in (("fwd", f.forward), ("inv", f.inverse)):
+            y, ld = fn(x)
+            assert_parity(y, fx[f"{tag}.{direction}"], fx[f"{tag}.{direction}64"], f"{direction} y")
+            assert_close(ld, fx[f"{tag}.ld_{direction}"], 3e-5, f"{direction} log_det")
+        # inverse(forward(x)) == x and the log-dets cancel
+        y, ld = f.forward(x)
+        back, ld_b = f.inverse(y)
+        assert float((back - x).abs().max()) <= 2e-4 * float(x.abs().max())
+        assert float((ld + ld_b).abs().max()) <= 2e-4 * max(float(ld.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("dim,K,n_h,rows", [(3, 5, 8, 1000), (12, 8, 4, 333), (32, 8, 8, 4099), (1, 5, 8, 17)])
+def test_nsf_ar_vs_oracle_and_in_a_stack(amd, O, dim, K, n_h, rows):
+    """Seeded shapes against the oracle (float64 budget as for every spline test), incl. dim = 1 (init_param only),
+    ragged row counts, +-T and outside-interval inputs, and the layer inside a NormalizingFlow (log_det += in-kernel)."""
+    from helpers import assert_parity
+
+    sd = recipes.nsf_ar_params(50 + dim, dim, K, n_h)
+    f = nsf_ar_layer(amd, sd, dim, K, n_h)
+    x = recipes.gaussian(51 + dim, rows, dim, scale=1.5)
+    x[0, 0] = 3.0
+    x[1 % rows, dim - 1] = -3.0
+    x[3 % rows, dim // 2] = 7.5  # outside the interval: identity, log-det 0
+    # (no NaN rows: a NaN element reaches the conditioners of the later elements, and the reference then stops at
+    #  its `assert discriminant >= 0`, spline_flow.py:143)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        for inverse in (False, True):
+            y, ld = (f.inverse if inverse else f.forward)(x.to(DEV))
+            r32 = O.nsf_ar(x, sd, K, 3.0, inverse)
+            r64 = O.nsf_ar(x.double(), sd64, K, 3.0, inverse)
+            assert_parity(y, r32[0].numpy(), r64[0].numpy(), f"inverse={inverse} y")
+            ok = ~torch.isnan(r32[1])
+            assert_parity(ld[ok.to(DEV)], r32[1][ok].numpy(), r64[1][ok].numpy(), f"inverse={inverse} log_det")
+        flow = amd.NormalizingFlow([f, nsf_ar_layer(amd, recipes.nsf_ar_params(99, dim, K, n_h), dim, K, n_h)])
+        xs = x[4:].contiguous()
+        zs, ld = flow.inverse(xs.to(DEV))
+        specs = [{"kind": "nsf_ar", "K": K, "B": 3.0, "params": sd},
+                 {"kind": "nsf_ar", "K": K, "B": 3.0, "params": recipes.nsf_ar_params(99, dim, K, n_h)}]
+        ref_zs, ref_ld = O.flow_stack(xs, specs, True)
+        assert len(zs) == 3
+        assert_close(zs[-1], ref_zs[-1], 1e-4, "stack z")  # (two splines deep: the reference's own fp32 noise)
+        assert_close(ld, ref_ld, 1e-4, "stack log_det")
+
+
+@pytest.mark.parametrize("dim,K,n_h", [(2, 8, 16), (5, 5, 8), (9, 8, 6)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_ar_gradients_vs_autograd_through_the_oracle(amd, O, dim, K, n_h, inverse):
+    """mnf_nsf_ar_bwd (reverse mode through the sequential direction too) against torch.autograd through the oracle:
+    gradient wrt the input and wrt every parameter tensor, loss = sum(w * y) + sum(v * log_det)."""
+    sd = recipes.nsf_ar_params(70 + dim, dim, K, n_h)
+    rows = 97
+    x = recipes.gaussian(71 + dim, rows, dim, scale=1.2)
+    w, v = recipes.gaussian(72, rows, dim), recipes.gaussian(73, rows, 1)[:, 0]
+    ref_p = {k: t.clone().double().requires_grad_(True) for k, t in sd.items()}
+    xr = x.clone().double().requires_grad_(True)
+    y_ref, ld_ref = O.nsf_ar(xr, ref_p, K, 3.0, inverse)
+    ((w.double() * y_ref).sum() + (v.double() * ld_ref).sum()).backward()
+    f = nsf_ar_layer(amd, sd, dim, K, n_h)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    y, ld = (f.inverse if inverse else f.forward)(xg)
+    ((w.to(DEV) * y).sum() + (v.to(DEV) * ld).sum()).backward()
+    assert_close(xg.grad, xr.grad.float(), 2e-4, "grad x")
+    for name, prm in f.named_parameters():
+        assert_close(prm.grad, ref_p[name].grad.float(), 2e-4, f"grad {name}")

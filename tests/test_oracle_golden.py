@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import recipes
-from helpers import assert_close, c2_layers, c3_layers, g1_layers, t, unpack_mask
+from helpers import assert_parity, assert_close, c2_layers, c3_layers, g1_layers, t, unpack_mask
 from oracle import flow_oracle as O
 
 torch.set_num_threads(4)
@@ -205,6 +205,22 @@ def test_g11_mnf_linear_forward(golden, tag):
     fx = golden("g11_mnf_linear_forward")
     _, y = g11_oracle(fx, tag)
     assert_close(y, fx[f"{tag}.y"], 1e-6, "y")
+
+
+G12_CASES = {"d2_k8": (2, 8, 16, 1.0), "d6_k5": (6, 5, 8, 1.0), "d16_k8": (16, 8, 8, 1.5)}  # dim, K, n_h, gain
+
+
+@pytest.mark.parametrize("tag", sorted(G12_CASES))
+def test_g12_nsf_ar(golden, tag):
+    """NSF_AR forward / inverse of the reference (spline_flow.py:182-235); budget as for the other spline fixtures."""
+    fx = golden("g12_nsf_ar")
+    dim, K, n_h, gain = G12_CASES[tag]
+    sd = recipes.nsf_ar_params(1200 + dim + K, dim, K, n_h, gain=gain)
+    x = t(fx[f"{tag}.x"])
+    for direction, inverse in (("fwd", False), ("inv", True)):
+        y, ld = O.nsf_ar(x, sd, K, 3.0, inverse)
+        assert_parity(y, fx[f"{tag}.{direction}"], fx[f"{tag}.{direction}64"], f"{direction} y", rtol=2e-6)
+        assert_close(ld, fx[f"{tag}.ld_{direction}"], 2e-5, f"{direction} log_det")
 
 
 def test_g9_logdet_shapes(golden):

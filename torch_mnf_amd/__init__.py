@@ -19,6 +19,7 @@ from .flows import (
     Glow,
     NormalizingFlow,
     NormalizingFlowModel,
+    NSF_AR,
     NSF_CL,
     RNVP,
     StandardNormal,
@@ -27,7 +28,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "library_path",
 ]
 
 

@@ -92,6 +92,11 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_nsf_ar": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_int, c_int,
+                           _intp, c_void_p]),
+    "mnf_nsf_ar_flat_floats": (c_int64, [c_int, c_int, c_int, _intp]),
+    "mnf_nsf_ar_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                               c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_mnf_linear_split_layout": (c_int, [c_int, c_int, _i64p, _i64p]),
     "mnf_mnf_linear_split_index": (c_int, [c_int, c_int, _i32p]),
     "mnf_mnf_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_float,

@@ -646,9 +646,169 @@ __global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------- NSF_AR
+struct NsfArBwdArgs {
+  const float* x;
+  const float* grad_y;
+  const float* grad_ld;
+  float* grad_x;
+  float* grad_flat;
+  const float* flat;
+  int64_t rows;
+  int dim, K, inverse;
+  float T;
+  int R, maxw, act_floats, n_hidden;
+  int hidden[MNF_MAX_LINEAR];
+  int act_off[MNF_MAX_LINEAR];
+};
+
+// the conditioner of element i >= 1 inside flat (same layout arithmetic as mnf_generic.hip's nsf_ar_net)
+__device__ __forceinline__ void nsf_ar_net_bwd(NetDesc& nd, int i, int n_hidden, const int* hidden, int P) {
+  int64_t C = 0;
+  {
+    int prev = 0;
+    for (int l = 0; l < n_hidden; ++l) {
+      C += (int64_t)prev * hidden[l] + hidden[l];
+      prev = hidden[l];
+    }
+    C += (int64_t)prev * P + P;
+  }
+  const int h0 = n_hidden > 0 ? hidden[0] : P;
+  int64_t off = P + (int64_t)h0 * ((int64_t)(i - 1) * i / 2) + C * (i - 1);
+  nd.n_lin = n_hidden + 1;
+  nd.sizes[0] = i;
+  for (int l = 0; l < n_hidden; ++l) nd.sizes[1 + l] = hidden[l];
+  nd.sizes[n_hidden + 1] = P;
+  nd.max_width = 0;
+  for (int l = 0; l < nd.n_lin; ++l) {
+    nd.w_off[l] = (int)off;
+    off += (int64_t)nd.sizes[l] * nd.sizes[l + 1];
+    nd.b_off[l] = (int)off;
+    off += nd.sizes[l + 1];
+  }
+}
+
+// Reverse mode through the autoregressive layer.  `cond` = what the conditioners saw: the layer's input (inverse
+// direction: elements are independent given it) or its output (forward direction: recomputed first, then walked
+// backwards, G[:, j] collecting the cotangent of output element j from the elements conditioned on it).
+__global__ void __launch_bounds__(kBwdThreads) nsf_ar_bwd_kernel(NsfArBwdArgs a) {
+  const int d = a.dim, P = 3 * a.K - 1;
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* src = bsmem;                  // [R][d]  the layer's input
+  float* out = src + a.R * d;          // [R][d]  its output (forward direction: recomputed)
+  float* G = out + a.R * d;            // [R][d]  cotangent of the conditioning tensor's elements
+  float* g_in = G + a.R * d;           // [R][d]  gradient wrt the layer's input
+  float* g_ldr = g_in + a.R * d;       // [R]
+  float* acts = g_ldr + a.R;           // [act_floats][R]
+  float* dA = acts + a.R * a.act_floats;
+  float* dB = dA + a.R * a.maxw;
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
+    src[idx] = a.x[row0 * d + idx];
+    G[idx] = a.grad_y ? a.grad_y[row0 * d + idx] : 0.f;
+    g_in[idx] = 0.f;
+  }
+  for (int r = threadIdx.x; r < R; r += blockDim.x) g_ldr[r] = a.grad_ld ? a.grad_ld[row0 + r] : 0.f;
+  __syncthreads();
+  const bool rqs_inv = !a.inverse;  // forward() runs the spline inverted (spline_flow.py:213-215)
+  const float* cond = a.inverse ? src : out;
+  NetDesc nd;
+  auto params_of = [&](int i) -> const float* {  // [R][P] spline parameters of element i (acts keeps the net's layers)
+    if (i == 0) {
+      float* p0 = acts + a.act_off[a.n_hidden] * R;
+      for (int idx = threadIdx.x; idx < R * P; idx += blockDim.x) p0[idx] = a.flat[idx % P];
+      __syncthreads();
+      return p0;
+    }
+    nsf_ar_net_bwd(nd, i, a.n_hidden, a.hidden, P);
+    mlp_forward_keep(a.flat, nd, cond, d, acts, a.act_off, R);
+    return acts + a.act_off[a.n_hidden] * R;
+  };
+  if (!a.inverse) {  // recompute the outputs, element by element
+    for (int i = 0; i < d; ++i) {
+      const float* params = params_of(i);
+      for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const float* p = params + r * P;
+        float o, l;
+        rqs_element<true>(src[r * d + i], a.K, a.T, rqs_inv, [&](int k) { return p[k]; },
+                          [&](int k) { return p[a.K + k]; }, [&](int k) { return p[2 * a.K + k]; }, o, l);
+        out[r * d + i] = o;
+      }
+      __syncthreads();
+    }
+  }
+  // inverse direction: the cotangent of output element i is grad_y[:, i] alone, and what flows back through the
+  // conditioners lands on the INPUT (g_in); forward direction: it lands on earlier OUTPUT elements (G), so walk down
+  for (int i = d - 1; i >= 0; --i) {
+    const float* params = params_of(i);
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float gv;
+      rqs_element_bwd(src[r * d + i], a.K, a.T, rqs_inv, params + r * P, G[r * d + i], g_ldr[r], gv, dA + r * P);
+      g_in[r * d + i] += gv;
+    }
+    __syncthreads();
+    if (i == 0) {  // init_param: the same P values for every row
+      if (a.grad_flat)
+        for (int k = threadIdx.x; k < P; k += blockDim.x) {
+          float acc = 0.f;
+          for (int r = 0; r < R; ++r) acc += dA[r * P + k];
+          atomicAdd(a.grad_flat + k, acc);
+        }
+      __syncthreads();
+    } else {
+      // gradient wrt the conditioner's input [R][i] -> dense scratch, then onto G (forward) or g_in (inverse)
+      float* g_cond = dB + a.R * a.maxw;  // [R][d]
+      for (int idx = threadIdx.x; idx < R * i; idx += blockDim.x) g_cond[idx] = 0.f;
+      __syncthreads();
+      mlp_backward(a.flat, a.grad_flat, false, nd, cond, d, acts, a.act_off, dA, dB, g_cond, R);
+      float* sink = a.inverse ? g_in : G;
+      for (int idx = threadIdx.x; idx < R * i; idx += blockDim.x) {
+        const int r = idx / i, k = idx - r * i;
+        sink[r * d + k] += g_cond[idx];
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) a.grad_x[row0 * d + idx] = g_in[idx];
+}
+
 }  // namespace mnf
 
 extern "C" {
+
+int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                   const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                   const int* hidden, void* stream) {
+  if (!x || !grad_x || !flat || rows < 0 || dim < 1 || K < 2 || K > kMaxBins || !(tail_bound > 0.f) ||
+      !hidden_ok(n_hidden, hidden))
+    return K > kMaxBins ? MNF_ERR_UNSUPPORTED : MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  NsfArBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat; a.flat = flat;
+  a.rows = rows; a.dim = dim; a.K = K; a.inverse = inverse != 0; a.T = tail_bound; a.n_hidden = n_hidden;
+  const int P = 3 * K - 1;
+  int act = 0, maxw = dim > P ? dim : P;
+  for (int l = 0; l < n_hidden; ++l) {
+    a.hidden[l] = hidden[l];
+    a.act_off[l] = act;
+    act += hidden[l];
+    if (hidden[l] > maxw) maxw = hidden[l];
+  }
+  a.act_off[n_hidden] = act;
+  act += P;
+  a.act_floats = act; a.maxw = maxw;
+  const int per_row = 5 * dim + 1 + act + 2 * maxw;  // src, out, G, g_in, g_cond; g_ldr; acts; dA, dB
+  int R = kBwdLdsFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  if (R > 32) R = 32;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nsf_ar_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
+                     (hipStream_t)stream, a);
+  return check_launch();
+}
 
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                    const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,

@@ -215,6 +215,96 @@ __global__ void __launch_bounds__(kThreads) nsf_generic_kernel(NsfArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------- NSF_AR
+// Autoregressive spline layer (flows/spline_flow.py:182-235): element i is transformed by a spline whose 3K-1
+// parameters come from MLP_i(first i elements) -- of the layer's OUTPUT in `forward` (sequential in i, :201-218) and of
+// its INPUT in `inverse` (:220-235); element 0 uses the learned `init_param`.  forward runs the spline inverted
+// (unconstrained_RQS(..., inverse=True)), inverse runs it forward.  Same double normalisation as NSF_CL.
+// flat: init_param (3K-1), then for i = 1 .. dim-1 the state_dict tensors of layers[i-1] = MLP(i, hidden..., 3K-1).
+struct NsfArArgs {
+  const float* x;
+  float* y;
+  float* log_det;
+  const float* flat;
+  int64_t rows;
+  int dim, K, inverse, accumulate;
+  float T;
+  int R, ldw;
+  int n_hidden;
+  int hidden[MNF_MAX_LINEAR];
+};
+
+// the conditioner of element i >= 1: MLP(i, hidden..., 3K-1) at its offset inside flat
+__host__ __device__ inline int64_t nsf_ar_net_floats(int i, int n_hidden, const int* hidden, int P) {
+  int64_t n = 0;
+  int prev = i;
+  for (int l = 0; l < n_hidden; ++l) {
+    n += (int64_t)prev * hidden[l] + hidden[l];
+    prev = hidden[l];
+  }
+  return n + (int64_t)prev * P + P;
+}
+__host__ __device__ inline void nsf_ar_net(NetDesc& nd, int i, int n_hidden, const int* hidden, int P) {
+  // offset of layers[i-1]: P + sum_{k=1}^{i-1} floats(k); floats(k) = k h0 + C  (h0 = first width after the input)
+  const int h0 = n_hidden > 0 ? hidden[0] : P;
+  const int64_t C = nsf_ar_net_floats(0, n_hidden, hidden, P);
+  int64_t off = P + (int64_t)h0 * ((int64_t)(i - 1) * i / 2) + C * (i - 1);
+  nd.n_lin = n_hidden + 1;
+  nd.sizes[0] = i;
+  for (int l = 0; l < n_hidden; ++l) nd.sizes[1 + l] = hidden[l];
+  nd.sizes[n_hidden + 1] = P;
+  nd.max_width = 0;
+  for (int l = 0; l < nd.n_lin; ++l) {
+    nd.w_off[l] = (int)off;
+    off += (int64_t)nd.sizes[l] * nd.sizes[l + 1];
+    nd.b_off[l] = (int)off;
+    off += nd.sizes[l + 1];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) nsf_ar_generic_kernel(NsfArArgs a) {
+  const int d = a.dim, P = 3 * a.K - 1;
+  const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  const int R = (int)min((int64_t)a.R, a.rows - row0);
+  float* src = smem;                  // [R][d]  the layer's input
+  float* dst = src + a.R * d;         // [R][d]  its output, element by element
+  float* lad_sum = dst + a.R * d;     // [R]
+  float* bufA = lad_sum + a.R;        // [R][ldw]
+  float* bufB = bufA + a.R * a.ldw;   // [R][ldw]
+  float* params = bufB + a.R * a.ldw; // [R][P]
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) src[idx] = a.x[row0 * d + idx];
+  for (int r = threadIdx.x; r < R; r += blockDim.x) lad_sum[r] = 0.f;
+  __syncthreads();
+  const float* cond = a.inverse ? src : dst;  // what the conditioners see (:209 / :228)
+  for (int i = 0; i < d; ++i) {
+    if (i == 0) {
+      for (int idx = threadIdx.x; idx < R * P; idx += blockDim.x) params[idx] = a.flat[idx % P];  // init_param
+      __syncthreads();
+    } else {
+      NetDesc nd;
+      nsf_ar_net(nd, i, a.n_hidden, a.hidden, P);
+      block_mlp(a.flat, nd, cond, d, bufA, bufB, a.ldw, params, P, R);
+    }
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      const float* p = params + r * P;
+      float out, lad;
+      rqs_element<true>(
+          src[r * d + i], a.K, a.T, !a.inverse, [&](int k) { return p[k]; }, [&](int k) { return p[a.K + k]; },
+          [&](int k) { return p[2 * a.K + k]; }, out, lad);
+      dst[r * d + i] = out;
+      lad_sum[r] += lad;
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) a.y[row0 * d + idx] = dst[idx];
+  if (a.log_det) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float* p = a.log_det + row0 + r;
+      *p = a.accumulate ? *p + lad_sum[r] : lad_sum[r];
+    }
+  }
+}
+
 // elementwise unconstrained_RQS on caller-supplied (W, H, D)
 __global__ void rqs_kernel(const float* __restrict__ v, const float* __restrict__ W,
                            const float* __restrict__ Hh, const float* __restrict__ D,
@@ -699,6 +789,46 @@ int mnf_pack_gather_batch(const float* flat, const int32_t* idx, float* images, 
 
 int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream) {
   return mnf_pack_gather_batch(flat, idx, image, n, 1, 0, stream);
+}
+
+// -------------------------------------------------------------------------- NSF_AR
+int64_t mnf_nsf_ar_flat_floats(int dim, int K, int n_hidden, const int* hidden) {
+  if (dim < 1 || K < 1 || !hidden_ok(n_hidden, hidden)) return -1;
+  const int P = 3 * K - 1;
+  int64_t n = P;
+  for (int i = 1; i < dim; ++i) n += mnf::nsf_ar_net_floats(i, n_hidden, hidden, P);
+  return n;
+}
+
+int mnf_nsf_ar(const float* x, float* y, float* log_det, int accumulate, const float* flat, int64_t rows, int dim, int K,
+               float tail_bound, int inverse, int n_hidden, const int* hidden, void* stream) {
+  if (!x || !y || x == y || !flat || rows < 0 || dim < 1 || K < 1 || !(tail_bound > 0.f) ||
+      !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (1e-3 * K > 1.0) return MNF_ERR_DOMAIN;  // spline_flow.py:90-93
+  if (rows == 0) return MNF_OK;
+  if (mnf_nsf_ar_flat_floats(dim, K, n_hidden, hidden) >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;
+  NsfArArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim; a.K = K;
+  a.inverse = inverse != 0; a.accumulate = accumulate != 0; a.T = tail_bound; a.n_hidden = n_hidden;
+  int ldw = 1;
+  for (int i = 0; i < n_hidden; ++i) {
+    a.hidden[i] = hidden[i];
+    if (hidden[i] > ldw) ldw = hidden[i];
+  }
+  a.ldw = ldw;
+  const int per_row = 2 * dim + 1 + 2 * ldw + (3 * K - 1);
+  int R = kLdsBudgetFloats / per_row;
+  if (R < 1) return MNF_ERR_UNSUPPORTED;
+  const int cap = pick_rows_per_group(rows, 64);
+  if (R > cap) R = cap;
+  a.R = R;
+  const int64_t blocks = (rows + R - 1) / R;
+  if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(nsf_ar_generic_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)R * per_row * sizeof(float),
+                     (hipStream_t)stream, a);
+  return check_launch();
 }
 
 // -------------------------------------------------------------------------- NSF_CL

@@ -38,7 +38,7 @@ _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 _NO_FUSED_LOGPROB_ENV = os.environ.get("MNF_NO_FUSED_LOGPROB", "") not in ("", "0")
 
 __all__ = [
-    "MLP", "AffineHalfFlow", "NSF_CL", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
+    "MLP", "AffineHalfFlow", "NSF_CL", "NSF_AR", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
     "NormalizingFlow", "NormalizingFlowModel", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs",
 ]
 
@@ -619,6 +619,81 @@ class NSF_CL(_TwoWayFlow):
             _ptr(split),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
             int(self.force_generic), _stream()))
+        return y, (None if accum is not None else ld)
+
+
+class _NsfArFn(torch.autograd.Function):
+    """NSF_AR with gradients (mnf_nsf_ar_bwd: recompute, then reverse mode through splines and conditioners)."""
+
+    @staticmethod
+    def forward(ctx, x, flat_with_grad, module, inverse):
+        flat = flat_with_grad.detach().contiguous()
+        y = torch.empty_like(x)
+        ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_nsf_ar", _lib.load().mnf_nsf_ar(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, flat.data_ptr(), x.shape[0], module.dim, module.K,
+            float(module.B), int(inverse), len(module.h_sizes), module._hid, _stream()))
+        ctx.module, ctx.inverse = module, inverse
+        ctx.save_for_backward(x, flat)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_ld):
+        x, flat = ctx.saved_tensors
+        m = ctx.module
+        gy = None if grad_y is None else grad_y.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_x = torch.empty_like(x)
+        grad_flat = torch.zeros_like(flat)
+        _lib.check("mnf_nsf_ar_bwd", _lib.load().mnf_nsf_ar_bwd(
+            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), x.shape[0],
+            m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid, _stream()))
+        return grad_x, grad_flat, None, None
+
+
+class NSF_AR(_TwoWayFlow):
+    """Neural-spline autoregressive layer (flows/spline_flow.py:182-235): element i is moved by a spline
+    parametrised by ``layers[i-1](first i elements)`` -- of the output in ``forward`` (sequential), of the input in
+    ``inverse`` --, element 0 by ``init_param``.  Same constructor, attribute names and state_dict keys
+    (``init_param``, ``layers.{i}.{0,2,4,6}.{weight,bias}``) as the reference; the arithmetic is one
+    ``mnf_nsf_ar`` launch per direction on the spline device function NSF_CL uses."""
+
+    def __init__(self, dim: int, K: int = 5, B: float = 3, n_h: int = 8, net_class=MLP) -> None:
+        super().__init__()
+        self.dim, self.K, self.B = int(dim), int(K), B
+        self.layers = nn.ModuleList()
+        self.init_param = nn.Parameter(torch.empty(3 * K - 1))
+        for i in range(1, dim):
+            self.layers.append(net_class(i, n_h, n_h, n_h, 3 * K - 1))
+        _require_mlp(*self.layers)
+        self.h_sizes = tuple(int(s) for s in self.layers[0].layer_sizes[1:-1]) if dim > 1 else (n_h, n_h, n_h)
+        self._hid = _lib.int_array(self.h_sizes)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.uniform_(self.init_param, -1 / 2, 1 / 2)  # spline_flow.py:196-197
+
+    def _packed_params(self) -> list[Tensor]:
+        return [self.init_param] + self._net_params(list(self.layers))
+
+    def _run(self, x, inverse, accum):
+        if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            xg = _grad_input(x)
+            if xg.shape[1] != self.dim:
+                raise ValueError(f"expected dim {self.dim}, got {xg.shape[1]}")
+            flat = torch.cat([p.reshape(-1) for p in self._packed_params()])
+            return _NsfArFn.apply(xg, flat, self, bool(inverse))
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        if x.shape[0] == 0:
+            return _empty_result(x, accum)
+        flat, _ = self._packed(x.device)
+        y = torch.empty_like(x)
+        ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_nsf_ar", _lib.load().mnf_nsf_ar(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), flat.data_ptr(), x.shape[0], self.dim,
+            self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid, _stream()))
         return y, (None if accum is not None else ld)
 
 

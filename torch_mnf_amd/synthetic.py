@@ -58,6 +58,15 @@ def nsf_cl_params(seed: int, dim: int, K: int, n_h: int, gain: float = 1.0) -> d
     return sd
 
 
+def nsf_ar_params(seed: int, dim: int, K: int, n_h: int, gain: float = 1.0) -> dict:
+    """NSF_AR state_dict: init_param ~ U(-1/2, 1/2) (3K-1,), layers.{i-1} = MLP(i, n_h, n_h, n_h, 3K-1)."""
+    rng = np.random.default_rng(seed)
+    sd = {"init_param": torch.from_numpy(rng.uniform(-0.5, 0.5, size=(3 * K - 1,)).astype(np.float32))}
+    for i in range(1, dim):
+        sd.update(mlp_params(rng, f"layers.{i - 1}", (i, n_h, n_h, n_h, 3 * K - 1), gain=gain))
+    return sd
+
+
 def rnvp_params(seed: int, dim: int, h: int, gain: float = 1.5) -> dict:
     """flows.RNVP state_dict: net = Linear(dim, h); t, s = Linear(h, dim)."""
     rng = np.random.default_rng(seed)
