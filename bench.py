@@ -102,6 +102,22 @@ def pmc_traffic(workload: str) -> tuple[float | None, str | None]:
     return None, None
 
 
+def valu_issue(workload: str) -> dict | None:
+    """The committed SQ-counter digest of the dominant kernel (tools/make_valu_json.py): share of the chip's vector
+    issue capacity it used.  Read, not measured in this run (PMC passes serialise the kernels)."""
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()),
+                    key=lambda d: -int(d[1:])) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    for r in rounds:
+        try:
+            with open(os.path.join(ROOT, "profiles", r, f"{workload}_valu_issue.json")) as fh:
+                d = json.load(fh)
+            d["file"] = f"profiles/{r}/{workload}_valu_issue.json"
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def physical(traffic, avg_kernel_s: float) -> dict:
     """The HBM fraction by bytes that actually cross the interface (PMC), next to the SURVEY 8(d) algorithmic one."""
     if not traffic:
@@ -554,6 +570,32 @@ def main() -> None:
             "mean_log_prob": gpu_mean,
             "forward_direction_samples_per_s_per_gpu": fwd_rate,
         }
+        if args.workload in ("c3", "c3f"):
+            # the spline kernel is VALU / transcendental bound by construction (264 B per row against
+            # ~2,300 vector instructions per 16 rows per layer): the roofline it is priced against is the vector
+            # ISSUE rate; the HBM figures stay in the object under their own names.
+            r = out["roofline"]
+            r.update({"hbm_achieved_GBps": r["achieved"], "hbm_frac": r["frac"], "hbm_peak_GBps": r["peak"]})
+            vi = valu_issue("c3")
+            if vi is not None:
+                # instructions per launch from the committed counters, time from THIS run's HIP events
+                cycles_now = vi["effective_clock_GHz"] * 1e9 * avg_kernel_s
+                plain = vi["SQ_INSTS_VALU"] - vi["SQ_INSTS_MFMA"]
+                ginstr = vi["SQ_INSTS_VALU"] / avg_kernel_s / 1e9
+                peak = 1024 / 2.0 * vi["effective_clock_GHz"]
+                r.update({"bound": "valu", "achieved": ginstr, "peak": peak, "unit": "G wave-instr/s",
+                          "frac": (2.0 * plain + 8.0 * vi["SQ_INSTS_MFMA"]) / (1024 * cycles_now),
+                          "frac_plain_count": ginstr / peak,
+                          "valu_source": f"{vi['file']} (SQ_INSTS_VALU {vi['SQ_INSTS_VALU']:.4g}, SQ_INSTS_MFMA "
+                                         f"{vi['SQ_INSTS_MFMA']:.4g} per launch, effective clock "
+                                         f"{vi['effective_clock_GHz']:.2f} GHz from GRBM_GUI_ACTIVE; committed "
+                                         "rocprofv3 --pmc profile, not measured in this run)",
+                          "valu_definition": "frac = (2 cyc x plain vector instr + 8 cyc x MFMA) / (1024 SIMDs x kernel "
+                                             "cycles): share of SIMD issue cycles used; peak = one wave64 vector "
+                                             "instruction per SIMD per 2 cycles"})
+            else:
+                r.update({"bound": "valu", "valu_source": None,
+                          "note": "no committed *_valu_issue.json: achieved / frac are the HBM figures"})
         if world == 1 and not args.no_cpu_baseline:
             info, cpu_mean, n = cpu_baseline(layers, dim, x)
             with torch.no_grad():

@@ -1,0 +1,55 @@
+"""profiles/rN/<workload>_valu_issue.json from the SQ counter passes of tools/profile_bench.sh: how much of the chip's
+vector-instruction issue capacity the dominant kernel used (the C3 spline kernel is VALU / transcendental bound by
+construction).
+usage: make_valu_json.py <gpurun_out/prof_TAG> <workload> <kernel substring> <out.json>"""
+import csv, glob, json, os, sys
+d, workload, kern, out = sys.argv[1:5]
+
+
+def mean_of(sub, counter):
+    for f in sorted(glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True)):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if r["Counter_Name"] == counter and kern in r["Kernel_Name"]]
+        if vals:
+            return sum(vals) / len(vals)
+    return None
+
+
+def kernel_ns():
+    for f in sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Name"]:
+                return float(r["AverageNs"])
+    return None
+
+
+valu = mean_of("pmc_sq", "SQ_INSTS_VALU")            # wave-level vector instructions, MFMAs included
+mfma = mean_of("pmc_sq2", "SQ_INSTS_MFMA")
+mfma_busy = mean_of("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
+gui = mean_of("pmc_sq2", "GRBM_GUI_ACTIVE")          # summed over the 8 XCDs
+wave_cycles = mean_of("pmc_sq", "SQ_WAVE_CYCLES")
+active = mean_of("pmc_sq", "SQ_ACTIVE_INST_ANY")
+ns = kernel_ns()
+cycles = gui / 8.0                                     # shader cycles of the dispatch
+simds = 256 * 4
+# MI355X_MICROARCH.md: a SIMD issues one wave64 vector instruction per 2 cycles (32 lanes / cycle); an MFMA
+# (16x16x16 / 16x16x32 f16) holds the SIMD's vector issue for 8 cycles
+plain = valu - mfma
+issue_cycles = 2.0 * plain + 8.0 * mfma
+json.dump({
+    "kernel": kern, "workload": workload,
+    "SQ_INSTS_VALU": valu, "SQ_INSTS_MFMA": mfma, "SQ_VALU_MFMA_BUSY_CYCLES": mfma_busy, "GRBM_GUI_ACTIVE": gui,
+    "SQ_WAVE_CYCLES": wave_cycles, "SQ_ACTIVE_INST_ANY": active, "kernel_avg_ns_profiled": ns,
+    "effective_clock_GHz": cycles / ns if ns else None,
+    "valu_issue_peak_instr_per_cycle": simds / 2.0,
+    "valu_instr_per_cycle": valu / cycles,
+    "valu_issue_frac": issue_cycles / (simds * cycles),
+    "mfma_pipe_frac": mfma_busy / (simds * cycles) if mfma_busy else None,
+    "definition": "valu_issue_frac = (2 cycles x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 8 cycles x SQ_INSTS_MFMA) / (1024 SIMDs x "
+                  "GRBM_GUI_ACTIVE / 8): the share of the dispatch's SIMD cycles in which a vector instruction was being "
+                  "issued at the hardware's peak issue rate (transcendentals priced like plain instructions: a lower "
+                  "bound of the issue time)",
+    "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload "
+              f"{workload}` (tools/profile_bench.sh)",
+}, open(out, "w"), indent=1)
+print(open(out).read())

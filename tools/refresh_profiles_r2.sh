@@ -16,6 +16,7 @@ for w in $WL; do
   cp "$REPO/gpurun_out/prof_r2_$w/summary.txt" "$OUT/${w}_rocprofv3_summary.txt"
   cp "$REPO"/gpurun_out/prof_r2_$w/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null
   python tools/make_traffic_json.py gpurun_out/prof_r2_$w $w "${KERN[$w]}" "$OUT/${w}_pmc_traffic.json" > /dev/null 2>&1
+  python tools/make_valu_json.py gpurun_out/prof_r2_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" > /dev/null 2>&1
 done
 ls -la "$OUT"
 for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', round(d['value']/1e6,1), 'M/s', round(d['ms_per_step'],3), 'ms', r['bound'], round(r['frac'],3), round(r['avg_kernel_us'],1), 'us', r.get('traffic'))"; done
