@@ -263,6 +263,14 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
                   int64_t rows, int dim, void* stream);
 
+/* ------------------------------------------------------------------ training: one optimizer launch
+ * torch.optim.Adam's update (no amsgrad; weight_decay as L2 on the gradient) over ONE flat buffer: param, grad and
+ * the two moment buffers are n floats each; step counts from 1.  The reference trains its flows with Adam
+ * (tests/test_flows.py:41-50, examples/half_moons.ipynb:170-200); with the model's parameters re-homed in one buffer
+ * (torch_mnf_amd.train.FlatParameters) the optimizer is one launch instead of one list entry per tensor. */
+int mnf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ------------------------------------------------------------------ NSF_AR (reuse of the spline device function)
  * torch_mnf/flows/spline_flow.py:182-235.  Element i is moved by a spline whose 3K-1 parameters come from
  * MLP_i(first i elements) -- of the OUTPUT in forward (inverse = 0; sequential in i; the spline runs inverted, :213-215)

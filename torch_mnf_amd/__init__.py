@@ -9,6 +9,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 """
 from . import _lib
 from .layers import MNFLinear
+from .train import FlatParameters, FusedAdam
 from .flows import (
     MLP,
     ActNormFlow,
@@ -28,7 +29,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "FlatParameters", "FusedAdam", "library_path",
 ]
 
 

@@ -92,6 +92,8 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_void_p]),
     "mnf_nsf_ar": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_int, c_int,
                            _intp, c_void_p]),
     "mnf_nsf_ar_flat_floats": (c_int64, [c_int, c_int, c_int, _intp]),

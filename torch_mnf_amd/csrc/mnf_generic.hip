@@ -539,6 +539,22 @@ __global__ void __launch_bounds__(kThreads) gauss_logprob_sq_kernel(const float*
   }
 }
 
+// torch.optim.Adam's update (no amsgrad, L2 weight decay folded into the gradient) over one flat buffer
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2, float eps,
+                            float weight_decay, float inv_sqrt_bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
+    const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);   // denom = sqrt(v) / sqrt(bc2) + eps
+  }
+}
+
 __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __restrict__ log_var,
                                  const float* __restrict__ eps, float* __restrict__ z0, int64_t n,
                                  int dim) {
@@ -789,6 +805,20 @@ int mnf_pack_gather_batch(const float* flat, const int32_t* idx, float* images, 
 
 int mnf_pack_gather(const float* flat, const int32_t* idx, float* image, int64_t n, void* stream) {
   return mnf_pack_gather_batch(flat, idx, image, n, 1, 0, stream);
+}
+
+// -------------------------------------------------------------------------- fused Adam on one flat buffer
+int mnf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f))
+    return MNF_ERR_INVALID_ARG;
+  if (n == 0) return MNF_OK;
+  // bias corrections in double on the host (torch.optim.Adam: step_size = lr / (1 - beta1^t); denom uses sqrt(1 - beta2^t))
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)));
+  return check_launch();
 }
 
 // -------------------------------------------------------------------------- NSF_AR

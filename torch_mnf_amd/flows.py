@@ -282,7 +282,11 @@ class _AffineRunFn(torch.autograd.Function):
     def forward(ctx, x, flat_with_grad, run, inverse):
         n = len(run.layers)
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        flat = flat_with_grad.detach()
+        # flat-homed parameters (train.FlatParameters): flat_with_grad is a one-element stand-in that only carries
+        # requires_grad; the kernels read the parameter slice and ADD their gradients to the gradient slice in place
+        home = run._flat_home
+        ctx.home = home
+        flat = home[0].data[home[1]:home[1] + home[2]] if home is not None else flat_with_grad.detach()
         imgs = run.images(x.device, flat)  # after a weight update: repacked from this one concatenation
         outs = run.launch(x, inverse, ld, False, None, keep=True, images=imgs) if imgs[0] is not None else None
         if outs is None:
@@ -301,7 +305,8 @@ class _AffineRunFn(torch.autograd.Function):
         order = list(reversed(run.layers)) if inverse else list(run.layers)
         grad_ld = grads[-1]
         gl = None if grad_ld is None else grad_ld.contiguous()
-        grad_flat = torch.zeros_like(flat)
+        home = ctx.home
+        grad_flat = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros_like(flat)
         # offset of every layer's parameters inside the run's flat vector (model order)
         sizes = [sum(p.numel() for p in f._packed_params()) for f in run.layers]
         offs = [0]
@@ -328,7 +333,7 @@ class _AffineRunFn(torch.autograd.Function):
                     len(f.h_sizes), f._hid, int(f.scale), int(f.shift), _stream())
             _lib.check("mnf_affine_half_bwd", rc)
             g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
-        return g, grad_flat, None, None
+        return g, (None if home is not None else grad_flat), None, None
 
 
 class _HipFlow(nn.Module):
@@ -1116,6 +1121,9 @@ class _AffineRun:
         self._unsupported = False  # set once the library reports that the shape has no stack kernel
         self._no_fused_logprob = False  # set once the library reports that the shape has no fused log-prob epilogue
         self.logprob_fused = False
+        self._flat_home = None   # (FlatParameters, offset, length) while the run's parameters live in one buffer
+        self._flat_checked = None
+        self._stand_in = None
 
     @staticmethod
     def compatible(a: "AffineHalfFlow", b: "AffineHalfFlow") -> bool:
@@ -1130,12 +1138,31 @@ class _AffineRun:
             self._plist = (sig, [p for f in self.layers for p in f._packed_params()])
         return self._plist[1]
 
+    def flat_home(self):
+        """(FlatParameters, offset, length) if every parameter of the run is a view of one train.FlatParameters
+        buffer, back to back in order -- then the kernels use that slice (no concatenation, no gradient scatter) --
+        else None.  Re-checked only when the FlatParameters object changes."""
+        flat = self.layers[0].__dict__.get("_mnf_flat")
+        if flat is not self._flat_checked:
+            self._flat_checked, self._flat_home = flat, None
+            if flat is not None:
+                sl = flat.slice_of(self._params())
+                if sl is not None:
+                    self._flat_home = (flat, sl[0], sl[1])
+        return self._flat_home
+
     def images(self, device, flat: Tensor | None = None):
         """(fp32 operand images, split operand images) of all layers, back to back; repacked after a weight update
         with ONE parameter concatenation (``flat``: the caller's, if it already has one) and one launch per kind."""
         params = self._params()
-        key = (device, [f.force_fp32_mfma or not f._split_ok for f in self.layers],
-               [(p.data_ptr(), p._version) for p in params])
+        home = self.flat_home()
+        if home is not None:  # one counter instead of 16 (data_ptr, version) pairs per layer
+            key = (device, [f.force_fp32_mfma or not f._split_ok for f in self.layers], id(home[0]), home[0].generation)
+            if flat is None:
+                flat = home[0].data[home[1]:home[1] + home[2]]
+        else:
+            key = (device, [f.force_fp32_mfma or not f._split_ok for f in self.layers],
+                   [(p.data_ptr(), p._version) for p in params])
         if key != self._key:
             f0, n = self.layers[0], len(self.layers)
             index = f0._device_index(device)
@@ -1186,7 +1213,12 @@ class _AffineRun:
 
     def launch_grad(self, x: Tensor, inverse: bool):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
-        flat = torch.cat([p.reshape(-1) for p in self._params()])
+        if self.flat_home() is not None:
+            if self._stand_in is None or self._stand_in.device != x.device:
+                self._stand_in = torch.zeros(1, device=x.device, requires_grad=True)
+            flat = self._stand_in
+        else:
+            flat = torch.cat([p.reshape(-1) for p in self._params()])
         try:
             out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
         except MnfHipError as err:  # an image exists but no stack kernel (e.g. hidden width 32): layer by layer

@@ -1,0 +1,113 @@
+"""Training support for the flow path: the model's parameters in ONE buffer, the optimizer in ONE launch.
+
+The reference trains its flows with ``torch.optim.Adam(model.parameters())`` (tests/test_flows.py:41-50,
+examples/half_moons.ipynb:170-200).  That works unchanged on these modules; but a 9-layer AffineHalfFlow stack has
+144 small parameter tensors, and at the batch sizes the reference trains at a step is then bound by the host's
+handling of 144 tensors (concatenate for the kernels, scatter the gradient back, a 144-entry optimizer list), not by
+the GPU.  ``FlatParameters`` re-homes every parameter of a model as a view of one contiguous fp32 buffer (names,
+shapes and ``state_dict`` keys unchanged) with every gradient a view of a second one; the fused layers then read
+their parameter slice and write their gradient slice in place, and ``FusedAdam`` updates the whole buffer with one
+``mnf_adam_step`` launch.
+
+    flat = FlatParameters(model)
+    opt = FusedAdam(flat, lr=1e-3)
+    for x in batches:
+        opt.zero_grad()                      # one memset
+        loss = -model.log_prob(x).mean()
+        loss.backward()
+        opt.step()                           # one launch
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .flows import _stream
+
+__all__ = ["FlatParameters", "FusedAdam"]
+
+
+class FlatParameters:
+    """Every trainable parameter of ``model`` as a view of ``self.data`` (fp32, one device), every gradient a view
+    of ``self.grad``, in ``model.parameters()`` order.  ``state_dict`` / ``load_state_dict`` keep working (they copy
+    into the views).  ``generation`` is bumped by whoever rewrites ``data`` in place (FusedAdam.step,
+    ``touch()``): the fused layers key their packed operand images on it."""
+
+    def __init__(self, model: nn.Module) -> None:
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("the model has no trainable parameters")
+        device = params[0].device
+        if any(p.device != device or p.dtype != torch.float32 for p in params):
+            raise ValueError("FlatParameters needs every parameter in float32 on one device")
+        n = sum(p.numel() for p in params)
+        self.model = model
+        self.data = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.offset: dict[int, int] = {}
+        self.generation = 0
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.data[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.data[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                self.offset[id(p)] = off
+                off += k
+        self.params = params
+        for m in model.modules():  # the fused layers look here for their slices
+            m.__dict__["_mnf_flat"] = self
+        if hasattr(model, "invalidate"):
+            model.invalidate()
+
+    def slice_of(self, params: list[Tensor]) -> tuple[int, int] | None:
+        """(offset, length) of ``params`` inside the buffers if they sit there back to back in this order."""
+        off0 = self.offset.get(id(params[0]))
+        if off0 is None:
+            return None
+        off = off0
+        for p in params:
+            if self.offset.get(id(p)) != off:
+                return None
+            off += p.numel()
+        return off0, off - off0
+
+    def zero_grad(self) -> None:
+        """One memset; the per-parameter ``.grad`` views stay in place (``set_to_none`` would detach them)."""
+        self.grad.zero_()
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offset[id(p)]:
+                off = self.offset[id(p)]
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def touch(self) -> None:
+        """Call after writing ``data`` (or a parameter's ``.data``) in place by other means than FusedAdam."""
+        self.generation += 1
+
+
+class FusedAdam:
+    """``torch.optim.Adam`` semantics (no amsgrad; ``weight_decay`` as L2 on the gradient) on a FlatParameters
+    buffer: one ``mnf_adam_step`` launch per step."""
+
+    def __init__(self, flat: FlatParameters, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), \
+            float(weight_decay)
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.steps = 0
+
+    def zero_grad(self) -> None:
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self) -> None:
+        f = self.flat
+        self.steps += 1
+        _lib.check("mnf_adam_step", _lib.load().mnf_adam_step(
+            f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.data.numel(),
+            self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, _stream()))
+        f.generation += 1
