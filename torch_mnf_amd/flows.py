@@ -82,6 +82,14 @@ def _narrow_hidden(h_sizes) -> bool:
     return len(h_sizes) > 0 and min(h_sizes) < _MIN_SPLIT_HIDDEN
 
 
+def _flat_gen(module) -> int:
+    """Generation counter of the train.FlatParameters buffer the module's parameters live in (0: none).  Optimizers
+    that rewrite that buffer through its raw pointer bump it; every packed-parameter cache key includes it, because
+    such a write does not move a parameter's own version counter."""
+    flat = module.__dict__.get("_mnf_flat")
+    return 0 if flat is None else flat.generation
+
+
 def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -422,7 +430,7 @@ class _HipFlow(nn.Module):
         params = self._packed_params()
         if not params:
             return None, None
-        key = (device, tuple((p.data_ptr(), p._version) for p in params))
+        key = (device, _flat_gen(self), tuple((p.data_ptr(), p._version) for p in params))
         if key != self._cache_key:
             flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
             self._flat = flat.contiguous()
@@ -912,7 +920,7 @@ class Glow(_TwoWayFlow):
         return W.to(device=device, dtype=torch.float32).contiguous()
 
     def _weights(self, device, inverse: bool) -> Tensor:
-        key = (device, tuple((p.data_ptr(), p._version) for p in (self.L, self.S, self.U)), id(self.P))
+        key = (device, _flat_gen(self), tuple((p.data_ptr(), p._version) for p in (self.L, self.S, self.U)), id(self.P))
         if key != self._w_key:
             self._w = self._assemble_W(device)
             self._w_inv = None
@@ -990,7 +998,7 @@ class _SplineBlockRun:
     def _affine(self, device, inverse: bool):
         """(aff buffer = [operand image of A | b], log-det constant, [exp(s) | t]) for one direction, cached."""
         an, gl = self.actnorm, self.glow
-        key = (device, tuple((p.data_ptr(), p._version) for p in (an.s, an.t, gl.L, gl.S, gl.U)), id(gl.P))
+        key = (device, _flat_gen(an), tuple((p.data_ptr(), p._version) for p in (an.s, an.t, gl.L, gl.S, gl.U)), id(gl.P))
         if key != self._aff_key:
             self._aff, self._aff_key = {}, key
         if inverse not in self._aff:

@@ -106,7 +106,9 @@ class MNFLinear(nn.Module):
         """(flat parameters, split operand image, var_unscale) of mnf_mnf_linear_fwd for the current parameters, or
         None when the shape has no kernel (n_out > 64).  Repacked when a parameter changes."""
         params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
-        key = (device, tuple((p.data_ptr(), p._version) for p in params))
+        flat_home = self.__dict__.get("_mnf_flat")
+        key = (device, 0 if flat_home is None else flat_home.generation,
+               tuple((p.data_ptr(), p._version) for p in params))
         cache = self.__dict__.get("_fwd_cache")
         if cache is None or cache[0] != key:
             lib = _lib.load()
