@@ -127,26 +127,41 @@ def rnvp_layer(amd, seed, dim=800, hid=50):
     return f.to(DEV), sd
 
 
-class streaming_rnvp:
-    """MNF_RNVP_RESIDENT=0 for the duration: the streaming split kernel instead of the register-resident one."""
+class rnvp_kernel:
+    """Which kernel a seeded d = 800, h = 50 launch runs, for the duration: "resident" (the default: one wave per 16-row
+    tile, rows in the register file), "pair" (MNF_RNVP_PAIR=1: two waves per tile) or "streaming"
+    (MNF_RNVP_RESIDENT=0)."""
+
+    def __init__(self, which):
+        self.env = {"resident": {}, "pair": {"MNF_RNVP_PAIR": "1"}, "streaming": {"MNF_RNVP_RESIDENT": "0"}}[which]
 
     def __enter__(self):
-        os.environ["MNF_RNVP_RESIDENT"] = "0"
+        os.environ.update(self.env)
 
     def __exit__(self, *exc):
-        os.environ.pop("MNF_RNVP_RESIDENT", None)
+        for k in self.env:
+            os.environ.pop(k, None)
 
 
-@pytest.mark.parametrize("rows", [64, 100, 64 * 300, 64 * 300 + 17, 3])
-def test_rnvp_resident_kernel_vs_oracle_and_streaming(amd, O, rows):
-    """d = 800, h = 50 with the in-kernel mask runs the register-resident kernel (every z read once): against the
+def streaming_rnvp():
+    return rnvp_kernel("streaming")
+
+
+REGISTER_KERNELS = ["pair", "resident"]
+
+
+@pytest.mark.parametrize("kernel", REGISTER_KERNELS)
+@pytest.mark.parametrize("rows", [64, 100, 128, 64 * 300, 64 * 301, 64 * 300 + 17, 128 * 700 + 3, 3])
+def test_rnvp_resident_kernel_vs_oracle_and_streaming(amd, O, rows, kernel):
+    """d = 800, h = 50 with the in-kernel mask runs a register-resident kernel (every z read once): against the
     oracle with the mask the launch used, and against the streaming split kernel on the same inputs.  Row counts:
-    whole 64-row groups, a short last group (fp32 body), more groups than CUs (in-place prefetch of the next rows),
-    fewer rows than one group."""
+    whole 64- / 128-row groups, a short last group (fp32 body), more groups than CUs (in-place prefetch of the next
+    rows), fewer rows than one group."""
     f, sd = rnvp_layer(amd, 901)
     z = recipes.gaussian(902, rows, 800, scale=1.3)
     zc = z.to(DEV)
-    x, ld = f.forward(zc, seed=12345)
+    with rnvp_kernel(kernel):
+        x, ld = f.forward(zc, seed=12345)
     mask = f.mask_for(12345, rows)
     ref_x, ref_ld = O.rnvp(z, sd, mask.cpu())
     assert_close(x, ref_x, RTOL, "x vs oracle")
@@ -157,25 +172,30 @@ def test_rnvp_resident_kernel_vs_oracle_and_streaming(amd, O, rows):
     assert_close(ld, ld_s, 2e-6, "log_det vs streaming kernel")
     # accumulate: log_det += inside the kernel, twice
     acc = torch.full((rows,), 0.5, device=DEV)
-    f._run(zc, False, acc, seed=12345)
-    f._run(zc, False, acc, seed=12345)
+    with rnvp_kernel(kernel):
+        f._run(zc, False, acc, seed=12345)
+        f._run(zc, False, acc, seed=12345)
     assert_close(acc, 0.5 + 2 * ref_ld, RTOL, "accumulated log_det")
 
 
 def test_rnvp_resident_kernel_is_the_one_that_runs(amd):
     """The seeded d = 800 launch must not silently stay on the streaming kernel: results differ in the last bits
-    (bias folded into the accumulator), and switching the resident kernel off changes them."""
+    (bias folded into the accumulator; K split over two waves), and switching a kernel off changes them."""
     f, _ = rnvp_layer(amd, 903)
     z = recipes.gaussian(904, 64 * 40, 800).to(DEV)
     with torch.no_grad():
-        x, _ = f.forward(z, seed=5)
+        x_r, _ = f.forward(z, seed=5)
+        with rnvp_kernel("pair"):
+            x_p, _ = f.forward(z, seed=5)
         with streaming_rnvp():
             x_s, _ = f.forward(z, seed=5)
-    assert not torch.equal(x, x_s) and normwise_err(x.cpu(), x_s.cpu()) < 2e-6
+    assert not torch.equal(x_r, x_s) and normwise_err(x_r.cpu(), x_s.cpu()) < 2e-6
+    assert not torch.equal(x_p, x_r) and normwise_err(x_p.cpu(), x_r.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("kernel", REGISTER_KERNELS)
 @pytest.mark.parametrize("case", ["big_inputs", "inf_input", "one_big_row", "big_weights"])
-def test_rnvp_resident_range_guard(amd, O, case):
+def test_rnvp_resident_range_guard(amd, O, case, kernel):
     """A 64-row group whose operands leave the f16 range is flagged and redone by the fp32 body at the end of the
     launch; the other groups stay on the split path."""
     hid, rows, dim = 50, 64 * 9, 800
@@ -198,7 +218,8 @@ def test_rnvp_resident_range_guard(amd, O, case):
     f = amd.RNVP(dim, h_sizes=(hid,))
     f.load_state_dict(sd)
     f.to(DEV)
-    x, ld = f.forward(z.to(DEV), seed=31)
+    with rnvp_kernel(kernel):
+        x, ld = f.forward(z.to(DEV), seed=31)
     ref_x, ref_ld = O.rnvp(z, sd, f.mask_for(31, rows).cpu())
     ok = torch.isfinite(ref_x).all(1)
     assert torch.equal(torch.isfinite(x).all(1).cpu(), ok)
@@ -206,7 +227,8 @@ def test_rnvp_resident_range_guard(amd, O, case):
     assert_close(ld[ok.to(DEV)], ref_ld[ok], RTOL, f"{case} ld")
 
 
-def test_sample_z_on_the_resident_kernel(amd, O):
+@pytest.mark.parametrize("kernel", REGISTER_KERNELS)
+def test_sample_z_on_the_resident_kernel(amd, O, kernel):
     """MNFLinear(800, 50).sample_z: the prologue z0 = q0_mean + q0_std eps is formed when the first flow's rows are
     first used and kept in the register file for the gate epilogue; the second flow accumulates log_det."""
     layer = amd.MNFLinear(800, 50)
@@ -216,7 +238,7 @@ def test_sample_z_on_the_resident_kernel(amd, O):
     rows = 64 * 70 + 5
     eps = recipes.gaussian(77, rows, 800)
     torch.manual_seed(99)
-    with torch.no_grad():
+    with torch.no_grad(), rnvp_kernel(kernel):
         z, ld = layer.sample_z(rows, eps=eps.to(DEV))
         torch.manual_seed(99)  # the same seeds again, masks materialised for the oracle
         seeds = [int(torch.empty((), dtype=torch.int64).random_().item()) for _ in range(2)]

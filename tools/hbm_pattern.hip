@@ -1,0 +1,123 @@
+// Microbenchmark: achieved HBM bandwidth of the register-resident RNVP kernels' access pattern, as a function of how
+// the per-tile accesses are grouped in time.  A wave owns 16 rows x T 16-float tiles (lane = (row j, quarter q): 16
+// bytes per lane per tile, i.e. 16 rows x 64 bytes per instruction, row stride 4 d bytes).  Per pass it "processes"
+// the tiles one after the other (a delay of SLEEP x 64 cycles each), storing the tile to x and re-loading its
+// registers from the next 64 rows' z -- either right away (B = 1, what the kernels do) or in batches of B tiles.
+// build: hipcc -O3 --offload-arch=gfx950 tools/hbm_pattern.hip -o tools/bin/hbm_pattern ; run: tools/bin/hbm_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+// DMA > 0: every processing step also copies DMA 1 KB pieces per wave of an L2-resident image into LDS (the operand
+// ring of the real kernels: 613 KB per 64-row pass per workgroup ~ 2 pieces per wave per step), waiting until at most
+// 16 vector-memory operations are in flight
+template <int DMA, int WAIT, bool PLAIN>
+__device__ __forceinline__ void dma_step(const uint32_t* image, uint32_t* lds, int& piece, int lane, int wave) {
+#pragma unroll
+  for (int i = 0; i < DMA; ++i) {
+    const int p = (piece++ % 72) * 8 + wave;  // 72 x 8 KB = 576 KB image, 128 KB ring in LDS
+    if constexpr (PLAIN) {  // the same bytes as an ordinary load into registers (never read: timing only)
+      asm volatile("global_load_dwordx4 a[0:3], %0, off" ::"v"(image + (int64_t)p * 256 + lane * 4) : "memory", "a0", "a1", "a2", "a3");
+    } else {
+      __builtin_amdgcn_global_load_lds(image + (int64_t)p * 256 + lane * 4, (lds_ptr)(lds + (p % 128) * 256), 16, 0, 0);
+    }
+  }
+  if (DMA > 0 && WAIT < 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+}
+
+template <int T, int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0>
+__global__ void __launch_bounds__(512) pattern(const float* __restrict__ z, float* __restrict__ x, int64_t rows, int d, int gemm1_sleep,
+                                               const uint32_t* __restrict__ image) {
+  extern __shared__ uint32_t lds[];
+  int piece = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, side = wave & 1;
+  const int j = lane & 15, q = lane >> 4;
+  const int n_pass = (int)(rows / 64);
+  f32x4 r[T];
+  // LAYOUT 1: tiles 2p and 2p + 1 are the two 16-byte halves of the lane's 32 contiguous bytes (a row's four lanes
+  // cover one whole 128-byte line per pair of tiles)
+  auto toff = [](int m) { return LAYOUT ? 32 * (m >> 1) + 4 * (m & 1) : 16 * m; };
+  int pass = blockIdx.x;
+  if (pass >= n_pass) return;
+  {
+    const float* zp = z + ((int64_t)pass * 64 + pair * 16 + j) * d + (LAYOUT ? 8 * q : 4 * q) + side * (16 * T);
+#pragma unroll
+    for (int m = 0; m < T; ++m) r[m] = *reinterpret_cast<const f32x4*>(zp + toff(m));
+  }
+  for (; pass < n_pass; pass += gridDim.x) {
+    const int next = pass + gridDim.x < n_pass ? pass + gridDim.x : blockIdx.x;
+    float* xp = x + ((int64_t)pass * 64 + pair * 16 + j) * d + (LAYOUT ? 8 * q : 4 * q) + side * (16 * T);
+    const float* zp = z + ((int64_t)next * 64 + pair * 16 + j) * d + (LAYOUT ? 8 * q : 4 * q) + side * (16 * T);
+    for (int s = 0; s < gemm1_sleep; ++s) {  // the GEMM-1 phase: no row traffic
+      dma_step<DMA, WAIT, PLAIN>(image, lds, piece, lane, wave);
+      __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    if constexpr (B == 0) {  // operand stream only: no row traffic at all
+      for (int m = 0; m < T; ++m) {
+        dma_step<DMA, WAIT, PLAIN>(image, lds, piece, lane, wave);
+        __builtin_amdgcn_s_sleep(SLEEP);
+      }
+    } else
+#pragma unroll
+    for (int m0 = 0; m0 < T; m0 += B) {
+#pragma unroll
+      for (int m = m0; m < m0 + B && m < T; ++m) {
+        dma_step<DMA, WAIT, PLAIN>(image, lds, piece, lane, wave);
+        __builtin_amdgcn_s_sleep(SLEEP);
+        r[m] = r[m] * 1.0001f + 1.f;
+        asm volatile("" : "+v"(r[m]));
+      }
+#pragma unroll
+      for (int m = m0; m < m0 + B && m < T; ++m) *reinterpret_cast<f32x4*>(xp + toff(m)) = r[m];
+#pragma unroll
+      for (int m = m0; m < m0 + B && m < T; ++m) r[m] = *reinterpret_cast<const f32x4*>(zp + toff(m));
+    }
+  }
+}
+
+static uint32_t* g_image = nullptr;
+template <int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0>
+void run(const float* z, float* x, int64_t rows, int d, int g1) {
+  constexpr int T = LAYOUT ? 24 : 25;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
+  CK(hipEventRecord(a));
+  const int N = 10;
+  for (int i = 0; i < N; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  const double us = ms * 1e3 / N, bytes = 8.0 * rows * d;
+  printf("batch %2d  sleep %3d x64 cycles/tile  gemm1 %2d  dma %d KB/step/wave wait vmcnt(%d) %s : %7.1f us  %5.2f TB/s\n", B, SLEEP, g1, DMA, WAIT, LAYOUT ? "lds-dma, line-paired tiles (24 of 25)" : PLAIN ? "plain loads" : "lds-dma", us, bytes / us / 1e6);
+}
+
+int main() {
+  const int64_t rows = 256000; const int d = 800;
+  float *z, *x;
+  CK(hipMalloc(&z, rows * d * 4)); CK(hipMalloc(&x, rows * d * 4));
+  CK(hipMemset(z, 0, rows * d * 4)); CK(hipMemset(x, 0, rows * d * 4));
+  CK(hipMalloc(&g_image, 1 << 20)); CK(hipMemset(g_image, 0, 1 << 20));
+  // no delay at all: the pattern's own ceiling
+  run<1, 0>(z, x, rows, d, 0); run<5, 0>(z, x, rows, d, 0); run<25, 0>(z, x, rows, d, 0);
+  // ~ 350 us of "compute" per launch = 22.4 us per pass = ~ 53k cycles: 12 GEMM-1 units + 25 tiles -> 1400 cycles each
+  run<1, 22>(z, x, rows, d, 12); run<5, 22>(z, x, rows, d, 12); run<25, 22>(z, x, rows, d, 12);
+  run<1, 12>(z, x, rows, d, 12); run<5, 12>(z, x, rows, d, 12); run<25, 12>(z, x, rows, d, 12);
+  // the same with the operand stream through the same L1
+  run<1, 22, 2>(z, x, rows, d, 12); run<5, 22, 2>(z, x, rows, d, 12); run<25, 22, 2>(z, x, rows, d, 12);
+  run<1, 22, 1>(z, x, rows, d, 12); run<1, 22, 4>(z, x, rows, d, 12);
+  // is it the wave's in-order wait or the L1 itself?  the same stream with later / no waits
+  run<1, 22, 2, 32>(z, x, rows, d, 12); run<1, 22, 2, 48>(z, x, rows, d, 12); run<1, 22, 2, 63>(z, x, rows, d, 12);
+  run<1, 22, 2, 4>(z, x, rows, d, 12);
+  run<1, 0, 2, 32>(z, x, rows, d, 12); run<0, 0, 2, 32>(z, x, rows, d, 12); run<0, 22, 2, 32>(z, x, rows, d, 12); run<0, 0, 4, 32>(z, x, rows, d, 12);
+  run<1, 22, 2, 32, true>(z, x, rows, d, 12); run<1, 22, 1, 32, true>(z, x, rows, d, 12); run<1, 22, 4, 32, true>(z, x, rows, d, 12);
+  // tiles paired into whole 128-byte lines (needs the K order of the operand image permuted to match)
+  run<1, 0, 0, 16, false, 1>(z, x, rows, d, 0); run<2, 0, 0, 16, false, 1>(z, x, rows, d, 0);
+  run<1, 22, 0, 16, false, 1>(z, x, rows, d, 12); run<2, 22, 0, 16, false, 1>(z, x, rows, d, 12);
+  run<1, 22, 2, 32, false, 1>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 1>(z, x, rows, d, 12); run<8, 22, 2, 32, false, 1>(z, x, rows, d, 12);
+  return 0;
+}

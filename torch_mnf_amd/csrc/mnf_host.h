@@ -118,6 +118,10 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 
 // the register-resident kernel (mnf_rnvp_resident.hip): in-kernel mask only, selected shapes; MNF_ERR_UNSUPPORTED
 // sends the caller on to the streaming kernels
+// the pair kernel (mnf_rnvp_pair.hip): rows resident in registers, two waves per 16-row tile; same contract
+int rnvp_pair_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
+                     const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
+                     const float* q0_log_var, int vec, hipStream_t stream);
 int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
                          const float* q0_log_var, int vec, hipStream_t stream);

@@ -554,8 +554,11 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   if (!ragged && !rows_aligned) return MNF_ERR_UNSUPPORTED;
   const int vec = rows_aligned && (dim & 3) == 0;
   if (split_image && !mask && rows_aligned) {  // in-kernel mask: the register-resident kernel where it exists
-    const int rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
-                                        q0_log_var, vec, stream);
+    int rc = rnvp_pair_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
+                              q0_log_var, vec, stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+    rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean, q0_log_var,
+                              vec, stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (split_image) {
