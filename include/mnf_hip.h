@@ -58,7 +58,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 5
+#define MNF_ABI_VERSION 6
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -317,6 +317,35 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden_host, int
 int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                              float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
                              int parity, int inverse, int n_hidden, const int* hidden_host, void* stream);
+/* mnf_affine_half_bwd_mfma on the listed 16-row tiles only: tile_list_dev = [count, tile, tile, ...] on the device
+ * (at most list_capacity tiles are read); NULL = every tile.  The fix-up pass of mnf_affine_half_bwd_split. */
+int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                                   float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                                   int parity, int inverse, int n_hidden, const int* hidden_host,
+                                   const int32_t* tile_list_dev, int list_capacity, void* stream);
+/* The same gradients on the f16 matrix pipe in split form (mnf_split.h; same shapes as mnf_affine_half_bwd_mfma):
+ * the training step's kernel (reference: every test in tests/test_flows.py:14-99 trains through these layers).
+ *   bwd_image       split image of the forward AND the transposed operands: mnf_pack_gather_split with the
+ *                   mnf_affine_half_bwd_split_index table (2 * n_split_words + n_plain_words int32s, see _layout);
+ *                   to be repacked after a weight update
+ *   index_dev       the mnf_affine_half_bwd_index table (flush order of the weight-gradient tiles)
+ *   grad_scale_dev  device float, a power of two that brings the incoming gradients near 1 (they are ~1/rows for a
+ *                   mean loss, below f16's normal range): mnf_affine_half_grad_scale writes one from a sample
+ *   cold_list       device int32 [1 + cold_capacity], cold_list[0] zeroed by the caller: 16-row tiles with an
+ *                   operand outside the split range are appended and NOT accumulated; the caller then runs
+ *                   mnf_affine_half_bwd_mfma_tiles on that list (same stream).  cold_capacity >= ceil(rows / 16)
+ *                   never overflows.
+ * grad_x is written, grad_flat ADDED to, as for the other gradient entry points. */
+int mnf_affine_half_bwd_split_layout(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                                     int64_t* n_split_words, int64_t* n_plain_words);
+int mnf_affine_half_bwd_split_index(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                                    int32_t* idx_host);
+int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_t rows, int dim, float* scale_out_dev,
+                               void* stream);
+int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                              float* grad_flat, const void* bwd_image, const int32_t* index_dev, int64_t rows, int dim,
+                              int parity, int inverse, int n_hidden, const int* hidden_host,
+                              const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, void* stream);
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);

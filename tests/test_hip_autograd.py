@@ -56,12 +56,32 @@ def test_affine_half_gradients(amd, O, dim, kw, inverse):
         assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
 
 
+def ahf_grads(amd, sd, dim, h_sizes, parity, inverse, x_cpu, w_y, w_l, mode):
+    """Gradients of one AffineHalfFlow on the GPU through the kernel `mode` names: "split" (the default: f16 split
+    MFMAs), "fp32" (fp32 MFMAs, forward too) or "generic"."""
+    f = amd.AffineHalfFlow(dim, parity, h_sizes=h_sizes)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    assert f._bwd_index(torch.device(DEV, 0)) is not None
+    f.force_generic = mode == "generic"
+    f.force_fp32_mfma = mode == "fp32"
+    assert (f._bwd_split_ok() and bool(f._bwd_split_index(torch.device(DEV, 0)))) == (mode == "split")
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = f.forward(x, inverse=inverse)
+    floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, 0  # (small batches default to the fp32 kernel)
+    try:
+        ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    finally:
+        amd.flows._BWD_SPLIT_MIN_ROWS = floor
+    return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+
+
 @pytest.mark.parametrize("dim,hid", [(64, 24), (32, 24), (64, 16), (32, 16)])
 @pytest.mark.parametrize("parity", [False, True])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_affine_half_mfma_gradient_kernel(amd, O, dim, hid, parity, inverse):
-    """The fp32-MFMA gradient kernel (every shape it exists for, ragged row count, both parities) against
-    autograd through the oracle and against the generic gradient kernel."""
+    """The split-MFMA and the fp32-MFMA gradient kernels (every shape they exist for, ragged row count, both
+    parities) against autograd through the oracle and against the generic gradient kernel."""
     h_sizes = (hid, hid, hid)
     sd = recipes.affine_half_params(61 + dim + hid, dim, h_sizes=h_sizes, s_last_gain=2.0)
     rows = 1000 + 7
@@ -71,23 +91,65 @@ def test_affine_half_mfma_gradient_kernel(amd, O, dim, hid, parity, inverse):
     p = leaf(sd)
     y, ld = O.affine_half(x_cpu, p, parity, inverse)
     ((y * w_y).sum() + (ld * w_l).sum()).backward()
-    grads = {}
-    for generic in (False, True):
-        f = amd.AffineHalfFlow(dim, parity, h_sizes=h_sizes)
-        f.load_state_dict(sd)
-        f.to(DEV)
-        assert f._bwd_index(torch.device(DEV, 0)) is not None
-        f.force_generic = generic
-        x = x_cpu.detach().to(DEV).requires_grad_(True)
-        yg, ldg = f.forward(x, inverse=inverse)
-        ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
-        grads[generic] = {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
-        if not generic:
-            assert_close(x.grad, x_cpu.grad, GTOL, "grad_x")
-            for name, prm in f.named_parameters():
-                assert_close(prm.grad, p[name].grad, GTOL, f"grad {name}")
-    for k in grads[False]:
-        assert_close(grads[False][k], grads[True][k], GTOL, f"mfma vs generic {k}")
+    grads = {mode: ahf_grads(amd, sd, dim, h_sizes, parity, inverse, x_cpu, w_y, w_l, mode)
+             for mode in ("split", "fp32", "generic")}
+    for mode in ("split", "fp32"):
+        assert_close(grads[mode]["x"], x_cpu.grad, GTOL, f"{mode} grad_x")
+        for name in p:
+            assert_close(grads[mode][name], p[name].grad, GTOL, f"{mode} grad {name}")
+        for k in grads[mode]:
+            assert_close(grads[mode][k], grads["generic"][k], GTOL, f"{mode} vs generic {k}")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("magnitude", [1e-7, 3e-3, 40.0])
+def test_split_gradient_kernel_does_not_depend_on_the_gradient_scale(amd, O, inverse, magnitude):
+    """Cotangents of a mean over 2^20 rows are ~1e-6, far below f16's normal range: the split kernel normalises them
+    by a power of two taken from a sample of the rows (exact) and scales the results back."""
+    dim, h_sizes, rows = 64, (24, 24, 24), 4096 + 300   # (rows beyond the 512-row sample too)
+    sd = recipes.affine_half_params(171, dim, h_sizes=h_sizes, s_last_gain=2.0)
+    x_cpu = recipes.gaussian(172, rows, dim).requires_grad_(True)
+    w_y = recipes.gaussian(173, rows, dim) * magnitude
+    w_l = recipes.gaussian(174, rows, 1)[:, 0] * magnitude
+    w_y[4200:] *= 37.0  # larger than anything in the sample
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, True, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    g = ahf_grads(amd, sd, dim, h_sizes, True, inverse, x_cpu, w_y, w_l, "split")
+    assert_close(g["x"], x_cpu.grad, GTOL, "grad_x")
+    for name in p:
+        assert_close(g[name], p[name].grad, GTOL, f"grad {name}")
+
+
+@pytest.mark.parametrize("case", ["big_rows", "big_gradients", "big_weights"])
+def test_split_gradient_kernel_range_guard(amd, O, case):
+    """16-row tiles with an operand outside the split range (inputs, activations or deltas) are handed to the fp32
+    kernel (fix-up pass over the listed tiles); a layer whose weights exceed the weight limit runs there entirely."""
+    dim, h_sizes, rows = 64, (24, 24, 24), 16 * 40 + 5
+    sd = recipes.affine_half_params(181, dim, h_sizes=h_sizes, s_last_gain=1.0)
+    x = recipes.gaussian(182, rows, dim)
+    w_y = recipes.gaussian(183, rows, dim)
+    w_l = recipes.gaussian(184, rows, 1)[:, 0]
+    if case == "big_rows":
+        x = x.clone()
+        x[37] *= 3e4
+        x[300:320] *= 1e5
+        sd = {k: (v * 1e-5 if k.endswith("_net.0.weight") else v) for k, v in sd.items()}
+    elif case == "big_gradients":
+        w_y = w_y.clone()
+        w_y[5] *= 1e6      # in the sample: sets the scale; the other rows become small, not wrong
+        w_y[4000 % rows] *= 1e5
+    elif case == "big_weights":
+        sd = {k: (v * 1e3 if k == "s_net.0.weight" else v) for k, v in sd.items()}
+        x = x * 1e-3
+    x_cpu = x.requires_grad_(True)
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, False, False)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    g = ahf_grads(amd, sd, dim, h_sizes, False, False, x_cpu, w_y, w_l, "split" if case != "big_weights" else "split")
+    assert_close(g["x"], x_cpu.grad, GTOL, "grad_x")
+    for name in p:
+        assert_close(g[name], p[name].grad, GTOL, f"grad {name}")
 
 
 @pytest.mark.parametrize("dim", [64, 2, 10, 256])
@@ -274,6 +336,42 @@ def test_stack_gradients_through_normalizing_flow(amd, O):
         for name, prm in mod.named_parameters():
             ref = spec["params"][name].grad
             assert_close(prm.grad, ref, 5e-5, f"layer {i} grad {name}")
+
+
+@pytest.mark.parametrize("flat_home", [False, True])
+def test_affine_run_backward_on_the_split_gradient_kernel(amd, O, flat_home):
+    """The 9-layer d = 64 stack as one autograd node, mean-log-prob loss (cotangents ~1/rows): the backward pass runs
+    the split gradient kernel layer by layer with one gradient scale for the run, one batched operand repack and a
+    fix-up list per layer.  Parameter gradients against the oracle's autograd and against the fp32 gradient kernel;
+    with train.FlatParameters the kernels add into the flat gradient buffer in place."""
+    dim, rows = 64, 3000 + 5
+    sds = recipes.c2_stack_params(dim)
+    x_cpu = recipes.gaussian(501, rows, dim)
+    specs = [{"kind": "affine_half", "parity": bool(i % 2), "params": leaf(sd)} for i, sd in enumerate(sds)]
+    zs, ld = O.flow_stack(x_cpu, specs, inverse=True)
+    (-(ld + O.std_normal_log_prob(zs[-1])).mean()).backward()
+
+    def gpu_grads(min_rows):
+        flows = []
+        for i, sd in enumerate(sds):
+            f = amd.AffineHalfFlow(dim, parity=bool(i % 2)); f.load_state_dict(sd); flows.append(f)
+        model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
+        flat = amd.FlatParameters(model) if flat_home else None
+        floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, min_rows
+        try:
+            if flat is not None:
+                flat.zero_grad()
+            (-model.log_prob(x_cpu.to(DEV)).mean()).backward()
+        finally:
+            amd.flows._BWD_SPLIT_MIN_ROWS = floor
+        return [{n: q.grad.clone() for n, q in f.named_parameters()} for f in flows]
+
+    split, fp32 = gpu_grads(0), gpu_grads(1 << 30)
+    for i, spec in enumerate(specs):
+        for name, ref in spec["params"].items():
+            assert_close(split[i][name], ref.grad, 5e-5, f"layer {i} grad {name} vs oracle")
+            assert_close(split[i][name], fp32[i][name], 5e-5, f"layer {i} grad {name} vs the fp32 kernel")
+    assert any(not torch.equal(split[i][n], fp32[i][n]) for i in range(len(sds)) for n in split[i])  # (it did switch)
 
 
 def moons(n):

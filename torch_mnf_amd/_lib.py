@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 5  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 6  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -84,6 +84,13 @@ SIGNATURES = {
     "mnf_affine_half_bwd_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_bwd_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_int, c_int, c_int, c_int, _intp, c_void_p]),
+    "mnf_affine_half_bwd_mfma_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int64, c_int, c_int, c_int, c_int, _intp, c_void_p, c_int, c_void_p]),
+    "mnf_affine_half_bwd_split_layout": (c_int, [c_int, c_int, _intp, c_int, c_int, _i64p, _i64p]),
+    "mnf_affine_half_bwd_split_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
+    "mnf_affine_half_grad_scale": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mnf_affine_half_bwd_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                          c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int, c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

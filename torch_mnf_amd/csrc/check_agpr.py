@@ -6,12 +6,15 @@ script reads the device assembly of such a file and fails when any instruction O
 accumulator register, or when the kernel touches scratch memory (a scratch access would join the vector-memory
 queue the kernel's hand-counted s_waitcnt vmcnt(N) values describe).
 
-usage: python check_agpr.py file.s"""
+With a second argument N the compiler may use a0 .. a(N-1) itself (a kernel whose own values overflow the 256 vector
+registers: it allocates accumulator registers from a0 upwards, the hand-managed ones then sit at the top of the file).
+
+usage: python check_agpr.py file.s [N]"""
 import re
 import sys
 
 
-def main(path):
+def main(path, allowed=0):
     inside, bad, kernel = False, [], None
     for n, line in enumerate(open(path), 1):
         t = line.strip()
@@ -23,7 +26,8 @@ def main(path):
             kernel = t[:-1]
         elif not inside and t and t[0] not in ";.":
             code = t.split(";")[0]
-            if re.search(r"\ba\[?\d", code) or code.startswith("scratch_"):
+            regs = [int(g) for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?", code) for g in m.groups() if g is not None]
+            if (regs and max(regs) >= allowed) or code.startswith("scratch_"):
                 bad.append((n, kernel, code.strip()))
     for n, kernel, code in bad[:20]:
         print(f"{path}:{n}: {kernel}: compiler-generated `{code}`", file=sys.stderr)
@@ -35,4 +39,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0))

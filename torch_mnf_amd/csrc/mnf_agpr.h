@@ -39,6 +39,14 @@ __device__ __forceinline__ void reserve_agprs_117() {
                MNF_A4(4), MNF_A4(5), MNF_A4(6), MNF_A4(7), MNF_A4(8), MNF_A4(9), MNF_A4(10), "a110", "a111", "a112",
                "a113", "a114", "a115", "a116");
 }
+// a92 .. a255: the TOP of the accumulator file (mnf_ahf_bwd_split.hip: its own values overflow the 256 vector
+// registers and the compiler places them from a0 upwards; check_agpr.py is told how far up it may go)
+constexpr int kTopAgprBase = 92;
+__device__ __forceinline__ void reserve_agprs_top() {
+  asm volatile("" ::: "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", MNF_A4(10), MNF_A4(11), MNF_A4(12),
+               MNF_A4(13), MNF_A4(14), MNF_A4(15), MNF_A4(16), MNF_A4(17), MNF_A4(18), MNF_A4(19), MNF_A4(20),
+               MNF_A4(21), MNF_A4(22), MNF_A4(23), MNF_A4(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
 #undef MNF_A4
 template <int GRP>
 __device__ __forceinline__ void row_load(const float* p) {  // a[4 GRP : 4 GRP + 3] <- 16 bytes at p + 64 GRP

@@ -16,57 +16,12 @@
 // workgroup through an index table the caller builds once per shape (mnf_affine_half_bwd_index).
 #include <hip/hip_runtime.h>
 
+#include "mnf_ahf_bwd_shape.h"
 #include "mnf_ahf_shape.h"
 #include "mnf_device.h"
 #include "mnf_host.h"
 
 namespace mnf {
-
-constexpr int kBwdWaves = 4;
-constexpr int kTilePitch = 20;                     // floats per row of an LDS scratch tile
-constexpr int kTileFloats = 16 * kTilePitch;
-
-template <int H, int HID>
-struct BwdShape {
-  static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported shape");
-  static constexpr int G = H / 16;
-  static constexpr int NT = (2 * HID + 15) / 16;
-  static constexpr int tile_nets(int m) {  // bit 0 = s, bit 1 = t
-    int nets = 0;
-    for (int i = 0; i < 16; ++i)
-      if (16 * m + i < 2 * HID) nets |= 1 << ((16 * m + i) / HID);
-    return nets;
-  }
-  static constexpr bool needs(int m, int mt) { return (tile_nets(m) & tile_nets(mt)) != 0; }
-  static constexpr int pairs() {
-    int n = 0;
-    for (int m = 0; m < NT; ++m)
-      for (int mt = 0; mt < NT; ++mt) n += needs(m, mt) ? 1 : 0;
-    return n;
-  }
-  static constexpr int net_tiles() {  // (hidden tile, net) incidences
-    int n = 0;
-    for (int m = 0; m < NT; ++m) n += (tile_nets(m) & 1) + ((tile_nets(m) >> 1) & 1);
-    return n;
-  }
-  static constexpr int PAIRS = pairs(), NET_TILES = net_tiles();
-  // MFMA operand counts (one op = 64 floats), in image order
-  static constexpr int N_F1 = NT * G * 4, N_FH = PAIRS * 4, N_F4 = NET_TILES * G * 4;
-  static constexpr int N_B4 = NET_TILES * G * 4, N_BH = PAIRS * 4, N_B1 = G * NT * 4;
-  static constexpr int N_OPS = N_F1 + 2 * N_FH + N_F4 + N_B4 + 2 * N_BH + N_B1;
-  static constexpr int A_FLOATS = ((N_OPS + 3) / 4) * 256;
-  static constexpr int BIAS_TILES = 3 * NT + 2 * G;
-  static constexpr int IMAGE_FLOATS = A_FLOATS + BIAS_TILES * 16;
-  // weight-gradient tiles: layer 1 (NT x G), hidden x 2 (PAIRS each), output (NET_TILES x G)
-  static constexpr int DW_TILES = NT * G + 2 * PAIRS + NET_TILES * G;
-  static constexpr int DB_TILES = 3 * NT + 2 * G;
-  // LDS scratch tiles per wave: x0 (G), h1..h3 (3 NT), deltas (max(NT, 2 G))
-  static constexpr int D_TILES = NT > 2 * G ? NT : 2 * G;
-  static constexpr int SCRATCH_TILES = G + 3 * NT + D_TILES;
-  // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
-  static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
-  static constexpr int LDS_FLOATS = IMAGE_FLOATS + kBwdWaves * SCRATCH_TILES * kTileFloats;
-};
 
 // D-layout tile (lane (j, q) holds units 4q..4q+3 of row j) -> LDS scratch [row][unit]
 __device__ __forceinline__ void tile_to_lds(float* tile, int j, int q, const f32x4& v) {
@@ -85,8 +40,12 @@ template <int H, int HID, bool INV>
 __global__ void __launch_bounds__(kBwdWaves * 64, 1)
 ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                     float* __restrict__ grad_x, float* __restrict__ grad_flat, const float* __restrict__ flat,
-                    const int32_t* __restrict__ index, int64_t rows, int parity) {
+                    const int32_t* __restrict__ index, int64_t rows, int parity, const int32_t* __restrict__ tile_list,
+                    int list_capacity) {
   using S = BwdShape<H, HID>;
+  // tile_list = [count, tile, tile, ...]: only those 16-row tiles (the ones mnf_affine_half_bwd_split handed back
+  // because an operand left the split range); nullptr: every tile
+  if (tile_list && tile_list[0] == 0) return;
   constexpr int G = S::G, NT = S::NT, dim = 2 * H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < S::IMAGE_FLOATS; i += blockDim.x) {
@@ -110,7 +69,9 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   for (int t = 0; t < S::DB_TILES; ++t) db[t] = 0.f;
 
   const int n_tiles = (int)((rows + 15) >> 4);
-  for (int tile = (int)blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kBwdWaves) {
+  const int n_items = tile_list ? (tile_list[0] < list_capacity ? tile_list[0] : list_capacity) : n_tiles;
+  for (int item = (int)blockIdx.x * kBwdWaves + wave; item < n_items; item += (int)gridDim.x * kBwdWaves) {
+    const int tile = tile_list ? tile_list[1 + item] : item;
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
@@ -469,7 +430,7 @@ static void build_bwd_index(int32_t* idx) {
 template <int H, int HID>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                       const float* flat, const int32_t* index, int64_t rows, int parity, int inverse,
-                      hipStream_t stream) {
+                      const int32_t* tile_list, int list_capacity, hipStream_t stream) {
   using S = BwdShape<H, HID>;
   constexpr size_t lds_bytes = S::LDS_FLOATS * sizeof(float);
   static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
@@ -484,13 +445,14 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)
+  if (tile_list && blocks > 32) blocks = 32;  // a fix-up pass: the list is short (usually empty: the kernel then returns at once)
   const dim3 grid((unsigned)blocks), block(kBwdWaves * 64);
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, flat, index, rows, parity);
+                       grad_flat, flat, index, rows, parity, tile_list, list_capacity);
   else
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
-                       grad_x, grad_flat, flat, index, rows, parity);
+                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity);
   return check_launch();
 }
 
@@ -533,7 +495,16 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_
 int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                              float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
                              int parity, int inverse, int n_hidden, const int* hidden, void* stream) {
+  return mnf_affine_half_bwd_mfma_tiles(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows, dim, parity,
+                                        inverse, n_hidden, hidden, nullptr, 0, stream);
+}
+
+int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                                   float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                                   int parity, int inverse, int n_hidden, const int* hidden, const int32_t* tile_list,
+                                   int list_capacity, void* stream) {
   int hid = 0;
+  if (list_capacity < 0) return MNF_ERR_INVALID_ARG;
   if (!x || !grad_x || !flat || !index_dev || rows < 0 || dim < 2 || (dim & 1) || !mnf::hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
@@ -543,7 +514,7 @@ int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* g
 #define X(HH, HD)                                                                                              \
   if (dim == 2 * HH && hid == HD)                                                                              \
     return mnf::launch_bwd<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows, parity != 0, \
-                                   inverse != 0, (hipStream_t)stream);
+                                   inverse != 0, tile_list, list_capacity, (hipStream_t)stream);
   MNF_AHF_BWD_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

@@ -200,12 +200,17 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
 // d <= 64: two row tiles per wave (shared operand reads), four waves, two workgroups per CU.
 // d >= 128: the rows of ONE tile already take 32-64 VGPRs and the double-buffered image 90-150 KB of LDS:
 // one tile per wave, eight waves sharing the image, one workgroup per CU (still two waves per SIMD).
+#ifndef MNF_STACK_TILES  // experiment switches for d <= 64 (tools/kernel_variants.sh)
+#define MNF_STACK_TILES 2
+#define MNF_STACK_WAVES 4
+#define MNF_STACK_WPS 2
+#endif
 template <int H>
-constexpr int stack_tiles() { return H <= 32 ? 2 : 1; }
+constexpr int stack_tiles() { return H <= 32 ? MNF_STACK_TILES : 1; }
 template <int H>
-constexpr int stack_waves() { return H <= 32 ? 4 : 8; }
+constexpr int stack_waves() { return H <= 32 ? MNF_STACK_WAVES : 8; }
 template <int H>
-constexpr int stack_waves_per_simd() { return 2; }
+constexpr int stack_waves_per_simd() { return H <= 32 ? MNF_STACK_WPS : 2; }
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // Image copy L2 -> LDS by LDS-DMA (no staging registers).  One wave-instruction copies 64 x 16 B; the LDS

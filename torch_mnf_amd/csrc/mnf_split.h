@@ -173,6 +173,13 @@ struct SplitShape {
         if (uses(1 << net, ks)) n += G;
     return n;
   }
+  static constexpr int hidden_ops() {  // operand pairs of one hidden layer
+    int n = 0;
+    for (int m = 0; m < NT; ++m)
+      for (int ks = 0; ks < NKS; ++ks)
+        if (uses(tile_nets(m), ks)) ++n;
+    return n;
+  }
   static constexpr int N_OPS = count_ops();              // (hi, lo) A-operand pairs = MFMA triples
   static constexpr int SPLIT_WORDS = N_OPS * 2 * 256;    // [op][hi|lo][lane][4 words]
   static constexpr int N_BIAS_TILES = 3 * NT + 2 * G;

@@ -32,6 +32,12 @@ from ._lib import MnfHipError
 
 # MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
 _FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
+# MNF_BWD_FP32=1: AffineHalfFlow gradients on the fp32-MFMA kernel instead of the split one, for A/B measurements
+_BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
+# ... and below this many rows anyway: the split kernel needs three small launches more per backward pass (gradient
+# scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
+# 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
+_BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "32768"))
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 # MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
@@ -126,6 +132,44 @@ def _wants_grad(module: nn.Module, x: Tensor) -> bool:
     return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
+def _grad_scale(gy: Tensor | None, gl: Tensor | None, rows: int, dim: int, device) -> Tensor:
+    """Device float: the power of two that brings the incoming gradients near 1 (the split gradient kernel carries
+    them as f16 pairs; a mean loss makes them ~1/rows).  Taken from a sample of the rows, without a host round trip."""
+    if gy is None and gl is None:
+        return torch.ones(1, dtype=torch.float32, device=device)
+    scale = torch.empty(1, dtype=torch.float32, device=device)
+    _lib.check("mnf_affine_half_grad_scale", _lib.load().mnf_affine_half_grad_scale(
+        _ptr(gy), _ptr(gl), rows, dim, scale.data_ptr(), _stream()))
+    return scale
+
+
+def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr, flat_ptr, bwd_image_ptr, scale, cold,
+                        inverse: bool) -> None:
+    """Gradients of ONE AffineHalfFlow layer: the split-MFMA kernel (+ its fp32 fix-up pass over the tiles it handed
+    back), else the fp32-MFMA kernel, else the generic one.  grad_x is written, the flat gradient added to."""
+    rows, hid = x_in.shape[0], (len(f.h_sizes), f._hid)
+    index = f._bwd_index(x_in.device) if grad_flat_ptr is not None and not f.force_generic else None
+    rc = _lib.MNF_ERR_UNSUPPORTED
+    if index is not None and bwd_image_ptr is not None:
+        cap = cold.numel() - 1
+        rc = lib.mnf_affine_half_bwd_split(
+            x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, bwd_image_ptr, index.data_ptr(), rows,
+            f.dim, int(bool(f.parity)), int(inverse), *hid, scale.data_ptr(), cold.data_ptr(), cap, _stream())
+        if rc == _lib.MNF_OK:
+            rc = lib.mnf_affine_half_bwd_mfma_tiles(
+                x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
+                f.dim, int(bool(f.parity)), int(inverse), *hid, cold.data_ptr(), cap, _stream())
+    if rc == _lib.MNF_ERR_UNSUPPORTED and index is not None:
+        rc = lib.mnf_affine_half_bwd_mfma(
+            x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows, f.dim,
+            int(bool(f.parity)), int(inverse), *hid, _stream())
+    if rc == _lib.MNF_ERR_UNSUPPORTED:  # no MFMA gradient kernel for this shape (e.g. a narrow half)
+        rc = lib.mnf_affine_half_bwd(
+            x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, rows, f.dim,
+            int(bool(f.parity)), int(inverse), *hid, int(f.scale), int(f.shift), _stream())
+    _lib.check("mnf_affine_half_bwd", rc)
+
+
 class _AffineHalfFn(torch.autograd.Function):
     """AffineHalfFlow with gradients: forward = the usual kernel, backward = mnf_affine_half_bwd
     (recomputes the conditioner, returns grad wrt x and wrt the flat parameter vector; autograd's
@@ -153,19 +197,15 @@ class _AffineHalfFn(torch.autograd.Function):
         gl = None if grad_ld is None else grad_ld.contiguous()
         grad_x = torch.empty_like(x)
         grad_flat = torch.zeros_like(flat)
-        index = m._bwd_index(x.device) if flat.numel() and not m.force_generic else None
-        if index is not None:  # fp32-MFMA gradient kernel
-            rc = _lib.load().mnf_affine_half_bwd_mfma(
-                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
-                index.data_ptr(), x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse), len(m.h_sizes), m._hid,
-                _stream())
-            if rc != _lib.MNF_ERR_UNSUPPORTED:
-                _lib.check("mnf_affine_half_bwd_mfma", rc)
-                return grad_x, grad_flat, None, None
-        _lib.check("mnf_affine_half_bwd", _lib.load().mnf_affine_half_bwd(
-            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), _ptr(grad_flat) if flat.numel() else None,
-            _ptr(flat) if flat.numel() else None, x.shape[0], m.dim, int(bool(m.parity)), int(ctx.inverse),
-            len(m.h_sizes), m._hid, int(m.scale), int(m.shift), _stream()))
+        has = flat.numel() > 0
+        bwd = (m._bwd_split_image(x.device, flat)
+               if has and not m.force_generic and x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None)
+        scale = cold = None
+        if bwd is not None:
+            scale = _grad_scale(gy, gl, x.shape[0], m.dim, x.device)
+            cold = torch.zeros((x.shape[0] + 15) // 16 + 1, dtype=torch.int32, device=x.device)
+        _ahf_layer_backward(_lib.load(), m, x, gy, gl, grad_x, _ptr(grad_flat) if has else None,
+                            _ptr(flat) if has else None, _ptr(bwd), scale, cold, ctx.inverse)
         return grad_x, (grad_flat if flat.numel() else None), None, None
 
 
@@ -322,24 +362,23 @@ class _AffineRunFn(torch.autograd.Function):
             offs.append(offs[-1] + sz)
         lib = _lib.load()
         g = grads[n - 1]
+        # split gradient kernel: every layer's backward image from one launch, one gradient scale for the run (the
+        # magnitude changes by e^s per layer: far inside the split range), one fix-up list per layer
+        bwd = run.bwd_images(x.device, flat) if x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None
+        scale = cold = None
+        if bwd is not None:
+            first = next((t for t in reversed(grads[:n]) if t is not None), None)
+            scale = _grad_scale(None if first is None else first.contiguous(), gl, x.shape[0], x.shape[1], x.device)
+            cold = torch.zeros((n, (x.shape[0] + 15) // 16 + 1), dtype=torch.int32, device=x.device)
         for li in range(n - 1, -1, -1):
             f = order[li]
             k = run.layers.index(f)
             gy = None if g is None else g.contiguous()
             gx = torch.empty_like(x)
-            index = f._bwd_index(x.device)
-            rc = _lib.MNF_ERR_UNSUPPORTED
-            if index is not None:
-                rc = lib.mnf_affine_half_bwd_mfma(
-                    inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
-                    flat.data_ptr() + 4 * offs[k], index.data_ptr(), x.shape[0], f.dim,
-                    int(bool(f.parity)), int(inverse), len(f.h_sizes), f._hid, _stream())
-            if rc == _lib.MNF_ERR_UNSUPPORTED:  # no MFMA gradient kernel for this shape (e.g. a narrow half)
-                rc = lib.mnf_affine_half_bwd(
-                    inputs[li].data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat.data_ptr() + 4 * offs[k],
-                    flat.data_ptr() + 4 * offs[k], x.shape[0], f.dim, int(bool(f.parity)), int(inverse),
-                    len(f.h_sizes), f._hid, int(f.scale), int(f.shift), _stream())
-            _lib.check("mnf_affine_half_bwd", rc)
+            _ahf_layer_backward(lib, f, inputs[li], gy, gl, gx, grad_flat.data_ptr() + 4 * offs[k],
+                                flat.data_ptr() + 4 * offs[k],
+                                None if bwd is None else bwd[0].data_ptr() + 4 * bwd[1] * k, scale,
+                                None if cold is None else cold[k], inverse)
             g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
         return g, (None if home is not None else grad_flat), None, None
 
@@ -503,6 +542,42 @@ class AffineHalfFlow(_TwoWayFlow):
         _lib.check("mnf_affine_half_image_index", lib.mnf_affine_half_image_index(
             self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
         return idx
+
+    def _bwd_split_index(self, device):
+        """(device index table, n_split_words, n_plain_words) of the split gradient kernel's operand image (forward
+        and transposed weights), built once per module; False: no such kernel for this shape."""
+        cached = self.__dict__.get("_bwd_split_index_cache")
+        if cached is None or (cached and cached[0].device != device):
+            lib = _lib.load()
+            n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = lib.mnf_affine_half_bwd_split_layout(self.dim, len(self.h_sizes), self._hid, self.scale, self.shift,
+                                                      ctypes.byref(n_split), ctypes.byref(n_plain))
+            cached = False
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_affine_half_bwd_split_layout", rc)
+                idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+                _lib.check("mnf_affine_half_bwd_split_index", lib.mnf_affine_half_bwd_split_index(
+                    self.dim, len(self.h_sizes), self._hid, self.scale, self.shift, idx))
+                cached = (torch.frombuffer(idx, dtype=torch.int32).clone().to(device), n_split.value, n_plain.value)
+            self.__dict__["_bwd_split_index_cache"] = cached
+        return cached
+
+    def _bwd_split_ok(self) -> bool:
+        return not (self.force_fp32_mfma or _FP32_MFMA_ENV or _BWD_FP32_ENV or self.force_generic or not self._split_ok)
+
+    def _bwd_split_image(self, device, flat: Tensor) -> Tensor | None:
+        """The split gradient kernel's operand image for the parameters in ``flat`` (packed per call: the weights
+        change between training steps), or None when this layer's gradients run on the fp32 kernels."""
+        if not self._bwd_split_ok():
+            return None
+        table = self._bwd_split_index(device)
+        if not table:
+            return None
+        idx, n_split, n_plain = table
+        image = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=device)
+        _lib.check("mnf_pack_gather_split", _lib.load().mnf_pack_gather_split(
+            flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, n_plain, _stream()))
+        return image
 
     def _bwd_index(self, device) -> Tensor | None:
         """Device index table of the MFMA gradient kernel (built once per module), or None."""
@@ -1196,6 +1271,23 @@ class _AffineRun:
                         _stream()))
             self._key = key
         return self._images, self._splits
+
+    def bwd_images(self, device, flat: Tensor):
+        """(split gradient-kernel images of all layers back to back, words per image) for the parameters in ``flat``
+        (the run's concatenation, model order), or None when the gradients run on the fp32 kernels.  Packed per
+        backward pass with one launch: the weights change between steps."""
+        f0, n = self.layers[0], len(self.layers)
+        if not all(f._bwd_split_ok() for f in self.layers):
+            return None
+        table = f0._bwd_split_index(device)
+        if not table:
+            return None
+        idx, n_split, n_plain = table
+        words = n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS
+        images = torch.empty(n * words, dtype=torch.int32, device=device)
+        _lib.check("mnf_pack_gather_split_batch", _lib.load().mnf_pack_gather_split_batch(
+            flat.data_ptr(), idx.data_ptr(), images.data_ptr(), n_split, n_plain, n, flat.numel() // n, _stream()))
+        return images, words
 
     def ready(self, x):
         """The run's (fp32 images, split images) if ``x`` can go through the stack kernel without gradients, else
