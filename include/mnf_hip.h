@@ -318,7 +318,8 @@ int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* g
                              float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
                              int parity, int inverse, int n_hidden, const int* hidden_host, void* stream);
 /* mnf_affine_half_bwd_mfma on the listed 16-row tiles only: tile_list_dev = [count, tile, tile, ...] on the device
- * (at most list_capacity tiles are read); NULL = every tile.  The fix-up pass of mnf_affine_half_bwd_split. */
+ * (at most list_capacity tiles are read; count < 0: every tile); NULL = every tile.  The fix-up pass of
+ * mnf_affine_half_bwd_split. */
 int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                                    float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
                                    int parity, int inverse, int n_hidden, const int* hidden_host,
@@ -332,7 +333,8 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
  *   grad_scale_dev  device float, a power of two that brings the incoming gradients near 1 (they are ~1/rows for a
  *                   mean loss, below f16's normal range): mnf_affine_half_grad_scale writes one from a sample
  *   cold_list       device int32 [1 + cold_capacity], cold_list[0] zeroed by the caller: 16-row tiles with an
- *                   operand outside the split range are appended and NOT accumulated; the caller then runs
+ *                   operand outside the split range are appended and NOT accumulated (cold_list[0] = -1: all of
+ *                   them -- weights beyond the split range, nothing was computed); the caller then runs
  *                   mnf_affine_half_bwd_mfma_tiles on that list (same stream).  cold_capacity >= ceil(rows / 16)
  *                   never overflows.
  * grad_x is written, grad_flat ADDED to, as for the other gradient entry points. */

@@ -44,8 +44,10 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
                     int list_capacity) {
   using S = BwdShape<H, HID>;
   // tile_list = [count, tile, tile, ...]: only those 16-row tiles (the ones mnf_affine_half_bwd_split handed back
-  // because an operand left the split range); nullptr: every tile
-  if (tile_list && tile_list[0] == 0) return;
+  // because an operand left the split range; count < 0: all of them -- weights beyond the split range); nullptr:
+  // every tile
+  const int listed = tile_list ? tile_list[0] : -1;
+  if (listed == 0) return;
   constexpr int G = S::G, NT = S::NT, dim = 2 * H;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < S::IMAGE_FLOATS; i += blockDim.x) {
@@ -69,9 +71,9 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   for (int t = 0; t < S::DB_TILES; ++t) db[t] = 0.f;
 
   const int n_tiles = (int)((rows + 15) >> 4);
-  const int n_items = tile_list ? (tile_list[0] < list_capacity ? tile_list[0] : list_capacity) : n_tiles;
+  const int n_items = listed < 0 ? n_tiles : (listed < list_capacity ? listed : list_capacity);
   for (int item = (int)blockIdx.x * kBwdWaves + wave; item < n_items; item += (int)gridDim.x * kBwdWaves) {
-    const int tile = tile_list ? tile_list[1 + item] : item;
+    const int tile = listed < 0 ? item : tile_list[1 + item];
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
@@ -445,7 +447,8 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)
-  if (tile_list && blocks > 32) blocks = 32;  // a fix-up pass: the list is short (usually empty: the kernel then returns at once)
+  // (a fix-up pass gets the full grid too: the list is usually empty and every workgroup returns at once, but it may
+  //  also name every tile)
   const dim3 grid((unsigned)blocks), block(kBwdWaves * 64);
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,

@@ -184,6 +184,12 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
   using F = typename B::F;
   constexpr int G = B::G, NT = B::NT, NKS = B::NKS, KS1 = B::KS1, dim = 2 * H;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // weights beyond the split range (max |w|, written behind the image by the pack kernel): the whole launch belongs
+  // to the fp32 pass
+  if (!(__builtin_bit_cast(float, image[B::SPLIT_WORDS + B::PLAIN_WORDS]) <= kSplitWeightLimit)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cold_list[0] = -1;
+    return;
+  }
   {
     const uint4* src = reinterpret_cast<const uint4*>(image);
     uint4* dst = reinterpret_cast<uint4*>(lds);
@@ -193,7 +199,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
-  const float wmax = __builtin_bit_cast(float, lds[B::SPLIT_WORDS + B::PLAIN_WORDS]);  // max |weight| (pack kernel)
   const float g_scale = scale_dev[0], g_unscale = 1.0f / g_scale;  // a power of two: both exact
 
   // identity operands of the transposing MFMA: B[k = 4 q + e][n = j] = (k == n), and the same times 2^-11
@@ -262,7 +267,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     const f16x8* A8 = reinterpret_cast<const f16x8*>(lds + a_off);  // + 64 * (2 op + part)
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + b_off);  // + 4 * bias tile
     int op = 0;
-    float mx = split_guard_seed(wmax);
+    float mx = 0.f;
     auto pair_of = [&](const u32x2* v, int a, int b) { return pair_operand(v[a], b >= 0 ? v[b >= 0 ? b : 0] : zero2); };
     // A stage = [its operands requested from LDS] [the vector work that builds its B operands] [its MFMAs], pinned in
     // that order (sched_barrier): with one wave per SIMD nothing else covers the LDS latency, and left alone hipcc

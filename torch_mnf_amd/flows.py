@@ -1587,6 +1587,26 @@ class NormalizingFlow(nn.Module):
         return self._pass(x, True)
 
 
+class _StdNormalLogProbFn(torch.autograd.Function):
+    """log N(z; 0, I) with the autograd link: forward = the epilogue kernel (one pass over z), backward = -z g.
+    (As torch ops -- pow, sum over dim 1, scale, shift and their backward -- this was 0.5 ms of a 4.5 ms training
+    step at 2^20 rows x 64.)"""
+
+    @staticmethod
+    def forward(ctx, z):
+        zc = z.detach().contiguous()
+        lp = torch.empty(zc.shape[0], dtype=torch.float32, device=zc.device)
+        _lib.check("mnf_gauss_logprob", _lib.load().mnf_gauss_logprob(
+            zc.data_ptr(), None, lp.data_ptr(), None, zc.shape[0], zc.shape[1], _stream()))
+        ctx.save_for_backward(zc)
+        return lp
+
+    @staticmethod
+    def backward(ctx, grad_lp):
+        (z,) = ctx.saved_tensors
+        return z * (-grad_lp).unsqueeze(1)
+
+
 class StandardNormal:
     """N(0, I_dim) base distribution whose ``log_prob`` is the HIP epilogue kernel.
 
@@ -1599,6 +1619,8 @@ class StandardNormal:
 
     def log_prob(self, z: Tensor) -> Tensor:
         if torch.is_grad_enabled() and z.requires_grad:  # training: keep the autograd link
+            if z.is_cuda and z.dim() == 2 and z.shape[0] > 0 and z.dtype == torch.float32:
+                return _StdNormalLogProbFn.apply(z)
             return -0.5 * z.pow(2).sum(1) - 0.5 * self.dim * math.log(2 * math.pi)
         z = _device_input(z, "z")
         lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
