@@ -121,6 +121,49 @@ def test_split_gradient_kernel_does_not_depend_on_the_gradient_scale(amd, O, inv
         assert_close(g[name], p[name].grad, GTOL, f"grad {name}")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_split_gradient_kernel_seeded_fuzz(amd, O, seed):
+    """Random draws over what the split gradient kernel is templated or branches on: shape, row count (ragged last
+    tile, fewer tiles than waves), parity, direction, input / weight / cotangent magnitudes, absent cotangents."""
+    rng = torch.Generator().manual_seed(9000 + seed)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=rng))]
+    dim, hid = pick([(64, 24), (32, 24), (64, 16), (32, 16)])
+    rows = pick([1, 15, 16, 17, 63, 200, 777, 2048 + 3])
+    parity, inverse = pick([False, True]), pick([False, True])
+    x_scale, w_scale, g_scale = pick([1e-3, 0.3, 1.0, 3.0]), pick([0.5, 1.0, 2.0]), pick([1e-8, 1e-4, 1.0, 1e3])
+    which = pick(["both", "y_only", "ld_only"])
+    h_sizes = (hid, hid, hid)
+    sd = {k: v * (w_scale if k.endswith("weight") else 1.0)
+          for k, v in recipes.affine_half_params(9100 + seed, dim, h_sizes=h_sizes, s_last_gain=1.5).items()}
+    x_cpu = (recipes.gaussian(9200 + seed, rows, dim) * x_scale).requires_grad_(True)
+    w_y = recipes.gaussian(9300 + seed, rows, dim) * g_scale
+    w_l = recipes.gaussian(9400 + seed, rows, 1)[:, 0] * g_scale
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, parity, inverse)
+    loss = (y * w_y).sum() * (which != "ld_only") + (ld * w_l).sum() * (which != "y_only")
+    loss.backward()
+    f = amd.AffineHalfFlow(dim, parity, h_sizes=h_sizes)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = f.forward(x, inverse=inverse)
+    floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, 0
+    try:
+        terms = ([(yg * w_y.to(DEV)).sum()] if which != "ld_only" else []) + \
+                ([(ldg * w_l.to(DEV)).sum()] if which != "y_only" else [])
+        sum(terms).backward()
+    finally:
+        amd.flows._BWD_SPLIT_MIN_ROWS = floor
+    what = f"d={dim} hid={hid} rows={rows} parity={parity} inverse={inverse} x*{x_scale} w*{w_scale} g*{g_scale} {which}"
+    assert_close(x.grad, x_cpu.grad, GTOL, f"grad_x [{what}]")
+    for name, prm in f.named_parameters():
+        ref = p[name].grad
+        if float(ref.abs().max()) == 0.0:
+            assert float(prm.grad.abs().max()) == 0.0, f"grad {name} [{what}]"
+        else:
+            assert_close(prm.grad, ref, GTOL, f"grad {name} [{what}]")
+
+
 @pytest.mark.parametrize("case", ["big_rows", "big_gradients", "big_weights"])
 def test_split_gradient_kernel_range_guard(amd, O, case):
     """16-row tiles with an operand outside the split range (inputs, activations or deltas) are handed to the fp32
