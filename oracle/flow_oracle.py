@@ -390,3 +390,37 @@ def mnf_linear_forward(x: Tensor, z: Tensor, W_mean: Tensor, W_log_var: Tensor, 
     mean = x * z @ W_mean.T + b_mean
     var = x**2 @ W_log_var.exp().T + b_log_var.exp()
     return mean + var.sqrt() * eps
+
+
+def mnf_conv2d_sample_z(q0_mean: Tensor, q0_log_var: Tensor, eps_z: Tensor, layers: Sequence[dict]) -> tuple[Tensor, Tensor]:
+    """MNFConv2d.sample_z with injected noise: one n_out-vector through flow_q.  layers/mnf_conv.py:90-98."""
+    z0 = q0_mean + q0_log_var.exp().sqrt() * eps_z
+    zs, log_det = flow_stack(z0[None, :], layers, inverse=False)
+    return zs[-1], log_det.squeeze()
+
+
+def mnf_conv2d_forward(x: Tensor, z: Tensor, W_mean: Tensor, W_log_var: Tensor, b_log_var: Tensor, eps: Tensor) -> Tensor:
+    """MNFConv2d.forward behind sample_z with the output noise injected.  layers/mnf_conv.py:67-88 (b_mean is the
+    zero tensor of :45)."""
+    mean = F.conv2d(x, weight=W_mean * z.view(-1, 1, 1, 1), bias=torch.zeros(W_mean.shape[0], dtype=x.dtype))
+    var = F.conv2d(x**2, weight=W_log_var.exp(), bias=b_log_var.exp())
+    return mean + var.sqrt() * eps
+
+
+def mnf_conv2d_kl(p: dict, z: Tensor, log_det_q: Tensor, eps_w: Tensor, eps_b: Tensor, r_layers: Sequence[dict]) -> Tensor:
+    """MNFConv2d.kl_div behind sample_z with eps_w / eps_b injected and flow_r given as oracle layer specs.
+    layers/mnf_conv.py:100-133 (linear auxiliary activation: no tanh, :119-123)."""
+    W_var, b_var = p["W_log_var"].exp(), p["b_log_var"].exp()
+    W_mean = p["W_mean"] * z.view(-1, 1, 1, 1)
+    b_mean = torch.zeros_like(p["b_log_var"]) * z
+    kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean**2 - 1)
+    kl_b = 0.5 * torch.sum(-b_var.log() + b_var + b_mean**2 - 1)
+    log_q = -log_det_q - 0.5 * p["q0_log_var"].sum()
+    n = p["r0_c"].numel()
+    act = W_mean.reshape(-1, n) @ p["r0_c"] + (W_var.sqrt().reshape(-1, n) @ p["r0_c"]) * eps_w  # eqs. (11), (12)
+    act = act + torch.sum(b_mean * p["r0_c"]) + torch.sum(b_var * p["r0_c"] ** 2).sqrt() * eps_b
+    mean_r = torch.outer(p["r0_b1"], act).mean(1)
+    log_var_r = torch.outer(p["r0_b2"], act).mean(1)
+    zs, log_det_r = flow_stack(z, r_layers, inverse=False)
+    log_r = log_det_r.squeeze() + 0.5 * torch.sum(-log_var_r.exp() * (zs[-1] - mean_r) ** 2 + log_var_r)
+    return kl_W + kl_b + log_q - log_r

@@ -27,7 +27,7 @@ from torch.distributions import MultivariateNormal  # noqa: E402
 import recipes  # noqa: E402
 import torch_mnf.flows as nf  # noqa: E402  (the reference)
 from torch_mnf.flows import spline_flow as ref_spline  # noqa: E402
-from torch_mnf.layers import MNFLinear  # noqa: E402
+from torch_mnf.layers import MNFConv2d, MNFLinear  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -425,6 +425,64 @@ def g12_nsf_ar():
 G12_CASES = {"d2_k8": (2, 8, 16), "d6_k5": (6, 5, 8), "d16_k8": (16, 8, 8)}
 
 
+# ----------------------------------------------------------------------------- G13
+def g13_mnf_conv2d():
+    """MNFConv2d (layers/mnf_conv.py:67-133) forward and kl_div with every random draw captured, for MNF-LeNet's two
+    convolutions at small image sizes: MNFConv2d(1, 20, 5) and MNFConv2d(20, 50, 5)."""
+    out = {}
+    for tag, (n_in, n_out, k, batch, side, seed) in {"c1": (1, 20, 5, 3, 12, 21), "c2": (20, 50, 5, 2, 8, 22)}.items():
+        torch.manual_seed(seed)
+        layer = MNFConv2d(n_in, n_out, k)
+        for name, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+            for i, f in enumerate(flow.flows):
+                f.load_state_dict(recipes.rnvp_params(1300 + seed + 10 * (name == "r") + i, n_out, 50))
+        x = recipes.gaussian(1300 + seed, batch, n_in * side * side).reshape(batch, n_in, side, side)
+        captured = {"randn_like": [], "bernoulli": [], "randn": []}
+        real = (torch.randn_like, torch.bernoulli, torch.randn)
+
+        def randn_like(t, *a, **kw):
+            r = real[0](t, *a, **kw)
+            captured["randn_like"].append(r.clone())
+            return r
+
+        def bernoulli(t, *a, **kw):
+            r = real[1](t, *a, **kw)
+            captured["bernoulli"].append(r.clone())
+            return r
+
+        def randn(*a, **kw):
+            r = real[2](*a, **kw)
+            captured["randn"].append(r.clone())
+            return r
+
+        torch.randn_like, torch.bernoulli, torch.randn = randn_like, bernoulli, randn
+        try:
+            with torch.no_grad():
+                y = layer.forward(x)
+                n_fwd = {key: len(v) for key, v in captured.items()}
+                kl = layer.kl_div()
+        finally:
+            torch.randn_like, torch.bernoulli, torch.randn = real
+        assert n_fwd == {"randn_like": 2, "bernoulli": 2, "randn": 0}, n_fwd
+        assert {key: len(v) for key, v in captured.items()} == {"randn_like": 4, "bernoulli": 6, "randn": 1}
+        for key in ("W_mean", "W_log_var", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"):
+            out[f"{tag}.{key}"] = npy(getattr(layer, key))
+        out[f"{tag}.x"] = npy(x)
+        # forward: eps_z, two flow_q masks, output noise
+        out[f"{tag}.fwd.eps_z"] = npy(captured["randn_like"][0])
+        out[f"{tag}.fwd.eps_out"] = npy(captured["randn_like"][1])
+        out[f"{tag}.fwd.masks"] = np.stack([npy(m) for m in captured["bernoulli"][:2]])
+        out[f"{tag}.y"] = npy(y)
+        # kl_div: eps_z, flow_q masks, eps_w, eps_b, flow_r masks
+        out[f"{tag}.kl.eps_z"] = npy(captured["randn_like"][2])
+        out[f"{tag}.kl.eps_w"] = npy(captured["randn_like"][3])
+        out[f"{tag}.kl.eps_b"] = npy(captured["randn"][0])
+        out[f"{tag}.kl.masks_q"] = np.stack([npy(m) for m in captured["bernoulli"][2:4]])
+        out[f"{tag}.kl.masks_r"] = np.stack([npy(m) for m in captured["bernoulli"][4:6]])
+        out[f"{tag}.kl"] = npy(kl)
+    save("g13_mnf_conv2d", **out)
+
+
 # ----------------------------------------------------------------------------- G9
 def g9_logdet_shapes():
     x = recipes.gaussian(900, 8, 4)
@@ -462,4 +520,5 @@ if __name__ == "__main__":
     g10_padded_shapes()
     g11_mnf_linear_forward()
     g12_nsf_ar()
+    g13_mnf_conv2d()
     g9_logdet_shapes()

@@ -675,3 +675,36 @@ def test_flat_parameters_and_fused_adam_match_torch_adam(amd, kind):
     flat.touch()
     with torch.no_grad():
         assert_close(model.log_prob(x), ref.log_prob(x), 1e-6, "after load_state_dict")
+
+
+# ------------------------------------------------------------------ MNFConv2d drop-in (fixture G13)
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_g13_mnf_conv2d_vs_reference(amd, golden, tag):
+    """Fixture G13: the reference's MNFConv2d.forward and kl_div with every random draw captured.  The drop-in takes the
+    reference's state_dict (same keys), runs flow_q / flow_r through the HIP RNVP kernels on the captured masks and
+    the convolutions on stock PyTorch-ROCm."""
+    from test_oracle_golden import G13_CASES, G13_KEYS
+
+    fx = golden("g13_mnf_conv2d")
+    n_in, n_out, k, seed = G13_CASES[tag]
+    layer = amd.MNFConv2d(n_in, n_out, k)
+    assert sorted(k_ for k_ in layer.state_dict() if "flow" not in k_) == sorted(G13_KEYS)  # b_mean: a plain tensor (:45)
+    layer.load_state_dict({k_: torch.from_numpy(fx[f"{tag}.{k_}"]) for k_ in G13_KEYS}, strict=False)
+    for which, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+        for i, f in enumerate(flow.flows):
+            f.load_state_dict(recipes.rnvp_params(1300 + seed + 10 * (which == "r") + i, n_out, 50))
+    layer.to(DEV)
+    dev = lambda name: torch.from_numpy(fx[f"{tag}.{name}"]).to(DEV)
+    masks = lambda name: [m for m in dev(name)]
+    with torch.no_grad():
+        y = layer.forward(dev("x"), eps=dev("fwd.eps_out"), eps_z=dev("fwd.eps_z"), masks=masks("fwd.masks"))
+        kl = layer.kl_div({"eps_z": dev("kl.eps_z"), "masks_q": masks("kl.masks_q"), "eps_w": dev("kl.eps_w"),
+                           "eps_b": dev("kl.eps_b"), "masks_r": masks("kl.masks_r")})
+    assert_close(y, fx[f"{tag}.y"], RTOL, "MNFConv2d.forward vs the reference")
+    assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))
+    # default draws: runs, finite, differentiable (flow_q gradients through the HIP backward kernels)
+    out = layer.forward(dev("x"))
+    loss = out.pow(2).mean() + 1e-3 * layer.kl_div()
+    loss.backward()
+    assert torch.isfinite(out).all() and all(p.grad is not None and torch.isfinite(p.grad).all()
+                                             for p in layer.parameters())

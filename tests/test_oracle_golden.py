@@ -262,3 +262,37 @@ def test_g10_padded_shapes(golden):
         x, ld = O.rnvp(t(fx[f"rnvp.{tag}.z"]), sd, unpack_mask(fx[f"rnvp.{tag}.mask_bits"], dim))
         assert_close(x, fx[f"rnvp.{tag}.x"], 1e-6, f"{tag}.x")
         assert_close(ld, fx[f"rnvp.{tag}.ld"], 1e-6, f"{tag}.ld")
+
+
+# ------------------------------------------------------------------ G13: MNFConv2d
+G13_CASES = {"c1": (1, 20, 5, 21), "c2": (20, 50, 5, 22)}
+G13_KEYS = ("W_mean", "W_log_var", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2")
+
+
+def g13_specs(tag, which, masks):
+    n_in, n_out, k, seed = G13_CASES[tag]
+    return [{"kind": "rnvp", "params": recipes.rnvp_params(1300 + seed + 10 * (which == "r") + i, n_out, 50),
+             "mask": torch.from_numpy(masks[i])} for i in range(2)]
+
+
+def g13_oracle(fx, tag):
+    """The oracle's MNFConv2d.forward and kl_div on fixture G13's captured draws."""
+    p = {k: torch.from_numpy(fx[f"{tag}.{k}"]) for k in G13_KEYS}
+    z, _ = O.mnf_conv2d_sample_z(p["q0_mean"], p["q0_log_var"], torch.from_numpy(fx[f"{tag}.fwd.eps_z"]),
+                                           g13_specs(tag, "q", fx[f"{tag}.fwd.masks"]))
+    y = O.mnf_conv2d_forward(torch.from_numpy(fx[f"{tag}.x"]), z, p["W_mean"], p["W_log_var"], p["b_log_var"],
+                                       torch.from_numpy(fx[f"{tag}.fwd.eps_out"]))
+    zk, ldq = O.mnf_conv2d_sample_z(p["q0_mean"], p["q0_log_var"], torch.from_numpy(fx[f"{tag}.kl.eps_z"]),
+                                              g13_specs(tag, "q", fx[f"{tag}.kl.masks_q"]))
+    kl = O.mnf_conv2d_kl(p, zk, ldq, torch.from_numpy(fx[f"{tag}.kl.eps_w"]), torch.from_numpy(fx[f"{tag}.kl.eps_b"]),
+                                   g13_specs(tag, "r", fx[f"{tag}.kl.masks_r"]))
+    return y, kl
+
+
+@pytest.mark.parametrize("tag", sorted(G13_CASES))
+def test_g13_mnf_conv2d(golden, tag):
+    """Oracle vs the reference's MNFConv2d.forward / kl_div (layers/mnf_conv.py:67-133), every draw replayed."""
+    fx = golden("g13_mnf_conv2d")
+    y, kl = g13_oracle(fx, tag)
+    assert_parity(y, fx[f"{tag}.y"], what="MNFConv2d.forward")
+    assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))

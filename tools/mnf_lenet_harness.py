@@ -1,44 +1,24 @@
 """Config 5 harness: one MNF-LeNet forward on 512 images x 500 MC repeats (256,000 rows).
 
-MNFLeNet / MNFConv2d are callers, not the path: convolution,
-pooling and the layers' own GEMMs run on stock PyTorch-ROCm here, the multiplicative-noise flows
-(MNFLinear.sample_z at (R, 800) and (R, 50); MNFConv2d's at (1, 20) / (1, 50)) run in libmnf_hip.so.
+MNFLeNet is a caller, not the path: convolution and pooling run on stock
+PyTorch-ROCm here (torch_mnf_amd.MNFConv2d: the reference's layer with its flows on the HIP kernels), the
+multiplicative-noise flows (MNFLinear.sample_z at (R, 800) and (R, 50); MNFConv2d's at (1, 20) / (1, 50)) and
+MNFLinear.forward run in libmnf_hip.so.
 The point of the measurement: how much of the end-to-end forward the flow path still is.
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-import torch.nn.functional as F
 from torch import nn
 import torch_mnf_amd as amd
-
-
-class ConvCaller(nn.Module):
-    """The reference's MNFConv2d.forward (layers/mnf_conv.py:67-88) with z from a HIP flow_q."""
-
-    def __init__(self, n_in, n_out, k):
-        super().__init__()
-        self.W_mean = nn.Parameter(0.1 * torch.randn(n_out, n_in, k, k))
-        self.W_log_var = nn.Parameter(-9 + 0.1 * torch.randn(n_out, n_in, k, k))
-        self.b_log_var = nn.Parameter(-9 + 0.1 * torch.randn(n_out))
-        self.q0_mean = nn.Parameter(0.1 * torch.randn(n_out))
-        self.q0_log_var = nn.Parameter(-9 + 0.1 * torch.randn(n_out))
-        self.flow_q = amd.NormalizingFlow([amd.RNVP(n_out, h_sizes=(50,)) for _ in range(2)])
-
-    def forward(self, x):
-        z0 = self.q0_mean + self.q0_log_var.exp().sqrt() * torch.randn_like(self.q0_mean)
-        zs, _ = self.flow_q.forward(z0[None, :].contiguous())
-        mean = F.conv2d(x, self.W_mean * zs[-1].view(-1, 1, 1, 1))
-        var = F.conv2d(x * x, self.W_log_var.exp(), self.b_log_var.exp())
-        return mean + var.sqrt() * torch.randn_like(var)
 
 
 def main():
     images, repeats = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 500
     dev = "cuda"
     torch.manual_seed(0)
-    net = nn.Sequential(ConvCaller(1, 20, 5), nn.ReLU(), nn.MaxPool2d(2), ConvCaller(20, 50, 5), nn.ReLU(),
+    net = nn.Sequential(amd.MNFConv2d(1, 20, 5), nn.ReLU(), nn.MaxPool2d(2), amd.MNFConv2d(20, 50, 5), nn.ReLU(),
                         nn.MaxPool2d(2), nn.Flatten(), amd.MNFLinear(800, 50), nn.ReLU(), amd.MNFLinear(50, 10),
                         nn.LogSoftmax(dim=-1)).to(dev)
     x = torch.rand(images, 1, 28, 28, device=dev).repeat_interleave(repeats, dim=0)  # each image `repeats` times

@@ -8,7 +8,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 (The directory is ``torch_mnf_amd``: ``torch-mnf_amd`` is not an importable name.)
 """
 from . import _lib
-from .layers import MNFLinear
+from .layers import MNFConv2d, MNFLinear
 from .train import FlatParameters, FusedAdam
 from .flows import (
     MLP,
@@ -29,7 +29,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "FlatParameters", "FusedAdam", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "library_path",
 ]
 
 

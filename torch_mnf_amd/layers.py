@@ -14,6 +14,7 @@ import ctypes
 import math
 
 import torch
+import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import _lib
@@ -201,4 +202,100 @@ class MNFLinear(nn.Module):
         zs, log_det_r = self.flow_r.forward(z)
         (log_det_r,) = log_det_r                            # relies on shape (1,), as the reference does
         log_r = log_det_r + 0.5 * torch.sum(-log_var_r.exp() * (zs[-1] - mean_r).pow(2) + log_var_r)
+        return kl_W + kl_b + log_q - log_r
+
+
+class MNFConv2d(nn.Module):
+    """Bayesian 2-D convolution with multiplicative normalizing-flow noise on the output channels
+    (layers/mnf_conv.py:10-133): same constructor, parameter names and state_dict keys as the reference.
+
+    What is on the library's path here is the flow: ``sample_z`` pushes one n_out-vector through ``flow_q`` (RNVP
+    layers, HIP kernels) and ``kl_div`` one through ``flow_r``.  The two convolutions are the caller's arithmetic
+     and stay ``F.conv2d`` on device tensors.  Noise can be injected for reproducible runs:
+    ``eps_z`` (n_out,), ``masks`` (one (1, n_out) float mask per flow layer), ``eps`` (shape of the output)."""
+
+    def __init__(self, n_in: int, n_out: int, kernel_size: int, n_flows_q: int = 2, n_flows_r: int = 2,
+                 h_sizes=(50,)) -> None:
+        super().__init__()
+        self.n_in, self.n_out, self.kernel_size = int(n_in), int(n_out), int(kernel_size)
+        small = lambda *shape: 0.1 * torch.randn(*shape)            # noqa: E731
+        log_var = lambda *shape: -9 + 0.1 * torch.randn(*shape)     # noqa: E731
+        w_shape = (n_out, n_in, kernel_size, kernel_size)
+        self.W_mean = nn.Parameter(small(*w_shape))
+        self.W_log_var = nn.Parameter(log_var(*w_shape))
+        self.b_mean = torch.zeros(n_out)  # (a plain tensor in the reference too: not in the state_dict, mnf_conv.py:45)
+        self.b_log_var = nn.Parameter(log_var(n_out))
+        self.q0_mean = nn.Parameter(small(n_out))
+        self.q0_log_var = nn.Parameter(log_var(n_out))
+        self.r0_c = nn.Parameter(small(n_out))
+        self.r0_b1 = nn.Parameter(small(n_out))
+        self.r0_b2 = nn.Parameter(small(n_out))
+        self.flow_q = NormalizingFlow([RNVP(n_out, h_sizes=h_sizes) for _ in range(n_flows_q)])
+        self.flow_r = NormalizingFlow([RNVP(n_out, h_sizes=h_sizes) for _ in range(n_flows_r)])
+
+    def _apply(self, fn, *args, **kwargs):  # b_mean follows the module across devices
+        super()._apply(fn, *args, **kwargs)
+        self.b_mean = fn(self.b_mean)
+        return self
+
+    @staticmethod
+    def _through(flow: NormalizingFlow, z: Tensor, masks):
+        """``flow.forward`` on a (1, n_out) row, with explicit masks when given: (last z, log_det (1,))."""
+        if masks is None:
+            zs, log_det = flow.forward(z)
+            return zs[-1], log_det
+        layers = list(flow.flows)
+        if len(masks) != len(layers):
+            raise ValueError(f"got {len(masks)} masks for {len(layers)} flow layers")
+        log_det = torch.zeros(z.shape[0], device=z.device)
+        for layer, m in zip(layers, masks):
+            if _wants_grad(layer, z):
+                z, ld = layer._run(z, False, None, m)
+                log_det = log_det + ld
+            else:
+                z, _ = layer._run(z, False, log_det, m)
+        return z, log_det
+
+    # ------------------------------------------------------------------ hot path (the flow)
+    def sample_z(self, eps_z: Tensor | None = None, masks=None) -> tuple[Tensor, Tensor]:
+        """(mnf_conv.py:90-98): z (1, n_out) and log|det J| (scalar) of flow_q at z0 = q0_mean + q0_std eps."""
+        q0_std = self.q0_log_var.exp().sqrt()
+        if eps_z is None:
+            eps_z = torch.randn_like(q0_std)
+        z0 = self.q0_mean + q0_std * eps_z.to(q0_std.device)
+        z, log_det = self._through(self.flow_q, z0[None, :].contiguous(), masks)
+        return z, log_det.squeeze()
+
+    # ------------------------------------------------------------------ caller (stock PyTorch-ROCm)
+    def forward(self, x: Tensor, eps: Tensor | None = None, eps_z: Tensor | None = None, masks=None) -> Tensor:
+        """(mnf_conv.py:67-88, algorithm 2 of the paper)."""
+        z, _ = self.sample_z(eps_z, masks)
+        mean = F.conv2d(x, weight=self.W_mean * z.view(-1, 1, 1, 1), bias=self.b_mean)
+        var = F.conv2d(x * x, weight=self.W_log_var.exp(), bias=self.b_log_var.exp())
+        return mean + var.sqrt() * (torch.randn_like(var) if eps is None else eps)
+
+    def kl_div(self, noise: dict | None = None) -> Tensor:
+        """(mnf_conv.py:100-133).  ``noise``: optional injected draws {"eps_z", "masks_q", "eps_w", "eps_b", "masks_r"}."""
+        noise = noise or {}
+        z, log_det_q = self.sample_z(noise.get("eps_z"), noise.get("masks_q"))
+        W_var = self.W_log_var.exp()
+        b_var = self.b_log_var.exp()
+        W_mean = self.W_mean * z.view(-1, 1, 1, 1)
+        b_mean = self.b_mean * z
+        kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean.pow(2) - 1)
+        kl_b = 0.5 * torch.sum(-b_var.log() + b_var + b_mean.pow(2) - 1)
+        log_q = -log_det_q - 0.5 * self.q0_log_var.sum()
+        n = self.r0_c.numel()
+        wm = W_mean.view(-1, n) @ self.r0_c                 # eq. (11)
+        ws = W_var.sqrt().view(-1, n) @ self.r0_c           # eq. (12)
+        eps_w = noise.get("eps_w")
+        act = wm + ws * (torch.randn_like(ws) if eps_w is None else eps_w.to(ws.device))  # (linear: no tanh, :119-123)
+        eps_b = noise.get("eps_b")
+        act = act + torch.sum(b_mean * self.r0_c) + torch.sum(b_var * self.r0_c.pow(2)).sqrt() * (
+            torch.randn([], device=ws.device) if eps_b is None else eps_b.to(ws.device))
+        mean_r = torch.outer(self.r0_b1, act).mean(1)
+        log_var_r = torch.outer(self.r0_b2, act).mean(1)
+        z_r, log_det_r = self._through(self.flow_r, z, noise.get("masks_r"))
+        (log_det_r,) = log_det_r                            # relies on shape (1,), as the reference does
+        log_r = log_det_r + 0.5 * torch.sum(-log_var_r.exp() * (z_r - mean_r).pow(2) + log_var_r)
         return kl_W + kl_b + log_q - log_r
