@@ -200,6 +200,9 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
 // d <= 64: two row tiles per wave (shared operand reads), four waves, two workgroups per CU.
 // d >= 128: the rows of ONE tile already take 32-64 VGPRs and the double-buffered image 90-150 KB of LDS:
 // one tile per wave, eight waves sharing the image, one workgroup per CU (still two waves per SIMD).
+#ifndef MNF_STACK_ABL
+#define MNF_STACK_ABL 0
+#endif
 #ifndef MNF_STACK_TILES  // experiment switches for d <= 64 (tools/kernel_variants.sh)
 #define MNF_STACK_TILES 2
 #define MNF_STACK_WAVES 4
@@ -326,7 +329,10 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
         for (int k = stage * PER; k < (stage + 1) * PER && k < TOTAL; ++k) {
           const int t = k / (2 * G), half = (k / G) & 1, g = k % G;
           if (live[t]) {
-            float* mr = mid + ((int64_t)(li - 1) * rows + rowc[t]) * dim + (half ? h : 0);
+            // (MNF_STACK_ABL=1, timing only: every wave stores to the first rows -- the store instructions without
+            //  their HBM traffic)
+            float* mr = mid + (MNF_STACK_ABL ? (int64_t)(threadIdx.x & 15) * dim
+                                             : ((int64_t)(li - 1) * rows + rowc[t]) * dim) + (half ? h : 0);
             half_store4<RAG>(mr, 16 * g + 4 * q, h, vec, half ? hi[t][g] : lo[t][g]);
           }
         }
