@@ -249,10 +249,18 @@ __device__ __forceinline__ f32x4 half_load4(const float* p, int col, int h, bool
   }
   return v;
 }
+// The stack kernel's row stores carry the non-temporal hint: every intermediate is written once and not read again
+// by this launch, and without the hint the 2.4 GB write stream (C2) competes with the operand images for L2.  Measured
+// (same box, A/B): C2 798-802 -> 783 us per launch, C4 1,411 -> 1,375; the single-layer kernel, whose output the
+// next launch reads right away, is better off without it (+8 us).  MNF_STACK_NT=0: A/B switch.
+#ifndef MNF_STACK_NT
+#define MNF_STACK_NT 1
+#endif
 template <bool RAG>
 __device__ __forceinline__ void half_store4(float* p, int col, int h, bool vec, f32x4 v) {
   if (!RAG) {
-    *reinterpret_cast<f32x4*>(p + col) = v;
+    if (MNF_STACK_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p + col));
+    else *reinterpret_cast<f32x4*>(p + col) = v;
   } else if (vec) {
     if (col < h) *reinterpret_cast<f32x4*>(p + col) = v;
   } else {
