@@ -22,6 +22,11 @@
 #include "mnf_host.h"
 #include "mnf_split.h"
 
+#ifndef MNF_NSF_NT
+#define MNF_NSF_NT 1  // the block's intermediate tensors are written once and not read by this or the next launch:
+                      // non-temporal stores (C3: 436-438 -> 431 us per block launch; 0 = A/B switch)
+#endif
+
 namespace mnf {
 
 template <int H, int NH, int K>
@@ -518,9 +523,15 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       if (!live) return;
       float* mr = base + rowc * dim + 4 * q;
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + 16 * g) = a[g];
+      for (int g = 0; g < G; ++g) {
+        if (MNF_NSF_NT) __builtin_nontemporal_store(a[g], reinterpret_cast<f32x4*>(mr + 16 * g));
+        else *reinterpret_cast<f32x4*>(mr + 16 * g) = a[g];
+      }
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(mr + H + 16 * g) = b[g];
+      for (int g = 0; g < G; ++g) {
+        if (MNF_NSF_NT) __builtin_nontemporal_store(b[g], reinterpret_cast<f32x4*>(mr + H + 16 * g));
+        else *reinterpret_cast<f32x4*>(mr + H + 16 * g) = b[g];
+      }
     };
     auto store_actnorm_of = [&](float* base) {  // rows e^s + t
       f32x4 a[G], b[G];
