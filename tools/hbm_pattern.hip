@@ -29,7 +29,7 @@ __device__ __forceinline__ void dma_step(const uint32_t* image, uint32_t* lds, i
   if (DMA > 0 && WAIT < 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
 }
 
-template <int T, int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0>
+template <int T, int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0, int NT = 0>
 __global__ void __launch_bounds__(512) pattern(const float* __restrict__ z, float* __restrict__ x, int64_t rows, int d, int gemm1_sleep,
                                                const uint32_t* __restrict__ image) {
   extern __shared__ uint32_t lds[];
@@ -72,28 +72,32 @@ __global__ void __launch_bounds__(512) pattern(const float* __restrict__ z, floa
         asm volatile("" : "+v"(r[m]));
       }
 #pragma unroll
-      for (int m = m0; m < m0 + B && m < T; ++m) *reinterpret_cast<f32x4*>(xp + toff(m)) = r[m];
+      for (int m = m0; m < m0 + B && m < T; ++m) {
+        if (NT & 1) __builtin_nontemporal_store(r[m], reinterpret_cast<f32x4*>(xp + toff(m)));
+        else *reinterpret_cast<f32x4*>(xp + toff(m)) = r[m];
+      }
 #pragma unroll
-      for (int m = m0; m < m0 + B && m < T; ++m) r[m] = *reinterpret_cast<const f32x4*>(zp + toff(m));
+      for (int m = m0; m < m0 + B && m < T; ++m)
+        r[m] = (NT & 2) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zp + toff(m))) : *reinterpret_cast<const f32x4*>(zp + toff(m));
     }
   }
 }
 
 static uint32_t* g_image = nullptr;
-template <int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0>
+template <int B, int SLEEP, int DMA = 0, int WAIT = 16, bool PLAIN = false, int LAYOUT = 0, int NT = 0>
 void run(const float* z, float* x, int64_t rows, int d, int g1) {
   constexpr int T = LAYOUT ? 24 : 25;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
+  for (int i = 0; i < 3; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT, NT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
   CK(hipEventRecord(a));
   const int N = 10;
-  for (int i = 0; i < N; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
+  for (int i = 0; i < N; ++i) pattern<T, B, SLEEP, DMA, WAIT, PLAIN, LAYOUT, NT><<<256, 512, 128 * 1024>>>(z, x, rows, d, g1, g_image);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   const double us = ms * 1e3 / N, bytes = 8.0 * rows * d;
-  printf("batch %2d  sleep %3d x64 cycles/tile  gemm1 %2d  dma %d KB/step/wave wait vmcnt(%d) %s : %7.1f us  %5.2f TB/s\n", B, SLEEP, g1, DMA, WAIT, LAYOUT ? "lds-dma, line-paired tiles (24 of 25)" : PLAIN ? "plain loads" : "lds-dma", us, bytes / us / 1e6);
+  printf("batch %2d  sleep %3d x64 cycles/tile  gemm1 %2d  dma %d KB/step/wave wait vmcnt(%d) %s nt=%d : %7.1f us  %5.2f TB/s\n", B, SLEEP, g1, DMA, WAIT, LAYOUT ? "lds-dma, line-paired tiles (24 of 25)" : PLAIN ? "plain loads" : "lds-dma", NT, us, bytes / us / 1e6);
 }
 
 int main() {
@@ -119,5 +123,11 @@ int main() {
   run<1, 0, 0, 16, false, 1>(z, x, rows, d, 0); run<2, 0, 0, 16, false, 1>(z, x, rows, d, 0);
   run<1, 22, 0, 16, false, 1>(z, x, rows, d, 12); run<2, 22, 0, 16, false, 1>(z, x, rows, d, 12);
   run<1, 22, 2, 32, false, 1>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 1>(z, x, rows, d, 12); run<8, 22, 2, 32, false, 1>(z, x, rows, d, 12);
+  // non-temporal hints (1 stores, 2 loads, 3 both), standard and line-paired layout, with the operand stream
+  run<1, 22, 2, 32, false, 0, 1>(z, x, rows, d, 12); run<1, 22, 2, 32, false, 0, 2>(z, x, rows, d, 12); run<1, 22, 2, 32, false, 0, 3>(z, x, rows, d, 12);
+  run<2, 22, 2, 32, false, 1, 1>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 1, 2>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 1, 3>(z, x, rows, d, 12);
+  // standard layout, two tiles (the two 64-byte halves of a line) back to back, with / without the hint on the stores
+  run<2, 22, 2, 32, false, 0, 0>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 0, 1>(z, x, rows, d, 12); run<2, 22, 2, 32, false, 0, 3>(z, x, rows, d, 12);
+  run<4, 22, 2, 32, false, 0, 1>(z, x, rows, d, 12);
   return 0;
 }
