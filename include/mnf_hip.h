@@ -337,6 +337,10 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
  *                   them -- weights beyond the split range, nothing was computed); the caller then runs
  *                   mnf_affine_half_bwd_mfma_tiles on that list (same stream).  cold_capacity >= ceil(rows / 16)
  *                   never overflows.
+ *   workspace       optional device floats (mnf_affine_half_bwd_split_workspace() of them for the current device):
+ *                   with it the parameter gradients are flushed in two stages (every workgroup stores its sums, a
+ *                   second small launch adds them into grad_flat) instead of one atomic per parameter per
+ *                   workgroup -- ~40 us less per launch whatever the row count; NULL / too small: atomics
  * grad_x is written, grad_flat ADDED to, as for the other gradient entry points. */
 int mnf_affine_half_bwd_split_layout(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
                                      int64_t* n_split_words, int64_t* n_plain_words);
@@ -344,10 +348,12 @@ int mnf_affine_half_bwd_split_index(int dim, int n_hidden, const int* hidden_hos
                                     int32_t* idx_host);
 int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_t rows, int dim, float* scale_out_dev,
                                void* stream);
+int64_t mnf_affine_half_bwd_split_workspace(int64_t rows, int dim, int n_hidden, const int* hidden_host);
 int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                               float* grad_flat, const void* bwd_image, const int32_t* index_dev, int64_t rows, int dim,
                               int parity, int inverse, int n_hidden, const int* hidden_host,
-                              const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, void* stream);
+                              const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
+                              int64_t workspace_floats, void* stream);
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);

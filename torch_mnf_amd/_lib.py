@@ -89,8 +89,10 @@ SIGNATURES = {
     "mnf_affine_half_bwd_split_layout": (c_int, [c_int, c_int, _intp, c_int, c_int, _i64p, _i64p]),
     "mnf_affine_half_bwd_split_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_grad_scale": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mnf_affine_half_bwd_split_workspace": (c_int64, [c_int64, c_int, c_int, _intp]),
     "mnf_affine_half_bwd_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                          c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int, c_void_p]),
+                                          c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int, c_void_p, c_int64,
+                                          c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

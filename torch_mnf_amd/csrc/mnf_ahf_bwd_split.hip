@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBsWaves * 64, 1)
 ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                      float* __restrict__ grad_x, float* __restrict__ grad_flat, const uint32_t* __restrict__ image,
                      const int32_t* __restrict__ index, int64_t rows, int parity, const float* __restrict__ scale_dev,
-                     int32_t* __restrict__ cold_list, int cold_capacity) {
+                     int32_t* __restrict__ cold_list, int cold_capacity, float* __restrict__ partials) {
   using B = BwdSplitShape<H, HID>;
   using S = typename B::S;
   using F = typename B::F;
@@ -599,6 +599,11 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     }
     __syncthreads();
   }
+  if (partials) {  // two-stage flush: this workgroup's sums as one coalesced block, ahf_bwd_reduce_kernel adds them up
+    float* dst = partials + (int64_t)blockIdx.x * B::RED_FLOATS;
+    for (int i = threadIdx.x; i < B::RED_FLOATS; i += blockDim.x) dst[i] = red[i];
+    return;
+  }
   const int32_t* flush_w = index + F::IMAGE_FLOATS;
   const int32_t* flush_b = flush_w + DW_FLOATS;
   for (int i = threadIdx.x; i < DW_FLOATS; i += blockDim.x) {
@@ -608,6 +613,45 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
   for (int i = threadIdx.x; i < F::DB_TILES * 16; i += blockDim.x) {
     const int32_t dst = flush_b[i];
     if (dst >= 0) atomicAdd(grad_flat + dst, red[DW_FLOATS + i] * g_unscale);
+  }
+}
+
+// Second stage of the flush.  One atomic per parameter per workgroup is 1.9 M device-scope atomics per launch on 7,376
+// addresses: ~40 us of the kernel whatever the row count (measured: 51 us for ONE tile per wave, 64 us at 65,536 rows,
+// 117 at 262,144).  With a workspace every workgroup stores its sums as one block and this kernel adds the blocks up:
+// thread i owns entry i of the flush tables (every parameter appears in exactly one entry: plain add, no atomics).
+__global__ void __launch_bounds__(256) ahf_bwd_reduce_kernel(const float* __restrict__ partials, int n_blocks, int red_floats,
+                                                             const int32_t* __restrict__ flush, float* __restrict__ grad_flat,
+                                                             const float* __restrict__ scale_dev,
+                                                             const int32_t* __restrict__ cold_list) {
+  if (cold_list[0] < 0) return;  // the whole launch went to the fp32 pass: nothing was stored
+  // 32 entries per workgroup x 8 slices of the blocks: the loads of a thread are few and independent (as one thread
+  // per entry walking all 256 blocks this kernel took 22 us, all of it load latency)
+  __shared__ float part[8][32];
+  const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
+  const bool mine = i < red_floats;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (mine) {
+    int b = slice;
+    for (; b + 24 < n_blocks; b += 32) {
+      s0 += partials[(int64_t)(b + 0) * red_floats + i];
+      s1 += partials[(int64_t)(b + 8) * red_floats + i];
+      s2 += partials[(int64_t)(b + 16) * red_floats + i];
+      s3 += partials[(int64_t)(b + 24) * red_floats + i];
+    }
+    for (; b < n_blocks; b += 8) s0 += partials[(int64_t)b * red_floats + i];
+  }
+  part[slice][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && mine) {
+    const int32_t dst = flush[i];
+    if (dst >= 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][e];
+      grad_flat[dst] += t * (1.0f / scale_dev[0]);
+    }
   }
 }
 
@@ -728,7 +772,8 @@ static int build_bwd_split_index(int32_t* idx) {
 template <int H, int HID>
 static int launch_bwd_split(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                             const uint32_t* image, const int32_t* index, int64_t rows, int parity, int inverse,
-                            const float* scale_dev, int32_t* cold_list, int cold_capacity, hipStream_t stream) {
+                            const float* scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
+                            int64_t workspace_floats, hipStream_t stream) {
   using B = BwdSplitShape<H, HID>;
   static constexpr size_t lds_bytes = B::LDS_WORDS * sizeof(uint32_t);
   static DeviceMemo memo;
@@ -744,12 +789,16 @@ static int launch_bwd_split(const float* x, const float* grad_y, const float* gr
   int64_t blocks = (n_tiles + kBsWaves - 1) / kBsWaves;
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (one wave per SIMD: the whole register file)
   const dim3 grid((unsigned)blocks), block(kBsWaves * 64);
+  float* partials = (grad_flat && workspace && workspace_floats >= blocks * B::RED_FLOATS) ? workspace : nullptr;
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_split_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity);
+                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials);
   else
     hipLaunchKernelGGL((ahf_bwd_split_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity);
+                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials);
+  if (partials)
+    hipLaunchKernelGGL(ahf_bwd_reduce_kernel, dim3((B::RED_FLOATS + 31) / 32), dim3(256), 0, stream, partials, (int)blocks,
+                       (int)B::RED_FLOATS, index + B::F::IMAGE_FLOATS, grad_flat, scale_dev, cold_list);
   return check_launch();
 }
 
@@ -794,6 +843,20 @@ int mnf_affine_half_bwd_split_index(int dim, int n_hidden, const int* hidden, in
   return MNF_ERR_UNSUPPORTED;
 }
 
+int64_t mnf_affine_half_bwd_split_workspace(int64_t rows, int dim, int n_hidden, const int* hidden) {
+  int hid = 0;
+  if (rows < 0 || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_split_uniform3(n_hidden, hidden, hid)) return 0;
+  const int64_t n_tiles = (rows + 15) / 16;
+  int64_t blocks = (n_tiles + mnf::kBsWaves - 1) / mnf::kBsWaves;
+  const int cus = mnf::device_cus(mnf::current_device());
+  if (blocks > cus) blocks = cus;
+#define X(HH, HD) \
+  if (dim == 2 * HH && hid == HD) return blocks * mnf::BwdSplitShape<HH, HD>::RED_FLOATS;
+  MNF_AHF_BWD_SPLIT_SHAPES(X)
+#undef X
+  return 0;
+}
+
 int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_t rows, int dim, float* scale_out,
                                void* stream) {
   if (!scale_out || rows < 0 || dim < 1 || (!grad_y && !grad_ld)) return MNF_ERR_INVALID_ARG;
@@ -806,7 +869,8 @@ int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_
 int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                               float* grad_flat, const void* bwd_image, const int32_t* index_dev, int64_t rows, int dim,
                               int parity, int inverse, int n_hidden, const int* hidden, const float* grad_scale_dev,
-                              int32_t* cold_list, int cold_capacity, void* stream) {
+                              int32_t* cold_list, int cold_capacity, float* workspace, int64_t workspace_floats,
+                              void* stream) {
   int hid = 0;
   if (!x || !grad_x || !bwd_image || !index_dev || !cold_list || cold_capacity < 0 || rows < 0 || dim < 2 || (dim & 1) ||
       !mnf::hidden_ok(n_hidden, hidden) || !grad_scale_dev)
@@ -820,7 +884,7 @@ int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* 
   if (dim == 2 * HH && hid == HD)                                                                                      \
     return mnf::launch_bwd_split<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, static_cast<const uint32_t*>(bwd_image), \
                                          index_dev, rows, parity != 0, inverse != 0, grad_scale_dev, cold_list,            \
-                                         cold_capacity, (hipStream_t)stream);
+                                         cold_capacity, workspace, workspace_floats, (hipStream_t)stream);
   MNF_AHF_BWD_SPLIT_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

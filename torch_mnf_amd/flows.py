@@ -143,8 +143,14 @@ def _grad_scale(gy: Tensor | None, gl: Tensor | None, rows: int, dim: int, devic
     return scale
 
 
+def _bwd_split_workspace(lib, f, rows: int, device) -> Tensor | None:
+    """Device floats for the split gradient kernel's two-stage flush (one buffer serves every layer of a run)."""
+    n = lib.mnf_affine_half_bwd_split_workspace(rows, f.dim, len(f.h_sizes), f._hid)
+    return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+
+
 def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr, flat_ptr, bwd_image_ptr, scale, cold,
-                        inverse: bool) -> None:
+                        inverse: bool, work: Tensor | None = None) -> None:
     """Gradients of ONE AffineHalfFlow layer: the split-MFMA kernel (+ its fp32 fix-up pass over the tiles it handed
     back), else the fp32-MFMA kernel, else the generic one.  grad_x is written, the flat gradient added to."""
     rows, hid = x_in.shape[0], (len(f.h_sizes), f._hid)
@@ -154,7 +160,8 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
         cap = cold.numel() - 1
         rc = lib.mnf_affine_half_bwd_split(
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, bwd_image_ptr, index.data_ptr(), rows,
-            f.dim, int(bool(f.parity)), int(inverse), *hid, scale.data_ptr(), cold.data_ptr(), cap, _stream())
+            f.dim, int(bool(f.parity)), int(inverse), *hid, scale.data_ptr(), cold.data_ptr(), cap, _ptr(work),
+            0 if work is None else work.numel(), _stream())
         if rc == _lib.MNF_OK:
             rc = lib.mnf_affine_half_bwd_mfma_tiles(
                 x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
@@ -200,12 +207,13 @@ class _AffineHalfFn(torch.autograd.Function):
         has = flat.numel() > 0
         bwd = (m._bwd_split_image(x.device, flat)
                if has and not m.force_generic and x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None)
-        scale = cold = None
+        scale = cold = work = None
         if bwd is not None:
             scale = _grad_scale(gy, gl, x.shape[0], m.dim, x.device)
             cold = torch.zeros((x.shape[0] + 15) // 16 + 1, dtype=torch.int32, device=x.device)
+            work = _bwd_split_workspace(_lib.load(), m, x.shape[0], x.device)
         _ahf_layer_backward(_lib.load(), m, x, gy, gl, grad_x, _ptr(grad_flat) if has else None,
-                            _ptr(flat) if has else None, _ptr(bwd), scale, cold, ctx.inverse)
+                            _ptr(flat) if has else None, _ptr(bwd), scale, cold, ctx.inverse, work)
         return grad_x, (grad_flat if flat.numel() else None), None, None
 
 
@@ -365,11 +373,12 @@ class _AffineRunFn(torch.autograd.Function):
         # split gradient kernel: every layer's backward image from one launch, one gradient scale for the run (the
         # magnitude changes by e^s per layer: far inside the split range), one fix-up list per layer
         bwd = run.bwd_images(x.device, flat) if x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None
-        scale = cold = None
+        scale = cold = work = None
         if bwd is not None:
             first = next((t for t in reversed(grads[:n]) if t is not None), None)
             scale = _grad_scale(None if first is None else first.contiguous(), gl, x.shape[0], x.shape[1], x.device)
             cold = torch.zeros((n, (x.shape[0] + 15) // 16 + 1), dtype=torch.int32, device=x.device)
+            work = _bwd_split_workspace(lib, run.layers[0], x.shape[0], x.device)
         for li in range(n - 1, -1, -1):
             f = order[li]
             k = run.layers.index(f)
@@ -378,7 +387,7 @@ class _AffineRunFn(torch.autograd.Function):
             _ahf_layer_backward(lib, f, inputs[li], gy, gl, gx, grad_flat.data_ptr() + 4 * offs[k],
                                 flat.data_ptr() + 4 * offs[k],
                                 None if bwd is None else bwd[0].data_ptr() + 4 * bwd[1] * k, scale,
-                                None if cold is None else cold[k], inverse)
+                                None if cold is None else cold[k], inverse, work)
             g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
         return g, (None if home is not None else grad_flat), None, None
 
