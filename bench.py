@@ -40,6 +40,8 @@ WORKLOADS = {
     "c3f": (32, 1 << 20, "3xFusedSplineBlock[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob "
                          "(opt-in fusion: block intermediates not materialised; reported separately from c3)"),
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
+    "c2t": (64, 1 << 20, "training step of 9xAffineHalfFlow d=64 batch=2^20: -mean log-prob, backward, Adam (SURVEY 8f "
+                         "rank 1; the reference's tests train through these layers, tests/test_flows.py:14-31)"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 
@@ -291,6 +293,125 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         dist.destroy_process_group()
 
 
+def main_train(args, rank, world, device, dim, rows, desc) -> None:
+    """SURVEY 8f rank 1 on the bench contract: a step = one Adam step of the C2 model on the resident batch -- forward
+    through the stack kernel (every intermediate kept for the backward pass), -mean log-prob, backward layer by layer
+    (mnf_affine_half_bwd_split + its fix-up pass), one fused Adam launch over the flat parameter buffer.  The dominant
+    kernel is the gradient kernel: x and grad_y in, grad_x out per layer = (12 d + 4) bytes per row per launch."""
+    if world != 1:
+        raise SystemExit("--workload c2t measures one GPU (data-parallel training would add a gradient all-reduce)")
+    import torch_mnf_amd as amd
+    from torch_mnf_amd import flows as amd_flows
+
+    model, layers = build_model(dim, device)
+    opt = amd.FusedAdam(amd.FlatParameters(model), lr=1e-4)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
+    loss_box = [None]
+
+    def step():
+        opt.zero_grad()
+        loss = -model.log_prob(x).mean()
+        loss.backward()
+        opt.step()
+        loss_box[0] = loss
+
+    step()
+    torch.cuda.synchronize()
+    first_loss = float(loss_box[0])
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        step()
+        torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    amd_flows.bwd_kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    events, amd_flows.bwd_kernel_events = amd_flows.bwd_kernel_events, None
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    split_kernel = len(kern_ms) > 0
+    out = {
+        "metric": f"samples/s, {desc}", "value": rows * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": len(model.flows), "hidden": [24, 24, 24],
+                   "optimizer": "FusedAdam over FlatParameters (one buffer, one launch)", "primed_ms": args.prime_ms,
+                   "arithmetic": ARITHMETIC, "total_rows": rows},
+        "distributed": dist_info(1, "nccl", [elapsed], args.steps),
+        "loss_first_step": first_loss, "loss_last_step": float(loss_box[0]),
+    }
+    if split_kernel:
+        avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+        algo_bytes = (12 * dim + 4) * rows
+        traffic, source = pmc_traffic("c2t")
+        gbs = algo_bytes / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": source, **physical(traffic, avg_s),
+                           "kernel": "ahf_bwd_split_kernel<32,24,inverse> (one layer's gradients per launch: recompute, "
+                                     "delta chain, weight gradients; 9 launches per step)",
+                           "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
+                           "launches_timed": len(kern_ms), "launches_per_step": len(model.flows),
+                           "note": "issue / latency bound at one wave per SIMD (DESIGN.md 3.6); the HBM figures say how "
+                                   "far the kernel is from the traffic it has to move"}
+    else:
+        out["roofline"] = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                           "traffic": None, "kernel": "ahf_bwd_mfma_kernel<32,24> (MNF_BWD_FP32=1 / MNF_FP32_MFMA=1)"}
+    if not args.no_cpu_baseline:
+        # the oracle's training step on the host: forward through the restated reference path, torch.autograd backward
+        # (the parameter update is negligible next to it), on a bounded slice of the same batch
+        from oracle import flow_oracle as O
+
+        n = 1 << 16
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        xs = x[:n].cpu()
+        specs = [{"kind": "affine_half", "parity": l["parity"],
+                  "params": {k: v.clone().requires_grad_(True) for k, v in l["params"].items()}} for l in layers]
+        best = float("inf")
+        for _ in range(2):
+            for sp in specs:
+                for v in sp["params"].values():
+                    v.grad = None
+            t1 = time.perf_counter()
+            zs, ld = O.flow_stack(xs, specs, inverse=True)
+            loss_cpu = -(ld + O.std_normal_log_prob(zs[-1])).mean()
+            loss_cpu.backward()
+            best = min(best, time.perf_counter() - t1)
+        out["cpu_baseline"] = {"value": n / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle forward + torch.autograd backward of -mean log-prob on the first {n} rows "
+                                         f"(initial parameters), best of 2, {best:.3f} s"}
+        # parity of the gradients: a fresh model with the same initial parameters on the same rows, against the
+        # oracle evaluated in float64 (sums over 65,536 rows: the fp32 oracle's own rounding is ~1e-4 there)
+        specs = [{"kind": "affine_half", "parity": l["parity"],
+                  "params": {k: v.double().requires_grad_(True) for k, v in l["params"].items()}} for l in layers]
+        zs, ld = O.flow_stack(xs.double(), specs, inverse=True)
+        loss_cpu = -(ld + O.std_normal_log_prob(zs[-1])).mean()
+        loss_cpu.backward()
+        fresh, _ = build_model(dim, device)
+        floor, amd_flows._BWD_SPLIT_MIN_ROWS = amd_flows._BWD_SPLIT_MIN_ROWS, 0
+        try:
+            loss_gpu = -fresh.log_prob(x[:n].contiguous()).mean()
+            loss_gpu.backward()
+        finally:
+            amd_flows._BWD_SPLIT_MIN_ROWS = floor
+        worst = 0.0
+        for sp, f in zip(specs, fresh.flows):
+            for name, prm in f.named_parameters():
+                ref = sp["params"][name].grad
+                worst = max(worst, float((prm.grad.cpu().double() - ref).abs().max() / ref.abs().max()))
+        out["parity"] = {"rows": n, "reference": "oracle in float64", "worst_parameter_gradient_normwise_err": worst,
+                         "tolerance": 5e-5,  # (tests/test_hip_autograd.py: the 9-layer run's gradient bar)
+                         "loss_gpu_vs_cpu_rel_err": abs(float(loss_gpu) - float(loss_cpu)) / abs(float(loss_cpu))}
+    print(json.dumps(out))
+
+
 def spawn_ranks(n: int, argv: list[str]) -> int:
     """`python bench.py --gpus N` without torchrun: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process
@@ -381,6 +502,8 @@ def main() -> None:
     dim, rows, desc = WORKLOADS[args.workload]
     if args.workload == "c5":
         return main_c5(args, rank, world, device, dim, rows, desc)
+    if args.workload == "c2t":
+        return main_train(args, rank, world, device, dim, rows, desc)
     if args.workload in ("c3", "c3f"):
         model, layers = build_c3(device)
         if args.workload == "c3f":

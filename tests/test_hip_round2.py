@@ -119,6 +119,19 @@ def test_bench_single_gpu_line(amd):
     assert "frac_physical" in r and "traffic_source" in r
 
 
+def test_bench_training_step_line(amd):
+    """--workload c2t: one Adam step of the C2 model per step; the line carries the gradient kernel's roofline, the
+    oracle's training step on the host as cpu_baseline and the gradients' parity against the float64 oracle."""
+    line = run_bench("--workload", "c2t", "--steps", "3", "--warmup", "1", "--prime-ms", "5")
+    r = line["roofline"]
+    assert line["unit"] == "samples/s" and r["bound"] == "hbm" and "ahf_bwd_split_kernel" in r["kernel"]
+    assert r["launches_timed"] == 3 * 9 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert line["loss_last_step"] < line["loss_first_step"]          # Adam is descending
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["worst_parameter_gradient_normwise_err"] <= line["parity"]["tolerance"]
+    assert line["parity"]["loss_gpu_vs_cpu_rel_err"] <= 1e-6
+
+
 # ------------------------------------------------------------------ RNVP: the register-resident kernel
 def rnvp_layer(amd, seed, dim=800, hid=50):
     sd = recipes.rnvp_params(seed, dim, hid)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round-2 evidence on the GPU box into gpurun_out/r2/ (copy what is to be judged into profiles/r2/):
 # bench JSON lines, rocprofv3 kernel-trace + PMC summaries (every profiler run under `timeout`), PMC traffic files.
-# usage: tools/refresh_profiles_r2.sh [workloads...]   (default: c2 c3 c4 c5)
+# usage: tools/refresh_profiles_r2.sh [workloads...]   (default: c2 c3 c4 c5; c2t = the training step)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/r2
@@ -9,7 +9,8 @@ mkdir -p "$OUT"
 cd "$REPO"
 WL=${*:-c2 c3 c4 c5}
 declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
-                  [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" )
+                  [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
+                  [c2t]="ahf_bwd_split_kernel<32, 24, true" )
 for w in $WL; do
   python bench.py --workload $w > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
   tools/profile_bench.sh r2_$w --workload $w > /dev/null 2>&1

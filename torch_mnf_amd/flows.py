@@ -143,6 +143,9 @@ def _grad_scale(gy: Tensor | None, gl: Tensor | None, rows: int, dim: int, devic
     return scale
 
 
+bwd_kernel_events: list | None = None  # set to a list to collect (start, end) events of every split gradient launch
+
+
 def _bwd_split_workspace(lib, f, rows: int, device) -> Tensor | None:
     """Device floats for the split gradient kernel's two-stage flush (one buffer serves every layer of a run)."""
     n = lib.mnf_affine_half_bwd_split_workspace(rows, f.dim, len(f.h_sizes), f._hid)
@@ -158,10 +161,17 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
     rc = _lib.MNF_ERR_UNSUPPORTED
     if index is not None and bwd_image_ptr is not None:
         cap = cold.numel() - 1
+        marks = None
+        if bwd_kernel_events is not None:  # bench.py: (start, end) HIP events around the gradient kernel proper
+            marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            marks[0].record()
         rc = lib.mnf_affine_half_bwd_split(
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, bwd_image_ptr, index.data_ptr(), rows,
             f.dim, int(bool(f.parity)), int(inverse), *hid, scale.data_ptr(), cold.data_ptr(), cap, _ptr(work),
             0 if work is None else work.numel(), _stream())
+        if marks is not None:
+            marks[1].record()
+            bwd_kernel_events.append(marks)
         if rc == _lib.MNF_OK:
             rc = lib.mnf_affine_half_bwd_mfma_tiles(
                 x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
