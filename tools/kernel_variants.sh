@@ -11,6 +11,7 @@ SRC=${SRC:-mnf_rnvp_resident}
 # per-file flags as in csrc/Makefile
 case $SRC in
   mnf_rnvp_resident|mnf_rnvp_pair) BASE="-mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-spill-vgpr-to-agpr=0";;
+  mnf_ahf_bwd_split) BASE="-mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-spill-vgpr-to-agpr=0 -fno-honor-nans -fno-slp-vectorize";;
   mnf_ahf_*) BASE="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans -fno-slp-vectorize";;
   *) BASE="-mllvm -amdgpu-mfma-vgpr-form";;
 esac
