@@ -37,7 +37,7 @@ __device__ __forceinline__ void tile_rows_on_k(const float* tile, int i, int kq,
 }
 
 template <int H, int HID, bool INV>
-__global__ void __launch_bounds__(kBwdWaves * 64, 1)
+__global__ void __launch_bounds__((BwdShape<H, HID>::WAVES * 64), 1)
 ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                     float* __restrict__ grad_x, float* __restrict__ grad_flat, const float* __restrict__ flat,
                     const int32_t* __restrict__ index, int64_t rows, int parity, const int32_t* __restrict__ tile_list,
@@ -72,7 +72,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 
   const int n_tiles = (int)((rows + 15) >> 4);
   const int n_items = listed < 0 ? n_tiles : (listed < list_capacity ? listed : list_capacity);
-  for (int item = (int)blockIdx.x * kBwdWaves + wave; item < n_items; item += (int)gridDim.x * kBwdWaves) {
+  for (int item = (int)blockIdx.x * S::WAVES + wave; item < n_items; item += (int)gridDim.x * S::WAVES) {
     const int tile = listed < 0 ? item : tile_list[1 + item];
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
@@ -266,7 +266,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   __syncthreads();
   float* red = lds;  // the images are no longer needed
   constexpr int DW_FLOATS = S::DW_TILES * 256;
-  for (int w = 0; w < kBwdWaves; ++w) {
+  for (int w = 0; w < S::WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int t = 0; t < S::DW_TILES; ++t) {
@@ -427,7 +427,7 @@ static void build_bwd_index(int32_t* idx) {
 }
 
 // shapes: hidden (24,24,24) / (16,16,16) at d = 32, 64
-#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16)
+#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24)
 
 template <int H, int HID>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
@@ -445,11 +445,11 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   });
   if (cus <= 0) return MNF_ERR_UNSUPPORTED;
   const int64_t n_tiles = (rows + 15) / 16;
-  int64_t blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
+  int64_t blocks = (n_tiles + S::WAVES - 1) / S::WAVES;
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)
   // (a fix-up pass gets the full grid too: the list is usually empty and every workgroup returns at once, but it may
   //  also name every tile)
-  const dim3 grid((unsigned)blocks), block(kBwdWaves * 64);
+  const dim3 grid((unsigned)blocks), block(S::WAVES * 64);
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
                        grad_flat, flat, index, rows, parity, tile_list, list_capacity);

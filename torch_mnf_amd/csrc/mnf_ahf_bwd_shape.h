@@ -5,7 +5,7 @@
 
 namespace mnf {
 
-constexpr int kBwdWaves = 4;
+constexpr int kBwdWaves = 4;                    // waves per workgroup of the split kernel and of the fp32 kernel at d <= 64
 constexpr int kTilePitch = 20;                     // floats per row of an LDS scratch tile
 constexpr int kTileFloats = 16 * kTilePitch;
 
@@ -13,6 +13,8 @@ template <int H, int HID>
 struct BwdShape {
   static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported shape");
   static constexpr int G = H / 16;
+  // fp32 kernel: the operand images grow with d; two waves' scratch is what fits beside them at d = 128
+  static constexpr int WAVES = H <= 32 ? kBwdWaves : 2;
   static constexpr int NT = (2 * HID + 15) / 16;
   static constexpr int tile_nets(int m) {  // bit 0 = s, bit 1 = t
     int nets = 0;
@@ -48,7 +50,7 @@ struct BwdShape {
   static constexpr int SCRATCH_TILES = G + 3 * NT + D_TILES;
   // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
   static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
-  static constexpr int LDS_FLOATS = IMAGE_FLOATS + kBwdWaves * SCRATCH_TILES * kTileFloats;
+  static constexpr int LDS_FLOATS = IMAGE_FLOATS + WAVES * SCRATCH_TILES * kTileFloats;
 };
 
 }  // namespace mnf
