@@ -58,7 +58,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 6
+#define MNF_ABI_VERSION 7
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -357,6 +357,14 @@ int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* 
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);
+/* The same gradients from the row-per-lane kernel (mnf_nsf_bwd_rows.hip): dim = 32, three hidden layers of one
+ * width <= 8, K = 5 or 8 -- the shapes mnf_nsf_cl_bwd_rows_supported() answers 1 for; MNF_ERR_UNSUPPORTED otherwise
+ * (callers then use mnf_nsf_cl_bwd).  Weight gradients are summed on the matrix cores over the rows of a wave and
+ * leave each workgroup as one atomic add per parameter. */
+int mnf_nsf_cl_bwd_rows_supported(int dim, int K, int n_hidden, const int* hidden_host);
+int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                        float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
+                        int inverse, int n_hidden, const int* hidden_host, void* stream);
 /* mask == NULL: the mask of the seeded forward call is regenerated from `seed`. */
 int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x,
                  const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,

@@ -289,6 +289,62 @@ def test_nsf_cl_gradients(amd, O, cfg, inverse):
         assert_close(prm.grad, p[name].grad, 1e-4, f"grad {name}")
 
 
+def nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic):
+    f = amd.NSF_CL(32, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    f.force_generic = generic
+    lib = amd._lib.load()
+    assert lib.mnf_nsf_cl_bwd_rows_supported(32, K, 3, f._hid) == 1
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = (f.inverse if inverse else f.forward)(x)
+    ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+
+
+@pytest.mark.parametrize("K,n_h", [(8, 8), (5, 8), (8, 6), (5, 3)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse):
+    """The row-per-lane NSF_CL gradient kernel (d = 32; DPP-rotation hidden layers, weight gradients summed over
+    rows by MFMAs) against autograd through the oracle and against the generic gradient kernel: ragged row count,
+    rows in the identity tails, elements exactly on the tail bound, hidden widths below the kernel's 8 units."""
+    rows = 1003
+    sd = recipes.nsf_cl_params(371 + K + n_h, 32, K, n_h)
+    x_cpu = recipes.gaussian(372 + K, rows, 32, scale=1.3)
+    x_cpu[0, :] = 5.0
+    x_cpu[1, ::2] = 3.0
+    x_cpu[2, 1::2] = -3.0
+    x_cpu.requires_grad_(True)
+    w_y = recipes.gaussian(373, rows, 32)
+    w_l = recipes.gaussian(374, rows, 1)[:, 0]
+    p = leaf(sd)
+    y, ld = O.nsf_cl(x_cpu, p, K, 3.0, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    got = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
+    ref = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=True)
+    assert_close(got["x"], x_cpu.grad, 1e-4, "grad_x")
+    for name in p:
+        assert_close(got[name], p[name].grad, 1e-4, f"grad {name}")
+    for k in got:
+        assert_close(got[k], ref[k], 1e-4, f"rows vs generic {k}")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_row_gradient_kernel_many_rows(amd, inverse):
+    """Enough rows for several trips of every wave of the persistent grid: against the generic kernel.
+    (Seeds matter here: a draw with a hidden pre-activation within rounding of the LeakyReLU kink -- recipe seeds
+    381/382 have one in row 51270, 1.5e-8 -- legitimately takes the other one-sided derivative in one of the kernels.)"""
+    rows, K, n_h = 70001, 8, 8
+    sd = recipes.nsf_cl_params(391, 32, K, n_h)
+    x_cpu = recipes.gaussian(392, rows, 32, scale=1.3)
+    w_y = recipes.gaussian(383, rows, 32)
+    w_l = recipes.gaussian(384, rows, 1)[:, 0]
+    got = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
+    ref = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=True)
+    for k in got:
+        assert_close(got[k], ref[k], 1e-4, f"rows vs generic {k}")
+
+
 @pytest.mark.parametrize("dim", [50, 800])
 def test_rnvp_gradients(amd, O, dim):
     sd = recipes.rnvp_params(81 + dim, dim, 50)

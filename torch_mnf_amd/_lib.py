@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 6  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 7  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -95,6 +95,9 @@ SIGNATURES = {
                                           c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
+    "mnf_nsf_cl_bwd_rows_supported": (c_int, [c_int, c_int, c_int, _intp]),
+    "mnf_nsf_cl_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                    c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_affine_const_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,544 @@
+// NSF_CL gradients with one lane per (row, element): d = 32, three hidden layers of one width <= 8, K = 5 or 8
+// (SURVEY.md 8f rank 1 for config 3; the generic kernel in mnf_backward.hip covers every other shape).
+//
+// A wave owns 4 rows at a time: lane (r = lane >> 4, j = lane & 15) is element j of both halves of row r.
+//   * Hidden layers (16 -> 8 -> 8 -> 8): lane j computes unit j & 7 (both 8-lane halves of a row hold the same
+//     units).  The inputs of a layer sit one per lane, so the dot product runs over DPP row rotations:
+//     sum_n W[unit][source(j, n)] * rot_n(h), with the rotated weights read per lane from LDS.
+//   * Output layer (8 -> 16 (3K-1)): the lane gathers the row's 8 h3 values (8 rotations) and computes the
+//     3K-1 spline parameters of ITS element with weights read from LDS (stored rotated per element, so that
+//     h3all[n] -- the unit rot_n delivers -- meets its weight), then differentiates the spline in registers.
+//   * W4^T g_p: every lane forms its element's share for the 8 units (rotated order), a rotation butterfly
+//     (1, 2, 4, 8 lanes, the unit index shifting along) sums the 16 elements of the row in every lane.
+//   * Weight gradients are sums over rows: dW[m][n] += sum_r A[r][m] B[r][n] is one v_mfma_f32_16x16x4_f32 per
+//     tile with the wave's 4 rows on the K axis -- lane (r, j) supplies A[r][j] and B[r][j] straight from its
+//     registers (A: g_p[k] or a delta, B: the layer input with a column of ones for the bias).  The 2 (3K+3) tiles
+//     stay in accumulator registers for the whole launch; one LDS sum over the 4 waves and one atomic per
+//     parameter per workgroup at the end.
+// No activations in LDS, no cross-lane traffic other than DPP, no atomics inside the row loop.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <type_traits>
+
+#include "mnf_ahf_shape.h"
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+namespace {
+
+constexpr int kNrWaves = 4;
+constexpr int kNrHalf = 16;    // elements per half row
+constexpr int kNrUnits = 8;    // hidden units per layer (narrower nets get structural-zero units)
+constexpr int kNrHidRec = 59;  // per-lane hidden-layer record in LDS (odd pitch: conflict free)
+// record: [0,16) W1 rotated, [16,24) W2 rotated, [24,32) W3 rotated, 32..34 biases,
+//         [35,43) W3^T rotated, [43,51) W2^T rotated, [51,59) W1^T rotated
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// value of lane (j - N) or (j + N) of the same 16-lane row (whichever way row_ror turns: the weight tables are
+// built from the rotation applied to the lane index itself)
+template <int N>
+__device__ __forceinline__ float rot(float x) {
+  constexpr int S = N & 15;
+  if constexpr (S == 0) {
+    return x;
+  } else {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + S, 0xf, 0xf, false));
+  }
+}
+template <int N>
+__device__ __forceinline__ int rot_int(int x) {
+  constexpr int S = N & 15;
+  if constexpr (S == 0) {
+    return x;
+  } else {
+    return __builtin_amdgcn_update_dpp(0, x, 0x120 + S, 0xf, 0xf, false);
+  }
+}
+
+template <int K>
+struct NrShape {
+  static constexpr int P = 3 * K - 1;
+  static constexpr int REC = 8 * P + 4;  // floats per element record of the rotated output weights (+4: banks)
+  static constexpr int NET_FLOATS = kNrHalf * REC + kNrHalf * P + kNrHalf * kNrHidRec;
+  static constexpr int TILES = P + 4;    // dW4 per parameter index, dW3, dW2, dW1, db1
+  static constexpr int RED_FLOATS = 2 * TILES * 256;
+  static constexpr int LDS_FLOATS = RED_FLOATS > 2 * NET_FLOATS ? RED_FLOATS : 2 * NET_FLOATS;
+};
+
+// one spline axis keeping both softmax levels: p1, p2 and the K+1 knots (spline_flow.py:254-255, :95-101)
+template <int K, int OFF, int NP>
+__device__ __forceinline__ void axis_keep(const float (&p)[NP], float T, float (&p1)[K], float (&p2)[K],
+                                          float (&knot)[K + 1]) {
+  const float twoT = 2.f * T, c1 = 1.f - kMinBin * (float)K;
+  float m = p[OFF];
+#pragma unroll
+  for (int k = 1; k < K; ++k) m = fmaxf(m, p[OFF + k]);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    p1[k] = __expf(p[OFF + k] - m);
+    s += p1[k];
+  }
+  const float r = 1.f / s;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    p1[k] *= r;
+    p2[k] = __expf(twoT * p1[k] - twoT * r);  // the largest p1 is r
+    s2 += p2[k];
+  }
+  const float r2 = 1.f / s2;
+  float c = 0.f;
+  knot[0] = -T;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    p2[k] *= r2;
+    c += kMinBin + c1 * p2[k];
+    knot[k + 1] = (k == K - 1) ? T : twoT * c - T;
+  }
+}
+
+// gradient wrt the K raw parameters of an axis given the gradients of knot_b and knot_{b+1}
+template <int K, int OFF, int NP>
+__device__ __forceinline__ void axis_grad(const float (&p1)[K], const float (&p2)[K], float T, int b, float g_lo,
+                                          float g_hi, float (&g_p)[NP]) {
+  const float twoT = 2.f * T, c1 = 1.f - kMinBin * (float)K;
+  // knot_i = 2T cum_{i-1} - T for 1 <= i <= K-1 (knot_0, knot_K are constants)
+  float g[K];
+  float dot2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float gf = 0.f;
+    gf += (b >= 1 && k < b) ? g_lo : 0.f;
+    gf += (b + 1 <= K - 1 && k <= b) ? g_hi : 0.f;
+    g[k] = c1 * twoT * gf;
+    dot2 += p2[k] * g[k];
+  }
+  float dot1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    g[k] = twoT * (p2[k] * (g[k] - dot2));
+    dot1 += p1[k] * g[k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) g_p[OFF + k] = p1[k] * (g[k] - dot1);
+}
+
+__device__ __forceinline__ float softplus_slope(float x) { return x > 20.f ? 1.f : 1.f / (1.f + __expf(-x)); }
+
+// the bin of v and its knots / raw derivative parameters, all indices compile-time
+template <int K>
+struct BinOf {
+  float x0, x1, y0, y1, raw0, raw1;
+  int b;
+};
+template <int K, bool INV, int NP>
+__device__ __forceinline__ BinOf<K> find_bin(float vs, const float (&xk)[K + 1], const float (&yk)[K + 1],
+                                             const float (&p)[NP]) {
+  BinOf<K> o;
+  o.b = 0;
+  o.x0 = xk[0]; o.x1 = xk[1]; o.y0 = yk[0]; o.y1 = yk[1];
+  o.raw0 = 0.f;
+  o.raw1 = p[2 * K];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool hit = vs >= (INV ? yk[k] : xk[k]);  // knots increase: hits are a prefix
+    o.b = hit ? k : o.b;
+    o.x0 = hit ? xk[k] : o.x0;
+    o.x1 = hit ? xk[k + 1] : o.x1;
+    o.y0 = hit ? yk[k] : o.y0;
+    o.y1 = hit ? yk[k + 1] : o.y1;
+    o.raw0 = hit ? p[2 * K + k - 1] : o.raw0;
+    if (k < K - 1) o.raw1 = hit ? p[2 * K + k] : o.raw1;
+  }
+  return o;
+}
+
+// spline value only (the half-step whose output conditions the other net)
+template <int K, bool INV>
+__device__ __forceinline__ float rqs_value(float v, float T, const float (&p)[3 * K - 1]) {
+  const bool inside = (v >= -T) && (v <= T);
+  const float vs = inside ? v : 0.f;
+  float p1[K], p2[K], xk[K + 1], yk[K + 1];
+  axis_keep<K, 0>(p, T, p1, p2, xk);
+  axis_keep<K, K>(p, T, p1, p2, yk);
+  const BinOf<K> bin = find_bin<K, INV>(vs, xk, yk, p);
+  const float pad0 = bin.b == 0 ? kEdgeDerivConst : softplus(bin.raw0);
+  const float pad1 = bin.b == K - 1 ? kEdgeDerivConst : softplus(bin.raw1);
+  const float d0 = kMinDeriv + softplus(pad0), d1 = kMinDeriv + softplus(pad1);
+  const float w = bin.x1 - bin.x0, h = bin.y1 - bin.y0, delta = h / w;
+  float o;
+  if (INV) {
+    const float dy = vs - bin.y0, cv = d0 + d1 - 2.f * delta;
+    const float a = dy * cv + h * (delta - d0), bb = h * d0 - dy * cv, c = -delta * dy;
+    const float root = (2.f * c) / (-bb - sqrtf(bb * bb - 4.f * a * c));
+    o = root * w + bin.x0;
+  } else {
+    const float th = (vs - bin.x0) / w, t1 = th * (1.f - th);
+    o = bin.y0 + h * (delta * th * th + d0 * t1) / (delta + (d0 + d1 - 2.f * delta) * t1);
+  }
+  return inside ? o : v;
+}
+
+// reverse-mode derivative of the spline for one element: g_o, g_l are the cotangents of (output, log-derivative);
+// returns the gradient wrt v and the 3K-1 raw parameters (the maths of rqs_element_bwd in mnf_backward.hip)
+template <int K, bool INV>
+__device__ __forceinline__ void rqs_grad(float v, float T, const float (&p)[3 * K - 1], float g_out, float g_ld,
+                                         float& g_v, float (&g_p)[3 * K - 1]) {
+  const bool inside = (v >= -T) && (v <= T);  // identity tails: g_v = g_out, no parameter gradient
+  const float vs = inside ? v : 0.f, g_o = inside ? g_out : 0.f, g_l = inside ? g_ld : 0.f;
+  float p1w[K], p2w[K], p1h[K], p2h[K], xk[K + 1], yk[K + 1];
+  axis_keep<K, 0>(p, T, p1w, p2w, xk);
+  axis_keep<K, K>(p, T, p1h, p2h, yk);
+  const BinOf<K> bin = find_bin<K, INV>(vs, xk, yk, p);
+  const int b = bin.b;
+  const float x0 = bin.x0, x1 = bin.x1, y0 = bin.y0, y1 = bin.y1, raw0 = bin.raw0, raw1 = bin.raw1;
+  const float pad0 = b == 0 ? kEdgeDerivConst : softplus(raw0);
+  const float pad1 = b == K - 1 ? kEdgeDerivConst : softplus(raw1);
+  const float d0 = kMinDeriv + softplus(pad0), d1 = kMinDeriv + softplus(pad1);
+  const float w = x1 - x0, h = y1 - y0, delta = h / w;
+  float g_x0 = 0.f, g_x1 = 0.f, g_y0 = 0.f, g_y1 = 0.f, g_d0 = 0.f, g_d1 = 0.f;
+  float g_w = 0.f, g_h = 0.f, g_delta = 0.f, gv = 0.f;
+  if (!INV) {
+    const float th = (vs - x0) / w, t1 = th * (1.f - th), omt = 1.f - th;
+    const float B = delta * th * th + d0 * t1, N = h * B;
+    const float cv = d0 + d1 - 2.f * delta, Dn = delta + cv * t1;
+    const float A = d1 * th * th + 2.f * delta * t1 + d0 * omt * omt, dn = delta * delta * A;
+    const float gN = g_o / Dn, gDn = -g_o * N / (Dn * Dn) - 2.f * g_l / Dn, g_dn = g_l / dn;
+    g_y0 += g_o;
+    float g_th = 0.f, g_t1 = 0.f;
+    g_delta += g_dn * (2.f * delta * A + delta * delta * 2.f * t1);
+    const float gA = g_dn * delta * delta;
+    g_d1 += gA * th * th; g_d0 += gA * omt * omt; g_th += gA * (2.f * d1 * th - 2.f * d0 * omt); g_t1 += gA * 2.f * delta;
+    g_delta += gDn * (1.f - 2.f * t1); g_d0 += gDn * t1; g_d1 += gDn * t1; g_t1 += gDn * cv;
+    g_h += gN * B;
+    const float gB = gN * h;
+    g_delta += gB * th * th; g_th += gB * 2.f * delta * th; g_d0 += gB * t1; g_t1 += gB * d0;
+    g_th += g_t1 * (1.f - 2.f * th);
+    gv = g_th / w; g_x0 -= g_th / w; g_w -= g_th * th / w;
+  } else {
+    const float dy = vs - y0, cv = d0 + d1 - 2.f * delta;
+    const float a = dy * cv + h * (delta - d0), bb = h * d0 - dy * cv, c = -delta * dy;
+    const float disc = bb * bb - 4.f * a * c, sq = sqrtf(disc), den = -bb - sq, xi = 2.f * c / den;
+    const float t1 = xi * (1.f - xi), omx = 1.f - xi, Dn = delta + cv * t1;
+    const float A = d1 * xi * xi + 2.f * delta * t1 + d0 * omx * omx, dn = delta * delta * A;
+    float g_xi = g_o * w, g_t1 = 0.f, g_cv = 0.f;
+    g_w += g_o * xi; g_x0 += g_o;
+    const float gDn = 2.f * g_l / Dn, g_dn = -g_l / dn;
+    g_delta += g_dn * (2.f * delta * A + 2.f * delta * delta * t1);
+    const float gA = g_dn * delta * delta;
+    g_d1 += gA * xi * xi; g_d0 += gA * omx * omx; g_xi += gA * (2.f * d1 * xi - 2.f * d0 * omx); g_t1 += gA * 2.f * delta;
+    g_delta += gDn; g_cv += gDn * t1; g_t1 += gDn * cv;
+    g_xi += g_t1 * (1.f - 2.f * xi);
+    float g_c = 2.f * g_xi / den;
+    const float g_den = -g_xi * xi / den;
+    float g_b = -g_den;
+    const float g_disc = -g_den / (2.f * sq);
+    g_b += 2.f * bb * g_disc;
+    const float g_a = -4.f * c * g_disc;
+    g_c += -4.f * a * g_disc;
+    float g_dy = 0.f;
+    g_delta += -dy * g_c; g_dy += -delta * g_c;
+    g_h += d0 * g_b; g_d0 += h * g_b; g_dy += -cv * g_b; g_cv += -dy * g_b;
+    g_dy += cv * g_a; g_cv += dy * g_a; g_h += (delta - d0) * g_a; g_delta += h * g_a; g_d0 += -h * g_a;
+    g_d0 += g_cv; g_d1 += g_cv; g_delta += -2.f * g_cv;
+    gv = g_dy; g_y0 -= g_dy;
+  }
+  g_h += g_delta / w; g_w -= g_delta * delta / w;
+  g_y1 += g_h; g_y0 -= g_h; g_x1 += g_w; g_x0 -= g_w;
+  g_v = inside ? gv : g_out;
+  // derivative parameters: knot b is raw parameter b - 1, knot b + 1 is raw parameter b (the outermost are constants)
+  const float gd0 = b == 0 ? 0.f : g_d0 * softplus_slope(pad0) * softplus_slope(raw0);
+  const float gd1 = b == K - 1 ? 0.f : g_d1 * softplus_slope(pad1) * softplus_slope(raw1);
+#pragma unroll
+  for (int i = 0; i < K - 1; ++i) g_p[2 * K + i] = (i == b - 1 ? gd0 : 0.f) + (i == b ? gd1 : 0.f);
+  axis_grad<K, 0>(p1w, p2w, T, b, g_x0, g_x1, g_p);
+  axis_grad<K, K>(p1h, p2h, T, b, g_y0, g_y1, g_p);
+}
+
+struct NrArgs {
+  const float* x;
+  const float* grad_y;
+  const float* grad_ld;
+  float* grad_x;
+  float* grad_flat;
+  const float* flat;
+  int64_t rows;
+  float T;
+  int hid;
+  NetDesc f1, f2;
+};
+
+// conditioner forward for this lane's row: hidden activations (unit j & 7), the row's h3 in rotated order, and the
+// 3K-1 raw spline parameters of element j
+template <int K>
+__device__ __forceinline__ void net_forward(const float* hw, const float* w4, const float* b4, float cond, float& h1,
+                                            float& h2, float& h3, float (&h3all)[kNrUnits], float (&p)[3 * K - 1]) {
+  float acc = hw[32];
+  static_for<0, 16>([&](auto n) { acc = fmaf(hw[n], rot<decltype(n)::value>(cond), acc); });
+  h1 = leaky(acc);
+  acc = hw[33];
+  static_for<0, 8>([&](auto n) { acc = fmaf(hw[16 + n], rot<decltype(n)::value>(h1), acc); });
+  h2 = leaky(acc);
+  acc = hw[34];
+  static_for<0, 8>([&](auto n) { acc = fmaf(hw[24 + n], rot<decltype(n)::value>(h2), acc); });
+  h3 = leaky(acc);
+  static_for<0, 8>([&](auto n) { h3all[n] = rot<decltype(n)::value>(h3); });
+#pragma unroll
+  for (int k = 0; k < 3 * K - 1; ++k) {
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(w4 + 8 * k);
+    const f32x4 wb = *reinterpret_cast<const f32x4*>(w4 + 8 * k + 4);
+    float a = b4[k];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) a = fmaf(wa[n], h3all[n], a);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) a = fmaf(wb[n], h3all[4 + n], a);
+    p[k] = a;
+    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (else all 2 (3K-1) weight reads are hoisted to the top)
+  }
+}
+
+// One half-step backwards.  cond: the conditioning half's element; val: the transformed half's element BEFORE the
+// spline; g_val: cotangent of the element after it (becomes the cotangent of val); g_cond gets the net's share.
+template <int K, bool INV>
+__device__ __forceinline__ void half_backward(const float* hw, const float* w4, const float* b4, int j, float T,
+                                              float cond, float val, float g_ld, float& g_val, float& g_cond,
+                                              f32x4 (&acc)[3 * K + 3]) {
+  constexpr int P = 3 * K - 1;
+  float h1, h2, h3, h3all[kNrUnits], p[P], g_p[P];
+  net_forward<K>(hw, w4, b4, cond, h1, h2, h3, h3all, p);
+  float g_v;
+  rqs_grad<K, INV>(val, T, p, g_val, g_ld, g_v, g_p);
+  g_val = g_v;
+  // B operands: the layer input with a ones column (n = 8) for the bias
+  const float one8 = j == kNrUnits ? 1.f : 0.f;
+  const float hb3 = j < kNrUnits ? h3 : one8, hb2 = j < kNrUnits ? h2 : one8, hb1 = j < kNrUnits ? h1 : one8;
+#pragma unroll
+  for (int k = 0; k < P; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(g_p[k], hb3, acc[k], 0, 0, 0);
+  // W4^T g_p: this element's share per unit (rotated order), then the sum over the row's 16 elements
+  float y[kNrUnits];
+#pragma unroll
+  for (int n = 0; n < kNrUnits; ++n) y[n] = 0.f;
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(w4 + 8 * k);
+    const f32x4 wb = *reinterpret_cast<const f32x4*>(w4 + 8 * k + 4);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      y[n] = fmaf(wa[n], g_p[k], y[n]);
+      y[4 + n] = fmaf(wb[n], g_p[k], y[4 + n]);
+    }
+    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  static_for<0, 3>([&](auto s) {
+    constexpr int t = 1 << decltype(s)::value;
+    float z[kNrUnits];
+    static_for<0, kNrUnits>([&](auto n) { z[n] = y[n] + rot<t>(y[(decltype(n)::value - t) & 7]); });
+#pragma unroll
+    for (int n = 0; n < kNrUnits; ++n) y[n] = z[n];
+  });
+#pragma unroll
+  for (int n = 0; n < kNrUnits; ++n) y[n] += rot<8>(y[n]);
+  // delta3 for every unit (rotated order; index 0 is this lane's own unit)
+#pragma unroll
+  for (int n = 0; n < kNrUnits; ++n) y[n] = h3all[n] > 0.f ? y[n] : kLeakySlope * y[n];
+  acc[P] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[0], hb2, acc[P], 0, 0, 0);
+  float g2 = 0.f;
+#pragma unroll
+  for (int n = 0; n < kNrUnits; ++n) g2 = fmaf(hw[35 + n], y[n], g2);
+  const float d2 = h2 > 0.f ? g2 : kLeakySlope * g2;
+  acc[P + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d2, hb1, acc[P + 1], 0, 0, 0);
+  float g1 = 0.f;
+  static_for<0, 8>([&](auto n) { g1 = fmaf(hw[43 + n], rot<decltype(n)::value>(d2), g1); });
+  const float d1 = h1 > 0.f ? g1 : kLeakySlope * g1;
+  acc[P + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, cond, acc[P + 2], 0, 0, 0);
+  acc[P + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, 1.f, acc[P + 3], 0, 0, 0);
+  float gc = 0.f;
+  static_for<0, 8>([&](auto n) { gc = fmaf(hw[51 + n], rot<decltype(n)::value>(d1), gc); });
+  g_cond += gc;
+}
+
+// flat-parameter offset of accumulator element (tile t, lane, reg) of a net, -1 if it is padding
+template <int K>
+__device__ __forceinline__ int flush_offset(const NetDesc& nd, int hid, int t, int lane, int reg) {
+  constexpr int P = 3 * K - 1;
+  const int n = lane & 15, m = 4 * (lane >> 4) + reg;
+  if (t < P) {  // output layer: row (element m, parameter t), column n = hidden unit, n = 8: bias
+    if (n < hid) return nd.w_off[3] + (m * P + t) * hid + n;
+    return n == kNrUnits ? nd.b_off[3] + m * P + t : -1;
+  }
+  if (m >= hid) return -1;
+  if (t == P || t == P + 1) {
+    const int l = t == P ? 2 : 1;
+    if (n < hid) return nd.w_off[l] + m * hid + n;
+    return n == kNrUnits ? nd.b_off[l] + m : -1;
+  }
+  if (t == P + 2) return nd.w_off[0] + m * kNrHalf + n;
+  return n == 0 ? nd.b_off[0] + m : -1;
+}
+
+template <int K, bool INV>
+__global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a) {
+  using S = NrShape<K>;
+  constexpr int P = S::P, dim = 2 * kNrHalf;
+  __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, r = lane >> 4;
+  const int hid = a.hid;
+  // which way the rotation turns: rot<1> of the lane's own element index is j - 1 or j + 1
+  const int sgn = ((rot_int<1>(j) - j) & 15) == 1 ? 1 : -1;
+
+  // ------------------------------------------------------------------ LDS images of both nets
+  for (int net = 0; net < 2; ++net) {
+    const NetDesc& nd = net ? a.f2 : a.f1;
+    float* base = lds + net * S::NET_FLOATS;
+    const float* W4 = a.flat + nd.w_off[3];
+    for (int i = threadIdx.x; i < kNrHalf * P * 8; i += blockDim.x) {
+      const int jj = i / (P * 8), rem = i - jj * (P * 8), k = rem >> 3, n = rem & 7;
+      const int unit = (jj + sgn * n) & 7;
+      base[jj * S::REC + k * 8 + n] = unit < hid ? W4[(jj * P + k) * hid + unit] : 0.f;
+    }
+    float* b4 = base + kNrHalf * S::REC;
+    for (int i = threadIdx.x; i < kNrHalf * P; i += blockDim.x) b4[i] = a.flat[nd.b_off[3] + i];
+    float* hwr = b4 + kNrHalf * P;
+    for (int i = threadIdx.x; i < kNrHalf * kNrHidRec; i += blockDim.x) {
+      const int jj = i / kNrHidRec, e = i - jj * kNrHidRec, u = jj & 7;
+      const bool uv = u < hid;
+      float v = 0.f;
+      if (e < 16) {
+        v = uv ? a.flat[nd.w_off[0] + u * kNrHalf + ((jj + sgn * e) & 15)] : 0.f;
+      } else if (e < 32) {
+        const int l = e < 24 ? 1 : 2, un = (jj + sgn * (e & 7)) & 7;
+        v = uv && un < hid ? a.flat[nd.w_off[l] + u * hid + un] : 0.f;
+      } else if (e < 35) {
+        v = uv ? a.flat[nd.b_off[e - 32] + u] : 0.f;
+      } else if (e < 51) {
+        const int l = e < 43 ? 2 : 1, un = (jj + sgn * ((e - 35) & 7)) & 7;
+        v = uv && un < hid ? a.flat[nd.w_off[l] + un * hid + u] : 0.f;
+      } else {
+        const int un = (jj + sgn * (e - 51)) & 7;
+        v = un < hid ? a.flat[nd.w_off[0] + un * kNrHalf + jj] : 0.f;
+      }
+      hwr[i] = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc1[S::TILES], acc2[S::TILES];
+#pragma unroll
+  for (int t = 0; t < S::TILES; ++t) acc1[t] = acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n_tiles = (a.rows + 3) >> 2;
+  for (int64_t tile = (int64_t)blockIdx.x * kNrWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kNrWaves) {
+    const int64_t row = tile * 4 + r;
+    const bool live = row < a.rows;
+    const int64_t rowc = live ? row : a.rows - 1;
+    const float lo0 = a.x[rowc * dim + j], up0 = a.x[rowc * dim + kNrHalf + j];
+    float g_lo = (a.grad_y && live) ? a.grad_y[rowc * dim + j] : 0.f;
+    float g_up = (a.grad_y && live) ? a.grad_y[rowc * dim + kNrHalf + j] : 0.f;
+    const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+
+    int off1 = j, off2 = S::NET_FLOATS + j;
+    asm volatile("" : "+v"(off1), "+v"(off2));  // keep the weight reads inside the row loop
+    const float* n1 = lds + (off1 - j), * n2 = lds + (off2 - j);
+    // per-lane pointers into a net's image: element record, biases, hidden record
+    auto w4_of = [&](const float* nb) { return nb + j * S::REC; };
+    auto b4_of = [&](const float* nb) { return nb + kNrHalf * S::REC + j * P; };
+    auto hw_of = [&](const float* nb) { return nb + kNrHalf * S::REC + kNrHalf * P + j * kNrHidRec; };
+    // forward:  up1 = S(up0; f1(lo0)),  lo1 = S(lo0; f2(up1))       -> reverse: f2's step, then f1's
+    // inverse:  lo1 = S^-1(lo0; f2(up0)), up1 = S^-1(up0; f1(lo1))  -> reverse: f1's step, then f2's
+    const float* na = INV ? n2 : n1;  // the net of the first half-step
+    const float* nb = INV ? n1 : n2;
+    const float cond_a = INV ? up0 : lo0, val_a = INV ? lo0 : up0, val_b = INV ? up0 : lo0;
+    float mid;
+    {
+      float h1, h2, h3, h3all[kNrUnits], p[P];
+      net_forward<K>(hw_of(na), w4_of(na), b4_of(na), cond_a, h1, h2, h3, h3all, p);
+      mid = rqs_value<K, INV>(val_a, a.T, p);
+    }
+    float& g_a = INV ? g_lo : g_up;  // cotangent of the first half-step's output half
+    float& g_b = INV ? g_up : g_lo;
+    half_backward<K, INV>(hw_of(nb), w4_of(nb), b4_of(nb), j, a.T, mid, val_b, gl, g_b, g_a, INV ? acc1 : acc2);
+    half_backward<K, INV>(hw_of(na), w4_of(na), b4_of(na), j, a.T, cond_a, val_a, gl, g_a, g_b, INV ? acc2 : acc1);
+    if (live) {
+      a.grad_x[rowc * dim + j] = g_lo;
+      a.grad_x[rowc * dim + kNrHalf + j] = g_up;
+    }
+  }
+
+  // ------------------------------------------------------------------ flush: sum over the waves, one atomic per parameter
+  if (a.grad_flat == nullptr) return;
+  __syncthreads();
+  for (int w = 0; w < kNrWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < S::TILES; ++t) {
+        f32x4* p1 = reinterpret_cast<f32x4*>(lds + t * 256 + lane * 4);
+        f32x4* p2 = reinterpret_cast<f32x4*>(lds + (S::TILES + t) * 256 + lane * 4);
+        *p1 = w == 0 ? acc1[t] : *p1 + acc1[t];
+        *p2 = w == 0 ? acc2[t] : *p2 + acc2[t];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < S::RED_FLOATS; i += blockDim.x) {
+    const int net = i >= S::TILES * 256, e = i - net * S::TILES * 256;
+    const int dst = flush_offset<K>(net ? a.f2 : a.f1, hid, e >> 8, (e >> 2) & 63, e & 3);
+    if (dst >= 0) atomicAdd(a.grad_flat + dst, lds[i]);
+  }
+}
+
+template <int K>
+int launch_rows(const NrArgs& a, int inverse, hipStream_t stream) {
+  const int dev = current_device();
+  const int64_t n_tiles = (a.rows + 3) / 4;
+  int64_t blocks = (n_tiles + kNrWaves - 1) / kNrWaves;
+  const int cus = device_cus(dev);
+  if (blocks > cus) blocks = cus;  // one persistent workgroup per CU: the accumulators take the register file
+  if (inverse)
+    hipLaunchKernelGGL((nsf_bwd_rows_kernel<K, true>), dim3((unsigned)blocks), dim3(kNrWaves * 64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((nsf_bwd_rows_kernel<K, false>), dim3((unsigned)blocks), dim3(kNrWaves * 64), 0, stream, a);
+  return check_launch();
+}
+
+}  // namespace
+}  // namespace mnf
+
+extern "C" {
+
+int mnf_nsf_cl_bwd_rows_supported(int dim, int K, int n_hidden, const int* hidden) {
+  if (dim != 2 * mnf::kNrHalf || (K != 5 && K != 8) || n_hidden != 3 || !hidden) return 0;
+  return hidden[0] >= 1 && hidden[0] <= mnf::kNrUnits && hidden[1] == hidden[0] && hidden[2] == hidden[0];
+}
+
+int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                        const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                        const int* hidden, void* stream) {
+  if (!x || !grad_x || !flat || rows < 0 || dim < 2 || (dim & 1) || K < 2 || !(tail_bound > 0.f) ||
+      !mnf::hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (!mnf_nsf_cl_bwd_rows_supported(dim, K, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  mnf::NrArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat; a.flat = flat;
+  a.rows = rows; a.T = tail_bound; a.hid = hidden[0];
+  int sizes[5] = {mnf::kNrHalf, hidden[0], hidden[1], hidden[2], (3 * K - 1) * mnf::kNrHalf};
+  const int64_t off = mnf::fill_net(a.f1, 5, sizes, 0);
+  mnf::fill_net(a.f2, 5, sizes, off);
+  return K == 8 ? mnf::launch_rows<8>(a, inverse, (hipStream_t)stream)
+                : mnf::launch_rows<5>(a, inverse, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -253,7 +253,11 @@ class _NsfFn(torch.autograd.Function):
         gl = None if grad_ld is None else grad_ld.contiguous()
         grad_x = torch.empty_like(x)
         grad_flat = torch.zeros_like(flat)
-        _lib.check("mnf_nsf_cl_bwd", _lib.load().mnf_nsf_cl_bwd(
+        lib = _lib.load()
+        # the row-per-lane kernel where it exists (d = 32, hidden width <= 8, K in {5, 8}), else the generic one
+        rows_kernel = not m.force_generic and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid)
+        name = "mnf_nsf_cl_bwd_rows" if rows_kernel else "mnf_nsf_cl_bwd"
+        _lib.check(name, getattr(lib, name)(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
             x.shape[0], m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid, _stream()))
         return grad_x, grad_flat, None, None
