@@ -65,6 +65,14 @@ __device__ __forceinline__ int rot_int(int x) {
   }
 }
 
+// one-instruction reciprocal / square root / exp / log (1 ulp): gradients are compared at 1e-4 and summed over rows
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+// softplus(x) = max(x, 0) + log(1 + exp(-|x|)); above F.softplus's threshold (20) this rounds to x as well
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log_f(1.f + exp_f(-fabsf(x))); }
+__device__ __forceinline__ float softplus_slope(float x) { return x > 20.f ? 1.f : rcp(1.f + exp_f(-x)); }
+
 template <int K>
 struct NrShape {
   static constexpr int P = 3 * K - 1;
@@ -86,18 +94,18 @@ __device__ __forceinline__ void axis_keep(const float (&p)[NP], float T, float (
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    p1[k] = __expf(p[OFF + k] - m);
+    p1[k] = exp_f(p[OFF + k] - m);
     s += p1[k];
   }
-  const float r = 1.f / s;
+  const float r = rcp(s);
   float s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     p1[k] *= r;
-    p2[k] = __expf(twoT * p1[k] - twoT * r);  // the largest p1 is r
+    p2[k] = exp_f(twoT * p1[k] - twoT * r);  // the largest p1 is r
     s2 += p2[k];
   }
-  const float r2 = 1.f / s2;
+  const float r2 = rcp(s2);
   float c = 0.f;
   knot[0] = -T;
 #pragma unroll
@@ -134,7 +142,6 @@ __device__ __forceinline__ void axis_grad(const float (&p1)[K], const float (&p2
   for (int k = 0; k < K; ++k) g_p[OFF + k] = p1[k] * (g[k] - dot1);
 }
 
-__device__ __forceinline__ float softplus_slope(float x) { return x > 20.f ? 1.f : 1.f / (1.f + __expf(-x)); }
 
 // the bin of v and its knots / raw derivative parameters, all indices compile-time
 template <int K>
@@ -173,19 +180,19 @@ __device__ __forceinline__ float rqs_value(float v, float T, const float (&p)[3 
   axis_keep<K, 0>(p, T, p1, p2, xk);
   axis_keep<K, K>(p, T, p1, p2, yk);
   const BinOf<K> bin = find_bin<K, INV>(vs, xk, yk, p);
-  const float pad0 = bin.b == 0 ? kEdgeDerivConst : softplus(bin.raw0);
-  const float pad1 = bin.b == K - 1 ? kEdgeDerivConst : softplus(bin.raw1);
-  const float d0 = kMinDeriv + softplus(pad0), d1 = kMinDeriv + softplus(pad1);
-  const float w = bin.x1 - bin.x0, h = bin.y1 - bin.y0, delta = h / w;
+  const float pad0 = bin.b == 0 ? kEdgeDerivConst : softplus_f(bin.raw0);
+  const float pad1 = bin.b == K - 1 ? kEdgeDerivConst : softplus_f(bin.raw1);
+  const float d0 = kMinDeriv + softplus_f(pad0), d1 = kMinDeriv + softplus_f(pad1);
+  const float w = bin.x1 - bin.x0, h = bin.y1 - bin.y0, rw = rcp(w), delta = h * rw;
   float o;
   if (INV) {
     const float dy = vs - bin.y0, cv = d0 + d1 - 2.f * delta;
     const float a = dy * cv + h * (delta - d0), bb = h * d0 - dy * cv, c = -delta * dy;
-    const float root = (2.f * c) / (-bb - sqrtf(bb * bb - 4.f * a * c));
+    const float root = (2.f * c) * rcp(-bb - __builtin_amdgcn_sqrtf(bb * bb - 4.f * a * c));
     o = root * w + bin.x0;
   } else {
-    const float th = (vs - bin.x0) / w, t1 = th * (1.f - th);
-    o = bin.y0 + h * (delta * th * th + d0 * t1) / (delta + (d0 + d1 - 2.f * delta) * t1);
+    const float th = (vs - bin.x0) * rw, t1 = th * (1.f - th);
+    o = bin.y0 + h * (delta * th * th + d0 * t1) * rcp(delta + (d0 + d1 - 2.f * delta) * t1);
   }
   return inside ? o : v;
 }
@@ -203,18 +210,19 @@ __device__ __forceinline__ void rqs_grad(float v, float T, const float (&p)[3 * 
   const BinOf<K> bin = find_bin<K, INV>(vs, xk, yk, p);
   const int b = bin.b;
   const float x0 = bin.x0, x1 = bin.x1, y0 = bin.y0, y1 = bin.y1, raw0 = bin.raw0, raw1 = bin.raw1;
-  const float pad0 = b == 0 ? kEdgeDerivConst : softplus(raw0);
-  const float pad1 = b == K - 1 ? kEdgeDerivConst : softplus(raw1);
-  const float d0 = kMinDeriv + softplus(pad0), d1 = kMinDeriv + softplus(pad1);
-  const float w = x1 - x0, h = y1 - y0, delta = h / w;
+  const float pad0 = b == 0 ? kEdgeDerivConst : softplus_f(raw0);
+  const float pad1 = b == K - 1 ? kEdgeDerivConst : softplus_f(raw1);
+  const float d0 = kMinDeriv + softplus_f(pad0), d1 = kMinDeriv + softplus_f(pad1);
+  const float w = x1 - x0, h = y1 - y0, rw = rcp(w), delta = h * rw;
   float g_x0 = 0.f, g_x1 = 0.f, g_y0 = 0.f, g_y1 = 0.f, g_d0 = 0.f, g_d1 = 0.f;
   float g_w = 0.f, g_h = 0.f, g_delta = 0.f, gv = 0.f;
   if (!INV) {
-    const float th = (vs - x0) / w, t1 = th * (1.f - th), omt = 1.f - th;
+    const float th = (vs - x0) * rw, t1 = th * (1.f - th), omt = 1.f - th;
     const float B = delta * th * th + d0 * t1, N = h * B;
     const float cv = d0 + d1 - 2.f * delta, Dn = delta + cv * t1;
     const float A = d1 * th * th + 2.f * delta * t1 + d0 * omt * omt, dn = delta * delta * A;
-    const float gN = g_o / Dn, gDn = -g_o * N / (Dn * Dn) - 2.f * g_l / Dn, g_dn = g_l / dn;
+    const float rDn = rcp(Dn);
+    const float gN = g_o * rDn, gDn = -g_o * N * (rDn * rDn) - 2.f * g_l * rDn, g_dn = g_l * rcp(dn);
     g_y0 += g_o;
     float g_th = 0.f, g_t1 = 0.f;
     g_delta += g_dn * (2.f * delta * A + delta * delta * 2.f * t1);
@@ -225,25 +233,26 @@ __device__ __forceinline__ void rqs_grad(float v, float T, const float (&p)[3 * 
     const float gB = gN * h;
     g_delta += gB * th * th; g_th += gB * 2.f * delta * th; g_d0 += gB * t1; g_t1 += gB * d0;
     g_th += g_t1 * (1.f - 2.f * th);
-    gv = g_th / w; g_x0 -= g_th / w; g_w -= g_th * th / w;
+    gv = g_th * rw; g_x0 -= g_th * rw; g_w -= g_th * th * rw;
   } else {
     const float dy = vs - y0, cv = d0 + d1 - 2.f * delta;
     const float a = dy * cv + h * (delta - d0), bb = h * d0 - dy * cv, c = -delta * dy;
-    const float disc = bb * bb - 4.f * a * c, sq = sqrtf(disc), den = -bb - sq, xi = 2.f * c / den;
+    const float disc = bb * bb - 4.f * a * c, sq = __builtin_amdgcn_sqrtf(disc), den = -bb - sq, rden = rcp(den);
+    const float xi = 2.f * c * rden;
     const float t1 = xi * (1.f - xi), omx = 1.f - xi, Dn = delta + cv * t1;
     const float A = d1 * xi * xi + 2.f * delta * t1 + d0 * omx * omx, dn = delta * delta * A;
     float g_xi = g_o * w, g_t1 = 0.f, g_cv = 0.f;
     g_w += g_o * xi; g_x0 += g_o;
-    const float gDn = 2.f * g_l / Dn, g_dn = -g_l / dn;
+    const float gDn = 2.f * g_l * rcp(Dn), g_dn = -g_l * rcp(dn);
     g_delta += g_dn * (2.f * delta * A + 2.f * delta * delta * t1);
     const float gA = g_dn * delta * delta;
     g_d1 += gA * xi * xi; g_d0 += gA * omx * omx; g_xi += gA * (2.f * d1 * xi - 2.f * d0 * omx); g_t1 += gA * 2.f * delta;
     g_delta += gDn; g_cv += gDn * t1; g_t1 += gDn * cv;
     g_xi += g_t1 * (1.f - 2.f * xi);
-    float g_c = 2.f * g_xi / den;
-    const float g_den = -g_xi * xi / den;
+    float g_c = 2.f * g_xi * rden;
+    const float g_den = -g_xi * xi * rden;
     float g_b = -g_den;
-    const float g_disc = -g_den / (2.f * sq);
+    const float g_disc = -g_den * (0.5f * rcp(sq));
     g_b += 2.f * bb * g_disc;
     const float g_a = -4.f * c * g_disc;
     g_c += -4.f * a * g_disc;
@@ -254,7 +263,7 @@ __device__ __forceinline__ void rqs_grad(float v, float T, const float (&p)[3 * 
     g_d0 += g_cv; g_d1 += g_cv; g_delta += -2.f * g_cv;
     gv = g_dy; g_y0 -= g_dy;
   }
-  g_h += g_delta / w; g_w -= g_delta * delta / w;
+  g_h += g_delta * rw; g_w -= g_delta * delta * rw;
   g_y1 += g_h; g_y0 -= g_h; g_x1 += g_w; g_x0 -= g_w;
   g_v = inside ? gv : g_out;
   // derivative parameters: knot b is raw parameter b - 1, knot b + 1 is raw parameter b (the outermost are constants)
@@ -279,6 +288,39 @@ struct NrArgs {
   NetDesc f1, f2;
 };
 
+// The element's output-layer weights, 8 per spline parameter, streamed from LDS in groups of 4 parameters: the next
+// group's reads are issued before the current group is consumed, and a scheduling barrier per group keeps the
+// compiler from hoisting all 2 (3K-1) reads (184 registers) to the top.  f(k, weights 0..3, weights 4..7, bias).
+template <int P, bool BIAS, typename F>
+__device__ __forceinline__ void w4_stream(const float* w4, const float* b4, F&& f) {
+  constexpr int GS = 4, NG = (P + GS - 1) / GS;
+  f32x4 wa[2][GS], wb[2][GS];
+  float bs[2][GS];
+  auto load = [&](auto g) {
+    constexpr int gi = decltype(g)::value;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int k = gi * GS + i;
+      if (k < P) {
+        wa[gi & 1][i] = *reinterpret_cast<const f32x4*>(w4 + 8 * k);
+        wb[gi & 1][i] = *reinterpret_cast<const f32x4*>(w4 + 8 * k + 4);
+        bs[gi & 1][i] = BIAS ? b4[k] : 0.f;
+      }
+    }
+  };
+  load(std::integral_constant<int, 0>{});
+  static_for<0, NG>([&](auto g) {
+    constexpr int gi = decltype(g)::value;
+    if constexpr (gi + 1 < NG) load(std::integral_constant<int, gi + 1>{});
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int k = gi * GS + i;
+      if (k < P) f(k, wa[gi & 1][i], wb[gi & 1][i], bs[gi & 1][i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // conditioner forward for this lane's row: hidden activations (unit j & 7), the row's h3 in rotated order, and the
 // 3K-1 raw spline parameters of element j
 template <int K>
@@ -294,18 +336,14 @@ __device__ __forceinline__ void net_forward(const float* hw, const float* w4, co
   static_for<0, 8>([&](auto n) { acc = fmaf(hw[24 + n], rot<decltype(n)::value>(h2), acc); });
   h3 = leaky(acc);
   static_for<0, 8>([&](auto n) { h3all[n] = rot<decltype(n)::value>(h3); });
-#pragma unroll
-  for (int k = 0; k < 3 * K - 1; ++k) {
-    const f32x4 wa = *reinterpret_cast<const f32x4*>(w4 + 8 * k);
-    const f32x4 wb = *reinterpret_cast<const f32x4*>(w4 + 8 * k + 4);
-    float a = b4[k];
+  w4_stream<3 * K - 1, true>(w4, b4, [&](int k, const f32x4& wa, const f32x4& wb, float bias) {
+    float a = bias;
 #pragma unroll
     for (int n = 0; n < 4; ++n) a = fmaf(wa[n], h3all[n], a);
 #pragma unroll
     for (int n = 0; n < 4; ++n) a = fmaf(wb[n], h3all[4 + n], a);
     p[k] = a;
-    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (else all 2 (3K-1) weight reads are hoisted to the top)
-  }
+  });
 }
 
 // One half-step backwards.  cond: the conditioning half's element; val: the transformed half's element BEFORE the
@@ -329,17 +367,13 @@ __device__ __forceinline__ void half_backward(const float* hw, const float* w4, 
   float y[kNrUnits];
 #pragma unroll
   for (int n = 0; n < kNrUnits; ++n) y[n] = 0.f;
-#pragma unroll
-  for (int k = 0; k < P; ++k) {
-    const f32x4 wa = *reinterpret_cast<const f32x4*>(w4 + 8 * k);
-    const f32x4 wb = *reinterpret_cast<const f32x4*>(w4 + 8 * k + 4);
+  w4_stream<P, false>(w4, b4, [&](int k, const f32x4& wa, const f32x4& wb, float) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       y[n] = fmaf(wa[n], g_p[k], y[n]);
       y[4 + n] = fmaf(wb[n], g_p[k], y[4 + n]);
     }
-    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-  }
+  });
   static_for<0, 3>([&](auto s) {
     constexpr int t = 1 << decltype(s)::value;
     float z[kNrUnits];
@@ -438,15 +472,33 @@ __global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a
 #pragma unroll
   for (int t = 0; t < S::TILES; ++t) acc1[t] = acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t n_tiles = (a.rows + 3) >> 2;
-  for (int64_t tile = (int64_t)blockIdx.x * kNrWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kNrWaves) {
+  const int64_t n_tiles = (a.rows + 3) >> 2, stride = (int64_t)gridDim.x * kNrWaves;
+  struct RowIn {
+    float lo, up, g_lo, g_up, g_ld;
+  };
+  auto load_rows = [&](int64_t tile) {
     const int64_t row = tile * 4 + r;
     const bool live = row < a.rows;
     const int64_t rowc = live ? row : a.rows - 1;
-    const float lo0 = a.x[rowc * dim + j], up0 = a.x[rowc * dim + kNrHalf + j];
-    float g_lo = (a.grad_y && live) ? a.grad_y[rowc * dim + j] : 0.f;
-    float g_up = (a.grad_y && live) ? a.grad_y[rowc * dim + kNrHalf + j] : 0.f;
-    const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+    RowIn in;
+    in.lo = a.x[rowc * dim + j];
+    in.up = a.x[rowc * dim + kNrHalf + j];
+    in.g_lo = (a.grad_y && live) ? a.grad_y[rowc * dim + j] : 0.f;
+    in.g_up = (a.grad_y && live) ? a.grad_y[rowc * dim + kNrHalf + j] : 0.f;
+    in.g_ld = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+    return in;
+  };
+  int64_t tile = (int64_t)blockIdx.x * kNrWaves + wave;
+  RowIn next = load_rows(tile < n_tiles ? tile : 0);
+  for (; tile < n_tiles; tile += stride) {
+    const RowIn cur = next;
+    next = load_rows(tile + stride < n_tiles ? tile + stride : tile);  // one trip ahead: a wave has no one to hide behind
+    __builtin_amdgcn_sched_barrier(0);
+    const int64_t row = tile * 4 + r;
+    const bool live = row < a.rows;
+    const int64_t rowc = live ? row : a.rows - 1;
+    const float lo0 = cur.lo, up0 = cur.up, gl = cur.g_ld;
+    float g_lo = cur.g_lo, g_up = cur.g_up;
 
     int off1 = j, off2 = S::NET_FLOATS + j;
     asm volatile("" : "+v"(off1), "+v"(off2));  // keep the weight reads inside the row loop
