@@ -421,6 +421,38 @@ def test_log_det_equals_log_abs_det_of_the_jacobian(amd, kind, inverse):
     assert float((logabs - ld_rows).abs().max()) <= 2e-5 * max(1.0, float(logabs.abs().max()))
 
 
+@pytest.mark.parametrize("dim,rows", [(32, 100003), (32, 5), (50, 30001), (6, 70001), (300, 777)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_actnorm_and_glow_gradients_many_rows(amd, O, dim, rows, inverse):
+    """ActNorm (one-pass kernel: grad_x and both column sums) and Glow (x^T g; at d = 32 on the matrix cores) against
+    autograd through the oracle, float64: ragged row counts, widths that do and do not divide the workgroup."""
+    ap, gp = recipes.actnorm_params(503 + dim, dim), recipes.glow_params(504 + dim, dim)
+    x_cpu = recipes.gaussian(505 + dim, rows, dim, scale=1.2)
+    w_y = recipes.gaussian(506, rows, dim)
+    an, gl = amd.ActNormFlow(dim), amd.Glow(dim)
+    an.load_state_dict(ap)
+    an.data_dep_init_done = True
+    gl.P = gp["P"]
+    gl.load_state_dict({k: gp[k] for k in "LSU"})
+    an.to(DEV), gl.to(DEV)
+    x = x_cpu.to(DEV).requires_grad_(True)
+    h, ld1 = (an.inverse if inverse else an.forward)(x)
+    y, ld2 = (gl.inverse if inverse else gl.forward)(h)
+    ((y * w_y.to(DEV)).sum() + (ld1.sum() + ld2.sum()) * rows).backward()
+
+    xc = x_cpu.double().requires_grad_(True)
+    pa = {k: v.double().requires_grad_(True) for k, v in ap.items()}
+    pg = {k: gp[k].double().requires_grad_(True) for k in "LSU"}
+    hc, l1 = O.affine_const(xc, pa["s"], pa["t"], inverse)
+    yc, l2 = O.glow(hc, gp["P"].double(), pg["L"], pg["S"], pg["U"], inverse)
+    ((yc * w_y.double()).sum() + (l1.sum() + l2.sum()) * rows).backward()
+    assert_close(x.grad, xc.grad, GTOL, "grad_x")
+    for k in pa:
+        assert_close(getattr(an, k).grad, pa[k].grad, GTOL, f"actnorm grad {k}")
+    for k in pg:
+        assert_close(getattr(gl, k).grad, pg[k].grad, 5e-5, f"glow grad {k}")
+
+
 def test_mnf_linear_kl_and_forward_are_differentiable(amd):
     """The MNF caller trains: gradients reach q0, the RNVP flows and the weights."""
     torch.manual_seed(1)

@@ -10,6 +10,7 @@
 
 #include <cstring>
 
+#include "mnf_ahf_shape.h"
 #include "mnf_device.h"
 #include "mnf_host.h"
 
@@ -220,6 +221,95 @@ __global__ void xtg_kernel(const float* __restrict__ x, const float* __restrict_
   atomicAdd(out + idx, acc);
 }
 
+// x^T g for dim = 32 on the matrix cores: a wave sums 4 rows per v_mfma_f32_16x16x4_f32 (rows on the K axis; lane
+// (c = lane & 15, k = lane >> 4) loads x[row k][16 mi + c] and g[row k][16 nj + c] -- whole 128-byte rows, each
+// read once), 2 x 2 output tiles in registers for the whole launch, one LDS sum over the waves and one atomic per
+// output element per workgroup.  HBM bound (8 bytes per row element).
+__global__ void __launch_bounds__(256) xtg32_mfma_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         float* __restrict__ out, int64_t rows) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, k = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_groups = (rows + 3) >> 2, stride = (int64_t)gridDim.x * 4;
+  constexpr int U = 4;  // 4-row groups in flight per trip
+  for (int64_t grp = ((int64_t)blockIdx.x * 4 + wave) * U; grp < n_groups; grp += stride * U) {
+    float xa[U][2], ga[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (grp + u) * 4 + k;
+      const bool live = row < rows;
+      const int64_t off = (live ? row : 0) * 32 + c;
+      xa[u][0] = live ? x[off] : 0.f;
+      xa[u][1] = live ? x[off + 16] : 0.f;
+      ga[u][0] = live ? g[off] : 0.f;
+      ga[u][1] = live ? g[off + 16] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i], ga[u][j], acc[i][j], 0, 0, 0);
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4* p = reinterpret_cast<f32x4*>(red + t * 256 + lane * 4);
+        *p = w == 0 ? acc[t >> 1][t & 1] : *p + acc[t >> 1][t & 1];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    const int t = e >> 8, l = (e >> 2) & 63, reg = e & 3;
+    const int i = 16 * (t >> 1) + 4 * (l >> 4) + reg, j = 16 * (t & 1) + (l & 15);
+    atomicAdd(out + i * 32 + j, red[e]);
+  }
+}
+
+// AffineConstantFlow / ActNorm gradients in one pass: grad_x = grad_y e^(+-s), and the column sums for grad_s,
+// grad_t.  A workgroup runs a multiple of `dim` threads, so a thread stays on one column while it strides over the
+// rows; the per-thread sums meet in LDS and leave as one atomic per column per workgroup.
+//   forward: y = x e^s + t    -> gs_j = sum_r gx x,   gt_j = sum_r gy
+//   inverse: y = (x - t) e^-s -> gs_j = -sum_r gy y,  gt_j = -sum_r gx
+__global__ void __launch_bounds__(256) affine_const_bwd_fused_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ y,
+                                                                     const float* __restrict__ gy,
+                                                                     const float* __restrict__ s, float* __restrict__ gx,
+                                                                     float* __restrict__ grad_s,
+                                                                     float* __restrict__ grad_t, int64_t n, int dim,
+                                                                     int inverse) {
+  __shared__ float red_s[256], red_t[256];
+  const int col = threadIdx.x % dim;
+  const float e = expf(inverse ? -s[col] : s[col]);
+  float acc_s = 0.f, acc_t = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // a multiple of dim
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = gy[i], v = g * e;
+    gx[i] = v;
+    acc_s += inverse ? -g * y[i] : v * x[i];
+    acc_t += inverse ? -v : g;
+  }
+  red_s[threadIdx.x] = acc_s;
+  red_t[threadIdx.x] = acc_t;
+  __syncthreads();
+  if ((int)threadIdx.x < dim) {
+    float a = 0.f, b = 0.f;
+    for (int t = threadIdx.x; t < (int)blockDim.x; t += dim) {
+      a += red_s[t];
+      b += red_t[t];
+    }
+    if (grad_s) atomicAdd(grad_s + threadIdx.x, a);
+    if (grad_t) atomicAdd(grad_t + threadIdx.x, b);
+  }
+}
+
 // grad_x = grad_y * exp(+-s) (AffineConstantFlow), elementwise
 __global__ void affine_const_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ s,
                                         float* __restrict__ gx, int64_t n, int dim, int inverse) {
@@ -287,6 +377,14 @@ int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, co
   if (rows == 0) return MNF_OK;
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = rows * dim;
+  if (dim <= 256) {  // one pass: a workgroup of (256 / dim) dim threads keeps every thread on its column
+    const int threads = (256 / dim) * dim;
+    int64_t blocks = (n + threads - 1) / threads;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(affine_const_bwd_fused_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, x, y, grad_y, s,
+                       grad_x, grad_s, grad_t, n, dim, inverse != 0);
+    return check_launch();
+  }
   int64_t g = (n + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(affine_const_bwd_kernel, dim3((unsigned)g), dim3(256), 0, st, grad_y, s, grad_x, n, dim,
@@ -311,6 +409,14 @@ int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_
                                void* stream) {
   if (!x || !grad_y || !grad_W || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
+  if (dim == 32) {
+    int64_t blocks = (rows + 63) / 64;  // 4 waves x 4 groups x 4 rows per trip
+    const int cap = 2 * device_cus(current_device());
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(xtg32_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, grad_y, grad_W,
+                       rows);
+    return check_launch();
+  }
   const dim3 grid((dim * dim + 255) / 256, (unsigned)(rows > 4096 ? 128 : 1));
   hipLaunchKernelGGL(xtg_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, grad_W, rows, dim);
   return check_launch();
