@@ -58,7 +58,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 7
+#define MNF_ABI_VERSION 8
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -270,6 +270,11 @@ int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* ep
  * (torch_mnf_amd.train.FlatParameters) the optimizer is one launch instead of one list entry per tensor. */
 int mnf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same update with the step counter on the device, for an optimizer step captured in a hipGraph (a replay runs no
+ * host code): state_dev = {step, 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} (3 floats, zero before the first
+ * step); a one-thread kernel advances it, the update kernel behind it reads the two factors. */
+int mnf_adam_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, float* state_dev, void* stream);
 
 /* ------------------------------------------------------------------ NSF_AR (reuse of the spline device function)
  * torch_mnf/flows/spline_flow.py:182-235.  Element i is moved by a spline whose 3K-1 parameters come from

@@ -124,6 +124,30 @@ def test_affine_half_fp32_mfma_gradient_kernel_d128(amd, O, parity, inverse):
         assert_close(grads["fp32"][k], grads["generic"][k], GTOL, f"fp32 vs generic {k}")
 
 
+@pytest.mark.parametrize("dim,hid", [(2, 24), (6, 24), (30, 16), (40, 24), (100, 24)])
+@pytest.mark.parametrize("parity", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_half_fp32_mfma_gradient_kernel_padded_halves(amd, O, dim, hid, parity, inverse):
+    """Coupling halves narrower than the kernel's tile (d = 2: the reference's half-moons model; 6, 30 -> 16 columns,
+    40 -> 32, 100 -> 64): zero operands in the padded columns, rows read and written under a column mask.  Against
+    autograd through the oracle and against the generic kernel."""
+    h_sizes, rows = (hid, hid, hid), 1000 + 7
+    sd = recipes.affine_half_params(281 + dim, dim, h_sizes=h_sizes, s_last_gain=2.0)
+    x_cpu = recipes.gaussian(282 + dim, rows, dim).requires_grad_(True)
+    w_y = recipes.gaussian(283, rows, dim)
+    w_l = recipes.gaussian(284, rows, 1)[:, 0]
+    p = leaf(sd)
+    y, ld = O.affine_half(x_cpu, p, parity, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    grads = {mode: ahf_grads(amd, sd, dim, h_sizes, parity, inverse, x_cpu, w_y, w_l, mode)
+             for mode in ("fp32", "generic")}
+    assert_close(grads["fp32"]["x"], x_cpu.grad, GTOL, "grad_x")
+    for name in p:
+        assert_close(grads["fp32"][name], p[name].grad, GTOL, f"grad {name}")
+    for k in grads["fp32"]:
+        assert_close(grads["fp32"][k], grads["generic"][k], GTOL, f"fp32 vs generic {k}")
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("magnitude", [1e-7, 3e-3, 40.0])
 def test_split_gradient_kernel_does_not_depend_on_the_gradient_scale(amd, O, inverse, magnitude):

@@ -9,7 +9,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 """
 from . import _lib
 from .layers import MNFConv2d, MNFLinear
-from .train import FlatParameters, FusedAdam
+from .train import FlatParameters, FusedAdam, GraphedStep
 from .flows import (
     MLP,
     ActNormFlow,
@@ -29,7 +29,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "GraphedStep", "library_path",
 ]
 
 

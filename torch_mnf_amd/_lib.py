@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 7  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 8  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -104,6 +104,8 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_adam_step_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                    c_float, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_void_p]),
     "mnf_nsf_ar": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_int, c_int,

@@ -36,19 +36,22 @@ __device__ __forceinline__ void tile_rows_on_k(const float* tile, int i, int kq,
   for (int s = 0; s < 4; ++s) out[s] = tile[(4 * s + kq) * kTilePitch + i];
 }
 
-template <int H, int HID, bool INV>
+// RAG: the coupling half is narrower than the tile (real_h < H: d = 2 ... ): the operand images carry zeros in the padded
+// columns (build_bwd_index), rows are read and written element by element under a column mask.
+template <int H, int HID, bool INV, bool RAG>
 __global__ void __launch_bounds__((BwdShape<H, HID>::WAVES * 64), 1)
 ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                     float* __restrict__ grad_x, float* __restrict__ grad_flat, const float* __restrict__ flat,
                     const int32_t* __restrict__ index, int64_t rows, int parity, const int32_t* __restrict__ tile_list,
-                    int list_capacity) {
+                    int list_capacity, int real_h) {
   using S = BwdShape<H, HID>;
   // tile_list = [count, tile, tile, ...]: only those 16-row tiles (the ones mnf_affine_half_bwd_split handed back
   // because an operand left the split range; count < 0: all of them -- weights beyond the split range); nullptr:
   // every tile
   const int listed = tile_list ? tile_list[0] : -1;
   if (listed == 0) return;
-  constexpr int G = S::G, NT = S::NT, dim = 2 * H;
+  constexpr int G = S::G, NT = S::NT;
+  const int hh = RAG ? real_h : H, dim = 2 * hh;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < S::IMAGE_FLOATS; i += blockDim.x) {
     const int32_t src = index[i];
@@ -57,7 +60,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
-  const int cond_off = parity ? H : 0, act_off = parity ? 0 : H;
+  const int cond_off = parity ? hh : 0, act_off = parity ? 0 : hh;
   float* scratch = lds + S::IMAGE_FLOATS + wave * S::SCRATCH_TILES * kTileFloats;
   float* TX = scratch;                             // x0: G tiles
   float* TH = TX + G * kTileFloats;                // h1, h2, h3: 3 NT tiles
@@ -81,11 +84,27 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     f32x4 cnd[G], act[G], gc[G], ga[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
-      act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g);
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-      gc[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + cond_off + 16 * g) : zero;
-      ga[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + act_off + 16 * g) : zero;
+      if constexpr (RAG) {
+        cnd[g] = act[g] = gc[g] = ga[g] = zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = 16 * g + 4 * q + e;
+          if (col < hh) {
+            cnd[g][e] = xr[cond_off + 16 * g + e];
+            act[g][e] = xr[act_off + 16 * g + e];
+            if (grad_y && live) {
+              gc[g][e] = grad_y[rowc * dim + cond_off + col];
+              ga[g][e] = grad_y[rowc * dim + act_off + col];
+            }
+          }
+        }
+      } else {
+        cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
+        act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g);
+        gc[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + cond_off + 16 * g) : zero;
+        ga[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + act_off + 16 * g) : zero;
+      }
     }
     const float gl = (grad_ld && live) ? grad_ld[rowc] : 0.f;
 
@@ -158,10 +177,17 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
         const float s = st[0][g][r], t = st[1][g][r], gy = ga[g][r], v = act[g][r];
         const float e = exp6(INV ? -s : s);
         gv[r] = gy * e;
-        d4[0][g][r] = live ? (INV ? -gy * ((v - t) * e) - gl : gy * e * v + gl) : 0.f;
+        const bool real = live && (!RAG || 16 * g + 4 * q + r < hh);  // (a padded column has no s to collect grad_ld)
+        d4[0][g][r] = real ? (INV ? -gy * ((v - t) * e) - gl : gy * e * v + gl) : 0.f;
         d4[1][g][r] = INV ? -gy * e : gy;
       }
-      if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + act_off + 16 * g) = gv;
+      if constexpr (RAG) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (live && 16 * g + 4 * q + r < hh) grad_x[rowc * dim + act_off + 16 * g + 4 * q + r] = gv[r];
+      } else {
+        if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + act_off + 16 * g) = gv;
+      }
     }
 
     // weight gradients of one layer: out tiles' deltas in TD[0..n_out), in tiles at `tin`; (mo, mi) pairs by `used`
@@ -257,7 +283,13 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mfma(dl[mt][r], gx0);
-      if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + cond_off + 16 * g) = gx0;
+      if constexpr (RAG) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (live && 16 * g + 4 * q + r < hh) grad_x[rowc * dim + cond_off + 16 * g + 4 * q + r] = gx0[r];
+      } else {
+        if (live) *reinterpret_cast<f32x4*>(grad_x + rowc * dim + 4 * q + cond_off + 16 * g) = gx0;
+      }
     }
   }
 
@@ -299,11 +331,12 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 }
 
 // ---------------------------------------------------------------- host: index table
+// rh: the real half width (<= H; columns rh .. H-1 of the tile are padding: -1 = zero operand, no flush)
 template <int H, int HID>
-static void build_bwd_index(int32_t* idx) {
+static void build_bwd_index(int32_t* idx, int rh) {
   using S = BwdShape<H, HID>;
   constexpr int G = S::G, NT = S::NT;
-  int sizes[5] = {H, HID, HID, HID, H};
+  int sizes[5] = {rh, HID, HID, HID, rh};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -318,7 +351,7 @@ static void build_bwd_index(int32_t* idx) {
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-          if (valid(u)) put(lane, net[netof(u)].w_off[0] + (u % HID) * H + 16 * g + 4 * kq + r);
+          if (valid(u) && 16 * g + 4 * kq + r < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + 4 * kq + r);
         }
   for (int l = 1; l <= 2; ++l)
     for (int m = 0; m < NT; ++m)
@@ -338,7 +371,7 @@ static void build_bwd_index(int32_t* idx) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, ui = 16 * mt + 4 * kq + r;
-            if (valid(ui) && netof(ui) == nn) put(lane, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+            if (valid(ui) && netof(ui) == nn && 16 * g + i < rh) put(lane, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
           }
       }
   // transposed operands
@@ -349,7 +382,8 @@ static void build_bwd_index(int32_t* idx) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-            if (valid(u) && netof(u) == nn) put(lane, net[nn].w_off[3] + (16 * g + 4 * kq + r) * HID + u % HID);
+            if (valid(u) && netof(u) == nn && 16 * g + 4 * kq + r < rh)
+              put(lane, net[nn].w_off[3] + (16 * g + 4 * kq + r) * HID + u % HID);
           }
     }
   for (int l = 2; l >= 1; --l)  // delta_{l}[unit 16 m + i] += W_{l+1}... here: W_l[out 16 mt + 4 kq + r][in unit]
@@ -368,7 +402,7 @@ static void build_bwd_index(int32_t* idx) {
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * mt + 4 * kq + r;
-          if (valid(u)) put(lane, net[netof(u)].w_off[0] + (u % HID) * H + 16 * g + i);
+          if (valid(u) && 16 * g + i < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + i);
         }
   // biases of the forward recompute
   int32_t* b = idx + S::A_FLOATS;
@@ -379,7 +413,8 @@ static void build_bwd_index(int32_t* idx) {
         if (valid(16 * m + i)) b[bt * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
-      for (int i = 0; i < 16; ++i) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+      for (int i = 0; i < 16; ++i)
+        if (16 * g + i < rh) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 
   // flush tables.  dW tile (mo, mi): lane (j = in index b, q), reg r <-> out index a = 4 q + r
   int32_t* fw = idx + S::IMAGE_FLOATS;
@@ -390,7 +425,7 @@ static void build_bwd_index(int32_t* idx) {
       for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
           const int bq = lane & 15, a = 4 * (lane >> 4) + r, u = 16 * mo + a;
-          if (valid(u)) put_w(lane, r, net[netof(u)].w_off[0] + (u % HID) * H + 16 * mi + bq);
+          if (valid(u) && 16 * mi + bq < rh) put_w(lane, r, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * mi + bq);
         }
   for (int l = 1; l <= 2; ++l)
     for (int mo = 0; mo < NT; ++mo)
@@ -411,7 +446,7 @@ static void build_bwd_index(int32_t* idx) {
       for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
           const int bq = lane & 15, a = 4 * (lane >> 4) + r, ui = 16 * mi + bq;
-          if (valid(ui) && netof(ui) == nn) put_w(lane, r, net[nn].w_off[3] + (16 * g + a) * HID + ui % HID);
+          if (valid(ui) && netof(ui) == nn && 16 * g + a < rh) put_w(lane, r, net[nn].w_off[3] + (16 * g + a) * HID + ui % HID);
         }
       ++t;
     }
@@ -423,23 +458,24 @@ static void build_bwd_index(int32_t* idx) {
         if (valid(16 * m + i)) fb[t * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++t)
-      for (int i = 0; i < 16; ++i) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+      for (int i = 0; i < 16; ++i)
+        if (16 * g + i < rh) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
-// shapes: hidden (24,24,24) / (16,16,16) at d = 32, 64
+// shapes: hidden (24,24,24) / (16,16,16) at tile halves 16, 32 (d <= 64; narrower halves padded), (24,24,24) at 64
 #define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24)
 
-template <int H, int HID>
+template <int H, int HID, bool RAG>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                       const float* flat, const int32_t* index, int64_t rows, int parity, int inverse,
-                      const int32_t* tile_list, int list_capacity, hipStream_t stream) {
+                      const int32_t* tile_list, int list_capacity, int real_h, hipStream_t stream) {
   using S = BwdShape<H, HID>;
   constexpr size_t lds_bytes = S::LDS_FLOATS * sizeof(float);
   static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
   const int cus = memo.get([](int dev) {
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, true>),
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, true, RAG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, false>),
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_mfma_kernel<H, HID, false, RAG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
     return ok ? device_cus(dev) : -1;
   });
@@ -451,12 +487,19 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   //  also name every tile)
   const dim3 grid((unsigned)blocks), block(S::WAVES * 64);
   if (inverse)
-    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, flat, index, rows, parity, tile_list, list_capacity);
+    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true, RAG>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
+                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity, real_h);
   else
-    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
-                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity);
+    hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, false, RAG>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
+                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity, real_h);
   return check_launch();
+}
+
+// the tile half width a layer of `dim` columns runs at (0: none): halves narrower than a tile are padded
+static int bwd_padded_half(int dim) {
+  if (dim < 2 || (dim & 1)) return 0;
+  const int h = dim / 2;
+  return h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : 0;
 }
 
 static bool bwd_uniform3(int n_hidden, const int* hidden, int& hid) {
@@ -473,8 +516,9 @@ int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden,
   int hid = 0;
   if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
     return 0;
+  const int ph = mnf::bwd_padded_half(dim);
 #define X(HH, HD) \
-  if (dim == 2 * HH && hid == HD) return mnf::BwdShape<HH, HD>::INDEX_INTS;
+  if (ph == HH && hid == HD) return mnf::BwdShape<HH, HD>::INDEX_INTS;
   MNF_AHF_BWD_SHAPES(X)
 #undef X
   return 0;
@@ -485,10 +529,11 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-#define X(HH, HD)                              \
-  if (dim == 2 * HH && hid == HD) {            \
-    mnf::build_bwd_index<HH, HD>(idx_host);    \
-    return MNF_OK;                             \
+  const int ph = mnf::bwd_padded_half(dim);
+#define X(HH, HD)                                       \
+  if (ph == HH && hid == HD) {                          \
+    mnf::build_bwd_index<HH, HD>(idx_host, dim / 2);    \
+    return MNF_OK;                                      \
   }
   MNF_AHF_BWD_SHAPES(X)
 #undef X
@@ -512,12 +557,19 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   if (!mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15)
+  const int ph = mnf::bwd_padded_half(dim);
+  const bool ragged = ph != dim / 2;  // (element-wise row accesses: no alignment condition)
+  if (!ragged &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15))
     return MNF_ERR_UNSUPPORTED;
-#define X(HH, HD)                                                                                              \
-  if (dim == 2 * HH && hid == HD)                                                                              \
-    return mnf::launch_bwd<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows, parity != 0, \
-                                   inverse != 0, tile_list, list_capacity, (hipStream_t)stream);
+#define X(HH, HD)                                                                                                      \
+  if (ph == HH && hid == HD)                                                                                           \
+    return ragged ? mnf::launch_bwd<HH, HD, true>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows,       \
+                                                  parity != 0, inverse != 0, tile_list, list_capacity, dim / 2,        \
+                                                  (hipStream_t)stream)                                                 \
+                  : mnf::launch_bwd<HH, HD, false>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows,      \
+                                                   parity != 0, inverse != 0, tile_list, list_capacity, dim / 2,       \
+                                                   (hipStream_t)stream);
   MNF_AHF_BWD_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

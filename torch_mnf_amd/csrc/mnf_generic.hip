@@ -555,6 +555,30 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// the step counter of a graph-captured optimizer lives on the device: state = {step, 1 / (1 - beta1^step),
+// 1 / sqrt(1 - beta2^step)}; one thread advances it, the update kernel behind it reads the two factors
+__global__ void adam_advance_kernel(float* __restrict__ state, float beta1, float beta2) {
+  const double step = (double)state[0] + 1.0;
+  state[0] = (float)step;
+  state[1] = (float)(1.0 / (1.0 - pow((double)beta1, step)));
+  state[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
+}
+__global__ void adam_state_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, const float* __restrict__ state) {
+  const float step_size = lr * state[1], inv_sqrt_bc2 = state[2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);
+    const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
+    const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+
 __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __restrict__ log_var,
                                  const float* __restrict__ eps, float* __restrict__ z0, int64_t n,
                                  int dim) {
@@ -818,6 +842,19 @@ int mnf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)));
+  return check_launch();
+}
+
+int mnf_adam_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, float* state_dev, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !state_dev || n < 0 || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f))
+    return MNF_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, beta1, beta2);
+  if (int rc = check_launch()) return rc;
+  if (n == 0) return MNF_OK;
+  hipLaunchKernelGGL(adam_state_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state_dev);
   return check_launch();
 }
 

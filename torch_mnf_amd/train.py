@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from . import _lib
 from .flows import _stream
 
-__all__ = ["FlatParameters", "FusedAdam"]
+__all__ = ["FlatParameters", "FusedAdam", "GraphedStep"]
 
 
 class FlatParameters:
@@ -92,13 +92,16 @@ class FusedAdam:
     buffer: one ``mnf_adam_step`` launch per step."""
 
     def __init__(self, flat: FlatParameters, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+                 eps: float = 1e-8, weight_decay: float = 0.0, capturable: bool = False) -> None:
         self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), \
             float(weight_decay)
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
         self.steps = 0
+        # capturable: the step counter (and the two bias-correction factors) live on the device, so that a step
+        # captured in a hipGraph (GraphedStep) advances them on every replay
+        self.state = torch.zeros(3, dtype=torch.float32, device=flat.data.device) if capturable else None
 
     def zero_grad(self) -> None:
         self.flat.zero_grad()
@@ -107,7 +110,72 @@ class FusedAdam:
     def step(self) -> None:
         f = self.flat
         self.steps += 1
+        if self.state is not None:
+            _lib.check("mnf_adam_step_graph", _lib.load().mnf_adam_step_graph(
+                f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                f.data.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                self.state.data_ptr(), _stream()))
+            f.generation += 1
+            return
         _lib.check("mnf_adam_step", _lib.load().mnf_adam_step(
             f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), f.data.numel(),
             self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps, _stream()))
         f.generation += 1
+
+
+class GraphedStep:
+    """One training step -- zero_grad, ``loss_fn(x)``, backward, ``FusedAdam.step`` -- captured once in a hipGraph and
+    replayed per batch: at the batch sizes the reference trains at (128 rows, examples/half_moons.ipynb:170-200) a
+    step is a few dozen kernels of microseconds each, and what it costs is their launches.
+
+        opt = FusedAdam(FlatParameters(model), lr=1e-3, capturable=True)
+        step = GraphedStep(opt, lambda x: -model.log_prob(x).mean(), example_batch)
+        for x in batches:                 # every batch with example_batch's shape
+            loss = step(x)                # device tensor, rewritten by the next call
+
+    The captured kernels are the ones an eager step launches (the Flow modules' HIP kernels run on the capture stream;
+    parameters, gradients and optimizer state sit in FlatParameters' / FusedAdam's buffers, which a replay updates
+    in place; the packed operand images are rebuilt inside the graph).  Everything the step decides on the host is
+    frozen at capture time: batch shape, kernel choices, and host-drawn random numbers -- RNVP's mask seed is a kernel
+    argument, so models with RNVP layers (MNFLinear / MNFConv2d) must not be captured; coupling and spline flows
+    draw nothing."""
+
+    def __init__(self, opt: FusedAdam, loss_fn, example: Tensor, warmup: int = 3) -> None:
+        if opt.state is None:
+            raise ValueError("GraphedStep needs FusedAdam(..., capturable=True): the step counter must live on the device")
+        if not example.is_cuda:
+            raise ValueError("GraphedStep captures a hipGraph: the batch must be a device tensor")
+        self.opt, self.loss_fn = opt, loss_fn
+        self.x = example.detach().clone()
+
+        def run():
+            opt.zero_grad()
+            loss = loss_fn(self.x)
+            loss.backward()
+            opt.step()
+            return loss
+
+        # warm-up on a side stream (torch.cuda.graphs' recipe): one-time attribute calls, index tables and caches
+        # happen here, not under capture.  These are real steps on example data.
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(torch.cuda.current_stream(example.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                run()
+        torch.cuda.current_stream(example.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = run().detach()
+        opt.steps -= 1               # (capture records the step, it does not run it)
+        opt.flat.generation += 1     # operand images "packed" under capture were only recorded: eager code repacks
+        self.replays = 0
+
+    def __call__(self, x: Tensor) -> Tensor:
+        if x.shape != self.x.shape:
+            raise ValueError(f"GraphedStep was captured for batches of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x)
+        self.graph.replay()
+        self.replays += 1
+        self.opt.steps += 1
+        self.opt.flat.generation += 1  # the replay rewrote the parameters: eager passes must repack their images
+        return self.loss
