@@ -53,9 +53,23 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   constexpr int G = S::G, NT = S::NT;
   const int hh = RAG ? real_h : H, dim = 2 * hh;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < S::IMAGE_FLOATS; i += blockDim.x) {
-    const int32_t src = index[i];
-    lds[i] = src < 0 ? 0.f : flat[src];
+  // (eight independent index -> weight load chains per thread in flight: at a few hundred rows the gather is what the
+  //  launch costs)
+  for (int i0 = threadIdx.x; i0 < S::IMAGE_FLOATS; i0 += 8 * blockDim.x) {
+    int32_t src[8];
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      src[u] = i < S::IMAGE_FLOATS ? index[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = src[u] < 0 ? 0.f : flat[src[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i < S::IMAGE_FLOATS) lds[i] = w[u];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -315,9 +329,16 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   }
   const int32_t* flush_w = index + S::IMAGE_FLOATS;
   const int32_t* flush_b = flush_w + DW_FLOATS;
-  for (int i = threadIdx.x; i < DW_FLOATS; i += blockDim.x) {
-    const int32_t dst = flush_w[i];
-    if (dst >= 0) atomicAdd(grad_flat + dst, red[i]);
+  for (int i0 = threadIdx.x; i0 < DW_FLOATS; i0 += 4 * blockDim.x) {
+    int32_t dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      dst[u] = i < DW_FLOATS ? flush_w[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dst[u] >= 0) atomicAdd(grad_flat + dst[u], red[i0 + u * (int)blockDim.x]);
   }
   // db: lane (i = unit, kq) holds a quarter of the rows' sum
   for (int i = threadIdx.x; i < S::DB_TILES * 16; i += blockDim.x) {
