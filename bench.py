@@ -9,7 +9,7 @@ A step = one density evaluation of one batch resident in HBM, through the drop-i
 followed, when N > 1, by one RCCL all-reduce of (sum, count).  Every rank holds its own 2^20
 rows (weak scaling); value = rows of all ranks / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c3|c2t|c3t|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -42,6 +42,8 @@ WORKLOADS = {
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
     "c2t": (64, 1 << 20, "training step of 9xAffineHalfFlow d=64 batch=2^20: -mean log-prob, backward, Adam (SURVEY 8f "
                          "rank 1; the reference's tests train through these layers, tests/test_flows.py:14-31)"),
+    "c3t": (32, 1 << 20, "training step of 3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20: -mean log-prob, backward, "
+                         "Adam (SURVEY 8f rank 1 for BASELINE configs[2]'s model; tests/test_flows.py:89-99 trains it)"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 
@@ -412,6 +414,119 @@ def main_train(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
+def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
+    """Config 3's model on the training side of the bench contract: a step = one Adam step of 3 x [ActNorm, Glow,
+    NSF_CL] on the resident batch (layer-by-layer forward keeping every intermediate, -mean log-prob, backward, Adam).
+    The dominant kernel is the NSF_CL gradient kernel (mnf_nsf_bwd_rows.hip: one lane per (row, element)); it is
+    vector-issue / latency bound, the HBM figures say how far it is from the traffic it has to move
+    ((12 d + 4) bytes per row per launch: x and grad_y in, grad_x out)."""
+    if world != 1:
+        raise SystemExit("--workload c3t measures one GPU (data-parallel training would add a gradient all-reduce)")
+    from torch_mnf_amd import flows as amd_flows
+
+    model, layers = build_c3(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(rows, dim, device=device, generator=gen)  # resident in HBM before timing
+    loss_box = [None]
+
+    def step():
+        opt.zero_grad()
+        loss = -model.log_prob(x).mean()
+        loss.backward()
+        opt.step()
+        loss_box[0] = loss
+
+    step()
+    torch.cuda.synchronize()
+    first_loss = float(loss_box[0])
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        step()
+        torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    amd_flows.bwd_kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    events, amd_flows.bwd_kernel_events = amd_flows.bwd_kernel_events, None
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    algo_bytes = (12 * dim + 4) * rows
+    gbs = algo_bytes / avg_s / 1e9
+    out = {
+        "metric": f"samples/s, {desc}", "value": rows * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "layers": len(model.flows), "hidden": [8, 8, 8],
+                   "K": 8, "tail_bound": 3.0, "optimizer": "torch.optim.Adam", "primed_ms": args.prime_ms,
+                   "arithmetic": "fp32 (v_rcp / v_exp / v_log one-instruction forms in the spline gradient)",
+                   "total_rows": rows},
+        "distributed": dist_info(1, "nccl", [elapsed], args.steps),
+        "loss_first_step": first_loss, "loss_last_step": float(loss_box[0]),
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": None, "traffic_source": None,
+                     "kernel": "nsf_bwd_rows_kernel<8,inverse> (one NSF_CL layer's gradients per launch; 3 launches per step)",
+                     "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
+                     "launches_timed": len(kern_ms), "launches_per_step": 3,
+                     "note": "vector-issue / latency bound by construction (about 3,400 vector instructions per 4 rows "
+                             "at one wave per SIMD; SQ counters in profiles/r2/c3_train_sq_counters.txt): the HBM "
+                             "fraction is low because the kernel's floor is arithmetic, not traffic (DESIGN.md 3.6)"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import flow_oracle as O
+
+        n = 1 << 13
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        xs = x[:n].cpu()
+
+        def specs_of(dtype):
+            out_specs = []
+            for l in layers:
+                sp = {k: v for k, v in l.items() if k != "params"}
+                sp["params"] = {k: (v.detach().clone().to(dtype).requires_grad_(True) if k != "P" else v.to(dtype))
+                                for k, v in l["params"].items()}
+                out_specs.append(sp)
+            return out_specs
+
+        best = float("inf")
+        for _ in range(2):
+            specs = specs_of(torch.float32)
+            t1 = time.perf_counter()
+            zs, ld = O.flow_stack(xs, specs, inverse=True)
+            (-(ld + O.std_normal_log_prob(zs[-1])).mean()).backward()
+            best = min(best, time.perf_counter() - t1)
+        out["cpu_baseline"] = {"value": n / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle forward + torch.autograd backward of -mean log-prob on the first {n} rows "
+                                         f"(initial parameters), best of 2, {best:.3f} s"}
+        specs = specs_of(torch.float64)
+        zs, ld = O.flow_stack(xs.double(), specs, inverse=True)
+        loss_cpu = -(ld + O.std_normal_log_prob(zs[-1])).mean()
+        loss_cpu.backward()
+        fresh, _ = build_c3(device)
+        loss_gpu = -fresh.log_prob(x[:n].contiguous()).mean()
+        loss_gpu.backward()
+        worst = 0.0
+        for sp, f in zip(specs, fresh.flows):
+            for name, prm in f.named_parameters():
+                ref = sp["params"][name].grad
+                if ref is None or prm.grad is None:
+                    continue
+                worst = max(worst, float((prm.grad.cpu().double().reshape(ref.shape) - ref).abs().max()
+                                         / ref.abs().max().clamp_min(1e-30)))
+        out["parity"] = {"rows": n, "reference": "oracle in float64", "worst_parameter_gradient_normwise_err": worst,
+                         "tolerance": 1e-4,  # (tests/test_hip_autograd.py: the NSF_CL gradient bar)
+                         "loss_gpu_vs_cpu_rel_err": abs(float(loss_gpu) - float(loss_cpu)) / abs(float(loss_cpu))}
+    print(json.dumps(out))
+
+
 def spawn_ranks(n: int, argv: list[str]) -> int:
     """`python bench.py --gpus N` without torchrun: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process
@@ -504,6 +619,8 @@ def main() -> None:
         return main_c5(args, rank, world, device, dim, rows, desc)
     if args.workload == "c2t":
         return main_train(args, rank, world, device, dim, rows, desc)
+    if args.workload == "c3t":
+        return main_train_c3(args, rank, world, device, dim, rows, desc)
     if args.workload in ("c3", "c3f"):
         model, layers = build_c3(device)
         if args.workload == "c3f":

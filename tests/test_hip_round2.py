@@ -132,6 +132,19 @@ def test_bench_training_step_line(amd):
     assert line["parity"]["loss_gpu_vs_cpu_rel_err"] <= 1e-6
 
 
+def test_bench_c3_training_step_line(amd):
+    """--workload c3t: one Adam step of config 3's model per step; the NSF_CL row gradient kernel's roofline figures,
+    the oracle's training step as cpu_baseline, the gradients' parity against the float64 oracle."""
+    line = run_bench("--workload", "c3t", "--steps", "3", "--warmup", "1", "--prime-ms", "5")
+    r = line["roofline"]
+    assert line["unit"] == "samples/s" and "nsf_bwd_rows_kernel" in r["kernel"]
+    assert r["launches_timed"] == 3 * 3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert line["loss_last_step"] < line["loss_first_step"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["worst_parameter_gradient_normwise_err"] <= line["parity"]["tolerance"]
+    assert line["parity"]["loss_gpu_vs_cpu_rel_err"] <= 1e-5
+
+
 # ------------------------------------------------------------------ RNVP: the register-resident kernel
 def rnvp_layer(amd, seed, dim=800, hid=50):
     sd = recipes.rnvp_params(seed, dim, hid)

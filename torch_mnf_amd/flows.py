@@ -257,9 +257,16 @@ class _NsfFn(torch.autograd.Function):
         # the row-per-lane kernel where it exists (d = 32, hidden width <= 8, K in {5, 8}), else the generic one
         rows_kernel = not m.force_generic and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid)
         name = "mnf_nsf_cl_bwd_rows" if rows_kernel else "mnf_nsf_cl_bwd"
+        marks = None
+        if bwd_kernel_events is not None and rows_kernel:  # bench.py --workload c3t
+            marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            marks[0].record()
         _lib.check(name, getattr(lib, name)(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
             x.shape[0], m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid, _stream()))
+        if marks is not None:
+            marks[1].record()
+            bwd_kernel_events.append(marks)
         return grad_x, grad_flat, None, None
 
 

@@ -138,7 +138,8 @@ class GraphedStep:
     in place; the packed operand images are rebuilt inside the graph).  Everything the step decides on the host is
     frozen at capture time: batch shape, kernel choices, and host-drawn random numbers -- RNVP's mask seed is a kernel
     argument, so models with RNVP layers (MNFLinear / MNFConv2d) must not be captured; coupling and spline flows
-    draw nothing."""
+    draw nothing.  Glow cannot be captured either (its weight assembly goes through torch.linalg calls that
+    synchronise with the host): the constructor says so."""
 
     def __init__(self, opt: FusedAdam, loss_fn, example: Tensor, warmup: int = 3) -> None:
         if opt.state is None:
@@ -164,8 +165,14 @@ class GraphedStep:
                 run()
         torch.cuda.current_stream(example.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = run().detach()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = run().detach()
+        except RuntimeError as err:  # (torch.AcceleratorError is a RuntimeError)
+            raise RuntimeError(
+                "GraphedStep: the step contains an operation that cannot be recorded in a hipGraph (one that "
+                "synchronises with the host -- e.g. Glow's LU-factor assembly and matrix inverse through "
+                "torch.linalg); capture models of AffineHalfFlow / NSF_CL / ActNorm layers") from err
         opt.steps -= 1               # (capture records the step, it does not run it)
         opt.flat.generation += 1     # operand images "packed" under capture were only recorded: eager code repacks
         self.replays = 0
