@@ -323,6 +323,33 @@ class _AffineConstFn(torch.autograd.Function):
         return gx, gs, gt, None
 
 
+_LINEAR_ROWS_INDEX: dict = {}  # (dim, device) -> index table of the MFMA kernel's operand image (None: no such kernel)
+
+
+def _linear_rows(lib, x: Tensor, W: Tensor, y: Tensor) -> None:
+    """y = x @ W for a (dim, dim) W that changes every call (the training path): on the MFMA kernel where dim has one
+    (the operand image is packed from W by one small gather launch), else on the generic kernel."""
+    dim, key = x.shape[1], (x.shape[1], x.device)
+    if key not in _LINEAR_ROWS_INDEX:
+        n = lib.mnf_linear_rows_image_floats(dim)
+        table = None
+        if n > 0:
+            idx = (ctypes.c_int32 * n)()
+            _lib.check("mnf_linear_rows_image_index", lib.mnf_linear_rows_image_index(dim, idx))
+            table = torch.frombuffer(idx, dtype=torch.int32).clone().to(x.device)
+        _LINEAR_ROWS_INDEX[key] = table
+    table = _LINEAR_ROWS_INDEX[key]
+    if table is None:
+        _lib.check("mnf_linear_rows", lib.mnf_linear_rows(x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], dim,
+                                                          _stream()))
+        return
+    img = torch.empty(table.numel(), dtype=torch.float32, device=x.device)
+    _lib.check("mnf_pack_gather", lib.mnf_pack_gather(W.data_ptr(), table.data_ptr(), img.data_ptr(), table.numel(),
+                                                      _stream()))
+    _lib.check("mnf_linear_rows_img", lib.mnf_linear_rows_img(x.data_ptr(), img.data_ptr(), y.data_ptr(), x.shape[0],
+                                                              dim, _stream()))
+
+
 class _LinearRowsFn(torch.autograd.Function):
     """y = x @ W with both gradients from the HIP library."""
 
@@ -330,8 +357,7 @@ class _LinearRowsFn(torch.autograd.Function):
     def forward(ctx, x, W):
         W = W.contiguous()
         y = torch.empty_like(x)
-        _lib.check("mnf_linear_rows", _lib.load().mnf_linear_rows(
-            x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()))
+        _linear_rows(_lib.load(), x, W, y)
         ctx.save_for_backward(x, W)
         return y
 
@@ -342,8 +368,7 @@ class _LinearRowsFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         Wt = W.t().contiguous()
         lib = _lib.load()
-        _lib.check("mnf_linear_rows", lib.mnf_linear_rows(gy.data_ptr(), Wt.data_ptr(), gx.data_ptr(), x.shape[0],
-                                                          x.shape[1], _stream()))
+        _linear_rows(lib, gy, Wt, gx)
         gW = torch.zeros_like(W)
         _lib.check("mnf_linear_rows_bwd_weight", lib.mnf_linear_rows_bwd_weight(
             x.data_ptr(), gy.data_ptr(), gW.data_ptr(), x.shape[0], x.shape[1], _stream()))
