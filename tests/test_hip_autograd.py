@@ -326,10 +326,17 @@ def nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic):
     return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
 
 
+@pytest.fixture(params=["pairs", "single"])
+def nsf_rows_kernel(request, monkeypatch):
+    """Both row-per-lane NSF_CL gradient kernels: the wave-pair one (default) and the one-wave-per-tile one."""
+    monkeypatch.setenv("MNF_NSF_BWD_PAIRS", "1" if request.param == "pairs" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("K,n_h", [(8, 8), (5, 8), (8, 6), (5, 3)])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse):
-    """The row-per-lane NSF_CL gradient kernel (d = 32; DPP-rotation hidden layers, weight gradients summed over
+def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse, nsf_rows_kernel):
+    """The row-per-lane NSF_CL gradient kernels (d = 32; DPP-rotation hidden layers, weight gradients summed over
     rows by MFMAs) against autograd through the oracle and against the generic gradient kernel: ragged row count,
     rows in the identity tails, elements exactly on the tail bound, hidden widths below the kernel's 8 units."""
     rows = 1003
@@ -354,7 +361,7 @@ def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
-def test_nsf_cl_row_gradient_kernel_many_rows(amd, inverse):
+def test_nsf_cl_row_gradient_kernel_many_rows(amd, inverse, nsf_rows_kernel):
     """Enough rows for several trips of every wave of the persistent grid (and the one-trip-ahead row prefetch).  The
     batch is 70 copies of a 1,003-row batch: every row's gradient must equal the single batch's (row arithmetic
     does not depend on where the row sits) and the parameter gradients must be 70 times the single batch's.

@@ -16,8 +16,12 @@
 //     stay in accumulator registers for the whole launch; one LDS sum over the 4 waves and one atomic per
 //     parameter per workgroup at the end.
 // No activations in LDS, no cross-lane traffic other than DPP, no atomics inside the row loop.
+// Two kernels: nsf_bwd_rows_kernel (a wave does a tile's three steps itself: both nets' accumulators, one wave per
+// SIMD) and nsf_bwd_pairs_kernel (the default: a pair of waves per tile, one net's accumulators each, two waves
+// per SIMD; MNF_NSF_BWD_PAIRS=0 selects the former).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -421,18 +425,12 @@ __device__ __forceinline__ int flush_offset(const NetDesc& nd, int hid, int t, i
   return n == 0 ? nd.b_off[0] + m : -1;
 }
 
-template <int K, bool INV>
-__global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a) {
+// LDS images of both nets (rotated output weights, biases, per-lane hidden records); the caller syncs
+template <int K>
+__device__ __forceinline__ void fill_net_images(float* lds, const NrArgs& a, int sgn) {
   using S = NrShape<K>;
-  constexpr int P = S::P, dim = 2 * kNrHalf;
-  __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, r = lane >> 4;
+  constexpr int P = S::P;
   const int hid = a.hid;
-  // which way the rotation turns: rot<1> of the lane's own element index is j - 1 or j + 1
-  const int sgn = ((rot_int<1>(j) - j) & 15) == 1 ? 1 : -1;
-
-  // ------------------------------------------------------------------ LDS images of both nets
   for (int net = 0; net < 2; ++net) {
     const NetDesc& nd = net ? a.f2 : a.f1;
     float* base = lds + net * S::NET_FLOATS;
@@ -466,6 +464,20 @@ __global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a
       hwr[i] = v;
     }
   }
+}
+
+template <int K, bool INV>
+__global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a) {
+  using S = NrShape<K>;
+  constexpr int P = S::P, dim = 2 * kNrHalf;
+  __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, r = lane >> 4;
+  const int hid = a.hid;
+  // which way the rotation turns: rot<1> of the lane's own element index is j - 1 or j + 1
+  const int sgn = ((rot_int<1>(j) - j) & 15) == 1 ? 1 : -1;
+
+  fill_net_images<K>(lds, a, sgn);
   __syncthreads();
 
   f32x4 acc1[S::TILES], acc2[S::TILES];
@@ -550,6 +562,110 @@ __global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a
   }
 }
 
+// Two waves per SIMD: the accumulators of BOTH nets (216 registers) are what keeps nsf_bwd_rows_kernel at one wave per
+// SIMD, where nothing hides a dependent instruction's latency (vector unit busy 51 % of the time).  Here a pair of
+// waves shares a 4-row tile: wave X (waves 0..3 of the workgroup) owns the first half-step's net and its
+// accumulators, wave Y (waves 4..7) the second's.  Per tile: X runs the first net forward and hands the half it
+// produced to Y; Y differentiates the second half-step and hands both cotangents back; X differentiates the first.
+// Software-pipelined over the pair's tiles, one workgroup barrier per slot: in slot s, X does step 3 of tile s - 2
+// and step 1 of tile s while Y does step 2 of tile s - 1.  (Step 1 holds no accumulators and could alternate between
+// the waves to even their load out: measured slower, 2.04 vs 1.87 ms at 2^20 rows -- both code paths in both waves.)  Hand-over through a double-buffered 3-float mailbox per lane.
+constexpr int kNpPairs = 4;
+
+template <int K, bool INV>
+__global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrArgs a) {
+  using S = NrShape<K>;
+  constexpr int P = S::P, dim = 2 * kNrHalf;
+  __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
+  __shared__ float mail[2][kNpPairs][3][64];  // [slot parity][pair][first step's output | g_a | g_b][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = wave & (kNpPairs - 1), role = wave / kNpPairs;  // role 0: X, 1: Y (one of each per SIMD)
+  const int j = lane & 15, r = lane >> 4;
+  const int sgn = ((rot_int<1>(j) - j) & 15) == 1 ? 1 : -1;
+  fill_net_images<K>(lds, a, sgn);
+  __syncthreads();
+
+  f32x4 acc[S::TILES];
+#pragma unroll
+  for (int t = 0; t < S::TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n_tiles = (a.rows + 3) >> 2, stride = (int64_t)gridDim.x * kNpPairs;
+  const int64_t first0 = (int64_t)blockIdx.x * kNpPairs, first = first0 + pair;
+  // workgroup-uniform slot count (pair 0 has the most tiles), + 2 slots to drain the pipeline
+  const int64_t n_slots = (first0 < n_tiles ? (n_tiles - first0 + stride - 1) / stride : 0) + 2;
+  // forward:  up1 = S(up0; f1(lo0)),  lo1 = S(lo0; f2(up1))       -> reverse: f2's step, then f1's
+  // inverse:  lo1 = S^-1(lo0; f2(up0)), up1 = S^-1(up0; f1(lo1))  -> reverse: f1's step, then f2's
+  constexpr int net_a = INV ? 1 : 0, net_b = 1 - net_a;      // f1 = 0, f2 = 1
+  constexpr int col_a = INV ? 0 : kNrHalf, col_b = kNrHalf - col_a;  // columns of the half each step transforms
+  for (int64_t s = 0; s < n_slots; ++s) {
+    int off = (role ? net_b : net_a) * S::NET_FLOATS + j;
+    asm volatile("" : "+v"(off));  // keep the weight reads inside the slot loop
+    const float* nb = lds + (off - j);
+    const float* w4 = nb + j * S::REC;
+    const float* b4 = nb + kNrHalf * S::REC + j * P;
+    const float* hw = nb + kNrHalf * S::REC + kNrHalf * P + j * kNrHidRec;
+    if (role == 0) {
+      const int64_t t3 = first + (s - 2) * stride, t1 = first + s * stride;
+      if (s >= 2 && t3 < n_tiles) {  // step 3: the first half-step backwards
+        const int64_t row = t3 * 4 + r;
+        const bool live = row < a.rows;
+        const int64_t rowc = live ? row : a.rows - 1;
+        const float cond_a = a.x[rowc * dim + col_b + j], val_a = a.x[rowc * dim + col_a + j];
+        const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+        float g_a = mail[(s - 1) & 1][pair][1][lane], g_b = mail[(s - 1) & 1][pair][2][lane];
+        half_backward<K, INV>(hw, w4, b4, j, a.T, cond_a, val_a, gl, g_a, g_b, acc);
+        if (live) {
+          a.grad_x[rowc * dim + col_a + j] = g_a;
+          a.grad_x[rowc * dim + col_b + j] = g_b;
+        }
+      }
+      if (t1 < n_tiles) {  // step 1: the first net forward, the half it produces
+        const int64_t row = t1 * 4 + r;
+        const int64_t rowc = row < a.rows ? row : a.rows - 1;
+        const float cond_a = a.x[rowc * dim + col_b + j], val_a = a.x[rowc * dim + col_a + j];
+        float h1, h2, h3, h3all[kNrUnits], p[P];
+        net_forward<K>(hw, w4, b4, cond_a, h1, h2, h3, h3all, p);
+        mail[s & 1][pair][0][lane] = rqs_value<K, INV>(val_a, a.T, p);
+      }
+    } else {
+      const int64_t t2 = first + (s - 1) * stride;
+      if (s >= 1 && t2 < n_tiles) {  // step 2: the second half-step backwards, conditioned on X's output
+        const int64_t row = t2 * 4 + r;
+        const bool live = row < a.rows;
+        const int64_t rowc = live ? row : a.rows - 1;
+        const float val_b = a.x[rowc * dim + col_b + j];
+        float g_a = (a.grad_y && live) ? a.grad_y[rowc * dim + col_a + j] : 0.f;
+        float g_b = (a.grad_y && live) ? a.grad_y[rowc * dim + col_b + j] : 0.f;
+        const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+        const float mid = mail[(s - 1) & 1][pair][0][lane];
+        half_backward<K, INV>(hw, w4, b4, j, a.T, mid, val_b, gl, g_b, g_a, acc);
+        mail[s & 1][pair][1][lane] = g_a;
+        mail[s & 1][pair][2][lane] = g_b;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ flush: X waves hold the first net's sums, Y waves the second's
+  if (a.grad_flat == nullptr) return;
+  for (int w = 0; w < kNpPairs; ++w) {
+    if (pair == w) {
+      float* area = lds + (role ? net_b : net_a) * S::TILES * 256;
+#pragma unroll
+      for (int t = 0; t < S::TILES; ++t) {
+        f32x4* q = reinterpret_cast<f32x4*>(area + t * 256 + lane * 4);
+        *q = w == 0 ? acc[t] : *q + acc[t];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < S::RED_FLOATS; i += blockDim.x) {
+    const int net = i >= S::TILES * 256, e = i - net * S::TILES * 256;
+    const int dst = flush_offset<K>(net ? a.f2 : a.f1, a.hid, e >> 8, (e >> 2) & 63, e & 3);
+    if (dst >= 0) atomicAdd(a.grad_flat + dst, lds[i]);
+  }
+}
+
 template <int K>
 int launch_rows(const NrArgs& a, int inverse, hipStream_t stream) {
   const int dev = current_device();
@@ -557,6 +673,14 @@ int launch_rows(const NrArgs& a, int inverse, hipStream_t stream) {
   int64_t blocks = (n_tiles + kNrWaves - 1) / kNrWaves;
   const int cus = device_cus(dev);
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU: the accumulators take the register file
+  const char* e = getenv("MNF_NSF_BWD_PAIRS");  // (read per call: the tests run both kernels in one process)
+  if (!e || e[0] != '0') {  // (same tiles per workgroup and trip: 4 pairs of waves instead of 4 waves)
+    if (inverse)
+      hipLaunchKernelGGL((nsf_bwd_pairs_kernel<K, true>), dim3((unsigned)blocks), dim3(2 * kNpPairs * 64), 0, stream, a);
+    else
+      hipLaunchKernelGGL((nsf_bwd_pairs_kernel<K, false>), dim3((unsigned)blocks), dim3(2 * kNpPairs * 64), 0, stream, a);
+    return check_launch();
+  }
   if (inverse)
     hipLaunchKernelGGL((nsf_bwd_rows_kernel<K, true>), dim3((unsigned)blocks), dim3(kNrWaves * 64), 0, stream, a);
   else
