@@ -12,8 +12,10 @@
 //      transposed; the bias gradients are the sums of those same operand reads.
 // The 28 weight-gradient tiles (112 VGPRs at d = 64) stay in registers across all tiles of a wave; at the
 // end the four waves of a workgroup add them up in LDS and issue one atomic add per parameter.
-// Operand images (forward and transposed weights, 57 KB) are gathered from `flat` into LDS by every
+// Operand images (forward and transposed weights, 57 KB at d = 64) are gathered from `flat` into LDS by every
 // workgroup through an index table the caller builds once per shape (mnf_affine_half_bwd_index).
+// Tile halves of 16, 32 and 64 columns (d = 128: 86 KB of images, two waves per workgroup); a coupling half narrower
+// than its tile is padded (RAG: zero operands, masked row accesses) -- d = 2, the reference's half-moons model, runs here.
 #include <hip/hip_runtime.h>
 
 #include "mnf_ahf_bwd_shape.h"

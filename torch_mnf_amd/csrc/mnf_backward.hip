@@ -1,6 +1,8 @@
 // Backward (gradient) kernels: what torch.autograd needs so the Flow modules train like the
 // reference's (tests/test_flows.py trains through the layers).
 //
+// (Specialised gradient kernels live next door: mnf_ahf_bwd_split.hip / mnf_ahf_bwd_mfma.hip for AffineHalfFlow,
+// mnf_nsf_bwd_rows.hip for NSF_CL at d = 32; here also Glow's x^T g on MFMAs at d = 32 and the one-pass ActNorm kernel.)
 // Generic, any-shape kernels in the style of mnf_generic.hip: one 256-thread workgroup owns R
 // rows, recomputes the conditioner's forward pass keeping every layer's activations in LDS,
 // back-propagates through the MLPs and adds the parameter gradients into `grad_flat` (same
