@@ -124,15 +124,17 @@ def test_affine_half_fp32_mfma_gradient_kernel_d128(amd, O, parity, inverse):
         assert_close(grads["fp32"][k], grads["generic"][k], GTOL, f"fp32 vs generic {k}")
 
 
-@pytest.mark.parametrize("dim,hid", [(2, 24), (6, 24), (30, 16), (40, 24), (100, 24)])
+@pytest.mark.parametrize("dim,hid", [(2, 24), (6, 24), (30, 16), (40, 24), (100, 24), (64, (20, 7, 24)), (2, (5, 16, 9)),
+                                     (128, (16, 16, 16)), (32, (1, 1, 1)), (64, 32), (32, (32, 17, 25)), (2, 32)])
 @pytest.mark.parametrize("parity", [False, True])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_affine_half_fp32_mfma_gradient_kernel_padded_halves(amd, O, dim, hid, parity, inverse):
     """Coupling halves narrower than the kernel's tile (d = 2: the reference's half-moons model; 6, 30 -> 16 columns,
-    40 -> 32, 100 -> 64): zero operands in the padded columns, rows read and written under a column mask.  Against
-    autograd through the oracle and against the generic kernel."""
-    h_sizes, rows = (hid, hid, hid), 1000 + 7
-    sd = recipes.affine_half_params(281 + dim, dim, h_sizes=h_sizes, s_last_gain=2.0)
+    40 -> 32, 100 -> 64) and hidden layers narrower than its 16 / 24 / 32 unit slots (any three widths <= 32; <= 24 at d > 64): zero
+    operands in the padded columns and units, rows read and written under a column mask.  Against autograd through
+    the oracle and against the generic kernel."""
+    h_sizes, rows = (hid, hid, hid) if isinstance(hid, int) else hid, 1000 + 7
+    sd = recipes.affine_half_params(281 + dim + sum(h_sizes), dim, h_sizes=h_sizes, s_last_gain=2.0)
     x_cpu = recipes.gaussian(282 + dim, rows, dim).requires_grad_(True)
     w_y = recipes.gaussian(283, rows, dim)
     w_l = recipes.gaussian(284, rows, 1)[:, 0]

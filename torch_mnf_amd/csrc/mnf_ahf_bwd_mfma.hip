@@ -354,18 +354,20 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 }
 
 // ---------------------------------------------------------------- host: index table
-// rh: the real half width (<= H; columns rh .. H-1 of the tile are padding: -1 = zero operand, no flush)
+// rh: the real half width (<= H; columns rh .. H-1 of the tile are padding: -1 = zero operand, no flush);
+// hs: the three real hidden widths (<= HID each; the unit slots above them are structural zeros the same way)
 template <int H, int HID>
-static void build_bwd_index(int32_t* idx, int rh) {
+static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
   using S = BwdShape<H, HID>;
   constexpr int G = S::G, NT = S::NT;
-  int sizes[5] = {rh, HID, HID, HID, rh};
+  int sizes[5] = {rh, hs[0], hs[1], hs[2], rh};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
   for (int i = 0; i < S::INDEX_INTS; ++i) idx[i] = -1;
   auto netof = [&](int u) { return u / HID; };
-  auto valid = [&](int u) { return u < 2 * HID; };
+  // slot u of the concatenated net is a real unit of hidden layer `layer` (0, 1, 2)
+  auto valid = [&](int u, int layer) { return u < 2 * HID && u % HID < hs[layer]; };
   int n = 0;
   auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
   // forward operands: A[i][kq] = W[out unit of row i][input behind K slot kq of step r]
@@ -374,7 +376,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-          if (valid(u) && 16 * g + 4 * kq + r < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + 4 * kq + r);
+          if (valid(u, 0) && 16 * g + 4 * kq + r < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + 4 * kq + r);
         }
   for (int l = 1; l <= 2; ++l)
     for (int m = 0; m < NT; ++m)
@@ -383,8 +385,8 @@ static void build_bwd_index(int32_t* idx, int rh) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, uo = 16 * m + i, ui = 16 * mt + 4 * kq + r;
-            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
-              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+            if (valid(uo, l) && valid(ui, l - 1) && netof(uo) == netof(ui))
+              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * hs[l - 1] + ui % HID);
           }
       }
   for (int nn = 0; nn < 2; ++nn)
@@ -394,7 +396,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, ui = 16 * mt + 4 * kq + r;
-            if (valid(ui) && netof(ui) == nn && 16 * g + i < rh) put(lane, net[nn].w_off[3] + (16 * g + i) * HID + ui % HID);
+            if (valid(ui, 2) && netof(ui) == nn && 16 * g + i < rh) put(lane, net[nn].w_off[3] + (16 * g + i) * hs[2] + ui % HID);
           }
       }
   // transposed operands
@@ -405,8 +407,8 @@ static void build_bwd_index(int32_t* idx, int rh) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-            if (valid(u) && netof(u) == nn && 16 * g + 4 * kq + r < rh)
-              put(lane, net[nn].w_off[3] + (16 * g + 4 * kq + r) * HID + u % HID);
+            if (valid(u, 2) && netof(u) == nn && 16 * g + 4 * kq + r < rh)
+              put(lane, net[nn].w_off[3] + (16 * g + 4 * kq + r) * hs[2] + u % HID);
           }
     }
   for (int l = 2; l >= 1; --l)  // delta_{l}[unit 16 m + i] += W_{l+1}... here: W_l[out 16 mt + 4 kq + r][in unit]
@@ -416,8 +418,8 @@ static void build_bwd_index(int32_t* idx, int rh) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, ui = 16 * m + i, uo = 16 * mt + 4 * kq + r;
-            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
-              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+            if (valid(uo, l) && valid(ui, l - 1) && netof(uo) == netof(ui))
+              put(lane, net[netof(uo)].w_off[l] + (uo % HID) * hs[l - 1] + ui % HID);
           }
       }
   for (int g = 0; g < G; ++g)  // grad x0[dim 16 g + i] += W1[unit 16 mt + 4 kq + r][dim] delta1[unit]
@@ -425,7 +427,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * mt + 4 * kq + r;
-          if (valid(u) && 16 * g + i < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + i);
+          if (valid(u, 0) && 16 * g + i < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + i);
         }
   // biases of the forward recompute
   int32_t* b = idx + S::A_FLOATS;
@@ -433,7 +435,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
   for (int l = 0; l < 3; ++l)
     for (int m = 0; m < NT; ++m, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (valid(16 * m + i)) b[bt * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
+        if (valid(16 * m + i, l)) b[bt * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
       for (int i = 0; i < 16; ++i)
@@ -448,7 +450,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
       for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
           const int bq = lane & 15, a = 4 * (lane >> 4) + r, u = 16 * mo + a;
-          if (valid(u) && 16 * mi + bq < rh) put_w(lane, r, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * mi + bq);
+          if (valid(u, 0) && 16 * mi + bq < rh) put_w(lane, r, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * mi + bq);
         }
   for (int l = 1; l <= 2; ++l)
     for (int mo = 0; mo < NT; ++mo)
@@ -457,8 +459,8 @@ static void build_bwd_index(int32_t* idx, int rh) {
         for (int lane = 0; lane < 64; ++lane)
           for (int r = 0; r < 4; ++r) {
             const int bq = lane & 15, a = 4 * (lane >> 4) + r, uo = 16 * mo + a, ui = 16 * mi + bq;
-            if (valid(uo) && valid(ui) && netof(uo) == netof(ui))
-              put_w(lane, r, net[netof(uo)].w_off[l] + (uo % HID) * HID + ui % HID);
+            if (valid(uo, l) && valid(ui, l - 1) && netof(uo) == netof(ui))
+              put_w(lane, r, net[netof(uo)].w_off[l] + (uo % HID) * hs[l - 1] + ui % HID);
           }
         ++t;
       }
@@ -469,7 +471,7 @@ static void build_bwd_index(int32_t* idx, int rh) {
       for (int lane = 0; lane < 64; ++lane)
         for (int r = 0; r < 4; ++r) {
           const int bq = lane & 15, a = 4 * (lane >> 4) + r, ui = 16 * mi + bq;
-          if (valid(ui) && netof(ui) == nn && 16 * g + a < rh) put_w(lane, r, net[nn].w_off[3] + (16 * g + a) * HID + ui % HID);
+          if (valid(ui, 2) && netof(ui) == nn && 16 * g + a < rh) put_w(lane, r, net[nn].w_off[3] + (16 * g + a) * hs[2] + ui % HID);
         }
       ++t;
     }
@@ -478,15 +480,15 @@ static void build_bwd_index(int32_t* idx, int rh) {
   for (int l = 0; l < 3; ++l)
     for (int m = 0; m < NT; ++m, ++t)
       for (int i = 0; i < 16; ++i)
-        if (valid(16 * m + i)) fb[t * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
+        if (valid(16 * m + i, l)) fb[t * 16 + i] = net[netof(16 * m + i)].b_off[l] + (16 * m + i) % HID;
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++t)
       for (int i = 0; i < 16; ++i)
         if (16 * g + i < rh) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
-// shapes: hidden (24,24,24) / (16,16,16) at tile halves 16, 32 (d <= 64; narrower halves padded), (24,24,24) at 64
-#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24)
+// shapes: 16, 24 or 32 hidden-unit slots at tile halves 16, 32 (d <= 64; narrower halves and layers padded), 24 at 64
+#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(16, 32) X(32, 32)
 
 template <int H, int HID, bool RAG>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
@@ -525,10 +527,14 @@ static int bwd_padded_half(int dim) {
   return h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : 0;
 }
 
+// the hidden width the kernel runs three hidden layers of widths hidden[0..2] at: 16, 24 or 32, whichever holds the widest
+// (narrower layers get structural-zero units: zero operands, LeakyReLU(0) = 0, no flush); false: none
 static bool bwd_uniform3(int n_hidden, const int* hidden, int& hid) {
   if (n_hidden != 3 || !hidden) return false;
-  hid = hidden[0];
-  return hidden[1] == hid && hidden[2] == hid;
+  int mx = 0;
+  for (int i = 0; i < 3; ++i) mx = hidden[i] > mx ? hidden[i] : mx;
+  hid = mx <= 16 ? 16 : mx <= 24 ? 24 : mx <= 32 ? 32 : 0;
+  return hid != 0;
 }
 
 }  // namespace mnf
@@ -540,6 +546,7 @@ int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden,
   if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
     return 0;
   const int ph = mnf::bwd_padded_half(dim);
+  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
 #define X(HH, HD) \
   if (ph == HH && hid == HD) return mnf::BwdShape<HH, HD>::INDEX_INTS;
   MNF_AHF_BWD_SHAPES(X)
@@ -553,9 +560,10 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int ph = mnf::bwd_padded_half(dim);
+  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
 #define X(HH, HD)                                       \
   if (ph == HH && hid == HD) {                          \
-    mnf::build_bwd_index<HH, HD>(idx_host, dim / 2);    \
+    mnf::build_bwd_index<HH, HD>(idx_host, dim / 2, hidden);    \
     return MNF_OK;                                      \
   }
   MNF_AHF_BWD_SHAPES(X)
@@ -581,6 +589,7 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
   if (rows == 0) return MNF_OK;
   if (!mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int ph = mnf::bwd_padded_half(dim);
+  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
   const bool ragged = ph != dim / 2;  // (element-wise row accesses: no alignment condition)
   if (!ragged &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15))

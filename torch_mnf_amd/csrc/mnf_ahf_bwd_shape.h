@@ -13,8 +13,6 @@ template <int H, int HID>
 struct BwdShape {
   static_assert(H % 16 == 0 && HID % 4 == 0, "unsupported shape");
   static constexpr int G = H / 16;
-  // fp32 kernel: the operand images grow with d; two waves' scratch is what fits beside them at d = 128
-  static constexpr int WAVES = H <= 32 ? kBwdWaves : 2;
   static constexpr int NT = (2 * HID + 15) / 16;
   static constexpr int tile_nets(int m) {  // bit 0 = s, bit 1 = t
     int nets = 0;
@@ -50,6 +48,14 @@ struct BwdShape {
   static constexpr int SCRATCH_TILES = G + 3 * NT + D_TILES;
   // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
   static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
+  // fp32 kernel: as many waves (<= kBwdWaves) as find room for their scratch tiles beside the operand images in the
+  // CU's 160 KB of LDS (d <= 64 with 24 hidden units: 4; d = 128: 2; 32 hidden units at d = 64: 3)
+  static constexpr int waves_that_fit() {
+    int w = kBwdWaves;
+    while (w > 1 && (IMAGE_FLOATS + w * SCRATCH_TILES * kTileFloats) * 4 > 160 * 1024) --w;
+    return w;
+  }
+  static constexpr int WAVES = waves_that_fit();
   static constexpr int LDS_FLOATS = IMAGE_FLOATS + WAVES * SCRATCH_TILES * kTileFloats;
 };
 
