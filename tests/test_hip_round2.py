@@ -774,3 +774,30 @@ def test_graphed_training_step_follows_the_eager_one(amd, dim, rows):
         step(batches[1][:-1])
     with pytest.raises(ValueError):
         amd.GraphedStep(amd.FusedAdam(opt_e.flat), lambda x: x.sum(), batches[0])
+
+
+def test_graphed_training_step_of_an_mnf_model(amd):
+    """A step of an MNF classifier (MNFLinear layers: RNVP flows, torch.optim.Adam(capturable=True)) captured in a
+    hipGraph: the RNVP masks are device draws there, so replays on the same batch differ (fresh masks and noise), the
+    loss falls over replays, and an eager pass afterwards sees the trained parameters."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(amd.MNFLinear(64, 50), torch.nn.ReLU(), amd.MNFLinear(50, 10),
+                              torch.nn.LogSoftmax(dim=-1)).to("cuda")
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, capturable=True)
+    x = torch.rand(128, 64, device="cuda")
+    y = (x[:, :10].argmax(1)).to(torch.int64)
+
+    def loss_fn(xb, yb):
+        kl = sum(m.kl_div() for m in net if hasattr(m, "kl_div"))
+        return torch.nn.functional.nll_loss(net(xb), yb) + kl / 60000
+
+    with pytest.raises(ValueError):
+        amd.GraphedStep(torch.optim.Adam(net.parameters()), loss_fn, (x, y), model=net)
+    step = amd.GraphedStep(opt, loss_fn, (x, y), model=net)
+    losses = [float(step(x, y)) for _ in range(150)]
+    assert all(l == l for l in losses)
+    assert len({round(l, 6) for l in losses[:8]}) > 1, "replays must redraw masks and noise"
+    assert sum(losses[-20:]) / 20 < sum(losses[:20]) / 20 - 0.05, (losses[:3], losses[-3:])
+    with torch.no_grad():
+        acc = float((net(x).argmax(1) == y).float().mean())
+    assert acc > 0.5, acc  # (chance is 0.1; the eager pass repacked its operands from the replayed parameters)

@@ -18,6 +18,7 @@ Reference classes (below /root/reference/torch_mnf):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 from collections.abc import Sequence
@@ -321,6 +322,22 @@ class _AffineConstFn(torch.autograd.Function):
             x.data_ptr(), y.data_ptr(), gy.data_ptr(), s.contiguous().data_ptr(), gx.data_ptr(), gs.data_ptr(),
             gt.data_ptr(), x.shape[0], x.shape[1], int(ctx.inverse), _stream()))
         return gx, gs, gt, None
+
+
+_DEVICE_MASKS = False
+
+
+@contextlib.contextmanager
+def device_drawn_masks():
+    """Inside: RNVP layers called without mask or seed draw their Bernoulli mask as a device tensor (torch.bernoulli,
+    the reference's rnvp.py:28) instead of hashing a host-drawn seed in the kernel.  A step recorded in a hipGraph
+    (train.GraphedStep) needs this: kernel arguments are frozen by the capture, device draws are not."""
+    global _DEVICE_MASKS
+    before, _DEVICE_MASKS = _DEVICE_MASKS, True
+    try:
+        yield
+    finally:
+        _DEVICE_MASKS = before
 
 
 _LINEAR_ROWS_INDEX: dict = {}  # (dim, device) -> index table of the MFMA kernel's operand image (None: no such kernel)
@@ -923,6 +940,10 @@ class RNVP(_HipFlow):
             mask = _device_input(mask, "mask")
             if mask.shape != z.shape:
                 raise ValueError("mask must have the shape of z")
+        elif seed is None and _DEVICE_MASKS:
+            # the reference's own draw (rnvp.py:28), on the device generator: unlike a host-drawn seed (a kernel
+            # argument) it is redrawn by every replay of a captured hipGraph
+            mask = torch.bernoulli(torch.full_like(z, 0.5))
         elif seed is None:  # one draw from torch's global generator per call
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
         if want_grad and prologue is not None:

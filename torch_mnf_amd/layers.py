@@ -178,6 +178,11 @@ class MNFLinear(nn.Module):
             self.n_out, _stream()))
         return out
 
+    def invalidate(self) -> None:
+        """Drop the packed operands of ``forward`` (they are keyed on the parameters' version counters, which a write
+        through ``p.data`` or a hipGraph replay does not bump); the flows have their own ``invalidate``."""
+        self.__dict__.pop("_fwd_cache", None)
+
     def noise_for(self, seed: int, rows: int, device="cuda") -> Tensor:
         """The (rows, n_out) noise an in-kernel-noise ``forward`` call with this seed used (tests)."""
         e = torch.empty(rows, self.n_out, dtype=torch.float32, device=device)

@@ -126,65 +126,101 @@ class FusedAdam:
 
 
 class GraphedStep:
-    """One training step -- zero_grad, ``loss_fn(x)``, backward, ``FusedAdam.step`` -- captured once in a hipGraph and
-    replayed per batch: at the batch sizes the reference trains at (128 rows, examples/half_moons.ipynb:170-200) a
-    step is a few dozen kernels of microseconds each, and what it costs is their launches.
+    """One training step -- zero_grad, ``loss_fn(*batch)``, backward, ``opt.step()`` -- captured once in a hipGraph and
+    replayed per batch: at the batch sizes the reference trains at (128 rows: examples/half_moons.ipynb:170-200, the
+    MNF MNIST example) a step is dozens to a thousand kernels of microseconds each, and what it costs is their
+    launches.
 
         opt = FusedAdam(FlatParameters(model), lr=1e-3, capturable=True)
         step = GraphedStep(opt, lambda x: -model.log_prob(x).mean(), example_batch)
         for x in batches:                 # every batch with example_batch's shape
             loss = step(x)                # device tensor, rewritten by the next call
 
+    ``opt`` is a ``FusedAdam(..., capturable=True)`` or any torch optimizer built with ``capturable=True`` (pass
+    ``model=`` then: its layers' packed operand images are invalidated after every replay); ``example`` is a tensor or
+    a tuple of tensors (inputs, labels, ...), and the step is called with batches of exactly those shapes.
     The captured kernels are the ones an eager step launches (the Flow modules' HIP kernels run on the capture stream;
-    parameters, gradients and optimizer state sit in FlatParameters' / FusedAdam's buffers, which a replay updates
-    in place; the packed operand images are rebuilt inside the graph).  Everything the step decides on the host is
-    frozen at capture time: batch shape, kernel choices, and host-drawn random numbers -- RNVP's mask seed is a kernel
-    argument, so models with RNVP layers (MNFLinear / MNFConv2d) must not be captured; coupling and spline flows
-    draw nothing.  Glow cannot be captured either (its weight assembly goes through torch.linalg calls that
-    synchronise with the host): the constructor says so."""
+    parameters, gradients and optimizer state are updated in place by a replay; the operand images are repacked
+    inside the graph).  Everything the step decides on the host is frozen at capture time: batch shapes, kernel
+    choices, host-drawn random numbers.  RNVP layers therefore draw their masks on the device while the step is
+    warmed up and recorded (``flows.device_drawn_masks``: torch.bernoulli, the reference's own draw, redrawn by every
+    replay like torch.randn is) instead of hashing a host-drawn seed in the kernel.  Glow cannot be captured (its
+    weight assembly goes through torch.linalg calls that synchronise with the host): the constructor says so.
+    If eager steps ran before, drop their loss tensors first (``del loss``): a live loss keeps that step's autograd
+    graph, and with it gradient-accumulation nodes bound to the default stream, alive into the capture."""
 
-    def __init__(self, opt: FusedAdam, loss_fn, example: Tensor, warmup: int = 3) -> None:
-        if opt.state is None:
+    def __init__(self, opt, loss_fn, example, warmup: int = 3, model: nn.Module | None = None) -> None:
+        from .flows import device_drawn_masks
+
+        fused = isinstance(opt, FusedAdam)
+        if fused and opt.state is None:
             raise ValueError("GraphedStep needs FusedAdam(..., capturable=True): the step counter must live on the device")
-        if not example.is_cuda:
-            raise ValueError("GraphedStep captures a hipGraph: the batch must be a device tensor")
-        self.opt, self.loss_fn = opt, loss_fn
-        self.x = example.detach().clone()
+        if not fused and any(not g.get("capturable", False) for g in opt.param_groups):
+            raise ValueError("GraphedStep needs a torch optimizer built with capturable=True (its step counters must "
+                             "live on the device)")
+        batch = tuple(example) if isinstance(example, (tuple, list)) else (example,)
+        if not batch or not all(isinstance(t, Tensor) and t.is_cuda for t in batch):
+            raise ValueError("GraphedStep captures a hipGraph: the example batch must be device tensor(s)")
+        self.opt, self.loss_fn, self.fused = opt, loss_fn, fused
+        self.model = model if model is not None else (opt.flat.model if fused else None)
+        self.batch = tuple(t.detach().clone() for t in batch)
+        device = self.batch[0].device
+        # every layer that caches packed operand images per parameter version
+        self._invalidators = [] if self.model is None else [
+            m.invalidate for m in self.model.modules() if callable(getattr(m, "invalidate", None))]
 
         def run():
-            opt.zero_grad()
-            loss = loss_fn(self.x)
+            if fused:
+                opt.zero_grad()  # (one memset of the flat gradient buffer, inside the graph)
+            loss = loss_fn(*self.batch)
             loss.backward()
             opt.step()
             return loss
 
-        # warm-up on a side stream (torch.cuda.graphs' recipe): one-time attribute calls, index tables and caches
-        # happen here, not under capture.  These are real steps on example data.
-        side = torch.cuda.Stream(device=example.device)
-        side.wait_stream(torch.cuda.current_stream(example.device))
-        with torch.cuda.stream(side):
+        # warm-up on a side stream (torch.cuda.graphs' recipe): one-time attribute calls, index tables, algorithm
+        # searches and caches happen here, not under capture.  These are real steps on the example batch.
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), device_drawn_masks():
             for _ in range(warmup):
+                if not fused:
+                    opt.zero_grad(set_to_none=True)
                 run()
-        torch.cuda.current_stream(example.device).wait_stream(side)
+        torch.cuda.current_stream(device).wait_stream(side)
+        if not fused:
+            opt.zero_grad(set_to_none=True)  # the gradients then live in the graph's memory pool, rewritten per replay
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph), device_drawn_masks():
                 self.loss = run().detach()
         except RuntimeError as err:  # (torch.AcceleratorError is a RuntimeError)
             raise RuntimeError(
                 "GraphedStep: the step contains an operation that cannot be recorded in a hipGraph (one that "
                 "synchronises with the host -- e.g. Glow's LU-factor assembly and matrix inverse through "
-                "torch.linalg); capture models of AffineHalfFlow / NSF_CL / ActNorm layers") from err
-        opt.steps -= 1               # (capture records the step, it does not run it)
-        opt.flat.generation += 1     # operand images "packed" under capture were only recorded: eager code repacks
+                "torch.linalg)") from err
+        if fused:
+            opt.steps -= 1           # (capture records the step, it does not run it)
+        self._touch()                # operand images "packed" under capture were only recorded: eager code repacks
         self.replays = 0
 
-    def __call__(self, x: Tensor) -> Tensor:
-        if x.shape != self.x.shape:
-            raise ValueError(f"GraphedStep was captured for batches of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
-        self.x.copy_(x)
+    def _touch(self) -> None:
+        """The parameters changed behind Python's back (a replay bumps no version counter): whatever the layers cache
+        per parameter version must be rebuilt by the next eager pass."""
+        if self.fused:
+            self.opt.flat.generation += 1  # (the layers key their images on this counter)
+            return
+        for inv in self._invalidators:
+            inv()
+
+    def __call__(self, *batch: Tensor) -> Tensor:
+        if len(batch) != len(self.batch) or any(b.shape != s.shape for b, s in zip(batch, self.batch)):
+            raise ValueError(f"GraphedStep was captured for batches of shapes {[tuple(s.shape) for s in self.batch]}, "
+                             f"got {[tuple(b.shape) for b in batch]}")
+        for s, b in zip(self.batch, batch):
+            s.copy_(b)
         self.graph.replay()
         self.replays += 1
-        self.opt.steps += 1
-        self.opt.flat.generation += 1  # the replay rewrote the parameters: eager passes must repack their images
+        if self.fused:
+            self.opt.steps += 1
+        self._touch()
         return self.loss
