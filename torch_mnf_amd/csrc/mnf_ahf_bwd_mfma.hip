@@ -78,9 +78,8 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
   const int j = lane & 15, q = lane >> 4;
   const int cond_off = parity ? hh : 0, act_off = parity ? 0 : hh;
   float* scratch = lds + S::IMAGE_FLOATS + wave * S::SCRATCH_TILES * kTileFloats;
-  float* TX = scratch;                             // x0: G tiles
-  float* TH = TX + G * kTileFloats;                // h1, h2, h3: 3 NT tiles
-  float* TD = TH + 3 * NT * kTileFloats;           // deltas of the layer in flight
+  float* TH = scratch;                             // h1, h2, h3: 3 NT tiles
+  float* TD = TH + 3 * NT * kTileFloats;           // deltas of the layer in flight (the output layer's: one net at a time)
 
   f32x4 dW[S::DW_TILES];
   float db[S::DB_TILES];
@@ -137,8 +136,6 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     };
 
     // ------------------------------------------------------------------ forward recompute
-#pragma unroll
-    for (int g = 0; g < G; ++g) tile_to_lds(TX + g * kTileFloats, j, q, cnd[g]);
     f32x4 h[3][NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
@@ -206,8 +203,9 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
       }
     }
 
-    // weight gradients of one layer: out tiles' deltas in TD[0..n_out), in tiles at `tin`; (mo, mi) pairs by `used`
-    auto weight_grads = [&](int n_out, int n_in, const float* tin, auto used) {
+    // weight gradients of one layer: out tiles' deltas in TD[0..n_out), in tile mi with its rows on K from `load_in`;
+    // (mo, mi) pairs by `used`
+    auto weight_grads = [&](int n_out, int n_in, auto load_in, auto used) {
       float aop[S::D_TILES][4], bop[NT > G ? NT : G][4];
 #pragma unroll
       for (int mo = 0; mo < S::D_TILES; ++mo)
@@ -217,7 +215,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
         }
 #pragma unroll
       for (int mi = 0; mi < (NT > G ? NT : G); ++mi)
-        if (mi < n_in) tile_rows_on_k(tin + mi * kTileFloats, j, q, bop[mi]);
+        if (mi < n_in) load_in(mi, bop[mi]);
 #pragma unroll
       for (int mo = 0; mo < S::D_TILES; ++mo)
 #pragma unroll
@@ -235,14 +233,18 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     //  counters are set per layer instead of running)
     constexpr int DW_L1 = 0, DW_H1 = NT * G, DW_H2 = DW_H1 + S::PAIRS, DW_OUT = DW_H2 + S::PAIRS;
     constexpr int DB_L1 = 0, DB_H1 = NT, DB_H2 = 2 * NT, DB_OUT = 3 * NT;
-#pragma unroll
-    for (int net = 0; net < 2; ++net)
-#pragma unroll
-      for (int g = 0; g < G; ++g) tile_to_lds(TD + (net * G + g) * kTileFloats, j, q, d4[net][g]);
+    auto from_lds = [&](const float* tiles) {
+      return [=](int mi, float (&o)[4]) { tile_rows_on_k(tiles + mi * kTileFloats, j, q, o); };
+    };
     dwt = DW_OUT;
     dbt = DB_OUT;
-    weight_grads(2 * G, NT, TH + 2 * NT * kTileFloats,
-                 [](int mo, int mi) { return ((S::tile_nets(mi) >> (mo / G)) & 1) != 0; });
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {  // (one net's deltas in the scratch tiles at a time: s tiles, then t tiles)
+#pragma unroll
+      for (int g = 0; g < G; ++g) tile_to_lds(TD + g * kTileFloats, j, q, d4[net][g]);
+      weight_grads(G, NT, from_lds(TH + 2 * NT * kTileFloats),
+                   [net](int, int mi) { return ((S::tile_nets(mi) >> net) & 1) != 0; });
+    }
     f32x4 dl[NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
@@ -267,7 +269,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
       }
       dwt = l == 2 ? DW_H2 : DW_H1;
       dbt = l == 2 ? DB_H2 : DB_H1;
-      weight_grads(NT, NT, TH + (l - 1) * NT * kTileFloats, [](int mo, int mi) { return S::needs(mo, mi); });
+      weight_grads(NT, NT, from_lds(TH + (l - 1) * NT * kTileFloats), [](int mo, int mi) { return S::needs(mo, mi); });
       f32x4 dn[NT];
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
@@ -291,7 +293,18 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     }
     dwt = DW_L1;
     dbt = DB_L1;
-    weight_grads(NT, G, TX, [](int, int) { return true; });
+    // layer 1's input is x0 itself, rows on K straight from global memory (element [row 4 s + q][dim 16 mi + j]: the
+    // lines this wave read as row float4s a moment ago): no scratch tiles for it
+    weight_grads(NT, G,
+                 [&](int mi, float (&o)[4]) {
+#pragma unroll
+                   for (int s4 = 0; s4 < 4; ++s4) {
+                     const int64_t rk = (int64_t)tile * 16 + 4 * s4 + q;
+                     const int col = 16 * mi + j;
+                     o[s4] = (!RAG || col < hh) ? x[(rk < rows ? rk : rows - 1) * dim + cond_off + col] : 0.f;
+                   }
+                 },
+                 [](int, int) { return true; });
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       f32x4 gx0 = gc[g];

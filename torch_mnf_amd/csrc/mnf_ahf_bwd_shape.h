@@ -43,13 +43,14 @@ struct BwdShape {
   // weight-gradient tiles: layer 1 (NT x G), hidden x 2 (PAIRS each), output (NET_TILES x G)
   static constexpr int DW_TILES = NT * G + 2 * PAIRS + NET_TILES * G;
   static constexpr int DB_TILES = 3 * NT + 2 * G;
-  // LDS scratch tiles per wave: x0 (G), h1..h3 (3 NT), deltas (max(NT, 2 G))
-  static constexpr int D_TILES = NT > 2 * G ? NT : 2 * G;
-  static constexpr int SCRATCH_TILES = G + 3 * NT + D_TILES;
+  // LDS scratch tiles per wave (fp32 kernel): h1..h3 (3 NT), deltas of the layer in flight (max(NT, G): the output
+  // layer's go through one net at a time; layer 1's input x0 is read back from global memory, rows on K)
+  static constexpr int D_TILES = NT > G ? NT : G;
+  static constexpr int SCRATCH_TILES = 3 * NT + D_TILES;
   // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
   static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
   // fp32 kernel: as many waves (<= kBwdWaves) as find room for their scratch tiles beside the operand images in the
-  // CU's 160 KB of LDS (d <= 64 with 24 hidden units: 4; d = 128: 2; 32 hidden units at d = 64: 3)
+  // CU's 160 KB of LDS (4 everywhere today: d = 128 keeps 152 KB busy)
   static constexpr int waves_that_fit() {
     int w = kBwdWaves;
     while (w > 1 && (IMAGE_FLOATS + w * SCRATCH_TILES * kTileFloats) * 4 > 160 * 1024) --w;
