@@ -125,7 +125,8 @@ def test_affine_half_fp32_mfma_gradient_kernel_d128(amd, O, parity, inverse):
 
 
 @pytest.mark.parametrize("dim,hid", [(2, 24), (6, 24), (30, 16), (40, 24), (100, 24), (64, (20, 7, 24)), (2, (5, 16, 9)),
-                                     (128, (16, 16, 16)), (32, (1, 1, 1)), (64, 32), (32, (32, 17, 25)), (2, 32)])
+                                     (128, (16, 16, 16)), (32, (1, 1, 1)), (64, 32), (32, (32, 17, 25)), (2, 32),
+                                     (256, 24), (200, (24, 9, 16))])
 @pytest.mark.parametrize("parity", [False, True])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_affine_half_fp32_mfma_gradient_kernel_padded_halves(amd, O, dim, hid, parity, inverse):

@@ -14,7 +14,7 @@
 // end the four waves of a workgroup add them up in LDS and issue one atomic add per parameter.
 // Operand images (forward and transposed weights, 57 KB at d = 64) are gathered from `flat` into LDS by every
 // workgroup through an index table the caller builds once per shape (mnf_affine_half_bwd_index).
-// Tile halves of 16, 32 and 64 columns (d = 128: 86 KB of images, two waves per workgroup); a coupling half narrower
+// Tile halves of 16, 32, 64 and 128 columns (d = 256: 143 KB of images, ONE wave per workgroup); a coupling half narrower
 // than its tile is padded (RAG: zero operands, masked row accesses) -- d = 2, the reference's half-moons model, runs here.
 #include <hip/hip_runtime.h>
 
@@ -239,11 +239,15 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     dwt = DW_OUT;
     dbt = DB_OUT;
 #pragma unroll
-    for (int net = 0; net < 2; ++net) {  // (one net's deltas in the scratch tiles at a time: s tiles, then t tiles)
+    for (int net = 0; net < 2; ++net) {  // (one net's deltas in the scratch tiles at a time: s tiles, then t tiles,
+      constexpr int DC = G < S::D_TILES ? G : S::D_TILES;  //  at most D_TILES of them per trip)
 #pragma unroll
-      for (int g = 0; g < G; ++g) tile_to_lds(TD + g * kTileFloats, j, q, d4[net][g]);
-      weight_grads(G, NT, from_lds(TH + 2 * NT * kTileFloats),
-                   [net](int, int mi) { return ((S::tile_nets(mi) >> net) & 1) != 0; });
+      for (int g0 = 0; g0 < G; g0 += DC) {
+#pragma unroll
+        for (int g = 0; g < DC; ++g) tile_to_lds(TD + g * kTileFloats, j, q, d4[net][g0 + g]);
+        weight_grads(DC, NT, from_lds(TH + 2 * NT * kTileFloats),
+                     [net](int, int mi) { return ((S::tile_nets(mi) >> net) & 1) != 0; });
+      }
     }
     f32x4 dl[NT];
 #pragma unroll
@@ -500,8 +504,8 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
         if (16 * g + i < rh) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
-// shapes: 16, 24 or 32 hidden-unit slots at tile halves 16, 32 (d <= 64; narrower halves and layers padded), 24 at 64
-#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(16, 32) X(32, 32)
+// shapes: 16, 24 or 32 hidden-unit slots at tile halves 16, 32 (d <= 64; narrower halves and layers padded), 24 at 64, 128
+#define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(16, 32) X(32, 32) X(128, 24)
 
 template <int H, int HID, bool RAG>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
@@ -537,7 +541,7 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
 static int bwd_padded_half(int dim) {
   if (dim < 2 || (dim & 1)) return 0;
   const int h = dim / 2;
-  return h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : 0;
+  return h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : h <= 128 ? 128 : 0;
 }
 
 // the hidden width the kernel runs three hidden layers of widths hidden[0..2] at: 16, 24 or 32, whichever holds the widest
@@ -559,7 +563,7 @@ int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden,
   if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
     return 0;
   const int ph = mnf::bwd_padded_half(dim);
-  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
+  if (ph >= 64) hid = hid <= 24 ? 24 : 0;  // (the 64- and 128-column tiles exist with 24 hidden units only)
 #define X(HH, HD) \
   if (ph == HH && hid == HD) return mnf::BwdShape<HH, HD>::INDEX_INTS;
   MNF_AHF_BWD_SHAPES(X)
@@ -573,7 +577,7 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int ph = mnf::bwd_padded_half(dim);
-  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
+  if (ph >= 64) hid = hid <= 24 ? 24 : 0;  // (the 64- and 128-column tiles exist with 24 hidden units only)
 #define X(HH, HD)                                       \
   if (ph == HH && hid == HD) {                          \
     mnf::build_bwd_index<HH, HD>(idx_host, dim / 2, hidden);    \
@@ -602,7 +606,7 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
   if (rows == 0) return MNF_OK;
   if (!mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int ph = mnf::bwd_padded_half(dim);
-  if (ph == 64) hid = hid <= 24 ? 24 : 0;  // (the 64-column tile exists with 24 hidden units only)
+  if (ph >= 64) hid = hid <= 24 ? 24 : 0;  // (the 64- and 128-column tiles exist with 24 hidden units only)
   const bool ragged = ph != dim / 2;  // (element-wise row accesses: no alignment condition)
   if (!ragged &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15))

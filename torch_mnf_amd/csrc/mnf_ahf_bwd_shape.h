@@ -45,7 +45,7 @@ struct BwdShape {
   static constexpr int DB_TILES = 3 * NT + 2 * G;
   // LDS scratch tiles per wave (fp32 kernel): h1..h3 (3 NT), deltas of the layer in flight (max(NT, G): the output
   // layer's go through one net at a time; layer 1's input x0 is read back from global memory, rows on K)
-  static constexpr int D_TILES = NT > G ? NT : G;
+  static constexpr int D_TILES = NT > G ? NT : (G > 4 ? 4 : G);  // (at most 4 output-delta tiles at a time)
   static constexpr int SCRATCH_TILES = 3 * NT + D_TILES;
   // index table: image gather, then dW flush ([tile][lane][reg]), then db flush ([tile][unit])
   static constexpr int INDEX_INTS = IMAGE_FLOATS + DW_TILES * 256 + DB_TILES * 16;
