@@ -14,7 +14,8 @@
 // end the four waves of a workgroup add them up in LDS and issue one atomic add per parameter.
 // Operand images (forward and transposed weights, 57 KB at d = 64) are gathered from `flat` into LDS by every
 // workgroup through an index table the caller builds once per shape (mnf_affine_half_bwd_index).
-// Tile halves of 16, 32, 64 and 128 columns (d = 256: 143 KB of images, ONE wave per workgroup); a coupling half narrower
+// Tile halves of 16, 32, 64 and 128 columns (d = 256: the layer-1 / output-layer weights once in the image, read
+// transposed by the backward products -- BwdShape::SHARED_T); a coupling half narrower
 // than its tile is padded (RAG: zero operands, masked row accesses) -- d = 2, the reference's half-moons model, runs here.
 #include <hip/hip_runtime.h>
 
@@ -123,16 +124,29 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     }
     const float gl = (grad_ld && live) ? grad_ld[rowc] : 0.f;
 
+    // SHARED_T: the layer-1 / output-layer blocks are stored with lane (i, kq) in slot 16 kq + 4 (i >> 2) + ((i + kq) & 3);
+    // element (row 4 kq + r, column i) of such a block -- the transposed operand -- is then at t_off[r]
     int a_off = lane * 4, b_off = S::A_FLOATS + q * 4;
-    asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop
+    int p_off = S::SHARED_T ? (16 * q + 4 * (j >> 2) + ((j + q) & 3)) * 4 : lane * 4;
+    int t_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t_off[r] = 64 * (j >> 2) + 16 * q + 4 * ((r + (j >> 2)) & 3) + (j & 3);
+    asm volatile("" : "+v"(a_off), "+v"(b_off), "+v"(p_off), "+v"(t_off[0]), "+v"(t_off[1]), "+v"(t_off[2]),
+                 "+v"(t_off[3]));  // keep the operand reads inside the tile loop
     const f32x4* A4 = reinterpret_cast<const f32x4*>(lds + a_off);
+    const f32x4* P4 = reinterpret_cast<const f32x4*>(lds + p_off);
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + b_off);
     int n = 0, bt = 0, dwt = 0, dbt = 0;
     f32x4 a4;
-    auto mfma = [&](float b, f32x4& acc) {
-      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+    auto mfma_from = [&](const f32x4* base, float b, f32x4& acc) {
+      if ((n & 3) == 0) a4 = base[64 * (n >> 2)];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], b, acc, 0, 0, 0);
       ++n;
+    };
+    auto mfma = [&](float b, f32x4& acc) { mfma_from(A4, b, acc); };
+    auto mfma_w = [&](float b, f32x4& acc) { mfma_from(P4, b, acc); };  // layer-1 / output-layer weights
+    auto mfma_t = [&](int group, int r, float b, f32x4& acc) {          // ... read transposed (no image order)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[group * 256 + t_off[r]], b, acc, 0, 0, 0);
     };
 
     // ------------------------------------------------------------------ forward recompute
@@ -143,7 +157,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mfma(cnd[g][r], h[0][m]);
+        for (int r = 0; r < 4; ++r) mfma_w(cnd[g][r], h[0][m]);
     }
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
@@ -175,7 +189,7 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
         for (int mt = 0; mt < NT; ++mt)
           if ((S::tile_nets(mt) >> net) & 1)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mfma(h[2][mt][r], st[net][g]);
+            for (int r = 0; r < 4; ++r) mfma_w(h[2][mt][r], st[net][g]);
       }
 
     // ------------------------------------------------------------------ output deltas, grad of the transformed half
@@ -259,7 +273,12 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 #pragma unroll
           for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mfma(d4[net][g][r], dl[m]);
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (S::SHARED_T)
+                mfma_t(S::F4_GROUP0 + S::f4_rank(net, g, m), r, d4[net][g][r], dl[m]);
+              else
+                mfma(d4[net][g][r], dl[m]);
+            }
     }
     // ------------------------------------------------------------------ hidden layers 3 and 2
 #pragma unroll
@@ -315,7 +334,12 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mfma(dl[mt][r], gx0);
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (S::SHARED_T)
+            mfma_t(mt * G + g, r, dl[mt][r], gx0);
+          else
+            mfma(dl[mt][r], gx0);
+        }
       if constexpr (RAG) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -387,13 +411,20 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
   auto valid = [&](int u, int layer) { return u < 2 * HID && u % HID < hs[layer]; };
   int n = 0;
   auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
+  // layer-1 / output-layer blocks: with SHARED_T lane (i, kq) sits in slot 16 kq + 4 (i >> 2) + ((i + kq) & 3), which
+  // keeps the forward float4 reads and the transposed single-float reads of the backward products conflict free
+  auto put_perm = [&](int lane, int32_t src) {
+    const int i = lane & 15, kq = lane >> 4;
+    put(S::SHARED_T ? 16 * kq + 4 * (i >> 2) + ((i + kq) & 3) : lane, src);
+  };
   // forward operands: A[i][kq] = W[out unit of row i][input behind K slot kq of step r]
   for (int m = 0; m < NT; ++m)
     for (int g = 0; g < G; ++g)
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
-          if (valid(u, 0) && 16 * g + 4 * kq + r < rh) put(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + 4 * kq + r);
+          if (valid(u, 0) && 16 * g + 4 * kq + r < rh)
+            put_perm(lane, net[netof(u)].w_off[0] + (u % HID) * rh + 16 * g + 4 * kq + r);
         }
   for (int l = 1; l <= 2; ++l)
     for (int m = 0; m < NT; ++m)
@@ -413,13 +444,14 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kq = lane >> 4, ui = 16 * mt + 4 * kq + r;
-            if (valid(ui, 2) && netof(ui) == nn && 16 * g + i < rh) put(lane, net[nn].w_off[3] + (16 * g + i) * hs[2] + ui % HID);
+            if (valid(ui, 2) && netof(ui) == nn && 16 * g + i < rh)
+              put_perm(lane, net[nn].w_off[3] + (16 * g + i) * hs[2] + ui % HID);
           }
       }
-  // transposed operands
+  // transposed operands (the layer-1 and output-layer ones only without SHARED_T)
   for (int m = 0; m < NT; ++m)  // delta3[unit 16 m + i] += W4[dim 16 g + 4 kq + r][unit] delta4[dim]
     for (int nn = 0; nn < 2; ++nn) {
-      if (!((S::tile_nets(m) >> nn) & 1)) continue;
+      if (S::SHARED_T || !((S::tile_nets(m) >> nn) & 1)) continue;
       for (int g = 0; g < G; ++g)
         for (int r = 0; r < 4; ++r, ++n)
           for (int lane = 0; lane < 64; ++lane) {
@@ -439,7 +471,7 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
               put(lane, net[netof(uo)].w_off[l] + (uo % HID) * hs[l - 1] + ui % HID);
           }
       }
-  for (int g = 0; g < G; ++g)  // grad x0[dim 16 g + i] += W1[unit 16 mt + 4 kq + r][dim] delta1[unit]
+  for (int g = 0; g < (S::SHARED_T ? 0 : G); ++g)  // grad x0[dim 16 g + i] += W1[unit 16 mt + 4 kq + r][dim] delta1[unit]
     for (int mt = 0; mt < NT; ++mt)
       for (int r = 0; r < 4; ++r, ++n)
         for (int lane = 0; lane < 64; ++lane) {

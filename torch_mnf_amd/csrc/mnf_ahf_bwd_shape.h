@@ -33,9 +33,23 @@ struct BwdShape {
     return n;
   }
   static constexpr int PAIRS = pairs(), NET_TILES = net_tiles();
+  // fp32 kernel at d = 256: the layer-1 and output-layer weights sit in the image ONCE; the backward products read
+  // the forward blocks transposed (their lane slots are permuted so that both reads are bank-conflict free)
+  static constexpr bool SHARED_T = H >= 128;
   // MFMA operand counts (one op = 64 floats), in image order
   static constexpr int N_F1 = NT * G * 4, N_FH = PAIRS * 4, N_F4 = NET_TILES * G * 4;
-  static constexpr int N_B4 = NET_TILES * G * 4, N_BH = PAIRS * 4, N_B1 = G * NT * 4;
+  static constexpr int N_B4 = SHARED_T ? 0 : NET_TILES * G * 4, N_BH = PAIRS * 4, N_B1 = SHARED_T ? 0 : G * NT * 4;
+  static constexpr int F4_GROUP0 = (N_F1 + 2 * N_FH) / 4;  // first 4-op group of the output-layer block
+  static constexpr int f4_rank(int nn, int g, int mt) {    // position of block (net, dim group, hidden tile) in it
+    int n = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < G; ++b)
+        for (int c = 0; c < NT; ++c) {
+          if (a == nn && b == g && c == mt) return n;
+          if ((tile_nets(c) >> a) & 1) ++n;
+        }
+    return -1;
+  }
   static constexpr int N_OPS = N_F1 + 2 * N_FH + N_F4 + N_B4 + 2 * N_BH + N_B1;
   static constexpr int A_FLOATS = ((N_OPS + 3) / 4) * 256;
   static constexpr int BIAS_TILES = 3 * NT + 2 * G;
