@@ -253,7 +253,7 @@ def test_nsf_split_index_covers_every_parameter(lib, dim, K, nh):
     assert len(used) == n_params and len(np.unique(used)) == n_params
 
 
-@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (32, 16), (64, 16)])
+@pytest.mark.parametrize("dim,hid", [(32, 24), (64, 24), (32, 16), (64, 16), (128, 24), (256, 24), (64, 32)])
 def test_affine_half_gradient_index_tables(lib, dim, hid):
     """The MFMA gradient kernel's tables: the operand gather stays inside the flat vector and uses every
     parameter; the flush table sends exactly one accumulator element to every parameter."""
@@ -263,7 +263,7 @@ def test_affine_half_gradient_index_tables(lib, dim, hid):
     sd = recipes.affine_half_params(0, dim, h_sizes=(hid,) * 3)
     n_params = sum(v.numel() for v in sd.values())
     n = lib.mnf_affine_half_bwd_index_ints(dim, 3, hid3, 1, 1)
-    assert n > 0 and lib.mnf_affine_half_bwd_index_ints(256, 3, hid3, 1, 1) == 0
+    assert n > 0 and lib.mnf_affine_half_bwd_index_ints(258, 3, hid3, 1, 1) == 0  # (halves beyond 128 columns: none)
     idx = (ctypes.c_int32 * n)()
     assert lib.mnf_affine_half_bwd_index(dim, 3, hid3, 1, 1, idx) == 0
     a = np.frombuffer(idx, dtype=np.int32)
