@@ -38,7 +38,7 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 # ... and below this many rows anyway: the split kernel needs three small launches more per backward pass (gradient
 # scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
 # 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
-_BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "32768"))
+_BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 # MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
