@@ -801,3 +801,31 @@ def test_graphed_training_step_of_an_mnf_model(amd):
     with torch.no_grad():
         acc = float((net(x).argmax(1) == y).float().mean())
     assert acc > 0.5, acc  # (chance is 0.1; the eager pass repacked its operands from the replayed parameters)
+
+
+def test_graphed_training_step_of_the_spline_block_model(amd):
+    """ActNorm + Glow + NSF_CL blocks (config 3's model) captured in a hipGraph: Glow's permutation is copied to the
+    device once (not per call) and its inverse has no host-side check, so the whole step records; the replayed
+    losses follow the eager loop's."""
+    import bench
+
+    def build():
+        model, _ = bench.build_c3(torch.device("cuda", 0))
+        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+    batches = [recipes.gaussian(950 + i, 512, 32).to("cuda") for i in range(13)]
+    model_e, opt_e = build()
+    losses_e = []
+    for x in [batches[0]] * 3 + batches[1:]:
+        opt_e.zero_grad()
+        loss = -model_e.log_prob(x).mean()
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss.detach()))
+    del loss
+    model_g, opt_g = build()
+    step = amd.GraphedStep(opt_g, lambda x: -model_g.log_prob(x).mean(), batches[0], model=model_g)
+    losses_g = [float(step(x)) for x in batches[1:]]
+    for a, b in zip(losses_e[3:], losses_g):
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(a)), (a, b)
+    assert losses_g[-1] < losses_g[0]

@@ -1063,11 +1063,20 @@ class Glow(_TwoWayFlow):
         self._w_img: dict = {}                # inverse? -> MFMA operand image of W / W^-1
         self._w_index: Tensor | None = None
 
+    def _P_on(self, device) -> Tensor:
+        """``P`` on ``device`` (P is a plain attribute -- it does not follow ``.to()`` -- so it may live on the host:
+        the copy is made once per (P, device), not per call, and never under a hipGraph capture)."""
+        cached = self.__dict__.get("_P_dev")
+        if cached is None or cached[0] is not self.P or cached[1].device != device:
+            cached = (self.P, self.P.to(device))
+            self.__dict__["_P_dev"] = cached
+        return cached[1]
+
     def _assemble_W(self, device=None) -> Tensor:
         device = self.L.device if device is None else device
         L = torch.tril(self.L.detach(), diagonal=-1) + torch.eye(self.dim, device=self.L.device)
         U = torch.triu(self.U.detach(), diagonal=1)
-        W = self.P.to(self.L.device) @ L @ (U + self.S.detach().diag())
+        W = self._P_on(self.L.device) @ L @ (U + self.S.detach().diag())
         return W.to(device=device, dtype=torch.float32).contiguous()
 
     def _weights(self, device, inverse: bool) -> Tensor:
@@ -1107,11 +1116,13 @@ class Glow(_TwoWayFlow):
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
             xg = _grad_input(x)
             eye = torch.eye(self.dim, device=self.L.device)
-            W = self.P.to(self.L.device) @ (torch.tril(self.L, diagonal=-1) + eye) @ (
+            W = self._P_on(self.L.device) @ (torch.tril(self.L, diagonal=-1) + eye) @ (
                 torch.triu(self.U, diagonal=1) + self.S.diag())  # glow.py:20-24, differentiable
             ld = self.S.abs().log().sum()
             if inverse:
-                return _LinearRowsFn.apply(xg, torch.inverse(W).to(xg.device)), -ld.to(xg.device)
+                # (inv_ex: torch.inverse's singularity check is a host synchronisation, which a hipGraph capture of the
+                #  training step cannot record; a singular W shows up as inf/nan in the loss either way)
+                return _LinearRowsFn.apply(xg, torch.linalg.inv_ex(W).inverse.to(xg.device)), -ld.to(xg.device)
             return _LinearRowsFn.apply(xg, W.to(xg.device)), ld.to(xg.device)
         x = _device_input(x, "input")
         if x.shape[1] != self.dim:

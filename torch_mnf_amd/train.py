@@ -144,9 +144,9 @@ class GraphedStep:
     inside the graph).  Everything the step decides on the host is frozen at capture time: batch shapes, kernel
     choices, host-drawn random numbers.  RNVP layers therefore draw their masks on the device while the step is
     warmed up and recorded (``flows.device_drawn_masks``: torch.bernoulli, the reference's own draw, redrawn by every
-    replay like torch.randn is) instead of hashing a host-drawn seed in the kernel.  Glow cannot be captured (its
-    weight assembly goes through torch.linalg calls that synchronise with the host): the constructor says so.
-    If eager steps ran before, drop their loss tensors first (``del loss``): a live loss keeps that step's autograd
+    replay like torch.randn is) instead of hashing a host-drawn seed in the kernel.  Glow captures too: its
+    permutation sits on the device once, and its training-path inverse is torch.linalg.inv_ex (no host-side
+    singularity check).  If eager steps ran before, drop their loss tensors first (``del loss``): a live loss keeps that step's autograd
     graph, and with it gradient-accumulation nodes bound to the default stream, alive into the capture."""
 
     def __init__(self, opt, loss_fn, example, warmup: int = 3, model: nn.Module | None = None) -> None:
@@ -195,9 +195,9 @@ class GraphedStep:
                 self.loss = run().detach()
         except RuntimeError as err:  # (torch.AcceleratorError is a RuntimeError)
             raise RuntimeError(
-                "GraphedStep: the step contains an operation that cannot be recorded in a hipGraph (one that "
-                "synchronises with the host -- e.g. Glow's LU-factor assembly and matrix inverse through "
-                "torch.linalg)") from err
+                "GraphedStep: the step contains an operation that cannot be recorded in a hipGraph (a host "
+                "synchronisation, a host-to-device copy of pageable memory, a .item()); the chained exception "
+                "names the call") from err
         if fused:
             opt.steps -= 1           # (capture records the step, it does not run it)
         self._touch()                # operand images "packed" under capture were only recorded: eager code repacks
