@@ -314,7 +314,8 @@ int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_l
                         void* stream);
 /* The same gradients at matrix-pipe rate (fp32 MFMAs; three hidden layers of any widths <= 32 at even d <= 64, of any
  * widths <= 24 at even d <= 256: halves narrower than the kernel's 16/32/64/128-column tile and layers narrower than its
- * 16/24/32 unit slots are padded with structural zeros -- d = 2 runs here; scale and shift nets both present).  index_dev: device copy of the mnf_affine_half_bwd_index table
+ * 16/24/32 unit slots are padded with structural zeros -- d = 2 runs here; a NICE-style layer with only one of the two
+ * nets runs with the other as structural zeros too).  index_dev: device copy of the mnf_affine_half_bwd_index table
  * (mnf_affine_half_bwd_index_ints() int32s, built once per shape; 0 = no such kernel).  Same contract as
  * mnf_affine_half_bwd: grad_x is written, grad_flat is ADDED to; MNF_ERR_UNSUPPORTED otherwise. */
 int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden_host, int has_scale, int has_shift);

@@ -30,7 +30,7 @@ def leaf(sd):
 
 
 @pytest.mark.parametrize("dim,kw", [(64, {}), (10, dict(h_sizes=(16, 40))), (2, {}), (10, dict(scale=False)),
-                                    (10, dict(shift=False))])
+                                    (10, dict(shift=False)), (64, dict(scale=False)), (256, dict(shift=False))])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_affine_half_gradients(amd, O, dim, kw, inverse):
     sd = recipes.affine_half_params(31 + dim, dim, s_last_gain=2.0, **kw)

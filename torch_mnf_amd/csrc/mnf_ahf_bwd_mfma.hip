@@ -397,18 +397,22 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
 // ---------------------------------------------------------------- host: index table
 // rh: the real half width (<= H; columns rh .. H-1 of the tile are padding: -1 = zero operand, no flush);
 // hs: the three real hidden widths (<= HID each; the unit slots above them are structural zeros the same way)
+// has_s / has_t: a NICE-style layer has only one of the two nets (affine_half_flow.py:38: the other is the zero
+// function): the absent net's operands, biases and flush entries all stay -1, so it computes s = 0 (or t = 0) and
+// receives no gradient
 template <int H, int HID>
-static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
+static void build_bwd_index(int32_t* idx, int rh, const int* hs, bool has_s, bool has_t) {
   using S = BwdShape<H, HID>;
   constexpr int G = S::G, NT = S::NT;
   int sizes[5] = {rh, hs[0], hs[1], hs[2], rh};
   NetDesc net[2];
-  int64_t off = fill_net(net[0], 5, sizes, 0);
-  fill_net(net[1], 5, sizes, off);
+  const int64_t off = fill_net(net[0], 5, sizes, 0);
+  fill_net(net[1], 5, sizes, has_s ? off : 0);  // flat = [s_net if present][t_net if present]
+  const bool present[2] = {has_s, has_t};
   for (int i = 0; i < S::INDEX_INTS; ++i) idx[i] = -1;
   auto netof = [&](int u) { return u / HID; };
   // slot u of the concatenated net is a real unit of hidden layer `layer` (0, 1, 2)
-  auto valid = [&](int u, int layer) { return u < 2 * HID && u % HID < hs[layer]; };
+  auto valid = [&](int u, int layer) { return u < 2 * HID && u % HID < hs[layer] && present[u / HID]; };
   int n = 0;
   auto put = [&](int lane, int32_t src) { idx[(n >> 2) * 256 + lane * 4 + (n & 3)] = src; };
   // layer-1 / output-layer blocks: with SHARED_T lane (i, kq) sits in slot 16 kq + 4 (i >> 2) + ((i + kq) & 3), which
@@ -488,7 +492,7 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++bt)
       for (int i = 0; i < 16; ++i)
-        if (16 * g + i < rh) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+        if (16 * g + i < rh && present[nn]) b[bt * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 
   // flush tables.  dW tile (mo, mi): lane (j = in index b, q), reg r <-> out index a = 4 q + r
   int32_t* fw = idx + S::IMAGE_FLOATS;
@@ -533,7 +537,7 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs) {
   for (int nn = 0; nn < 2; ++nn)
     for (int g = 0; g < G; ++g, ++t)
       for (int i = 0; i < 16; ++i)
-        if (16 * g + i < rh) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
+        if (16 * g + i < rh && present[nn]) fb[t * 16 + i] = net[nn].b_off[3] + 16 * g + i;
 }
 
 // shapes: 16, 24 or 32 hidden-unit slots at tile halves 16, 32 (d <= 64; narrower halves and layers padded), 24 at 64, 128
@@ -592,7 +596,7 @@ extern "C" {
 
 int64_t mnf_affine_half_bwd_index_ints(int dim, int n_hidden, const int* hidden, int has_scale, int has_shift) {
   int hid = 0;
-  if (!has_scale || !has_shift || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
+  if ((!has_scale && !has_shift) || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
     return 0;
   const int ph = mnf::bwd_padded_half(dim);
   if (ph >= 64) hid = hid <= 24 ? 24 : 0;  // (the 64- and 128-column tiles exist with 24 hidden units only)
@@ -607,12 +611,12 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden, int has_
                               int32_t* idx_host) {
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
-  if (!has_scale || !has_shift || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((!has_scale && !has_shift) || !mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
   const int ph = mnf::bwd_padded_half(dim);
   if (ph >= 64) hid = hid <= 24 ? 24 : 0;  // (the 64- and 128-column tiles exist with 24 hidden units only)
 #define X(HH, HD)                                       \
   if (ph == HH && hid == HD) {                          \
-    mnf::build_bwd_index<HH, HD>(idx_host, dim / 2, hidden);    \
+    mnf::build_bwd_index<HH, HD>(idx_host, dim / 2, hidden, has_scale != 0, has_shift != 0);    \
     return MNF_OK;                                      \
   }
   MNF_AHF_BWD_SHAPES(X)
