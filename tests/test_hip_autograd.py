@@ -1,5 +1,6 @@
 """Gradients of the HIP Flow modules against torch.autograd through the CPU
 oracle, and the reference's own training contracts (tests/test_flows.py:14-31,53-55,76-86)."""
+import numpy as np
 import pytest
 import torch
 
@@ -361,6 +362,27 @@ def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse, nsf_rows_kernel):
         assert_close(got[name], p[name].grad, 1e-4, f"grad {name}")
     for k in got:
         assert_close(got[k], ref[k], 1e-4, f"rows vs generic {k}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nsf_cl_row_gradient_kernel_seeded_fuzz(amd, O, seed, nsf_rows_kernel):
+    """Random row counts (1 ... 300: partial tiles, fewer tiles than waves), K, hidden widths, directions and input
+    scales against autograd through the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    K, n_h = int(rng.choice([5, 8])), int(rng.integers(1, 9))
+    rows, inverse, scale = int(rng.integers(1, 301)), bool(rng.integers(0, 2)), float(rng.choice([0.3, 1.0, 2.5]))
+    sd = recipes.nsf_cl_params(7100 + seed, 32, K, n_h)
+    x_cpu = recipes.gaussian(7200 + seed, rows, 32, scale=scale).requires_grad_(True)
+    w_y = recipes.gaussian(7300 + seed, rows, 32)
+    w_l = recipes.gaussian(7400 + seed, rows, 1)[:, 0]
+    p = leaf(sd)
+    y, ld = O.nsf_cl(x_cpu, p, K, 3.0, inverse)
+    ((y * w_y).sum() + (ld * w_l).sum()).backward()
+    got = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
+    what = f"seed {seed}: K={K} n_h={n_h} rows={rows} inverse={inverse} scale={scale}"
+    assert_close(got["x"], x_cpu.grad, 1e-4, f"grad_x ({what})")
+    for name in p:
+        assert_close(got[name], p[name].grad, 1e-4, f"grad {name} ({what})")
 
 
 @pytest.mark.parametrize("inverse", [False, True])
