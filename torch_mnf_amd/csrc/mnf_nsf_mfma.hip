@@ -172,7 +172,10 @@ __device__ __forceinline__ void rqs_regs(float v, float T, const float (&p)[NP],
   lad = inside ? l : 0.f;
 }
 
-constexpr int kNsfWaves = 4;
+#ifndef MNF_NSF_WAVES
+#define MNF_NSF_WAVES 4  // waves per workgroup (experiment switch, with MNF_NSF_WPE = waves per SIMD for the register cap)
+#endif
+constexpr int kNsfWaves = MNF_NSF_WAVES;
 
 // One half-step: params = net(cond); act <- spline(act; params); returns this lane's sum of
 // log-derivatives over its S elements.
@@ -456,7 +459,11 @@ __device__ __forceinline__ void affine_rows(const float* aff, int lane, int q, f
 // SPLIT: the conditioner on f16 MFMAs in split arithmetic (`simage`), with `image` (fp32, read from global
 // memory) behind it for tiles whose operands leave the f16 range.
 template <int H, int NH, int K, bool INV, int AFF = 0, bool SPLIT = false>
+#ifdef MNF_NSF_WPE
+__global__ void __launch_bounds__(kNsfWaves * 64, MNF_NSF_WPE)
+#else
 __global__ void __launch_bounds__(kNsfWaves * 64)
+#endif
 nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ log_det,
                 const float* __restrict__ image, const uint32_t* __restrict__ simage, int64_t rows, float T,
                 int accumulate,
