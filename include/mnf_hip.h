@@ -338,7 +338,8 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
  *                   to be repacked after a weight update
  *   index_dev       the mnf_affine_half_bwd_index table (flush order of the weight-gradient tiles)
  *   grad_scale_dev  device float, a power of two that brings the incoming gradients near 1 (they are ~1/rows for a
- *                   mean loss, below f16's normal range): mnf_affine_half_grad_scale writes one from a sample
+ *                   mean loss, below f16's normal range): mnf_affine_half_grad_scale writes one from a sample of up
+ *                   to 512 rows spread evenly over the batch (row s * (rows / 512))
  *   cold_list       device int32 [1 + cold_capacity], cold_list[0] zeroed by the caller: 16-row tiles with an
  *                   operand outside the split range are appended and NOT accumulated (cold_list[0] = -1: all of
  *                   them -- weights beyond the split range, nothing was computed); the caller then runs

@@ -34,21 +34,48 @@ def assert_close(a, b, rtol: float = RTOL, what: str = ""):
     return err
 
 
-def assert_parity(got, ref32, ref64=None, what: str = "", rtol: float = RTOL):
+# every assert_parity call leaves a record here (what, err, budget, widening): the audit trail of how much of each
+# budget was used and how much of it was float64 head-room (tests/test_hip_parity.py::test_parity_budget_audit prints it)
+PARITY_LOG: list[dict] = []
+# widening a NON-stress fixture may claim: beyond this the float64 head-room is hiding something (the G4 edge cases
+# and the x2-weight stress fixtures pass max_widening=None and say why)
+MAX_WIDENING = 5e-5
+
+
+def assert_parity(got, ref32, ref64=None, what: str = "", rtol: float = RTOL, max_widening: float | None = MAX_WIDENING):
     """The parity rule.  max|got - ref32| <= rtol * max|ref32| (BASELINE.json: 1e-5 rel fp32,
     normwise).  Where the fixture also carries the reference's own float64 run, the budget is
     widened by twice the reference's fp32-vs-fp64 distance on the same inputs: on
     ill-conditioned inputs (spline knots a few ulps from the sample, stress-gain weights) two
     correct fp32 evaluations differ by about that much, and 1e-5 alone is below the
-    reference's own rounding noise (measured: up to 1.5e-4 on the G4 edge cases)."""
+    reference's own rounding noise (measured: up to 1.5e-4 on the G4 edge cases).
+
+    The widening is capped: above ``max_widening`` (5e-5) the call fails unless the caller passes
+    ``max_widening=None`` -- the stress fixtures, which are built to sit on knots.  Every call is recorded in
+    ``PARITY_LOG`` with the share of the budget that was float64 head-room, and returns the error."""
     if isinstance(got, torch.Tensor):
         got = got.detach().cpu().numpy()
-    budget = rtol
+    widening = 0.0
     if ref64 is not None:
-        budget += 2.0 * normwise_err(np.asarray(ref32), np.asarray(ref64))
+        widening = 2.0 * normwise_err(np.asarray(ref32), np.asarray(ref64))
+    budget = rtol + widening
     err = normwise_err(got, np.asarray(ref32))
-    assert err <= budget, f"{what}: normwise error {err:.3e} > budget {budget:.3e}"
+    PARITY_LOG.append({"what": what, "err": err, "budget": budget, "widening": widening,
+                       "widening_share": widening / budget, "used": err / budget})
+    if max_widening is not None:
+        assert widening <= max_widening, (f"{what}: the float64 head-room {widening:.3e} exceeds {max_widening:.1e} "
+                                          f"on a fixture that is not a stress case (err {err:.3e})")
+    assert err <= budget, (f"{what}: normwise error {err:.3e} > budget {budget:.3e} "
+                           f"(= {rtol:.1e} + float64 head-room {widening:.3e})")
     return err
+
+
+def parity_report() -> str:
+    """One line per recorded assert_parity call that used float64 head-room, worst first."""
+    rows = sorted((r for r in PARITY_LOG if r["widening"] > 0), key=lambda r: -r["widening"])
+    return "\n".join(f"{r['what']:48s} err {r['err']:.2e}  budget {r['budget']:.2e}  of which fp64 head-room "
+                     f"{r['widening']:.2e} ({100 * r['widening_share']:.0f} %)  used {100 * r['used']:.0f} %"
+                     for r in rows)
 
 
 def t(a) -> torch.Tensor:

@@ -294,6 +294,7 @@ def test_seeded_fuzz_slice_against_float64(amd, O, seed):
     rng = np.random.default_rng(1000 + seed)
     torch.manual_seed(seed)
     worst = 0.0
+    nsf_widest = 0.0  # largest float64 head-room a spline draw claimed (printed; capped at 5e-5 per draw)
     for case in range(150):
         u = rng.random()
         if u < 0.2:
@@ -313,9 +314,12 @@ def test_seeded_fuzz_slice_against_float64(amd, O, seed):
             # the spline's bin search is discontinuous in rounding: an element a few ulps from a knot lands in the
             # neighbouring bin in one fp32 evaluation and not in another.  Budget as in helpers.assert_parity: 1e-5 +
             # twice the fp32 oracle's own distance from float64 on this draw.
-            budget_y = RTOL + 2 * normwise_err(y32.numpy(), y64.numpy())
-            budget_ld = RTOL + 2 * normwise_err(ld32.numpy(), ld64.numpy())
+            wid_y, wid_ld = 2 * normwise_err(y32.numpy(), y64.numpy()), 2 * normwise_err(ld32.numpy(), ld64.numpy())
+            # (tame nn.Linear-scale weights: the head-room itself may not exceed 5e-5, helpers.MAX_WIDENING)
+            assert max(wid_y, wid_ld) <= 5e-5, (case, "nsf head-room", wid_y, wid_ld)
+            budget_y, budget_ld = RTOL + wid_y, RTOL + wid_ld
             assert rel(y, y64) <= budget_y and rel(ld, ld64) <= budget_ld, (case, "nsf", dim, K, n_h, rows, inverse)
+            nsf_widest = max(nsf_widest, wid_y, wid_ld)
             continue
         if u < 0.8:
             dim = int(rng.integers(1, 129)) * 2
@@ -363,6 +367,7 @@ def test_seeded_fuzz_slice_against_float64(amd, O, seed):
         worst = max(worst, e)
         assert e <= RTOL, (case, "rnvp", dim, hid, rows, e)
     assert worst > 0.0
+    print(f"fuzz seed {seed}: worst error outside the spline draws {worst:.2e}; widest spline head-room {nsf_widest:.2e}")
 
 
 def test_narrow_hidden_layers_take_the_fp32_kernels(amd, O):
@@ -578,7 +583,8 @@ def test_g12_nsf_ar_vs_reference(amd, golden, tag):
     with torch.no_grad():
         for direction, fn in (("fwd", f.forward), ("inv", f.inverse)):
             y, ld = fn(x)
-            assert_parity(y, fx[f"{tag}.{direction}"], fx[f"{tag}.{direction}64"], f"{direction} y")
+            assert_parity(y, fx[f"{tag}.{direction}"], fx[f"{tag}.{direction}64"], f"g12 {tag} {direction} y",
+                          max_widening=None if gain != 1.0 else 5e-5)
             assert_close(ld, fx[f"{tag}.ld_{direction}"], 3e-5, f"{direction} log_det")
         # inverse(forward(x)) == x and the log-dets cancel
         y, ld = f.forward(x)

@@ -655,16 +655,22 @@ __global__ void __launch_bounds__(256) ahf_bwd_reduce_kernel(const float* __rest
   }
 }
 
-// The power of two that brings max(|grad_y|, |grad_ld|) over the first `rows` rows into [1, 2) (1 for an all-zero or
-// non-finite sample): one workgroup, the sample is small.
+// The power of two that brings max(|grad_y|, |grad_ld|) over a sample of `sample` rows into [1, 2) (1 for an all-zero or
+// non-finite sample): one workgroup, the sample is small.  The sample is spread evenly over the whole batch (row
+// s * stride): a sorted, masked or weighted batch whose first rows carry no or atypically small cotangents would
+// otherwise set a scale that leaves the rest far outside [1, 2).
 __global__ void __launch_bounds__(1024) grad_scale_kernel(const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
-                                                          int64_t n_y, int64_t n_ld, float* __restrict__ scale_out) {
+                                                          int64_t sample, int64_t stride, int dim,
+                                                          float* __restrict__ scale_out) {
   __shared__ float part[16];
   float m = 0.f;
   if (grad_y)
-    for (int64_t i = threadIdx.x; i < n_y; i += blockDim.x) m = fmaxf(m, fabsf(grad_y[i]));
+    for (int64_t i = threadIdx.x; i < sample * dim; i += blockDim.x) {
+      const int64_t r = i / dim, c = i - r * dim;
+      m = fmaxf(m, fabsf(grad_y[r * stride * dim + c]));
+    }
   if (grad_ld)
-    for (int64_t i = threadIdx.x; i < n_ld; i += blockDim.x) m = fmaxf(m, fabsf(grad_ld[i]));
+    for (int64_t i = threadIdx.x; i < sample; i += blockDim.x) m = fmaxf(m, fabsf(grad_ld[i * stride]));
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -861,8 +867,9 @@ int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_
                                void* stream) {
   if (!scale_out || rows < 0 || dim < 1 || (!grad_y && !grad_ld)) return MNF_ERR_INVALID_ARG;
   const int64_t sample = rows < 512 ? rows : 512;  // (one workgroup: a larger sample costs more than it tells)
-  hipLaunchKernelGGL(mnf::grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, grad_y, grad_ld, sample * dim,
-                     sample, scale_out);
+  const int64_t stride = sample > 0 ? rows / sample : 1;  // rows 0, stride, 2 stride, ...: spread over the whole batch
+  hipLaunchKernelGGL(mnf::grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, grad_y, grad_ld, sample,
+                     stride, dim, scale_out);
   return mnf::check_launch();
 }
 

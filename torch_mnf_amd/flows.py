@@ -85,6 +85,37 @@ def _require_mlp(*nets: nn.Module) -> None:
 _MIN_SPLIT_HIDDEN = 4
 
 
+# MNF_CHECK_PARAMS=N (N >= 1): on every N-th use of a cached operand image, compare the parameters it was packed from
+# with the parameters as they are now (exact comparison on the device, one host round trip) and raise if they differ.
+# The caches are keyed on (data_ptr, _version) of every parameter; a write THROUGH ``p.data`` (``p.data.mul_(2)``,
+# ``p.data.clamp_()``, ``p.data.copy_()``: weight clipping, EMA, some init code) bumps neither, and the kernels would
+# go on computing with the old weights, silently.  ``invalidate()`` is the remedy; this switch is the detector.
+_CHECK_PARAMS_EVERY = int(os.environ.get("MNF_CHECK_PARAMS", "0") or 0)
+_check_params_calls = 0
+
+
+def _check_params_fresh(params, packed_flat: Tensor | None, what: str) -> None:
+    """Raise if ``packed_flat`` (what the operand images were packed from) no longer equals the parameters."""
+    global _check_params_calls
+    if _CHECK_PARAMS_EVERY <= 0 or packed_flat is None:
+        return
+    _check_params_calls += 1
+    if _check_params_calls % _CHECK_PARAMS_EVERY:
+        return
+    if packed_flat.is_cuda and torch.cuda.is_current_stream_capturing():
+        return  # (the comparison reads a result back: not inside a hipGraph capture)
+    with torch.no_grad():
+        now = torch.cat([p.detach().reshape(-1) for p in params]).to(packed_flat.device, torch.float32)
+        # (bitwise: NaN parameters compare equal to themselves, -0.0 differs from +0.0)
+        same = now.numel() == packed_flat.numel() and bool(torch.equal(now.view(torch.int32), packed_flat.view(torch.int32)))
+    if not same:
+        raise RuntimeError(
+            f"torch_mnf_amd: the parameters of {what} changed without their version counters moving (a write "
+            "through p.data, or memory rewritten behind PyTorch's back): the packed operand images are stale. "
+            "Call .invalidate() on the layer (or on the NormalizingFlow / MNFLinear) after such a write, or write "
+            "with `with torch.no_grad(): p.mul_(2)` instead of `p.data.mul_(2)`.")
+
+
 def _narrow_hidden(h_sizes) -> bool:
     return len(h_sizes) > 0 and min(h_sizes) < _MIN_SPLIT_HIDDEN
 
@@ -403,7 +434,7 @@ class _AffineRunFn(torch.autograd.Function):
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         # flat-homed parameters (train.FlatParameters): flat_with_grad is a one-element stand-in that only carries
         # requires_grad; the kernels read the parameter slice and ADD their gradients to the gradient slice in place
-        home = run._flat_home
+        home = run._home_now  # (the validated flat home launch_grad decided on for this call)
         ctx.home = home
         flat = home[0].data[home[1]:home[1] + home[2]] if home is not None else flat_with_grad.detach()
         imgs = run.images(x.device, flat)  # after a weight update: repacked from this one concatenation
@@ -564,6 +595,8 @@ class _HipFlow(nn.Module):
             else:
                 self._split = None
             self._cache_key = key
+        elif _CHECK_PARAMS_EVERY:
+            _check_params_fresh(params, self._flat, type(self).__name__)
         return self._flat, self._image
 
     # out-of-place layer on raw buffers; accum: (rows,) tensor receiving ``+= log_det`` or None
@@ -1087,6 +1120,10 @@ class Glow(_TwoWayFlow):
             self._w_img = {}
             self._w_ld = self.S.detach().abs().log().sum().to(device)  # 0-dim, parameter-only (glow.py:29)
             self._w_key = key
+            self._w_from = (torch.cat([p.detach().reshape(-1) for p in (self.L, self.S, self.U)]).clone()
+                            if _CHECK_PARAMS_EVERY else None)
+        elif _CHECK_PARAMS_EVERY:
+            _check_params_fresh((self.L, self.S, self.U), self.__dict__.get("_w_from"), "Glow")
         if inverse:
             if self._w_inv is None:
                 self._w_inv = torch.inverse(self._w).contiguous()
@@ -1163,6 +1200,10 @@ class _SplineBlockRun:
         key = (device, _flat_gen(an), tuple((p.data_ptr(), p._version) for p in (an.s, an.t, gl.L, gl.S, gl.U)), id(gl.P))
         if key != self._aff_key:
             self._aff, self._aff_key = {}, key
+            self._aff_from = (torch.cat([p.detach().reshape(-1) for p in (an.s, an.t, gl.L, gl.S, gl.U)]).clone()
+                              if _CHECK_PARAMS_EVERY else None)
+        elif _CHECK_PARAMS_EVERY:
+            _check_params_fresh((an.s, an.t, gl.L, gl.S, gl.U), self.__dict__.get("_aff_from"), "an [ActNorm, Glow] block")
         if inverse not in self._aff:
             lib = _lib.load()
             n = lib.mnf_linear_rows_image_floats(self.dim)
@@ -1293,6 +1334,8 @@ class _AffineRun:
         self.logprob_fused = False
         self._flat_home = None   # (FlatParameters, offset, length) while the run's parameters live in one buffer
         self._flat_checked = None
+        self._grad_i0 = None     # index of the run's first parameter in FlatParameters.params
+        self._home_now = None    # the flat home of the call in flight (set by launch_grad, read by _AffineRunFn)
         self._stand_in = None
 
     @staticmethod
@@ -1319,7 +1362,29 @@ class _AffineRun:
                 sl = flat.slice_of(self._params())
                 if sl is not None:
                     self._flat_home = (flat, sl[0], sl[1])
-        return self._flat_home
+        home = self._flat_home
+        if home is not None:
+            # Re-validated on every call (two data pointers, the requires_grad flags, one gradient view): after
+            # model.to() / .float() / load_state_dict(assign=True) the parameters no longer live in the buffer, a
+            # parameter frozen with requires_grad_(False) must not receive the in-place gradient sums, and a torch
+            # optimizer's zero_grad(set_to_none=True) detaches p.grad from the gradient buffer (the in-place sums
+            # would then be invisible to it).  In each case the run takes the ordinary path: one concatenation,
+            # gradients returned to autograd.  (torch.autograd.grad() on a flat-homed run still ADDS into
+            # FlatParameters.grad as a side effect and returns no parameter gradients: use .backward() there.)
+            if not self._home_ok(home[0], self._params()):
+                return None
+        return home
+
+    def _home_ok(self, flat, params) -> bool:
+        if not flat.home_is_valid(params):
+            return False
+        i0 = self._grad_i0
+        if i0 is None or flat.params[i0] is not params[0]:
+            try:
+                i0 = self._grad_i0 = next(i for i, q in enumerate(flat.params) if q is params[0])
+            except StopIteration:
+                return False
+        return params[0].grad is flat._grad_views[i0] and params[-1].grad is flat._grad_views[i0 + len(params) - 1]
 
     def images(self, device, flat: Tensor | None = None):
         """(fp32 operand images, split operand images) of all layers, back to back; repacked after a weight update
@@ -1356,7 +1421,12 @@ class _AffineRun:
                     _lib.check("mnf_pack_gather_split_batch", lib.mnf_pack_gather_split_batch(
                         flat.data_ptr(), table.data_ptr(), self._splits.data_ptr(), n_split, n_plain, n, stride,
                         _stream()))
+                # (debug switch MNF_CHECK_PARAMS: keep what the images were packed from -- with a flat home `flat` is
+                #  the live buffer itself, so a copy)
+                self._packed_from = flat.detach().clone() if _CHECK_PARAMS_EVERY else None
             self._key = key
+        elif _CHECK_PARAMS_EVERY:
+            _check_params_fresh(params, self.__dict__.get("_packed_from"), "a run of AffineHalfFlow layers")
         return self._images, self._splits
 
     def bwd_images(self, device, flat: Tensor):
@@ -1400,7 +1470,8 @@ class _AffineRun:
 
     def launch_grad(self, x: Tensor, inverse: bool):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
-        if self.flat_home() is not None:
+        self._home_now = self.flat_home()
+        if self._home_now is not None:
             if self._stand_in is None or self._stand_in.device != x.device:
                 self._stand_in = torch.zeros(1, device=x.device, requires_grad=True)
             flat = self._stand_in
@@ -1507,6 +1578,13 @@ class FusedAffineStack(_TwoWayFlow):
                     break
                 y, done = out[-1], k + 1
             if done == len(runs):
+                return y, (None if accum is not None else ld)
+            if done > 0:
+                # a later chunk has no stack kernel AFTER earlier chunks have already added their log-dets into ld:
+                # go on from y layer by layer (restarting from x would count the first chunks twice)
+                rest = [f for r in runs[done:] for f in (reversed(r.layers) if inverse else r.layers)]
+                for i, f in enumerate(rest):
+                    y, _ = f._run(y, inverse, ld, sqnorm if i == len(rest) - 1 else None)
                 return y, (None if accum is not None else ld)
         elif isinstance(x, Tensor) and x.dim() == 2 and x.shape[1] != self.dim:
             raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import _lib
+from . import flows as _flows
 from .flows import RNVP, NormalizingFlow, _stream, _wants_grad
 
 
@@ -141,7 +142,11 @@ class MNFLinear(nn.Module):
                 _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
                     flat.data_ptr(), index.data_ptr(), image.data_ptr(), n_split.value, n_plain.value, _stream()))
                 cache = (key, (flat, image, 2.0 ** -shift))
+                if _flows._CHECK_PARAMS_EVERY:  # debug switch: the raw parameters the image was packed from
+                    self.__dict__["_fwd_packed_from"] = torch.cat([p.detach().reshape(-1) for p in params]).clone()
             self.__dict__["_fwd_cache"] = cache
+        elif _flows._CHECK_PARAMS_EVERY:
+            _flows._check_params_fresh(params, self.__dict__.get("_fwd_packed_from"), "MNFLinear.forward")
         return cache[1]
 
     def forward(self, x: Tensor, eps: Tensor | None = None) -> Tensor:

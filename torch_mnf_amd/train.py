@@ -57,8 +57,14 @@ class FlatParameters:
                 self.offset[id(p)] = off
                 off += k
         self.params = params
+        self._grad_views = [p.grad for p in params]  # identity-compared in _reattach (one `is` per parameter)
         for m in model.modules():  # the fused layers look here for their slices
             m.__dict__["_mnf_flat"] = self
+        # The reference's loops clear gradients with ``model.zero_grad()`` (tests/test_flows.py:27,
+        # examples/half_moons.ipynb:188), whose default sets every ``p.grad`` to None: the next backward would then
+        # give each parameter a fresh gradient tensor outside ``self.grad``, and the fused layers' in-place sums in
+        # ``self.grad`` would never be cleared.  On this model ``zero_grad`` is the one memset instead.
+        model.zero_grad = lambda set_to_none=True: self.zero_grad()  # noqa: ARG005 (instance attribute shadows the method)
         if hasattr(model, "invalidate"):
             model.invalidate()
 
@@ -74,15 +80,39 @@ class FlatParameters:
             off += p.numel()
         return off0, off - off0
 
+    def _reattach(self, fold: bool) -> None:
+        """Make every ``p.grad`` the view of ``self.grad`` again.  A torch optimizer's ``zero_grad(set_to_none=True)``
+        (or ``p.grad = None``) detaches a parameter from the buffer: autograd then allocates a stray gradient tensor
+        that FusedAdam would never see.  ``fold``: add a stray gradient's content into the view first (called before
+        an optimizer step: nothing a backward pass produced may be lost).  One identity comparison per parameter --
+        ``p.grad`` returns the same Python object as long as nobody replaced it."""
+        for i, p in enumerate(self.params):
+            g = p.grad
+            view = self._grad_views[i]
+            if g is view:
+                continue
+            if fold and g is not None:
+                view.add_(g.detach().to(view.dtype).view(view.shape))
+            p.grad = view
+
+    def home_is_valid(self, params: list[Tensor]) -> bool:
+        """Do ``params`` still live in ``self.data`` (first and last data pointer where the offsets say) and do they
+        all still want gradients?  ``model.to()``, ``.float()``, ``load_state_dict(assign=True)`` re-home parameters
+        behind this object's back, and ``requires_grad_(False)`` freezes one; a fused layer that wrote its gradient
+        slice in place would then update the wrong memory, or a frozen parameter."""
+        first, last = params[0], params[-1]
+        off_f, off_l = self.offset.get(id(first)), self.offset.get(id(last))
+        if off_f is None or off_l is None:
+            return False
+        base = self.data.data_ptr()
+        return (first.data_ptr() == base + 4 * off_f and last.data_ptr() == base + 4 * off_l
+                and all(p.requires_grad for p in params))
+
     def zero_grad(self) -> None:
-        """One memset; the per-parameter ``.grad`` views stay in place (``set_to_none`` would detach them)."""
+        """One memset; the per-parameter ``.grad`` views stay in place (re-attached if someone set them to None or
+        let autograd allocate a stray gradient: ``set_to_none`` semantics would detach them from the buffer)."""
         self.grad.zero_()
-        for p in self.params:
-            # (autograd accumulates into an existing .grad in place, so a view only goes missing when someone set it
-            #  to None; comparing 144 data pointers per step cost more than the step's launches)
-            if p.grad is None:
-                off = self.offset[id(p)]
-                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+        self._reattach(fold=False)
 
     def touch(self) -> None:
         """Call after writing ``data`` (or a parameter's ``.data``) in place by other means than FusedAdam."""
@@ -111,6 +141,7 @@ class FusedAdam:
     @torch.no_grad()
     def step(self) -> None:
         f = self.flat
+        f._reattach(fold=True)  # a gradient that landed outside the buffer (p.grad was None at backward) is added in
         self.steps += 1
         if self.state is not None:
             _lib.check("mnf_adam_step_graph", _lib.load().mnf_adam_step_graph(
