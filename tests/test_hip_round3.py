@@ -143,7 +143,7 @@ def test_fused_stack_falls_back_without_double_counting(amd, O):
     earlier one has already added its log-dets, the rest runs layer by layer from where the chunks stopped (ADVICE
     round 2: it used to restart from x and count the first chunks twice)."""
     dim, n = 8, 40
-    sds = [recipes.affine_half_params(900 + i, dim) for i in range(n)]
+    sds = [recipes.affine_half_params(900 + i, dim, s_last_gain=0.5) for i in range(n)]
     layers = []
     for i, sd in enumerate(sds):
         f = amd.AffineHalfFlow(dim, bool(i % 2))
