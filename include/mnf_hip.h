@@ -377,6 +377,28 @@ int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_l
 int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x,
                  const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,
                  int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
+/* The same gradients (flows/rnvp.py:25-39 under loss.backward(); what layers/mnf_linear.py:58-64,84 and
+ * tests/test_mnf_mnist.py:14-56 train through) on the matrix cores in split arithmetic, for the shapes the split
+ * forward kernels cover (one hidden layer of width <= 50, padded dim >= 64).  Two launches: a row-parallel one that
+ * recomputes y, forms g_y and hands both over as MFMA operands (1 KB per row in `workspace`), and one in which a
+ * workgroup owns 32 dims and a range of rows (grad_z; dWt, dWs, dWn, dbt, dbs as sums over rows in registers); row
+ * groups outside the split range are redone by mnf_rnvp_bwd's kernel on those groups only.
+ *   split_image     the FORWARD split image (mnf_rnvp_split_layout / _index + mnf_pack_gather_split)
+ *   bwd_image       the backward-only image: mnf_pack_gather_split with the mnf_rnvp_bwd_mfma_index table
+ *                   (2 * n_split_words + n_plain_words int32s, see _layout); repacked after a weight update
+ *   grad_scale_dev  device float, a power of two that brings grad_x / grad_ld near 1 (mnf_affine_half_grad_scale)
+ *   workspace       caller-owned device scratch of at least mnf_rnvp_bwd_mfma_workspace_bytes(rows, ...) bytes,
+ *                   16-byte aligned (no need to clear it)
+ * grad_x / grad_ld may be NULL (no cotangent for that output), grad_flat may be NULL (grad_z only).  grad_z is
+ * written, grad_flat ADDED to.  MNF_ERR_UNSUPPORTED: no such kernel for the shape (use mnf_rnvp_bwd). */
+int64_t mnf_rnvp_bwd_mfma_workspace_bytes(int64_t rows, int dim, int n_hidden, const int* hidden_host);
+int mnf_rnvp_bwd_mfma_layout(int dim, int n_hidden, const int* hidden_host, int64_t* n_split_words,
+                             int64_t* n_plain_words);
+int mnf_rnvp_bwd_mfma_index(int dim, int n_hidden, const int* hidden_host, int32_t* idx_host);
+int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                      float* grad_z, float* grad_flat, const float* flat, const void* split_image,
+                      const void* bwd_image, const float* grad_scale_dev, void* workspace, int64_t workspace_bytes,
+                      int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
 /* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
 int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,

@@ -179,3 +179,152 @@ def test_gradient_scale_sample_spans_the_batch(amd):
     scale = amd.flows._grad_scale(g, None, rows, dim, torch.device(DEV))
     top = float(g[::rows // 512].abs().max())
     assert 1.0 <= float(scale) * top < 2.0
+
+
+# ------------------------------------------------------------------------------------------------ RNVP gradients (MFMA)
+def _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l):
+    """(fp32, fp64) gradient dicts of sum(x * w_x) + sum(log_det * w_l) through the oracle."""
+    out = []
+    for dt in (torch.float32, torch.float64):
+        zz = z.detach().to(dt).requires_grad_(True)
+        p = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+        x, ld = O.rnvp(zz, p, mask.to(dt))
+        loss = 0
+        if w_x is not None:
+            loss = loss + (x * w_x.to(dt)).sum()
+        if w_l is not None:
+            loss = loss + (ld * w_l.to(dt)).sum()
+        loss.backward()
+        out.append({"z": zz.grad, **{k: v.grad for k, v in p.items()}})
+    return out
+
+
+def _check_grads(got, g32, g64, what, base=1e-5):
+    worst = 0.0
+    for k, r64 in g64.items():
+        if r64 is None or float(r64.abs().max()) == 0.0:  # the loss does not depend on this parameter
+            assert got[k] is None or float(got[k].abs().max()) == 0.0, f"{what}: grad {k} should be zero"
+            continue
+        widening = 2.0 * normwise_err(g32[k].numpy(), r64.numpy())
+        err = normwise_err(got[k].detach().double().cpu().numpy(), r64.numpy())
+        assert err <= base + widening, (f"{what}: grad {k} is {err:.3e} from the float64 oracle; budget "
+                                        f"{base + widening:.3e} (fp32 oracle vs fp64 {widening / 2:.2e})")
+        worst = max(worst, err)
+    return worst
+
+
+def _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask=None, seed=None, generic=False):
+    f = amd.RNVP(dim, h_sizes=(hid,))
+    f.load_state_dict(sd)
+    f.to(DEV)
+    f.force_generic = generic
+    zz = z.detach().to(DEV).requires_grad_(True)
+    x, ld = f.forward(zz, mask=None if mask is None else mask.to(DEV), seed=seed)
+    loss = 0
+    if w_x is not None:
+        loss = loss + (x * w_x.to(DEV)).sum()
+    if w_l is not None:
+        loss = loss + (ld * w_l.to(DEV)).sum()
+    loss.backward()
+    return f, {"z": zz.grad, **{n: q.grad for n, q in f.named_parameters()}}
+
+
+@pytest.mark.parametrize("dim,hid,rows", [(800, 50, 70), (800, 50, 1000), (50, 50, 129), (64, 30, 33), (784, 50, 300),
+                                          (100, 17, 257), (96, 50, 1), (128, 8, 4099)])
+@pytest.mark.parametrize("masked", ["explicit", "seeded"])
+def test_rnvp_mfma_gradient_kernels(amd, O, dim, hid, rows, masked):
+    """mnf_rnvp_bwd_mfma (row-parallel launch A + dims-slab launch B) against autograd through the oracle in float64
+    and against the generic gradient kernel: MNF-LeNet's widths (800, 50), ragged widths (784, 100, 50), hidden widths
+    below the kernels' 30 / 50 units, a single row, ragged row counts, explicit float masks and the in-kernel mask."""
+    sd = recipes.rnvp_params(3100 + dim + hid, dim, hid)
+    z = recipes.gaussian(3200 + dim, rows, dim)
+    w_x = recipes.gaussian(3300 + dim, rows, dim)
+    w_l = recipes.gaussian(3400 + dim, rows, 1)[:, 0]
+    if masked == "explicit":
+        mask, seed = recipes.bernoulli_mask(3500 + dim, rows, dim), None
+    else:
+        seed = 4242 + dim
+        probe = amd.RNVP(dim, h_sizes=(hid,))
+        mask = probe.mask_for(seed, rows).cpu()
+    g32, g64 = _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l)
+    f, got = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask if masked == "explicit" else None, seed)
+    assert f._bwd_index(torch.device(DEV, 0)), "this shape should have the matrix-core gradient kernels"
+    worst = _check_grads(got, g32, g64, f"rnvp mfma d={dim} h={hid} rows={rows} {masked}")
+    _, gen = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask if masked == "explicit" else None, seed, generic=True)
+    for k in got:
+        assert_close(got[k], gen[k], 2e-5, f"mfma vs generic {k}")
+    print(f"rnvp mfma gradients d={dim} h={hid} rows={rows} {masked}: worst {worst:.2e} from float64")
+
+
+@pytest.mark.parametrize("which", ["x_only", "ld_only"])
+def test_rnvp_mfma_gradient_kernels_absent_cotangents(amd, O, which):
+    dim, hid, rows = 800, 50, 200
+    sd = recipes.rnvp_params(3601, dim, hid)
+    z = recipes.gaussian(3602, rows, dim)
+    mask = recipes.bernoulli_mask(3603, rows, dim)
+    w_x = recipes.gaussian(3604, rows, dim) if which == "x_only" else None
+    w_l = recipes.gaussian(3605, rows, 1)[:, 0] if which == "ld_only" else None
+    g32, g64 = _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l)
+    _, got = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask)
+    _check_grads(got, g32, g64, f"rnvp mfma {which}")
+
+
+@pytest.mark.parametrize("magnitude", [1e-7, 1.0, 300.0])
+def test_rnvp_mfma_gradient_kernels_do_not_depend_on_the_gradient_scale(amd, O, magnitude):
+    """Cotangents of a mean over 256,000 rows are ~4e-6 (far below f16's normal range): the kernels normalise them by a
+    power of two from a sample of the rows and scale the results back."""
+    dim, hid, rows = 800, 50, 600
+    sd = recipes.rnvp_params(3701, dim, hid)
+    z = recipes.gaussian(3702, rows, dim)
+    mask = recipes.bernoulli_mask(3703, rows, dim)
+    w_x = recipes.gaussian(3704, rows, dim) * magnitude
+    w_l = recipes.gaussian(3705, rows, 1)[:, 0] * magnitude
+    w_x[550:] *= 20.0   # outside the 512-row sample
+    g32, g64 = _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l)
+    _, got = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask)
+    _check_grads(got, g32, g64, f"rnvp mfma, cotangents x {magnitude}")
+
+
+@pytest.mark.parametrize("case", ["big_rows", "big_weights", "one_huge_gradient"])
+def test_rnvp_mfma_gradient_kernels_range_guard(amd, O, case):
+    """128-row groups with an operand outside the split range are flagged by launch A, skipped by launch B and redone
+    by the generic fp32 kernel on exactly those groups; weights beyond the limit send every group there."""
+    dim, hid, rows = 800, 50, 128 * 5 + 37
+    sd = recipes.rnvp_params(3801, dim, hid)
+    z = recipes.gaussian(3802, rows, dim)
+    mask = recipes.bernoulli_mask(3803, rows, dim)
+    w_x = recipes.gaussian(3804, rows, dim)
+    w_l = recipes.gaussian(3805, rows, 1)[:, 0]
+    if case == "big_rows":
+        z = z.clone()
+        z[130] *= 3e4          # one row of group 1
+        z[400:410] *= 1e5      # group 3
+        sd = {k: (v * 1e-5 if k == "net.0.weight" else v) for k, v in sd.items()}
+    elif case == "big_weights":
+        sd = {k: (v * 1e4 if k == "net.0.weight" else v) for k, v in sd.items()}
+        z = z * 1e-4
+    else:
+        w_x = w_x.clone()
+        w_x[300, 5] = 1e7      # in the sample: it sets the scale, every other row becomes small (not wrong)
+        w_x[640] *= 3e4        # last group, beyond the sample: 3e4 x the scale -> out of range there
+    g32, g64 = _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l)
+    _, got = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask)
+    _check_grads(got, g32, g64, f"rnvp mfma range guard {case}", base=2e-5)
+
+
+def test_rnvp_mfma_gradient_kernels_many_rows(amd):
+    """Enough rows for several row parts per XCD and several trips per wave (65,536 x 800: 70 copies of a 937-row
+    batch, so that every copy's grad_z must equal the single batch's and the parameter gradients 70 x it)."""
+    dim, hid, rows, copies = 800, 50, 937, 70
+    sd = recipes.rnvp_params(3901, dim, hid)
+    z = recipes.gaussian(3902, rows, dim)
+    mask = recipes.bernoulli_mask(3903, rows, dim)
+    w_x = recipes.gaussian(3904, rows, dim)
+    w_l = recipes.gaussian(3905, rows, 1)[:, 0]
+    _, one = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask)
+    _, many = _rnvp_gpu_grads(amd, sd, dim, hid, z.repeat(copies, 1), w_x.repeat(copies, 1), w_l.repeat(copies),
+                              mask.repeat(copies, 1))
+    assert_close(many["z"], one["z"].repeat(copies, 1), 2e-6, "grad_z of the copies")
+    for k in one:
+        if k != "z":
+            assert_close(many[k], copies * one[k], 1e-5, f"{k}: {copies} copies")

@@ -100,6 +100,11 @@ SIGNATURES = {
                                     c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int64, c_int, c_int, _intp, c_void_p]),
+    "mnf_rnvp_bwd_mfma_workspace_bytes": (c_int64, [c_int64, c_int, c_int, _intp]),
+    "mnf_rnvp_bwd_mfma_layout": (c_int, [c_int, c_int, _intp, _i64p, _i64p]),
+    "mnf_rnvp_bwd_mfma_index": (c_int, [c_int, c_int, _intp, _i32p]),
+    "mnf_rnvp_bwd_mfma": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_affine_const_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -677,11 +677,14 @@ struct RnvpBwdArgs {
   uint64_t seed;
   int act_off[MNF_MAX_LINEAR];
   NetDesc net;
+  const int32_t* flags;  // non-null: only the row groups (rows_per_flag rows each, a multiple of R) flagged non-zero
+  int rows_per_flag;
 };
 
 __global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
   const int d = a.dim, hl = a.net.sizes[a.net.n_lin];
   const int64_t row0 = (int64_t)blockIdx.x * a.R;
+  if (a.flags && a.flags[row0 / a.rows_per_flag] == 0) return;  // (block-uniform)
   const int R = (int)min((int64_t)a.R, a.rows - row0);
   float* kept = bsmem;                 // [R][d]  m z
   float* g_t = kept + a.R * d;         // [R][d]
@@ -955,9 +958,14 @@ int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
   return check_launch();
 }
 
-int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
-                 float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
-                 const int* hidden, void* stream) {
+}  // extern "C"
+
+namespace mnf {
+// flags != nullptr: the fix-up pass of mnf_rnvp_bwd_mfma -- only row groups of `rows_per_flag` rows with a non-zero flag
+// are computed (every other workgroup returns at once); rows per workgroup then divide rows_per_flag
+int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                            float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
+                            const int* hidden, const int32_t* flags, int rows_per_flag, hipStream_t stream) {
   if (!z || !grad_z || !flat || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
@@ -965,6 +973,7 @@ int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* 
   memset(&a, 0, sizeof(a));
   a.z = z; a.mask = mask; a.seed = seed; a.grad_x = grad_x; a.grad_ld = grad_ld; a.grad_z = grad_z;
   a.grad_flat = grad_flat; a.flat = flat; a.rows = rows; a.dim = dim;
+  a.flags = flags; a.rows_per_flag = rows_per_flag;
   int sizes[MNF_MAX_LINEAR + 1];
   sizes[0] = dim;
   for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
@@ -985,12 +994,27 @@ int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* 
   int R = kBwdLdsFloats / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
   if (R > 32) R = 32;
+  if (flags) {  // a workgroup must not straddle two flag groups
+    int r2 = 1;
+    while (2 * r2 <= R && rows_per_flag % (2 * r2) == 0) r2 *= 2;
+    R = r2;
+  }
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
-                     (hipStream_t)stream, a);
+                     stream, a);
   return check_launch();
+}
+}  // namespace mnf
+
+extern "C" {
+
+int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                 float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
+                 const int* hidden, void* stream) {
+  return mnf::rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
+                                      nullptr, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

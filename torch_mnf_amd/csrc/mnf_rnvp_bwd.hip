@@ -1,0 +1,829 @@
+// Gradients of the masked / gated RNVP coupling (flows/rnvp.py:25-39 under loss.backward()) on the f16 matrix pipe in
+// split (hi + lo) fp32 arithmetic (mnf_split.h), gfx950.  This is what MNFLinear / MNFConv2d train through
+// (layers/mnf_linear.py:58-64,84; tests/test_mnf_mnist.py:14-56).
+//
+//   forward   k = m z;  y = Wn k + bn;  t = Wt y + bt;  s = Ws y + bs;  gate = sigmoid(s)
+//             x = (1-m) z gate + (1-gate) t + m z;      log_det = sum_c (1-m_c) log gate_c
+//   backward  g_t = G (1-gate);   g_s = (G ((1-m) z - t) gate + g_ld (1-m)) (1-gate)           [G = grad_x]
+//             g_y = Wt^T g_t + Ws^T g_s;     g_k = Wn^T g_y;     grad_z = G ((1-m) gate + m) + m g_k
+//             dWt = g_t^T y, dbt = sum g_t (same for s);  dWn = g_y^T k, dbn = sum g_y            [sums over rows]
+//
+// Two things pull in opposite directions.  g_y is a sum over ALL d dims of a row, so it wants a wave to own rows and
+// sweep the dims (like the forward kernels).  The weight gradients are sums over ALL rows with 3 d h = 120,000
+// accumulators at d = 800, h = 50 (480 KB: no workgroup can hold them), so they want a workgroup to own a SLAB of dims
+// and sweep the rows.  Hence two launches with a small per-row hand-over between them:
+//
+//   A  (row-parallel, the forward kernel's streaming scheme)   y = GEMM 1 over z;  second sweep over z and G: s, t, gate,
+//      g_t, g_s and g_y += [Wt^T | Ws^T] [g_t; g_s] (one K = 32 step per 16 dims).  Writes, per 16-row tile, y and g_y
+//      as ready-made split MFMA operands in BOTH orientations (units along the lane's registers for the K = units
+//      products of B, rows along them for B's sums over rows; the second orientation is one MFMA against the identity
+//      per tile, exact) -- 1 KB per row -- and dbn.  No row data is written.
+//   B  (a workgroup owns 32 dims and a range of rows)           per 32 rows: s, t again from y (K = 64 units), gate, g_t,
+//      g_s, g_k = Wn^T g_y, grad_z (the one write of row data), and dWt, dWs, dWn, dbt, dbs as K = 32-ROW products
+//      into 24 accumulator tiles that stay in registers over the whole row range.
+//      Everything here is computed TRANSPOSED (rows on the MFMA M axis): an accumulator then holds four ROWS of one dim
+//      per lane, which is exactly the operand layout of a sum over rows, so no tile is ever transposed in B; rows are
+//      read and written as 8-byte pieces (dims 2 j, 2 j + 1 of the slab: the slab's two 16-column tiles are its even
+//      and its odd dims), 4 rows x 128 B per instruction.
+//
+// HBM traffic per row: z three times (A twice, the second mostly from cache; B once), G twice, grad_z once: <= 6 x 4 d
+// bytes against the 3 x 4 d a gradient pass must move.  Storing g_t / g_s instead would cost 8 x 4 d.
+//
+// Cotangents of a mean over 256,000 rows are ~4e-6, below f16's normal range: G and g_ld are multiplied by a power of
+// two from mnf_affine_half_grad_scale on the way in (exact) and the results scaled back on the way out.  Range guard: A
+// tracks max|operand| per 128-row group (z, y, g_t, g_s, g_y); a group that reaches the split limit -- or any group when
+// a weight exceeds the weight limit -- is flagged, skipped by B, and redone by the generic fp32 kernel on the flagged
+// groups behind B (mnf_rnvp_bwd's kernel with a flag list: it returns at once for every other group).
+#include <hip/hip_runtime.h>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+#include "mnf_rnvp_common.h"
+#include "mnf_split.h"
+
+namespace mnf {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBwdGroupRows = 16 * kRnvpWaves;  // rows per flag (A's 8-wave group)
+constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
+
+template <int HN>
+struct RnvpBwdShape {
+  using S = RnvpSplitShape<HN>;
+  static constexpr int YT = S::YT, NKS2 = S::NKS2;
+  // backward-only operand image: [A3: per 16-dim group, YT (hi, lo) operands of [Wt^T | Ws^T]]
+  //                              [B2: per 32-dim slab: (dim tile E/O) x (t, s) x NKS2 x (hi, lo)   B operands, K = units]
+  //                              [B4: per slab: (E/O) x NKS2 x (hi, lo)                            Wn as B operand    ]
+  //                      plain:  per slab: bt_E[16] bt_O[16] bs_E[16] bs_O[16]
+  static constexpr int A3_TILE_WORDS = YT * 512;
+  static constexpr int B2_SLAB_WORDS = 2 * 2 * NKS2 * 512;
+  static constexpr int B4_SLAB_WORDS = 2 * NKS2 * 512;
+  static constexpr int B_SLAB_PLAIN = 64;
+  static constexpr int64_t n_slabs(int dm) { return (dm + 31) / 32; }
+  static constexpr int64_t a3_words(int d16) { return (int64_t)(d16 / 16) * A3_TILE_WORDS; }
+  static constexpr int64_t b2_words(int dm) { return n_slabs(dm) * B2_SLAB_WORDS; }
+  static constexpr int64_t b4_words(int dm) { return n_slabs(dm) * B4_SLAB_WORDS; }
+  static constexpr int64_t split_words(int dm, int d16) { return a3_words(d16) + b2_words(dm) + b4_words(dm); }
+  static constexpr int64_t plain_words(int dm) { return n_slabs(dm) * B_SLAB_PLAIN; }
+  // hand-over per 16-row tile (32-bit words): y and g_y as A operands with units on K ([ks][hi|lo][lane][4]) and with
+  // rows on K ([unit tile][hi|lo'][lane][2]; lo' = the UNSCALED residual, so that a sum over rows needs one accumulator)
+  static constexpr int OP_WORDS = NKS2 * 2 * 256;
+  static constexpr int TR_WORDS = YT * 2 * 128;
+  static constexpr int TILE_WORDS = 2 * OP_WORDS + 2 * TR_WORDS;
+  static constexpr int Y_OP = 0, G_OP = OP_WORDS, Y_TR = 2 * OP_WORDS, G_TR = 2 * OP_WORDS + TR_WORDS;
+  // A's LDS window: a GEMM-1 chunk (KC K-steps) or one second-sweep tile (forward GEMM-2 tile + its A3 operands)
+  static constexpr int CHUNK_WORDS =
+      S::KC * S::KS1_WORDS > S::TILE2_WORDS + A3_TILE_WORDS ? S::KC * S::KS1_WORDS : S::TILE2_WORDS + A3_TILE_WORDS;
+  static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);
+};
+
+__device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+// four fp32 values -> f16 heads and UNSCALED f16 residuals (v - head): the operands of a product whose three partial
+// products go into one accumulator.  Below 2^-13 the residual is an f16 subnormal or zero: an absolute error of at most
+// 2^-25 on data scaled to O(1), fp32's own rounding of a sum whose largest terms are O(1).
+__device__ __forceinline__ void split_plain(const f32x4& v, u32x2& hi, u32x2& lo) {
+  const uint32_t h0 = cvt_pk(v[0], v[1]), h1 = cvt_pk(v[2], v[3]);
+  hi = u32x2{h0, h1};
+  lo = u32x2{cvt_pk(residual_lo(h0, v[0]), residual_hi(h0, v[1])), cvt_pk(residual_lo(h1, v[2]), residual_hi(h1, v[3]))};
+}
+
+// ================================================================================================ kernel A
+template <int HN, bool SEEDED, bool RAG>
+__device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
+                                                 const float* __restrict__ mask, const float* __restrict__ gx,
+                                                 const float* __restrict__ gld, const uint32_t* __restrict__ simage,
+                                                 const uint32_t* __restrict__ bimage, uint32_t* __restrict__ side,
+                                                 int32_t* __restrict__ flags, float gscale, bool weights_ok,
+                                                 f32x4 (&bn_acc)[RnvpSplitShape<HN>::YT], int64_t rows, int d,
+                                                 uint64_t seed, int dm_ragged, bool vec) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  const int dm = RAG ? dm_ragged : d;
+  constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int G = d / 16;
+  const int n_ks1 = (G + 1) / 2;
+  const int nc1 = (n_ks1 + KC - 1) / KC, nc = nc1 + G;  // second sweep: one 16-dim tile per chunk
+  const uint32_t* img1 = simage;
+  const uint32_t* img2 = simage + S::part1_words(d);
+  const float* bias2 = reinterpret_cast<const float*>(simage + S::split_words(d));
+  const float* bias_y = bias2 + (int64_t)G * 32;
+  const uint32_t* img3 = bimage;  // A3
+
+  const int64_t row = (int64_t)grp * kBwdGroupRows + wave * 16 + j;
+  const bool live = row < rows;
+  const int64_t rowc = live ? row : rows - 1;
+  const float* zr = z + rowc * dm + 4 * q;
+  const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
+  const float* gr = gx ? gx + rowc * dm + 4 * q : nullptr;
+  const float glr = (gld && live) ? gld[rowc] * gscale : 0.f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  auto mask4 = [&](int g) -> f32x4 {
+    if (g < 0) return zero4;
+    if (!SEEDED) return row_load4<RAG>(mr, 16 * g, 4 * q, dm, vec);
+    const int dd = 16 * g + 4 * q;
+    const uint32_t w = rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31);
+    return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
+  };
+  auto z4 = [&](int g) -> f32x4 { return row_load4<RAG>(zr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec); };
+  auto g4 = [&](int g) -> f32x4 {
+    if (gr == nullptr) return zero4;
+    return row_load4<RAG>(gr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec);
+  };
+
+  // operands of chunk c: GEMM-1 chunks are contiguous in the forward image; a second-sweep chunk is the forward
+  // GEMM-2 tile followed by the tile's A3 operands from the backward image
+  uint4 st[B::STAGE_U4];
+  auto request_operands = [&](int c, int& n4) {
+    const int cc = c < nc ? c : nc - 1;
+    const uint4 *src_a, *src_b;
+    int n4a;
+    if (cc < nc1) {
+      n4a = n4 = min(KC, n_ks1 - cc * KC) * (S::KS1_WORDS / 4);
+      src_a = src_b = reinterpret_cast<const uint4*>(img1 + (int64_t)cc * KC * S::KS1_WORDS);
+    } else {
+      const int m = cc - nc1;
+      n4a = S::TILE2_WORDS / 4;
+      n4 = n4a + B::A3_TILE_WORDS / 4;
+      src_a = reinterpret_cast<const uint4*>(img2 + (int64_t)m * S::TILE2_WORDS);
+      src_b = reinterpret_cast<const uint4*>(img3 + (int64_t)m * B::A3_TILE_WORDS) - n4a;
+    }
+#pragma unroll
+    for (int i = 0; i < B::STAGE_U4; ++i) {
+      const int k = threadIdx.x + i * (kRnvpWaves * 64);
+      const int kk = k < n4 ? k : 0;
+      st[i] = kk < n4a ? src_a[kk] : src_b[kk];
+    }
+  };
+  auto hand_over = [&](uint32_t* buf, int n4) {
+    uint4* dst = reinterpret_cast<uint4*>(buf);
+#pragma unroll
+    for (int i = 0; i < B::STAGE_U4; ++i) {
+      const int k = threadIdx.x + i * (kRnvpWaves * 64);
+      if (k < n4) dst[k] = st[i];
+    }
+  };
+  auto row_group1 = [&](int c, int i) -> int {
+    const int g = 2 * (c * KC) + i;
+    return g < G ? g : -1;
+  };
+
+  // ---- sweep 1: y^T = Wn (m z)^T + bn, exactly as the forward kernel (rows requested D1 chunks ahead)
+  constexpr int D1 = SEEDED ? 2 : 1;
+  f32x4 z1[D1][2 * KC], m1[D1][2 * KC];
+  auto request_rows1 = [&](int c, int u) {
+#pragma unroll
+    for (int i = 0; i < 2 * KC; ++i) {
+      const int g = row_group1(c < nc1 ? c : nc1 - 1, i);
+      z1[u][i] = z4(g);
+      m1[u][i] = mask4(g);
+    }
+  };
+  __syncthreads();  // the previous group's last chunk is fully consumed
+  {
+    int n4;
+#pragma unroll
+    for (int u = 0; u < D1; ++u) request_rows1(u, u);
+    request_operands(0, n4);
+    hand_over(lds0, n4);
+  }
+  __syncthreads();
+  f32x4 ym[YT], yc[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) {
+    ym[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
+    yc[m] = zero4;
+  }
+  float mx = weights_ok ? 0.f : __builtin_inff();
+  for (int c0 = 0; c0 < nc1; c0 += D1) {
+#pragma unroll
+    for (int u = 0; u < D1; ++u) {
+      const int c = c0 + u;
+      if (c < nc1) {
+        f16x8 bh[KC], bl[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          u32x2 h0, l0, h1, l1;
+          split_tile(m1[u][2 * kk] * z1[u][2 * kk], h0, l0, mx);
+          split_tile(m1[u][2 * kk + 1] * z1[u][2 * kk + 1], h1, l1, mx);
+          bh[kk] = pair_operand(h0, h1);
+          bl[kk] = pair_operand(l0, l1);
+        }
+        int n4_next = 0;
+        request_rows1(c + D1, u);
+        request_operands(c + 1, n4_next);  // c + 1 == nc1: the first second-sweep tile
+        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          if (c * KC + kk < n_ks1) {
+#pragma unroll
+            for (int m = 0; m < YT; ++m)
+              split_mac(A8[64 * (2 * (kk * YT + m))], A8[64 * (2 * (kk * YT + m) + 1)], bh[kk], bl[kk], ym[m], yc[m]);
+          }
+        }
+        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        __syncthreads();
+      }
+    }
+  }
+  // ---- y complete: GEMM-2 operands
+  constexpr int D2 = SEEDED ? 2 : 1;
+  f32x4 z2[D2], g2[D2], m2[D2];
+  auto request_rows2 = [&](int c, int u) {
+    const int cc = c < nc ? c : nc - 1;
+    z2[u] = z4(cc - nc1);
+    g2[u] = g4(cc - nc1);
+    m2[u] = mask4(cc - nc1);
+  };
+#pragma unroll
+  for (int u = 0; u < D2; ++u) request_rows2(nc1 + u, u);
+  u32x2 yh[YT], yl[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
+
+  // ---- sweep 2: per 16 dims  s, t -> gate -> g_t, g_s -> g_y += [Wt^T | Ws^T] [g_t; g_s]
+  f32x4 gm[YT], gc[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) gm[m] = gc[m] = zero4;
+  for (int c0 = nc1; c0 < nc; c0 += D2) {
+#pragma unroll
+    for (int u = 0; u < D2; ++u) {
+      const int c = c0 + u;
+      if (c < nc) {
+        int n4_next = 0;
+        request_operands(c + 1, n4_next);
+        const int m = c - nc1;
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 4 * q);
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 16 + 4 * q);
+        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const f16x8* T8 = reinterpret_cast<const f16x8*>(buf) + lane;
+        const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + S::TILE2_WORDS) + lane;
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) {
+          const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
+          split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
+        }
+        const f32x4 t4 = tc * kSplitInvScale + tm + bt;
+        const f32x4 s4 = sc * kSplitInvScale + sm + bs;
+        f32x4 gt, gs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zz = z2[u][r], mm = m2[u][r], nm = 1.f - mm;
+          const float GG = live ? g2[u][r] * gscale : 0.f;
+          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+          const float omg = 1.f - gate;
+          gt[r] = GG * omg;
+          gs[r] = (GG * (nm * zz - t4[r]) * gate + glr * nm) * omg;
+        }
+        u32x2 th, tl, sh, sl;
+        split_tile(gt, th, tl, mx);
+        split_tile(gs, sh, sl, mx);
+        const f16x8 bh = pair_operand(th, sh), bl = pair_operand(tl, sl);
+#pragma unroll
+        for (int m2i = 0; m2i < YT; ++m2i) split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
+        request_rows2(c + D2, u);
+        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        __syncthreads();
+      }
+    }
+  }
+  // ---- g_y complete: the group's verdict, then the hand-over
+  f32x4 gy[YT];
+  u32x2 gh[YT], gl2[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) {
+    gy[m] = gc[m] * kSplitInvScale + gm[m];
+    split_tile(gy[m], gh[m], gl2[m], mx);
+  }
+  const bool bad = __syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0) != 0;
+  if (threadIdx.x == 0) flags[grp] = bad ? 1 : 0;
+  if (bad) return;
+  const int64_t tile = (int64_t)grp * kRnvpWaves + wave;
+  if (tile * 16 >= rows) return;  // wave-uniform: a tile past the end (the group's last rows)
+#pragma unroll
+  for (int m = 0; m < YT; ++m) bn_acc[m] += gy[m];  // (dead rows carry g_y = 0)
+  uint32_t* out = side + tile * B::TILE_WORDS;
+  // units on K: operand ks = (tiles 2 ks, 2 ks + 1)
+#pragma unroll
+  for (int ks = 0; ks < NKS2; ++ks) {
+    const bool two = 2 * ks + 1 < YT;
+    const u32x2 yb = two ? yh[two ? 2 * ks + 1 : 0] : zero2, ybl = two ? yl[two ? 2 * ks + 1 : 0] : zero2;
+    const u32x2 gb = two ? gh[two ? 2 * ks + 1 : 0] : zero2, gbl = two ? gl2[two ? 2 * ks + 1 : 0] : zero2;
+    *reinterpret_cast<u32x4*>(out + B::Y_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{yh[2 * ks][0], yh[2 * ks][1], yb[0], yb[1]};
+    *reinterpret_cast<u32x4*>(out + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{yl[2 * ks][0], yl[2 * ks][1], ybl[0], ybl[1]};
+    *reinterpret_cast<u32x4*>(out + B::G_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{gh[2 * ks][0], gh[2 * ks][1], gb[0], gb[1]};
+    *reinterpret_cast<u32x4*>(out + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{gl2[2 * ks][0], gl2[2 * ks][1], gbl[0], gbl[1]};
+  }
+  // rows on K: one MFMA against the identity per tile and part turns "lane = row, registers = units" into
+  // "lane = unit, registers = rows" (D[row][unit'] = sum_k A[row][k] I[k][unit'], every product x 1: exact); the tail
+  // goes against 2^-11 I and comes out unscaled
+  u32x2 id, ids;
+  {
+    const _Float16 one = (_Float16)1.f, tiny = (_Float16)kSplitInvScale, zero = (_Float16)0.f;
+    f16x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (4 * q + e == j) ? one : zero;
+      b[e] = (4 * q + e == j) ? tiny : zero;
+    }
+    id = __builtin_bit_cast(u32x2, a);
+    ids = __builtin_bit_cast(u32x2, b);
+  }
+#pragma unroll
+  for (int m = 0; m < YT; ++m) {
+    const f32x4 a = mfma16(yh[m], id, zero4), b = mfma16(yl[m], ids, zero4);
+    const f32x4 c = mfma16(gh[m], id, zero4), e = mfma16(gl2[m], ids, zero4);
+    *reinterpret_cast<u32x2*>(out + B::Y_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(a[0], a[1]), cvt_pk(a[2], a[3])};
+    *reinterpret_cast<u32x2*>(out + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(b[0], b[1]), cvt_pk(b[2], b[3])};
+    *reinterpret_cast<u32x2*>(out + B::G_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(c[0], c[1]), cvt_pk(c[2], c[3])};
+    *reinterpret_cast<u32x2*>(out + B::G_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(e[0], e[1]), cvt_pk(e[2], e[3])};
+  }
+}
+
+template <int HN, bool SEEDED, bool RAG>
+__global__ void __launch_bounds__(kRnvpWaves * 64, 2)
+rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
+                  const float* __restrict__ gld, const uint32_t* __restrict__ simage, const uint32_t* __restrict__ bimage,
+                  uint32_t* __restrict__ side, int32_t* __restrict__ flags, const float* __restrict__ gscale_dev,
+                  float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged, int hn, uint64_t seed, int vec_ok,
+                  int64_t bimage_tail) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][B::CHUNK_WORDS];
+  const int dm = RAG ? dm_ragged : d;
+  const float gscale = gscale_dev[0];
+  const float wmax_f = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
+  const float wmax_b = __builtin_bit_cast(float, bimage[bimage_tail]);
+  const bool weights_ok = wmax_f <= kSplitWeightLimit && wmax_b <= kSplitWeightLimit;
+  f32x4 bn_acc[S::YT];
+#pragma unroll
+  for (int m = 0; m < S::YT; ++m) bn_acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_groups = (int)((rows + kBwdGroupRows - 1) / kBwdGroupRows);
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
+    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, gscale,
+                                      weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0);
+  // dbn: sum over the wave's rows (the 16 lanes j of a q), one atomic per unit per wave
+  if (grad_flat) {
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const float inv = 1.f / gscale;
+    float* dbn = grad_flat + (int64_t)hn * dm;
+#pragma unroll
+    for (int m = 0; m < S::YT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = bn_acc[m][r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        const int unit = 16 * m + 4 * q + r;
+        if (j == 0 && unit < hn && v != 0.f) atomicAdd(dbn + unit, v * inv);
+      }
+  }
+}
+
+// ================================================================================================ kernel B
+// lane (c, q): column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers
+template <int HN, bool SEEDED, bool RAG>
+__global__ void __launch_bounds__(kBwdBWaves * 64, 2)
+rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
+                  const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
+                  const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
+                  const float* __restrict__ gscale_dev, int64_t rows, int dm, int d16, int hn, uint64_t seed, int n_slabs,
+                  int row_parts, int vec2) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  constexpr int W_WORDS = B::B2_SLAB_WORDS + B::B4_SLAB_WORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t w_lds[W_WORDS + B::B_SLAB_PLAIN];
+  // Work items = (row part, slab).  With >= 8 row parts, part p belongs to XCD p % 8 (workgroups go to the XCDs round
+  // robin: block b runs on XCD b % 8) and that XCD's workgroups take its items in (part, slab) order: the n_slabs
+  // workgroups on one row part then run on ONE XCD at about the same time and walk the same rows, so the per-row
+  // hand-over (1 KB per row, read by every slab) is fetched into that XCD's L2 once.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float gscale = gscale_dev[0], inv_gscale = 1.f / gscale;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
+  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
+  const bool by_xcd = row_parts >= 8;
+  const int xcd = blockIdx.x & 7, wg_local = blockIdx.x >> 3, wgs_local = gridDim.x >> 3;
+  const int local_parts = by_xcd ? (row_parts - xcd + 7) / 8 : 0;
+  const int n_items = by_xcd ? local_parts * n_slabs : row_parts * n_slabs;
+  for (int item = by_xcd ? wg_local : blockIdx.x; item < n_items; item += by_xcd ? wgs_local : gridDim.x) {
+  const int slab = item % n_slabs, part = by_xcd ? (item / n_slabs) * 8 + xcd : item / n_slabs;
+  __syncthreads();  // the previous item's operands are no longer read
+  {
+    const uint32_t* b2 = bimage + B::a3_words(d16) + (int64_t)slab * B::B2_SLAB_WORDS;
+    const uint32_t* b4 = bimage + B::a3_words(d16) + B::b2_words(dm) + (int64_t)slab * B::B4_SLAB_WORDS;
+    const uint32_t* pl = bimage + B::split_words(dm, d16) + (int64_t)slab * B::B_SLAB_PLAIN;
+    for (int i = threadIdx.x; i < B::B2_SLAB_WORDS / 4; i += blockDim.x)
+      reinterpret_cast<uint4*>(w_lds)[i] = reinterpret_cast<const uint4*>(b2)[i];
+    for (int i = threadIdx.x; i < B::B4_SLAB_WORDS / 4; i += blockDim.x)
+      reinterpret_cast<uint4*>(w_lds + B::B2_SLAB_WORDS)[i] = reinterpret_cast<const uint4*>(b4)[i];
+    for (int i = threadIdx.x; i < B::B_SLAB_PLAIN; i += blockDim.x) w_lds[W_WORDS + i] = pl[i];
+  }
+  __syncthreads();
+  const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
+  const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
+  const float* bias = reinterpret_cast<const float*>(w_lds + W_WORDS);
+  const float bt[2] = {bias[j], bias[16 + j]}, bs[2] = {bias[32 + j], bias[48 + j]};
+  const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds) + lane;  // + 64 * operand
+  // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it
+  auto w2 = [&](int dt, int net, int ks, int part_) { return W8[64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
+  auto w4 = [&](int dt, int ks, int part_) { return W8[64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
+
+  f32x4 aWt[2][YT], aWs[2][YT], aWn[2][YT];
+  float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = aWn[dt][m] = zero4;
+
+  const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+  for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kBwdBWaves) {
+    if (flags[(p * 32) / kBwdGroupRows]) continue;  // the generic kernel redoes flagged groups
+    u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2], kh[2][2], kl[2][2];  // [row tile][dim tile]: operands of the row sums
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int64_t tile = 2 * p + tt;
+      const bool has = tile < n_tiles;
+      const uint32_t* sd = side + (has ? tile : n_tiles - 1) * B::TILE_WORDS;
+      // rows 16 tile + 4 q + r
+      f32x2 zz[4], GG[4], mm[4];
+      float gl[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = tile * 16 + 4 * q + r;
+        const bool live = has && row < rows;
+        const int64_t rc = live ? row : 0;
+        f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
+        if (!RAG) {
+          zv = *reinterpret_cast<const f32x2*>(z + rc * dm + dim0);
+          if (gx) gv = *reinterpret_cast<const f32x2*>(gx + rc * dm + dim0);
+          if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mask + rc * dm + dim0);
+        } else if (vec2) {
+          if (in0) {
+            zv = *reinterpret_cast<const f32x2*>(z + rc * dm + dim0);
+            if (gx) gv = *reinterpret_cast<const f32x2*>(gx + rc * dm + dim0);
+            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mask + rc * dm + dim0);
+          }
+        } else {
+          if (in0) {
+            zv[0] = z[rc * dm + dim0];
+            if (gx) gv[0] = gx[rc * dm + dim0];
+            if (!SEEDED) mv[0] = mask[rc * dm + dim0];
+          }
+          if (in1) {
+            zv[1] = z[rc * dm + dim0 + 1];
+            if (gx) gv[1] = gx[rc * dm + dim0 + 1];
+            if (!SEEDED) mv[1] = mask[rc * dm + dim0 + 1];
+          }
+        }
+        if (SEEDED) {
+          const uint32_t w = rnvp_mask_word(seed, rc, slab) >> (2 * j);
+          mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
+        }
+        zz[r] = zv;
+        GG[r] = live ? gv * gscale : f32x2{0.f, 0.f};
+        mm[r] = mv;
+        gl[r] = (live && gld) ? gld[rc] * gscale : 0.f;
+      }
+      // y and g_y of the tile as A operands, units on K
+      f16x8 yoh[NKS2], yol[NKS2], goh[NKS2], gol[NKS2];
+#pragma unroll
+      for (int ks = 0; ks < NKS2; ++ks) {
+        yoh[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
+        yol[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
+        goh[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
+        gol[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) {
+          split_mac(yoh[ks], yol[ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
+          split_mac(yoh[ks], yol[ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+          split_mac(goh[ks], gol[ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+        }
+        const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
+        const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
+        const f32x4 gk = kc * kSplitInvScale + km;
+        f32x4 gt, gs, kk, gz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zv = zz[r][dt], G_ = GG[r][dt], m_ = mm[r][dt], nm = 1.f - m_;
+          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+          const float omg = 1.f - gate;
+          gt[r] = G_ * omg;
+          gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl[r] * nm) * omg;
+          kk[r] = m_ * zv;
+          gz[r] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;
+        }
+        abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+        abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
+        split_plain(gt, th[tt][dt], tl[tt][dt]);
+        split_plain(gs, sh[tt][dt], sl[tt][dt]);
+        split_plain(kk, kh[tt][dt], kl[tt][dt]);
+        // grad_z: the lane's dim dt of rows 4 q .. 4 q + 3 (paired with the other dim tile's below)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zz[r][dt] = gz[r];  // (z of this dim is dead: reuse its registers)
+      }
+      if (has) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = tile * 16 + 4 * q + r;
+          if (row < rows) {
+            if (!RAG) {
+              *reinterpret_cast<f32x2*>(grad_z + row * dm + dim0) = zz[r];
+            } else if (vec2) {  // (dm even: in0 implies in1)
+              if (in0) *reinterpret_cast<f32x2*>(grad_z + row * dm + dim0) = zz[r];
+            } else {
+              if (in0) grad_z[row * dm + dim0] = zz[r][0];
+              if (in1) grad_z[row * dm + dim0 + 1] = zz[r][1];
+            }
+          }
+        }
+      }
+    }
+    if (grad_flat) {
+      // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
+      const int64_t t0 = 2 * p, t1 = 2 * p + 1 < n_tiles ? 2 * p + 1 : 2 * p;
+      const bool has1 = 2 * p + 1 < n_tiles;
+      const uint32_t* s0 = side + t0 * B::TILE_WORDS;
+      const uint32_t* s1 = side + t1 * B::TILE_WORDS;
+#pragma unroll
+      for (int m = 0; m < YT; ++m) {
+        const u32x2 y0h = *reinterpret_cast<const u32x2*>(s0 + B::Y_TR + ((2 * m) * 64 + lane) * 2);
+        const u32x2 y0l = *reinterpret_cast<const u32x2*>(s0 + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2);
+        const u32x2 g0h = *reinterpret_cast<const u32x2*>(s0 + B::G_TR + ((2 * m) * 64 + lane) * 2);
+        const u32x2 g0l = *reinterpret_cast<const u32x2*>(s0 + B::G_TR + ((2 * m + 1) * 64 + lane) * 2);
+        u32x2 y1h = *reinterpret_cast<const u32x2*>(s1 + B::Y_TR + ((2 * m) * 64 + lane) * 2);
+        u32x2 y1l = *reinterpret_cast<const u32x2*>(s1 + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2);
+        u32x2 g1h = *reinterpret_cast<const u32x2*>(s1 + B::G_TR + ((2 * m) * 64 + lane) * 2);
+        u32x2 g1l = *reinterpret_cast<const u32x2*>(s1 + B::G_TR + ((2 * m + 1) * 64 + lane) * 2);
+        if (!has1) y1h = y1l = g1h = g1l = zero2;
+        const f16x8 yh8 = pair_operand(y0h, y1h), yl8 = pair_operand(y0l, y1l);
+        const f16x8 gh8 = pair_operand(g0h, g1h), gl8 = pair_operand(g0l, g1l);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f16x8 tH = pair_operand(th[0][dt], th[1][dt]), tL = pair_operand(tl[0][dt], tl[1][dt]);
+          const f16x8 sH = pair_operand(sh[0][dt], sh[1][dt]), sL = pair_operand(sl[0][dt], sl[1][dt]);
+          const f16x8 kH = pair_operand(kh[0][dt], kh[1][dt]), kL = pair_operand(kl[0][dt], kl[1][dt]);
+          aWt[dt][m] = mfma_h(yh8, tH, aWt[dt][m]);
+          aWs[dt][m] = mfma_h(yh8, sH, aWs[dt][m]);
+          aWn[dt][m] = mfma_h(gh8, kH, aWn[dt][m]);
+          aWt[dt][m] = mfma_h(yh8, tL, aWt[dt][m]);
+          aWs[dt][m] = mfma_h(yh8, sL, aWs[dt][m]);
+          aWn[dt][m] = mfma_h(gh8, kL, aWn[dt][m]);
+          aWt[dt][m] = mfma_h(yl8, tH, aWt[dt][m]);
+          aWs[dt][m] = mfma_h(yl8, sH, aWs[dt][m]);
+          aWn[dt][m] = mfma_h(gl8, kH, aWn[dt][m]);
+        }
+      }
+    }
+  }
+  if (!grad_flat) continue;
+  // flush: lane (c, q) register r of tile (dt, m) = d W [unit 16 m + 4 q + r][dim 32 slab + 2 c + dt]
+  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, btf = wt + (int64_t)dm * hn, ws = btf + dm,
+                bsf = ws + (int64_t)dm * hn;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int dim = dim0 + dt;
+    const bool in = dim < dm;
+#pragma unroll
+    for (int m = 0; m < YT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int unit = 16 * m + 4 * q + r;
+        if (in && unit < hn) {
+          atomicAdd(grad_flat + wt + (int64_t)dim * hn + unit, aWt[dt][m][r] * inv_gscale);
+          atomicAdd(grad_flat + ws + (int64_t)dim * hn + unit, aWs[dt][m][r] * inv_gscale);
+          atomicAdd(grad_flat + wn + (int64_t)unit * dm + dim, aWn[dt][m][r] * inv_gscale);
+        }
+      }
+    float vt = abt[dt], vs = abs_[dt];
+    vt += __shfl_xor(vt, 16, 64);
+    vt += __shfl_xor(vt, 32, 64);
+    vs += __shfl_xor(vs, 16, 64);
+    vs += __shfl_xor(vs, 32, 64);
+    if (in && q == 0) {
+      atomicAdd(grad_flat + btf + dim, vt * inv_gscale);
+      atomicAdd(grad_flat + bsf + dim, vs * inv_gscale);
+    }
+  }
+  }  // items
+}
+
+// ================================================================================================ host
+// index table of the backward-only image (2 entries per split word, then 1 per plain word; see build_split_index)
+template <int HN>
+static void build_bwd_index(int dm, int32_t* idx, int hn) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  const int d16 = rnvp_padded_dim(dm), G = d16 / 16, n_slabs = (int)B::n_slabs(dm);
+  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, bt = wt + (int64_t)dm * hn, ws = bt + dm,
+                bs = ws + (int64_t)dm * hn;
+  const int64_t n_split = B::split_words(dm, d16), n_entries = 2 * n_split + B::plain_words(dm);
+  for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
+  auto put = [&](int64_t base_words, int op, int lane, int e, int64_t src) {
+    for (int part = 0; part < 2; ++part)
+      idx[2 * base_words + (((int64_t)(2 * op + part) * 64 + lane) * 4 + (e >> 1)) * 2 + (e & 1)] =
+          (int32_t)src | (part ? kSplitLoBit : 0);
+  };
+  // A3: tile m, unit tile u: A[unit 16 u + i][slot 8 kq + e]; slots 0..3 of a quad = t dims 16 m + 4 kq + e, 4..7 = s dims
+  for (int m = 0; m < G; ++m)
+    for (int u = 0; u < YT; ++u)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kq = lane >> 4, unit = 16 * u + i;
+        if (unit >= hn) continue;
+        for (int e = 0; e < 8; ++e) {
+          const int dim = 16 * m + 4 * kq + (e & 3);
+          if (dim < dm) put(0, m * YT + u, lane, e, ((e >> 2) ? ws : wt) + (int64_t)dim * hn + unit);
+        }
+      }
+  // slot of a K = 32 step over units: slot 8 kq + e <-> unit 16 (2 ks + (e >> 2)) + 4 kq + (e & 3)
+  auto unit_of = [&](int ks, int kq, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * kq + (e & 3); };
+  const int64_t b2 = B::a3_words(d16), b4 = b2 + B::b2_words(dm);
+  for (int sl = 0; sl < n_slabs; ++sl)
+    for (int dt = 0; dt < 2; ++dt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int c = lane & 15, kq = lane >> 4, dim = 32 * sl + 2 * c + dt;
+        if (dim >= dm) continue;
+        for (int ks = 0; ks < NKS2; ++ks)
+          for (int e = 0; e < 8; ++e) {
+            const int unit = unit_of(ks, kq, e);
+            if (unit >= hn || 2 * ks + (e >> 2) >= YT) continue;
+            for (int net = 0; net < 2; ++net)  // B[unit][dim] = W[dim][unit]
+              put(b2 + (int64_t)sl * B::B2_SLAB_WORDS, (dt * 2 + net) * NKS2 + ks, lane, e,
+                  (net ? ws : wt) + (int64_t)dim * hn + unit);
+            put(b4 + (int64_t)sl * B::B4_SLAB_WORDS, dt * NKS2 + ks, lane, e, wn + (int64_t)unit * dm + dim);
+          }
+      }
+  int32_t* pl = idx + 2 * n_split;
+  for (int sl = 0; sl < n_slabs; ++sl)
+    for (int dt = 0; dt < 2; ++dt)
+      for (int c = 0; c < 16; ++c) {
+        const int dim = 32 * sl + 2 * c + dt;
+        const bool real = dim < dm;
+        pl[(int64_t)sl * B::B_SLAB_PLAIN + dt * 16 + c] = real ? (int32_t)(bt + dim) : -1;
+        pl[(int64_t)sl * B::B_SLAB_PLAIN + 32 + dt * 16 + c] = real ? (int32_t)(bs + dim) : kPackBigBias;
+      }
+}
+
+template <int HN>
+static int64_t bwd_workspace_bytes(int64_t rows) {
+  const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows, n_tiles = (rows + 15) / 16;
+  return ((n_groups * 4 + 255) & ~(int64_t)255) + n_tiles * RnvpBwdShape<HN>::TILE_WORDS * 4;
+}
+
+template <int HN, bool SEEDED, bool RAG>
+static int launch_bwd(const float* z, const float* mask, uint64_t seed, const float* gx, const float* gld, float* grad_z,
+                      float* grad_flat, const uint32_t* simage, const uint32_t* bimage, const float* gscale, void* work,
+                      int64_t rows, int dm, int hn, int vec4, int vec2, hipStream_t stream) {
+  using B = RnvpBwdShape<HN>;
+  const int d16 = rnvp_padded_dim(dm);
+  const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows;
+  int32_t* flags = static_cast<int32_t*>(work);
+  uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + ((n_groups * 4 + 255) & ~(int64_t)255));
+  static DeviceMemo memo_a, memo_b;
+  const int resident_a = memo_a.get(
+      [](int dev) { return resident_by_occupancy(rnvp_bwd_a_kernel<HN, SEEDED, RAG>, kRnvpWaves * 64, dev, 1); });
+  const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
+  const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
+  hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
+                     mask, gx, gld, simage, bimage, side, flags, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
+  if (int rc = check_launch()) return rc;
+  // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see the
+  // kernel); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
+  const int n_slabs = (int)B::n_slabs(dm);
+  const int resident_b = memo_b.get(
+      [](int dev) { return resident_by_occupancy(rnvp_bwd_b_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
+  const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
+  const int64_t max_parts = (n_pairs + kBwdBWaves - 1) / kBwdBWaves;  // at least one pair per wave
+  int row_parts, grid;
+  if (max_parts < 8) {
+    row_parts = (int)max_parts;
+    grid = row_parts * n_slabs;
+  } else {
+    const int wgs_xcd = resident_b / 8 > 0 ? resident_b / 8 : 1;
+    int best_l = 1;
+    double best_fill = 0.0;
+    for (int l = 1; l <= 32 && (int64_t)l * 8 <= max_parts; ++l) {
+      const int items = l * n_slabs, rounds = (items + wgs_xcd - 1) / wgs_xcd;
+      const double fill = (double)items / ((double)rounds * wgs_xcd);
+      if (fill > best_fill + 0.02) {  // (prefer fewer parts -- fewer flushes -- unless the fill improves by > 2 %)
+        best_fill = fill;
+        best_l = l;
+      }
+    }
+    row_parts = best_l * 8;
+    const int items = best_l * n_slabs;
+    grid = 8 * (items < wgs_xcd ? items : wgs_xcd);
+  }
+  hipLaunchKernelGGL((rnvp_bwd_b_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
+                     mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows, dm, d16, hn, seed, n_slabs,
+                     row_parts, vec2);
+  return check_launch();
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+using namespace mnf;
+
+int64_t mnf_rnvp_bwd_mfma_workspace_bytes(int64_t rows, int dim, int n_hidden, const int* hidden) {
+  if (rows < 0 || !rnvp_shape_ok(dim, n_hidden, hidden)) return 0;
+#define X(HN) if (rnvp_padded_hidden(n_hidden, hidden) == HN) return bwd_workspace_bytes<HN>(rows < 1 ? 1 : rows);
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return 0;
+}
+
+int mnf_rnvp_bwd_mfma_layout(int dim, int n_hidden, const int* hidden, int64_t* n_split_words, int64_t* n_plain_words) {
+  if (!n_split_words || !n_plain_words) return MNF_ERR_INVALID_ARG;
+  if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+#define X(HN)                                                                       \
+  if (rnvp_padded_hidden(n_hidden, hidden) == HN) {                                 \
+    *n_split_words = RnvpBwdShape<HN>::split_words(dim, rnvp_padded_dim(dim));      \
+    *n_plain_words = RnvpBwdShape<HN>::plain_words(dim);                            \
+    return MNF_OK;                                                                  \
+  }
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_rnvp_bwd_mfma_index(int dim, int n_hidden, const int* hidden, int32_t* idx_host) {
+  if (!idx_host) return MNF_ERR_INVALID_ARG;
+  if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+#define X(HN)                                         \
+  if (rnvp_padded_hidden(n_hidden, hidden) == HN) {   \
+    build_bwd_index<HN>(dim, idx_host, hidden[0]);    \
+    return MNF_OK;                                    \
+  }
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                      float* grad_z, float* grad_flat, const float* flat, const void* split_image, const void* bwd_image,
+                      const float* grad_scale_dev, void* workspace, int64_t workspace_bytes, int64_t rows, int dim,
+                      int n_hidden, const int* hidden, void* stream) {
+  if (!z || !grad_z || !flat || !split_image || !bwd_image || !grad_scale_dev || !workspace || rows < 0 || dim < 1 ||
+      n_hidden < 1 || !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  if (workspace_bytes < mnf_rnvp_bwd_mfma_workspace_bytes(rows, dim, n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(mask) |
+                         reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(grad_z);
+  if ((reinterpret_cast<uintptr_t>(split_image) | reinterpret_cast<uintptr_t>(bwd_image) |
+       reinterpret_cast<uintptr_t>(workspace)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+  const int d16 = rnvp_padded_dim(dim);
+  const bool ragged = d16 != dim || (dim & 31) != 0 || (ptrs & 15) != 0;
+  const int vec4 = (ptrs & 15) == 0 && (dim & 3) == 0, vec2 = (ptrs & 7) == 0 && (dim & 1) == 0;
+  const int hn_pad = rnvp_padded_hidden(n_hidden, hidden);
+  const uint32_t* si = static_cast<const uint32_t*>(split_image);
+  const uint32_t* bi = static_cast<const uint32_t*>(bwd_image);
+  const float* gs = grad_scale_dev;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = MNF_ERR_UNSUPPORTED;
+#define X(HN)                                                                                                            \
+  if (hn_pad == HN)                                                                                                      \
+    rc = mask ? (ragged ? launch_bwd<HN, false, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, st)                   \
+                        : launch_bwd<HN, false, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,    \
+                                                       workspace, rows, dim, hidden[0], vec4, vec2, st))                 \
+              : (ragged ? launch_bwd<HN, true, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,      \
+                                                     workspace, rows, dim, hidden[0], vec4, vec2, st)                    \
+                        : launch_bwd<HN, true, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, st));
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  if (rc != MNF_OK) return rc;
+  // groups outside the split range: the generic fp32 kernel, on the flagged groups only
+  return rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
+                                 static_cast<const int32_t*>(workspace), kBwdGroupRows, st);
+}
+
+}  // extern "C"

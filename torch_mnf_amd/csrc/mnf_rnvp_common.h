@@ -270,4 +270,82 @@ struct RnvpSplitShape {
   static constexpr int64_t plain_words(int d) { return (int64_t)(d / 16) * 32 + YT * 16; }  // (bt, bs) per tile, then bn
 };
 
+// ---------------------------------------------------------------- host: shapes and the split image's index table
+// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default); any other width up
+// to 50 runs at the next one up with structural-zero units (rnvp_padded_hidden)
+#define MNF_RNVP_HIDDEN(X) X(50) X(30)
+inline int rnvp_padded_hidden(int n_hidden, const int* hidden) {
+  if (n_hidden != 1 || !hidden || hidden[0] < 1) return 0;
+  return hidden[0] <= 30 ? 30 : hidden[0] <= 50 ? 50 : 0;
+}
+
+
+// dim rounded up to whole 16-dim groups (the kernels' d); a layer with dim % 16 != 0 runs the ragged variants
+inline int rnvp_padded_dim(int dim) { return (dim + 15) & ~15; }
+
+inline bool rnvp_shape_ok(int dim, int n_hidden, const int* hidden) {
+  const int d = rnvp_padded_dim(dim);
+  if (n_hidden != 1 || !hidden || dim < 1 || d < 64 || (int64_t)d * 64 * 3 >= (1ll << 30)) return false;
+#define X(HN) if (rnvp_padded_hidden(n_hidden, hidden) == HN) return true;
+  MNF_RNVP_HIDDEN(X)
+#undef X
+  return false;
+}
+
+
+// 2 entries per split word (low half, high half), then 1 entry per plain word -- see mnf_pack_gather_split
+// dm: the layer's real width (flat-parameter offsets, valid columns / rows); d: dm rounded up to 16
+// hn <= HN: the layer's real hidden width (units hn .. HN-1 are structural zeros: y = 0 there)
+template <int HN>
+inline void build_split_index(int dm, int d, int32_t* idx, int hn = HN) {
+  using S = RnvpSplitShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  const int G = d / 16;
+  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, bt = wt + (int64_t)dm * hn, ws = bt + dm,
+                bs = ws + (int64_t)dm * hn;
+  const int64_t n_entries = 2 * S::split_words(d) + S::plain_words(d);
+  for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
+  // element e of lane (i, kq) of operand `op` (hi at 2 op, lo at 2 op + 1), base = first word of the region
+  auto put = [&](int64_t base_words, int op, int lane, int e, int64_t src) {
+    for (int part = 0; part < 2; ++part)
+      idx[2 * base_words + (((int64_t)(2 * op + part) * 64 + lane) * 4 + (e >> 1)) * 2 + (e & 1)] =
+          (int32_t)src | (part ? kSplitLoBit : 0);
+  };
+  // part 1: K-step ks covers groups 2 ks (slots 8 kq + 0..3) and 2 ks + 1 (slots 8 kq + 4..7)
+  for (int ks = 0; ks < S::n_ks1(d); ++ks)
+    for (int m = 0; m < YT; ++m)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
+        if (u >= hn) continue;
+        for (int e = 0; e < 8; ++e) {
+          const int g = 2 * ks + (e >> 2), col = 16 * g + 4 * kq + (e & 3);
+          if (g < G && col < dm) put(0, ks * YT + m, lane, e, wn + (int64_t)u * dm + col);
+        }
+      }
+  // part 2: per output tile m: t operands for K-steps 0..NKS2-1, then s operands
+  for (int m = 0; m < G; ++m)
+    for (int which = 0; which < 2; ++which)
+      for (int ks = 0; ks < NKS2; ++ks)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4;
+          for (int e = 0; e < 8; ++e) {
+            const int tile = 2 * ks + (e >> 2), unit = 16 * tile + 4 * kq + (e & 3);
+            if (tile < YT && unit < hn && 16 * m + i < dm)
+              put(S::part1_words(d) + (int64_t)m * S::TILE2_WORDS, which * NKS2 + ks, lane, e,
+                  (which ? ws : wt) + (int64_t)(16 * m + i) * hn + unit);
+          }
+        }
+  int32_t* pl = idx + 2 * S::split_words(d);
+  for (int m = 0; m < G; ++m)
+    for (int i = 0; i < 16; ++i) {
+      const bool real = 16 * m + i < dm;  // padded output dims: shift 0, scale bias "big" (gate 1, log gate 0)
+      pl[(int64_t)m * 32 + i] = real ? (int32_t)(bt + 16 * m + i) : -1;
+      pl[(int64_t)m * 32 + 16 + i] = real ? (int32_t)(bs + 16 * m + i) : kPackBigBias;
+    }
+  for (int m = 0; m < YT; ++m)
+    for (int i = 0; i < 16; ++i)
+      if (16 * m + i < hn) pl[(int64_t)G * 32 + m * 16 + i] = (int32_t)(bn + 16 * m + i);
+}
+
+
 }  // namespace mnf

@@ -39,6 +39,8 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 # scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
 # 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
 _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
+# MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
+_RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 # MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
@@ -326,7 +328,25 @@ class _RnvpFn(torch.autograd.Function):
         gl = None if grad_ld is None else grad_ld.contiguous()
         grad_z = torch.empty_like(z)
         grad_flat = torch.zeros_like(flat)
-        _lib.check("mnf_rnvp_bwd", _lib.load().mnf_rnvp_bwd(
+        lib = _lib.load()
+        if gx is None and gl is None:
+            return grad_z.zero_(), grad_flat, None, None, None
+        # the matrix-core gradient kernels (two launches + the fp32 fix-up over flagged row groups); shapes they do not
+        # cover, the fp32 switches and force_generic take the generic kernel
+        bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV) else m._bwd_image(z.device, flat)
+        split = m._split_image(z.device) if bwd is not None else None
+        if bwd is not None and split is not None:
+            rows = z.shape[0]
+            work = m._bwd_workspace(lib, rows, z.device)
+            scale = _grad_scale(gx, gl, rows, m.dim, z.device)
+            rc = lib.mnf_rnvp_bwd_mfma(
+                z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
+                flat.data_ptr(), split.data_ptr(), bwd.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(), rows,
+                m.dim, len(m.h_sizes), m._hid, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_rnvp_bwd_mfma", rc)
+                return grad_z, grad_flat, None, None, None
+        _lib.check("mnf_rnvp_bwd", lib.mnf_rnvp_bwd(
             z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
             flat.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
         return grad_z, grad_flat, None, None, None
@@ -909,6 +929,9 @@ def rqs(inputs: Tensor, W: Tensor, H: Tensor, D: Tensor, inverse: bool = False,
     return out.reshape(shape), lad.reshape(shape)
 
 
+_RNVP_BWD_WORK: dict = {}  # device -> scratch of mnf_rnvp_bwd_mfma
+
+
 class RNVP(_HipFlow):
     """Forward-only masked/gated coupling used by the MNF layers (flows/rnvp.py:7-39).
 
@@ -950,6 +973,48 @@ class RNVP(_HipFlow):
         idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
         _lib.check("mnf_rnvp_split_index", lib.mnf_rnvp_split_index(self.dim, len(self.h_sizes), self._hid, idx))
         return idx, n_split.value, n_plain.value
+
+    def _bwd_index(self, device):
+        """(device index table, n_split_words, n_plain_words) of the gradient kernels' operand image, or False."""
+        cached = self.__dict__.get("_bwd_idx")
+        if cached is None or (cached and cached[0].device != device):
+            lib = _lib.load()
+            n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = lib.mnf_rnvp_bwd_mfma_layout(self.dim, len(self.h_sizes), self._hid, ctypes.byref(n_split),
+                                              ctypes.byref(n_plain))
+            if rc == _lib.MNF_ERR_UNSUPPORTED:
+                cached = False
+            else:
+                _lib.check("mnf_rnvp_bwd_mfma_layout", rc)
+                idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+                _lib.check("mnf_rnvp_bwd_mfma_index", lib.mnf_rnvp_bwd_mfma_index(self.dim, len(self.h_sizes), self._hid, idx))
+                cached = (torch.frombuffer(idx, dtype=torch.int32).clone().to(device), n_split.value, n_plain.value)
+            self.__dict__["_bwd_idx"] = cached
+        return cached
+
+    def _bwd_image(self, device, flat: Tensor) -> Tensor | None:
+        """The gradient kernels' operand image for the parameters in ``flat`` (repacked per backward pass: the weights
+        change between steps, and the pack is one small launch), or None when the shape has no such kernels."""
+        if self.force_fp32_mfma or _FP32_MFMA_ENV or not self._split_ok:
+            return None
+        table = self._bwd_index(device)
+        if not table:
+            return None
+        idx, n_split, n_plain = table
+        image = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=device)
+        _lib.check("mnf_pack_gather_split", _lib.load().mnf_pack_gather_split(
+            flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, n_plain, _stream()))
+        return image
+
+    def _bwd_workspace(self, lib, rows: int, device) -> Tensor:
+        """Scratch of the gradient kernels (1 KB per row + flags).  One buffer per device, shared by every RNVP layer
+        and grown on demand: the layers' backward passes follow one another on the stream."""
+        need = int(lib.mnf_rnvp_bwd_mfma_workspace_bytes(rows, self.dim, len(self.h_sizes), self._hid))
+        work = _RNVP_BWD_WORK.get(device)
+        if work is None or work.numel() < need:
+            work = torch.empty(need, dtype=torch.uint8, device=device)
+            _RNVP_BWD_WORK[device] = work
+        return work
 
     def mask_for(self, seed: int, rows: int, device="cuda") -> Tensor:
         m = torch.empty(rows, self.dim, dtype=torch.float32, device=device)
