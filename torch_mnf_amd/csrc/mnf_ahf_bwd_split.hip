@@ -659,6 +659,17 @@ __global__ void __launch_bounds__(256) ahf_bwd_reduce_kernel(const float* __rest
 // non-finite sample): one workgroup, the sample is small.  The sample is spread evenly over the whole batch (row
 // s * stride): a sorted, masked or weighted batch whose first rows carry no or atypically small cotangents would
 // otherwise set a scale that leaves the rest far outside [1, 2).
+__device__ __forceinline__ float scale_of_max(float m) {
+  float scale = 1.f;
+  if (m > 0.f && m < __builtin_inff()) {
+    int e;
+    frexpf(m, &e);  // m = f 2^e, f in [0.5, 1)
+    e = 1 - e;
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    scale = ldexpf(1.f, e);
+  }
+  return scale;
+}
 __global__ void __launch_bounds__(1024) grad_scale_kernel(const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                                                           int64_t sample, int64_t stride, int dim,
                                                           float* __restrict__ scale_out) {
@@ -676,16 +687,33 @@ __global__ void __launch_bounds__(1024) grad_scale_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, part[w]);
-    float scale = 1.f;
-    if (m > 0.f && m < __builtin_inff()) {
-      int e;
-      frexpf(m, &e);  // m = f 2^e, f in [0.5, 1)
-      e = 1 - e;
-      e = e > 120 ? 120 : (e < -120 ? -120 : e);
-      scale = ldexpf(1.f, e);
-    }
-    scale_out[0] = scale;
+    scale_out[0] = scale_of_max(m);
   }
+}
+
+// Wide rows (RNVP at d = 800: 512 x 800 sample values): the same maximum over several workgroups -- sample rows
+// blockIdx.x, blockIdx.x + gridDim.x, ... each -- collected with one atomic per workgroup into *scale_out (zeroed by the
+// caller; non-negative floats order like their bit patterns), then turned into the power of two by one thread.
+__global__ void __launch_bounds__(256) grad_max_kernel(const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
+                                                       int64_t sample, int64_t stride, int dim,
+                                                       uint32_t* __restrict__ max_bits) {
+  __shared__ float part[4];
+  float m = 0.f;
+  for (int64_t r = blockIdx.x; r < sample; r += gridDim.x) {
+    if (grad_y)
+      for (int c = threadIdx.x; c < dim; c += blockDim.x) m = fmaxf(m, fabsf(grad_y[r * stride * dim + c]));
+    if (grad_ld && threadIdx.x == 0) m = fmaxf(m, fabsf(grad_ld[r * stride]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, part[w]);
+    if (m > 0.f) atomicMax(max_bits, __builtin_bit_cast(uint32_t, m));
+  }
+}
+__global__ void grad_scale_finalize_kernel(float* __restrict__ scale_out) {
+  scale_out[0] = scale_of_max(scale_out[0]);
 }
 
 // ---------------------------------------------------------------- host: index table of the backward split image
@@ -868,6 +896,14 @@ int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_
   if (!scale_out || rows < 0 || dim < 1 || (!grad_y && !grad_ld)) return MNF_ERR_INVALID_ARG;
   const int64_t sample = rows < 512 ? rows : 512;  // (one workgroup: a larger sample costs more than it tells)
   const int64_t stride = sample > 0 ? rows / sample : 1;  // rows 0, stride, 2 stride, ...: spread over the whole batch
+  if (grad_y && sample * dim > 65536) {  // wide rows: several workgroups (one took 150 us at 512 x 800)
+    if (hipMemsetAsync(scale_out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return mnf::check_launch();
+    hipLaunchKernelGGL(mnf::grad_max_kernel, dim3((unsigned)(sample < 128 ? sample : 128)), dim3(256), 0,
+                       (hipStream_t)stream, grad_y, grad_ld, sample, stride, dim, reinterpret_cast<uint32_t*>(scale_out));
+    if (int rc = mnf::check_launch()) return rc;
+    hipLaunchKernelGGL(mnf::grad_scale_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale_out);
+    return mnf::check_launch();
+  }
   hipLaunchKernelGGL(mnf::grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, grad_y, grad_ld, sample,
                      stride, dim, scale_out);
   return mnf::check_launch();

@@ -677,14 +677,12 @@ struct RnvpBwdArgs {
   uint64_t seed;
   int act_off[MNF_MAX_LINEAR];
   NetDesc net;
-  const int32_t* flags;  // non-null: only the row groups (rows_per_flag rows each, a multiple of R) flagged non-zero
-  int rows_per_flag;
+  const int32_t* list;  // non-null: only the row groups list[1 .. list[0]] (rows_per_group rows each, a multiple of R)
+  int rows_per_group;
 };
 
-__global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
+__device__ __forceinline__ void rnvp_bwd_block(const RnvpBwdArgs& a, const int64_t row0) {
   const int d = a.dim, hl = a.net.sizes[a.net.n_lin];
-  const int64_t row0 = (int64_t)blockIdx.x * a.R;
-  if (a.flags && a.flags[row0 / a.rows_per_flag] == 0) return;  // (block-uniform)
   const int R = (int)min((int64_t)a.R, a.rows - row0);
   float* kept = bsmem;                 // [R][d]  m z
   float* g_t = kept + a.R * d;         // [R][d]
@@ -754,6 +752,22 @@ __global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
   for (int idx = threadIdx.x; idx < R * d; idx += blockDim.x) {
     const int r = idx / d, j = idx - r * d;
     a.grad_z[(row0 + r) * d + j] += mask_of(r, j) * g_kept[idx];
+  }
+}
+
+__global__ void __launch_bounds__(kBwdThreads) rnvp_bwd_kernel(RnvpBwdArgs a) {
+  if (a.list == nullptr) {
+    rnvp_bwd_block(a, (int64_t)blockIdx.x * a.R);
+    return;
+  }
+  // fix-up pass: a fixed grid walks the listed row groups (an empty list costs one load per workgroup)
+  const int n = a.list[0];
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int64_t g0 = (int64_t)a.list[1 + e] * a.rows_per_group;
+    for (int64_t row0 = g0; row0 < g0 + a.rows_per_group && row0 < a.rows; row0 += a.R) {
+      __syncthreads();  // the previous rows' LDS contents are no longer read
+      rnvp_bwd_block(a, row0);
+    }
   }
 }
 
@@ -961,11 +975,11 @@ int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
 }  // extern "C"
 
 namespace mnf {
-// flags != nullptr: the fix-up pass of mnf_rnvp_bwd_mfma -- only row groups of `rows_per_flag` rows with a non-zero flag
-// are computed (every other workgroup returns at once); rows per workgroup then divide rows_per_flag
+// list != nullptr: the fix-up pass of mnf_rnvp_bwd_mfma -- only the row groups list[1 .. list[0]] (device memory) of
+// `rows_per_group` rows each are computed, by a fixed grid; rows per workgroup then divide rows_per_group
 int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
                             float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
-                            const int* hidden, const int32_t* flags, int rows_per_flag, hipStream_t stream) {
+                            const int* hidden, const int32_t* list, int rows_per_group, hipStream_t stream) {
   if (!z || !grad_z || !flat || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
@@ -973,7 +987,7 @@ int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, co
   memset(&a, 0, sizeof(a));
   a.z = z; a.mask = mask; a.seed = seed; a.grad_x = grad_x; a.grad_ld = grad_ld; a.grad_z = grad_z;
   a.grad_flat = grad_flat; a.flat = flat; a.rows = rows; a.dim = dim;
-  a.flags = flags; a.rows_per_flag = rows_per_flag;
+  a.list = list; a.rows_per_group = rows_per_group;
   int sizes[MNF_MAX_LINEAR + 1];
   sizes[0] = dim;
   for (int i = 0; i < n_hidden; ++i) sizes[1 + i] = hidden[i];
@@ -994,13 +1008,13 @@ int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, co
   int R = kBwdLdsFloats / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
   if (R > 32) R = 32;
-  if (flags) {  // a workgroup must not straddle two flag groups
+  if (list) {  // a workgroup must not straddle two groups
     int r2 = 1;
-    while (2 * r2 <= R && rows_per_flag % (2 * r2) == 0) r2 *= 2;
+    while (2 * r2 <= R && rows_per_group % (2 * r2) == 0) r2 *= 2;
     R = r2;
   }
   a.R = R;
-  const int64_t blocks = (rows + R - 1) / R;
+  const int64_t blocks = list ? 256 : (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      stream, a);

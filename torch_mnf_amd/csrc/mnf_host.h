@@ -126,10 +126,10 @@ int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulat
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
                          const float* q0_log_var, int vec, hipStream_t stream);
 
-// the generic RNVP gradient kernel (mnf_backward.hip); flags != nullptr: only the flagged row groups (the fix-up pass
-// of mnf_rnvp_bwd_mfma)
+// the generic RNVP gradient kernel (mnf_backward.hip); list != nullptr: only the row groups list[1 .. list[0]] (the
+// fix-up pass of mnf_rnvp_bwd_mfma)
 int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
                             float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
-                            const int* hidden, const int32_t* flags, int rows_per_flag, hipStream_t stream);
+                            const int* hidden, const int32_t* list, int rows_per_group, hipStream_t stream);
 
 }  // namespace mnf

@@ -47,6 +47,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBwdGroupRows = 16 * kRnvpWaves;  // rows per flag (A's 8-wave group)
 constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
+#ifndef MNF_RNVP_BWD_ABL
+#define MNF_RNVP_BWD_ABL 0  // timing experiments only (results are wrong): bit 0 no hand-over loads in B, bit 1 no row
+#endif                      // loads, bit 2 no row-sum MFMAs, bit 3 no grad_z stores, bit 4 no K = units MFMAs
+constexpr int kBwdAbl = MNF_RNVP_BWD_ABL;
+#ifndef MNF_RNVP_BWD_B_OCC
+#define MNF_RNVP_BWD_B_OCC 1  // waves per SIMD launch B is compiled for (experiment switch: 2 -> 256 registers, spills)
+#endif
 
 template <int HN>
 struct RnvpBwdShape {
@@ -99,7 +106,8 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
                                                  const float* __restrict__ mask, const float* __restrict__ gx,
                                                  const float* __restrict__ gld, const uint32_t* __restrict__ simage,
                                                  const uint32_t* __restrict__ bimage, uint32_t* __restrict__ side,
-                                                 int32_t* __restrict__ flags, float gscale, bool weights_ok,
+                                                 int32_t* __restrict__ flags, int32_t* __restrict__ list, float gscale,
+                                                 bool weights_ok,
                                                  f32x4 (&bn_acc)[RnvpSplitShape<HN>::YT], int64_t rows, int d,
                                                  uint64_t seed, int dm_ragged, bool vec) {
   using S = RnvpSplitShape<HN>;
@@ -308,7 +316,10 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
     split_tile(gy[m], gh[m], gl2[m], mx);
   }
   const bool bad = __syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0) != 0;
-  if (threadIdx.x == 0) flags[grp] = bad ? 1 : 0;
+  if (threadIdx.x == 0) {
+    flags[grp] = bad ? 1 : 0;
+    if (bad) list[1 + atomicAdd(list, 1)] = grp;  // (list[0] zeroed by the launcher)
+  }
   if (bad) return;
   const int64_t tile = (int64_t)grp * kRnvpWaves + wave;
   if (tile * 16 >= rows) return;  // wave-uniform: a tile past the end (the group's last rows)
@@ -356,9 +367,9 @@ template <int HN, bool SEEDED, bool RAG>
 __global__ void __launch_bounds__(kRnvpWaves * 64, 2)
 rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
                   const float* __restrict__ gld, const uint32_t* __restrict__ simage, const uint32_t* __restrict__ bimage,
-                  uint32_t* __restrict__ side, int32_t* __restrict__ flags, const float* __restrict__ gscale_dev,
-                  float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged, int hn, uint64_t seed, int vec_ok,
-                  int64_t bimage_tail) {
+                  uint32_t* __restrict__ side, int32_t* __restrict__ flags, int32_t* __restrict__ list,
+                  const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged,
+                  int hn, uint64_t seed, int vec_ok, int64_t bimage_tail) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][B::CHUNK_WORDS];
@@ -372,7 +383,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   for (int m = 0; m < S::YT; ++m) bn_acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int n_groups = (int)((rows + kBwdGroupRows - 1) / kBwdGroupRows);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
-    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, gscale,
+    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
                                       weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0);
   // dbn: sum over the wave's rows (the 16 lanes j of a q), one atomic per unit per wave
   if (grad_flat) {
@@ -397,7 +408,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
 // ================================================================================================ kernel B
 // lane (c, q): column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers
 template <int HN, bool SEEDED, bool RAG>
-__global__ void __launch_bounds__(kBwdBWaves * 64, 2)
+__global__ void __launch_bounds__(kBwdBWaves * 64, MNF_RNVP_BWD_B_OCC)
 rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
                   const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
                   const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
@@ -441,10 +452,13 @@ rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
   const float* bias = reinterpret_cast<const float*>(w_lds + W_WORDS);
   const float bt[2] = {bias[j], bias[16 + j]}, bs[2] = {bias[32 + j], bias[48 + j]};
-  const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds) + lane;  // + 64 * operand
-  // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it
-  auto w2 = [&](int dt, int net, int ks, int part_) { return W8[64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
-  auto w4 = [&](int dt, int ks, int part_) { return W8[64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
+  // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it.  The reads
+  // do not depend on the row pair: an opaque offset, refreshed per pair, keeps hipcc from hoisting 24 KB of operands
+  // out of the pair loop into registers (it did: 240 spilled registers)
+  int w_lane = lane;
+  const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds);  // (16-byte aligned: one ds_read_b128 per operand)
+  auto w2 = [&](int dt, int net, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
+  auto w4 = [&](int dt, int ks, int part_) { return W8[w_lane + 64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
 
   f32x4 aWt[2][YT], aWs[2][YT], aWn[2][YT];
   float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
@@ -453,73 +467,133 @@ rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
 #pragma unroll
     for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = aWn[dt][m] = zero4;
 
-  const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
-  for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kBwdBWaves) {
-    if (flags[(p * 32) / kBwdGroupRows]) continue;  // the generic kernel redoes flagged groups
+  // One wave per SIMD (the accumulators, the operands of the row sums and a pair's inputs take ~400 registers), so
+  // nothing but the wave itself hides a load's latency: the NEXT pair's row data and K = units operands are requested
+  // before the current pair is computed (two register sets, the loop is unrolled by two), the K = rows operands of the
+  // current pair at its start -- they are needed last.
+  struct Inputs {
+    f32x2 zz[2][4], GG[2][4], mm[2][4];
+    float gl[2][4];
+    bool skip;
+  };
+  // row r of tile T, the lane's two dims: element (16 T + 4 q + r) dm + dim0 = [tile base, wave-uniform] + lane_off + r dm
+  const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
+  const float* gsrc = gx ? gx : z;               // (no cotangent for x: read z and multiply by zero)
+  const float gx_scale = gx ? gscale : 0.f;
+  const float gl_scale = gld ? gscale : 0.f;
+  const float* lsrc = gld ? gld : z;
+  auto load_inputs = [&](int64_t p, Inputs& in) {
+    in.skip = flags[(p * 32) / kBwdGroupRows] != 0;  // the generic kernel redoes flagged groups
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int64_t tile = 2 * p + tt;
+      const bool has = tile < n_tiles;
+      const int64_t tbase = (has ? tile : n_tiles - 1) * 16;       // wave-uniform
+      const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
+      const float* zt = z + tbase * dm;
+      const float* gt_ = gsrc + tbase * dm;
+      const float* mt = SEEDED ? nullptr : mask + tbase * dm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * q + r;
+        const bool live = rr < n_live;
+        // a row past the end reads the tile's first row instead (its cotangents are zeroed, nothing of it is stored)
+        const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0;
+        f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
+        if (kBwdAbl & 2) {
+          zv = gv = f32x2{0.25f * lane, 1.f};
+        } else if (!RAG) {
+          zv = *reinterpret_cast<const f32x2*>(zt + off);
+          gv = *reinterpret_cast<const f32x2*>(gt_ + off);
+          if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
+        } else if (vec2) {
+          if (in0) {
+            zv = *reinterpret_cast<const f32x2*>(zt + off);
+            gv = *reinterpret_cast<const f32x2*>(gt_ + off);
+            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
+          }
+        } else {
+          if (in0) {
+            zv[0] = zt[off];
+            gv[0] = gt_[off];
+            if (!SEEDED) mv[0] = mt[off];
+          }
+          if (in1) {
+            zv[1] = zt[off + 1];
+            gv[1] = gt_[off + 1];
+            if (!SEEDED) mv[1] = mt[off + 1];
+          }
+        }
+        if (SEEDED) {
+          const uint32_t w = rnvp_mask_word(seed, tbase + (live ? rr : 0), slab) >> (2 * j);
+          mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
+        }
+        const float keep = live ? 1.f : 0.f;
+        in.zz[tt][r] = zv;
+        in.GG[tt][r] = gv * (gx_scale * keep);
+        in.mm[tt][r] = mv;
+        in.gl[tt][r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
+      }
+    }
+  };
+  auto compute = [&](int64_t p, Inputs& in) {
+    if (in.skip) return;
+    asm volatile("" : "+v"(w_lane));
+    // the pair's hand-over from launch A (L2): K = units operands now, K = rows operands for the row sums at the end
+    const bool has1 = 2 * p + 1 < n_tiles;
+    f16x8 yoh[2][NKS2], yol[2][NKS2], goh[2][NKS2], gol[2][NKS2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const uint32_t* sd = side + (2 * p + (has1 ? tt : 0)) * B::TILE_WORDS;
+#pragma unroll
+      for (int ks = 0; ks < NKS2; ++ks) {
+        if (kBwdAbl & 1) {
+          yoh[tt][ks] = yol[tt][ks] = goh[tt][ks] = gol[tt][ks] = w2(0, 0, ks, 0);
+          continue;
+        }
+        yoh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
+        yol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
+        goh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
+        gol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
+      }
+    }
+    u32x2 ytr[2][YT][2], gtr[2][YT][2];
+    if (grad_flat) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const uint32_t* st = side + (2 * p + (has1 ? tt : 0)) * B::TILE_WORDS;
+#pragma unroll
+        for (int m = 0; m < YT; ++m)
+#pragma unroll
+          for (int part_ = 0; part_ < 2; ++part_) {
+            if (kBwdAbl & 1) {
+              ytr[tt][m][part_] = gtr[tt][m][part_] = u32x2{(uint32_t)lane, (uint32_t)m};
+              continue;
+            }
+            ytr[tt][m][part_] = *reinterpret_cast<const u32x2*>(st + B::Y_TR + ((2 * m + part_) * 64 + lane) * 2);
+            gtr[tt][m][part_] = *reinterpret_cast<const u32x2*>(st + B::G_TR + ((2 * m + part_) * 64 + lane) * 2);
+          }
+      }
+    }
     u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2], kh[2][2], kl[2][2];  // [row tile][dim tile]: operands of the row sums
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int64_t tile = 2 * p + tt;
       const bool has = tile < n_tiles;
-      const uint32_t* sd = side + (has ? tile : n_tiles - 1) * B::TILE_WORDS;
-      // rows 16 tile + 4 q + r
-      f32x2 zz[4], GG[4], mm[4];
-      float gl[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = tile * 16 + 4 * q + r;
-        const bool live = has && row < rows;
-        const int64_t rc = live ? row : 0;
-        f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
-        if (!RAG) {
-          zv = *reinterpret_cast<const f32x2*>(z + rc * dm + dim0);
-          if (gx) gv = *reinterpret_cast<const f32x2*>(gx + rc * dm + dim0);
-          if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mask + rc * dm + dim0);
-        } else if (vec2) {
-          if (in0) {
-            zv = *reinterpret_cast<const f32x2*>(z + rc * dm + dim0);
-            if (gx) gv = *reinterpret_cast<const f32x2*>(gx + rc * dm + dim0);
-            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mask + rc * dm + dim0);
-          }
-        } else {
-          if (in0) {
-            zv[0] = z[rc * dm + dim0];
-            if (gx) gv[0] = gx[rc * dm + dim0];
-            if (!SEEDED) mv[0] = mask[rc * dm + dim0];
-          }
-          if (in1) {
-            zv[1] = z[rc * dm + dim0 + 1];
-            if (gx) gv[1] = gx[rc * dm + dim0 + 1];
-            if (!SEEDED) mv[1] = mask[rc * dm + dim0 + 1];
-          }
-        }
-        if (SEEDED) {
-          const uint32_t w = rnvp_mask_word(seed, rc, slab) >> (2 * j);
-          mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
-        }
-        zz[r] = zv;
-        GG[r] = live ? gv * gscale : f32x2{0.f, 0.f};
-        mm[r] = mv;
-        gl[r] = (live && gld) ? gld[rc] * gscale : 0.f;
-      }
-      // y and g_y of the tile as A operands, units on K
-      f16x8 yoh[NKS2], yol[NKS2], goh[NKS2], gol[NKS2];
-#pragma unroll
-      for (int ks = 0; ks < NKS2; ++ks) {
-        yoh[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
-        yol[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
-        goh[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
-        gol[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
-      }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
         f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
 #pragma unroll
         for (int ks = 0; ks < NKS2; ++ks) {
-          split_mac(yoh[ks], yol[ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
-          split_mac(yoh[ks], yol[ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
-          split_mac(goh[ks], gol[ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+          if (kBwdAbl & 16) {
+            tm += __builtin_bit_cast(f32x4, yoh[tt][ks]);
+            sm += __builtin_bit_cast(f32x4, goh[tt][ks]);
+            continue;
+          }
+          split_mac(yoh[tt][ks], yol[tt][ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
+          split_mac(yoh[tt][ks], yol[tt][ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+          split_mac(goh[tt][ks], gol[tt][ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
         }
         const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
         const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
@@ -527,11 +601,11 @@ rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
         f32x4 gt, gs, kk, gz;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float zv = zz[r][dt], G_ = GG[r][dt], m_ = mm[r][dt], nm = 1.f - m_;
+          const float zv = in.zz[tt][r][dt], G_ = in.GG[tt][r][dt], m_ = in.mm[tt][r][dt], nm = 1.f - m_;
           const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
           const float omg = 1.f - gate;
           gt[r] = G_ * omg;
-          gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl[r] * nm) * omg;
+          gs[r] = (G_ * (nm * zv - t4[r]) * gate + in.gl[tt][r] * nm) * omg;
           kk[r] = m_ * zv;
           gz[r] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;
         }
@@ -540,46 +614,36 @@ rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
         split_plain(gt, th[tt][dt], tl[tt][dt]);
         split_plain(gs, sh[tt][dt], sl[tt][dt]);
         split_plain(kk, kh[tt][dt], kl[tt][dt]);
-        // grad_z: the lane's dim dt of rows 4 q .. 4 q + 3 (paired with the other dim tile's below)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zz[r][dt] = gz[r];  // (z of this dim is dead: reuse its registers)
+        for (int r = 0; r < 4; ++r) in.zz[tt][r][dt] = gz[r];  // (z of this dim is dead: its registers take grad_z)
       }
-      if (has) {
+      if (has && (!(kBwdAbl & 8) || in.zz[tt][0][0] == 1.2345e30f)) {
+        const int n_live = (int)min((int64_t)16, rows - tile * 16);
+        float* ot = grad_z + tile * 16 * dm;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = tile * 16 + 4 * q + r;
-          if (row < rows) {
+          if (4 * q + r < n_live) {
+            const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
             if (!RAG) {
-              *reinterpret_cast<f32x2*>(grad_z + row * dm + dim0) = zz[r];
+              *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
             } else if (vec2) {  // (dm even: in0 implies in1)
-              if (in0) *reinterpret_cast<f32x2*>(grad_z + row * dm + dim0) = zz[r];
+              if (in0) *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
             } else {
-              if (in0) grad_z[row * dm + dim0] = zz[r][0];
-              if (in1) grad_z[row * dm + dim0 + 1] = zz[r][1];
+              if (in0) ot[off] = in.zz[tt][r][0];
+              if (in1) ot[off + 1] = in.zz[tt][r][1];
             }
           }
         }
       }
     }
-    if (grad_flat) {
+    if (grad_flat && !(kBwdAbl & 4)) {
       // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
-      const int64_t t0 = 2 * p, t1 = 2 * p + 1 < n_tiles ? 2 * p + 1 : 2 * p;
-      const bool has1 = 2 * p + 1 < n_tiles;
-      const uint32_t* s0 = side + t0 * B::TILE_WORDS;
-      const uint32_t* s1 = side + t1 * B::TILE_WORDS;
 #pragma unroll
       for (int m = 0; m < YT; ++m) {
-        const u32x2 y0h = *reinterpret_cast<const u32x2*>(s0 + B::Y_TR + ((2 * m) * 64 + lane) * 2);
-        const u32x2 y0l = *reinterpret_cast<const u32x2*>(s0 + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2);
-        const u32x2 g0h = *reinterpret_cast<const u32x2*>(s0 + B::G_TR + ((2 * m) * 64 + lane) * 2);
-        const u32x2 g0l = *reinterpret_cast<const u32x2*>(s0 + B::G_TR + ((2 * m + 1) * 64 + lane) * 2);
-        u32x2 y1h = *reinterpret_cast<const u32x2*>(s1 + B::Y_TR + ((2 * m) * 64 + lane) * 2);
-        u32x2 y1l = *reinterpret_cast<const u32x2*>(s1 + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2);
-        u32x2 g1h = *reinterpret_cast<const u32x2*>(s1 + B::G_TR + ((2 * m) * 64 + lane) * 2);
-        u32x2 g1l = *reinterpret_cast<const u32x2*>(s1 + B::G_TR + ((2 * m + 1) * 64 + lane) * 2);
-        if (!has1) y1h = y1l = g1h = g1l = zero2;
-        const f16x8 yh8 = pair_operand(y0h, y1h), yl8 = pair_operand(y0l, y1l);
-        const f16x8 gh8 = pair_operand(g0h, g1h), gl8 = pair_operand(g0l, g1l);
+        const f16x8 yh8 = pair_operand(ytr[0][m][0], has1 ? ytr[1][m][0] : zero2);
+        const f16x8 yl8 = pair_operand(ytr[0][m][1], has1 ? ytr[1][m][1] : zero2);
+        const f16x8 gh8 = pair_operand(gtr[0][m][0], has1 ? gtr[1][m][0] : zero2);
+        const f16x8 gl8 = pair_operand(gtr[0][m][1], has1 ? gtr[1][m][1] : zero2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const f16x8 tH = pair_operand(th[0][dt], th[1][dt]), tL = pair_operand(tl[0][dt], tl[1][dt]);
@@ -596,6 +660,23 @@ rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
           aWn[dt][m] = mfma_h(gl8, kH, aWn[dt][m]);
         }
       }
+    }
+  };
+  {
+    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    int64_t p = (int64_t)part * per_part + wave;
+    Inputs ia, ib;
+    if (p < p_end) load_inputs(p, ia);
+    while (p < p_end) {
+      int64_t pn = p + kBwdBWaves;
+      if (pn < p_end) load_inputs(pn, ib);
+      compute(p, ia);
+      p = pn;
+      if (p >= p_end) break;
+      pn = p + kBwdBWaves;
+      if (pn < p_end) load_inputs(pn, ia);
+      compute(p, ib);
+      p = pn;
     }
   }
   if (!grad_flat) continue;
@@ -687,10 +768,14 @@ static void build_bwd_index(int dm, int32_t* idx, int hn) {
       }
 }
 
+// workspace: [list: count, then up to n_groups flagged groups][flags: n_groups], padded to 256 B; then the hand-over
+static int64_t bwd_header_bytes(int64_t rows) {
+  const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows;
+  return (((1 + 2 * n_groups) * 4 + 255) & ~(int64_t)255);
+}
 template <int HN>
 static int64_t bwd_workspace_bytes(int64_t rows) {
-  const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows, n_tiles = (rows + 15) / 16;
-  return ((n_groups * 4 + 255) & ~(int64_t)255) + n_tiles * RnvpBwdShape<HN>::TILE_WORDS * 4;
+  return bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4;
 }
 
 template <int HN, bool SEEDED, bool RAG>
@@ -700,15 +785,17 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   using B = RnvpBwdShape<HN>;
   const int d16 = rnvp_padded_dim(dm);
   const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows;
-  int32_t* flags = static_cast<int32_t*>(work);
-  uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + ((n_groups * 4 + 255) & ~(int64_t)255));
+  int32_t* list = static_cast<int32_t*>(work);
+  int32_t* flags = list + 1 + n_groups;
+  uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + bwd_header_bytes(rows));
+  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
   static DeviceMemo memo_a, memo_b;
   const int resident_a = memo_a.get(
       [](int dev) { return resident_by_occupancy(rnvp_bwd_a_kernel<HN, SEEDED, RAG>, kRnvpWaves * 64, dev, 1); });
   const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
-                     mask, gx, gld, simage, bimage, side, flags, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
+                     mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
   if (int rc = check_launch()) return rc;
   // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see the
   // kernel); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
@@ -823,7 +910,7 @@ int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const fl
   if (rc != MNF_OK) return rc;
   // groups outside the split range: the generic fp32 kernel, on the flagged groups only
   return rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
-                                 static_cast<const int32_t*>(workspace), kBwdGroupRows, st);
+                                 static_cast<const int32_t*>(workspace), kBwdGroupRows, st);  // (the list heads the workspace)
 }
 
 }  // extern "C"
