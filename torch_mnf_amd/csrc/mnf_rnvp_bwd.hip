@@ -51,8 +51,8 @@ constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
 #define MNF_RNVP_BWD_ABL 0  // timing experiments only (results are wrong): bit 0 no hand-over loads in B, bit 1 no row
 #endif                      // loads, bit 2 no row-sum MFMAs, bit 3 no grad_z stores, bit 4 no K = units MFMAs
 constexpr int kBwdAbl = MNF_RNVP_BWD_ABL;
-#ifndef MNF_RNVP_BWD_B_OCC
-#define MNF_RNVP_BWD_B_OCC 1  // waves per SIMD launch B is compiled for (experiment switch: 2 -> 256 registers, spills)
+#ifndef MNF_RNVP_BWD_TS_OCC
+#define MNF_RNVP_BWD_TS_OCC 2  // waves per SIMD launch B-ts is compiled for (experiment switch)
 #endif
 
 template <int HN>
@@ -405,310 +405,419 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   }
 }
 
-// ================================================================================================ kernel B
-// lane (c, q): column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers
+// ================================================================================================ kernels B
+// Work items = (row part, slab) over a persistent grid.  With >= 8 row parts, part p belongs to XCD p % 8 (workgroups
+// go to the XCDs round robin: block b runs on XCD b % 8) and that XCD's workgroups take its items in (part, slab) order:
+// the n_slabs workgroups on one row part then run on ONE XCD at about the same time and walk the same rows, so the
+// per-row hand-over (read by every slab) is fetched into that XCD's L2 once.
+struct BwdItems {
+  int n_items, first, step, n_slabs, xcd;
+  bool by_xcd;
+  __device__ __forceinline__ BwdItems(int n_slabs_, int row_parts) : n_slabs(n_slabs_) {
+    by_xcd = row_parts >= 8;
+    xcd = blockIdx.x & 7;
+    const int local_parts = by_xcd ? (row_parts - xcd + 7) / 8 : 0;
+    n_items = by_xcd ? local_parts * n_slabs : row_parts * n_slabs;
+    first = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  }
+  __device__ __forceinline__ int slab(int item) const { return item % n_slabs; }
+  __device__ __forceinline__ int part(int item) const { return by_xcd ? (item / n_slabs) * 8 + xcd : item / n_slabs; }
+};
+
+// the mask words of a tile's 16 rows for one 32-dim slab: lane l hashes row (l & 15) once, the four rows a lane needs
+// (4 q + r) are fetched from the lanes that hold them -- one hash and four cross-lane reads instead of four hashes
+__device__ __forceinline__ void tile_mask_words(uint64_t seed, int64_t tbase, int n_live, int slab, int lane, int q,
+                                                uint32_t (&w)[4]) {
+  const int jr = lane & 15;
+  const uint32_t h = rnvp_mask_word(seed, tbase + (jr < n_live ? jr : 0), slab);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (4 * q + r), (int)h);
+}
+
+// B-ts: lane (c, q) = column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers.
+// Per 32 rows and 32 dims: s, t from y (K = units), gate, g_t, g_s, g_k = Wn^T g_y, grad_z; dWt, dWs (16 accumulator
+// tiles), dbt, dbs.  Two waves per SIMD: no register prefetch, the partner wave covers the loads.
 template <int HN, bool SEEDED, bool RAG>
-__global__ void __launch_bounds__(kBwdBWaves * 64, MNF_RNVP_BWD_B_OCC)
-rnvp_bwd_b_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
-                  const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
-                  const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
-                  const float* __restrict__ gscale_dev, int64_t rows, int dm, int d16, int hn, uint64_t seed, int n_slabs,
-                  int row_parts, int vec2) {
+__global__ void __launch_bounds__(kBwdBWaves * 64, MNF_RNVP_BWD_TS_OCC)
+rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
+                   const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
+                   const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
+                   const float* __restrict__ gscale_dev, int64_t rows, int dm, int d16, int hn, uint64_t seed, int n_slabs,
+                   int row_parts, int vec2) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   constexpr int YT = S::YT, NKS2 = S::NKS2;
   constexpr int W_WORDS = B::B2_SLAB_WORDS + B::B4_SLAB_WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t w_lds[W_WORDS + B::B_SLAB_PLAIN];
-  // Work items = (row part, slab).  With >= 8 row parts, part p belongs to XCD p % 8 (workgroups go to the XCDs round
-  // robin: block b runs on XCD b % 8) and that XCD's workgroups take its items in (part, slab) order: the n_slabs
-  // workgroups on one row part then run on ONE XCD at about the same time and walk the same rows, so the per-row
-  // hand-over (1 KB per row, read by every slab) is fetched into that XCD's L2 once.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a SCALAR: tile numbers, hand-over addresses and the flag test then stay in scalar registers)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   const float gscale = gscale_dev[0], inv_gscale = 1.f / gscale;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x2 zero2 = u32x2{0u, 0u};
   const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
   const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
-  const bool by_xcd = row_parts >= 8;
-  const int xcd = blockIdx.x & 7, wg_local = blockIdx.x >> 3, wgs_local = gridDim.x >> 3;
-  const int local_parts = by_xcd ? (row_parts - xcd + 7) / 8 : 0;
-  const int n_items = by_xcd ? local_parts * n_slabs : row_parts * n_slabs;
-  for (int item = by_xcd ? wg_local : blockIdx.x; item < n_items; item += by_xcd ? wgs_local : gridDim.x) {
-  const int slab = item % n_slabs, part = by_xcd ? (item / n_slabs) * 8 + xcd : item / n_slabs;
-  __syncthreads();  // the previous item's operands are no longer read
-  {
-    const uint32_t* b2 = bimage + B::a3_words(d16) + (int64_t)slab * B::B2_SLAB_WORDS;
-    const uint32_t* b4 = bimage + B::a3_words(d16) + B::b2_words(dm) + (int64_t)slab * B::B4_SLAB_WORDS;
-    const uint32_t* pl = bimage + B::split_words(dm, d16) + (int64_t)slab * B::B_SLAB_PLAIN;
-    for (int i = threadIdx.x; i < B::B2_SLAB_WORDS / 4; i += blockDim.x)
-      reinterpret_cast<uint4*>(w_lds)[i] = reinterpret_cast<const uint4*>(b2)[i];
-    for (int i = threadIdx.x; i < B::B4_SLAB_WORDS / 4; i += blockDim.x)
-      reinterpret_cast<uint4*>(w_lds + B::B2_SLAB_WORDS)[i] = reinterpret_cast<const uint4*>(b4)[i];
-    for (int i = threadIdx.x; i < B::B_SLAB_PLAIN; i += blockDim.x) w_lds[W_WORDS + i] = pl[i];
-  }
-  __syncthreads();
-  const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
-  const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
-  const float* bias = reinterpret_cast<const float*>(w_lds + W_WORDS);
-  const float bt[2] = {bias[j], bias[16 + j]}, bs[2] = {bias[32 + j], bias[48 + j]};
-  // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it.  The reads
-  // do not depend on the row pair: an opaque offset, refreshed per pair, keeps hipcc from hoisting 24 KB of operands
-  // out of the pair loop into registers (it did: 240 spilled registers)
-  int w_lane = lane;
-  const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds);  // (16-byte aligned: one ds_read_b128 per operand)
-  auto w2 = [&](int dt, int net, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
-  auto w4 = [&](int dt, int ks, int part_) { return W8[w_lane + 64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
-
-  f32x4 aWt[2][YT], aWs[2][YT], aWn[2][YT];
-  float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = aWn[dt][m] = zero4;
-
-  // One wave per SIMD (the accumulators, the operands of the row sums and a pair's inputs take ~400 registers), so
-  // nothing but the wave itself hides a load's latency: the NEXT pair's row data and K = units operands are requested
-  // before the current pair is computed (two register sets, the loop is unrolled by two), the K = rows operands of the
-  // current pair at its start -- they are needed last.
-  struct Inputs {
-    f32x2 zz[2][4], GG[2][4], mm[2][4];
-    float gl[2][4];
-    bool skip;
-  };
-  // row r of tile T, the lane's two dims: element (16 T + 4 q + r) dm + dim0 = [tile base, wave-uniform] + lane_off + r dm
-  const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
   const float* gsrc = gx ? gx : z;               // (no cotangent for x: read z and multiply by zero)
   const float gx_scale = gx ? gscale : 0.f;
   const float gl_scale = gld ? gscale : 0.f;
   const float* lsrc = gld ? gld : z;
-  auto load_inputs = [&](int64_t p, Inputs& in) {
-    in.skip = flags[(p * 32) / kBwdGroupRows] != 0;  // the generic kernel redoes flagged groups
+  const BwdItems items(n_slabs, row_parts);
+  for (int item = items.first; item < items.n_items; item += items.step) {
+    const int slab = items.slab(item), part = items.part(item);
+    __syncthreads();  // the previous item's operands are no longer read
+    {
+      const uint32_t* b2 = bimage + B::a3_words(d16) + (int64_t)slab * B::B2_SLAB_WORDS;
+      const uint32_t* b4 = bimage + B::a3_words(d16) + B::b2_words(dm) + (int64_t)slab * B::B4_SLAB_WORDS;
+      const uint32_t* pl = bimage + B::split_words(dm, d16) + (int64_t)slab * B::B_SLAB_PLAIN;
+      for (int i = threadIdx.x; i < B::B2_SLAB_WORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(w_lds)[i] = reinterpret_cast<const uint4*>(b2)[i];
+      for (int i = threadIdx.x; i < B::B4_SLAB_WORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(w_lds + B::B2_SLAB_WORDS)[i] = reinterpret_cast<const uint4*>(b4)[i];
+      for (int i = threadIdx.x; i < B::B_SLAB_PLAIN; i += blockDim.x) w_lds[W_WORDS + i] = pl[i];
+    }
+    __syncthreads();
+    const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
+    const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
+    const float* bias = reinterpret_cast<const float*>(w_lds + W_WORDS);
+    const float bt[2] = {bias[j], bias[16 + j]}, bs[2] = {bias[32 + j], bias[48 + j]};
+    // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it.  The reads
+    // do not depend on the row pair: an opaque lane index, refreshed per pair, keeps hipcc from hoisting 24 KB of
+    // operands out of the pair loop into registers
+    int w_lane = lane;
+    const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds);  // (16-byte aligned: one ds_read_b128 per operand)
+    auto w2 = [&](int dt, int net, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
+    auto w4 = [&](int dt, int ks, int part_) { return W8[w_lane + 64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
+    // row r of tile T, the lane's two dims: element (16 T + 4 q + r) dm + dim0 = [tile base, uniform] + lane_off + r dm
+    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
+
+    f32x4 aWt[2][YT], aWs[2][YT];
+    float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int64_t tile = 2 * p + tt;
-      const bool has = tile < n_tiles;
-      const int64_t tbase = (has ? tile : n_tiles - 1) * 16;       // wave-uniform
-      const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
-      const float* zt = z + tbase * dm;
-      const float* gt_ = gsrc + tbase * dm;
-      const float* mt = SEEDED ? nullptr : mask + tbase * dm;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 4 * q + r;
-        const bool live = rr < n_live;
-        // a row past the end reads the tile's first row instead (its cotangents are zeroed, nothing of it is stored)
-        const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0;
-        f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
-        if (kBwdAbl & 2) {
-          zv = gv = f32x2{0.25f * lane, 1.f};
-        } else if (!RAG) {
-          zv = *reinterpret_cast<const f32x2*>(zt + off);
-          gv = *reinterpret_cast<const f32x2*>(gt_ + off);
-          if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
-        } else if (vec2) {
-          if (in0) {
+      for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = zero4;
+
+    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kBwdBWaves) {
+      if (flags[(p * 32) / kBwdGroupRows]) continue;  // the generic kernel redoes flagged groups
+      asm volatile("" : "+v"(w_lane));
+      const bool has1 = 2 * p + 1 < n_tiles;
+      u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2];  // [row tile][dim tile]: B operands of the row sums
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int64_t tile = 2 * p + tt;
+        const bool has = tt == 0 || has1;
+        const int64_t tbase = (has ? tile : 2 * p) * 16;                 // wave-uniform
+        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
+        const float* zt = z + tbase * dm;
+        const float* gt_ = gsrc + tbase * dm;
+        const float* mt = SEEDED ? nullptr : mask + tbase * dm;
+        const uint32_t* sd = side + (tbase >> 4) * B::TILE_WORDS;
+        f32x2 zz[4], GG[4], mm[4];
+        float gl[4];
+        uint32_t mw[4];
+        if (SEEDED) tile_mask_words(seed, tbase, n_live, slab, lane, q, mw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 4 * q + r;
+          const bool live = rr < n_live;
+          // a row past the end reads the tile's first row instead (its cotangents are zeroed, nothing of it is stored)
+          const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0;
+          f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
+          if (kBwdAbl & 2) {
+            zv = gv = f32x2{0.25f * lane, 1.f};
+          } else if (!RAG) {
             zv = *reinterpret_cast<const f32x2*>(zt + off);
             gv = *reinterpret_cast<const f32x2*>(gt_ + off);
             if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
-          }
-        } else {
-          if (in0) {
-            zv[0] = zt[off];
-            gv[0] = gt_[off];
-            if (!SEEDED) mv[0] = mt[off];
-          }
-          if (in1) {
-            zv[1] = zt[off + 1];
-            gv[1] = gt_[off + 1];
-            if (!SEEDED) mv[1] = mt[off + 1];
-          }
-        }
-        if (SEEDED) {
-          const uint32_t w = rnvp_mask_word(seed, tbase + (live ? rr : 0), slab) >> (2 * j);
-          mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
-        }
-        const float keep = live ? 1.f : 0.f;
-        in.zz[tt][r] = zv;
-        in.GG[tt][r] = gv * (gx_scale * keep);
-        in.mm[tt][r] = mv;
-        in.gl[tt][r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
-      }
-    }
-  };
-  auto compute = [&](int64_t p, Inputs& in) {
-    if (in.skip) return;
-    asm volatile("" : "+v"(w_lane));
-    // the pair's hand-over from launch A (L2): K = units operands now, K = rows operands for the row sums at the end
-    const bool has1 = 2 * p + 1 < n_tiles;
-    f16x8 yoh[2][NKS2], yol[2][NKS2], goh[2][NKS2], gol[2][NKS2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const uint32_t* sd = side + (2 * p + (has1 ? tt : 0)) * B::TILE_WORDS;
-#pragma unroll
-      for (int ks = 0; ks < NKS2; ++ks) {
-        if (kBwdAbl & 1) {
-          yoh[tt][ks] = yol[tt][ks] = goh[tt][ks] = gol[tt][ks] = w2(0, 0, ks, 0);
-          continue;
-        }
-        yoh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
-        yol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
-        goh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
-        gol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
-      }
-    }
-    u32x2 ytr[2][YT][2], gtr[2][YT][2];
-    if (grad_flat) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const uint32_t* st = side + (2 * p + (has1 ? tt : 0)) * B::TILE_WORDS;
-#pragma unroll
-        for (int m = 0; m < YT; ++m)
-#pragma unroll
-          for (int part_ = 0; part_ < 2; ++part_) {
-            if (kBwdAbl & 1) {
-              ytr[tt][m][part_] = gtr[tt][m][part_] = u32x2{(uint32_t)lane, (uint32_t)m};
-              continue;
+          } else if (vec2) {
+            if (in0) {
+              zv = *reinterpret_cast<const f32x2*>(zt + off);
+              gv = *reinterpret_cast<const f32x2*>(gt_ + off);
+              if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
             }
-            ytr[tt][m][part_] = *reinterpret_cast<const u32x2*>(st + B::Y_TR + ((2 * m + part_) * 64 + lane) * 2);
-            gtr[tt][m][part_] = *reinterpret_cast<const u32x2*>(st + B::G_TR + ((2 * m + part_) * 64 + lane) * 2);
+          } else {
+            if (in0) {
+              zv[0] = zt[off];
+              gv[0] = gt_[off];
+              if (!SEEDED) mv[0] = mt[off];
+            }
+            if (in1) {
+              zv[1] = zt[off + 1];
+              gv[1] = gt_[off + 1];
+              if (!SEEDED) mv[1] = mt[off + 1];
+            }
           }
-      }
-    }
-    u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2], kh[2][2], kl[2][2];  // [row tile][dim tile]: operands of the row sums
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int64_t tile = 2 * p + tt;
-      const bool has = tile < n_tiles;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
-        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
+          if (SEEDED) {
+            const uint32_t w = mw[r] >> (2 * j);
+            mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
+          }
+          const float keep = live ? 1.f : 0.f;
+          zz[r] = zv;
+          GG[r] = gv * (gx_scale * keep);
+          mm[r] = mv;
+          gl[r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
+        }
+        // y and g_y of the tile as A operands, units on K (launch A's hand-over, from L2)
+        f16x8 yoh[NKS2], yol[NKS2], goh[NKS2], gol[NKS2];
 #pragma unroll
         for (int ks = 0; ks < NKS2; ++ks) {
-          if (kBwdAbl & 16) {
-            tm += __builtin_bit_cast(f32x4, yoh[tt][ks]);
-            sm += __builtin_bit_cast(f32x4, goh[tt][ks]);
+          if (kBwdAbl & 1) {
+            yoh[ks] = yol[ks] = goh[ks] = gol[ks] = w2(0, 0, ks, 0);
             continue;
           }
-          split_mac(yoh[tt][ks], yol[tt][ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
-          split_mac(yoh[tt][ks], yol[tt][ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
-          split_mac(goh[tt][ks], gol[tt][ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+          yoh[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
+          yol[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
+          goh[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
+          gol[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
         }
-        const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
-        const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
-        const f32x4 gk = kc * kSplitInvScale + km;
-        f32x4 gt, gs, kk, gz;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float zv = in.zz[tt][r][dt], G_ = in.GG[tt][r][dt], m_ = in.mm[tt][r][dt], nm = 1.f - m_;
-          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
-          const float omg = 1.f - gate;
-          gt[r] = G_ * omg;
-          gs[r] = (G_ * (nm * zv - t4[r]) * gate + in.gl[tt][r] * nm) * omg;
-          kk[r] = m_ * zv;
-          gz[r] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;
-        }
-        abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
-        abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
-        split_plain(gt, th[tt][dt], tl[tt][dt]);
-        split_plain(gs, sh[tt][dt], sl[tt][dt]);
-        split_plain(kk, kh[tt][dt], kl[tt][dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+          // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
+          f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) in.zz[tt][r][dt] = gz[r];  // (z of this dim is dead: its registers take grad_z)
-      }
-      if (has && (!(kBwdAbl & 8) || in.zz[tt][0][0] == 1.2345e30f)) {
-        const int n_live = (int)min((int64_t)16, rows - tile * 16);
-        float* ot = grad_z + tile * 16 * dm;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * q + r < n_live) {
-            const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
-            if (!RAG) {
-              *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
-            } else if (vec2) {  // (dm even: in0 implies in1)
-              if (in0) *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
-            } else {
-              if (in0) ot[off] = in.zz[tt][r][0];
-              if (in1) ot[off + 1] = in.zz[tt][r][1];
+          for (int ks = 0; ks < NKS2; ++ks) {
+            if (kBwdAbl & 16) {
+              tm += __builtin_bit_cast(f32x4, yoh[ks]);
+              sm += __builtin_bit_cast(f32x4, goh[ks]);
+              continue;
             }
+            split_mac(yoh[ks], yol[ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
+            split_mac(yoh[ks], yol[ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+            split_mac(goh[ks], gol[ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+          }
+          const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
+          const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
+          const f32x4 gk = kc * kSplitInvScale + km;
+          f32x4 gt, gs;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float zv = zz[r][dt], G_ = GG[r][dt], m_ = mm[r][dt], nm = 1.f - m_;
+            const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+            const float omg = 1.f - gate;
+            gt[r] = G_ * omg;
+            gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl[r] * nm) * omg;
+            zz[r][dt] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;  // grad_z takes z's register
+          }
+          abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+          abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
+          split_plain(gt, th[tt][dt], tl[tt][dt]);
+          split_plain(gs, sh[tt][dt], sl[tt][dt]);
+        }
+        if (has && (!(kBwdAbl & 8) || zz[0][0] == 1.2345e30f)) {
+          float* ot = grad_z + tbase * dm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (4 * q + r < n_live) {
+              const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
+              if (!RAG) {
+                *reinterpret_cast<f32x2*>(ot + off) = zz[r];
+              } else if (vec2) {  // (dm even: in0 implies in1)
+                if (in0) *reinterpret_cast<f32x2*>(ot + off) = zz[r];
+              } else {
+                if (in0) ot[off] = zz[r][0];
+                if (in1) ot[off + 1] = zz[r][1];
+              }
+            }
+          }
+        }
+        if (!has) {  // no second tile: its operands are zero
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) th[tt][dt] = tl[tt][dt] = sh[tt][dt] = sl[tt][dt] = zero2;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one row tile at a time: interleaving the two exceeds the 256 registers
+      }
+      if (grad_flat && !(kBwdAbl & 4)) {
+        // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
+        const uint32_t* s0 = side + (2 * p) * B::TILE_WORDS + B::Y_TR + lane * 2;
+        const uint32_t* s1 = side + (2 * p + (has1 ? 1 : 0)) * B::TILE_WORDS + B::Y_TR + lane * 2;
+#pragma unroll
+        for (int m = 0; m < YT; ++m) {
+          const u32x2 y0h = *reinterpret_cast<const u32x2*>(s0 + (2 * m) * 128);
+          const u32x2 y0l = *reinterpret_cast<const u32x2*>(s0 + (2 * m + 1) * 128);
+          const u32x2 y1h = *reinterpret_cast<const u32x2*>(s1 + (2 * m) * 128);
+          const u32x2 y1l = *reinterpret_cast<const u32x2*>(s1 + (2 * m + 1) * 128);
+          const f16x8 yh8 = pair_operand(y0h, y1h), yl8 = pair_operand(y0l, y1l);  // (no second tile: B is zero there)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const f16x8 tH = pair_operand(th[0][dt], th[1][dt]), tL = pair_operand(tl[0][dt], tl[1][dt]);
+            const f16x8 sH = pair_operand(sh[0][dt], sh[1][dt]), sL = pair_operand(sl[0][dt], sl[1][dt]);
+            aWt[dt][m] = mfma_h(yh8, tH, aWt[dt][m]);
+            aWs[dt][m] = mfma_h(yh8, sH, aWs[dt][m]);
+            aWt[dt][m] = mfma_h(yh8, tL, aWt[dt][m]);
+            aWs[dt][m] = mfma_h(yh8, sL, aWs[dt][m]);
+            aWt[dt][m] = mfma_h(yl8, tH, aWt[dt][m]);
+            aWs[dt][m] = mfma_h(yl8, sH, aWs[dt][m]);
           }
         }
       }
     }
-    if (grad_flat && !(kBwdAbl & 4)) {
-      // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
+    if (!grad_flat || ((kBwdAbl & 32) && abt[0] != 1.2345e30f)) continue;
+    // flush.  Lane (c, q) register r of tile (dt, m) = d W [unit 16 m + 4 q + r][dim 32 slab + 2 c + dt]: written to
+    // memory as it stands, a wave-instruction's 64 atomics land in 16 different rows of Wt, and the memory-side atomic
+    // units take scattered adds an order of magnitude slower than contiguous ones (0.85 of this launch's 2.5 ms).  So
+    // the four waves first add their tiles up in LDS (the operand area is free now) as [tensor][dim of the slab][unit],
+    // and the workgroup then adds the slab's CONTIGUOUS blocks of Wt and Ws (32 dims x hn floats each) to grad_flat:
+    // 256 consecutive bytes per wave-instruction, and a quarter of the atomics.
+    constexpr int UP = 16 * YT + 1;  // padded row: lanes of one instruction hit 16 different banks
+    float* red = reinterpret_cast<float*>(w_lds);
+    static_assert(2 * 32 * UP + 64 <= W_WORDS + B::B_SLAB_PLAIN, "the flush area fits the operand area");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 32 * UP + 64; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(red + (2 * j + dt) * UP + 16 * m + 4 * q + r, aWt[dt][m][r]);
+          atomicAdd(red + 32 * UP + (2 * j + dt) * UP + 16 * m + 4 * q + r, aWs[dt][m][r]);
+        }
+      float vt = abt[dt], vs = abs_[dt];
+      vt += __shfl_xor(vt, 16, 64);
+      vt += __shfl_xor(vt, 32, 64);
+      vs += __shfl_xor(vs, 16, 64);
+      vs += __shfl_xor(vs, 32, 64);
+      if (q == 0) {
+        atomicAdd(red + 2 * 32 * UP + 2 * j + dt, vt);
+        atomicAdd(red + 2 * 32 * UP + 32 + 2 * j + dt, vs);
+      }
+    }
+    __syncthreads();
+    const int64_t bn = (int64_t)hn * dm, wt = bn + hn, btf = wt + (int64_t)dm * hn, ws = btf + dm,
+                  bsf = ws + (int64_t)dm * hn;
+    const int n_dims = min(32, dm - 32 * slab);  // dims of this slab that exist
+    for (int e = threadIdx.x; e < n_dims * hn; e += blockDim.x) {
+      const int dl = e / hn, unit = e - dl * hn;
+      atomicAdd(grad_flat + wt + (int64_t)(32 * slab) * hn + e, red[dl * UP + unit] * inv_gscale);
+      atomicAdd(grad_flat + ws + (int64_t)(32 * slab) * hn + e, red[32 * UP + dl * UP + unit] * inv_gscale);
+    }
+    if ((int)threadIdx.x < n_dims) {
+      atomicAdd(grad_flat + btf + 32 * slab + threadIdx.x, red[2 * 32 * UP + threadIdx.x] * inv_gscale);
+      atomicAdd(grad_flat + bsf + 32 * slab + threadIdx.x, red[2 * 32 * UP + 32 + threadIdx.x] * inv_gscale);
+    }
+  }
+}
+
+// B-n: dWn [unit][dim] += sum over rows of g_y [row][unit] (m z) [row][dim] -- needs z, the mask and launch A's g_y only
+// (no gate arithmetic, 8 accumulator tiles): its own launch, four waves per SIMD, so that B-ts keeps 16 accumulator
+// tiles instead of 24 and fits two waves per SIMD.
+template <int HN, bool SEEDED, bool RAG>
+__global__ void __launch_bounds__(kBwdBWaves * 64, 4)
+rnvp_bwd_n_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ grad_flat,
+                  const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
+                  const float* __restrict__ gscale_dev, int64_t rows, int dm, int hn, uint64_t seed, int n_slabs,
+                  int row_parts, int vec2) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  constexpr int YT = S::YT;
+  __shared__ float red[16 * YT * 33];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const float inv_gscale = 1.f / gscale_dev[0];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
+  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
+  const BwdItems items(n_slabs, row_parts);
+  for (int item = items.first; item < items.n_items; item += items.step) {
+    const int slab = items.slab(item), part = items.part(item);
+    const int dim0 = 32 * slab + 2 * j;
+    const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
+    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
+    f32x4 aWn[2][YT];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m) aWn[dt][m] = zero4;
+    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kBwdBWaves) {
+      if (flags[(p * 32) / kBwdGroupRows]) continue;
+      const bool has1 = 2 * p + 1 < n_tiles;
+      u32x2 kh[2][2], kl[2][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const bool has = tt == 0 || has1;
+        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;
+        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;
+        const float* zt = z + tbase * dm;
+        const float* mt = SEEDED ? nullptr : mask + tbase * dm;
+        uint32_t mw[4];
+        if (SEEDED) tile_mask_words(seed, tbase, n_live, slab, lane, q, mw);
+        f32x4 k0, k1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool live = 4 * q + r < n_live;
+          const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0;
+          f32x2 zv = {0.f, 0.f}, mv = {0.f, 0.f};
+          if (!RAG) {
+            zv = *reinterpret_cast<const f32x2*>(zt + off);
+            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
+          } else if (vec2) {
+            if (in0) {
+              zv = *reinterpret_cast<const f32x2*>(zt + off);
+              if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
+            }
+          } else {
+            if (in0) {
+              zv[0] = zt[off];
+              if (!SEEDED) mv[0] = mt[off];
+            }
+            if (in1) {
+              zv[1] = zt[off + 1];
+              if (!SEEDED) mv[1] = mt[off + 1];
+            }
+          }
+          if (SEEDED) {
+            const uint32_t w = mw[r] >> (2 * j);
+            mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
+          }
+          const float keep = live ? 1.f : 0.f;  // (g_y of a row past the end is zero anyway; keep k finite)
+          k0[r] = mv[0] * zv[0] * keep;
+          k1[r] = mv[1] * zv[1] * keep;
+        }
+        split_plain(k0, kh[tt][0], kl[tt][0]);
+        split_plain(k1, kh[tt][1], kl[tt][1]);
+        if (!has) kh[tt][0] = kl[tt][0] = kh[tt][1] = kl[tt][1] = zero2;
+      }
+      const uint32_t* s0 = side + (2 * p) * B::TILE_WORDS + B::G_TR + lane * 2;
+      const uint32_t* s1 = side + (2 * p + (has1 ? 1 : 0)) * B::TILE_WORDS + B::G_TR + lane * 2;
 #pragma unroll
       for (int m = 0; m < YT; ++m) {
-        const f16x8 yh8 = pair_operand(ytr[0][m][0], has1 ? ytr[1][m][0] : zero2);
-        const f16x8 yl8 = pair_operand(ytr[0][m][1], has1 ? ytr[1][m][1] : zero2);
-        const f16x8 gh8 = pair_operand(gtr[0][m][0], has1 ? gtr[1][m][0] : zero2);
-        const f16x8 gl8 = pair_operand(gtr[0][m][1], has1 ? gtr[1][m][1] : zero2);
+        const u32x2 g0h = *reinterpret_cast<const u32x2*>(s0 + (2 * m) * 128);
+        const u32x2 g0l = *reinterpret_cast<const u32x2*>(s0 + (2 * m + 1) * 128);
+        const u32x2 g1h = *reinterpret_cast<const u32x2*>(s1 + (2 * m) * 128);
+        const u32x2 g1l = *reinterpret_cast<const u32x2*>(s1 + (2 * m + 1) * 128);
+        const f16x8 gh8 = pair_operand(g0h, g1h), gl8 = pair_operand(g0l, g1l);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const f16x8 tH = pair_operand(th[0][dt], th[1][dt]), tL = pair_operand(tl[0][dt], tl[1][dt]);
-          const f16x8 sH = pair_operand(sh[0][dt], sh[1][dt]), sL = pair_operand(sl[0][dt], sl[1][dt]);
           const f16x8 kH = pair_operand(kh[0][dt], kh[1][dt]), kL = pair_operand(kl[0][dt], kl[1][dt]);
-          aWt[dt][m] = mfma_h(yh8, tH, aWt[dt][m]);
-          aWs[dt][m] = mfma_h(yh8, sH, aWs[dt][m]);
           aWn[dt][m] = mfma_h(gh8, kH, aWn[dt][m]);
-          aWt[dt][m] = mfma_h(yh8, tL, aWt[dt][m]);
-          aWs[dt][m] = mfma_h(yh8, sL, aWs[dt][m]);
           aWn[dt][m] = mfma_h(gh8, kL, aWn[dt][m]);
-          aWt[dt][m] = mfma_h(yl8, tH, aWt[dt][m]);
-          aWs[dt][m] = mfma_h(yl8, sH, aWs[dt][m]);
           aWn[dt][m] = mfma_h(gl8, kH, aWn[dt][m]);
         }
       }
     }
-  };
-  {
-    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
-    int64_t p = (int64_t)part * per_part + wave;
-    Inputs ia, ib;
-    if (p < p_end) load_inputs(p, ia);
-    while (p < p_end) {
-      int64_t pn = p + kBwdBWaves;
-      if (pn < p_end) load_inputs(pn, ib);
-      compute(p, ia);
-      p = pn;
-      if (p >= p_end) break;
-      pn = p + kBwdBWaves;
-      if (pn < p_end) load_inputs(pn, ia);
-      compute(p, ib);
-      p = pn;
+    // flush through LDS as in B-ts: [unit][dim of the slab], then 128 contiguous bytes of a Wn row per half wave
+    if ((kBwdAbl & 32) && aWn[0][0][0] != 1.2345e30f) continue;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * YT * 33; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * m + 4 * q + r) * 33 + 2 * j + dt, aWn[dt][m][r]);
+    __syncthreads();
+    const int n_dims = min(32, dm - 32 * slab);
+    for (int e = threadIdx.x; e < hn * 32; e += blockDim.x) {
+      const int unit = e >> 5, dl = e & 31;
+      if (dl < n_dims) atomicAdd(grad_flat + (int64_t)unit * dm + 32 * slab + dl, red[unit * 33 + dl] * inv_gscale);
     }
   }
-  if (!grad_flat) continue;
-  // flush: lane (c, q) register r of tile (dt, m) = d W [unit 16 m + 4 q + r][dim 32 slab + 2 c + dt]
-  const int64_t wn = 0, bn = wn + (int64_t)hn * dm, wt = bn + hn, btf = wt + (int64_t)dm * hn, ws = btf + dm,
-                bsf = ws + (int64_t)dm * hn;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
-    const int dim = dim0 + dt;
-    const bool in = dim < dm;
-#pragma unroll
-    for (int m = 0; m < YT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int unit = 16 * m + 4 * q + r;
-        if (in && unit < hn) {
-          atomicAdd(grad_flat + wt + (int64_t)dim * hn + unit, aWt[dt][m][r] * inv_gscale);
-          atomicAdd(grad_flat + ws + (int64_t)dim * hn + unit, aWs[dt][m][r] * inv_gscale);
-          atomicAdd(grad_flat + wn + (int64_t)unit * dm + dim, aWn[dt][m][r] * inv_gscale);
-        }
-      }
-    float vt = abt[dt], vs = abs_[dt];
-    vt += __shfl_xor(vt, 16, 64);
-    vt += __shfl_xor(vt, 32, 64);
-    vs += __shfl_xor(vs, 16, 64);
-    vs += __shfl_xor(vs, 32, 64);
-    if (in && q == 0) {
-      atomicAdd(grad_flat + btf + dim, vt * inv_gscale);
-      atomicAdd(grad_flat + bsf + dim, vs * inv_gscale);
-    }
-  }
-  }  // items
 }
 
 // ================================================================================================ host
@@ -797,19 +906,18 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
   if (int rc = check_launch()) return rc;
-  // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see the
-  // kernel); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
+  // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see
+  // BwdItems); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
   const int n_slabs = (int)B::n_slabs(dm);
-  const int resident_b = memo_b.get(
-      [](int dev) { return resident_by_occupancy(rnvp_bwd_b_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
   const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
   const int64_t max_parts = (n_pairs + kBwdBWaves - 1) / kBwdBWaves;  // at least one pair per wave
-  int row_parts, grid;
-  if (max_parts < 8) {
-    row_parts = (int)max_parts;
-    grid = row_parts * n_slabs;
-  } else {
-    const int wgs_xcd = resident_b / 8 > 0 ? resident_b / 8 : 1;
+  auto plan = [&](int resident, int& row_parts, int& grid) {
+    if (max_parts < 8) {
+      row_parts = (int)max_parts;
+      grid = row_parts * n_slabs;
+      return;
+    }
+    const int wgs_xcd = resident / 8 > 0 ? resident / 8 : 1;
     int best_l = 1;
     double best_fill = 0.0;
     for (int l = 1; l <= 32 && (int64_t)l * 8 <= max_parts; ++l) {
@@ -823,10 +931,22 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     row_parts = best_l * 8;
     const int items = best_l * n_slabs;
     grid = 8 * (items < wgs_xcd ? items : wgs_xcd);
-  }
-  hipLaunchKernelGGL((rnvp_bwd_b_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
+  };
+  static DeviceMemo memo_n;
+  const int resident_b = memo_b.get(
+      [](int dev) { return resident_by_occupancy(rnvp_bwd_ts_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
+  int row_parts, grid;
+  plan(resident_b, row_parts, grid);
+  hipLaunchKernelGGL((rnvp_bwd_ts_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
                      mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows, dm, d16, hn, seed, n_slabs,
                      row_parts, vec2);
+  if (int rc = check_launch()) return rc;
+  if (!grad_flat) return MNF_OK;
+  const int resident_n = memo_n.get(
+      [](int dev) { return resident_by_occupancy(rnvp_bwd_n_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 4); });
+  plan(resident_n, row_parts, grid);
+  hipLaunchKernelGGL((rnvp_bwd_n_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
+                     mask, grad_flat, side, flags, gscale, rows, dm, hn, seed, n_slabs, row_parts, vec2);
   return check_launch();
 }
 
