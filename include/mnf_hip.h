@@ -58,7 +58,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 8
+#define MNF_ABI_VERSION 9
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -303,6 +303,32 @@ int mnf_mnf_linear_fwd(const float* x, const float* z, const float* eps, uint64_
                        const void* split_image, float var_unscale, int32_t* workspace, int64_t rows, int n_in, int n_out,
                        void* stream);
 int mnf_mnf_linear_noise(uint64_t seed, float* eps, int64_t rows, int n_out, void* stream);
+/* The training form of mnf_mnf_linear_fwd: additionally writes sd = sqrt(var) (rows, n_out) when sd_out != NULL (the
+ * backward pass needs d out / d var = eps / (2 sd)); `workspace` then also carries the per-128-row range flags
+ * mnf_mnf_linear_bwd reads.  Everything else as mnf_mnf_linear_fwd. */
+int mnf_mnf_linear_fwd_train(const float* x, const float* z, const float* eps, uint64_t seed, float* out, float* sd_out,
+                             const float* flat, const void* split_image, float var_unscale, int32_t* workspace,
+                             int64_t rows, int n_in, int n_out, void* stream);
+/* Gradients of MNFLinear.forward (layers/mnf_linear.py:46-56 under loss.backward(): what tests/test_mnf_mnist.py:14-56
+ * trains through) on the matrix cores, n_out <= 64.  Two launches + an fp32 fix-up: a row-parallel prologue turns
+ * grad_out, eps and sd into the cotangents of mean and var as split MFMA operands (1 KB per row in `workspace`) and
+ * sums the bias gradients; a dims-slab launch (a workgroup owns 32 input dims and a range of rows) writes grad_x and
+ * grad_z and sums dW_mean, dW_log_var over the rows in registers; 128-row groups flagged by the forward pass (or whose
+ * cotangents leave the split range) are redone in fp32.
+ *   flat            W_mean | exp(W_log_var) / var_unscale | b_mean | exp(b_log_var)   (the forward call's `flat`)
+ *   bwd_image       mnf_pack_gather_split of `flat` through the mnf_mnf_linear_bwd_index table (see _layout)
+ *   sd, fwd_flags   sd_out and workspace of the mnf_mnf_linear_fwd_train call; eps / seed as passed there
+ *   grad_scale_dev  device float, a power of two that brings grad_out near 1 (mnf_affine_half_grad_scale)
+ *   workspace       >= mnf_mnf_linear_bwd_workspace_bytes(rows, n_in, n_out) bytes, 16-byte aligned
+ * grad_x, grad_z (rows, n_in) are written; grad_flat (layout of `flat`: d W_mean | d W_log_var | d b_mean |
+ * d b_log_var) is ADDED to, or NULL. */
+int64_t mnf_mnf_linear_bwd_workspace_bytes(int64_t rows, int n_in, int n_out);
+int mnf_mnf_linear_bwd_layout(int n_in, int n_out, int64_t* n_split_words, int64_t* n_plain_words);
+int mnf_mnf_linear_bwd_index(int n_in, int n_out, int32_t* idx_host);
+int mnf_mnf_linear_bwd(const float* x, const float* z, const float* grad_out, const float* sd, const float* eps,
+                       uint64_t seed, float* grad_x, float* grad_z, float* grad_flat, const float* flat,
+                       const void* bwd_image, float var_unscale, const int32_t* fwd_flags, const float* grad_scale_dev,
+                       void* workspace, int64_t workspace_bytes, int64_t rows, int n_in, int n_out, void* stream);
 
 /* ------------------------------------------------------------------ gradients (autograd)
  * What torch.autograd.Function.backward needs so the modules train like the reference's

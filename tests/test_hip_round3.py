@@ -328,3 +328,145 @@ def test_rnvp_mfma_gradient_kernels_many_rows(amd):
     for k in one:
         if k != "z":
             assert_close(many[k], copies * one[k], 1e-5, f"{k}: {copies} copies")
+
+
+# ------------------------------------------------------------------------------------------------ MNFLinear.forward gradients
+def _mnf_linear_oracle_grads(O, p, x, z, eps, w_out):
+    """(fp32, fp64) gradients of sum(out * w_out) through the oracle's MNFLinear.forward (mnf_linear.py:46-56)."""
+    out = []
+    for dt in (torch.float32, torch.float64):
+        xx = x.detach().to(dt).requires_grad_(True)
+        zz = z.detach().to(dt).requires_grad_(True)
+        q = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in p.items()}
+        o = O.mnf_linear_forward(xx, zz, q["W_mean"], q["W_log_var"], q["b_mean"], q["b_log_var"], eps.to(dt))
+        (o * w_out.to(dt)).sum().backward()
+        out.append({"x": xx.grad, "z": zz.grad, **{k: v.grad for k, v in q.items()}})
+        val = o.detach()
+    return out[0], out[1], val
+
+
+def _mnf_linear_params(seed, n_in, n_out):
+    g = torch.Generator().manual_seed(seed)
+    return {"W_mean": 0.1 * torch.randn(n_out, n_in, generator=g), "W_log_var": -9 + 0.5 * torch.randn(n_out, n_in, generator=g),
+            "b_mean": 0.1 * torch.randn(n_out, generator=g), "b_log_var": -9 + 0.5 * torch.randn(n_out, generator=g)}
+
+
+class _FixedZ:
+    """Stand-in for sample_z: MNFLinear.forward draws z itself; the gradient tests need a known z with a grad slot."""
+
+    def __init__(self, z):
+        self.z = z
+
+    def __call__(self, batch_size=1, eps=None, masks=None):
+        return self.z, torch.zeros(self.z.shape[0], device=self.z.device)
+
+
+@pytest.mark.parametrize("n_in,n_out,rows", [(800, 50, 300), (50, 10, 129), (800, 50, 1), (784, 50, 70), (100, 64, 257),
+                                             (96, 17, 4099), (33, 3, 40)])
+def test_mnf_linear_forward_gradients(amd, O, n_in, n_out, rows):
+    """MNFLinear.forward with gradients = mnf_mnf_linear_fwd_train + mnf_mnf_linear_bwd: grad x, grad z, dW_mean,
+    dW_log_var, db_mean, db_log_var against autograd through the oracle evaluated in float64 (MNF-LeNet's two dense
+    shapes, ragged widths, a single row, ragged row counts)."""
+    p = _mnf_linear_params(5000 + n_in + n_out, n_in, n_out)
+    x = recipes.gaussian(5100 + n_in, rows, n_in).abs()          # (activations after a ReLU in the reference's models)
+    z = 1.0 + 0.3 * recipes.gaussian(5200 + n_in, rows, n_in)
+    eps = recipes.gaussian(5300 + n_out, rows, n_out)
+    w_out = recipes.gaussian(5400 + n_out, rows, n_out)
+    g32, g64, ref_out = _mnf_linear_oracle_grads(O, p, x, z, eps, w_out)
+    layer = amd.MNFLinear(n_in, n_out)
+    layer.load_state_dict(p, strict=False)
+    layer.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    zg = z.to(DEV).requires_grad_(True)
+    layer.sample_z = _FixedZ(zg)
+    out = layer.forward(xg, eps=eps.to(DEV))
+    assert out.requires_grad and type(out.grad_fn).__name__.startswith("_MnfLinearFn")
+    assert_close(out, ref_out.float(), RTOL, "out")
+    (out * w_out.to(DEV)).sum().backward()
+    got = {"x": xg.grad, "z": zg.grad, **{k: getattr(layer, k).grad for k in p}}
+    worst = _check_grads(got, g32, g64, f"MNFLinear({n_in},{n_out}) rows={rows}")
+    print(f"MNFLinear({n_in},{n_out}) rows={rows}: worst gradient {worst:.2e} from float64")
+
+
+def test_mnf_linear_forward_gradients_with_in_kernel_noise_and_tiny_cotangents(amd, O):
+    """The default call: noise generated in the kernel from a seed (the backward pass regenerates it), cotangents of a
+    mean over the batch (~1e-6: normalised by the gradient scale)."""
+    n_in, n_out, rows = 800, 50, 2000
+    p = _mnf_linear_params(5501, n_in, n_out)
+    x = recipes.gaussian(5502, rows, n_in).abs()
+    z = 1.0 + 0.3 * recipes.gaussian(5503, rows, n_in)
+    layer = amd.MNFLinear(n_in, n_out)
+    layer.load_state_dict(p, strict=False)
+    layer.to(DEV)
+    xg, zg = x.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+    layer.sample_z = _FixedZ(zg)
+    torch.manual_seed(77)
+    out = layer.forward(xg)
+    torch.manual_seed(77)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+    eps = layer.noise_for(seed, rows).cpu()
+    w_out = recipes.gaussian(5504, rows, n_out) / (rows * n_out)
+    g32, g64, ref_out = _mnf_linear_oracle_grads(O, p, x, z, eps, w_out)
+    assert_close(out, ref_out.float(), RTOL, "out (in-kernel noise)")
+    (out * w_out.to(DEV)).sum().backward()
+    got = {"x": xg.grad, "z": zg.grad, **{k: getattr(layer, k).grad for k in p}}
+    _check_grads(got, g32, g64, "MNFLinear, in-kernel noise, mean-loss cotangents")
+
+
+def test_mnf_linear_forward_gradients_range_guard(amd, O):
+    """Rows whose x z or x^2 leave the split range are flagged by the FORWARD launch; the backward pass skips their
+    128-row groups on the matrix cores and redoes them in fp32."""
+    n_in, n_out, rows = 800, 50, 128 * 3 + 50
+    p = _mnf_linear_params(5601, n_in, n_out)
+    x = recipes.gaussian(5602, rows, n_in).abs()
+    x[140] *= 400.0          # x^2 ~ 1e5 in group 1
+    x[300:303] *= 1e3        # group 2
+    z = 1.0 + 0.3 * recipes.gaussian(5603, rows, n_in)
+    eps = recipes.gaussian(5604, rows, n_out)
+    w_out = recipes.gaussian(5605, rows, n_out)
+    g32, g64, ref_out = _mnf_linear_oracle_grads(O, p, x, z, eps, w_out)
+    layer = amd.MNFLinear(n_in, n_out)
+    layer.load_state_dict(p, strict=False)
+    layer.to(DEV)
+    xg, zg = x.to(DEV).requires_grad_(True), z.to(DEV).requires_grad_(True)
+    layer.sample_z = _FixedZ(zg)
+    out = layer.forward(xg, eps=eps.to(DEV))
+    assert_close(out, ref_out.float(), RTOL, "out")
+    (out * w_out.to(DEV)).sum().backward()
+    got = {"x": xg.grad, "z": zg.grad, **{k: getattr(layer, k).grad for k in p}}
+    _check_grads(got, g32, g64, "MNFLinear range guard", base=2e-5)
+
+
+def test_mnf_linear_training_path_issues_hip_launches_only(amd):
+    """MNFLinear.forward + kl_div with gradients: no stock-PyTorch matrix product (aten::mm / addmm / bmm / linear) in
+    the forward + backward trace of the layer's forward -- the products are libmnf_hip.so launches (the
+    training path used to fall back to `(x * z) @ W_mean.T`)."""
+    from torch.profiler import ProfilerActivity, profile
+
+    torch.manual_seed(3)
+    layer = amd.MNFLinear(800, 50).to(DEV)
+    x = torch.rand(128, 800, device=DEV)
+    layer.forward(x).sum().backward()  # warm-up: index tables, images
+    layer.zero_grad()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        out = layer.forward(x)
+        out.pow(2).mean().backward()
+    names = {e.name for e in prof.events()}
+    gemms = sorted(n for n in names if n in ("aten::mm", "aten::addmm", "aten::bmm", "aten::linear", "aten::matmul"))
+    assert not gemms, f"stock-PyTorch matrix products on the MNFLinear.forward training path: {gemms}"
+    assert any("_MnfLinearFn" in n for n in names) and any("_RnvpFn" in n for n in names)
+    for name, prm in layer.named_parameters():
+        if name.startswith(("r0_", "flow_r")):
+            continue  # (kl_div's side of the layer: not touched by forward)
+        assert prm.grad is not None and torch.isfinite(prm.grad).all() and float(prm.grad.abs().sum()) > 0, name
+
+
+def test_mnf_linear_rejects_what_the_kernels_cannot_take(amd):
+    layer = amd.MNFLinear(32, 10).to(DEV)
+    with pytest.raises(ValueError):
+        layer.forward(torch.randn(4, 31, device=DEV))          # wrong width (ADVICE round 2: used to read out of bounds)
+    with pytest.raises(RuntimeError):
+        layer.forward(torch.randn(4, 32))                      # CPU input: no fallback
+    wide = amd.MNFLinear(32, 100).to(DEV)
+    with pytest.raises(amd.MnfHipError):
+        wide.forward(torch.randn(4, 32, device=DEV))           # n_out > 64: no kernel

@@ -8,6 +8,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 (The directory is ``torch_mnf_amd``: ``torch-mnf_amd`` is not an importable name.)
 """
 from . import _lib
+from ._lib import MnfHipError
 from .layers import MNFConv2d, MNFLinear
 from .train import FlatParameters, FusedAdam, GraphedStep
 from .flows import (
@@ -29,7 +30,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "GraphedStep", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "GraphedStep", "MnfHipError", "library_path",
 ]
 
 

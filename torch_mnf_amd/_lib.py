@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 8  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 9  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -123,6 +123,14 @@ SIGNATURES = {
     "mnf_mnf_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mnf_mnf_linear_noise": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_mnf_linear_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "mnf_mnf_linear_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "mnf_mnf_linear_bwd_layout": (c_int, [c_int, c_int, _i64p, _i64p]),
+    "mnf_mnf_linear_bwd_index": (c_int, [c_int, c_int, _i32p]),
+    "mnf_mnf_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -175,6 +175,19 @@ __device__ __forceinline__ float rnvp_mask_bit(uint64_t seed, int64_t row, int d
   return (float)((rnvp_mask_word(seed, row, dim >> 5) >> (dim & 31)) & 1u);
 }
 
+// counter-based N(0, 1) for the in-kernel noise: Box-Muller on two hashes of (seed, row, column).  Stateless, so
+// mnf_mnf_linear_noise() materialises exactly the numbers a seeded call used.
+__device__ __forceinline__ float ml_normal(uint64_t seed, int64_t row, int col) {
+  const uint32_t a = mix32((uint32_t)row * 0x9e3779b1u + (uint32_t)((uint64_t)row >> 32) + (uint32_t)(seed >> 32));
+  const uint32_t h1 = mix32(a ^ ((uint32_t)col * 0x85ebca77u + (uint32_t)seed));
+  const uint32_t h2 = mix32(h1 ^ 0x68bc21ebu);
+  const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
+  const float u2 = ((float)(h2 >> 8) + 0.5f) * (1.f / 16777216.f);
+  // hardware transcendentals (v_log_f32 = log2, v_cos_f32 takes revolutions): the stream is defined by these
+  // instructions, and mnf_mnf_linear_noise() reproduces it with the same ones
+  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
+
 // sum over the 4 lanes {j, j+16, j+32, j+48} that share a sample in the 16x16 MFMA layout
 __device__ __forceinline__ float sum_over_q(float v) {
   v += __shfl_xor(v, 16, 64);

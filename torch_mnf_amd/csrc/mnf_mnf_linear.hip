@@ -70,24 +70,12 @@ static void build_ml_index(int n_in, int n_out, int32_t* idx) {
         if (16 * m + i < n_out) pl[(which * YT + m) * 16 + i] = (int32_t)((which ? bv : bm) + 16 * m + i);
 }
 
-// counter-based N(0, 1) for the in-kernel noise: Box-Muller on two hashes of (seed, row, column).  Stateless, so
-// mnf_mnf_linear_noise() materialises exactly the numbers a seeded call used.
-__device__ __forceinline__ float ml_normal(uint64_t seed, int64_t row, int col) {
-  const uint32_t a = mix32((uint32_t)row * 0x9e3779b1u + (uint32_t)((uint64_t)row >> 32) + (uint32_t)(seed >> 32));
-  const uint32_t h1 = mix32(a ^ ((uint32_t)col * 0x85ebca77u + (uint32_t)seed));
-  const uint32_t h2 = mix32(h1 ^ 0x68bc21ebu);
-  const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
-  const float u2 = ((float)(h2 >> 8) + 0.5f) * (1.f / 16777216.f);
-  // hardware transcendentals (v_log_f32 = log2, v_cos_f32 takes revolutions): the stream is defined by these
-  // instructions, and mnf_mnf_linear_noise() reproduces it with the same ones
-  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
-}
-
 template <int YT, bool RAG>
 __global__ void __launch_bounds__(kMlWaves * 64, 2)
 mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
-                      float* __restrict__ out, const uint32_t* __restrict__ simage, int32_t* __restrict__ flags,
-                      int64_t rows, int n_in, int n_out, float var_unscale, uint64_t seed, int vec_ok) {
+                      float* __restrict__ out, float* __restrict__ sd_out, const uint32_t* __restrict__ simage,
+                      int32_t* __restrict__ flags, int64_t rows, int n_in, int n_out, float var_unscale, uint64_t seed,
+                      int vec_ok) {
   using S = MlShape<YT>;
   constexpr int KC = kMlKC, OPS = S::OPS;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][S::CHUNK_WORDS];
@@ -215,7 +203,9 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
           const int o = 16 * m + 4 * q + r;
           if (o < n_out) {
             const float e = eps ? eps[row * n_out + o] : ml_normal(seed, row, o);
-            out[row * n_out + o] = mean[r] + sqrtf(var[r]) * e;  // :56
+            const float sd = sqrtf(var[r]);
+            out[row * n_out + o] = mean[r] + sd * e;  // :56
+            if (sd_out) sd_out[row * n_out + o] = sd;  // (training: the backward pass needs d out / d var = eps / (2 sd))
           }
         }
       }
@@ -226,8 +216,9 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
 // fp32 recomputation of the flagged 128-row groups, from the flat parameters (k order, fmaf chain)
 __global__ void __launch_bounds__(256)
 mnf_linear_fixup_kernel(const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ eps,
-                        float* __restrict__ out, const float* __restrict__ flat, const int32_t* __restrict__ flags,
-                        int64_t rows, int n_in, int n_out, float var_unscale, uint64_t seed) {
+                        float* __restrict__ out, float* __restrict__ sd_out, const float* __restrict__ flat,
+                        const int32_t* __restrict__ flags, int64_t rows, int n_in, int n_out, float var_unscale,
+                        uint64_t seed) {
   const int grp = blockIdx.x;
   if (!flags[grp]) return;
   const float* wm = flat;
@@ -248,6 +239,7 @@ mnf_linear_fixup_kernel(const float* __restrict__ x, const float* __restrict__ z
     var = var * var_unscale + bv[o];
     const float e = eps ? eps[row * n_out + o] : ml_normal(seed, row, o);
     out[row * n_out + o] = mean + sqrtf(var) * e;
+    if (sd_out) sd_out[row * n_out + o] = sqrtf(var);
   }
 }
 
@@ -259,16 +251,16 @@ __global__ void mnf_linear_noise_kernel(uint64_t seed, float* __restrict__ eps, 
 static int ml_tiles(int n_out) { return n_out < 1 || n_out > 64 ? 0 : (n_out + 15) / 16; }
 
 template <int YT, bool RAG>
-static int launch_ml(const float* x, const float* z, const float* eps, float* out, const uint32_t* simage,
-                     int32_t* flags, int64_t rows, int n_in, int n_out, float var_unscale, uint64_t seed, int vec,
-                     hipStream_t stream) {
+static int launch_ml(const float* x, const float* z, const float* eps, float* out, float* sd_out,
+                     const uint32_t* simage, int32_t* flags, int64_t rows, int n_in, int n_out, float var_unscale,
+                     uint64_t seed, int vec, hipStream_t stream) {
   static DeviceMemo memo;
   const int resident = memo.get(
       [](int dev) { return resident_by_occupancy(mnf_linear_fwd_kernel<YT, RAG>, kMlWaves * 64, dev, 1); });
   const int64_t n_groups = (rows + 16 * kMlWaves - 1) / (16 * kMlWaves);
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   hipLaunchKernelGGL((mnf_linear_fwd_kernel<YT, RAG>), dim3((unsigned)blocks), dim3(kMlWaves * 64), 0, stream, x, z, eps,
-                     out, simage, flags, rows, n_in, n_out, var_unscale, seed, vec);
+                     out, sd_out, simage, flags, rows, n_in, n_out, var_unscale, seed, vec);
   return check_launch();
 }
 
@@ -304,9 +296,9 @@ int mnf_mnf_linear_split_index(int n_in, int n_out, int32_t* idx_host) {
   return MNF_ERR_UNSUPPORTED;
 }
 
-int mnf_mnf_linear_fwd(const float* x, const float* z, const float* eps, uint64_t seed, float* out, const float* flat,
-                       const void* split_image, float var_unscale, int32_t* workspace, int64_t rows, int n_in, int n_out,
-                       void* stream) {
+int mnf_mnf_linear_fwd_train(const float* x, const float* z, const float* eps, uint64_t seed, float* out, float* sd_out,
+                             const float* flat, const void* split_image, float var_unscale, int32_t* workspace,
+                             int64_t rows, int n_in, int n_out, void* stream) {
   if (!x || !z || !out || !flat || !split_image || !workspace || rows < 0 || n_in < 1 || n_out < 1 ||
       !(var_unscale > 0.f))
     return MNF_ERR_INVALID_ARG;
@@ -322,17 +314,24 @@ int mnf_mnf_linear_fwd(const float* x, const float* z, const float* eps, uint64_
   int rc = MNF_ERR_UNSUPPORTED;
 #define X(YT)                                                                                                         \
   if (yt == YT)                                                                                                       \
-    rc = ragged ? mnf::launch_ml<YT, true>(x, z, eps, out, simage, workspace, rows, n_in, n_out, var_unscale, seed,   \
-                                           vec, s)                                                                    \
-                : mnf::launch_ml<YT, false>(x, z, eps, out, simage, workspace, rows, n_in, n_out, var_unscale, seed,  \
-                                            vec, s);
+    rc = ragged ? mnf::launch_ml<YT, true>(x, z, eps, out, sd_out, simage, workspace, rows, n_in, n_out, var_unscale, \
+                                           seed, vec, s)                                                              \
+                : mnf::launch_ml<YT, false>(x, z, eps, out, sd_out, simage, workspace, rows, n_in, n_out,             \
+                                            var_unscale, seed, vec, s);
   X(1) X(2) X(3) X(4)
 #undef X
   if (rc != MNF_OK) return rc;
   const int64_t n_groups = (rows + 16 * mnf::kMlWaves - 1) / (16 * mnf::kMlWaves);
-  hipLaunchKernelGGL(mnf::mnf_linear_fixup_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, x, z, eps, out, flat,
+  hipLaunchKernelGGL(mnf::mnf_linear_fixup_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, x, z, eps, out, sd_out, flat,
                      workspace, rows, n_in, n_out, var_unscale, seed);
   return mnf::check_launch();
+}
+
+int mnf_mnf_linear_fwd(const float* x, const float* z, const float* eps, uint64_t seed, float* out, const float* flat,
+                       const void* split_image, float var_unscale, int32_t* workspace, int64_t rows, int n_in, int n_out,
+                       void* stream) {
+  return mnf_mnf_linear_fwd_train(x, z, eps, seed, out, nullptr, flat, split_image, var_unscale, workspace, rows, n_in,
+                                  n_out, stream);
 }
 
 int mnf_mnf_linear_noise(uint64_t seed, float* eps, int64_t rows, int n_out, void* stream) {

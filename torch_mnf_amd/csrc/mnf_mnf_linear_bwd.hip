@@ -1,0 +1,528 @@
+// Gradients of MNFLinear.forward (layers/mnf_linear.py:46-56 under loss.backward(); what tests/test_mnf_mnist.py:14-56
+// and examples/mnf_mnist.ipynb train through) on the f16 matrix pipe in split (hi + lo) fp32 arithmetic, gfx950.
+//
+//   forward   mean = (x z) Wm^T + bm;   var = x^2 Wv^T + bv   (Wv = exp(W_log_var), bv = exp(b_log_var));
+//             out = mean + sd eps,  sd = sqrt(var)
+//   backward  g_m = G;   g_v = G eps / (2 sd)                                         [G = grad_out, (rows, n_out)]
+//             a = g_m Wm,  b = g_v Wv   (rows, n_in);   grad_x = z a + 2 x b;   grad_z = x a
+//             dWm = g_m^T (x z);   dW_log_var = Wv (.) g_v^T x^2;   dbm = sum g_m;   db_log_var = bv sum g_v
+//
+// The same two-launch shape as the RNVP gradient kernels (mnf_rnvp_bwd.hip), with the roles of "hidden units" played
+// by the n_out <= 64 outputs: the per-row vectors g_m and g_v are small, the weight gradients are 2 n_out n_in sums over
+// all rows.  A row-parallel PROLOGUE turns G, eps and the saved sd into g_m, g_v as ready-made split MFMA operands in
+// both orientations (HandoverShape: 1 KB per row at n_out = 50) and sums the bias gradients; the SLAB launch gives a
+// workgroup 32 input dims and a range of rows: per 32 rows a, b (K = outputs), grad_x and grad_z (the only row data
+// written; x and z are read once), and dWm, dWv as K = 32-ROW products into 4 YT accumulator tiles that stay in
+// registers over the whole row range.  Everything in the slab launch is computed transposed (rows on the MFMA M axis),
+// so an accumulator holds four ROWS of one dim per lane -- the operand layout of a sum over rows; rows are read and
+// written as 8-byte pieces (dims 2 j, 2 j + 1 of the slab).
+//
+// The image's exp(W_log_var) carries the power of two of the forward image; `var_unscale` undoes it on the way OUT of
+// every product with it (folded into the operand g_v it would push that operand to ~1e-4, where the unscaled f16
+// residuals of the row sums have no bits left).  G takes the gradient scale on the way in (mnf_affine_half_grad_scale:
+// cotangents of a mean are ~1 / rows, below f16's normal range), undone on the way out.  128-row groups
+// the FORWARD pass flagged (|x z| or x^2 beyond the split range, or weights beyond the weight limit) and groups whose
+// cotangents leave the range are skipped by the slab launch and redone in fp32 by ml_bwd_fixup_kernel.
+#include <hip/hip_runtime.h>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+#include "mnf_rnvp_common.h"
+#include "mnf_split.h"
+
+namespace mnf {
+
+constexpr int kMlbGroupRows = 128;  // rows per flag: the forward kernel's 8-wave group
+constexpr int kMlbWaves = 4;        // waves of a slab workgroup
+
+template <int YT>
+struct MlBwdShape {
+  using H = HandoverShape<YT>;
+  static constexpr int NKS = H::NKS;
+  // backward image, per 32-dim slab: (dim tile E/O) x (Wm, Wv') x NKS x (hi, lo) B operands with the outputs on K
+  static constexpr int SLAB_WORDS = 2 * 2 * NKS * 512;
+  static constexpr int64_t n_slabs(int n_in) { return (n_in + 31) / 32; }
+  static constexpr int64_t split_words(int n_in) { return n_slabs(n_in) * SLAB_WORDS; }
+};
+
+// ------------------------------------------------------------------------------------------------ prologue
+// one 8-wave workgroup per 128-row group (the forward pass's flag granularity), a wave per 16-row tile
+template <int YT>
+__global__ void __launch_bounds__(8 * 64)
+ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__ sd, const float* __restrict__ eps,
+                       uint64_t seed, const float* __restrict__ flat, const int32_t* __restrict__ fwd_flags,
+                       uint32_t* __restrict__ side, int32_t* __restrict__ flags, int32_t* __restrict__ list,
+                       const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int n_in,
+                       int n_out, float var_unscale, float wmax_limit_ok) {
+  using H = HandoverShape<YT>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float gscale = gscale_dev[0];
+  const int n_groups = (int)((rows + kMlbGroupRows - 1) / kMlbGroupRows);
+  f32x4 bm_acc[YT], bv_acc[YT];
+#pragma unroll
+  for (int m = 0; m < YT; ++m) bm_acc[m] = bv_acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t tile = (int64_t)grp * 8 + wave;
+    const int64_t row = tile * 16 + j;
+    const bool live = row < rows;
+    const int64_t rc = live ? row : rows - 1;
+    f32x4 gm[YT], gv[YT], gvt[YT];
+    u32x2 mh[YT], ml[YT], vh[YT], vl[YT];
+    float mx = wmax_limit_ok > 0.f ? 0.f : __builtin_inff();
+#pragma unroll
+    for (int m = 0; m < YT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * m + 4 * q + r;
+        float g = 0.f, v = 0.f;
+        if (live && o < n_out) {
+          g = gout[rc * n_out + o];
+          const float e = eps ? eps[rc * n_out + o] : ml_normal(seed, rc, o);
+          v = g * e / (2.f * sd[rc * n_out + o]);  // d out / d var = eps / (2 sqrt(var))   (mnf_linear.py:56)
+        }
+        gm[m][r] = g * gscale;
+        gvt[m][r] = v;
+        gv[m][r] = v * gscale;  // (O(1) like g_m: the unscaled residuals of the row sums need operands near 1)
+      }
+      split_tile(gm[m], mh[m], ml[m], mx);
+      split_tile(gv[m], vh[m], vl[m], mx);
+    }
+    const bool bad = __syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0) != 0 || fwd_flags[grp] != 0;
+    if (threadIdx.x == 0) {
+      flags[grp] = bad ? 1 : 0;
+      if (bad) list[1 + atomicAdd(list, 1)] = grp;  // (list[0] zeroed by the launcher)
+    }
+    if (bad || tile * 16 >= rows) continue;
+#pragma unroll
+    for (int m = 0; m < YT; ++m) {
+      bm_acc[m] += gm[m];
+      bv_acc[m] += gvt[m];
+    }
+    store_handover<YT>(side + tile * H::TILE_WORDS, mh, ml, vh, vl, lane, j, q);
+  }
+  // db_mean, db_log_var = exp(b_log_var) sum g_v: sums over the wave's rows (the 16 lanes j of a q)
+  if (grad_flat) {
+    const float inv = 1.f / gscale;
+    const int64_t bmo = 2 * (int64_t)n_out * n_in, bvo = bmo + n_out;
+#pragma unroll
+    for (int m = 0; m < YT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = bm_acc[m][r], b = bv_acc[m][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          a += __shfl_xor(a, off, 64);
+          b += __shfl_xor(b, off, 64);
+        }
+        const int o = 16 * m + 4 * q + r;
+        if (j == 0 && o < n_out) {
+          if (a != 0.f) atomicAdd(grad_flat + bmo + o, a * inv);
+          if (b != 0.f) atomicAdd(grad_flat + bvo + o, b * flat[bvo + o]);
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ slab launch
+// lane (c, q): column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers
+template <int YT, bool RAG>
+__global__ void __launch_bounds__(kMlbWaves * 64, 2)
+ml_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ grad_x,
+                   float* __restrict__ grad_z, float* __restrict__ grad_flat, const float* __restrict__ flat,
+                   const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
+                   const float* __restrict__ gscale_dev, int64_t rows, int n_in, int n_out, int n_slabs, int row_parts,
+                   int vec2, float var_unscale) {
+  using S = MlBwdShape<YT>;
+  using H = HandoverShape<YT>;
+  constexpr int NKS = S::NKS;
+  constexpr int UP = 33;  // padded row of the flush area ([output][dim of the slab])
+  constexpr int LDS_WORDS = S::SLAB_WORDS > 2 * 16 * YT * UP ? S::SLAB_WORDS : 2 * 16 * YT * UP;
+  __shared__ __attribute__((aligned(16))) uint32_t w_lds[LDS_WORDS];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const float inv_gscale = 1.f / gscale_dev[0];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
+  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
+  const SlabItems items(n_slabs, row_parts);
+  for (int item = items.first; item < items.n_items; item += items.step) {
+    const int slab = items.slab(item), part = items.part(item);
+    __syncthreads();  // the previous item's flush area is no longer read
+    {
+      const uint32_t* src = bimage + (int64_t)slab * S::SLAB_WORDS;
+      for (int i = threadIdx.x; i < S::SLAB_WORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(w_lds)[i] = reinterpret_cast<const uint4*>(src)[i];
+    }
+    __syncthreads();
+    const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
+    const bool in0 = dim0 < n_in, in1 = dim0 + 1 < n_in;
+    // operand numbering in LDS: [(dt * 2 + which) * NKS + ks][part], which = 0: W_mean, 1: exp(W_log_var) (scaled)
+    int w_lane = lane;  // (opaque, refreshed per pair: keeps the operand reads inside the pair loop)
+    const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds);
+    auto wop = [&](int dt, int which, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + which) * NKS + ks) + part_)]; };
+    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)n_in + (uint32_t)dim0;
+
+    f32x4 aWm[2][YT], aWv[2][YT];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m) aWm[dt][m] = aWv[dt][m] = zero4;
+
+    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kMlbWaves) {
+      if (flags[(p * 32) / kMlbGroupRows]) continue;  // the fp32 kernel redoes flagged groups
+      asm volatile("" : "+v"(w_lane));
+      const bool has1 = 2 * p + 1 < n_tiles;
+      u32x2 ph[2][2], pl[2][2], sh[2][2], sl[2][2];  // [row tile][dim tile]: x z and x^2 as B operands of the row sums
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const bool has = tt == 0 || has1;
+        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;              // wave-uniform
+        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
+        const float* xt = x + tbase * n_in;
+        const float* zt = z + tbase * n_in;
+        const uint32_t* sd_ = side + (tbase >> 4) * H::TILE_WORDS;
+        f32x2 xx[4], zz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool live = 4 * q + r < n_live;
+          const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)n_in : (uint32_t)dim0;
+          f32x2 xv = {0.f, 0.f}, zv = {0.f, 0.f};
+          if (!RAG) {
+            xv = *reinterpret_cast<const f32x2*>(xt + off);
+            zv = *reinterpret_cast<const f32x2*>(zt + off);
+          } else if (vec2) {
+            if (in0) {
+              xv = *reinterpret_cast<const f32x2*>(xt + off);
+              zv = *reinterpret_cast<const f32x2*>(zt + off);
+            }
+          } else {
+            if (in0) {
+              xv[0] = xt[off];
+              zv[0] = zt[off];
+            }
+            if (in1) {
+              xv[1] = xt[off + 1];
+              zv[1] = zt[off + 1];
+            }
+          }
+          const float keep = live ? 1.f : 0.f;  // (the cotangents of a row past the end are zero; keep its x z finite)
+          xx[r] = xv * keep;
+          zz[r] = zv * keep;
+        }
+        f16x8 moh[NKS], mol[NKS], voh[NKS], vol[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          moh[ks] = *reinterpret_cast<const f16x8*>(sd_ + H::A_OP + ((2 * ks) * 64 + lane) * 4);
+          mol[ks] = *reinterpret_cast<const f16x8*>(sd_ + H::A_OP + ((2 * ks + 1) * 64 + lane) * 4);
+          voh[ks] = *reinterpret_cast<const f16x8*>(sd_ + H::B_OP + ((2 * ks) * 64 + lane) * 4);
+          vol[ks] = *reinterpret_cast<const f16x8*>(sd_ + H::B_OP + ((2 * ks + 1) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          // a^T, b^T [row][dim] = g [row][output] W [output][dim]
+          f32x4 am = zero4, ac = zero4, bm = zero4, bc = zero4;
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            split_mac(moh[ks], mol[ks], wop(dt, 0, ks, 0), wop(dt, 0, ks, 1), am, ac);
+            split_mac(voh[ks], vol[ks], wop(dt, 1, ks, 0), wop(dt, 1, ks, 1), bm, bc);
+          }
+          const f32x4 a4 = (ac * kSplitInvScale + am) * inv_gscale;
+          const f32x4 b4 = (bc * kSplitInvScale + bm) * (inv_gscale * var_unscale);
+          f32x4 pz, x2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xv = xx[r][dt], zv = zz[r][dt];
+            pz[r] = xv * zv;                                   // the forward pass's operands (mnf_linear.py:48,53)
+            x2[r] = xv * xv;
+            xx[r][dt] = zv * a4[r] + 2.f * (xv * b4[r]);       // grad_x takes x's register, grad_z z's
+            zz[r][dt] = xv * a4[r];
+          }
+          split_plain(pz, ph[tt][dt], pl[tt][dt]);
+          split_plain(x2, sh[tt][dt], sl[tt][dt]);
+        }
+        if (has) {
+          float* ox = grad_x + tbase * n_in;
+          float* oz = grad_z + tbase * n_in;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (4 * q + r < n_live) {
+              const uint32_t off = lane_off + (uint32_t)r * (uint32_t)n_in;
+              if (!RAG) {
+                *reinterpret_cast<f32x2*>(ox + off) = xx[r];
+                *reinterpret_cast<f32x2*>(oz + off) = zz[r];
+              } else if (vec2) {  // (n_in even: in0 implies in1)
+                if (in0) {
+                  *reinterpret_cast<f32x2*>(ox + off) = xx[r];
+                  *reinterpret_cast<f32x2*>(oz + off) = zz[r];
+                }
+              } else {
+                if (in0) {
+                  ox[off] = xx[r][0];
+                  oz[off] = zz[r][0];
+                }
+                if (in1) {
+                  ox[off + 1] = xx[r][1];
+                  oz[off + 1] = zz[r][1];
+                }
+              }
+            }
+          }
+        }
+        if (!has) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) ph[tt][dt] = pl[tt][dt] = sh[tt][dt] = sl[tt][dt] = zero2;
+        }
+      }
+      if (grad_flat) {
+        // sums over the 32 rows: D [output][dim] += A [output][row] B [row][dim], three partial products, one accumulator
+        const uint32_t* s0 = side + (2 * p) * H::TILE_WORDS + lane * 2;
+        const uint32_t* s1 = side + (2 * p + (has1 ? 1 : 0)) * H::TILE_WORDS + lane * 2;
+#pragma unroll
+        for (int m = 0; m < YT; ++m) {
+          const f16x8 mh8 = pair_operand(*reinterpret_cast<const u32x2*>(s0 + H::A_TR + (2 * m) * 128),
+                                         *reinterpret_cast<const u32x2*>(s1 + H::A_TR + (2 * m) * 128));
+          const f16x8 ml8 = pair_operand(*reinterpret_cast<const u32x2*>(s0 + H::A_TR + (2 * m + 1) * 128),
+                                         *reinterpret_cast<const u32x2*>(s1 + H::A_TR + (2 * m + 1) * 128));
+          const f16x8 vh8 = pair_operand(*reinterpret_cast<const u32x2*>(s0 + H::B_TR + (2 * m) * 128),
+                                         *reinterpret_cast<const u32x2*>(s1 + H::B_TR + (2 * m) * 128));
+          const f16x8 vl8 = pair_operand(*reinterpret_cast<const u32x2*>(s0 + H::B_TR + (2 * m + 1) * 128),
+                                         *reinterpret_cast<const u32x2*>(s1 + H::B_TR + (2 * m + 1) * 128));
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {  // (no second tile: the B operands are zero there)
+            const f16x8 pH = pair_operand(ph[0][dt], ph[1][dt]), pL = pair_operand(pl[0][dt], pl[1][dt]);
+            const f16x8 sH = pair_operand(sh[0][dt], sh[1][dt]), sL = pair_operand(sl[0][dt], sl[1][dt]);
+            aWm[dt][m] = mfma_h(mh8, pH, aWm[dt][m]);
+            aWv[dt][m] = mfma_h(vh8, sH, aWv[dt][m]);
+            aWm[dt][m] = mfma_h(mh8, pL, aWm[dt][m]);
+            aWv[dt][m] = mfma_h(vh8, sL, aWv[dt][m]);
+            aWm[dt][m] = mfma_h(ml8, pH, aWm[dt][m]);
+            aWv[dt][m] = mfma_h(vl8, sH, aWv[dt][m]);
+          }
+        }
+      }
+    }
+    if (!grad_flat) continue;
+    // flush through LDS (the operand area is free now): the four waves add their tiles up as [tensor][output][dim of
+    // the slab]; the workgroup then adds 128 contiguous bytes of a weight row per half wave to grad_flat (scattered
+    // atomics run an order of magnitude slower at the memory side).  dW_log_var = exp(W_log_var) (.) dWv: the image's
+    // scaled exp(W_log_var) (flat) times the scaled sum is the true product.
+    float* red = reinterpret_cast<float*>(w_lds);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 16 * YT * UP; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(red + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWm[dt][m][r]);
+          atomicAdd(red + 16 * YT * UP + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWv[dt][m][r]);
+        }
+    __syncthreads();
+    const int n_dims = min(32, n_in - 32 * slab);
+    const int64_t wv = (int64_t)n_out * n_in;
+    for (int e = threadIdx.x; e < n_out * 32; e += blockDim.x) {
+      const int o = e >> 5, dl = e & 31;
+      if (dl < n_dims) {
+        const int64_t at = (int64_t)o * n_in + 32 * slab + dl;
+        atomicAdd(grad_flat + at, red[o * UP + dl] * inv_gscale);
+        atomicAdd(grad_flat + wv + at, red[16 * YT * UP + o * UP + dl] * flat[wv + at] * (inv_gscale * var_unscale));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 fix-up
+// the listed 128-row groups from the flat parameters: grad_x, grad_z per element, weight gradients by atomics (rare path)
+__global__ void __launch_bounds__(256)
+ml_bwd_fixup_kernel(const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ gout,
+                    const float* __restrict__ sd, const float* __restrict__ eps, uint64_t seed, float* __restrict__ grad_x,
+                    float* __restrict__ grad_z, float* __restrict__ grad_flat, const float* __restrict__ flat,
+                    const int32_t* __restrict__ list, int64_t rows, int n_in, int n_out, float var_unscale) {
+  __shared__ float gm[64], gv[64];
+  const float* wm = flat;
+  const float* wvs = flat + (int64_t)n_out * n_in;  // exp(W_log_var) / var_unscale
+  const int64_t bmo = 2 * (int64_t)n_out * n_in, bvo = bmo + n_out;
+  const int n = list[0];
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int64_t row0 = (int64_t)list[1 + e] * kMlbGroupRows;
+    for (int64_t row = row0; row < row0 + kMlbGroupRows && row < rows; ++row) {
+      __syncthreads();
+      if ((int)threadIdx.x < n_out) {
+        const int o = threadIdx.x;
+        const float g = gout[row * n_out + o];
+        const float ev = eps ? eps[row * n_out + o] : ml_normal(seed, row, o);
+        const float v = g * ev / (2.f * sd[row * n_out + o]);
+        gm[o] = g;
+        gv[o] = v;
+        if (grad_flat) {
+          atomicAdd(grad_flat + bmo + o, g);
+          atomicAdd(grad_flat + bvo + o, v * flat[bvo + o]);
+        }
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < n_in; c += blockDim.x) {
+        const float xv = x[row * n_in + c], zv = z[row * n_in + c];
+        float a = 0.f, b = 0.f;
+        for (int o = 0; o < n_out; ++o) {
+          a = fmaf(gm[o], wm[(int64_t)o * n_in + c], a);
+          b = fmaf(gv[o], wvs[(int64_t)o * n_in + c], b);
+        }
+        b *= var_unscale;
+        grad_x[row * n_in + c] = zv * a + 2.f * (xv * b);
+        grad_z[row * n_in + c] = xv * a;
+        if (grad_flat)
+          for (int o = 0; o < n_out; ++o) {
+            atomicAdd(grad_flat + (int64_t)o * n_in + c, gm[o] * (xv * zv));
+            atomicAdd(grad_flat + (int64_t)n_out * n_in + (int64_t)o * n_in + c,
+                      gv[o] * (xv * xv) * (wvs[(int64_t)o * n_in + c] * var_unscale));
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+// flat: W_mean (n_out, n_in) | exp(W_log_var) * 2^shift (n_out, n_in) | b_mean | exp(b_log_var)   (as for the forward image)
+template <int YT>
+static void build_mlb_index(int n_in, int n_out, int32_t* idx) {
+  using S = MlBwdShape<YT>;
+  constexpr int NKS = S::NKS;
+  const int64_t wm = 0, wv = (int64_t)n_out * n_in;
+  const int64_t n_entries = 2 * S::split_words(n_in);
+  for (int64_t i = 0; i < n_entries; ++i) idx[i] = -1;
+  auto put = [&](int64_t base_words, int op, int lane, int e, int64_t src) {
+    for (int part = 0; part < 2; ++part)
+      idx[2 * base_words + (((int64_t)(2 * op + part) * 64 + lane) * 4 + (e >> 1)) * 2 + (e & 1)] =
+          (int32_t)src | (part ? kSplitLoBit : 0);
+  };
+  // slot 8 kq + e of K-step ks <-> output 16 (2 ks + (e >> 2)) + 4 kq + (e & 3)   (as the hand-over's A operands)
+  for (int sl = 0; sl < S::n_slabs(n_in); ++sl)
+    for (int dt = 0; dt < 2; ++dt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int c = lane & 15, kq = lane >> 4, dim = 32 * sl + 2 * c + dt;
+        if (dim >= n_in) continue;
+        for (int ks = 0; ks < NKS; ++ks)
+          for (int e = 0; e < 8; ++e) {
+            const int o = 16 * (2 * ks + (e >> 2)) + 4 * kq + (e & 3);
+            if (o >= n_out || 2 * ks + (e >> 2) >= YT) continue;
+            for (int which = 0; which < 2; ++which)
+              put((int64_t)sl * S::SLAB_WORDS, (dt * 2 + which) * NKS + ks, lane, e, (which ? wv : wm) + (int64_t)o * n_in + dim);
+          }
+      }
+}
+
+static int mlb_tiles(int n_out) { return n_out < 1 || n_out > 64 ? 0 : (n_out + 15) / 16; }
+
+static int64_t mlb_header_bytes(int64_t rows) {
+  const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
+  return (((1 + 2 * n_groups) * 4 + 255) & ~(int64_t)255);
+}
+
+template <int YT, bool RAG>
+static int launch_mlb(const float* x, const float* z, const float* gout, const float* sd, const float* eps, uint64_t seed,
+                      float* grad_x, float* grad_z, float* grad_flat, const float* flat, const uint32_t* bimage,
+                      float var_unscale, const int32_t* fwd_flags, const float* gscale, void* work, int64_t rows, int n_in,
+                      int n_out, int vec2, hipStream_t stream) {
+  using S = MlBwdShape<YT>;
+  using H = HandoverShape<YT>;
+  const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
+  int32_t* list = static_cast<int32_t*>(work);
+  int32_t* flags = list + 1 + n_groups;
+  uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + mlb_header_bytes(rows));
+  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
+  const int cus = device_cus(current_device());
+  const int64_t blocks_p = n_groups < 2 * cus ? n_groups : 2 * cus;
+  hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,
+                     flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f);
+  if (int rc = check_launch()) return rc;
+  static DeviceMemo memo;
+  const int resident = memo.get(
+      [](int dev) { return resident_by_occupancy(ml_bwd_slab_kernel<YT, RAG>, kMlbWaves * 64, dev, 2); });
+  const int n_slabs = (int)S::n_slabs(n_in);
+  int row_parts, grid;
+  plan_slab_launch(((rows + 15) / 16 + 1) / 2, kMlbWaves, n_slabs, resident, row_parts, grid);
+  hipLaunchKernelGGL((ml_bwd_slab_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlbWaves * 64), 0, stream, x, z, grad_x,
+                     grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out, n_slabs, row_parts, vec2,
+                     var_unscale);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(ml_bwd_fixup_kernel, dim3(256), dim3(256), 0, stream, x, z, gout, sd, eps, seed, grad_x, grad_z,
+                     grad_flat, flat, list, rows, n_in, n_out, var_unscale);
+  return check_launch();
+}
+
+}  // namespace mnf
+
+extern "C" {
+
+using namespace mnf;
+
+int64_t mnf_mnf_linear_bwd_workspace_bytes(int64_t rows, int n_in, int n_out) {
+  const int yt = mlb_tiles(n_out);
+  if (rows < 0 || n_in < 1 || yt == 0) return 0;
+  const int64_t r = rows < 1 ? 1 : rows;
+  int64_t tile_words = 0;
+#define X(YT) if (yt == YT) tile_words = HandoverShape<YT>::TILE_WORDS;
+  X(1) X(2) X(3) X(4)
+#undef X
+  return mlb_header_bytes(r) + ((r + 15) / 16) * tile_words * 4;
+}
+
+int mnf_mnf_linear_bwd_layout(int n_in, int n_out, int64_t* n_split_words, int64_t* n_plain_words) {
+  if (!n_split_words || !n_plain_words || n_in < 1) return MNF_ERR_INVALID_ARG;
+  const int yt = mlb_tiles(n_out);
+  if (yt == 0 || (int64_t)n_in * 64 * 8 >= (1ll << 30)) return MNF_ERR_UNSUPPORTED;
+#define X(YT) if (yt == YT) *n_split_words = MlBwdShape<YT>::split_words(n_in);
+  X(1) X(2) X(3) X(4)
+#undef X
+  *n_plain_words = 0;
+  return MNF_OK;
+}
+
+int mnf_mnf_linear_bwd_index(int n_in, int n_out, int32_t* idx_host) {
+  if (!idx_host || n_in < 1) return MNF_ERR_INVALID_ARG;
+  const int yt = mlb_tiles(n_out);
+#define X(YT)                                   \
+  if (yt == YT) {                               \
+    build_mlb_index<YT>(n_in, n_out, idx_host); \
+    return MNF_OK;                              \
+  }
+  X(1) X(2) X(3) X(4)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int mnf_mnf_linear_bwd(const float* x, const float* z, const float* grad_out, const float* sd, const float* eps,
+                       uint64_t seed, float* grad_x, float* grad_z, float* grad_flat, const float* flat,
+                       const void* bwd_image, float var_unscale, const int32_t* fwd_flags, const float* grad_scale_dev,
+                       void* workspace, int64_t workspace_bytes, int64_t rows, int n_in, int n_out, void* stream) {
+  if (!x || !z || !grad_out || !sd || !grad_x || !grad_z || !flat || !bwd_image || !fwd_flags || !grad_scale_dev ||
+      !workspace || rows < 0 || n_in < 1 || n_out < 1 || !(var_unscale > 0.f))
+    return MNF_ERR_INVALID_ARG;
+  const int yt = mlb_tiles(n_out);
+  if (yt == 0) return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  if (workspace_bytes < mnf_mnf_linear_bwd_workspace_bytes(rows, n_in, n_out)) return MNF_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(workspace)) & 15) return MNF_ERR_UNSUPPORTED;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(z) |
+                         reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(grad_z);
+  const bool ragged = (n_in & 31) != 0 || (ptrs & 7) != 0;
+  const int vec2 = (ptrs & 7) == 0 && (n_in & 1) == 0;
+  const uint32_t* bi = static_cast<const uint32_t*>(bwd_image);
+  hipStream_t st = (hipStream_t)stream;
+#define X(YT)                                                                                                          \
+  if (yt == YT)                                                                                                        \
+    return ragged ? launch_mlb<YT, true>(x, z, grad_out, sd, eps, seed, grad_x, grad_z, grad_flat, flat, bi, var_unscale, \
+                                         fwd_flags, grad_scale_dev, workspace, rows, n_in, n_out, vec2, st)            \
+                  : launch_mlb<YT, false>(x, z, grad_out, sd, eps, seed, grad_x, grad_z, grad_flat, flat, bi,          \
+                                          var_unscale, fwd_flags, grad_scale_dev, workspace, rows, n_in, n_out, vec2, st);
+  X(1) X(2) X(3) X(4)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

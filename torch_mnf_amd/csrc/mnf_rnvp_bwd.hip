@@ -43,7 +43,6 @@
 
 namespace mnf {
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBwdGroupRows = 16 * kRnvpWaves;  // rows per flag (A's 8-wave group)
 constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
@@ -73,32 +72,15 @@ struct RnvpBwdShape {
   static constexpr int64_t b4_words(int dm) { return n_slabs(dm) * B4_SLAB_WORDS; }
   static constexpr int64_t split_words(int dm, int d16) { return a3_words(d16) + b2_words(dm) + b4_words(dm); }
   static constexpr int64_t plain_words(int dm) { return n_slabs(dm) * B_SLAB_PLAIN; }
-  // hand-over per 16-row tile (32-bit words): y and g_y as A operands with units on K ([ks][hi|lo][lane][4]) and with
-  // rows on K ([unit tile][hi|lo'][lane][2]; lo' = the UNSCALED residual, so that a sum over rows needs one accumulator)
-  static constexpr int OP_WORDS = NKS2 * 2 * 256;
-  static constexpr int TR_WORDS = YT * 2 * 128;
-  static constexpr int TILE_WORDS = 2 * OP_WORDS + 2 * TR_WORDS;
-  static constexpr int Y_OP = 0, G_OP = OP_WORDS, Y_TR = 2 * OP_WORDS, G_TR = 2 * OP_WORDS + TR_WORDS;
+  // hand-over per 16-row tile: y ("a") and g_y ("b"), see HandoverShape
+  using H = HandoverShape<YT>;
+  static constexpr int TILE_WORDS = H::TILE_WORDS;
+  static constexpr int Y_OP = H::A_OP, G_OP = H::B_OP, Y_TR = H::A_TR, G_TR = H::B_TR;
   // A's LDS window: a GEMM-1 chunk (KC K-steps) or one second-sweep tile (forward GEMM-2 tile + its A3 operands)
   static constexpr int CHUNK_WORDS =
       S::KC * S::KS1_WORDS > S::TILE2_WORDS + A3_TILE_WORDS ? S::KC * S::KS1_WORDS : S::TILE2_WORDS + A3_TILE_WORDS;
   static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);
 };
-
-__device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
-}
-// four fp32 values -> f16 heads and UNSCALED f16 residuals (v - head): the operands of a product whose three partial
-// products go into one accumulator.  Below 2^-13 the residual is an f16 subnormal or zero: an absolute error of at most
-// 2^-25 on data scaled to O(1), fp32's own rounding of a sum whose largest terms are O(1).
-__device__ __forceinline__ void split_plain(const f32x4& v, u32x2& hi, u32x2& lo) {
-  const uint32_t h0 = cvt_pk(v[0], v[1]), h1 = cvt_pk(v[2], v[3]);
-  hi = u32x2{h0, h1};
-  lo = u32x2{cvt_pk(residual_lo(h0, v[0]), residual_hi(h0, v[1])), cvt_pk(residual_lo(h1, v[2]), residual_hi(h1, v[3]))};
-}
 
 // ================================================================================================ kernel A
 template <int HN, bool SEEDED, bool RAG>
@@ -325,42 +307,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
   if (tile * 16 >= rows) return;  // wave-uniform: a tile past the end (the group's last rows)
 #pragma unroll
   for (int m = 0; m < YT; ++m) bn_acc[m] += gy[m];  // (dead rows carry g_y = 0)
-  uint32_t* out = side + tile * B::TILE_WORDS;
-  // units on K: operand ks = (tiles 2 ks, 2 ks + 1)
-#pragma unroll
-  for (int ks = 0; ks < NKS2; ++ks) {
-    const bool two = 2 * ks + 1 < YT;
-    const u32x2 yb = two ? yh[two ? 2 * ks + 1 : 0] : zero2, ybl = two ? yl[two ? 2 * ks + 1 : 0] : zero2;
-    const u32x2 gb = two ? gh[two ? 2 * ks + 1 : 0] : zero2, gbl = two ? gl2[two ? 2 * ks + 1 : 0] : zero2;
-    *reinterpret_cast<u32x4*>(out + B::Y_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{yh[2 * ks][0], yh[2 * ks][1], yb[0], yb[1]};
-    *reinterpret_cast<u32x4*>(out + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{yl[2 * ks][0], yl[2 * ks][1], ybl[0], ybl[1]};
-    *reinterpret_cast<u32x4*>(out + B::G_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{gh[2 * ks][0], gh[2 * ks][1], gb[0], gb[1]};
-    *reinterpret_cast<u32x4*>(out + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{gl2[2 * ks][0], gl2[2 * ks][1], gbl[0], gbl[1]};
-  }
-  // rows on K: one MFMA against the identity per tile and part turns "lane = row, registers = units" into
-  // "lane = unit, registers = rows" (D[row][unit'] = sum_k A[row][k] I[k][unit'], every product x 1: exact); the tail
-  // goes against 2^-11 I and comes out unscaled
-  u32x2 id, ids;
-  {
-    const _Float16 one = (_Float16)1.f, tiny = (_Float16)kSplitInvScale, zero = (_Float16)0.f;
-    f16x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      a[e] = (4 * q + e == j) ? one : zero;
-      b[e] = (4 * q + e == j) ? tiny : zero;
-    }
-    id = __builtin_bit_cast(u32x2, a);
-    ids = __builtin_bit_cast(u32x2, b);
-  }
-#pragma unroll
-  for (int m = 0; m < YT; ++m) {
-    const f32x4 a = mfma16(yh[m], id, zero4), b = mfma16(yl[m], ids, zero4);
-    const f32x4 c = mfma16(gh[m], id, zero4), e = mfma16(gl2[m], ids, zero4);
-    *reinterpret_cast<u32x2*>(out + B::Y_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(a[0], a[1]), cvt_pk(a[2], a[3])};
-    *reinterpret_cast<u32x2*>(out + B::Y_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(b[0], b[1]), cvt_pk(b[2], b[3])};
-    *reinterpret_cast<u32x2*>(out + B::G_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(c[0], c[1]), cvt_pk(c[2], c[3])};
-    *reinterpret_cast<u32x2*>(out + B::G_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(e[0], e[1]), cvt_pk(e[2], e[3])};
-  }
+  store_handover<YT>(side + tile * B::TILE_WORDS, yh, yl, gh, gl2, lane, j, q);
 }
 
 template <int HN, bool SEEDED, bool RAG>
@@ -406,25 +353,6 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
 }
 
 // ================================================================================================ kernels B
-// Work items = (row part, slab) over a persistent grid.  With >= 8 row parts, part p belongs to XCD p % 8 (workgroups
-// go to the XCDs round robin: block b runs on XCD b % 8) and that XCD's workgroups take its items in (part, slab) order:
-// the n_slabs workgroups on one row part then run on ONE XCD at about the same time and walk the same rows, so the
-// per-row hand-over (read by every slab) is fetched into that XCD's L2 once.
-struct BwdItems {
-  int n_items, first, step, n_slabs, xcd;
-  bool by_xcd;
-  __device__ __forceinline__ BwdItems(int n_slabs_, int row_parts) : n_slabs(n_slabs_) {
-    by_xcd = row_parts >= 8;
-    xcd = blockIdx.x & 7;
-    const int local_parts = by_xcd ? (row_parts - xcd + 7) / 8 : 0;
-    n_items = by_xcd ? local_parts * n_slabs : row_parts * n_slabs;
-    first = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  }
-  __device__ __forceinline__ int slab(int item) const { return item % n_slabs; }
-  __device__ __forceinline__ int part(int item) const { return by_xcd ? (item / n_slabs) * 8 + xcd : item / n_slabs; }
-};
-
 // the mask words of a tile's 16 rows for one 32-dim slab: lane l hashes row (l & 15) once, the four rows a lane needs
 // (4 q + r) are fetched from the lanes that hold them -- one hash and four cross-lane reads instead of four hashes
 __device__ __forceinline__ void tile_mask_words(uint64_t seed, int64_t tbase, int n_live, int slab, int lane, int q,
@@ -462,7 +390,7 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
   const float gx_scale = gx ? gscale : 0.f;
   const float gl_scale = gld ? gscale : 0.f;
   const float* lsrc = gld ? gld : z;
-  const BwdItems items(n_slabs, row_parts);
+  const SlabItems items(n_slabs, row_parts);
   for (int item = items.first; item < items.n_items; item += items.step) {
     const int slab = items.slab(item), part = items.part(item);
     __syncthreads();  // the previous item's operands are no longer read
@@ -498,24 +426,27 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
 #pragma unroll
       for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = zero4;
 
-    const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
-    for (int64_t p = (int64_t)part * per_part + wave; p < p_end; p += kBwdBWaves) {
-      if (flags[(p * 32) / kBwdGroupRows]) continue;  // the generic kernel redoes flagged groups
-      asm volatile("" : "+v"(w_lane));
+    // A pair's inputs: its rows (z, G, mask, g_ld) and launch A's hand-over with units on K.  With MNF_RNVP_BWD_TS_OCC
+    // = 1 (one wave per SIMD, accumulators in the AGPR half of the file) the NEXT pair's inputs are requested before the
+    // current pair is computed -- nothing else hides a load there.
+    struct Inputs {
+      f32x2 zz[2][4], GG[2][4], mm[2][4];
+      float gl[2][4];
+      f16x8 yoh[2][NKS2], yol[2][NKS2], goh[2][NKS2], gol[2][NKS2];
+      bool skip;
+    };
+    auto load_inputs = [&](int64_t p, Inputs& in) {
+      in.skip = flags[(p * 32) / kBwdGroupRows] != 0;  // the generic kernel redoes flagged groups
       const bool has1 = 2 * p + 1 < n_tiles;
-      u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2];  // [row tile][dim tile]: B operands of the row sums
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const int64_t tile = 2 * p + tt;
         const bool has = tt == 0 || has1;
-        const int64_t tbase = (has ? tile : 2 * p) * 16;                 // wave-uniform
+        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;              // wave-uniform
         const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
         const float* zt = z + tbase * dm;
         const float* gt_ = gsrc + tbase * dm;
         const float* mt = SEEDED ? nullptr : mask + tbase * dm;
         const uint32_t* sd = side + (tbase >> 4) * B::TILE_WORDS;
-        f32x2 zz[4], GG[4], mm[4];
-        float gl[4];
         uint32_t mw[4];
         if (SEEDED) tile_mask_words(seed, tbase, n_live, slab, lane, q, mw);
 #pragma unroll
@@ -554,24 +485,34 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
             mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
           }
           const float keep = live ? 1.f : 0.f;
-          zz[r] = zv;
-          GG[r] = gv * (gx_scale * keep);
-          mm[r] = mv;
-          gl[r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
+          in.zz[tt][r] = zv;
+          in.GG[tt][r] = gv * (gx_scale * keep);
+          in.mm[tt][r] = mv;
+          in.gl[tt][r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
         }
-        // y and g_y of the tile as A operands, units on K (launch A's hand-over, from L2)
-        f16x8 yoh[NKS2], yol[NKS2], goh[NKS2], gol[NKS2];
 #pragma unroll
         for (int ks = 0; ks < NKS2; ++ks) {
           if (kBwdAbl & 1) {
-            yoh[ks] = yol[ks] = goh[ks] = gol[ks] = w2(0, 0, ks, 0);
+            in.yoh[tt][ks] = in.yol[tt][ks] = in.goh[tt][ks] = in.gol[tt][ks] = w2(0, 0, ks, 0);
             continue;
           }
-          yoh[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
-          yol[ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
-          goh[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
-          gol[ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
+          in.yoh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
+          in.yol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
+          in.goh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
+          in.gol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
         }
+      }
+    };
+    auto compute = [&](int64_t p, Inputs& in) {
+      if (in.skip) return;
+      asm volatile("" : "+v"(w_lane));
+      const bool has1 = 2 * p + 1 < n_tiles;
+      u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2];  // [row tile][dim tile]: B operands of the row sums
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const bool has = tt == 0 || has1;
+        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;
+        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
@@ -579,13 +520,13 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
 #pragma unroll
           for (int ks = 0; ks < NKS2; ++ks) {
             if (kBwdAbl & 16) {
-              tm += __builtin_bit_cast(f32x4, yoh[ks]);
-              sm += __builtin_bit_cast(f32x4, goh[ks]);
+              tm += __builtin_bit_cast(f32x4, in.yoh[tt][ks]);
+              sm += __builtin_bit_cast(f32x4, in.goh[tt][ks]);
               continue;
             }
-            split_mac(yoh[ks], yol[ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
-            split_mac(yoh[ks], yol[ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
-            split_mac(goh[ks], gol[ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+            split_mac(in.yoh[tt][ks], in.yol[tt][ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
+            split_mac(in.yoh[tt][ks], in.yol[tt][ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+            split_mac(in.goh[tt][ks], in.gol[tt][ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
           }
           const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
           const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
@@ -593,31 +534,31 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
           f32x4 gt, gs;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float zv = zz[r][dt], G_ = GG[r][dt], m_ = mm[r][dt], nm = 1.f - m_;
+            const float zv = in.zz[tt][r][dt], G_ = in.GG[tt][r][dt], m_ = in.mm[tt][r][dt], nm = 1.f - m_;
             const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
             const float omg = 1.f - gate;
             gt[r] = G_ * omg;
-            gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl[r] * nm) * omg;
-            zz[r][dt] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;  // grad_z takes z's register
+            gs[r] = (G_ * (nm * zv - t4[r]) * gate + in.gl[tt][r] * nm) * omg;
+            in.zz[tt][r][dt] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;  // grad_z takes z's register
           }
           abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
           abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
           split_plain(gt, th[tt][dt], tl[tt][dt]);
           split_plain(gs, sh[tt][dt], sl[tt][dt]);
         }
-        if (has && (!(kBwdAbl & 8) || zz[0][0] == 1.2345e30f)) {
+        if (has && (!(kBwdAbl & 8) || in.zz[tt][0][0] == 1.2345e30f)) {
           float* ot = grad_z + tbase * dm;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (4 * q + r < n_live) {
               const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
               if (!RAG) {
-                *reinterpret_cast<f32x2*>(ot + off) = zz[r];
+                *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
               } else if (vec2) {  // (dm even: in0 implies in1)
-                if (in0) *reinterpret_cast<f32x2*>(ot + off) = zz[r];
+                if (in0) *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
               } else {
-                if (in0) ot[off] = zz[r][0];
-                if (in1) ot[off + 1] = zz[r][1];
+                if (in0) ot[off] = in.zz[tt][r][0];
+                if (in1) ot[off + 1] = in.zz[tt][r][1];
               }
             }
           }
@@ -626,7 +567,6 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) th[tt][dt] = tl[tt][dt] = sh[tt][dt] = sl[tt][dt] = zero2;
         }
-        __builtin_amdgcn_sched_barrier(0);  // one row tile at a time: interleaving the two exceeds the 256 registers
       }
       if (grad_flat && !(kBwdAbl & 4)) {
         // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
@@ -650,6 +590,29 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
             aWt[dt][m] = mfma_h(yl8, tH, aWt[dt][m]);
             aWs[dt][m] = mfma_h(yl8, sH, aWs[dt][m]);
           }
+        }
+      }
+    };
+    {
+      const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+      int64_t p = (int64_t)part * per_part + wave;
+      if (MNF_RNVP_BWD_TS_OCC >= 2) {
+        for (; p < p_end; p += kBwdBWaves) {
+          Inputs in;
+          load_inputs(p, in);
+          compute(p, in);
+        }
+      } else if (p < p_end) {
+        Inputs cur, nxt;
+        load_inputs(p, cur);
+        while (true) {
+          const int64_t pn = p + kBwdBWaves;
+          const bool more = pn < p_end;
+          if (more) load_inputs(pn, nxt);
+          compute(p, cur);
+          if (!more) break;
+          cur = nxt;
+          p = pn;
         }
       }
     }
@@ -721,7 +684,7 @@ rnvp_bwd_n_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   const u32x2 zero2 = u32x2{0u, 0u};
   const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
   const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
-  const BwdItems items(n_slabs, row_parts);
+  const SlabItems items(n_slabs, row_parts);
   for (int item = items.first; item < items.n_items; item += items.step) {
     const int slab = items.slab(item), part = items.part(item);
     const int dim0 = 32 * slab + 2 * j;
@@ -910,27 +873,8 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   // BwdItems); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
   const int n_slabs = (int)B::n_slabs(dm);
   const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
-  const int64_t max_parts = (n_pairs + kBwdBWaves - 1) / kBwdBWaves;  // at least one pair per wave
   auto plan = [&](int resident, int& row_parts, int& grid) {
-    if (max_parts < 8) {
-      row_parts = (int)max_parts;
-      grid = row_parts * n_slabs;
-      return;
-    }
-    const int wgs_xcd = resident / 8 > 0 ? resident / 8 : 1;
-    int best_l = 1;
-    double best_fill = 0.0;
-    for (int l = 1; l <= 32 && (int64_t)l * 8 <= max_parts; ++l) {
-      const int items = l * n_slabs, rounds = (items + wgs_xcd - 1) / wgs_xcd;
-      const double fill = (double)items / ((double)rounds * wgs_xcd);
-      if (fill > best_fill + 0.02) {  // (prefer fewer parts -- fewer flushes -- unless the fill improves by > 2 %)
-        best_fill = fill;
-        best_l = l;
-      }
-    }
-    row_parts = best_l * 8;
-    const int items = best_l * n_slabs;
-    grid = 8 * (items < wgs_xcd ? items : wgs_xcd);
+    plan_slab_launch(n_pairs, kBwdBWaves, n_slabs, resident, row_parts, grid);
   };
   static DeviceMemo memo_n;
   const int resident_b = memo_b.get(

@@ -270,6 +270,123 @@ struct RnvpSplitShape {
   static constexpr int64_t plain_words(int d) { return (int64_t)(d / 16) * 32 + YT * 16; }  // (bt, bs) per tile, then bn
 };
 
+// ---------------------------------------------------------------- hand-over between a row-parallel and a dims-slab launch
+// (the RNVP gradient kernels, mnf_rnvp_bwd.hip, and MNFLinear's, mnf_mnf_linear_bwd.hip)
+// Per 16-row tile, two small per-row vectors "a" and "b" of 16 YT entries each (RNVP: y and g_y over the hidden units;
+// MNFLinear: the cotangents of mean and var over the outputs), written by the row-parallel launch as ready-made split
+// MFMA operands in BOTH orientations: entries along the lane's registers ([ks][hi|lo][lane][4 words], the A operand of a
+// K = entries product with the rows on M) and rows along them ([entry tile][hi|lo'][lane][2 words], the A operand of a
+// sum over rows; lo' = the UNSCALED residual, so that such a sum needs one accumulator).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int YT>
+struct HandoverShape {
+  static constexpr int NKS = (YT + 1) / 2;
+  static constexpr int OP_WORDS = NKS * 2 * 256;
+  static constexpr int TR_WORDS = YT * 2 * 128;
+  static constexpr int TILE_WORDS = 2 * OP_WORDS + 2 * TR_WORDS;
+  static constexpr int A_OP = 0, B_OP = OP_WORDS, A_TR = 2 * OP_WORDS, B_TR = 2 * OP_WORDS + TR_WORDS;
+};
+__device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+// four fp32 values -> f16 heads and UNSCALED f16 residuals (v - head): the operands of a product whose three partial
+// products go into one accumulator.  Below 2^-13 the residual is an f16 subnormal or zero: an absolute error of at most
+// 2^-25 on data scaled to O(1), fp32's own rounding of a sum whose largest terms are O(1).
+__device__ __forceinline__ void split_plain(const f32x4& v, u32x2& hi, u32x2& lo) {
+  const uint32_t h0 = cvt_pk(v[0], v[1]), h1 = cvt_pk(v[2], v[3]);
+  hi = u32x2{h0, h1};
+  lo = u32x2{cvt_pk(residual_lo(h0, v[0]), residual_hi(h0, v[1])), cvt_pk(residual_lo(h1, v[2]), residual_hi(h1, v[3]))};
+}
+// lane (row j, q) holds entries 16 m + 4 q .. + 3 of its row as split tiles (ah/al, bh/bl: hi and 2^11-scaled lo)
+template <int YT>
+__device__ __forceinline__ void store_handover(uint32_t* __restrict__ out, const u32x2 (&ah)[YT], const u32x2 (&al)[YT],
+                                               const u32x2 (&bh)[YT], const u32x2 (&bl)[YT], int lane, int j, int q) {
+  using H = HandoverShape<YT>;
+  const u32x2 zero2 = u32x2{0u, 0u};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // entries on K: operand ks = (tiles 2 ks, 2 ks + 1)
+#pragma unroll
+  for (int ks = 0; ks < H::NKS; ++ks) {
+    const bool two = 2 * ks + 1 < YT;
+    const u32x2 a1 = two ? ah[two ? 2 * ks + 1 : 0] : zero2, a1l = two ? al[two ? 2 * ks + 1 : 0] : zero2;
+    const u32x2 b1 = two ? bh[two ? 2 * ks + 1 : 0] : zero2, b1l = two ? bl[two ? 2 * ks + 1 : 0] : zero2;
+    *reinterpret_cast<u32x4*>(out + H::A_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{ah[2 * ks][0], ah[2 * ks][1], a1[0], a1[1]};
+    *reinterpret_cast<u32x4*>(out + H::A_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{al[2 * ks][0], al[2 * ks][1], a1l[0], a1l[1]};
+    *reinterpret_cast<u32x4*>(out + H::B_OP + ((2 * ks) * 64 + lane) * 4) = u32x4{bh[2 * ks][0], bh[2 * ks][1], b1[0], b1[1]};
+    *reinterpret_cast<u32x4*>(out + H::B_OP + ((2 * ks + 1) * 64 + lane) * 4) = u32x4{bl[2 * ks][0], bl[2 * ks][1], b1l[0], b1l[1]};
+  }
+  // rows on K: one MFMA against the identity per tile and part turns "lane = row, registers = entries" into
+  // "lane = entry, registers = rows" (D[row][e'] = sum_k A[row][k] I[k][e'], every product x 1: exact); the tail goes
+  // against 2^-11 I and comes out unscaled
+  u32x2 id, ids;
+  {
+    const _Float16 one = (_Float16)1.f, tiny = (_Float16)kSplitInvScale, zero = (_Float16)0.f;
+    f16x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (4 * q + e == j) ? one : zero;
+      b[e] = (4 * q + e == j) ? tiny : zero;
+    }
+    id = __builtin_bit_cast(u32x2, a);
+    ids = __builtin_bit_cast(u32x2, b);
+  }
+#pragma unroll
+  for (int m = 0; m < YT; ++m) {
+    const f32x4 a = mfma16(ah[m], id, zero4), b = mfma16(al[m], ids, zero4);
+    const f32x4 c = mfma16(bh[m], id, zero4), e = mfma16(bl[m], ids, zero4);
+    *reinterpret_cast<u32x2*>(out + H::A_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(a[0], a[1]), cvt_pk(a[2], a[3])};
+    *reinterpret_cast<u32x2*>(out + H::A_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(b[0], b[1]), cvt_pk(b[2], b[3])};
+    *reinterpret_cast<u32x2*>(out + H::B_TR + ((2 * m) * 64 + lane) * 2) = u32x2{cvt_pk(c[0], c[1]), cvt_pk(c[2], c[3])};
+    *reinterpret_cast<u32x2*>(out + H::B_TR + ((2 * m + 1) * 64 + lane) * 2) = u32x2{cvt_pk(e[0], e[1]), cvt_pk(e[2], e[3])};
+  }
+}
+
+// Work items = (row part, slab) of a dims-slab launch over a persistent grid.  With >= 8 row parts, part p belongs to
+// XCD p % 8 (workgroups go to the XCDs round robin: block b runs on XCD b % 8) and that XCD's workgroups take its items
+// in (part, slab) order: the n_slabs workgroups on one row part then run on ONE XCD at about the same time and walk the
+// same rows, so the per-row hand-over (read by every slab) is fetched into that XCD's L2 once.
+struct SlabItems {
+  int n_items, first, step, n_slabs, xcd;
+  bool by_xcd;
+  __device__ __forceinline__ SlabItems(int n_slabs_, int row_parts) : n_slabs(n_slabs_) {
+    by_xcd = row_parts >= 8;
+    xcd = blockIdx.x & 7;
+    const int local_parts = by_xcd ? (row_parts - xcd + 7) / 8 : 0;
+    n_items = by_xcd ? local_parts * n_slabs : row_parts * n_slabs;
+    first = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  }
+  __device__ __forceinline__ int slab(int item) const { return item % n_slabs; }
+  __device__ __forceinline__ int part(int item) const { return by_xcd ? (item / n_slabs) * 8 + xcd : item / n_slabs; }
+};
+// host: row parts and grid of such a launch.  Row parts come in multiples of 8 (one XCD each); their number per XCD
+// is chosen so that the XCD's items fill whole rounds of its resident workgroups.
+inline void plan_slab_launch(int64_t n_pairs, int waves, int n_slabs, int resident, int& row_parts, int& grid) {
+  const int64_t max_parts = (n_pairs + waves - 1) / waves;  // at least one pair per wave
+  if (max_parts < 8) {
+    row_parts = (int)(max_parts < 1 ? 1 : max_parts);
+    grid = row_parts * n_slabs;
+    return;
+  }
+  const int wgs_xcd = resident / 8 > 0 ? resident / 8 : 1;
+  int best_l = 1;
+  double best_fill = 0.0;
+  for (int l = 1; l <= 32 && (int64_t)l * 8 <= max_parts; ++l) {
+    const int items = l * n_slabs, rounds = (items + wgs_xcd - 1) / wgs_xcd;
+    const double fill = (double)items / ((double)rounds * wgs_xcd);
+    if (fill > best_fill + 0.02) {  // (prefer fewer parts -- fewer flushes -- unless the fill improves by > 2 %)
+      best_fill = fill;
+      best_l = l;
+    }
+  }
+  row_parts = best_l * 8;
+  const int items = best_l * n_slabs;
+  grid = 8 * (items < wgs_xcd ? items : wgs_xcd);
+}
+
 // ---------------------------------------------------------------- host: shapes and the split image's index table
 // hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default); any other width up
 // to 50 runs at the next one up with structural-zero units (rnvp_padded_hidden)

@@ -19,7 +19,69 @@ from torch import Tensor, nn
 
 from . import _lib
 from . import flows as _flows
+from ._lib import MnfHipError
 from .flows import RNVP, NormalizingFlow, _stream, _wants_grad
+
+
+def _mnf_linear_forward(module, x, z, eps, seed, ops, sd):
+    """One mnf_mnf_linear_fwd(_train) launch: (out, range-flag workspace)."""
+    flat, image, var_unscale = ops
+    rows = x.shape[0]
+    out = torch.empty(rows, module.n_out, dtype=torch.float32, device=x.device)
+    work = torch.empty((rows + 127) // 128, dtype=torch.int32, device=x.device)
+    _lib.check("mnf_mnf_linear_fwd_train", _lib.load().mnf_mnf_linear_fwd_train(
+        x.data_ptr(), z.data_ptr(), None if eps is None else eps.data_ptr(), seed, out.data_ptr(),
+        None if sd is None else sd.data_ptr(), flat.data_ptr(), image.data_ptr(), var_unscale, work.data_ptr(), rows,
+        module.n_in, module.n_out, _stream()))
+    return out, work
+
+
+_MNF_LINEAR_BWD_WORK: dict = {}  # device -> scratch of mnf_mnf_linear_bwd (its launches follow one another on the stream)
+
+
+class _MnfLinearFn(torch.autograd.Function):
+    """MNFLinear.forward with gradients: the forward launch keeps sqrt(var); backward = mnf_mnf_linear_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, z, W_mean, W_log_var, b_mean, b_log_var, module, eps, seed):
+        ops = module._forward_operands(x.device)
+        xc, zc = x.detach().contiguous(), z.detach().contiguous()
+        sd = torch.empty(xc.shape[0], module.n_out, dtype=torch.float32, device=x.device)
+        out, work = _mnf_linear_forward(module, xc, zc, eps, seed, ops, sd)
+        ctx.module, ctx.seed, ctx.var_unscale = module, seed, ops[2]
+        ctx.save_for_backward(xc, zc, sd, work, ops[0], *([eps] if eps is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m = ctx.module
+        xc, zc, sd, fwd_flags, flat, *rest = ctx.saved_tensors
+        eps = rest[0] if rest else None
+        lib = _lib.load()
+        rows, dev = xc.shape[0], xc.device
+        g = grad_out.contiguous()
+        idx, n_split = m._bwd_index(dev)
+        image = torch.empty(n_split + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=dev)
+        _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
+            flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, 0, _stream()))
+        need = int(lib.mnf_mnf_linear_bwd_workspace_bytes(rows, m.n_in, m.n_out))
+        work = _MNF_LINEAR_BWD_WORK.get(dev)
+        if work is None or work.numel() < need:
+            work = torch.empty(need, dtype=torch.uint8, device=dev)
+            _MNF_LINEAR_BWD_WORK[dev] = work
+        scale = _flows._grad_scale(g, None, rows, m.n_out, dev)
+        grad_x, grad_z = torch.empty_like(xc), torch.empty_like(zc)
+        grad_flat = torch.zeros_like(flat)
+        _lib.check("mnf_mnf_linear_bwd", lib.mnf_mnf_linear_bwd(
+            xc.data_ptr(), zc.data_ptr(), g.data_ptr(), sd.data_ptr(), None if eps is None else eps.data_ptr(), ctx.seed,
+            grad_x.data_ptr(), grad_z.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), image.data_ptr(), ctx.var_unscale,
+            fwd_flags.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(), rows, m.n_in, m.n_out, _stream()))
+        n = m.n_in * m.n_out
+        gW_mean = grad_flat[:n].view(m.n_out, m.n_in)
+        gW_log_var = grad_flat[n:2 * n].view(m.n_out, m.n_in)
+        gb_mean = grad_flat[2 * n:2 * n + m.n_out]
+        gb_log_var = grad_flat[2 * n + m.n_out:2 * n + 2 * m.n_out]
+        return grad_x, grad_z, gW_mean, gW_log_var, gb_mean, gb_log_var, None, None, None
 
 
 class MNFLinear(nn.Module):
@@ -129,10 +191,19 @@ class MNFLinear(nn.Module):
                 with torch.no_grad():
                     w_var = self.W_log_var.detach().to(device, torch.float32).exp()
                     # exp(W_log_var) is ~1e-4 at init and shrinks in training: times a power of two that puts its
-                    # largest entry in [0.5, 1), so that the f16 halves of the image are normal numbers
-                    top = float(w_var.max())
-                    shift = -math.frexp(top)[1] if top > 0.0 and math.isfinite(top) else 0
-                    shift = max(min(shift, 100), -100)
+                    # largest entry near [0.5, 1), so that the f16 halves of the image are normal numbers.  The power
+                    # is read back from the device (one host synchronisation) at the first pack and re-read every 64th
+                    # pack after that -- never while a hipGraph is being captured: log-variances drift by a few powers
+                    # of two over a training run, f16 has 2^-14 .. 2^15 of normal range around the target, and a
+                    # weight that does leave the range sends the launch to the fp32 path (the image's weight guard).
+                    shift = self.__dict__.get("_var_shift")
+                    packs = self.__dict__.get("_var_shift_age", 0)
+                    if shift is None or (packs >= 64 and not torch.cuda.is_current_stream_capturing()):
+                        top = float(w_var.max())
+                        shift = -math.frexp(top)[1] if top > 0.0 and math.isfinite(top) else 0
+                        shift = max(min(shift, 100), -100)
+                        self.__dict__["_var_shift"], packs = shift, 0
+                    self.__dict__["_var_shift_age"] = packs + 1
                     flat = torch.cat([self.W_mean.detach().to(device, torch.float32).reshape(-1),
                                       (w_var * (2.0 ** shift)).reshape(-1),
                                       self.b_mean.detach().to(device, torch.float32),
@@ -149,39 +220,56 @@ class MNFLinear(nn.Module):
             _flows._check_params_fresh(params, self.__dict__.get("_fwd_packed_from"), "MNFLinear.forward")
         return cache[1]
 
+    def _bwd_index(self, device):
+        """(device index table, n_split_words) of the gradient kernels' operand image."""
+        cached = self.__dict__.get("_bwd_idx")
+        if cached is None or cached[0].device != device:
+            lib = _lib.load()
+            n_split, n_plain = ctypes.c_int64(0), ctypes.c_int64(0)
+            _lib.check("mnf_mnf_linear_bwd_layout", lib.mnf_mnf_linear_bwd_layout(
+                self.n_in, self.n_out, ctypes.byref(n_split), ctypes.byref(n_plain)))
+            idx = (ctypes.c_int32 * (2 * n_split.value))()
+            _lib.check("mnf_mnf_linear_bwd_index", lib.mnf_mnf_linear_bwd_index(self.n_in, self.n_out, idx))
+            cached = (torch.frombuffer(idx, dtype=torch.int32).clone().to(device), n_split.value)
+            self.__dict__["_bwd_idx"] = cached
+        return cached
+
     def forward(self, x: Tensor, eps: Tensor | None = None) -> Tensor:
         """Algorithm 1 of the MNF paper (mnf_linear.py:46-56): ``mean + sqrt(var) * eps`` with
         ``mean = (x * z) @ W_mean.T + b_mean`` and ``var = x**2 @ exp(W_log_var).T + exp(b_log_var)``.
 
-        Without gradients both products and the noise epilogue are ONE HIP launch behind ``sample_z`` (x and z read
-        once; ``eps`` (rows, n_out) may be injected, by default it is generated inside the kernel from a seed drawn
-        from torch's generator).  With gradients the reference's formulas run on device tensors (autograd)."""
+        Both products and the noise epilogue are ONE HIP launch behind ``sample_z`` (x and z read once; ``eps``
+        (rows, n_out) may be injected, by default it is generated inside the kernel from a seed drawn from torch's
+        generator).  With gradients wanted the same launch also keeps ``sqrt(var)``, and the backward pass is
+        ``mnf_mnf_linear_bwd`` (grad x, grad z, dW_mean, dW_log_var, db_mean, db_log_var on the matrix cores): no
+        stock-PyTorch matrix product anywhere on the path.  Layers wider than 64 outputs have no kernel (the
+        reference's MNF models use 50 and 10) and raise."""
+        if x.dim() != 2 or x.shape[1] != self.n_in:
+            raise ValueError(f"MNFLinear({self.n_in}, {self.n_out}) expects (rows, {self.n_in}) inputs, got {tuple(x.shape)}")
         z, _ = self.sample_z(x.size(0))
-        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        ops = None
-        if not training and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32:
-            ops = self._forward_operands(x.device)
-        if ops is None:  # training, or a shape without a kernel: the reference's composition (stock PyTorch-ROCm)
-            mean = (x * z) @ self.W_mean.T + self.b_mean
-            var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
-            return mean + var.sqrt() * (torch.randn_like(var) if eps is None else eps)
-        flat, image, var_unscale = ops
-        xc, zc = x.detach().contiguous(), z.detach().contiguous()
-        rows = xc.shape[0]
-        out = torch.empty(rows, self.n_out, dtype=torch.float32, device=x.device)
-        work = torch.empty((rows + 127) // 128, dtype=torch.int32, device=x.device)
+        if not x.is_cuda or z.device != x.device:
+            raise RuntimeError(f"torch_mnf_amd: MNFLinear.forward needs the input ({x.device}) and the layer "
+                               f"({z.device}) on the same GPU; the HIP path has no CPU fallback")
+        if x.dtype != torch.float32:
+            raise TypeError(f"torch_mnf_amd: MNFLinear.forward needs float32 inputs, got {x.dtype}")
+        if x.shape[0] == 0:
+            return x.new_empty(0, self.n_out)
+        ops = self._forward_operands(x.device)
+        if ops is None:
+            raise MnfHipError("mnf_mnf_linear_fwd", _lib.MNF_ERR_UNSUPPORTED,
+                              f"MNFLinear.forward has kernels for n_out <= 64 only (got {self.n_out})")
         seed = 0
         if eps is None:
-            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
         else:
             eps = eps.detach().to(x.device, torch.float32).contiguous()
-            if eps.shape != out.shape:
-                raise ValueError(f"eps must be {tuple(out.shape)}, got {tuple(eps.shape)}")
-        _lib.check("mnf_mnf_linear_fwd", _lib.load().mnf_mnf_linear_fwd(
-            xc.data_ptr(), zc.data_ptr(), None if eps is None else eps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF,
-            out.data_ptr(), flat.data_ptr(), image.data_ptr(), var_unscale, work.data_ptr(), rows, self.n_in,
-            self.n_out, _stream()))
-        return out
+            if eps.shape != (x.shape[0], self.n_out):
+                raise ValueError(f"eps must be {(x.shape[0], self.n_out)}, got {tuple(eps.shape)}")
+        params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
+        training = torch.is_grad_enabled() and (x.requires_grad or z.requires_grad or any(p.requires_grad for p in params))
+        if training:
+            return _MnfLinearFn.apply(x, z, *params, self, eps, seed)
+        return _mnf_linear_forward(self, x.detach().contiguous(), z.detach().contiguous(), eps, seed, ops, None)[0]
 
     def invalidate(self) -> None:
         """Drop the packed operands of ``forward`` (they are keyed on the parameters' version counters, which a write
