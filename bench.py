@@ -42,6 +42,9 @@ WORKLOADS = {
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
     "c2t": (64, 1 << 20, "training step of 9xAffineHalfFlow d=64 batch=2^20: -mean log-prob, backward, Adam (SURVEY 8f "
                          "rank 1; the reference's tests train through these layers, tests/test_flows.py:14-31)"),
+    "c5t": (800, 512 * 500, "training step of MNFLinear(800,50) on 512x500 MC rows: sample_z (2xRNVP d=800 h=50), forward, "
+                            "mean-square loss, backward, Adam (BASELINE configs[4]'s caller under loss.backward(): what "
+                            "tests/test_mnf_mnist.py:14-56 trains through)"),
     "c3t": (32, 1 << 20, "training step of 3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20: -mean log-prob, backward, "
                          "Adam (SURVEY 8f rank 1 for BASELINE configs[2]'s model; tests/test_flows.py:89-99 trains it)"),
 }
@@ -414,6 +417,144 @@ def main_train(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
+def main_train_c5(args, rank, world, device, dim, rows, desc) -> None:
+    """Config 5's caller on the training side of the bench contract: a step = one Adam step of MNFLinear(800, 50) on the
+    resident batch -- sample_z (prologue + two RNVP launches with autograd), forward (mnf_mnf_linear_fwd_train), a
+    mean-square loss, backward (mnf_mnf_linear_bwd; per RNVP layer mnf_rnvp_bwd_mfma = launches A, B-ts, B-n + fix-up),
+    one fused Adam launch.  The dominant kernel is B-ts (grad_z and the t / s weight gradients of one RNVP layer): z and
+    grad_x in, grad_z out = (12 d + 4) bytes per row per launch."""
+    if world != 1:
+        raise SystemExit("--workload c5t measures one GPU (data-parallel training would add a gradient all-reduce)")
+    import torch_mnf_amd as amd
+    from torch_mnf_amd import flows as amd_flows
+    from torch_mnf_amd import synthetic as recipes
+
+    n_out = 50
+
+    def build():
+        torch.manual_seed(55)
+        layer = amd.MNFLinear(dim, n_out)
+        for i, f in enumerate(layer.flow_q.flows):
+            f.load_state_dict(recipes.rnvp_params(800 + i, dim, 50))
+        return layer.to(device)
+
+    layer = build()
+    opt = amd.FusedAdam(amd.FlatParameters(layer), lr=1e-4)
+    gen = torch.Generator(device=device).manual_seed(2468 + rank)
+    x = torch.rand(rows, dim, device=device, generator=gen)  # (activations: non-negative, as after the reference's ReLU)
+    loss_box = [None]
+
+    def step():
+        opt.zero_grad()
+        loss = layer.forward(x).pow(2).mean()
+        loss.backward()
+        opt.step()
+        loss_box[0] = loss
+
+    step()
+    torch.cuda.synchronize()
+    first_loss = float(loss_box[0])
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        step()
+        torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    amd_flows.rnvp_bwd_kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    events, amd_flows.rnvp_bwd_kernel_events = amd_flows.rnvp_bwd_kernel_events, None
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    out = {
+        "metric": f"rows/s, {desc}", "value": rows * args.steps / elapsed, "unit": "rows/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "n_out": n_out, "hidden": [50],
+                   "mask": "in-kernel (seeded)", "optimizer": "FusedAdam over FlatParameters (one buffer, one launch)",
+                   "primed_ms": args.prime_ms, "arithmetic": ARITHMETIC, "total_rows": rows},
+        "distributed": dist_info(1, "nccl", [elapsed], args.steps),
+        "loss_first_step": first_loss, "loss_last_step": float(loss_box[0]),
+    }
+    if kern_ms:
+        avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+        algo_bytes = (12 * dim + 4) * rows
+        traffic, source = pmc_traffic("c5t")
+        gbs = algo_bytes / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": source, **physical(traffic, avg_s),
+                           "kernel": "rnvp_bwd_ts_kernel<50,seeded> (launch B-ts of one RNVP layer's gradient pass: s, t, "
+                                     "gate, g_k, grad_z and the row sums dWt, dWs; 2 launches per step)",
+                           "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
+                           "launches_timed": len(kern_ms), "launches_per_step": 2,
+                           "note": "z and grad_x in, grad_z out; launch A of the same pass reads z twice and grad_x once "
+                                   "more (DESIGN.md 3.6)"}
+    if not args.no_cpu_baseline:
+        # the oracle's training step on the host (sample_z + MNFLinear.forward restated, torch.autograd backward) on a
+        # bounded slice, with the masks and both noise draws materialised so that the GPU leg below sees the same ones
+        from oracle import flow_oracle as O
+
+        n = 1 << 14
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        fresh = build()
+        g = torch.Generator().manual_seed(97)
+        eps_z, eps_o = torch.randn(n, dim, generator=g), torch.randn(n, n_out, generator=g)
+        masks = [fresh.flow_q.flows[i].mask_for(21 + i, n, device).cpu() for i in range(2)]
+        names = ["W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var"]
+
+        def oracle_step(dt):
+            p = {k: getattr(fresh, k).detach().cpu().to(dt).requires_grad_(True) for k in names}
+            specs = [{"kind": "rnvp", "mask": masks[i].to(dt),
+                      "params": {k: v.detach().cpu().to(dt).requires_grad_(True)
+                                 for k, v in fresh.flow_q.flows[i].state_dict().items()}} for i in range(2)]
+            z, _ = O.sample_z(p["q0_mean"], p["q0_log_var"], eps_z.to(dt), specs)
+            o = O.mnf_linear_forward(x[:n].cpu().to(dt), z, p["W_mean"], p["W_log_var"], p["b_mean"], p["b_log_var"],
+                                     eps_o.to(dt))
+            loss = o.pow(2).mean()
+            loss.backward()
+            grads = {k: v.grad for k, v in p.items()}
+            for i, sp in enumerate(specs):
+                grads.update({f"flow_q.flows.{i}.{k}": v.grad for k, v in sp["params"].items()})
+            return loss, grads
+
+        best = float("inf")
+        for _ in range(2):
+            t1 = time.perf_counter()
+            oracle_step(torch.float32)
+            best = min(best, time.perf_counter() - t1)
+        out["cpu_baseline"] = {"value": n / best, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle sample_z + MNFLinear.forward + torch.autograd backward of the mean-square "
+                                         f"loss on the first {n} rows (initial parameters), best of 2, {best:.3f} s"}
+        loss64, g64 = oracle_step(torch.float64)
+        _, g32 = oracle_step(torch.float32)
+        fresh.zero_grad()
+        z, _ = fresh.sample_z(n, eps=eps_z.to(device), masks=[m.to(device) for m in masks])
+        fresh.sample_z = lambda *a, **k: (z, None)
+        loss_gpu = fresh.forward(x[:n].contiguous(), eps=eps_o.to(device)).pow(2).mean()
+        loss_gpu.backward()
+        worst, worst_name, worst_budget = 0.0, "", 0.0
+        got = dict(fresh.named_parameters())
+        for k, r64 in g64.items():
+            if r64 is None or float(r64.abs().max()) == 0.0:
+                continue
+            scale = float(r64.abs().max())
+            err = float((got[k].grad.cpu().double() - r64).abs().max()) / scale
+            widening = 2.0 * float((g32[k].double() - r64).abs().max()) / scale
+            if err - widening > worst - worst_budget or not worst_name:
+                worst, worst_name, worst_budget = err, k, widening
+        out["parity"] = {"rows": n, "reference": "oracle in float64 (same masks and noise)",
+                         "worst_parameter_gradient_normwise_err": worst, "parameter": worst_name,
+                         "fp32_oracle_vs_fp64_x2": worst_budget, "tolerance": 1e-5 + worst_budget,
+                         "loss_gpu_vs_cpu_rel_err": abs(float(loss_gpu) - float(loss64)) / abs(float(loss64))}
+    print(json.dumps(out))
+
+
 def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     """Config 3's model on the training side of the bench contract: a step = one Adam step of 3 x [ActNorm, Glow,
     NSF_CL] on the resident batch (layer-by-layer forward keeping every intermediate, -mean log-prob, backward, Adam).
@@ -619,6 +760,8 @@ def main() -> None:
         return main_c5(args, rank, world, device, dim, rows, desc)
     if args.workload == "c2t":
         return main_train(args, rank, world, device, dim, rows, desc)
+    if args.workload == "c5t":
+        return main_train_c5(args, rank, world, device, dim, rows, desc)
     if args.workload == "c3t":
         return main_train_c3(args, rank, world, device, dim, rows, desc)
     if args.workload in ("c3", "c3f"):

@@ -425,6 +425,14 @@ int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const fl
                       float* grad_z, float* grad_flat, const float* flat, const void* split_image,
                       const void* bwd_image, const float* grad_scale_dev, void* workspace, int64_t workspace_bytes,
                       int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
+/* The same call with its launches selectable (measurements: HIP events around one of them): phases bit 0 the
+ * row-parallel launch A, bit 1 launch B-ts (grad_z, dWt, dWs), bit 2 launch B-n (dWn), bit 3 the fp32 fix-up; the
+ * phases of one backward pass must run in that order on one stream.  15 = mnf_rnvp_bwd_mfma. */
+int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, const float* grad_x,
+                             const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,
+                             const void* split_image, const void* bwd_image, const float* grad_scale_dev,
+                             void* workspace, int64_t workspace_bytes, int64_t rows, int dim, int n_hidden,
+                             const int* hidden_host, int phases, void* stream);
 /* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
 int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,

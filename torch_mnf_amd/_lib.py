@@ -105,6 +105,9 @@ SIGNATURES = {
     "mnf_rnvp_bwd_mfma_index": (c_int, [c_int, c_int, _intp, _i32p]),
     "mnf_rnvp_bwd_mfma": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, _intp, c_void_p]),
+    "mnf_rnvp_bwd_mfma_phases": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, _intp,
+                                         c_int, c_void_p]),
     "mnf_affine_const_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

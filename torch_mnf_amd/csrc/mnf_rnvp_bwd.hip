@@ -850,25 +850,28 @@ static int64_t bwd_workspace_bytes(int64_t rows) {
   return bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4;
 }
 
+// phases: bit 0 launch A, bit 1 B-ts, bit 2 B-n (bit 3, the fp32 fix-up, is the caller's)
 template <int HN, bool SEEDED, bool RAG>
 static int launch_bwd(const float* z, const float* mask, uint64_t seed, const float* gx, const float* gld, float* grad_z,
                       float* grad_flat, const uint32_t* simage, const uint32_t* bimage, const float* gscale, void* work,
-                      int64_t rows, int dm, int hn, int vec4, int vec2, hipStream_t stream) {
+                      int64_t rows, int dm, int hn, int vec4, int vec2, int phases, hipStream_t stream) {
   using B = RnvpBwdShape<HN>;
   const int d16 = rnvp_padded_dim(dm);
   const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows;
   int32_t* list = static_cast<int32_t*>(work);
   int32_t* flags = list + 1 + n_groups;
   uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + bwd_header_bytes(rows));
-  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
   static DeviceMemo memo_a, memo_b;
   const int resident_a = memo_a.get(
       [](int dev) { return resident_by_occupancy(rnvp_bwd_a_kernel<HN, SEEDED, RAG>, kRnvpWaves * 64, dev, 1); });
   const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
+  if (phases & 1) {
+  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
   if (int rc = check_launch()) return rc;
+  }
   // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see
   // BwdItems); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
   const int n_slabs = (int)B::n_slabs(dm);
@@ -881,11 +884,13 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
       [](int dev) { return resident_by_occupancy(rnvp_bwd_ts_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
   int row_parts, grid;
   plan(resident_b, row_parts, grid);
-  hipLaunchKernelGGL((rnvp_bwd_ts_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
-                     mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows, dm, d16, hn, seed, n_slabs,
-                     row_parts, vec2);
-  if (int rc = check_launch()) return rc;
-  if (!grad_flat) return MNF_OK;
+  if (phases & 2) {
+    hipLaunchKernelGGL((rnvp_bwd_ts_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
+                       mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows, dm, d16, hn, seed, n_slabs,
+                       row_parts, vec2);
+    if (int rc = check_launch()) return rc;
+  }
+  if (!grad_flat || !(phases & 4)) return MNF_OK;
   const int resident_n = memo_n.get(
       [](int dev) { return resident_by_occupancy(rnvp_bwd_n_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 4); });
   plan(resident_n, row_parts, grid);
@@ -935,10 +940,10 @@ int mnf_rnvp_bwd_mfma_index(int dim, int n_hidden, const int* hidden, int32_t* i
   return MNF_ERR_UNSUPPORTED;
 }
 
-int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
-                      float* grad_z, float* grad_flat, const float* flat, const void* split_image, const void* bwd_image,
-                      const float* grad_scale_dev, void* workspace, int64_t workspace_bytes, int64_t rows, int dim,
-                      int n_hidden, const int* hidden, void* stream) {
+int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                             float* grad_z, float* grad_flat, const float* flat, const void* split_image,
+                             const void* bwd_image, const float* grad_scale_dev, void* workspace, int64_t workspace_bytes,
+                             int64_t rows, int dim, int n_hidden, const int* hidden, int phases, void* stream) {
   if (!z || !grad_z || !flat || !split_image || !bwd_image || !grad_scale_dev || !workspace || rows < 0 || dim < 1 ||
       n_hidden < 1 || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
@@ -962,19 +967,27 @@ int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const fl
 #define X(HN)                                                                                                            \
   if (hn_pad == HN)                                                                                                      \
     rc = mask ? (ragged ? launch_bwd<HN, false, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
-                                                      workspace, rows, dim, hidden[0], vec4, vec2, st)                   \
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, st)                   \
                         : launch_bwd<HN, false, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,    \
-                                                       workspace, rows, dim, hidden[0], vec4, vec2, st))                 \
+                                                       workspace, rows, dim, hidden[0], vec4, vec2, phases, st))                 \
               : (ragged ? launch_bwd<HN, true, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,      \
-                                                     workspace, rows, dim, hidden[0], vec4, vec2, st)                    \
+                                                     workspace, rows, dim, hidden[0], vec4, vec2, phases, st)                    \
                         : launch_bwd<HN, true, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
-                                                      workspace, rows, dim, hidden[0], vec4, vec2, st));
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, st));
   MNF_RNVP_HIDDEN(X)
 #undef X
-  if (rc != MNF_OK) return rc;
+  if (rc != MNF_OK || !(phases & 8)) return rc;
   // groups outside the split range: the generic fp32 kernel, on the flagged groups only
   return rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
                                  static_cast<const int32_t*>(workspace), kBwdGroupRows, st);  // (the list heads the workspace)
+}
+
+int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                      float* grad_z, float* grad_flat, const float* flat, const void* split_image, const void* bwd_image,
+                      const float* grad_scale_dev, void* workspace, int64_t workspace_bytes, int64_t rows, int dim,
+                      int n_hidden, const int* hidden, void* stream) {
+  return mnf_rnvp_bwd_mfma_phases(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, split_image, bwd_image,
+                                  grad_scale_dev, workspace, workspace_bytes, rows, dim, n_hidden, hidden, 15, stream);
 }
 
 }  // extern "C"

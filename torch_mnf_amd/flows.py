@@ -178,6 +178,7 @@ def _grad_scale(gy: Tensor | None, gl: Tensor | None, rows: int, dim: int, devic
 
 
 bwd_kernel_events: list | None = None  # set to a list to collect (start, end) events of every split gradient launch
+rnvp_bwd_kernel_events: list | None = None  # likewise for launch B-ts of every RNVP gradient pass
 
 
 def _bwd_split_workspace(lib, f, rows: int, device) -> Tensor | None:
@@ -339,10 +340,24 @@ class _RnvpFn(torch.autograd.Function):
             rows = z.shape[0]
             work = m._bwd_workspace(lib, rows, z.device)
             scale = _grad_scale(gx, gl, rows, m.dim, z.device)
-            rc = lib.mnf_rnvp_bwd_mfma(
-                z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
-                flat.data_ptr(), split.data_ptr(), bwd.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(), rows,
-                m.dim, len(m.h_sizes), m._hid, _stream())
+            def go(phases):
+                return lib.mnf_rnvp_bwd_mfma_phases(
+                    z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
+                    flat.data_ptr(), split.data_ptr(), bwd.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(),
+                    rows, m.dim, len(m.h_sizes), m._hid, phases, _stream())
+
+            if rnvp_bwd_kernel_events is None:
+                rc = go(15)
+            else:  # bench.py: HIP events around launch B-ts, the pass's dominant kernel
+                rc = go(1)
+                if rc == _lib.MNF_OK:
+                    marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    marks[0].record()
+                    rc = go(2)
+                    marks[1].record()
+                    rnvp_bwd_kernel_events.append(marks)
+                if rc == _lib.MNF_OK:
+                    rc = go(12)
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_rnvp_bwd_mfma", rc)
                 return grad_z, grad_flat, None, None, None
