@@ -897,7 +897,7 @@ int mnf_affine_half_grad_scale(const float* grad_y, const float* grad_ld, int64_
   const int64_t sample = rows < 512 ? rows : 512;  // (one workgroup: a larger sample costs more than it tells)
   const int64_t stride = sample > 0 ? rows / sample : 1;  // rows 0, stride, 2 stride, ...: spread over the whole batch
   if (grad_y && sample * dim > 65536) {  // wide rows: several workgroups (one took 150 us at 512 x 800)
-    if (hipMemsetAsync(scale_out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return mnf::check_launch();
+    if (int rc = mnf::zero_word_async(scale_out, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(mnf::grad_max_kernel, dim3((unsigned)(sample < 128 ? sample : 128)), dim3(256), 0,
                        (hipStream_t)stream, grad_y, grad_ld, sample, stride, dim, reinterpret_cast<uint32_t*>(scale_out));
     if (int rc = mnf::check_launch()) return rc;

@@ -640,6 +640,7 @@ __global__ void pack_gather_split_kernel(const float* __restrict__ flat, const i
 using namespace mnf;
 
 namespace mnf {
+__global__ void zero_word_kernel(uint32_t* w) { *w = 0u; }
 thread_local int g_last_hip_error = 0;
 
 int check_launch() {
@@ -649,6 +650,11 @@ int check_launch() {
     return MNF_ERR_LAUNCH;
   }
   return MNF_OK;
+}
+
+int zero_word_async(void* word, hipStream_t stream) {
+  hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, stream, static_cast<uint32_t*>(word));
+  return check_launch();
 }
 
 // Fill a NetDesc for MLP(sizes...) whose parameters start at float offset `base` of the flat

@@ -126,6 +126,11 @@ int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulat
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
                          const float* q0_log_var, int vec, hipStream_t stream);
 
+// one 32-bit word := 0 on the stream, as a KERNEL node (mnf_generic.hip).  A 4-byte hipMemsetAsync in front of a kernel
+// that counts into the word was fine eagerly but, recorded in a hipGraph, faulted after ~100 replays of the MNF-LeNet
+// training step (memory access fault; the same step with these resets as kernels replays cleanly).
+int zero_word_async(void* word, hipStream_t stream);
+
 // the generic RNVP gradient kernel (mnf_backward.hip); list != nullptr: only the row groups list[1 .. list[0]] (the
 // fix-up pass of mnf_rnvp_bwd_mfma)
 int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,

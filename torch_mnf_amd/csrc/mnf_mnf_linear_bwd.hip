@@ -55,6 +55,8 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
                        const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int n_in,
                        int n_out, float var_unscale, float wmax_limit_ok) {
   using H = HandoverShape<YT>;
+  constexpr int kPitch = 16 * YT + 1;  // (odd: the 16 rows a lane group reads land on 16 different banks)
+  __shared__ float stage[8 * 2 * 16 * kPitch];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const float gscale = gscale_dev[0];
@@ -67,6 +69,27 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
     const int64_t row = tile * 16 + j;
     const bool live = row < rows;
     const int64_t rc = live ? row : rows - 1;
+    // the tile's 16 x n_out cotangents, sd and noise are contiguous in memory: read them coalesced, form g_m and g_v per
+    // element, and turn them into the (row, 4 outputs per lane) layout through LDS (read per lane as 4-byte pieces with
+    // a 200-byte row stride they took 0.55 ms per 256,000 rows)
+    float* tm_ = stage + wave * (2 * 16 * kPitch);
+    float* tv_ = tm_ + 16 * kPitch;
+    {
+      const int64_t base = tile * 16 * n_out;
+      const int n_el = (int)min((int64_t)16 * n_out, max((int64_t)0, rows * n_out - base));
+      for (int i = lane; i < 16 * n_out; i += 64) {
+        const int r_ = i / n_out, o = i - r_ * n_out;
+        float g = 0.f, v = 0.f;
+        if (i < n_el) {
+          g = gout[base + i];
+          const float e = eps ? eps[base + i] : ml_normal(seed, tile * 16 + r_, o);
+          v = g * e / (2.f * sd[base + i]);  // d out / d var = eps / (2 sqrt(var))   (mnf_linear.py:56)
+        }
+        tm_[r_ * kPitch + o] = g;
+        tv_[r_ * kPitch + o] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the wave's own LDS writes, read back by other lanes of the same wave below)
     f32x4 gm[YT], gv[YT], gvt[YT];
     u32x2 mh[YT], ml[YT], vh[YT], vl[YT];
     float mx = wmax_limit_ok > 0.f ? 0.f : __builtin_inff();
@@ -75,12 +98,8 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * m + 4 * q + r;
-        float g = 0.f, v = 0.f;
-        if (live && o < n_out) {
-          g = gout[rc * n_out + o];
-          const float e = eps ? eps[rc * n_out + o] : ml_normal(seed, rc, o);
-          v = g * e / (2.f * sd[rc * n_out + o]);  // d out / d var = eps / (2 sqrt(var))   (mnf_linear.py:56)
-        }
+        const bool in = live && o < n_out;
+        const float g = in ? tm_[j * kPitch + o] : 0.f, v = in ? tv_[j * kPitch + o] : 0.f;
         gm[m][r] = g * gscale;
         gvt[m][r] = v;
         gv[m][r] = v * gscale;  // (O(1) like g_m: the unscaled residuals of the row sums need operands near 1)
@@ -93,6 +112,7 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
       flags[grp] = bad ? 1 : 0;
       if (bad) list[1 + atomicAdd(list, 1)] = grp;  // (list[0] zeroed by the launcher)
     }
+    __builtin_amdgcn_wave_barrier();  // (the next group overwrites the staging area)
     if (bad || tile * 16 >= rows) continue;
 #pragma unroll
     for (int m = 0; m < YT; ++m) {
@@ -434,7 +454,7 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   int32_t* list = static_cast<int32_t*>(work);
   int32_t* flags = list + 1 + n_groups;
   uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + mlb_header_bytes(rows));
-  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
+  if (int rc = zero_word_async(list, stream)) return rc;
   const int cus = device_cus(current_device());
   const int64_t blocks_p = n_groups < 2 * cus ? n_groups : 2 * cus;
   hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,

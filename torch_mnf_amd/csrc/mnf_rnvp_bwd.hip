@@ -867,7 +867,7 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
   if (phases & 1) {
-  if (hipMemsetAsync(list, 0, sizeof(int32_t), stream) != hipSuccess) return check_launch();
+  if (int rc = zero_word_async(list, stream)) return rc;
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
   if (int rc = check_launch()) return rc;

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -267,6 +268,10 @@ class MNFLinear(nn.Module):
                 raise ValueError(f"eps must be {(x.shape[0], self.n_out)}, got {tuple(eps.shape)}")
         params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
         training = torch.is_grad_enabled() and (x.requires_grad or z.requires_grad or any(p.requires_grad for p in params))
+        if training and os.environ.get("MNF_DEBUG_LINEAR_TORCH") == "1":  # (bisecting aid, not a product path)
+            mean = (x * z) @ self.W_mean.T + self.b_mean
+            var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
+            return mean + var.sqrt() * torch.randn_like(var)
         if training:
             return _MnfLinearFn.apply(x, z, *params, self, eps, seed)
         return _mnf_linear_forward(self, x.detach().contiguous(), z.detach().contiguous(), eps, seed, ops, None)[0]
