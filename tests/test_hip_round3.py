@@ -213,6 +213,16 @@ def _check_grads(got, g32, g64, what, base=1e-5):
     return worst
 
 
+@pytest.fixture(autouse=True)
+def _mfma_gradient_path_at_every_size(monkeypatch):
+    """The library sends few-row / narrow RNVP layers to the generic gradient kernel (it is faster there); these tests
+    exercise the matrix-core kernels at every size."""
+    import torch_mnf_amd.flows as fl
+
+    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_ROWS", 0)
+    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_DIM", 0)
+
+
 def _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask=None, seed=None, generic=False):
     f = amd.RNVP(dim, h_sizes=(hid,))
     f.load_state_dict(sd)

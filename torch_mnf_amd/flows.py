@@ -41,6 +41,10 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
 # MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
+# the matrix-core RNVP gradient pass from this many rows / dims on (d = 800: 227 vs 252 us at 128 rows, 284 vs 837 us at
+# 2,048; d = 50: the generic kernel stays ahead up to 32,768 rows)
+_RNVP_BWD_MFMA_MIN_ROWS = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_ROWS", "64"))
+_RNVP_BWD_MFMA_MIN_DIM = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_DIM", "128"))
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 # MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
@@ -334,7 +338,10 @@ class _RnvpFn(torch.autograd.Function):
             return grad_z.zero_(), grad_flat, None, None, None
         # the matrix-core gradient kernels (two launches + the fp32 fix-up over flagged row groups); shapes they do not
         # cover, the fp32 switches and force_generic take the generic kernel
-        bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV) else m._bwd_image(z.device, flat)
+        # (few rows or a narrow layer: the one-launch generic kernel is the faster one -- the matrix-core pass is four
+        #  launches, the first a single workgroup's sweep over all dims: tools/time_rnvp_small.py)
+        small = z.shape[0] < _RNVP_BWD_MFMA_MIN_ROWS or m.dim < _RNVP_BWD_MFMA_MIN_DIM
+        bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV or small) else m._bwd_image(z.device, flat)
         split = m._split_image(z.device) if bwd is not None else None
         if bwd is not None and split is not None:
             rows = z.shape[0]
@@ -1016,9 +1023,17 @@ class RNVP(_HipFlow):
         if not table:
             return None
         idx, n_split, n_plain = table
+        # one pack per parameter state: `flat` is the forward pass's packed-parameter tensor (replaced, never rewritten,
+        # when a parameter changes), and a layer is differentiated several times per step (MNF: sample_z in forward
+        # and again in kl_div)
+        cached = self.__dict__.get("_bwd_img")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if cached is not None and cached[0] is flat and cached[1] == (flat._version, capturing):
+            return cached[2]
         image = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=device)
         _lib.check("mnf_pack_gather_split", _lib.load().mnf_pack_gather_split(
             flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, n_plain, _stream()))
+        self.__dict__["_bwd_img"] = (flat, (flat._version, capturing), image)
         return image
 
     def _bwd_workspace(self, lib, rows: int, device) -> Tensor:
