@@ -168,10 +168,20 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
             best = min(best, time.perf_counter() - t0)
             if time.perf_counter() - t_start > 2.0 * budget_s:
                 break
+    # ... and on ONE thread, on a sample sized for about a second
+    torch.set_num_threads(1)
+    n1 = int(min(rows, 1 << 13))
+    with torch.no_grad():
+        O.mean_log_prob(x[:1024], layers)
+        t0 = time.perf_counter()
+        O.mean_log_prob(x[:n1], layers)
+        one_thread = n1 / (time.perf_counter() - t0)
+    torch.set_num_threads(cores)
     info = {
         "value": rows / best,
         "unit": "samples/s",
         "cores": cores,
+        "one_thread": {"value": one_thread, "unit": "samples/s", "sample": f"first {n1} rows, one ATen thread, one pass"},
         "host_cores": host,
         "kind": "port",
         "sample": f"oracle (PyTorch-CPU restatement of the reference path), first {rows} rows of the "
@@ -668,6 +678,37 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
+SECONDARY = ("c3", "c4", "c5", "c2t", "c3t", "c5t")
+
+
+def secondary_lines(args) -> dict:
+    """The other configurations, driver-observable: after the headline's timed region (and outside it) each of them
+    runs as a CHILD process -- `bench.py --workload X --steps 20 --warmup 3 --no-cpu-baseline` -- and its line is
+    condensed to {ms_per_step, value, unit, kernel, avg_kernel_us, bound, frac}.  (A child process, never an exec: this
+    process has initialised the GPU.)  A workload that fails or overruns its time limit is reported as such."""
+    import subprocess
+
+    out = {}
+    for w in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "3",
+               "--no-cpu-baseline", "--no-secondary", "--prime-ms", str(args.prime_ms)]
+        try:
+            t0 = time.perf_counter()
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=90)
+            line = next((l for l in reversed(res.stdout.splitlines()) if l.startswith("{")), None)
+            if res.returncode != 0 or line is None:
+                out[w] = {"error": (res.stderr or "no JSON line").strip().splitlines()[-1][:200]}
+                continue
+            d = json.loads(line)
+            r = d.get("roofline", {})
+            out[w] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                      "kernel": (r.get("kernel") or "")[:80], "avg_kernel_us": r.get("avg_kernel_us"),
+                      "bound": r.get("bound"), "frac": r.get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[w] = {"error": "timed out after 90 s"}
+    return out
+
+
 def spawn_ranks(n: int, argv: list[str]) -> int:
     """`python bench.py --gpus N` without torchrun: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process
@@ -716,6 +757,9 @@ def main() -> None:
                          "state only after tens of ms of load, and the first ~25 passes run ~10 %% slower")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default (c2, one GPU) run only: skip the 20-step runs of the other configurations that are "
+                         "attached to the line as `secondary`")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -841,13 +885,18 @@ def main() -> None:
         else:
             launches = [(i, 1) for i in range(n_layers)]
         timed_layers = [i for i, _ in launches if args.workload != "c3" or i % 3 == 0]
+        # one HIP event per step boundary (on the launch stream, no synchronisation): the per-step durations behind
+        # `median_ms` / `min_ms` (SURVEY 8d asks for median + min next to the K-step wall clock)
+        step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
         for k in range(args.steps):
             # one layer per step carries the (start, end) marks, rotating: every mark costs a few us of
             # stream time, and ten of them per step would be ~4 % of the step they are measuring
             model.layer_event_pick = timed_layers[k % len(timed_layers)]
+            step_marks[k].record()
             step()
         mean = finish()  # the last pass's mean: every pass's reduction completes inside the timed region
+        step_marks[args.steps].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -892,6 +941,8 @@ def main() -> None:
                 print(f"layer {i} per step (us):", [round(t * 1e3) for t in v], file=sys.stderr)
         kern_ms = [t for v in by_layer.values() for t in v]
         avg_kernel_s = sum(kern_ms) / len(kern_ms) / 1e3
+        step_ms = sorted(step_marks[k].elapsed_time(step_marks[k + 1]) for k in range(args.steps))
+        kern_sorted = sorted(kern_ms)
         # per layer and row: read 4d, write 4d, log_det read+write; a launch that covers a run of
         # layers is priced at the algorithmic bytes of all of them, although it moves only
         # 4d (span + 1) + 8 bytes per row (each intermediate is written once and never re-read)
@@ -910,6 +961,8 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "median_ms": step_ms[len(step_ms) // 2],   # per-step durations between HIP events on the launch stream
+            "min_ms": step_ms[0],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -941,6 +994,8 @@ def main() -> None:
                            f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<{dim // 2},24,inverse> ({span_dom} layers per launch, "
                            "every intermediate written)" if span_dom > 1 else f"{AHF_KERNEL}<{dim // 2},24,inverse>"),
                 "avg_kernel_us": avg_kernel_s * 1e6,
+                "median_kernel_us": kern_sorted[len(kern_sorted) // 2] * 1e3,
+                "min_kernel_us": kern_sorted[0] * 1e3,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "launches_timed": len(kern_ms),
                 "layers_per_launch": span_dom,
@@ -988,6 +1043,8 @@ def main() -> None:
             out["parity"] = {"rows": n, "mean_log_prob_gpu": gpu_sample_mean, "mean_log_prob_cpu": cpu_mean,
                              "rel_err": abs(gpu_sample_mean - cpu_mean) / abs(cpu_mean), "tolerance": 1e-5}
             out["speedup_vs_cpu"] = out["value"] / info["value"]
+        if world == 1 and args.workload == "c2" and not args.no_secondary:
+            out["secondary"] = secondary_lines(args)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -112,11 +112,13 @@ def test_bench_starts_its_own_ranks(amd):
 
 def test_bench_single_gpu_line(amd):
     """--gpus 1 is unchanged by the launcher logic, and the roofline object carries both fractions."""
-    line = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--prime-ms", "5")
+    line = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--prime-ms", "5")
     assert line["n_gpus"] == 1 and line["distributed"]["ranks"] == 1
     r = line["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "frac_physical" in r and "traffic_source" in r
+    assert line["min_ms"] <= line["median_ms"] and r["min_kernel_us"] <= r["median_kernel_us"]
+    assert "secondary" not in line
 
 
 def test_bench_training_step_line(amd):

@@ -480,3 +480,44 @@ def test_mnf_linear_rejects_what_the_kernels_cannot_take(amd):
     wide = amd.MNFLinear(32, 100).to(DEV)
     with pytest.raises(amd.MnfHipError):
         wide.forward(torch.randn(4, 32, device=DEV))           # n_out > 64: no kernel
+
+
+# ------------------------------------------------------------------------------------------------ bench lines
+def _run_bench(*args):
+    import json
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_c5t_training_step_line(amd):
+    """--workload c5t: one Adam step of MNFLinear(800, 50) at 256,000 rows per step; the line carries launch B-ts's
+    roofline, the oracle's training step as cpu_baseline and the gradients' parity against the float64 oracle at
+    1e-5 + twice the fp32 oracle's own distance from it."""
+    line = _run_bench("--workload", "c5t", "--steps", "3", "--warmup", "1", "--prime-ms", "5")
+    r = line["roofline"]
+    assert line["unit"] == "rows/s" and r["bound"] == "hbm" and "rnvp_bwd_ts_kernel" in r["kernel"]
+    assert r["launches_timed"] == 3 * 2 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert line["loss_last_step"] < line["loss_first_step"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["worst_parameter_gradient_normwise_err"] <= line["parity"]["tolerance"]
+    assert line["parity"]["loss_gpu_vs_cpu_rel_err"] <= 1e-6
+
+
+def test_bench_default_line_carries_the_other_configurations(amd):
+    """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c2t, c3t, c5t as `secondary`
+    (only c2 used to be driver-observable), the per-step median / min and a one-thread CPU
+    figure."""
+    line = _run_bench("--steps", "5", "--warmup", "2", "--prime-ms", "5")
+    assert line["config"]["workload"].startswith("9xAffineHalfFlow d=64")
+    sec = line["secondary"]
+    assert set(sec) == {"c3", "c4", "c5", "c2t", "c3t", "c5t"}
+    for w, d in sec.items():
+        assert "error" not in d, (w, d)
+        assert d["ms_per_step"] > 0 and d["avg_kernel_us"] > 0 and d["bound"] in ("hbm", "valu", "mfma"), (w, d)
+    assert line["cpu_baseline"]["one_thread"]["value"] > 0
+    assert line["min_ms"] <= line["median_ms"]
