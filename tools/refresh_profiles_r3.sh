@@ -1,0 +1,37 @@
+#!/bin/bash
+# Regenerates the round-3 evidence on the GPU box into gpurun_out/r3/ (copy what is to be judged into profiles/r3/):
+# bench JSON lines, rocprofv3 kernel-trace + PMC summaries (every profiler run under `timeout`), PMC traffic files.
+# usage: tools/refresh_profiles_r3.sh [workloads...]   (default: c2 c3 c4 c5 c2t c5t)
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/r3
+mkdir -p "$OUT"
+cd "$REPO"
+WL=${*:-c2 c3 c4 c5 c2t c5t}
+declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
+                  [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
+                  [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_kernel<50, true, false" \
+                  [c3t]="nsf_bwd" )
+for w in $WL; do
+  extra=""; [ "$w" = c2 ] && extra="--no-secondary"
+  timeout 400 python bench.py --workload $w $extra > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
+  P=$REPO/gpurun_out/prof_r3_$w
+  mkdir -p "$P"
+  ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --workload $w"
+  [ "$w" = c5t ] && ARGS="--steps 6 --warmup 2 --no-cpu-baseline --workload $w"
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 "$REPO/bench.py" $ARGS > "$P/trace.log" 2>&1
+    timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_fetch.log" 2>&1
+    timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_write.log" 2>&1
+    if [ "$w" != c5t ]; then
+      timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$P/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq.log" 2>&1
+      timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d "$P/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq2.log" 2>&1
+    fi )
+  python3 tools/summarize_prof.py "$P" > "$OUT/${w}_rocprofv3_summary.txt" 2>&1
+  cp "$P"/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null || cp "$P"/trace/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null
+  python3 tools/make_traffic_json.py gpurun_out/prof_r3_$w $w "${KERN[$w]}" "$OUT/${w}_pmc_traffic.json" > /dev/null 2>&1
+  [ "$w" != c5t ] && python3 tools/make_valu_json.py gpurun_out/prof_r3_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" > /dev/null 2>&1
+done
+ls -la "$OUT"
+for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python3 -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', round(d['value']/1e6,1), 'M/s', round(d['ms_per_step'],3), 'ms', r['bound'], round(r['frac'],3), round(r['avg_kernel_us'],1), 'us', r.get('traffic'))"; done
+for f in "$OUT"/*_pmc_traffic.json; do echo "$f"; grep -E "FETCH|WRITE|traffic_bytes" "$f"; done

@@ -121,10 +121,16 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
     }
     store_handover<YT>(side + tile * H::TILE_WORDS, mh, ml, vh, vl, lane, j, q);
   }
-  // db_mean, db_log_var = exp(b_log_var) sum g_v: sums over the wave's rows (the 16 lanes j of a q)
+  // db_mean, db_log_var = exp(b_log_var) sum g_v: sums over the wave's rows (the 16 lanes j of a q), over the
+  // workgroup's waves in LDS, then one atomic per output per workgroup (one per output per WAVE -- 410,000 atomics on
+  // 100 addresses -- serialised at the memory side for 0.5 ms)
   if (grad_flat) {
     const float inv = 1.f / gscale;
     const int64_t bmo = 2 * (int64_t)n_out * n_in, bvo = bmo + n_out;
+    float* bsum = stage;  // [0, 64): mean, [64, 128): var
+    __syncthreads();
+    if (threadIdx.x < 128) bsum[threadIdx.x] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < YT; ++m)
 #pragma unroll
@@ -135,12 +141,17 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
           a += __shfl_xor(a, off, 64);
           b += __shfl_xor(b, off, 64);
         }
-        const int o = 16 * m + 4 * q + r;
-        if (j == 0 && o < n_out) {
-          if (a != 0.f) atomicAdd(grad_flat + bmo + o, a * inv);
-          if (b != 0.f) atomicAdd(grad_flat + bvo + o, b * flat[bvo + o]);
+        if (j == 0) {
+          atomicAdd(bsum + 16 * m + 4 * q + r, a);
+          atomicAdd(bsum + 64 + 16 * m + 4 * q + r, b);
         }
       }
+    __syncthreads();
+    if ((int)threadIdx.x < n_out) {
+      const int o = threadIdx.x;
+      if (bsum[o] != 0.f) atomicAdd(grad_flat + bmo + o, bsum[o] * inv);
+      if (bsum[64 + o] != 0.f) atomicAdd(grad_flat + bvo + o, bsum[64 + o] * flat[bvo + o]);
+    }
   }
 }
 

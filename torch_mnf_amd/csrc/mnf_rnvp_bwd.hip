@@ -332,11 +332,14 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
     rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
                                       weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0);
-  // dbn: sum over the wave's rows (the 16 lanes j of a q), one atomic per unit per wave
-  if (grad_flat) {
+  // dbn: sum over the wave's rows (the 16 lanes j of a q), over the workgroup's waves in LDS, then ONE atomic per unit
+  // per workgroup (atomics on a few dozen addresses serialise at the memory side: one per unit per WAVE cost 0.16 ms)
+  if (grad_flat && !(kBwdAbl & 64)) {
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    const float inv = 1.f / gscale;
-    float* dbn = grad_flat + (int64_t)hn * dm;
+    float* bsum = reinterpret_cast<float*>(&lds[0][0]);
+    __syncthreads();  // the operand window is no longer read
+    if (threadIdx.x < 16 * S::YT) bsum[threadIdx.x] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < S::YT; ++m)
 #pragma unroll
@@ -346,9 +349,11 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 8, 64);
-        const int unit = 16 * m + 4 * q + r;
-        if (j == 0 && unit < hn && v != 0.f) atomicAdd(dbn + unit, v * inv);
+        if (j == 0) atomicAdd(bsum + 16 * m + 4 * q + r, v);
       }
+    __syncthreads();
+    if ((int)threadIdx.x < hn && bsum[threadIdx.x] != 0.f)
+      atomicAdd(grad_flat + (int64_t)hn * dm + threadIdx.x, bsum[threadIdx.x] * (1.f / gscale));
   }
 }
 
