@@ -690,7 +690,9 @@ def secondary_lines(args) -> dict:
 
     out = {}
     for w in SECONDARY:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "3",
+        # (MNF_BENCH_SECONDARY_STEPS: the test suite shortens the child runs)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps",
+               os.environ.get("MNF_BENCH_SECONDARY_STEPS", "20"), "--warmup", "3",
                "--no-cpu-baseline", "--no-secondary", "--prime-ms", str(args.prime_ms)]
         try:
             t0 = time.perf_counter()

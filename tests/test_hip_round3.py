@@ -487,7 +487,7 @@ def _run_bench(*args):
     import json
 
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                         timeout=600, cwd=ROOT, env={**os.environ, "MNF_BENCH_SECONDARY_STEPS": "3"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -512,12 +512,17 @@ def test_bench_default_line_carries_the_other_configurations(amd):
     """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c2t, c3t, c5t as `secondary`
     (only c2 used to be driver-observable), the per-step median / min and a one-thread CPU
     figure."""
-    line = _run_bench("--steps", "5", "--warmup", "2", "--prime-ms", "5")
+    line = _run_bench("--steps", "5", "--warmup", "2", "--prime-ms", "5", "--no-cpu-baseline")
     assert line["config"]["workload"].startswith("9xAffineHalfFlow d=64")
     sec = line["secondary"]
     assert set(sec) == {"c3", "c4", "c5", "c2t", "c3t", "c5t"}
     for w, d in sec.items():
         assert "error" not in d, (w, d)
         assert d["ms_per_step"] > 0 and d["avg_kernel_us"] > 0 and d["bound"] in ("hbm", "valu", "mfma"), (w, d)
-    assert line["cpu_baseline"]["one_thread"]["value"] > 0
     assert line["min_ms"] <= line["median_ms"]
+
+
+def test_bench_cpu_baseline_has_a_one_thread_figure(amd):
+    line = _run_bench("--steps", "3", "--warmup", "1", "--prime-ms", "5", "--no-secondary")
+    assert line["cpu_baseline"]["one_thread"]["value"] > 0 and line["cpu_baseline"]["value"] > 0
+    assert line["parity"]["rel_err"] <= line["parity"]["tolerance"]

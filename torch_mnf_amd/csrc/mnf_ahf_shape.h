@@ -34,6 +34,18 @@ __device__ __forceinline__ float exp6(float x) {
 }
 
 
+// exp(x) in TWO instructions for the split kernels' hot path: exp2(fl32(x log2 e)).  What it gives up against exp6 is the
+// rounding of x log2 e, a relative error of |x| 4e-8 in the result -- below half an ulp for |x| <= 1.4 (there the
+// two agree bit for bit: exp6's correction factor rounds to 1) and 4e-7 at |s| = 10, against a parity bar of 1e-5.
+// Same limits: overflow gives +inf, underflow 0, NaN stays NaN.  Worth 3.1 % of the 9-layer C2 launch (784 -> 759 us,
+// same box; tools/split_accuracy.py: the distance from float64 does not move).
+#ifndef MNF_EXP_FAST
+#define MNF_EXP_FAST 1  // 0: exp6 everywhere (A/B builds)
+#endif
+__device__ __forceinline__ float exp2x(float x) {
+  return MNF_EXP_FAST ? __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f) : exp6(x);
+}
+
 template <int H, int HID>
 struct AhfShape {
   static_assert(H % 16 == 0, "conditioner width must be a multiple of 16");
@@ -137,7 +149,8 @@ __device__ __forceinline__ void ahf_cond_f32(const float* img, int lane, int q, 
 
 // act <- exp(s) act + t, or its inverse (act - t) exp(-s): one multiply instead of a ~10-instruction
 // IEEE divide, same limits (0, inf, NaN), <= 2 ulp from the quotient.  Returns this lane's sum of s.
-template <int H, bool INV>
+// FAST: the two-instruction exp (the split kernels' hot path); the fp32-MFMA kernels and the range-guard path keep exp6
+template <int H, bool INV, bool FAST = false>
 __device__ __forceinline__ float ahf_transform(const f32x4 (&s4)[H / 16], const f32x4 (&t4)[H / 16],
                                                f32x4 (&act)[H / 16]) {
   float ld = 0.f;
@@ -145,7 +158,7 @@ __device__ __forceinline__ float ahf_transform(const f32x4 (&s4)[H / 16], const 
   for (int m = 0; m < H / 16; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = exp6(INV ? -s4[m][r] : s4[m][r]);
+      const float e = FAST ? exp2x(INV ? -s4[m][r] : s4[m][r]) : exp6(INV ? -s4[m][r] : s4[m][r]);
       act[m][r] = INV ? (act[m][r] - t4[m][r]) * e : __builtin_fmaf(e, act[m][r], t4[m][r]);
       ld += s4[m][r];
     }

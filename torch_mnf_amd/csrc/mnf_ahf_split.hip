@@ -166,7 +166,7 @@ ahf_split_kernel(const float* __restrict__ x, float* __restrict__ y, float* __re
         ahf_cond_f32<H, HID>(image_f32, lane, q, again, s4[0], t4[0]);
       }
     }
-    float ld = ahf_transform<H, INV>(s4[0], t4[0], act);
+    float ld = ahf_transform<H, INV, true>(s4[0], t4[0], act);
     if (live) {
 #pragma unroll
       for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + act_off + 16 * g) = act[g];
@@ -361,7 +361,7 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                       const float sv = sc[t][g][r], tv = tc[t][g][r];
-                      const float e = exp6(INV ? -sv : sv);
+                      const float e = exp2x(INV ? -sv : sv);
                       const float a = act_rows[t][g0 + g][r];
                       act_rows[t][g0 + g][r] = INV ? (a - tv) * e : __builtin_fmaf(e, a, tv);
                       ld[t] += sv;
@@ -382,7 +382,7 @@ ahf_split_stack_kernel(const float* __restrict__ x, float* __restrict__ y, float
         } else {
           ahf_cond_guarded<H, HID, NTL>(img, f32img, lane, q, cnd_rows, s4, t4, store_previous);
 #pragma unroll
-          for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV>(s4[t], t4[t], act_rows[t]);
+          for (int t = 0; t < NTL; ++t) ld[t] += ahf_transform<H, INV, true>(s4[t], t4[t], act_rows[t]);
         }
       };
       if ((parity_bits >> layer) & 1u) run_layer(hi, lo);  // conditioner = upper half
