@@ -58,7 +58,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 9
+#define MNF_ABI_VERSION 10
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -329,6 +329,40 @@ int mnf_mnf_linear_bwd(const float* x, const float* z, const float* grad_out, co
                        uint64_t seed, float* grad_x, float* grad_z, float* grad_flat, const float* flat,
                        const void* bwd_image, float var_unscale, const int32_t* fwd_flags, const float* grad_scale_dev,
                        void* workspace, int64_t workspace_bytes, int64_t rows, int n_in, int n_out, void* stream);
+
+/* ------------------------------------------------ the MNF layers' KL term behind their flows
+ * MNFLinear.kl_div (torch_mnf/layers/mnf_linear.py:66-90) and MNFConv2d.kl_div (torch_mnf/layers/mnf_conv.py:100-133)
+ * with every random draw and both flows' results handed in: one launch forward, one backward (composed from stock
+ * elementwise ops a layer's term is ~70 + ~100 launches).  The weight tensor is seen as a (rows, cols) matrix:
+ *   conv = 0 (MNFLinear):  rows = n_out, cols = n_in, n_bias = n_out; eps (rows, cols) = the draw for `weight`
+ *                          (mnf_linear.py:70-71); eps_b NULL; act = tanh(weight r0_c)
+ *   conv = 1 (MNFConv2d):  rows = n_in k k, cols = n_out = n_bias (the `.view(-1, len(r0_c))` of mnf_conv.py:117-118
+ *                          over the flat (n_out, n_in, k, k) tensor); eps (rows) = epsilon_w, eps_b (1) = epsilon_b;
+ *                          linear act (:119-123); b_mean may be NULL (the zero buffer of :45)
+ * z, z_r (cols): sample_z's z and flow_r's last output; log_det_q, log_det_r (1); q0_log_var, r0_c, r0_b1, r0_b2 (cols).
+ * All pointers are device memory.  out (1) = kl_div_W + kl_div_b + log_q - log_r.
+ * saved: mnf_mnf_kl_saved_floats(rows) floats written by _fwd and read by _bwd (act, its mean, the bias deviation).
+ * _bwd, every entry times grad_out[0]:
+ *   grads (written), mnf_mnf_kl_grad_floats(cols) floats:  dz (cols: the term's direct dependence; what reaches z
+ *     through flow_r comes back through dz_r) | dz_r (cols) | dlog_det_q | dlog_det_r
+ *   param_grads, mnf_mnf_kl_param_grad_floats(...) floats, in the order both reference modules register their
+ *     parameters (mnf_linear.py:24-33, mnf_conv.py:43-57):  dW_mean (rows cols) | dW_log_var (rows cols) | db_mean
+ *     (n_bias; conv = 0 only: MNFConv2d's b_mean is not a parameter) | db_log_var (n_bias) | dq0_mean (cols: no direct
+ *     dependence) | dq0_log_var | dr0_c | dr0_b1 | dr0_b2 (cols each).  accumulate = 0: written (dq0_mean = 0);
+ *     accumulate = 1: ADDED to -- a training loop that keeps all gradients in one buffer hands in the layer's slice.
+ * rows > 28,672: MNF_ERR_UNSUPPORTED. */
+int64_t mnf_mnf_kl_saved_floats(int64_t rows);
+int64_t mnf_mnf_kl_grad_floats(int cols);
+int64_t mnf_mnf_kl_param_grad_floats(int conv, int64_t rows, int cols, int n_bias);
+int mnf_mnf_kl_fwd(const float* W_mean, const float* W_log_var, const float* eps, const float* eps_b, const float* z,
+                   const float* z_r, const float* log_det_q, const float* log_det_r, const float* b_mean,
+                   const float* b_log_var, const float* q0_log_var, const float* r0_c, const float* r0_b1,
+                   const float* r0_b2, int conv, int64_t rows, int cols, int n_bias, float* out, float* saved,
+                   void* stream);
+int mnf_mnf_kl_bwd(const float* W_mean, const float* W_log_var, const float* eps, const float* eps_b, const float* z,
+                   const float* z_r, const float* b_mean, const float* b_log_var, const float* r0_c, const float* r0_b1,
+                   const float* r0_b2, const float* saved, const float* grad_out, int conv, int64_t rows, int cols,
+                   int n_bias, float* grads, float* param_grads, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ gradients (autograd)
  * What torch.autograd.Function.backward needs so the modules train like the reference's

@@ -392,6 +392,23 @@ def mnf_linear_forward(x: Tensor, z: Tensor, W_mean: Tensor, W_log_var: Tensor, 
     return mean + var.sqrt() * eps
 
 
+def mnf_linear_kl(p: dict, z: Tensor, log_det_q: Tensor, eps_w: Tensor, r_layers: Sequence[dict]) -> Tensor:
+    """MNFLinear.kl_div behind sample_z with the weight noise injected and flow_r given as oracle layer specs.
+    torch_mnf/layers/mnf_linear.py:66-90 (tanh auxiliary activation, eqs. (9), (10))."""
+    W_mean = z * p["W_mean"]
+    W_var = p["W_log_var"].exp()
+    weight = W_mean + W_var.sqrt() * eps_w
+    kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean**2 - 1)
+    kl_b = 0.5 * torch.sum(-p["b_log_var"] + p["b_log_var"].exp() + p["b_mean"] ** 2 - 1)
+    log_q = -log_det_q - 0.5 * p["q0_log_var"].sum()
+    act = torch.tanh(p["r0_c"] @ weight.T)
+    mean_r = torch.outer(p["r0_b1"], act).mean(1)
+    log_var_r = torch.outer(p["r0_b2"], act).mean(1)
+    zs, log_det_r = flow_stack(z, r_layers, inverse=False)
+    log_r = log_det_r.squeeze() + 0.5 * torch.sum(-log_var_r.exp() * (zs[-1] - mean_r) ** 2 + log_var_r)
+    return kl_W + kl_b + log_q - log_r
+
+
 def mnf_conv2d_sample_z(q0_mean: Tensor, q0_log_var: Tensor, eps_z: Tensor, layers: Sequence[dict]) -> tuple[Tensor, Tensor]:
     """MNFConv2d.sample_z with injected noise: one n_out-vector through flow_q.  layers/mnf_conv.py:90-98."""
     z0 = q0_mean + q0_log_var.exp().sqrt() * eps_z

@@ -483,6 +483,49 @@ def g13_mnf_conv2d():
     save("g13_mnf_conv2d", **out)
 
 
+# ----------------------------------------------------------------------------- G14
+def g14_mnf_linear_kl():
+    """MNFLinear.kl_div (mnf_linear.py:66-90) with every random draw captured (the sample_z noise, flow_q's two masks,
+    the weight noise, flow_r's two masks) -- for MNFLinear(800, 50) and MNFLinear(50, 10), MNF-LeNet's dense layers."""
+    out = {}
+    for tag, (n_in, n_out, seed) in {"l800": (800, 50, 31), "l50": (50, 10, 32)}.items():
+        torch.manual_seed(seed)
+        layer = MNFLinear(n_in, n_out)
+        for name, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+            for i, f in enumerate(flow.flows):
+                f.load_state_dict(recipes.rnvp_params(1400 + seed + 10 * (name == "r") + i, n_in, 50))
+        with torch.no_grad():  # (b_mean is zero at init: give the bias term something to square)
+            layer.b_mean.copy_(recipes.gaussian(1400 + seed, 1, n_out, scale=0.3)[0])
+        captured = {"randn_like": [], "bernoulli": []}
+        real = (torch.randn_like, torch.bernoulli)
+
+        def randn_like(t, *a, **kw):
+            r = real[0](t, *a, **kw)
+            captured["randn_like"].append(r.clone())
+            return r
+
+        def bernoulli(t, *a, **kw):
+            r = real[1](t, *a, **kw)
+            captured["bernoulli"].append(r.clone())
+            return r
+
+        torch.randn_like, torch.bernoulli = randn_like, bernoulli
+        try:
+            with torch.no_grad():
+                kl = layer.kl_div()
+        finally:
+            torch.randn_like, torch.bernoulli = real
+        assert {key: len(v) for key, v in captured.items()} == {"randn_like": 2, "bernoulli": 4}
+        for key in ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"):
+            out[f"{tag}.{key}"] = npy(getattr(layer, key))
+        out[f"{tag}.eps_z"] = npy(captured["randn_like"][0])
+        out[f"{tag}.eps_w"] = npy(captured["randn_like"][1])
+        out[f"{tag}.masks_q"] = np.stack([npy(m) for m in captured["bernoulli"][:2]])
+        out[f"{tag}.masks_r"] = np.stack([npy(m) for m in captured["bernoulli"][2:]])
+        out[f"{tag}.kl"] = npy(kl)
+    save("g14_mnf_linear_kl", **out)
+
+
 # ----------------------------------------------------------------------------- G9
 def g9_logdet_shapes():
     x = recipes.gaussian(900, 8, 4)
@@ -521,4 +564,5 @@ if __name__ == "__main__":
     g11_mnf_linear_forward()
     g12_nsf_ar()
     g13_mnf_conv2d()
+    g14_mnf_linear_kl()
     g9_logdet_shapes()

@@ -1,0 +1,228 @@
+"""GPU tests of the MNF layers' KL term in one launch each way (``mnf_mnf_kl_fwd`` / ``mnf_mnf_kl_bwd`` behind
+``MNFLinear.kl_div`` and ``MNFConv2d.kl_div``): values against the reference's own runs (fixtures G13, G14), gradients
+of every parameter -- the layer's and both flows' -- against autograd through the float64 oracle on the same draws."""
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from helpers import normwise_err
+from test_oracle_golden import G13_CASES, G13_KEYS, G14_CASES, G14_KEYS, g13_specs, g14_specs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+# gradient bar: 1e-5 normwise + twice the fp32-vs-fp64 distance of the oracle itself
+GBASE = 1e-5
+# Ill-conditioned by construction: every activation-side gradient of MNFConv2d's term is proportional to d kl / d abar
+# = sum_i (d/d mean_r[i] b1[i] + d/d log_var_r[i] b2[i]), and on fixture c1 (20 channels) those 20 terms cancel to
+# 1/4257 of their magnitude (float64 oracle: sum = -1.852e-4, sum of magnitudes 0.788).  d r0_c is that factor times a
+# well-conditioned sum, so fp32 rounding of the flows' output z_r (2^-23 relative) shows up 4257 times larger; the
+# float32 oracle itself is 1.5e-5 away from the float64 one there.  The bar for that tensor carries the condition number.
+COND_BARS = {("conv", "c1", "r0_c"): 4257 * 2.0 ** -23}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch_mnf_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    torch_mnf_amd._lib.load()
+    return torch_mnf_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import flow_oracle
+
+    return flow_oracle
+
+
+def linear_layer(amd, fx, tag):
+    n_in, n_out, seed = G14_CASES[tag]
+    layer = amd.MNFLinear(n_in, n_out)
+    layer.load_state_dict({k: torch.from_numpy(fx[f"{tag}.{k}"]) for k in G14_KEYS}, strict=False)
+    for which, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+        for i, f in enumerate(flow.flows):
+            f.load_state_dict(recipes.rnvp_params(1400 + seed + 10 * (which == "r") + i, n_in, 50))
+    dev = lambda name: torch.from_numpy(fx[f"{tag}.{name}"]).to(DEV)
+    noise = {"eps_z": dev("eps_z"), "masks_q": list(dev("masks_q")), "eps_w": dev("eps_w"), "masks_r": list(dev("masks_r"))}
+    return layer.to(DEV), noise
+
+
+def conv_layer(amd, fx, tag):
+    n_in, n_out, k, seed = G13_CASES[tag]
+    layer = amd.MNFConv2d(n_in, n_out, k)
+    layer.load_state_dict({k_: torch.from_numpy(fx[f"{tag}.{k_}"]) for k_ in G13_KEYS}, strict=False)
+    for which, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+        for i, f in enumerate(flow.flows):
+            f.load_state_dict(recipes.rnvp_params(1300 + seed + 10 * (which == "r") + i, n_out, 50))
+    dev = lambda name: torch.from_numpy(fx[f"{tag}.{name}"]).to(DEV)
+    noise = {"eps_z": dev("kl.eps_z"), "masks_q": list(dev("kl.masks_q")), "eps_w": dev("kl.eps_w"),
+             "eps_b": dev("kl.eps_b"), "masks_r": list(dev("kl.masks_r"))}
+    return layer.to(DEV), noise
+
+
+@pytest.mark.parametrize("tag", sorted(G14_CASES))
+def test_g14_mnf_linear_kl_vs_reference(amd, golden, tag):
+    """Fixture G14: the reference's MNFLinear.kl_div (mnf_linear.py:66-90) with every random draw captured."""
+    fx = golden("g14_mnf_linear_kl")
+    layer, noise = linear_layer(amd, fx, tag)
+    with torch.no_grad():
+        kl = layer.kl_div(noise)
+    assert kl.shape == ()
+    assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))
+    with torch.no_grad():  # default draws: finite, and a different draw gives a different value
+        a, b = layer.kl_div(), layer.kl_div()
+    assert torch.isfinite(a) and torch.isfinite(b) and float(a) != float(b)
+
+
+def oracle_grads(O, kind, fx, tag, dtype):
+    """d kl / d (every layer parameter, every flow parameter) by autograd through the oracle in `dtype`."""
+    if kind == "linear":
+        keys, seed, dim = G14_KEYS, G14_CASES[tag][2], G14_CASES[tag][0]
+        specs = lambda which, name: g14_specs(tag, which, fx[f"{tag}.{name}"], dtype)
+        p = {k: torch.from_numpy(fx[f"{tag}.{k}"]).to(dtype).requires_grad_() for k in keys}
+        q_layers, r_layers = specs("q", "masks_q"), specs("r", "masks_r")
+    else:
+        keys, seed, dim = G13_KEYS, G13_CASES[tag][3], G13_CASES[tag][1]
+        p = {k: torch.from_numpy(fx[f"{tag}.{k}"]).to(dtype).requires_grad_() for k in keys}
+        q_layers, r_layers = g13_specs(tag, "q", fx[f"{tag}.kl.masks_q"]), g13_specs(tag, "r", fx[f"{tag}.kl.masks_r"])
+    for layers in (q_layers, r_layers):
+        for spec in layers:
+            spec["mask"] = spec["mask"].to(dtype)
+            spec["params"] = {k: v.to(dtype).clone().requires_grad_() for k, v in spec["params"].items()}
+    t = lambda name: torch.from_numpy(fx[f"{tag}.{name}"]).to(dtype)
+    if kind == "linear":
+        z, ldq = O.sample_z(p["q0_mean"], p["q0_log_var"], t("eps_z"), q_layers)
+        kl = O.mnf_linear_kl(p, z, ldq, t("eps_w"), r_layers)
+    else:
+        z, ldq = O.mnf_conv2d_sample_z(p["q0_mean"], p["q0_log_var"], t("kl.eps_z"), q_layers)
+        kl = O.mnf_conv2d_kl(p, z, ldq, t("kl.eps_w"), t("kl.eps_b"), r_layers)
+    kl.backward()
+    grads = {k: v.grad for k, v in p.items()}
+    for which, layers in (("flow_q", q_layers), ("flow_r", r_layers)):
+        for i, spec in enumerate(layers):
+            for k, v in spec["params"].items():
+                grads[f"{which}.flows.{i}.{k}"] = v.grad
+    return float(kl.detach()), grads
+
+
+@pytest.mark.parametrize("kind,tag", [("linear", "l800"), ("linear", "l50"), ("conv", "c1"), ("conv", "c2")])
+def test_kl_gradients_vs_float64_oracle(amd, O, golden, kind, tag):
+    """loss = kl_div(): every gradient -- W_mean, W_log_var, the biases, q0, r0_c / r0_b1 / r0_b2 from
+    ``mnf_mnf_kl_bwd``, and flow_q's / flow_r's parameters through dz, dz_r and the RNVP gradient kernels -- within
+    1e-5 + 2 dist(fp32 oracle, fp64 oracle) of autograd through the float64 oracle on the fixture's draws."""
+    fx = golden("g14_mnf_linear_kl" if kind == "linear" else "g13_mnf_conv2d")
+    layer, noise = (linear_layer if kind == "linear" else conv_layer)(amd, fx, tag)
+    kl = layer.kl_div(noise)
+    kl.backward()
+    kl64, g64 = oracle_grads(O, kind, fx, tag, torch.float64)
+    kl32, g32 = oracle_grads(O, kind, fx, tag, torch.float32)
+    assert abs(float(kl) - kl64) <= 1e-5 * abs(kl64) + 2 * abs(kl32 - kl64)
+    named = dict(layer.named_parameters())
+    worst = 0.0
+    for name, ref in g64.items():
+        if name not in named:  # (conv: b_mean is the reference's zero buffer, no gradient)
+            continue
+        got = named[name].grad
+        assert got is not None, name
+        ref_np, got_np = ref.numpy(), got.detach().cpu().double().numpy().reshape(ref.shape)
+        if not np.any(ref_np):
+            assert not np.any(got_np), name
+            continue
+        widen = 2 * normwise_err(g32[name].double().numpy(), ref_np)
+        err = normwise_err(got_np, ref_np)
+        worst = max(worst, err - widen - COND_BARS.get((kind, tag, name), 0.0))
+        bar = GBASE + widen + COND_BARS.get((kind, tag, name), 0.0)
+        assert err <= bar, f"{kind} {tag} {name}: {err:.2e} > {bar:.2e} (1e-5 + {widen:.2e} of float64 head-room)"
+    assert set(named) <= set(g64), sorted(set(named) - set(g64))
+    print(f"kl gradients {kind} {tag}: worst error beyond the oracle's own fp32 distance {worst:.2e}")
+
+
+def test_kl_gradients_scale_with_the_cotangent_and_accumulate(amd, golden):
+    """(3 kl).backward() = 3 x kl.backward(), and two backward passes accumulate (the kernel writes fresh gradients; the
+    accumulation is autograd's)."""
+    fx = golden("g13_mnf_conv2d")
+    layer, noise = conv_layer(amd, fx, "c1")
+    layer.kl_div(noise).backward()
+    g1 = {n: p.grad.clone() for n, p in layer.named_parameters()}
+    layer.zero_grad()
+    (3.0 * layer.kl_div(noise)).backward()
+    for n, p in layer.named_parameters():
+        assert normwise_err(p.grad.cpu().numpy(), 3 * g1[n].cpu().numpy()) <= 2e-6, n
+    layer.kl_div(noise).backward()
+    for n, p in layer.named_parameters():
+        assert normwise_err(p.grad.cpu().numpy(), 4 * g1[n].cpu().numpy()) <= 2e-6, n
+
+
+def test_kl_is_two_library_launches_and_no_stock_arithmetic(amd, golden):
+    """Behind the flows the term is one library launch forward and one backward: no aten arithmetic kernel besides the
+    random draws and autograd's gradient accumulation."""
+    from torch.profiler import ProfilerActivity, profile
+
+    fx = golden("g14_mnf_linear_kl")
+    layer, noise = linear_layer(amd, fx, "l50")
+    layer.kl_div(noise).backward()
+    layer.zero_grad()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        layer.kl_div(noise).backward()
+        torch.cuda.synchronize()
+    ops = {e.key for e in prof.key_averages()}
+    for banned in ("aten::mm", "aten::addmm", "aten::tanh", "aten::outer", "aten::log", "aten::mean", "aten::tanh_backward"):
+        assert banned not in ops, banned
+    kernels = [e.key for e in prof.key_averages() if "kl_fwd_kernel" in e.key or "kl_bwd_kernel" in e.key]
+    assert len(kernels) == 2, kernels
+
+
+def test_kl_rejects_misplaced_operands(amd, golden):
+    fx = golden("g14_mnf_linear_kl")
+    layer, noise = linear_layer(amd, fx, "l50")
+    with pytest.raises(ValueError, match="eps"):
+        layer.kl_div({**noise, "eps_w": noise["eps_w"][:, :7]})
+    with pytest.raises(ValueError, match="masks"):
+        layer.kl_div({**noise, "masks_r": noise["masks_r"][:1]})
+
+
+@pytest.mark.parametrize("kind", ["linear", "conv"])
+def test_flat_parameter_home_receives_the_gradients_in_place(amd, golden, kind):
+    """A layer whose parameters live in a train.FlatParameters buffer: the RNVP gradient kernels, mnf_mnf_linear_bwd and
+    mnf_mnf_kl_bwd ADD to the gradient slices in place (no per-parameter add_, no parameter concatenation).  Same
+    gradients as the same layer outside such a buffer, on the same draws; a second backward pass accumulates."""
+    from torch.profiler import ProfilerActivity, profile
+
+    if kind == "linear":
+        fx = golden("g14_mnf_linear_kl")
+        plain, noise = linear_layer(amd, fx, "l800")
+        homed, _ = linear_layer(amd, fx, "l800")
+        x = recipes.gaussian(77, 128, 800).abs().to(DEV)
+        fwd = lambda layer: layer.forward(x)
+    else:
+        fx = golden("g13_mnf_conv2d")
+        plain, noise = conv_layer(amd, fx, "c2")
+        homed, _ = conv_layer(amd, fx, "c2")
+        x = recipes.gaussian(78, 4, 20 * 12 * 12).reshape(4, 20, 12, 12).to(DEV)
+        fwd = lambda layer: layer.forward(x)
+    flat = amd.FlatParameters(homed)
+
+    def step(layer):
+        torch.manual_seed(5)
+        loss = fwd(layer).pow(2).mean() + 1e-3 * layer.kl_div(noise)
+        loss.backward()
+        return float(loss)
+
+    l0, l1 = step(plain), step(homed)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert all(p.grad is v for p, v in zip(flat.params, flat._grad_views))
+    for (n0, p0), (n1, p1) in zip(plain.named_parameters(), homed.named_parameters()):
+        assert n0 == n1
+        assert normwise_err(p1.grad.cpu().numpy(), p0.grad.cpu().numpy()) <= 2e-6, n0
+    once = flat.grad.clone()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step(homed)
+        torch.cuda.synchronize()
+    assert normwise_err(flat.grad.cpu().numpy(), 2 * once.cpu().numpy()) <= 2e-6
+    ops = {e.key: e.count for e in prof.key_averages()}
+    assert "aten::cat" not in ops or kind == "linear", ops.get("aten::cat")  # (MNFLinear.forward packs exp(W_log_var))
+    # autograd's own accumulation is left with the prologue (q0_mean, q0_log_var) and, for the convolution, the stock
+    # F.conv2d weights: the flows' 24 tensors and the KL term's 8-9 no longer pass through it
+    assert ops.get("aten::add_", 0) <= 8, ops.get("aten::add_")

@@ -296,3 +296,34 @@ def test_g13_mnf_conv2d(golden, tag):
     y, kl = g13_oracle(fx, tag)
     assert_parity(y, fx[f"{tag}.y"], what="MNFConv2d.forward")
     assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))
+
+
+# ------------------------------------------------------------------ G14: MNFLinear.kl_div
+G14_CASES = {"l800": (800, 50, 31), "l50": (50, 10, 32)}
+G14_KEYS = ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2")
+
+
+def g14_specs(tag, which, masks, dtype=torch.float32):
+    n_in, n_out, seed = G14_CASES[tag]
+    return [{"kind": "rnvp", "mask": torch.from_numpy(masks[i]).to(dtype),
+             "params": {k: v.to(dtype) for k, v in
+                        recipes.rnvp_params(1400 + seed + 10 * (which == "r") + i, n_in, 50).items()}}
+            for i in range(2)]
+
+
+def g14_oracle(fx, tag, dtype=torch.float32):
+    """The oracle's MNFLinear.kl_div on fixture G14's captured draws: (kl, parameter dict, z)."""
+    p = {k: torch.from_numpy(fx[f"{tag}.{k}"]).to(dtype) for k in G14_KEYS}
+    z, ldq = O.sample_z(p["q0_mean"], p["q0_log_var"], torch.from_numpy(fx[f"{tag}.eps_z"]).to(dtype),
+                            g14_specs(tag, "q", fx[f"{tag}.masks_q"], dtype))
+    kl = O.mnf_linear_kl(p, z, ldq, torch.from_numpy(fx[f"{tag}.eps_w"]).to(dtype),
+                         g14_specs(tag, "r", fx[f"{tag}.masks_r"], dtype))
+    return kl, p, z
+
+
+@pytest.mark.parametrize("tag", sorted(G14_CASES))
+def test_g14_mnf_linear_kl(golden, tag):
+    """Oracle vs the reference's MNFLinear.kl_div (layers/mnf_linear.py:66-90), every draw replayed."""
+    fx = golden("g14_mnf_linear_kl")
+    kl, _, _ = g14_oracle(fx, tag)
+    assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))

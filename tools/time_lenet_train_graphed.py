@@ -1,5 +1,6 @@
 """MNF-LeNet training step, eager vs replayed from a hipGraph (GraphedStep with torch.optim.Adam(capturable=True)):
-`python3 tools/time_lenet_train_graphed.py [batch] [steps]`."""
+`python3 tools/time_lenet_train_graphed.py [batch] [steps] [torch|fused]` (fused: FlatParameters + FusedAdam, one
+optimiser launch and one memset for zero_grad)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +15,11 @@ torch.manual_seed(0)
 net = nn.Sequential(amd.MNFConv2d(1, 20, 5), nn.ReLU(), nn.MaxPool2d(2), amd.MNFConv2d(20, 50, 5), nn.ReLU(),
                     nn.MaxPool2d(2), nn.Flatten(), amd.MNFLinear(800, 50), nn.ReLU(), amd.MNFLinear(50, 10),
                     nn.LogSoftmax(dim=-1)).to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+which = sys.argv[3] if len(sys.argv) > 3 else "fused"
+if which == "fused":
+    opt = amd.FusedAdam(amd.FlatParameters(net), lr=1e-3, capturable=True)
+else:
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
 x = torch.rand(batch, 1, 28, 28, device=dev)
 y = torch.randint(0, 10, (batch,), device=dev)
 
@@ -41,5 +46,5 @@ for _ in range(3): step(x, y)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): loss = step(x, y)
 torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / steps
-print(f"MNF-LeNet training step, batch {batch}: eager {t_eager * 1e3:.2f} ms, hipGraph replay {t_graph * 1e3:.2f} ms "
+print(f"MNF-LeNet training step, batch {batch}, {which} Adam: eager {t_eager * 1e3:.2f} ms, hipGraph replay {t_graph * 1e3:.2f} ms "
       f"({t_eager / t_graph:.1f} x), loss {float(loss):.4f}")

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 9  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 10  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -134,6 +134,11 @@ SIGNATURES = {
     "mnf_mnf_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),
+    "mnf_mnf_kl_saved_floats": (c_int64, [c_int64]),
+    "mnf_mnf_kl_grad_floats": (c_int64, [c_int]),
+    "mnf_mnf_kl_param_grad_floats": (c_int64, [c_int, c_int64, c_int, c_int]),
+    "mnf_mnf_kl_fwd": (c_int, [c_void_p] * 14 + [c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mnf_mnf_kl_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

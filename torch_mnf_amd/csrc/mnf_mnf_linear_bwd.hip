@@ -68,7 +68,6 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
     const int64_t tile = (int64_t)grp * 8 + wave;
     const int64_t row = tile * 16 + j;
     const bool live = row < rows;
-    const int64_t rc = live ? row : rows - 1;
     // the tile's 16 x n_out cotangents, sd and noise are contiguous in memory: read them coalesced, form g_m and g_v per
     // element, and turn them into the (row, 4 outputs per lane) layout through LDS (read per lane as 4-byte pieces with
     // a 200-byte row stride they took 0.55 ms per 256,000 rows)
@@ -460,7 +459,6 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
                       float var_unscale, const int32_t* fwd_flags, const float* gscale, void* work, int64_t rows, int n_in,
                       int n_out, int vec2, hipStream_t stream) {
   using S = MlBwdShape<YT>;
-  using H = HandoverShape<YT>;
   const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
   int32_t* list = static_cast<int32_t*>(work);
   int32_t* flags = list + 1 + n_groups;

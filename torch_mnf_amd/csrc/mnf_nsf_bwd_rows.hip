@@ -647,6 +647,9 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
   }
 
   // ------------------------------------------------------------------ flush: X waves hold the first net's sums, Y waves the second's
+#ifdef MNF_NSF_BWD_NOFLUSH  // (timing experiment: what the flush costs)
+  if (a.rows > 0) return;
+#endif
   if (a.grad_flat == nullptr) return;
   for (int w = 0; w < kNpPairs; ++w) {
     if (pair == w) {

@@ -134,6 +134,40 @@ def _flat_gen(module) -> int:
     return 0 if flat is None else flat.generation
 
 
+def _flat_home_of(module: nn.Module, params: list) -> tuple | None:
+    """(FlatParameters, offset, length) when ``params`` (the module's packed parameters, in order) are back-to-back
+    views of one train.FlatParameters buffer AND their ``.grad`` are still that object's gradient views -- the kernels
+    then read the slice (no concatenation) and ADD their gradients to the gradient slice in place (no per-parameter
+    ``add_``) -- else None.  The slice lookup is cached per FlatParameters object; what can change behind its back is
+    re-validated on every call (see _AffineRun.flat_home for the cases)."""
+    flat = module.__dict__.get("_mnf_flat")
+    if flat is None or not params:
+        return None
+    cache = module.__dict__.setdefault("_home_cache", {})
+    key = (id(params[0]), id(params[-1]), len(params))  # (a module may ask for several parameter lists)
+    cached = cache.get(key)
+    if cached is None or cached[0] is not flat or cached[1] is not params[0]:
+        sl = flat.slice_of(params)
+        i0 = next((i for i, q in enumerate(flat.params) if q is params[0]), None) if sl is not None else None
+        cached = cache[key] = (flat, params[0], sl, i0)
+    _, _, sl, i0 = cached
+    if sl is None or i0 is None or not flat.home_is_valid(params):
+        return None
+    views = flat._grad_views
+    if params[0].grad is not views[i0] or params[-1].grad is not views[i0 + len(params) - 1]:
+        return None
+    return flat, sl[0], sl[1]
+
+
+def _home_stand_in(module: nn.Module, device) -> Tensor:
+    """A one-element tensor that carries ``requires_grad`` through an autograd function whose parameters live in a
+    flat home (the function reads the parameter slice and adds to the gradient slice itself)."""
+    t = module.__dict__.get("_stand_in_t")
+    if t is None or t.device != device:
+        t = module.__dict__["_stand_in_t"] = torch.zeros(1, device=device, requires_grad=True)
+    return t
+
+
 def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -313,8 +347,11 @@ class _RnvpFn(torch.autograd.Function):
     """RNVP with gradients; the backward pass sees the same mask (explicit or regenerated from the seed)."""
 
     @staticmethod
-    def forward(ctx, z, flat_with_grad, module, mask, seed):
+    def forward(ctx, z, flat_with_grad, module, mask, seed, home=None):
+        # home = (FlatParameters, offset, length): flat_with_grad is a stand-in that only carries requires_grad; the
+        # kernels read the parameter slice and backward ADDS to the gradient slice in place
         flat, image = module._packed(z.device)
+        ctx.home = home
         x = torch.empty_like(z)
         ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
@@ -332,10 +369,14 @@ class _RnvpFn(torch.autograd.Function):
         gx = None if grad_x is None else grad_x.contiguous()
         gl = None if grad_ld is None else grad_ld.contiguous()
         grad_z = torch.empty_like(z)
-        grad_flat = torch.zeros_like(flat)
+        home = ctx.home
         lib = _lib.load()
         if gx is None and gl is None:
-            return grad_z.zero_(), grad_flat, None, None, None
+            return grad_z.zero_(), (None if home is not None else torch.zeros_like(flat)), None, None, None, None
+        if home is not None:
+            grad_flat, ret_flat = home[0].grad[home[1]:home[1] + home[2]], None
+        else:
+            grad_flat = ret_flat = torch.zeros_like(flat)
         # the matrix-core gradient kernels (two launches + the fp32 fix-up over flagged row groups); shapes they do not
         # cover, the fp32 switches and force_generic take the generic kernel
         # (few rows or a narrow layer: the one-launch generic kernel is the faster one -- the matrix-core pass is four
@@ -367,11 +408,11 @@ class _RnvpFn(torch.autograd.Function):
                     rc = go(12)
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_rnvp_bwd_mfma", rc)
-                return grad_z, grad_flat, None, None, None
+                return grad_z, ret_flat, None, None, None, None
         _lib.check("mnf_rnvp_bwd", lib.mnf_rnvp_bwd(
             z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
             flat.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
-        return grad_z, grad_flat, None, None, None
+        return grad_z, ret_flat, None, None, None, None
 
 
 class _AffineConstFn(torch.autograd.Function):
@@ -616,8 +657,12 @@ class _HipFlow(nn.Module):
             return None, None
         key = (device, _flat_gen(self), tuple((p.data_ptr(), p._version) for p in params))
         if key != self._cache_key:
-            flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
-            self._flat = flat.contiguous()
+            home = _flat_home_of(self, params) if params[0].device == device else None
+            if home is not None:  # the parameters ARE one buffer: a (new) view of it, no concatenation
+                self._flat = home[0].data[home[1]:home[1] + home[2]]
+            else:
+                flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
+                self._flat = flat.contiguous()
             self._device_index(device)
             if self._index is not None:
                 image = torch.empty(self._index.numel(), dtype=torch.float32, device=device)
@@ -1077,8 +1122,10 @@ class RNVP(_HipFlow):
         if want_grad and prologue is not None:
             return None
         if want_grad:
-            flat_g = torch.cat([p.reshape(-1) for p in self._packed_params()])
-            return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF)
+            params = self._packed_params()
+            home = _flat_home_of(self, params)
+            flat_g = _home_stand_in(self, z.device) if home is not None else torch.cat([p.reshape(-1) for p in params])
+            return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF, home)
         flat, image, split = self._packed3(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)

@@ -5,8 +5,8 @@
 (a stack of masked/gated ``RNVP`` layers) -- at MNF-LeNet's 512 images x 500 MC samples that is
 256,000 rows of 800 dims.  Both steps run in libmnf_hip.so, and so does what ``forward`` does with the
 result: the two products of the local reparametrisation and the noise epilogue are one
-launch that reads x and z once (``mnf_mnf_linear_fwd``).  The closed-form KL terms of ``kl_div`` are the
-reference's own formulas on device tensors (stock PyTorch-ROCm): a caller, not the path.
+launch that reads x and z once (``mnf_mnf_linear_fwd``).  ``kl_div`` runs both flows and then every closed-form
+term of the reference's formula in one launch each way (``mnf_mnf_kl_fwd`` / ``_bwd``).
 """
 from __future__ import annotations
 
@@ -50,6 +50,8 @@ class _MnfLinearFn(torch.autograd.Function):
         sd = torch.empty(xc.shape[0], module.n_out, dtype=torch.float32, device=x.device)
         out, work = _mnf_linear_forward(module, xc, zc, eps, seed, ops, sd)
         ctx.module, ctx.seed, ctx.var_unscale = module, seed, ops[2]
+        # the four parameters in one train.FlatParameters buffer: backward adds to their gradient slice in place
+        ctx.home = _flows._flat_home_of(module, [W_mean, W_log_var, b_mean, b_log_var])
         ctx.save_for_backward(xc, zc, sd, work, ops[0], *([eps] if eps is not None else []))
         return out
 
@@ -72,17 +74,116 @@ class _MnfLinearFn(torch.autograd.Function):
             _MNF_LINEAR_BWD_WORK[dev] = work
         scale = _flows._grad_scale(g, None, rows, m.n_out, dev)
         grad_x, grad_z = torch.empty_like(xc), torch.empty_like(zc)
-        grad_flat = torch.zeros_like(flat)
+        home = ctx.home
+        grad_flat = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros_like(flat)
         _lib.check("mnf_mnf_linear_bwd", lib.mnf_mnf_linear_bwd(
             xc.data_ptr(), zc.data_ptr(), g.data_ptr(), sd.data_ptr(), None if eps is None else eps.data_ptr(), ctx.seed,
             grad_x.data_ptr(), grad_z.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), image.data_ptr(), ctx.var_unscale,
             fwd_flags.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(), rows, m.n_in, m.n_out, _stream()))
+        if home is not None:
+            return grad_x, grad_z, None, None, None, None, None, None, None
         n = m.n_in * m.n_out
         gW_mean = grad_flat[:n].view(m.n_out, m.n_in)
         gW_log_var = grad_flat[n:2 * n].view(m.n_out, m.n_in)
         gb_mean = grad_flat[2 * n:2 * n + m.n_out]
         gb_log_var = grad_flat[2 * n + m.n_out:2 * n + 2 * m.n_out]
         return grad_x, grad_z, gW_mean, gW_log_var, gb_mean, gb_log_var, None, None, None
+
+
+def _flow_through(flow: NormalizingFlow, z: Tensor, masks):
+    """``flow.forward`` on a (1, n_out) row, with explicit masks when given: (last z, log_det (1,))."""
+    if masks is None:
+        zs, log_det = flow.forward(z)
+        return zs[-1], log_det
+    layers = list(flow.flows)
+    if len(masks) != len(layers):
+        raise ValueError(f"got {len(masks)} masks for {len(layers)} flow layers")
+    log_det = torch.zeros(z.shape[0], device=z.device)
+    for layer, m in zip(layers, masks):
+        if _wants_grad(layer, z):
+            z, ld = layer._run(z, False, None, m)
+            log_det = log_det + ld
+        else:
+            z, _ = layer._run(z, False, log_det, m)
+    return z, log_det
+
+
+class _MnfKlFn(torch.autograd.Function):
+    """``kl_div`` of either MNF layer behind its flows (mnf_linear.py:66-90, mnf_conv.py:100-133): one launch forward
+    (``mnf_mnf_kl_fwd``) and one backward (``mnf_mnf_kl_bwd``) instead of ~70 + ~100 elementwise kernels.  The random
+    draws (``eps``, ``eps_b``) and both flows' outputs are inputs; see include/mnf_hip.h for the (rows, cols) view.
+    ``params``: the layer's own parameters in registration order (W_mean, W_log_var, [b_mean,] b_log_var, q0_mean,
+    q0_log_var, r0_c, r0_b1, r0_b2) -- also the layout of the kernel's parameter gradients, so that a layer living in a
+    train.FlatParameters buffer has them added to its gradient slice in place."""
+
+    @staticmethod
+    def forward(ctx, z, log_det_q, z_r, log_det_r, eps, eps_b, module, conv, b_mean, *params):
+        W_mean, W_log_var = params[0], params[1]
+        if conv:
+            b_log_var, _, q0_log_var, r0_c, r0_b1, r0_b2 = params[2:]
+        else:
+            b_mean, b_log_var, _, q0_log_var, r0_c, r0_b1, r0_b2 = params[2:]
+        dev = W_mean.device
+        if dev.type != "cuda":
+            raise MnfHipError("mnf_mnf_kl_fwd", _lib.MNF_ERR_NO_DEVICE,
+                              "kl_div runs in libmnf_hip.so: the layer must live on a HIP device")
+        cols = r0_c.numel()
+        rows = W_mean.numel() // cols
+        n_bias = b_log_var.numel()
+
+        def f32(t, n, name):
+            if t is None:
+                return None
+            if t.device != dev or t.numel() != n:
+                raise ValueError(f"kl_div: {name} must hold {n} elements on {dev}, got {tuple(t.shape)} on {t.device}")
+            return t.detach().to(torch.float32).contiguous()
+
+        ops = [f32(W_mean, rows * cols, "W_mean"), f32(W_log_var, rows * cols, "W_log_var"),
+               f32(eps, rows if conv else rows * cols, "eps"), f32(eps_b, 1, "eps_b") if conv else None,
+               f32(z, cols, "z"), f32(z_r, cols, "flow_r's output"), f32(log_det_q, 1, "log_det_q"),
+               f32(log_det_r, 1, "log_det_r"), f32(b_mean, n_bias, "b_mean"), f32(b_log_var, n_bias, "b_log_var"),
+               f32(q0_log_var, cols, "q0_log_var"), f32(r0_c, cols, "r0_c"), f32(r0_b1, cols, "r0_b1"),
+               f32(r0_b2, cols, "r0_b2")]
+        lib = _lib.load()
+        out = torch.empty((), device=dev)
+        saved = torch.empty(lib.mnf_mnf_kl_saved_floats(rows), device=dev)
+        ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        _lib.check("mnf_mnf_kl_fwd", lib.mnf_mnf_kl_fwd(*[ptr(t) for t in ops], int(conv), rows, cols, n_bias,
+                                                       out.data_ptr(), saved.data_ptr(), _stream()))
+        ctx.ops, ctx.saved_acts, ctx.shape = ops, saved, (int(conv), rows, cols, n_bias)
+        ctx.like = (z, log_det_q, z_r, log_det_r)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.home = _flows._flat_home_of(module, list(params)) if all(p.requires_grad for p in params) else None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        conv, rows, cols, n_bias = ctx.shape
+        W_mean, W_log_var, eps, eps_b, z, z_r, _, _, b_mean, b_log_var, _, c, b1, b2 = ctx.ops
+        z_in, ldq_in, zr_in, ldr_in = ctx.like
+        lib = _lib.load()
+        dev = W_mean.device
+        grads = torch.empty(lib.mnf_mnf_kl_grad_floats(cols), device=dev)
+        n_param = lib.mnf_mnf_kl_param_grad_floats(conv, rows, cols, n_bias)
+        home = ctx.home
+        if home is not None and home[2] != n_param:
+            raise MnfHipError("mnf_mnf_kl_bwd", _lib.MNF_ERR_INVALID_ARG,
+                              f"the layer's parameter slice holds {home[2]} floats, the kernel writes {n_param}")
+        pg = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.empty(n_param, device=dev)
+        g = grad_out.detach().to(torch.float32).contiguous()
+        ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        _lib.check("mnf_mnf_kl_bwd", lib.mnf_mnf_kl_bwd(
+            *[ptr(t) for t in (W_mean, W_log_var, eps, eps_b, z, z_r, b_mean, b_log_var, c, b1, b2)],
+            ctx.saved_acts.data_ptr(), g.data_ptr(), conv, rows, cols, n_bias, grads.data_ptr(), pg.data_ptr(),
+            int(home is not None), _stream()))
+        gz, gzr, gldq, gldr = torch.split(grads, [cols, cols, 1, 1])
+        head = (gz.view_as(z_in), gldq.view_as(ldq_in), gzr.view_as(zr_in), gldr.view_as(ldr_in), None, None, None, None,
+                None)
+        if home is not None:
+            return head + (None,) * len(ctx.param_shapes)
+        sizes = [math.prod(sh) for sh in ctx.param_shapes]
+        return head + tuple(t.view(sh) for t, sh in zip(torch.split(pg, sizes), ctx.param_shapes))
 
 
 class MNFLinear(nn.Module):
@@ -260,7 +361,11 @@ class MNFLinear(nn.Module):
             raise MnfHipError("mnf_mnf_linear_fwd", _lib.MNF_ERR_UNSUPPORTED,
                               f"MNFLinear.forward has kernels for n_out <= 64 only (got {self.n_out})")
         seed = 0
-        if eps is None:
+        if eps is None and _flows._DEVICE_MASKS:
+            # a step being recorded in a hipGraph (train.GraphedStep): a host-drawn seed would be frozen into the
+            # kernel arguments and every replay would add the same noise; torch.randn is redrawn by every replay
+            eps = torch.randn(x.shape[0], self.n_out, device=x.device)
+        elif eps is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
         else:
             eps = eps.detach().to(x.device, torch.float32).contiguous()
@@ -268,10 +373,6 @@ class MNFLinear(nn.Module):
                 raise ValueError(f"eps must be {(x.shape[0], self.n_out)}, got {tuple(eps.shape)}")
         params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
         training = torch.is_grad_enabled() and (x.requires_grad or z.requires_grad or any(p.requires_grad for p in params))
-        if training and os.environ.get("MNF_DEBUG_LINEAR_TORCH") == "1":  # (bisecting aid, not a product path)
-            mean = (x * z) @ self.W_mean.T + self.b_mean
-            var = x.pow(2) @ self.W_log_var.exp().T + self.b_log_var.exp()
-            return mean + var.sqrt() * torch.randn_like(var)
         if training:
             return _MnfLinearFn.apply(x, z, *params, self, eps, seed)
         return _mnf_linear_forward(self, x.detach().contiguous(), z.detach().contiguous(), eps, seed, ops, None)[0]
@@ -289,23 +390,22 @@ class MNFLinear(nn.Module):
                 int(seed) & 0xFFFFFFFFFFFFFFFF, e.data_ptr(), rows, self.n_out, _stream()))
         return e
 
-    # ------------------------------------------------------------------ caller (stock PyTorch-ROCm)
-
-    def kl_div(self) -> Tensor:  # mnf_linear.py:66-90
-        z, log_det_q = self.sample_z()
-        W_mean = z * self.W_mean
-        W_var = self.W_log_var.exp()
-        weight = W_mean + W_var.sqrt() * torch.randn_like(W_var)
-        kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean.pow(2) - 1)
-        kl_b = 0.5 * torch.sum(-self.b_log_var + self.b_log_var.exp() + self.b_mean.pow(2) - 1)
-        log_q = -log_det_q - 0.5 * self.q0_log_var.sum()
-        act = torch.tanh(self.r0_c @ weight.T)
-        mean_r = torch.outer(self.r0_b1, act).mean(1)       # eq. (9)
-        log_var_r = torch.outer(self.r0_b2, act).mean(1)    # eq. (10)
-        zs, log_det_r = self.flow_r.forward(z)
-        (log_det_r,) = log_det_r                            # relies on shape (1,), as the reference does
-        log_r = log_det_r + 0.5 * torch.sum(-log_var_r.exp() * (zs[-1] - mean_r).pow(2) + log_var_r)
-        return kl_W + kl_b + log_q - log_r
+    # ------------------------------------------------------------------ the KL term behind both flows
+    def kl_div(self, noise: dict | None = None) -> Tensor:
+        """(mnf_linear.py:66-90): ``sample_z()`` through flow_q, the same z through flow_r, and every closed-form term
+        in one launch (``mnf_mnf_kl_fwd``; gradients: ``mnf_mnf_kl_bwd``).  ``noise``: optional injected draws
+        {"eps_z" (1, n_in), "masks_q", "eps_w" (n_out, n_in), "masks_r"}; by default all are drawn on the device."""
+        noise = noise or {}
+        z, log_det_q = self.sample_z(1, noise.get("eps_z"), noise.get("masks_q"))
+        z_r, log_det_r = _flow_through(self.flow_r, z, noise.get("masks_r"))
+        eps_w = noise.get("eps_w")
+        if eps_w is None:
+            eps_w = torch.randn_like(self.W_log_var)
+        if log_det_r.numel() != 1:  # the reference unpacks `[log_det_r]` (:84)
+            raise ValueError(f"kl_div: flow_r returned {log_det_r.numel()} log-determinants for one row")
+        return _MnfKlFn.apply(z, log_det_q, z_r, log_det_r, eps_w, None, self, False, None, self.W_mean, self.W_log_var,
+                              self.b_mean, self.b_log_var, self.q0_mean, self.q0_log_var, self.r0_c, self.r0_b1,
+                              self.r0_b2)
 
 
 class MNFConv2d(nn.Module):
@@ -341,24 +441,6 @@ class MNFConv2d(nn.Module):
         self.b_mean = fn(self.b_mean)
         return self
 
-    @staticmethod
-    def _through(flow: NormalizingFlow, z: Tensor, masks):
-        """``flow.forward`` on a (1, n_out) row, with explicit masks when given: (last z, log_det (1,))."""
-        if masks is None:
-            zs, log_det = flow.forward(z)
-            return zs[-1], log_det
-        layers = list(flow.flows)
-        if len(masks) != len(layers):
-            raise ValueError(f"got {len(masks)} masks for {len(layers)} flow layers")
-        log_det = torch.zeros(z.shape[0], device=z.device)
-        for layer, m in zip(layers, masks):
-            if _wants_grad(layer, z):
-                z, ld = layer._run(z, False, None, m)
-                log_det = log_det + ld
-            else:
-                z, _ = layer._run(z, False, log_det, m)
-        return z, log_det
-
     # ------------------------------------------------------------------ hot path (the flow)
     def sample_z(self, eps_z: Tensor | None = None, masks=None) -> tuple[Tensor, Tensor]:
         """(mnf_conv.py:90-98): z (1, n_out) and log|det J| (scalar) of flow_q at z0 = q0_mean + q0_std eps."""
@@ -366,7 +448,7 @@ class MNFConv2d(nn.Module):
         if eps_z is None:
             eps_z = torch.randn_like(q0_std)
         z0 = self.q0_mean + q0_std * eps_z.to(q0_std.device)
-        z, log_det = self._through(self.flow_q, z0[None, :].contiguous(), masks)
+        z, log_det = _flow_through(self.flow_q, z0[None, :].contiguous(), masks)
         return z, log_det.squeeze()
 
     # ------------------------------------------------------------------ caller (stock PyTorch-ROCm)
@@ -378,27 +460,19 @@ class MNFConv2d(nn.Module):
         return mean + var.sqrt() * (torch.randn_like(var) if eps is None else eps)
 
     def kl_div(self, noise: dict | None = None) -> Tensor:
-        """(mnf_conv.py:100-133).  ``noise``: optional injected draws {"eps_z", "masks_q", "eps_w", "eps_b", "masks_r"}."""
+        """(mnf_conv.py:100-133): both flows, then every closed-form term in one launch (``mnf_mnf_kl_fwd``).
+        ``noise``: optional injected draws {"eps_z", "masks_q", "eps_w", "eps_b", "masks_r"}."""
         noise = noise or {}
         z, log_det_q = self.sample_z(noise.get("eps_z"), noise.get("masks_q"))
-        W_var = self.W_log_var.exp()
-        b_var = self.b_log_var.exp()
-        W_mean = self.W_mean * z.view(-1, 1, 1, 1)
-        b_mean = self.b_mean * z
-        kl_W = 0.5 * torch.sum(-W_var.log() + W_var + W_mean.pow(2) - 1)
-        kl_b = 0.5 * torch.sum(-b_var.log() + b_var + b_mean.pow(2) - 1)
-        log_q = -log_det_q - 0.5 * self.q0_log_var.sum()
-        n = self.r0_c.numel()
-        wm = W_mean.view(-1, n) @ self.r0_c                 # eq. (11)
-        ws = W_var.sqrt().view(-1, n) @ self.r0_c           # eq. (12)
-        eps_w = noise.get("eps_w")
-        act = wm + ws * (torch.randn_like(ws) if eps_w is None else eps_w.to(ws.device))  # (linear: no tanh, :119-123)
-        eps_b = noise.get("eps_b")
-        act = act + torch.sum(b_mean * self.r0_c) + torch.sum(b_var * self.r0_c.pow(2)).sqrt() * (
-            torch.randn([], device=ws.device) if eps_b is None else eps_b.to(ws.device))
-        mean_r = torch.outer(self.r0_b1, act).mean(1)
-        log_var_r = torch.outer(self.r0_b2, act).mean(1)
-        z_r, log_det_r = self._through(self.flow_r, z, noise.get("masks_r"))
-        (log_det_r,) = log_det_r                            # relies on shape (1,), as the reference does
-        log_r = log_det_r + 0.5 * torch.sum(-log_var_r.exp() * (z_r - mean_r).pow(2) + log_var_r)
-        return kl_W + kl_b + log_q - log_r
+        z_r, log_det_r = _flow_through(self.flow_r, z, noise.get("masks_r"))
+        dev = self.W_mean.device
+        rows = self.W_mean.numel() // self.n_out
+        eps_w, eps_b = noise.get("eps_w"), noise.get("eps_b")
+        eps_w = torch.randn(rows, device=dev) if eps_w is None else eps_w.to(dev)
+        eps_b = torch.randn(1, device=dev) if eps_b is None else eps_b.to(dev).reshape(1)
+        if log_det_r.numel() != 1:  # the reference unpacks `[log_det_r]` (:127)
+            raise ValueError(f"kl_div: flow_r returned {log_det_r.numel()} log-determinants for one row")
+        b_mean = self.b_mean if self.b_mean.device == dev else self.b_mean.to(dev)
+        return _MnfKlFn.apply(z, log_det_q, z_r, log_det_r, eps_w, eps_b, self, True, b_mean, self.W_mean,
+                              self.W_log_var, self.b_log_var, self.q0_mean, self.q0_log_var, self.r0_c, self.r0_b1,
+                              self.r0_b2)
