@@ -214,6 +214,13 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
+/* Up to MNF_RNVP_FEW_ROWS rows through a layer with ONE hidden layer (what the MNF layers' kl_div and MNFConv2d's
+ * sample_z run: one row per call, mnf_linear.py:67/84, mnf_conv.py:90-101/127) take a latency kernel instead -- one
+ * workgroup, weight reads coalesced, and in mnf_rnvp_bwd no atomics -- when `flat` is given and force_generic is 0
+ * (1 row of 800 dims: 86 -> ~5 us forward, 150 -> ~10 us backward).  MNF_RNVP_FEW=0 in the environment switches it off. */
+#define MNF_RNVP_FEW_ROWS 2
+/* 1 when mnf_rnvp_seeded / mnf_rnvp_bwd take that kernel for this shape (the caller then needs no operand images). */
+int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host);
 /* MNFLinear.sample_z's prologue fused into its first flow (torch_mnf/layers/mnf_linear.py:58-64):
  * x = RNVP(q0_mean + sqrt(exp(q0_log_var)) * eps); z0 is formed in the kernel's loads and never stored.
  * mask == NULL: in-kernel mask from `seed`.  Needs image and split_image (split MFMA kernel) and dim <= 1024;
@@ -262,6 +269,10 @@ int mnf_gauss_logprob_sq(const float* z_sqnorm, const float* log_det, float* log
 /* z0 = q0_mean + exp(q0_log_var)^(1/2) * eps   (rows, dim); mean, log_var: (dim,). */
 int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* eps, float* z0,
                   int64_t rows, int dim, void* stream);
+/* Gradients of that prologue: grad_mean[j] += sum_r grad_z0[r][j];  grad_log_var[j] += sum_r grad_z0[r][j] eps[r][j] *
+ * 0.5 sqrt(exp(q0_log_var[j])).  Both outputs (dim floats each) are ADDED to. */
+int mnf_sample_z0_bwd(const float* grad_z0, const float* eps, const float* q0_log_var, float* grad_mean,
+                      float* grad_log_var, int64_t rows, int dim, void* stream);
 
 /* ------------------------------------------------------------------ training: one optimizer launch
  * torch.optim.Adam's update (no amsgrad; weight_decay as L2 on the gradient) over ONE flat buffer: param, grad and

@@ -112,6 +112,7 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_adam_step_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                     c_float, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
@@ -134,6 +135,7 @@ SIGNATURES = {
     "mnf_mnf_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),
+    "mnf_rnvp_few_rows_ok": (c_int, [c_int64, c_int, c_int, _intp]),
     "mnf_mnf_kl_saved_floats": (c_int64, [c_int64]),
     "mnf_mnf_kl_grad_floats": (c_int64, [c_int]),
     "mnf_mnf_kl_param_grad_floats": (c_int64, [c_int, c_int64, c_int, c_int]),

@@ -1027,6 +1027,9 @@ extern "C" {
 int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
                  float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
                  const int* hidden, void* stream) {
+  if (z && grad_z && flat && hidden && mnf::rnvp_few_ok(rows, dim, n_hidden, hidden))
+    return mnf::rnvp_few_bwd_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, hidden[0],
+                                    (hipStream_t)stream);
   return mnf::rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
                                       nullptr, 0, (hipStream_t)stream);
 }

@@ -589,6 +589,40 @@ __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __
   }
 }
 
+// gradients of the prologue: d mean[j] = sum_r g[r][j];  d log_var[j] = sum_r g[r][j] eps[r][j] * 0.5 sqrt(exp(log_var[j])).
+// blockDim = (64 dims, 4 row lanes); a workgroup takes 64 dims and the rows blockIdx.y, blockIdx.y + gridDim.y, ... in
+// steps of 4, sums in registers, then over its 4 row lanes in LDS, and adds one value per dim to the outputs.
+__global__ void __launch_bounds__(256) sample_z0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ eps,
+                                                            const float* __restrict__ log_var,
+                                                            float* __restrict__ g_mean, float* __restrict__ g_log_var,
+                                                            int64_t rows, int dim, int atomic) {
+  __shared__ float part[2][4][64];
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  float sm = 0.f, sv = 0.f;
+  if (j < dim) {
+    for (int64_t r = (int64_t)blockIdx.y * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.y * 4) {
+      const float gv = g[r * dim + j];
+      sm += gv;
+      sv = fmaf(gv, eps[r * dim + j], sv);
+    }
+  }
+  part[0][threadIdx.y][threadIdx.x] = sm;
+  part[1][threadIdx.y][threadIdx.x] = sv;
+  __syncthreads();
+  if (threadIdx.y == 0 && j < dim) {
+    sm = (part[0][0][threadIdx.x] + part[0][1][threadIdx.x]) + (part[0][2][threadIdx.x] + part[0][3][threadIdx.x]);
+    sv = (part[1][0][threadIdx.x] + part[1][1][threadIdx.x]) + (part[1][2][threadIdx.x] + part[1][3][threadIdx.x]);
+    sv *= 0.5f * sqrtf(expf(log_var[j]));
+    if (atomic) {
+      atomicAdd(g_mean + j, sm);
+      atomicAdd(g_log_var + j, sv);
+    } else {  // one workgroup per dim block: plain adds, results repeat bit for bit
+      g_mean[j] += sm;
+      g_log_var[j] += sv;
+    }
+  }
+}
+
 // blockIdx.y = image number: the k-th image is gathered from flat + k * flat_stride (layers of one shape whose
 // parameters sit back to back share the index table)
 __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
@@ -628,8 +662,11 @@ __global__ void pack_gather_split_kernel(const float* __restrict__ flat, const i
     const int32_t e = idx[2 * n_split + (w - n_split)];
     image[w] = __builtin_bit_cast(uint32_t, e >= 0 ? flat[e] : (e == kPackBigBias ? kPackBigBiasValue : 0.f));
   }
-  // non-negative floats order like their bit patterns
-  if (mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));
+  // one atomic per wave (every thread doing its own serialised on the one address: 17 us for a 100 k-word image, of
+  // which the gather itself is 3); non-negative floats order like their bit patterns
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));
 }
 
 }  // namespace mnf
@@ -1034,6 +1071,8 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
       (!flat && !image))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
+  if (flat && !force_generic && rnvp_few_ok(rows, dim, n_hidden, hidden))  // a handful of rows: the latency kernel
+    return rnvp_few_fwd_launch(z, mask, seed, x, log_det, accumulate, flat, rows, dim, hidden[0], (hipStream_t)stream);
   if (image && !force_generic) {
     const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, split_image, rows, dim, n_hidden, hidden,
                                     seed, (hipStream_t)stream);
@@ -1142,6 +1181,19 @@ int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* ep
   const int64_t n = rows * dim;
   hipLaunchKernelGGL(sample_z0_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, q0_mean,
                      q0_log_var, eps, z0, n, dim);
+  return check_launch();
+}
+
+int mnf_sample_z0_bwd(const float* grad_z0, const float* eps, const float* q0_log_var, float* grad_mean,
+                      float* grad_log_var, int64_t rows, int dim, void* stream) {
+  if (!grad_z0 || !eps || !q0_log_var || !grad_mean || !grad_log_var || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  // enough workgroups to fill the chip once rows x dim is large; a single row block (no atomics) while it is small
+  const int dim_blocks = (dim + 63) / 64;
+  int64_t row_blocks = (rows * dim) / (64 * 1024);
+  row_blocks = row_blocks < 1 ? 1 : row_blocks > 2048 / dim_blocks + 1 ? 2048 / dim_blocks + 1 : row_blocks;
+  hipLaunchKernelGGL(sample_z0_bwd_kernel, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
+                     grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0);
   return check_launch();
 }
 

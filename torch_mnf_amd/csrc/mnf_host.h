@@ -126,6 +126,15 @@ int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulat
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
                          const float* q0_log_var, int vec, hipStream_t stream);
 
+// RNVP on <= MNF_RNVP_FEW_ROWS rows with one hidden layer (mnf_rnvp_few.hip): one workgroup, no atomics.  `flat` is the
+// layer's plain parameter buffer (the state_dict order of mnf_rnvp); gradients are ADDED to grad_flat.
+bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden);
+int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
+                        const float* flat, int64_t rows, int dim, int hid, hipStream_t stream);
+int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                        float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int hid,
+                        hipStream_t stream);
+
 // one 32-bit word := 0 on the stream, as a KERNEL node (mnf_generic.hip).  A 4-byte hipMemsetAsync in front of a kernel
 // that counts into the word was fine eagerly but, recorded in a hipGraph, faulted after ~100 replays of the MNF-LeNet
 // training step (memory access fault; the same step with these resets as kernels replays cleanly).

@@ -350,13 +350,14 @@ class _RnvpFn(torch.autograd.Function):
     def forward(ctx, z, flat_with_grad, module, mask, seed, home=None):
         # home = (FlatParameters, offset, length): flat_with_grad is a stand-in that only carries requires_grad; the
         # kernels read the parameter slice and backward ADDS to the gradient slice in place
-        flat, image = module._packed(z.device)
+        few = module._few(z.shape[0])
+        flat, image = module._packed(z.device, images=not few)
         ctx.home = home
         x = torch.empty_like(z)
         ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
             z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image),
-            _ptr(module._split_image(z.device)), z.shape[0],
+            None if few else _ptr(module._split_image(z.device)), z.shape[0],
             module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _stream()))
         ctx.module, ctx.seed, ctx.mask = module, seed, mask
         ctx.save_for_backward(z, flat)
@@ -651,7 +652,10 @@ class _HipFlow(nn.Module):
                 torch.frombuffer(host[0], dtype=torch.int32).clone().to(device), host[1], host[2])
         return self._split_index
 
-    def _packed(self, device: torch.device) -> tuple[Tensor | None, Tensor | None]:
+    def _packed(self, device: torch.device, images: bool = True) -> tuple[Tensor | None, Tensor | None]:
+        """(flat parameters, fp32 operand image) for the current parameter values.  ``images=False``: the caller's
+        kernel reads ``flat`` only (RNVP on one or two rows) -- the operand images are then not packed (two launches
+        per layer per weight update saved: an MNF layer's flow_r never sees more than one row)."""
         params = self._packed_params()
         if not params:
             return None, None
@@ -663,6 +667,12 @@ class _HipFlow(nn.Module):
             else:
                 flat = torch.cat([p.detach().reshape(-1) for p in params]).to(device=device, dtype=torch.float32)
                 self._flat = flat.contiguous()
+            self._image = self._split = None
+            self.__dict__["_images_key"] = None
+            self._cache_key = key
+        elif _CHECK_PARAMS_EVERY:
+            _check_params_fresh(params, self._flat, type(self).__name__)
+        if images and self.__dict__.get("_images_key") != key:
             self._device_index(device)
             if self._index is not None:
                 image = torch.empty(self._index.numel(), dtype=torch.float32, device=device)
@@ -681,9 +691,7 @@ class _HipFlow(nn.Module):
                 self._split = split
             else:
                 self._split = None
-            self._cache_key = key
-        elif _CHECK_PARAMS_EVERY:
-            _check_params_fresh(params, self._flat, type(self).__name__)
+            self.__dict__["_images_key"] = key
         return self._flat, self._image
 
     # out-of-place layer on raw buffers; accum: (rows,) tensor receiving ``+= log_det`` or None
@@ -1091,6 +1099,17 @@ class RNVP(_HipFlow):
             _RNVP_BWD_WORK[device] = work
         return work
 
+    def _few(self, rows: int) -> bool:
+        """Does the library run this many rows on the few-rows kernels (mnf_rnvp_few.hip)?  They read the plain
+        parameter buffer: no operand image is needed then."""
+        if self.force_generic:
+            return False
+        cache = self.__dict__.setdefault("_few_cache", {})
+        ok = cache.get(rows)
+        if ok is None:
+            ok = cache[rows] = bool(_lib.load().mnf_rnvp_few_rows_ok(rows, self.dim, len(self.h_sizes), self._hid))
+        return ok
+
     def mask_for(self, seed: int, rows: int, device="cuda") -> Tensor:
         m = torch.empty(rows, self.dim, dtype=torch.float32, device=device)
         if rows:
@@ -1126,7 +1145,10 @@ class RNVP(_HipFlow):
             home = _flat_home_of(self, params)
             flat_g = _home_stand_in(self, z.device) if home is not None else torch.cat([p.reshape(-1) for p in params])
             return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF, home)
-        flat, image, split = self._packed3(z.device)
+        if prologue is None and self._few(z.shape[0]):
+            flat, image, split = self._packed(z.device, images=False)[0], None, None
+        else:
+            flat, image, split = self._packed3(z.device)
         x = torch.empty_like(z)
         ld = accum if accum is not None else torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         if prologue is not None:

@@ -108,6 +108,35 @@ def _flow_through(flow: NormalizingFlow, z: Tensor, masks):
     return z, log_det
 
 
+class _SampleZ0Fn(torch.autograd.Function):
+    """z0 = q0_mean + sqrt(exp(q0_log_var)) * eps (mnf_linear.py:59-62, mnf_conv.py:91-93) with its two parameter
+    gradients from the library: one launch each way instead of four elementwise kernels forward and ~eight backward."""
+
+    @staticmethod
+    def forward(ctx, q0_mean, q0_log_var, eps, module):
+        mean, log_var = q0_mean.detach().contiguous(), q0_log_var.detach().contiguous()
+        z0 = torch.empty_like(eps)
+        _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
+            mean.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z0.data_ptr(), eps.shape[0], eps.shape[1], _stream()))
+        ctx.save_for_backward(eps, log_var)
+        ctx.home = _flows._flat_home_of(module, [q0_mean, q0_log_var])
+        return z0
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_z0):
+        eps, log_var = ctx.saved_tensors
+        dim, home = eps.shape[1], ctx.home
+        out = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros(2 * dim, device=eps.device)
+        g = grad_z0.contiguous()
+        _lib.check("mnf_sample_z0_bwd", _lib.load().mnf_sample_z0_bwd(
+            g.data_ptr(), eps.data_ptr(), log_var.data_ptr(), out.data_ptr(), out.data_ptr() + 4 * dim, eps.shape[0], dim,
+            _stream()))
+        if home is not None:
+            return None, None, None, None
+        return out[:dim], out[dim:], None, None
+
+
 class _MnfKlFn(torch.autograd.Function):
     """``kl_div`` of either MNF layer behind its flows (mnf_linear.py:66-90, mnf_conv.py:100-133): one launch forward
     (``mnf_mnf_kl_fwd``) and one backward (``mnf_mnf_kl_bwd``) instead of ~70 + ~100 elementwise kernels.  The random
@@ -245,8 +274,7 @@ class MNFLinear(nn.Module):
                     z, _ = flow._run(z, False, log_det, m)
                 return z, log_det.squeeze()
         if training:
-            # training: the two-parameter prologue stays on autograd (it is O(rows*n_in) elementwise)
-            z0 = self.q0_mean + self.q0_log_var.exp().sqrt() * eps
+            z0 = _SampleZ0Fn.apply(self.q0_mean, self.q0_log_var, eps, self)
         else:
             z0 = torch.empty_like(eps)
             if eps.shape[0] > 0:
@@ -444,11 +472,13 @@ class MNFConv2d(nn.Module):
     # ------------------------------------------------------------------ hot path (the flow)
     def sample_z(self, eps_z: Tensor | None = None, masks=None) -> tuple[Tensor, Tensor]:
         """(mnf_conv.py:90-98): z (1, n_out) and log|det J| (scalar) of flow_q at z0 = q0_mean + q0_std eps."""
-        q0_std = self.q0_log_var.exp().sqrt()
-        if eps_z is None:
-            eps_z = torch.randn_like(q0_std)
-        z0 = self.q0_mean + q0_std * eps_z.to(q0_std.device)
-        z, log_det = _flow_through(self.flow_q, z0[None, :].contiguous(), masks)
+        dev = self.q0_mean.device
+        eps_z = torch.randn(1, self.n_out, device=dev) if eps_z is None else \
+            eps_z.to(dev, torch.float32).reshape(1, self.n_out).contiguous()
+        if dev.type != "cuda":
+            raise RuntimeError(f"torch_mnf_amd: input must be a GPU tensor (got {dev.type}); the HIP path has no CPU fallback")
+        z0 = _SampleZ0Fn.apply(self.q0_mean, self.q0_log_var, eps_z, self)
+        z, log_det = _flow_through(self.flow_q, z0, masks)
         return z, log_det.squeeze()
 
     # ------------------------------------------------------------------ caller (stock PyTorch-ROCm)
