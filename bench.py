@@ -45,6 +45,9 @@ WORKLOADS = {
     "c5t": (800, 512 * 500, "training step of MNFLinear(800,50) on 512x500 MC rows: sample_z (2xRNVP d=800 h=50), forward, "
                             "mean-square loss, backward, Adam (BASELINE configs[4]'s caller under loss.backward(): what "
                             "tests/test_mnf_mnist.py:14-56 trains through)"),
+    "lenet": (784, 128, "training step of MNF-LeNet (MNFConv2d(1,20,5), MNFConv2d(20,50,5), MNFLinear(800,50), "
+                        "MNFLinear(50,10)) on a batch of 128 28x28 images: kl_div of the four layers + NLL, backward, Adam "
+                        "(what tests/test_mnf_mnist.py:14-56 does per batch), replayed from one hipGraph"),
     "c3t": (32, 1 << 20, "training step of 3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20: -mean log-prob, backward, "
                          "Adam (SURVEY 8f rank 1 for BASELINE configs[2]'s model; tests/test_flows.py:89-99 trains it)"),
 }
@@ -565,6 +568,75 @@ def main_train_c5(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
+def main_lenet(args, rank, world, device, dim, rows, desc) -> None:
+    """The MNF example model's training step at the reference's batch size (128): a launch-bound step -- 291 launches
+    of a few microseconds each -- recorded once in a hipGraph (train.GraphedStep) and replayed.  What the library
+    contributes: kl_div as one launch each way per layer, the one-row flows on the latency kernels, every parameter
+    gradient added in place to one buffer, one Adam launch.  The convolutions are stock MIOpen."""
+    if world != 1:
+        raise SystemExit("--workload lenet measures one GPU")
+    from torch import nn
+
+    import torch_mnf_amd as amd
+
+    torch.manual_seed(0)
+    net = nn.Sequential(amd.MNFConv2d(1, 20, 5), nn.ReLU(), nn.MaxPool2d(2), amd.MNFConv2d(20, 50, 5), nn.ReLU(),
+                        nn.MaxPool2d(2), nn.Flatten(), amd.MNFLinear(800, 50), nn.ReLU(), amd.MNFLinear(50, 10),
+                        nn.LogSoftmax(dim=-1)).to(device)
+    opt = amd.FusedAdam(amd.FlatParameters(net), lr=1e-3, capturable=True)
+    gen = torch.Generator(device=device).manual_seed(1357)
+    x = torch.rand(rows, 1, 28, 28, device=device, generator=gen)
+    y = torch.randint(0, 10, (rows,), device=device, generator=gen)
+
+    def loss_fn(xb, yb):
+        kl = sum(m.kl_div() for m in net if hasattr(m, "kl_div"))
+        return nn.functional.nll_loss(net(xb), yb) + kl / 60000
+
+    def eager():
+        opt.zero_grad()
+        loss = loss_fn(x, y)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    first_loss = eager()
+    for _ in range(2):
+        eager()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        opt.zero_grad()
+        loss_fn(x, y).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / 10 * 1e3
+    step = amd.GraphedStep(opt, loss_fn, (x, y), model=net)
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        step(x, y)
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(x, y)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": f"images/s, {desc}", "value": rows * args.steps / elapsed, "unit": "images/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "batch": rows, "optimizer": "FusedAdam over FlatParameters (one buffer, one launch)",
+                   "execution": "one hipGraph replay per step", "primed_ms": args.prime_ms},
+        "eager_ms_per_step": eager_ms, "loss_first_step": first_loss, "loss_last_step": float(loss),
+        "distributed": dist_info(1, "nccl", [elapsed], args.steps),
+        "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "kernel": "(launch-bound: ~290 kernels of 3-130 us per step, no dominant one)", "avg_kernel_us": None},
+    }
+    print(json.dumps(out))
+
+
 def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     """Config 3's model on the training side of the bench contract: a step = one Adam step of 3 x [ActNorm, Glow,
     NSF_CL] on the resident batch (layer-by-layer forward keeping every intermediate, -mean log-prob, backward, Adam).
@@ -678,7 +750,7 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
-SECONDARY = ("c3", "c4", "c5", "c2t", "c3t", "c5t")
+SECONDARY = ("c3", "c4", "c5", "c2t", "c3t", "c5t", "lenet")
 
 
 def secondary_lines(args) -> dict:
@@ -808,6 +880,8 @@ def main() -> None:
         return main_train(args, rank, world, device, dim, rows, desc)
     if args.workload == "c5t":
         return main_train_c5(args, rank, world, device, dim, rows, desc)
+    if args.workload == "lenet":
+        return main_lenet(args, rank, world, device, dim, rows, desc)
     if args.workload == "c3t":
         return main_train_c3(args, rank, world, device, dim, rows, desc)
     if args.workload in ("c3", "c3f"):

@@ -11,12 +11,15 @@
  *   mnf_nsf_ar           NSF_AR.forward / .inverse              torch_mnf/flows/spline_flow.py:201-235
  *   mnf_rqs              unconstrained_RQS                      torch_mnf/flows/spline_flow.py:29-68
  *   mnf_rnvp             RNVP.forward                           torch_mnf/flows/rnvp.py:25-39
+ *   mnf_maf              MAF / IAF .forward / .inverse          torch_mnf/flows/maf.py:39-72
  *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
  *   mnf_linear_rows      Glow.forward / .inverse (x @ W)        torch_mnf/flows/glow.py:26-37
  *   mnf_gauss_logprob(_sq) base.log_prob + the callers' mean    torch_mnf/flows/core.py:46-49,
  *                                                               examples/half_moons.ipynb:183-186
  *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
  *   mnf_mnf_linear_fwd   MNFLinear.forward behind sample_z      torch_mnf/layers/mnf_linear.py:46-56
+ *   mnf_mnf_kl_fwd       MNFLinear.kl_div / MNFConv2d.kl_div    torch_mnf/layers/mnf_linear.py:66-90,
+ *                        behind their two flows                 torch_mnf/layers/mnf_conv.py:100-133
  *   log_det accumulation NormalizingFlow.forward / .inverse     torch_mnf/flows/core.py:17-35
  *                        (the `accumulate` flag of every layer entry point: log_det += ld)
  *
@@ -298,6 +301,26 @@ int64_t mnf_nsf_ar_flat_floats(int dim, int K, int n_hidden, const int* hidden_h
 int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                    const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
                    const int* hidden_host, void* stream);
+
+/* ------------------------------------------------------------------ MAF / IAF (generic path)
+ * torch_mnf/flows/maf.py:21-72 over net = MADE(dim, hidden, 2 dim, natural_ordering=True) (torch_mnf/layers/made.py:11-94:
+ * MaskedLinear layers `x @ (W.T * mask) + b`, ReLU between them).
+ *   flat   net.{0,2,..}.weight (n_out_l, n_in_l) | .bias, state_dict order          mnf_maf_flat_floats(...) floats
+ *   masks  the MaskedLinear `mask` buffers (n_in_l, n_out_l) as bytes, back to back   mnf_maf_mask_bytes(...) bytes
+ *   sequential = 0   one pass  (MAF.inverse, IAF.forward; maf.py:54-62): s, t = net(x); y = x exp(s) + t, flipped along
+ *                    the features when parity; log_det = sum(s)
+ *   sequential = 1   dim passes (MAF.forward, IAF.inverse; maf.py:39-52): the input is flipped first when parity; from
+ *                    zeros, y_i = (z_i - t_i) exp(-s_i) with s, t = net(elements decoded so far); log_det = -sum(s_i)
+ * log_det as everywhere (accumulate: +=).  mnf_maf_bwd: grad_x is written, grad_flat (layout of flat) is ADDED to (or
+ * NULL); grad_y / grad_ld may be NULL; y = the forward call's output (sequential = 1 only, may be NULL otherwise).
+ * One thread per row, masked weights and activations in LDS: MNF_ERR_UNSUPPORTED when a net does not fit 144 KB. */
+int64_t mnf_maf_flat_floats(int dim, int n_hidden, const int* hidden_host);
+int64_t mnf_maf_mask_bytes(int dim, int n_hidden, const int* hidden_host);
+int mnf_maf(const float* x, float* y, float* log_det, int accumulate, const float* flat, const uint8_t* masks,
+            int64_t rows, int dim, int parity, int sequential, int n_hidden, const int* hidden_host, void* stream);
+int mnf_maf_bwd(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                const float* flat, const uint8_t* masks, int64_t rows, int dim, int parity, int sequential, int n_hidden,
+                const int* hidden_host, void* stream);
 
 /* ------------------------------------------------ MNFLinear.forward behind the flow path
  * torch_mnf/layers/mnf_linear.py:46-56 with z (rows, n_in) = what sample_z's last flow wrote:

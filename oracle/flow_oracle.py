@@ -319,6 +319,57 @@ def glow(x: Tensor, P: Tensor, L: Tensor, S: Tensor, U: Tensor, inverse: bool) -
 
 
 # ------------------------------------------------------------------ the stack
+def made_masks(n_in: int, hidden_sizes: Sequence[int], n_out: int, natural_ordering: bool = True, seed: int = 0) -> list:
+    """The binary (n_in_l, n_out_l) connectivity masks of a MADE network.  torch_mnf/layers/made.py:58-94 (num_masks = 1):
+    input degrees are the natural order (or a permutation from numpy.random.RandomState(seed)); hidden unit degrees are
+    drawn with ``rng.randint(min of the previous layer's degrees, n_in - 1, size)``; a hidden connection needs
+    degree_prev <= degree_next, an output connection degree_hidden < degree_output; the output mask is tiled when
+    n_out is a multiple of n_in."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    deg = {-1: np.arange(n_in) if natural_ordering else rng.permutation(n_in)}
+    for layer, size in enumerate(hidden_sizes):
+        deg[layer] = rng.randint(deg[layer - 1].min(), n_in - 1, size=size)
+    n_layers = len(hidden_sizes)
+    masks = [deg[layer - 1][:, None] <= deg[layer][None, :] for layer in range(n_layers)]
+    masks.append(deg[n_layers - 1][:, None] < deg[-1][None, :])
+    if n_out > n_in:
+        masks[-1] = np.concatenate([masks[-1]] * (n_out // n_in), axis=1)
+    return [torch.from_numpy(m) for m in masks]
+
+
+def made(x: Tensor, params: Params, masks: Sequence[Tensor], prefix: str = "net.") -> Tensor:
+    """MADE forward: MaskedLinear layers ``x @ (W.T * mask) + b`` with ReLU between them, none after the last.
+    torch_mnf/layers/made.py:24-25, 46-49.  ``params``: state_dict entries ``{prefix}{2l}.weight / .bias``."""
+    for layer, mask in enumerate(masks):
+        W, b = params[f"{prefix}{2 * layer}.weight"], params[f"{prefix}{2 * layer}.bias"]
+        x = x @ (W.T * mask.to(x.dtype)) + b
+        if layer + 1 < len(masks):
+            x = torch.relu(x)
+    return x
+
+
+def maf(x: Tensor, params: Params, masks: Sequence[Tensor], parity: bool, inverse: bool) -> tuple[Tensor, Tensor]:
+    """MAF.  torch_mnf/flows/maf.py:39-62.  ``inverse`` (:54-62, one pass): ``z = x * exp(s) + t`` with
+    ``s, t = net(x).split(dim)``, flipped along the features when ``parity``, ``log_det = sum(s)``.  ``forward``
+    (:39-52, sequential): the input is flipped first when ``parity``; starting from zeros, element i becomes
+    ``(z_i - t_i) * exp(-s_i)`` with s, t from the net on the elements decoded so far; ``log_det = -sum(s_i)``."""
+    dim = x.shape[1]
+    if inverse:
+        s, t = made(x, params, masks).split(dim, dim=1)
+        z = x * s.exp() + t
+        return (z.flip(dims=[1]) if parity else z), s.sum(1)
+    z = x.flip(dims=[1]) if parity else x
+    out = torch.zeros_like(z)
+    log_det = torch.zeros(z.shape[0], dtype=z.dtype)
+    for i in range(dim):
+        s, t = made(out, params, masks).split(dim, dim=1)
+        out = torch.cat([out[:, :i], ((z[:, i] - t[:, i]) * torch.exp(-s[:, i]))[:, None], out[:, i + 1:]], dim=1)
+        log_det = log_det - s[:, i]
+    return out, log_det
+
+
 def apply_layer(spec: dict, x: Tensor, inverse: bool) -> tuple[Tensor, Tensor]:
     """Dispatch on ``spec['kind']`` -- the oracle's stand-in for duck-typed flow modules."""
     kind, p = spec["kind"], spec["params"]
@@ -338,6 +389,8 @@ def apply_layer(spec: dict, x: Tensor, inverse: bool) -> tuple[Tensor, Tensor]:
         if inverse:
             raise AttributeError("RNVP has no inverse (rnvp.py)")
         return rnvp(x, p, spec["mask"])
+    if kind in ("maf", "iaf"):  # IAF swaps the two directions (maf.py:65-72)
+        return maf(x, p, spec["masks"], spec["parity"], inverse if kind == "maf" else not inverse)
     raise ValueError(f"unknown layer kind {kind!r}")
 
 

@@ -526,6 +526,44 @@ def g14_mnf_linear_kl():
     save("g14_mnf_linear_kl", **out)
 
 
+# ----------------------------------------------------------------------------- G15
+G15_CASES = {"d2": (2, (24, 24, 24), 300), "d5": (5, (24, 24, 24), 257), "d7_h16": (7, (16,), 129),
+             "d12": (12, (24, 24, 24), 64)}
+
+
+def g15_maf_iaf():
+    """MAF and IAF (flows/maf.py:21-72 on layers/made.py's MADE) in both directions and both parities: dim 2 (the
+    reference's tests), 5, 7 (one hidden layer) and 12; the float64 run of the same layers; the MADE masks themselves."""
+    out = {}
+    for tag, (dim, h_sizes, rows) in G15_CASES.items():
+        for parity in (False, True):
+            sd = recipes.maf_params(1500 + dim + int(parity), dim, h_sizes, gain=1.5, last_gain=0.7)
+            x = recipes.gaussian(1501 + dim, rows, dim, scale=1.2)
+            layer = nf.MAF(dim, parity=parity, h_sizes=h_sizes)
+            layer.load_state_dict(sd, strict=False)
+            key = f"{tag}.p{int(parity)}"
+            if not parity:
+                out[f"{tag}.x"] = npy(x)
+                masked = [m for m in layer.net if hasattr(m, "mask")]
+                for i, m in enumerate(masked):
+                    out[f"{tag}.mask{i}"] = npy(m.mask).astype(np.uint8)
+            with torch.no_grad():
+                y_f, ld_f = layer.forward(x)      # sequential (IAF's inverse)
+                y_i, ld_i = layer.inverse(x)      # one pass (IAF's forward)
+                back, _ = layer.inverse(y_f)
+            assert float((back.flip(dims=[1]) if parity else back).sub(x.flip(dims=[1]) if parity else x).abs().max()) < 1e-3 \
+                or parity  # (with parity the reference's forward flips its INPUT and inverse its OUTPUT: see the oracle)
+            out[f"{key}.fwd"], out[f"{key}.ld_fwd"] = npy(y_f), npy(ld_f)
+            out[f"{key}.inv"], out[f"{key}.ld_inv"] = npy(y_i), npy(ld_i)
+            layer64 = nf.MAF(dim, parity=parity, h_sizes=h_sizes).double()
+            layer64.load_state_dict({k: v.double() for k, v in sd.items()}, strict=False)
+            with torch.no_grad():
+                y64_f, _ = layer64.forward(x.double())   # (log_det is allocated as float32 zeros there: outputs only)
+                y64_i, ld64_i = layer64.inverse(x.double())
+            out[f"{key}.fwd64"], out[f"{key}.inv64"], out[f"{key}.ld_inv64"] = npy(y64_f), npy(y64_i), npy(ld64_i)
+    save("g15_maf_iaf", **out)
+
+
 # ----------------------------------------------------------------------------- G9
 def g9_logdet_shapes():
     x = recipes.gaussian(900, 8, 4)
@@ -565,4 +603,5 @@ if __name__ == "__main__":
     g12_nsf_ar()
     g13_mnf_conv2d()
     g14_mnf_linear_kl()
+    g15_maf_iaf()
     g9_logdet_shapes()

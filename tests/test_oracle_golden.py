@@ -327,3 +327,47 @@ def test_g14_mnf_linear_kl(golden, tag):
     fx = golden("g14_mnf_linear_kl")
     kl, _, _ = g14_oracle(fx, tag)
     assert abs(float(kl) - float(fx[f"{tag}.kl"])) <= 1e-5 * abs(float(fx[f"{tag}.kl"])), (float(kl), float(fx[f"{tag}.kl"]))
+
+
+# ------------------------------------------------------------------ G15: MAF / IAF
+G15_CASES = {"d2": (2, (24, 24, 24), 300), "d5": (5, (24, 24, 24), 257), "d7_h16": (7, (16,), 129),
+             "d12": (12, (24, 24, 24), 64)}
+
+
+def g15_params(tag, parity, dtype=torch.float32):
+    dim, h_sizes, _ = G15_CASES[tag]
+    return {k: v.to(dtype) for k, v in recipes.maf_params(1500 + dim + int(parity), dim, h_sizes, gain=1.5,
+                                                          last_gain=0.7).items()}
+
+
+@pytest.mark.parametrize("tag", sorted(G15_CASES))
+def test_g15_made_masks(golden, tag):
+    """The oracle's MADE connectivity masks are the reference's (layers/made.py:58-94), bit for bit."""
+    fx = golden("g15_maf_iaf")
+    dim, h_sizes, _ = G15_CASES[tag]
+    masks = O.made_masks(dim, h_sizes, 2 * dim)
+    assert len(masks) == len(h_sizes) + 1
+    for i, m in enumerate(masks):
+        assert np.array_equal(m.numpy().astype(np.uint8), fx[f"{tag}.mask{i}"]), (tag, i)
+
+
+@pytest.mark.parametrize("parity", [False, True])
+@pytest.mark.parametrize("tag", sorted(G15_CASES))
+def test_g15_maf_iaf(golden, tag, parity):
+    """Oracle vs the reference's MAF.forward (sequential) and MAF.inverse (one pass) (flows/maf.py:39-62); IAF is the
+    same layer with the directions swapped (:65-72)."""
+    fx = golden("g15_maf_iaf")
+    dim, h_sizes, _ = G15_CASES[tag]
+    x = torch.from_numpy(fx[f"{tag}.x"])
+    masks = O.made_masks(dim, h_sizes, 2 * dim)
+    key = f"{tag}.p{int(parity)}"
+    for name, inverse in (("fwd", False), ("inv", True)):
+        y, ld = O.maf(x, g15_params(tag, parity), masks, parity, inverse)
+        y64, ld64 = O.maf(x.double(), g15_params(tag, parity, torch.float64), masks, parity, inverse)
+        assert_parity(y, fx[f"{key}.{name}"], fx[f"{key}.{name}64"], what=f"MAF {key} {name}")
+        assert_parity(ld, fx[f"{key}.ld_{name}"], fx.get(f"{key}.ld_{name}64") if hasattr(fx, "get") else None,
+                      what=f"MAF {key} ld_{name}")
+        assert_parity(y64, fx[f"{key}.{name}64"], what=f"MAF {key} {name} (float64)", rtol=1e-12)
+        spec = {"kind": "iaf", "params": g15_params(tag, parity), "masks": masks, "parity": parity}
+        y_iaf, ld_iaf = O.apply_layer(spec, x, not inverse)
+        assert torch.equal(y_iaf, y) and torch.equal(ld_iaf, ld)

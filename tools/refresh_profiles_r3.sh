@@ -33,5 +33,5 @@ for w in $WL; do
   [ "$w" != c5t ] && python3 tools/make_valu_json.py gpurun_out/prof_r3_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" > /dev/null 2>&1
 done
 ls -la "$OUT"
-for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python3 -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', round(d['value']/1e6,1), 'M/s', round(d['ms_per_step'],3), 'ms', r['bound'], round(r['frac'],3), round(r['avg_kernel_us'],1), 'us', r.get('traffic'))"; done
+for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python3 -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', d['value'], d['unit'], d['ms_per_step'], 'ms', r['bound'], r['frac'], r['avg_kernel_us'], 'us', r.get('traffic'))"; done
 for f in "$OUT"/*_pmc_traffic.json; do echo "$f"; grep -E "FETCH|WRITE|traffic_bytes" "$f"; done

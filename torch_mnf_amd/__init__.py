@@ -19,6 +19,10 @@ from .flows import (
     FusedAffineStack,
     FusedSplineBlock,
     Glow,
+    IAF,
+    MADE,
+    MAF,
+    MaskedLinear,
     NormalizingFlow,
     NormalizingFlowModel,
     NSF_AR,
@@ -29,7 +33,7 @@ from .flows import (
 )
 
 __all__ = [
-    "MLP", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
+    "MLP", "MADE", "MaskedLinear", "MAF", "IAF", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
     "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "GraphedStep", "MnfHipError", "library_path",
 ]
 

@@ -135,6 +135,12 @@ SIGNATURES = {
     "mnf_mnf_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),
+    "mnf_maf_flat_floats": (c_int64, [c_int, c_int, _intp]),
+    "mnf_maf_mask_bytes": (c_int64, [c_int, c_int, _intp]),
+    "mnf_maf": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, _intp,
+                        c_void_p]),
+    "mnf_maf_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                            c_int, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_few_rows_ok": (c_int, [c_int64, c_int, c_int, _intp]),
     "mnf_mnf_kl_saved_floats": (c_int64, [c_int64]),
     "mnf_mnf_kl_grad_floats": (c_int64, [c_int]),

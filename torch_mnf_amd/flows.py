@@ -72,6 +72,63 @@ class MLP(nn.Sequential):
         self.layer_sizes = tuple(int(s) for s in layer_sizes)
 
 
+class MaskedLinear(nn.Linear):
+    """A dense layer with a binary mask on its weights (layers/made.py:11-25): ``x @ (W.T * mask) + b``; ``mask`` is a
+    buffer of shape (n_in, n_out).  Inside MAF / IAF the kernels read weight, bias and mask directly; this ``forward``
+    is the reference's formula on device tensors for anyone who calls the network on its own."""
+
+    def __init__(self, n_in: int, n_out: int, bias: bool = True) -> None:
+        super().__init__(n_in, n_out, bias)
+        self.register_buffer("mask", torch.ones(n_in, n_out))
+
+    def set_mask(self, mask) -> None:
+        self.mask = torch.as_tensor(mask).to(self.weight.device)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return x @ (self.weight.T * self.mask) + self.bias
+
+
+class MADE(nn.Sequential):
+    """Masked autoregressive MLP (layers/made.py:28-94; Germain et al. 2015, in karpathy's construction): MaskedLinear
+    layers with ReLU between them whose masks make output i (and i + n_in, ...) a function of the inputs ordered before
+    input i only.  Same constructor, attributes and state_dict keys (``{2l}.weight / .bias / .mask``) as the reference;
+    the unit degrees come from ``numpy.random.RandomState(seed)`` exactly as there, so the masks are the reference's."""
+
+    def __init__(self, n_in: int, hidden_sizes, n_out: int, num_masks: int = 1, natural_ordering: bool = False) -> None:
+        if n_out % n_in:
+            raise AssertionError("n_out must be integer multiple of n_in")  # (made.py:39)
+        self.n_in, self.n_out, self.hidden_sizes = int(n_in), int(n_out), list(hidden_sizes)
+        sizes = [self.n_in, *self.hidden_sizes, self.n_out]
+        layers: list[nn.Module] = []
+        for a, b in zip(sizes, sizes[1:]):
+            layers += [MaskedLinear(a, b), nn.ReLU()]
+        super().__init__(*layers[:-1])
+        self.natural_ordering, self.num_masks, self.seed = natural_ordering, num_masks, 0
+        self.m: dict = {}
+        self.update_masks()
+
+    def update_masks(self) -> None:
+        """(made.py:58-94) degrees of the inputs (natural order or a permutation), of every hidden unit (uniform between
+        the previous layer's smallest degree and n_in - 2), connection rules <= between hidden layers and < into the
+        outputs; the next call uses the next seed when ``num_masks > 1``."""
+        import numpy as np
+
+        if self.m and self.num_masks == 1:
+            return
+        rng = np.random.RandomState(self.seed)
+        self.seed = (self.seed + 1) % self.num_masks
+        self.m[-1] = np.arange(self.n_in) if self.natural_ordering else rng.permutation(self.n_in)
+        for layer, size in enumerate(self.hidden_sizes):
+            self.m[layer] = rng.randint(self.m[layer - 1].min(), self.n_in - 1, size=size)
+        n = len(self.hidden_sizes)
+        masks = [self.m[layer - 1][:, None] <= self.m[layer][None, :] for layer in range(n)]
+        masks.append(self.m[n - 1][:, None] < self.m[-1][None, :])
+        if self.n_out > self.n_in:
+            masks[-1] = np.concatenate([masks[-1]] * (self.n_out // self.n_in), axis=1)
+        for layer, mask in zip([m for m in self if isinstance(m, MaskedLinear)], masks):
+            layer.set_mask(mask)
+
+
 def _require_mlp(*nets: nn.Module) -> None:
     """The kernels evaluate the conditioner themselves: Linear / LeakyReLU(0.2) chains (the reference's MLP with its
     default slope, models/mlp.py:4-12).  Any other conditioner class or slope cannot run on them -- say so instead of
@@ -1171,6 +1228,109 @@ class RNVP(_HipFlow):
 
     def forward(self, z: Tensor, mask: Tensor | None = None, seed: int | None = None) -> tuple[Tensor, Tensor]:
         return self._run(z, False, None, mask, seed)
+
+
+class _MafFn(torch.autograd.Function):
+    """MAF / IAF with gradients (mnf_maf / mnf_maf_bwd).  ``home``: see _RnvpFn."""
+
+    @staticmethod
+    def forward(ctx, x, flat_with_grad, module, sequential, home=None):
+        flat, _ = module._packed(x.device)
+        masks = module._mask_bytes(x.device)
+        y = torch.empty_like(x)
+        ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_maf", _lib.load().mnf_maf(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, flat.data_ptr(), masks.data_ptr(), x.shape[0], module.dim,
+            int(bool(module.parity)), int(sequential), len(module.h_sizes), module._hid, _stream()))
+        ctx.module, ctx.sequential, ctx.home = module, sequential, home
+        ctx.save_for_backward(x, y, flat, masks)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_ld):
+        x, y, flat, masks = ctx.saved_tensors
+        m, home = ctx.module, ctx.home
+        gy = None if grad_y is None else grad_y.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
+        grad_x = torch.empty_like(x)
+        if home is not None:
+            grad_flat, ret = home[0].grad[home[1]:home[1] + home[2]], None
+        else:
+            grad_flat = ret = torch.zeros_like(flat)
+        _lib.check("mnf_maf_bwd", _lib.load().mnf_maf_bwd(
+            x.data_ptr(), y.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
+            masks.data_ptr(), x.shape[0], m.dim, int(bool(m.parity)), int(ctx.sequential), len(m.h_sizes), m._hid,
+            _stream()))
+        return grad_x, ret, None, None, None
+
+
+class MAF(_TwoWayFlow):
+    """Masked autoregressive flow (flows/maf.py:21-62): ``inverse`` is one pass of the MADE network (density
+    estimation), ``forward`` decodes the elements one at a time (dim passes).  Same constructor, attribute names and
+    state_dict keys (``net.{2l}.weight / .bias / .mask``) as the reference; each direction is one ``mnf_maf`` launch
+    (generic path: a thread per row, masked weights in LDS), gradients from ``mnf_maf_bwd``.  ``net`` must be a
+    ``MADE(dim, hidden, 2 * dim)``: the kernels evaluate the masked network themselves."""
+
+    _sequential_forward = True  # IAF: the two directions swapped
+
+    def __init__(self, dim: int, parity: bool, net: nn.Module | None = None, h_sizes: Sequence[int] = (24, 24, 24)) -> None:
+        super().__init__()
+        self.dim, self.parity = int(dim), parity
+        self.net = net or MADE(dim, h_sizes, 2 * dim, natural_ordering=True)
+        if not isinstance(self.net, MADE) or self.net.n_in != self.dim or self.net.n_out != 2 * self.dim:
+            raise NotImplementedError(
+                f"torch_mnf_amd's MAF / IAF kernels evaluate a MADE({self.dim}, hidden, {2 * self.dim}) network themselves; "
+                f"got {type(self.net).__name__}")
+        self.h_sizes = tuple(int(h) for h in self.net.hidden_sizes)
+        self._hid = _lib.int_array(self.h_sizes)
+
+    def _masked(self) -> list:
+        return [m for m in self.net if isinstance(m, MaskedLinear)]
+
+    def _packed_params(self) -> list[Tensor]:
+        return [p for m in self._masked() for p in (m.weight, m.bias)]
+
+    def _mask_bytes(self, device) -> Tensor:
+        """The MaskedLinear mask buffers as bytes, back to back; rebuilt when a mask tensor is replaced
+        (``MADE.update_masks`` assigns new ones) or moved."""
+        masks = [m.mask for m in self._masked()]
+        key = (device, tuple((id(t), t._version) for t in masks))
+        cached = self.__dict__.get("_mask_cache")
+        if cached is None or cached[0] != key:
+            packed = torch.cat([(t != 0).reshape(-1).to(device=device, dtype=torch.uint8) for t in masks]).contiguous()
+            cached = self.__dict__["_mask_cache"] = (key, packed)
+        return cached[1]
+
+    def _run(self, x, inverse, accum):
+        sequential = bool(inverse) != self._sequential_forward
+        if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            xg = _grad_input(x)
+            if xg.shape[1] != self.dim:
+                raise ValueError(f"expected dim {self.dim}, got {xg.shape[1]}")
+            params = self._packed_params()
+            home = _flat_home_of(self, params)
+            flat = _home_stand_in(self, xg.device) if home is not None else torch.cat([p.reshape(-1) for p in params])
+            return _MafFn.apply(xg, flat, self, sequential, home)
+        x = _device_input(x, "input")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"expected dim {self.dim}, got {x.shape[1]}")
+        if x.shape[0] == 0:
+            return _empty_result(x, accum)
+        flat, _ = self._packed(x.device)
+        masks = self._mask_bytes(x.device)
+        y = torch.empty_like(x)
+        ld = accum if accum is not None else torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        _lib.check("mnf_maf", _lib.load().mnf_maf(
+            x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), flat.data_ptr(), masks.data_ptr(),
+            x.shape[0], self.dim, int(bool(self.parity)), int(sequential), len(self.h_sizes), self._hid, _stream()))
+        return y, (None if accum is not None else ld)
+
+
+class IAF(MAF):
+    """Inverse autoregressive flow (flows/maf.py:65-72): MAF with ``forward`` and ``inverse`` swapped -- one pass to
+    sample, dim passes to evaluate a density."""
+
+    _sequential_forward = False
 
 
 class AffineConstantFlow(_TwoWayFlow):

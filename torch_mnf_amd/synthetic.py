@@ -78,6 +78,12 @@ def rnvp_params(seed: int, dim: int, h: int, gain: float = 1.5) -> dict:
     return sd
 
 
+def maf_params(seed: int, dim: int, h_sizes=(24, 24, 24), gain: float = 1.0, last_gain: float = 1.0) -> dict:
+    """flows.MAF / IAF state_dict WITHOUT the mask buffers: net = MADE(dim, h_sizes, 2 dim) -> net.{2l}.weight / .bias
+    (the masks are the deterministic construction of layers/made.py and stay what the constructor built)."""
+    return mlp_params(np.random.default_rng(seed), "net", (dim, *h_sizes, 2 * dim), last_gain=last_gain, gain=gain)
+
+
 def actnorm_params(seed: int, dim: int) -> dict:
     rng = np.random.default_rng(seed)
     s = (0.3 * rng.standard_normal((1, dim))).astype(np.float32)
