@@ -509,16 +509,17 @@ def test_bench_c5t_training_step_line(amd):
 
 
 def test_bench_default_line_carries_the_other_configurations(amd):
-    """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c2t, c3t, c5t as `secondary`
+    """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c2t, c3t, c5t and the MNF-LeNet step as `secondary`
     (only c2 used to be driver-observable), the per-step median / min and a one-thread CPU
     figure."""
     line = _run_bench("--steps", "5", "--warmup", "2", "--prime-ms", "5", "--no-cpu-baseline")
     assert line["config"]["workload"].startswith("9xAffineHalfFlow d=64")
     sec = line["secondary"]
-    assert set(sec) == {"c3", "c4", "c5", "c2t", "c3t", "c5t"}
+    assert set(sec) == {"c3", "c4", "c5", "c2t", "c3t", "c5t", "lenet"}
     for w, d in sec.items():
         assert "error" not in d, (w, d)
-        assert d["ms_per_step"] > 0 and d["avg_kernel_us"] > 0 and d["bound"] in ("hbm", "valu", "mfma"), (w, d)
+        assert d["ms_per_step"] > 0 and d["bound"] in ("hbm", "valu", "mfma"), (w, d)
+        assert w == "lenet" or d["avg_kernel_us"] > 0, (w, d)  # (lenet: launch-bound, no dominant kernel)
     assert line["min_ms"] <= line["median_ms"]
 
 

@@ -425,6 +425,50 @@ __device__ __forceinline__ int flush_offset(const NetDesc& nd, int hid, int t, i
   return n == 0 ? nd.b_off[0] + m : -1;
 }
 
+// the inverse: accumulator element (t * 256 + lane * 4 + reg) that holds the gradient of flat parameter p of the net
+template <int K>
+__device__ __forceinline__ int flush_source(const NetDesc& nd, int hid, int p) {
+  constexpr int P = 3 * K - 1;
+  int t, m, n;
+  if (p >= nd.b_off[3]) {
+    const int q = p - nd.b_off[3];
+    m = q / P, t = q - m * P, n = kNrUnits;
+  } else if (p >= nd.w_off[3]) {
+    const int q = p - nd.w_off[3], mt = q / hid;
+    n = q - mt * hid, m = mt / P, t = mt - m * P;
+  } else if (p >= nd.b_off[2]) {
+    m = p - nd.b_off[2], t = P, n = kNrUnits;
+  } else if (p >= nd.w_off[2]) {
+    const int q = p - nd.w_off[2];
+    m = q / hid, n = q - m * hid, t = P;
+  } else if (p >= nd.b_off[1]) {
+    m = p - nd.b_off[1], t = P + 1, n = kNrUnits;
+  } else if (p >= nd.w_off[1]) {
+    const int q = p - nd.w_off[1];
+    m = q / hid, n = q - m * hid, t = P + 1;
+  } else if (p >= nd.b_off[0]) {
+    m = p - nd.b_off[0], t = P + 3, n = 0;
+  } else {
+    const int q = p - nd.w_off[0];
+    m = q / kNrHalf, n = q - m * kNrHalf, t = P + 2;
+  }
+  return t * 256 + (16 * (m >> 2) + n) * 4 + (m & 3);
+}
+
+// The workgroup's sums (lds: [net][tile][lane][reg]) added to grad_flat in PARAMETER order: consecutive threads add to
+// consecutive addresses.  (In accumulator order the same 7,184 atomics per workgroup were scattered over the buffer and
+// cost 123 us of the launch's 1,858 at 2^20 rows: scattered atomics run ~10 x slower at the memory side, section 3.6.)
+template <int K>
+__device__ __forceinline__ void flush_nets(const NrArgs& a, const float* lds) {
+  using S = NrShape<K>;
+  for (int net = 0; net < 2; ++net) {
+    const NetDesc& nd = net ? a.f2 : a.f1;
+    const int base = nd.w_off[0], count = nd.b_off[3] + kNrHalf * S::P - base;
+    for (int i = threadIdx.x; i < count; i += blockDim.x)
+      atomicAdd(a.grad_flat + base + i, lds[net * S::TILES * 256 + flush_source<K>(nd, a.hid, base + i)]);
+  }
+}
+
 // LDS images of both nets (rotated output weights, biases, per-lane hidden records); the caller syncs
 template <int K>
 __device__ __forceinline__ void fill_net_images(float* lds, const NrArgs& a, int sgn) {
@@ -473,7 +517,6 @@ __global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, r = lane >> 4;
-  const int hid = a.hid;
   // which way the rotation turns: rot<1> of the lane's own element index is j - 1 or j + 1
   const int sgn = ((rot_int<1>(j) - j) & 15) == 1 ? 1 : -1;
 
@@ -555,11 +598,7 @@ __global__ void __launch_bounds__(kNrWaves * 64, 1) nsf_bwd_rows_kernel(NrArgs a
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < S::RED_FLOATS; i += blockDim.x) {
-    const int net = i >= S::TILES * 256, e = i - net * S::TILES * 256;
-    const int dst = flush_offset<K>(net ? a.f2 : a.f1, hid, e >> 8, (e >> 2) & 63, e & 3);
-    if (dst >= 0) atomicAdd(a.grad_flat + dst, lds[i]);
-  }
+  flush_nets<K>(a, lds);
 }
 
 // Two waves per SIMD: the accumulators of BOTH nets (216 registers) are what keeps nsf_bwd_rows_kernel at one wave per
@@ -647,9 +686,6 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
   }
 
   // ------------------------------------------------------------------ flush: X waves hold the first net's sums, Y waves the second's
-#ifdef MNF_NSF_BWD_NOFLUSH  // (timing experiment: what the flush costs)
-  if (a.rows > 0) return;
-#endif
   if (a.grad_flat == nullptr) return;
   for (int w = 0; w < kNpPairs; ++w) {
     if (pair == w) {
@@ -662,11 +698,7 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < S::RED_FLOATS; i += blockDim.x) {
-    const int net = i >= S::TILES * 256, e = i - net * S::TILES * 256;
-    const int dst = flush_offset<K>(net ? a.f2 : a.f1, a.hid, e >> 8, (e >> 2) & 63, e & 3);
-    if (dst >= 0) atomicAdd(a.grad_flat + dst, lds[i]);
-  }
+  flush_nets<K>(a, lds);
 }
 
 template <int K>
