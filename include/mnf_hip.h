@@ -217,13 +217,21 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
-/* Up to MNF_RNVP_FEW_ROWS rows through a layer with ONE hidden layer (what the MNF layers' kl_div and MNFConv2d's
- * sample_z run: one row per call, mnf_linear.py:67/84, mnf_conv.py:90-101/127) take a latency kernel instead -- one
- * workgroup, weight reads coalesced, and in mnf_rnvp_bwd no atomics -- when `flat` is given and force_generic is 0
- * (1 row of 800 dims: 86 -> ~5 us forward, 150 -> ~10 us backward).  MNF_RNVP_FEW=0 in the environment switches it off. */
+/* Few rows through a layer with ONE hidden layer of at most 64 units take latency kernels (mnf_rnvp_few.hip) instead of
+ * the streaming ones when `flat` is given and force_generic is 0: weight rows read coalesced by a wave per dim, DPP
+ * wave sums, no operand image.
+ *   mnf_rnvp_seeded   a workgroup per two rows: up to MNF_RNVP_FEW_FWD_ROWS rows with an explicit mask (the reference's
+ *                     batch of 128 rows of 800 dims: 103 -> 35 us), up to 64 with the in-kernel mask (the register-
+ *                     resident kernels are as fast from ~100 rows); one row of 800 dims: 86 -> 22 us.  The
+ *                     environment variable MNF_RNVP_FEW_FWD_ROWS overrides both limits
+ *   mnf_rnvp_bwd      up to MNF_RNVP_FEW_ROWS rows -- what the MNF layers' kl_div runs (one row per call,
+ *                     mnf_linear.py:67/84, mnf_conv.py:90-101/127): ONE workgroup owns every parameter gradient, no
+ *                     atomics (one row of 800 dims: 150 -> 49 us)
+ * MNF_RNVP_FEW=0 in the environment switches both off. */
 #define MNF_RNVP_FEW_ROWS 2
-/* 1 when mnf_rnvp_seeded / mnf_rnvp_bwd take that kernel for this shape (the caller then needs no operand images). */
-int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host);
+#define MNF_RNVP_FEW_FWD_ROWS 512
+/* 1 when mnf_rnvp_seeded takes that kernel for this shape (the caller then needs no operand image for the forward call). */
+int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host, int explicit_mask);
 /* MNFLinear.sample_z's prologue fused into its first flow (torch_mnf/layers/mnf_linear.py:58-64):
  * x = RNVP(q0_mean + sqrt(exp(q0_log_var)) * eps); z0 is formed in the kernel's loads and never stored.
  * mask == NULL: in-kernel mask from `seed`.  Needs image and split_image (split MFMA kernel) and dim <= 1024;

@@ -10,7 +10,8 @@ from test_hip_round3 import _check_grads, _rnvp_gpu_grads, _rnvp_oracle_grads
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# (rows 3: past the few-rows kernels -- the streaming kernels, same checks; hidden 70: wider than a wave, ditto)
+# (gradients at 3 rows: past the one-workgroup kernel -- the streaming kernels, same checks; hidden 70: wider than a
+#  wave, ditto.  The forward kernel also runs as a grid, a workgroup per two rows: FWD_SHAPES adds batch-sized cases.)
 SHAPES = [(800, 50, 1), (800, 50, 2), (800, 50, 3), (50, 50, 1), (20, 50, 1), (20, 50, 2), (784, 30, 2), (33, 7, 1),
           (1100, 64, 2), (2, 16, 1), (96, 70, 1)]
 
@@ -31,7 +32,10 @@ def O():
     return flow_oracle
 
 
-@pytest.mark.parametrize("dim,hid,rows", SHAPES)
+FWD_SHAPES = SHAPES + [(800, 50, 128), (800, 50, 129), (50, 50, 300), (20, 50, 63), (784, 30, 512)]
+
+
+@pytest.mark.parametrize("dim,hid,rows", FWD_SHAPES)
 @pytest.mark.parametrize("masked", ["explicit", "seeded"])
 def test_few_rows_forward_vs_oracle(amd, O, dim, hid, rows, masked):
     sd = recipes.rnvp_params(5100 + dim + hid, dim, hid)

@@ -1071,7 +1071,7 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
       (!flat && !image))
     return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  if (flat && !force_generic && rnvp_few_ok(rows, dim, n_hidden, hidden))  // a handful of rows: the latency kernel
+  if (flat && !force_generic && rnvp_few_fwd_ok(rows, dim, n_hidden, hidden, mask != nullptr))  // few rows: the latency kernel
     return rnvp_few_fwd_launch(z, mask, seed, x, log_det, accumulate, flat, rows, dim, hidden[0], (hipStream_t)stream);
   if (image && !force_generic) {
     const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, split_image, rows, dim, n_hidden, hidden,

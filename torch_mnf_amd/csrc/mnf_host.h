@@ -128,7 +128,8 @@ int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulat
 
 // RNVP on <= MNF_RNVP_FEW_ROWS rows with one hidden layer (mnf_rnvp_few.hip): one workgroup, no atomics.  `flat` is the
 // layer's plain parameter buffer (the state_dict order of mnf_rnvp); gradients are ADDED to grad_flat.
-bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden);
+bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden);      // gradients: <= MNF_RNVP_FEW_ROWS
+bool rnvp_few_fwd_ok(int64_t rows, int dim, int n_hidden, const int* hidden, bool explicit_mask);  // forward: a workgroup per two rows
 int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
                         const float* flat, int64_t rows, int dim, int hid, hipStream_t stream);
 int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,

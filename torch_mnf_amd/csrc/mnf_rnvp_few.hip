@@ -28,6 +28,8 @@ namespace mnf {
 constexpr int kFewThreads = MNF_FEW_THREADS;
 constexpr int kFewWaves = kFewThreads / 64;
 constexpr int kFewRows = MNF_RNVP_FEW_ROWS;
+constexpr int kFewFwdRows = MNF_RNVP_FEW_FWD_ROWS;
+constexpr int kFewFwdRowsSeeded = 64;
 constexpr int kFewLdsFloats = 36 * 1024;  // 144 KB
 
 struct RnvpFewArgs {
@@ -43,6 +45,7 @@ struct RnvpFewArgs {
   float* grad_flat;
   const float* flat;
   int rows, dim, hid;
+  int64_t row0;  // absolute index of this workgroup's first row (the in-kernel mask is a function of it)
 };
 
 // Sum over the wave, returned to every lane, on the DPP path (row-internal butterflies, row broadcasts, one readlane): 9
@@ -69,7 +72,7 @@ __device__ __forceinline__ void few_hidden(const RnvpFewArgs& a, float* kept, fl
   for (int idx = tid; idx < R * d; idx += kFewThreads) {
     const int r = idx / d, j = idx - r * d;
     float v = 0.f;  // (rows past the end of the batch: zeros, their cotangents are zero too)
-    if (r < a.rows) v = (a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, r, j)) * a.z[idx];
+    if (r < a.rows) v = (a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, a.row0 + r, j)) * a.z[idx];
     kept[idx] = v;
   }
   __syncthreads();
@@ -165,9 +168,21 @@ __device__ __forceinline__ void few_shift_scale(const RnvpFewArgs& a, const floa
   __syncthreads();
 }
 
+// (forward only: also launched as a grid, a workgroup per R rows, for batches of up to a few hundred rows -- the reference's
+//  training batch is 128 -- where the matrix-core kernel has 8 waves on the whole chip walking all dims: 103 us)
 template <int R>
-__global__ void __launch_bounds__(kFewThreads) rnvp_few_fwd_kernel(const RnvpFewArgs a) {
+__global__ void __launch_bounds__(kFewThreads) rnvp_few_fwd_kernel(const RnvpFewArgs a_in) {
   extern __shared__ float few_lds[];
+  RnvpFewArgs a = a_in;
+  {
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    a.row0 = row0;
+    a.rows = (int)min((int64_t)R, (int64_t)a_in.rows - row0);
+    a.z += row0 * a.dim;
+    a.x += row0 * a.dim;
+    if (a.mask) a.mask += row0 * a.dim;
+    if (a.log_det) a.log_det += row0;
+  }
   const int d = a.dim, h = a.hid, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* kept = few_lds;          // [R][d]
   float* sh = kept + R * d;       // [R][d]  shift, scale without their biases
@@ -190,7 +205,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_fwd_kernel(const RnvpFew
     for (int r = 0; r < R; ++r) {
       if (r < a.rows) {
         const int idx = r * d + j;
-        const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, r, j), z = a.z[idx];
+        const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, a.row0 + r, j), z = a.z[idx];
         const float gate = sigmoidf(sc[idx] + b_s), shift = sh[idx] + b_t;
         a.x[idx] = ((1.f - m) * z * gate + (1.f - gate) * shift) + m * z;  // rnvp.py:37
         lad[r] += (1.f - m) * logf(gate);                                  // :36 (0 * -inf = NaN, as there)
@@ -237,7 +252,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
       float gt = 0.f, gs = 0.f;
       const int idx = r * d + j;
       if (r < a.rows) {
-        const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, r, j), z = a.z[idx];
+        const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, a.row0 + r, j), z = a.z[idx];
         const float G = a.grad_x ? a.grad_x[idx] : 0.f, gl = a.grad_ld ? a.grad_ld[r] : 0.f;
         const float gate = sigmoidf(g_s[idx] + b_s), shift = g_t[idx] + b_t;
         // x = (1-m) z g + (1-g) t + m z ; ld = sum (1-m) log g
@@ -371,7 +386,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
           float sum = 0.f;
           for (int g = 0; g < groups; ++g) sum += part[(g * R + r) * width + tid];
           const int idx = r * d + j;
-          const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, r, j);
+          const float m = a.mask ? a.mask[idx] : rnvp_mask_bit(a.seed, a.row0 + r, j);
           a.grad_z[idx] += m * sum;
         }
       }
@@ -381,14 +396,32 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
 
 static inline int few_rows_class(int64_t rows) { return rows <= 1 ? 1 : 2; }
 
-bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden) {
+static bool few_shape_ok(int64_t rows, int64_t max_rows, int dim, int n_hidden, const int* hidden) {
   static const bool off = [] {  // MNF_RNVP_FEW=0: the streaming kernels at every row count (A/B runs)
     const char* e = getenv("MNF_RNVP_FEW");
     return e && e[0] == '0';
   }();
-  if (off || rows < 1 || rows > kFewRows || n_hidden != 1 || !hidden || hidden[0] < 1 || hidden[0] > 64) return false;
-  const int64_t R = few_rows_class(rows);
-  return 3 * R * dim + 2 * R * hidden[0] + R * 1024 <= kFewLdsFloats;  // (the gradient kernel's layout, the larger one)
+  if (off || rows < 1 || rows > max_rows || n_hidden != 1 || !hidden || hidden[0] < 1 || hidden[0] > 64) return false;
+  return 3 * 2 * (int64_t)dim + 2 * 2 * hidden[0] + 2 * 1024 <= kFewLdsFloats;  // (the gradient kernel's layout at R = 2)
+}
+
+// gradients: one workgroup owns every parameter gradient -- one or two rows
+bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden) {
+  return few_shape_ok(rows, kFewRows, dim, n_hidden, hidden);
+}
+
+// forward: a workgroup per two rows.  With an explicit mask tensor up to MNF_RNVP_FEW_FWD_ROWS rows (the streaming
+// kernel for explicit masks takes 103 us at 128 rows of 800 dims, this one 35 up to 512 rows); with the in-kernel mask
+// the register-resident kernels take over at ~100 rows (31 us at 128): up to 64 rows.  (tools/time_rnvp_fwd_rows.py;
+// the environment variable MNF_RNVP_FEW_FWD_ROWS overrides both limits.)
+bool rnvp_few_fwd_ok(int64_t rows, int dim, int n_hidden, const int* hidden, bool explicit_mask) {
+  static const int64_t forced = [] {
+    const char* e = getenv("MNF_RNVP_FEW_FWD_ROWS");
+    const long v = e ? atol(e) : 0;
+    return (int64_t)(v > 0 ? v : 0);
+  }();
+  const int64_t max_rows = forced ? forced : explicit_mask ? kFewFwdRows : kFewFwdRowsSeeded;
+  return few_shape_ok(rows, max_rows, dim, n_hidden, hidden);
 }
 
 template <typename K>
@@ -401,8 +434,9 @@ static int few_attr(K kernel) {
 
 int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
                         const float* flat, int64_t rows, int dim, int hid, hipStream_t stream) {
-  RnvpFewArgs a{z, mask, seed, x, log_det, accumulate, nullptr, nullptr, nullptr, nullptr, flat, (int)rows, dim, hid};
+  RnvpFewArgs a{z, mask, seed, x, log_det, accumulate, nullptr, nullptr, nullptr, nullptr, flat, (int)rows, dim, hid, 0};
   const int R = few_rows_class(rows);
+  const unsigned grid = (unsigned)((rows + R - 1) / R);
   const size_t lds = (3 * (size_t)R * dim + (size_t)R * hid + kFewWaves * R) * sizeof(float);
   static DeviceMemo attrs;
   if (attrs.get([&](int) {
@@ -410,8 +444,8 @@ int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float*
       }) < 0)
     return MNF_ERR_LAUNCH;
   switch (R) {
-    case 1: hipLaunchKernelGGL(rnvp_few_fwd_kernel<1>, dim3(1), dim3(kFewThreads), lds, stream, a); break;
-    default: hipLaunchKernelGGL(rnvp_few_fwd_kernel<2>, dim3(1), dim3(kFewThreads), lds, stream, a); break;
+    case 1: hipLaunchKernelGGL(rnvp_few_fwd_kernel<1>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
+    default: hipLaunchKernelGGL(rnvp_few_fwd_kernel<2>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
   }
   return check_launch();
 }
@@ -419,7 +453,7 @@ int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float*
 int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
                         float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int hid,
                         hipStream_t stream) {
-  RnvpFewArgs a{z, mask, seed, nullptr, nullptr, 0, grad_x, grad_ld, grad_z, grad_flat, flat, (int)rows, dim, hid};
+  RnvpFewArgs a{z, mask, seed, nullptr, nullptr, 0, grad_x, grad_ld, grad_z, grad_flat, flat, (int)rows, dim, hid, 0};
   const int R = few_rows_class(rows);
   const size_t lds = (3 * (size_t)R * dim + 2 * (size_t)R * hid + (size_t)R * 1024) * sizeof(float);
   static DeviceMemo attrs;
@@ -436,6 +470,6 @@ int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const 
 
 }  // namespace mnf
 
-extern "C" int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host) {
-  return mnf::rnvp_few_ok(rows, dim, n_hidden, hidden_host) ? 1 : 0;
+extern "C" int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host, int explicit_mask) {
+  return mnf::rnvp_few_fwd_ok(rows, dim, n_hidden, hidden_host, explicit_mask != 0) ? 1 : 0;
 }

@@ -407,7 +407,7 @@ class _RnvpFn(torch.autograd.Function):
     def forward(ctx, z, flat_with_grad, module, mask, seed, home=None):
         # home = (FlatParameters, offset, length): flat_with_grad is a stand-in that only carries requires_grad; the
         # kernels read the parameter slice and backward ADDS to the gradient slice in place
-        few = module._few(z.shape[0])
+        few = module._few(z.shape[0], mask is not None)
         flat, image = module._packed(z.device, images=not few)
         ctx.home = home
         x = torch.empty_like(z)
@@ -1156,15 +1156,16 @@ class RNVP(_HipFlow):
             _RNVP_BWD_WORK[device] = work
         return work
 
-    def _few(self, rows: int) -> bool:
-        """Does the library run this many rows on the few-rows kernels (mnf_rnvp_few.hip)?  They read the plain
-        parameter buffer: no operand image is needed then."""
+    def _few(self, rows: int, explicit_mask: bool) -> bool:
+        """Does the library run a forward call of this many rows on the few-rows kernel (mnf_rnvp_few.hip)?  It reads
+        the plain parameter buffer: no operand image is needed then."""
         if self.force_generic:
             return False
         cache = self.__dict__.setdefault("_few_cache", {})
-        ok = cache.get(rows)
+        ok = cache.get((rows, explicit_mask))
         if ok is None:
-            ok = cache[rows] = bool(_lib.load().mnf_rnvp_few_rows_ok(rows, self.dim, len(self.h_sizes), self._hid))
+            ok = cache[(rows, explicit_mask)] = bool(_lib.load().mnf_rnvp_few_rows_ok(
+                rows, self.dim, len(self.h_sizes), self._hid, int(explicit_mask)))
         return ok
 
     def mask_for(self, seed: int, rows: int, device="cuda") -> Tensor:
@@ -1202,7 +1203,7 @@ class RNVP(_HipFlow):
             home = _flat_home_of(self, params)
             flat_g = _home_stand_in(self, z.device) if home is not None else torch.cat([p.reshape(-1) for p in params])
             return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF, home)
-        if prologue is None and self._few(z.shape[0]):
+        if prologue is None and self._few(z.shape[0], mask is not None):
             flat, image, split = self._packed(z.device, images=False)[0], None, None
         else:
             flat, image, split = self._packed3(z.device)
