@@ -180,7 +180,7 @@ class _MnfKlFn(torch.autograd.Function):
         _lib.check("mnf_mnf_kl_fwd", lib.mnf_mnf_kl_fwd(*[ptr(t) for t in ops], int(conv), rows, cols, n_bias,
                                                        out.data_ptr(), saved.data_ptr(), _stream()))
         ctx.ops, ctx.saved_acts, ctx.shape = ops, saved, (int(conv), rows, cols, n_bias)
-        ctx.like = (z, log_det_q, z_r, log_det_r)
+        ctx.like = tuple(tuple(t.shape) for t in (z, log_det_q, z_r, log_det_r))  # (shapes only: no references kept)
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.home = _flows._flat_home_of(module, list(params)) if all(p.requires_grad for p in params) else None
         return out
@@ -207,8 +207,7 @@ class _MnfKlFn(torch.autograd.Function):
             ctx.saved_acts.data_ptr(), g.data_ptr(), conv, rows, cols, n_bias, grads.data_ptr(), pg.data_ptr(),
             int(home is not None), _stream()))
         gz, gzr, gldq, gldr = torch.split(grads, [cols, cols, 1, 1])
-        head = (gz.view_as(z_in), gldq.view_as(ldq_in), gzr.view_as(zr_in), gldr.view_as(ldr_in), None, None, None, None,
-                None)
+        head = (gz.view(z_in), gldq.view(ldq_in), gzr.view(zr_in), gldr.view(ldr_in), None, None, None, None, None)
         if home is not None:
             return head + (None,) * len(ctx.param_shapes)
         sizes = [math.prod(sh) for sh in ctx.param_shapes]

@@ -175,7 +175,8 @@ class GraphedStep:
     inside the graph).  Everything the step decides on the host is frozen at capture time: batch shapes, kernel
     choices, host-drawn random numbers.  RNVP layers therefore draw their masks on the device while the step is
     warmed up and recorded (``flows.device_drawn_masks``: torch.bernoulli, the reference's own draw, redrawn by every
-    replay like torch.randn is) instead of hashing a host-drawn seed in the kernel.  Glow captures too: its
+    replay like torch.randn is) instead of hashing a host-drawn seed in the kernel, and ``MNFLinear.forward`` draws its
+    output noise with torch.randn instead of seeding the in-kernel generator from the host, for the same reason.  Glow captures too: its
     permutation sits on the device once, and its training-path inverse is torch.linalg.inv_ex (no host-side
     singularity check).  If eager steps ran before, drop their loss tensors first (``del loss``): a live loss keeps that step's autograd
     graph, and with it gradient-accumulation nodes bound to the default stream, alive into the capture."""
