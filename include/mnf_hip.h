@@ -230,6 +230,16 @@ int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* strea
  * MNF_RNVP_FEW=0 in the environment switches both off. */
 #define MNF_RNVP_FEW_ROWS 2
 #define MNF_RNVP_FEW_FWD_ROWS 512
+#define MNF_RNVP_FEW_BWD_ROWS 512
+/* The gradient kernel of the same family as a grid for batch-sized calls (3 .. MNF_RNVP_FEW_BWD_ROWS rows; the reference
+ * trains at 128): a workgroup per two rows WRITES its copy of the parameter gradients to `workspace`
+ * (mnf_rnvp_bwd_few_workspace_floats(...) floats; 0 = shape or row count not covered) and a second launch adds the
+ * copies to grad_flat (ADDED to, as in mnf_rnvp_bwd; grad_z written).  128 rows of 800 dims: ~85 us against ~190 for the
+ * three matrix-core launches, whose first is one workgroup's two sweeps over all dims at that size. */
+int64_t mnf_rnvp_bwd_few_workspace_floats(int64_t rows, int dim, int n_hidden, const int* hidden_host);
+int mnf_rnvp_bwd_few(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                     float* grad_z, float* grad_flat, const float* flat, float* workspace, int64_t rows, int dim,
+                     int n_hidden, const int* hidden_host, void* stream);
 /* 1 when mnf_rnvp_seeded takes that kernel for this shape (the caller then needs no operand image for the forward call). */
 int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host, int explicit_mask);
 /* MNFLinear.sample_z's prologue fused into its first flow (torch_mnf/layers/mnf_linear.py:58-64):

@@ -11,7 +11,7 @@ from test_hip_round3 import _check_grads, _rnvp_gpu_grads, _rnvp_oracle_grads
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 # (gradients at 3 rows: past the one-workgroup kernel -- the streaming kernels, same checks; hidden 70: wider than a
-#  wave, ditto.  The forward kernel also runs as a grid, a workgroup per two rows: FWD_SHAPES adds batch-sized cases.)
+#  wave, ditto.  Both kernels also run as a grid, a workgroup per two rows: FWD_SHAPES / GRID_SHAPES add batch-sized cases.)
 SHAPES = [(800, 50, 1), (800, 50, 2), (800, 50, 3), (50, 50, 1), (20, 50, 1), (20, 50, 2), (784, 30, 2), (33, 7, 1),
           (1100, 64, 2), (2, 16, 1), (96, 70, 1)]
 
@@ -84,6 +84,55 @@ def test_few_rows_gradients_vs_float64_oracle(amd, O, dim, hid, rows):
         if rows <= 2 and hid <= 64:
             assert torch.equal(got[k], again[k]), f"{k}: the few-rows gradient kernel has no atomics, runs must repeat"
     print(f"few-rows rnvp gradients d={dim} h={hid} rows={rows}: worst {worst:.2e} from float64")
+
+
+GRID_SHAPES = [(800, 50, 3), (800, 50, 128), (800, 50, 129), (50, 50, 128), (20, 50, 300), (784, 30, 512), (33, 7, 65)]
+
+
+@pytest.mark.parametrize("dim,hid,rows", GRID_SHAPES)
+@pytest.mark.parametrize("masked", ["explicit", "seeded"])
+def test_few_rows_gradient_grid_vs_float64_oracle(amd, O, dim, hid, rows, masked):
+    """Batch-sized gradient calls (3 .. 512 rows): ``mnf_rnvp_bwd_few`` -- a workgroup per two rows writing its own copy
+    of the parameter gradients, one reduction launch.  Against autograd through the float64 oracle, against the
+    streaming gradient kernels, bit-for-bit repeatable (no atomics), and ADDING to what the gradient buffer holds."""
+    import torch_mnf_amd.flows as fl
+
+    sd = recipes.rnvp_params(6100 + dim + hid, dim, hid)
+    z = recipes.gaussian(6200 + dim, rows, dim)
+    w_x = recipes.gaussian(6300 + dim, rows, dim)
+    w_l = recipes.gaussian(6400 + dim, rows, 1)[:, 0]
+    probe = amd.RNVP(dim, h_sizes=(hid,))
+    seed = 31 + dim
+    mask = recipes.bernoulli_mask(6500 + dim, rows, dim) if masked == "explicit" else probe.mask_for(seed, rows).cpu()
+    kw = (mask, None) if masked == "explicit" else (None, seed)
+    assert amd._lib.load().mnf_rnvp_bwd_few_workspace_floats(rows, dim, 1, probe._hid) > 0
+    g32, g64 = _rnvp_oracle_grads(O, sd, z, mask, w_x, w_l)
+    f, got = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, *kw)
+    worst = _check_grads(got, g32, g64, f"few-rows grid rnvp d={dim} h={hid} rows={rows} {masked}")
+    _, again = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, *kw)
+    for k in got:
+        assert torch.equal(got[k], again[k]), k
+    fl._RNVP_BWD_FEW_GRID_OFF = True
+    try:
+        _, streaming = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, *kw)
+    finally:
+        fl._RNVP_BWD_FEW_GRID_OFF = False
+    for k in got:
+        assert_close(got[k], streaming[k], 2e-5, f"grid vs streaming gradient kernels: {k}")
+    # a second backward pass adds to the first (FlatParameters home: in place)
+    homed = amd.RNVP(dim, h_sizes=(hid,))
+    homed.load_state_dict(sd)
+    homed.to(DEV)
+    flat = amd.FlatParameters(homed)
+    for n in (1, 2):
+        x, ld = homed.forward(z.to(DEV), mask=None if kw[0] is None else kw[0].to(DEV), seed=kw[1])
+        ((x * w_x.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
+        if n == 1:
+            once = flat.grad.clone()
+    assert_close(flat.grad, 2 * once, 1e-6, "two passes into the flat gradient buffer")
+    for name, p in homed.named_parameters():
+        assert_close(p.grad / 2, got[name], 1e-6, f"flat-home gradient {name}")
+    print(f"few-rows grid gradients d={dim} h={hid} rows={rows} {masked}: worst {worst:.2e} from float64")
 
 
 @pytest.mark.parametrize("which", ["x_only", "ld_only"])

@@ -221,6 +221,7 @@ def _mfma_gradient_path_at_every_size(monkeypatch):
 
     monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_ROWS", 0)
     monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_DIM", 0)
+    monkeypatch.setattr(fl, "_RNVP_BWD_FEW_GRID_OFF", True)  # (batches of <= 512 rows otherwise take mnf_rnvp_bwd_few)
 
 
 def _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask=None, seed=None, generic=False):

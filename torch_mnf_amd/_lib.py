@@ -141,6 +141,9 @@ SIGNATURES = {
                         c_void_p]),
     "mnf_maf_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                             c_int, c_int, c_int, _intp, c_void_p]),
+    "mnf_rnvp_bwd_few_workspace_floats": (c_int64, [c_int64, c_int, c_int, _intp]),
+    "mnf_rnvp_bwd_few": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_few_rows_ok": (c_int, [c_int64, c_int, c_int, _intp, c_int]),
     "mnf_mnf_kl_saved_floats": (c_int64, [c_int64]),
     "mnf_mnf_kl_grad_floats": (c_int64, [c_int]),

@@ -1028,7 +1028,7 @@ int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* 
                  float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int n_hidden,
                  const int* hidden, void* stream) {
   if (z && grad_z && flat && hidden && mnf::rnvp_few_ok(rows, dim, n_hidden, hidden))
-    return mnf::rnvp_few_bwd_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, hidden[0],
+    return mnf::rnvp_few_bwd_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, nullptr, rows, dim, hidden[0],
                                     (hipStream_t)stream);
   return mnf::rnvp_bwd_generic_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, rows, dim, n_hidden, hidden,
                                       nullptr, 0, (hipStream_t)stream);

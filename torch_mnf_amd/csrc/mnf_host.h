@@ -133,8 +133,8 @@ bool rnvp_few_fwd_ok(int64_t rows, int dim, int n_hidden, const int* hidden, boo
 int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
                         const float* flat, int64_t rows, int dim, int hid, hipStream_t stream);
 int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
-                        float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int hid,
-                        hipStream_t stream);
+                        float* grad_z, float* grad_flat, const float* flat, float* partial, int64_t rows, int dim,
+                        int hid, hipStream_t stream);
 
 // one 32-bit word := 0 on the stream, as a KERNEL node (mnf_generic.hip).  A 4-byte hipMemsetAsync in front of a kernel
 // that counts into the word was fine eagerly but, recorded in a hipGraph, faulted after ~100 replays of the MNF-LeNet

@@ -30,6 +30,7 @@ constexpr int kFewWaves = kFewThreads / 64;
 constexpr int kFewRows = MNF_RNVP_FEW_ROWS;
 constexpr int kFewFwdRows = MNF_RNVP_FEW_FWD_ROWS;
 constexpr int kFewFwdRowsSeeded = 64;
+constexpr int kFewBwdRows = MNF_RNVP_FEW_BWD_ROWS;
 constexpr int kFewLdsFloats = 36 * 1024;  // 144 KB
 
 struct RnvpFewArgs {
@@ -46,6 +47,8 @@ struct RnvpFewArgs {
   const float* flat;
   int rows, dim, hid;
   int64_t row0;  // absolute index of this workgroup's first row (the in-kernel mask is a function of it)
+  float* partial;  // gradients launched as a grid: workgroup w WRITES its parameter gradients to partial + w * n_par
+  int64_t n_par;
 };
 
 // Sum over the wave, returned to every lane, on the DPP path (row-internal butterflies, row broadcasts, one readlane): 9
@@ -227,9 +230,25 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_fwd_kernel(const RnvpFew
   }
 }
 
+// Launched as a grid (a workgroup per R rows) for batch-sized calls, every workgroup WRITES its own copy of the parameter
+// gradients (each parameter exactly once: no zeroing, no read-modify-write) and rnvp_few_reduce_kernel adds the copies
+// to grad_flat; launched as one workgroup it adds to grad_flat itself.
 template <int R>
-__global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFewArgs a) {
+__global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFewArgs a_in) {
   extern __shared__ float few_lds[];
+  RnvpFewArgs a = a_in;
+  const bool rmw = a_in.partial == nullptr;  // add to what the buffer holds (one workgroup) or write (grid)
+  {
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    a.row0 = row0;
+    a.rows = (int)min((int64_t)R, (int64_t)a_in.rows - row0);
+    a.z += row0 * a.dim;
+    a.grad_z += row0 * a.dim;
+    if (a.mask) a.mask += row0 * a.dim;
+    if (a.grad_x) a.grad_x += row0 * a.dim;
+    if (a.grad_ld) a.grad_ld += row0;
+    if (a_in.partial) a.grad_flat = a_in.partial + (int64_t)blockIdx.x * a_in.n_par;
+  }
   const int d = a.dim, h = a.hid, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* kept = few_lds;                  // [R][d]
   float* g_t = kept + R * d;              // [R][d]  shift (pass A), then its cotangent (pass B)
@@ -266,8 +285,8 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
       sum_s += gs;
     }
     if (gf) {
-      gf[tb + j] += sum_t;
-      gf[sb + j] += sum_s;
+      gf[tb + j] = (rmw ? gf[tb + j] : 0.f) + sum_t;
+      gf[sb + j] = (rmw ? gf[sb + j] : 0.f) + sum_s;
     }
   }
   __syncthreads();
@@ -289,8 +308,8 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
         const bool in = kin && j < d;
         wt[u] = in ? Wt[(size_t)j * h + lane] : 0.f;
         ws[u] = in ? Ws[(size_t)j * h + lane] : 0.f;
-        ot[u] = in && gf ? gf[tw + (size_t)j * h + lane] : 0.f;
-        os[u] = in && gf ? gf[sw + (size_t)j * h + lane] : 0.f;
+        ot[u] = in && gf && rmw ? gf[tw + (size_t)j * h + lane] : 0.f;
+        os[u] = in && gf && rmw ? gf[sw + (size_t)j * h + lane] : 0.f;
       }
     };
     auto work = [&](const float (&wt)[JC], const float (&ws)[JC], const float (&ot)[JC], const float (&os)[JC], int j0) {
@@ -336,7 +355,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) sum += dA[r * h + tid];
-    gf[b1o + tid] += sum;
+    gf[b1o + tid] = (rmw ? gf[b1o + tid] : 0.f) + sum;
   }
   // d W1[k][j] = sum_r g_y[r][k] kept[r][j];  g_kept[r][j] = sum_k W1[k][j] g_y[r][k]: threads (unit group, dim),
   // reads and writes along the dims; a narrow layer spreads the hidden units over the groups
@@ -356,7 +375,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
         for (int u = 0; u < 8; ++u) {
           const int k = k0 + groups * u;
           w[u] = k < h ? a.flat[w1 + (size_t)k * d + j] : 0.f;
-          old[u] = k < h && gf ? gf[w1 + (size_t)k * d + j] : 0.f;
+          old[u] = k < h && gf && rmw ? gf[w1 + (size_t)k * d + j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -392,6 +411,23 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
       }
     }
   }
+}
+
+// grad_flat[i] += sum over the workgroups' copies (coalesced: consecutive threads, consecutive parameters)
+__global__ void __launch_bounds__(256) rnvp_few_reduce_kernel(const float* __restrict__ partial, int n_copies, int64_t n_par,
+                                                              float* __restrict__ grad_flat) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_par) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= n_copies; c += 4) {
+    s0 += partial[(int64_t)c * n_par + i];
+    s1 += partial[(int64_t)(c + 1) * n_par + i];
+    s2 += partial[(int64_t)(c + 2) * n_par + i];
+    s3 += partial[(int64_t)(c + 3) * n_par + i];
+  }
+  for (; c < n_copies; ++c) s0 += partial[(int64_t)c * n_par + i];
+  grad_flat[i] += (s0 + s1) + (s2 + s3);
 }
 
 static inline int few_rows_class(int64_t rows) { return rows <= 1 ? 1 : 2; }
@@ -434,7 +470,8 @@ static int few_attr(K kernel) {
 
 int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
                         const float* flat, int64_t rows, int dim, int hid, hipStream_t stream) {
-  RnvpFewArgs a{z, mask, seed, x, log_det, accumulate, nullptr, nullptr, nullptr, nullptr, flat, (int)rows, dim, hid, 0};
+  RnvpFewArgs a{z, mask, seed, x, log_det, accumulate, nullptr, nullptr, nullptr, nullptr, flat, (int)rows, dim, hid, 0,
+                nullptr, 0};
   const int R = few_rows_class(rows);
   const unsigned grid = (unsigned)((rows + R - 1) / R);
   const size_t lds = (3 * (size_t)R * dim + (size_t)R * hid + kFewWaves * R) * sizeof(float);
@@ -450,11 +487,28 @@ int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float*
   return check_launch();
 }
 
+static inline int64_t few_n_par(int dim, int hid) { return 3 * (int64_t)hid * dim + hid + 2 * (int64_t)dim; }
+
+// gradients as a grid: up to MNF_RNVP_FEW_BWD_ROWS rows (environment variable of that name overrides)
+bool rnvp_few_bwd_grid_ok(int64_t rows, int dim, int n_hidden, const int* hidden) {
+  static const int64_t max_rows = [] {
+    const char* e = getenv("MNF_RNVP_FEW_BWD_ROWS");
+    const long v = e ? atol(e) : 0;
+    return (int64_t)(v > 0 ? v : kFewBwdRows);
+  }();
+  return rows > kFewRows && few_shape_ok(rows, max_rows, dim, n_hidden, hidden);
+}
+
+// partial == nullptr: one workgroup (rows <= 2) adding to grad_flat; else a workgroup per two rows writing its copy
+// of the parameter gradients to partial, summed into grad_flat by a second launch
 int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
-                        float* grad_z, float* grad_flat, const float* flat, int64_t rows, int dim, int hid,
-                        hipStream_t stream) {
-  RnvpFewArgs a{z, mask, seed, nullptr, nullptr, 0, grad_x, grad_ld, grad_z, grad_flat, flat, (int)rows, dim, hid, 0};
-  const int R = few_rows_class(rows);
+                        float* grad_z, float* grad_flat, const float* flat, float* partial, int64_t rows, int dim,
+                        int hid, hipStream_t stream) {
+  const int64_t n_par = few_n_par(dim, hid);
+  RnvpFewArgs a{z, mask, seed, nullptr, nullptr, 0, grad_x, grad_ld, grad_z, grad_flat, flat, (int)rows, dim, hid, 0,
+                grad_flat ? partial : nullptr, n_par};
+  const int R = partial ? 2 : few_rows_class(rows);
+  const unsigned grid = partial ? (unsigned)((rows + 1) / 2) : 1u;
   const size_t lds = (3 * (size_t)R * dim + 2 * (size_t)R * hid + (size_t)R * 1024) * sizeof(float);
   static DeviceMemo attrs;
   if (attrs.get([&](int) {
@@ -462,14 +516,34 @@ int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const 
       }) < 0)
     return MNF_ERR_LAUNCH;
   switch (R) {
-    case 1: hipLaunchKernelGGL(rnvp_few_bwd_kernel<1>, dim3(1), dim3(kFewThreads), lds, stream, a); break;
-    default: hipLaunchKernelGGL(rnvp_few_bwd_kernel<2>, dim3(1), dim3(kFewThreads), lds, stream, a); break;
+    case 1: hipLaunchKernelGGL(rnvp_few_bwd_kernel<1>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
+    default: hipLaunchKernelGGL(rnvp_few_bwd_kernel<2>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
   }
-  return check_launch();
+  if (int rc = check_launch()) return rc;
+  if (partial && grad_flat) {
+    hipLaunchKernelGGL(rnvp_few_reduce_kernel, dim3((unsigned)((n_par + 255) / 256)), dim3(256), 0, stream, partial,
+                       (int)grid, n_par, grad_flat);
+    return check_launch();
+  }
+  return MNF_OK;
 }
 
 }  // namespace mnf
 
 extern "C" int mnf_rnvp_few_rows_ok(int64_t rows, int dim, int n_hidden, const int* hidden_host, int explicit_mask) {
   return mnf::rnvp_few_fwd_ok(rows, dim, n_hidden, hidden_host, explicit_mask != 0) ? 1 : 0;
+}
+
+extern "C" int64_t mnf_rnvp_bwd_few_workspace_floats(int64_t rows, int dim, int n_hidden, const int* hidden_host) {
+  if (!mnf::rnvp_few_bwd_grid_ok(rows, dim, n_hidden, hidden_host)) return 0;
+  return ((rows + 1) / 2) * mnf::few_n_par(dim, hidden_host[0]);
+}
+
+extern "C" int mnf_rnvp_bwd_few(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
+                                float* grad_z, float* grad_flat, const float* flat, float* workspace, int64_t rows, int dim,
+                                int n_hidden, const int* hidden_host, void* stream) {
+  if (!z || !grad_z || !flat || !workspace || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (!mnf::rnvp_few_bwd_grid_ok(rows, dim, n_hidden, hidden_host)) return MNF_ERR_UNSUPPORTED;
+  return mnf::rnvp_few_bwd_launch(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, workspace, rows, dim,
+                                  hidden_host[0], (hipStream_t)stream);
 }

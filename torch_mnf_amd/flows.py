@@ -43,6 +43,7 @@ _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # 
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
 # the matrix-core RNVP gradient pass from this many rows / dims on (d = 800: 227 vs 252 us at 128 rows, 284 vs 837 us at
 # 2,048; d = 50: the generic kernel stays ahead up to 32,768 rows)
+_RNVP_BWD_FEW_GRID_OFF = False  # (tests: the matrix-core / generic gradient kernels at every row count)
 _RNVP_BWD_MFMA_MIN_ROWS = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_ROWS", "64"))
 _RNVP_BWD_MFMA_MIN_DIM = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_DIM", "128"))
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
@@ -439,6 +440,16 @@ class _RnvpFn(torch.autograd.Function):
         # cover, the fp32 switches and force_generic take the generic kernel
         # (few rows or a narrow layer: the one-launch generic kernel is the faster one -- the matrix-core pass is four
         #  launches, the first a single workgroup's sweep over all dims: tools/time_rnvp_small.py)
+        # a batch of a few hundred rows (the reference trains at 128): the latency kernel as a grid, a workgroup per
+        # two rows writing its own copy of the parameter gradients, then one reduction launch
+        if not (m.force_generic or _RNVP_BWD_GENERIC_ENV or _RNVP_BWD_FEW_GRID_OFF):
+            n_ws = lib.mnf_rnvp_bwd_few_workspace_floats(z.shape[0], m.dim, len(m.h_sizes), m._hid)
+            if n_ws > 0:
+                ws = torch.empty(n_ws, dtype=torch.float32, device=z.device)
+                _lib.check("mnf_rnvp_bwd_few", lib.mnf_rnvp_bwd_few(
+                    z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
+                    flat.data_ptr(), ws.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
+                return grad_z, ret_flat, None, None, None, None
         small = z.shape[0] < _RNVP_BWD_MFMA_MIN_ROWS or m.dim < _RNVP_BWD_MFMA_MIN_DIM
         bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV or small) else m._bwd_image(z.device, flat)
         split = m._split_image(z.device) if bwd is not None else None
