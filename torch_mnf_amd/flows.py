@@ -1204,7 +1204,7 @@ class RNVP(_HipFlow):
         elif seed is None and _DEVICE_MASKS:
             # the reference's own draw (rnvp.py:28), on the device generator: unlike a host-drawn seed (a kernel
             # argument) it is redrawn by every replay of a captured hipGraph
-            mask = torch.bernoulli(torch.full_like(z, 0.5))
+            mask = torch.empty_like(z).bernoulli_(0.5)  # (one kernel; full_like + bernoulli would be two)
         elif seed is None:  # one draw from torch's global generator per call
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
         if want_grad and prologue is not None:
@@ -1996,7 +1996,13 @@ class NormalizingFlow(nn.Module):
         # a first layer whose kernel writes log_det for every row saves zero-filling it
         fresh = (bool(order) and isinstance(order[0], (AffineHalfFlow, FusedAffineStack)) and isinstance(x, Tensor)
                  and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and not _wants_grad(order[0], x))
-        log_det = torch.empty(x.size(0), device=x.device) if fresh else torch.zeros(x.size(0), device=x.device)
+        # a first layer on the autograd path returns its own per-row log_det: it BECOMES the running sum (no zero fill,
+        # no add -- two launches of a step that is made of launches)
+        lazy = (not fresh and bool(order) and isinstance(order[0], (RNVP, AffineHalfFlow, NSF_CL, NSF_AR, MAF))
+                and (not inverse or isinstance(order[0], _TwoWayFlow)) and run_at.get(0) is None and prologue is None
+                and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and _wants_grad(order[0], x))
+        log_det = None if lazy else (torch.empty(x.size(0), device=x.device) if fresh
+                                     else torch.zeros(x.size(0), device=x.device))
         seen = [x]
         self._last_sqnorm = None
         self._logprob_done = False
@@ -2059,7 +2065,7 @@ class NormalizingFlow(nn.Module):
                 elif isinstance(flow, _HipFlow) and (inverse is False or isinstance(flow, _TwoWayFlow)) \
                         and _wants_grad(flow, x):
                     x, ld = flow._run(x, inverse, None)    # autograd path: gradients from the *_bwd kernels
-                    log_det = log_det + ld
+                    log_det = ld if log_det is None else log_det + ld
                 elif prologue is not None and i == 0:
                     res = flow._run(x, inverse, log_det, prologue=prologue)
                     if res is None:  # no fused kernel after all: z0 by the formula, then the layer as usual
