@@ -569,7 +569,7 @@ def main_train_c5(args, rank, world, device, dim, rows, desc) -> None:
 
 
 def main_lenet(args, rank, world, device, dim, rows, desc) -> None:
-    """The MNF example model's training step at the reference's batch size (128): a launch-bound step -- 291 launches
+    """The MNF example model's training step at the reference's batch size (128): a launch-bound step -- ~250 launches
     of a few microseconds each -- recorded once in a hipGraph (train.GraphedStep) and replayed.  What the library
     contributes: kl_div as one launch each way per layer, the one-row flows on the latency kernels, every parameter
     gradient added in place to one buffer, one Adam launch.  The convolutions are stock MIOpen."""
@@ -632,7 +632,7 @@ def main_lenet(args, rank, world, device, dim, rows, desc) -> None:
         "eager_ms_per_step": eager_ms, "loss_first_step": first_loss, "loss_last_step": float(loss),
         "distributed": dist_info(1, "nccl", [elapsed], args.steps),
         "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                     "kernel": "(launch-bound: ~290 kernels of 3-130 us per step, no dominant one)", "avg_kernel_us": None},
+                     "kernel": "(launch-bound: ~250 kernels of 3-75 us per step, no dominant one)", "avg_kernel_us": None},
     }
     print(json.dumps(out))
 
