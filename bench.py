@@ -580,17 +580,14 @@ def main_lenet(args, rank, world, device, dim, rows, desc) -> None:
     import torch_mnf_amd as amd
 
     torch.manual_seed(0)
-    net = nn.Sequential(amd.MNFConv2d(1, 20, 5), nn.ReLU(), nn.MaxPool2d(2), amd.MNFConv2d(20, 50, 5), nn.ReLU(),
-                        nn.MaxPool2d(2), nn.Flatten(), amd.MNFLinear(800, 50), nn.ReLU(), amd.MNFLinear(50, 10),
-                        nn.LogSoftmax(dim=-1)).to(device)
+    net = amd.MNFLeNet().to(device)  # (models/mnf_lenet.py:8-33)
     opt = amd.FusedAdam(amd.FlatParameters(net), lr=1e-3, capturable=True)
     gen = torch.Generator(device=device).manual_seed(1357)
     x = torch.rand(rows, 1, 28, 28, device=device, generator=gen)
     y = torch.randint(0, 10, (rows,), device=device, generator=gen)
 
     def loss_fn(xb, yb):
-        kl = sum(m.kl_div() for m in net if hasattr(m, "kl_div"))
-        return nn.functional.nll_loss(net(xb), yb) + kl / 60000
+        return nn.functional.nll_loss(net(xb), yb) + net.kl_div() / 60000
 
     def eager():
         opt.zero_grad()

@@ -226,3 +226,37 @@ def test_flat_parameter_home_receives_the_gradients_in_place(amd, golden, kind):
     # autograd's own accumulation is left with the prologue (q0_mean, q0_log_var) and, for the convolution, the stock
     # F.conv2d weights: the flows' 24 tensors and the KL term's 8-9 no longer pass through it
     assert ops.get("aten::add_", 0) <= 8, ops.get("aten::add_")
+
+
+def test_mnf_lenet_trains_on_a_synthetic_ten_class_problem(amd):
+    """The reference's tests/test_mnf_mnist.py without the download: MNFLeNet, Adam, batches of 32, loss =
+    nll + 1e-3 kl_div, until the batch accuracy passes 0.95; validation accuracy > 0.8 ("just make sure it trains").
+    The images are ten fixed random 28 x 28 patterns plus noise."""
+    torch.manual_seed(0)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    protos = torch.rand(10, 1, 28, 28, device=DEV, generator=gen)
+
+    def batch(n):
+        y = torch.randint(0, 10, (n,), device=DEV, generator=gen)
+        return (protos[y] + 0.35 * torch.randn(n, 1, 28, 28, device=DEV, generator=gen)).clamp(0, 1), y
+
+    model = amd.MNFLeNet().to(DEV)
+    assert [type(m).__name__ for m in model][:4] == ["MNFConv2d", "ReLU", "MaxPool2d", "MNFConv2d"]
+    adam = torch.optim.Adam(model.parameters())
+    for _ in range(400):
+        x, y = batch(32)
+        adam.zero_grad()
+        preds = model(x)
+        loss = torch.nn.functional.nll_loss(preds, y) + model.kl_div() * 1e-3
+        loss.backward()
+        adam.step()
+        if float((y == preds.argmax(1)).float().mean()) > 0.95:
+            break
+    x_val, y_val = batch(500)
+    with torch.no_grad():
+        val_acc = float((y_val == model(x_val).argmax(1)).float().mean())
+    assert val_acc > 0.8, val_acc
+    ff = amd.MNFFeedForward([12, 16, 4]).to(DEV)
+    out = ff(torch.randn(9, 12, device=DEV))
+    assert out.shape == (9, 4) and torch.isfinite(ff.kl_div())
+    assert [type(m).__name__ for m in ff] == ["MNFLinear", "ReLU", "BatchNorm1d", "MNFLinear"]

@@ -9,7 +9,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 """
 from . import _lib
 from ._lib import MnfHipError
-from .layers import MNFConv2d, MNFLinear
+from .layers import MNFConv2d, MNFFeedForward, MNFLeNet, MNFLinear
 from .train import FlatParameters, FusedAdam, GraphedStep
 from .flows import (
     MLP,
@@ -34,7 +34,7 @@ from .flows import (
 
 __all__ = [
     "MLP", "MADE", "MaskedLinear", "MAF", "IAF", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
-    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "FlatParameters", "FusedAdam", "GraphedStep", "MnfHipError", "library_path",
+    "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "MNFLeNet", "MNFFeedForward", "FlatParameters", "FusedAdam", "GraphedStep", "MnfHipError", "library_path",
 ]
 
 

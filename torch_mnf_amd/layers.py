@@ -505,3 +505,31 @@ class MNFConv2d(nn.Module):
         return _MnfKlFn.apply(z, log_det_q, z_r, log_det_r, eps_w, eps_b, self, True, b_mean, self.W_mean,
                               self.W_log_var, self.b_log_var, self.q0_mean, self.q0_log_var, self.r0_c, self.r0_b1,
                               self.r0_b2)
+
+
+class MNFLeNet(nn.Sequential):
+    """The reference's Bayesian LeNet (models/mnf_lenet.py:8-33): the container the MNF layers are trained in
+    (tests/test_mnf_mnist.py).  ``kl_div()`` is the sum over the MNF layers, as there."""
+
+    def __init__(self, **kwargs) -> None:
+        super().__init__(MNFConv2d(1, 20, kernel_size=5, **kwargs), nn.ReLU(), nn.MaxPool2d(kernel_size=2),
+                         MNFConv2d(20, 50, kernel_size=5, **kwargs), nn.ReLU(), nn.MaxPool2d(kernel_size=2), nn.Flatten(),
+                         MNFLinear(50 * 16, 50, **kwargs), nn.ReLU(), MNFLinear(50, 10, **kwargs), nn.LogSoftmax(dim=-1))
+
+    def kl_div(self) -> Tensor:
+        return sum(layer.kl_div() for layer in self if hasattr(layer, "kl_div"))
+
+
+class MNFFeedForward(nn.Sequential):
+    """The reference's MNF multilayer perceptron (models/mnf_feed_forward.py:14-41): MNFLinear / activation /
+    BatchNorm1d blocks, the last activation and batch norm dropped."""
+
+    def __init__(self, layer_sizes, activation=nn.ReLU, **kwargs) -> None:
+        layers: list[nn.Module] = []
+        for s1, s2 in zip(layer_sizes, layer_sizes[1:]):
+            layers += [MNFLinear(s1, s2, **kwargs), activation(), nn.BatchNorm1d(s2)]
+        super().__init__(*layers[:-2])
+
+    def kl_div(self) -> Tensor:
+        return sum(layer.kl_div() for layer in self if hasattr(layer, "kl_div"))
+
