@@ -588,37 +588,74 @@ __global__ void sample_z0_kernel(const float* __restrict__ mean, const float* __
     z0[i] = mean[j] + sqrtf(expf(log_var[j])) * eps[i];  // mnf_linear.py:59-62
   }
 }
+// the same on 16-byte pieces (dim % 4 == 0, 16-byte aligned buffers): 1.64 GB of eps in, z0 out at 256,000 x 800
+__global__ void sample_z0_kernel_v4(const float* __restrict__ mean, const float* __restrict__ log_var,
+                                    const float4* __restrict__ eps, float4* __restrict__ z0, int64_t n4, int dim4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int j = 4 * (int)(i % dim4);
+    const float4 e = eps[i];
+    float4 o;
+    o.x = fmaf(sqrtf(expf(log_var[j])), e.x, mean[j]);
+    o.y = fmaf(sqrtf(expf(log_var[j + 1])), e.y, mean[j + 1]);
+    o.z = fmaf(sqrtf(expf(log_var[j + 2])), e.z, mean[j + 2]);
+    o.w = fmaf(sqrtf(expf(log_var[j + 3])), e.w, mean[j + 3]);
+    z0[i] = o;
+  }
+}
 
 // gradients of the prologue: d mean[j] = sum_r g[r][j];  d log_var[j] = sum_r g[r][j] eps[r][j] * 0.5 sqrt(exp(log_var[j])).
-// blockDim = (64 dims, 4 row lanes); a workgroup takes 64 dims and the rows blockIdx.y, blockIdx.y + gridDim.y, ... in
-// steps of 4, sums in registers, then over its 4 row lanes in LDS, and adds one value per dim to the outputs.
+// blockDim = (64 lanes, 4 row lanes); a lane owns VEC consecutive dims (VEC = 4: 16-byte loads, a wave reads 1 KB of a
+// row at a time -- with 4-byte loads the 1.64 GB pass ran at half the HBM rate); a workgroup takes 64 VEC dims and the
+// rows blockIdx.y, blockIdx.y + gridDim.y, ... in steps of 4, sums in registers, then over its 4 row lanes in LDS, and
+// adds one value per dim to the outputs.
+template <int VEC>
 __global__ void __launch_bounds__(256) sample_z0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ eps,
                                                             const float* __restrict__ log_var,
                                                             float* __restrict__ g_mean, float* __restrict__ g_log_var,
                                                             int64_t rows, int dim, int atomic) {
-  __shared__ float part[2][4][64];
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  float sm = 0.f, sv = 0.f;
-  if (j < dim) {
+  __shared__ float part[2][4][64 * VEC];
+  const int j0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
+  float sm[VEC], sv[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) sm[v] = sv[v] = 0.f;
+  if (j0 < dim) {  // (VEC = 4: dim % 4 == 0, so the whole piece is inside)
     for (int64_t r = (int64_t)blockIdx.y * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.y * 4) {
-      const float gv = g[r * dim + j];
-      sm += gv;
-      sv = fmaf(gv, eps[r * dim + j], sv);
+      float gv[VEC], ev[VEC];
+      if (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(g + r * dim + j0);
+        const float4 b = *reinterpret_cast<const float4*>(eps + r * dim + j0);
+        gv[0] = a.x, gv[VEC > 1 ? 1 : 0] = a.y, gv[VEC > 2 ? 2 : 0] = a.z, gv[VEC > 3 ? 3 : 0] = a.w;
+        ev[0] = b.x, ev[VEC > 1 ? 1 : 0] = b.y, ev[VEC > 2 ? 2 : 0] = b.z, ev[VEC > 3 ? 3 : 0] = b.w;
+      } else {
+        gv[0] = g[r * dim + j0];
+        ev[0] = eps[r * dim + j0];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        sm[v] += gv[v];
+        sv[v] = fmaf(gv[v], ev[v], sv[v]);
+      }
     }
   }
-  part[0][threadIdx.y][threadIdx.x] = sm;
-  part[1][threadIdx.y][threadIdx.x] = sv;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    part[0][threadIdx.y][threadIdx.x * VEC + v] = sm[v];
+    part[1][threadIdx.y][threadIdx.x * VEC + v] = sv[v];
+  }
   __syncthreads();
-  if (threadIdx.y == 0 && j < dim) {
-    sm = (part[0][0][threadIdx.x] + part[0][1][threadIdx.x]) + (part[0][2][threadIdx.x] + part[0][3][threadIdx.x]);
-    sv = (part[1][0][threadIdx.x] + part[1][1][threadIdx.x]) + (part[1][2][threadIdx.x] + part[1][3][threadIdx.x]);
-    sv *= 0.5f * sqrtf(expf(log_var[j]));
+  for (int c = threadIdx.y * 64 + threadIdx.x; c < 64 * VEC; c += 256) {
+    const int j = blockIdx.x * 64 * VEC + c;
+    if (j >= dim) continue;
+    const float m = (part[0][0][c] + part[0][1][c]) + (part[0][2][c] + part[0][3][c]);
+    float w = (part[1][0][c] + part[1][1][c]) + (part[1][2][c] + part[1][3][c]);
+    w *= 0.5f * sqrtf(expf(log_var[j]));
     if (atomic) {
-      atomicAdd(g_mean + j, sm);
-      atomicAdd(g_log_var + j, sv);
+      atomicAdd(g_mean + j, m);
+      atomicAdd(g_log_var + j, w);
     } else {  // one workgroup per dim block: plain adds, results repeat bit for bit
-      g_mean[j] += sm;
-      g_log_var[j] += sv;
+      g_mean[j] += m;
+      g_log_var[j] += w;
     }
   }
 }
@@ -1179,8 +1216,12 @@ int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* ep
   if (!q0_mean || !q0_log_var || !eps || !z0 || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   const int64_t n = rows * dim;
-  hipLaunchKernelGGL(sample_z0_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, q0_mean,
-                     q0_log_var, eps, z0, n, dim);
+  if (dim % 4 == 0 && !((reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(z0)) & 15))
+    hipLaunchKernelGGL(sample_z0_kernel_v4, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, q0_mean,
+                       q0_log_var, reinterpret_cast<const float4*>(eps), reinterpret_cast<float4*>(z0), n / 4, dim / 4);
+  else
+    hipLaunchKernelGGL(sample_z0_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, q0_mean,
+                       q0_log_var, eps, z0, n, dim);
   return check_launch();
 }
 
@@ -1189,11 +1230,17 @@ int mnf_sample_z0_bwd(const float* grad_z0, const float* eps, const float* q0_lo
   if (!grad_z0 || !eps || !q0_log_var || !grad_mean || !grad_log_var || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
   // enough workgroups to fill the chip once rows x dim is large; a single row block (no atomics) while it is small
-  const int dim_blocks = (dim + 63) / 64;
+  const bool vec = dim % 4 == 0 && !((reinterpret_cast<uintptr_t>(grad_z0) | reinterpret_cast<uintptr_t>(eps)) & 15);
+  const int per_block = vec ? 256 : 64;
+  const int dim_blocks = (dim + per_block - 1) / per_block;
   int64_t row_blocks = (rows * dim) / (64 * 1024);
   row_blocks = row_blocks < 1 ? 1 : row_blocks > 2048 / dim_blocks + 1 ? 2048 / dim_blocks + 1 : row_blocks;
-  hipLaunchKernelGGL(sample_z0_bwd_kernel, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
-                     grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0);
+  if (vec)
+    hipLaunchKernelGGL(sample_z0_bwd_kernel<4>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
+                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(sample_z0_bwd_kernel<1>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
+                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0);
   return check_launch();
 }
 
