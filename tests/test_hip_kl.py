@@ -260,3 +260,80 @@ def test_mnf_lenet_trains_on_a_synthetic_ten_class_problem(amd):
     out = ff(torch.randn(9, 12, device=DEV))
     assert out.shape == (9, 4) and torch.isfinite(ff.kl_div())
     assert [type(m).__name__ for m in ff] == ["MNFLinear", "ReLU", "BatchNorm1d", "MNFLinear"]
+
+
+def _kl_shape_case(amd, O, kind, n_in, n_out, k, seed, dtype_pairs=(torch.float32, torch.float64)):
+    """One layer of the given shape with random parameters and draws: (GPU kl, GPU grads), {dtype: (oracle kl, grads)}."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, scale=1.0: scale * torch.randn(*s, generator=g)
+    dim = n_in if kind == "linear" else n_out
+    w_shape = (n_out, n_in) if kind == "linear" else (n_out, n_in, k, k)
+    p = {"W_mean": rn(*w_shape, scale=0.3), "W_log_var": -5 + rn(*w_shape, scale=0.5), "b_log_var": -4 + rn(n_out, scale=0.5),
+         "q0_mean": 1 + rn(dim, scale=0.2), "q0_log_var": -4 + rn(dim, scale=0.3), "r0_c": rn(dim, scale=0.4),
+         "r0_b1": rn(dim, scale=0.3), "r0_b2": rn(dim, scale=0.3)}
+    if kind == "linear":
+        p["b_mean"] = rn(n_out, scale=0.3)
+    flows = {w: [recipes.rnvp_params(seed + 10 * i + (5 if w == "r" else 0), dim, 50) for i in range(2)] for w in "qr"}
+    masks = {w: [recipes.bernoulli_mask(seed + 100 + 10 * i + (5 if w == "r" else 0), 1, dim) for i in range(2)] for w in "qr"}
+    eps_z = rn(1, dim)
+    rows = n_out if kind == "linear" else n_in * k * k
+    eps_w = rn(n_out, n_in) if kind == "linear" else rn(rows)
+    eps_b = rn(())
+    layer = amd.MNFLinear(n_in, n_out) if kind == "linear" else amd.MNFConv2d(n_in, n_out, k)
+    layer.load_state_dict(p, strict=False)
+    for w, flow in (("q", layer.flow_q), ("r", layer.flow_r)):
+        for i, f in enumerate(flow.flows):
+            f.load_state_dict(flows[w][i])
+    layer.to(DEV)
+    noise = {"eps_z": (eps_z if kind == "linear" else eps_z[0]).to(DEV), "masks_q": [m.to(DEV) for m in masks["q"]],
+             "eps_w": eps_w.to(DEV), "masks_r": [m.to(DEV) for m in masks["r"]]}
+    if kind == "conv":
+        noise["eps_b"] = eps_b.to(DEV)
+    kl = layer.kl_div(noise)
+    kl.backward()
+    got = {n: q.grad.detach().cpu().double() for n, q in layer.named_parameters()}
+    ref = {}
+    for dt in dtype_pairs:
+        pp = {k_: v.to(dt).clone().requires_grad_(True) for k_, v in p.items()}
+        specs = {w: [{"kind": "rnvp", "mask": masks[w][i].to(dt),
+                      "params": {k_: v.to(dt).clone().requires_grad_(True) for k_, v in flows[w][i].items()}}
+                     for i in range(2)] for w in "qr"}
+        if kind == "linear":
+            z, ldq = O.sample_z(pp["q0_mean"], pp["q0_log_var"], eps_z.to(dt), specs["q"])
+            val = O.mnf_linear_kl(pp, z, ldq, eps_w.to(dt), specs["r"])
+        else:
+            z, ldq = O.mnf_conv2d_sample_z(pp["q0_mean"], pp["q0_log_var"], eps_z[0].to(dt), specs["q"])
+            val = O.mnf_conv2d_kl(pp, z, ldq, eps_w.to(dt), eps_b.to(dt), specs["r"])
+        val.backward()
+        grads = {k_: v.grad for k_, v in pp.items()}
+        for w, name in (("q", "flow_q"), ("r", "flow_r")):
+            for i in range(2):
+                grads.update({f"{name}.flows.{i}.{k_}": v.grad for k_, v in specs[w][i]["params"].items()})
+        ref[dt] = (float(val.detach()), grads)
+    return float(kl.detach()), got, ref
+
+
+@pytest.mark.parametrize("kind,n_in,n_out,k", [("linear", 1100, 3, 0), ("linear", 7, 64, 0), ("linear", 129, 17, 0),
+                                               ("linear", 1, 5, 0), ("conv", 3, 70, 3), ("conv", 1, 6, 1),
+                                               ("conv", 5, 9, 2), ("conv", 2, 130, 5)])
+def test_kl_kernel_shapes(amd, O, kind, n_in, n_out, k):
+    """Shapes off the reference models' beaten path: more than 1,024 columns (the kernels loop over column tiles), fewer
+    columns than a wave, one input, more channels than a wave, 1 x 1 filters.  Value and every gradient against the
+    float64 oracle, the activation-side gradients' bar carrying the condition number of d kl / d abar where it is
+    large (see COND_BARS)."""
+    seed = 7000 + 13 * n_in + n_out + k
+    kl, got, ref = _kl_shape_case(amd, O, kind, n_in, n_out, k, seed)
+    kl64, g64 = ref[torch.float64]
+    kl32, g32 = ref[torch.float32]
+    assert abs(kl - kl64) <= 1e-5 * abs(kl64) + 2 * abs(kl32 - kl64)
+    for name, r64 in g64.items():
+        if name not in got or r64 is None:
+            continue
+        r = r64.numpy()
+        if not np.any(r):
+            assert not np.any(got[name].numpy().reshape(r.shape)), name
+            continue
+        widen = 2 * normwise_err(g32[name].double().numpy(), r)
+        err = normwise_err(got[name].numpy().reshape(r.shape), r)
+        # the fp32 oracle's own distance already reflects the conditioning of this draw: allow a few of them
+        assert err <= GBASE + 3 * widen, f"{kind} ({n_in}, {n_out}, {k}) {name}: {err:.2e} > 1e-5 + 3 x {widen / 2:.2e}"

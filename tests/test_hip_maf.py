@@ -164,3 +164,42 @@ def test_maf_in_a_flat_parameter_buffer_and_errors(amd):
         plain.forward(torch.zeros(3, 5, device=DEV))
     y, ld = plain.forward(torch.zeros(0, 4, device=DEV))
     assert y.shape == (0, 4) and ld.shape == (0,)
+
+
+@pytest.mark.parametrize("dim,h_sizes,rows", [(64, (32, 32), 70), (40, (128,), 33), (3, (5,), 257), (96, (24, 24, 24), 65),
+                                              (2, (200, 100), 40)])
+@pytest.mark.parametrize("parity", [False, True])
+def test_maf_wide_and_odd_shapes(amd, O, dim, h_sizes, rows, parity):
+    """Nets wider than the reference's defaults: fewer rows per workgroup than lanes (the activation slots of 64 rows do
+    not fit LDS), hidden layers wider than the input, a ragged last workgroup.  Both directions and their gradients
+    against the oracle (float64 for the gradients)."""
+    sd = recipes.maf_params(1900 + dim, dim, h_sizes, gain=1.2, last_gain=0.5)
+    masks = O.made_masks(dim, h_sizes, 2 * dim)
+    layer = amd.MAF(dim, parity=parity, h_sizes=h_sizes)
+    layer.load_state_dict(sd, strict=False)
+    layer.to(DEV)
+    x = recipes.gaussian(1901 + dim, rows, dim)
+    w_y, w_l = recipes.gaussian(1902 + dim, rows, dim), recipes.gaussian(1903 + dim, rows, 1)[:, 0]
+    for inverse in (True, False):
+        xx = x.to(DEV).requires_grad_(True)
+        y, ld = layer.inverse(xx) if inverse else layer.forward(xx)
+        y_ref, ld_ref = O.maf(x, sd, masks, parity, inverse)
+        y64, _ = O.maf(x.double(), {k: v.double() for k, v in sd.items()}, masks, parity, inverse)
+        assert_parity(y, y_ref.numpy(), y64.numpy(), what=f"MAF d={dim} h={h_sizes} inverse={inverse}")
+        assert_close(ld, ld_ref, 5e-5, "log_det")
+        layer.zero_grad()
+        ((y * w_y.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
+        got = {"x": xx.grad, **{n: p.grad.clone() for n, p in layer.named_parameters()}}
+        ref = {}
+        for dt in (torch.float32, torch.float64):
+            p = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+            xr = x.to(dt).clone().requires_grad_(True)
+            yy, ll = O.maf(xr, p, masks, parity, inverse)
+            ((yy * w_y.to(dt)).sum() + (ll * w_l.to(dt)).sum()).backward()
+            ref[dt] = {"x": xr.grad, **{k: v.grad for k, v in p.items()}}
+        for k, r64 in ref[torch.float64].items():
+            if float(r64.abs().max()) == 0.0:
+                continue
+            widen = 2 * normwise_err(ref[torch.float32][k].double().numpy(), r64.numpy())
+            err = normwise_err(got[k].detach().cpu().double().numpy(), r64.numpy())
+            assert err <= 1e-5 + 2 * widen, f"MAF d={dim} h={h_sizes} inverse={inverse} grad {k}: {err:.2e} vs {widen:.2e}"

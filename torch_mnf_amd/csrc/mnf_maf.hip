@@ -42,6 +42,8 @@ struct MafArgs {
   int sizes[MNF_MAX_LINEAR + 1];   // dim, hidden..., 2 dim
   int w_off[MNF_MAX_LINEAR], b_off[MNF_MAX_LINEAR], m_off[MNF_MAX_LINEAR], a_off[MNF_MAX_LINEAR + 1];
   int n_par, act_floats, maxw;
+  int rows_per_block;  // rows (= LDS activation slots) per workgroup; blockDim is this rounded up to whole waves
+  int lds_grads;       // the workgroup sums the parameter gradients in LDS first (else: one global atomic per wave)
 };
 
 template <int CTRL, int ROW_MASK = 0xf>
@@ -95,12 +97,12 @@ __device__ __forceinline__ void maf_eval(const MafArgs& a, const float* wm, floa
 
 __global__ void __launch_bounds__(256) maf_fwd_kernel(const MafArgs a) {
   extern __shared__ float maf_lds[];
-  const int T = blockDim.x, tid = threadIdx.x, d = a.dim;
+  const int T = a.rows_per_block, tid = threadIdx.x, d = a.dim;  // T rows per workgroup (<= blockDim: wide nets leave lanes idle)
   float* wm = maf_lds;
   float* act = wm + a.n_par;
   maf_stage(a, wm);
   const int64_t row = (int64_t)blockIdx.x * T + tid;
-  if (row >= a.rows) return;
+  if (tid >= T || row >= a.rows) return;
   const float* xr = a.x + row * d;
   float* yr = a.out + row * d;
   float* in0 = act + tid;
@@ -133,6 +135,7 @@ __global__ void __launch_bounds__(256) maf_fwd_kernel(const MafArgs a) {
 // g_in[unit * T + tid].  Weight / bias gradients: wave sums into gacc (LDS, flat layout).
 __device__ __forceinline__ void maf_backprop(const MafArgs& a, const float* wm, const float* act, float* dl, float* dl2,
                                              float* g_in, float* gacc, int T, bool live) {
+  // live: this lane has a row (and an LDS slot); lanes without one only take part in the wave sums
   const int tid = threadIdx.x, lane = tid & 63;
   float* cur = dl + tid;
   float* nxt = dl2 + tid;
@@ -154,13 +157,15 @@ __device__ __forceinline__ void maf_backprop(const MafArgs& a, const float* wm, 
       }
     }
     // cotangent of this layer's input (through the ReLU of the layer below, whose output it is)
-    for (int k = 0; k < n_in; ++k) {
-      float acc = 0.f;
-      for (int o = 0; o < n_out; ++o) acc = fmaf(W[o * n_in + k], cur[(size_t)o * T], acc);
-      if (l > 0)
-        nxt[(size_t)k * T] = in[(size_t)k * T] > 0.f ? acc : 0.f;
-      else
-        g_in[(size_t)k * T + tid] += acc;
+    if (live) {
+      for (int k = 0; k < n_in; ++k) {
+        float acc = 0.f;
+        for (int o = 0; o < n_out; ++o) acc = fmaf(W[o * n_in + k], cur[(size_t)o * T], acc);
+        if (l > 0)
+          nxt[(size_t)k * T] = in[(size_t)k * T] > 0.f ? acc : 0.f;
+        else
+          g_in[(size_t)k * T + tid] += acc;
+      }
     }
     float* t = cur;
     cur = nxt;
@@ -170,61 +175,65 @@ __device__ __forceinline__ void maf_backprop(const MafArgs& a, const float* wm, 
 
 __global__ void __launch_bounds__(256) maf_bwd_kernel(const MafArgs a) {
   extern __shared__ float maf_lds[];
-  const int T = blockDim.x, tid = threadIdx.x, d = a.dim;
+  const int T = a.rows_per_block, tid = threadIdx.x, d = a.dim;  // T rows (LDS slots) per workgroup, <= blockDim
   float* wm = maf_lds;
-  float* gacc = a.grad_flat ? wm + a.n_par : nullptr;
-  float* act = wm + (a.grad_flat ? 2 : 1) * a.n_par;
+  const bool lds_grads = a.grad_flat && a.lds_grads;
+  float* gacc = lds_grads ? wm + a.n_par : a.grad_flat;  // (a net too large for a second LDS copy: straight to memory)
+  float* act = wm + (lds_grads ? 2 : 1) * a.n_par;
   float* dl = act + (size_t)a.act_floats * T;
   float* dl2 = dl + (size_t)a.maxw * T;
   float* g_in = dl2 + (size_t)a.maxw * T;  // [dim][T]
-  if (gacc)
-    for (int i = tid; i < a.n_par; i += T) gacc[i] = 0.f;
+  if (lds_grads)
+    for (int i = tid; i < a.n_par; i += blockDim.x) gacc[i] = 0.f;
   maf_stage(a, wm);
   const int64_t row = (int64_t)blockIdx.x * T + tid;
-  const bool live = row < a.rows;
-  const int64_t rc = live ? row : a.rows - 1;
+  const bool live = tid < T && row < a.rows;  // lanes without a row keep out of LDS and add zeros to the wave sums
+  const int64_t rc = live ? row : 0;
   const float* xr = a.x + rc * d;
   float* in0 = act + tid;
   const float* st = act + (size_t)a.a_off[a.n_lin] * T + tid;
   const float gl = a.grad_ld && live ? a.grad_ld[rc] : 0.f;
   const int n_last = 2 * d;
   if (!a.sequential) {
-    for (int j = 0; j < d; ++j) {
-      in0[(size_t)j * T] = xr[j];
-      g_in[(size_t)j * T + tid] = 0.f;
-    }
-    maf_eval(a, wm, act, T, -1, -1);
-    for (int j = 0; j < d; ++j) {
-      const float gy = a.grad_y && live ? a.grad_y[rc * d + (a.parity ? d - 1 - j : j)] : 0.f;
-      const float e = expf(st[(size_t)j * T]);
-      dl[(size_t)j * T + tid] = live ? fmaf(gy * xr[j], e, gl) : 0.f;   // y = x e^s + t; log_det = sum s
-      dl[(size_t)(d + j) * T + tid] = live ? gy : 0.f;
-      g_in[(size_t)j * T + tid] = gy * e;
+    if (live) {
+      for (int j = 0; j < d; ++j) in0[(size_t)j * T] = xr[j];
+      maf_eval(a, wm, act, T, -1, -1);
+      for (int j = 0; j < d; ++j) {
+        const float gy = a.grad_y ? a.grad_y[rc * d + (a.parity ? d - 1 - j : j)] : 0.f;
+        const float e = expf(st[(size_t)j * T]);
+        dl[(size_t)j * T + tid] = fmaf(gy * xr[j], e, gl);   // y = x e^s + t; log_det = sum s
+        dl[(size_t)(d + j) * T + tid] = gy;
+        g_in[(size_t)j * T + tid] = gy * e;
+      }
     }
     maf_backprop(a, wm, act, dl, dl2, g_in, gacc, T, live);
     if (live)
       for (int j = 0; j < d; ++j) a.grad_x[row * d + j] = g_in[(size_t)j * T + tid];
   } else {
     const float* yr = a.y + rc * d;
-    for (int j = 0; j < d; ++j) {
-      in0[(size_t)j * T] = yr[j];
-      g_in[(size_t)j * T + tid] = a.grad_y && live ? a.grad_y[rc * d + j] : 0.f;  // G: cotangent of element j
+    if (live) {
+      for (int j = 0; j < d; ++j) {
+        in0[(size_t)j * T] = yr[j];
+        g_in[(size_t)j * T + tid] = a.grad_y ? a.grad_y[rc * d + j] : 0.f;  // G: cotangent of element j
+      }
+      maf_eval(a, wm, act, T, -1, -1);
     }
-    maf_eval(a, wm, act, T, -1, -1);
     for (int i = d - 1; i >= 0; --i) {
-      const float G = g_in[(size_t)i * T + tid];
-      const float e = expf(-st[(size_t)i * T]);
-      for (int o = 0; o < n_last; ++o) dl[(size_t)o * T + tid] = 0.f;
-      // x_i = (z_i - t_i) e^{-s_i}; log_det = -sum s_i
-      dl[(size_t)i * T + tid] = live ? -(G * yr[i]) - gl : 0.f;
-      dl[(size_t)(d + i) * T + tid] = live ? -(G * e) : 0.f;
-      if (live) a.grad_x[row * d + (a.parity ? d - 1 - i : i)] = G * e;
+      if (live) {
+        const float G = g_in[(size_t)i * T + tid];
+        const float e = expf(-st[(size_t)i * T]);
+        for (int o = 0; o < n_last; ++o) dl[(size_t)o * T + tid] = 0.f;
+        // x_i = (z_i - t_i) e^{-s_i}; log_det = -sum s_i
+        dl[(size_t)i * T + tid] = -(G * yr[i]) - gl;
+        dl[(size_t)(d + i) * T + tid] = -(G * e);
+        a.grad_x[row * d + (a.parity ? d - 1 - i : i)] = G * e;
+      }
       maf_backprop(a, wm, act, dl, dl2, g_in, gacc, T, live);
     }
   }
-  if (gacc) {
+  if (lds_grads) {
     __syncthreads();
-    for (int i = tid; i < a.n_par; i += T)
+    for (int i = tid; i < a.n_par; i += blockDim.x)
       if (gacc[i] != 0.f) atomicAdd(a.grad_flat + i, gacc[i]);
   }
 }
@@ -261,11 +270,10 @@ static int maf_fill(MafArgs& a, int dim, int n_hidden, const int* hidden) {
   return MNF_OK;
 }
 
-// threads per workgroup: the largest of 256 / 128 / 64 whose LDS need fits (0: none)
-static int maf_threads(int64_t fixed_floats, int64_t per_thread_floats) {
-  for (int t = 256; t >= 64; t /= 2)
-    if (fixed_floats + per_thread_floats * t <= kMafLdsFloats) return t;
-  return 0;
+// rows (LDS activation slots) per workgroup: as many as fit, at most 256 (0: not even one)
+static int maf_rows_per_block(int64_t fixed_floats, int64_t per_row_floats) {
+  const int64_t r = (kMafLdsFloats - fixed_floats) / per_row_floats;
+  return r < 1 ? 0 : r >= 256 ? 256 : r >= 128 ? 128 : r >= 64 ? 64 : (int)r;
 }
 
 }  // namespace mnf
@@ -297,8 +305,9 @@ int mnf_maf(const float* x, float* y, float* log_det, int accumulate, const floa
   if (rows == 0) return MNF_OK;
   a.x = x; a.out = y; a.log_det = log_det; a.accumulate = accumulate != 0; a.flat = flat; a.masks = masks;
   a.rows = rows; a.parity = parity != 0; a.sequential = sequential != 0;
-  const int T = maf_threads(a.n_par, a.act_floats);
+  const int T = maf_rows_per_block(a.n_par, a.act_floats);
   if (!T) return MNF_ERR_UNSUPPORTED;
+  a.rows_per_block = T;
   const size_t lds = ((size_t)a.n_par + (size_t)a.act_floats * T) * sizeof(float);
   static DeviceMemo attr;
   if (attr.get([&](int) {
@@ -308,7 +317,7 @@ int mnf_maf(const float* x, float* y, float* log_det, int accumulate, const floa
     return MNF_ERR_LAUNCH;
   const int64_t blocks = (rows + T - 1) / T;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(maf_fwd_kernel, dim3((unsigned)blocks), dim3(T), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(maf_fwd_kernel, dim3((unsigned)blocks), dim3((T + 63) / 64 * 64), lds, (hipStream_t)stream, a);
   return check_launch();
 }
 
@@ -322,10 +331,17 @@ int mnf_maf_bwd(const float* x, const float* y, const float* grad_y, const float
   if (rows == 0) return MNF_OK;
   a.x = x; a.y = y; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat; a.flat = flat;
   a.masks = masks; a.rows = rows; a.parity = parity != 0; a.sequential = sequential != 0;
-  const int64_t fixed = (int64_t)a.n_par * (grad_flat ? 2 : 1);
   const int64_t per_thread = (int64_t)a.act_floats + 2 * (int64_t)a.maxw + dim;
-  const int T = maf_threads(fixed, per_thread);
+  int64_t fixed = (int64_t)a.n_par * (grad_flat ? 2 : 1);
+  a.lds_grads = grad_flat != nullptr;
+  int T = maf_rows_per_block(fixed, per_thread);
+  if (T < 16 && grad_flat) {  // no room for the gradient copy next to a useful number of rows
+    fixed = a.n_par;
+    a.lds_grads = 0;
+    T = maf_rows_per_block(fixed, per_thread);
+  }
   if (!T) return MNF_ERR_UNSUPPORTED;
+  a.rows_per_block = T;
   const size_t lds = ((size_t)fixed + (size_t)per_thread * T) * sizeof(float);
   static DeviceMemo attr;
   if (attr.get([&](int) {
@@ -335,7 +351,7 @@ int mnf_maf_bwd(const float* x, const float* y, const float* grad_y, const float
     return MNF_ERR_LAUNCH;
   const int64_t blocks = (rows + T - 1) / T;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(maf_bwd_kernel, dim3((unsigned)blocks), dim3(T), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(maf_bwd_kernel, dim3((unsigned)blocks), dim3((T + 63) / 64 * 64), lds, (hipStream_t)stream, a);
   return check_launch();
 }
 
