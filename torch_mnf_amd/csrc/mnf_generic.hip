@@ -674,36 +674,45 @@ __global__ void pack_gather_kernel(const float* __restrict__ flat, const int32_t
 }
 
 // ---------------------------------------------------------------- pack: flat fp32 -> split image
-__global__ void pack_gather_split_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
+__global__ void __launch_bounds__(1024) pack_gather_split_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
                                          uint32_t* __restrict__ image, int64_t n_split, int64_t n_plain,
                                          int64_t flat_stride) {
   flat += (int64_t)blockIdx.y * flat_stride;
   image += (int64_t)blockIdx.y * (n_split + n_plain + MNF_SPLIT_TAIL_WORDS);
-  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float mx = 0.f;
-  if (w < n_split) {
-    uint32_t word = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_split + n_plain; w += stride) {
+    if (w < n_split) {
+      uint32_t word = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int32_t e = idx[2 * w + h];
-      if (e < 0) continue;
-      const float v = flat[e & (kSplitLoBit - 1)];
-      const _Float16 hi = (_Float16)v;
-      const _Float16 part = (e & kSplitLoBit) ? (_Float16)((v - (float)hi) * kSplitScale) : hi;
-      word |= (uint32_t)__builtin_bit_cast(uint16_t, part) << (16 * h);
-      mx = fmaxf(mx, fabsf(v));  // NaN weights: fmaxf drops them here, the MFMAs propagate them
-      if (!(fabsf(v) <= 3.0e38f)) mx = __builtin_inff();  // inf or NaN weight: always take the fp32 path
+      for (int h = 0; h < 2; ++h) {
+        const int32_t e = idx[2 * w + h];
+        if (e < 0) continue;
+        const float v = flat[e & (kSplitLoBit - 1)];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 part = (e & kSplitLoBit) ? (_Float16)((v - (float)hi) * kSplitScale) : hi;
+        word |= (uint32_t)__builtin_bit_cast(uint16_t, part) << (16 * h);
+        mx = fmaxf(mx, fabsf(v));  // NaN weights: fmaxf drops them here, the MFMAs propagate them
+        if (!(fabsf(v) <= 3.0e38f)) mx = __builtin_inff();  // inf or NaN weight: always take the fp32 path
+      }
+      image[w] = word;
+    } else {
+      const int32_t e = idx[2 * n_split + (w - n_split)];
+      image[w] = __builtin_bit_cast(uint32_t, e >= 0 ? flat[e] : (e == kPackBigBias ? kPackBigBiasValue : 0.f));
     }
-    image[w] = word;
-  } else if (w < n_split + n_plain) {
-    const int32_t e = idx[2 * n_split + (w - n_split)];
-    image[w] = __builtin_bit_cast(uint32_t, e >= 0 ? flat[e] : (e == kPackBigBias ? kPackBigBiasValue : 0.f));
   }
-  // one atomic per wave (every thread doing its own serialised on the one address: 17 us for a 100 k-word image, of
-  // which the gather itself is 3); non-negative floats order like their bit patterns
+  // ONE atomic per workgroup: the maxima all go to one address and same-address atomics serialise at the memory side
+  // (~7 ns each: with one per wave, 1,600 of them were 11 of the launch's 16 us at a 100 k-word image; with one per
+  // thread no better).  Non-negative floats order like their bit patterns.
+  __shared__ float wave_max[16];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) mx = fmaxf(mx, wave_max[wv]);
+    if (mx > 0.f) atomicMax(image + n_split + n_plain, __builtin_bit_cast(uint32_t, mx));
+  }
 }
 
 }  // namespace mnf
@@ -892,7 +901,7 @@ int mnf_pack_gather_split_batch(const float* flat, const int32_t* idx, void* ima
   hipLaunchKernelGGL(zero_tails_kernel, dim3(n_images), dim3(64), 0, (hipStream_t)stream, img + n, image_words);
   if (int rc = check_launch()) return rc;
   if (n == 0) return MNF_OK;
-  hipLaunchKernelGGL(pack_gather_split_kernel, dim3(grid_for(n, 256), n_images), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pack_gather_split_kernel, dim3(grid_for(n, 1024), n_images), dim3(1024), 0, (hipStream_t)stream,
                      flat, idx, img, n_split_words, n_plain_words, flat_stride);
   return check_launch();
 }
