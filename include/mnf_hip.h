@@ -61,7 +61,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 10
+#define MNF_ABI_VERSION 11
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -217,6 +217,15 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
+/* The training form of mnf_rnvp_seeded: when y_out != NULL and the kernel that takes the call can (the register-resident
+ * one: in-kernel mask, its shapes), it also writes y = net(mask * z) -- (rows, mnf_rnvp_y_floats_per_row(...)) floats,
+ * NaN for rows it recomputed in fp32 -- for mnf_rnvp_bwd_mfma_phases, and sets *y_written_host = 1; otherwise
+ * *y_written_host = 0 and y_out is untouched.  Everything else as mnf_rnvp_seeded. */
+int mnf_rnvp_y_floats_per_row(int n_hidden, const int* hidden_host);
+int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
+                          const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
+                          int n_hidden, const int* hidden_host, int force_generic, float* y_out, int* y_written_host,
+                          void* stream);
 /* Few rows through a layer with ONE hidden layer of at most 64 units take latency kernels (mnf_rnvp_few.hip) instead of
  * the streaming ones when `flat` is given and force_generic is 0: weight rows read coalesced by a wave per dim, DPP
  * wave sums, no operand image.
@@ -513,12 +522,16 @@ int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const fl
                       int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
 /* The same call with its launches selectable (measurements: HIP events around one of them): phases bit 0 the
  * row-parallel launch A, bit 1 launch B-ts (grad_z, dWt, dWs), bit 2 launch B-n (dWn), bit 3 the fp32 fix-up; the
- * phases of one backward pass must run in that order on one stream.  15 = mnf_rnvp_bwd_mfma. */
+ * phases of one backward pass must run in that order on one stream.  15 = mnf_rnvp_bwd_mfma.
+ * y: NULL, or the y = net(mask * z) the forward call kept (mnf_rnvp_seeded_train; rows x mnf_rnvp_y_floats_per_row
+ * floats): launch A then skips its own sweep over z that recomputes it (a third of the launch: the Adam step of
+ * MNFLinear(800, 50) at 256,000 rows 10.7 -> 10.1 ms).  Rows of NaN (row groups the forward pass recomputed in fp32)
+ * send their group to this call's fp32 fix-up. */
 int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, const float* grad_x,
                              const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,
                              const void* split_image, const void* bwd_image, const float* grad_scale_dev,
                              void* workspace, int64_t workspace_bytes, int64_t rows, int dim, int n_hidden,
-                             const int* hidden_host, int phases, void* stream);
+                             const int* hidden_host, int phases, const float* y, void* stream);
 /* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
 int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,

@@ -528,3 +528,56 @@ def test_bench_cpu_baseline_has_a_one_thread_figure(amd):
     line = _run_bench("--steps", "3", "--warmup", "1", "--prime-ms", "5", "--no-secondary")
     assert line["cpu_baseline"]["one_thread"]["value"] > 0 and line["cpu_baseline"]["value"] > 0
     assert line["parity"]["rel_err"] <= line["parity"]["tolerance"]
+
+
+@pytest.mark.parametrize("case", ["plain", "cold_rows", "ragged_tail"])
+def test_rnvp_gradient_pass_with_the_forward_pass_y(amd, O, case, monkeypatch):
+    """Large batches with the in-kernel mask: the register-resident forward kernel keeps y = net(mask * z) and launch A
+    of the gradient pass skips its own first sweep over z (mnf_rnvp_seeded_train -> mnf_rnvp_bwd_mfma_phases(y)).  Same
+    gradients as without (to rounding: the same y either way), and the float64 oracle on a slice.  cold_rows: rows
+    whose operands leave the f16 range make the forward pass recompute their 64-row groups in fp32 and leave NaN rows in
+    y, which must send those groups to the gradient pass's own fp32 fix-up; ragged_tail: the last, short group."""
+    import torch_mnf_amd.flows as fl
+
+    dim, hid = 800, 50
+    rows = 8192 + (37 if case == "ragged_tail" else 0)
+    sd = recipes.rnvp_params(8100, dim, hid)
+    z = recipes.gaussian(8101, rows, dim)
+    if case == "cold_rows":
+        z[100] *= 3.0e4
+        z[5000, 17] = 2.0e5
+    w_x = recipes.gaussian(8102, rows, dim)
+    w_l = recipes.gaussian(8103, rows, 1)[:, 0]
+    seed = 99
+
+    def run(keep):
+        monkeypatch.setattr(fl, "_RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
+        f = amd.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(sd)
+        f.to(DEV)
+        zz = z.to(DEV).requires_grad_(True)
+        x, ld = f.forward(zz, seed=seed)
+        kept = x.grad_fn.kept_y
+        ((x * w_x.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
+        return kept, x.detach(), {"z": zz.grad, **{n: p.grad for n, p in f.named_parameters()}}
+
+    kept, x1, g1 = run(True)
+    none, x0, g0 = run(False)
+    assert kept is not None and none is None
+    assert torch.equal(x1, x0)
+    if case == "cold_rows":
+        assert torch.isnan(kept[100]).all() and torch.isnan(kept[5000]).all() and not torch.isnan(kept[300]).any()
+    elif case == "ragged_tail":  # the short last group takes the fp32 body in the forward kernel too
+        assert not torch.isnan(kept[:8192]).any() and torch.isnan(kept[8192:]).all()
+    else:
+        assert not torch.isnan(kept).any()
+    for k in g0:
+        assert_close(g1[k], g0[k], 2e-6, f"{case}: gradient {k} with the kept y vs recomputed")
+    # the float64 oracle on a slice of ordinary rows (a row's grad_z does not depend on the other rows)
+    sl = slice(1024, 1536)
+    probe = amd.RNVP(dim, h_sizes=(hid,))
+    mask = probe.mask_for(seed, rows).cpu()
+    g32, g64 = _rnvp_oracle_grads(O, sd, z[sl], mask[sl], w_x[sl], w_l[sl])
+    widen = 2.0 * normwise_err(g32["z"].numpy(), g64["z"].numpy())
+    err = normwise_err(g1["z"][sl].cpu().double().numpy(), g64["z"].numpy())
+    assert err <= 1e-5 + widen, (case, err, widen)

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 10  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 11  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -107,7 +107,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd_mfma_phases": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, _intp,
-                                         c_int, c_void_p]),
+                                         c_int, c_void_p, c_void_p]),
+    "mnf_rnvp_y_floats_per_row": (c_int, [c_int, _intp]),
+    "mnf_rnvp_seeded_train": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_int, c_int, _intp, c_int, c_void_p, POINTER(c_int), c_void_p]),
     "mnf_affine_const_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_void_p]),
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -1113,6 +1113,15 @@ int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* strea
 int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
                     const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
                     int n_hidden, const int* hidden, int force_generic, void* stream) {
+  return mnf_rnvp_seeded_train(z, mask, seed, x, log_det, accumulate, flat, image, split_image, rows, dim, n_hidden,
+                               hidden, force_generic, nullptr, nullptr, stream);
+}
+
+int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
+                          const float* flat, const float* image, const void* split_image, int64_t rows, int dim,
+                          int n_hidden, const int* hidden, int force_generic, float* y_out, int* y_written_host,
+                          void* stream) {
+  if (y_written_host) *y_written_host = 0;
   if (!z || !x || z == x || rows < 0 || dim < 1 || n_hidden < 1 || !hidden_ok(n_hidden, hidden) ||
       (!flat && !image))
     return MNF_ERR_INVALID_ARG;
@@ -1121,7 +1130,7 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
     return rnvp_few_fwd_launch(z, mask, seed, x, log_det, accumulate, flat, rows, dim, hidden[0], (hipStream_t)stream);
   if (image && !force_generic) {
     const int rc = rnvp_mfma_launch(z, mask, x, log_det, accumulate, image, split_image, rows, dim, n_hidden, hidden,
-                                    seed, (hipStream_t)stream);
+                                    seed, (hipStream_t)stream, nullptr, nullptr, y_out, y_written_host);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (!flat) return MNF_ERR_INVALID_ARG;

@@ -114,7 +114,7 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, const void* split_image, int64_t rows, int dim, int n_hidden,
                      const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean = nullptr,
-                     const float* q0_log_var = nullptr);
+                     const float* q0_log_var = nullptr, float* y_out = nullptr, int* y_written = nullptr);
 
 // the register-resident kernel (mnf_rnvp_resident.hip): in-kernel mask only, selected shapes; MNF_ERR_UNSUPPORTED
 // sends the caller on to the streaming kernels
@@ -122,9 +122,11 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 int rnvp_pair_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
                      const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
                      const float* q0_log_var, int vec, hipStream_t stream);
+// y_out != nullptr (training): additionally writes y = Wn (m z) + bn, rows x 16 * ceil(hn_pad / 16) floats, for the
+// gradient pass (NaN rows for groups that took the fp32 body)
 int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
-                         const float* q0_log_var, int vec, hipStream_t stream);
+                         const float* q0_log_var, int vec, hipStream_t stream, float* y_out = nullptr);
 
 // RNVP on <= MNF_RNVP_FEW_ROWS rows with one hidden layer (mnf_rnvp_few.hip): one workgroup, no atomics.  `flat` is the
 // layer's plain parameter buffer (the state_dict order of mnf_rnvp); gradients are ADDED to grad_flat.

@@ -91,7 +91,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
                                                  int32_t* __restrict__ flags, int32_t* __restrict__ list, float gscale,
                                                  bool weights_ok,
                                                  f32x4 (&bn_acc)[RnvpSplitShape<HN>::YT], int64_t rows, int d,
-                                                 uint64_t seed, int dm_ragged, bool vec) {
+                                                 uint64_t seed, int dm_ragged, bool vec, const float* __restrict__ y_in) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   const int dm = RAG ? dm_ragged : d;
@@ -177,23 +177,42 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
       m1[u][i] = mask4(g);
     }
   };
+  // y_in != nullptr: the forward pass kept y = Wn (m z) + bn (rows x 16 YT floats): sweep 1 -- a third of this launch,
+  // one of its two reads of z -- is skipped and the operand pipeline starts at the first second-sweep tile
+  const bool have_y = y_in != nullptr;
   __syncthreads();  // the previous group's last chunk is fully consumed
   {
     int n4;
+    if (!have_y) {
 #pragma unroll
-    for (int u = 0; u < D1; ++u) request_rows1(u, u);
-    request_operands(0, n4);
-    hand_over(lds0, n4);
+      for (int u = 0; u < D1; ++u) request_rows1(u, u);
+      request_operands(0, n4);
+      hand_over(lds0, n4);
+    } else {
+      request_operands(nc1, n4);
+      hand_over(lds0 + (nc1 & 1) * B::CHUNK_WORDS, n4);
+    }
   }
   __syncthreads();
   f32x4 ym[YT], yc[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) {
-    ym[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
+    if (have_y)
+      ym[m] = *reinterpret_cast<const f32x4*>(y_in + rowc * (16 * YT) + m * 16 + 4 * q);
+    else
+      ym[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
     yc[m] = zero4;
   }
   float mx = weights_ok ? 0.f : __builtin_inff();
-  for (int c0 = 0; c0 < nc1; c0 += D1) {
+  if (have_y) {  // NaN rows: the forward pass recomputed their group in fp32 and kept no y -- this group's fix-up, then
+                 // (explicitly: the fmaxf of the range check drops NaNs)
+#pragma unroll
+    for (int m = 0; m < YT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (live && !(ym[m][r] == ym[m][r])) mx = __builtin_inff();
+  }
+  for (int c0 = 0; c0 < (have_y ? 0 : nc1); c0 += D1) {
 #pragma unroll
     for (int u = 0; u < D1; ++u) {
       const int c = c0 + u;
@@ -210,7 +229,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
         int n4_next = 0;
         request_rows1(c + D1, u);
         request_operands(c + 1, n4_next);  // c + 1 == nc1: the first second-sweep tile
-        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const uint32_t* buf = lds0 + (c & 1) * B::CHUNK_WORDS;  // (= lds[c & 1]: one base, no pointer select)
         const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
@@ -220,7 +239,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
               split_mac(A8[64 * (2 * (kk * YT + m))], A8[64 * (2 * (kk * YT + m) + 1)], bh[kk], bl[kk], ym[m], yc[m]);
           }
         }
-        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        hand_over(lds0 + ((c + 1) & 1) * B::CHUNK_WORDS, n4_next);
         __syncthreads();
       }
     }
@@ -254,7 +273,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
         const int m = c - nc1;
         const f32x4 bt = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 4 * q);
         const f32x4 bs = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 16 + 4 * q);
-        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const uint32_t* buf = lds0 + (c & 1) * B::CHUNK_WORDS;  // (= lds[c & 1]: one base, no pointer select)
         const f16x8* T8 = reinterpret_cast<const f16x8*>(buf) + lane;
         const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + S::TILE2_WORDS) + lane;
         f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
@@ -271,6 +290,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float zz = z2[u][r], mm = m2[u][r], nm = 1.f - mm;
+          mx = __builtin_fmaxf(mx, __builtin_fabsf(mm * zz));  // (launch B-n splits m z: sweep 1's guard when it is skipped)
           const float GG = live ? g2[u][r] * gscale : 0.f;
           const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
           const float omg = 1.f - gate;
@@ -284,7 +304,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
         for (int m2i = 0; m2i < YT; ++m2i) split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
         request_rows2(c + D2, u);
-        hand_over((c & 1) ? lds0 : lds1, n4_next);
+        hand_over(lds0 + ((c + 1) & 1) * B::CHUNK_WORDS, n4_next);
         __syncthreads();
       }
     }
@@ -316,7 +336,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
                   const float* __restrict__ gld, const uint32_t* __restrict__ simage, const uint32_t* __restrict__ bimage,
                   uint32_t* __restrict__ side, int32_t* __restrict__ flags, int32_t* __restrict__ list,
                   const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged,
-                  int hn, uint64_t seed, int vec_ok, int64_t bimage_tail) {
+                  int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][B::CHUNK_WORDS];
@@ -331,7 +351,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   const int n_groups = (int)((rows + kBwdGroupRows - 1) / kBwdGroupRows);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
     rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
-                                      weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0);
+                                      weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0, y_in);
   // dbn: sum over the wave's rows (the 16 lanes j of a q), over the workgroup's waves in LDS, then ONE atomic per unit
   // per workgroup (atomics on a few dozen addresses serialise at the memory side: one per unit per WAVE cost 0.16 ms)
   if (grad_flat && !(kBwdAbl & 64)) {
@@ -859,7 +879,7 @@ static int64_t bwd_workspace_bytes(int64_t rows) {
 template <int HN, bool SEEDED, bool RAG>
 static int launch_bwd(const float* z, const float* mask, uint64_t seed, const float* gx, const float* gld, float* grad_z,
                       float* grad_flat, const uint32_t* simage, const uint32_t* bimage, const float* gscale, void* work,
-                      int64_t rows, int dm, int hn, int vec4, int vec2, int phases, hipStream_t stream) {
+                      int64_t rows, int dm, int hn, int vec4, int vec2, int phases, const float* y_in, hipStream_t stream) {
   using B = RnvpBwdShape<HN>;
   const int d16 = rnvp_padded_dim(dm);
   const int64_t n_groups = (rows + kBwdGroupRows - 1) / kBwdGroupRows;
@@ -874,7 +894,8 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   if (phases & 1) {
   if (int rc = zero_word_async(list, stream)) return rc;
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
-                     mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail);
+                     mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail,
+                     y_in);
   if (int rc = check_launch()) return rc;
   }
   // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see
@@ -948,7 +969,8 @@ int mnf_rnvp_bwd_mfma_index(int dim, int n_hidden, const int* hidden, int32_t* i
 int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,
                              float* grad_z, float* grad_flat, const float* flat, const void* split_image,
                              const void* bwd_image, const float* grad_scale_dev, void* workspace, int64_t workspace_bytes,
-                             int64_t rows, int dim, int n_hidden, const int* hidden, int phases, void* stream) {
+                             int64_t rows, int dim, int n_hidden, const int* hidden, int phases, const float* y,
+                             void* stream) {
   if (!z || !grad_z || !flat || !split_image || !bwd_image || !grad_scale_dev || !workspace || rows < 0 || dim < 1 ||
       n_hidden < 1 || !hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
@@ -968,17 +990,18 @@ int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, c
   const uint32_t* bi = static_cast<const uint32_t*>(bwd_image);
   const float* gs = grad_scale_dev;
   hipStream_t st = (hipStream_t)stream;
+  const float* y_in = y;
   int rc = MNF_ERR_UNSUPPORTED;
 #define X(HN)                                                                                                            \
   if (hn_pad == HN)                                                                                                      \
     rc = mask ? (ragged ? launch_bwd<HN, false, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
-                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, st)                   \
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, y_in, st)                   \
                         : launch_bwd<HN, false, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,    \
-                                                       workspace, rows, dim, hidden[0], vec4, vec2, phases, st))                 \
+                                                       workspace, rows, dim, hidden[0], vec4, vec2, phases, y_in, st))                 \
               : (ragged ? launch_bwd<HN, true, true>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,      \
-                                                     workspace, rows, dim, hidden[0], vec4, vec2, phases, st)                    \
+                                                     workspace, rows, dim, hidden[0], vec4, vec2, phases, y_in, st)                    \
                         : launch_bwd<HN, true, false>(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, si, bi, gs,     \
-                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, st));
+                                                      workspace, rows, dim, hidden[0], vec4, vec2, phases, y_in, st));
   MNF_RNVP_HIDDEN(X)
 #undef X
   if (rc != MNF_OK || !(phases & 8)) return rc;
@@ -992,7 +1015,7 @@ int mnf_rnvp_bwd_mfma(const float* z, const float* mask, uint64_t seed, const fl
                       const float* grad_scale_dev, void* workspace, int64_t workspace_bytes, int64_t rows, int dim,
                       int n_hidden, const int* hidden, void* stream) {
   return mnf_rnvp_bwd_mfma_phases(z, mask, seed, grad_x, grad_ld, grad_z, grad_flat, flat, split_image, bwd_image,
-                                  grad_scale_dev, workspace, workspace_bytes, rows, dim, n_hidden, hidden, 15, stream);
+                                  grad_scale_dev, workspace, workspace_bytes, rows, dim, n_hidden, hidden, 15, nullptr, stream);
 }
 
 }  // extern "C"

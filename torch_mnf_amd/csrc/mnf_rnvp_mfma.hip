@@ -468,7 +468,8 @@ static int launch_rnvp(const float* z, const float* mask, float* x, float* log_d
 int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                      const float* image, const void* split_image, int64_t rows, int dim, int n_hidden,
                      const int* hidden, uint64_t seed, hipStream_t stream, const float* q0_mean,
-                     const float* q0_log_var) {
+                     const float* q0_log_var, float* y_out, int* y_written) {
+  if (y_written) *y_written = 0;
   if (!rnvp_shape_ok(dim, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
   const int d = rnvp_padded_dim(dim);
   if (q0_mean && (!split_image || !q0_log_var || d > kRnvpMaxPrologueDim)) return MNF_ERR_UNSUPPORTED;
@@ -479,6 +480,14 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   const int hn_pad = rnvp_padded_hidden(n_hidden, hidden);
   if (!ragged && !rows_aligned) return MNF_ERR_UNSUPPORTED;
   const int vec = rows_aligned && (dim & 3) == 0;
+  if (split_image && !mask && rows_aligned && y_out) {  // training: the kernel that can keep y for the gradient pass
+    const int rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
+                                        q0_log_var, vec, stream, y_out);
+    if (rc != MNF_ERR_UNSUPPORTED) {
+      if (rc == MNF_OK && y_written) *y_written = 1;
+      return rc;
+    }
+  }
   if (split_image && !mask && rows_aligned) {  // in-kernel mask: the register-resident kernel where it exists
     int rc = rnvp_pair_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
                               q0_log_var, vec, stream);
@@ -510,6 +519,12 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 }  // namespace mnf
 
 extern "C" {
+
+int mnf_rnvp_y_floats_per_row(int n_hidden, const int* hidden) {
+  if (n_hidden < 1 || !mnf::hidden_ok(n_hidden, hidden)) return 0;
+  const int hn = mnf::rnvp_padded_hidden(n_hidden, hidden);
+  return hn > 0 ? 16 * ((hn + 15) / 16) : 0;
+}
 
 int64_t mnf_rnvp_image_floats(int dim, int n_hidden, const int* hidden) {
   if (!mnf::rnvp_shape_ok(dim, n_hidden, hidden)) return 0;

@@ -151,7 +151,8 @@ template <int HN, int G, bool SAMPLE>
 __global__ void __launch_bounds__(kResWaves * 64, 1)
 rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* __restrict__ log_det,
                      const uint32_t* __restrict__ simage, const float* __restrict__ image, int64_t rows, int accumulate,
-                     uint64_t seed, const float* __restrict__ q0_mean, const float* __restrict__ q0_log_var) {
+                     uint64_t seed, const float* __restrict__ q0_mean, const float* __restrict__ q0_log_var,
+                     float* __restrict__ y_out) {
   using S = RnvpSplitShape<HN>;
   using R = ResShape<HN>;
   constexpr int d = 16 * G;
@@ -389,6 +390,13 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       primed = false;
       continue;
     }
+    // training: y is kept for the gradient pass (mnf_rnvp_bwd_mfma's launch A then skips its own GEMM-1 sweep over z).
+    // (YT stores the wait counts below do not know about: the counts are lower bounds, the waits get stricter.)
+    if (y_out) {
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+        *reinterpret_cast<f32x4*>(y_out + row * (16 * YT) + 16 * m + 4 * q) = yc[m] * kSplitInvScale + ym[m];
+    }
     f16x8 ybh[NKS2], ybl[NKS2];
 #pragma unroll
     for (int ks = 0; ks < NKS2; ++ks) {
@@ -470,16 +478,23 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
   // the flagged groups, on the fp32 MFMA body (reads its rows from memory itself)
   __syncthreads();
   for (int grp = blockIdx.x, it = 0; grp < n_groups; grp += gridDim.x, ++it)
-    if ((cold_flags[it >> 5] >> (it & 31)) & 1u)
+    if ((cold_flags[it >> 5] >> (it & 31)) & 1u) {
       rnvp_resident_f32_cold<HN, false>(reinterpret_cast<float*>(lds_dyn), grp, z, x, log_det, image, rows, d,
                                         accumulate, seed, zprm, d, true);
+      if (y_out) {  // no y from the fp32 body: NaN rows make launch A flag the group for its own fp32 fix-up
+        for (int i = threadIdx.x; i < GROUP_ROWS * 16 * YT; i += blockDim.x) {
+          const int64_t r = (int64_t)grp * GROUP_ROWS + i / (16 * YT);
+          if (r < rows) y_out[r * (16 * YT) + i % (16 * YT)] = __builtin_nanf("");
+        }
+      }
+    }
 }
 
 // ---------------------------------------------------------------- host
 template <int HN, int G, bool SAMPLE>
 static int launch_resident(const float* z, float* x, float* log_det, int accumulate, const uint32_t* simage,
                            const float* image, int64_t rows, uint64_t seed, const float* q0_mean,
-                           const float* q0_log_var, hipStream_t stream) {
+                           const float* q0_log_var, float* y_out, hipStream_t stream) {
   constexpr size_t lds_bytes = ResShape<HN>::lds_bytes(16 * G);
   static_assert(lds_bytes <= 160 * 1024, "operand window + biases must fit the CU's LDS");
   static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
@@ -494,7 +509,7 @@ static int launch_resident(const float* z, float* x, float* log_det, int accumul
   const int64_t blocks = n_groups < cus ? n_groups : cus;  // one persistent workgroup per CU
   if ((n_groups + blocks - 1) / (blocks > 0 ? blocks : 1) > 32 * kResColdWords) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((rnvp_resident_kernel<HN, G, SAMPLE>), dim3((unsigned)blocks), dim3(kResWaves * 64), lds_bytes,
-                     stream, z, x, log_det, simage, image, rows, accumulate, seed, q0_mean, q0_log_var);
+                     stream, z, x, log_det, simage, image, rows, accumulate, seed, q0_mean, q0_log_var, y_out);
   return check_launch();
 }
 
@@ -505,7 +520,7 @@ static int launch_resident(const float* z, float* x, float* log_det, int accumul
 // MNF_ERR_UNSUPPORTED: no resident kernel for this shape -- the caller runs the streaming split kernel
 int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
                          const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
-                         const float* q0_log_var, int vec, hipStream_t stream) {
+                         const float* q0_log_var, int vec, hipStream_t stream, float* y_out) {
   // MNF_RNVP_RESIDENT=0 (read per call: tests and A/B runs flip it): the streaming kernels only
   const char* env = getenv("MNF_RNVP_RESIDENT");
   if ((env && env[0] == '0') || !split_image || !image || !log_det) return MNF_ERR_UNSUPPORTED;
@@ -514,9 +529,9 @@ int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulat
 #define X(HN, GG)                                                                                                  \
   if (hn_pad == HN && dim == 16 * GG)                                                                              \
     return q0_mean ? launch_resident<HN, GG, true>(z, x, log_det, accumulate, simage, image, rows, seed, q0_mean,   \
-                                                   q0_log_var, stream)                                             \
+                                                   q0_log_var, y_out, stream)                                      \
                    : launch_resident<HN, GG, false>(z, x, log_det, accumulate, simage, image, rows, seed, q0_mean,  \
-                                                    q0_log_var, stream);
+                                                    q0_log_var, y_out, stream);
   MNF_RNVP_RESIDENT_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

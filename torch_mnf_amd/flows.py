@@ -43,6 +43,7 @@ _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # 
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
 # the matrix-core RNVP gradient pass from this many rows / dims on (d = 800: 227 vs 252 us at 128 rows, 284 vs 837 us at
 # 2,048; d = 50: the generic kernel stays ahead up to 32,768 rows)
+_RNVP_KEEP_Y_MIN_ROWS = int(os.environ.get("MNF_RNVP_KEEP_Y_MIN_ROWS", "4096"))  # (0 rows of y below: nothing to gain)
 _RNVP_BWD_FEW_GRID_OFF = False  # (tests: the matrix-core / generic gradient kernels at every row count)
 _RNVP_BWD_MFMA_MIN_ROWS = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_ROWS", "64"))
 _RNVP_BWD_MFMA_MIN_DIM = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_DIM", "128"))
@@ -413,11 +414,22 @@ class _RnvpFn(torch.autograd.Function):
         ctx.home = home
         x = torch.empty_like(z)
         ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
-        _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
+        lib = _lib.load()
+        # a large batch with the in-kernel mask: the register-resident kernel can keep y = net(mask * z) (64 floats per
+        # row) for the gradient pass, whose first launch then skips its own sweep over z
+        y, wrote = None, ctypes.c_int(0)
+        if (not few and mask is None and z.shape[0] >= _RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
+                and not _RNVP_BWD_GENERIC_ENV):
+            per_row = lib.mnf_rnvp_y_floats_per_row(len(module.h_sizes), module._hid)
+            if per_row > 0:
+                y = torch.empty(z.shape[0], per_row, dtype=torch.float32, device=z.device)
+        _lib.check("mnf_rnvp_seeded_train", lib.mnf_rnvp_seeded_train(
             z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image),
             None if few else _ptr(module._split_image(z.device)), z.shape[0],
-            module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _stream()))
+            module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _ptr(y), ctypes.byref(wrote),
+            _stream()))
         ctx.module, ctx.seed, ctx.mask = module, seed, mask
+        ctx.kept_y = y if wrote.value else None
         ctx.save_for_backward(z, flat)
         return x, ld
 
@@ -461,7 +473,7 @@ class _RnvpFn(torch.autograd.Function):
                 return lib.mnf_rnvp_bwd_mfma_phases(
                     z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
                     flat.data_ptr(), split.data_ptr(), bwd.data_ptr(), scale.data_ptr(), work.data_ptr(), work.numel(),
-                    rows, m.dim, len(m.h_sizes), m._hid, phases, _stream())
+                    rows, m.dim, len(m.h_sizes), m._hid, phases, _ptr(ctx.kept_y), _stream())
 
             if rnvp_bwd_kernel_events is None:
                 rc = go(15)
