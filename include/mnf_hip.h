@@ -217,8 +217,8 @@ int mnf_rnvp_seeded(const float* z, const float* mask, uint64_t seed, float* x, 
                     int64_t rows, int dim, int n_hidden, const int* hidden_host,
                     int force_generic, void* stream);
 int mnf_rnvp_mask(uint64_t seed, float* mask, int64_t rows, int dim, void* stream);
-/* The training form of mnf_rnvp_seeded: when y_out != NULL and the kernel that takes the call can (the register-resident
- * one: in-kernel mask, its shapes), it also writes y = net(mask * z) -- (rows, mnf_rnvp_y_floats_per_row(...)) floats,
+/* The training form of mnf_rnvp_seeded: when y_out != NULL and the kernel that takes the call can (the split-arithmetic
+ * kernels: the register-resident one and the streaming one, either mask form), it also writes y = net(mask * z) -- (rows, mnf_rnvp_y_floats_per_row(...)) floats,
  * NaN for rows it recomputed in fp32 -- for mnf_rnvp_bwd_mfma_phases, and sets *y_written_host = 1; otherwise
  * *y_written_host = 0 and y_out is untouched.  Everything else as mnf_rnvp_seeded. */
 int mnf_rnvp_y_floats_per_row(int n_hidden, const int* hidden_host);

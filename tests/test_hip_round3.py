@@ -540,6 +540,45 @@ def test_bench_cpu_baseline_has_a_one_thread_figure(amd):
     assert line["parity"]["rel_err"] <= line["parity"]["tolerance"]
 
 
+@pytest.mark.parametrize("dim,hid,rows,masked", [(784, 50, 4500, "explicit"), (800, 50, 4200, "explicit"),
+                                                 (100, 17, 5000, "seeded"), (784, 30, 4100, "seeded")])
+def test_rnvp_gradient_pass_with_the_forward_pass_y_streaming_kernels(amd, O, dim, hid, rows, masked, monkeypatch):
+    """The streaming split forward kernel keeps y too (explicit masks, ragged widths, hidden widths below the tile):
+    same gradients as with launch A's own first sweep, and the float64 oracle on a slice."""
+    import torch_mnf_amd.flows as fl
+
+    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_DIM", 0)
+    sd = recipes.rnvp_params(8200 + dim, dim, hid)
+    z = recipes.gaussian(8201 + dim, rows, dim)
+    z[7] *= 3.0e4  # one group through the fp32 bodies
+    w_x = recipes.gaussian(8202 + dim, rows, dim)
+    w_l = recipes.gaussian(8203 + dim, rows, 1)[:, 0]
+    probe = amd.RNVP(dim, h_sizes=(hid,))
+    seed = 5 + dim
+    mask = recipes.bernoulli_mask(8204 + dim, rows, dim) if masked == "explicit" else probe.mask_for(seed, rows).cpu()
+
+    def run(keep):
+        monkeypatch.setattr(fl, "_RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
+        f = amd.RNVP(dim, h_sizes=(hid,))
+        f.load_state_dict(sd)
+        f.to(DEV)
+        zz = z.to(DEV).requires_grad_(True)
+        x, ld = f.forward(zz, mask=mask.to(DEV)) if masked == "explicit" else f.forward(zz, seed=seed)
+        kept = x.grad_fn.kept_y
+        ((x * w_x.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
+        return kept, {"z": zz.grad, **{n: p.grad for n, p in f.named_parameters()}}
+
+    kept, g1 = run(True)
+    none, g0 = run(False)
+    assert kept is not None and none is None and torch.isnan(kept[7]).all() and not torch.isnan(kept[200:]).any()
+    for k in g0:
+        assert_close(g1[k], g0[k], 2e-6, f"gradient {k} with the kept y vs recomputed")
+    sl = slice(1024, 1400)
+    g32, g64 = _rnvp_oracle_grads(O, sd, z[sl], mask[sl], w_x[sl], w_l[sl])
+    widen = 2.0 * normwise_err(g32["z"].numpy(), g64["z"].numpy())
+    assert normwise_err(g1["z"][sl].cpu().double().numpy(), g64["z"].numpy()) <= 1e-5 + widen
+
+
 @pytest.mark.parametrize("case", ["plain", "cold_rows", "ragged_tail"])
 def test_rnvp_gradient_pass_with_the_forward_pass_y(amd, O, case, monkeypatch):
     """Large batches with the in-kernel mask: the register-resident forward kernel keeps y = net(mask * z) and launch A

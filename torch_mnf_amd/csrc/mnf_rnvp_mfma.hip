@@ -64,7 +64,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
                                                  const float* __restrict__ mask, float* __restrict__ x,
                                                  float* __restrict__ log_det, const uint32_t* __restrict__ simage,
                                                  int64_t rows, int d, int accumulate, uint64_t seed,
-                                                 const float* zprm, int dm_ragged, bool vec) {
+                                                 const float* zprm, int dm_ragged, bool vec, float* __restrict__ y_out) {
   using S = RnvpSplitShape<HN>;
   const int dm = RAG ? dm_ragged : d;  // row width in memory (d: rounded up to whole 16-dim groups)
   constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC, MC = S::MC;
@@ -245,6 +245,11 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
   for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
   if (__syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0)) return false;  // nothing has been stored yet
+  if (y_out && live) {  // training: y kept for the gradient pass (mnf_rnvp_seeded_train)
+#pragma unroll
+    for (int m = 0; m < YT; ++m)
+      *reinterpret_cast<f32x4*>(y_out + row * (16 * YT) + 16 * m + 4 * q) = yc[m] * kSplitInvScale + ym[m];
+  }
 
   // ---- GEMM 2 + gate, 16 output dims per tile
   float ld = 0.f, ld2 = 0.f;  // ld2: sum of log2(1 + e^-s) over the gated elements (seeded path)
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(kRnvpWaves * 64, 4)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
                   int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
-                  const float* __restrict__ q0_log_var, int dm_ragged, int vec_ok) {
+                  const float* __restrict__ q0_log_var, int dm_ragged, int vec_ok, float* __restrict__ y_out) {
   const int dm = RAG ? dm_ragged : d;
   const bool vec = vec_ok != 0;
   using S = RnvpSplitShape<HN>;
@@ -368,17 +373,25 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     if (split_ok && rnvp_group_split<HN, SEEDED, RAG>(reinterpret_cast<uint32_t*>(lds[0]),
                                                       reinterpret_cast<uint32_t*>(lds[1]), grp, z, mask, x, log_det,
-                                                      simage, rows, d, accumulate, seed, zprm, dm, vec))
+                                                      simage, rows, d, accumulate, seed, zprm, dm, vec, y_out))
       continue;
     rnvp_group_f32_cold<HN, SEEDED, RAG>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm,
                                          dm, vec);
+    if (y_out) {  // no y from the fp32 body: NaN rows make the gradient pass's launch A flag the group for its fix-up
+      constexpr int W = 16 * S::YT, GR = 16 * kRnvpWaves;
+      for (int i = threadIdx.x; i < GR * W; i += blockDim.x) {
+        const int64_t r = (int64_t)grp * GR + i / W;
+        if (r < rows) y_out[r * W + i % W] = __builtin_nanf("");
+      }
+    }
   }
 }
 
 template <int HN, bool RAG>
 static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
-                             const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream) {
+                             const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
+                             float* y_out = nullptr) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
   static DeviceMemo memo_mask, memo_seed;
   const int resident_mask = memo_mask.get(
@@ -392,10 +405,10 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)
     hipLaunchKernelGGL((rnvp_split_kernel<HN, false, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
-                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec);
+                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
   else
     hipLaunchKernelGGL((rnvp_split_kernel<HN, true, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
-                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec);
+                       z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
   return check_launch();
 }
 
@@ -488,7 +501,7 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
       return rc;
     }
   }
-  if (split_image && !mask && rows_aligned) {  // in-kernel mask: the register-resident kernel where it exists
+  if (split_image && !mask && rows_aligned && !y_out) {  // in-kernel mask: the register-resident kernels where they exist
     int rc = rnvp_pair_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
                               q0_log_var, vec, stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
@@ -498,14 +511,16 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
   }
   if (split_image) {
     const uint32_t* simage = static_cast<const uint32_t*>(split_image);
+    if (y_out && y_written) *y_written = 1;  // (every kernel below keeps y when asked)
 #define X(HN)                                                                                                        \
   if (hn_pad == HN)                                                                                                  \
     return ragged ? launch_rnvp_split<HN, true>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,       \
-                                                q0_mean, q0_log_var, dim, vec, stream)                               \
+                                                q0_mean, q0_log_var, dim, vec, stream, y_out)                        \
                   : launch_rnvp_split<HN, false>(z, mask, x, log_det, accumulate, simage, image, rows, d, seed,      \
-                                                 q0_mean, q0_log_var, dim, vec, stream);
+                                                 q0_mean, q0_log_var, dim, vec, stream, y_out);
     MNF_RNVP_HIDDEN(X)
 #undef X
+    if (y_written) *y_written = 0;
   }
 #define X(HN)                                                                                                        \
   if (hn_pad == HN)                                                                                                  \

@@ -415,11 +415,11 @@ class _RnvpFn(torch.autograd.Function):
         x = torch.empty_like(z)
         ld = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
         lib = _lib.load()
-        # a large batch with the in-kernel mask: the register-resident kernel can keep y = net(mask * z) (64 floats per
-        # row) for the gradient pass, whose first launch then skips its own sweep over z
+        # a large batch: the split forward kernels can keep y = net(mask * z) (64 floats per row) for the matrix-core
+        # gradient pass, whose first launch then skips its own sweep over z
         y, wrote = None, ctypes.c_int(0)
-        if (not few and mask is None and z.shape[0] >= _RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
-                and not _RNVP_BWD_GENERIC_ENV):
+        if (not few and z.shape[0] >= _RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
+                and not _RNVP_BWD_GENERIC_ENV and z.shape[0] >= _RNVP_BWD_MFMA_MIN_ROWS and module.dim >= _RNVP_BWD_MFMA_MIN_DIM):
             per_row = lib.mnf_rnvp_y_floats_per_row(len(module.h_sizes), module._hid)
             if per_row > 0:
                 y = torch.empty(z.shape[0], per_row, dtype=torch.float32, device=z.device)
