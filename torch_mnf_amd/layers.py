@@ -21,7 +21,7 @@ from torch import Tensor, nn
 from . import _lib
 from . import flows as _flows
 from ._lib import MnfHipError
-from .flows import RNVP, NormalizingFlow, _stream, _wants_grad
+from .flows import MADE, RNVP, MaskedLinear, NormalizingFlow, _stream, _wants_grad  # noqa: F401 (MADE, MaskedLinear: torch_mnf.layers exports them)
 
 
 def _mnf_linear_forward(module, x, z, eps, seed, ops, sd):
