@@ -14,6 +14,7 @@
  *   mnf_maf              MAF / IAF .forward / .inverse          torch_mnf/flows/maf.py:39-72
  *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
  *   mnf_linear_rows      Glow.forward / .inverse (x @ W)        torch_mnf/flows/glow.py:26-37
+ *   mnf_glow_weight      Glow._assemble_W, W^-1, log_det        torch_mnf/flows/glow.py:20-37
  *   mnf_gauss_logprob(_sq) base.log_prob + the callers' mean    torch_mnf/flows/core.py:46-49,
  *                                                               examples/half_moons.ipynb:183-186
  *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
@@ -328,6 +329,20 @@ int64_t mnf_nsf_ar_flat_floats(int dim, int K, int n_hidden, const int* hidden_h
 int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                    const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
                    const int* hidden_host, void* stream);
+
+/* ------------------------------------------------------------------ Glow: the d x d parameter preparation
+ * torch_mnf/flows/glow.py:20-37.  out = W = P (tril(L,-1) + I) (triu(U,1) + diag(S)) (inverse = 0) or its inverse
+ * (inverse = 1: two triangular inverses by substitution -- the matrix is given in PLU form -- instead of the
+ * reference's torch.inverse of the assembled W, :34); log_det (1) = +-sum log|S| (:29, :35).  P, L, U (dim, dim), S (dim),
+ * row-major, all device memory.  _bwd: grad_out = the cotangent of `out` (or NULL), grad_log_det (1) or NULL;
+ * grad_L (strictly lower part; zeros elsewhere), grad_S, grad_U (strictly upper part) are written (accumulate = 0) or
+ * ADDED to (accumulate = 1).  dim <= MNF_GLOW_WEIGHT_MAX_DIM, else MNF_ERR_UNSUPPORTED (one workgroup, matrices in LDS). */
+#define MNF_GLOW_WEIGHT_MAX_DIM 64
+int mnf_glow_weight(const float* P, const float* L, const float* S, const float* U, float* out, float* log_det, int dim,
+                    int inverse, void* stream);
+int mnf_glow_weight_bwd(const float* P, const float* L, const float* S, const float* U, const float* grad_out,
+                        const float* grad_log_det, float* grad_L, float* grad_S, float* grad_U, int dim, int inverse,
+                        int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ MAF / IAF (generic path)
  * torch_mnf/flows/maf.py:21-72 over net = MADE(dim, hidden, 2 dim, natural_ordering=True) (torch_mnf/layers/made.py:11-94:

@@ -1420,6 +1420,47 @@ class ActNormFlow(AffineConstantFlow):
         return super()._run(x, inverse, accum)
 
 
+_GLOW_WEIGHT_MAX_DIM = 64  # include/mnf_hip.h MNF_GLOW_WEIGHT_MAX_DIM
+
+
+class _GlowWeightFn(torch.autograd.Function):
+    """Glow's parameter preparation with gradients (mnf_glow_weight / _bwd): (W or W^-1, +-sum log|S|) from P, L, S, U in
+    one launch each way -- the inverse by two triangular substitutions, no factorisation.  ``home``: see _RnvpFn."""
+
+    @staticmethod
+    def forward(ctx, L, S, U, P, inverse, home):
+        Lc, Sc, Uc = (t.detach().contiguous() for t in (L, S, U))
+        d = Sc.numel()
+        out = torch.empty(d, d, dtype=torch.float32, device=Sc.device)
+        ld = torch.empty((), dtype=torch.float32, device=Sc.device)
+        _lib.check("mnf_glow_weight", _lib.load().mnf_glow_weight(
+            P.data_ptr(), Lc.data_ptr(), Sc.data_ptr(), Uc.data_ptr(), out.data_ptr(), ld.data_ptr(), d, int(inverse),
+            _stream()))
+        ctx.save_for_backward(Lc, Sc, Uc, P)
+        ctx.inverse, ctx.home = inverse, home
+        ctx.set_materialize_grads(False)
+        return out, ld
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out, g_ld):
+        Lc, Sc, Uc, P = ctx.saved_tensors
+        d, home = Sc.numel(), ctx.home
+        go = None if g_out is None else g_out.contiguous()
+        gl = None if g_ld is None else g_ld.contiguous()
+        if home is not None:  # L, S, U back to back in a train.FlatParameters buffer: added to their gradient slice
+            buf = home[0].grad[home[1]:home[1] + home[2]]
+        else:
+            buf = torch.empty(2 * d * d + d, dtype=torch.float32, device=Sc.device)
+        gL, gS, gU = buf[:d * d], buf[d * d:d * d + d], buf[d * d + d:]
+        _lib.check("mnf_glow_weight_bwd", _lib.load().mnf_glow_weight_bwd(
+            P.data_ptr(), Lc.data_ptr(), Sc.data_ptr(), Uc.data_ptr(), _ptr(go), _ptr(gl), gL.data_ptr(), gS.data_ptr(),
+            gU.data_ptr(), d, int(ctx.inverse), int(home is not None), _stream()))
+        if home is not None:
+            return None, None, None, None, None, None
+        return gL.view(d, d), gS, gU.view(d, d), None, None, None
+
+
 class Glow(_TwoWayFlow):
     """Invertible d x d linear map, PLU-parametrised (flows/glow.py:5-37).
 
@@ -1500,6 +1541,14 @@ class Glow(_TwoWayFlow):
     def _run(self, x, inverse, accum):
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
             xg = _grad_input(x)
+            if (self.dim <= _GLOW_WEIGHT_MAX_DIM and self.L.is_cuda and self.L.device == xg.device
+                    and self.L.dtype == torch.float32):
+                # W (or W^-1, by triangular substitution) and log_det with their gradients: one launch each way
+                params = [self.L, self.S, self.U]
+                home = _flat_home_of(self, params) if all(p.requires_grad for p in params) else None
+                M, ld = _GlowWeightFn.apply(self.L, self.S, self.U, self._P_on(xg.device).to(torch.float32).contiguous(),
+                                            bool(inverse), home)
+                return _LinearRowsFn.apply(xg, M), ld
             eye = torch.eye(self.dim, device=self.L.device)
             W = self._P_on(self.L.device) @ (torch.tril(self.L, diagonal=-1) + eye) @ (
                 torch.triu(self.U, diagonal=1) + self.S.diag())  # glow.py:20-24, differentiable
