@@ -1504,10 +1504,14 @@ class Glow(_TwoWayFlow):
     def _weights(self, device, inverse: bool) -> Tensor:
         key = (device, _flat_gen(self), tuple((p.data_ptr(), p._version) for p in (self.L, self.S, self.U)), id(self.P))
         if key != self._w_key:
-            self._w = self._assemble_W(device)
+            fused = self._fused_weight(device, False)
+            if fused is not None:
+                self._w, self._w_ld = fused
+            else:
+                self._w = self._assemble_W(device)
+                self._w_ld = self.S.detach().abs().log().sum().to(device)  # 0-dim, parameter-only (glow.py:29)
             self._w_inv = None
             self._w_img = {}
-            self._w_ld = self.S.detach().abs().log().sum().to(device)  # 0-dim, parameter-only (glow.py:29)
             self._w_key = key
             self._w_from = (torch.cat([p.detach().reshape(-1) for p in (self.L, self.S, self.U)]).clone()
                             if _CHECK_PARAMS_EVERY else None)
@@ -1515,9 +1519,23 @@ class Glow(_TwoWayFlow):
             _check_params_fresh((self.L, self.S, self.U), self.__dict__.get("_w_from"), "Glow")
         if inverse:
             if self._w_inv is None:
-                self._w_inv = torch.inverse(self._w).contiguous()
+                fused = self._fused_weight(device, True)  # (two triangular substitutions: no LU, no host round trip)
+                self._w_inv = fused[0] if fused is not None else torch.inverse(self._w).contiguous()
             return self._w_inv
         return self._w
+
+    def _fused_weight(self, device, inverse: bool):
+        """(W or W^-1, sum log|S|) from ``mnf_glow_weight``, or None when the shape / placement has no such kernel."""
+        if (self.dim > _GLOW_WEIGHT_MAX_DIM or not self.L.is_cuda or self.L.device != device
+                or self.L.dtype != torch.float32):
+            return None
+        out = torch.empty(self.dim, self.dim, dtype=torch.float32, device=device)
+        ld = torch.empty((), dtype=torch.float32, device=device)
+        P = self._P_on(device).to(torch.float32).contiguous()
+        _lib.check("mnf_glow_weight", _lib.load().mnf_glow_weight(
+            P.data_ptr(), self.L.detach().contiguous().data_ptr(), self.S.detach().contiguous().data_ptr(),
+            self.U.detach().contiguous().data_ptr(), out.data_ptr(), ld.data_ptr(), self.dim, int(inverse), _stream()))
+        return out, (-ld if inverse else ld)
 
     def _w_image(self, device, inverse: bool) -> Tensor | None:
         """W (or W^-1) in MFMA operand order, or None when dim has no specialised kernel."""
