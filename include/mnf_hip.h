@@ -440,6 +440,23 @@ int mnf_mnf_kl_bwd(const float* W_mean, const float* W_log_var, const float* eps
                    const float* r0_b2, const float* saved, const float* grad_out, int conv, int64_t rows, int cols,
                    int n_bias, float* grads, float* param_grads, int accumulate, void* stream);
 
+/* ------------------------------------------------ the elementwise parts of MNFConv2d.forward
+ * torch_mnf/layers/mnf_conv.py:67-88 around its two convolutions (which stay the caller's: MIOpen), one launch each way:
+ *   _operands   Wz = W_mean * z[o] (the mean convolution's weight, :72),  W_var = exp(W_log_var),  b_var = exp(b_log_var)
+ *               (:69-70); W_* are (n_out, per_out = n_in k k) row-major, z / b_* (n_out)
+ *   _operands_bwd  from the cotangents of Wz, W_var, b_var (each may be NULL): grad_W_mean, grad_W_log_var,
+ *               grad_b_log_var (written, or ADDED to when accumulate = 1) and grad_z (written)
+ *   _noise      out = mean + sqrt(var) * eps (:86-88);  _noise_bwd: grad_var = grad_out * eps / (2 sqrt(var)) (the
+ *               cotangent of mean is grad_out itself) */
+int mnf_mnf_conv_operands(const float* W_mean, const float* W_log_var, const float* b_log_var, const float* z, float* Wz,
+                          float* W_var, float* b_var, int n_out, int per_out, void* stream);
+int mnf_mnf_conv_operands_bwd(const float* W_mean, const float* W_log_var, const float* b_log_var, const float* z,
+                              const float* grad_Wz, const float* grad_W_var, const float* grad_b_var, float* grad_W_mean,
+                              float* grad_W_log_var, float* grad_b_log_var, float* grad_z, int n_out, int per_out,
+                              int accumulate, void* stream);
+int mnf_mnf_noise(const float* mean, const float* var, const float* eps, float* out, int64_t n, void* stream);
+int mnf_mnf_noise_bwd(const float* var, const float* eps, const float* grad_out, float* grad_var, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ gradients (autograd)
  * What torch.autograd.Function.backward needs so the modules train like the reference's
  * (tests/test_flows.py:14-31 trains through forward/inverse).  grad_flat has the `flat` layout and

@@ -337,3 +337,53 @@ def test_kl_kernel_shapes(amd, O, kind, n_in, n_out, k):
         err = normwise_err(got[name].numpy().reshape(r.shape), r)
         # the fp32 oracle's own distance already reflects the conditioning of this draw: allow a few of them
         assert err <= GBASE + 3 * widen, f"{kind} ({n_in}, {n_out}, {k}) {name}: {err:.2e} > 1e-5 + 3 x {widen / 2:.2e}"
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_mnf_conv2d_forward_gradients_vs_float64_oracle(amd, O, golden, tag):
+    """MNFConv2d.forward under loss.backward(): the operand kernel (W_mean * z, exp(W_log_var), exp(b_log_var)), the two
+    stock convolutions and the noise epilogue kernel, differentiated -- every parameter the output depends on (the
+    weights, b_log_var, q0_mean / q0_log_var and flow_q through z) against autograd through the float64 oracle on
+    fixture G13's draws; a FlatParameters home receives the same gradients in place."""
+    fx = golden("g13_mnf_conv2d")
+    n_in, n_out, k, seed = G13_CASES[tag]
+    t = lambda name, dt: torch.from_numpy(fx[f"{tag}.{name}"]).to(dt)
+    w_out = recipes.gaussian(7700 + n_out, *fx[f"{tag}.y"].shape[:1], int(np.prod(fx[f"{tag}.y"].shape[1:]))).reshape(fx[f"{tag}.y"].shape)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        p = {k_: t(k_, dt).clone().requires_grad_(True) for k_ in G13_KEYS}
+        specs = g13_specs(tag, "q", fx[f"{tag}.fwd.masks"])
+        for sp in specs:
+            sp["mask"] = sp["mask"].to(dt)
+            sp["params"] = {k_: v.to(dt).clone().requires_grad_(True) for k_, v in sp["params"].items()}
+        z, _ = O.mnf_conv2d_sample_z(p["q0_mean"], p["q0_log_var"], t("fwd.eps_z", dt), specs)
+        y = O.mnf_conv2d_forward(t("x", dt), z, p["W_mean"], p["W_log_var"], p["b_log_var"], t("fwd.eps_out", dt))
+        (y * w_out.to(dt)).sum().backward()
+        grads = {k_: v.grad for k_, v in p.items() if v.grad is not None}
+        for i, sp in enumerate(specs):
+            grads.update({f"flow_q.flows.{i}.{k_}": v.grad for k_, v in sp["params"].items()})
+        ref[dt] = grads
+
+    def run(homed):
+        layer, _ = conv_layer(amd, fx, tag)
+        flat = amd.FlatParameters(layer) if homed else None
+        dev = lambda name: torch.from_numpy(fx[f"{tag}.{name}"]).to(DEV)
+        y = layer.forward(dev("x"), eps=dev("fwd.eps_out"), eps_z=dev("fwd.eps_z"), masks=list(dev("fwd.masks")))
+        (y * w_out.to(DEV)).sum().backward()
+        return {n: (p.grad.detach().cpu().double() if p.grad is not None else None) for n, p in layer.named_parameters()}, flat
+
+    got, _ = run(False)
+    for name, r64 in ref[torch.float64].items():
+        r = r64.numpy()
+        g = got[name]
+        if not np.any(r):
+            assert g is None or not np.any(g.numpy()), name
+            continue
+        widen = 2 * normwise_err(ref[torch.float32][name].double().numpy(), r)
+        err = normwise_err(g.numpy().reshape(r.shape), r)
+        assert err <= GBASE + widen, f"MNFConv2d.forward {tag} grad {name}: {err:.2e} > 1e-5 + {widen:.2e}"
+    homed, flat = run(True)
+    for name, g in got.items():
+        if g is not None and homed[name] is not None and float(g.abs().max()) > 0:
+            assert normwise_err(homed[name].numpy(), g.numpy()) <= 2e-6, name
+    assert all(p.grad is v for p, v in zip(flat.params, flat._grad_views))

@@ -138,6 +138,10 @@ SIGNATURES = {
     "mnf_mnf_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),
+    "mnf_mnf_conv_operands": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
+    "mnf_mnf_conv_operands_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p]),
+    "mnf_mnf_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mnf_mnf_noise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_glow_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mnf_glow_weight_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_void_p]),

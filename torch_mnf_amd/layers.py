@@ -137,6 +137,69 @@ class _SampleZ0Fn(torch.autograd.Function):
         return out[:dim], out[dim:], None, None
 
 
+class _ConvOperandsFn(torch.autograd.Function):
+    """(W_mean * z per output channel, exp(W_log_var), exp(b_log_var)) -- the weights and bias of MNFConv2d.forward's two
+    convolutions (mnf_conv.py:69-72) -- one launch each way; the three parameters' gradients are added in place when
+    they live in a train.FlatParameters buffer."""
+
+    @staticmethod
+    def forward(ctx, W_mean, W_log_var, b_log_var, z, module):
+        Wm, Wl, bl, zc = (t.detach().contiguous() for t in (W_mean, W_log_var, b_log_var, z.reshape(-1)))
+        n_out, per_out = Wm.shape[0], Wm[0].numel()
+        Wz, Wv, bv = torch.empty_like(Wm), torch.empty_like(Wm), torch.empty_like(bl)
+        _lib.check("mnf_mnf_conv_operands", _lib.load().mnf_mnf_conv_operands(
+            Wm.data_ptr(), Wl.data_ptr(), bl.data_ptr(), zc.data_ptr(), Wz.data_ptr(), Wv.data_ptr(), bv.data_ptr(),
+            n_out, per_out, _stream()))
+        ctx.save_for_backward(Wm, Wl, bl, zc)
+        ctx.z_shape = tuple(z.shape)
+        params = [W_mean, W_log_var, b_log_var]
+        ctx.home = _flows._flat_home_of(module, params) if all(p.requires_grad for p in params) else None
+        ctx.set_materialize_grads(False)
+        return Wz, Wv, bv
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_wz, g_wv, g_bv):
+        Wm, Wl, bl, zc = ctx.saved_tensors
+        n_out, per_out, home = Wm.shape[0], Wm[0].numel(), ctx.home
+        n = n_out * per_out
+        buf = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.empty(2 * n + n_out, device=Wm.device)
+        gz = torch.empty(n_out, device=Wm.device)
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        g_wz, g_wv, g_bv = cont(g_wz), cont(g_wv), cont(g_bv)
+        _lib.check("mnf_mnf_conv_operands_bwd", _lib.load().mnf_mnf_conv_operands_bwd(
+            Wm.data_ptr(), Wl.data_ptr(), bl.data_ptr(), zc.data_ptr(), _flows._ptr(g_wz), _flows._ptr(g_wv),
+            _flows._ptr(g_bv), buf.data_ptr(), buf.data_ptr() + 4 * n, buf.data_ptr() + 8 * n, gz.data_ptr(), n_out,
+            per_out, int(home is not None), _stream()))
+        gz = gz.view(ctx.z_shape)
+        if home is not None:
+            return None, None, None, gz, None
+        return buf[:n].view_as(Wm), buf[n:2 * n].view_as(Wm), buf[2 * n:], gz, None
+
+
+class _NoiseFn(torch.autograd.Function):
+    """mean + sqrt(var) * eps (mnf_conv.py:86-88; the local-reparametrisation draw), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, mean, var, eps):
+        m, v, e = mean.detach().contiguous(), var.detach().contiguous(), eps.detach().contiguous()
+        out = torch.empty_like(m)
+        _lib.check("mnf_mnf_noise", _lib.load().mnf_mnf_noise(m.data_ptr(), v.data_ptr(), e.data_ptr(), out.data_ptr(),
+                                                             m.numel(), _stream()))
+        ctx.save_for_backward(v, e)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        v, e = ctx.saved_tensors
+        gc = g.contiguous()
+        gv = torch.empty_like(v)
+        _lib.check("mnf_mnf_noise_bwd", _lib.load().mnf_mnf_noise_bwd(v.data_ptr(), e.data_ptr(), gc.data_ptr(),
+                                                                     gv.data_ptr(), v.numel(), _stream()))
+        return gc, gv, None
+
+
 class _MnfKlFn(torch.autograd.Function):
     """``kl_div`` of either MNF layer behind its flows (mnf_linear.py:66-90, mnf_conv.py:100-133): one launch forward
     (``mnf_mnf_kl_fwd``) and one backward (``mnf_mnf_kl_bwd``) instead of ~70 + ~100 elementwise kernels.  The random
@@ -484,9 +547,16 @@ class MNFConv2d(nn.Module):
     def forward(self, x: Tensor, eps: Tensor | None = None, eps_z: Tensor | None = None, masks=None) -> Tensor:
         """(mnf_conv.py:67-88, algorithm 2 of the paper)."""
         z, _ = self.sample_z(eps_z, masks)
-        mean = F.conv2d(x, weight=self.W_mean * z.view(-1, 1, 1, 1), bias=self.b_mean)
-        var = F.conv2d(x * x, weight=self.W_log_var.exp(), bias=self.b_log_var.exp())
-        return mean + var.sqrt() * (torch.randn_like(var) if eps is None else eps)
+        if not x.is_cuda or x.device != self.W_mean.device or x.dtype != torch.float32:
+            raise RuntimeError(f"torch_mnf_amd: MNFConv2d.forward needs a float32 input on the layer's GPU "
+                               f"({self.W_mean.device}), got {x.dtype} on {x.device}; the HIP path has no CPU fallback")
+        # the convolutions' operands and the noise epilogue are one library launch each (and one each in backward); the
+        # two convolutions are the caller's arithmetic (MIOpen)
+        Wz, W_var, b_var = _ConvOperandsFn.apply(self.W_mean, self.W_log_var, self.b_log_var, z, self)
+        b_mean = self.b_mean if self.b_mean.device == x.device else self.b_mean.to(x.device)
+        mean = F.conv2d(x, weight=Wz, bias=b_mean)
+        var = F.conv2d(x * x, weight=W_var, bias=b_var)
+        return _NoiseFn.apply(mean, var, torch.randn_like(var) if eps is None else eps.to(var.device))
 
     def kl_div(self, noise: dict | None = None) -> Tensor:
         """(mnf_conv.py:100-133): both flows, then every closed-form term in one launch (``mnf_mnf_kl_fwd``).
