@@ -26,7 +26,10 @@ namespace mnf {
 
 constexpr int kMlWaves = 8;  // 128 rows share every staged operand chunk
 constexpr int kMlKC = 1;     // K-steps (32 input dims each) per chunk
-constexpr int kMlRing = 4;   // chunks of row data in flight per wave
+// chunks of row data in flight per wave: 4, but 2 at four output tiles (n_out > 48), where 64 accumulator registers plus a
+// 4-deep ring came to 256 VGPRs with 6 spilled: 582 -> 524 us at 256,000 x (800 -> 50)
+template <int YT>
+constexpr int kMlRing = YT >= 4 ? 2 : 4;
 
 template <int YT>
 struct MlShape {
@@ -123,7 +126,7 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
     // Row data comes from HBM with a couple of microseconds of latency under load while a chunk of split MFMAs takes
     // well under one: rows are requested D chunks ahead into a ring of register sets (the chunk loop is unrolled by D
     // so that the ring index is static); a set is re-requested as soon as it has been turned into MFMA operands.
-    constexpr int D = kMlRing;
+    constexpr int D = kMlRing<YT>;
     f32x4 xs[D][2 * KC], zs[D][2 * KC];
     __syncthreads();  // the previous group's last chunk is fully consumed
     {
