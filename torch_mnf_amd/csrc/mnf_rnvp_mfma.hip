@@ -343,8 +343,11 @@ __device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int gr
                                   log_det, image, rows, d, accumulate, seed, zprm, dm, vec);
 }
 
+#ifndef MNF_RNVP_SPLIT_OCC
+#define MNF_RNVP_SPLIT_OCC 4  // workgroups per CU the register allocation aims at (experiment switch)
+#endif
 template <int HN, bool SEEDED, bool RAG>
-__global__ void __launch_bounds__(kRnvpWaves * 64, 4)
+__global__ void __launch_bounds__(kRnvpWaves * 64, MNF_RNVP_SPLIT_OCC)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
                   int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
