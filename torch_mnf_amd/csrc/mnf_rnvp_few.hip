@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(kFewThreads) rnvp_few_bwd_kernel(const RnvpFew
   for (int r = 0; r < R; ++r) gy[r] = 0.f;
   {
     const bool kin = lane < h;
-    constexpr int JC = 4, step = kFewWaves * JC;
+    constexpr int JC = R == 1 ? 4 : 2, step = kFewWaves * JC;  // (R = 2 at JC = 4: 12 registers spilled)
     float yk[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) yk[r] = kin ? y[r * h + lane] : 0.f;
