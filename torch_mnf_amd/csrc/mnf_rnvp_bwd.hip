@@ -36,6 +36,9 @@
 // groups behind B (mnf_rnvp_bwd's kernel with a flag list: it returns at once for every other group).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "mnf_device.h"
 #include "mnf_host.h"
 #include "mnf_rnvp_common.h"
@@ -689,6 +692,353 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ B-ts, shared hand-over
+// The kernel above re-reads launch A's hand-over (1 KB per row) once per 32-dim slab -- 4 x the bytes of the slab's own
+// row data -- and holds both row tiles' hand-over operands in registers (64 of them) next to 64 accumulators: it spills
+// ~70 registers at two waves per SIMD and waits on each load in turn.  Here a workgroup of EIGHT waves owns FOUR adjacent
+// slabs and walks its row pairs together: wave (slab s, tile t) computes tile 2 p + t of pair p for slab s.  The pair's
+// hand-over (y and g_y with units on K, y with rows on K: 12 KB per tile at 64 units) and its 32 g_ld values are copied
+// ONCE per workgroup into a double-buffered LDS window by LDS-DMA (global_load_lds: no staging registers) while the
+// previous pair is being computed, and every wave reads its MFMA operands out of it as it needs them: a quarter of the
+// hand-over traffic, no hand-over registers, and the next pair's rows prefetched into the registers that frees.  A wave
+// owns ONE 16-row tile, so the sums over rows run as K = 16 products (v_mfma_f32_16x16x16_f16) straight off the tile's
+// accumulators.  LDS: 4 slabs x 24 KB of operands + 1 KB of biases + 2 x 2 x 12 KB of hand-over = 145 KB: one workgroup
+// per CU, two waves per SIMD.  One barrier per pair.
+typedef __attribute__((address_space(3))) void* lds_void_ptr_b;
+constexpr int kTsSlabs = 4;              // slabs per workgroup
+constexpr int kTsWaves = 2 * kTsSlabs;   // (slab, tile of the pair)
+
+template <int HN>
+struct RnvpTsShape {
+  using B = RnvpBwdShape<HN>;
+  using H = typename B::H;
+  static constexpr int YT = B::YT;
+  static constexpr int W_WORDS = B::B2_SLAB_WORDS + B::B4_SLAB_WORDS;  // one slab's split operands
+  static constexpr int HT_WORDS = 2 * H::OP_WORDS + H::TR_WORDS;       // A_OP, B_OP, A_TR: the head of a tile's hand-over
+  static_assert(H::A_OP == 0 && H::B_OP == H::OP_WORDS && H::A_TR == 2 * H::OP_WORDS, "the three parts are contiguous");
+  static_assert(HT_WORDS % 256 == 0, "whole 1 KB pieces");
+  static constexpr int HT_PIECES = HT_WORDS / 256;
+  static constexpr int N_DMA = (2 * HT_PIECES + kTsWaves - 1) / kTsWaves;  // pieces per wave and pair
+  static constexpr int BIAS_OFF = kTsSlabs * W_WORDS;
+  static constexpr int H_OFF = BIAS_OFF + kTsSlabs * B::B_SLAB_PLAIN;
+  static constexpr int GL_OFF = H_OFF + 2 * 2 * HT_WORDS;  // the pair's 32 g_ld values, double-buffered (64 words each)
+  static constexpr int LDS_WORDS = GL_OFF + 2 * 64;
+  static constexpr int UP = 16 * YT + 1;                 // padded [dim] row of the flush area
+  static constexpr int RED_SLAB = 2 * 32 * UP + 64;      // Wt, Ws blocks and the two bias rows of one slab
+  static_assert(kTsSlabs * RED_SLAB <= BIAS_OFF, "the flush area fits the operand area");
+  static_assert(LDS_WORDS * 4 <= 160 * 1024, "fits the CU's LDS");
+};
+
+template <int HN, bool SEEDED, bool RAG>
+__global__ void __launch_bounds__(kTsWaves * 64, 2)
+rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
+                          const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
+                          const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side,
+                          const int32_t* __restrict__ flags, const float* __restrict__ gscale_dev, int64_t rows, int dm,
+                          int d16, int hn, uint64_t seed, int n_slabs, int row_parts, int vec2) {
+  using S = RnvpSplitShape<HN>;
+  using B = RnvpBwdShape<HN>;
+  using T = RnvpTsShape<HN>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t ts_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sl = wave & (kTsSlabs - 1), tt = wave / kTsSlabs;  // (waves w and w + 4 share a SIMD: same slab, other tile)
+  const int j = lane & 15, q = lane >> 4;
+  const float gscale = gscale_dev[0], inv_gscale = 1.f / gscale;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
+  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
+  const float* gsrc = gx ? gx : z;  // (no cotangent for x: read z and multiply by zero)
+  const float gx_scale = gx ? gscale : 0.f;
+  const float gl_scale = gld ? gscale : 0.f;
+  const float* lsrc = gld ? gld : z;
+  const int n_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
+  const SlabItems items(n_groups, row_parts);
+  for (int item = items.first; item < items.n_items; item += items.step) {
+    const int sg = items.slab(item), part = items.part(item);
+    const int slab = sg * kTsSlabs + sl;
+    const bool slab_ok = slab < n_slabs;  // (wave-uniform: the last group may hold fewer than four slabs)
+    const int64_t p0 = (int64_t)part * per_part, p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    if (p0 >= p_end) continue;  // (workgroup-uniform)
+    __syncthreads();  // the previous item's flush is over
+#pragma unroll 1
+    for (int s = 0; s < kTsSlabs; ++s) {
+      const int sb = sg * kTsSlabs + s;
+      if (sb >= n_slabs) break;
+      const uint4* b2 = reinterpret_cast<const uint4*>(bimage + B::a3_words(d16) + (int64_t)sb * B::B2_SLAB_WORDS);
+      const uint4* b4 =
+          reinterpret_cast<const uint4*>(bimage + B::a3_words(d16) + B::b2_words(dm) + (int64_t)sb * B::B4_SLAB_WORDS);
+      const uint32_t* pl = bimage + B::split_words(dm, d16) + (int64_t)sb * B::B_SLAB_PLAIN;
+      uint4* w = reinterpret_cast<uint4*>(ts_lds + s * T::W_WORDS);
+      for (int i = threadIdx.x; i < B::B2_SLAB_WORDS / 4; i += blockDim.x) w[i] = b2[i];
+      for (int i = threadIdx.x; i < B::B4_SLAB_WORDS / 4; i += blockDim.x) w[B::B2_SLAB_WORDS / 4 + i] = b4[i];
+      if ((int)threadIdx.x < B::B_SLAB_PLAIN) ts_lds[T::BIAS_OFF + s * B::B_SLAB_PLAIN + threadIdx.x] = pl[threadIdx.x];
+    }
+    // (visible to every wave behind the pair loop's first barrier)
+    const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
+    const bool in0 = slab_ok && dim0 < dm, in1 = slab_ok && dim0 + 1 < dm;
+    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
+    int w_lane = lane;  // opaque, refreshed per pair: keeps the (pair-independent) operand reads inside the loop
+    const f16x8* W8 = reinterpret_cast<const f16x8*>(ts_lds + sl * T::W_WORDS);
+    auto w2 = [&](int dt, int net, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
+    auto w4 = [&](int dt, int ks, int part_) { return W8[w_lane + 64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
+
+    f32x4 aWt[2][YT], aWs[2][YT];
+    float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = zero4;
+
+    // a tile's rows as LOADED (nothing here waits for a load: the values are first touched by compute(), one pair later)
+    struct RowsIn {
+      f32x2 zz[4], GG[4], mm[4];
+      uint32_t mbits;  // SEEDED: bit 2 r + dt = the mask of (row 4 q + r, dim dim0 + dt)
+      bool active;
+      int n_live;
+      int64_t tbase;
+    };
+    auto load_rows = [&](int64_t p, RowsIn& in) {
+      const int64_t tile = 2 * p + tt;
+      const bool has = tile < n_tiles;
+      in.tbase = (has ? tile : 2 * p) * 16;  // wave-uniform
+      in.n_live = has ? (int)min((int64_t)16, rows - in.tbase) : 0;
+      in.active = has && slab_ok && flags[(p * 32) / kBwdGroupRows] == 0;  // the generic kernel redoes flagged groups
+      if (!in.active) return;
+      const float* zt = z + in.tbase * dm;
+      const float* gt_ = gsrc + in.tbase * dm;
+      const float* mt = SEEDED ? nullptr : mask + in.tbase * dm;
+      in.mbits = 0u;
+      if (SEEDED) {
+        uint32_t mw[4];
+        tile_mask_words(seed, in.tbase, in.n_live, slab, lane, q, mw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in.mbits |= ((mw[r] >> (2 * j)) & 3u) << (2 * r);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * q + r;
+        const bool live = rr < in.n_live;
+        // a row past the end reads the tile's first row instead (its cotangents are zeroed, nothing of it is stored);
+        // byte offsets in 32 bits: [uniform tile base] + offset addressing, no 64-bit address pair per access
+        const uint32_t ob = (live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0) * 4u;
+        auto at = [&](const float* base) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ob); };
+        f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
+        if (!RAG) {
+          zv = *reinterpret_cast<const f32x2*>(at(zt));
+          gv = *reinterpret_cast<const f32x2*>(at(gt_));
+          if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(at(mt));
+        } else if (vec2) {
+          if (in0) {
+            zv = *reinterpret_cast<const f32x2*>(at(zt));
+            gv = *reinterpret_cast<const f32x2*>(at(gt_));
+            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(at(mt));
+          }
+        } else {
+          if (in0) {
+            zv[0] = at(zt)[0];
+            gv[0] = at(gt_)[0];
+            if (!SEEDED) mv[0] = at(mt)[0];
+          }
+          if (in1) {
+            zv[1] = at(zt)[1];
+            gv[1] = at(gt_)[1];
+            if (!SEEDED) mv[1] = at(mt)[1];
+          }
+        }
+        in.zz[r] = zv;
+        in.GG[r] = gv;
+        in.mm[r] = mv;
+      }
+    };
+    // the pair's hand-over -> LDS buffer `buf`: 2 x HT_PIECES pieces of 1 KB, dealt to the eight waves; its g_ld values
+    auto request_handover = [&](int64_t p, int buf) {
+      const int n_pieces = (2 * p + 1 < n_tiles ? 2 : 1) * T::HT_PIECES;
+#pragma unroll
+      for (int i = 0; i < T::N_DMA; ++i) {
+        const int piece = i * kTsWaves + wave;  // wave-uniform
+        if (piece < n_pieces) {
+          const int t = piece / T::HT_PIECES, k = piece - t * T::HT_PIECES;
+          const uint32_t* src = side + (2 * p + t) * B::TILE_WORDS + k * 256 + lane * 4;
+          uint32_t* dst = ts_lds + T::H_OFF + (buf * 2 + t) * T::HT_WORDS + k * 256;
+          __builtin_amdgcn_global_load_lds(src, (lds_void_ptr_b)dst, 16, 0, 0);
+        }
+      }
+      if (wave == kTsWaves - 1 && lane < 32) {  // (rows past the end: the last row's value, multiplied by zero later)
+        const int64_t row = min(p * 32 + lane, rows - 1);
+        __builtin_amdgcn_global_load_lds(lsrc + row, (lds_void_ptr_b)(ts_lds + T::GL_OFF + buf * 64), 4, 0, 0);
+      }
+      asm volatile("" ::: "memory");  // (the pair's stores stay behind the pieces: landed_barrier() counts on it)
+    };
+    // Vector-memory operations complete in issue order: with `stores` operations known to have been issued behind this
+    // wave's pieces, all but the youngest `stores` being complete means the pieces are in LDS (the stores stay in flight).
+    // Inline asm, not __syncthreads(): that one's release fence drains every outstanding store (s_waitcnt vmcnt(0)).
+    auto landed_barrier = [&](int stores) {
+      if (stores == 4)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // returns the number of vector-memory instructions it issued for certain (4 or 0)
+    auto compute = [&](RowsIn& in, int buf) -> int {
+      if (!in.active) return 0;
+      asm volatile("" : "+v"(w_lane));
+      uint32_t h_off = (uint32_t)(T::H_OFF + (buf * 2 + tt) * T::HT_WORDS) * 4u + (uint32_t)lane * 16u;
+      asm volatile("" : "+v"(h_off));
+      const char* hb = reinterpret_cast<const char*>(ts_lds) + h_off;             // + operand * 1 KB
+      const char* hb_tr = reinterpret_cast<const char*>(ts_lds) + h_off - lane * 8u + 2 * T::H::OP_WORDS * 4;  // 8 B per lane
+      auto y_op = [&](int ks, int part_) { return *reinterpret_cast<const f16x8*>(hb + (2 * ks + part_) * 1024); };
+      auto g_op = [&](int ks, int part_) {
+        return *reinterpret_cast<const f16x8*>(hb + T::H::OP_WORDS * 4 + (2 * ks + part_) * 1024);
+      };
+      auto y_tr = [&](int m, int part_) { return *reinterpret_cast<const u32x2*>(hb_tr + (2 * m + part_) * 512); };
+      const float* bias = reinterpret_cast<const float*>(ts_lds + T::BIAS_OFF + sl * B::B_SLAB_PLAIN);
+      const f32x4 gl4 = *reinterpret_cast<const f32x4*>(ts_lds + T::GL_OFF + buf * 64 + tt * 16 + 4 * q);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        __builtin_amdgcn_sched_barrier(0);  // (one dim tile's operand reads at a time)
+        // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim]
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) {
+          const f16x8 yh = y_op(ks, 0), yl = y_op(ks, 1);
+          split_mac(yh, yl, w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
+          split_mac(yh, yl, w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+        }
+        const f32x4 t4 = tc * kSplitInvScale + tm + bias[dt * 16 + j];
+        const f32x4 s4 = sc * kSplitInvScale + sm + bias[32 + dt * 16 + j];
+        f32x4 gt, gs, gz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float keep = 4 * q + r < in.n_live ? 1.f : 0.f;
+          float m_;
+          if (SEEDED)
+            m_ = (float)((in.mbits >> (2 * r + dt)) & 1u);
+          else
+            m_ = in.mm[r][dt];
+          const float zv = in.zz[r][dt], G_ = in.GG[r][dt] * (gx_scale * keep), nm = 1.f - m_;
+          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+          const float omg = 1.f - gate;
+          gt[r] = G_ * omg;
+          gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl4[r] * (gl_scale * keep) * nm) * omg;
+          gz[r] = G_ * (nm * gate + m_);
+        }
+        abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+        abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
+        u32x2 th, tl, sh, sl_;  // B operands of the sums over the tile's 16 rows
+        split_plain(gt, th, tl);
+        split_plain(gs, sh, sl_);
+        // g_k^T = g_y Wn;  grad_z = G ((1-m) gate + m) + m g_k  (takes z's register)
+        f32x4 km = zero4, kc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) split_mac(g_op(ks, 0), g_op(ks, 1), w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
+        const f32x4 gk = kc * kSplitInvScale + km;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float m_;
+          if (SEEDED)
+            m_ = (float)((in.mbits >> (2 * r + dt)) & 1u);
+          else
+            m_ = in.mm[r][dt];
+          in.zz[r][dt] = (gz[r] + m_ * gk[r]) * inv_gscale;
+        }
+        if (grad_flat) {
+          // D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
+#pragma unroll
+          for (int m = 0; m < YT; ++m) {
+            const u32x2 yh = y_tr(m, 0), yl = y_tr(m, 1);
+            aWt[dt][m] = mfma16(yh, th, aWt[dt][m]);
+            aWs[dt][m] = mfma16(yh, sh, aWs[dt][m]);
+            aWt[dt][m] = mfma16(yh, tl, aWt[dt][m]);
+            aWs[dt][m] = mfma16(yh, sl_, aWs[dt][m]);
+            aWt[dt][m] = mfma16(yl, th, aWt[dt][m]);
+            aWs[dt][m] = mfma16(yl, sh, aWs[dt][m]);
+          }
+        }
+      }
+      float* ot = grad_z + in.tbase * dm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (4 * q + r < in.n_live) {
+          const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
+          if (!RAG) {
+            *reinterpret_cast<f32x2*>(ot + off) = in.zz[r];
+          } else if (vec2) {  // (dm even: in0 implies in1)
+            if (in0) *reinterpret_cast<f32x2*>(ot + off) = in.zz[r];
+          } else {
+            if (in0) ot[off] = in.zz[r][0];
+            if (in1) ot[off + 1] = in.zz[r][1];
+          }
+        }
+      }
+      return (in.n_live == 16 && (!RAG || vec2)) ? 4 : 0;
+    };
+
+    {
+      RowsIn cur, nxt;
+      load_rows(p0, cur);
+      request_handover(p0, 0);
+      int stores = 0;
+      for (int64_t p = p0; p < p_end; ++p) {
+        const int buf = (int)(p - p0) & 1;
+        landed_barrier(stores);  // every wave's pieces of pair p are in LDS, pair p - 1 (the other buffer) is consumed
+        const bool more = p + 1 < p_end;
+        if (more) {
+          load_rows(p + 1, nxt);
+          request_handover(p + 1, buf ^ 1);
+        }
+        stores = compute(cur, buf);
+        if (more) cur = nxt;
+      }
+    }
+    if (!grad_flat) continue;
+    // flush: as in the kernel above, per slab -- the workgroup's waves add their tiles up in LDS (the operand area is free
+    // now) as [slab][tensor][dim of the slab][unit], then the group's CONTIGUOUS blocks of Wt / Ws go to grad_flat
+    float* red = reinterpret_cast<float*>(ts_lds);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTsSlabs * T::RED_SLAB; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    if (slab_ok) {
+      float* rs = red + sl * T::RED_SLAB;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int m = 0; m < YT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(rs + (2 * j + dt) * T::UP + 16 * m + 4 * q + r, aWt[dt][m][r]);
+            atomicAdd(rs + 32 * T::UP + (2 * j + dt) * T::UP + 16 * m + 4 * q + r, aWs[dt][m][r]);
+          }
+        float vt = abt[dt], vs = abs_[dt];
+        vt += __shfl_xor(vt, 16, 64);
+        vt += __shfl_xor(vt, 32, 64);
+        vs += __shfl_xor(vs, 16, 64);
+        vs += __shfl_xor(vs, 32, 64);
+        if (q == 0) {
+          atomicAdd(rs + 2 * 32 * T::UP + 2 * j + dt, vt);
+          atomicAdd(rs + 2 * 32 * T::UP + 32 + 2 * j + dt, vs);
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t bn = (int64_t)hn * dm, wt = bn + hn, btf = wt + (int64_t)dm * hn, ws = btf + dm,
+                  bsf = ws + (int64_t)dm * hn;
+    const int dim_g = 32 * kTsSlabs * sg;                       // first dim of the group
+    const int n_dims = min(32 * kTsSlabs, dm - dim_g);          // dims of this group that exist
+    for (int e = threadIdx.x; e < n_dims * hn; e += blockDim.x) {
+      const int dl = e / hn, unit = e - dl * hn;
+      const float* rs = red + (dl >> 5) * T::RED_SLAB + (dl & 31) * T::UP + unit;
+      atomicAdd(grad_flat + wt + (int64_t)dim_g * hn + e, rs[0] * inv_gscale);
+      atomicAdd(grad_flat + ws + (int64_t)dim_g * hn + e, rs[32 * T::UP] * inv_gscale);
+    }
+    if ((int)threadIdx.x < n_dims) {
+      const float* rs = red + (threadIdx.x >> 5) * T::RED_SLAB + 2 * 32 * T::UP + (threadIdx.x & 31);
+      atomicAdd(grad_flat + btf + dim_g + threadIdx.x, rs[0] * inv_gscale);
+      atomicAdd(grad_flat + bsf + dim_g + threadIdx.x, rs[32] * inv_gscale);
+    }
+  }
+}
+
 // B-n: dWn [unit][dim] += sum over rows of g_y [row][unit] (m z) [row][dim] -- needs z, the mask and launch A's g_y only
 // (no gate arithmetic, 8 accumulator tiles): its own launch, four waves per SIMD, so that B-ts keeps 16 accumulator
 // tiles instead of 24 and fits two waves per SIMD.
@@ -875,6 +1225,16 @@ static int64_t bwd_workspace_bytes(int64_t rows) {
   return bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4;
 }
 
+// MNF_RNVP_BWD_TS=split in the environment: launch B-ts on the one-slab-per-workgroup kernel (the round-3 kernel, kept
+// for same-box A/B runs and as the fallback when the shared kernel's LDS request is refused)
+static bool bwd_ts_split_forced() {
+  static const bool forced = [] {
+    const char* v = getenv("MNF_RNVP_BWD_TS");
+    return v != nullptr && strcmp(v, "split") == 0;
+  }();
+  return forced;
+}
+
 // phases: bit 0 launch A, bit 1 B-ts, bit 2 B-n (bit 3, the fp32 fix-up, is the caller's)
 template <int HN, bool SEEDED, bool RAG>
 static int launch_bwd(const float* z, const float* mask, uint64_t seed, const float* gx, const float* gld, float* grad_z,
@@ -909,6 +1269,31 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   const int resident_b = memo_b.get(
       [](int dev) { return resident_by_occupancy(rnvp_bwd_ts_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
   int row_parts, grid;
+  if ((phases & 2) && !bwd_ts_split_forced()) {
+    // the shared-hand-over kernel: four slabs per workgroup, one workgroup per CU (145 KB of LDS at 64 units)
+    using T = RnvpTsShape<HN>;
+    static DeviceMemo memo_s;
+    const int resident_s = memo_s.get([](int dev) {
+      const auto kernel = rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              T::LDS_WORDS * 4) != hipSuccess)
+        return -1;
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTsWaves * 64, T::LDS_WORDS * 4) != hipSuccess ||
+          per_cu < 1)
+        per_cu = 1;
+      return per_cu * device_cus(dev);
+    });
+    if (resident_s > 0) {
+      const int n_slab_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
+      plan_slab_launch(n_pairs, 1, n_slab_groups, resident_s, row_parts, grid);
+      hipLaunchKernelGGL((rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kTsWaves * 64),
+                         T::LDS_WORDS * 4, stream, z, mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows,
+                         dm, d16, hn, seed, n_slabs, row_parts, vec2);
+      if (int rc = check_launch()) return rc;
+      phases &= ~2;
+    }
+  }
   plan(resident_b, row_parts, grid);
   if (phases & 2) {
     hipLaunchKernelGGL((rnvp_bwd_ts_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
