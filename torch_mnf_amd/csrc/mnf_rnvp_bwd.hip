@@ -721,8 +721,8 @@ struct RnvpTsShape {
   static constexpr int N_DMA = (2 * HT_PIECES + kTsWaves - 1) / kTsWaves;  // pieces per wave and pair
   static constexpr int BIAS_OFF = kTsSlabs * W_WORDS;
   static constexpr int H_OFF = BIAS_OFF + kTsSlabs * B::B_SLAB_PLAIN;
-  static constexpr int GL_OFF = H_OFF + 2 * 2 * HT_WORDS;  // the pair's 32 g_ld values, double-buffered (64 words each)
-  static constexpr int LDS_WORDS = GL_OFF + 2 * 64;
+  static constexpr int GL_OFF = H_OFF + 2 * 2 * HT_WORDS;  // g_ld of the pair's rows: [buffer][wave][64 words]
+  static constexpr int LDS_WORDS = GL_OFF + 2 * kTsWaves * 64;
   static constexpr int UP = 16 * YT + 1;                 // padded [dim] row of the flush area
   static constexpr int RED_SLAB = 2 * 32 * UP + 64;      // Wt, Ws blocks and the two bias rows of one slab
   static_assert(kTsSlabs * RED_SLAB <= BIAS_OFF, "the flush area fits the operand area");
@@ -751,7 +751,7 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
   const float* gsrc = gx ? gx : z;  // (no cotangent for x: read z and multiply by zero)
   const float gx_scale = gx ? gscale : 0.f;
   const float gl_scale = gld ? gscale : 0.f;
-  const float* lsrc = gld ? gld : z;
+  [[maybe_unused]] const float* lsrc = gld ? gld : z;
   const int n_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
   const SlabItems items(n_groups, row_parts);
   for (int item = items.first; item < items.n_items; item += items.step) {
@@ -775,8 +775,8 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
       if ((int)threadIdx.x < B::B_SLAB_PLAIN) ts_lds[T::BIAS_OFF + s * B::B_SLAB_PLAIN + threadIdx.x] = pl[threadIdx.x];
     }
     // (visible to every wave behind the pair loop's first barrier)
-    const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
-    const bool in0 = slab_ok && dim0 < dm, in1 = slab_ok && dim0 + 1 < dm;
+    const int dim0 = 32 * (slab_ok ? slab : n_slabs - 1) + 2 * j;  // the lane's even dim; + 1: its odd dim
+    const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
     const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
     int w_lane = lane;  // opaque, refreshed per pair: keeps the (pair-independent) operand reads inside the loop
     const f16x8* W8 = reinterpret_cast<const f16x8*>(ts_lds + sl * T::W_WORDS);
@@ -804,7 +804,8 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
       in.tbase = (has ? tile : 2 * p) * 16;  // wave-uniform
       in.n_live = has ? (int)min((int64_t)16, rows - in.tbase) : 0;
       in.active = has && slab_ok && flags[(p * 32) / kBwdGroupRows] == 0;  // the generic kernel redoes flagged groups
-      if (!in.active) return;
+      // (an idle wave loads all the same, from its clamped slab: no branch around the loads, so that the compiler's
+      // count of the operations in flight stays exact)
       const float* zt = z + in.tbase * dm;
       const float* gt_ = gsrc + in.tbase * dm;
       const float* mt = SEEDED ? nullptr : mask + in.tbase * dm;
@@ -851,23 +852,32 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
         in.mm[r] = mv;
       }
     };
-    // the pair's hand-over -> LDS buffer `buf`: 2 x HT_PIECES pieces of 1 KB, dealt to the eight waves; its g_ld values
+    // the pair's hand-over -> LDS buffer `buf`: 2 x HT_PIECES pieces of 1 KB, dealt to the eight waves (no branches: a
+    // piece past the end, or of a second tile that does not exist, repeats a valid one), and g_ld of the pair's rows
+    // (buffer_load ... lds, not global_load_lds: the compiler files the latter under "flat, may touch LDS and memory" and
+    // from then on waits for EVERY outstanding load -- s_waitcnt vmcnt(0) -- at the first use of any loaded register)
     auto request_handover = [&](int64_t p, int buf) {
-      const int n_pieces = (2 * p + 1 < n_tiles ? 2 : 1) * T::HT_PIECES;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in hipcc's host pass over this file)
+      const int has1 = 2 * p + 1 < n_tiles ? 1 : 0;
+      const __amdgpu_buffer_rsrc_t pair_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint32_t*>(side + (2 * p) * B::TILE_WORDS), 0, 2 * B::TILE_WORDS * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < T::N_DMA; ++i) {
-        const int piece = i * kTsWaves + wave;  // wave-uniform
-        if (piece < n_pieces) {
-          const int t = piece / T::HT_PIECES, k = piece - t * T::HT_PIECES;
-          const uint32_t* src = side + (2 * p + t) * B::TILE_WORDS + k * 256 + lane * 4;
-          uint32_t* dst = ts_lds + T::H_OFF + (buf * 2 + t) * T::HT_WORDS + k * 256;
-          __builtin_amdgcn_global_load_lds(src, (lds_void_ptr_b)dst, 16, 0, 0);
-        }
+        const int piece = min(i * kTsWaves + wave, 2 * T::HT_PIECES - 1);  // wave-uniform
+        const int t = piece / T::HT_PIECES, k = piece - t * T::HT_PIECES;
+        uint32_t* dst = ts_lds + T::H_OFF + (buf * 2 + t) * T::HT_WORDS + k * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pair_rsrc, (lds_void_ptr_b)dst, 16, lane * 16,
+                                             (t & has1) * (B::TILE_WORDS * 4) + k * 1024, 0, 0);
       }
-      if (wave == kTsWaves - 1 && lane < 32) {  // (rows past the end: the last row's value, multiplied by zero later)
-        const int64_t row = min(p * 32 + lane, rows - 1);
-        __builtin_amdgcn_global_load_lds(lsrc + row, (lds_void_ptr_b)(ts_lds + T::GL_OFF + buf * 64), 4, 0, 0);
+      {  // g_ld of the pair's rows (past the end: the last row's value, multiplied by zero later)
+        const int64_t left = rows - p * 32;  // >= 1
+        const int l = left > lane ? lane : (int)left - 1;
+        const __amdgpu_buffer_rsrc_t gl_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lsrc + p * 32), 0, 64 * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gl_rsrc, (lds_void_ptr_b)(ts_lds + T::GL_OFF + (buf * kTsWaves + wave) * 64), 4,
+                                             l * 4, 0, 0, 0);
       }
+#endif
       asm volatile("" ::: "memory");  // (the pair's stores stay behind the pieces: landed_barrier() counts on it)
     };
     // Vector-memory operations complete in issue order: with `stores` operations known to have been issued behind this
@@ -893,7 +903,7 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
       };
       auto y_tr = [&](int m, int part_) { return *reinterpret_cast<const u32x2*>(hb_tr + (2 * m + part_) * 512); };
       const float* bias = reinterpret_cast<const float*>(ts_lds + T::BIAS_OFF + sl * B::B_SLAB_PLAIN);
-      const f32x4 gl4 = *reinterpret_cast<const f32x4*>(ts_lds + T::GL_OFF + buf * 64 + tt * 16 + 4 * q);
+      const f32x4 gl4 = *reinterpret_cast<const f32x4*>(ts_lds + T::GL_OFF + (buf * kTsWaves + wave) * 64 + tt * 16 + 4 * q);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         __builtin_amdgcn_sched_barrier(0);  // (one dim tile's operand reads at a time)
@@ -975,20 +985,30 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
     };
 
     {
-      RowsIn cur, nxt;
-      load_rows(p0, cur);
+      // two register sets, alternating roles (no copies: a copy would wait for the loads it moves); the last pair
+      // requests itself once more into the idle buffer rather than branching around the requests
+      RowsIn ra, rb;
+      load_rows(p0, ra);
       request_handover(p0, 0);
       int stores = 0;
-      for (int64_t p = p0; p < p_end; ++p) {
-        const int buf = (int)(p - p0) & 1;
+      int64_t p = p0;
+      while (true) {
         landed_barrier(stores);  // every wave's pieces of pair p are in LDS, pair p - 1 (the other buffer) is consumed
-        const bool more = p + 1 < p_end;
-        if (more) {
-          load_rows(p + 1, nxt);
-          request_handover(p + 1, buf ^ 1);
+        {
+          const int64_t pn = min(p + 1, p_end - 1);
+          load_rows(pn, rb);
+          request_handover(pn, 1);
         }
-        stores = compute(cur, buf);
-        if (more) cur = nxt;
+        stores = compute(ra, 0);
+        if (++p >= p_end) break;
+        landed_barrier(stores);
+        {
+          const int64_t pn = min(p + 1, p_end - 1);
+          load_rows(pn, ra);
+          request_handover(pn, 0);
+        }
+        stores = compute(rb, 1);
+        if (++p >= p_end) break;
       }
     }
     if (!grad_flat) continue;
@@ -1273,13 +1293,15 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     // the shared-hand-over kernel: four slabs per workgroup, one workgroup per CU (145 KB of LDS at 64 units)
     using T = RnvpTsShape<HN>;
     static DeviceMemo memo_s;
-    const int resident_s = memo_s.get([](int dev) {
-      const auto kernel = rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>;
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    void (*const ts_kernel)(const float*, const float*, const float*, const float*, float*, float*, const uint32_t*,
+                            const uint32_t*, const int32_t*, const float*, int64_t, int, int, int, uint64_t, int, int, int) =
+        rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>;  // (named out here: a kernel first named inside a lambda gets no host stub)
+    const int resident_s = memo_s.get([ts_kernel](int dev) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS_WORDS * 4) != hipSuccess)
         return -1;
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTsWaves * 64, T::LDS_WORDS * 4) != hipSuccess ||
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ts_kernel, kTsWaves * 64, T::LDS_WORDS * 4) != hipSuccess ||
           per_cu < 1)
         per_cu = 1;
       return per_cu * device_cus(dev);
