@@ -502,7 +502,7 @@ def main_train_c5(args, rank, world, device, dim, rows, desc) -> None:
         gbs = algo_bytes / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": source, **physical(traffic, avg_s),
-                           "kernel": "rnvp_bwd_ts_kernel<50,seeded> (launch B-ts of one RNVP layer's gradient pass: s, t, "
+                           "kernel": "rnvp_bwd_ts_shared_kernel<50,seeded> (launch B-ts of one RNVP layer's gradient pass: s, t, "
                                      "gate, g_k, grad_z and the row sums dWt, dWs; 2 launches per step)",
                            "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
                            "launches_timed": len(kern_ms), "launches_per_step": 2,

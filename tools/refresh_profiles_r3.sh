@@ -10,7 +10,7 @@ cd "$REPO"
 WL=${*:-c2 c3 c4 c5 c2t c5t}
 declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
                   [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
-                  [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_kernel<50, true, false" \
+                  [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_shared_kernel<50, true, false" \
                   [c3t]="nsf_bwd" )
 for w in $WL; do
   extra=""; [ "$w" = c2 ] && extra="--no-secondary"

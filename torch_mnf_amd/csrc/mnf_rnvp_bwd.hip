@@ -701,10 +701,14 @@ rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
 // ONCE per workgroup into a double-buffered LDS window by LDS-DMA (global_load_lds: no staging registers) while the
 // previous pair is being computed, and every wave reads its MFMA operands out of it as it needs them: a quarter of the
 // hand-over traffic, no hand-over registers, and the next pair's rows prefetched into the registers that frees.  A wave
-// owns ONE 16-row tile, so the sums over rows run as K = 16 products (v_mfma_f32_16x16x16_f16) straight off the tile's
-// accumulators.  LDS: 4 slabs x 24 KB of operands + 1 KB of biases + 2 x 2 x 12 KB of hand-over = 145 KB: one workgroup
+// owns ONE 16-row tile, so the sums over rows run straight off the tile's accumulators (as K = 32 products whose two K
+// halves carry the head and the residual of y: see row_sums).  LDS: 4 slabs x 24 KB of operands + 1 KB of biases + 2 x 2 x 12 KB of hand-over = 145 KB: one workgroup
 // per CU, two waves per SIMD.  One barrier per pair.
 typedef __attribute__((address_space(3))) void* lds_void_ptr_b;
+#ifndef MNF_RNVP_TS_ABL
+#define MNF_RNVP_TS_ABL 0  // timing experiments only (results are wrong): bit 0 no arithmetic (loads, pieces, stores and
+#endif                     // barriers only), bit 1 no row loads / pieces / stores (arithmetic on whatever is there)
+constexpr int kTsAbl = MNF_RNVP_TS_ABL;
 constexpr int kTsSlabs = 4;              // slabs per workgroup
 constexpr int kTsWaves = 2 * kTsSlabs;   // (slab, tile of the pair)
 
@@ -825,7 +829,9 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
         const uint32_t ob = (live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0) * 4u;
         auto at = [&](const float* base) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ob); };
         f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
-        if (!RAG) {
+        if (kTsAbl & 2) {
+          zv = gv = f32x2{0.25f * lane, 1.f};
+        } else if (!RAG) {
           zv = *reinterpret_cast<const f32x2*>(at(zt));
           gv = *reinterpret_cast<const f32x2*>(at(gt_));
           if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(at(mt));
@@ -858,6 +864,7 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
     // from then on waits for EVERY outstanding load -- s_waitcnt vmcnt(0) -- at the first use of any loaded register)
     auto request_handover = [&](int64_t p, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in hipcc's host pass over this file)
+      if (kTsAbl & 2) return;
       const int has1 = 2 * p + 1 < n_tiles ? 1 : 0;
       const __amdgpu_buffer_rsrc_t pair_rsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<uint32_t*>(side + (2 * p) * B::TILE_WORDS), 0, 2 * B::TILE_WORDS * 4, 0x00020000);
@@ -904,72 +911,95 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
       auto y_tr = [&](int m, int part_) { return *reinterpret_cast<const u32x2*>(hb_tr + (2 * m + part_) * 512); };
       const float* bias = reinterpret_cast<const float*>(ts_lds + T::BIAS_OFF + sl * B::B_SLAB_PLAIN);
       const f32x4 gl4 = *reinterpret_cast<const f32x4*>(ts_lds + T::GL_OFF + (buf * kTsWaves + wave) * 64 + tt * 16 + 4 * q);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        __builtin_amdgcn_sched_barrier(0);  // (one dim tile's operand reads at a time)
-        // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim]
-        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+      // Three blocks: U (K = units products: t, s from y and g_k from g_y; 36 MFMAs and their operand reads), V (the gate
+      // arithmetic) and R (the sums over the tile's rows, 48 MFMAs).  What bounds this kernel is INSTRUCTION ISSUE: the two
+      // waves of a SIMD share its issue slots, and at ~600 instructions per wave and pair the arithmetic alone took 737 us
+      // of a 956 us launch (software-pipelining U / V / R across the dim tiles in pinned pieces of ~25 vector instructions
+      // and 3 .. 6 MFMAs changed nothing: 951 us).  So V is written on f32x2 values -- the lane's two dims of a row, as
+      // they are loaded -- and goes out as packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
+      // elements per issue slot) wherever the operation has a packed form.
+      struct Units {
+        f32x4 t4, s4, gk;
+      };
+      auto units = [&](int dt) -> Units {  // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
 #pragma unroll
         for (int ks = 0; ks < NKS2; ++ks) {
           const f16x8 yh = y_op(ks, 0), yl = y_op(ks, 1);
           split_mac(yh, yl, w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
           split_mac(yh, yl, w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
+          split_mac(g_op(ks, 0), g_op(ks, 1), w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
         }
-        const f32x4 t4 = tc * kSplitInvScale + tm + bias[dt * 16 + j];
-        const f32x4 s4 = sc * kSplitInvScale + sm + bias[32 + dt * 16 + j];
-        f32x4 gt, gs, gz;
+        Units u;
+        u.t4 = tc * kSplitInvScale + tm + bias[dt * 16 + j];
+        u.s4 = sc * kSplitInvScale + sm + bias[32 + dt * 16 + j];
+        u.gk = kc * kSplitInvScale + km;
+        return u;
+      };
+      // R(dt):  D [unit][dim] += A [unit][row] B [row][dim] over the tile's 16 rows, three partial products (yh th, yl th,
+      // yh tl) into one accumulator.  NOT as K = 16 products: v_mfma_f32_16x16x16_f16 occupies the matrix pipe four times
+      // as long as v_mfma_f32_16x16x32_f16 on gfx950 (48 of them per wave and pair were 3/4 of this kernel's arithmetic
+      // time).  A K = 32 product sums its two K halves, so with A = [yh | yl] (one ds_read2: the two parts of a unit tile
+      // side by side) B = [th | th] gives yh th + yl th in ONE instruction and B = [tl | 0] adds yh tl: two K = 32
+      // MFMAs per (unit tile, net) instead of three K = 16 ones, a sixth of the pipe time.
+      auto row_sums = [&](int dt, const u32x2& th, const u32x2& tl, const u32x2& sh, const u32x2& sl_) {
+        const u32x2 zero2 = u32x2{0u, 0u};
+        const f16x8 t_hh = pair_operand(th, th), t_l0 = pair_operand(tl, zero2);
+        const f16x8 s_hh = pair_operand(sh, sh), s_l0 = pair_operand(sl_, zero2);
+#pragma unroll
+        for (int m = 0; m < YT; ++m) {
+          const f16x8 y_hl = pair_operand(y_tr(m, 0), y_tr(m, 1));
+          aWt[dt][m] = mfma_h(y_hl, t_hh, aWt[dt][m]);
+          aWs[dt][m] = mfma_h(y_hl, s_hh, aWs[dt][m]);
+          aWt[dt][m] = mfma_h(y_hl, t_l0, aWt[dt][m]);
+          aWs[dt][m] = mfma_h(y_hl, s_l0, aWs[dt][m]);
+        }
+      };
+      if (!(kTsAbl & 1)) {
+        const Units u0 = units(0), u1 = units(1);
+        f32x4 gt[2], gs[2];
+        const f32x2 one2 = f32x2{1.f, 1.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float keep = 4 * q + r < in.n_live ? 1.f : 0.f;
-          float m_;
+          f32x2 m2;
           if (SEEDED)
-            m_ = (float)((in.mbits >> (2 * r + dt)) & 1u);
+            m2 = f32x2{(float)((in.mbits >> (2 * r)) & 1u), (float)((in.mbits >> (2 * r + 1)) & 1u)};
           else
-            m_ = in.mm[r][dt];
-          const float zv = in.zz[r][dt], G_ = in.GG[r][dt] * (gx_scale * keep), nm = 1.f - m_;
-          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
-          const float omg = 1.f - gate;
-          gt[r] = G_ * omg;
-          gs[r] = (G_ * (nm * zv - t4[r]) * gate + gl4[r] * (gl_scale * keep) * nm) * omg;
-          gz[r] = G_ * (nm * gate + m_);
+            m2 = in.mm[r];
+          const f32x2 t2 = f32x2{u0.t4[r], u1.t4[r]}, s2 = f32x2{u0.s4[r], u1.s4[r]}, k2 = f32x2{u0.gk[r], u1.gk[r]};
+          const f32x2 nm = one2 - m2;
+          const f32x2 G2 = in.GG[r] * (gx_scale * keep);
+          const f32x2 sx = s2 * -1.44269504088896341f;
+          const f32x2 ex = f32x2{__builtin_amdgcn_exp2f(sx[0]), __builtin_amdgcn_exp2f(sx[1])} + one2;
+          const f32x2 gate_ = f32x2{__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+          const f32x2 omg = one2 - gate_;
+          const f32x2 gt2 = G2 * omg;
+          const f32x2 gs2 = (G2 * (nm * in.zz[r] - t2) * gate_ + nm * (gl4[r] * (gl_scale * keep))) * omg;
+          in.zz[r] = (G2 * (nm * gate_ + m2) + m2 * k2) * inv_gscale;  // grad_z takes z's register
+          gt[0][r] = gt2[0];
+          gt[1][r] = gt2[1];
+          gs[0][r] = gs2[0];
+          gs[1][r] = gs2[1];
         }
-        abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
-        abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
-        u32x2 th, tl, sh, sl_;  // B operands of the sums over the tile's 16 rows
-        split_plain(gt, th, tl);
-        split_plain(gs, sh, sl_);
-        // g_k^T = g_y Wn;  grad_z = G ((1-m) gate + m) + m g_k  (takes z's register)
-        f32x4 km = zero4, kc = zero4;
 #pragma unroll
-        for (int ks = 0; ks < NKS2; ++ks) split_mac(g_op(ks, 0), g_op(ks, 1), w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
-        const f32x4 gk = kc * kSplitInvScale + km;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float m_;
-          if (SEEDED)
-            m_ = (float)((in.mbits >> (2 * r + dt)) & 1u);
-          else
-            m_ = in.mm[r][dt];
-          in.zz[r][dt] = (gz[r] + m_ * gk[r]) * inv_gscale;
+        for (int dt = 0; dt < 2; ++dt) {
+          abt[dt] += (gt[dt][0] + gt[dt][1]) + (gt[dt][2] + gt[dt][3]);
+          abs_[dt] += (gs[dt][0] + gs[dt][1]) + (gs[dt][2] + gs[dt][3]);
+          u32x2 th, tl, sh, sl_;  // B operands of the sums over the tile's 16 rows
+          split_plain(gt[dt], th, tl);
+          split_plain(gs[dt], sh, sl_);
+          row_sums(dt, th, tl, sh, sl_);
         }
-        if (grad_flat) {
-          // D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
+      }
+      if (kTsAbl & 1) {
 #pragma unroll
-          for (int m = 0; m < YT; ++m) {
-            const u32x2 yh = y_tr(m, 0), yl = y_tr(m, 1);
-            aWt[dt][m] = mfma16(yh, th, aWt[dt][m]);
-            aWs[dt][m] = mfma16(yh, sh, aWs[dt][m]);
-            aWt[dt][m] = mfma16(yh, tl, aWt[dt][m]);
-            aWs[dt][m] = mfma16(yh, sl_, aWs[dt][m]);
-            aWt[dt][m] = mfma16(yl, th, aWt[dt][m]);
-            aWs[dt][m] = mfma16(yl, sh, aWs[dt][m]);
-          }
-        }
+        for (int r = 0; r < 4; ++r) in.zz[r] = in.zz[r] * gl4[r] + in.GG[r] * (float)in.mbits;
       }
       float* ot = grad_z + in.tbase * dm;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (4 * q + r < in.n_live) {
+        if (4 * q + r < in.n_live && (!(kTsAbl & 2) || in.zz[r][0] == 1.2345e30f)) {
           const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
           if (!RAG) {
             *reinterpret_cast<f32x2*>(ot + off) = in.zz[r];
