@@ -116,6 +116,8 @@ SIGNATURES = {
     "mnf_linear_rows_bwd_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0_seeded_bwd": (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_adam_step_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                     c_float, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,

@@ -110,31 +110,46 @@ def _flow_through(flow: NormalizingFlow, z: Tensor, masks):
 
 class _SampleZ0Fn(torch.autograd.Function):
     """z0 = q0_mean + sqrt(exp(q0_log_var)) * eps (mnf_linear.py:59-62, mnf_conv.py:91-93) with its two parameter
-    gradients from the library: one launch each way instead of four elementwise kernels forward and ~eight backward."""
+    gradients from the library: one launch each way instead of four elementwise kernels forward and ~eight backward.
+    ``eps`` None: the noise is the library's counter-based N(0, 1) of (``seed``, row, column), generated inside both
+    launches (``mnf_mnf_linear_noise(seed, ., rows, n_in)`` materialises it): no (rows, n_in) noise tensor exists."""
 
     @staticmethod
-    def forward(ctx, q0_mean, q0_log_var, eps, module):
+    def forward(ctx, q0_mean, q0_log_var, eps, module, seed=0, rows=0):
         mean, log_var = q0_mean.detach().contiguous(), q0_log_var.detach().contiguous()
-        z0 = torch.empty_like(eps)
-        _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
-            mean.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z0.data_ptr(), eps.shape[0], eps.shape[1], _stream()))
-        ctx.save_for_backward(eps, log_var)
+        if eps is None:
+            z0 = torch.empty(rows, mean.numel(), device=mean.device)
+            _lib.check("mnf_sample_z0_seeded", _lib.load().mnf_sample_z0_seeded(
+                mean.data_ptr(), log_var.data_ptr(), seed, z0.data_ptr(), rows, mean.numel(), _stream()))
+            ctx.save_for_backward(log_var)
+        else:
+            z0 = torch.empty_like(eps)
+            _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
+                mean.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z0.data_ptr(), eps.shape[0], eps.shape[1], _stream()))
+            ctx.save_for_backward(log_var, eps)
+        ctx.seed = seed
         ctx.home = _flows._flat_home_of(module, [q0_mean, q0_log_var])
         return z0
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_z0):
-        eps, log_var = ctx.saved_tensors
-        dim, home = eps.shape[1], ctx.home
-        out = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros(2 * dim, device=eps.device)
+        log_var, *rest = ctx.saved_tensors
+        eps = rest[0] if rest else None
+        dim, home = log_var.numel(), ctx.home
+        out = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros(2 * dim, device=log_var.device)
         g = grad_z0.contiguous()
-        _lib.check("mnf_sample_z0_bwd", _lib.load().mnf_sample_z0_bwd(
-            g.data_ptr(), eps.data_ptr(), log_var.data_ptr(), out.data_ptr(), out.data_ptr() + 4 * dim, eps.shape[0], dim,
-            _stream()))
+        if eps is None:
+            _lib.check("mnf_sample_z0_seeded_bwd", _lib.load().mnf_sample_z0_seeded_bwd(
+                g.data_ptr(), ctx.seed, log_var.data_ptr(), out.data_ptr(), out.data_ptr() + 4 * dim, g.shape[0], dim,
+                _stream()))
+        else:
+            _lib.check("mnf_sample_z0_bwd", _lib.load().mnf_sample_z0_bwd(
+                g.data_ptr(), eps.data_ptr(), log_var.data_ptr(), out.data_ptr(), out.data_ptr() + 4 * dim, eps.shape[0],
+                dim, _stream()))
         if home is not None:
-            return None, None, None, None
-        return out[:dim], out[dim:], None, None
+            return None, None, None, None, None, None
+        return out[:dim], out[dim:], None, None, None, None
 
 
 class _ConvOperandsFn(torch.autograd.Function):
@@ -314,13 +329,20 @@ class MNFLinear(nn.Module):
         """(mnf_linear.py:58-64).  ``eps`` (batch, n_in) and ``masks`` (one per flow_q layer) may be
         injected for reproducible runs; by default both are drawn on the device."""
         dev = self.q0_mean.device
-        if eps is None:
-            eps = torch.randn(batch_size, self.n_in, device=dev)
-        eps = eps.to(dev, torch.float32).contiguous()
         training = torch.is_grad_enabled() and (self.q0_mean.requires_grad or self.q0_log_var.requires_grad)
         flows = list(self.flow_q.flows)
         if masks is not None and len(masks) != len(flows):
             raise ValueError(f"sample_z got {len(masks)} masks for {len(flows)} flow_q layers")
+        if eps is None and training and batch_size > 0 and dev.type == "cuda" and not _flows._DEVICE_MASKS:
+            # training, nothing injected: the noise is generated inside the prologue launch and again inside its gradient
+            # launch from one host-drawn seed (never as a (batch, n_in) tensor).  (A step being recorded in a hipGraph
+            # keeps the tensor draw: a seed would be frozen into the recorded kernel arguments.)
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+            z0 = _SampleZ0Fn.apply(self.q0_mean, self.q0_log_var, None, self, seed, int(batch_size))
+            return self._through_flow_q(z0, masks, dev)
+        if eps is None:
+            eps = torch.randn(batch_size, self.n_in, device=dev)
+        eps = eps.to(dev, torch.float32).contiguous()
         if (not training and eps.shape[0] > 0 and flows and isinstance(flows[0], RNVP)
                 and self._fused_prologue_ok(flows[0], eps)):
             # the prologue z0 = q0_mean + q0_std eps is formed inside the first flow's kernel: z0 is never stored
@@ -343,6 +365,9 @@ class MNFLinear(nn.Module):
                 _lib.check("mnf_sample_z0", _lib.load().mnf_sample_z0(
                     self.q0_mean.detach().contiguous().data_ptr(), self.q0_log_var.detach().contiguous().data_ptr(),
                     eps.data_ptr(), z0.data_ptr(), eps.shape[0], self.n_in, _stream()))
+        return self._through_flow_q(z0, masks, dev)
+
+    def _through_flow_q(self, z0: Tensor, masks, dev) -> tuple[Tensor, Tensor]:
         if masks is None:
             zs, log_det = self.flow_q.forward(z0)
         else:  # same loop as NormalizingFlow.forward with the masks handed to each RNVP
