@@ -304,13 +304,14 @@ int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* ep
  * 0.5 sqrt(exp(q0_log_var[j])).  Both outputs (dim floats each) are ADDED to. */
 int mnf_sample_z0_bwd(const float* grad_z0, const float* eps, const float* q0_log_var, float* grad_mean,
                       float* grad_log_var, int64_t rows, int dim, void* stream);
-/* The same two with the noise generated in place, eps[r][j] = the counter-based N(0, 1) of (seed, r, j) -- exactly what
- * mnf_mnf_linear_noise(seed, eps, rows, dim) writes: `epsilon = torch.randn_like(...)` of mnf_linear.py:59-61 /
+/* The same two with the noise generated in place, eps[r][j] = a counter-based N(0, 1) of (seed, r, j) -- exactly what
+ * mnf_sample_z0_noise(seed, eps, rows, dim) writes: `epsilon = torch.randn_like(...)` of mnf_linear.py:59-61 /
  * mnf_conv.py:91-93 without a (rows, dim) noise tensor being drawn, stored and read back by the gradient launch. */
 int mnf_sample_z0_seeded(const float* q0_mean, const float* q0_log_var, uint64_t seed, float* z0, int64_t rows, int dim,
                          void* stream);
 int mnf_sample_z0_seeded_bwd(const float* grad_z0, uint64_t seed, const float* q0_log_var, float* grad_mean,
                              float* grad_log_var, int64_t rows, int dim, void* stream);
+int mnf_sample_z0_noise(uint64_t seed, float* eps, int64_t rows, int dim, void* stream);
 
 /* ------------------------------------------------------------------ training: one optimizer launch
  * torch.optim.Adam's update (no amsgrad; weight_decay as L2 on the gradient) over ONE flat buffer: param, grad and

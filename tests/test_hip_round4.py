@@ -34,7 +34,7 @@ def _err(a, b) -> float:
 
 def _noise(amd, seed, rows, cols):
     eps = torch.empty(rows, cols, device=DEV)
-    amd._lib.check("mnf_mnf_linear_noise", amd._lib.load().mnf_mnf_linear_noise(
+    amd._lib.check("mnf_sample_z0_noise", amd._lib.load().mnf_sample_z0_noise(
         ctypes.c_uint64(seed), eps.data_ptr(), rows, cols, None))
     torch.cuda.synchronize()
     return eps
@@ -43,7 +43,7 @@ def _noise(amd, seed, rows, cols):
 # ------------------------------------------------------------------------------------------------ seeded prologue
 @pytest.mark.parametrize("rows,dim", [(1, 7), (333, 50), (4096, 800), (1000, 27)])
 def test_seeded_sample_z0_is_the_explicit_prologue_on_the_materialised_noise(amd, rows, dim):
-    """mnf_sample_z0_seeded / _seeded_bwd == mnf_sample_z0 / _bwd fed the numbers mnf_mnf_linear_noise(seed) writes
+    """mnf_sample_z0_seeded / _seeded_bwd == mnf_sample_z0 / _bwd fed the numbers mnf_sample_z0_noise(seed) writes
     (mnf_linear.py:59-62 with `epsilon` never stored): values bit for bit, the two parameter gradients to summation
     order."""
     lib = amd._lib.load()

@@ -118,6 +118,7 @@ SIGNATURES = {
     "mnf_sample_z0_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_seeded_bwd": (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0_noise": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_adam_step_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                     c_float, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,

@@ -188,6 +188,28 @@ __device__ __forceinline__ float ml_normal(uint64_t seed, int64_t row, int col) 
   return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
+// The sample_z prologue's noise (mnf_sample_z0_seeded): both Box-Muller outputs of one (u1, u2) serve the column pair
+// (2 c, 2 c + 1) of a row, and the row's hash is shared by its columns -- one hash pair, one log, one sqrt per TWO
+// numbers (ml_normal spends three hashes per number: 0.38 ms per 256,000 x 800 prologue launch against 0.14 ms of
+// stores).  mnf_sample_z0_noise() materialises exactly these numbers.
+__device__ __forceinline__ uint32_t z0_row_hash(uint64_t seed, int64_t row) {
+  return mix32((uint32_t)row * 0x9e3779b1u + (uint32_t)((uint64_t)row >> 32) + (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ void z0_normal_pair(uint32_t row_hash, uint32_t seed_lo, int pair, float& n0, float& n1) {
+  const uint32_t h1 = mix32(row_hash ^ ((uint32_t)pair * 0x85ebca77u + (seed_lo ^ 0x5bd1e995u)));
+  const uint32_t h2 = mix32(h1 ^ 0x68bc21ebu);
+  const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
+  const float u2 = ((float)(h2 >> 8) + 0.5f) * (1.f / 16777216.f);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // (v_log_f32 = log2)
+  n0 = r * __builtin_amdgcn_cosf(u2);                                                           // (revolutions)
+  n1 = r * __builtin_amdgcn_sinf(u2);
+}
+__device__ __forceinline__ float z0_normal(uint64_t seed, int64_t row, int col) {
+  float n0, n1;
+  z0_normal_pair(z0_row_hash(seed, row), (uint32_t)seed, col >> 1, n0, n1);
+  return (col & 1) ? n1 : n0;
+}
+
 // sum over the 4 lanes {j, j+16, j+32, j+48} that share a sample in the 16x16 MFMA layout
 __device__ __forceinline__ float sum_over_q(float v) {
   v += __shfl_xor(v, 16, 64);

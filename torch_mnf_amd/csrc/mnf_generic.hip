@@ -604,25 +604,43 @@ __global__ void sample_z0_kernel_v4(const float* __restrict__ mean, const float*
   }
 }
 
-// the prologue with its noise generated in place: eps[r][j] = ml_normal(seed, r, j) (mnf_device.h; what
-// mnf_mnf_linear_noise(seed, ., rows, dim) writes) -- no (rows, dim) noise tensor is drawn, stored or read back: 3.3 GB less
+// the prologue with its noise generated in place: eps[r][j] = z0_normal(seed, r, j) (mnf_device.h; what
+// mnf_sample_z0_noise(seed, ., rows, dim) writes) -- no (rows, dim) noise tensor is drawn, stored or read back: 3.3 GB less
 // traffic per training step of MNFLinear(800, .) at 256,000 rows (the draw, this launch's read, the gradient launch's read)
+// blockDim = (64 lanes, 4 row lanes), like the gradient kernel below: a lane owns VEC consecutive dims -- their mean and
+// standard deviation are formed once -- and walks the rows blockIdx.y * 4 + threadIdx.y, + 4 gridDim.y, ...: no index
+// division and no exp / sqrt inside the loop (the first version, one flat index per piece, took 0.30 ms for a 0.14 ms store)
 template <int VEC>
 __global__ void __launch_bounds__(256) sample_z0_seeded_kernel(const float* __restrict__ mean, const float* __restrict__ log_var,
                                                                uint64_t seed, float* __restrict__ z0, int64_t rows, int dim) {
-  const int per_row = dim / VEC;
-  const int64_t n = rows * per_row, stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t r = i / per_row;
-    const int j = VEC * (int)(i - r * per_row);
-    float o[VEC];
+  const int j0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
+  if (j0 >= dim) return;  // (VEC = 4: dim % 4 == 0, so the whole piece is inside)
+  float mu[VEC], sd[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) o[v] = fmaf(sqrtf(expf(log_var[j + v])), ml_normal(seed, r, j + v), mean[j + v]);
-    if (VEC == 4)
-      *reinterpret_cast<float4*>(z0 + r * dim + j) = float4{o[0], o[VEC > 1 ? 1 : 0], o[VEC > 2 ? 2 : 0], o[VEC > 3 ? 3 : 0]};
-    else
-      z0[r * dim + j] = o[0];
+  for (int v = 0; v < VEC; ++v) {
+    mu[v] = mean[j0 + v];
+    sd[v] = sqrtf(expf(log_var[j0 + v]));  // mnf_linear.py:60
   }
+  for (int64_t r = (int64_t)blockIdx.y * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.y * 4) {
+    if (VEC == 4) {  // (j0 % 4 == 0: the piece is two whole column pairs)
+      float e[4];
+      const uint32_t rh = z0_row_hash(seed, r);
+      z0_normal_pair(rh, (uint32_t)seed, j0 >> 1, e[0], e[1]);
+      z0_normal_pair(rh, (uint32_t)seed, (j0 >> 1) + 1, e[2], e[3]);
+      float4 o;
+      o.x = fmaf(sd[0], e[0], mu[0]);
+      o.y = fmaf(sd[VEC > 1 ? 1 : 0], e[1], mu[VEC > 1 ? 1 : 0]);
+      o.z = fmaf(sd[VEC > 2 ? 2 : 0], e[2], mu[VEC > 2 ? 2 : 0]);
+      o.w = fmaf(sd[VEC > 3 ? 3 : 0], e[3], mu[VEC > 3 ? 3 : 0]);
+      *reinterpret_cast<float4*>(z0 + r * dim + j0) = o;
+    } else {
+      z0[r * dim + j0] = fmaf(sd[0], z0_normal(seed, r, j0), mu[0]);
+    }
+  }
+}
+__global__ void sample_z0_noise_kernel(uint64_t seed, float* __restrict__ eps, int64_t rows, int dim) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * dim) eps[i] = z0_normal(seed, i / dim, (int)(i % dim));
 }
 
 // gradients of the prologue: d mean[j] = sum_r g[r][j];  d log_var[j] = sum_r g[r][j] eps[r][j] * 0.5 sqrt(exp(log_var[j])).
@@ -656,8 +674,13 @@ __global__ void __launch_bounds__(256) sample_z0_bwd_kernel(const float* __restr
         if (eps) ev[0] = eps[r * dim + j0];
       }
       if (!eps) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) ev[v] = ml_normal(seed, r, j0 + v);
+        if (VEC == 4) {
+          const uint32_t rh = z0_row_hash(seed, r);
+          z0_normal_pair(rh, (uint32_t)seed, j0 >> 1, ev[0], ev[VEC > 1 ? 1 : 0]);
+          z0_normal_pair(rh, (uint32_t)seed, (j0 >> 1) + 1, ev[VEC > 2 ? 2 : 0], ev[VEC > 3 ? 3 : 0]);
+        } else {
+          ev[0] = z0_normal(seed, r, j0);
+        }
       }
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
@@ -1299,12 +1322,25 @@ int mnf_sample_z0_seeded(const float* q0_mean, const float* q0_log_var, uint64_t
                          void* stream) {
   if (!q0_mean || !q0_log_var || !z0 || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
   if (rows == 0) return MNF_OK;
-  if (dim % 4 == 0 && !(reinterpret_cast<uintptr_t>(z0) & 15))
-    hipLaunchKernelGGL(sample_z0_seeded_kernel<4>, dim3(grid_for(rows * (dim / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+  const bool vec = dim % 4 == 0 && !(reinterpret_cast<uintptr_t>(z0) & 15);
+  const int per_block = vec ? 256 : 64;
+  const int dim_blocks = (dim + per_block - 1) / per_block;
+  int64_t row_blocks = (rows + 3) / 4;  // at most one row per thread row; enough workgroups to fill the chip otherwise
+  row_blocks = row_blocks > 4096 / dim_blocks + 1 ? 4096 / dim_blocks + 1 : row_blocks;
+  if (vec)
+    hipLaunchKernelGGL(sample_z0_seeded_kernel<4>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
                        q0_mean, q0_log_var, seed, z0, rows, dim);
   else
-    hipLaunchKernelGGL(sample_z0_seeded_kernel<1>, dim3(grid_for(rows * dim, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(sample_z0_seeded_kernel<1>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
                        q0_mean, q0_log_var, seed, z0, rows, dim);
+  return check_launch();
+}
+
+int mnf_sample_z0_noise(uint64_t seed, float* eps, int64_t rows, int dim, void* stream) {
+  if (!eps || rows < 0 || dim < 1) return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(sample_z0_noise_kernel, dim3((unsigned)((rows * dim + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                     eps, rows, dim);
   return check_launch();
 }
 

@@ -112,7 +112,7 @@ class _SampleZ0Fn(torch.autograd.Function):
     """z0 = q0_mean + sqrt(exp(q0_log_var)) * eps (mnf_linear.py:59-62, mnf_conv.py:91-93) with its two parameter
     gradients from the library: one launch each way instead of four elementwise kernels forward and ~eight backward.
     ``eps`` None: the noise is the library's counter-based N(0, 1) of (``seed``, row, column), generated inside both
-    launches (``mnf_mnf_linear_noise(seed, ., rows, n_in)`` materialises it): no (rows, n_in) noise tensor exists."""
+    launches (``mnf_sample_z0_noise(seed, ., rows, n_in)`` materialises it): no (rows, n_in) noise tensor exists."""
 
     @staticmethod
     def forward(ctx, q0_mean, q0_log_var, eps, module, seed=0, rows=0):
