@@ -86,8 +86,17 @@ struct RnvpBwdShape {
 };
 
 // ================================================================================================ kernel A
+typedef __attribute__((address_space(3))) void* lds_void_ptr_a;
+constexpr int kBwdRing = 3;  // buffers of launch A's LDS operand window (chunks c, c + 1, c + 2)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+#else
+typedef int BufRsrc;  // (hipcc's host pass over this file: the type and its builtins exist on the device side only)
+#endif
+
 template <int HN, bool SEEDED, bool RAG>
-__device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
+__device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& s_rsrc, const BufRsrc& b_rsrc, int grp,
+                                                 const float* __restrict__ z,
                                                  const float* __restrict__ mask, const float* __restrict__ gx,
                                                  const float* __restrict__ gld, const uint32_t* __restrict__ simage,
                                                  const uint32_t* __restrict__ bimage, uint32_t* __restrict__ side,
@@ -104,11 +113,8 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
   const int G = d / 16;
   const int n_ks1 = (G + 1) / 2;
   const int nc1 = (n_ks1 + KC - 1) / KC, nc = nc1 + G;  // second sweep: one 16-dim tile per chunk
-  const uint32_t* img1 = simage;
-  const uint32_t* img2 = simage + S::part1_words(d);
   const float* bias2 = reinterpret_cast<const float*>(simage + S::split_words(d));
   const float* bias_y = bias2 + (int64_t)G * 32;
-  const uint32_t* img3 = bimage;  // A3
 
   const int64_t row = (int64_t)grp * kBwdGroupRows + wave * 16 + j;
   const bool live = row < rows;
@@ -132,37 +138,47 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
     return row_load4<RAG>(gr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec);
   };
 
-  // operands of chunk c: GEMM-1 chunks are contiguous in the forward image; a second-sweep chunk is the forward
-  // GEMM-2 tile followed by the tile's A3 operands from the backward image
-  uint4 st[B::STAGE_U4];
-  auto request_operands = [&](int c, int& n4) {
-    const int cc = c < nc ? c : nc - 1;
-    const uint4 *src_a, *src_b;
-    int n4a;
-    if (cc < nc1) {
-      n4a = n4 = min(KC, n_ks1 - cc * KC) * (S::KS1_WORDS / 4);
-      src_a = src_b = reinterpret_cast<const uint4*>(img1 + (int64_t)cc * KC * S::KS1_WORDS);
-    } else {
-      const int m = cc - nc1;
-      n4a = S::TILE2_WORDS / 4;
-      n4 = n4a + B::A3_TILE_WORDS / 4;
-      src_a = reinterpret_cast<const uint4*>(img2 + (int64_t)m * S::TILE2_WORDS);
-      src_b = reinterpret_cast<const uint4*>(img3 + (int64_t)m * B::A3_TILE_WORDS) - n4a;
-    }
+  // Operands of chunk c -- a GEMM-1 chunk is contiguous in the forward image; a second-sweep chunk is the forward GEMM-2
+  // tile followed by the tile's A3 operands from the backward image -- travel L2 -> LDS by LDS-DMA (buffer_load ... lds:
+  // no staging registers) into a ring of kBwdRing buffers, requested TWO chunks ahead: at the top of chunk c the wave
+  // asks for its pieces of chunk c + 2, at the end of chunk c it waits for its pieces of chunk c + 1 and meets the
+  // others at the chunk's one barrier.  (Round 3 staged chunk c + 1 through registers during chunk c and wrote it to LDS
+  // at the chunk's end: with one workgroup per CU two thirds of the wave cycles went to waiting there.)
+  constexpr int N_PIECES = B::CHUNK_WORDS / 256, N_DMA = (N_PIECES + kRnvpWaves - 1) / kRnvpWaves;
+  [[maybe_unused]] constexpr int T2_PIECES = S::TILE2_WORDS / 256;
+  static_assert(B::CHUNK_WORDS % 256 == 0 && S::TILE2_WORDS % 256 == 0, "whole 1 KB pieces");
+  auto request_operands = [&](int c) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in hipcc's host pass over this file)
+    const int cc = c < nc ? c : nc - 1;  // (past the end: the last chunk once more, into the buffer it already fills)
+    uint32_t* dst = lds0 + (cc % kBwdRing) * B::CHUNK_WORDS;
 #pragma unroll
-    for (int i = 0; i < B::STAGE_U4; ++i) {
-      const int k = threadIdx.x + i * (kRnvpWaves * 64);
-      const int kk = k < n4 ? k : 0;
-      st[i] = kk < n4a ? src_a[kk] : src_b[kk];
+    for (int i = 0; i < N_DMA; ++i) {
+      const int piece = min(i * kRnvpWaves + wave, N_PIECES - 1);  // wave-uniform; a piece past the end repeats the last
+      int64_t word;
+      bool from_b = false;
+      if (cc < nc1) {
+        word = (int64_t)cc * KC * S::KS1_WORDS + piece * 256;  // (a short last chunk reads on into part 2: unused)
+      } else {
+        const int m = cc - nc1;
+        from_b = piece >= T2_PIECES;
+        word = from_b ? (int64_t)m * B::A3_TILE_WORDS + (piece - T2_PIECES) * 256
+                      : S::part1_words(d) + (int64_t)m * S::TILE2_WORDS + piece * 256;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(from_b ? b_rsrc : s_rsrc, (lds_void_ptr_a)(dst + piece * 256), 16, lane * 16,
+                                               (int)(word * 4), 0, 0);
     }
+#endif
+    asm volatile("" ::: "memory");
   };
-  auto hand_over = [&](uint32_t* buf, int n4) {
-    uint4* dst = reinterpret_cast<uint4*>(buf);
-#pragma unroll
-    for (int i = 0; i < B::STAGE_U4; ++i) {
-      const int k = threadIdx.x + i * (kRnvpWaves * 64);
-      if (k < n4) dst[k] = st[i];
-    }
+  // end of a chunk: this wave's pieces of the NEXT chunk are in LDS (vector-memory operations complete in issue order;
+  // behind those pieces the wave has issued at least the N_DMA pieces of the chunk after it and two row / bias loads),
+  // every LDS read of this chunk has returned, then the workgroup's barrier.  Inline asm: __syncthreads() drains every
+  // outstanding vector-memory operation.
+  auto chunk_barrier = [&](bool drain) {
+    if (drain)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_DMA + 2) : "memory");
   };
   auto row_group1 = [&](int c, int i) -> int {
     const int g = 2 * (c * KC) + i;
@@ -183,20 +199,15 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
   // y_in != nullptr: the forward pass kept y = Wn (m z) + bn (rows x 16 YT floats): sweep 1 -- a third of this launch,
   // one of its two reads of z -- is skipped and the operand pipeline starts at the first second-sweep tile
   const bool have_y = y_in != nullptr;
-  __syncthreads();  // the previous group's last chunk is fully consumed
-  {
-    int n4;
-    if (!have_y) {
+  const int c_first = have_y ? nc1 : 0;
+  chunk_barrier(true);  // the previous group's last chunk is fully consumed (and its hand-over stores are out)
+  if (!have_y) {
 #pragma unroll
-      for (int u = 0; u < D1; ++u) request_rows1(u, u);
-      request_operands(0, n4);
-      hand_over(lds0, n4);
-    } else {
-      request_operands(nc1, n4);
-      hand_over(lds0 + (nc1 & 1) * B::CHUNK_WORDS, n4);
-    }
+    for (int u = 0; u < D1; ++u) request_rows1(u, u);
   }
-  __syncthreads();
+  request_operands(c_first);
+  request_operands(c_first + 1);
+  chunk_barrier(true);  // (the first chunk's pieces: the one exposed operand latency of the group)
   f32x4 ym[YT], yc[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) {
@@ -229,10 +240,9 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
           bh[kk] = pair_operand(h0, h1);
           bl[kk] = pair_operand(l0, l1);
         }
-        int n4_next = 0;
+        request_operands(c + 2);  // (c + 1 == nc1: the first second-sweep tile)
         request_rows1(c + D1, u);
-        request_operands(c + 1, n4_next);  // c + 1 == nc1: the first second-sweep tile
-        const uint32_t* buf = lds0 + (c & 1) * B::CHUNK_WORDS;  // (= lds[c & 1]: one base, no pointer select)
+        const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
         const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
@@ -242,19 +252,20 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
               split_mac(A8[64 * (2 * (kk * YT + m))], A8[64 * (2 * (kk * YT + m) + 1)], bh[kk], bl[kk], ym[m], yc[m]);
           }
         }
-        hand_over(lds0 + ((c + 1) & 1) * B::CHUNK_WORDS, n4_next);
-        __syncthreads();
+        chunk_barrier(false);
       }
     }
   }
   // ---- y complete: GEMM-2 operands
   constexpr int D2 = SEEDED ? 2 : 1;
-  f32x4 z2[D2], g2[D2], m2[D2];
+  f32x4 z2[D2], g2[D2], m2[D2], bt2[D2], bs2[D2];  // rows and the tile's (bt, bs), requested D2 chunks ahead
   auto request_rows2 = [&](int c, int u) {
     const int cc = c < nc ? c : nc - 1;
     z2[u] = z4(cc - nc1);
     g2[u] = g4(cc - nc1);
     m2[u] = mask4(cc - nc1);
+    bt2[u] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)(cc - nc1) * 32 + 4 * q);
+    bs2[u] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)(cc - nc1) * 32 + 16 + 4 * q);
   };
 #pragma unroll
   for (int u = 0; u < D2; ++u) request_rows2(nc1 + u, u);
@@ -271,12 +282,9 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
     for (int u = 0; u < D2; ++u) {
       const int c = c0 + u;
       if (c < nc) {
-        int n4_next = 0;
-        request_operands(c + 1, n4_next);
-        const int m = c - nc1;
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 4 * q);
-        const f32x4 bs = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 16 + 4 * q);
-        const uint32_t* buf = lds0 + (c & 1) * B::CHUNK_WORDS;  // (= lds[c & 1]: one base, no pointer select)
+        request_operands(c + 2);
+        const f32x4 bt = bt2[u], bs = bs2[u];
+        const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
         const f16x8* T8 = reinterpret_cast<const f16x8*>(buf) + lane;
         const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + S::TILE2_WORDS) + lane;
         f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
@@ -307,8 +315,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, uint32_t* lds1,
 #pragma unroll
         for (int m2i = 0; m2i < YT; ++m2i) split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
         request_rows2(c + D2, u);
-        hand_over(lds0 + ((c + 1) & 1) * B::CHUNK_WORDS, n4_next);
-        __syncthreads();
+        chunk_barrier(false);
       }
     }
   }
@@ -342,8 +349,16 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
                   int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2][B::CHUNK_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kBwdRing][B::CHUNK_WORDS];
   const int dm = RAG ? dm_ragged : d;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const BufRsrc s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(simage), 0, (int)((S::split_words(d) + S::plain_words(d) + kSplitTailWords) * 4), 0x00020000);
+  const BufRsrc b_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(bimage), 0, (int)((bimage_tail + kSplitTailWords) * 4), 0x00020000);
+#else
+  const BufRsrc s_rsrc = 0, b_rsrc = 0;
+#endif
   const float gscale = gscale_dev[0];
   const float wmax_f = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
   const float wmax_b = __builtin_bit_cast(float, bimage[bimage_tail]);
@@ -353,7 +368,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   for (int m = 0; m < S::YT; ++m) bn_acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int n_groups = (int)((rows + kBwdGroupRows - 1) / kBwdGroupRows);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
-    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], lds[1], grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
+    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], s_rsrc, b_rsrc, grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
                                       weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0, y_in);
   // dbn: sum over the wave's rows (the 16 lanes j of a q), over the workgroup's waves in LDS, then ONE atomic per unit
   // per workgroup (atomics on a few dozen addresses serialise at the memory side: one per unit per WAVE cost 0.16 ms)
