@@ -25,6 +25,9 @@
 // cotangents leave the range are skipped by the slab launch and redone in fp32 by ml_bwd_fixup_kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "mnf_device.h"
 #include "mnf_host.h"
 #include "mnf_rnvp_common.h"
@@ -366,6 +369,314 @@ ml_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ z, flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------ slab launch, shared hand-over
+// The kernel above re-reads the prologue's hand-over (1 KB per row) once per 32-dim slab -- twice the bytes of the slab's
+// own x and z -- and each of its waves waits on its loads in turn.  Here, as in rnvp_bwd_ts_shared_kernel
+// (mnf_rnvp_bwd.hip), a workgroup of EIGHT waves owns FOUR adjacent slabs and walks its row pairs together -- wave
+// (slab s, tile t) computes tile 2 p + t of pair p for slab s --; the pair's hand-over is copied once per workgroup into
+// a double-buffered LDS window by LDS-DMA (buffer_load ... lds) while the previous pair is computed, every wave reads its
+// MFMA operands out of it, and the next pair's x and z rows are prefetched into registers.  The sums over a tile's 16
+// rows are two K = 32 MFMAs per (output tile, tensor): A = [g_hi | g_lo'] against B = [p_hi | p_hi] and [p_lo' | 0].
+// LDS at 64 outputs: 4 x 16 KB of operands + 2 x 2 x 16 KB of hand-over = 128 KB: one workgroup per CU.
+typedef __attribute__((address_space(3))) void* lds_void_ptr_m;
+constexpr int kMlsSlabs = 4;
+constexpr int kMlsWaves = 2 * kMlsSlabs;
+
+template <int YT>
+struct MlSharedShape {
+  using S = MlBwdShape<YT>;
+  using H = HandoverShape<YT>;
+  static constexpr int W_WORDS = S::SLAB_WORDS;
+  static constexpr int HT_WORDS = H::TILE_WORDS;  // the whole tile: g_m, g_v with outputs on K and with rows on K
+  static_assert(HT_WORDS % 256 == 0, "whole 1 KB pieces");
+  static constexpr int HT_PIECES = HT_WORDS / 256;
+  static constexpr int N_DMA = (2 * HT_PIECES + kMlsWaves - 1) / kMlsWaves;
+  static constexpr int H_OFF = kMlsSlabs * W_WORDS;
+  static constexpr int LDS_WORDS = H_OFF + 2 * 2 * HT_WORDS;
+  static constexpr int UP = 33;                          // padded row of the flush area ([output][dim of the slab])
+  static constexpr int RED_SLAB = 2 * 16 * YT * UP;      // both tensors of one slab
+  static_assert(kMlsSlabs * RED_SLAB <= LDS_WORDS, "the flush area fits (it may run on into the hand-over window: every "
+                                                   "piece has landed behind the barrier in front of the flush)");
+  static_assert(LDS_WORDS * 4 <= 160 * 1024, "fits the CU's LDS");
+};
+
+template <int YT, bool RAG>
+__global__ void __launch_bounds__(kMlsWaves * 64, 2)
+ml_bwd_slab_shared_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ grad_x,
+                          float* __restrict__ grad_z, float* __restrict__ grad_flat, const float* __restrict__ flat,
+                          const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side,
+                          const int32_t* __restrict__ flags, const float* __restrict__ gscale_dev, int64_t rows, int n_in,
+                          int n_out, int n_slabs, int row_parts, int vec2, float var_unscale) {
+  using S = MlBwdShape<YT>;
+  using H = HandoverShape<YT>;
+  using T = MlSharedShape<YT>;
+  constexpr int NKS = S::NKS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t ms_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sl = wave & (kMlsSlabs - 1), tt = wave / kMlsSlabs;  // (waves w and w + 4 share a SIMD: same slab, other tile)
+  const int j = lane & 15, q = lane >> 4;
+  const float inv_gscale = 1.f / gscale_dev[0];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
+  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
+  const int n_groups = (n_slabs + kMlsSlabs - 1) / kMlsSlabs;
+  const SlabItems items(n_groups, row_parts);
+  for (int item = items.first; item < items.n_items; item += items.step) {
+    const int sg = items.slab(item), part = items.part(item);
+    const int slab = sg * kMlsSlabs + sl;
+    const bool slab_ok = slab < n_slabs;  // (wave-uniform: the last group may hold fewer than four slabs)
+    const int64_t p0 = (int64_t)part * per_part, p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
+    if (p0 >= p_end) continue;  // (workgroup-uniform)
+    __syncthreads();  // the previous item's flush is over
+#pragma unroll 1
+    for (int s_ = 0; s_ < kMlsSlabs; ++s_) {
+      const int sb = sg * kMlsSlabs + s_;
+      if (sb >= n_slabs) break;
+      const uint4* src = reinterpret_cast<const uint4*>(bimage + (int64_t)sb * S::SLAB_WORDS);
+      uint4* w = reinterpret_cast<uint4*>(ms_lds + s_ * T::W_WORDS);
+      for (int i = threadIdx.x; i < S::SLAB_WORDS / 4; i += blockDim.x) w[i] = src[i];
+    }
+    // (visible to every wave behind the pair loop's first barrier)
+    const int dim0 = 32 * (slab_ok ? slab : n_slabs - 1) + 2 * j;  // the lane's even dim; + 1: its odd dim
+    const bool in0 = dim0 < n_in, in1 = dim0 + 1 < n_in;
+    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)n_in + (uint32_t)dim0;
+    // operand numbering in LDS: [(dt * 2 + which) * NKS + ks][part], which = 0: W_mean, 1: exp(W_log_var) (scaled)
+    int w_lane = lane;  // (opaque, refreshed per pair: keeps the operand reads inside the pair loop)
+    const f16x8* W8 = reinterpret_cast<const f16x8*>(ms_lds + sl * T::W_WORDS);
+    auto wop = [&](int dt, int which, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + which) * NKS + ks) + part_)]; };
+
+    f32x4 aWm[2][YT], aWv[2][YT];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int m = 0; m < YT; ++m) aWm[dt][m] = aWv[dt][m] = zero4;
+
+    // a tile's rows as LOADED (nothing here waits for a load: the values are first touched by compute(), one pair later)
+    struct RowsIn {
+      f32x2 xx[4], zz[4];
+      bool active;
+      int n_live;
+      int64_t tbase;
+    };
+    auto load_rows = [&](int64_t p, RowsIn& in) {
+      const int64_t tile = 2 * p + tt;
+      const bool has = tile < n_tiles;
+      in.tbase = (has ? tile : 2 * p) * 16;  // wave-uniform
+      in.n_live = has ? (int)min((int64_t)16, rows - in.tbase) : 0;
+      in.active = has && slab_ok && flags[(p * 32) / kMlbGroupRows] == 0;  // the fp32 kernel redoes flagged groups
+      // (an idle wave loads all the same, from its clamped slab: no branch around the loads, so that the compiler's
+      // count of the operations in flight stays exact)
+      const float* xt = x + in.tbase * n_in;
+      const float* zt = z + in.tbase * n_in;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool live = 4 * q + r < in.n_live;
+        // a row past the end reads the tile's first row instead (multiplied by zero, nothing of it is stored)
+        const uint32_t ob = (live ? lane_off + (uint32_t)r * (uint32_t)n_in : (uint32_t)dim0) * 4u;
+        auto at = [&](const float* base) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + ob); };
+        f32x2 xv = {0.f, 0.f}, zv = {0.f, 0.f};
+        if (!RAG) {
+          xv = *reinterpret_cast<const f32x2*>(at(xt));
+          zv = *reinterpret_cast<const f32x2*>(at(zt));
+        } else if (vec2) {
+          if (in0) {
+            xv = *reinterpret_cast<const f32x2*>(at(xt));
+            zv = *reinterpret_cast<const f32x2*>(at(zt));
+          }
+        } else {
+          if (in0) {
+            xv[0] = at(xt)[0];
+            zv[0] = at(zt)[0];
+          }
+          if (in1) {
+            xv[1] = at(xt)[1];
+            zv[1] = at(zt)[1];
+          }
+        }
+        in.xx[r] = xv;
+        in.zz[r] = zv;
+      }
+    };
+    // the pair's hand-over -> LDS buffer `buf`: 2 x HT_PIECES pieces of 1 KB, dealt to the eight waves (no branches: a
+    // piece past the end, or of a second tile that does not exist, repeats a valid one)
+    auto request_handover = [&](int64_t p, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in hipcc's host pass over this file)
+      const int has1 = 2 * p + 1 < n_tiles ? 1 : 0;
+      const __amdgpu_buffer_rsrc_t pair_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint32_t*>(side + (2 * p) * H::TILE_WORDS), 0, 2 * H::TILE_WORDS * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < T::N_DMA; ++i) {
+        const int piece = min(i * kMlsWaves + wave, 2 * T::HT_PIECES - 1);  // wave-uniform
+        const int t = piece / T::HT_PIECES, k = piece - t * T::HT_PIECES;
+        uint32_t* dst = ms_lds + T::H_OFF + (buf * 2 + t) * T::HT_WORDS + k * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pair_rsrc, (lds_void_ptr_m)dst, 16, lane * 16,
+                                                 (t & has1) * (H::TILE_WORDS * 4) + k * 1024, 0, 0);
+      }
+#endif
+      asm volatile("" ::: "memory");  // (the pair's stores stay behind the pieces: landed_barrier() counts on it)
+    };
+    // Vector-memory operations complete in issue order: with `stores` operations known to have been issued behind this
+    // wave's pieces, all but the youngest `stores` being complete means the pieces are in LDS (the stores stay in flight).
+    auto landed_barrier = [&](int stores) {
+      if (stores == 8)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // returns the number of vector-memory instructions it issued for certain (8 or 0)
+    auto compute = [&](RowsIn& in, int buf) -> int {
+      if (!in.active) return 0;
+      asm volatile("" : "+v"(w_lane));
+      uint32_t h_off = (uint32_t)(T::H_OFF + (buf * 2 + tt) * T::HT_WORDS) * 4u + (uint32_t)lane * 16u;
+      asm volatile("" : "+v"(h_off));
+      const char* hb = reinterpret_cast<const char*>(ms_lds) + h_off;                   // 16 B per lane: + operand * 1 KB
+      const char* hb_tr = reinterpret_cast<const char*>(ms_lds) + h_off - lane * 8u;  // 8 B per lane: + operand * 512 B
+      auto op = [&](int base_words, int ks, int part_) {
+        return *reinterpret_cast<const f16x8*>(hb + base_words * 4 + (2 * ks + part_) * 1024);
+      };
+      auto tr = [&](int base_words, int m, int part_) {
+        return *reinterpret_cast<const u32x2*>(hb_tr + base_words * 4 + (2 * m + part_) * 512);
+      };
+      f32x4 a4[2], b4[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {  // a^T, b^T [row][dim] = g [row][output] W [output][dim]
+        f32x4 am = zero4, ac = zero4, bm = zero4, bc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          split_mac(op(H::A_OP, ks, 0), op(H::A_OP, ks, 1), wop(dt, 0, ks, 0), wop(dt, 0, ks, 1), am, ac);
+          split_mac(op(H::B_OP, ks, 0), op(H::B_OP, ks, 1), wop(dt, 1, ks, 0), wop(dt, 1, ks, 1), bm, bc);
+        }
+        a4[dt] = (ac * kSplitInvScale + am) * inv_gscale;
+        b4[dt] = (bc * kSplitInvScale + bm) * (inv_gscale * var_unscale);
+      }
+      // the element-wise part on f32x2 values (the lane's two dims of a row): packed fp32 instructions
+      f32x4 pz[2], x2[2];
+      f32x2 gxo[4], gzo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float keep = 4 * q + r < in.n_live ? 1.f : 0.f;  // (the cotangents of a row past the end are zero; keep
+        const f32x2 xv = in.xx[r] * keep, zv = in.zz[r] * keep;  //  its x z finite)
+        const f32x2 a2 = f32x2{a4[0][r], a4[1][r]}, b2 = f32x2{b4[0][r], b4[1][r]};
+        const f32x2 p2 = xv * zv, s2 = xv * xv;  // the forward pass's operands (mnf_linear.py:48,53)
+        gxo[r] = zv * a2 + (xv * b2) * 2.f;
+        gzo[r] = xv * a2;
+        pz[0][r] = p2[0];
+        pz[1][r] = p2[1];
+        x2[0][r] = s2[0];
+        x2[1][r] = s2[1];
+      }
+      float* ox = grad_x + in.tbase * n_in;
+      float* oz = grad_z + in.tbase * n_in;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (4 * q + r < in.n_live) {
+          const uint32_t off = lane_off + (uint32_t)r * (uint32_t)n_in;
+          if (!RAG) {
+            *reinterpret_cast<f32x2*>(ox + off) = gxo[r];
+            *reinterpret_cast<f32x2*>(oz + off) = gzo[r];
+          } else if (vec2) {  // (n_in even: in0 implies in1)
+            if (in0) {
+              *reinterpret_cast<f32x2*>(ox + off) = gxo[r];
+              *reinterpret_cast<f32x2*>(oz + off) = gzo[r];
+            }
+          } else {
+            if (in0) {
+              ox[off] = gxo[r][0];
+              oz[off] = gzo[r][0];
+            }
+            if (in1) {
+              ox[off + 1] = gxo[r][1];
+              oz[off + 1] = gzo[r][1];
+            }
+          }
+        }
+      }
+      if (grad_flat) {
+        const u32x2 zero2 = u32x2{0u, 0u};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          u32x2 ph, pl, sh, sl_;
+          split_plain(pz[dt], ph, pl);
+          split_plain(x2[dt], sh, sl_);
+          const f16x8 p_hh = pair_operand(ph, ph), p_l0 = pair_operand(pl, zero2);
+          const f16x8 s_hh = pair_operand(sh, sh), s_l0 = pair_operand(sl_, zero2);
+#pragma unroll
+          for (int m = 0; m < YT; ++m) {  // D [output][dim] += A [output][row] B [row][dim] over the tile's 16 rows
+            const f16x8 m_hl = pair_operand(tr(H::A_TR, m, 0), tr(H::A_TR, m, 1));
+            const f16x8 v_hl = pair_operand(tr(H::B_TR, m, 0), tr(H::B_TR, m, 1));
+            aWm[dt][m] = mfma_h(m_hl, p_hh, aWm[dt][m]);
+            aWv[dt][m] = mfma_h(v_hl, s_hh, aWv[dt][m]);
+            aWm[dt][m] = mfma_h(m_hl, p_l0, aWm[dt][m]);
+            aWv[dt][m] = mfma_h(v_hl, s_l0, aWv[dt][m]);
+          }
+        }
+      }
+      return (in.n_live == 16 && (!RAG || vec2)) ? 8 : 0;
+    };
+
+    {
+      // two register sets, alternating roles (no copies: a copy would wait for the loads it moves); the last pair
+      // requests itself once more into the idle buffer rather than branching around the requests
+      RowsIn ra, rb;
+      load_rows(p0, ra);
+      request_handover(p0, 0);
+      int stores = 0;
+      int64_t p = p0;
+      while (true) {
+        landed_barrier(stores);  // every wave's pieces of pair p are in LDS, pair p - 1 (the other buffer) is consumed
+        {
+          const int64_t pn = min(p + 1, p_end - 1);
+          load_rows(pn, rb);
+          request_handover(pn, 1);
+        }
+        stores = compute(ra, 0);
+        if (++p >= p_end) break;
+        landed_barrier(stores);
+        {
+          const int64_t pn = min(p + 1, p_end - 1);
+          load_rows(pn, ra);
+          request_handover(pn, 0);
+        }
+        stores = compute(rb, 1);
+        if (++p >= p_end) break;
+      }
+    }
+    if (!grad_flat) continue;
+    // flush through LDS: the waves add their tiles up as [slab][tensor][output][dim of the slab]; the workgroup then adds
+    // 128 contiguous bytes of a weight row per half wave to grad_flat.  dW_log_var = exp(W_log_var) (.) dWv: the image's
+    // scaled exp(W_log_var) (flat) times the scaled sum is the true product.
+    float* red = reinterpret_cast<float*>(ms_lds);
+    __syncthreads();  // (drains every wave's outstanding pieces too: the area may run on into the hand-over window)
+    for (int i = threadIdx.x; i < kMlsSlabs * T::RED_SLAB; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    if (slab_ok) {
+      float* rs = red + sl * T::RED_SLAB;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int m = 0; m < YT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(rs + (16 * m + 4 * q + r) * T::UP + 2 * j + dt, aWm[dt][m][r]);
+            atomicAdd(rs + 16 * YT * T::UP + (16 * m + 4 * q + r) * T::UP + 2 * j + dt, aWv[dt][m][r]);
+          }
+    }
+    __syncthreads();
+    const int dim_g = 32 * kMlsSlabs * sg;                   // first dim of the group
+    const int n_dims = min(32 * kMlsSlabs, n_in - dim_g);    // dims of this group that exist
+    const int64_t wv = (int64_t)n_out * n_in;
+    for (int e = threadIdx.x; e < n_out * 32 * kMlsSlabs; e += blockDim.x) {
+      const int o = e / (32 * kMlsSlabs), dl = e - o * (32 * kMlsSlabs);
+      if (dl < n_dims) {
+        const float* rs = red + (dl >> 5) * T::RED_SLAB + o * T::UP + (dl & 31);
+        const int64_t at = (int64_t)o * n_in + dim_g + dl;
+        atomicAdd(grad_flat + at, rs[0] * inv_gscale);
+        atomicAdd(grad_flat + wv + at, rs[16 * YT * T::UP] * flat[wv + at] * (inv_gscale * var_unscale));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fp32 fix-up
 // the listed 128-row groups from the flat parameters: grad_x, grad_z per element, weight gradients by atomics (rare path)
 __global__ void __launch_bounds__(256)
@@ -448,6 +759,16 @@ static void build_mlb_index(int n_in, int n_out, int32_t* idx) {
 
 static int mlb_tiles(int n_out) { return n_out < 1 || n_out > 64 ? 0 : (n_out + 15) / 16; }
 
+// MNF_MNF_LINEAR_BWD_SLAB=split in the environment: the slab launch on the one-slab-per-workgroup kernel (the round-3
+// kernel, kept for same-box A/B runs and as the fallback when the shared kernel's LDS request is refused)
+static bool mlb_slab_split_forced() {
+  static const bool forced = [] {
+    const char* v = getenv("MNF_MNF_LINEAR_BWD_SLAB");
+    return v != nullptr && strcmp(v, "split") == 0;
+  }();
+  return forced;
+}
+
 static int64_t mlb_header_bytes(int64_t rows) {
   const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
   return (((1 + 2 * n_groups) * 4 + 255) & ~(int64_t)255);
@@ -469,16 +790,46 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,
                      flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f);
   if (int rc = check_launch()) return rc;
-  static DeviceMemo memo;
-  const int resident = memo.get(
-      [](int dev) { return resident_by_occupancy(ml_bwd_slab_kernel<YT, RAG>, kMlbWaves * 64, dev, 2); });
   const int n_slabs = (int)S::n_slabs(n_in);
+  const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
   int row_parts, grid;
-  plan_slab_launch(((rows + 15) / 16 + 1) / 2, kMlbWaves, n_slabs, resident, row_parts, grid);
-  hipLaunchKernelGGL((ml_bwd_slab_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlbWaves * 64), 0, stream, x, z, grad_x,
-                     grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out, n_slabs, row_parts, vec2,
-                     var_unscale);
-  if (int rc = check_launch()) return rc;
+  bool launched = false;
+  if (!mlb_slab_split_forced()) {
+    // the shared-hand-over kernel: four slabs per workgroup, one workgroup per CU
+    using T = MlSharedShape<YT>;
+    static DeviceMemo memo_s;
+    void (*const kernel)(const float*, const float*, float*, float*, float*, const float*, const uint32_t*, const uint32_t*,
+                         const int32_t*, const float*, int64_t, int, int, int, int, int, float) =
+        ml_bwd_slab_shared_kernel<YT, RAG>;  // (named out here: a kernel first named inside a lambda gets no host stub)
+    const int resident_s = memo_s.get([kernel](int dev) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              T::LDS_WORDS * 4) != hipSuccess)
+        return -1;
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kMlsWaves * 64, T::LDS_WORDS * 4) != hipSuccess ||
+          per_cu < 1)
+        per_cu = 1;
+      return per_cu * device_cus(dev);
+    });
+    if (resident_s > 0) {
+      plan_slab_launch(n_pairs, 1, (n_slabs + kMlsSlabs - 1) / kMlsSlabs, resident_s, row_parts, grid);
+      hipLaunchKernelGGL((ml_bwd_slab_shared_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlsWaves * 64), T::LDS_WORDS * 4,
+                         stream, x, z, grad_x, grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out,
+                         n_slabs, row_parts, vec2, var_unscale);
+      if (int rc = check_launch()) return rc;
+      launched = true;
+    }
+  }
+  if (!launched) {
+    static DeviceMemo memo;
+    const int resident = memo.get(
+        [](int dev) { return resident_by_occupancy(ml_bwd_slab_kernel<YT, RAG>, kMlbWaves * 64, dev, 2); });
+    plan_slab_launch(n_pairs, kMlbWaves, n_slabs, resident, row_parts, grid);
+    hipLaunchKernelGGL((ml_bwd_slab_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlbWaves * 64), 0, stream, x, z, grad_x,
+                       grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out, n_slabs, row_parts, vec2,
+                       var_unscale);
+    if (int rc = check_launch()) return rc;
+  }
   hipLaunchKernelGGL(ml_bwd_fixup_kernel, dim3(256), dim3(256), 0, stream, x, z, gout, sd, eps, seed, grad_x, grad_z,
                      grad_flat, flat, list, rows, n_in, n_out, var_unscale);
   return check_launch();
