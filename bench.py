@@ -39,7 +39,11 @@ WORKLOADS = {
                          "fusion: no intermediates; reported separately from c2)"),
     "c3f": (32, 1 << 20, "3xFusedSplineBlock[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob "
                          "(opt-in fusion: block intermediates not materialised; reported separately from c3)"),
+    "c1": (2, 4096, "9xAffineHalfFlow d=2 batch=4096 (half-moons) inverse+log_prob: LATENCY per pass, eager and replayed "
+                    "from a hipGraph (BASELINE configs[0]: SURVEY 8d 'report latency, not roofline')"),
     "c5": (800, 512 * 500, "MNFLinear(800,50).sample_z: 2xRNVP d=800 h=50 on 512x500 MC rows (BASELINE configs[4])"),
+    "c5b": (50, 512 * 500, "MNFLinear(50,10).sample_z: 2xRNVP d=50 h=50 on 512x500 MC rows (the second MNFLinear of "
+                           "BASELINE configs[4]'s MNF-LeNet)"),
     "c2t": (64, 1 << 20, "training step of 9xAffineHalfFlow d=64 batch=2^20: -mean log-prob, backward, Adam (SURVEY 8f "
                          "rank 1; the reference's tests train through these layers, tests/test_flows.py:14-31)"),
     "c5t": (800, 512 * 500, "training step of MNFLinear(800,50) on 512x500 MC rows: sample_z (2xRNVP d=800 h=50), forward, "
@@ -171,20 +175,37 @@ def cpu_baseline(layers, dim: int, x_sample_gpu: torch.Tensor, budget_s: float =
             best = min(best, time.perf_counter() - t0)
             if time.perf_counter() - t_start > 2.0 * budget_s:
                 break
-    # ... and on ONE thread, on a sample sized for about a second
+    # ... and on ONE thread on the SAME rows as the multi-thread figure when that takes under ~20 s, else
+    # both on the first 65,536 rows (the two figures are then measured on one and the same sample either way)
     torch.set_num_threads(1)
-    n1 = int(min(rows, 1 << 13))
     with torch.no_grad():
         O.mean_log_prob(x[:1024], layers)
+        t0 = time.perf_counter()
+        O.mean_log_prob(x[:8192], layers)
+        est = (time.perf_counter() - t0) / 8192 * rows
+    n1 = rows if est < 20.0 else int(min(rows, 1 << 16))
+    with torch.no_grad():
         t0 = time.perf_counter()
         O.mean_log_prob(x[:n1], layers)
         one_thread = n1 / (time.perf_counter() - t0)
     torch.set_num_threads(cores)
+    if n1 == rows:
+        multi_same = rows / best
+    else:
+        with torch.no_grad():
+            O.mean_log_prob(x[:n1], layers)
+            t0 = time.perf_counter()
+            O.mean_log_prob(x[:n1], layers)
+            multi_same = n1 / (time.perf_counter() - t0)
     info = {
         "value": rows / best,
         "unit": "samples/s",
         "cores": cores,
-        "one_thread": {"value": one_thread, "unit": "samples/s", "sample": f"first {n1} rows, one ATen thread, one pass"},
+        "torch_num_threads": torch.get_num_threads(),
+        "one_thread": {"value": one_thread, "unit": "samples/s", "rows": n1,
+                       "multi_thread_on_the_same_rows": multi_same,
+                       "sample": f"first {n1} rows (the SAME rows as `multi_thread_on_the_same_rows`, {cores} ATen "
+                                 f"threads), one ATen thread, one pass"},
         "host_cores": host,
         "kind": "port",
         "sample": f"oracle (PyTorch-CPU restatement of the reference path), first {rows} rows of the "
@@ -202,13 +223,13 @@ ARITHMETIC = ("fp32 via split f16 MFMA (hi+lo, 3 products per fp32 product, fp32
 AHF_KERNEL = "ahf_split_kernel" if SPLIT else "ahf_mfma_kernel"
 
 
-def main_c5(args, rank, world, device, dim, rows, desc) -> None:
-    """Config 5: the flow_q of MNFLinear(800, 50) on 256,000 MC rows.  A step = one sample_z call
-    (prologue kernel + two seeded RNVP kernels, log-det accumulated in-kernel); fp32-MFMA bound."""
+def main_c5(args, rank, world, device, dim, rows, desc, n_out: int = 50) -> None:
+    """Config 5: the flow_q of MNFLinear(800, 50) -- c5b: of MNFLinear(50, 10) -- on 256,000 MC rows.  A step = one
+    sample_z call (prologue kernel + two seeded RNVP kernels, log-det accumulated in-kernel); fp32-MFMA bound."""
     from torch_mnf_amd import synthetic as recipes
     import torch_mnf_amd as amd
 
-    layer = amd.MNFLinear(dim, 50)
+    layer = amd.MNFLinear(dim, n_out)
     for i, f in enumerate(layer.flow_q.flows):
         f.load_state_dict(recipes.rnvp_params(800 + i, dim, 50))
     layer.to(device)
@@ -263,10 +284,11 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         # register-resident kernel moves exactly that; the streaming kernel (MNF_RNVP_RESIDENT=0) reads z a second
         # time for the gate epilogue: 12d + 8.
         algo_bytes = (8 * dim + 8) * rows
-        resident = SPLIT and os.environ.get("MNF_RNVP_RESIDENT", "1") != "0"  # rows held in registers: z read once
+        # rows held in registers, z read once: the kernel exists for d = 800 (c5b, d = 50, runs the streaming kernel)
+        resident = SPLIT and os.environ.get("MNF_RNVP_RESIDENT", "1") != "0" and dim == 800
         if SPLIT:  # memory-path bound (tools ablations: no MFMAs -> same time), priced against HBM
             gbs = algo_bytes / avg_s / 1e9
-            traffic, source = pmc_traffic("c5" if resident else "c5_streaming")
+            traffic, source = pmc_traffic("c5" if resident else "c5b" if dim != 800 else "c5_streaming")
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                                **physical(traffic, avg_s),
@@ -309,6 +331,77 @@ def main_c5(args, rank, world, device, dim, rows, desc) -> None:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_c1(args, rank, world, device, dim, rows, desc) -> None:
+    """Config 1 (the reference's own CPU-runnable case, examples/half_moons.ipynb): nine AffineHalfFlow layers on 4,096
+    two-dimensional points.  At this size a pass is nine launches of a few microseconds: what is reported is the LATENCY
+    of one inverse + log-prob pass, eager and replayed from a hipGraph, not a roofline fraction."""
+    if world != 1:
+        raise SystemExit("--workload c1 is a single-GPU latency measurement")
+    import torch_mnf_amd as amd
+    from torch_mnf_amd import synthetic as recipes
+
+    torch.manual_seed(11)
+    flows = []
+    for i, sd in enumerate(recipes.c2_stack_params(dim, 9)):
+        f = amd.AffineHalfFlow(dim, bool(i % 2))
+        f.load_state_dict(sd)
+        flows.append(f)
+    model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(device)
+    gen = torch.Generator(device=device).manual_seed(99)
+    x = torch.randn(rows, dim, device=device, generator=gen)
+
+    def timed(fn, n):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        t_prime = time.perf_counter()
+        while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+            model.log_prob(x, return_sum=True)
+            torch.cuda.synchronize()
+        eager_s = timed(lambda: model.log_prob(x, return_sum=True), args.steps)
+        _, tot = model.log_prob(x, return_sum=True)
+        replay = model.graphed_log_prob(x)
+        graph_s = timed(lambda: replay(x), args.steps)
+        _, tot_g = replay(x)
+    out = {
+        "metric": f"samples/s, {desc}", "value": rows / eager_s, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": eager_s * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": rows, "dim": dim, "n_layers": 9, "total_rows": rows},
+        "latency_us": {"eager_pass": eager_s * 1e6, "graphed_pass": graph_s * 1e6,
+                       "graphed_samples_per_s": rows / graph_s,
+                       "note": "one inverse + log-prob pass over 4,096 rows: nine launches + the epilogue; launch-bound"},
+        "roofline": {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                     "kernel": "(launch-bound: latency reported instead, SURVEY 8d)", "avg_kernel_us": None},
+        "mean_log_prob": float(tot) / rows, "mean_log_prob_graphed": float(tot_g) / rows,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import flow_oracle as O
+
+        layers = [{"kind": "affine_half", "parity": bool(i % 2), "params": sd}
+                  for i, sd in enumerate(recipes.c2_stack_params(dim, 9))]
+        torch.set_num_threads(1)
+        xc = x.cpu()
+        with torch.no_grad():
+            O.mean_log_prob(xc, layers)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                mean, _ = O.mean_log_prob(xc, layers)
+            cpu_s = (time.perf_counter() - t0) / 20
+        out["cpu_baseline"] = {"value": rows / cpu_s, "unit": "samples/s", "cores": 1, "kind": "port",
+                               "latency_us": cpu_s * 1e6,
+                               "sample": "oracle, the same 4,096 rows, one ATen thread, mean of 20 passes"}
+        out["parity"] = {"mean_log_prob_rel_err": abs(float(tot) / rows - float(mean)) / abs(float(mean)), "tolerance": 1e-5}
+    print(json.dumps(out))
 
 
 def main_train(args, rank, world, device, dim, rows, desc) -> None:
@@ -747,36 +840,46 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     print(json.dumps(out))
 
 
-SECONDARY = ("c3", "c4", "c5", "c2t", "c3t", "c5t", "lenet")
+# (key in `secondary`, workload, extra environment)
+SECONDARY = (("c3", "c3", {}), ("c4", "c4", {}), ("c5", "c5", {}), ("c5b", "c5b", {}), ("c1", "c1", {}),
+             ("c2_fp32", "c2", {"MNF_FP32_MFMA": "1"}),  # the headline on the strict fp32-MFMA stack kernel
+             ("c2t", "c2t", {}), ("c3t", "c3t", {}), ("c5t", "c5t", {}), ("lenet", "lenet", {}))
 
 
 def secondary_lines(args) -> dict:
     """The other configurations, driver-observable: after the headline's timed region (and outside it) each of them
     runs as a CHILD process -- `bench.py --workload X --steps 20 --warmup 3 --no-cpu-baseline` -- and its line is
-    condensed to {ms_per_step, value, unit, kernel, avg_kernel_us, bound, frac}.  (A child process, never an exec: this
-    process has initialised the GPU.)  A workload that fails or overruns its time limit is reported as such."""
+    condensed to {ms_per_step, value, unit, kernel, avg_kernel_us, bound, frac, traffic, frac_physical} (+ latency_us
+    for c1).  (A child process, never an exec: this process has initialised the GPU.)  A workload that fails or
+    overruns its time limit is reported as such."""
     import subprocess
 
     out = {}
-    for w in SECONDARY:
+    for key, w, extra_env in SECONDARY:
         # (MNF_BENCH_SECONDARY_STEPS: the test suite shortens the child runs)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps",
                os.environ.get("MNF_BENCH_SECONDARY_STEPS", "20"), "--warmup", "3",
                "--no-cpu-baseline", "--no-secondary", "--prime-ms", str(args.prime_ms)]
         try:
             t0 = time.perf_counter()
-            res = subprocess.run(cmd, capture_output=True, text=True, timeout=90)
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=90, env={**os.environ, **extra_env})
             line = next((l for l in reversed(res.stdout.splitlines()) if l.startswith("{")), None)
             if res.returncode != 0 or line is None:
-                out[w] = {"error": (res.stderr or "no JSON line").strip().splitlines()[-1][:200]}
+                out[key] = {"error": (res.stderr or "no JSON line").strip().splitlines()[-1][:200]}
                 continue
             d = json.loads(line)
             r = d.get("roofline", {})
-            out[w] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
-                      "kernel": (r.get("kernel") or "")[:80], "avg_kernel_us": r.get("avg_kernel_us"),
-                      "bound": r.get("bound"), "frac": r.get("frac"), "wall_s": round(time.perf_counter() - t0, 1)}
+            out[key] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                        "kernel": (r.get("kernel") or "")[:80], "avg_kernel_us": r.get("avg_kernel_us"),
+                        "bound": r.get("bound"), "frac": r.get("frac"), "traffic": r.get("traffic"),
+                        "frac_physical": r.get("frac_physical"), "wall_s": round(time.perf_counter() - t0, 1)}
+            if "latency_us" in d:
+                out[key]["latency_us"] = {k: v for k, v in d["latency_us"].items() if k != "note"}
+            if extra_env:
+                out[key]["env"] = extra_env
+                out[key]["arithmetic"] = d.get("config", {}).get("arithmetic")
         except subprocess.TimeoutExpired:
-            out[w] = {"error": "timed out after 90 s"}
+            out[key] = {"error": "timed out after 90 s"}
     return out
 
 
@@ -873,6 +976,10 @@ def main() -> None:
     dim, rows, desc = WORKLOADS[args.workload]
     if args.workload == "c5":
         return main_c5(args, rank, world, device, dim, rows, desc)
+    if args.workload == "c5b":
+        return main_c5(args, rank, world, device, dim, rows, desc, n_out=10)
+    if args.workload == "c1":
+        return main_c1(args, rank, world, device, dim, rows, desc)
     if args.workload == "c2t":
         return main_train(args, rank, world, device, dim, rows, desc)
     if args.workload == "c5t":
