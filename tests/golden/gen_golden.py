@@ -394,6 +394,59 @@ def g11_mnf_linear_forward():
     save("g11_mnf_linear_forward", **out)
 
 
+# ----------------------------------------------------------------------------- G16
+def g16_mnf_linear_wide():
+    """MNFLinear(784, 256) (mnf_linear.py:46-64 under loss.backward(); the first layer of an ordinary
+    MNFFeedForward([784, 256, 10]), models/mnf_feed_forward.py:27-31): forward with every random draw captured, and the
+    reference's own autograd gradients of sum(y * w) for x and every parameter on that path.  The layer's parameters are
+    recipe draws (rebuilt by the tests, not stored): W_mean 0.1 N, W_log_var -9 + 0.1 N, b_log_var -9 + 0.1 N,
+    q0_mean 1 + 0.1 N, q0_log_var -9 + 0.1 N."""
+    n_in, n_out, rows, seed = 784, 256, 48, 16
+    torch.manual_seed(seed)
+    layer = MNFLinear(n_in, n_out)
+    with torch.no_grad():
+        layer.W_mean.copy_(0.1 * recipes.gaussian(1600, n_out, n_in))
+        layer.W_log_var.copy_(-9 + 0.1 * recipes.gaussian(1601, n_out, n_in))
+        layer.b_mean.copy_(0.3 * recipes.gaussian(1602, 1, n_out)[0])
+        layer.b_log_var.copy_(-9 + 0.1 * recipes.gaussian(1603, 1, n_out)[0])
+        layer.q0_mean.copy_(1 + 0.1 * recipes.gaussian(1604, 1, n_in)[0])
+        layer.q0_log_var.copy_(-9 + 0.1 * recipes.gaussian(1605, 1, n_in)[0])
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(1610 + i, n_in, 50))
+    x = recipes.gaussian(1620, rows, n_in, scale=1.5).abs().requires_grad_(True)
+    w = recipes.gaussian(1621, rows, n_out) / (rows * n_out)
+    captured = {"eps": [], "mask": []}
+    real_randn_like, real_bernoulli = torch.randn_like, torch.bernoulli
+
+    def randn_like(t, *a, **k):
+        r = real_randn_like(t, *a, **k)
+        captured["eps"].append(r.clone())
+        return r
+
+    def bernoulli(t, *a, **k):
+        r = real_bernoulli(t, *a, **k)
+        captured["mask"].append(r.clone())
+        return r
+
+    torch.randn_like, torch.bernoulli = randn_like, bernoulli
+    try:
+        y = layer.forward(x)
+    finally:
+        torch.randn_like, torch.bernoulli = real_randn_like, real_bernoulli
+    assert len(captured["eps"]) == 2 and len(captured["mask"]) == 2
+    (y * w).sum().backward()
+    out = {"eps_z": npy(captured["eps"][0]), "eps_out": npy(captured["eps"][1]),
+           "mask0_bits": np.packbits(npy(captured["mask"][0]).astype(np.uint8), axis=1),
+           "mask1_bits": np.packbits(npy(captured["mask"][1]).astype(np.uint8), axis=1),
+           "y": npy(y), "grad.x": npy(x.grad)}
+    for k in ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean", "q0_log_var"):
+        out[f"grad.{k}"] = npy(getattr(layer, k).grad)
+    for i, f in enumerate(layer.flow_q.flows):
+        for k, prm in f.named_parameters():
+            out[f"grad.flow_q.{i}.{k}"] = npy(prm.grad)
+    save("g16_mnf_linear_wide", **out)
+
+
 # ----------------------------------------------------------------------------- G12
 def g12_nsf_ar():
     """NSF_AR (spline_flow.py:182-235) forward and inverse: K in {5, 8}, dims 2 (the reference's tests), 6 and 16."""
@@ -604,4 +657,5 @@ if __name__ == "__main__":
     g13_mnf_conv2d()
     g14_mnf_linear_kl()
     g15_maf_iaf()
+    g16_mnf_linear_wide()
     g9_logdet_shapes()

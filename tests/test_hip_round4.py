@@ -100,3 +100,87 @@ def test_mnf_linear_training_draws_no_noise_tensor_for_sample_z(amd):
     ((z2 * w).sum() + ld2.mean()).backward()
     for k, v in got.items():
         assert _err(v, getattr(layer, k).grad) < 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------ MNFLinear wider than 64 outputs
+def _g16_layer(amd):
+    n_in, n_out = 784, 256
+    layer = amd.MNFLinear(n_in, n_out)
+    with torch.no_grad():
+        layer.W_mean.copy_(0.1 * recipes.gaussian(1600, n_out, n_in))
+        layer.W_log_var.copy_(-9 + 0.1 * recipes.gaussian(1601, n_out, n_in))
+        layer.b_mean.copy_(0.3 * recipes.gaussian(1602, 1, n_out)[0])
+        layer.b_log_var.copy_(-9 + 0.1 * recipes.gaussian(1603, 1, n_out)[0])
+        layer.q0_mean.copy_(1 + 0.1 * recipes.gaussian(1604, 1, n_in)[0])
+        layer.q0_log_var.copy_(-9 + 0.1 * recipes.gaussian(1605, 1, n_in)[0])
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(1610 + i, n_in, 50))
+    return layer.to(DEV), n_in, n_out
+
+
+def test_g16_wide_mnf_linear_forward_and_gradients_vs_reference(amd, golden):
+    """Fixture G16: the reference's MNFLinear(784, 256).forward with its draws captured and its own autograd gradients
+    of sum(y w) (mnf_linear.py:46-64; the first layer of an ordinary MNFFeedForward([784, 256, 10])).  Here the layer
+    runs the <= 64-output kernels once per 64-output slab, forward and backward."""
+    from helpers import unpack_mask
+
+    fx = golden("g16_mnf_linear_wide")
+    layer, n_in, n_out = _g16_layer(amd)
+    rows = fx["y"].shape[0]
+    x = recipes.gaussian(1620, rows, n_in, scale=1.5).abs().to(DEV).requires_grad_(True)
+    w = (recipes.gaussian(1621, rows, n_out) / (rows * n_out)).to(DEV)
+    masks = [unpack_mask(fx[f"mask{i}_bits"], n_in).to(DEV) for i in range(2)]
+    eps_z, eps_out = torch.from_numpy(fx["eps_z"]).to(DEV), torch.from_numpy(fx["eps_out"]).to(DEV)
+    real = layer.sample_z
+    layer.sample_z = lambda n: real(n, eps=eps_z, masks=masks)
+    try:
+        y = layer.forward(x, eps=eps_out)
+    finally:
+        layer.sample_z = real
+    assert_close(y, fx["y"], RTOL, "y vs the reference")
+    (y * w).sum().backward()
+    worst = {}
+    got = {"x": x.grad, **{k: getattr(layer, k).grad for k in ("W_mean", "W_log_var", "b_mean", "b_log_var", "q0_mean",
+                                                                 "q0_log_var")}}
+    for i, f in enumerate(layer.flow_q.flows):
+        for k, prm in f.named_parameters():
+            got[f"flow_q.{i}.{k}"] = prm.grad
+    for k, g in got.items():
+        assert g is not None, k
+        worst[k] = normwise_err(g.detach().cpu().numpy(), fx[f"grad.{k}"])
+    # the reference's gradients are fp32 autograd: two fp32 evaluations of these sums differ by ~1e-6 normwise
+    assert max(worst.values()) < 2e-5, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+
+
+def test_mnf_feed_forward_784_256_10_runs_and_trains(amd):
+    """models/mnf_feed_forward.py:27-31 at an ordinary layout: forward, kl_div and a few Adam steps on the library."""
+    torch.manual_seed(5)
+    model = amd.MNFFeedForward([784, 256, 10]).to(DEV)
+    x = torch.rand(96, 784, device=DEV)
+    yb = torch.randint(0, 10, (96,), device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(x), yb) + 1e-4 * model.kl_div()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    with torch.no_grad():
+        assert model(x).shape == (96, 10)
+    # in-kernel noise of the wide layer: forward(x) with a seed == forward(x, eps=noise_for(seed))
+    wide = model[0]
+    real = wide.sample_z
+    z = real(96)[0].detach()
+    wide.sample_z = lambda n: (z, None)
+    try:
+        with torch.no_grad():
+            torch.manual_seed(77)
+            a = wide.forward(x)
+            torch.manual_seed(77)
+            seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+            b = wide.forward(x, eps=wide.noise_for(seed, 96))
+    finally:
+        wide.sample_z = real
+    assert torch.equal(a, b)

@@ -207,6 +207,32 @@ def test_g11_mnf_linear_forward(golden, tag):
     assert_close(y, fx[f"{tag}.y"], 1e-6, "y")
 
 
+def test_g16_mnf_linear_wide_forward_and_gradients(golden):
+    """MNFLinear(784, 256): the reference's forward with every draw captured, and its own autograd gradients of
+    sum(y w), against autograd through the oracle (mnf_linear.py:46-64; models/mnf_feed_forward.py:27-31)."""
+    fx = golden("g16_mnf_linear_wide")
+    n_in, n_out = 784, 256
+    rows = fx["y"].shape[0]
+    p = {"W_mean": 0.1 * recipes.gaussian(1600, n_out, n_in), "W_log_var": -9 + 0.1 * recipes.gaussian(1601, n_out, n_in),
+         "b_mean": 0.3 * recipes.gaussian(1602, 1, n_out)[0], "b_log_var": -9 + 0.1 * recipes.gaussian(1603, 1, n_out)[0],
+         "q0_mean": 1 + 0.1 * recipes.gaussian(1604, 1, n_in)[0], "q0_log_var": -9 + 0.1 * recipes.gaussian(1605, 1, n_in)[0]}
+    p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    flow_p = [{k: v.clone().requires_grad_(True) for k, v in recipes.rnvp_params(1610 + i, n_in, 50).items()} for i in range(2)]
+    layers = [{"kind": "rnvp", "params": flow_p[i], "mask": unpack_mask(fx[f"mask{i}_bits"], n_in)} for i in range(2)]
+    x = recipes.gaussian(1620, rows, n_in, scale=1.5).abs().requires_grad_(True)
+    w = recipes.gaussian(1621, rows, n_out) / (rows * n_out)
+    z, _ = O.sample_z(p["q0_mean"], p["q0_log_var"], t(fx["eps_z"]), layers)
+    y = O.mnf_linear_forward(x, z, p["W_mean"], p["W_log_var"], p["b_mean"], p["b_log_var"], t(fx["eps_out"]))
+    assert_close(y, fx["y"], 2e-6, "y")
+    (y * w).sum().backward()
+    assert_close(x.grad, fx["grad.x"], 5e-6, "grad x")
+    for k, v in p.items():
+        assert_close(v.grad, fx[f"grad.{k}"], 5e-6, f"grad {k}")
+    for i in range(2):
+        for k, v in flow_p[i].items():
+            assert_close(v.grad, fx[f"grad.flow_q.{i}.{k}"], 5e-6, f"grad flow_q.{i}.{k}")
+
+
 G12_CASES = {"d2_k8": (2, 8, 16, 1.0), "d6_k5": (6, 5, 8, 1.0), "d16_k8": (16, 8, 8, 1.5)}  # dim, K, n_h, gain
 
 

@@ -292,6 +292,21 @@ class _MnfKlFn(torch.autograd.Function):
         return head + tuple(t.view(sh) for t, sh in zip(torch.split(pg, sizes), ctx.param_shapes))
 
 
+class _OutputSlab:
+    """Outputs [lo, hi) of an MNFLinear wider than 64 outputs, seen as a layer of its own by the <= 64-output kernels
+    (mnf_mnf_linear_fwd / _bwd): the parameter attributes are fresh slices of the parent's parameters (autograd views:
+    the slab's gradients flow back into the parent's through the slice), the operand caches live on this object."""
+
+    def __init__(self, parent: "MNFLinear", lo: int, hi: int) -> None:
+        self.parent, self.lo, self.hi = parent, lo, hi
+        self.n_in, self.n_out = parent.n_in, hi - lo
+
+    W_mean = property(lambda self: self.parent.W_mean[self.lo:self.hi])
+    W_log_var = property(lambda self: self.parent.W_log_var[self.lo:self.hi])
+    b_mean = property(lambda self: self.parent.b_mean[self.lo:self.hi])
+    b_log_var = property(lambda self: self.parent.b_log_var[self.lo:self.hi])
+
+
 class MNFLinear(nn.Module):
     """Bayesian linear layer with multiplicative normalizing-flow noise.
 
@@ -459,8 +474,8 @@ class MNFLinear(nn.Module):
         (rows, n_out) may be injected, by default it is generated inside the kernel from a seed drawn from torch's
         generator).  With gradients wanted the same launch also keeps ``sqrt(var)``, and the backward pass is
         ``mnf_mnf_linear_bwd`` (grad x, grad z, dW_mean, dW_log_var, db_mean, db_log_var on the matrix cores): no
-        stock-PyTorch matrix product anywhere on the path.  Layers wider than 64 outputs have no kernel (the
-        reference's MNF models use 50 and 10) and raise."""
+        stock-PyTorch matrix product anywhere on the path.  A layer wider than 64 outputs runs the same launches once
+        per 64-output slab."""
         if x.dim() != 2 or x.shape[1] != self.n_in:
             raise ValueError(f"MNFLinear({self.n_in}, {self.n_out}) expects (rows, {self.n_in}) inputs, got {tuple(x.shape)}")
         z, _ = self.sample_z(x.size(0))
@@ -471,10 +486,6 @@ class MNFLinear(nn.Module):
             raise TypeError(f"torch_mnf_amd: MNFLinear.forward needs float32 inputs, got {x.dtype}")
         if x.shape[0] == 0:
             return x.new_empty(0, self.n_out)
-        ops = self._forward_operands(x.device)
-        if ops is None:
-            raise MnfHipError("mnf_mnf_linear_fwd", _lib.MNF_ERR_UNSUPPORTED,
-                              f"MNFLinear.forward has kernels for n_out <= 64 only (got {self.n_out})")
         seed = 0
         if eps is None and _flows._DEVICE_MASKS:
             # a step being recorded in a hipGraph (train.GraphedStep): a host-drawn seed would be frozen into the
@@ -488,17 +499,56 @@ class MNFLinear(nn.Module):
                 raise ValueError(f"eps must be {(x.shape[0], self.n_out)}, got {tuple(eps.shape)}")
         params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
         training = torch.is_grad_enabled() and (x.requires_grad or z.requires_grad or any(p.requires_grad for p in params))
+        if self.n_out > 64:
+            # the kernels hold one row's outputs in <= 4 accumulator tiles: a wider layer (mnf_linear.py:46-56 has no
+            # width limit; an ordinary MNFFeedForward([784, 256, 10])) runs them once per 64-output slab -- x and z are
+            # re-read per slab, the slabs' gradients for x and z are summed by autograd
+            outs = []
+            xc, zc = (None, None) if training else (x.detach().contiguous(), z.detach().contiguous())
+            for k, slab in enumerate(self._output_slabs()):
+                eps_k = None if eps is None else eps[:, slab.lo:slab.hi].contiguous()
+                seed_k = self._slab_seed(seed, k)
+                if training:
+                    outs.append(_MnfLinearFn.apply(x, z, slab.W_mean, slab.W_log_var, slab.b_mean, slab.b_log_var, slab,
+                                                   eps_k, seed_k))
+                else:
+                    outs.append(_mnf_linear_forward(slab, xc, zc, eps_k, seed_k, slab._forward_operands(x.device), None)[0])
+            return torch.cat(outs, dim=1)
         if training:
             return _MnfLinearFn.apply(x, z, *params, self, eps, seed)
+        ops = self._forward_operands(x.device)
         return _mnf_linear_forward(self, x.detach().contiguous(), z.detach().contiguous(), eps, seed, ops, None)[0]
+
+    def _output_slabs(self) -> list:
+        slabs = self.__dict__.get("_slabs")
+        if slabs is None:
+            slabs = self.__dict__["_slabs"] = [_OutputSlab(self, lo, min(lo + 64, self.n_out))
+                                               for lo in range(0, self.n_out, 64)]
+        return slabs
+
+    @staticmethod
+    def _slab_seed(seed: int, k: int) -> int:
+        """The in-kernel noise seed of output slab k (the stream is indexed by the column INSIDE the slab)."""
+        return (int(seed) + k * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     def invalidate(self) -> None:
         """Drop the packed operands of ``forward`` (they are keyed on the parameters' version counters, which a write
         through ``p.data`` or a hipGraph replay does not bump); the flows have their own ``invalidate``."""
         self.__dict__.pop("_fwd_cache", None)
+        for slab in self.__dict__.get("_slabs") or ():
+            slab.__dict__.pop("_fwd_cache", None)
 
     def noise_for(self, seed: int, rows: int, device="cuda") -> Tensor:
         """The (rows, n_out) noise an in-kernel-noise ``forward`` call with this seed used (tests)."""
+        if self.n_out > 64:  # one stream per 64-output slab (forward)
+            parts = []
+            for k, slab in enumerate(self._output_slabs()):
+                e = torch.empty(rows, slab.n_out, dtype=torch.float32, device=device)
+                if rows:
+                    _lib.check("mnf_mnf_linear_noise", _lib.load().mnf_mnf_linear_noise(
+                        self._slab_seed(seed, k), e.data_ptr(), rows, slab.n_out, _stream()))
+                parts.append(e)
+            return torch.cat(parts, dim=1)
         e = torch.empty(rows, self.n_out, dtype=torch.float32, device=device)
         if rows:
             _lib.check("mnf_mnf_linear_noise", _lib.load().mnf_mnf_linear_noise(
@@ -521,6 +571,10 @@ class MNFLinear(nn.Module):
         return _MnfKlFn.apply(z, log_det_q, z_r, log_det_r, eps_w, None, self, False, None, self.W_mean, self.W_log_var,
                               self.b_mean, self.b_log_var, self.q0_mean, self.q0_log_var, self.r0_c, self.r0_b1,
                               self.r0_b2)
+
+
+_OutputSlab._forward_operands = MNFLinear._forward_operands
+_OutputSlab._bwd_index = MNFLinear._bwd_index
 
 
 class MNFConv2d(nn.Module):
