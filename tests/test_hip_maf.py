@@ -203,3 +203,35 @@ def test_maf_wide_and_odd_shapes(amd, O, dim, h_sizes, rows, parity):
             widen = 2 * normwise_err(ref[torch.float32][k].double().numpy(), r64.numpy())
             err = normwise_err(got[k].detach().cpu().double().numpy(), r64.numpy())
             assert err <= 1e-5 + 2 * widen, f"MAF d={dim} h={h_sizes} inverse={inverse} grad {k}: {err:.2e} vs {widen:.2e}"
+
+
+def test_maf_with_a_permuted_made_values_match_and_sequential_gradients_are_refused(amd, O):
+    """A MADE with natural_ordering=False (made.py's default): both directions' VALUES are the reference's; the one-pass
+    direction trains; the element-by-element direction's gradient pass (which reuses one network evaluation for every
+    step, valid only for masks that are autoregressive in index order) raises instead of returning wrong gradients
+    (ADVICE round 3)."""
+    from torch_mnf_amd.flows import MADE
+
+    dim = 6
+    torch.manual_seed(4)
+    net = MADE(dim, (16, 16), 2 * dim, natural_ordering=False)
+    flow = amd.MAF(dim, True, net=net).to(DEV)
+    assert not flow._autoregressive_in_index_order() and amd.MAF(dim, True)._autoregressive_in_index_order()
+    x = (0.5 * recipes.gaussian(31, 200, dim)).to(DEV)
+    with torch.no_grad():
+        z, ld_inv = flow.inverse(x)          # one pass
+        xr, ld_fwd = flow.forward(z)         # element by element: values fine
+    # the oracle on the same masked network (CPU)
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    masks = [m.mask.detach().cpu() for m in net if hasattr(m, "mask")]  # (in, out), as the oracle's made() takes them
+    z_ref, ld_ref = O.maf(x.cpu(), sd, masks, True, inverse=True)
+    assert_close(z, z_ref, 1e-5, "z (permuted MADE)")
+    assert_close(ld_inv, ld_ref, 2e-5, "log_det (permuted MADE)")
+    xr_ref, _ = O.maf(z_ref, sd, masks, True, inverse=False)
+    assert_close(xr, xr_ref, 1e-4, "element-by-element values (permuted MADE)")
+    zg = x.clone().requires_grad_(True)
+    out, ld = flow.inverse(zg)               # one pass: gradients exist
+    (out.sum() + ld.sum()).backward()
+    assert zg.grad is not None and all(p.grad is not None for p in flow.parameters())
+    with pytest.raises(NotImplementedError, match="natural_ordering"):
+        flow.forward(x.clone().requires_grad_(True))

@@ -1325,9 +1325,35 @@ class MAF(_TwoWayFlow):
             cached = self.__dict__["_mask_cache"] = (key, packed)
         return cached[1]
 
+    def _autoregressive_in_index_order(self) -> bool:
+        """Does output i (and dim + i) of the masked network depend on inputs j < i only?  (The composed masks are
+        strictly lower triangular: MADE's natural ordering.)  Cached with the mask tensors' identities and versions."""
+        masks = [m.mask for m in self._masked()]
+        key = tuple((id(t), t._version) for t in masks)
+        cached = self.__dict__.get("_order_cache")
+        if cached is None or cached[0] != key:
+            conn = None  # (outputs of the layers so far, inputs) connectivity
+            for t in masks:
+                layer = (t.detach().to("cpu", torch.float64) != 0).to(torch.float64).T  # MaskedLinear.mask is (in, out)
+                conn = layer if conn is None else ((layer @ conn) != 0).to(torch.float64)
+            out_elem = torch.arange(conn.shape[0]) % self.dim
+            allowed = torch.arange(self.dim)[None, :] < out_elem[:, None]
+            cached = self.__dict__["_order_cache"] = (key, bool(((conn != 0) & ~allowed).sum() == 0))
+        return cached[1]
+
     def _run(self, x, inverse, accum):
         sequential = bool(inverse) != self._sequential_forward
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
+            if sequential and not self._autoregressive_in_index_order():
+                # mnf_maf_bwd evaluates the network ONCE on the decoded output and reuses those activations for every
+                # step of the element-by-element pass: right only when element i never sees elements >= i, i.e. for
+                # masks that are autoregressive in index order.  With any other MADE (natural_ordering=False, several
+                # masks, masks from a state_dict) the VALUES of this direction still match the reference (flows/maf.py:
+                # 39-50: elements not yet decoded are zero at step i), its gradients would not.
+                raise NotImplementedError(
+                    f"{type(self).__name__}: gradients of the element-by-element direction need a MADE whose masks are "
+                    f"autoregressive in index order (MADE(..., natural_ordering=True)); the one-pass direction and both "
+                    f"directions' values work with any MADE")
             xg = _grad_input(x)
             if xg.shape[1] != self.dim:
                 raise ValueError(f"expected dim {self.dim}, got {xg.shape[1]}")
