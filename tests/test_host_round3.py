@@ -87,3 +87,30 @@ def test_stale_parameter_detector(monkeypatch):
         raise AssertionError("a stale image went undetected")
     monkeypatch.setattr(flows, "_CHECK_PARAMS_EVERY", 0)
     flows._check_params_fresh([p], packed, "test")            # switched off: no check
+
+
+def test_flat_homed_model_pickles_and_a_copy_clears_its_own_gradients():
+    """FlatParameters used to install ``model.zero_grad`` as a local lambda closing over itself --
+    unpicklable, and a ``copy.deepcopy`` of the model kept the ORIGINAL's function object (``copy.zero_grad()`` cleared
+    the original's gradient buffer).  Now a bound module-level function that finds the flat buffer through the module."""
+    import copy
+    import pickle
+
+    import torch_mnf_amd as amd
+
+    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    flat = amd.FlatParameters(model)
+    flat.grad.fill_(1.0)
+    clone = copy.deepcopy(model)
+    clone.zero_grad()
+    assert float(flat.grad.abs().sum()) == flat.grad.numel(), "the copy cleared the original's gradient buffer"
+    assert float(clone.__dict__["_mnf_flat"].grad.abs().sum()) == 0.0
+    model.zero_grad()
+    assert float(flat.grad.abs().sum()) == 0.0
+    restored = pickle.loads(pickle.dumps(model))
+    restored.zero_grad()
+    # a middle parameter that left the buffer invalidates the fused layers' in-place gradient path
+    params = list(model.parameters())
+    assert flat.home_is_valid(params)
+    params[1].data = params[1].data.clone()
+    assert not flat.home_is_valid(params)

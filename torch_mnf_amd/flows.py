@@ -213,8 +213,9 @@ def _flat_home_of(module: nn.Module, params: list) -> tuple | None:
     if sl is None or i0 is None or not flat.home_is_valid(params):
         return None
     views = flat._grad_views
-    if params[0].grad is not views[i0] or params[-1].grad is not views[i0 + len(params) - 1]:
-        return None
+    for k, prm in enumerate(params):  # every parameter's gradient is still its view of the flat gradient buffer
+        if prm.grad is not views[i0 + k]:
+            return None
     return flat, sl[0], sl[1]
 
 
@@ -1084,7 +1085,7 @@ def rqs(inputs: Tensor, W: Tensor, H: Tensor, D: Tensor, inverse: bool = False,
     return out.reshape(shape), lad.reshape(shape)
 
 
-_RNVP_BWD_WORK: dict = {}  # device -> scratch of mnf_rnvp_bwd_mfma
+_RNVP_BWD_WORK: dict = {}  # (device, stream) -> scratch of mnf_rnvp_bwd_mfma (two streams never share hand-over tiles)
 
 
 class RNVP(_HipFlow):
@@ -1170,13 +1171,15 @@ class RNVP(_HipFlow):
         return image
 
     def _bwd_workspace(self, lib, rows: int, device) -> Tensor:
-        """Scratch of the gradient kernels (1 KB per row + flags).  One buffer per device, shared by every RNVP layer
-        and grown on demand: the layers' backward passes follow one another on the stream."""
+        """Scratch of the gradient kernels (1 KB per row + flags).  One buffer per (device, stream), shared by every RNVP
+        layer and grown on demand: the layers' backward passes follow one another on a stream; two streams (a side-stream
+        warm-up next to eager work, a captured graph's private pool) never share hand-over tiles."""
         need = int(lib.mnf_rnvp_bwd_mfma_workspace_bytes(rows, self.dim, len(self.h_sizes), self._hid))
-        work = _RNVP_BWD_WORK.get(device)
+        key = (device, _stream())
+        work = _RNVP_BWD_WORK.get(key)
         if work is None or work.numel() < need:
             work = torch.empty(need, dtype=torch.uint8, device=device)
-            _RNVP_BWD_WORK[device] = work
+            _RNVP_BWD_WORK[key] = work
         return work
 
     def _few(self, rows: int, explicit_mask: bool) -> bool:

@@ -37,7 +37,7 @@ def _mnf_linear_forward(module, x, z, eps, seed, ops, sd):
     return out, work
 
 
-_MNF_LINEAR_BWD_WORK: dict = {}  # device -> scratch of mnf_mnf_linear_bwd (its launches follow one another on the stream)
+_MNF_LINEAR_BWD_WORK: dict = {}  # (device, stream) -> scratch of mnf_mnf_linear_bwd (its launches follow one another on a stream)
 
 
 class _MnfLinearFn(torch.autograd.Function):
@@ -68,10 +68,11 @@ class _MnfLinearFn(torch.autograd.Function):
         _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
             flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, 0, _stream()))
         need = int(lib.mnf_mnf_linear_bwd_workspace_bytes(rows, m.n_in, m.n_out))
-        work = _MNF_LINEAR_BWD_WORK.get(dev)
+        key = (dev, _stream())
+        work = _MNF_LINEAR_BWD_WORK.get(key)
         if work is None or work.numel() < need:
             work = torch.empty(need, dtype=torch.uint8, device=dev)
-            _MNF_LINEAR_BWD_WORK[dev] = work
+            _MNF_LINEAR_BWD_WORK[key] = work
         scale = _flows._grad_scale(g, None, rows, m.n_out, dev)
         grad_x, grad_z = torch.empty_like(xc), torch.empty_like(zc)
         home = ctx.home

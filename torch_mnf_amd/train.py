@@ -19,6 +19,8 @@ their parameter slice and write their gradient slice in place, and ``FusedAdam``
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 from torch import Tensor, nn
 
@@ -26,6 +28,14 @@ from . import _lib
 from .flows import _stream
 
 __all__ = ["FlatParameters", "FusedAdam", "GraphedStep"]
+
+
+def _flat_zero_grad(model, set_to_none: bool = True) -> None:  # noqa: ARG001 (nn.Module.zero_grad's signature)
+    """``model.zero_grad()`` of a model whose parameters live in a FlatParameters buffer: the buffer's one memset."""
+    flat = model.__dict__.get("_mnf_flat")
+    if flat is None:
+        return nn.Module.zero_grad(model, set_to_none)
+    flat.zero_grad()
 
 
 class FlatParameters:
@@ -64,7 +74,9 @@ class FlatParameters:
         # examples/half_moons.ipynb:188), whose default sets every ``p.grad`` to None: the next backward would then
         # give each parameter a fresh gradient tensor outside ``self.grad``, and the fused layers' in-place sums in
         # ``self.grad`` would never be cleared.  On this model ``zero_grad`` is the one memset instead.
-        model.zero_grad = lambda set_to_none=True: self.zero_grad()  # noqa: ARG005 (instance attribute shadows the method)
+        # (a module-level function bound to the model with functools.partial and resolved through the module at call
+        # time: picklable, and a copy.deepcopy of the model clears ITS OWN buffer, not this one's)
+        model.zero_grad = functools.partial(_flat_zero_grad, model)
         if hasattr(model, "invalidate"):
             model.invalidate()
 
@@ -96,17 +108,16 @@ class FlatParameters:
             p.grad = view
 
     def home_is_valid(self, params: list[Tensor]) -> bool:
-        """Do ``params`` still live in ``self.data`` (first and last data pointer where the offsets say) and do they
+        """Do ``params`` still live in ``self.data`` (every data pointer where the offsets say) and do they
         all still want gradients?  ``model.to()``, ``.float()``, ``load_state_dict(assign=True)`` re-home parameters
         behind this object's back, and ``requires_grad_(False)`` freezes one; a fused layer that wrote its gradient
         slice in place would then update the wrong memory, or a frozen parameter."""
-        first, last = params[0], params[-1]
-        off_f, off_l = self.offset.get(id(first)), self.offset.get(id(last))
-        if off_f is None or off_l is None:
-            return False
         base = self.data.data_ptr()
-        return (first.data_ptr() == base + 4 * off_f and last.data_ptr() == base + 4 * off_l
-                and all(p.requires_grad for p in params))
+        for p in params:  # every parameter of the list (<= ~9 of them): a middle one may have been re-homed or frozen
+            off = self.offset.get(id(p))
+            if off is None or p.data_ptr() != base + 4 * off or not p.requires_grad:
+                return False
+        return True
 
     def zero_grad(self) -> None:
         """One memset; the per-parameter ``.grad`` views stay in place (re-attached if someone set them to None or
