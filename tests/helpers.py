@@ -61,12 +61,25 @@ def assert_parity(got, ref32, ref64=None, what: str = "", rtol: float = RTOL, ma
     budget = rtol + widening
     err = normwise_err(got, np.asarray(ref32))
     PARITY_LOG.append({"what": what, "err": err, "budget": budget, "widening": widening,
-                       "widening_share": widening / budget, "used": err / budget})
+                       "widening_share": widening / budget, "used": err / budget, "stress": max_widening is None})
     if max_widening is not None:
         assert widening <= max_widening, (f"{what}: the float64 head-room {widening:.3e} exceeds {max_widening:.1e} "
                                           f"on a fixture that is not a stress case (err {err:.3e})")
     assert err <= budget, (f"{what}: normwise error {err:.3e} > budget {budget:.3e} "
                            f"(= {rtol:.1e} + float64 head-room {widening:.3e})")
+    return err
+
+
+# one record per gradient / optimiser comparison against a float64 oracle (test_hip_autograd.OracleGrads.check,
+# check_vs_float64, budgeted()): what, err, budget, widening -- tests/test_zz_audit.py enforces the 80 % rule on these too
+GRAD_LOG: list[dict] = []
+
+
+def budgeted(err: float, budget: float, what: str, stress: bool = False) -> float:
+    """A comparison with a fixed, stated budget (no float64 head-room to compute): recorded for the audit like the
+    others.  ``stress``: exempt from the audit's 80 % rule (say why at the call)."""
+    GRAD_LOG.append({"what": what, "err": err, "budget": budget, "widening": 0.0, "stress": stress})
+    assert err <= budget, f"{what}: {err:.3e} > budget {budget:.3e}"
     return err
 
 

@@ -23,7 +23,7 @@ GBASE = 1e-5
 # its reciprocals, exponentials and logarithms are the hardware's 1-ulp instructions).  Those call sites say so.
 GBASE_STRESS = 2e-5
 GTOL = 2e-5  # kernel vs kernel only: two fp32 evaluations, each carrying its own rounding of the row sums
-GRAD_LOG: list[dict] = []  # one record per OracleGrads.check call (test_zz_gradient_budget_audit prints the worst)
+from helpers import GRAD_LOG  # noqa: E402  one record per OracleGrads.check call (tests/test_zz_audit.py enforces the 80 % rule)
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +73,8 @@ class OracleGrads:
         r32n = r32.numpy() if r32 is not None else np.zeros_like(r64.numpy(), dtype=np.float32)
         widening = 2.0 * normwise_err(r32n, r64.numpy())
         err = normwise_err(got.detach().double().cpu().numpy(), r64.numpy())
-        GRAD_LOG.append({"what": f"{what} grad {key}", "err": err, "budget": base + widening, "widening": widening})
+        GRAD_LOG.append({"what": f"{what} grad {key}", "err": err, "budget": base + widening, "widening": widening,
+                         "stress": base != GBASE})
         assert err <= base + widening, (f"{what}: grad {key} is {err:.3e} from the float64 oracle; budget "
                                         f"{base + widening:.3e} = {base:.0e} + 2 x (fp32 oracle vs fp64 oracle = "
                                         f"{widening / 2:.3e})")
@@ -87,7 +88,7 @@ def check_vs_float64(got, r32, r64, what, base=GBASE):
     """The OracleGrads.check rule for tests that build their float32 / float64 oracle runs themselves."""
     widening = 2.0 * normwise_err(r32.detach().numpy(), r64.detach().numpy())
     err = normwise_err(got.detach().double().cpu().numpy(), r64.detach().numpy())
-    GRAD_LOG.append({"what": what, "err": err, "budget": base + widening, "widening": widening})
+    GRAD_LOG.append({"what": what, "err": err, "budget": base + widening, "widening": widening, "stress": base != GBASE})
     assert err <= base + widening, (f"{what}: {err:.3e} from the float64 oracle; budget {base + widening:.3e} = "
                                     f"{base:.0e} + 2 x (fp32 oracle vs fp64 oracle = {widening / 2:.3e})")
     return err

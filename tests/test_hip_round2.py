@@ -572,7 +572,7 @@ def nsf_ar_layer(amd, sd, dim, K, n_h):
 
 
 @pytest.mark.parametrize("tag", sorted(G12_CASES))
-def test_g12_nsf_ar_vs_reference(amd, golden, tag):
+def test_g12_nsf_ar_vs_reference(amd, O, golden, tag):
     """Fixture G12: the reference's NSF_AR.forward / .inverse (spline_flow.py:182-235)."""
     from helpers import assert_parity
 
@@ -587,7 +587,11 @@ def test_g12_nsf_ar_vs_reference(amd, golden, tag):
             y, ld = fn(x)
             assert_parity(y, fx[f"{tag}.{direction}"], fx[f"{tag}.{direction}64"], f"g12 {tag} {direction} y",
                           max_widening=None if gain != 1.0 else 5e-5)
-            assert_close(ld, fx[f"{tag}.ld_{direction}"], 3e-5, f"{direction} log_det")
+            # (the fixture carries the reference's fp32 log-det only -- its float64 run allocates a float32 log-det --: the
+            # float64 head-room comes from the oracle in float64 on the same inputs; round 3: a flat 3e-5)
+            _, ld64 = O.nsf_ar(x.cpu().double(), {k: v.double() for k, v in sd.items()}, K, 3.0, direction == "inv")
+            assert_parity(ld, fx[f"{tag}.ld_{direction}"], ld64.numpy(), f"g12 {tag} {direction} log_det",
+                          max_widening=None if gain != 1.0 else 5e-5)
         # inverse(forward(x)) == x and the log-dets cancel
         y, ld = f.forward(x)
         back, ld_b = f.inverse(y)
@@ -634,21 +638,21 @@ def test_nsf_ar_vs_oracle_and_in_a_stack(amd, O, dim, K, n_h, rows):
 def test_nsf_ar_gradients_vs_autograd_through_the_oracle(amd, O, dim, K, n_h, inverse):
     """mnf_nsf_ar_bwd (reverse mode through the sequential direction too) against torch.autograd through the oracle:
     gradient wrt the input and wrt every parameter tensor, loss = sum(w * y) + sum(v * log_det)."""
+    from test_hip_autograd import OracleGrads, cot_loss
+
     sd = recipes.nsf_ar_params(70 + dim, dim, K, n_h)
     rows = 97
     x = recipes.gaussian(71 + dim, rows, dim, scale=1.2)
     w, v = recipes.gaussian(72, rows, dim), recipes.gaussian(73, rows, 1)[:, 0]
-    ref_p = {k: t.clone().double().requires_grad_(True) for k, t in sd.items()}
-    xr = x.clone().double().requires_grad_(True)
-    y_ref, ld_ref = O.nsf_ar(xr, ref_p, K, 3.0, inverse)
-    ((w.double() * y_ref).sum() + (v.double() * ld_ref).sum()).backward()
+    # fp32 AND float64 autograd through the oracle: the budget is 1e-5 + twice the fp32 oracle's own distance from
+    # float64 (round 3 held this test to a flat 2e-4)
+    og = OracleGrads(cot_loss(lambda xx, p: O.nsf_ar(xx, p, K, 3.0, inverse), w, v), x, sd)
     f = nsf_ar_layer(amd, sd, dim, K, n_h)
     xg = x.clone().to(DEV).requires_grad_(True)
     y, ld = (f.inverse if inverse else f.forward)(xg)
     ((w.to(DEV) * y).sum() + (v.to(DEV) * ld).sum()).backward()
-    assert_close(xg.grad, xr.grad.float(), 2e-4, "grad x")
-    for name, prm in f.named_parameters():
-        assert_close(prm.grad, ref_p[name].grad.float(), 2e-4, f"grad {name}")
+    got = {"x": xg.grad, **{name: prm.grad for name, prm in f.named_parameters()}}
+    og.check_all(got, f"NSF_AR d={dim} K={K} inverse={inverse}")
 
 
 # ------------------------------------------------------------------ training: flat parameters, one optimizer launch
@@ -700,9 +704,16 @@ def test_flat_parameters_and_fused_adam_match_torch_adam(amd, kind):
         loss.backward()
         opt.step()
         assert abs(float(loss) - float(loss_ref)) <= 2e-5 * abs(float(loss_ref)), (step, float(loss), float(loss_ref))
+    # Two Adam implementations fed by the same HIP gradients: what separates them after six steps is the run-to-run
+    # noise of the gradient sums (fp32 atomics: ~1e-7 relative) passed through m / (sqrt(v) + eps), which turns a
+    # relative change of a near-zero gradient into a change of up to one step (lr) of that parameter.  Budget: 1 % of
+    # the distance six steps can move a parameter (6 lr), relative to the largest parameter -- recorded for the audit.
+    from helpers import budgeted, normwise_err
     for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
         assert n1 == n2
-        assert_close(p1, p2, 2e-4, n1)
+        scale = float(p2.detach().abs().max())
+        budgeted(normwise_err(p1.detach().cpu().numpy(), p2.detach().cpu().numpy()), 0.01 * 6 * 2e-3 / max(scale, 1e-30),
+                 f"FusedAdam vs torch.optim.Adam, 6 steps: {n1}")
     # the parameters are still views of the one buffer, and loading a state_dict writes through them
     assert all(p.data_ptr() == flat.data.data_ptr() + 4 * flat.offset[id(p)] for p in flat.params)
     model.load_state_dict(ref.state_dict())

@@ -113,9 +113,13 @@ def test_reference_loop_with_flat_parameters_and_fused_adam(amd):
         lb.backward()
         opt_b.step()
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb)), (step, float(la), float(lb))
+    # (the optimiser-equivalence budget of tests/test_hip_round2.py: 1 % of the distance six steps can move a parameter)
+    from helpers import budgeted
     for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert na == nb
-        assert_close(pa, pb, 2e-4, f"parameter {na} after 6 steps")
+        scale = float(pb.detach().abs().max())
+        budgeted(normwise_err(pa.detach().cpu().numpy(), pb.detach().cpu().numpy()), 0.01 * 6 * 1e-2 / max(scale, 1e-30),
+                 f"FusedAdam vs torch.optim.Adam (mixed model), 6 steps: {na}")
     # every gradient is still a view of the one buffer
     assert all(p.grad is flat._grad_views[i] for i, p in enumerate(flat.params))
 
