@@ -1,33 +1,39 @@
 #!/bin/bash
-# Regenerates everything under profiles/r1/ on the GPU box (writes to gpurun_out/r1/, copy from there):
-#   bench JSON lines for every workload (default path, plus the A/B switches), rocprofv3 kernel-trace + PMC
-#   summaries for c2 / c3 / c5, the training-step timings.
+# Regenerates a round's evidence on the GPU box into gpurun_out/$ROUND/ (copy what is to be judged into profiles/$ROUND/):
+# bench JSON lines, rocprofv3 kernel-trace + PMC summaries (every profiler run under `timeout`), PMC traffic files.
+# usage: [ROUND=r4] tools/refresh_profiles.sh [workloads...]   (default: c2 c3 c4 c5 c5b c2t c3t c5t)
 set -u
+ROUND=${ROUND:-r4}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$REPO/gpurun_out/r1
-mkdir -p "$OUT" "$OUT/fp32_mfma"
+OUT=$REPO/gpurun_out/$ROUND
+mkdir -p "$OUT"
 cd "$REPO"
-python bench.py > "$OUT/c2_bench.json" 2> "$OUT/c2_bench.err"
-for w in c4 c3 c5; do python bench.py --workload $w > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"; done
-python bench.py --workload c2f --no-cpu-baseline > "$OUT/c2_fused_stack_optin_bench.json" 2>/dev/null
-python bench.py --workload c3f --no-cpu-baseline > "$OUT/c3_fused_optin_bench.json" 2>/dev/null
-MNF_NO_RUN_FUSION=1 python bench.py --no-cpu-baseline > "$OUT/c2_layer_by_layer_bench.json" 2>/dev/null
-MNF_NO_RUN_FUSION=1 python bench.py --workload c3 --no-cpu-baseline > "$OUT/c3_layer_by_layer_bench.json" 2>/dev/null
-MNF_NO_RUN_FUSION=1 python bench.py --workload c4 --no-cpu-baseline > "$OUT/c4_layer_by_layer_bench.json" 2>/dev/null
-MNF_FP32_MFMA=1 python bench.py --no-cpu-baseline > "$OUT/fp32_mfma/c2_bench_same_build.json" 2>/dev/null
-MNF_FP32_MFMA=1 MNF_NO_RUN_FUSION=1 python bench.py --no-cpu-baseline > "$OUT/fp32_mfma/c2_layer_by_layer_bench_same_build.json" 2>/dev/null
-MNF_FP32_MFMA=1 python bench.py --workload c5 --no-cpu-baseline > "$OUT/fp32_mfma/c5_bench_same_build.json" 2>/dev/null
-python tools/bench_backward.py > "$OUT/training_step.txt" 2>&1
-python tools/bench_c1.py > "$OUT/c1_latency.txt" 2>&1
-python tools/bench_c5.py 2>/dev/null | grep MNFLinear > "$OUT/c5_sample_z.txt"
-python tools/mnf_lenet_harness.py 2>/dev/null | grep MNF-LeNet > "$OUT/c5_mnf_lenet_forward.txt"
-for w in c2 c3 c5; do
-  tools/profile_bench.sh r1_$w --workload $w > /dev/null 2>&1
-  cp "$REPO/gpurun_out/prof_r1_$w/summary.txt" "$OUT/${w}_rocprofv3_summary.txt"
-  cp "$REPO"/gpurun_out/prof_r1_$w/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv"
+WL=${*:-c2 c3 c4 c5 c5b c2t c3t c5t}
+declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
+                  [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
+                  [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_shared_kernel<50, true, false" \
+                  [c3t]="nsf_bwd" [c5b]="rnvp_split_kernel<50" )
+for w in $WL; do
+  extra=""; [ "$w" = c2 ] && extra="--no-secondary"
+  timeout 400 python bench.py --workload $w $extra > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
+  P=$REPO/gpurun_out/prof_${ROUND}_$w
+  mkdir -p "$P"
+  ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --workload $w"
+  [ "$w" = c5t ] && ARGS="--steps 6 --warmup 2 --no-cpu-baseline --workload $w"
+  [ "$w" = c3t ] && ARGS="--steps 6 --warmup 2 --no-cpu-baseline --workload $w"
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -- python3 "$REPO/bench.py" $ARGS > "$P/trace.log" 2>&1
+    timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_fetch.log" 2>&1
+    timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_write.log" 2>&1
+    if true; then
+      timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$P/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq.log" 2>&1
+      timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d "$P/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq2.log" 2>&1
+    fi )
+  python3 tools/summarize_prof.py "$P" > "$OUT/${w}_rocprofv3_summary.txt" 2>&1
+  cp "$P"/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null || cp "$P"/trace/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null
+  python3 tools/make_traffic_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_pmc_traffic.json" > /dev/null 2>&1
+  python3 tools/make_valu_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" > /dev/null 2>&1
 done
-python tools/make_traffic_json.py gpurun_out/prof_r1_c2 c2 "ahf_split_stack_kernel<32, 24, true" "$OUT/c2_pmc_traffic.json" > /dev/null
-python tools/make_traffic_json.py gpurun_out/prof_r1_c5 c5 "rnvp_split_kernel<50, true" "$OUT/c5_pmc_traffic.json" > /dev/null
-python tools/make_traffic_json.py gpurun_out/prof_r1_c3 c3 "nsf_mfma_kernel<16, 8, 8, true, 2, true" "$OUT/c3_pmc_traffic.json" > /dev/null
 ls -la "$OUT"
-for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', round(d['value']/1e6,1), 'M/s', round(d['ms_per_step'],3), 'ms', r['bound'], round(r['frac'],3), round(r['avg_kernel_us'],1), 'us', r.get('traffic'))"; done
+for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python3 -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', d['value'], d['unit'], d['ms_per_step'], 'ms', r['bound'], r['frac'], r['avg_kernel_us'], 'us', r.get('traffic'))"; done
+for f in "$OUT"/*_pmc_traffic.json; do echo "$f"; grep -E "FETCH|WRITE|traffic_bytes" "$f"; done

@@ -79,9 +79,12 @@ struct RnvpBwdShape {
   using H = HandoverShape<YT>;
   static constexpr int TILE_WORDS = H::TILE_WORDS;
   static constexpr int Y_OP = H::A_OP, G_OP = H::B_OP, Y_TR = H::A_TR, G_TR = H::B_TR;
-  // A's LDS window: a GEMM-1 chunk (KC K-steps) or one second-sweep tile (forward GEMM-2 tile + its A3 operands)
-  static constexpr int CHUNK_WORDS =
-      S::KC * S::KS1_WORDS > S::TILE2_WORDS + A3_TILE_WORDS ? S::KC * S::KS1_WORDS : S::TILE2_WORDS + A3_TILE_WORDS;
+  // A's LDS window: a GEMM-1 chunk (KC K-steps) or MT second-sweep tiles (forward GEMM-2 tile + its A3 operands each)
+  // followed by their (bt, bs) biases (32 words per tile; the window is padded to whole 1 KB pieces)
+  static constexpr int MT = 2;
+  static constexpr int TILE_OPS_WORDS = S::TILE2_WORDS + A3_TILE_WORDS;
+  static constexpr int SWEEP2_WORDS = (MT * TILE_OPS_WORDS + MT * 32 + 255) / 256 * 256;
+  static constexpr int CHUNK_WORDS = S::KC * S::KS1_WORDS > SWEEP2_WORDS ? S::KC * S::KS1_WORDS : SWEEP2_WORDS;
   static constexpr int STAGE_U4 = (CHUNK_WORDS / 4 + kRnvpWaves * 64 - 1) / (kRnvpWaves * 64);
 };
 
@@ -112,7 +115,8 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   const int j = lane & 15, q = lane >> 4;
   const int G = d / 16;
   const int n_ks1 = (G + 1) / 2;
-  const int nc1 = (n_ks1 + KC - 1) / KC, nc = nc1 + G;  // second sweep: one 16-dim tile per chunk
+  constexpr int MT = B::MT;
+  const int nc1 = (n_ks1 + KC - 1) / KC, nc = nc1 + (G + MT - 1) / MT;  // second sweep: MT 16-dim tiles per chunk
   const float* bias2 = reinterpret_cast<const float*>(simage + S::split_words(d));
   const float* bias_y = bias2 + (int64_t)G * 32;
 
@@ -145,26 +149,34 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   // others at the chunk's one barrier.  (Round 3 staged chunk c + 1 through registers during chunk c and wrote it to LDS
   // at the chunk's end: with one workgroup per CU two thirds of the wave cycles went to waiting there.)
   constexpr int N_PIECES = B::CHUNK_WORDS / 256, N_DMA = (N_PIECES + kRnvpWaves - 1) / kRnvpWaves;
-  [[maybe_unused]] constexpr int T2_PIECES = S::TILE2_WORDS / 256;
-  static_assert(B::CHUNK_WORDS % 256 == 0 && S::TILE2_WORDS % 256 == 0, "whole 1 KB pieces");
+  [[maybe_unused]] constexpr int T2_PIECES = S::TILE2_WORDS / 256, TILE_PIECES = B::TILE_OPS_WORDS / 256;
+  static_assert(B::CHUNK_WORDS % 256 == 0 && S::TILE2_WORDS % 256 == 0 && B::TILE_OPS_WORDS % 256 == 0, "whole 1 KB pieces");
   auto request_operands = [&](int c) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in hipcc's host pass over this file)
     const int cc = c < nc ? c : nc - 1;  // (past the end: the last chunk once more, into the buffer it already fills)
     uint32_t* dst = lds0 + (cc % kBwdRing) * B::CHUNK_WORDS;
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) {
-      const int piece = min(i * kRnvpWaves + wave, N_PIECES - 1);  // wave-uniform; a piece past the end repeats the last
+      // wave-uniform; a piece past the chunk's operands repeats the last one (same bytes to the same place)
+      const int piece = min(i * kRnvpWaves + wave, (cc < nc1 ? KC * S::KS1_WORDS / 256 : MT * TILE_PIECES) - 1);
       int64_t word;
       bool from_b = false;
       if (cc < nc1) {
         word = (int64_t)cc * KC * S::KS1_WORDS + piece * 256;  // (a short last chunk reads on into part 2: unused)
       } else {
-        const int m = cc - nc1;
-        from_b = piece >= T2_PIECES;
-        word = from_b ? (int64_t)m * B::A3_TILE_WORDS + (piece - T2_PIECES) * 256
-                      : S::part1_words(d) + (int64_t)m * S::TILE2_WORDS + piece * 256;
+        // piece -> (tile of the chunk, piece of the tile); a tile past the end (odd G) repeats the last one: not computed
+        const int mi = piece / TILE_PIECES, pt = piece - mi * TILE_PIECES;
+        const int m = min(MT * (cc - nc1) + mi, G - 1);
+        from_b = pt >= T2_PIECES;
+        word = from_b ? (int64_t)m * B::A3_TILE_WORDS + (pt - T2_PIECES) * 256
+                      : S::part1_words(d) + (int64_t)m * S::TILE2_WORDS + pt * 256;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(from_b ? b_rsrc : s_rsrc, (lds_void_ptr_a)(dst + piece * 256), 16, lane * 16,
+                                               (int)(word * 4), 0, 0);
+    }
+    if (cc >= nc1) {  // the chunk's (bt, bs) biases: 64 words behind the operands, 4 bytes per lane (every wave: same bytes)
+      const int64_t word = S::split_words(d) + (int64_t)MT * (cc - nc1) * 32;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void_ptr_a)(dst + MT * B::TILE_OPS_WORDS), 4, lane * 4,
                                                (int)(word * 4), 0, 0);
     }
 #endif
@@ -257,64 +269,79 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
     }
   }
   // ---- y complete: GEMM-2 operands
-  constexpr int D2 = SEEDED ? 2 : 1;
-  f32x4 z2[D2], g2[D2], m2[D2], bt2[D2], bs2[D2];  // rows and the tile's (bt, bs), requested D2 chunks ahead
+  // rows of a chunk's MT tiles, requested two chunks ahead into the register set of the chunk's parity (the in-kernel
+  // mask is hashed where it is used; (bt, bs) come out of the LDS window)
+  f32x4 z2[2][MT], g2[2][MT], m2[2][MT];
+  auto tile_of = [&](int c, int mi) { return min(MT * ((c < nc ? c : nc - 1) - nc1) + mi, G - 1); };
   auto request_rows2 = [&](int c, int u) {
-    const int cc = c < nc ? c : nc - 1;
-    z2[u] = z4(cc - nc1);
-    g2[u] = g4(cc - nc1);
-    m2[u] = mask4(cc - nc1);
-    bt2[u] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)(cc - nc1) * 32 + 4 * q);
-    bs2[u] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)(cc - nc1) * 32 + 16 + 4 * q);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      z2[u][mi] = z4(tile_of(c, mi));
+      g2[u][mi] = g4(tile_of(c, mi));
+      if (!SEEDED) m2[u][mi] = mask4(tile_of(c, mi));
+    }
   };
 #pragma unroll
-  for (int u = 0; u < D2; ++u) request_rows2(nc1 + u, u);
+  for (int u = 0; u < 2; ++u) request_rows2(nc1 + u, (nc1 + u) & 1);
   u32x2 yh[YT], yl[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
 
-  // ---- sweep 2: per 16 dims  s, t -> gate -> g_t, g_s -> g_y += [Wt^T | Ws^T] [g_t; g_s]
+  // ---- sweep 2: per 16 dims  s, t -> gate -> g_t, g_s -> g_y += [Wt^T | Ws^T] [g_t; g_s]; MT tiles per chunk (one
+  // barrier per 32 dims, and two independent tiles for the scheduler to overlap)
   f32x4 gm[YT], gc[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) gm[m] = gc[m] = zero4;
-  for (int c0 = nc1; c0 < nc; c0 += D2) {
+  for (int c0 = nc1 & ~1; c0 < nc; c0 += 2) {
 #pragma unroll
-    for (int u = 0; u < D2; ++u) {
+    for (int u = 0; u < 2; ++u) {  // (u = the chunk's parity: compile-time register sets)
       const int c = c0 + u;
-      if (c < nc) {
+      if (c >= nc1 && c < nc) {
         request_operands(c + 2);
-        const f32x4 bt = bt2[u], bs = bs2[u];
         const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
-        const f16x8* T8 = reinterpret_cast<const f16x8*>(buf) + lane;
-        const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + S::TILE2_WORDS) + lane;
-        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+        const float* bias = reinterpret_cast<const float*>(buf + MT * B::TILE_OPS_WORDS);
 #pragma unroll
-        for (int ks = 0; ks < NKS2; ++ks) {
-          const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
-          const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
-          split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
-          split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
+        for (int mi = 0; mi < MT; ++mi) {
+          const int m = MT * (c - nc1) + mi;
+          // (one tile at a time: left free, the scheduler interleaves the chunk's tiles and spills ~90 registers)
+          __builtin_amdgcn_sched_barrier(0);
+          if (m < G) {  // (wave-uniform: an odd number of tiles leaves the last chunk's second tile empty)
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 4 * q);
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 16 + 4 * q);
+            const f16x8* T8 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS) + lane;
+            const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS + S::TILE2_WORDS) + lane;
+            f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+#pragma unroll
+            for (int ks = 0; ks < NKS2; ++ks) {
+              const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+              const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+              split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
+              split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
+            }
+            const f32x4 t4 = tc * kSplitInvScale + tm + bt;
+            const f32x4 s4 = sc * kSplitInvScale + sm + bs;
+            const f32x4 mk = SEEDED ? mask4(m) : m2[u][mi];
+            f32x4 gt, gs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float zz = z2[u][mi][r], mm = mk[r], nm = 1.f - mm;
+              mx = __builtin_fmaxf(mx, __builtin_fabsf(mm * zz));  // (launch B-n splits m z: sweep 1's guard when it is skipped)
+              const float GG = live ? g2[u][mi][r] * gscale : 0.f;
+              const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+              const float omg = 1.f - gate;
+              gt[r] = GG * omg;
+              gs[r] = (GG * (nm * zz - t4[r]) * gate + glr * nm) * omg;
+            }
+            u32x2 th, tl, sh, sl;
+            split_tile(gt, th, tl, mx);
+            split_tile(gs, sh, sl, mx);
+            const f16x8 bh = pair_operand(th, sh), bl = pair_operand(tl, sl);
+#pragma unroll
+            for (int m2i = 0; m2i < YT; ++m2i)
+              split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
+          }
         }
-        const f32x4 t4 = tc * kSplitInvScale + tm + bt;
-        const f32x4 s4 = sc * kSplitInvScale + sm + bs;
-        f32x4 gt, gs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float zz = z2[u][r], mm = m2[u][r], nm = 1.f - mm;
-          mx = __builtin_fmaxf(mx, __builtin_fabsf(mm * zz));  // (launch B-n splits m z: sweep 1's guard when it is skipped)
-          const float GG = live ? g2[u][r] * gscale : 0.f;
-          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
-          const float omg = 1.f - gate;
-          gt[r] = GG * omg;
-          gs[r] = (GG * (nm * zz - t4[r]) * gate + glr * nm) * omg;
-        }
-        u32x2 th, tl, sh, sl;
-        split_tile(gt, th, tl, mx);
-        split_tile(gs, sh, sl, mx);
-        const f16x8 bh = pair_operand(th, sh), bl = pair_operand(tl, sl);
-#pragma unroll
-        for (int m2i = 0; m2i < YT; ++m2i) split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
-        request_rows2(c + D2, u);
+        request_rows2(c + 2, u);
         chunk_barrier(false);
       }
     }
@@ -349,7 +376,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
                   int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[kBwdRing][B::CHUNK_WORDS];
+  extern __shared__ __attribute__((aligned(16))) uint32_t a_lds[];  // kBwdRing x RnvpBwdShape::CHUNK_WORDS (101 KB at 64 units)
   const int dm = RAG ? dm_ragged : d;
 #if defined(__HIP_DEVICE_COMPILE__)
   const BufRsrc s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -368,13 +395,13 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
   for (int m = 0; m < S::YT; ++m) bn_acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int n_groups = (int)((rows + kBwdGroupRows - 1) / kBwdGroupRows);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x)
-    rnvp_bwd_group_a<HN, SEEDED, RAG>(lds[0], s_rsrc, b_rsrc, grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
+    rnvp_bwd_group_a<HN, SEEDED, RAG>(a_lds, s_rsrc, b_rsrc, grp, z, mask, gx, gld, simage, bimage, side, flags, list, gscale,
                                       weights_ok, bn_acc, rows, d, seed, dm, vec_ok != 0, y_in);
   // dbn: sum over the wave's rows (the 16 lanes j of a q), over the workgroup's waves in LDS, then ONE atomic per unit
   // per workgroup (atomics on a few dozen addresses serialise at the memory side: one per unit per WAVE cost 0.16 ms)
   if (grad_flat && !(kBwdAbl & 64)) {
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-    float* bsum = reinterpret_cast<float*>(&lds[0][0]);
+    float* bsum = reinterpret_cast<float*>(a_lds);
     __syncthreads();  // the operand window is no longer read
     if (threadIdx.x < 16 * S::YT) bsum[threadIdx.x] = 0.f;
     __syncthreads();
@@ -1312,13 +1339,25 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   int32_t* flags = list + 1 + n_groups;
   uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + bwd_header_bytes(rows));
   static DeviceMemo memo_a, memo_b;
-  const int resident_a = memo_a.get(
-      [](int dev) { return resident_by_occupancy(rnvp_bwd_a_kernel<HN, SEEDED, RAG>, kRnvpWaves * 64, dev, 1); });
+  constexpr int a_lds_bytes = kBwdRing * B::CHUNK_WORDS * 4;
+  void (*const a_kernel)(const float*, const float*, const float*, const float*, const uint32_t*, const uint32_t*, uint32_t*,
+                         int32_t*, int32_t*, const float*, float*, int64_t, int, int, int, uint64_t, int, int64_t,
+                         const float*) = rnvp_bwd_a_kernel<HN, SEEDED, RAG>;
+  const int resident_a = memo_a.get([a_kernel](int dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            a_lds_bytes) != hipSuccess)
+      return -1;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, a_kernel, kRnvpWaves * 64, a_lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    return per_cu * device_cus(dev);
+  });
+  if (resident_a < 0) return MNF_ERR_UNSUPPORTED;
   const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
   if (phases & 1) {
   if (int rc = zero_word_async(list, stream)) return rc;
-  hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), 0, stream, z,
+  hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), a_lds_bytes, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail,
                      y_in);
   if (int rc = check_launch()) return rc;
