@@ -81,7 +81,7 @@ struct RnvpBwdShape {
   static constexpr int Y_OP = H::A_OP, G_OP = H::B_OP, Y_TR = H::A_TR, G_TR = H::B_TR;
   // A's LDS window: a GEMM-1 chunk (KC K-steps) or MT second-sweep tiles (forward GEMM-2 tile + its A3 operands each)
   // followed by their (bt, bs) biases (32 words per tile; the window is padded to whole 1 KB pieces)
-  static constexpr int MT = 2;
+  static constexpr int MT = 2;  // (three tiles per chunk: 967 us against 817, and the extra row registers spill)
   static constexpr int TILE_OPS_WORDS = S::TILE2_WORDS + A3_TILE_WORDS;
   static constexpr int SWEEP2_WORDS = (MT * TILE_OPS_WORDS + MT * 32 + 255) / 256 * 256;
   static constexpr int CHUNK_WORDS = S::KC * S::KS1_WORDS > SWEEP2_WORDS ? S::KC * S::KS1_WORDS : SWEEP2_WORDS;
