@@ -297,7 +297,11 @@ struct NrArgs {
 // compiler from hoisting all 2 (3K-1) reads (184 registers) to the top.  f(k, weights 0..3, weights 4..7, bias).
 template <int P, bool BIAS, typename F>
 __device__ __forceinline__ void w4_stream(const float* w4, const float* b4, F&& f) {
-  constexpr int GS = 4, NG = (P + GS - 1) / GS;
+  // (groups of 2: 1,752 us per launch against 1,800 with groups of 4, and no spills.  Round 4 also tried the two dot
+  // products over the 8 units as v_pk_fma_f32 on adjacent weight pairs -- 490 packed instead of 1,053 plain fma in the
+  // kernel -- and measured it SLOWER, 1,830 - 1,950 us with and without spills: on gfx950 a v_pk_fma_f32 costs more
+  // issue time than the two v_fma_f32 it replaces.)
+  constexpr int GS = 2, NG = (P + GS - 1) / GS;
   f32x4 wa[2][GS], wb[2][GS];
   float bs[2][GS];
   auto load = [&](auto g) {
