@@ -470,7 +470,7 @@ def main_train(args, rank, world, device, dim, rows, desc) -> None:
                                      "delta chain, weight gradients; 9 launches per step)",
                            "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
                            "launches_timed": len(kern_ms), "launches_per_step": len(model.flows),
-                           "note": "issue / latency bound at one wave per SIMD (DESIGN.md 3.6); the HBM figures say how "
+                           "note": "issue / latency bound at one wave per SIMD (DESIGN.md 3.5); the HBM figures say how "
                                    "far the kernel is from the traffic it has to move"}
     else:
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
@@ -600,7 +600,7 @@ def main_train_c5(args, rank, world, device, dim, rows, desc) -> None:
                            "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
                            "launches_timed": len(kern_ms), "launches_per_step": 2,
                            "note": "z and grad_x in, grad_z out; launch A of the same pass reads z twice and grad_x once "
-                                   "more (DESIGN.md 3.6)"}
+                                   "more (DESIGN.md 3.5)"}
     if not args.no_cpu_baseline:
         # the oracle's training step on the host (sample_z + MNFLinear.forward restated, torch.autograd backward) on a
         # bounded slice, with the masks and both noise draws materialised so that the GPU leg below sees the same ones
@@ -791,7 +791,7 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
                      "launches_timed": len(kern_ms), "launches_per_step": 3,
                      "note": "vector-issue / latency bound by construction (about 3,400 vector instructions per 4 rows "
                              "at one wave per SIMD; SQ counters in profiles/r2/c3_train_sq_counters.txt): the HBM "
-                             "fraction is low because the kernel's floor is arithmetic, not traffic (DESIGN.md 3.6)"},
+                             "fraction is low because the kernel's floor is arithmetic, not traffic (DESIGN.md 3.5)"},
     }
     if not args.no_cpu_baseline:
         from oracle import flow_oracle as O

@@ -1,5 +1,5 @@
 """Soak: the captured MNF-LeNet training step replayed thousands of times -- no fault, finite parameters, a replay time
-that does not drift (the two hipGraph findings of DESIGN.md 3.6 both showed up only after tens to hundreds of replays).
+that does not drift (the two hipGraph findings of profiles/r3/DESIGN_round3.md 3.6 both showed up only after tens to hundreds of replays).
 `python3 tools/soak_lenet_graph.py [replays]`"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
