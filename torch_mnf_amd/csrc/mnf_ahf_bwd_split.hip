@@ -10,7 +10,8 @@
 //   2. forms the output deltas from grad_y / grad_ld and the transform (as the fp32 kernel does);
 //   3. back-propagates through the TRANSPOSED weights, a second operand image of the same form: the accumulator
 //      layout of one product is the B-operand layout of the next, so the delta chain needs no data movement either;
-//   4. accumulates dW_l += delta_l^T a_{l-1} with the 16 rows on the K axis of v_mfma_f32_16x16x16_f16.  That product
+//   4. accumulates dW_l += delta_l^T a_{l-1} with the 16 rows on the K axis (as K = 32 products whose two K halves carry
+//      the head and the residual of delta: acc_outer32).  That product
 //      wants both operands with ROWS along a lane's registers, the chain has UNITS there: a tile is transposed by
 //      one more MFMA against the identity matrix (exact: every product is x * 1), the hi and the lo part separately;
 //      the lo part is multiplied by 2^-11 on the way (identity entries 2^-11), so the three products
@@ -125,22 +126,23 @@ struct DwOrder {
 // A vector instruction's result needs 2 wait states before an MFMA may read it; hipcc inserts them for the MFMAs it
 // generates but cannot see into these, and it does place operand-producing instructions (a v_cvt_pk of a transpose,
 // the v_mov that materialises the ones) directly in front: every statement therefore starts with its own s_nop 1.
-// One weight-gradient tile: acc += dh ah + dh al + dl ah
+// One weight-gradient tile: acc += dh ah + dl ah + dh al + dl al as TWO K = 32 products (round 4; three K = 16 ones
+// before -- v_mfma_f32_16x16x16_f16 occupies the matrix pipe as long as v_mfma_f32_16x16x32_f16 does): a K = 32
+// product sums its two K halves, so A = [dh | dl] against B = [ah | ah] gives (dh + dl) ah and against [al | al]
+// (dh + dl) al -- the lo x lo term the three-product form drops comes along for free.
 template <int T>
-__device__ __forceinline__ void acc_outer16(const f16x4& dh, const f16x4& dl, const f16x4& ah, const f16x4& al) {
+__device__ __forceinline__ void acc_outer32(const f16x8& d_hl, const f16x8& a_hh, const f16x8& a_ll) {
   asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_16x16x16_f16 a[%0:%1], %2, %4, a[%0:%1]\n\t"
-               "v_mfma_f32_16x16x16_f16 a[%0:%1], %2, %5, a[%0:%1]\n\t"
-               "v_mfma_f32_16x16x16_f16 a[%0:%1], %3, %4, a[%0:%1]" ::"n"(kTopAgprBase + 4 * T),
-               "n"(kTopAgprBase + 4 * T + 3), "v"(dh), "v"(dl), "v"(ah), "v"(al));
+               "v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %3, a[%0:%1]\n\t"
+               "v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %4, a[%0:%1]" ::"n"(kTopAgprBase + 4 * T),
+               "n"(kTopAgprBase + 4 * T + 3), "v"(d_hl), "v"(a_hh), "v"(a_ll));
 }
-// One bias-gradient tile: acc += (dh + dl) ones
+// One bias-gradient tile: acc += (dh + dl) ones: one K = 32 product against [ones | ones]
 template <int T>
-__device__ __forceinline__ void acc_bias16(const f16x4& dh, const f16x4& dl, const f16x4& ones) {
+__device__ __forceinline__ void acc_bias32(const f16x8& d_hl, const f16x8& ones8) {
   asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_16x16x16_f16 a[%0:%1], %2, %4, a[%0:%1]\n\t"
-               "v_mfma_f32_16x16x16_f16 a[%0:%1], %3, %4, a[%0:%1]" ::"n"(kTopAgprBase + 4 * T),
-               "n"(kTopAgprBase + 4 * T + 3), "v"(dh), "v"(dl), "v"(ones));
+               "v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(kTopAgprBase + 4 * T),
+               "n"(kTopAgprBase + 4 * T + 3), "v"(d_hl), "v"(ones8));
 }
 template <int T>
 __device__ __forceinline__ void acc_zero() {
@@ -508,34 +510,46 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       continue;
     }
     // ------------------------------------------------------------------ weight gradients: rows on the K axis
-    // T(v): the tile with rows along the registers: lane (unit = j, q) holds rows 4 q .. 4 q + 3
+    // T(v): the tile with rows along the registers: lane (unit = j, q) holds rows 4 q .. 4 q + 3, head and residual
     auto transpose = [&](const u32x2& hi, const u32x2& lo, f16x4& th, f16x4& tl) {
       const f32x4 o = mfma_x16(as_f16x4(hi), ident, zero4);
       const f32x4 ol = mfma_x16(as_f16x4(lo), ident_lo, zero4);  // (lo 2^-11: the residual itself)
       th = __builtin_convertvector(o, f16x4);
       tl = __builtin_convertvector(ol, f16x4);
     };
-    // one weight-gradient tile += delta^T a (three split products), one bias-gradient tile += delta^T ones
-    auto outer = [&](auto t, const f16x4& dth, const f16x4& dtl, const f16x4& ath, const f16x4& atl) {
-      acc_outer16<decltype(t)::value>(dth, dtl, ath, atl);
+    // a delta tile as the A operand [head | residual] of the K = 32 products, an activation tile as the two B operands
+    // [head | head], [residual | residual]
+    auto delta_op = [&](const u32x2& hi, const u32x2& lo) -> f16x8 {
+      f16x4 th, tl;
+      transpose(hi, lo, th, tl);
+      return __builtin_shufflevector(th, tl, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    auto bias = [&](auto t, const f16x4& dth, const f16x4& dtl) {
-      acc_bias16<F::DW_TILES + decltype(t)::value>(dth, dtl, ones);
+    auto act_ops = [&](const u32x2& hi, const u32x2& lo, f16x8& hh_, f16x8& ll_) {
+      f16x4 th, tl;
+      transpose(hi, lo, th, tl);
+      hh_ = __builtin_shufflevector(th, th, 0, 1, 2, 3, 4, 5, 6, 7);
+      ll_ = __builtin_shufflevector(tl, tl, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+    const f16x8 ones8 = __builtin_shufflevector(ones, ones, 0, 1, 2, 3, 4, 5, 6, 7);
+    // one weight-gradient tile += delta^T a (all four split products), one bias-gradient tile += delta^T ones
+    auto outer = [&](auto t, const f16x8& d_hl, const f16x8& a_hh, const f16x8& a_ll) {
+      acc_outer32<decltype(t)::value>(d_hl, a_hh, a_ll);
+    };
+    auto bias = [&](auto t, const f16x8& d_hl) { acc_bias32<F::DW_TILES + decltype(t)::value>(d_hl, ones8); };
     {
       // output layer: delta 4 (2 G tiles) x h3 (NT tiles)
-      f16x4 ath[NT], atl[NT], dth[2 * G > NT ? 2 * G : NT], dtl[2 * G > NT ? 2 * G : NT];
+      f16x8 a_hh[NT], a_ll[NT], d_hl[2 * G > NT ? 2 * G : NT];
 #pragma unroll
-      for (int m = 0; m < NT; ++m) transpose(hh[2][m], hl[2][m], ath[m], atl[m]);
+      for (int m = 0; m < NT; ++m) act_ops(hh[2][m], hl[2][m], a_hh[m], a_ll[m]);
 #pragma unroll
-      for (int c = 0; c < 2 * G; ++c) transpose(d4h[c], d4l[c], dth[c], dtl[c]);
+      for (int c = 0; c < 2 * G; ++c) d_hl[c] = delta_op(d4h[c], d4l[c]);
       bs_static_for<2 * G>([&](auto mo_c) {
         constexpr int mo = decltype(mo_c)::value;
-        bias(integral_constant<int, DB_OUT + mo>{}, dth[mo], dtl[mo]);
+        bias(integral_constant<int, DB_OUT + mo>{}, d_hl[mo]);
         bs_static_for<NT>([&](auto mi_c) {
           constexpr int mi = decltype(mi_c)::value;
           if constexpr (O::out_used(mo, mi))
-            outer(integral_constant<int, DW_OUT + O::out_rank(mo, mi)>{}, dth[mo], dtl[mo], ath[mi], atl[mi]);
+            outer(integral_constant<int, DW_OUT + O::out_rank(mo, mi)>{}, d_hl[mo], a_hh[mi], a_ll[mi]);
         });
       });
       // hidden layer W_2 (h2 -> h3): delta 3 x h2;  W_1 (h1 -> h2): delta 2 x h1
@@ -543,32 +557,32 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
         constexpr int l = 2 - decltype(lc)::value;
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
-          transpose(dh[l][m], dl_[l][m], dth[m], dtl[m]);
-          transpose(hh[l - 1][m], hl[l - 1][m], ath[m], atl[m]);
+          d_hl[m] = delta_op(dh[l][m], dl_[l][m]);
+          act_ops(hh[l - 1][m], hl[l - 1][m], a_hh[m], a_ll[m]);
         }
-          bs_static_for<NT>([&](auto mo_c) {
+        bs_static_for<NT>([&](auto mo_c) {
           constexpr int mo = decltype(mo_c)::value;
-          bias(integral_constant<int, (l == 2 ? DB_H2 : DB_H1) + mo>{}, dth[mo], dtl[mo]);
+          bias(integral_constant<int, (l == 2 ? DB_H2 : DB_H1) + mo>{}, d_hl[mo]);
           bs_static_for<NT>([&](auto mi_c) {
             constexpr int mi = decltype(mi_c)::value;
             if constexpr (F::needs(mo, mi))
-              outer(integral_constant<int, (l == 2 ? DW_H2 : DW_H1) + O::hid_rank(mo, mi)>{}, dth[mo], dtl[mo], ath[mi],
-                    atl[mi]);
+              outer(integral_constant<int, (l == 2 ? DW_H2 : DW_H1) + O::hid_rank(mo, mi)>{}, d_hl[mo], a_hh[mi],
+                    a_ll[mi]);
           });
         });
-        });
+      });
       // layer 1: delta 1 x x0
-      f16x4 xth[G], xtl[G];
+      f16x8 x_hh[G], x_ll[G];
 #pragma unroll
-      for (int m = 0; m < NT; ++m) transpose(dh[0][m], dl_[0][m], dth[m], dtl[m]);
+      for (int m = 0; m < NT; ++m) d_hl[m] = delta_op(dh[0][m], dl_[0][m]);
 #pragma unroll
-      for (int g = 0; g < G; ++g) transpose(xh[g], xl[g], xth[g], xtl[g]);
+      for (int g = 0; g < G; ++g) act_ops(xh[g], xl[g], x_hh[g], x_ll[g]);
       bs_static_for<NT>([&](auto mo_c) {
         constexpr int mo = decltype(mo_c)::value;
-        bias(integral_constant<int, DB_L1 + mo>{}, dth[mo], dtl[mo]);
+        bias(integral_constant<int, DB_L1 + mo>{}, d_hl[mo]);
         bs_static_for<G>([&](auto mi_c) {
           constexpr int mi = decltype(mi_c)::value;
-          outer(integral_constant<int, DW_L1 + mo * G + mi>{}, dth[mo], dtl[mo], xth[mi], xtl[mi]);
+          outer(integral_constant<int, DW_L1 + mo * G + mi>{}, d_hl[mo], x_hh[mi], x_ll[mi]);
         });
       });
     }
