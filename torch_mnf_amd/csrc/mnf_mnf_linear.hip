@@ -187,7 +187,10 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
             }
           }
           hand_over(lds[(c + 1) & 1], n4_next);
-          __syncthreads();
+          // (not __syncthreads(): its release fence is `s_waitcnt vmcnt(0)`, which would make every chunk wait for the
+          // row loads of the D chunks ahead -- the whole point of the ring.  What the barrier has to order is LDS only:
+          // this wave's reads of the current buffer and its writes to the next one.)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
       }
     }

@@ -220,7 +220,8 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
           }
         }
         hand_over((c & 1) ? lds0 : lds1, n4_next);
-        if (c < nc1 - 1) __syncthreads();
+        // (LDS-only barrier: __syncthreads() would also wait -- vmcnt(0) -- for the row loads requested chunks ahead)
+        if (c < nc1 - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
   }
@@ -321,7 +322,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
         }
         request_rows2(c + D2, u);
         hand_over((c & 1) ? lds0 : lds1, n4_next);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS-only, as above: the row stores stay in flight)
       }
     }
   }

@@ -246,8 +246,11 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     constexpr int e = decltype(ec)::value;
     if (kResAbl != 11 && kResAbl != 13) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::dma_wait_count(e)) : "memory");
   };
+  // (inline asm, not __syncthreads(): that one's release fence is `s_waitcnt vmcnt(0)` -- every chunk would wait for
+  // all of the wave's outstanding row loads and stores, and the counted waits of landed() would count for nothing.
+  // What the barrier orders is LDS: this wave's operand reads of the chunk, done, before anyone's DMA refills it.)
   auto chunk_barrier = [] {
-    if (kResAbl != 11 && kResAbl != 13) __syncthreads();
+    if (kResAbl != 11 && kResAbl != 13) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
   auto mfma3 = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
