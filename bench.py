@@ -774,6 +774,7 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     avg_s = sum(kern_ms) / len(kern_ms) / 1e3
     algo_bytes = (12 * dim + 4) * rows
     gbs = algo_bytes / avg_s / 1e9
+    traffic, traffic_source = pmc_traffic("c3t")
     out = {
         "metric": f"samples/s, {desc}", "value": rows * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -785,12 +786,12 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
         "distributed": dist_info(1, "nccl", [elapsed], args.steps),
         "loss_first_step": first_loss, "loss_last_step": float(loss_box[0]),
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                     "traffic": None, "traffic_source": None,
-                     "kernel": "nsf_bwd_rows_kernel<8,inverse> (one NSF_CL layer's gradients per launch; 3 launches per step)",
+                     "traffic": traffic, "traffic_source": traffic_source, **physical(traffic, avg_s),
+                     "kernel": "nsf_bwd_pairs_kernel<8,inverse> (one NSF_CL layer's gradients per launch; 3 launches per step)",
                      "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
                      "launches_timed": len(kern_ms), "launches_per_step": 3,
-                     "note": "vector-issue / latency bound by construction (about 3,400 vector instructions per 4 rows "
-                             "at one wave per SIMD; SQ counters in profiles/r2/c3_train_sq_counters.txt): the HBM "
+                     "note": "vector-issue bound by construction (8.9e8 vector instructions per launch, issue 0.45 of "
+                             "capacity at two waves per SIMD: profiles/r4/c3t_valu_issue.json): the HBM "
                              "fraction is low because the kernel's floor is arithmetic, not traffic (DESIGN.md 3.5)"},
     }
     if not args.no_cpu_baseline:
