@@ -139,7 +139,7 @@ def test_bench_c3_training_step_line(amd):
     the oracle's training step as cpu_baseline, the gradients' parity against the float64 oracle."""
     line = run_bench("--workload", "c3t", "--steps", "3", "--warmup", "1", "--prime-ms", "5")
     r = line["roofline"]
-    assert line["unit"] == "samples/s" and "nsf_bwd_rows_kernel" in r["kernel"]
+    assert line["unit"] == "samples/s" and "nsf_bwd_pairs_kernel" in r["kernel"]
     assert r["launches_timed"] == 3 * 3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert line["loss_last_step"] < line["loss_first_step"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0

@@ -14,6 +14,16 @@ int check_launch();
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base);
 bool hidden_ok(int n_hidden, const int* hidden);
 
+// mnf_ahf_bwd_net.hip: the split gradient kernel with one conditioner net per wave (what mnf_affine_half_bwd_split* run
+// under MNF_AHF_BWD_SPLIT=net: measured slower than the joint kernel), behind the same C entry points
+bool bwd_net_mode();
+int bwd_net_layout(int dim, int hid, int64_t* n_split_words, int64_t* n_plain_words);
+int bwd_net_index(int dim, int hid, int32_t* idx_host);
+int64_t bwd_net_workspace(int64_t rows, int dim, int hid);
+int bwd_net_launch(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                   const void* image, int64_t rows, int dim, int hid, int parity, int inverse, const float* scale_dev,
+                   int32_t* cold_list, int cold_capacity, float* workspace, int64_t workspace_floats, hipStream_t stream);
+
 // Half width the AffineHalfFlow MFMA kernels pad a coupling half of `h` columns to (0: none).  A layer
 // whose half is narrower than its tile runs on the stack kernel's ragged variant: zero operands in the
 // padded columns, element-wise masked row accesses.
