@@ -274,7 +274,21 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     // A stage = [its operands requested from LDS] [the vector work that builds its B operands] [its MFMAs], pinned in
     // that order (sched_barrier): with one wave per SIMD nothing else covers the LDS latency, and left alone hipcc
     // sinks every ds_read to just in front of its MFMA (SQ counters: 40 % of the wave's cycles in s_waitcnt).
-    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+#ifndef MNF_BS_RFENCE
+#define MNF_BS_RFENCE 1
+#endif
+    auto fence = [] {
+      if (MNF_BS_RFENCE) __builtin_amdgcn_sched_barrier(0);
+    };
+    // the fence between a stage's vector work and the next stage's MFMAs is NOT placed (round 4): without it hipcc moves
+    // the first MFMAs of the next stage in between the vector instructions of the last tile, 308 -> 300 us per launch
+    // at 2^20 x 64 (same box; without the read fences as well 306-310)
+#ifndef MNF_BS_VFENCE
+#define MNF_BS_VFENCE 0
+#endif
+    auto fence_v = [] {
+      if (MNF_BS_VFENCE) __builtin_amdgcn_sched_barrier(0);
+    };
     constexpr int N1 = NT * KS1, NH = S::hidden_ops();
     auto read_ops = [&](auto n_tag, f16x8* ah, f16x8* al) {
       constexpr int N = decltype(n_tag)::value;
@@ -303,7 +317,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       fence();
 #pragma unroll
       for (int g = 0; g < G; ++g) split_tile(cnd[g], xh[g], xl[g], mx);
-      fence();
+      fence_v();
       f32x4 mn[NT], cr[NT];
       int i = 0;
 #pragma unroll
@@ -328,7 +342,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
         const f32x4 p = cr[m] * kSplitInvScale + mn[m];
         split_tile(__builtin_elementwise_max(p, p * kLeakySlope), hh[0][m], hl[0][m], mx);
       }
-      fence();
+      fence_v();
       // hidden layers 2 and 3; the operands of the layer after each are requested before its activation
 #pragma unroll
       for (int l = 1; l <= 2; ++l) {
@@ -357,7 +371,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
           const f32x4 p = cr[m] * kSplitInvScale + mn[m];
           split_tile(__builtin_elementwise_max(p, p * kLeakySlope), hh[l][m], hl[l][m], mx);
         }
-        fence();
+        fence_v();
       }
     }
     f32x4 st[2][G];  // raw s (net 0) and t (net 1)
@@ -416,7 +430,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     fence();                                               //  register demand peaks)
 #pragma unroll
     for (int c = 0; c < 2 * G; ++c) split_tile(d4[c], d4h[c], d4l[c], mx);
-    fence();
+    fence_v();
     f16x8 t1h[N_T1], t1l[N_T1];
     {
       f32x4 mn[NT], cr[NT];
@@ -443,7 +457,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
         for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[2][m], hl[2][m], r) ? d[r] : kLeakySlope * d[r];
         split_tile(d, dh[2][m], dl_[2][m], mx);
       }
-      fence();
+      fence_v();
 #pragma unroll
       for (int l = 2; l >= 1; --l) {  // delta_l = W_l^T delta_{l+1} .* LeakyReLU'(h_l)
 #pragma unroll
@@ -470,7 +484,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
           for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[l - 1][m], hl[l - 1][m], r) ? d[r] : kLeakySlope * d[r];
           split_tile(d, dh[l - 1][m], dl_[l - 1][m], mx);
         }
-        fence();
+        fence_v();
       }
     }
     f32x4 gx0[G];
