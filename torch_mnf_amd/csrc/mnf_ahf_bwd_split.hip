@@ -69,6 +69,20 @@ struct BwdSplitShape {
       if (S::uses(3, ks)) n += G;
     return n;
   }
+  // the last K-step hidden tile m takes part in (hidden layers / the transposed output layer): its vector work can
+  // start behind that step while the later steps' MFMAs run
+  static constexpr int last_ks(int m) {
+    int r = 0;
+    for (int ks = 0; ks < NKS; ++ks)
+      if (S::uses(S::tile_nets(m), ks)) r = ks;
+    return r;
+  }
+  static constexpr int last_p4(int m) {
+    int r = 0;
+    for (int p = 0; p < NP4; ++p)
+      if (needs4(m, p)) r = p;
+    return r;
+  }
   static constexpr int T_OPS = t4_ops() + 2 * S::hidden_ops() + t1_ops();
   static constexpr int FWD_WORDS = S::SPLIT_WORDS;
   static constexpr int T_WORDS = T_OPS * 2 * 256;
@@ -283,6 +297,9 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     // the fence between a stage's vector work and the next stage's MFMAs is NOT placed (round 4): without it hipcc moves
     // the first MFMAs of the next stage in between the vector instructions of the last tile, 308 -> 300 us per launch
     // at 2^20 x 64 (same box; without the read fences as well 306-310)
+#ifndef MNF_BS_EARLY
+#define MNF_BS_EARLY 1
+#endif
 #ifndef MNF_BS_VFENCE
 #define MNF_BS_VFENCE 0
 #endif
@@ -363,11 +380,19 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
               split_mac(ahl[i], all_[i], bh, bl, mn[m], cr[m]);
               ++i;
             }
+          // (a tile no later K-step adds to: its activation goes in front of the read fence, next to those MFMAs)
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            if (MNF_BS_EARLY && ks < NKS - 1 && B::last_ks(m) == ks) {
+              const f32x4 p = cr[m] * kSplitInvScale + mn[m];
+              split_tile(__builtin_elementwise_max(p, p * kLeakySlope), hh[l][m], hl[l][m], mx);
+            }
         }
         if (l == 1) read_ops(integral_constant<int, NH>{}, ah2, al2);  // (hidden layer 3's; the registers are free again)
         fence();
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
+          if (MNF_BS_EARLY && B::last_ks(m) < NKS - 1) continue;
           const f32x4 p = cr[m] * kSplitInvScale + mn[m];
           split_tile(__builtin_elementwise_max(p, p * kLeakySlope), hh[l][m], hl[l][m], mx);
         }
@@ -446,12 +471,21 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
             split_mac(t4h[i], t4l[i], bh, bl, mn[m], cr[m]);
             ++i;
           }
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          if (MNF_BS_EARLY && p < B::NP4 - 1 && B::last_p4(m) == p) {
+            f32x4 d = cr[m] * kSplitInvScale + mn[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[2][m], hl[2][m], r) ? d[r] : kLeakySlope * d[r];
+            split_tile(d, dh[2][m], dl_[2][m], mx);
+          }
       }
       f16x8 ah[NH], al[NH];
       read_ops(integral_constant<int, NH>{}, ah, al);
       fence();
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
+        if (MNF_BS_EARLY && B::last_p4(m) < B::NP4 - 1) continue;
         f32x4 d = cr[m] * kSplitInvScale + mn[m];
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[2][m], hl[2][m], r) ? d[r] : kLeakySlope * d[r];
@@ -472,6 +506,14 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
               split_mac(ah[i], al[i], bh, bl, mn[m], cr[m]);
               ++i;
             }
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            if (MNF_BS_EARLY && ks < NKS - 1 && B::last_ks(m) == ks) {
+              f32x4 d = cr[m] * kSplitInvScale + mn[m];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[l - 1][m], hl[l - 1][m], r) ? d[r] : kLeakySlope * d[r];
+              split_tile(d, dh[l - 1][m], dl_[l - 1][m], mx);
+            }
         }
         // the next stage's operands: the other hidden layer's (l = 2), the first layer's (l = 1)
         if (l == 2) read_ops(integral_constant<int, NH>{}, ah, al);
@@ -479,6 +521,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
         fence();
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
+          if (MNF_BS_EARLY && B::last_ks(m) < NKS - 1) continue;
           f32x4 d = cr[m] * kSplitInvScale + mn[m];
 #pragma unroll
           for (int r = 0; r < 4; ++r) d[r] = unit_active(hh[l - 1][m], hl[l - 1][m], r) ? d[r] : kLeakySlope * d[r];
