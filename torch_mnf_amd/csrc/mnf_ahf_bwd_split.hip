@@ -312,11 +312,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         ah[i] = A8[64 * (2 * op)];
-#ifdef MNF_BS_ABL_HALF_READS  // (timing experiment, results wrong: half the operand bytes out of LDS)
-        al[i] = ah[i];
-#else
         al[i] = A8[64 * (2 * op + 1)];
-#endif
         ++op;
       }
     };
