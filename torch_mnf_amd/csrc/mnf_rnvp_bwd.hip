@@ -375,7 +375,7 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
                   const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged,
                   int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in) {
   using S = RnvpSplitShape<HN>;
-  using B = RnvpBwdShape<HN>;
+  using B [[maybe_unused]] = RnvpBwdShape<HN>;  // (used by the device pass only)
   extern __shared__ __attribute__((aligned(16))) uint32_t a_lds[];  // kBwdRing x RnvpBwdShape::CHUNK_WORDS (101 KB at 64 units)
   const int dm = RAG ? dm_ragged : d;
 #if defined(__HIP_DEVICE_COMPILE__)
