@@ -190,14 +190,16 @@ def test_split_gradient_kernel_with_one_net_per_wave_passes_the_same_parity_test
     """MNF_AHF_BWD_SPLIT=net (csrc/mnf_ahf_bwd_net.hip: a pair of waves per 16-row tile, one conditioner net each --
     slower than the default kernel, kept as the measured alternative): the library reads the switch once per process,
     so the split-gradient parity tests run again in a child process with it set (every shape, both parities and
-    directions, ragged row count, against the float64 oracle and the generic kernel)."""
+    directions, ragged row count, the gradient-scale, seeded-fuzz and range-guard cases, whole runs: against the float64
+    oracle and the generic kernel)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MNF_AHF_BWD_SPLIT="net")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_autograd.py"), "-m", "gpu",
-                          "-q", "-x", "-k", "affine_half_mfma_gradient_kernel or stack", "-p", "no:cacheprovider"],
+                          "-q", "-x", "-k", "affine_half_mfma_gradient_kernel or split_gradient_kernel or affine_run", "-p",
+                          "no:cacheprovider"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
