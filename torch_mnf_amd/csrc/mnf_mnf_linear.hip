@@ -22,12 +22,26 @@
 #include "mnf_rnvp_common.h"
 #include "mnf_split.h"
 
+#include <utility>
+
 namespace mnf {
 
 constexpr int kMlWaves = 8;  // 128 rows share every staged operand chunk
 constexpr int kMlKC = 1;     // K-steps (32 input dims each) per chunk
+#ifndef MNF_ML_OPS_FIRST
+#define MNF_ML_OPS_FIRST 1
+#endif
 // chunks of row data in flight per wave: 4, but 2 at four output tiles (n_out > 48), where 64 accumulator registers plus a
 // 4-deep ring came to 256 VGPRs with 6 spilled: 582 -> 524 us at 256,000 x (800 -> 50)
+template <typename Fn, int... I>
+__device__ __forceinline__ void mnf_static_for_impl(Fn&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename Fn>
+__device__ __forceinline__ void mnf_static_for(Fn&& f) {
+  mnf_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int YT>
 constexpr int kMlRing = YT >= 4 ? 2 : 4;
 
@@ -99,9 +113,16 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
     const float* xr = x + rowc * n_in + 4 * q;
     const float* zr = z + rowc * n_in + 4 * q;
     // the four 16-dim groups chunk c works on (two per K-step); groups past the row end read as zeros
+    // (whole rows: a group past the row end -- the odd last group of a K-step, the ring's requests past the last chunk --
+    //  reads the row's last group instead, UNCONDITIONALLY: its weights in the image are zeros, and a load under a branch
+    //  makes hipcc's wait counts fall back to vmcnt(0) for every load in flight, which empties the ring at every chunk)
     auto load4 = [&](const float* p, int g) -> f32x4 {
-      if (g >= n_groups16) return zero4;
-      return RAG ? row_load4<true>(p, 16 * g, 4 * q, n_in, vec) : row_load4<false>(p, 16 * g, 4 * q, n_in, vec);
+      if constexpr (RAG) {
+        if (g >= n_groups16) return zero4;
+        return row_load4<true>(p, 16 * g, 4 * q, n_in, vec);
+      } else {
+        return row_load4<false>(p, 16 * (g < n_groups16 ? g : n_groups16 - 1), 4 * q, n_in, vec);
+      }
     };
     u32x4 st[S::STAGE_U4];
     auto request_operands = [&](int c, int& n4) {
@@ -151,49 +172,58 @@ mnf_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z, 
       vc[m] = zero4;
     }
     float mx = wmax <= kSplitWeightLimit ? 0.f : __builtin_inff();
-    for (int c0 = 0; c0 < nc; c0 += D) {
+    // one chunk: ring set u (static), chunk number c.  Whole groups of D chunks run WITHOUT a guard around the loads (see
+    // load4); the last nc % D chunks follow one by one.
+    auto chunk = [&](int c, auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      f16x8 bh[KC], bl[KC], ch[KC], cl[KC];
 #pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const int c = c0 + u;
-        if (c < nc) {
-          f16x8 bh[KC], bl[KC], ch[KC], cl[KC];
+      for (int kk = 0; kk < KC; ++kk) {
+        u32x2 ph0, pl0, ph1, pl1, sh0, sl0, sh1, sl1;
+        split_tile(xs[u][2 * kk] * zs[u][2 * kk], ph0, pl0, mx);          // x * z        (mnf_linear.py:48)
+        split_tile(xs[u][2 * kk + 1] * zs[u][2 * kk + 1], ph1, pl1, mx);
+        split_tile(xs[u][2 * kk] * xs[u][2 * kk], sh0, sl0, mx);          // x ** 2       (:53)
+        split_tile(xs[u][2 * kk + 1] * xs[u][2 * kk + 1], sh1, sl1, mx);
+        bh[kk] = pair_operand(ph0, ph1), bl[kk] = pair_operand(pl0, pl1);
+        ch[kk] = pair_operand(sh0, sh1), cl[kk] = pair_operand(sl0, sl1);
+      }
+      int n4_next = 0;
+#if MNF_ML_OPS_FIRST
+      // the next chunk's operands are requested BEFORE the rows of chunk c + D: vector-memory loads return in order, so
+      // the wait for the operands (hand_over below) must not have the row requests in front of it
+      request_operands(c + 1, n4_next);
+#endif
 #pragma unroll
-          for (int kk = 0; kk < KC; ++kk) {
-            u32x2 ph0, pl0, ph1, pl1, sh0, sl0, sh1, sl1;
-            split_tile(xs[u][2 * kk] * zs[u][2 * kk], ph0, pl0, mx);          // x * z        (mnf_linear.py:48)
-            split_tile(xs[u][2 * kk + 1] * zs[u][2 * kk + 1], ph1, pl1, mx);
-            split_tile(xs[u][2 * kk] * xs[u][2 * kk], sh0, sl0, mx);          // x ** 2       (:53)
-            split_tile(xs[u][2 * kk + 1] * xs[u][2 * kk + 1], sh1, sl1, mx);
-            bh[kk] = pair_operand(ph0, ph1), bl[kk] = pair_operand(pl0, pl1);
-            ch[kk] = pair_operand(sh0, sh1), cl[kk] = pair_operand(sl0, sl1);
+      for (int i = 0; i < 2 * KC; ++i) {  // the set is free: rows of chunk c + D (past the end: zeros, no load)
+        xs[u][i] = load4(xr, 2 * KC * (c + D) + i);
+        zs[u][i] = load4(zr, 2 * KC * (c + D) + i);
+      }
+#if !MNF_ML_OPS_FIRST
+      request_operands(c + 1, n4_next);
+#endif
+      const f16x8* A8 = reinterpret_cast<const f16x8*>(lds[c & 1]) + lane;  // + 64 * operand
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        if (c * KC + kk < n_ks) {
+#pragma unroll
+          for (int m = 0; m < YT; ++m) {
+            split_mac(A8[64 * (2 * (kk * OPS + m))], A8[64 * (2 * (kk * OPS + m) + 1)], bh[kk], bl[kk], mm[m], mc[m]);
+            split_mac(A8[64 * (2 * (kk * OPS + YT + m))], A8[64 * (2 * (kk * OPS + YT + m) + 1)], ch[kk], cl[kk],
+                      vm[m], vc[m]);
           }
-          int n4_next = 0;
-#pragma unroll
-          for (int i = 0; i < 2 * KC; ++i) {  // the set is free: rows of chunk c + D (past the end: zeros, no load)
-            xs[u][i] = load4(xr, 2 * KC * (c + D) + i);
-            zs[u][i] = load4(zr, 2 * KC * (c + D) + i);
-          }
-          request_operands(c + 1, n4_next);
-          const f16x8* A8 = reinterpret_cast<const f16x8*>(lds[c & 1]) + lane;  // + 64 * operand
-#pragma unroll
-          for (int kk = 0; kk < KC; ++kk) {
-            if (c * KC + kk < n_ks) {
-#pragma unroll
-              for (int m = 0; m < YT; ++m) {
-                split_mac(A8[64 * (2 * (kk * OPS + m))], A8[64 * (2 * (kk * OPS + m) + 1)], bh[kk], bl[kk], mm[m], mc[m]);
-                split_mac(A8[64 * (2 * (kk * OPS + YT + m))], A8[64 * (2 * (kk * OPS + YT + m) + 1)], ch[kk], cl[kk],
-                          vm[m], vc[m]);
-              }
-            }
-          }
-          hand_over(lds[(c + 1) & 1], n4_next);
-          // (not __syncthreads(): its release fence is `s_waitcnt vmcnt(0)`, which would make every chunk wait for the
-          // row loads of the D chunks ahead -- the whole point of the ring.  What the barrier has to order is LDS only:
-          // this wave's reads of the current buffer and its writes to the next one.)
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
       }
-    }
+      hand_over(lds[(c + 1) & 1], n4_next);
+      // (not __syncthreads(): its release fence is `s_waitcnt vmcnt(0)`, which would make every chunk wait for the
+      // row loads of the D chunks ahead -- the whole point of the ring.  What the barrier has to order is LDS only:
+      // this wave's reads of the current buffer and its writes to the next one.)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    const int nc_full = nc / D * D;
+    for (int c0 = 0; c0 < nc_full; c0 += D) mnf_static_for<D>([&](auto u_c) { chunk(c0 + decltype(u_c)::value, u_c); });
+    mnf_static_for<D>([&](auto u_c) {
+      if (nc_full + decltype(u_c)::value < nc) chunk(nc_full + decltype(u_c)::value, u_c);
+    });
     // range verdict for the whole 128-row group: flagged groups are redone by the fix-up kernel
     const int bad = __syncthreads_or(!(mx <= kSplitLimit) ? 1 : 0);
     if (threadIdx.x == 0) flags[grp] = bad;
