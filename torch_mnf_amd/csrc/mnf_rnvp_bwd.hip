@@ -44,6 +44,8 @@
 #include "mnf_rnvp_common.h"
 #include "mnf_split.h"
 
+#include <type_traits>
+
 namespace mnf {
 
 
@@ -111,7 +113,9 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   using B = RnvpBwdShape<HN>;
   const int dm = RAG ? dm_ragged : d;
   constexpr int YT = S::YT, NKS2 = S::NKS2, KC = S::KC;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a SCALAR: which image a piece comes from is then a scalar select of the buffer resource, not a
+  //  waterfall loop per piece)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int G = d / 16;
   const int n_ks1 = (G + 1) / 2;
@@ -125,7 +129,11 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   const int64_t rowc = live ? row : rows - 1;
   const float* zr = z + rowc * dm + 4 * q;
   const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
-  const float* gr = gx ? gx + rowc * dm + 4 * q : nullptr;
+  // (no grad_x: its loads read z instead and count for nothing -- every load of the second sweep is issued without a
+  //  branch: behind a load under a guard hipcc's wait counts fall back to vmcnt(0), which would empty the two-chunk
+  //  ring of rows and operand pieces at every chunk)
+  const float* gr = (gx ? gx : z) + rowc * dm + 4 * q;
+  const float g_on = gx ? gscale : 0.f;
   const float glr = (gld && live) ? gld[rowc] * gscale : 0.f;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32x2 zero2 = u32x2{0u, 0u};
@@ -137,10 +145,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
     return f32x4{(float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u)};
   };
   auto z4 = [&](int g) -> f32x4 { return row_load4<RAG>(zr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec); };
-  auto g4 = [&](int g) -> f32x4 {
-    if (gr == nullptr) return zero4;
-    return row_load4<RAG>(gr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec);
-  };
+  auto g4 = [&](int g) -> f32x4 { return row_load4<RAG>(gr, 16 * (g < 0 ? 0 : g), 4 * q, dm, vec); };
 
   // Operands of chunk c -- a GEMM-1 chunk is contiguous in the forward image; a second-sweep chunk is the forward GEMM-2
   // tile followed by the tile's A3 operands from the backward image -- travel L2 -> LDS by LDS-DMA (buffer_load ... lds:
@@ -179,6 +184,28 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void_ptr_a)(dst + MT * B::TILE_OPS_WORDS), 4, lane * 4,
                                                (int)(word * 4), 0, 0);
     }
+#endif
+    asm volatile("" ::: "memory");
+  };
+  // the same for a chunk of the second sweep only (c >= nc1 known: no branch around the requests)
+  auto request_operands2 = [&](int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int cc = c < nc ? c : nc - 1;
+    uint32_t* dst = lds0 + (cc % kBwdRing) * B::CHUNK_WORDS;
+#pragma unroll
+    for (int i = 0; i < N_DMA; ++i) {
+      const int piece = min(i * kRnvpWaves + wave, MT * TILE_PIECES - 1);
+      const int mi = piece / TILE_PIECES, pt = piece - mi * TILE_PIECES;
+      const int m = min(MT * (cc - nc1) + mi, G - 1);
+      const bool from_b = pt >= T2_PIECES;
+      const int64_t word = from_b ? (int64_t)m * B::A3_TILE_WORDS + (pt - T2_PIECES) * 256
+                                  : S::part1_words(d) + (int64_t)m * S::TILE2_WORDS + pt * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(from_b ? b_rsrc : s_rsrc, (lds_void_ptr_a)(dst + piece * 256), 16, lane * 16,
+                                               (int)(word * 4), 0, 0);
+    }
+    const int64_t bword = S::split_words(d) + (int64_t)MT * (cc - nc1) * 32;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void_ptr_a)(dst + MT * B::TILE_OPS_WORDS), 4, lane * 4,
+                                             (int)(bword * 4), 0, 0);
 #endif
     asm volatile("" ::: "memory");
   };
@@ -282,7 +309,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
     }
   };
 #pragma unroll
-  for (int u = 0; u < 2; ++u) request_rows2(nc1 + u, (nc1 + u) & 1);
+  for (int u = 0; u < 2; ++u) request_rows2(nc1 + u, u);  // (register set = the chunk's parity counted from nc1)
   u32x2 yh[YT], yl[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
@@ -292,60 +319,62 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   f32x4 gm[YT], gc[YT];
 #pragma unroll
   for (int m = 0; m < YT; ++m) gm[m] = gc[m] = zero4;
-  for (int c0 = nc1 & ~1; c0 < nc; c0 += 2) {
+  // (pairs of chunks without a guard around their requests -- see g_on above --, then the odd last one)
+  auto chunk2 = [&](int c, auto u_c) {
+    constexpr int u = decltype(u_c)::value;
+    request_operands2(c + 2);
+    const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
+    const float* bias = reinterpret_cast<const float*>(buf + MT * B::TILE_OPS_WORDS);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {  // (u = the chunk's parity: compile-time register sets)
-      const int c = c0 + u;
-      if (c >= nc1 && c < nc) {
-        request_operands(c + 2);
-        const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
-        const float* bias = reinterpret_cast<const float*>(buf + MT * B::TILE_OPS_WORDS);
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = MT * (c - nc1) + mi;
+      // (one tile at a time: left free, the scheduler interleaves the chunk's tiles and spills ~90 registers)
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < G) {  // (wave-uniform: an odd number of tiles leaves the last chunk's second tile empty)
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 4 * q);
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 16 + 4 * q);
+        const f16x8* T8 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS) + lane;
+        const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS + S::TILE2_WORDS) + lane;
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int m = MT * (c - nc1) + mi;
-          // (one tile at a time: left free, the scheduler interleaves the chunk's tiles and spills ~90 registers)
-          __builtin_amdgcn_sched_barrier(0);
-          if (m < G) {  // (wave-uniform: an odd number of tiles leaves the last chunk's second tile empty)
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 4 * q);
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + mi * 32 + 16 + 4 * q);
-            const f16x8* T8 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS) + lane;
-            const f16x8* A3 = reinterpret_cast<const f16x8*>(buf + mi * B::TILE_OPS_WORDS + S::TILE2_WORDS) + lane;
-            f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
-#pragma unroll
-            for (int ks = 0; ks < NKS2; ++ks) {
-              const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
-              const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
-              split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
-              split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
-            }
-            const f32x4 t4 = tc * kSplitInvScale + tm + bt;
-            const f32x4 s4 = sc * kSplitInvScale + sm + bs;
-            const f32x4 mk = SEEDED ? mask4(m) : m2[u][mi];
-            f32x4 gt, gs;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float zz = z2[u][mi][r], mm = mk[r], nm = 1.f - mm;
-              mx = __builtin_fmaxf(mx, __builtin_fabsf(mm * zz));  // (launch B-n splits m z: sweep 1's guard when it is skipped)
-              const float GG = live ? g2[u][mi][r] * gscale : 0.f;
-              const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
-              const float omg = 1.f - gate;
-              gt[r] = GG * omg;
-              gs[r] = (GG * (nm * zz - t4[r]) * gate + glr * nm) * omg;
-            }
-            u32x2 th, tl, sh, sl;
-            split_tile(gt, th, tl, mx);
-            split_tile(gs, sh, sl, mx);
-            const f16x8 bh = pair_operand(th, sh), bl = pair_operand(tl, sl);
-#pragma unroll
-            for (int m2i = 0; m2i < YT; ++m2i)
-              split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
-          }
+        for (int ks = 0; ks < NKS2; ++ks) {
+          const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
+          split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
         }
-        request_rows2(c + 2, u);
-        chunk_barrier(false);
+        const f32x4 t4 = tc * kSplitInvScale + tm + bt;
+        const f32x4 s4 = sc * kSplitInvScale + sm + bs;
+        const f32x4 mk = SEEDED ? mask4(m) : m2[u][mi];
+        f32x4 gt, gs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zz = z2[u][mi][r], mm = mk[r], nm = 1.f - mm;
+          mx = __builtin_fmaxf(mx, __builtin_fabsf(mm * zz));  // (launch B-n splits m z: sweep 1's guard when it is skipped)
+          const float GG = live ? g2[u][mi][r] * g_on : 0.f;
+          const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
+          const float omg = 1.f - gate;
+          gt[r] = GG * omg;
+          gs[r] = (GG * (nm * zz - t4[r]) * gate + glr * nm) * omg;
+        }
+        u32x2 th, tl, sh, sl;
+        split_tile(gt, th, tl, mx);
+        split_tile(gs, sh, sl, mx);
+        const f16x8 bh = pair_operand(th, sh), bl = pair_operand(tl, sl);
+#pragma unroll
+        for (int m2i = 0; m2i < YT; ++m2i)
+          split_mac(A3[64 * (2 * m2i)], A3[64 * (2 * m2i + 1)], bh, bl, gm[m2i], gc[m2i]);
       }
     }
+    request_rows2(c + 2, u);
+    chunk_barrier(false);
+  };
+  int c2 = nc1;
+  for (; c2 + 1 < nc; c2 += 2) {
+    chunk2(c2, std::integral_constant<int, 0>{});
+    chunk2(c2 + 1, std::integral_constant<int, 1>{});
   }
+  if (c2 < nc) chunk2(c2, std::integral_constant<int, 0>{});
   // ---- g_y complete: the group's verdict, then the hand-over
   f32x4 gy[YT];
   u32x2 gh[YT], gl2[YT];
