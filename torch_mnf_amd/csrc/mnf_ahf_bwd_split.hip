@@ -247,6 +247,8 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
   // training step at 2^20 rows; pulling them through the caches by LDS-DMA instead gave 4.77).
   f32x4 n_cnd[G], n_act[G], n_gc[G], n_ga[G];
   float n_gl;
+  const float* const gy_or_x = grad_y ? grad_y : x;
+  const float* const gl_or_x = grad_ld ? grad_ld : x;
   auto load_rows = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
@@ -256,10 +258,13 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     for (int g = 0; g < G; ++g) {
       n_cnd[g] = *reinterpret_cast<const f32x4*>(xr + cond_off + 16 * g);
       n_act[g] = *reinterpret_cast<const f32x4*>(xr + act_off + 16 * g);
-      n_gc[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + cond_off + 16 * g) : zero4;
-      n_ga[g] = (grad_y && live) ? *reinterpret_cast<const f32x4*>(grad_y + rowc * dim + 4 * q + act_off + 16 * g) : zero4;
+      // (no branch around a load: behind one hipcc's wait counts fall back to vmcnt(0), and the tile's first use of its
+      //  rows would also wait for the previous tile's grad_x stores.  A missing cotangent reads x instead and a row past
+      //  the end the last row: both are multiplied by zero where they are used.)
+      n_gc[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + cond_off + 16 * g);
+      n_ga[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + act_off + 16 * g);
     }
-    n_gl = (grad_ld && live) ? grad_ld[rowc] : 0.f;
+    n_gl = gl_or_x[rowc];
   };
   const int first_tile = (int)blockIdx.x * kBsWaves + wave;
   load_rows(first_tile < n_tiles ? first_tile : 0);
@@ -267,15 +272,16 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
+    const float gy_on = (grad_y && live) ? g_scale : 0.f;
     f32x4 cnd[G], act[G], gc[G], ga[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       cnd[g] = n_cnd[g];
       act[g] = n_act[g];
-      gc[g] = n_gc[g] * g_scale;
-      ga[g] = n_ga[g] * g_scale;
+      gc[g] = n_gc[g] * gy_on;
+      ga[g] = n_ga[g] * gy_on;
     }
-    const float gl = n_gl * g_scale;
+    const float gl = n_gl * ((grad_ld && live) ? g_scale : 0.f);
     load_rows(tile + tile_step < n_tiles ? tile + tile_step : tile);  // (past the end: this tile again, unused)
 
     int a_off = lane * 4, b_off = B::SPLIT_WORDS + q * 4;
