@@ -632,15 +632,52 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
 #pragma unroll
   for (int t = 0; t < S::TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int64_t n_tiles = (a.rows + 3) >> 2, stride = (int64_t)gridDim.x * kNpPairs;
-  const int64_t first0 = (int64_t)blockIdx.x * kNpPairs, first = first0 + pair;
+  // (32-bit tile numbers and element offsets -- the launcher admits rows x dim < 2^31 --: the 64-bit forms of these cost
+  //  the registers the row prefetch below needs)
+  const int n_rows = (int)a.rows;
+  const int n_tiles = (n_rows + 3) >> 2, stride = (int)gridDim.x * kNpPairs;
+  const int first0 = (int)blockIdx.x * kNpPairs, first = first0 + pair;
   // workgroup-uniform slot count (pair 0 has the most tiles), + 2 slots to drain the pipeline
-  const int64_t n_slots = (first0 < n_tiles ? (n_tiles - first0 + stride - 1) / stride : 0) + 2;
+  const int n_slots = (first0 < n_tiles ? (n_tiles - first0 + stride - 1) / stride : 0) + 2;
   // forward:  up1 = S(up0; f1(lo0)),  lo1 = S(lo0; f2(up1))       -> reverse: f2's step, then f1's
   // inverse:  lo1 = S^-1(lo0; f2(up0)), up1 = S^-1(up0; f1(lo1))  -> reverse: f1's step, then f2's
   constexpr int net_a = INV ? 1 : 0, net_b = 1 - net_a;      // f1 = 0, f2 = 1
   constexpr int col_a = INV ? 0 : kNrHalf, col_b = kNrHalf - col_a;  // columns of the half each step transforms
-  for (int64_t s = 0; s < n_slots; ++s) {
+  // Row values a slot AHEAD (round 4): every step used to load its x / grad_y / grad_ld values where it needed them -- up
+  // to three exposed global-memory latencies per slot, the third behind the slot's grad_x stores -- with both waves of a
+  // SIMD (one pair) waiting at the same time.  Now slot s requests what slot s + 1 will use: five loads per wave from
+  // role-dependent addresses, no branch around them (behind a load under a branch hipcc's wait counts fall back to
+  // vmcnt(0)); a missing cotangent reads x, a step without a tile the nearest tile: both are not used.
+  //   X (role 0): 0 cond, 1 value, 2 grad_ld of step 3's tile; 3 cond, 4 value of step 1's tile
+  //   Y (role 1): 0 value, 1 g_a, 2 grad_ld, 3 g_b of step 2's tile
+  const float* const gy_or_x = a.grad_y ? a.grad_y : a.x;
+  const float* const gl_or_x = a.grad_ld ? a.grad_ld : a.x;
+  auto tile_row = [&](int t) -> uint32_t {
+    t = t < 0 ? 0 : (t < n_tiles ? t : n_tiles - 1);
+    const int row = t * 4 + r;
+    return (uint32_t)(row < n_rows ? row : n_rows - 1);
+  };
+  float nx[5];
+  auto request_rows = [&](int sn) {
+    const uint32_t ra = tile_row(first + (sn - (role ? 1 : 2)) * stride);  // step 3's (X) / step 2's (Y) tile
+    const uint32_t rb = role ? ra : tile_row(first + sn * stride);          // step 1's tile (X)
+    const float* p0 = a.x + ra * dim + col_b + j;
+    const float* p1 = (role ? gy_or_x : a.x) + ra * dim + col_a + j;
+    const float* p2 = gl_or_x + ra;
+    const float* p3 = (role ? gy_or_x : a.x) + rb * dim + col_b + j;
+    const float* p4 = a.x + rb * dim + col_a + j;
+    nx[0] = *p0;
+    nx[1] = *p1;
+    nx[2] = *p2;
+    nx[3] = *p3;
+    nx[4] = *p4;
+  };
+  request_rows(0);
+  for (int s = 0; s < n_slots; ++s) {
+    float cur[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cur[i] = nx[i];
+    request_rows(s + 1);
     int off = (role ? net_b : net_a) * S::NET_FLOATS + j;
     asm volatile("" : "+v"(off));  // keep the weight reads inside the slot loop
     const float* nb = lds + (off - j);
@@ -648,13 +685,13 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
     const float* b4 = nb + kNrHalf * S::REC + j * P;
     const float* hw = nb + kNrHalf * S::REC + kNrHalf * P + j * kNrHidRec;
     if (role == 0) {
-      const int64_t t3 = first + (s - 2) * stride, t1 = first + s * stride;
+      const int t3 = first + (s - 2) * stride, t1 = first + s * stride;
       if (s >= 2 && t3 < n_tiles) {  // step 3: the first half-step backwards
-        const int64_t row = t3 * 4 + r;
-        const bool live = row < a.rows;
-        const int64_t rowc = live ? row : a.rows - 1;
-        const float cond_a = a.x[rowc * dim + col_b + j], val_a = a.x[rowc * dim + col_a + j];
-        const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+        const int row = t3 * 4 + r;
+        const bool live = row < n_rows;
+        const uint32_t rowc = (uint32_t)(live ? row : n_rows - 1);
+        const float cond_a = cur[0], val_a = cur[1];
+        const float gl = (a.grad_ld && live) ? cur[2] : 0.f;
         float g_a = mail[(s - 1) & 1][pair][1][lane], g_b = mail[(s - 1) & 1][pair][2][lane];
         half_backward<K, INV>(hw, w4, b4, j, a.T, cond_a, val_a, gl, g_a, g_b, acc);
         if (live) {
@@ -663,23 +700,20 @@ __global__ void __launch_bounds__(2 * kNpPairs * 64, 1) nsf_bwd_pairs_kernel(NrA
         }
       }
       if (t1 < n_tiles) {  // step 1: the first net forward, the half it produces
-        const int64_t row = t1 * 4 + r;
-        const int64_t rowc = row < a.rows ? row : a.rows - 1;
-        const float cond_a = a.x[rowc * dim + col_b + j], val_a = a.x[rowc * dim + col_a + j];
+        const float cond_a = cur[3], val_a = cur[4];
         float h1, h2, h3, h3all[kNrUnits], p[P];
         net_forward<K>(hw, w4, b4, cond_a, h1, h2, h3, h3all, p);
         mail[s & 1][pair][0][lane] = rqs_value<K, INV>(val_a, a.T, p);
       }
     } else {
-      const int64_t t2 = first + (s - 1) * stride;
+      const int t2 = first + (s - 1) * stride;
       if (s >= 1 && t2 < n_tiles) {  // step 2: the second half-step backwards, conditioned on X's output
-        const int64_t row = t2 * 4 + r;
-        const bool live = row < a.rows;
-        const int64_t rowc = live ? row : a.rows - 1;
-        const float val_b = a.x[rowc * dim + col_b + j];
-        float g_a = (a.grad_y && live) ? a.grad_y[rowc * dim + col_a + j] : 0.f;
-        float g_b = (a.grad_y && live) ? a.grad_y[rowc * dim + col_b + j] : 0.f;
-        const float gl = (a.grad_ld && live) ? a.grad_ld[rowc] : 0.f;
+        const int row = t2 * 4 + r;
+        const bool live = row < n_rows;
+        const float val_b = cur[0];
+        float g_a = (a.grad_y && live) ? cur[1] : 0.f;
+        float g_b = (a.grad_y && live) ? cur[3] : 0.f;
+        const float gl = (a.grad_ld && live) ? cur[2] : 0.f;
         const float mid = mail[(s - 1) & 1][pair][0][lane];
         half_backward<K, INV>(hw, w4, b4, j, a.T, mid, val_b, gl, g_b, g_a, acc);
         mail[s & 1][pair][1][lane] = g_a;
@@ -744,6 +778,7 @@ int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_l
       !mnf::hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   if (!mnf_nsf_cl_bwd_rows_supported(dim, K, n_hidden, hidden)) return MNF_ERR_UNSUPPORTED;
+  if (rows * dim >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;  // (32-bit element offsets: the caller's generic kernel)
   if (rows == 0) return MNF_OK;
   mnf::NrArgs a;
   memset(&a, 0, sizeof(a));

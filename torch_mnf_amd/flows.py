@@ -388,7 +388,8 @@ class _NsfFn(torch.autograd.Function):
         grad_flat = torch.zeros_like(flat)
         lib = _lib.load()
         # the row-per-lane kernel where it exists (d = 32, hidden width <= 8, K in {5, 8}), else the generic one
-        rows_kernel = not m.force_generic and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid)
+        rows_kernel = (not m.force_generic and x.shape[0] * m.dim < (1 << 31)
+                       and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid))
         name = "mnf_nsf_cl_bwd_rows" if rows_kernel else "mnf_nsf_cl_bwd"
         marks = None
         if bwd_kernel_events is not None and rows_kernel:  # bench.py --workload c3t
