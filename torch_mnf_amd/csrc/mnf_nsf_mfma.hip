@@ -510,24 +510,44 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 
   double lp_acc = 0.0;
   const int n_tiles = (int)((rows + 15) >> 4);
-  for (int tile = (int)blockIdx.x * kNsfWaves + wave; tile < n_tiles; tile += (int)gridDim.x * kNsfWaves) {
+  // The NEXT tile's row (and its log_det entry when this launch adds to it) is requested at the top of a tile (round 4):
+  // loaded where it was used, the row waited for its own latency AND -- vector-memory operations complete in order --
+  // for the previous tile's stores, and the log_det read-modify-write at the tile's end did so again.  No branch around
+  // the requests (behind one hipcc's wait counts fall back to vmcnt(0)): past the end the same tile is read again.
+  const int tile_step = (int)gridDim.x * kNsfWaves, tile0 = (int)blockIdx.x * kNsfWaves + wave;
+  const float* const ld_or_x = (log_det && accumulate) ? log_det : x;
+  f32x4 n_lo[G], n_up[G];
+  float n_ld;
+  auto request_tile = [&](int t) {
+    const int64_t rw = (int64_t)(t < n_tiles ? t : n_tiles - 1) * 16 + j;
+    const int64_t rc = rw < rows ? rw : rows - 1;
+    const float* xr = x + rc * dim + 4 * q;
+#pragma unroll
+    for (int g = 0; g < G; ++g) n_lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) n_up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+    n_ld = ld_or_x[rc];
+  };
+  if (n_tiles > 0) request_tile(tile0);
+  for (int tile = tile0; tile < n_tiles; tile += tile_step) {
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
-    const float* xr = x + rowc * dim + 4 * q;
     float* yr = y + rowc * dim + 4 * q;
     f32x4 lo[G], up[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
-#pragma unroll
-    for (int g = 0; g < G; ++g) up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+    for (int g = 0; g < G; ++g) lo[g] = n_lo[g], up[g] = n_up[g];
+    const float ld_before = n_ld;
+    request_tile(tile + tile_step);
     float ld;
     // the block's two intermediate tensors (mid1, mid2 in application order), written once from registers:
     //   forward: ActNorm(x) = x e^s + t elementwise, then the affine result = Glow(ActNorm(x))
     //   inverse: NSF^-1(x), then Glow^-1 of it = (final) e^s + t elementwise from the affine result
     const float* ss = lds + NET_IMAGE + AFF_FLOATS + 4 * q;
+    // (every lane stores: a lane past the last row holds the last row's values -- clamped loads, the same arithmetic -- and
+    //  writes them to the last row again.  A store under a branch would make the next tile's first use of its prefetched
+    //  row wait for vmcnt(0), i.e. for these stores to reach memory.)
     auto store_row = [&](float* base, const f32x4 (&a)[G], const f32x4 (&b)[G]) {
-      if (!live) return;
       float* mr = base + rowc * dim + 4 * q;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -567,16 +587,14 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       affine_rows<H>(lds + NET_IMAGE, lane, q, lo, up);
       if (mid2) store_actnorm_of(mid2);
     }
-    if (live) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
+    for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
 #pragma unroll
-      for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = up[g];
-    }
+    for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = up[g];
     if (log_det) {
       ld = sum_over_q(ld) + ld_const;
-      if (accumulate && live) ld += log_det[row];
-      if (live && q == 0) log_det[row] = ld;
+      if (accumulate) ld += ld_before;
+      log_det[rowc] = ld;  // (the row's four lanes and any lane past the end: the same value)
       if (log_prob) {  // last launch of a density pass: log p = log_det - |y|^2 / 2 - d/2 log(2 pi)  (core.py:46-49)
         float sq = 0.f;
 #pragma unroll
