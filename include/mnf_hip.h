@@ -523,6 +523,20 @@ int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* 
                               int parity, int inverse, int n_hidden, const int* hidden_host,
                               const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
                               int64_t workspace_floats, void* stream);
+/* mnf_affine_half_bwd_split for the LAST layer of a density pass under a standard-normal base, differentiating
+ * log p = log_det + log N(y; 0, I) directly (the `loss.backward()` of `-model.log_prob(x).mean()`, the reference's
+ * training loops: tests/test_flows.py:14-31 with flows/core.py:46-49): the cotangents are formed in the kernel from
+ *   lp_grad      device floats (rows): d loss / d log p per row -- grad_ld = lp_grad, grad_y = -y lp_grad with the
+ *                layer's output y recomputed from x (no `-z g` elementwise pass, no grad_y read);
+ *   gy_scratch   device floats (rows x dim), 16-byte aligned, uninitialised: the rows of grad_y of every tile put on
+ *                cold_list are stored there, for the mnf_affine_half_bwd_mfma_tiles fix-up (grad_y = gy_scratch,
+ *                grad_ld = lp_grad).
+ * mnf_affine_half_grad_scale(NULL, lp_grad, ...) gives a suitable grad_scale_dev.  Everything else as above. */
+int mnf_affine_half_bwd_split_lp(const float* x, const float* lp_grad, float* gy_scratch, float* grad_x,
+                                 float* grad_flat, const void* bwd_image, const int32_t* index_dev, int64_t rows, int dim,
+                                 int parity, int inverse, int n_hidden, const int* hidden_host,
+                                 const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
+                                 int64_t workspace_floats, void* stream);
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);

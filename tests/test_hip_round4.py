@@ -203,3 +203,38 @@ def test_split_gradient_kernel_with_one_net_per_wave_passes_the_same_parity_test
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+@pytest.mark.parametrize("rows", [1007, 4096])
+def test_log_prob_training_node_matches_the_unfused_route(amd, rows):
+    """`-model.log_prob(x).mean()` under a standard-normal base with the whole model one run of AffineHalfFlow layers:
+    ONE autograd node from x to log p (the stack kernel's log-prob epilogue forward; the last layer's cotangents formed
+    inside mnf_affine_half_bwd_split_lp backward) against the unfused route (log_det + base.log_prob(z) with its own
+    autograd link, validated against the float64 oracle by tests/test_hip_autograd.py)."""
+    dim = 64
+    flows_mod = amd.flows
+    floor, flows_mod._BWD_SPLIT_MIN_ROWS = flows_mod._BWD_SPLIT_MIN_ROWS, 0
+    try:
+        results = {}
+        for fused in (True, False):
+            layers = []
+            for i, sd in enumerate(recipes.c2_stack_params(dim)):
+                f = amd.AffineHalfFlow(dim, parity=bool(i % 2))
+                f.load_state_dict(sd)
+                layers.append(f)
+            model = amd.NormalizingFlowModel(amd.StandardNormal(dim), layers).to(DEV)
+            x = recipes.gaussian(77, rows, dim).to(DEV).requires_grad_(True)
+            w = recipes.gaussian(78, rows, 1)[:, 0].to(DEV)  # a row-dependent cotangent, not just 1 / rows
+            env, flows_mod._NO_FUSED_LOGPROB_ENV = flows_mod._NO_FUSED_LOGPROB_ENV, not fused
+            try:
+                lp = model.log_prob(x)
+                (-(lp * w).mean()).backward()
+            finally:
+                flows_mod._NO_FUSED_LOGPROB_ENV = env
+            results[fused] = (lp.detach(), x.grad, {n: p.grad for n, p in model.named_parameters()})
+        assert float((results[True][0] - results[False][0]).abs().max()) <= 2e-5 * float(results[False][0].abs().max())
+        assert normwise_err(results[True][1].cpu().numpy(), results[False][1].cpu().numpy()) <= 2e-6
+        for n, g in results[False][2].items():
+            assert normwise_err(results[True][2][n].cpu().numpy(), g.cpu().numpy()) <= 5e-6, n
+    finally:
+        flows_mod._BWD_SPLIT_MIN_ROWS = floor

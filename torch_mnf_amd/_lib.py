@@ -93,6 +93,9 @@ SIGNATURES = {
     "mnf_affine_half_bwd_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                           c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int, c_void_p, c_int64,
                                           c_void_p]),
+    "mnf_affine_half_bwd_split_lp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int64, c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_int64, c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_nsf_cl_bwd_rows_supported": (c_int, [c_int, c_int, c_int, _intp]),

@@ -189,12 +189,16 @@ __device__ __forceinline__ f32x4 mfma_x16(const f16x4& a, const f16x4& b, const 
 }
 __device__ __forceinline__ f16x4 as_f16x4(const u32x2& v) { return __builtin_bit_cast(f16x4, v); }
 
-template <int H, int HID, bool INV>
+// LP: the launch differentiates log p = log_det + log N(y; 0, I) of a density pass whose LAST layer this is: the
+// cotangents are not read but formed from the per-row d loss / d log p (`lp_grad`): grad_ld = g, grad_y = -y g, with the
+// layer's output y recomputed here (y_cond = x_cond; y_act from s, t) -- no `-z g` elementwise launch, no grad_y read.
+// A tile the range verdict hands to the fp32 pass leaves its grad_y rows in `gy_scratch` for that pass.
+template <int H, int HID, bool INV, bool LP>
 __global__ void __launch_bounds__(kBsWaves * 64, 1)
 ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
                      float* __restrict__ grad_x, float* __restrict__ grad_flat, const uint32_t* __restrict__ image,
                      const int32_t* __restrict__ index, int64_t rows, int parity, const float* __restrict__ scale_dev,
-                     int32_t* __restrict__ cold_list, int cold_capacity, float* __restrict__ partials) {
+                     int32_t* __restrict__ cold_list, int cold_capacity, float* __restrict__ partials, const float* __restrict__ lp_grad, float* __restrict__ gy_scratch) {
   using B = BwdSplitShape<H, HID>;
   using S = typename B::S;
   using F = typename B::F;
@@ -248,7 +252,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
   f32x4 n_cnd[G], n_act[G], n_gc[G], n_ga[G];
   float n_gl;
   const float* const gy_or_x = grad_y ? grad_y : x;
-  const float* const gl_or_x = grad_ld ? grad_ld : x;
+  const float* const gl_or_x = LP ? lp_grad : (grad_ld ? grad_ld : x);
   auto load_rows = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
@@ -261,8 +265,10 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       // (no branch around a load: behind one hipcc's wait counts fall back to vmcnt(0), and the tile's first use of its
       //  rows would also wait for the previous tile's grad_x stores.  A missing cotangent reads x instead and a row past
       //  the end the last row: both are multiplied by zero where they are used.)
-      n_gc[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + cond_off + 16 * g);
-      n_ga[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + act_off + 16 * g);
+      if constexpr (!LP) {
+        n_gc[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + cond_off + 16 * g);
+        n_ga[g] = *reinterpret_cast<const f32x4*>(gy_or_x + rowc * dim + 4 * q + act_off + 16 * g);
+      }
     }
     n_gl = gl_or_x[rowc];
   };
@@ -273,15 +279,21 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
     const float gy_on = (grad_y && live) ? g_scale : 0.f;
-    f32x4 cnd[G], act[G], gc[G], ga[G];
+    const float g_raw = n_gl;                          // (LP: d loss / d log p of the row, unscaled)
+    const float g_row = live ? n_gl * g_scale : 0.f;   // (LP: the same, scaled; zero past the last row)
+    f32x4 cnd[G], act[G], gc[G], ga[G], y_act[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       cnd[g] = n_cnd[g];
       act[g] = n_act[g];
-      gc[g] = n_gc[g] * gy_on;
-      ga[g] = n_ga[g] * gy_on;
+      if constexpr (LP) {
+        gc[g] = cnd[g] * -g_row;  // grad_y of the conditioning half: y_cond = x_cond
+      } else {
+        gc[g] = n_gc[g] * gy_on;
+        ga[g] = n_ga[g] * gy_on;
+      }
     }
-    const float gl = n_gl * ((grad_ld && live) ? g_scale : 0.f);
+    const float gl = LP ? g_row : n_gl * ((grad_ld && live) ? g_scale : 0.f);
     load_rows(tile + tile_step < n_tiles ? tile + tile_step : tile);  // (past the end: this tile again, unused)
 
     int a_off = lane * 4, b_off = B::SPLIT_WORDS + q * 4;
@@ -446,8 +458,15 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       f32x4 gv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s = st[0][g][r], t = st[1][g][r], gy = ga[g][r], v = act[g][r];
+        const float s = st[0][g][r], t = st[1][g][r], v = act[g][r];
         const float e = exp6(INV ? -s : s);
+        float gy;
+        if constexpr (LP) {
+          y_act[g][r] = INV ? (v - t) * e : __builtin_fmaf(e, v, t);
+          gy = y_act[g][r] * -g_row;
+        } else {
+          gy = ga[g][r];
+        }
         gv[r] = gy * e * g_unscale;
         d4[g][r] = live ? (INV ? -gy * ((v - t) * e) - gl : gy * e * v + gl) : 0.f;
         d4[G + g][r] = INV ? -gy * e : gy;
@@ -569,6 +588,16 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       if (lane == 0) {
         const int slot = atomicAdd(cold_list, 1);
         if (slot < cold_capacity) cold_list[1 + slot] = tile;
+      }
+      if constexpr (LP) {  // the fp32 pass reads its cotangents: this tile's grad_y rows, unscaled
+        if (live) {
+          float* const gs = gy_scratch + rowc * dim + 4 * q;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            *reinterpret_cast<f32x4*>(gs + cond_off + 16 * g) = cnd[g] * -g_raw;
+            *reinterpret_cast<f32x4*>(gs + act_off + 16 * g) = y_act[g] * -g_raw;
+          }
+        }
       }
       continue;
     }
@@ -884,15 +913,20 @@ template <int H, int HID>
 static int launch_bwd_split(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                             const uint32_t* image, const int32_t* index, int64_t rows, int parity, int inverse,
                             const float* scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
-                            int64_t workspace_floats, hipStream_t stream) {
+                            int64_t workspace_floats, hipStream_t stream, const float* lp_grad = nullptr,
+                            float* gy_scratch = nullptr) {
   using B = BwdSplitShape<H, HID>;
+  using Kernel = void (*)(const float*, const float*, const float*, float*, float*, const uint32_t*, const int32_t*, int64_t,
+                          int, const float*, int32_t*, int, float*, const float*, float*);
   static constexpr size_t lds_bytes = B::LDS_WORDS * sizeof(uint32_t);
+  const Kernel all[4] = {ahf_bwd_split_kernel<H, HID, true, false>, ahf_bwd_split_kernel<H, HID, false, false>,
+                         ahf_bwd_split_kernel<H, HID, true, true>, ahf_bwd_split_kernel<H, HID, false, true>};
   static DeviceMemo memo;
-  const int cus = memo.get([](int dev) {
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_split_kernel<H, HID, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_split_kernel<H, HID, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  const int cus = memo.get([&](int dev) {
+    bool ok = true;
+    for (int k = 0; k < 4; ++k)
+      ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(all[k]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes) == hipSuccess;
     return ok ? device_cus(dev) : -1;
   });
   if (cus <= 0) return MNF_ERR_UNSUPPORTED;
@@ -901,12 +935,9 @@ static int launch_bwd_split(const float* x, const float* grad_y, const float* gr
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (one wave per SIMD: the whole register file)
   const dim3 grid((unsigned)blocks), block(kBsWaves * 64);
   float* partials = (grad_flat && workspace && workspace_floats >= blocks * B::RED_FLOATS) ? workspace : nullptr;
-  if (inverse)
-    hipLaunchKernelGGL((ahf_bwd_split_kernel<H, HID, true>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials);
-  else
-    hipLaunchKernelGGL((ahf_bwd_split_kernel<H, HID, false>), grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
-                       grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials);
+  hipLaunchKernelGGL(all[(lp_grad ? 2 : 0) + (inverse ? 0 : 1)], grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
+                     grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials, lp_grad,
+                     gy_scratch);
   if (partials)
     hipLaunchKernelGGL(ahf_bwd_reduce_kernel, dim3((B::RED_FLOATS + 31) / 32), dim3(256), 0, stream, partials, (int)blocks,
                        (int)B::RED_FLOATS, index + B::F::IMAGE_FLOATS, grad_flat, scale_dev, cold_list);
@@ -1011,6 +1042,32 @@ int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* 
     return mnf::launch_bwd_split<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, static_cast<const uint32_t*>(bwd_image), \
                                          index_dev, rows, parity != 0, inverse != 0, grad_scale_dev, cold_list,            \
                                          cold_capacity, workspace, workspace_floats, (hipStream_t)stream);
+  MNF_AHF_BWD_SPLIT_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+
+int mnf_affine_half_bwd_split_lp(const float* x, const float* lp_grad, float* gy_scratch, float* grad_x,
+                              float* grad_flat, const void* bwd_image, const int32_t* index_dev, int64_t rows, int dim,
+                              int parity, int inverse, int n_hidden, const int* hidden, const float* grad_scale_dev,
+                              int32_t* cold_list, int cold_capacity, float* workspace, int64_t workspace_floats,
+                              void* stream) {
+  int hid = 0;
+  if (!x || !lp_grad || !gy_scratch || !grad_x || !bwd_image || !index_dev || !cold_list || cold_capacity < 0 || rows < 0 || dim < 2 || (dim & 1) ||
+      !mnf::hidden_ok(n_hidden, hidden) || !grad_scale_dev)
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (!mnf::bwd_split_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy_scratch) | reinterpret_cast<uintptr_t>(grad_x) |
+       reinterpret_cast<uintptr_t>(bwd_image)) & 15)
+    return MNF_ERR_UNSUPPORTED;
+  if (mnf::bwd_net_mode()) return MNF_ERR_UNSUPPORTED;  // (the one-net-per-wave kernels take their cotangents from memory)
+#define X(HH, HD)                                                                                                      \
+  if (dim == 2 * HH && hid == HD)                                                                                      \
+    return mnf::launch_bwd_split<HH, HD>(x, nullptr, nullptr, grad_x, grad_flat, static_cast<const uint32_t*>(bwd_image), \
+                                         index_dev, rows, parity != 0, inverse != 0, grad_scale_dev, cold_list,            \
+                                         cold_capacity, workspace, workspace_floats, (hipStream_t)stream, lp_grad, gy_scratch);
   MNF_AHF_BWD_SPLIT_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

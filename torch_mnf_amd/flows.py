@@ -286,12 +286,38 @@ def _bwd_split_workspace(lib, f, rows: int, device) -> Tensor | None:
 
 
 def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr, flat_ptr, bwd_image_ptr, scale, cold,
-                        inverse: bool, work: Tensor | None = None) -> None:
+                        inverse: bool, work: Tensor | None = None, lp_scratch: Tensor | None = None) -> bool:
     """Gradients of ONE AffineHalfFlow layer: the split-MFMA kernel (+ its fp32 fix-up pass over the tiles it handed
-    back), else the fp32-MFMA kernel, else the generic one.  grad_x is written, the flat gradient added to."""
+    back), else the fp32-MFMA kernel, else the generic one.  grad_x is written, the flat gradient added to.
+
+    ``lp_scratch`` (rows x dim, uninitialised) asks for the log-prob form of the split kernel: ``gl`` is d loss / d
+    log p per row, ``gy`` is None -- the kernel forms grad_y = -y gl itself (mnf_affine_half_bwd_split_lp).  Returns
+    False when that form does not exist for this call (nothing has been computed: the caller materialises grad_y)."""
     rows, hid = x_in.shape[0], (len(f.h_sizes), f._hid)
     index = f._bwd_index(x_in.device) if grad_flat_ptr is not None and not f.force_generic else None
     rc = _lib.MNF_ERR_UNSUPPORTED
+    if lp_scratch is not None:
+        if index is None or bwd_image_ptr is None or gl is None:
+            return False
+        cap = cold.numel() - 1
+        marks = None
+        if bwd_kernel_events is not None:
+            marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            marks[0].record()
+        rc = lib.mnf_affine_half_bwd_split_lp(
+            x_in.data_ptr(), gl.data_ptr(), lp_scratch.data_ptr(), gx.data_ptr(), grad_flat_ptr, bwd_image_ptr,
+            index.data_ptr(), rows, f.dim, int(bool(f.parity)), int(inverse), *hid, scale.data_ptr(), cold.data_ptr(),
+            cap, _ptr(work), 0 if work is None else work.numel(), _stream())
+        if rc == _lib.MNF_ERR_UNSUPPORTED:
+            return False
+        if marks is not None:
+            marks[1].record()
+            bwd_kernel_events.append(marks)
+        _lib.check("mnf_affine_half_bwd_split_lp", rc)
+        _lib.check("mnf_affine_half_bwd_mfma_tiles", lib.mnf_affine_half_bwd_mfma_tiles(
+            x_in.data_ptr(), lp_scratch.data_ptr(), gl.data_ptr(), gx.data_ptr(), grad_flat_ptr, flat_ptr,
+            index.data_ptr(), rows, f.dim, int(bool(f.parity)), int(inverse), *hid, cold.data_ptr(), cap, _stream()))
+        return True
     if index is not None and bwd_image_ptr is not None:
         cap = cold.numel() - 1
         marks = None
@@ -318,6 +344,7 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, rows, f.dim,
             int(bool(f.parity)), int(inverse), *hid, int(f.scale), int(f.shift), _stream())
     _lib.check("mnf_affine_half_bwd", rc)
+    return True
 
 
 class _AffineHalfFn(torch.autograd.Function):
@@ -595,7 +622,10 @@ class _AffineRunFn(torch.autograd.Function):
     intermediates.  One parameter cat / one grad scatter for the whole run instead of one per layer."""
 
     @staticmethod
-    def forward(ctx, x, flat_with_grad, run, inverse):
+    def forward(ctx, x, flat_with_grad, run, inverse, with_lp=False):
+        """``with_lp``: the run is a whole density pass under a standard-normal base -- the stack kernel's epilogue also
+        writes log p = log_det + log N(z; 0, I), the ONLY output of the node then, and the backward pass forms the last
+        layer's cotangents from d loss / d log p inside the gradient kernel (mnf_affine_half_bwd_split_lp)."""
         n = len(run.layers)
         ld = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
         # flat-homed parameters (train.FlatParameters): flat_with_grad is a one-element stand-in that only carries
@@ -604,19 +634,30 @@ class _AffineRunFn(torch.autograd.Function):
         ctx.home = home
         flat = home[0].data[home[1]:home[1] + home[2]] if home is not None else flat_with_grad.detach()
         imgs = run.images(x.device, flat)  # after a weight update: repacked from this one concatenation
-        outs = run.launch(x, inverse, ld, False, None, keep=True, images=imgs) if imgs[0] is not None else None
-        if outs is None:
+        lp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device) if with_lp else None
+        outs = (run.launch(x, inverse, ld, False, None, keep=True, images=imgs, logprob=(lp, None) if with_lp else None)
+                if imgs[0] is not None else None)
+        if outs is None or (with_lp and not run.logprob_fused):
             raise MnfHipError("mnf_affine_half_stack", _lib.MNF_ERR_UNSUPPORTED, "no stack kernel for this shape")
-        ctx.run, ctx.inverse = run, inverse
+        ctx.run, ctx.inverse, ctx.with_lp = run, inverse, with_lp
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x, flat, *outs[:-1])
         ctx.n = n
+        if with_lp:
+            ctx.save_for_backward(x, flat, *outs)  # (the last output too: the fallback's grad_y = -z g)
+            return lp
+        ctx.save_for_backward(x, flat, *outs[:-1])
         return (*outs, ld)
 
     @staticmethod
     def backward(ctx, *grads):
         run, inverse, n = ctx.run, ctx.inverse, ctx.n
         x, flat, *mids = ctx.saved_tensors
+        z_last = None
+        if ctx.with_lp:  # one incoming cotangent: d loss / d log p
+            z_last, mids = mids[-1], mids[:-1]
+            if grads[0] is None:
+                return None, None, None, None, None
+            grads = (None,) * n + (grads[0],)  # log p = log_det + base(z): d / d log_det = g; d / d z below
         inputs = [x] + list(mids)                     # input of the li-th applied layer
         order = list(reversed(run.layers)) if inverse else list(run.layers)
         grad_ld = grads[-1]
@@ -642,14 +683,21 @@ class _AffineRunFn(torch.autograd.Function):
         for li in range(n - 1, -1, -1):
             f = order[li]
             k = run.layers.index(f)
-            gy = None if g is None else g.contiguous()
             gx = torch.empty_like(x)
-            _ahf_layer_backward(lib, f, inputs[li], gy, gl, gx, grad_flat.data_ptr() + 4 * offs[k],
-                                flat.data_ptr() + 4 * offs[k],
-                                None if bwd is None else bwd[0].data_ptr() + 4 * bwd[1] * k, scale,
-                                None if cold is None else cold[k], inverse, work)
+            args = (grad_flat.data_ptr() + 4 * offs[k], flat.data_ptr() + 4 * offs[k],
+                    None if bwd is None else bwd[0].data_ptr() + 4 * bwd[1] * k, scale,
+                    None if cold is None else cold[k], inverse, work)
+            done = False
+            if ctx.with_lp and li == n - 1:  # the last layer: grad_y = -z g formed inside the gradient kernel
+                if bwd is not None:
+                    done = _ahf_layer_backward(lib, f, inputs[li], None, gl, gx, *args, lp_scratch=torch.empty_like(x))
+                if not done:
+                    g = z_last * (-gl).unsqueeze(1)
+            if not done:
+                gy = None if g is None else g.contiguous()
+                _ahf_layer_backward(lib, f, inputs[li], gy, gl, gx, *args)
             g = gx if li == 0 or grads[li - 1] is None else gx + grads[li - 1]
-        return g, (None if home is not None else grad_flat), None, None
+        return g, (None if home is not None else grad_flat), None, None, None
 
 
 class _HipFlow(nn.Module):
@@ -1913,8 +1961,9 @@ class _AffineRun:
                 and any(_wants_grad(f, x) for f in self.layers)
                 and self.layers[0]._device_index(x.device) is not None)
 
-    def launch_grad(self, x: Tensor, inverse: bool):
-        """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels."""
+    def launch_grad(self, x: Tensor, inverse: bool, with_lp: bool = False):
+        """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels.
+        ``with_lp``: log p under a standard-normal base instead, as ONE tensor (see _AffineRunFn.forward)."""
         self._home_now = self.flat_home()
         if self._home_now is not None:
             if self._stand_in is None or self._stand_in.device != x.device:
@@ -1923,12 +1972,16 @@ class _AffineRun:
         else:
             flat = torch.cat([p.reshape(-1) for p in self._params()])
         try:
-            out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse))
+            out = _AffineRunFn.apply(_grad_input(x), flat, self, bool(inverse), bool(with_lp))
         except MnfHipError as err:  # an image exists but no stack kernel (e.g. hidden width 32): layer by layer
             if err.code != _lib.MNF_ERR_UNSUPPORTED:
                 raise
+            if with_lp:  # (only the epilogue may be missing: the caller takes the unfused route)
+                return None
             self._unsupported = True
             return None
+        if with_lp:
+            return out
         return list(out[:-1]), out[-1]
 
     def launch(self, x: Tensor, inverse: bool, log_det: Tensor, accumulate: bool, sqnorm: Tensor | None,
@@ -2302,6 +2355,18 @@ class NormalizingFlowModel(NormalizingFlow):
         base the epilogue kernel also produces the fp64 sum over rows."""
         std = isinstance(self.base, StandardNormal)
         lp = total = None
+        if (std and torch.is_grad_enabled() and not _NO_FUSED_LOGPROB_ENV and not _NO_RUN_FUSION_ENV
+                and self.fuse_affine_runs and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2
+                and x.shape[0] >= _BWD_SPLIT_MIN_ROWS and x.dtype == torch.float32 and self.layer_events is None):
+            # training, the whole model ONE run of AffineHalfFlow layers: one autograd node from x to log p -- the
+            # stack kernel's epilogue writes log p, the gradient kernel of the last layer forms -z g itself
+            runs = self._affine_runs()
+            run = runs.get(0) if len(runs) == 1 else None
+            if isinstance(run, _AffineRun) and len(run.layers) == len(self.flows) and run.trainable(x):
+                lp_fused = run.launch_grad(x, True, with_lp=True)
+                if lp_fused is not None:
+                    self._last_sqnorm, self._logprob_done = None, False
+                    return (lp_fused, lp_fused.detach().double().sum().reshape(1)) if return_sum else lp_fused
         if std and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0:
             lp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
             total = torch.zeros(1, dtype=torch.float64, device=x.device) if return_sum else None
