@@ -205,12 +205,14 @@ def test_split_gradient_kernel_with_one_net_per_wave_passes_the_same_parity_test
     assert " passed" in out.stdout and "failed" not in out.stdout
 
 
-@pytest.mark.parametrize("rows", [1007, 4096])
-def test_log_prob_training_node_matches_the_unfused_route(amd, rows):
+@pytest.mark.parametrize("rows,n_layers,x_scale,s_gain", [(1007, 9, 1.0, 2.0), (4096, 9, 1.0, 2.0), (1007, 2, 2500.0, 0.002)])
+def test_log_prob_training_node_matches_the_unfused_route(amd, rows, n_layers, x_scale, s_gain):
     """`-model.log_prob(x).mean()` under a standard-normal base with the whole model one run of AffineHalfFlow layers:
     ONE autograd node from x to log p (the stack kernel's log-prob epilogue forward; the last layer's cotangents formed
     inside mnf_affine_half_bwd_split_lp backward) against the unfused route (log_det + base.log_prob(z) with its own
-    autograd link, validated against the float64 oracle by tests/test_hip_autograd.py)."""
+    autograd link, validated against the float64 oracle by tests/test_hip_autograd.py).  The third case scales x
+    beyond the split range (two layers, |x| up to ~1e4 > 8192): most 16-row tiles go to the fp32 fix-up pass, which
+    then reads the grad_y rows the split kernel left in its scratch buffer."""
     dim = 64
     flows_mod = amd.flows
     floor, flows_mod._BWD_SPLIT_MIN_ROWS = flows_mod._BWD_SPLIT_MIN_ROWS, 0
@@ -218,12 +220,12 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows):
         results = {}
         for fused in (True, False):
             layers = []
-            for i, sd in enumerate(recipes.c2_stack_params(dim)):
+            for i in range(n_layers):
                 f = amd.AffineHalfFlow(dim, parity=bool(i % 2))
-                f.load_state_dict(sd)
+                f.load_state_dict(recipes.affine_half_params(1000 + i, dim, s_last_gain=s_gain))
                 layers.append(f)
             model = amd.NormalizingFlowModel(amd.StandardNormal(dim), layers).to(DEV)
-            x = recipes.gaussian(77, rows, dim).to(DEV).requires_grad_(True)
+            x = (recipes.gaussian(77, rows, dim) * x_scale).to(DEV).requires_grad_(True)
             w = recipes.gaussian(78, rows, 1)[:, 0].to(DEV)  # a row-dependent cotangent, not just 1 / rows
             env, flows_mod._NO_FUSED_LOGPROB_ENV = flows_mod._NO_FUSED_LOGPROB_ENV, not fused
             try:
@@ -232,6 +234,7 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows):
             finally:
                 flows_mod._NO_FUSED_LOGPROB_ENV = env
             results[fused] = (lp.detach(), x.grad, {n: p.grad for n, p in model.named_parameters()})
+        assert bool(torch.isfinite(results[False][0]).all()) and bool(torch.isfinite(results[False][1]).all())
         assert float((results[True][0] - results[False][0]).abs().max()) <= 2e-5 * float(results[False][0].abs().max())
         assert normwise_err(results[True][1].cpu().numpy(), results[False][1].cpu().numpy()) <= 2e-6
         for n, g in results[False][2].items():
