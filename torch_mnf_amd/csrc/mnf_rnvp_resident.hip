@@ -324,8 +324,15 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
       primed = true;
     }
     // log_det of the rows, read early: its wait must not be the one that drains the loop's loads at the end
-    float ld_prev = 0.f;
-    if (accumulate && q == 0) ld_prev = log_det[row];
+    // (Round 4: as a C++ load under `if (accumulate && q == 0)` its use at the group's end made hipcc wait vmcnt(0) there
+    //  -- behind a load under a branch its wait counts are not exact --, i.e. for the NEXT group's rows and this
+    //  group's stores: the launches that add to log_det took 590 us against 550.  Now an asm load into a240, issued
+    //  by every lane without a branch, read back at the end behind a counted wait: vector-memory operations complete
+    //  in order and ops_group() of them are issued behind it -- with more than 63, the counter's range, no wait at all.)
+    {
+      const float* ldp = accumulate ? log_det + row : z;
+      asm volatile("global_load_dword a240, %0, off" ::"v"(ldp) : "memory", "a240");
+    }
 
     // ---- GEMM 1: y^T += Wn[:, 32 dims] (m z)^T, two 16-dim groups per K-step.  Software pipeline, one K-step per
     // slot (one wave per SIMD: nothing else hides a latency): slot k issues the MFMAs of K-step k - 1 (operands read
@@ -475,6 +482,8 @@ rnvp_resident_kernel(const float* __restrict__ z, float* __restrict__ x, float* 
     });
     {  // (log_det is never null here: a conditional use would let the compiler sink the 4 G adds of ld2 down to it)
       const float ld = sum_over_q(-0.693147180559945309f * ld2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::ops_group() < 63 ? P::ops_group() : 63) : "memory");
+      const float ld_prev = accumulate ? __builtin_bit_cast(float, agpr_get<240>()) : 0.f;
       if (q == 0) log_det[row] = ld_prev + ld;
     }
   }
