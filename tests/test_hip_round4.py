@@ -241,3 +241,100 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows, n_layers, x
             assert normwise_err(results[True][2][n].cpu().numpy(), g.cpu().numpy()) <= 5e-6, n
     finally:
         flows_mod._BWD_SPLIT_MIN_ROWS = floor
+
+
+# ------------------------------------------------------------------------ Glow.inverse + ActNormFlow.inverse, fused
+def _pair_case(seed, rows, dim=32):
+    """(u, M, s, t, cotangent) in float64 on the host; M a well-conditioned dense matrix."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(rows, dim, generator=g, dtype=torch.float64) * 1.7 + 0.3
+    M = torch.eye(dim, dtype=torch.float64) + 0.2 * torch.randn(dim, dim, generator=g, dtype=torch.float64)
+    s = 0.5 * torch.randn(1, dim, generator=g, dtype=torch.float64)
+    t = torch.randn(1, dim, generator=g, dtype=torch.float64)
+    gz = torch.randn(rows, dim, generator=g, dtype=torch.float64) / max(rows, 1)
+    return u, M, s, t, gz
+
+
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 63, 1000, 4099, 70001])
+def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
+    """mnf_glow_actnorm_inv / _bwd against the oracle's two layers composed in float64 (oracle.glow's product with M
+    given, then oracle.affine_const inverse) and torch.autograd through them.  fp32 MFMA products, fp32 sums over the
+    rows by atomics: 2e-6 normwise on the rows, 2e-5 on the sums over up to 70,001 rows."""
+    lib, flows_mod = amd._lib.load(), amd.flows
+    u, M, s, t, gz = _pair_case(100 + rows, rows)
+    u64, M64, s64, t64 = (a.clone().requires_grad_(True) for a in (u, M, s, t))
+    z64, _ = O.affine_const(u64 @ M64, s64, t64, inverse=True)
+    z64.backward(gz)
+    ud, Md, gzd = u.float().to(DEV), M.float().to(DEV).contiguous(), gz.float().to(DEV)
+    post = torch.cat((torch.exp(-s.float().reshape(-1)), t.float().reshape(-1))).to(DEV).contiguous()
+    table = flows_mod._linear_rows_table(lib, 32, ud.device)
+    img = flows_mod._linear_rows_image(lib, Md, table)
+    img_t = flows_mod._linear_rows_image(lib, Md.t().contiguous(), table)
+    z = torch.empty_like(ud)
+    amd._lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
+        ud.data_ptr(), img.data_ptr(), post.data_ptr(), z.data_ptr(), rows, 32, None))
+    gu = torch.full_like(ud, float("nan"))
+    gM, gs, gt = torch.zeros(32, 32, device=DEV), torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
+        ud.data_ptr(), gzd.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+        gs.data_ptr(), gt.data_ptr(), rows, 32, None))
+    torch.cuda.synchronize()
+    assert _err(z.double(), z64) <= 2e-6
+    assert _err(gu.double(), u64.grad) <= 2e-6
+    assert _err(gM.double(), M64.grad) <= 2e-5
+    assert _err(gs.double(), s64.grad.reshape(-1)) <= 2e-5
+    assert _err(gt.double(), t64.grad.reshape(-1)) <= 2e-5
+    # the sums are ADDED to, and either column sum may be left out
+    amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
+        ud.data_ptr(), gzd.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+        None, gt.data_ptr(), rows, 32, None))
+    torch.cuda.synchronize()
+    assert _err(gM.double(), 2 * M64.grad) <= 2e-5 and _err(gt.double(), 2 * t64.grad.reshape(-1)) <= 2e-5
+
+
+def test_glow_actnorm_inverse_pair_rejects_what_it_has_no_kernel_for(amd):
+    lib = amd._lib.load()
+    a = torch.zeros(64, 64, device=DEV)
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 32, None) \
+        == amd._lib.MNF_ERR_INVALID_ARG  # in place
+    b = torch.zeros(64, 64, device=DEV)
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 64, 64, None) \
+        == amd._lib.MNF_ERR_UNSUPPORTED
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 0, 32, None) == amd._lib.MNF_OK
+    assert lib.mnf_glow_actnorm_inv_bwd(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), None,
+                                        b.data_ptr(), None, None, 64, 32, None) == amd._lib.MNF_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("rows", [777, 8192])
+def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(amd, rows):
+    """-mean log_prob of 3 x [ActNormFlow, Glow, NSF_CL] at d = 32 (bench.py's c3t model): the pass with Glow.inverse +
+    ActNormFlow.inverse as one autograd node (the default under log_prob) against the same pass layer by layer
+    (MNF_NO_PAIR_FUSION=1, whose gradients tests/test_hip_autograd.py checks against the float64 oracle)."""
+    flows_mod = amd.flows
+    results = {}
+    for fused in (True, False):
+        torch.manual_seed(11)
+        layers = []
+        for _ in range(3):
+            layers += [amd.ActNormFlow(32), amd.Glow(32), amd.NSF_CL(32, K=8, B=3, n_h=8)]
+        model = amd.NormalizingFlowModel(amd.StandardNormal(32), layers).to(DEV)
+        x = recipes.gaussian(5, rows, 32).to(DEV).requires_grad_(True)
+        with torch.no_grad():
+            model.log_prob(x.detach())  # ActNorm's data-dependent initialisation
+        env, flows_mod._NO_PAIR_FUSION_ENV = flows_mod._NO_PAIR_FUSION_ENV, not fused
+        try:
+            loss = -model.log_prob(x).mean()
+            loss.backward()
+        finally:
+            flows_mod._NO_PAIR_FUSION_ENV = env
+        results[fused] = (loss.detach(), x.grad, {n: p.grad for n, p in model.named_parameters()})
+    assert abs(float(results[True][0]) - float(results[False][0])) <= 1e-6 * abs(float(results[False][0]))
+    assert _err(results[True][1], results[False][1]) <= 5e-6
+    for n, g in results[False][2].items():
+        assert g is not None and results[True][2][n] is not None, n
+        if n.endswith(".s"):
+            # ActNorm's s right after its data-dependent initialisation: +1 from log_det and -(1 - 1/rows) from the rows
+            # cancel to 1/rows, so the budget is the fp32 error of the O(1) terms, not of their difference
+            assert float((results[True][2][n] - g).abs().max()) <= 2e-6, n
+        else:
+            assert _err(results[True][2][n], g) <= 2e-5, n

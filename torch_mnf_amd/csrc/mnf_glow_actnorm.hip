@@ -1,0 +1,263 @@
+// Glow.inverse followed by ActNormFlow.inverse -- the pair every [ActNormFlow, Glow, NSF_CL] block applies after its
+// spline layer on the way x -> z, i.e. in every log_prob / training pass (torch_mnf/flows/glow.py:33-37,
+// affine_constant_flow.py:22-26) -- as ONE forward launch and ONE gradient launch for d = 32:
+//
+//   forward    z = (u @ M - t) e^-s                                  M = W^-1 (Glow's assembled inverse)
+//   gradients  g_v = g_z e^-s      g_u = g_v @ M^T      g_M = u^T g_v
+//              g_s = -sum_r g_z z  g_t = -sum_r g_v                   (z is recomputed from u: never read)
+//
+// As separate layers the training step moved 14 d floats per row through HBM for this pair (ActNorm and Glow each
+// read and write the rows forward, then Glow's two gradient launches and ActNorm's one read 2 + 2 + 2 arrays and write
+// 2); fused it is 2 d forward (u in, z out) and 3 d backward (u, g_z in, g_u out).  Both launches are HBM bound; the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products) do all three products.
+//
+// Two register layouts of the same rows meet in the gradient kernel:
+//   * "row on the lane" (mnf_linear_mfma.hip): lane (j, q) holds dims 16 g + 4 q + e of row j of a 16-row tile as
+//     float4s; u @ M and g_v @ M^T run in it, and so do the elementwise gradients and the column sums.
+//   * "rows on the K axis" (xtg32_mfma_kernel in mnf_backward.hip): lane (c, k) holds dims c and c + 16 of row k of a
+//     4-row group; u^T g_v is a sum over rows and needs them on K.  The second layout is loaded from memory again
+//     (the same 4 KB the wave has just pulled in: L2 hits, no HBM traffic).
+// Every load and store of the row loop is issued unconditionally (rows past the end read / rewrite the last row and
+// are masked out of the sums): hipcc's vmcnt counts stay exact, the next tile's rows are in flight under this one's
+// arithmetic.
+#include <hip/hip_runtime.h>
+
+#include "mnf_device.h"
+#include "mnf_host.h"
+
+namespace mnf {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kGaWaves = 4;
+constexpr int kGaD = 32;
+
+// acc[m] += image (A operand order of mnf_linear_rows_image_index) x rows held as xv (B operand)
+__device__ __forceinline__ void rows_times_image(const float* lds_image, int lane, const f32x4 (&xv)[2], f32x4 (&acc)[2]) {
+  constexpr int G = kGaD / 16, NK = kGaD / 4;
+  int a_off = lane * 4;
+  asm volatile("" : "+v"(a_off));  // keep the operand reads in the loop (see mnf_ahf_mfma.hip)
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(lds_image + a_off);
+  int n = 0;
+  f32x4 a4;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      if ((n & 3) == 0) a4 = A4[64 * (n >> 2)];
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[n & 3], xv[kk >> 2][kk & 3], acc[m], 0, 0, 0);
+      ++n;
+    }
+}
+
+__device__ __forceinline__ void stage_image(float* lds, const float* image) {
+  const float4* src = reinterpret_cast<const float4*>(image);
+  float4* dst = reinterpret_cast<float4*>(lds);
+  for (int i = threadIdx.x; i < kGaD * kGaD / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// z = (u @ M - t) e^-s; post = [e^-s (32) | t (32)]
+__global__ void __launch_bounds__(kGaWaves * 64)
+glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ image, const float* __restrict__ post,
+                        float* __restrict__ z, int64_t rows) {
+  __shared__ __attribute__((aligned(16))) float lds[kGaD * kGaD];
+  stage_image(lds, image);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  f32x4 es[2], tt[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    es[m] = *reinterpret_cast<const f32x4*>(post + 16 * m + 4 * q);
+    tt[m] = *reinterpret_cast<const f32x4*>(post + kGaD + 16 * m + 4 * q);
+  }
+  const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * kGaWaves;
+  auto row_of = [&](int tile) {
+    const int64_t row = (int64_t)tile * 16 + j;
+    return row < rows ? row : rows - 1;
+  };
+  int tile = (int)blockIdx.x * kGaWaves + wave;
+  if (tile >= n_tiles) return;
+  f32x4 nx[2];
+  {
+    const float* p = u + row_of(tile) * kGaD + 4 * q;
+    nx[0] = *reinterpret_cast<const f32x4*>(p);
+    nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
+  }
+  for (; tile < n_tiles; tile += step) {
+    const f32x4 xv[2] = {nx[0], nx[1]};
+    {  // the next tile's rows (past the end: the last tile's again)
+      const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
+      const float* p = u + row_of(nt) * kGaD + 4 * q;
+      nx[0] = *reinterpret_cast<const f32x4*>(p);
+      nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    rows_times_image(lds, lane, xv, acc);
+    float* zr = z + row_of(tile) * kGaD + 4 * q;  // (rows past the end rewrite the last row with its own values)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(zr + 16 * m) = (acc[m] - tt[m]) * es[m];
+  }
+}
+
+__global__ void __launch_bounds__(kGaWaves * 64)
+glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ image,
+                            const float* __restrict__ image_t, const float* __restrict__ post,
+                            float* __restrict__ gu, float* __restrict__ grad_m, float* __restrict__ grad_s,
+                            float* __restrict__ grad_t, int64_t rows) {
+  __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  __shared__ float red_st[2 * kGaD];
+  stage_image(lds_m, image);
+  stage_image(lds_mt, image_t);
+  if (threadIdx.x < 2 * kGaD) red_st[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;  // row-on-the-lane layout
+  const int c = lane & 15, k = lane >> 4;  // rows-on-K layout
+  f32x4 es[2], tt[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    es[m] = *reinterpret_cast<const f32x4*>(post + 16 * m + 4 * q);
+    tt[m] = *reinterpret_cast<const f32x4*>(post + kGaD + 16 * m + 4 * q);
+  }
+  const float es_c[2] = {post[c], post[c + 16]};
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 wacc[2][2] = {{zero4, zero4}, {zero4, zero4}};  // g_M tiles, summed over this wave's rows
+  f32x4 sacc[2] = {zero4, zero4}, tacc[2] = {zero4, zero4};
+  const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * kGaWaves;
+  auto row_of = [&](int tile) {
+    const int64_t row = (int64_t)tile * 16 + j;
+    return row < rows ? row : rows - 1;
+  };
+  int tile = (int)blockIdx.x * kGaWaves + wave;
+  f32x4 nu[2], ng[2];
+  {
+    const int t0 = tile < n_tiles ? tile : n_tiles - 1;
+    const int64_t off = row_of(t0) * kGaD + 4 * q;
+    nu[0] = *reinterpret_cast<const f32x4*>(u + off);
+    nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
+    ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
+    ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+  }
+  for (; tile < n_tiles; tile += step) {
+    const f32x4 uv[2] = {nu[0], nu[1]}, gv_in[2] = {ng[0], ng[1]};
+    {  // the next tile's rows in the first layout
+      const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
+      const int64_t off = row_of(nt) * kGaD + 4 * q;
+      nu[0] = *reinterpret_cast<const f32x4*>(u + off);
+      nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
+      ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
+      ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+    }
+    // this tile's rows in the second layout (four 4-row groups; consumed after the two row products below)
+    float ua[4][2], ga[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t row = (int64_t)tile * 16 + 4 * g + k;
+      const float on = row < rows ? 1.f : 0.f;
+      const int64_t off = (row < rows ? row : rows - 1) * kGaD + c;
+      ua[g][0] = u[off] * on;
+      ua[g][1] = u[off + 16] * on;
+      ga[g][0] = gz[off];
+      ga[g][1] = gz[off + 16];
+    }
+    const float live = (int64_t)tile * 16 + j < rows ? 1.f : 0.f;
+    // z = (u @ M - t) e^-s, recomputed; g_s -= g_z z; g_v = g_z e^-s; g_t -= g_v
+    f32x4 acc[2] = {zero4, zero4};
+    rows_times_image(lds_m, lane, uv, acc);
+    f32x4 gv[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x4 zz = (acc[m] - tt[m]) * es[m];
+      gv[m] = gv_in[m] * es[m];
+      sacc[m] -= gv_in[m] * zz * live;
+      tacc[m] -= gv[m] * live;
+    }
+    // g_u = g_v @ M^T
+    f32x4 gacc[2] = {zero4, zero4};
+    rows_times_image(lds_mt, lane, gv, gacc);
+    float* gr = gu + row_of(tile) * kGaD + 4 * q;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(gr + 16 * m) = gacc[m];
+    // g_M += u^T g_v, 4 rows per MFMA
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[g][a], ga[g][b] * es_c[b], wacc[a][b], 0, 0, 0);
+  }
+  // column sums: the 16 row lanes of a q group hold the same 8 columns
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(red_st + 16 * m + 4 * q + r, sacc[m][r]);
+      atomicAdd(red_st + kGaD + 16 * m + 4 * q + r, tacc[m][r]);
+    }
+  for (int w = 0; w < kGaWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4* p = reinterpret_cast<f32x4*>(red + t * 256 + lane * 4);
+        *p = w == 0 ? wacc[t >> 1][t & 1] : *p + wacc[t >> 1][t & 1];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    const int t = e >> 8, l = (e >> 2) & 63, reg = e & 3;
+    const int i = 16 * (t >> 1) + 4 * (l >> 4) + reg, jj = 16 * (t & 1) + (l & 15);
+    atomicAdd(grad_m + i * kGaD + jj, red[e]);
+  }
+  if (threadIdx.x < kGaD) {
+    if (grad_s) atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x]);
+    if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[kGaD + threadIdx.x]);
+  }
+}
+
+int64_t grid_for_tiles(int64_t rows, int per_cu) {
+  const int64_t n_tiles = (rows + 15) / 16;
+  int64_t blocks = (n_tiles + kGaWaves - 1) / kGaWaves;
+  const int64_t cap = (int64_t)per_cu * device_cus(current_device());
+  return blocks > cap ? cap : blocks;
+}
+
+bool aligned16(const void* a, const void* b, const void* c2) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c2)) & 15) == 0;
+}
+
+}  // namespace
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" {
+
+int mnf_glow_actnorm_inv(const float* u, const float* image, const float* post, float* z, int64_t rows, int dim,
+                         void* stream) {
+  if (!u || !image || !post || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
+  if (dim != kGaD || !aligned16(u, z, image) || !aligned16(post, post, post) || rows >= (int64_t)1 << 31)
+    return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(glow_actnorm_inv_kernel, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
+                     (hipStream_t)stream, u, image, post, z, rows);
+  return check_launch();
+}
+
+int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* image, const float* image_t,
+                             const float* post, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
+                             int64_t rows, int dim, void* stream) {
+  if (!u || !grad_z || !image || !image_t || !post || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
+    return MNF_ERR_INVALID_ARG;
+  if (dim != kGaD || !aligned16(u, grad_z, grad_u) || !aligned16(image, image_t, post) || rows >= (int64_t)1 << 31)
+    return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel, dim3((unsigned)grid_for_tiles(rows, 4)), dim3(kGaWaves * 64), 0,
+                     (hipStream_t)stream, u, grad_z, image, image_t, post, grad_u, grad_m, grad_s, grad_t, rows);
+  return check_launch();
+}
+
+}  // extern "C"

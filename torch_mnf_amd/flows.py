@@ -584,11 +584,75 @@ def _linear_rows(lib, x: Tensor, W: Tensor, y: Tensor) -> None:
         _lib.check("mnf_linear_rows", lib.mnf_linear_rows(x.data_ptr(), W.data_ptr(), y.data_ptr(), x.shape[0], dim,
                                                           _stream()))
         return
-    img = torch.empty(table.numel(), dtype=torch.float32, device=x.device)
-    _lib.check("mnf_pack_gather", lib.mnf_pack_gather(W.data_ptr(), table.data_ptr(), img.data_ptr(), table.numel(),
-                                                      _stream()))
+    img = _linear_rows_image(lib, W, table)
     _lib.check("mnf_linear_rows_img", lib.mnf_linear_rows_img(x.data_ptr(), img.data_ptr(), y.data_ptr(), x.shape[0],
                                                               dim, _stream()))
+
+
+def _linear_rows_image(lib, W: Tensor, table: Tensor) -> Tensor:
+    """W (dim, dim, contiguous) in the MFMA kernels' operand order: one small gather launch."""
+    img = torch.empty(table.numel(), dtype=torch.float32, device=W.device)
+    _lib.check("mnf_pack_gather", lib.mnf_pack_gather(W.data_ptr(), table.data_ptr(), img.data_ptr(), table.numel(),
+                                                      _stream()))
+    return img
+
+
+def _linear_rows_table(lib, dim: int, device) -> Tensor | None:
+    key = (dim, device)
+    if key not in _LINEAR_ROWS_INDEX:
+        n = lib.mnf_linear_rows_image_floats(dim)
+        table = None
+        if n > 0:
+            idx = (ctypes.c_int32 * n)()
+            _lib.check("mnf_linear_rows_image_index", lib.mnf_linear_rows_image_index(dim, idx))
+            table = torch.frombuffer(idx, dtype=torch.int32).clone().to(device)
+        _LINEAR_ROWS_INDEX[key] = table
+    return _LINEAR_ROWS_INDEX[key]
+
+
+_PAIR_FUSION_DIM = 32  # mnf_glow_actnorm_inv / _bwd (csrc/mnf_glow_actnorm.hip)
+_NO_PAIR_FUSION_ENV = os.environ.get("MNF_NO_PAIR_FUSION", "0") == "1"
+
+
+class _GlowActNormInvFn(torch.autograd.Function):
+    """Glow.inverse then ActNormFlow.inverse -- z = (u @ M - t) e^-s, M = W^-1 -- as ONE autograd node with one launch
+    each way (glow.py:33-37, affine_constant_flow.py:22-26).  The intermediate u @ M is never written; the gradient
+    launch reads u and grad_z once and produces grad_u, grad_M, grad_s and grad_t."""
+
+    @staticmethod
+    def forward(ctx, u, M, s, t):
+        lib = _lib.load()
+        table = _linear_rows_table(lib, u.shape[1], u.device)
+        Mc = M.detach().contiguous()
+        sc = s.detach().to(u.device, torch.float32).reshape(-1)
+        tc = t.detach().to(u.device, torch.float32).reshape(-1)
+        post = torch.cat((torch.exp(-sc), tc)).contiguous()
+        z = torch.empty_like(u)
+        img = _linear_rows_image(lib, Mc, table)
+        _lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
+            u.data_ptr(), img.data_ptr(), post.data_ptr(), z.data_ptr(), u.shape[0], u.shape[1], _stream()))
+        ctx.save_for_backward(u, Mc, post)
+        ctx.shapes = (s.shape, t.shape)
+        return z
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_z):
+        u, Mc, post = ctx.saved_tensors
+        lib = _lib.load()
+        dim = u.shape[1]
+        table = _linear_rows_table(lib, dim, u.device)
+        gz = grad_z.contiguous()
+        gu = torch.empty_like(u)
+        sums = torch.zeros(dim * dim + 2 * dim, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t
+        gM, gs, gt = sums[:dim * dim], sums[dim * dim:dim * dim + dim], sums[dim * dim + dim:]
+        # (both images stay referenced until the launch is queued: a temporary freed in between hands its block to the next)
+        img, img_t = _linear_rows_image(lib, Mc, table), _linear_rows_image(lib, Mc.t().contiguous(), table)
+        _lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
+            u.data_ptr(), gz.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(),
+            gM.data_ptr(), gs.data_ptr(), gt.data_ptr(), u.shape[0], dim, _stream()))
+        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(ctx.shapes[0]),
+                gt.view(ctx.shapes[1]))
 
 
 class _LinearRowsFn(torch.autograd.Function):
@@ -2096,6 +2160,25 @@ class FusedAffineStack(_TwoWayFlow):
         return y, ld
 
 
+def _pair_fusable(glow: "Glow", actnorm: "ActNormFlow", x) -> bool:
+    """Training pass, x -> z: can Glow.inverse + ActNormFlow.inverse at this input go out as the fused pair?"""
+    return (not _NO_PAIR_FUSION_ENV and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+            and x.dtype == torch.float32 and glow.dim == actnorm.dim == x.shape[1] == _PAIR_FUSION_DIM
+            and actnorm.data_dep_init_done is not False and not glow.force_generic
+            and glow.L.is_cuda and glow.L.device == x.device and glow.L.dtype == torch.float32
+            and _wants_grad(glow, x) and _wants_grad(actnorm, x))
+
+
+def _glow_actnorm_inverse(glow: "Glow", actnorm: "ActNormFlow", x: Tensor) -> tuple[Tensor, Tensor]:
+    xg = _grad_input(x)
+    params = [glow.L, glow.S, glow.U]
+    home = _flat_home_of(glow, params) if all(p.requires_grad for p in params) else None
+    M, ld_glow = _GlowWeightFn.apply(glow.L, glow.S, glow.U, glow._P_on(xg.device).to(torch.float32).contiguous(), True,
+                                     home)
+    z = _GlowActNormInvFn.apply(xg, M, actnorm.s.to(xg.device), actnorm.t.to(xg.device))
+    return z, ld_glow + torch.sum(-actnorm.s, dim=1).to(xg.device)
+
+
 class NormalizingFlow(nn.Module):
     """Runs flows in order (forward) or reversed (inverse), summing log|det J| and keeping every
     intermediate (flows/core.py:10-35).  Layers from this package accumulate ``log_det`` inside
@@ -2145,8 +2228,11 @@ class NormalizingFlow(nn.Module):
             self.__dict__["_runs_cache"] = cache
         return cache[1]
 
-    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None, want_logprob=None):
+    def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None, want_logprob=None,
+              last_only: bool = False):
         """prologue (forward only, first flow an RNVP): see RNVP._run; the returned list then starts with eps.
+        last_only: the caller reads only the last tensor of the returned list (log_prob): pairs of layers with a fused
+        training kernel go out as one autograd node and their intermediate is not materialised.
         want_logprob = (lp, total-or-None): when the LAST launch is an affine run whose kernel can add the
         standard-normal epilogue, it fills them and ``self._logprob_done`` is set."""
         n = len(self.flows)
@@ -2218,6 +2304,13 @@ class NormalizingFlow(nn.Module):
                     x = outs[-1]
                 else:
                     span, last = 1, i + 1 == n
+            if (outs is None and last_only and inverse and i + 1 < n and type(flow) is Glow
+                    and type(order[i + 1]) is ActNormFlow and _pair_fusable(flow, order[i + 1], x)):
+                # Glow.inverse + ActNormFlow.inverse of a training pass: one launch each way (csrc/mnf_glow_actnorm.hip)
+                x, ld = _glow_actnorm_inverse(flow, order[i + 1], x)
+                log_det = ld if log_det is None else log_det + ld
+                seen.append(x)
+                span, outs = 2, [x]
             if outs is None:
                 if (want_sqnorm and last and isinstance(flow, (AffineHalfFlow, FusedAffineStack))
                         and x.is_cuda and x.shape[0] > 0 and not _wants_grad(flow, x) and flow.emits_sqnorm(x.device)):
@@ -2370,7 +2463,8 @@ class NormalizingFlowModel(NormalizingFlow):
         if std and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0:
             lp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
             total = torch.zeros(1, dtype=torch.float64, device=x.device) if return_sum else None
-        zs, log_det = self._pass(x, True, want_sqnorm=std, want_logprob=(lp, total) if lp is not None else None)
+        zs, log_det = self._pass(x, True, want_sqnorm=std, want_logprob=(lp, total) if lp is not None else None,
+                                 last_only=True)
         z = zs[-1]
         if self._logprob_done:  # the last coupling launch already produced log p and its sum
             return (lp, total) if return_sum else lp
