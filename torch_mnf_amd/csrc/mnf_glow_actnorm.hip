@@ -15,8 +15,11 @@
 //   * "row on the lane" (mnf_linear_mfma.hip): lane (j, q) holds dims 16 g + 4 q + e of row j of a 16-row tile as
 //     float4s; u @ M and g_v @ M^T run in it, and so do the elementwise gradients and the column sums.
 //   * "rows on the K axis" (xtg32_mfma_kernel in mnf_backward.hip): lane (c, k) holds dims c and c + 16 of row k of a
-//     4-row group; u^T g_v is a sum over rows and needs them on K.  The second layout is loaded from memory again
-//     (the same 4 KB the wave has just pulled in: L2 hits, no HBM traffic).
+//     4-row group; u^T g_v is a sum over rows and needs them on K.  The wave turns its tile through a private 6 KB of
+//     LDS (row pitch 48 floats: both the float4 writes and the per-row-group reads are conflict free).  Loading the
+//     second layout from memory again was measured first: 106-111 us per launch at 2^20 rows, and SLOWER with more
+//     waves resident (139 us at four per SIMD) -- the re-read comes an iteration after the first touch, by which time
+//     the other waves' streams have pushed the lines out of the XCD's L2.
 // Every load and store of the row loop is issued unconditionally (rows past the end read / rewrite the last row and
 // are masked out of the sums): hipcc's vmcnt counts stay exact, the next tile's rows are in flight under this one's
 // arithmetic.
@@ -31,6 +34,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGaWaves = 4;
 constexpr int kGaD = 32;
+constexpr int kGaPitch = 48;  // floats per row of the wave's turn buffer: rows 4 g + k land 16 banks apart
 
 // acc[m] += image (A operand order of mnf_linear_rows_image_index) x rows held as xv (B operand)
 __device__ __forceinline__ void rows_times_image(const float* lds_image, int lane, const f32x4 (&xv)[2], f32x4 (&acc)[2]) {
@@ -100,13 +104,15 @@ glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ i
   }
 }
 
-__global__ void __launch_bounds__(kGaWaves * 64)
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ image,
                             const float* __restrict__ image_t, const float* __restrict__ post,
                             float* __restrict__ gu, float* __restrict__ grad_m, float* __restrict__ grad_s,
                             float* __restrict__ grad_t, int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * kGaPitch];
   __shared__ float red_st[2 * kGaD];
   stage_image(lds_m, image);
   stage_image(lds_mt, image_t);
@@ -121,16 +127,17 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
     es[m] = *reinterpret_cast<const f32x4*>(post + 16 * m + 4 * q);
     tt[m] = *reinterpret_cast<const f32x4*>(post + kGaD + 16 * m + 4 * q);
   }
-  const float es_c[2] = {post[c], post[c + 16]};
+  float* const my_u = &turn[wave][0][0];
+  float* const my_g = &turn[wave][1][0];
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 wacc[2][2] = {{zero4, zero4}, {zero4, zero4}};  // g_M tiles, summed over this wave's rows
   f32x4 sacc[2] = {zero4, zero4}, tacc[2] = {zero4, zero4};
-  const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * kGaWaves;
+  const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * WAVES;
   auto row_of = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
     return row < rows ? row : rows - 1;
   };
-  int tile = (int)blockIdx.x * kGaWaves + wave;
+  int tile = (int)blockIdx.x * WAVES + wave;
   f32x4 nu[2], ng[2];
   {
     const int t0 = tile < n_tiles ? tile : n_tiles - 1;
@@ -150,18 +157,6 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
       ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
       ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
     }
-    // this tile's rows in the second layout (four 4-row groups; consumed after the two row products below)
-    float ua[4][2], ga[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t row = (int64_t)tile * 16 + 4 * g + k;
-      const float on = row < rows ? 1.f : 0.f;
-      const int64_t off = (row < rows ? row : rows - 1) * kGaD + c;
-      ua[g][0] = u[off] * on;
-      ua[g][1] = u[off + 16] * on;
-      ga[g][0] = gz[off];
-      ga[g][1] = gz[off + 16];
-    }
     const float live = (int64_t)tile * 16 + j < rows ? 1.f : 0.f;
     // z = (u @ M - t) e^-s, recomputed; g_s -= g_z z; g_v = g_z e^-s; g_t -= g_v
     f32x4 acc[2] = {zero4, zero4};
@@ -173,6 +168,9 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
       gv[m] = gv_in[m] * es[m];
       sacc[m] -= gv_in[m] * zz * live;
       tacc[m] -= gv[m] * live;
+      // the tile for the second layout (rows past the end: zeros on the u side)
+      *reinterpret_cast<f32x4*>(my_u + j * kGaPitch + 16 * m + 4 * q) = uv[m] * live;
+      *reinterpret_cast<f32x4*>(my_g + j * kGaPitch + 16 * m + 4 * q) = gv[m];
     }
     // g_u = g_v @ M^T
     f32x4 gacc[2] = {zero4, zero4};
@@ -180,14 +178,19 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
     float* gr = gu + row_of(tile) * kGaD + 4 * q;
 #pragma unroll
     for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(gr + 16 * m) = gacc[m];
-    // g_M += u^T g_v, 4 rows per MFMA
+    // g_M += u^T g_v, 4 rows per MFMA (LDS operations of a wave run in order: its reads see its lanes' writes)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+      const int at = (4 * g + k) * kGaPitch + c;
+      const float ua[2] = {my_u[at], my_u[at + 16]}, ga[2] = {my_g[at], my_g[at + 16]};
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[g][a], ga[g][b] * es_c[b], wacc[a][b], 0, 0, 0);
+          wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[a], ga[b], wacc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   // column sums: the 16 row lanes of a q group hold the same 8 columns
 #pragma unroll
@@ -197,7 +200,7 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
       atomicAdd(red_st + 16 * m + 4 * q + r, sacc[m][r]);
       atomicAdd(red_st + kGaD + 16 * m + 4 * q + r, tacc[m][r]);
     }
-  for (int w = 0; w < kGaWaves; ++w) {
+  for (int w = 0; w < WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -218,9 +221,9 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
   }
 }
 
-int64_t grid_for_tiles(int64_t rows, int per_cu) {
+int64_t grid_for_tiles(int64_t rows, int per_cu, int waves = kGaWaves) {
   const int64_t n_tiles = (rows + 15) / 16;
-  int64_t blocks = (n_tiles + kGaWaves - 1) / kGaWaves;
+  int64_t blocks = (n_tiles + waves - 1) / waves;
   const int64_t cap = (int64_t)per_cu * device_cus(current_device());
   return blocks > cap ? cap : blocks;
 }
@@ -255,8 +258,19 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* i
   if (dim != kGaD || !aligned16(u, grad_z, grad_u) || !aligned16(image, image_t, post) || rows >= (int64_t)1 << 31)
     return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel, dim3((unsigned)grid_for_tiles(rows, 4)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, grad_z, image, image_t, post, grad_u, grad_m, grad_s, grad_t, rows);
+#ifndef MNF_GA_BWD_WAVES
+#define MNF_GA_BWD_WAVES 4
+#endif
+#ifndef MNF_GA_BWD_PER_CU
+#define MNF_GA_BWD_PER_CU 2
+#endif
+  // eight waves per CU measured best at 2^20 rows (workgroups of 4 waves: 1 per CU 95 us, 2: 89, 3: 95, 4: 101; 8 waves
+  // x 2: 101, 16 x 1: 101 -- the same 8 waves as 8 x 1: 90, so it is not the count of closing atomics; the operand
+  // images held in registers instead of re-read from LDS per tile: 101)
+  hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES>,
+                     dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
+                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, image, image_t, post, grad_u,
+                     grad_m, grad_s, grad_t, rows);
   return check_launch();
 }
 
