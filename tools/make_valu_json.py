@@ -29,6 +29,7 @@ mfma_busy = mean_of("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
 gui = mean_of("pmc_sq2", "GRBM_GUI_ACTIVE")          # summed over the 8 XCDs
 wave_cycles = mean_of("pmc_sq", "SQ_WAVE_CYCLES")
 active = mean_of("pmc_sq", "SQ_ACTIVE_INST_ANY")
+active_valu = mean_of("pmc_sq2", "SQ_ACTIVE_INST_VALU")  # quad-cycles the waves spent inside vector instructions
 ns = kernel_ns()
 cycles = gui / 8.0                                     # shader cycles of the dispatch
 simds = 256 * 4
@@ -45,10 +46,19 @@ json.dump({
     "valu_instr_per_cycle": valu / cycles,
     "valu_issue_frac": issue_cycles / (simds * cycles),
     "mfma_pipe_frac": mfma_busy / (simds * cycles) if mfma_busy else None,
+    # measured, not priced: the share of the waves' resident cycles spent INSIDE a vector instruction (both counters are
+    # quad-cycles summed over the waves), the average length of one, and what that makes of the SIMDs' time
+    "SQ_ACTIVE_INST_VALU": active_valu,
+    "wave_cycles_in_valu_frac": active_valu / wave_cycles if active_valu and wave_cycles else None,
+    "cycles_per_valu_instr": 4.0 * active_valu / valu if active_valu else None,
+    "simd_valu_busy_frac": 4.0 * active_valu / (simds * cycles) if active_valu else None,
     "definition": "valu_issue_frac = (2 cycles x (SQ_INSTS_VALU - SQ_INSTS_MFMA) + 8 cycles x SQ_INSTS_MFMA) / (1024 SIMDs x "
                   "GRBM_GUI_ACTIVE / 8): the share of the dispatch's SIMD cycles in which a vector instruction was being "
                   "issued at the hardware's peak issue rate (transcendentals priced like plain instructions: a lower "
-                  "bound of the issue time)",
+                  "bound of the issue time).  simd_valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / the same SIMD cycles: how "
+                  "long the SIMDs' vector units were actually occupied (one wave's instruction occupies its SIMD for "
+                  "cycles_per_valu_instr cycles; MI355X_MICROARCH.md prices v_fma_f32 at 4 cycles for one wave's stream, "
+                  "transcendentals at 8)",
     "source": "rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload "
               f"{workload}` (tools/profile_bench.sh)",
 }, open(out, "w"), indent=1)

@@ -27,7 +27,7 @@ for w in $WL; do
     timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_write.log" 2>&1
     if true; then
       timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$P/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq.log" 2>&1
-      timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d "$P/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq2.log" 2>&1
+      timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$P/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$P/pmc_sq2.log" 2>&1
     fi )
   python3 tools/summarize_prof.py "$P" > "$OUT/${w}_rocprofv3_summary.txt" 2>&1
   cp "$P"/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null || cp "$P"/trace/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null
