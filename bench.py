@@ -790,9 +790,10 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
                      "kernel": "nsf_bwd_pairs_kernel<8,inverse> (one NSF_CL layer's gradients per launch; 3 launches per step)",
                      "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
                      "launches_timed": len(kern_ms), "launches_per_step": 3,
-                     "note": "vector-issue bound by construction (8.9e8 vector instructions per launch, issue 0.45 of "
-                             "capacity at two waves per SIMD: profiles/r4/c3t_valu_issue.json): the HBM "
-                             "fraction is low because the kernel's floor is arithmetic, not traffic (DESIGN.md 3.5)"},
+                     "note": "vector-unit bound by construction (8.9e8 vector instructions per launch at 4.2 cycles "
+                             "each: the SIMDs' vector units are occupied 0.91 of the launch, "
+                             "profiles/r4/c3t_valu_issue.json simd_valu_busy_frac): the HBM fraction is low because "
+                             "the kernel's floor is arithmetic, not traffic (DESIGN.md 3.5)"},
     }
     if not args.no_cpu_baseline:
         from oracle import flow_oracle as O
