@@ -338,3 +338,34 @@ def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(a
             assert float((results[True][2][n] - g).abs().max()) <= 2e-6, n
         else:
             assert _err(results[True][2][n], g) <= 2e-5, n
+
+
+def test_graphed_training_step_of_a_spline_block_with_the_fused_pair(amd):
+    """GraphedStep over 2 x [ActNormFlow, Glow, NSF_CL] at d = 32 -- the pair node's launches (operand-image gathers,
+    mnf_glow_actnorm_inv / _bwd, the sums buffer) recorded in a hipGraph -- against the same steps run eagerly."""
+    def build():
+        torch.manual_seed(21)
+        layers = []
+        for _ in range(2):
+            layers += [amd.ActNormFlow(32), amd.Glow(32), amd.NSF_CL(32, K=8, B=3, n_h=8)]
+        model = amd.NormalizingFlowModel(amd.StandardNormal(32), layers).to(DEV)
+        with torch.no_grad():
+            model.log_prob(recipes.gaussian(300, 2048, 32).to(DEV))  # ActNorm's data-dependent initialisation
+        return model, amd.FusedAdam(amd.FlatParameters(model), lr=1e-3, capturable=True)
+
+    batches = [recipes.gaussian(300 + i, 2048, 32).to(DEV) for i in range(9)]
+    model_e, opt_e = build()
+    losses_e = []
+    for x in [batches[0]] * 3 + batches[1:]:
+        opt_e.zero_grad()
+        loss = -model_e.log_prob(x).mean()
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss))
+    del loss
+    model_g, opt_g = build()
+    step = amd.GraphedStep(opt_g, lambda x: -model_g.log_prob(x).mean(), batches[0])
+    losses_g = [float(step(x)) for x in batches[1:]]
+    for a, b in zip(losses_e[3:], losses_g):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (a, b)
+    assert_close(opt_g.flat.data, opt_e.flat.data, 2e-3, "parameters after 11 steps")
