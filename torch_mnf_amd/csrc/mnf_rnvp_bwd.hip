@@ -92,7 +92,11 @@ struct RnvpBwdShape {
 
 // ================================================================================================ kernel A
 typedef __attribute__((address_space(3))) void* lds_void_ptr_a;
-constexpr int kBwdRing = 3;  // buffers of launch A's LDS operand window (chunks c, c + 1, c + 2)
+#ifndef MNF_A_DIST
+#define MNF_A_DIST 2
+#endif
+constexpr int kBwdDist = MNF_A_DIST;     // launch A requests its operands this many chunks ahead ...
+constexpr int kBwdRing = kBwdDist + 1;   // ... into a ring of this many LDS buffers (chunks c .. c + kBwdDist)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 #else
@@ -217,7 +221,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
     if (drain)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_DMA + 2) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_DMA * (kBwdDist - 1) + 2) : "memory");
   };
   auto row_group1 = [&](int c, int i) -> int {
     const int g = 2 * (c * KC) + i;
@@ -244,8 +248,8 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
 #pragma unroll
     for (int u = 0; u < D1; ++u) request_rows1(u, u);
   }
-  request_operands(c_first);
-  request_operands(c_first + 1);
+#pragma unroll
+  for (int u = 0; u < kBwdDist; ++u) request_operands(c_first + u);
   chunk_barrier(true);  // (the first chunk's pieces: the one exposed operand latency of the group)
   f32x4 ym[YT], yc[YT];
 #pragma unroll
@@ -279,7 +283,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
           bh[kk] = pair_operand(h0, h1);
           bl[kk] = pair_operand(l0, l1);
         }
-        request_operands(c + 2);  // (c + 1 == nc1: the first second-sweep tile)
+        request_operands(c + kBwdDist);  // (c + 1 == nc1: the first second-sweep tile)
         request_rows1(c + D1, u);
         const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
         const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
@@ -322,7 +326,7 @@ __device__ __forceinline__ void rnvp_bwd_group_a(uint32_t* lds0, const BufRsrc& 
   // (pairs of chunks without a guard around their requests -- see g_on above --, then the odd last one)
   auto chunk2 = [&](int c, auto u_c) {
     constexpr int u = decltype(u_c)::value;
-    request_operands2(c + 2);
+    request_operands2(c + kBwdDist);
     const uint32_t* buf = lds0 + (c % kBwdRing) * B::CHUNK_WORDS;
     const float* bias = reinterpret_cast<const float*>(buf + MT * B::TILE_OPS_WORDS);
 #pragma unroll
