@@ -260,23 +260,22 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
     """mnf_glow_actnorm_inv / _bwd against the oracle's two layers composed in float64 (oracle.glow's product with M
     given, then oracle.affine_const inverse) and torch.autograd through them.  fp32 MFMA products, fp32 sums over the
     rows by atomics: 2e-6 normwise on the rows, 2e-5 on the sums over up to 70,001 rows."""
-    lib, flows_mod = amd._lib.load(), amd.flows
+    lib = amd._lib.load()
     u, M, s, t, gz = _pair_case(100 + rows, rows)
     u64, M64, s64, t64 = (a.clone().requires_grad_(True) for a in (u, M, s, t))
     z64, _ = O.affine_const(u64 @ M64, s64, t64, inverse=True)
     z64.backward(gz)
     ud, Md, gzd = u.float().to(DEV), M.float().to(DEV).contiguous(), gz.float().to(DEV)
-    post = torch.cat((torch.exp(-s.float().reshape(-1)), t.float().reshape(-1))).to(DEV).contiguous()
-    table = flows_mod._linear_rows_table(lib, 32, ud.device)
-    img = flows_mod._linear_rows_image(lib, Md, table)
-    img_t = flows_mod._linear_rows_image(lib, Md.t().contiguous(), table)
+    # (s and t handed over 4-byte aligned only, as views into a flat parameter buffer are)
+    st = torch.cat((torch.zeros(1), s.float().reshape(-1), t.float().reshape(-1))).to(DEV)
+    sd, td = st[1:33], st[33:65]
     z = torch.empty_like(ud)
     amd._lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
-        ud.data_ptr(), img.data_ptr(), post.data_ptr(), z.data_ptr(), rows, 32, None))
+        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), z.data_ptr(), rows, 32, None))
     gu = torch.full_like(ud, float("nan"))
     gM, gs, gt = torch.zeros(32, 32, device=DEV), torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
-        ud.data_ptr(), gzd.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+        ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
         gs.data_ptr(), gt.data_ptr(), rows, 32, None))
     torch.cuda.synchronize()
     assert _err(z.double(), z64) <= 2e-6
@@ -286,7 +285,7 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
     assert _err(gt.double(), t64.grad.reshape(-1)) <= 2e-5
     # the sums are ADDED to, and either column sum may be left out
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
-        ud.data_ptr(), gzd.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+        ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
         None, gt.data_ptr(), rows, 32, None))
     torch.cuda.synchronize()
     assert _err(gM.double(), 2 * M64.grad) <= 2e-5 and _err(gt.double(), 2 * t64.grad.reshape(-1)) <= 2e-5
@@ -295,12 +294,13 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
 def test_glow_actnorm_inverse_pair_rejects_what_it_has_no_kernel_for(amd):
     lib = amd._lib.load()
     a = torch.zeros(64, 64, device=DEV)
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 32, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 32, None) \
         == amd._lib.MNF_ERR_INVALID_ARG  # in place
     b = torch.zeros(64, 64, device=DEV)
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 64, 64, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 64, 64, None) \
         == amd._lib.MNF_ERR_UNSUPPORTED
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 0, 32, None) == amd._lib.MNF_OK
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 0, 32, None) \
+        == amd._lib.MNF_OK
     assert lib.mnf_glow_actnorm_inv_bwd(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), None,
                                         b.data_ptr(), None, None, 64, 32, None) == amd._lib.MNF_ERR_INVALID_ARG
 

@@ -54,27 +54,42 @@ __device__ __forceinline__ void rows_times_image(const float* lds_image, int lan
     }
 }
 
-__device__ __forceinline__ void stage_image(float* lds, const float* image) {
-  const float4* src = reinterpret_cast<const float4*>(image);
-  float4* dst = reinterpret_cast<float4*>(lds);
-  for (int i = threadIdx.x; i < kGaD * kGaD / 4; i += blockDim.x) dst[i] = src[i];
+// M (row-major, or its transpose when T) into LDS in A-operand order -- the layout mnf_linear_rows_image_index describes:
+// word (n >> 2) * 256 + lane * 4 + (n & 3) of MFMA n = (K-step kk, output tile m) is M[16 g + 4 (lane >> 4) + e][16 m +
+// (lane & 15)] with kk = 4 g + e.  Done here, per workgroup, from the 4 KB matrix in L2: no packing launch per step.
+template <bool T>
+__device__ __forceinline__ void stage_matrix(float* lds, const float* M) {
+  constexpr int G = kGaD / 16;
+  for (int p = threadIdx.x; p < kGaD * kGaD; p += blockDim.x) {
+    const int n = 4 * (p >> 8) + (p & 3), lane = (p >> 2) & 63;
+    const int kk = n / G, m = n - kk * G;
+    const int k = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), o = 16 * m + (lane & 15);
+    lds[p] = T ? M[o * kGaD + k] : M[k * kGaD + o];
+  }
 }
 
-// z = (u @ M - t) e^-s; post = [e^-s (32) | t (32)]
+// [e^-s | t] of the lane's eight columns (16 m + 4 q + r)
+__device__ __forceinline__ void load_post(const float* s, const float* t, int q, f32x4 (&es)[2], f32x4 (&tt)[2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // (scalar loads: s and t may sit anywhere in a flat parameter buffer)
+      es[m][r] = expf(-s[16 * m + 4 * q + r]);
+      tt[m][r] = t[16 * m + 4 * q + r];
+    }
+}
+
+// z = (u @ M - t) e^-s
 __global__ void __launch_bounds__(kGaWaves * 64)
-glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ image, const float* __restrict__ post,
-                        float* __restrict__ z, int64_t rows) {
+glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M, const float* __restrict__ s,
+                        const float* __restrict__ t, float* __restrict__ z, int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds[kGaD * kGaD];
-  stage_image(lds, image);
+  stage_matrix<false>(lds, M);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   f32x4 es[2], tt[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    es[m] = *reinterpret_cast<const f32x4*>(post + 16 * m + 4 * q);
-    tt[m] = *reinterpret_cast<const f32x4*>(post + kGaD + 16 * m + 4 * q);
-  }
+  load_post(s, t, q, es, tt);
   const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * kGaWaves;
   auto row_of = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
@@ -106,27 +121,23 @@ glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ i
 
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ image,
-                            const float* __restrict__ image_t, const float* __restrict__ post,
-                            float* __restrict__ gu, float* __restrict__ grad_m, float* __restrict__ grad_s,
-                            float* __restrict__ grad_t, int64_t rows) {
+glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ M,
+                            const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ gu,
+                            float* __restrict__ grad_m, float* __restrict__ grad_s, float* __restrict__ grad_t,
+                            int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * kGaPitch];
   __shared__ float red_st[2 * kGaD];
-  stage_image(lds_m, image);
-  stage_image(lds_mt, image_t);
+  stage_matrix<false>(lds_m, M);
+  stage_matrix<true>(lds_mt, M);
   if (threadIdx.x < 2 * kGaD) red_st[threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;  // row-on-the-lane layout
   const int c = lane & 15, k = lane >> 4;  // rows-on-K layout
   f32x4 es[2], tt[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    es[m] = *reinterpret_cast<const f32x4*>(post + 16 * m + 4 * q);
-    tt[m] = *reinterpret_cast<const f32x4*>(post + kGaD + 16 * m + 4 * q);
-  }
+  load_post(s, t, q, es, tt);
   float* const my_u = &turn[wave][0][0];
   float* const my_g = &turn[wave][1][0];
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -239,23 +250,22 @@ using namespace mnf;
 
 extern "C" {
 
-int mnf_glow_actnorm_inv(const float* u, const float* image, const float* post, float* z, int64_t rows, int dim,
+int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, int64_t rows, int dim,
                          void* stream) {
-  if (!u || !image || !post || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, z, image) || !aligned16(post, post, post) || rows >= (int64_t)1 << 31)
-    return MNF_ERR_UNSUPPORTED;
+  if (!u || !M || !s || !t || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
+  if (dim != kGaD || !aligned16(u, z, z) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
   hipLaunchKernelGGL(glow_actnorm_inv_kernel, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, image, post, z, rows);
+                     (hipStream_t)stream, u, M, s, t, z, rows);
   return check_launch();
 }
 
-int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* image, const float* image_t,
-                             const float* post, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
-                             int64_t rows, int dim, void* stream) {
-  if (!u || !grad_z || !image || !image_t || !post || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
+int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
+                             float* grad_u, float* grad_m, float* grad_s, float* grad_t, int64_t rows, int dim,
+                             void* stream) {
+  if (!u || !grad_z || !M || !s || !t || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
     return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, grad_z, grad_u) || !aligned16(image, image_t, post) || rows >= (int64_t)1 << 31)
+  if (dim != kGaD || !aligned16(u, grad_z, grad_u) || rows >= (int64_t)1 << 31)
     return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
 #ifndef MNF_GA_BWD_WAVES
@@ -269,8 +279,8 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* i
   // images held in registers instead of re-read from LDS per tile: 101)
   hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES>,
                      dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
-                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, image, image_t, post, grad_u,
-                     grad_m, grad_s, grad_t, rows);
+                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, M, s, t, grad_u, grad_m, grad_s,
+                     grad_t, rows);
   return check_launch();
 }
 

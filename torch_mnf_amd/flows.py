@@ -621,38 +621,28 @@ class _GlowActNormInvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, M, s, t):
-        lib = _lib.load()
-        table = _linear_rows_table(lib, u.shape[1], u.device)
         Mc = M.detach().contiguous()
-        sc = s.detach().to(u.device, torch.float32).reshape(-1)
-        tc = t.detach().to(u.device, torch.float32).reshape(-1)
-        post = torch.cat((torch.exp(-sc), tc)).contiguous()
+        sc = s.detach().to(u.device, torch.float32).contiguous()
+        tc = t.detach().to(u.device, torch.float32).contiguous()
         z = torch.empty_like(u)
-        img = _linear_rows_image(lib, Mc, table)
-        _lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
-            u.data_ptr(), img.data_ptr(), post.data_ptr(), z.data_ptr(), u.shape[0], u.shape[1], _stream()))
-        ctx.save_for_backward(u, Mc, post)
-        ctx.shapes = (s.shape, t.shape)
+        _lib.check("mnf_glow_actnorm_inv", _lib.load().mnf_glow_actnorm_inv(
+            u.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), z.data_ptr(), u.shape[0], u.shape[1], _stream()))
+        ctx.save_for_backward(u, Mc, sc, tc)
         return z
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_z):
-        u, Mc, post = ctx.saved_tensors
-        lib = _lib.load()
+        u, Mc, sc, tc = ctx.saved_tensors
         dim = u.shape[1]
-        table = _linear_rows_table(lib, dim, u.device)
         gz = grad_z.contiguous()
         gu = torch.empty_like(u)
         sums = torch.zeros(dim * dim + 2 * dim, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t
         gM, gs, gt = sums[:dim * dim], sums[dim * dim:dim * dim + dim], sums[dim * dim + dim:]
-        # (both images stay referenced until the launch is queued: a temporary freed in between hands its block to the next)
-        img, img_t = _linear_rows_image(lib, Mc, table), _linear_rows_image(lib, Mc.t().contiguous(), table)
-        _lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
-            u.data_ptr(), gz.data_ptr(), img.data_ptr(), img_t.data_ptr(), post.data_ptr(), gu.data_ptr(),
-            gM.data_ptr(), gs.data_ptr(), gt.data_ptr(), u.shape[0], dim, _stream()))
-        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(ctx.shapes[0]),
-                gt.view(ctx.shapes[1]))
+        _lib.check("mnf_glow_actnorm_inv_bwd", _lib.load().mnf_glow_actnorm_inv_bwd(
+            u.data_ptr(), gz.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+            gs.data_ptr(), gt.data_ptr(), u.shape[0], dim, _stream()))
+        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape))
 
 
 class _LinearRowsFn(torch.autograd.Function):
