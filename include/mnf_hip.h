@@ -594,12 +594,14 @@ int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, co
  * every [ActNormFlow, Glow, NSF_CL] block applies on the way x -> z) as one launch each way, dim = 32 (else
  * MNF_ERR_UNSUPPORTED): z = (u @ M - t) e^-s with M = W^-1 (dim, dim) row-major and s, t (dim,) as the modules hold
  * them (no packed image: the kernels arrange M themselves).  The gradient launch writes grad_u and ADDS to grad_m
- * (dim, dim) = u^T (grad_z e^-s), grad_s, grad_t (dim,; either may be NULL); z is recomputed, not read. */
-int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, int64_t rows, int dim,
-                         void* stream);
+ * (dim, dim) = u^T (grad_z e^-s), grad_s, grad_t (dim,; either may be NULL); z is recomputed, not read.
+ * ld_out (1, or NULL): the pair's log|det J| = ld_glow[0] (Glow's -sum log|S|, glow.py:35; NULL: 0) - sum s
+ * (affine_constant_flow.py:25); grad_ld (1, or NULL): its cotangent, which enters grad_s as -grad_ld per column. */
+int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, const float* ld_glow,
+                         float* ld_out, int64_t rows, int dim, void* stream);
 int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
-                             float* grad_u, float* grad_m, float* grad_s, float* grad_t, int64_t rows, int dim,
-                             void* stream);
+                             float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
+                             int64_t rows, int dim, void* stream);
 /* Glow: grad_W (dim, dim) += x^T grad_y   (grad_x is mnf_linear_rows with W^T). */
 int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_W, int64_t rows, int dim,
                                void* stream);

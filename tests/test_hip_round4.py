@@ -270,13 +270,18 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
     st = torch.cat((torch.zeros(1), s.float().reshape(-1), t.float().reshape(-1))).to(DEV)
     sd, td = st[1:33], st[33:65]
     z = torch.empty_like(ud)
+    ld_in, ld = torch.full((1,), 0.75, device=DEV), torch.empty(1, device=DEV)
     amd._lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
-        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), z.data_ptr(), rows, 32, None))
+        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), z.data_ptr(), ld_in.data_ptr(), ld.data_ptr(), rows,
+        32, None))
     gu = torch.full_like(ud, float("nan"))
     gM, gs, gt = torch.zeros(32, 32, device=DEV), torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    g_ld = torch.full((1,), -0.3, device=DEV)  # cotangent of the pair's log|det J| = 0.75 - sum s
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
         ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-        gs.data_ptr(), gt.data_ptr(), rows, 32, None))
+        gs.data_ptr(), gt.data_ptr(), g_ld.data_ptr(), rows, 32, None))
+    assert abs(float(ld) - (0.75 - float(s.sum()))) <= 1e-5
+    gs = gs - 0.3  # (checked below against the gradient of z alone)
     torch.cuda.synchronize()
     assert _err(z.double(), z64) <= 2e-6
     assert _err(gu.double(), u64.grad) <= 2e-6
@@ -286,7 +291,7 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
     # the sums are ADDED to, and either column sum may be left out
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
         ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-        None, gt.data_ptr(), rows, 32, None))
+        None, gt.data_ptr(), None, rows, 32, None))
     torch.cuda.synchronize()
     assert _err(gM.double(), 2 * M64.grad) <= 2e-5 and _err(gt.double(), 2 * t64.grad.reshape(-1)) <= 2e-5
 
@@ -294,15 +299,15 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
 def test_glow_actnorm_inverse_pair_rejects_what_it_has_no_kernel_for(amd):
     lib = amd._lib.load()
     a = torch.zeros(64, 64, device=DEV)
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 32, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), None, None, 64, 32, None) \
         == amd._lib.MNF_ERR_INVALID_ARG  # in place
     b = torch.zeros(64, 64, device=DEV)
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 64, 64, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, 64, 64, None) \
         == amd._lib.MNF_ERR_UNSUPPORTED
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), 0, 32, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, 0, 32, None) \
         == amd._lib.MNF_OK
     assert lib.mnf_glow_actnorm_inv_bwd(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), None,
-                                        b.data_ptr(), None, None, 64, 32, None) == amd._lib.MNF_ERR_INVALID_ARG
+                                        b.data_ptr(), None, None, None, 64, 32, None) == amd._lib.MNF_ERR_INVALID_ARG
 
 
 @pytest.mark.parametrize("rows", [777, 8192])

@@ -82,9 +82,16 @@ __device__ __forceinline__ void load_post(const float* s, const float* t, int q,
 // z = (u @ M - t) e^-s
 __global__ void __launch_bounds__(kGaWaves * 64)
 glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M, const float* __restrict__ s,
-                        const float* __restrict__ t, float* __restrict__ z, int64_t rows) {
+                        const float* __restrict__ t, float* __restrict__ z, const float* __restrict__ ld_glow,
+                        float* __restrict__ ld_out, int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds[kGaD * kGaD];
   stage_matrix<false>(lds, M);
+  if (ld_out && blockIdx.x == 0 && threadIdx.x < 64) {  // the pair's log|det J|: Glow's (given) - sum s
+    float v = threadIdx.x < kGaD ? -s[threadIdx.x] : 0.f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (threadIdx.x == 0) ld_out[0] = v + (ld_glow ? ld_glow[0] : 0.f);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
@@ -124,7 +131,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ M,
                             const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ gu,
                             float* __restrict__ grad_m, float* __restrict__ grad_s, float* __restrict__ grad_t,
-                            int64_t rows) {
+                            const float* __restrict__ grad_ld, int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * kGaPitch];
@@ -227,7 +234,8 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
     atomicAdd(grad_m + i * kGaD + jj, red[e]);
   }
   if (threadIdx.x < kGaD) {
-    if (grad_s) atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x]);
+    // (d log|det J| / d s = -1 per column: once, from the first workgroup)
+    if (grad_s) atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x] - (grad_ld && blockIdx.x == 0 ? grad_ld[0] : 0.f));
     if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[kGaD + threadIdx.x]);
   }
 }
@@ -250,19 +258,19 @@ using namespace mnf;
 
 extern "C" {
 
-int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, int64_t rows, int dim,
-                         void* stream) {
+int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, const float* ld_glow,
+                         float* ld_out, int64_t rows, int dim, void* stream) {
   if (!u || !M || !s || !t || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
   if (dim != kGaD || !aligned16(u, z, z) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
   hipLaunchKernelGGL(glow_actnorm_inv_kernel, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, M, s, t, z, rows);
+                     (hipStream_t)stream, u, M, s, t, z, ld_glow, ld_out, rows);
   return check_launch();
 }
 
 int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
-                             float* grad_u, float* grad_m, float* grad_s, float* grad_t, int64_t rows, int dim,
-                             void* stream) {
+                             float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
+                             int64_t rows, int dim, void* stream) {
   if (!u || !grad_z || !M || !s || !t || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
     return MNF_ERR_INVALID_ARG;
   if (dim != kGaD || !aligned16(u, grad_z, grad_u) || rows >= (int64_t)1 << 31)
@@ -280,7 +288,7 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M
   hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES>,
                      dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
                      dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, M, s, t, grad_u, grad_m, grad_s,
-                     grad_t, rows);
+                     grad_t, grad_ld, rows);
   return check_launch();
 }
 

@@ -617,32 +617,39 @@ _NO_PAIR_FUSION_ENV = os.environ.get("MNF_NO_PAIR_FUSION", "0") == "1"
 class _GlowActNormInvFn(torch.autograd.Function):
     """Glow.inverse then ActNormFlow.inverse -- z = (u @ M - t) e^-s, M = W^-1 -- as ONE autograd node with one launch
     each way (glow.py:33-37, affine_constant_flow.py:22-26).  The intermediate u @ M is never written; the gradient
-    launch reads u and grad_z once and produces grad_u, grad_M, grad_s and grad_t."""
+    launch reads u and grad_z once and produces grad_u, grad_M, grad_s and grad_t.  The pair's log|det J| (Glow's, handed
+    in, minus sum s) is a second output of the same launch."""
 
     @staticmethod
-    def forward(ctx, u, M, s, t):
+    def forward(ctx, u, M, s, t, ld_glow):
         Mc = M.detach().contiguous()
         sc = s.detach().to(u.device, torch.float32).contiguous()
         tc = t.detach().to(u.device, torch.float32).contiguous()
         z = torch.empty_like(u)
+        ld = torch.empty(1, dtype=torch.float32, device=u.device)  # Glow's log|det| - sum s, formed by the launch
         _lib.check("mnf_glow_actnorm_inv", _lib.load().mnf_glow_actnorm_inv(
-            u.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), z.data_ptr(), u.shape[0], u.shape[1], _stream()))
+            u.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), z.data_ptr(), ld_glow.detach().data_ptr(),
+            ld.data_ptr(), u.shape[0], u.shape[1], _stream()))
         ctx.save_for_backward(u, Mc, sc, tc)
-        return z
+        ctx.ld_shape = ld_glow.shape
+        ctx.set_materialize_grads(False)
+        return z, ld
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_z):
+    def backward(ctx, grad_z, grad_ld):
         u, Mc, sc, tc = ctx.saved_tensors
         dim = u.shape[1]
-        gz = grad_z.contiguous()
+        gz = torch.zeros_like(u) if grad_z is None else grad_z.contiguous()
+        gl = None if grad_ld is None else grad_ld.contiguous()
         gu = torch.empty_like(u)
         sums = torch.zeros(dim * dim + 2 * dim, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t
         gM, gs, gt = sums[:dim * dim], sums[dim * dim:dim * dim + dim], sums[dim * dim + dim:]
         _lib.check("mnf_glow_actnorm_inv_bwd", _lib.load().mnf_glow_actnorm_inv_bwd(
             u.data_ptr(), gz.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-            gs.data_ptr(), gt.data_ptr(), u.shape[0], dim, _stream()))
-        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape))
+            gs.data_ptr(), gt.data_ptr(), _ptr(gl), u.shape[0], dim, _stream()))
+        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape),
+                None if gl is None else gl.reshape(ctx.ld_shape))
 
 
 class _LinearRowsFn(torch.autograd.Function):
@@ -2165,8 +2172,7 @@ def _glow_actnorm_inverse(glow: "Glow", actnorm: "ActNormFlow", x: Tensor) -> tu
     home = _flat_home_of(glow, params) if all(p.requires_grad for p in params) else None
     M, ld_glow = _GlowWeightFn.apply(glow.L, glow.S, glow.U, glow._P_on(xg.device).to(torch.float32).contiguous(), True,
                                      home)
-    z = _GlowActNormInvFn.apply(xg, M, actnorm.s.to(xg.device), actnorm.t.to(xg.device))
-    return z, ld_glow + torch.sum(-actnorm.s, dim=1).to(xg.device)
+    return _GlowActNormInvFn.apply(xg, M, actnorm.s.to(xg.device), actnorm.t.to(xg.device), ld_glow)
 
 
 class NormalizingFlow(nn.Module):
