@@ -602,6 +602,16 @@ int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const f
 int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
                              float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
                              int64_t rows, int dim, void* stream);
+/* The same pair closing a density pass under a standard-normal base (core.py:46-49: log p = log_det + base.log_prob(z),
+ * distributions.py's Normal(0, 1)): log_prob[row] = log_det_rows[row] + (ld_glow[0] - sum s) - |z|^2 / 2 - dim log(2 pi) / 2
+ * with z = (u @ M - t) e^-s never written.  The gradient launch takes grad_log_prob (rows,), forms grad_z = -z grad_log_prob
+ * from the recomputed z, writes grad_u and ADDS to grad_m, grad_s, grad_t (as above) and to grad_ld_glow (1, or NULL) =
+ * sum_r grad_log_prob[r]; the cotangent of log_det_rows is grad_log_prob itself. */
+int mnf_glow_actnorm_inv_logprob(const float* u, const float* M, const float* s, const float* t, const float* ld_glow,
+                                 const float* log_det_rows, float* log_prob, int64_t rows, int dim, void* stream);
+int mnf_glow_actnorm_inv_logprob_bwd(const float* u, const float* grad_log_prob, const float* M, const float* s,
+                                     const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
+                                     float* grad_ld_glow, int64_t rows, int dim, void* stream);
 /* Glow: grad_W (dim, dim) += x^T grad_y   (grad_x is mnf_linear_rows with W^T). */
 int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_W, int64_t rows, int dim,
                                void* stream);

@@ -374,3 +374,41 @@ def test_graphed_training_step_of_a_spline_block_with_the_fused_pair(amd):
     for a, b in zip(losses_e[3:], losses_g):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (a, b)
     assert_close(opt_g.flat.data, opt_e.flat.data, 2e-3, "parameters after 11 steps")
+
+
+@pytest.mark.parametrize("rows", [1, 17, 1000, 70001])
+def test_glow_actnorm_inverse_pair_logprob_kernels_vs_float64_oracle(amd, O, rows):
+    """mnf_glow_actnorm_inv_logprob / _bwd (the pair closing a density pass, standard-normal base) against the oracle's
+    layers and base.log_prob composed in float64: log p per row, and with a row-dependent cotangent the gradients of
+    u, M, s, t, Glow's log|det| and the running log_det.  Budgets as for the plain pair kernels."""
+    import math
+    lib = amd._lib.load()
+    u, M, s, t, _ = _pair_case(500 + rows, rows)
+    g = torch.Generator().manual_seed(9 + rows)
+    ld_rows = torch.randn(rows, generator=g, dtype=torch.float64)
+    g_lp = torch.randn(rows, generator=g, dtype=torch.float64) / rows
+    u64, M64, s64, t64, ldr64 = (a.clone().requires_grad_(True) for a in (u, M, s, t, ld_rows))
+    ldg64 = torch.tensor(0.75, dtype=torch.float64, requires_grad=True)
+    z64, ld_an = O.affine_const(u64 @ M64, s64, t64, inverse=True)
+    lp64 = ldr64 + ldg64 + ld_an + (-0.5 * z64 ** 2 - 0.5 * math.log(2 * math.pi)).sum(1)  # distributions: Normal(0, 1)
+    lp64.backward(g_lp)
+    ud, Md = u.float().to(DEV), M.float().to(DEV).contiguous()
+    st = torch.cat((torch.zeros(1), s.float().reshape(-1), t.float().reshape(-1))).to(DEV)
+    sd, td = st[1:33], st[33:65]
+    ldg, ldr, gl = torch.full((1,), 0.75, device=DEV), ld_rows.float().to(DEV), g_lp.float().to(DEV)
+    lp = torch.empty(rows, device=DEV)
+    amd._lib.check("mnf_glow_actnorm_inv_logprob", lib.mnf_glow_actnorm_inv_logprob(
+        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), ldg.data_ptr(), ldr.data_ptr(), lp.data_ptr(), rows, 32,
+        None))
+    gu = torch.full_like(ud, float("nan"))
+    gM, gs, gt, gld = (torch.zeros(n, device=DEV) for n in (1024, 32, 32, 1))
+    amd._lib.check("mnf_glow_actnorm_inv_logprob_bwd", lib.mnf_glow_actnorm_inv_logprob_bwd(
+        ud.data_ptr(), gl.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+        gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), rows, 32, None))
+    torch.cuda.synchronize()
+    assert _err(lp.double(), lp64.detach()) <= 2e-6
+    assert _err(gu.double(), u64.grad) <= 2e-6
+    assert _err(gM.view(32, 32).double(), M64.grad) <= 2e-5
+    assert _err(gs.double(), s64.grad.reshape(-1)) <= 2e-5
+    assert _err(gt.double(), t64.grad.reshape(-1)) <= 2e-5
+    assert abs(float(gld) - float(ldg64.grad)) <= 2e-5 * max(1.0, float(g_lp.abs().sum()))

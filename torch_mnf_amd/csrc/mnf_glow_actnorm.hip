@@ -79,18 +79,26 @@ __device__ __forceinline__ void load_post(const float* s, const float* t, int q,
     }
 }
 
-// z = (u @ M - t) e^-s
+// z = (u @ M - t) e^-s.  LP (the pair closes a density pass under a standard-normal base, core.py:46-49): z is not
+// stored; the launch writes log p(row) = log_det_rows[row] + (ld_glow - sum s) - |z|^2 / 2 - d log(2 pi) / 2 instead.
+template <bool LP>
 __global__ void __launch_bounds__(kGaWaves * 64)
 glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M, const float* __restrict__ s,
                         const float* __restrict__ t, float* __restrict__ z, const float* __restrict__ ld_glow,
-                        float* __restrict__ ld_out, int64_t rows) {
+                        float* __restrict__ ld_out, const float* __restrict__ ld_rows, float* __restrict__ lp_out,
+                        int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds[kGaD * kGaD];
+  __shared__ float ld_pair;
   stage_matrix<false>(lds, M);
-  if (ld_out && blockIdx.x == 0 && threadIdx.x < 64) {  // the pair's log|det J|: Glow's (given) - sum s
+  if (threadIdx.x < 64) {  // the pair's log|det J|: Glow's (given) - sum s
     float v = threadIdx.x < kGaD ? -s[threadIdx.x] : 0.f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if (threadIdx.x == 0) ld_out[0] = v + (ld_glow ? ld_glow[0] : 0.f);
+    v += ld_glow ? ld_glow[0] : 0.f;
+    if (threadIdx.x == 0) {
+      ld_pair = v;
+      if (ld_out && blockIdx.x == 0) ld_out[0] = v;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,41 +112,59 @@ glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M
   };
   int tile = (int)blockIdx.x * kGaWaves + wave;
   if (tile >= n_tiles) return;
+  const float ldc = ld_pair - (float)kGaD * kHalfLog2Pi;
   f32x4 nx[2];
+  float nl = 0.f;
   {
     const float* p = u + row_of(tile) * kGaD + 4 * q;
     nx[0] = *reinterpret_cast<const f32x4*>(p);
     nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
+    if (LP) nl = ld_rows[row_of(tile)];
   }
   for (; tile < n_tiles; tile += step) {
     const f32x4 xv[2] = {nx[0], nx[1]};
+    const float ldr = nl;
     {  // the next tile's rows (past the end: the last tile's again)
       const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
       const float* p = u + row_of(nt) * kGaD + 4 * q;
       nx[0] = *reinterpret_cast<const f32x4*>(p);
       nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
+      if (LP) nl = ld_rows[row_of(nt)];
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     rows_times_image(lds, lane, xv, acc);
-    float* zr = z + row_of(tile) * kGaD + 4 * q;  // (rows past the end rewrite the last row with its own values)
+    if (LP) {
+      float sq = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(zr + 16 * m) = (acc[m] - tt[m]) * es[m];
+      for (int m = 0; m < 2; ++m) {
+        const f32x4 zz = (acc[m] - tt[m]) * es[m];
+        sq += (zz[0] * zz[0] + zz[1] * zz[1]) + (zz[2] * zz[2] + zz[3] * zz[3]);
+      }
+      sq = sum_over_q(sq);
+      lp_out[row_of(tile)] = ldr + (ldc - 0.5f * sq);  // (every q lane of a row, and rows past the end, store the same value)
+    } else {
+      float* zr = z + row_of(tile) * kGaD + 4 * q;  // (rows past the end rewrite the last row with its own values)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(zr + 16 * m) = (acc[m] - tt[m]) * es[m];
+    }
   }
 }
 
-template <int WAVES>
+// LP: gz holds d loss / d log p per ROW; grad_z = -z gz[row] is formed from the recomputed z, and the row sums of gz --
+// the cotangent of the pair's log|det J| -- leave through grad_ld_out (added to) and enter grad_s.
+template <int WAVES, bool LP>
 __global__ void __launch_bounds__(WAVES * 64)
 glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ M,
                             const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ gu,
                             float* __restrict__ grad_m, float* __restrict__ grad_s, float* __restrict__ grad_t,
-                            const float* __restrict__ grad_ld, int64_t rows) {
+                            const float* __restrict__ grad_ld, float* __restrict__ grad_ld_out, int64_t rows) {
   __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * kGaPitch];
-  __shared__ float red_st[2 * kGaD];
+  __shared__ float red_st[2 * kGaD + 1];
   stage_matrix<false>(lds_m, M);
   stage_matrix<true>(lds_mt, M);
-  if (threadIdx.x < 2 * kGaD) red_st[threadIdx.x] = 0.f;
+  if (threadIdx.x < 2 * kGaD + 1) red_st[threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;  // row-on-the-lane layout
@@ -157,25 +183,38 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
   };
   int tile = (int)blockIdx.x * WAVES + wave;
   f32x4 nu[2], ng[2];
+  float nl = 0.f, lacc = 0.f;
   {
     const int t0 = tile < n_tiles ? tile : n_tiles - 1;
     const int64_t off = row_of(t0) * kGaD + 4 * q;
     nu[0] = *reinterpret_cast<const f32x4*>(u + off);
     nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
-    ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
-    ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+    if (LP) {
+      nl = gz[row_of(t0)];
+    } else {
+      ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
+      ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+    }
   }
   for (; tile < n_tiles; tile += step) {
-    const f32x4 uv[2] = {nu[0], nu[1]}, gv_in[2] = {ng[0], ng[1]};
+    const f32x4 uv[2] = {nu[0], nu[1]};
+    f32x4 gv_in[2];
+    const float glp = nl;
+    if (!LP) gv_in[0] = ng[0], gv_in[1] = ng[1];
     {  // the next tile's rows in the first layout
       const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
       const int64_t off = row_of(nt) * kGaD + 4 * q;
       nu[0] = *reinterpret_cast<const f32x4*>(u + off);
       nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
-      ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
-      ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+      if (LP) {
+        nl = gz[row_of(nt)];
+      } else {
+        ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
+        ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
+      }
     }
     const float live = (int64_t)tile * 16 + j < rows ? 1.f : 0.f;
+    if (LP && q == 0) lacc += glp * live;  // (one lane per row)
     // z = (u @ M - t) e^-s, recomputed; g_s -= g_z z; g_v = g_z e^-s; g_t -= g_v
     f32x4 acc[2] = {zero4, zero4};
     rows_times_image(lds_m, lane, uv, acc);
@@ -183,6 +222,7 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f32x4 zz = (acc[m] - tt[m]) * es[m];
+      if (LP) gv_in[m] = zz * -glp;  // d log N(z) / d z = -z
       gv[m] = gv_in[m] * es[m];
       sacc[m] -= gv_in[m] * zz * live;
       tacc[m] -= gv[m] * live;
@@ -218,6 +258,11 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
       atomicAdd(red_st + 16 * m + 4 * q + r, sacc[m][r]);
       atomicAdd(red_st + kGaD + 16 * m + 4 * q + r, tacc[m][r]);
     }
+  if (LP) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lacc += __shfl_xor(lacc, m, 64);
+    if (lane == 0) atomicAdd(red_st + 2 * kGaD, lacc);
+  }
   for (int w = 0; w < WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -235,8 +280,11 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
   }
   if (threadIdx.x < kGaD) {
     // (d log|det J| / d s = -1 per column: once, from the first workgroup)
-    if (grad_s) atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x] - (grad_ld && blockIdx.x == 0 ? grad_ld[0] : 0.f));
+    if (grad_s)
+      atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x] - (grad_ld && blockIdx.x == 0 ? grad_ld[0] : 0.f) -
+                                          (LP ? red_st[2 * kGaD] : 0.f));
     if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[kGaD + threadIdx.x]);
+    if (LP && grad_ld_out && threadIdx.x == 0) atomicAdd(grad_ld_out, red_st[2 * kGaD]);
   }
 }
 
@@ -263,8 +311,19 @@ int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const f
   if (!u || !M || !s || !t || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
   if (dim != kGaD || !aligned16(u, z, z) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL(glow_actnorm_inv_kernel, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, M, s, t, z, ld_glow, ld_out, rows);
+  hipLaunchKernelGGL(glow_actnorm_inv_kernel<false>, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
+                     (hipStream_t)stream, u, M, s, t, z, ld_glow, ld_out, (const float*)nullptr, (float*)nullptr, rows);
+  return check_launch();
+}
+
+int mnf_glow_actnorm_inv_logprob(const float* u, const float* M, const float* s, const float* t, const float* ld_glow,
+                                 const float* log_det_rows, float* log_prob, int64_t rows, int dim, void* stream) {
+  if (!u || !M || !s || !t || !log_det_rows || !log_prob || rows < 0) return MNF_ERR_INVALID_ARG;
+  if (dim != kGaD || !aligned16(u, u, u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL(glow_actnorm_inv_kernel<true>, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
+                     (hipStream_t)stream, u, M, s, t, (float*)nullptr, ld_glow, (float*)nullptr, log_det_rows, log_prob,
+                     rows);
   return check_launch();
 }
 
@@ -285,10 +344,23 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M
   // eight waves per CU measured best at 2^20 rows (workgroups of 4 waves: 1 per CU 95 us, 2: 89, 3: 95, 4: 101; 8 waves
   // x 2: 101, 16 x 1: 101 -- the same 8 waves as 8 x 1: 90, so it is not the count of closing atomics; the operand
   // images held in registers instead of re-read from LDS per tile: 101)
-  hipLaunchKernelGGL(glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES>,
+  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES, false>),
                      dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
                      dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, M, s, t, grad_u, grad_m, grad_s,
-                     grad_t, grad_ld, rows);
+                     grad_t, grad_ld, (float*)nullptr, rows);
+  return check_launch();
+}
+
+int mnf_glow_actnorm_inv_logprob_bwd(const float* u, const float* grad_log_prob, const float* M, const float* s,
+                                     const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
+                                     float* grad_ld_glow, int64_t rows, int dim, void* stream) {
+  if (!u || !grad_log_prob || !M || !s || !t || !grad_u || !grad_m || grad_u == u || rows < 0) return MNF_ERR_INVALID_ARG;
+  if (dim != kGaD || !aligned16(u, grad_u, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
+  if (rows == 0) return MNF_OK;
+  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES, true>),
+                     dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
+                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_log_prob, M, s, t, grad_u, grad_m,
+                     grad_s, grad_t, (const float*)nullptr, grad_ld_glow, rows);
   return check_launch();
 }
 

@@ -2157,6 +2157,41 @@ class FusedAffineStack(_TwoWayFlow):
         return y, ld
 
 
+class _GlowActNormInvLogProbFn(torch.autograd.Function):
+    """The pair closing a density pass under a standard-normal base: log p from (u, the running log_det) in one launch --
+    z is not written --, and one gradient launch that forms grad_z = -z d loss / d log p from the recomputed z
+    (mnf_glow_actnorm_inv_logprob / _bwd).  Replaces the pair node + gauss_logprob + the -z g elementwise launch."""
+
+    @staticmethod
+    def forward(ctx, u, M, s, t, ld_glow, log_det):
+        Mc = M.detach().contiguous()
+        sc = s.detach().to(u.device, torch.float32).contiguous()
+        tc = t.detach().to(u.device, torch.float32).contiguous()
+        lp = torch.empty(u.shape[0], dtype=torch.float32, device=u.device)
+        _lib.check("mnf_glow_actnorm_inv_logprob", _lib.load().mnf_glow_actnorm_inv_logprob(
+            u.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), ld_glow.detach().data_ptr(),
+            log_det.detach().contiguous().data_ptr(), lp.data_ptr(), u.shape[0], u.shape[1], _stream()))
+        ctx.save_for_backward(u, Mc, sc, tc)
+        ctx.ld_shape = ld_glow.shape
+        return lp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_lp):
+        u, Mc, sc, tc = ctx.saved_tensors
+        dim = u.shape[1]
+        g = grad_lp.contiguous()
+        gu = torch.empty_like(u)
+        sums = torch.zeros(dim * dim + 2 * dim + 1, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t | grad_ld
+        gM, gs = sums[:dim * dim], sums[dim * dim:dim * dim + dim]
+        gt, gld = sums[dim * dim + dim:dim * dim + 2 * dim], sums[dim * dim + 2 * dim:]
+        _lib.check("mnf_glow_actnorm_inv_logprob_bwd", _lib.load().mnf_glow_actnorm_inv_logprob_bwd(
+            u.data_ptr(), g.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), gu.data_ptr(), gM.data_ptr(),
+            gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), u.shape[0], dim, _stream()))
+        return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape),
+                gld.reshape(ctx.ld_shape), g)
+
+
 def _pair_fusable(glow: "Glow", actnorm: "ActNormFlow", x) -> bool:
     """Training pass, x -> z: can Glow.inverse + ActNormFlow.inverse at this input go out as the fused pair?"""
     return (not _NO_PAIR_FUSION_ENV and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
@@ -2166,12 +2201,15 @@ def _pair_fusable(glow: "Glow", actnorm: "ActNormFlow", x) -> bool:
             and _wants_grad(glow, x) and _wants_grad(actnorm, x))
 
 
-def _glow_actnorm_inverse(glow: "Glow", actnorm: "ActNormFlow", x: Tensor) -> tuple[Tensor, Tensor]:
+def _glow_actnorm_inverse(glow: "Glow", actnorm: "ActNormFlow", x: Tensor, log_det: Tensor | None = None):
+    """(z, the pair's log|det J|); with ``log_det`` (rows,): log p under a standard-normal base instead (one tensor)."""
     xg = _grad_input(x)
     params = [glow.L, glow.S, glow.U]
     home = _flat_home_of(glow, params) if all(p.requires_grad for p in params) else None
     M, ld_glow = _GlowWeightFn.apply(glow.L, glow.S, glow.U, glow._P_on(xg.device).to(torch.float32).contiguous(), True,
                                      home)
+    if log_det is not None:
+        return _GlowActNormInvLogProbFn.apply(xg, M, actnorm.s.to(xg.device), actnorm.t.to(xg.device), ld_glow, log_det)
     return _GlowActNormInvFn.apply(xg, M, actnorm.s.to(xg.device), actnorm.t.to(xg.device), ld_glow)
 
 
@@ -2225,10 +2263,12 @@ class NormalizingFlow(nn.Module):
         return cache[1]
 
     def _pass(self, x: Tensor, inverse: bool, want_sqnorm: bool = False, prologue=None, want_logprob=None,
-              last_only: bool = False):
+              last_only: bool = False, lp_tail: bool = False):
         """prologue (forward only, first flow an RNVP): see RNVP._run; the returned list then starts with eps.
         last_only: the caller reads only the last tensor of the returned list (log_prob): pairs of layers with a fused
         training kernel go out as one autograd node and their intermediate is not materialised.
+        lp_tail (with last_only, standard-normal base): when such a pair CLOSES the pass its node produces log p itself
+        (``self._lp_node``; the list then ends with None and log_det is not extended).
         want_logprob = (lp, total-or-None): when the LAST launch is an affine run whose kernel can add the
         standard-normal epilogue, it fills them and ``self._logprob_done`` is set."""
         n = len(self.flows)
@@ -2250,6 +2290,7 @@ class NormalizingFlow(nn.Module):
         seen = [x]
         self._last_sqnorm = None
         self._logprob_done = False
+        self._lp_node = None
         # layer_events: list receiving (start, end, index) HIP events per launch; layer_event_pick = i restricts
         # the marks to the launch at position i of this pass (a mark costs a few us of stream time)
         pick = self.layer_event_pick
@@ -2303,8 +2344,13 @@ class NormalizingFlow(nn.Module):
             if (outs is None and last_only and inverse and i + 1 < n and type(flow) is Glow
                     and type(order[i + 1]) is ActNormFlow and _pair_fusable(flow, order[i + 1], x)):
                 # Glow.inverse + ActNormFlow.inverse of a training pass: one launch each way (csrc/mnf_glow_actnorm.hip)
-                x, ld = _glow_actnorm_inverse(flow, order[i + 1], x)
-                log_det = ld if log_det is None else log_det + ld
+                if (lp_tail and i + 2 == n and not _NO_FUSED_LOGPROB_ENV and isinstance(log_det, Tensor)
+                        and log_det.shape == (x.shape[0],) and log_det.dtype == torch.float32):
+                    self._lp_node = _glow_actnorm_inverse(flow, order[i + 1], x, log_det)
+                    x = None
+                else:
+                    x, ld = _glow_actnorm_inverse(flow, order[i + 1], x)
+                    log_det = ld if log_det is None else log_det + ld
                 seen.append(x)
                 span, outs = 2, [x]
             if outs is None:
@@ -2460,7 +2506,10 @@ class NormalizingFlowModel(NormalizingFlow):
             lp = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
             total = torch.zeros(1, dtype=torch.float64, device=x.device) if return_sum else None
         zs, log_det = self._pass(x, True, want_sqnorm=std, want_logprob=(lp, total) if lp is not None else None,
-                                 last_only=True)
+                                 last_only=True, lp_tail=std and self.layer_events is None)
+        if self._lp_node is not None:  # the closing [Glow, ActNorm] pair's node produced log p (training)
+            lp_node, self._lp_node = self._lp_node, None
+            return (lp_node, lp_node.detach().double().sum().reshape(1)) if return_sum else lp_node
         z = zs[-1]
         if self._logprob_done:  # the last coupling launch already produced log p and its sum
             return (lp, total) if return_sum else lp
