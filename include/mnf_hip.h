@@ -591,7 +591,7 @@ int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, co
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,
                          int inverse, void* stream);
 /* Glow.inverse followed by ActNormFlow.inverse (torch_mnf/flows/glow.py:33-37, affine_constant_flow.py:22-26: the pair
- * every [ActNormFlow, Glow, NSF_CL] block applies on the way x -> z) as one launch each way, dim = 32 (else
+ * every [ActNormFlow, Glow, NSF_CL] block applies on the way x -> z) as one launch each way, dim = 16, 32 or 64 (else
  * MNF_ERR_UNSUPPORTED): z = (u @ M - t) e^-s with M = W^-1 (dim, dim) row-major and s, t (dim,) as the modules hold
  * them (no packed image: the kernels arrange M themselves).  The gradient launch writes grad_u and ADDS to grad_m
  * (dim, dim) = u^T (grad_z e^-s), grad_s, grad_t (dim,; either may be NULL); z is recomputed, not read.

@@ -255,31 +255,32 @@ def _pair_case(seed, rows, dim=32):
     return u, M, s, t, gz
 
 
-@pytest.mark.parametrize("rows", [1, 15, 16, 17, 63, 1000, 4099, 70001])
-def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
+@pytest.mark.parametrize("rows,dim", [(1, 32), (15, 32), (16, 32), (17, 32), (63, 32), (1000, 32), (4099, 32), (70001, 32),
+                                      (1, 16), (37, 16), (5000, 16), (1, 64), (37, 64), (5000, 64)])
+def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows, dim):
     """mnf_glow_actnorm_inv / _bwd against the oracle's two layers composed in float64 (oracle.glow's product with M
     given, then oracle.affine_const inverse) and torch.autograd through them.  fp32 MFMA products, fp32 sums over the
     rows by atomics: 2e-6 normwise on the rows, 2e-5 on the sums over up to 70,001 rows."""
     lib = amd._lib.load()
-    u, M, s, t, gz = _pair_case(100 + rows, rows)
+    u, M, s, t, gz = _pair_case(100 + rows + dim, rows, dim)
     u64, M64, s64, t64 = (a.clone().requires_grad_(True) for a in (u, M, s, t))
     z64, _ = O.affine_const(u64 @ M64, s64, t64, inverse=True)
     z64.backward(gz)
     ud, Md, gzd = u.float().to(DEV), M.float().to(DEV).contiguous(), gz.float().to(DEV)
     # (s and t handed over 4-byte aligned only, as views into a flat parameter buffer are)
     st = torch.cat((torch.zeros(1), s.float().reshape(-1), t.float().reshape(-1))).to(DEV)
-    sd, td = st[1:33], st[33:65]
+    sd, td = st[1:1 + dim], st[1 + dim:1 + 2 * dim]
     z = torch.empty_like(ud)
     ld_in, ld = torch.full((1,), 0.75, device=DEV), torch.empty(1, device=DEV)
     amd._lib.check("mnf_glow_actnorm_inv", lib.mnf_glow_actnorm_inv(
         ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), z.data_ptr(), ld_in.data_ptr(), ld.data_ptr(), rows,
-        32, None))
+        dim, None))
     gu = torch.full_like(ud, float("nan"))
-    gM, gs, gt = torch.zeros(32, 32, device=DEV), torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    gM, gs, gt = torch.zeros(dim, dim, device=DEV), torch.zeros(dim, device=DEV), torch.zeros(dim, device=DEV)
     g_ld = torch.full((1,), -0.3, device=DEV)  # cotangent of the pair's log|det J| = 0.75 - sum s
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
         ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-        gs.data_ptr(), gt.data_ptr(), g_ld.data_ptr(), rows, 32, None))
+        gs.data_ptr(), gt.data_ptr(), g_ld.data_ptr(), rows, dim, None))
     assert abs(float(ld) - (0.75 - float(s.sum()))) <= 1e-5
     gs = gs - 0.3  # (checked below against the gradient of z alone)
     torch.cuda.synchronize()
@@ -291,7 +292,7 @@ def test_glow_actnorm_inverse_pair_kernels_vs_float64_oracle(amd, O, rows):
     # the sums are ADDED to, and either column sum may be left out
     amd._lib.check("mnf_glow_actnorm_inv_bwd", lib.mnf_glow_actnorm_inv_bwd(
         ud.data_ptr(), gzd.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-        None, gt.data_ptr(), None, rows, 32, None))
+        None, gt.data_ptr(), None, rows, dim, None))
     torch.cuda.synchronize()
     assert _err(gM.double(), 2 * M64.grad) <= 2e-5 and _err(gt.double(), 2 * t64.grad.reshape(-1)) <= 2e-5
 
@@ -302,7 +303,7 @@ def test_glow_actnorm_inverse_pair_rejects_what_it_has_no_kernel_for(amd):
     assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), None, None, 64, 32, None) \
         == amd._lib.MNF_ERR_INVALID_ARG  # in place
     b = torch.zeros(64, 64, device=DEV)
-    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, 64, 64, None) \
+    assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, 64, 48, None) \
         == amd._lib.MNF_ERR_UNSUPPORTED
     assert lib.mnf_glow_actnorm_inv(a.data_ptr(), a.data_ptr(), a.data_ptr(), a.data_ptr(), b.data_ptr(), None, None, 0, 32, None) \
         == amd._lib.MNF_OK
@@ -310,9 +311,9 @@ def test_glow_actnorm_inverse_pair_rejects_what_it_has_no_kernel_for(amd):
                                         b.data_ptr(), None, None, None, 64, 32, None) == amd._lib.MNF_ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("rows", [777, 8192])
-def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(amd, rows):
-    """-mean log_prob of 3 x [ActNormFlow, Glow, NSF_CL] at d = 32 (bench.py's c3t model): the pass with Glow.inverse +
+@pytest.mark.parametrize("rows,dim", [(777, 32), (8192, 32), (777, 64), (777, 16)])
+def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(amd, rows, dim):
+    """-mean log_prob of 3 x [ActNormFlow, Glow, NSF_CL] (d = 32: bench.py's c3t model; 16 and 64: the other dims the pair kernels are built for): the pass with Glow.inverse +
     ActNormFlow.inverse as one autograd node (the default under log_prob) against the same pass layer by layer
     (MNF_NO_PAIR_FUSION=1, whose gradients tests/test_hip_autograd.py checks against the float64 oracle)."""
     flows_mod = amd.flows
@@ -321,9 +322,9 @@ def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(a
         torch.manual_seed(11)
         layers = []
         for _ in range(3):
-            layers += [amd.ActNormFlow(32), amd.Glow(32), amd.NSF_CL(32, K=8, B=3, n_h=8)]
-        model = amd.NormalizingFlowModel(amd.StandardNormal(32), layers).to(DEV)
-        x = recipes.gaussian(5, rows, 32).to(DEV).requires_grad_(True)
+            layers += [amd.ActNormFlow(dim), amd.Glow(dim), amd.NSF_CL(dim, K=8, B=3, n_h=8)]
+        model = amd.NormalizingFlowModel(amd.StandardNormal(dim), layers).to(DEV)
+        x = recipes.gaussian(5, rows, dim).to(DEV).requires_grad_(True)
         with torch.no_grad():
             model.log_prob(x.detach())  # ActNorm's data-dependent initialisation
         env, flows_mod._NO_PAIR_FUSION_ENV = flows_mod._NO_PAIR_FUSION_ENV, not fused
@@ -376,14 +377,14 @@ def test_graphed_training_step_of_a_spline_block_with_the_fused_pair(amd):
     assert_close(opt_g.flat.data, opt_e.flat.data, 2e-3, "parameters after 11 steps")
 
 
-@pytest.mark.parametrize("rows", [1, 17, 1000, 70001])
-def test_glow_actnorm_inverse_pair_logprob_kernels_vs_float64_oracle(amd, O, rows):
+@pytest.mark.parametrize("rows,dim", [(1, 32), (17, 32), (1000, 32), (70001, 32), (37, 16), (5000, 16), (37, 64), (5000, 64)])
+def test_glow_actnorm_inverse_pair_logprob_kernels_vs_float64_oracle(amd, O, rows, dim):
     """mnf_glow_actnorm_inv_logprob / _bwd (the pair closing a density pass, standard-normal base) against the oracle's
     layers and base.log_prob composed in float64: log p per row, and with a row-dependent cotangent the gradients of
     u, M, s, t, Glow's log|det| and the running log_det.  Budgets as for the plain pair kernels."""
     import math
     lib = amd._lib.load()
-    u, M, s, t, _ = _pair_case(500 + rows, rows)
+    u, M, s, t, _ = _pair_case(500 + rows + dim, rows, dim)
     g = torch.Generator().manual_seed(9 + rows)
     ld_rows = torch.randn(rows, generator=g, dtype=torch.float64)
     g_lp = torch.randn(rows, generator=g, dtype=torch.float64) / rows
@@ -394,21 +395,21 @@ def test_glow_actnorm_inverse_pair_logprob_kernels_vs_float64_oracle(amd, O, row
     lp64.backward(g_lp)
     ud, Md = u.float().to(DEV), M.float().to(DEV).contiguous()
     st = torch.cat((torch.zeros(1), s.float().reshape(-1), t.float().reshape(-1))).to(DEV)
-    sd, td = st[1:33], st[33:65]
+    sd, td = st[1:1 + dim], st[1 + dim:1 + 2 * dim]
     ldg, ldr, gl = torch.full((1,), 0.75, device=DEV), ld_rows.float().to(DEV), g_lp.float().to(DEV)
     lp = torch.empty(rows, device=DEV)
     amd._lib.check("mnf_glow_actnorm_inv_logprob", lib.mnf_glow_actnorm_inv_logprob(
-        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), ldg.data_ptr(), ldr.data_ptr(), lp.data_ptr(), rows, 32,
+        ud.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), ldg.data_ptr(), ldr.data_ptr(), lp.data_ptr(), rows, dim,
         None))
     gu = torch.full_like(ud, float("nan"))
-    gM, gs, gt, gld = (torch.zeros(n, device=DEV) for n in (1024, 32, 32, 1))
+    gM, gs, gt, gld = (torch.zeros(n, device=DEV) for n in (dim * dim, dim, dim, 1))
     amd._lib.check("mnf_glow_actnorm_inv_logprob_bwd", lib.mnf_glow_actnorm_inv_logprob_bwd(
         ud.data_ptr(), gl.data_ptr(), Md.data_ptr(), sd.data_ptr(), td.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-        gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), rows, 32, None))
+        gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), rows, dim, None))
     torch.cuda.synchronize()
     assert _err(lp.double(), lp64.detach()) <= 2e-6
     assert _err(gu.double(), u64.grad) <= 2e-6
-    assert _err(gM.view(32, 32).double(), M64.grad) <= 2e-5
+    assert _err(gM.view(dim, dim).double(), M64.grad) <= 2e-5
     assert _err(gs.double(), s64.grad.reshape(-1)) <= 2e-5
     assert _err(gt.double(), t64.grad.reshape(-1)) <= 2e-5
     assert abs(float(gld) - float(ldg64.grad)) <= 2e-5 * max(1.0, float(g_lp.abs().sum()))

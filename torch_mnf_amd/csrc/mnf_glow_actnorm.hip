@@ -1,6 +1,6 @@
 // Glow.inverse followed by ActNormFlow.inverse -- the pair every [ActNormFlow, Glow, NSF_CL] block applies after its
 // spline layer on the way x -> z, i.e. in every log_prob / training pass (torch_mnf/flows/glow.py:33-37,
-// affine_constant_flow.py:22-26) -- as ONE forward launch and ONE gradient launch for d = 32:
+// affine_constant_flow.py:22-26) -- as ONE forward launch and ONE gradient launch for d = 16, 32 or 64:
 //
 //   forward    z = (u @ M - t) e^-s                                  M = W^-1 (Glow's assembled inverse)
 //   gradients  g_v = g_z e^-s      g_u = g_v @ M^T      g_M = u^T g_v
@@ -33,12 +33,27 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGaWaves = 4;
-constexpr int kGaD = 32;
-constexpr int kGaPitch = 48;  // floats per row of the wave's turn buffer: rows 4 g + k land 16 banks apart
+
+template <int D>
+struct GaShape {
+  static_assert(D == 16 || D == 32 || D == 64, "a whole number of 16-dim tiles, at most four");
+  static constexpr int G = D / 16, NK = D / 4;
+  // floats per row of a wave's turn buffer: the four rows 4 g + k of a group land 16 banks apart (48, 80 = 16 mod 64
+  // up to order), and a row of float4 writes stays 16-byte aligned
+  static constexpr int PITCH = D == 64 ? 80 : 48;
+};
+
+template <int G>
+__device__ __forceinline__ void zero_tiles(f32x4 (&a)[G]) {
+#pragma unroll
+  for (int m = 0; m < G; ++m) a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 
 // acc[m] += image (A operand order of mnf_linear_rows_image_index) x rows held as xv (B operand)
-__device__ __forceinline__ void rows_times_image(const float* lds_image, int lane, const f32x4 (&xv)[2], f32x4 (&acc)[2]) {
-  constexpr int G = kGaD / 16, NK = kGaD / 4;
+template <int D>
+__device__ __forceinline__ void rows_times_image(const float* lds_image, int lane, const f32x4 (&xv)[D / 16],
+                                                 f32x4 (&acc)[D / 16]) {
+  constexpr int G = D / 16, NK = D / 4;
   int a_off = lane * 4;
   asm volatile("" : "+v"(a_off));  // keep the operand reads in the loop (see mnf_ahf_mfma.hip)
   const f32x4* A4 = reinterpret_cast<const f32x4*>(lds_image + a_off);
@@ -56,22 +71,23 @@ __device__ __forceinline__ void rows_times_image(const float* lds_image, int lan
 
 // M (row-major, or its transpose when T) into LDS in A-operand order -- the layout mnf_linear_rows_image_index describes:
 // word (n >> 2) * 256 + lane * 4 + (n & 3) of MFMA n = (K-step kk, output tile m) is M[16 g + 4 (lane >> 4) + e][16 m +
-// (lane & 15)] with kk = 4 g + e.  Done here, per workgroup, from the 4 KB matrix in L2: no packing launch per step.
-template <bool T>
+// (lane & 15)] with kk = 4 g + e.  Done here, per workgroup, from the few KB of the matrix in L2: no packing launch per step.
+template <int D, bool T>
 __device__ __forceinline__ void stage_matrix(float* lds, const float* M) {
-  constexpr int G = kGaD / 16;
-  for (int p = threadIdx.x; p < kGaD * kGaD; p += blockDim.x) {
+  constexpr int G = D / 16;
+  for (int p = threadIdx.x; p < D * D; p += blockDim.x) {
     const int n = 4 * (p >> 8) + (p & 3), lane = (p >> 2) & 63;
     const int kk = n / G, m = n - kk * G;
     const int k = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), o = 16 * m + (lane & 15);
-    lds[p] = T ? M[o * kGaD + k] : M[k * kGaD + o];
+    lds[p] = T ? M[o * D + k] : M[k * D + o];
   }
 }
 
-// [e^-s | t] of the lane's eight columns (16 m + 4 q + r)
-__device__ __forceinline__ void load_post(const float* s, const float* t, int q, f32x4 (&es)[2], f32x4 (&tt)[2]) {
+// [e^-s | t] of the lane's columns 16 m + 4 q + r
+template <int G>
+__device__ __forceinline__ void load_post(const float* s, const float* t, int q, f32x4 (&es)[G], f32x4 (&tt)[G]) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < G; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // (scalar loads: s and t may sit anywhere in a flat parameter buffer)
       es[m][r] = expf(-s[16 * m + 4 * q + r]);
@@ -79,19 +95,26 @@ __device__ __forceinline__ void load_post(const float* s, const float* t, int q,
     }
 }
 
+template <int G>
+__device__ __forceinline__ void load_row(const float* p, f32x4 (&v)[G]) {
+#pragma unroll
+  for (int m = 0; m < G; ++m) v[m] = *reinterpret_cast<const f32x4*>(p + 16 * m);
+}
+
 // z = (u @ M - t) e^-s.  LP (the pair closes a density pass under a standard-normal base, core.py:46-49): z is not
 // stored; the launch writes log p(row) = log_det_rows[row] + (ld_glow - sum s) - |z|^2 / 2 - d log(2 pi) / 2 instead.
-template <bool LP>
+template <int D, bool LP>
 __global__ void __launch_bounds__(kGaWaves * 64)
 glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M, const float* __restrict__ s,
                         const float* __restrict__ t, float* __restrict__ z, const float* __restrict__ ld_glow,
                         float* __restrict__ ld_out, const float* __restrict__ ld_rows, float* __restrict__ lp_out,
                         int64_t rows) {
-  __shared__ __attribute__((aligned(16))) float lds[kGaD * kGaD];
+  constexpr int G = D / 16;
+  __shared__ __attribute__((aligned(16))) float lds[D * D];
   __shared__ float ld_pair;
-  stage_matrix<false>(lds, M);
+  stage_matrix<D, false>(lds, M);
   if (threadIdx.x < 64) {  // the pair's log|det J|: Glow's (given) - sum s
-    float v = threadIdx.x < kGaD ? -s[threadIdx.x] : 0.f;
+    float v = threadIdx.x < D ? -s[threadIdx.x] : 0.f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     v += ld_glow ? ld_glow[0] : 0.f;
@@ -103,8 +126,8 @@ glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
-  f32x4 es[2], tt[2];
-  load_post(s, t, q, es, tt);
+  f32x4 es[G], tt[G];
+  load_post<G>(s, t, q, es, tt);
   const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * kGaWaves;
   auto row_of = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
@@ -112,179 +135,181 @@ glow_actnorm_inv_kernel(const float* __restrict__ u, const float* __restrict__ M
   };
   int tile = (int)blockIdx.x * kGaWaves + wave;
   if (tile >= n_tiles) return;
-  const float ldc = ld_pair - (float)kGaD * kHalfLog2Pi;
-  f32x4 nx[2];
+  const float ldc = ld_pair - (float)D * kHalfLog2Pi;
+  f32x4 nx[G];
   float nl = 0.f;
-  {
-    const float* p = u + row_of(tile) * kGaD + 4 * q;
-    nx[0] = *reinterpret_cast<const f32x4*>(p);
-    nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
-    if (LP) nl = ld_rows[row_of(tile)];
-  }
+  load_row<G>(u + row_of(tile) * D + 4 * q, nx);
+  if (LP) nl = ld_rows[row_of(tile)];
   for (; tile < n_tiles; tile += step) {
-    const f32x4 xv[2] = {nx[0], nx[1]};
+    f32x4 xv[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) xv[m] = nx[m];
     const float ldr = nl;
     {  // the next tile's rows (past the end: the last tile's again)
       const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
-      const float* p = u + row_of(nt) * kGaD + 4 * q;
-      nx[0] = *reinterpret_cast<const f32x4*>(p);
-      nx[1] = *reinterpret_cast<const f32x4*>(p + 16);
+      load_row<G>(u + row_of(nt) * D + 4 * q, nx);
       if (LP) nl = ld_rows[row_of(nt)];
     }
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    rows_times_image(lds, lane, xv, acc);
+    f32x4 acc[G];
+    zero_tiles<G>(acc);
+    rows_times_image<D>(lds, lane, xv, acc);
     if (LP) {
       float sq = 0.f;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < G; ++m) {
         const f32x4 zz = (acc[m] - tt[m]) * es[m];
         sq += (zz[0] * zz[0] + zz[1] * zz[1]) + (zz[2] * zz[2] + zz[3] * zz[3]);
       }
       sq = sum_over_q(sq);
       lp_out[row_of(tile)] = ldr + (ldc - 0.5f * sq);  // (every q lane of a row, and rows past the end, store the same value)
     } else {
-      float* zr = z + row_of(tile) * kGaD + 4 * q;  // (rows past the end rewrite the last row with its own values)
+      float* zr = z + row_of(tile) * D + 4 * q;  // (rows past the end rewrite the last row with its own values)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(zr + 16 * m) = (acc[m] - tt[m]) * es[m];
+      for (int m = 0; m < G; ++m) *reinterpret_cast<f32x4*>(zr + 16 * m) = (acc[m] - tt[m]) * es[m];
     }
   }
 }
 
 // LP: gz holds d loss / d log p per ROW; grad_z = -z gz[row] is formed from the recomputed z, and the row sums of gz --
 // the cotangent of the pair's log|det J| -- leave through grad_ld_out (added to) and enter grad_s.
-template <int WAVES, bool LP>
+template <int D, int WAVES, bool LP>
 __global__ void __launch_bounds__(WAVES * 64)
 glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ M,
                             const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ gu,
                             float* __restrict__ grad_m, float* __restrict__ grad_s, float* __restrict__ grad_t,
                             const float* __restrict__ grad_ld, float* __restrict__ grad_ld_out, int64_t rows) {
-  __shared__ __attribute__((aligned(16))) float lds_m[kGaD * kGaD], lds_mt[kGaD * kGaD];
-  __shared__ __attribute__((aligned(16))) float red[4 * 256];
-  __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * kGaPitch];
-  __shared__ float red_st[2 * kGaD + 1];
-  stage_matrix<false>(lds_m, M);
-  stage_matrix<true>(lds_mt, M);
-  if (threadIdx.x < 2 * kGaD + 1) red_st[threadIdx.x] = 0.f;
+  constexpr int G = D / 16, PITCH = GaShape<D>::PITCH;
+  __shared__ __attribute__((aligned(16))) float lds_m[D * D], lds_mt[D * D];
+  __shared__ __attribute__((aligned(16))) float red[G * G * 256];
+  __shared__ __attribute__((aligned(16))) float turn[WAVES][2][16 * PITCH];
+  __shared__ float red_st[2 * D + 1];
+  stage_matrix<D, false>(lds_m, M);
+  stage_matrix<D, true>(lds_mt, M);
+  if (threadIdx.x < 2 * D + 1) red_st[threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;  // row-on-the-lane layout
   const int c = lane & 15, k = lane >> 4;  // rows-on-K layout
-  f32x4 es[2], tt[2];
-  load_post(s, t, q, es, tt);
+  f32x4 es[G], tt[G];
+  load_post<G>(s, t, q, es, tt);
   float* const my_u = &turn[wave][0][0];
   float* const my_g = &turn[wave][1][0];
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 wacc[2][2] = {{zero4, zero4}, {zero4, zero4}};  // g_M tiles, summed over this wave's rows
-  f32x4 sacc[2] = {zero4, zero4}, tacc[2] = {zero4, zero4};
+  f32x4 wacc[G][G];  // g_M tiles, summed over this wave's rows
+#pragma unroll
+  for (int a = 0; a < G; ++a) zero_tiles<G>(wacc[a]);
+  f32x4 sacc[G], tacc[G];
+  zero_tiles<G>(sacc);
+  zero_tiles<G>(tacc);
   const int n_tiles = (int)((rows + 15) >> 4), step = (int)gridDim.x * WAVES;
   auto row_of = [&](int tile) {
     const int64_t row = (int64_t)tile * 16 + j;
     return row < rows ? row : rows - 1;
   };
   int tile = (int)blockIdx.x * WAVES + wave;
-  f32x4 nu[2], ng[2];
+  f32x4 nu[G], ng[G];
   float nl = 0.f, lacc = 0.f;
   {
     const int t0 = tile < n_tiles ? tile : n_tiles - 1;
-    const int64_t off = row_of(t0) * kGaD + 4 * q;
-    nu[0] = *reinterpret_cast<const f32x4*>(u + off);
-    nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
-    if (LP) {
+    const int64_t off = row_of(t0) * D + 4 * q;
+    load_row<G>(u + off, nu);
+    if (LP)
       nl = gz[row_of(t0)];
-    } else {
-      ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
-      ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
-    }
+    else
+      load_row<G>(gz + off, ng);
   }
   for (; tile < n_tiles; tile += step) {
-    const f32x4 uv[2] = {nu[0], nu[1]};
-    f32x4 gv_in[2];
+    f32x4 uv[G], gv_in[G];
     const float glp = nl;
-    if (!LP) gv_in[0] = ng[0], gv_in[1] = ng[1];
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      uv[m] = nu[m];
+      if (!LP) gv_in[m] = ng[m];
+    }
     {  // the next tile's rows in the first layout
       const int nt = tile + step < n_tiles ? tile + step : n_tiles - 1;
-      const int64_t off = row_of(nt) * kGaD + 4 * q;
-      nu[0] = *reinterpret_cast<const f32x4*>(u + off);
-      nu[1] = *reinterpret_cast<const f32x4*>(u + off + 16);
-      if (LP) {
+      const int64_t off = row_of(nt) * D + 4 * q;
+      load_row<G>(u + off, nu);
+      if (LP)
         nl = gz[row_of(nt)];
-      } else {
-        ng[0] = *reinterpret_cast<const f32x4*>(gz + off);
-        ng[1] = *reinterpret_cast<const f32x4*>(gz + off + 16);
-      }
+      else
+        load_row<G>(gz + off, ng);
     }
     const float live = (int64_t)tile * 16 + j < rows ? 1.f : 0.f;
     if (LP && q == 0) lacc += glp * live;  // (one lane per row)
     // z = (u @ M - t) e^-s, recomputed; g_s -= g_z z; g_v = g_z e^-s; g_t -= g_v
-    f32x4 acc[2] = {zero4, zero4};
-    rows_times_image(lds_m, lane, uv, acc);
-    f32x4 gv[2];
+    f32x4 acc[G];
+    zero_tiles<G>(acc);
+    rows_times_image<D>(lds_m, lane, uv, acc);
+    f32x4 gv[G];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < G; ++m) {
       const f32x4 zz = (acc[m] - tt[m]) * es[m];
       if (LP) gv_in[m] = zz * -glp;  // d log N(z) / d z = -z
       gv[m] = gv_in[m] * es[m];
       sacc[m] -= gv_in[m] * zz * live;
       tacc[m] -= gv[m] * live;
       // the tile for the second layout (rows past the end: zeros on the u side)
-      *reinterpret_cast<f32x4*>(my_u + j * kGaPitch + 16 * m + 4 * q) = uv[m] * live;
-      *reinterpret_cast<f32x4*>(my_g + j * kGaPitch + 16 * m + 4 * q) = gv[m];
+      *reinterpret_cast<f32x4*>(my_u + j * PITCH + 16 * m + 4 * q) = uv[m] * live;
+      *reinterpret_cast<f32x4*>(my_g + j * PITCH + 16 * m + 4 * q) = gv[m];
     }
     // g_u = g_v @ M^T
-    f32x4 gacc[2] = {zero4, zero4};
-    rows_times_image(lds_mt, lane, gv, gacc);
-    float* gr = gu + row_of(tile) * kGaD + 4 * q;
+    f32x4 gacc[G];
+    zero_tiles<G>(gacc);
+    rows_times_image<D>(lds_mt, lane, gv, gacc);
+    float* gr = gu + row_of(tile) * D + 4 * q;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) *reinterpret_cast<f32x4*>(gr + 16 * m) = gacc[m];
+    for (int m = 0; m < G; ++m) *reinterpret_cast<f32x4*>(gr + 16 * m) = gacc[m];
     // g_M += u^T g_v, 4 rows per MFMA (LDS operations of a wave run in order: its reads see its lanes' writes)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int at = (4 * g + k) * kGaPitch + c;
-      const float ua[2] = {my_u[at], my_u[at + 16]}, ga[2] = {my_g[at], my_g[at + 16]};
+      const int at = (4 * g + k) * PITCH + c;
+      float ua[G], ga[G];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < G; ++a) ua[a] = my_u[at + 16 * a], ga[a] = my_g[at + 16 * a];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < G; ++a)
+#pragma unroll
+        for (int b = 0; b < G; ++b)
           wacc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[a], ga[b], wacc[a][b], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // column sums: the 16 row lanes of a q group hold the same 8 columns
+  // column sums: the 16 row lanes of a q group hold the same columns
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < G; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       atomicAdd(red_st + 16 * m + 4 * q + r, sacc[m][r]);
-      atomicAdd(red_st + kGaD + 16 * m + 4 * q + r, tacc[m][r]);
+      atomicAdd(red_st + D + 16 * m + 4 * q + r, tacc[m][r]);
     }
   if (LP) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lacc += __shfl_xor(lacc, m, 64);
-    if (lane == 0) atomicAdd(red_st + 2 * kGaD, lacc);
+    if (lane == 0) atomicAdd(red_st + 2 * D, lacc);
   }
   for (int w = 0; w < WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        f32x4* p = reinterpret_cast<f32x4*>(red + t * 256 + lane * 4);
-        *p = w == 0 ? wacc[t >> 1][t & 1] : *p + wacc[t >> 1][t & 1];
+      for (int tl = 0; tl < G * G; ++tl) {
+        f32x4* p = reinterpret_cast<f32x4*>(red + tl * 256 + lane * 4);
+        *p = w == 0 ? wacc[tl / G][tl % G] : *p + wacc[tl / G][tl % G];
       }
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
-    const int t = e >> 8, l = (e >> 2) & 63, reg = e & 3;
-    const int i = 16 * (t >> 1) + 4 * (l >> 4) + reg, jj = 16 * (t & 1) + (l & 15);
-    atomicAdd(grad_m + i * kGaD + jj, red[e]);
+  for (int e = threadIdx.x; e < G * G * 256; e += blockDim.x) {
+    const int tl = e >> 8, l = (e >> 2) & 63, reg = e & 3;
+    const int i = 16 * (tl / G) + 4 * (l >> 4) + reg, jj = 16 * (tl % G) + (l & 15);
+    atomicAdd(grad_m + i * D + jj, red[e]);
   }
-  if (threadIdx.x < kGaD) {
+  if (threadIdx.x < D) {
     // (d log|det J| / d s = -1 per column: once, from the first workgroup)
     if (grad_s)
       atomicAdd(grad_s + threadIdx.x, red_st[threadIdx.x] - (grad_ld && blockIdx.x == 0 ? grad_ld[0] : 0.f) -
-                                          (LP ? red_st[2 * kGaD] : 0.f));
-    if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[kGaD + threadIdx.x]);
-    if (LP && grad_ld_out && threadIdx.x == 0) atomicAdd(grad_ld_out, red_st[2 * kGaD]);
+                                          (LP ? red_st[2 * D] : 0.f));
+    if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[D + threadIdx.x]);
+    if (LP && grad_ld_out && threadIdx.x == 0) atomicAdd(grad_ld_out, red_st[2 * D]);
   }
 }
 
@@ -299,32 +324,69 @@ bool aligned16(const void* a, const void* b, const void* c2) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c2)) & 15) == 0;
 }
 
+#ifndef MNF_GA_BWD_WAVES
+#define MNF_GA_BWD_WAVES 4
+#endif
+#ifndef MNF_GA_BWD_PER_CU
+#define MNF_GA_BWD_PER_CU 2
+#endif
+
+template <int D, bool LP>
+int launch_fwd(const float* u, const float* M, const float* s, const float* t, float* z, const float* ld_glow, float* ld_out,
+               const float* ld_rows, float* lp_out, int64_t rows, hipStream_t stream) {
+  hipLaunchKernelGGL((glow_actnorm_inv_kernel<D, LP>), dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
+                     stream, u, M, s, t, z, ld_glow, ld_out, ld_rows, lp_out, rows);
+  return check_launch();
+}
+
+// eight waves per CU measured best at d = 32, 2^20 rows (workgroups of 4 waves: 1 per CU 95 us, 2: 89, 3: 95, 4: 101; 8
+// waves x 2: 101, 16 x 1: 101 -- the same 8 waves as 8 x 1: 90, so it is not the count of closing atomics; the operand
+// images held in registers instead of re-read from LDS per tile: 101); d = 64 holds 88 KB of LDS: one workgroup per CU
+template <int D, bool LP>
+int launch_bwd(const float* u, const float* g, const float* M, const float* s, const float* t, float* grad_u, float* grad_m,
+               float* grad_s, float* grad_t, const float* grad_ld, float* grad_ld_out, int64_t rows, hipStream_t stream) {
+  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<D, MNF_GA_BWD_WAVES, LP>),
+                     dim3((unsigned)grid_for_tiles(rows, D == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
+                     dim3(MNF_GA_BWD_WAVES * 64), 0, stream, u, g, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld,
+                     grad_ld_out, rows);
+  return check_launch();
+}
+
+bool dim_ok(int dim) { return dim == 16 || dim == 32 || dim == 64; }
+
 }  // namespace
 }  // namespace mnf
 
 using namespace mnf;
+
+#define MNF_GA_DISPATCH(call16, call32, call64) (dim == 16 ? (call16) : dim == 32 ? (call32) : (call64))
 
 extern "C" {
 
 int mnf_glow_actnorm_inv(const float* u, const float* M, const float* s, const float* t, float* z, const float* ld_glow,
                          float* ld_out, int64_t rows, int dim, void* stream) {
   if (!u || !M || !s || !t || !z || u == z || rows < 0) return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, z, z) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
+  if (!dim_ok(dim) || !aligned16(u, z, z) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL(glow_actnorm_inv_kernel<false>, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, M, s, t, z, ld_glow, ld_out, (const float*)nullptr, (float*)nullptr, rows);
-  return check_launch();
+  hipStream_t st = (hipStream_t)stream;
+  const float* no_rows = nullptr;
+  float* no_lp = nullptr;
+  return MNF_GA_DISPATCH((launch_fwd<16, false>(u, M, s, t, z, ld_glow, ld_out, no_rows, no_lp, rows, st)),
+                         (launch_fwd<32, false>(u, M, s, t, z, ld_glow, ld_out, no_rows, no_lp, rows, st)),
+                         (launch_fwd<64, false>(u, M, s, t, z, ld_glow, ld_out, no_rows, no_lp, rows, st)));
 }
 
 int mnf_glow_actnorm_inv_logprob(const float* u, const float* M, const float* s, const float* t, const float* ld_glow,
                                  const float* log_det_rows, float* log_prob, int64_t rows, int dim, void* stream) {
   if (!u || !M || !s || !t || !log_det_rows || !log_prob || rows < 0) return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, u, u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
+  if (!dim_ok(dim) || !aligned16(u, u, u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL(glow_actnorm_inv_kernel<true>, dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
-                     (hipStream_t)stream, u, M, s, t, (float*)nullptr, ld_glow, (float*)nullptr, log_det_rows, log_prob,
-                     rows);
-  return check_launch();
+  hipStream_t st = (hipStream_t)stream;
+  float* no_z = nullptr;
+  float* no_ld = nullptr;
+  return MNF_GA_DISPATCH((launch_fwd<16, true>(u, M, s, t, no_z, ld_glow, no_ld, log_det_rows, log_prob, rows, st)),
+                         (launch_fwd<32, true>(u, M, s, t, no_z, ld_glow, no_ld, log_det_rows, log_prob, rows, st)),
+                         (launch_fwd<64, true>(u, M, s, t, no_z, ld_glow, no_ld, log_det_rows, log_prob, rows, st)));
 }
 
 int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
@@ -332,36 +394,28 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M
                              int64_t rows, int dim, void* stream) {
   if (!u || !grad_z || !M || !s || !t || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
     return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, grad_z, grad_u) || rows >= (int64_t)1 << 31)
-    return MNF_ERR_UNSUPPORTED;
+  if (!dim_ok(dim) || !aligned16(u, grad_z, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-#ifndef MNF_GA_BWD_WAVES
-#define MNF_GA_BWD_WAVES 4
-#endif
-#ifndef MNF_GA_BWD_PER_CU
-#define MNF_GA_BWD_PER_CU 2
-#endif
-  // eight waves per CU measured best at 2^20 rows (workgroups of 4 waves: 1 per CU 95 us, 2: 89, 3: 95, 4: 101; 8 waves
-  // x 2: 101, 16 x 1: 101 -- the same 8 waves as 8 x 1: 90, so it is not the count of closing atomics; the operand
-  // images held in registers instead of re-read from LDS per tile: 101)
-  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES, false>),
-                     dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
-                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_z, M, s, t, grad_u, grad_m, grad_s,
-                     grad_t, grad_ld, (float*)nullptr, rows);
-  return check_launch();
+  hipStream_t st = (hipStream_t)stream;
+  float* no_out = nullptr;
+  return MNF_GA_DISPATCH(
+      (launch_bwd<16, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)),
+      (launch_bwd<32, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)),
+      (launch_bwd<64, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)));
 }
 
 int mnf_glow_actnorm_inv_logprob_bwd(const float* u, const float* grad_log_prob, const float* M, const float* s,
                                      const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
                                      float* grad_ld_glow, int64_t rows, int dim, void* stream) {
   if (!u || !grad_log_prob || !M || !s || !t || !grad_u || !grad_m || grad_u == u || rows < 0) return MNF_ERR_INVALID_ARG;
-  if (dim != kGaD || !aligned16(u, grad_u, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
+  if (!dim_ok(dim) || !aligned16(u, grad_u, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
-  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<MNF_GA_BWD_WAVES, true>),
-                     dim3((unsigned)grid_for_tiles(rows, MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
-                     dim3(MNF_GA_BWD_WAVES * 64), 0, (hipStream_t)stream, u, grad_log_prob, M, s, t, grad_u, grad_m,
-                     grad_s, grad_t, (const float*)nullptr, grad_ld_glow, rows);
-  return check_launch();
+  hipStream_t st = (hipStream_t)stream;
+  const float* no_ld = nullptr;
+  return MNF_GA_DISPATCH(
+      (launch_bwd<16, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)),
+      (launch_bwd<32, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)),
+      (launch_bwd<64, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)));
 }
 
 }  // extern "C"

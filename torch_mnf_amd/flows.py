@@ -610,7 +610,7 @@ def _linear_rows_table(lib, dim: int, device) -> Tensor | None:
     return _LINEAR_ROWS_INDEX[key]
 
 
-_PAIR_FUSION_DIM = 32  # mnf_glow_actnorm_inv / _bwd (csrc/mnf_glow_actnorm.hip)
+_PAIR_FUSION_DIMS = (16, 32, 64)  # mnf_glow_actnorm_inv / _bwd (csrc/mnf_glow_actnorm.hip)
 _NO_PAIR_FUSION_ENV = os.environ.get("MNF_NO_PAIR_FUSION", "0") == "1"
 
 
@@ -2195,7 +2195,7 @@ class _GlowActNormInvLogProbFn(torch.autograd.Function):
 def _pair_fusable(glow: "Glow", actnorm: "ActNormFlow", x) -> bool:
     """Training pass, x -> z: can Glow.inverse + ActNormFlow.inverse at this input go out as the fused pair?"""
     return (not _NO_PAIR_FUSION_ENV and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
-            and x.dtype == torch.float32 and glow.dim == actnorm.dim == x.shape[1] == _PAIR_FUSION_DIM
+            and x.dtype == torch.float32 and glow.dim == actnorm.dim == x.shape[1] and glow.dim in _PAIR_FUSION_DIMS
             and actnorm.data_dep_init_done is not False and not glow.force_generic
             and glow.L.is_cuda and glow.L.device == x.device and glow.L.dtype == torch.float32
             and _wants_grad(glow, x) and _wants_grad(actnorm, x))
