@@ -77,18 +77,34 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
     float* tm_ = stage + wave * (2 * 16 * kPitch);
     float* tv_ = tm_ + 16 * kPitch;
     {
-      const int64_t base = tile * 16 * n_out;
+      // (every load of the tile requested up front, without a branch -- elements past the tile or the last row read a
+      //  clamped address and are zeroed by a select: as a loop of guarded loads each of the ~13 passes waited for its own
+      //  three loads, 180 us per 256,000 x 50 launch)
+      constexpr int IT = 4 * YT;  // ceil(16 n_out / 64) at n_out = 16 YT
+      const int64_t base = tile * 16 * n_out, last = rows * n_out - 1;
       const int n_el = (int)min((int64_t)16 * n_out, max((int64_t)0, rows * n_out - base));
-      for (int i = lane; i < 16 * n_out; i += 64) {
+      const float* eps_or_g = eps ? eps : gout;
+      float gl[IT], sl[IT], el[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int64_t at = min(base + lane + 64 * it, last);
+        gl[it] = gout[at];
+        sl[it] = sd[at];
+        el[it] = eps_or_g[at];
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int i = lane + 64 * it;
         const int r_ = i / n_out, o = i - r_ * n_out;
-        float g = 0.f, v = 0.f;
-        if (i < n_el) {
-          g = gout[base + i];
-          const float e = eps ? eps[base + i] : ml_normal(seed, tile * 16 + r_, o);
-          v = g * e / (2.f * sd[base + i]);  // d out / d var = eps / (2 sqrt(var))   (mnf_linear.py:56)
+        const bool on = i < n_el;
+        float e = el[it];
+        if (!eps) e = ml_normal(seed, tile * 16 + r_, o);  // (wave-uniform; no memory operation inside)
+        const float g = on ? gl[it] : 0.f;
+        const float v = on ? g * e / (2.f * sl[it]) : 0.f;  // d out / d var = eps / (2 sqrt(var))   (mnf_linear.py:56)
+        if (i < 16 * n_out) {
+          tm_[r_ * kPitch + o] = g;
+          tv_[r_ * kPitch + o] = v;
         }
-        tm_[r_ * kPitch + o] = g;
-        tv_[r_ * kPitch + o] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();  // (the wave's own LDS writes, read back by other lanes of the same wave below)
