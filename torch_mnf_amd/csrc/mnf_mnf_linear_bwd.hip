@@ -801,8 +801,12 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   int32_t* flags = list + 1 + n_groups;
   uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + mlb_header_bytes(rows));
   if (int rc = zero_word_async(list, stream)) return rc;
-  const int cus = device_cus(current_device());
-  const int64_t blocks_p = n_groups < 2 * cus ? n_groups : 2 * cus;
+  // as many workgroups as are resident at once (YT = 4 holds a tile's 48 loads in registers: one per CU; a second one
+  // per CU queued behind the first measured 99 us against 89 at 256,000 x 50)
+  static DeviceMemo memo_p;
+  const int resident_p =
+      memo_p.get([](int dev) { return resident_by_occupancy(ml_bwd_prologue_kernel<YT>, 8 * 64, dev, 1); });
+  const int64_t blocks_p = n_groups < resident_p ? n_groups : resident_p;
   hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,
                      flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f);
   if (int rc = check_launch()) return rc;
