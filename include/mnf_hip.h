@@ -15,6 +15,9 @@
  *   mnf_affine_const     AffineConstantFlow.forward / .inverse  torch_mnf/flows/affine_constant_flow.py:18-26
  *   mnf_linear_rows      Glow.forward / .inverse (x @ W)        torch_mnf/flows/glow.py:26-37
  *   mnf_glow_weight      Glow._assemble_W, W^-1, log_det        torch_mnf/flows/glow.py:20-37
+ *   mnf_glow_actnorm_inv Glow.inverse + ActNormFlow.inverse     torch_mnf/flows/glow.py:33-37,
+ *     (+ _logprob)       (a block's pair on the way x -> z;     torch_mnf/flows/affine_constant_flow.py:22-26,
+ *                        closing a density pass: + log_prob)    torch_mnf/flows/core.py:46-49
  *   mnf_gauss_logprob(_sq) base.log_prob + the callers' mean    torch_mnf/flows/core.py:46-49,
  *                                                               examples/half_moons.ipynb:183-186
  *   mnf_sample_z0        MNFLinear.sample_z prologue            torch_mnf/layers/mnf_linear.py:58-62
