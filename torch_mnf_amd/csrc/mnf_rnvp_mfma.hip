@@ -344,11 +344,14 @@ __device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int gr
                                   log_det, image, rows, d, accumulate, seed, zprm, dm, vec);
 }
 
-#ifndef MNF_RNVP_SPLIT_OCC
-#define MNF_RNVP_SPLIT_OCC 4  // workgroups per CU the register allocation aims at (experiment switch)
-#endif
-template <int HN, bool SEEDED, bool RAG>
-__global__ void __launch_bounds__(kRnvpWaves * 64, MNF_RNVP_SPLIT_OCC)
+// OCC = waves per SIMD the register allocation aims at.  4 (<= 128 registers, two 8-wave workgroups per CU, 50-140
+// registers spilled) or 2 (no spills, one workgroup per CU), chosen per launch -- measured at 256,000 rows, seeded mask,
+// us per launch at OCC 4 / 2: ragged rows d = 50: 146 / 123, 96: 118 / 114, 200: 274 / 269, 400: 387 / 397, 799: 1,518 /
+// 1,250; whole 16-dim groups d = 64: 89 / 80, 128: 151 / 140, 256: 254 / 272, 512: 474 / 481, 784: 754 / 734, 800: 714 /
+// 777, 1,024: 919 / 1,471.  (The spills are scratch traffic: at d = 50 the launch moved 241 MB of writes for a 51 MB
+// output, `rocprofv3 --pmc WRITE_SIZE`.)  So: 2 for ragged rows and for d <= 128, else 4.
+template <int HN, bool SEEDED, bool RAG, int OCC>
+__global__ void __launch_bounds__(kRnvpWaves * 64, OCC)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
                   int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
@@ -391,29 +394,49 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   }
 }
 
-template <int HN, bool RAG>
-static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
-                             const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
-                             const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
-                             float* y_out = nullptr) {
+template <int HN, bool RAG, int OCC>
+static int launch_rnvp_split_occ(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                                 const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
+                                 const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
+                                 float* y_out) {
   const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
   static DeviceMemo memo_mask, memo_seed;
   const int resident_mask = memo_mask.get(
-      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, false, RAG>, kRnvpWaves * 64, dev, 1); });
+      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, false, RAG, OCC>, kRnvpWaves * 64, dev, 1); });
   const int resident_seed = memo_seed.get(
-      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, true, RAG>, kRnvpWaves * 64, dev, 1); });
+      [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, true, RAG, OCC>, kRnvpWaves * 64, dev, 1); });
   // experiment switch: MNF_RNVP_BLOCKS_PER_CU=n caps the persistent grid at n workgroups per CU
   static const int cap = [] { const char* e = getenv("MNF_RNVP_BLOCKS_PER_CU"); return e ? atoi(e) * 256 : 1 << 30; }();
   const int resident0 = mask ? resident_mask : resident_seed;
   const int resident = resident0 < cap ? resident0 : cap;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   if (mask)
-    hipLaunchKernelGGL((rnvp_split_kernel<HN, false, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, false, RAG, OCC>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
                        z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
   else
-    hipLaunchKernelGGL((rnvp_split_kernel<HN, true, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
+    hipLaunchKernelGGL((rnvp_split_kernel<HN, true, RAG, OCC>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
                        z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
   return check_launch();
+}
+
+template <int HN, bool RAG>
+static int launch_rnvp_split(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                             const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
+                             const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
+                             float* y_out = nullptr) {
+  // MNF_RNVP_SPLIT_OCC=2|4 forces one register target for rows of whole 16-dim groups (A/B measurements)
+  static const int forced = [] { const char* e = getenv("MNF_RNVP_SPLIT_OCC"); return e ? atoi(e) : 0; }();
+  const bool two = forced == 2 || (forced != 4 && (RAG || dim <= 128));
+  if constexpr (RAG) {
+    return launch_rnvp_split_occ<HN, true, 2>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
+                                              q0_log_var, dm, vec, stream, y_out);
+  } else {
+    if (two)
+      return launch_rnvp_split_occ<HN, false, 2>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
+                                                 q0_log_var, dm, vec, stream, y_out);
+    return launch_rnvp_split_occ<HN, false, 4>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
+                                               q0_log_var, dm, vec, stream, y_out);
+  }
 }
 
 // ---------------------------------------------------------------- host: image index table
