@@ -347,13 +347,15 @@ int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
  * reference's torch.inverse of the assembled W, :34); log_det (1) = +-sum log|S| (:29, :35).  P, L, U (dim, dim), S (dim),
  * row-major, all device memory.  _bwd: grad_out = the cotangent of `out` (or NULL), grad_log_det (1) or NULL;
  * grad_L (strictly lower part; zeros elsewhere), grad_S, grad_U (strictly upper part) are written (accumulate = 0) or
- * ADDED to (accumulate = 1).  dim <= MNF_GLOW_WEIGHT_MAX_DIM, else MNF_ERR_UNSUPPORTED (one workgroup, matrices in LDS). */
+ * ADDED to (accumulate = 1).  out_fwd (inverse = 1; or NULL): the `out` mnf_glow_weight produced for the same parameters --
+ * the gradient launch then starts from that W^-1 instead of recomputing it (two substitutions and two products less).
+ * dim <= MNF_GLOW_WEIGHT_MAX_DIM, else MNF_ERR_UNSUPPORTED (one workgroup, matrices in LDS). */
 #define MNF_GLOW_WEIGHT_MAX_DIM 64
 int mnf_glow_weight(const float* P, const float* L, const float* S, const float* U, float* out, float* log_det, int dim,
                     int inverse, void* stream);
 int mnf_glow_weight_bwd(const float* P, const float* L, const float* S, const float* U, const float* grad_out,
                         const float* grad_log_det, float* grad_L, float* grad_S, float* grad_U, int dim, int inverse,
-                        int accumulate, void* stream);
+                        int accumulate, const float* out_fwd, void* stream);
 
 /* ------------------------------------------------------------------ MAF / IAF (generic path)
  * torch_mnf/flows/maf.py:21-72 over net = MADE(dim, hidden, 2 dim, natural_ordering=True) (torch_mnf/layers/made.py:11-94:

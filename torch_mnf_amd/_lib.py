@@ -158,7 +158,7 @@ SIGNATURES = {
     "mnf_mnf_noise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mnf_glow_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mnf_glow_weight_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_int, c_int, c_int, c_void_p]),
+                                    c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mnf_maf_flat_floats": (c_int64, [c_int, c_int, _intp]),
     "mnf_maf_mask_bytes": (c_int64, [c_int, c_int, _intp]),
     "mnf_maf": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, _intp,

@@ -35,6 +35,7 @@ struct GlowArgs {
   float* gS;
   float* gU;
   int d, inverse, accumulate;
+  const float* out_fwd;  // backward, inverse direction: the W^-1 the forward launch handed out (or nullptr: recomputed)
 };
 
 // The matrices live in LDS padded to DP x DP (DP = 8, 16, 32 or 64; identity padding: the padded W is diag(W, I), whose
@@ -145,9 +146,17 @@ __global__ void __launch_bounds__(kGlowThreads) glow_weight_bwd_kernel(const Glo
   }
   __syncthreads();
   if (a.inverse) {
-    glow_tri_inverses<DP>(Lm, Um, T1, T2);
-    glow_mm<DP, false, true>(T1, Pm, T3);        // T3 = Lm^-1 P^T
-    glow_mm<DP, false, false>(T2, T3, T1);       // T1 = W^-1
+    if (a.out_fwd) {  // W^-1 as the forward launch computed it (identity padding): two substitutions and two products less
+      for (int idx = threadIdx.x; idx < n; idx += kGlowThreads) {
+        const int i = idx / DP, j = idx - i * DP;
+        T1[idx] = i < d && j < d ? a.out_fwd[i * d + j] : (i == j ? 1.f : 0.f);
+      }
+      __syncthreads();
+    } else {
+      glow_tri_inverses<DP>(Lm, Um, T1, T2);
+      glow_mm<DP, false, true>(T1, Pm, T3);      // T3 = Lm^-1 P^T
+      glow_mm<DP, false, false>(T2, T3, T1);     // T1 = W^-1
+    }
     glow_mm<DP, true, false>(T1, Gm, T2);        // T2 = W^-T G
     glow_mm<DP, false, true>(T2, T1, Gm, -1.f);  // Gm = -W^-T G W^-T = cotangent of W
   }
@@ -212,16 +221,17 @@ int mnf_glow_weight(const float* P, const float* L, const float* S, const float*
                     int inverse, void* stream) {
   if (!P || !L || !S || !U || !out || !log_det || dim < 1) return MNF_ERR_INVALID_ARG;
   if (dim > kGlowMaxDim) return MNF_ERR_UNSUPPORTED;
-  GlowArgs a{P, L, S, U, out, log_det, nullptr, nullptr, nullptr, nullptr, nullptr, dim, inverse != 0, 0};
+  GlowArgs a{P, L, S, U, out, log_det, nullptr, nullptr, nullptr, nullptr, nullptr, dim, inverse != 0, 0, nullptr};
   return glow_dispatch(a, false, (hipStream_t)stream);
 }
 
 int mnf_glow_weight_bwd(const float* P, const float* L, const float* S, const float* U, const float* grad_out,
                         const float* grad_log_det, float* grad_L, float* grad_S, float* grad_U, int dim, int inverse,
-                        int accumulate, void* stream) {
+                        int accumulate, const float* out_fwd, void* stream) {
   if (!P || !L || !S || !U || !grad_L || !grad_S || !grad_U || dim < 1) return MNF_ERR_INVALID_ARG;
   if (dim > kGlowMaxDim) return MNF_ERR_UNSUPPORTED;
-  GlowArgs a{P, L, S, U, nullptr, nullptr, grad_out, grad_log_det, grad_L, grad_S, grad_U, dim, inverse != 0, accumulate != 0};
+  GlowArgs a{P, L, S, U, nullptr, nullptr, grad_out, grad_log_det, grad_L, grad_S, grad_U, dim, inverse != 0, accumulate != 0,
+             inverse ? out_fwd : nullptr};
   return glow_dispatch(a, true, (hipStream_t)stream);
 }
 

@@ -1575,7 +1575,7 @@ class _GlowWeightFn(torch.autograd.Function):
         _lib.check("mnf_glow_weight", _lib.load().mnf_glow_weight(
             P.data_ptr(), Lc.data_ptr(), Sc.data_ptr(), Uc.data_ptr(), out.data_ptr(), ld.data_ptr(), d, int(inverse),
             _stream()))
-        ctx.save_for_backward(Lc, Sc, Uc, P)
+        ctx.save_for_backward(Lc, Sc, Uc, P, out)  # (out: in the inverse direction the gradient launch starts from W^-1)
         ctx.inverse, ctx.home = inverse, home
         ctx.set_materialize_grads(False)
         return out, ld
@@ -1583,7 +1583,7 @@ class _GlowWeightFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out, g_ld):
-        Lc, Sc, Uc, P = ctx.saved_tensors
+        Lc, Sc, Uc, P, out = ctx.saved_tensors
         d, home = Sc.numel(), ctx.home
         go = None if g_out is None else g_out.contiguous()
         gl = None if g_ld is None else g_ld.contiguous()
@@ -1594,7 +1594,7 @@ class _GlowWeightFn(torch.autograd.Function):
         gL, gS, gU = buf[:d * d], buf[d * d:d * d + d], buf[d * d + d:]
         _lib.check("mnf_glow_weight_bwd", _lib.load().mnf_glow_weight_bwd(
             P.data_ptr(), Lc.data_ptr(), Sc.data_ptr(), Uc.data_ptr(), _ptr(go), _ptr(gl), gL.data_ptr(), gS.data_ptr(),
-            gU.data_ptr(), d, int(ctx.inverse), int(home is not None), _stream()))
+            gU.data_ptr(), d, int(ctx.inverse), int(home is not None), out.data_ptr() if ctx.inverse else None, _stream()))
         if home is not None:
             return None, None, None, None, None, None
         return gL.view(d, d), gS, gU.view(d, d), None, None, None
