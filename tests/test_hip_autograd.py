@@ -373,10 +373,12 @@ def nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic):
     return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
 
 
-@pytest.fixture(params=["pairs", "single"])
-def nsf_rows_kernel(request, monkeypatch):
-    """Both row-per-lane NSF_CL gradient kernels: the wave-pair one (default) and the one-wave-per-tile one."""
-    monkeypatch.setenv("MNF_NSF_BWD_PAIRS", "1" if request.param == "pairs" else "0")
+@pytest.fixture(params=["tile", "pairs", "single"])
+def nsf_rows_kernel(request, monkeypatch, amd):
+    """The NSF_CL gradient kernels with matrix-core sums: the tile kernel (default: the conditioner as split MFMAs, 16
+    rows per wave) and round 4's two lane-per-element kernels (the wave-pair one and the one-wave-per-tile one)."""
+    monkeypatch.setattr(amd.flows, "_NSF_BWD_KERNEL", "tile" if request.param == "tile" else "rows")
+    monkeypatch.setenv("MNF_NSF_BWD_PAIRS", "0" if request.param == "single" else "1")
     return request.param
 
 
@@ -441,6 +443,86 @@ def test_nsf_cl_row_gradient_kernel_many_rows(amd, inverse, nsf_rows_kernel):
     for k in one:
         if k != "x":
             assert_close(many[k], copies * one[k], GTOL, f"{k}: {copies} copies")
+
+
+def nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=False):
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    f.force_generic = generic
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = (f.inverse if inverse else f.forward)(x)
+    ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+
+
+@pytest.mark.parametrize("dim,K,n_h", [(16, 8, 8), (24, 5, 4), (8, 8, 8), (32, 8, 7)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
+    """The tile gradient kernel away from d = 32: halves narrower than its 16-element tile (whole float4 groups of a
+    lane are dead), against autograd through the oracle and against the generic kernel."""
+    lib = amd._lib.load()
+    assert lib.mnf_nsf_cl_bwd_tile_supported(dim, K, 3, amd._lib.int_array((n_h,) * 3)) == 1
+    rows = 777
+    sd = recipes.nsf_cl_params(4100 + dim + K, dim, K, n_h)
+    x_cpu = recipes.gaussian(4200 + dim, rows, dim, scale=1.3)
+    x_cpu[0, :] = 5.0
+    x_cpu[1, ::2] = 3.0
+    x_cpu.requires_grad_(True)
+    w_y = recipes.gaussian(4300, rows, dim)
+    w_l = recipes.gaussian(4400, rows, 1)[:, 0]
+    oracle = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse), w_y, w_l), x_cpu, sd)
+    got = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l)
+    ref = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=True)
+    oracle.check_all(got, f"nsf tile kernel d={dim} K={K} n_h={n_h} inv={inverse}")
+    for k in got:
+        assert_close(got[k], ref[k], 5e-5, f"tile vs generic {k}")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_tile_gradient_kernel_cold_tiles(amd, O, inverse):
+    """Rows whose conditioner operands leave the split range (|x| >= 2^13: identity tails for the spline, but the other
+    half's net sees them) send their 16-row tile to the fix-up pass: the tile kernel must add nothing for those tiles
+    and the generic kernel everything."""
+    rows, K, n_h = 1003, 8, 8
+    sd = recipes.nsf_cl_params(4500, 32, K, n_h)
+    x_cpu = recipes.gaussian(4501, rows, 32, scale=1.3)
+    x_cpu[40, :16] = 2.0e4    # lower half: the first net's input (forward) / the second step's (inverse)
+    x_cpu[333, 16:] = -1.5e4  # upper half
+    x_cpu[1002, 3] = 9.0e3    # the ragged last tile
+    x_cpu.requires_grad_(True)
+    w_y = recipes.gaussian(4502, rows, 32)
+    w_l = recipes.gaussian(4503, rows, 1)[:, 0]
+    oracle = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse), w_y, w_l), x_cpu, sd)
+    got = nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
+    oracle.check_all(got, f"nsf tile kernel, cold tiles, inv={inverse}", base=GBASE_STRESS)
+
+
+def test_nsf_cl_tile_gradient_kernel_poisoned_launch(amd, O):
+    """A cotangent far above the scale the sampled rows set (row 900 of 1,003: the sample is the first 512) overflows
+    f16 as a gradient operand: the launch is poisoned, the reduction adds nothing and the fix-up pass does every row."""
+    rows, K, n_h = 1003, 8, 8
+    sd = recipes.nsf_cl_params(4600, 32, K, n_h)
+    x_cpu = recipes.gaussian(4601, rows, 32, scale=1.3).requires_grad_(True)
+    w_y = recipes.gaussian(4602, rows, 32)
+    w_l = recipes.gaussian(4603, rows, 1)[:, 0]
+    w_l[900] = 3.0e7
+    oracle = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, True), w_y, w_l), x_cpu, sd)
+    got = nsf_grads(amd, sd, K, n_h, True, x_cpu, w_y, w_l, generic=False)
+    oracle.check_all(got, "nsf tile kernel, poisoned launch", base=GBASE_STRESS)
+
+
+def test_nsf_cl_tile_gradient_kernel_repeats_bit_for_bit(amd):
+    """No float atomics: two runs of the same gradient pass give identical bits (fixed-order two-stage reduction)."""
+    rows, K, n_h = 40000, 8, 8
+    sd = recipes.nsf_cl_params(4700, 32, K, n_h)
+    x_cpu = recipes.gaussian(4701, rows, 32, scale=1.3)
+    w_y = recipes.gaussian(4702, rows, 32)
+    w_l = recipes.gaussian(4703, rows, 1)[:, 0]
+    a = nsf_grads(amd, sd, K, n_h, True, x_cpu, w_y, w_l, generic=False)
+    b = nsf_grads(amd, sd, K, n_h, True, x_cpu, w_y, w_l, generic=False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("dim", [50, 800])

@@ -573,6 +573,10 @@ struct NsfBwdArgs {
   int R, maxw, act_floats, ldp;
   int act_off[MNF_MAX_LINEAR];
   NetDesc f1, f2;
+  // non-null: the fix-up pass of mnf_nsf_cl_bwd_tile -- only the 16-row tiles cold[2 .. 2 + cold[0]) (every tile when
+  // cold[0] < 0 or cold[1] != 0), by a fixed grid; R then divides 16
+  const int32_t* cold;
+  int cold_capacity;
 };
 
 // one half-step forward on LDS rows: vals <- spline(vals; net(cond)); acts keeps the net's layers
@@ -612,9 +616,8 @@ __device__ __forceinline__ void nsf_half_backward(const float* flat, float* grad
   mlp_backward(flat, grad_flat, false, nd, cond, H, acts, act_off, dA, dB, g_cond, R);
 }
 
-__global__ void __launch_bounds__(kBwdThreads) nsf_bwd_kernel(NsfBwdArgs a) {
+__device__ __forceinline__ void nsf_bwd_block(const NsfBwdArgs& a, const int64_t row0) {
   const int H = a.dim / 2;
-  const int64_t row0 = (int64_t)blockIdx.x * a.R;
   const int R = (int)min((int64_t)a.R, a.rows - row0);
   float* lo0 = bsmem;                 // lower half, input
   float* up0 = lo0 + a.R * H;         // upper half, input
@@ -660,6 +663,23 @@ __global__ void __launch_bounds__(kBwdThreads) nsf_bwd_kernel(NsfBwdArgs a) {
     const int64_t g = (row0 + r) * a.dim;
     a.grad_x[g + j] = g_lo[idx];
     a.grad_x[g + H + j] = g_up[idx];
+  }
+}
+
+__global__ void __launch_bounds__(kBwdThreads) nsf_bwd_kernel(NsfBwdArgs a) {
+  if (a.cold == nullptr) {
+    nsf_bwd_block(a, (int64_t)blockIdx.x * a.R);
+    return;
+  }
+  const int64_t n_tiles = (a.rows + 15) >> 4;
+  const bool all = a.cold[0] < 0 || a.cold[1] != 0;
+  const int64_t n = all ? n_tiles : min((int64_t)a.cold[0], (int64_t)a.cold_capacity);
+  const int per = 16 / a.R;
+  for (int64_t item = blockIdx.x; item < n * per; item += gridDim.x) {
+    const int64_t tile = all ? item / per : a.cold[2 + item / per];
+    const int64_t row0 = tile * 16 + (item % per) * a.R;
+    if (row0 < a.rows) nsf_bwd_block(a, row0);
+    __syncthreads();  // the block's LDS rows are reused by the next item
   }
 }
 
@@ -935,9 +955,9 @@ int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
   return check_launch();
 }
 
-int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
-                   const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
-                   const int* hidden, void* stream) {
+static int nsf_cl_bwd_launch(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                             const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                             const int* hidden, const int32_t* cold, int cold_capacity, void* stream) {
   if (!x || !grad_x || !flat || rows < 0 || dim < 2 || (dim & 1) || K < 2 || K > kMaxBins || !(tail_bound > 0.f) ||
       !hidden_ok(n_hidden, hidden))
     return K > kMaxBins ? MNF_ERR_UNSUPPORTED : MNF_ERR_INVALID_ARG;
@@ -964,12 +984,35 @@ int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
   int R = kBwdLdsFloats / per_row;
   if (R < 1) return MNF_ERR_UNSUPPORTED;
   if (R > 32) R = 32;
+  int64_t blocks = (rows + R - 1) / R;
+  if (cold) {  // the listed 16-row tiles only: R divides 16, a fixed grid walks the list
+    R = R >= 16 ? 16 : (R >= 8 ? 8 : (R >= 4 ? 4 : (R >= 2 ? 2 : 1)));
+    a.cold = cold;
+    a.cold_capacity = cold_capacity;
+    blocks = ((rows + 15) / 16) * (16 / R);
+    const int64_t cap = 8 * (int64_t)device_cus(current_device());
+    if (blocks > cap) blocks = cap;
+  }
   a.R = R;
-  const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(nsf_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      (hipStream_t)stream, a);
   return check_launch();
+}
+
+int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                   const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse, int n_hidden,
+                   const int* hidden, void* stream) {
+  return nsf_cl_bwd_launch(x, grad_y, grad_ld, grad_x, grad_flat, flat, rows, dim, K, tail_bound, inverse, n_hidden,
+                           hidden, nullptr, 0, stream);
+}
+
+int mnf_nsf_cl_bwd_tile_fixup(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+                              const float* flat, int64_t rows, int dim, int K, float tail_bound, int inverse,
+                              int n_hidden, const int* hidden, const int32_t* cold, int cold_capacity, void* stream) {
+  if (!cold || cold_capacity < (rows + 15) / 16) return MNF_ERR_INVALID_ARG;
+  return nsf_cl_bwd_launch(x, grad_y, grad_ld, grad_x, grad_flat, flat, rows, dim, K, tail_bound, inverse, n_hidden,
+                           hidden, cold, cold_capacity, stream);
 }
 
 }  // extern "C"

@@ -38,6 +38,9 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 # ... and below this many rows anyway: the split kernel needs three small launches more per backward pass (gradient
 # scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
 # 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
+# NSF_CL gradient kernel: "tile" (default: mnf_nsf_bwd_tile.hip where the shape has one), "rows" (round 3/4's lane-per-
+# element kernel, d = 32 only; kept for A/B runs), "generic"
+_NSF_BWD_KERNEL = os.environ.get("MNF_NSF_BWD_KERNEL", "tile")
 _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
 # MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
@@ -414,18 +417,48 @@ class _NsfFn(torch.autograd.Function):
         grad_x = torch.empty_like(x)
         grad_flat = torch.zeros_like(flat)
         lib = _lib.load()
-        # the row-per-lane kernel where it exists (d = 32, hidden width <= 8, K in {5, 8}), else the generic one
-        rows_kernel = (not m.force_generic and x.shape[0] * m.dim < (1 << 31)
+        rows = x.shape[0]
+        args = (rows, m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid)
+        # the tile kernel (conditioner on the matrix cores, 16 rows per wave) where it exists -- dim a multiple of 8 up to
+        # 64, hidden width <= 16, K in {5, 8} --, followed by its fp32 fix-up pass over the tiles it handed back; else
+        # the generic kernel
+        table = None
+        if not (m.force_generic or m.force_fp32_mfma or _FP32_MFMA_ENV or _NSF_BWD_KERNEL == "generic"
+                or rows * m.dim >= (1 << 31)):
+            table = m._bwd_tile_tables(x.device)
+        marks = None
+        if bwd_kernel_events is not None and (table or _NSF_BWD_KERNEL == "rows"):  # bench.py --workload c3t
+            marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if table and _NSF_BWD_KERNEL != "rows":
+            idx, flush, n_split, n_plain = table
+            image = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=x.device)
+            _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
+                flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, n_plain, _stream()))
+            scale = _grad_scale(gy, gl, rows, m.dim, x.device)
+            cap = (rows + 15) // 16
+            cold = torch.zeros(cap + 2, dtype=torch.int32, device=x.device)
+            n_work = lib.mnf_nsf_cl_bwd_tile_workspace(rows, m.dim, m.K, len(m.h_sizes), m._hid)
+            work = torch.empty(n_work, dtype=torch.float32, device=x.device)
+            if marks is not None:
+                marks[0].record()
+            _lib.check("mnf_nsf_cl_bwd_tile", lib.mnf_nsf_cl_bwd_tile(
+                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), image.data_ptr(),
+                flush.data_ptr(), *args, scale.data_ptr(), cold.data_ptr(), cap, work.data_ptr(), n_work, _stream()))
+            if marks is not None:
+                marks[1].record()
+                bwd_kernel_events.append(marks)
+            _lib.check("mnf_nsf_cl_bwd_tile_fixup", lib.mnf_nsf_cl_bwd_tile_fixup(
+                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
+                cold.data_ptr(), cap, _stream()))
+            return grad_x, grad_flat, None, None
+        rows_kernel = (_NSF_BWD_KERNEL == "rows" and not m.force_generic and rows * m.dim < (1 << 31)
                        and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid))
         name = "mnf_nsf_cl_bwd_rows" if rows_kernel else "mnf_nsf_cl_bwd"
-        marks = None
-        if bwd_kernel_events is not None and rows_kernel:  # bench.py --workload c3t
-            marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if marks is not None and rows_kernel:
             marks[0].record()
         _lib.check(name, getattr(lib, name)(
-            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
-            x.shape[0], m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid, _stream()))
-        if marks is not None:
+            x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
+        if marks is not None and rows_kernel:
             marks[1].record()
             bwd_kernel_events.append(marks)
         return grad_x, grad_flat, None, None
@@ -1077,6 +1110,27 @@ class NSF_CL(_TwoWayFlow):
         _lib.check("mnf_nsf_cl_split_index", lib.mnf_nsf_cl_split_index(
             self.dim, self.K, len(self.h_sizes), self._hid, idx))
         return idx, n_split.value, n_plain.value
+
+    def _bwd_tile_tables(self, device):
+        """(operand index table, flush table, n_split_words, n_plain_words) of the tile gradient kernel on the device,
+        built once per module; False: no such kernel for this shape."""
+        cached = self.__dict__.get("_bwd_tile_cache")
+        if cached is None or (cached and cached[0].device != device):
+            lib = _lib.load()
+            n_split, n_plain, n_params = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = lib.mnf_nsf_cl_bwd_tile_layout(self.dim, self.K, len(self.h_sizes), self._hid, ctypes.byref(n_split),
+                                                ctypes.byref(n_plain), ctypes.byref(n_params))
+            cached = False
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_nsf_cl_bwd_tile_layout", rc)
+                idx = (ctypes.c_int32 * (2 * n_split.value + n_plain.value))()
+                flush = (ctypes.c_int32 * n_params.value)()
+                _lib.check("mnf_nsf_cl_bwd_tile_index", lib.mnf_nsf_cl_bwd_tile_index(
+                    self.dim, self.K, len(self.h_sizes), self._hid, idx, flush))
+                cached = (torch.frombuffer(idx, dtype=torch.int32).clone().to(device),
+                          torch.frombuffer(flush, dtype=torch.int32).clone().to(device), n_split.value, n_plain.value)
+            self.__dict__["_bwd_tile_cache"] = cached
+        return cached
 
     def _run(self, x, inverse, accum):
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
