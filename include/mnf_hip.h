@@ -557,13 +557,15 @@ int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_l
  * (mnf_nsf_bwd_tile.hip; NSF_CL under loss.backward(): torch_mnf/flows/spline_flow.py:249-285, tests/test_flows.py:89-99):
  * dim a multiple of 8 up to 64, three hidden layers of at most 16 units, K = 5 or 8 -- the shapes
  * mnf_nsf_cl_bwd_tile_supported() answers 1 for.
+ *   y            the layer's OUTPUT for the same x, direction and parameters (mnf_nsf_cl's): the second net's conditioner
+ *                input is a column block of it, so the first half-step is not recomputed to get it
  *   bwd_image    mnf_pack_gather_split of `flat` through the table of mnf_nsf_cl_bwd_tile_index (n_split_words,
  *                n_plain_words from _layout; 2 * n_split_words + n_plain_words entries)
  *   flush_dev    the second table of _index on the device: n_params int32
  *   grad_scale_dev  device float, a power of two that brings the cotangents near 1 (mnf_affine_half_grad_scale)
- *   cold         device int32 [2 + cold_capacity], ZEROED by the caller, cold_capacity >= ceil(rows / 16): [0] the number
- *                of 16-row tiles whose operands left the split range (-1: the weights did), [1] != 0 when a gradient
- *                operand left f16's range, [2 ..] the tiles.  mnf_nsf_cl_bwd_tile_fixup (same stream, same arguments,
+ *   cold         device int32 [2 + 2 * cold_capacity], ZEROED by the caller, cold_capacity >= ceil(rows / 16): [0] the
+ *                number of 16-row tiles whose operands left the split range (-1: the weights did), [1] != 0 when a gradient
+ *                operand left f16's range, [2 ..] the tiles, [2 + cold_capacity ..] a flag per tile.  mnf_nsf_cl_bwd_tile_fixup (same stream, same arguments,
  *                `flat`) MUST follow: it recomputes exactly those rows -- every row in the last two cases -- on the
  *                generic fp32 kernel.
  *   workspace    mnf_nsf_cl_bwd_tile_workspace(...) floats: every workgroup's sums as one block; a second kernel adds
@@ -574,7 +576,7 @@ int mnf_nsf_cl_bwd_tile_layout(int dim, int K, int n_hidden, const int* hidden_h
 int mnf_nsf_cl_bwd_tile_index(int dim, int K, int n_hidden, const int* hidden_host, int32_t* idx_host,
                               int32_t* flush_host);
 int64_t mnf_nsf_cl_bwd_tile_workspace(int64_t rows, int dim, int K, int n_hidden, const int* hidden_host);
-int mnf_nsf_cl_bwd_tile(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+int mnf_nsf_cl_bwd_tile(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                         const void* bwd_image, const int32_t* flush_dev, int64_t rows, int dim, int K, float tail_bound,
                         int inverse, int n_hidden, const int* hidden_host, const float* grad_scale_dev, int32_t* cold,
                         int cold_capacity, float* workspace, int64_t workspace_floats, void* stream);

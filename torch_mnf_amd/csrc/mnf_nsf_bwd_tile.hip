@@ -21,15 +21,22 @@
 //     MFMA adds to is selected by a scalar branch, which compiler-managed loop-carried values would not survive
 //     without copies.
 //
-// Two waves per tile, as in the row kernel: X (waves 0 .. PAIRS-1) owns the first half-step's net and its sums, Y the
-// second's; per tile X runs the first net forward and hands the half it produced to Y, Y differentiates the second
-// half-step and hands both cotangents back, X differentiates the first.  Software-pipelined over the pair's tiles,
-// one workgroup barrier per slot.
+// Two launches per layer, one per half-step, each over all tiles with every wave on its own: stage 0 differentiates the
+// SECOND half-step (its net's sums, the cotangent of the half it transforms, and the first half-step's output half's
+// cotangent, which it parks in grad_x), stage 1 the FIRST (reading both cotangents back from grad_x).  The second
+// net's conditioner input -- the half the first half-step produced -- is a column block of the layer's OUTPUT, which the
+// forward pass has written and autograd keeps: the caller passes it (`y`) and nothing of the first half-step is
+// recomputed to get it (the row kernel spent a fifth of its instructions there).  A wave therefore holds ONE net's
+// sums and LDS one net's operand image (d = 64 fits), and there is no hand-over between waves: round 5's first form
+// of this kernel gave a tile to a pair of waves (one net each, a mailbox and a workgroup barrier per tile) and the
+// two waves of a SIMD then ran in lockstep -- both in their MFMA bursts, both in the spline -- with the vector units
+// 68 % busy; independent waves drift apart and cover each other's bursts.
 //
 // Cotangents of a mean over 2^20 rows are ~1e-6, below f16's normal range: the caller passes a power of two
 // (`scale_dev`) that brings max |cotangent| near 1; grad_x and the parameter gradients are scaled back on the way out.
-// Range: a tile whose forward operands (x, h1, h2, h3) reach kSplitLimit is not computed at all -- X finds that for its
-// net in step 1, Y for its net at the top of step 2, before anything is accumulated -- and goes to `cold`; the caller
+// Range: a tile whose forward operands (x, h1, h2, h3 of either net) reach kSplitLimit is not computed at all -- stage 0
+// runs both nets' hidden layers at the top of a tile, before anything is accumulated, and flags the tile for stage 1
+// -- and goes to `cold`; the caller
 // runs mnf_nsf_cl_bwd_tile_fixup (the generic kernel over the listed tiles) next.  Gradient operands (g_p, the deltas)
 // are only known while the sums are being formed: one beyond f16's range poisons the launch (cold[1] = 1), the
 // reduction kernel then adds nothing and the fix-up pass recomputes every row.  The sums leave the kernel as one block
@@ -89,15 +96,18 @@ struct NtShape {
   static constexpr int T_B4 = T_BH + 1;            // !BIASCOL: [entry][one-hot column = tile number & 15]
   static constexpr int N_B4 = BIASCOL ? 0 : (S * NB + 15) / 16;
   static constexpr int TILES = T_B4 + N_B4;
-  static constexpr int RED_FLOATS = 2 * TILES * 256;
+  static constexpr int RED_FLOATS = TILES * 256;
   // one wave per SIMD when the sums take more than half of the wave's registers at two
   static constexpr int WAVES_PER_SIMD = (4 * TILES <= 112) ? 2 : 1;
-  static constexpr int PAIRS = 2 * WAVES_PER_SIMD;  // wave pairs per workgroup (one workgroup per CU)
+  static constexpr int WAVES = 4 * WAVES_PER_SIMD;               // per workgroup (one workgroup per CU)
   static constexpr bool ACC_AG = WAVES_PER_SIMD == 1;            // the sums in accumulator registers / at the top of the vector file
   static constexpr int ACC_BASE = ACC_AG ? 0 : 256 - 4 * TILES;
-  static constexpr int MAIL_WORDS = 2 * PAIRS * 3 * G * 64 * 4;
-  static constexpr int LDS_WORDS = (IMAGE_WORDS > RED_FLOATS ? IMAGE_WORDS : RED_FLOATS) + MAIL_WORDS + 4 * PAIRS;
-  static_assert(4 * TILES <= 208, "accumulator registers");
+  // LDS: [the stage's net: operands | biases][stage 0: the other net's hidden layers: G + 2 operands | 3 bias tiles]
+  static constexpr int OTHER_OPS = G + 2;
+  static constexpr int LDS_NET = SPLIT_WORDS_NET + PLAIN_WORDS_NET;
+  static constexpr int LDS_IMG = LDS_NET + OTHER_OPS * 256 + 3 * 16;
+  static constexpr int LDS_WORDS = LDS_IMG > RED_FLOATS ? LDS_IMG : RED_FLOATS;
+  static_assert(4 * TILES <= 256, "accumulator registers");
   static_assert(LDS_WORDS * 4 <= 160 * 1024, "LDS");
 };
 
@@ -180,6 +190,7 @@ __device__ __forceinline__ bool unit_active(const u32x2& hi, const u32x2& lo, in
 
 struct NtArgs {
   const float* x;
+  const float* y;  // the layer's output (the forward pass's)
   const float* grad_y;
   const float* grad_ld;
   float* grad_x;
@@ -188,7 +199,7 @@ struct NtArgs {
   const int32_t* flush;  // per flat parameter: its element in the workgroup's reduced sums
   float* partials;       // [workgroup][n_params]
   const float* scale_dev;
-  int32_t* cold;         // [0] count (-1: weights out of range), [1] poison, [2 ..] tiles
+  int32_t* cold;         // [0] count (-1: weights out of range), [1] poison, [2 ..] tiles, [2 + capacity ..] per-tile flags
   int cold_capacity;
   int64_t rows;
   float T;
@@ -255,15 +266,19 @@ __device__ __forceinline__ void slot_params(const NetView<H, NH, K>& nv, int s, 
   using Sh = NtShape<H, NH, K>;
   constexpr int NB = Sh::NB;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the slot's operands and bias tiles are requested together and waited for ONCE (left alone hipcc puts each read in
+  // front of its MFMAs: six exposed LDS latencies per slot with only one other wave on the SIMD to cover them)
   f32x4 prm[NB], prc[NB];
+  u32x2 ah[NB], al[NB];
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
-    u32x2 ah, al;
-    nv.op(Sh::OP_F4 + s * NB + kb, ah, al);
+    nv.op(Sh::OP_F4 + s * NB + kb, ah[kb], al[kb]);
     prm[kb] = nv.bias[4 * (3 + s * NB + kb)];
     prc[kb] = zero4;
-    mac16(ah, al, h3h, h3l, prm[kb], prc[kb]);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) mac16(ah[kb], al[kb], h3h, h3l, prm[kb], prc[kb]);
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     const f32x4 v = prc[kb] * kSplitInvScale + prm[kb];
@@ -272,36 +287,7 @@ __device__ __forceinline__ void slot_params(const NetView<H, NH, K>& nv, int s, 
   }
 }
 
-// Step 1: the first half-step's output half (the other net's conditioner input).  Returns max |operand|.
-template <int H, int NH, int K, bool INV>
-__device__ __forceinline__ float step_value(const NetView<H, NH, K>& nv, const f32x4 (&cond)[H / 16],
-                                            const f32x4 (&val)[H / 16], float T, float wmax_seed,
-                                            f32x4 (&out)[H / 16]) {
-  using Sh = NtShape<H, NH, K>;
-  constexpr int G = Sh::G, P = Sh::P;
-  u32x2 xh[G], xl[G], hh[3], hl[3];
-  float mx = wmax_seed;
-  hidden_forward<H, NH, K>(nv, cond, xh, xl, hh, hl, mx);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    f32x4 v4 = val[g], o4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma nounroll
-    for (int r = 0; r < 4; ++r) {
-      float p[4 * Sh::NB];
-      slot_params<H, NH, K>(nv, 4 * g + r, hh[2], hl[2], p);
-      float pp[P];
-#pragma unroll
-      for (int i = 0; i < P; ++i) pp[i] = p[i];
-      const float o = rqs_value<K, INV>(v4[0], T, pp);
-      v4 = f32x4{v4[1], v4[2], v4[3], v4[0]};   // (the run-time slot loop always works on component 0)
-      o4 = f32x4{o4[1], o4[2], o4[3], o};
-    }
-    out[g] = o4;
-  }
-  return mx;
-}
-
-// One half-step backwards (steps 2 and 3).  cond: the conditioning half; val: the transformed half BEFORE the spline;
+// One half-step backwards.  cond: the conditioning half; val: the transformed half BEFORE the spline;
 // g_val: cotangent of that half after the spline (becomes the cotangent of val); g_cond += the net's share.
 // Returns false -- before anything has been accumulated -- when a forward operand is out of the split range.
 template <int H, int NH, int K, bool INV>
@@ -378,6 +364,10 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
       v4 = f32x4{v4[1], v4[2], v4[3], v4[0]};
       go4 = f32x4{go4[1], go4[2], go4[3], g_v};
       f16x8 d_hl[NB];
+      u32x2 t4h[NB], t4l[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) nv.op(Sh::OP_T4 + s * NB + kb, t4h[kb], t4l[kb]);  // (requested together: see slot_params)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
         f32x4 gt;
@@ -385,9 +375,7 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
         for (int i = 0; i < 4; ++i) gt[i] = 4 * kb + i < P ? g_p[4 * kb + i < P ? 4 * kb + i : 0] : 0.f;
         u32x2 gh, gl;
         split_tile(gt, gh, gl, mx_grad);
-        u32x2 ah, al;
-        nv.op(Sh::OP_T4 + s * NB + kb, ah, al);
-        mac16(ah, al, gh, gl, y_mn, y_cr);
+        mac16(t4h[kb], t4l[kb], gh, gl, y_mn, y_cr);
         d_hl[kb] = delta_op(gh, gl);
       }
       // the slot's accumulators: a scalar branch on r (g is unrolled)
@@ -465,10 +453,12 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
   return true;
 }
 
-template <int H, int NH, int K, bool INV>
+// ST = 0: the second half-step (forward: f2, inverse: f1), cotangents from grad_y; ST = 1: the first, cotangents from
+// where stage 0 left them in grad_x
+template <int H, int NH, int K, bool INV, int ST>
 __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
   using Sh = NtShape<H, NH, K>;
-  constexpr int G = Sh::G, PAIRS = Sh::PAIRS;
+  constexpr int G = Sh::G, WAVES = Sh::WAVES;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   // weights beyond the split range (max |w|, written behind the image by the pack kernel): the fix-up pass does it all
   const float wmax = __builtin_bit_cast(float, a.image[Sh::SPLIT_WORDS + Sh::PLAIN_WORDS]);
@@ -476,45 +466,50 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cold[0] = -1;
     return;
   }
+  // forward:  up1 = S(up0; f1(lo0)),  lo1 = S(lo0; f2(up1))       -> reverse: f2's step, then f1's
+  // inverse:  lo1 = S^-1(lo0; f2(up0)), up1 = S^-1(up0; f1(lo1))  -> reverse: f1's step, then f2's
+  constexpr int net_first = INV ? 1 : 0;                     // the first half-step's net (f1 = 0, f2 = 1)
+  constexpr int my_net = ST ? net_first : 1 - net_first, other_net = 1 - my_net;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(a.image);
-    uint4* dst = reinterpret_cast<uint4*>(lds);
-    for (int i = threadIdx.x; i < (Sh::SPLIT_WORDS + Sh::PLAIN_WORDS) / 4; i += blockDim.x) dst[i] = src[i];
+    auto copy = [&](int dst_word, int src_word, int n_words) {
+      const uint4* src = reinterpret_cast<const uint4*>(a.image + src_word);
+      uint4* dst = reinterpret_cast<uint4*>(lds + dst_word);
+      for (int i = threadIdx.x; i < n_words / 4; i += blockDim.x) dst[i] = src[i];
+    };
+    copy(0, my_net * Sh::SPLIT_WORDS_NET, Sh::SPLIT_WORDS_NET);
+    copy(Sh::SPLIT_WORDS_NET, Sh::SPLIT_WORDS + my_net * Sh::PLAIN_WORDS_NET, Sh::PLAIN_WORDS_NET);
+    if (ST == 0) {
+      copy(Sh::LDS_NET, other_net * Sh::SPLIT_WORDS_NET, Sh::OTHER_OPS * 256);
+      copy(Sh::LDS_NET + Sh::OTHER_OPS * 256, Sh::SPLIT_WORDS + other_net * Sh::PLAIN_WORDS_NET, 3 * 16);
+    }
   }
-  constexpr int IMG = Sh::IMAGE_WORDS > Sh::RED_FLOATS ? Sh::IMAGE_WORDS : Sh::RED_FLOATS;
-  f32x4* const mail = reinterpret_cast<f32x4*>(lds + IMG);  // [slot parity][pair][mid | g_a | g_b][G][lane]
-  int32_t* const mail_cold = reinterpret_cast<int32_t*>(lds + IMG + Sh::MAIL_WORDS);  // [slot parity][pair][X's | Y's]
-  if (threadIdx.x < 4 * PAIRS) mail_cold[threadIdx.x] = 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pair = wave % PAIRS, role = wave / PAIRS;  // role 0: X, 1: Y (one of each per SIMD)
   const int j = lane & 15, q = lane >> 4;
   const float g_scale = a.scale_dev[0], g_unscale = 1.0f / g_scale;  // a power of two: both exact
 
   reserve_acc<Sh::ACC_AG>();
   nt_static_for<0, Sh::TILES>([&](auto t) { AccT<Sh, decltype(t)::value>::zero(); });
 
-  // forward:  up1 = S(up0; f1(lo0)),  lo1 = S(lo0; f2(up1))       -> reverse: f2's step, then f1's
-  // inverse:  lo1 = S^-1(lo0; f2(up0)), up1 = S^-1(up0; f1(lo1))  -> reverse: f1's step, then f2's
-  constexpr int net_a = INV ? 1 : 0, net_b = 1 - net_a;  // f1 = 0, f2 = 1
   const int hr = a.hr, dim = 2 * hr;
-  const int col_a = INV ? 0 : hr, col_b = hr - col_a;  // columns of the half each step transforms
-  const int my_net = role ? net_b : net_a;
-  NetView<H, NH, K> nv;
+  // columns of the half the first half-step transforms (col_first) and of the other one
+  const int col_first = INV ? 0 : hr, col_second = hr - col_first;
+  const int col_val = ST ? col_first : col_second, col_cond = hr - col_val;  // this stage's value half / conditioner half
+  NetView<H, NH, K> nv, nv_other;
   {
-    int o_off = my_net * Sh::SPLIT_WORDS_NET + lane * 4, b_off = Sh::SPLIT_WORDS + my_net * Sh::PLAIN_WORDS_NET + q * 4;
-    asm volatile("" : "+v"(o_off), "+v"(b_off));  // keep the operand reads inside the slot loop
+    int o_off = lane * 4, b_off = Sh::SPLIT_WORDS_NET + q * 4;
+    asm volatile("" : "+v"(o_off), "+v"(b_off));  // keep the operand reads inside the tile loop
     nv.ops = reinterpret_cast<const u32x4*>(lds + o_off);
     nv.bias = reinterpret_cast<const f32x4*>(lds + b_off);
+    nv_other.ops = reinterpret_cast<const u32x4*>(lds + (o_off + Sh::LDS_NET));
+    nv_other.bias = reinterpret_cast<const f32x4*>(lds + (b_off - Sh::SPLIT_WORDS_NET + Sh::LDS_NET + Sh::OTHER_OPS * 256));
   }
   const float wseed = split_guard_seed(wmax);
 
   const int n_rows = (int)a.rows;
-  const int n_tiles = (n_rows + 15) >> 4, stride = (int)gridDim.x * PAIRS;
-  const int first0 = (int)blockIdx.x * PAIRS, first = first0 + pair;
-  // workgroup-uniform slot count (pair 0 has the most tiles), + 2 slots to drain the pipeline
-  const int n_slots = (first0 < n_tiles ? (n_tiles - first0 + stride - 1) / stride : 0) + 2;
+  const int n_tiles = (n_rows + 15) >> 4, stride = (int)gridDim.x * WAVES;
+  int32_t* const cold_flag = a.cold + 2 + a.cold_capacity;
 
   // this lane's float4 groups that exist (the real half may be narrower than H): a dead group reads group 0, as zeros
   bool g_live[G];
@@ -524,26 +519,22 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
     g_live[g] = 16 * g + 4 * q < hr;
     g_off[g] = g_live[g] ? 16 * g + 4 * q : 0;
   }
-  // Row values a slot AHEAD, no branch around the loads (behind one hipcc's wait counts fall back to vmcnt(0)); a
-  // missing cotangent reads x, a step without a tile the nearest tile: both are not used.
-  //   X (role 0): 0 cond, 1 value of step 3's tile; 2 cond, 3 value of step 1's tile; its grad_ld
-  //   Y (role 1): 0 value, 1 g_a, 2 g_b of step 2's tile (3: the value again); its grad_ld
-  const float* const gy_or_x = a.grad_y ? a.grad_y : a.x;
+  // The NEXT tile's rows are requested at the top of a tile, no branch around the loads (behind one hipcc's wait counts
+  // fall back to vmcnt(0)); a missing cotangent reads x, a trip past the end the last tile: both are not used.
+  //   0 the conditioner half (stage 0: of y, stage 1: of x), 1 the value half of x, 2 / 3 their cotangents, grad_ld
+  const float* const g_src = ST ? a.grad_x : (a.grad_y ? a.grad_y : a.x);
+  const bool have_g = ST || a.grad_y != nullptr;
   const float* const gl_or_x = a.grad_ld ? a.grad_ld : a.x;
-  auto tile_row = [&](int t) -> uint32_t {
-    t = t < 0 ? 0 : (t < n_tiles ? t : n_tiles - 1);
-    const int row = t * 16 + j;
-    return (uint32_t)(row < n_rows ? row : n_rows - 1);
-  };
   f32x4 nx[4][G];
   float nx_gl;
-  auto request_rows = [&](int sn) {
-    const uint32_t ra = tile_row(first + (sn - (role ? 1 : 2)) * stride);  // step 3's (X) / step 2's (Y) tile
-    const uint32_t rb = role ? ra : tile_row(first + sn * stride);          // step 1's tile (X)
-    const float* p0 = a.x + ra * dim + col_b;
-    const float* p1 = (role ? gy_or_x : a.x) + ra * dim + col_a;
-    const float* p2 = (role ? gy_or_x : a.x) + rb * dim + col_b;
-    const float* p3 = a.x + rb * dim + (role ? col_b : col_a);
+  auto request_rows = [&](int t) {
+    t = t < n_tiles ? t : n_tiles - 1;
+    const int rw = t * 16 + j;
+    const uint32_t r = (uint32_t)(rw < n_rows ? rw : n_rows - 1);
+    const float* p0 = (ST ? a.x : a.y) + r * dim + col_cond;
+    const float* p1 = a.x + r * dim + col_val;
+    const float* p2 = g_src + r * dim + col_cond;
+    const float* p3 = g_src + r * dim + col_val;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       nx[0][g] = *reinterpret_cast<const f32x4*>(p0 + g_off[g]);
@@ -551,136 +542,106 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
       nx[2][g] = *reinterpret_cast<const f32x4*>(p2 + g_off[g]);
       nx[3][g] = *reinterpret_cast<const f32x4*>(p3 + g_off[g]);
     }
-    nx_gl = gl_or_x[ra];
-  };
-  auto mail_at = [&](int parity, int what, int g) -> f32x4* {
-    return mail + (((parity * PAIRS + pair) * 3 + what) * G + g) * 64 + lane;
+    nx_gl = gl_or_x[r];
   };
   float mx_grad = 0.f;
-  request_rows(0);
-  for (int s = 0; s < n_slots; ++s) {
+  const int tile0 = (int)blockIdx.x * WAVES + wave;
+  // the second wave of a SIMD starts half a slot late: both run the same code, and from the same start they would sit in
+  // their MFMA bursts together and in the spline together
+  if (Sh::WAVES_PER_SIMD == 2 && wave >= 4) __builtin_amdgcn_s_sleep(31);
+  if (tile0 < n_tiles) request_rows(tile0);
+  for (int tile = tile0; tile < n_tiles; tile += stride) {
     f32x4 cur[4][G];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int g = 0; g < G; ++g) cur[i][g] = g_live[g] ? nx[i][g] : f32x4{0.f, 0.f, 0.f, 0.f};
     const float cur_gl = nx_gl;
-    request_rows(s + 1);
-    if (role == 0) {
-      const int t3 = first + (s - 2) * stride, t1 = first + s * stride;
-      if (s >= 2 && t3 < n_tiles && mail_cold[(((s - 1) & 1) * PAIRS + pair) * 2 + 1] == 0) {  // step 3
-        const int row = t3 * 16 + j;
-        const bool live = row < n_rows;
-        const float gl = (a.grad_ld && live) ? cur_gl * g_scale : 0.f;
-        f32x4 g_a[G], g_b[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          g_a[g] = *mail_at((s - 1) & 1, 1, g);
-          g_b[g] = *mail_at((s - 1) & 1, 2, g);
-        }
-        half_backward<H, NH, K, INV>(nv, lane, cur[0], cur[1], gl, g_a, g_b, a.T, wseed, mx_grad);
-        if (live) {
-          float* gr = a.grad_x + (uint32_t)row * dim;
-#pragma unroll
-          for (int g = 0; g < G; ++g)
-            if (g_live[g]) {
-              *reinterpret_cast<f32x4*>(gr + col_a + g_off[g]) = g_a[g] * g_unscale;
-              *reinterpret_cast<f32x4*>(gr + col_b + g_off[g]) = g_b[g] * g_unscale;
-            }
-        }
-      }
-      if (t1 < n_tiles) {  // step 1: the first net forward, the half it produces
-        f32x4 mid[G];
-        const float mx = step_value<H, NH, K, INV>(nv, cur[2], cur[3], a.T, wseed, mid);
-        const bool cold1 = wave_any(!(mx <= kSplitLimit));
-#pragma unroll
-        for (int g = 0; g < G; ++g) *mail_at(s & 1, 0, g) = mid[g];
-        if (lane == 0) {
-          mail_cold[((s & 1) * PAIRS + pair) * 2] = cold1;
-          if (cold1) {
-            const int slot = atomicAdd(a.cold, 1);
-            if (slot < a.cold_capacity) a.cold[2 + slot] = t1;
-          }
-        }
-      }
+    request_rows(tile + stride);
+    const int row = tile * 16 + j;
+    const bool live = row < n_rows;
+    const float gl = (a.grad_ld && live) ? cur_gl * g_scale : 0.f;
+    const float g_on = (have_g && live) ? g_scale : 0.f;
+    bool cold;
+    if (ST == 0) {
+      // the range verdict of the WHOLE tile first: the other net will run its hidden layers on this stage's value half
+      // (stage 1 could only find out after this stage's sums have taken the tile in)
+      u32x2 xh[G], xl[G], hh[3], hl[3];
+      float mx = wseed;
+      hidden_forward<H, NH, K>(nv_other, cur[1], xh, xl, hh, hl, mx);
+      cold = wave_any(!(mx <= kSplitLimit));
     } else {
-      const int t2 = first + (s - 1) * stride;
-      if (s >= 1 && t2 < n_tiles) {  // step 2: the second half-step backwards, conditioned on X's output
-        const int row = t2 * 16 + j;
-        const bool live = row < n_rows;
-        const float gy_on = (a.grad_y && live) ? g_scale : 0.f;
-        const float gl = (a.grad_ld && live) ? cur_gl * g_scale : 0.f;
-        bool cold2 = mail_cold[(((s - 1) & 1) * PAIRS + pair) * 2] != 0;
-        if (!cold2) {
-          f32x4 mid[G], g_a[G], g_b[G];
+      cold = cold_flag[tile] != 0;
+    }
+    if (!cold) {
+      f32x4 g_cond[G], g_val[G];
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            mid[g] = *mail_at((s - 1) & 1, 0, g);
-            g_a[g] = cur[1][g] * gy_on;
-            g_b[g] = cur[2][g] * gy_on;
-          }
-          const bool ok = half_backward<H, NH, K, INV>(nv, lane, mid, cur[0], gl, g_b, g_a, a.T, wseed, mx_grad);
+      for (int g = 0; g < G; ++g) {
+        g_cond[g] = cur[2][g] * g_on;
+        g_val[g] = cur[3][g] * g_on;
+      }
+      cold = !half_backward<H, NH, K, INV>(nv, lane, cur[0], cur[1], gl, g_val, g_cond, a.T, wseed, mx_grad);
+      if (!cold && live) {
+        float* gr = a.grad_x + (uint32_t)row * dim;
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            *mail_at(s & 1, 1, g) = g_a[g];
-            *mail_at(s & 1, 2, g) = g_b[g];
+        for (int g = 0; g < G; ++g)
+          if (g_live[g]) {
+            *reinterpret_cast<f32x4*>(gr + col_cond + g_off[g]) = g_cond[g] * g_unscale;
+            *reinterpret_cast<f32x4*>(gr + col_val + g_off[g]) = g_val[g] * g_unscale;
           }
-          if (!ok) {
-            cold2 = true;
-            if (lane == 0) {
-              const int slot = atomicAdd(a.cold, 1);
-              if (slot < a.cold_capacity) a.cold[2 + slot] = t2;
-            }
-          }
-        }
-        if (lane == 0) mail_cold[((s & 1) * PAIRS + pair) * 2 + 1] = cold2;
       }
     }
-    __syncthreads();
+    if (ST == 0 && cold && lane == 0) {
+      cold_flag[tile] = 1;
+      const int slot = atomicAdd(a.cold, 1);
+      if (slot < a.cold_capacity) a.cold[2 + slot] = tile;
+    }
   }
   if (wave_any(!(mx_grad <= 32768.f)) && lane == 0) a.cold[1] = 1;  // a gradient operand beyond f16: see the header
 
-  // ------------------------------------------------------------------ flush: X waves hold the first net's sums, Y waves the second's
-  float* red = reinterpret_cast<float*>(lds);  // the images are no longer needed
+  // ------------------------------------------------------------------ flush: the waves' sums added up in LDS, then one block per workgroup
+  __syncthreads();  // (every wave is done with the image)
+  float* red = reinterpret_cast<float*>(lds);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the last MFMAs' results, before the accumulators are read)
-  for (int w = 0; w < PAIRS; ++w) {
-    if (pair == w) {
-      float* area = red + my_net * Sh::TILES * 256;
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) {
       nt_static_for<0, Sh::TILES>([&](auto t) {
         constexpr int TT = decltype(t)::value;
-        f32x4* p = reinterpret_cast<f32x4*>(area + TT * 256 + lane * 4);
+        f32x4* p = reinterpret_cast<f32x4*>(red + TT * 256 + lane * 4);
         const f32x4 v = AccT<Sh, TT>::read();
         *p = w == 0 ? v : *p + v;
       });
     }
     __syncthreads();
   }
-  float* dst = a.partials + (int64_t)blockIdx.x * a.n_params;
-  for (int i = threadIdx.x; i < a.n_params; i += blockDim.x) dst[i] = red[a.flush[i]];
+  const int per_net = a.n_params / 2, base = my_net * per_net;
+  float* dst = a.partials + (int64_t)blockIdx.x * a.n_params + base;
+  for (int i = threadIdx.x; i < per_net; i += blockDim.x) dst[i] = red[a.flush[base + i]];
 }
 
-// The kernels proper.  amdgpu_num_vgpr wants a literal: one pair (inverse, forward) per shape, the compiler's share of a
-// two-waves-per-SIMD shape's register file (NtShape::ACC_BASE) spelled out; 0 = one wave per SIMD, no limit.
+// The kernels proper.  amdgpu_num_vgpr wants a literal: one kernel per (shape, direction, stage), the compiler's share of
+// a two-waves-per-SIMD shape's register file (NtShape::ACC_BASE) spelled out; the one-wave-per-SIMD shapes keep their sums
+// in accumulator registers (BASE = 0) and carry no limit.
 typedef void (*NtKernel)(NtArgs);
-template <int H, int NH, int K, bool INV>
+template <int H, int NH, int K, bool INV, int ST>
 struct NtKernelOf;
-#define MNF_NT_KERNEL_DECL(HH, NHH, KK, INVV, NAME, ATTR, BASE)                                        \
-  __global__ void __launch_bounds__((2 * NtShape<HH, NHH, KK>::PAIRS * 64), 1) ATTR NAME(NtArgs a) {     \
+#define MNF_NT_KERNEL_DECL(HH, NHH, KK, INVV, STV, NAME, ATTR, BASE)                                   \
+  __global__ void __launch_bounds__((NtShape<HH, NHH, KK>::WAVES * 64), 1) ATTR NAME(NtArgs a) {        \
     static_assert(BASE == NtShape<HH, NHH, KK>::ACC_BASE, "the compiler's registers end where the accumulators begin"); \
-    nsf_bwd_tile_body<HH, NHH, KK, INVV>(a);                                                           \
+    nsf_bwd_tile_body<HH, NHH, KK, INVV, STV>(a);                                                      \
   }                                                                                                    \
   template <>                                                                                          \
-  struct NtKernelOf<HH, NHH, KK, INVV> {                                                               \
+  struct NtKernelOf<HH, NHH, KK, INVV, STV> {                                                          \
     static NtKernel get() { return NAME; }                                                             \
   };
-#define MNF_NT_KERNEL2(HH, NHH, KK, BASE)                                                                              \
-  MNF_NT_KERNEL_DECL(HH, NHH, KK, true, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_inv, __attribute__((amdgpu_num_vgpr(BASE / 2))), BASE) \
-  MNF_NT_KERNEL_DECL(HH, NHH, KK, false, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_fwd, __attribute__((amdgpu_num_vgpr(BASE / 2))), BASE)
-#define MNF_NT_KERNEL1(HH, NHH, KK)                                                           \
-  MNF_NT_KERNEL_DECL(HH, NHH, KK, true, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_inv, , 0)    \
-  MNF_NT_KERNEL_DECL(HH, NHH, KK, false, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_fwd, , 0)
-MNF_NT_KERNEL2(16, 8, 8, 144)
-MNF_NT_KERNEL2(16, 8, 5, 176)
+#define MNF_NT_KERNEL4(HH, NHH, KK, ATTR, BASE)                                                          \
+  MNF_NT_KERNEL_DECL(HH, NHH, KK, true, 0, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_inv_s0, ATTR, BASE)  \
+  MNF_NT_KERNEL_DECL(HH, NHH, KK, true, 1, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_inv_s1, ATTR, BASE)  \
+  MNF_NT_KERNEL_DECL(HH, NHH, KK, false, 0, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_fwd_s0, ATTR, BASE) \
+  MNF_NT_KERNEL_DECL(HH, NHH, KK, false, 1, nsf_bwd_tile_kernel_##HH##_##NHH##_##KK##_fwd_s1, ATTR, BASE)
+#define MNF_NT_TOP(BASE) __attribute__((amdgpu_num_vgpr(BASE / 2)))
+MNF_NT_KERNEL4(16, 8, 8, MNF_NT_TOP(144), 144)
+MNF_NT_KERNEL4(16, 8, 5, MNF_NT_TOP(176), 176)
 
 // grad_flat[p] += (sum over the workgroups' blocks, in a fixed order) / scale; nothing when the launch went cold
 __global__ void __launch_bounds__(256) nsf_tile_reduce_kernel(const float* __restrict__ partials, int n_blocks, int n_params,
@@ -784,7 +745,7 @@ static void build_tables(int hr, const int* w, int32_t* idx, int32_t* flush) {
       }
     if (!flush) continue;
     // accumulator element (tile t, lane (n, q), reg r) = D[m = 4 q + r][n]
-    auto at = [&](int t, int m, int n) { return nn * Sh::TILES * 256 + t * 256 + (16 * (m >> 2) + n) * 4 + (m & 3); };
+    auto at = [&](int t, int m, int n) { return t * 256 + (16 * (m >> 2) + n) * 4 + (m & 3); };
     for (int s = 0; s < S; ++s)
       for (int kb = 0; kb < NB; ++kb)
         for (int m = 0; m < 16; ++m) {
@@ -809,22 +770,22 @@ template <int H, int NH, int K>
 static int launch_tile(const NtArgs& a, int inverse, hipStream_t stream) {
   using Sh = NtShape<H, NH, K>;
   const int64_t n_tiles = (a.rows + 15) / 16;
-  int64_t blocks = (n_tiles + Sh::PAIRS - 1) / Sh::PAIRS;
+  int64_t blocks = (n_tiles + Sh::WAVES - 1) / Sh::WAVES;
   const int cus = device_cus(current_device());
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU: the sums take the register file
   const size_t lds_bytes = (size_t)Sh::LDS_WORDS * 4;
-  static DeviceMemo attr_f, attr_i;
-  auto set_attr = [&](auto kernel, DeviceMemo& memo) {
-    return memo.get([&](int) {
+  static DeviceMemo attr[4];
+  for (int st = 0; st < 2; ++st) {
+    const NtKernel kernel = inverse ? (st ? NtKernelOf<H, NH, K, true, 1>::get() : NtKernelOf<H, NH, K, true, 0>::get())
+                                    : (st ? NtKernelOf<H, NH, K, false, 1>::get() : NtKernelOf<H, NH, K, false, 0>::get());
+    const int ok = attr[2 * (inverse ? 1 : 0) + st].get([&](int) {
       return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds_bytes) == hipSuccess ? 1 : -1;
     });
-  };
-  NtArgs b = a;
-  const NtKernel kernel = inverse ? NtKernelOf<H, NH, K, true>::get() : NtKernelOf<H, NH, K, false>::get();
-  if (set_attr(kernel, inverse ? attr_i : attr_f) < 0) return MNF_ERR_LAUNCH;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(2 * Sh::PAIRS * 64), lds_bytes, stream, b);
-  if (int rc = check_launch()) return rc;
+    if (ok < 0) return MNF_ERR_LAUNCH;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Sh::WAVES * 64), lds_bytes, stream, a);
+    if (int rc = check_launch()) return rc;
+  }
   hipLaunchKernelGGL(nsf_tile_reduce_kernel, dim3((unsigned)((a.n_params + 31) / 32)), dim3(256), 0, stream, a.partials,
                      (int)blocks, a.n_params, a.grad_flat, a.scale_dev, a.cold);
   return check_launch();
@@ -905,25 +866,25 @@ int64_t mnf_nsf_cl_bwd_tile_workspace(int64_t rows, int dim, int K, int n_hidden
   return (int64_t)mnf::device_cus(mnf::current_device()) * np;
 }
 
-int mnf_nsf_cl_bwd_tile(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
+int mnf_nsf_cl_bwd_tile(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                         const void* image, const int32_t* flush, int64_t rows, int dim, int K, float tail_bound,
                         int inverse, int n_hidden, const int* hidden, const float* scale_dev, int32_t* cold,
                         int cold_capacity, float* workspace, int64_t workspace_floats, void* stream) {
-  if (!x || !grad_x || !grad_flat || !image || !flush || !scale_dev || !cold || !workspace || rows < 0 || dim < 2 ||
+  if (!x || !y || !grad_x || !grad_flat || !image || !flush || !scale_dev || !cold || !workspace || rows < 0 || dim < 2 ||
       (dim & 1) || K < 2 || !(tail_bound > 0.f) || !mnf::hidden_ok(n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   mnf::TileShape ts;
   if (!mnf::tile_shape(dim, K, n_hidden, hidden, ts)) return MNF_ERR_UNSUPPORTED;
   if (rows * dim >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;  // (32-bit element offsets: the caller's generic kernel)
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x) |
-       reinterpret_cast<uintptr_t>(image)) & 15)
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(grad_y) |
+       reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(image)) & 15)
     return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
   if (cold_capacity < (rows + 15) / 16 || workspace_floats < mnf_nsf_cl_bwd_tile_workspace(rows, dim, K, n_hidden, hidden))
     return MNF_ERR_INVALID_ARG;
   mnf::NtArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat;
+  a.x = x; a.y = y; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat;
   a.image = static_cast<const uint32_t*>(image); a.flush = flush; a.partials = workspace; a.scale_dev = scale_dev;
   a.cold = cold; a.cold_capacity = cold_capacity; a.rows = rows; a.T = tail_bound; a.hr = ts.hr;
   int sizes[5] = {ts.hr, ts.w[0], ts.w[1], ts.w[2], (3 * K - 1) * ts.hr};

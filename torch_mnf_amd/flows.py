@@ -405,12 +405,14 @@ class _NsfFn(torch.autograd.Function):
             module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
             int(module.force_generic), _stream()))
         ctx.module, ctx.inverse = module, inverse
-        ctx.save_for_backward(x, flat)
+        # (y too: the tile gradient kernel reads the second net's conditioner input out of it instead of recomputing the
+        #  first half-step; the next layer keeps its input alive anyway)
+        ctx.save_for_backward(x, flat, y)
         return y, ld
 
     @staticmethod
     def backward(ctx, grad_y, grad_ld):
-        x, flat = ctx.saved_tensors
+        x, flat, y_out = ctx.saved_tensors
         m = ctx.module
         gy = None if grad_y is None else grad_y.contiguous()
         gl = None if grad_ld is None else grad_ld.contiguous()
@@ -436,14 +438,14 @@ class _NsfFn(torch.autograd.Function):
                 flat.data_ptr(), idx.data_ptr(), image.data_ptr(), n_split, n_plain, _stream()))
             scale = _grad_scale(gy, gl, rows, m.dim, x.device)
             cap = (rows + 15) // 16
-            cold = torch.zeros(cap + 2, dtype=torch.int32, device=x.device)
+            cold = torch.zeros(2 * cap + 2, dtype=torch.int32, device=x.device)
             n_work = lib.mnf_nsf_cl_bwd_tile_workspace(rows, m.dim, m.K, len(m.h_sizes), m._hid)
             work = torch.empty(n_work, dtype=torch.float32, device=x.device)
             if marks is not None:
                 marks[0].record()
             _lib.check("mnf_nsf_cl_bwd_tile", lib.mnf_nsf_cl_bwd_tile(
-                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), image.data_ptr(),
-                flush.data_ptr(), *args, scale.data_ptr(), cold.data_ptr(), cap, work.data_ptr(), n_work, _stream()))
+                x.data_ptr(), y_out.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(),
+                image.data_ptr(), flush.data_ptr(), *args, scale.data_ptr(), cold.data_ptr(), cap, work.data_ptr(), n_work, _stream()))
             if marks is not None:
                 marks[1].record()
                 bwd_kernel_events.append(marks)
