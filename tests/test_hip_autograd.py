@@ -456,11 +456,14 @@ def nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
     return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
 
 
-@pytest.mark.parametrize("dim,K,n_h", [(16, 8, 8), (24, 5, 4), (8, 8, 8), (32, 8, 7)])
+@pytest.mark.parametrize("dim,K,n_h", [(16, 8, 8), (24, 5, 4), (8, 8, 8), (32, 8, 7), (64, 8, 8), (64, 5, 16), (48, 8, 8),
+                                       (32, 8, 16), (32, 5, 12), (16, 8, 16), (64, 8, 16)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
-    """The tile gradient kernel away from d = 32: halves narrower than its 16-element tile (whole float4 groups of a
-    lane are dead), against autograd through the oracle and against the generic kernel."""
+    """The tile gradient kernel away from d = 32, n_h = 8: halves narrower than its 16- or 32-element tile (whole float4
+    groups of a lane are dead), d = 64 (two float4 groups per lane, eight slots, one wave per SIMD with the sums in
+    accumulator registers), hidden widths up to 16 (no spare column for the bias sums: one-hot bias tiles) -- against
+    autograd through the oracle and against the generic kernel."""
     lib = amd._lib.load()
     assert lib.mnf_nsf_cl_bwd_tile_supported(dim, K, 3, amd._lib.int_array((n_h,) * 3)) == 1
     rows = 777

@@ -92,10 +92,9 @@ def main(dim=32, K=8, hidden=(8, 8, 8)):
     OP_T2, OP_T1 = OP_T3 + 1, OP_T3 + 2
     T_W3 = S * NB
     T_W2, T_W1 = T_W3 + 1, T_W3 + 2
-    T_BH = T_W1 + G
-    T_B4 = T_BH + 1
+    T_B = T_W1 + G
     biascol = NH <= 8
-    tiles = T_B4 + (0 if biascol else (S * NB + 15) // 16)
+    tiles = T_B + (3 + (0 if biascol else S * NB) + 15) // 16
 
     def c_layout(M):  # M [16 features][16 rows] -> [64][4]
         out = np.zeros((64, 4))
@@ -183,7 +182,7 @@ def main(dim=32, K=8, hidden=(8, 8, 8)):
                 t = s * NB + kb
                 red[t] += mfma32(d, h3ops)
                 if not biascol:
-                    red[T_B4 + t // 16] += mfma32(d, onehot(t & 15))
+                    red[T_B + (3 + t) // 16] += mfma32(d, onehot((3 + t) & 15))
         ref_y = gp.reshape(16, hr * P) @ Ws[3]  # [row][u]
         assert np.allclose(from_c(y)[:hidden[2]].T, ref_y), "W4^T g"
         assert np.allclose(from_c(y)[hidden[2]:], 0)
@@ -199,17 +198,17 @@ def main(dim=32, K=8, hidden=(8, 8, 8)):
         d3 = masked(y, 2)
         red[T_W3] += mfma32(delta_op(d3), act_ops(h[1], biascol))
         if not biascol:
-            red[T_BH] += mfma32(delta_op(d3), onehot(2))
+            red[T_B] += mfma32(delta_op(d3), onehot(2))
         d2 = masked(mfma16(ops[nn, OP_T3], d3), 1)
         ref_d[1] = (ref_d[2] @ Ws[2]) * masks[1]
         assert np.allclose(from_c(d2)[:hidden[1]].T, ref_d[1]), "delta 2"
         red[T_W2] += mfma32(delta_op(d2), act_ops(h[0], biascol))
         if not biascol:
-            red[T_BH] += mfma32(delta_op(d2), onehot(1))
+            red[T_B] += mfma32(delta_op(d2), onehot(1))
         d1 = masked(mfma16(ops[nn, OP_T2], d2), 0)
         ref_d[0] = (ref_d[1] @ Ws[1]) * masks[0]
         assert np.allclose(from_c(d1)[:hidden[0]].T, ref_d[0]), "delta 1"
-        red[T_BH] += mfma32(delta_op(d1), onehot(0))
+        red[T_B] += mfma32(delta_op(d1), onehot(0))
         for g in range(G):
             red[T_W1 + g] += mfma32(delta_op(d1), act_ops(cond[g], False))
             gc = from_c(mfma16(ops[nn, OP_T1 + g], d1))
@@ -246,3 +245,8 @@ if __name__ == "__main__":
         main(32, 8, (3, 5, 8))
         main(16, 8, (8, 8, 8))
         main(24, 5, (4, 4, 4))
+        main(32, 8, (16, 16, 16))
+        main(32, 5, (12, 16, 9))
+        main(64, 8, (8, 8, 8))
+        main(64, 5, (16, 16, 16))
+        main(48, 8, (8, 8, 8))

@@ -92,16 +92,18 @@ struct NtShape {
   static constexpr int T_W4 = 0;                   // S * NB: [entry (q, r) of tile (s, kb)][unit | ones]
   static constexpr int T_W3 = S * NB, T_W2 = T_W3 + 1;
   static constexpr int T_W1 = T_W2 + 1;            // G: [unit][cond feature of group g]
-  static constexpr int T_BH = T_W1 + G;            // [unit][one-hot column: 0 = b1, 1 = b2, 2 = b3]
-  static constexpr int T_B4 = T_BH + 1;            // !BIASCOL: [entry][one-hot column = tile number & 15]
-  static constexpr int N_B4 = BIASCOL ? 0 : (S * NB + 15) / 16;
-  static constexpr int TILES = T_B4 + N_B4;
+  // bias tiles: [A operand's feature][one-hot column]: columns 0, 1, 2 = b1, b2, b3 (rows = units), and without the
+  // ones column, column 3 + t = b4 of output tile t (rows = its 16 entries)
+  static constexpr int T_B = T_W1 + G;
+  static constexpr int N_BCOLS = 3 + (BIASCOL ? 0 : S * NB);
+  static constexpr int N_BT = (N_BCOLS + 15) / 16;
+  static constexpr int TILES = T_B + N_BT;
   static constexpr int RED_FLOATS = TILES * 256;
   // one wave per SIMD when the sums take more than half of the wave's registers at two
-  static constexpr int WAVES_PER_SIMD = (4 * TILES <= 112) ? 2 : 1;
+  static constexpr int WAVES_PER_SIMD = (4 * TILES <= 116) ? 2 : 1;
   static constexpr int WAVES = 4 * WAVES_PER_SIMD;               // per workgroup (one workgroup per CU)
   static constexpr bool ACC_AG = WAVES_PER_SIMD == 1;            // the sums in accumulator registers / at the top of the vector file
-  static constexpr int ACC_BASE = ACC_AG ? 0 : 256 - 4 * TILES;
+  static constexpr int ACC_BASE = 256 - 4 * TILES;  // (of the accumulator file / of the vector file)
   // LDS: [the stage's net: operands | biases][stage 0: the other net's hidden layers: G + 2 operands | 3 bias tiles]
   static constexpr int OTHER_OPS = G + 2;
   static constexpr int LDS_NET = SPLIT_WORDS_NET + PLAIN_WORDS_NET;
@@ -133,7 +135,9 @@ __device__ __forceinline__ void nt_static_for(F&& f) {
 //     below BASE, and the clobber of v255 makes the register count 256 (the scheme of round 4's one-net-per-wave
 //     AffineHalfFlow kernel: as soon as an asm statement names an ACCUMULATOR register hipcc splits the wave's budget
 //     128 + 128 -- too few vector registers for the spline's derivative); check_vgpr_top.py guards the build;
-//   one wave per SIMD (512): the accumulator half a[4 t ..], BASE = 0 (mnf_agpr.h's rules, check_agpr.py).
+//   one wave per SIMD (512): the TOP of the accumulator half, a[BASE + 4 t ..], BASE = 256 - 4 TILES (mnf_agpr.h's
+//     rules; the compiler parks values of its own that overflow the vector registers in accumulator registers from a0
+//     upwards -- a clobber list does not keep it from doing so -- and check_agpr.py is told how far up it may go).
 #define MNF_NT_ACC(AGV, RF, ZERO, READ)                                                                                 \
   template <int R>                                                                                                      \
   struct AccReg<AGV, R> {                                                                                               \
@@ -163,7 +167,7 @@ __device__ __forceinline__ void nt_static_for(F&& f) {
 MNF_NT_ACC(true, "a", "v_accvgpr_write_b32", "v_accvgpr_read_b32")
 MNF_NT_ACC(false, "v", "v_mov_b32", "v_mov_b32")
 #undef MNF_NT_ACC
-// a0 .. a207 are part of the kernel's register allocation (the one-wave-per-SIMD shapes)
+// a0 .. a255 are part of the kernel's register allocation (the one-wave-per-SIMD shapes)
 #define MNF_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 template <bool AG>
 __device__ __forceinline__ void reserve_acc() {
@@ -171,7 +175,8 @@ __device__ __forceinline__ void reserve_acc() {
     asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", MNF_A10(1), MNF_A10(2), MNF_A10(3),
                  MNF_A10(4), MNF_A10(5), MNF_A10(6), MNF_A10(7), MNF_A10(8), MNF_A10(9), MNF_A10(10), MNF_A10(11),
                  MNF_A10(12), MNF_A10(13), MNF_A10(14), MNF_A10(15), MNF_A10(16), MNF_A10(17), MNF_A10(18), MNF_A10(19),
-                 "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+                 MNF_A10(20), MNF_A10(21), MNF_A10(22), MNF_A10(23), MNF_A10(24), "a250", "a251", "a252", "a253", "a254",
+                 "a255");
   else
     asm volatile("" ::: "v255");
 }
@@ -385,7 +390,7 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
           constexpr int kb = decltype(kbc)::value;
           constexpr int t = sc * NB + kb;
           AccT<Sh, Sh::T_W4 + t>::outer32(d_hl[kb], h3_hh, h3_ll);
-          if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_B4 + t / 16>::one32(d_hl[kb], onehot(t & 15));
+          if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_B + (3 + t) / 16>::one32(d_hl[kb], onehot((3 + t) & 15));
         });
       };
       nt_static_for<0, G>([&](auto gc) {
@@ -416,7 +421,7 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
     f16x8 d = delta_op(dh[2], dl[2]);
     act_ops(hh[1], hl[1], Sh::BIASCOL, a_hh, a_ll);
     AccT<Sh, Sh::T_W3>::outer32(d, a_hh, a_ll);
-    if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_BH>::one32(d, onehot(2));
+    if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_B>::one32(d, onehot(2));
     // delta 2 = W3^T delta 3 .* LeakyReLU'(h2)
     u32x2 ah, al;
     f32x4 mn = zero4, cr = zero4;
@@ -427,7 +432,7 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
     d = delta_op(dh[1], dl[1]);
     act_ops(hh[0], hl[0], Sh::BIASCOL, a_hh, a_ll);
     AccT<Sh, Sh::T_W2>::outer32(d, a_hh, a_ll);
-    if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_BH>::one32(d, onehot(1));
+    if constexpr (!Sh::BIASCOL) AccT<Sh, Sh::T_B>::one32(d, onehot(1));
     // delta 1 = W2^T delta 2 .* LeakyReLU'(h1)
     mn = cr = zero4;
     nv.op(Sh::OP_T2, ah, al);
@@ -435,7 +440,7 @@ __device__ __forceinline__ bool half_backward(const NetView<H, NH, K>& nv, int l
     masked_split(mn, cr, hh[0], hl[0], dh[0], dl[0]);
     // dW1: delta 1 x cond, db1
     d = delta_op(dh[0], dl[0]);
-    AccT<Sh, Sh::T_BH>::one32(d, onehot(0));
+    AccT<Sh, Sh::T_B>::one32(d, onehot(0));
     nt_static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       act_ops(xh[g], xl[g], false, a_hh, a_ll);
@@ -621,7 +626,7 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
 
 // The kernels proper.  amdgpu_num_vgpr wants a literal: one kernel per (shape, direction, stage), the compiler's share of
 // a two-waves-per-SIMD shape's register file (NtShape::ACC_BASE) spelled out; the one-wave-per-SIMD shapes keep their sums
-// in accumulator registers (BASE = 0) and carry no limit.
+// at the top of the accumulator file and carry no limit (BASE: the first accumulator register of the sums).
 typedef void (*NtKernel)(NtArgs);
 template <int H, int NH, int K, bool INV, int ST>
 struct NtKernelOf;
@@ -642,6 +647,12 @@ struct NtKernelOf;
 #define MNF_NT_TOP(BASE) __attribute__((amdgpu_num_vgpr(BASE / 2)))
 MNF_NT_KERNEL4(16, 8, 8, MNF_NT_TOP(144), 144)
 MNF_NT_KERNEL4(16, 8, 5, MNF_NT_TOP(176), 176)
+MNF_NT_KERNEL4(16, 16, 8, MNF_NT_TOP(140), 140)
+MNF_NT_KERNEL4(16, 16, 5, MNF_NT_TOP(172), 172)
+MNF_NT_KERNEL4(32, 8, 8, , 44)
+MNF_NT_KERNEL4(32, 8, 5, , 108)
+MNF_NT_KERNEL4(32, 16, 8, , 32)
+MNF_NT_KERNEL4(32, 16, 5, , 100)
 
 // grad_flat[p] += (sum over the workgroups' blocks, in a fixed order) / scale; nothing when the launch went cold
 __global__ void __launch_bounds__(256) nsf_tile_reduce_kernel(const float* __restrict__ partials, int n_blocks, int n_params,
@@ -752,16 +763,16 @@ static void build_tables(int hr, const int* w, int32_t* idx, int32_t* flush) {
           const int o = out_of(s, kb, m), t = s * NB + kb;
           if (o < 0) continue;
           for (int u = 0; u < w[2]; ++u) flush[nd.w_off[3] + o * w[2] + u] = at(Sh::T_W4 + t, m, u);
-          flush[nd.b_off[3] + o] = Sh::BIASCOL ? at(Sh::T_W4 + t, m, 8) : at(Sh::T_B4 + t / 16, m, t & 15);
+          flush[nd.b_off[3] + o] = Sh::BIASCOL ? at(Sh::T_W4 + t, m, 8) : at(Sh::T_B + (3 + t) / 16, m, (3 + t) & 15);
         }
     for (int l = 1; l <= 2; ++l)
       for (int m = 0; m < w[l]; ++m) {
         for (int n = 0; n < w[l - 1]; ++n) flush[nd.w_off[l] + m * w[l - 1] + n] = at(l == 2 ? Sh::T_W3 : Sh::T_W2, m, n);
-        flush[nd.b_off[l]+ m] = Sh::BIASCOL ? at(l == 2 ? Sh::T_W3 : Sh::T_W2, m, 8) : at(Sh::T_BH, m, l);
+        flush[nd.b_off[l] + m] = Sh::BIASCOL ? at(l == 2 ? Sh::T_W3 : Sh::T_W2, m, 8) : at(Sh::T_B, m, l);
       }
     for (int m = 0; m < w[0]; ++m) {
       for (int f = 0; f < hr; ++f) flush[nd.w_off[0] + m * hr + f] = at(Sh::T_W1 + (f >> 4), m, f & 15);
-      flush[nd.b_off[0] + m] = at(Sh::T_BH, m, 0);
+      flush[nd.b_off[0] + m] = at(Sh::T_B, m, 0);
     }
   }
 }
@@ -792,7 +803,7 @@ static int launch_tile(const NtArgs& a, int inverse, hipStream_t stream) {
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NT_SHAPES(X) X(16, 8, 8) X(16, 8, 5)
+#define MNF_NT_SHAPES(X) X(16, 8, 8) X(16, 8, 5) X(16, 16, 8) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(32, 16, 5)
 
 struct TileShape {
   int H, NH, K, hr;
