@@ -132,6 +132,37 @@ def valu_issue(workload: str) -> dict | None:
     return None
 
 
+def apply_valu_convention(r: dict, workload: str, avg_kernel_s: float) -> None:
+    """Re-express a roofline object whose kernel is bound by vector-instruction issue (the spline kernels, SURVEY 8(d):
+    264 B per row against thousands of vector instructions per 16 rows): `bound` "valu", achieved / peak / frac in wave
+    instructions per second, the HBM figures kept under their own names, and next to them what the counters MEASURED --
+    how long the SIMDs' vector units were occupied (`simd_valu_busy_frac`) and the matrix pipe (`mfma_pipe_frac`).
+    Instruction counts come from the committed SQ-counter digest (tools/make_valu_json.py), time from THIS run's HIP
+    events.  One convention for c3 and c3t."""
+    r.update({"hbm_achieved_GBps": r["achieved"], "hbm_frac": r["frac"], "hbm_peak_GBps": r["peak"]})
+    vi = valu_issue(workload)
+    if vi is None:
+        r.update({"bound": "valu", "valu_source": None,
+                  "note": "no committed *_valu_issue.json: achieved / frac are the HBM figures"})
+        return
+    cycles_now = vi["effective_clock_GHz"] * 1e9 * avg_kernel_s
+    plain = vi["SQ_INSTS_VALU"] - vi["SQ_INSTS_MFMA"]
+    ginstr = vi["SQ_INSTS_VALU"] / avg_kernel_s / 1e9
+    peak = 1024 / 2.0 * vi["effective_clock_GHz"]
+    r.update({"bound": "valu", "achieved": ginstr, "peak": peak, "unit": "G wave-instr/s",
+              "frac": (2.0 * plain + 8.0 * vi["SQ_INSTS_MFMA"]) / (1024 * cycles_now),
+              "frac_plain_count": ginstr / peak,
+              "simd_valu_busy_frac": vi.get("simd_valu_busy_frac"), "mfma_pipe_frac": vi.get("mfma_pipe_frac"),
+              "valu_source": f"{vi['file']} (SQ_INSTS_VALU {vi['SQ_INSTS_VALU']:.4g}, SQ_INSTS_MFMA "
+                             f"{vi['SQ_INSTS_MFMA']:.4g} per launch, effective clock "
+                             f"{vi['effective_clock_GHz']:.2f} GHz from GRBM_GUI_ACTIVE; committed "
+                             "rocprofv3 --pmc profile, not measured in this run)",
+              "valu_definition": "frac = (2 cyc x plain vector instr + 8 cyc x MFMA) / (1024 SIMDs x kernel "
+                                 "cycles): share of SIMD issue cycles used; peak = one wave64 vector "
+                                 "instruction per SIMD per 2 cycles; simd_valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / "
+                                 "the same SIMD cycles (how long the vector units were occupied, profiled run)"})
+
+
 def physical(traffic, avg_kernel_s: float) -> dict:
     """The HBM fraction by bytes that actually cross the interface (PMC), next to the SURVEY 8(d) algorithmic one."""
     if not traffic:
@@ -730,9 +761,10 @@ def main_lenet(args, rank, world, device, dim, rows, desc) -> None:
 def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
     """Config 3's model on the training side of the bench contract: a step = one Adam step of 3 x [ActNorm, Glow,
     NSF_CL] on the resident batch (layer-by-layer forward keeping every intermediate, -mean log-prob, backward, Adam).
-    The dominant kernel is the NSF_CL gradient kernel (mnf_nsf_bwd_rows.hip: one lane per (row, element)); it is
-    vector-issue / latency bound, the HBM figures say how far it is from the traffic it has to move
-    ((12 d + 4) bytes per row per launch: x and grad_y in, grad_x out)."""
+    The dominant kernels are the NSF_CL gradient pass's two launches (mnf_nsf_bwd_tile.hip: the conditioner as split
+    MFMAs in both directions, 16 rows per wave, one launch per half-step; timed together, per layer).  The pass is bound
+    by vector-instruction issue (the spline's derivative): the roofline object follows c3's "valu" convention, the HBM
+    figures -- (12 d + 4) bytes per row per layer: x and grad_y in, grad_x out -- stay under their own names."""
     if world != 1:
         raise SystemExit("--workload c3t measures one GPU (data-parallel training would add a gradient all-reduce)")
     from torch_mnf_amd import flows as amd_flows
@@ -787,14 +819,12 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
         "loss_first_step": first_loss, "loss_last_step": float(loss_box[0]),
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, **physical(traffic, avg_s),
-                     "kernel": "nsf_bwd_pairs_kernel<8,inverse> (one NSF_CL layer's gradients per launch; 3 launches per step)",
+                     "kernel": "nsf_bwd_tile_kernel_16_8_8_inv_s0 + _s1 (+ the fixed-order reduction): one NSF_CL layer's "
+                               "gradients = two launches, one per half-step; timed together; 3 layers per step",
                      "avg_kernel_us": avg_s * 1e6, "algorithmic_bytes_per_launch": algo_bytes,
-                     "launches_timed": len(kern_ms), "launches_per_step": 3,
-                     "note": "vector-unit bound by construction (8.9e8 vector instructions per launch at 4.2 cycles "
-                             "each: the SIMDs' vector units are occupied 0.91 of the launch, "
-                             "profiles/r4/c3t_valu_issue.json simd_valu_busy_frac): the HBM fraction is low because "
-                             "the kernel's floor is arithmetic, not traffic (DESIGN.md 3.5)"},
+                     "launches_timed": len(kern_ms), "launches_per_step": 3},
     }
+    apply_valu_convention(out["roofline"], "c3t", avg_s)
     if not args.no_cpu_baseline:
         from oracle import flow_oracle as O
 
@@ -1194,28 +1224,7 @@ def main() -> None:
             # the spline kernel is VALU / transcendental bound by construction (264 B per row against
             # ~2,300 vector instructions per 16 rows per layer): the roofline it is priced against is the vector
             # ISSUE rate; the HBM figures stay in the object under their own names.
-            r = out["roofline"]
-            r.update({"hbm_achieved_GBps": r["achieved"], "hbm_frac": r["frac"], "hbm_peak_GBps": r["peak"]})
-            vi = valu_issue("c3")
-            if vi is not None:
-                # instructions per launch from the committed counters, time from THIS run's HIP events
-                cycles_now = vi["effective_clock_GHz"] * 1e9 * avg_kernel_s
-                plain = vi["SQ_INSTS_VALU"] - vi["SQ_INSTS_MFMA"]
-                ginstr = vi["SQ_INSTS_VALU"] / avg_kernel_s / 1e9
-                peak = 1024 / 2.0 * vi["effective_clock_GHz"]
-                r.update({"bound": "valu", "achieved": ginstr, "peak": peak, "unit": "G wave-instr/s",
-                          "frac": (2.0 * plain + 8.0 * vi["SQ_INSTS_MFMA"]) / (1024 * cycles_now),
-                          "frac_plain_count": ginstr / peak,
-                          "valu_source": f"{vi['file']} (SQ_INSTS_VALU {vi['SQ_INSTS_VALU']:.4g}, SQ_INSTS_MFMA "
-                                         f"{vi['SQ_INSTS_MFMA']:.4g} per launch, effective clock "
-                                         f"{vi['effective_clock_GHz']:.2f} GHz from GRBM_GUI_ACTIVE; committed "
-                                         "rocprofv3 --pmc profile, not measured in this run)",
-                          "valu_definition": "frac = (2 cyc x plain vector instr + 8 cyc x MFMA) / (1024 SIMDs x kernel "
-                                             "cycles): share of SIMD issue cycles used; peak = one wave64 vector "
-                                             "instruction per SIMD per 2 cycles"})
-            else:
-                r.update({"bound": "valu", "valu_source": None,
-                          "note": "no committed *_valu_issue.json: achieved / frac are the HBM figures"})
+            apply_valu_convention(out["roofline"], "c3", avg_kernel_s)
         if world == 1 and not args.no_cpu_baseline:
             info, cpu_mean, n = cpu_baseline(layers, dim, x)
             with torch.no_grad():

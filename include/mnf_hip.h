@@ -545,14 +545,6 @@ int mnf_affine_half_bwd_split_lp(const float* x, const float* lp_grad, float* gy
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);
-/* The same gradients from the row-per-lane kernel (mnf_nsf_bwd_rows.hip): dim = 32, three hidden layers of one
- * width <= 8, K = 5 or 8 -- the shapes mnf_nsf_cl_bwd_rows_supported() answers 1 for; MNF_ERR_UNSUPPORTED otherwise
- * (callers then use mnf_nsf_cl_bwd).  Weight gradients are summed on the matrix cores over the rows of a wave and
- * leave each workgroup as one atomic add per parameter. */
-int mnf_nsf_cl_bwd_rows_supported(int dim, int K, int n_hidden, const int* hidden_host);
-int mnf_nsf_cl_bwd_rows(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
-                        float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
-                        int inverse, int n_hidden, const int* hidden_host, void* stream);
 /* The same gradients with the whole conditioner on the f16 matrix pipe in split arithmetic, a wave per 16-row tile
  * (mnf_nsf_bwd_tile.hip; NSF_CL under loss.backward(): torch_mnf/flows/spline_flow.py:249-285, tests/test_flows.py:89-99):
  * dim a multiple of 8 up to 64, three hidden layers of at most 16 units, K = 5 or 8 -- the shapes

@@ -366,28 +366,27 @@ def nsf_grads(amd, sd, K, n_h, inverse, x_cpu, w_y, w_l, generic):
     f.to(DEV)
     f.force_generic = generic
     lib = amd._lib.load()
-    assert lib.mnf_nsf_cl_bwd_rows_supported(32, K, 3, f._hid) == 1
+    assert lib.mnf_nsf_cl_bwd_tile_supported(32, K, 3, f._hid) == 1
     x = x_cpu.detach().to(DEV).requires_grad_(True)
     yg, ldg = (f.inverse if inverse else f.forward)(x)
     ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
     return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
 
 
-@pytest.fixture(params=["tile", "pairs", "single"])
-def nsf_rows_kernel(request, monkeypatch, amd):
-    """The NSF_CL gradient kernels with matrix-core sums: the tile kernel (default: the conditioner as split MFMAs, 16
-    rows per wave) and round 4's two lane-per-element kernels (the wave-pair one and the one-wave-per-tile one)."""
-    monkeypatch.setattr(amd.flows, "_NSF_BWD_KERNEL", "tile" if request.param == "tile" else "rows")
-    monkeypatch.setenv("MNF_NSF_BWD_PAIRS", "0" if request.param == "single" else "1")
+@pytest.fixture(params=["tile"])
+def nsf_rows_kernel(request):
+    """The NSF_CL gradient kernel with matrix-core sums: the tile kernel (the conditioner as split MFMAs in both
+    directions, 16 rows per wave).  (Rounds 3 and 4 had two lane-per-element kernels here; their measurements are in
+    profiles/r4 and profiles/r5/README.md.)"""
     return request.param
 
 
 @pytest.mark.parametrize("K,n_h", [(8, 8), (5, 8), (8, 6), (5, 3)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_row_gradient_kernel(amd, O, K, n_h, inverse, nsf_rows_kernel):
-    """The row-per-lane NSF_CL gradient kernels (d = 32; DPP-rotation hidden layers, weight gradients summed over
-    rows by MFMAs) against autograd through the oracle and against the generic gradient kernel: ragged row count,
-    rows in the identity tails, elements exactly on the tail bound, hidden widths below the kernel's 8 units."""
+    """The tile NSF_CL gradient kernel at d = 32 against autograd through the oracle and against the generic gradient
+    kernel: ragged row count, rows in the identity tails, elements exactly on the tail bound, hidden widths below the
+    kernel's 8 units."""
     rows = 1003
     sd = recipes.nsf_cl_params(371 + K + n_h, 32, K, n_h)
     x_cpu = recipes.gaussian(372 + K, rows, 32, scale=1.3)

@@ -494,8 +494,8 @@ def test_g3_c2_stack(amd, golden, dim):
 
 
 def test_c2_full_size_properties(amd, O):
-    """BASELINE configs[1] at full size (2^20 x 64): properties that need no CPU reference, plus
-    a 4096-row slice against the oracle."""
+    """BASELINE configs[1] at full size (2^20 x 64): properties that need no CPU reference, and a 4,096-row slice of the
+    full-size launches' every intermediate, log_det and log-prob against the oracle."""
     dim, rows = 64, 1 << 20
     model = build_ahf_stack(amd, c2_layers(dim), dim)
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -514,15 +514,26 @@ def test_c2_full_size_properties(amd, O):
     f.force_generic = False
     assert_close(y_fast, y_gen, RTOL, "mfma vs generic y")
     assert_close(ld_fast, ld_gen, RTOL, "mfma vs generic ld")
-    # mean log-prob: fused epilogue (fp64 sum) vs the oracle on a slice, rows chosen across the batch
+    # the FULL-SIZE launches against the oracle: every intermediate, log_det and log-prob of the 2^20-row passes,
+    # sliced at 4,096 rows spread over the batch (every workgroup position is sampled) -- as C3, C4 and C5 do
     sel = torch.arange(0, rows, rows // 4096, device=DEV)[:4096]
     xo = x[sel].cpu()
-    ref_mean, ref_lp = O.mean_log_prob(xo, c2_layers(dim))
+    layers = c2_layers(dim)
+    ref_zs, ref_ld = O.flow_stack(xo, layers, inverse=True)
+    assert len(zs) == len(ref_zs)
+    for k in range(len(zs)):
+        assert_close(zs[k][sel], ref_zs[k], RTOL, f"c2 full-size inverse zs[{k}] slice")
+    assert_close(ld[sel], ref_ld, RTOL, "c2 full-size inverse log_det slice")
+    ref_xs, ref_ldf = O.flow_stack(ref_zs[-1], layers, inverse=False)
+    xs_o, ld_o = model.forward(zs[-1][sel].contiguous())  # (the forward pass above started from the GPU's own z)
+    assert_close(xs_o[-1], ref_xs[-1], 2 * RTOL, "c2 forward of the oracle's z")
+    ref_mean, ref_lp = O.mean_log_prob(xo, layers)
+    lp_all, total_all = model.log_prob(x, return_sum=True)
+    assert_close(lp_all[sel], ref_lp, RTOL, "c2 full-size log_prob slice")
     lp, total = model.log_prob(x[sel].contiguous(), return_sum=True)
-    assert_close(lp, ref_lp, RTOL, "log_prob slice")
+    assert_close(lp, ref_lp, RTOL, "log_prob of the slice as its own launch")
     assert abs(float(total.item()) / 4096 - ref_mean) <= RTOL * abs(ref_mean)
     # sum of the per-row log-probs over the whole batch == the epilogue's fp64 sum
-    lp_all, total_all = model.log_prob(x, return_sum=True)
     assert abs(float(total_all.item()) - float(lp_all.double().sum())) <= 1e-9 * abs(float(total_all.item()))
 
 

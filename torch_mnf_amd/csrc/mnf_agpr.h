@@ -1,5 +1,5 @@
 // Rows resident in the ACCUMULATOR half of the register file, in registers the kernel assigns itself (shared by
-// mnf_rnvp_resident.hip and mnf_rnvp_pair.hip).
+// mnf_rnvp_resident.hip and mnf_ahf_bwd_split.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,12 +32,6 @@ __device__ __forceinline__ void reserve_agprs() {
                MNF_A4(4), MNF_A4(5), MNF_A4(6), MNF_A4(7), MNF_A4(8), MNF_A4(9), MNF_A4(10), MNF_A4(11), MNF_A4(12),
                MNF_A4(13), MNF_A4(14), MNF_A4(15), MNF_A4(16), MNF_A4(17), MNF_A4(18), MNF_A4(19), MNF_A4(20),
                MNF_A4(21), MNF_A4(22), MNF_A4(23));
-}
-// a0 .. a116 (mnf_rnvp_pair.hip: up to 26 groups of rows + 13 mask words per wave, two waves per SIMD)
-__device__ __forceinline__ void reserve_agprs_117() {
-  asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", MNF_A4(1), MNF_A4(2), MNF_A4(3),
-               MNF_A4(4), MNF_A4(5), MNF_A4(6), MNF_A4(7), MNF_A4(8), MNF_A4(9), MNF_A4(10), "a110", "a111", "a112",
-               "a113", "a114", "a115", "a116");
 }
 // a92 .. a255: the TOP of the accumulator file (mnf_ahf_bwd_split.hip: its own values overflow the 256 vector
 // registers and the compiler places them from a0 upwards; check_agpr.py is told how far up it may go)

@@ -962,7 +962,6 @@ int mnf_affine_half_bwd_split_layout(int dim, int n_hidden, const int* hidden, i
   int hid = 0;
   if (!n_split_words || !n_plain_words || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::bwd_split_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-  if (mnf::bwd_net_mode()) return mnf::bwd_net_layout(dim, hid, n_split_words, n_plain_words);
 #define X(HH, HD)                                                   \
   if (dim == 2 * HH && hid == HD) {                                 \
     *n_split_words = mnf::BwdSplitShape<HH, HD>::SPLIT_WORDS;       \
@@ -979,7 +978,6 @@ int mnf_affine_half_bwd_split_index(int dim, int n_hidden, const int* hidden, in
   int hid = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!has_scale || !has_shift || !mnf::bwd_split_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
-  if (mnf::bwd_net_mode()) return mnf::bwd_net_index(dim, hid, idx_host);
 #define X(HH, HD) \
   if (dim == 2 * HH && hid == HD) return mnf::build_bwd_split_index<HH, HD>(idx_host);
   MNF_AHF_BWD_SPLIT_SHAPES(X)
@@ -990,7 +988,6 @@ int mnf_affine_half_bwd_split_index(int dim, int n_hidden, const int* hidden, in
 int64_t mnf_affine_half_bwd_split_workspace(int64_t rows, int dim, int n_hidden, const int* hidden) {
   int hid = 0;
   if (rows < 0 || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_split_uniform3(n_hidden, hidden, hid)) return 0;
-  if (mnf::bwd_net_mode()) return mnf::bwd_net_workspace(rows, dim, hid);
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + mnf::kBsWaves - 1) / mnf::kBsWaves;
   const int cus = mnf::device_cus(mnf::current_device());
@@ -1034,9 +1031,6 @@ int mnf_affine_half_bwd_split(const float* x, const float* grad_y, const float* 
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x) |
        reinterpret_cast<uintptr_t>(bwd_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
-  if (mnf::bwd_net_mode())
-    return mnf::bwd_net_launch(x, grad_y, grad_ld, grad_x, grad_flat, bwd_image, rows, dim, hid, parity != 0, inverse != 0,
-                               grad_scale_dev, cold_list, cold_capacity, workspace, workspace_floats, (hipStream_t)stream);
 #define X(HH, HD)                                                                                                      \
   if (dim == 2 * HH && hid == HD)                                                                                      \
     return mnf::launch_bwd_split<HH, HD>(x, grad_y, grad_ld, grad_x, grad_flat, static_cast<const uint32_t*>(bwd_image), \
@@ -1062,7 +1056,6 @@ int mnf_affine_half_bwd_split_lp(const float* x, const float* lp_grad, float* gy
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy_scratch) | reinterpret_cast<uintptr_t>(grad_x) |
        reinterpret_cast<uintptr_t>(bwd_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
-  if (mnf::bwd_net_mode()) return MNF_ERR_UNSUPPORTED;  // (the one-net-per-wave kernels take their cotangents from memory)
 #define X(HH, HD)                                                                                                      \
   if (dim == 2 * HH && hid == HD)                                                                                      \
     return mnf::launch_bwd_split<HH, HD>(x, nullptr, nullptr, grad_x, grad_flat, static_cast<const uint32_t*>(bwd_image), \

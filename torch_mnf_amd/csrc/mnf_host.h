@@ -14,16 +14,6 @@ int check_launch();
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base);
 bool hidden_ok(int n_hidden, const int* hidden);
 
-// mnf_ahf_bwd_net.hip: the split gradient kernel with one conditioner net per wave (what mnf_affine_half_bwd_split* run
-// under MNF_AHF_BWD_SPLIT=net: measured slower than the joint kernel), behind the same C entry points
-bool bwd_net_mode();
-int bwd_net_layout(int dim, int hid, int64_t* n_split_words, int64_t* n_plain_words);
-int bwd_net_index(int dim, int hid, int32_t* idx_host);
-int64_t bwd_net_workspace(int64_t rows, int dim, int hid);
-int bwd_net_launch(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
-                   const void* image, int64_t rows, int dim, int hid, int parity, int inverse, const float* scale_dev,
-                   int32_t* cold_list, int cold_capacity, float* workspace, int64_t workspace_floats, hipStream_t stream);
-
 // Half width the AffineHalfFlow MFMA kernels pad a coupling half of `h` columns to (0: none).  A layer
 // whose half is narrower than its tile runs on the stack kernel's ragged variant: zero operands in the
 // padded columns, element-wise masked row accesses.
@@ -128,10 +118,6 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
 
 // the register-resident kernel (mnf_rnvp_resident.hip): in-kernel mask only, selected shapes; MNF_ERR_UNSUPPORTED
 // sends the caller on to the streaming kernels
-// the pair kernel (mnf_rnvp_pair.hip): rows resident in registers, two waves per 16-row tile; same contract
-int rnvp_pair_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,
-                     const float* image, int64_t rows, int dim, int hn_pad, uint64_t seed, const float* q0_mean,
-                     const float* q0_log_var, int vec, hipStream_t stream);
 // y_out != nullptr (training): additionally writes y = Wn (m z) + bn, rows x 16 * ceil(hn_pad / 16) floats, for the
 // gradient pass (NaN rows for groups that took the fp32 body)
 int rnvp_resident_launch(const float* z, float* x, float* log_det, int accumulate, const void* split_image,

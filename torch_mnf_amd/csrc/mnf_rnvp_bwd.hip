@@ -55,9 +55,6 @@ constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
 #define MNF_RNVP_BWD_ABL 0  // timing experiments only (results are wrong): bit 0 no hand-over loads in B, bit 1 no row
 #endif                      // loads, bit 2 no row-sum MFMAs, bit 3 no grad_z stores, bit 4 no K = units MFMAs
 constexpr int kBwdAbl = MNF_RNVP_BWD_ABL;
-#ifndef MNF_RNVP_BWD_TS_OCC
-#define MNF_RNVP_BWD_TS_OCC 2  // waves per SIMD launch B-ts is compiled for (experiment switch)
-#endif
 
 template <int HN>
 struct RnvpBwdShape {
@@ -92,10 +89,7 @@ struct RnvpBwdShape {
 
 // ================================================================================================ kernel A
 typedef __attribute__((address_space(3))) void* lds_void_ptr_a;
-#ifndef MNF_A_DIST
-#define MNF_A_DIST 2
-#endif
-constexpr int kBwdDist = MNF_A_DIST;     // launch A requests its operands this many chunks ahead ...
+constexpr int kBwdDist = 2;              // launch A requests its operands this many chunks ahead ...
 constexpr int kBwdRing = kBwdDist + 1;   // ... into a ring of this many LDS buffers (chunks c .. c + kBwdDist)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
@@ -464,307 +458,6 @@ __device__ __forceinline__ void tile_mask_words(uint64_t seed, int64_t tbase, in
   const uint32_t h = rnvp_mask_word(seed, tbase + (jr < n_live ? jr : 0), slab);
 #pragma unroll
   for (int r = 0; r < 4; ++r) w[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (4 * q + r), (int)h);
-}
-
-// B-ts: lane (c, q) = column c of a 16-column dim tile, rows 4 q .. 4 q + 3 of a 16-row tile in its registers.
-// Per 32 rows and 32 dims: s, t from y (K = units), gate, g_t, g_s, g_k = Wn^T g_y, grad_z; dWt, dWs (16 accumulator
-// tiles), dbt, dbs.  Two waves per SIMD: no register prefetch, the partner wave covers the loads.
-template <int HN, bool SEEDED, bool RAG>
-__global__ void __launch_bounds__(kBwdBWaves * 64, MNF_RNVP_BWD_TS_OCC)
-rnvp_bwd_ts_kernel(const float* __restrict__ z, const float* __restrict__ mask, const float* __restrict__ gx,
-                   const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
-                   const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
-                   const float* __restrict__ gscale_dev, int64_t rows, int dm, int d16, int hn, uint64_t seed, int n_slabs,
-                   int row_parts, int vec2) {
-  using S = RnvpSplitShape<HN>;
-  using B = RnvpBwdShape<HN>;
-  constexpr int YT = S::YT, NKS2 = S::NKS2;
-  constexpr int W_WORDS = B::B2_SLAB_WORDS + B::B4_SLAB_WORDS;
-  __shared__ __attribute__((aligned(16))) uint32_t w_lds[W_WORDS + B::B_SLAB_PLAIN];
-  // (the wave index as a SCALAR: tile numbers, hand-over addresses and the flag test then stay in scalar registers)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 15, q = lane >> 4;
-  const float gscale = gscale_dev[0], inv_gscale = 1.f / gscale;
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const u32x2 zero2 = u32x2{0u, 0u};
-  const int64_t n_tiles = (rows + 15) / 16, n_pairs = (n_tiles + 1) / 2;
-  const int64_t per_part = (n_pairs + row_parts - 1) / row_parts;
-  const float* gsrc = gx ? gx : z;               // (no cotangent for x: read z and multiply by zero)
-  const float gx_scale = gx ? gscale : 0.f;
-  const float gl_scale = gld ? gscale : 0.f;
-  const float* lsrc = gld ? gld : z;
-  const SlabItems items(n_slabs, row_parts);
-  for (int item = items.first; item < items.n_items; item += items.step) {
-    const int slab = items.slab(item), part = items.part(item);
-    __syncthreads();  // the previous item's operands are no longer read
-    {
-      const uint32_t* b2 = bimage + B::a3_words(d16) + (int64_t)slab * B::B2_SLAB_WORDS;
-      const uint32_t* b4 = bimage + B::a3_words(d16) + B::b2_words(dm) + (int64_t)slab * B::B4_SLAB_WORDS;
-      const uint32_t* pl = bimage + B::split_words(dm, d16) + (int64_t)slab * B::B_SLAB_PLAIN;
-      for (int i = threadIdx.x; i < B::B2_SLAB_WORDS / 4; i += blockDim.x)
-        reinterpret_cast<uint4*>(w_lds)[i] = reinterpret_cast<const uint4*>(b2)[i];
-      for (int i = threadIdx.x; i < B::B4_SLAB_WORDS / 4; i += blockDim.x)
-        reinterpret_cast<uint4*>(w_lds + B::B2_SLAB_WORDS)[i] = reinterpret_cast<const uint4*>(b4)[i];
-      for (int i = threadIdx.x; i < B::B_SLAB_PLAIN; i += blockDim.x) w_lds[W_WORDS + i] = pl[i];
-    }
-    __syncthreads();
-    const int dim0 = 32 * slab + 2 * j;  // the lane's even dim; + 1: its odd dim
-    const bool in0 = dim0 < dm, in1 = dim0 + 1 < dm;
-    const float* bias = reinterpret_cast<const float*>(w_lds + W_WORDS);
-    const float bt[2] = {bias[j], bias[16 + j]}, bs[2] = {bias[32 + j], bias[48 + j]};
-    // operand numbering in LDS: B2 [(dt * 2 + net) * NKS2 + ks][part] ; B4 [dt * NKS2 + ks][part] behind it.  The reads
-    // do not depend on the row pair: an opaque lane index, refreshed per pair, keeps hipcc from hoisting 24 KB of
-    // operands out of the pair loop into registers
-    int w_lane = lane;
-    const f16x8* W8 = reinterpret_cast<const f16x8*>(w_lds);  // (16-byte aligned: one ds_read_b128 per operand)
-    auto w2 = [&](int dt, int net, int ks, int part_) { return W8[w_lane + 64 * (2 * ((dt * 2 + net) * NKS2 + ks) + part_)]; };
-    auto w4 = [&](int dt, int ks, int part_) { return W8[w_lane + 64 * (2 * (4 * NKS2 + dt * NKS2 + ks) + part_)]; };
-    // row r of tile T, the lane's two dims: element (16 T + 4 q + r) dm + dim0 = [tile base, uniform] + lane_off + r dm
-    const uint32_t lane_off = (uint32_t)(4 * q) * (uint32_t)dm + (uint32_t)dim0;
-
-    f32x4 aWt[2][YT], aWs[2][YT];
-    float abt[2] = {0.f, 0.f}, abs_[2] = {0.f, 0.f};
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int m = 0; m < YT; ++m) aWt[dt][m] = aWs[dt][m] = zero4;
-
-    // A pair's inputs: its rows (z, G, mask, g_ld) and launch A's hand-over with units on K.  With MNF_RNVP_BWD_TS_OCC
-    // = 1 (one wave per SIMD, accumulators in the AGPR half of the file) the NEXT pair's inputs are requested before the
-    // current pair is computed -- nothing else hides a load there.
-    struct Inputs {
-      f32x2 zz[2][4], GG[2][4], mm[2][4];
-      float gl[2][4];
-      f16x8 yoh[2][NKS2], yol[2][NKS2], goh[2][NKS2], gol[2][NKS2];
-      bool skip;
-    };
-    auto load_inputs = [&](int64_t p, Inputs& in) {
-      in.skip = flags[(p * 32) / kBwdGroupRows] != 0;  // the generic kernel redoes flagged groups
-      const bool has1 = 2 * p + 1 < n_tiles;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const bool has = tt == 0 || has1;
-        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;              // wave-uniform
-        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;  // rows of the tile that exist
-        const float* zt = z + tbase * dm;
-        const float* gt_ = gsrc + tbase * dm;
-        const float* mt = SEEDED ? nullptr : mask + tbase * dm;
-        const uint32_t* sd = side + (tbase >> 4) * B::TILE_WORDS;
-        uint32_t mw[4];
-        if (SEEDED) tile_mask_words(seed, tbase, n_live, slab, lane, q, mw);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = 4 * q + r;
-          const bool live = rr < n_live;
-          // a row past the end reads the tile's first row instead (its cotangents are zeroed, nothing of it is stored)
-          const uint32_t off = live ? lane_off + (uint32_t)r * (uint32_t)dm : (uint32_t)dim0;
-          f32x2 zv = {0.f, 0.f}, gv = {0.f, 0.f}, mv = {0.f, 0.f};
-          if (kBwdAbl & 2) {
-            zv = gv = f32x2{0.25f * lane, 1.f};
-          } else if (!RAG) {
-            zv = *reinterpret_cast<const f32x2*>(zt + off);
-            gv = *reinterpret_cast<const f32x2*>(gt_ + off);
-            if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
-          } else if (vec2) {
-            if (in0) {
-              zv = *reinterpret_cast<const f32x2*>(zt + off);
-              gv = *reinterpret_cast<const f32x2*>(gt_ + off);
-              if (!SEEDED) mv = *reinterpret_cast<const f32x2*>(mt + off);
-            }
-          } else {
-            if (in0) {
-              zv[0] = zt[off];
-              gv[0] = gt_[off];
-              if (!SEEDED) mv[0] = mt[off];
-            }
-            if (in1) {
-              zv[1] = zt[off + 1];
-              gv[1] = gt_[off + 1];
-              if (!SEEDED) mv[1] = mt[off + 1];
-            }
-          }
-          if (SEEDED) {
-            const uint32_t w = mw[r] >> (2 * j);
-            mv = f32x2{(float)(w & 1u), (float)((w >> 1) & 1u)};
-          }
-          const float keep = live ? 1.f : 0.f;
-          in.zz[tt][r] = zv;
-          in.GG[tt][r] = gv * (gx_scale * keep);
-          in.mm[tt][r] = mv;
-          in.gl[tt][r] = lsrc[tbase + (live ? rr : 0)] * (gl_scale * keep);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKS2; ++ks) {
-          if (kBwdAbl & 1) {
-            in.yoh[tt][ks] = in.yol[tt][ks] = in.goh[tt][ks] = in.gol[tt][ks] = w2(0, 0, ks, 0);
-            continue;
-          }
-          in.yoh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks) * 64 + lane) * 4);
-          in.yol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::Y_OP + ((2 * ks + 1) * 64 + lane) * 4);
-          in.goh[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks) * 64 + lane) * 4);
-          in.gol[tt][ks] = *reinterpret_cast<const f16x8*>(sd + B::G_OP + ((2 * ks + 1) * 64 + lane) * 4);
-        }
-      }
-    };
-    auto compute = [&](int64_t p, Inputs& in) {
-      if (in.skip) return;
-      asm volatile("" : "+v"(w_lane));
-      const bool has1 = 2 * p + 1 < n_tiles;
-      u32x2 th[2][2], tl[2][2], sh[2][2], sl[2][2];  // [row tile][dim tile]: B operands of the row sums
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const bool has = tt == 0 || has1;
-        const int64_t tbase = (has ? 2 * p + tt : 2 * p) * 16;
-        const int n_live = has ? (int)min((int64_t)16, rows - tbase) : 0;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          // t^T, s^T [row][dim] = y [row][unit] W^T [unit][dim];  g_k^T = g_y Wn
-          f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4, km = zero4, kc = zero4;
-#pragma unroll
-          for (int ks = 0; ks < NKS2; ++ks) {
-            if (kBwdAbl & 16) {
-              tm += __builtin_bit_cast(f32x4, in.yoh[tt][ks]);
-              sm += __builtin_bit_cast(f32x4, in.goh[tt][ks]);
-              continue;
-            }
-            split_mac(in.yoh[tt][ks], in.yol[tt][ks], w2(dt, 0, ks, 0), w2(dt, 0, ks, 1), tm, tc);
-            split_mac(in.yoh[tt][ks], in.yol[tt][ks], w2(dt, 1, ks, 0), w2(dt, 1, ks, 1), sm, sc);
-            split_mac(in.goh[tt][ks], in.gol[tt][ks], w4(dt, ks, 0), w4(dt, ks, 1), km, kc);
-          }
-          const f32x4 t4 = tc * kSplitInvScale + tm + bt[dt];
-          const f32x4 s4 = sc * kSplitInvScale + sm + bs[dt];
-          const f32x4 gk = kc * kSplitInvScale + km;
-          f32x4 gt, gs;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float zv = in.zz[tt][r][dt], G_ = in.GG[tt][r][dt], m_ = in.mm[tt][r][dt], nm = 1.f - m_;
-            const float gate = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f));
-            const float omg = 1.f - gate;
-            gt[r] = G_ * omg;
-            gs[r] = (G_ * (nm * zv - t4[r]) * gate + in.gl[tt][r] * nm) * omg;
-            in.zz[tt][r][dt] = (G_ * (nm * gate + m_) + m_ * gk[r]) * inv_gscale;  // grad_z takes z's register
-          }
-          abt[dt] += (gt[0] + gt[1]) + (gt[2] + gt[3]);
-          abs_[dt] += (gs[0] + gs[1]) + (gs[2] + gs[3]);
-          split_plain(gt, th[tt][dt], tl[tt][dt]);
-          split_plain(gs, sh[tt][dt], sl[tt][dt]);
-        }
-        if (has && (!(kBwdAbl & 8) || in.zz[tt][0][0] == 1.2345e30f)) {
-          float* ot = grad_z + tbase * dm;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (4 * q + r < n_live) {
-              const uint32_t off = lane_off + (uint32_t)r * (uint32_t)dm;
-              if (!RAG) {
-                *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
-              } else if (vec2) {  // (dm even: in0 implies in1)
-                if (in0) *reinterpret_cast<f32x2*>(ot + off) = in.zz[tt][r];
-              } else {
-                if (in0) ot[off] = in.zz[tt][r][0];
-                if (in1) ot[off + 1] = in.zz[tt][r][1];
-              }
-            }
-          }
-        }
-        if (!has) {  // no second tile: its operands are zero
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) th[tt][dt] = tl[tt][dt] = sh[tt][dt] = sl[tt][dt] = zero2;
-        }
-      }
-      if (grad_flat && !(kBwdAbl & 4)) {
-        // sums over the 32 rows: D [unit][dim] += A [unit][row] B [row][dim], three partial products, one accumulator
-        const uint32_t* s0 = side + (2 * p) * B::TILE_WORDS + B::Y_TR + lane * 2;
-        const uint32_t* s1 = side + (2 * p + (has1 ? 1 : 0)) * B::TILE_WORDS + B::Y_TR + lane * 2;
-#pragma unroll
-        for (int m = 0; m < YT; ++m) {
-          const u32x2 y0h = *reinterpret_cast<const u32x2*>(s0 + (2 * m) * 128);
-          const u32x2 y0l = *reinterpret_cast<const u32x2*>(s0 + (2 * m + 1) * 128);
-          const u32x2 y1h = *reinterpret_cast<const u32x2*>(s1 + (2 * m) * 128);
-          const u32x2 y1l = *reinterpret_cast<const u32x2*>(s1 + (2 * m + 1) * 128);
-          const f16x8 yh8 = pair_operand(y0h, y1h), yl8 = pair_operand(y0l, y1l);  // (no second tile: B is zero there)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const f16x8 tH = pair_operand(th[0][dt], th[1][dt]), tL = pair_operand(tl[0][dt], tl[1][dt]);
-            const f16x8 sH = pair_operand(sh[0][dt], sh[1][dt]), sL = pair_operand(sl[0][dt], sl[1][dt]);
-            aWt[dt][m] = mfma_h(yh8, tH, aWt[dt][m]);
-            aWs[dt][m] = mfma_h(yh8, sH, aWs[dt][m]);
-            aWt[dt][m] = mfma_h(yh8, tL, aWt[dt][m]);
-            aWs[dt][m] = mfma_h(yh8, sL, aWs[dt][m]);
-            aWt[dt][m] = mfma_h(yl8, tH, aWt[dt][m]);
-            aWs[dt][m] = mfma_h(yl8, sH, aWs[dt][m]);
-          }
-        }
-      }
-    };
-    {
-      const int64_t p_end = min(n_pairs, (int64_t)(part + 1) * per_part);
-      int64_t p = (int64_t)part * per_part + wave;
-      if (MNF_RNVP_BWD_TS_OCC >= 2) {
-        for (; p < p_end; p += kBwdBWaves) {
-          Inputs in;
-          load_inputs(p, in);
-          compute(p, in);
-        }
-      } else if (p < p_end) {
-        Inputs cur, nxt;
-        load_inputs(p, cur);
-        while (true) {
-          const int64_t pn = p + kBwdBWaves;
-          const bool more = pn < p_end;
-          if (more) load_inputs(pn, nxt);
-          compute(p, cur);
-          if (!more) break;
-          cur = nxt;
-          p = pn;
-        }
-      }
-    }
-    if (!grad_flat || ((kBwdAbl & 32) && abt[0] != 1.2345e30f)) continue;
-    // flush.  Lane (c, q) register r of tile (dt, m) = d W [unit 16 m + 4 q + r][dim 32 slab + 2 c + dt]: written to
-    // memory as it stands, a wave-instruction's 64 atomics land in 16 different rows of Wt, and the memory-side atomic
-    // units take scattered adds an order of magnitude slower than contiguous ones (0.85 of this launch's 2.5 ms).  So
-    // the four waves first add their tiles up in LDS (the operand area is free now) as [tensor][dim of the slab][unit],
-    // and the workgroup then adds the slab's CONTIGUOUS blocks of Wt and Ws (32 dims x hn floats each) to grad_flat:
-    // 256 consecutive bytes per wave-instruction, and a quarter of the atomics.
-    constexpr int UP = 16 * YT + 1;  // padded row: lanes of one instruction hit 16 different banks
-    float* red = reinterpret_cast<float*>(w_lds);
-    static_assert(2 * 32 * UP + 64 <= W_WORDS + B::B_SLAB_PLAIN, "the flush area fits the operand area");
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * 32 * UP + 64; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-      for (int m = 0; m < YT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(red + (2 * j + dt) * UP + 16 * m + 4 * q + r, aWt[dt][m][r]);
-          atomicAdd(red + 32 * UP + (2 * j + dt) * UP + 16 * m + 4 * q + r, aWs[dt][m][r]);
-        }
-      float vt = abt[dt], vs = abs_[dt];
-      vt += __shfl_xor(vt, 16, 64);
-      vt += __shfl_xor(vt, 32, 64);
-      vs += __shfl_xor(vs, 16, 64);
-      vs += __shfl_xor(vs, 32, 64);
-      if (q == 0) {
-        atomicAdd(red + 2 * 32 * UP + 2 * j + dt, vt);
-        atomicAdd(red + 2 * 32 * UP + 32 + 2 * j + dt, vs);
-      }
-    }
-    __syncthreads();
-    const int64_t bn = (int64_t)hn * dm, wt = bn + hn, btf = wt + (int64_t)dm * hn, ws = btf + dm,
-                  bsf = ws + (int64_t)dm * hn;
-    const int n_dims = min(32, dm - 32 * slab);  // dims of this slab that exist
-    for (int e = threadIdx.x; e < n_dims * hn; e += blockDim.x) {
-      const int dl = e / hn, unit = e - dl * hn;
-      atomicAdd(grad_flat + wt + (int64_t)(32 * slab) * hn + e, red[dl * UP + unit] * inv_gscale);
-      atomicAdd(grad_flat + ws + (int64_t)(32 * slab) * hn + e, red[32 * UP + dl * UP + unit] * inv_gscale);
-    }
-    if ((int)threadIdx.x < n_dims) {
-      atomicAdd(grad_flat + btf + 32 * slab + threadIdx.x, red[2 * 32 * UP + threadIdx.x] * inv_gscale);
-      atomicAdd(grad_flat + bsf + 32 * slab + threadIdx.x, red[2 * 32 * UP + 32 + threadIdx.x] * inv_gscale);
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ B-ts, shared hand-over
@@ -1350,16 +1043,6 @@ static int64_t bwd_workspace_bytes(int64_t rows) {
   return bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4;
 }
 
-// MNF_RNVP_BWD_TS=split in the environment: launch B-ts on the one-slab-per-workgroup kernel (the round-3 kernel, kept
-// for same-box A/B runs and as the fallback when the shared kernel's LDS request is refused)
-static bool bwd_ts_split_forced() {
-  static const bool forced = [] {
-    const char* v = getenv("MNF_RNVP_BWD_TS");
-    return v != nullptr && strcmp(v, "split") == 0;
-  }();
-  return forced;
-}
-
 // phases: bit 0 launch A, bit 1 B-ts, bit 2 B-n (bit 3, the fp32 fix-up, is the caller's)
 template <int HN, bool SEEDED, bool RAG>
 static int launch_bwd(const float* z, const float* mask, uint64_t seed, const float* gx, const float* gld, float* grad_z,
@@ -1371,7 +1054,7 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   int32_t* list = static_cast<int32_t*>(work);
   int32_t* flags = list + 1 + n_groups;
   uint32_t* side = reinterpret_cast<uint32_t*>(static_cast<char*>(work) + bwd_header_bytes(rows));
-  static DeviceMemo memo_a, memo_b;
+  static DeviceMemo memo_a;
   constexpr int a_lds_bytes = kBwdRing * B::CHUNK_WORDS * 4;
   void (*const a_kernel)(const float*, const float*, const float*, const float*, const uint32_t*, const uint32_t*, uint32_t*,
                          int32_t*, int32_t*, const float*, float*, int64_t, int, int, int, uint64_t, int, int64_t,
@@ -1403,10 +1086,8 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     plan_slab_launch(n_pairs, kBwdBWaves, n_slabs, resident, row_parts, grid);
   };
   static DeviceMemo memo_n;
-  const int resident_b = memo_b.get(
-      [](int dev) { return resident_by_occupancy(rnvp_bwd_ts_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 2); });
   int row_parts, grid;
-  if ((phases & 2) && !bwd_ts_split_forced()) {
+  if (phases & 2) {
     // the shared-hand-over kernel: four slabs per workgroup, one workgroup per CU (145 KB of LDS at 64 units)
     using T = RnvpTsShape<HN>;
     static DeviceMemo memo_s;
@@ -1423,21 +1104,12 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
         per_cu = 1;
       return per_cu * device_cus(dev);
     });
-    if (resident_s > 0) {
-      const int n_slab_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
-      plan_slab_launch(n_pairs, 1, n_slab_groups, resident_s, row_parts, grid);
-      hipLaunchKernelGGL((rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kTsWaves * 64),
-                         T::LDS_WORDS * 4, stream, z, mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows,
-                         dm, d16, hn, seed, n_slabs, row_parts, vec2);
-      if (int rc = check_launch()) return rc;
-      phases &= ~2;
-    }
-  }
-  plan(resident_b, row_parts, grid);
-  if (phases & 2) {
-    hipLaunchKernelGGL((rnvp_bwd_ts_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
-                       mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows, dm, d16, hn, seed, n_slabs,
-                       row_parts, vec2);
+    if (resident_s < 0) return MNF_ERR_LAUNCH;  // (the LDS request was refused: not an MI355X)
+    const int n_slab_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
+    plan_slab_launch(n_pairs, 1, n_slab_groups, resident_s, row_parts, grid);
+    hipLaunchKernelGGL((rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kTsWaves * 64),
+                       T::LDS_WORDS * 4, stream, z, mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows,
+                       dm, d16, hn, seed, n_slabs, row_parts, vec2);
     if (int rc = check_launch()) return rc;
   }
   if (!grad_flat || !(phases & 4)) return MNF_OK;

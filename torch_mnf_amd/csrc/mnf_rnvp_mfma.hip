@@ -529,10 +529,7 @@ int rnvp_mfma_launch(const float* z, const float* mask, float* x, float* log_det
     }
   }
   if (split_image && !mask && rows_aligned && !y_out) {  // in-kernel mask: the register-resident kernels where they exist
-    int rc = rnvp_pair_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean,
-                              q0_log_var, vec, stream);
-    if (rc != MNF_ERR_UNSUPPORTED) return rc;
-    rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean, q0_log_var,
+    const int rc = rnvp_resident_launch(z, x, log_det, accumulate, split_image, image, rows, dim, hn_pad, seed, q0_mean, q0_log_var,
                               vec, stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }

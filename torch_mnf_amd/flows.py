@@ -38,8 +38,7 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 # ... and below this many rows anyway: the split kernel needs three small launches more per backward pass (gradient
 # scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
 # 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
-# NSF_CL gradient kernel: "tile" (default: mnf_nsf_bwd_tile.hip where the shape has one), "rows" (round 3/4's lane-per-
-# element kernel, d = 32 only; kept for A/B runs), "generic"
+# NSF_CL gradient kernel: "tile" (default: mnf_nsf_bwd_tile.hip where the shape has one) or "generic"
 _NSF_BWD_KERNEL = os.environ.get("MNF_NSF_BWD_KERNEL", "tile")
 _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
 # MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
@@ -429,9 +428,9 @@ class _NsfFn(torch.autograd.Function):
                 or rows * m.dim >= (1 << 31)):
             table = m._bwd_tile_tables(x.device)
         marks = None
-        if bwd_kernel_events is not None and (table or _NSF_BWD_KERNEL == "rows"):  # bench.py --workload c3t
+        if bwd_kernel_events is not None and table:  # bench.py --workload c3t
             marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        if table and _NSF_BWD_KERNEL != "rows":
+        if table:
             idx, flush, n_split, n_plain = table
             image = torch.empty(n_split + n_plain + _lib.MNF_SPLIT_TAIL_WORDS, dtype=torch.int32, device=x.device)
             _lib.check("mnf_pack_gather_split", lib.mnf_pack_gather_split(
@@ -453,16 +452,8 @@ class _NsfFn(torch.autograd.Function):
                 x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
                 cold.data_ptr(), cap, _stream()))
             return grad_x, grad_flat, None, None
-        rows_kernel = (_NSF_BWD_KERNEL == "rows" and not m.force_generic and rows * m.dim < (1 << 31)
-                       and lib.mnf_nsf_cl_bwd_rows_supported(m.dim, m.K, len(m.h_sizes), m._hid))
-        name = "mnf_nsf_cl_bwd_rows" if rows_kernel else "mnf_nsf_cl_bwd"
-        if marks is not None and rows_kernel:
-            marks[0].record()
-        _lib.check(name, getattr(lib, name)(
+        _lib.check("mnf_nsf_cl_bwd", lib.mnf_nsf_cl_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
-        if marks is not None and rows_kernel:
-            marks[1].record()
-            bwd_kernel_events.append(marks)
         return grad_x, grad_flat, None, None
 
 
@@ -2081,6 +2072,8 @@ class _AffineRun:
     def launch_grad(self, x: Tensor, inverse: bool, with_lp: bool = False):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels.
         ``with_lp``: log p under a standard-normal base instead, as ONE tensor (see _AffineRunFn.forward)."""
+        if with_lp and getattr(self, "_lp_unsupported", None) == (x.shape[1], x.device):
+            return None
         self._home_now = self.flat_home()
         if self._home_now is not None:
             if self._stand_in is None or self._stand_in.device != x.device:
@@ -2093,7 +2086,8 @@ class _AffineRun:
         except MnfHipError as err:  # an image exists but no stack kernel (e.g. hidden width 32): layer by layer
             if err.code != _lib.MNF_ERR_UNSUPPORTED:
                 raise
-            if with_lp:  # (only the epilogue may be missing: the caller takes the unfused route)
+            if with_lp:  # (only the epilogue may be missing: the caller takes the unfused route -- and does not ask
+                self._lp_unsupported = (x.shape[1], x.device)  # again: the refusal comes AFTER a whole stack launch)
                 return None
             self._unsupported = True
             return None

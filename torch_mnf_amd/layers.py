@@ -37,6 +37,16 @@ def _mnf_linear_forward(module, x, z, eps, seed, ops, sd):
     return out, work
 
 
+def _require_operands(module, device):
+    """The forward launch's packed operands, or a clear error when the library has no kernel for the shape (the split
+    layout refuses n_in * 512 >= 2^30): every caller unpacks the triple."""
+    ops = module._forward_operands(device)
+    if ops is None:
+        raise _lib.MnfHipError("mnf_mnf_linear_split_layout", _lib.MNF_ERR_UNSUPPORTED,
+                               f"MNFLinear({module.n_in}, {module.n_out}): no HIP kernel for this shape")
+    return ops
+
+
 _MNF_LINEAR_BWD_WORK: dict = {}  # (device, stream) -> scratch of mnf_mnf_linear_bwd (its launches follow one another on a stream)
 
 
@@ -45,7 +55,7 @@ class _MnfLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, z, W_mean, W_log_var, b_mean, b_log_var, module, eps, seed):
-        ops = module._forward_operands(x.device)
+        ops = _require_operands(module, x.device)
         xc, zc = x.detach().contiguous(), z.detach().contiguous()
         sd = torch.empty(xc.shape[0], module.n_out, dtype=torch.float32, device=x.device)
         out, work = _mnf_linear_forward(module, xc, zc, eps, seed, ops, sd)
@@ -119,7 +129,7 @@ class _SampleZ0Fn(torch.autograd.Function):
     def forward(ctx, q0_mean, q0_log_var, eps, module, seed=0, rows=0):
         mean, log_var = q0_mean.detach().contiguous(), q0_log_var.detach().contiguous()
         if eps is None:
-            z0 = torch.empty(rows, mean.numel(), device=mean.device)
+            z0 = torch.empty(rows, mean.numel(), dtype=torch.float32, device=mean.device)
             _lib.check("mnf_sample_z0_seeded", _lib.load().mnf_sample_z0_seeded(
                 mean.data_ptr(), log_var.data_ptr(), seed, z0.data_ptr(), rows, mean.numel(), _stream()))
             ctx.save_for_backward(log_var)
@@ -349,10 +359,12 @@ class MNFLinear(nn.Module):
         flows = list(self.flow_q.flows)
         if masks is not None and len(masks) != len(flows):
             raise ValueError(f"sample_z got {len(masks)} masks for {len(flows)} flow_q layers")
-        if eps is None and training and batch_size > 0 and dev.type == "cuda" and not _flows._DEVICE_MASKS:
+        if (eps is None and training and batch_size > 0 and dev.type == "cuda" and not _flows._DEVICE_MASKS
+                and not torch.cuda.is_current_stream_capturing()):
             # training, nothing injected: the noise is generated inside the prologue launch and again inside its gradient
             # launch from one host-drawn seed (never as a (batch, n_in) tensor).  (A step being recorded in a hipGraph
-            # keeps the tensor draw: a seed would be frozen into the recorded kernel arguments.)
+            # -- train.GraphedStep's, or a user's own torch.cuda.graph capture -- keeps the tensor draw: a seed would be
+            # frozen into the recorded kernel arguments and every replay would use the same noise.)
             seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
             z0 = _SampleZ0Fn.apply(self.q0_mean, self.q0_log_var, None, self, seed, int(batch_size))
             return self._through_flow_q(z0, masks, dev)
@@ -403,7 +415,10 @@ class MNFLinear(nn.Module):
         """(flat parameters, split operand image, var_unscale) of mnf_mnf_linear_fwd for the current parameters, or
         None when the shape has no kernel (n_out > 64).  Repacked when a parameter changes."""
         params = (self.W_mean, self.W_log_var, self.b_mean, self.b_log_var)
-        flat_home = self.__dict__.get("_mnf_flat")
+        # (an _OutputSlab borrows this method: its parameters are slices of its PARENT's, and it is the parent that a
+        #  train.FlatParameters buffer re-homes -- a fused optimizer step or a hipGraph replay writes that buffer through
+        #  raw pointers and only bumps the home's generation, never a parameter's version counter)
+        flat_home = getattr(self, "parent", self).__dict__.get("_mnf_flat")
         key = (device, 0 if flat_home is None else flat_home.generation,
                tuple((p.data_ptr(), p._version) for p in params))
         cache = self.__dict__.get("_fwd_cache")
@@ -513,11 +528,11 @@ class MNFLinear(nn.Module):
                     outs.append(_MnfLinearFn.apply(x, z, slab.W_mean, slab.W_log_var, slab.b_mean, slab.b_log_var, slab,
                                                    eps_k, seed_k))
                 else:
-                    outs.append(_mnf_linear_forward(slab, xc, zc, eps_k, seed_k, slab._forward_operands(x.device), None)[0])
+                    outs.append(_mnf_linear_forward(slab, xc, zc, eps_k, seed_k, _require_operands(slab, x.device), None)[0])
             return torch.cat(outs, dim=1)
         if training:
             return _MnfLinearFn.apply(x, z, *params, self, eps, seed)
-        ops = self._forward_operands(x.device)
+        ops = _require_operands(self, x.device)
         return _mnf_linear_forward(self, x.detach().contiguous(), z.detach().contiguous(), eps, seed, ops, None)[0]
 
     def _output_slabs(self) -> list:
