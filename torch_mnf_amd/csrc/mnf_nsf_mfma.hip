@@ -349,30 +349,47 @@ __device__ __forceinline__ float nsf_half_step_split(const uint32_t* ops, const 
       for (int m = 0; m < NTH; ++m) mac(ph[ks], pl[ks], main[m], corr[m]);
     activate();
   }
+  // The slots as a RUN-TIME loop (round 5): unrolled, hipcc hoisted the operand reads of all H / 4 slots to the top --
+  // 243-254 registers at d = 32 (two waves per SIMD), 512 with 66-82 spilled at d = 64.  The loop always works on
+  // component 0 of the group's float4, which is rotated by one element per trip (back in place after four).
   float lad_sum = 0.f;
+  const int op0 = op, bt0 = bt;
 #pragma unroll
-  for (int s = 0; s < SL; ++s) {
-    f32x4 prm[NB], prc[NB];
+  for (int g = 0; g < G; ++g) {
+    f32x4 a4 = act[g];
+#pragma nounroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * g + r;
+      const u32x2* As = A2 + 128 * (op0 + s * (NTH * NB));  // + 64 * (2 o + part), o = ks * NB + kb
+      const f32x4* Bs = B4 + 4 * (bt0 + s * NB);
+      f32x4 prm[NB], prc[NB];
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      prm[kb] = B4[4 * (bt++)];
-      prc[kb] = zero4;
+      for (int kb = 0; kb < NB; ++kb) {
+        prm[kb] = Bs[4 * kb];
+        prc[kb] = zero4;
+      }
+#pragma unroll
+      for (int ks = 0; ks < NTH; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+          const u32x2 ah = As[64 * (2 * (ks * NB + kb))], al = As[64 * (2 * (ks * NB + kb) + 1)];
+          prm[kb] = mfma_h16(ah, hh[ks], prm[kb]);
+          prc[kb] = mfma_h16(ah, hl[ks], prc[kb]);
+          prc[kb] = mfma_h16(al, hh[ks], prc[kb]);
+        }
+      float p[4 * NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        const f32x4 v = prc[kb] * kSplitInvScale + prm[kb];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[4 * kb + i] = v[i];
+      }
+      float o, l;
+      rqs_regs<K, INV, 4 * NB>(a4[0], T, p, o, l);
+      a4 = f32x4{a4[1], a4[2], a4[3], o};
+      lad_sum += l;
     }
-#pragma unroll
-    for (int ks = 0; ks < NTH; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < NB; ++kb) mac(hh[ks], hl[ks], prm[kb], prc[kb]);
-    float p[4 * NB];
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const f32x4 v = prc[kb] * kSplitInvScale + prm[kb];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[4 * kb + r] = v[r];
-    }
-    float o, l;
-    rqs_regs<K, INV, 4 * NB>(act[s >> 2][s & 3], T, p, o, l);
-    act[s >> 2][s & 3] = o;
-    lad_sum += l;
+    act[g] = a4;
   }
   return lad_sum;
 }
