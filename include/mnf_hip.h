@@ -65,11 +65,17 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 11
+#define MNF_ABI_VERSION 12
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
 int mnf_last_hip_error(void);
+/* Which kernel family the process's most recent layer call ran (any thread: autograd launches gradients on its own): a static string such as "ahf_split_stack",
+ * "nsf_mfma_split", "nsf_bwd_tile", "rnvp_resident" -- or "ahf_generic", "nsf_generic", "nsf_bwd_generic", ... for the
+ * any-shape kernels, which are 20-40 x slower at large batches.  The reference has no counterpart (one code path); here a
+ * caller can see which side of a shape cliff a layer landed on (shape -> kernel table).  "" before the
+ * first launch. */
+const char* mnf_last_kernel(void);
 /* Number of visible devices whose gcnArchName starts with gfx950 (0 = none / no driver). */
 int mnf_device_count(void);
 

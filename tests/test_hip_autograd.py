@@ -474,7 +474,18 @@ def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
     w_y = recipes.gaussian(4300, rows, dim)
     w_l = recipes.gaussian(4400, rows, 1)[:, 0]
     oracle = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse), w_y, w_l), x_cpu, sd)
+    # the forward kernel on the same shape (a half narrower than its tile: dead float4 groups), against the oracle
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    with torch.no_grad():
+        y_k, ld_k = (f.inverse if inverse else f.forward)(x_cpu.detach().to(DEV))
+        assert "generic" not in amd.last_kernel(), amd.last_kernel()
+        y_o, ld_o = O.nsf_cl(x_cpu.detach(), sd, K, 3.0, inverse)
+    assert_close(y_k, y_o, 1e-5, f"nsf forward kernel d={dim} y")
+    assert_close(ld_k, ld_o, 2e-5, f"nsf forward kernel d={dim} log_det")
     got = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l)
+    assert amd.last_kernel() == "nsf_bwd_tile", amd.last_kernel()
     ref = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=True)
     oracle.check_all(got, f"nsf tile kernel d={dim} K={K} n_h={n_h} inv={inverse}")
     for k in got:

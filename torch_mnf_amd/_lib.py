@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 11  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 12  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -30,6 +30,7 @@ SIGNATURES = {
     "mnf_abi_version": (c_int, []),
     "mnf_error_string": (c_char_p, [c_int]),
     "mnf_last_hip_error": (c_int, []),
+    "mnf_last_kernel": (c_char_p, []),
     "mnf_device_count": (c_int, []),
     "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
@@ -232,3 +233,29 @@ def check(fn: str, code: int) -> None:
 def int_array(values) -> ctypes.Array:
     values = [int(v) for v in values]
     return (c_int * max(len(values), 1))(*values)
+
+
+def last_kernel() -> str:
+    """The kernel family the process's most recent layer call ran ("ahf_split_stack", "nsf_bwd_tile", ... or a
+    "*_generic" name for the any-shape kernels; "" before the first launch): include/mnf_hip.h mnf_last_kernel."""
+    return (load().mnf_last_kernel() or b"").decode()
+
+
+_WARNED_GENERIC: set = set()
+GENERIC_WARN_ROWS = 4096
+
+
+def note_generic(layer: str, rows: int, shape: str) -> None:
+    """Once per (layer type, shape): tell the caller that a batch of >= 4,096 rows ran on an any-shape kernel.  The
+    specialised kernels are narrow templates (shape -> kernel table) and nothing else says which
+    side of a cliff a layer landed on; the generic kernels are correct but 20-40 x slower at large batches."""
+    if rows < GENERIC_WARN_ROWS:
+        return
+    name = last_kernel()
+    if "generic" not in name or (layer, shape) in _WARNED_GENERIC:
+        return
+    _WARNED_GENERIC.add((layer, shape))
+    import warnings
+    warnings.warn(f"torch_mnf_amd: {layer}({shape}) ran on the any-shape kernel {name!r} at {rows} rows: no matrix-core "
+                  "kernel for this shape (see INTEGRATION.md, 'Which kernel runs'); results are the same, the speed is not",
+                  RuntimeWarning, stacklevel=3)

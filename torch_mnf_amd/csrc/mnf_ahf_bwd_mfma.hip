@@ -564,6 +564,7 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   // (a fix-up pass gets the full grid too: the list is usually empty and every workgroup returns at once, but it may
   //  also name every tile)
   const dim3 grid((unsigned)blocks), block(S::WAVES * 64);
+  if (!tile_list) tag_kernel("ahf_bwd_mfma_fp32");  // (as the split kernel's fix-up pass it keeps that kernel's name)
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true, RAG>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
                        grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity, real_h);

@@ -935,6 +935,7 @@ static int launch_bwd_split(const float* x, const float* grad_y, const float* gr
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (one wave per SIMD: the whole register file)
   const dim3 grid((unsigned)blocks), block(kBsWaves * 64);
   float* partials = (grad_flat && workspace && workspace_floats >= blocks * B::RED_FLOATS) ? workspace : nullptr;
+  tag_kernel("ahf_bwd_split");
   hipLaunchKernelGGL(all[(lp_grad ? 2 : 0) + (inverse ? 0 : 1)], grid, block, lds_bytes, stream, x, grad_y, grad_ld, grad_x,
                      grad_flat, image, index, rows, parity, scale_dev, cold_list, cold_capacity, partials, lp_grad,
                      gy_scratch);

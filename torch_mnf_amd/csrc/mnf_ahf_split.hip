@@ -535,6 +535,7 @@ static int launch_split(const float* x, float* y, float* log_det, float* ysq, in
   const int cus = device_cus(current_device());
   const int64_t n_tiles = (rows + 15) / 16;
   const dim3 grid((unsigned)balanced_grid(n_tiles, kSplitWaves, resident, cus)), block(kSplitWaves * 64);
+  tag_kernel("ahf_split");
   if (inverse)
     hipLaunchKernelGGL((ahf_split_kernel<H, HID, true>), grid, block, 0, stream, x, y, log_det, ysq, simage, image,
                        rows, parity, accumulate);
@@ -571,6 +572,7 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
   constexpr int GROUP_ROWS = 16 * kStackTiles * kStackWaves;
   const int64_t n_groups = (rows + GROUP_ROWS - 1) / GROUP_ROWS;
   const dim3 grid((unsigned)(n_groups < resident ? n_groups : resident)), block(kStackWaves * 64);
+  tag_kernel("ahf_split_stack");
   if (inverse)
     hipLaunchKernelGGL((ahf_split_stack_kernel<H, HID, true, RAG>), grid, block, lds_bytes, stream, x, y, mid, log_det,
                        ysq, simages, images, parity_bits, n_layers, rows, accumulate, log_prob, log_prob_sum, h, vec_ok);

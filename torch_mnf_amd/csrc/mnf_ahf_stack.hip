@@ -131,6 +131,7 @@ static int launch_stack(const float* x, float* y, float* mid, float* log_det, fl
   });
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   const dim3 grid((unsigned)blocks), block(kStackWaves * 64);
+  tag_kernel("ahf_stack_fp32");
   if (inverse)
     hipLaunchKernelGGL((ahf_stack_kernel<H, HID, true>), grid, block, 0, stream, x, y, mid, log_det, ysq, images,
                        parity_bits, n_layers, rows, accumulate);

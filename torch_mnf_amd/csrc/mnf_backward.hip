@@ -366,6 +366,7 @@ int mnf_affine_half_bwd(const float* x, const float* grad_y, const float* grad_l
   int64_t blocks = (rows + R - 1) / R;
   if (a.n_params > 0 && blocks > 1024) blocks = 1024;  // persistent: 4 workgroups per CU, one flush each
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("ahf_bwd_generic");
   hipLaunchKernelGGL(ahf_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads),
                      ((size_t)R * per_row + a.n_params) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
@@ -950,6 +951,7 @@ int mnf_nsf_ar_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("nsf_ar_bwd_generic");
   hipLaunchKernelGGL(nsf_ar_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      (hipStream_t)stream, a);
   return check_launch();
@@ -995,6 +997,7 @@ static int nsf_cl_bwd_launch(const float* x, const float* grad_y, const float* g
   }
   a.R = R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  if (!cold) tag_kernel("nsf_bwd_generic");  // (as the tile kernel's fix-up pass it keeps that kernel's name)
   hipLaunchKernelGGL(nsf_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      (hipStream_t)stream, a);
   return check_launch();
@@ -1059,6 +1062,7 @@ int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, co
   a.R = R;
   const int64_t blocks = list ? 256 : (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("rnvp_bwd_generic");
   hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      stream, a);
   return check_launch();

@@ -779,6 +779,7 @@ __global__ void zero_tails_kernel(uint32_t* tail0, int64_t image_words) {
   if (threadIdx.x < MNF_SPLIT_TAIL_WORDS) tail0[(int64_t)blockIdx.x * image_words + threadIdx.x] = 0u;
 }
 thread_local int g_last_hip_error = 0;
+std::atomic<const char*> g_last_kernel{""};
 
 int check_launch() {
   hipError_t e = hipGetLastError();
@@ -846,6 +847,7 @@ const char* mnf_error_string(int code) {
 }
 
 int mnf_last_hip_error(void) { return g_last_hip_error; }
+const char* mnf_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 
 int mnf_device_count(void) {
   int n = 0;
@@ -933,6 +935,7 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("ahf_generic");
   hipLaunchKernelGGL(ahf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
                      ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
@@ -1038,6 +1041,7 @@ int mnf_nsf_ar(const float* x, float* y, float* log_det, int accumulate, const f
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("nsf_ar_generic");
   hipLaunchKernelGGL(nsf_ar_generic_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)R * per_row * sizeof(float),
                      (hipStream_t)stream, a);
   return check_launch();
@@ -1095,6 +1099,7 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const f
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("nsf_generic");
   hipLaunchKernelGGL(nsf_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
                      ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
@@ -1210,6 +1215,7 @@ int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, floa
   a.R = R;
   const int64_t blocks = (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("rnvp_generic");
   hipLaunchKernelGGL(rnvp_generic_kernel, dim3((unsigned)blocks), dim3(kThreads),
                      ((size_t)R * per_row + a.w_lds) * sizeof(float), (hipStream_t)stream, a);
   return check_launch();
@@ -1256,6 +1262,7 @@ int mnf_linear_rows(const float* x, const float* W, float* y, int64_t rows, int 
   if (R > 256) R = 256;
   const int64_t groups = (rows + R - 1) / R;
   const int grid = (int)(groups < 2048 ? groups : 2048);
+  tag_kernel("linear_rows_generic");
   hipLaunchKernelGGL(linear_rows_kernel, dim3(grid), dim3(kThreads), (size_t)(wf + (int64_t)R * dim) * 4,
                      (hipStream_t)stream, x, W, y, rows, dim, R, w_lds);
   return check_launch();

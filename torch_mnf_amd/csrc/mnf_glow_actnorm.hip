@@ -334,6 +334,7 @@ bool aligned16(const void* a, const void* b, const void* c2) {
 template <int D, bool LP>
 int launch_fwd(const float* u, const float* M, const float* s, const float* t, float* z, const float* ld_glow, float* ld_out,
                const float* ld_rows, float* lp_out, int64_t rows, hipStream_t stream) {
+  tag_kernel("glow_actnorm_inv");
   hipLaunchKernelGGL((glow_actnorm_inv_kernel<D, LP>), dim3((unsigned)grid_for_tiles(rows, 8)), dim3(kGaWaves * 64), 0,
                      stream, u, M, s, t, z, ld_glow, ld_out, ld_rows, lp_out, rows);
   return check_launch();
@@ -345,6 +346,7 @@ int launch_fwd(const float* u, const float* M, const float* s, const float* t, f
 template <int D, bool LP>
 int launch_bwd(const float* u, const float* g, const float* M, const float* s, const float* t, float* grad_u, float* grad_m,
                float* grad_s, float* grad_t, const float* grad_ld, float* grad_ld_out, int64_t rows, hipStream_t stream) {
+  tag_kernel("glow_actnorm_inv_bwd");
   hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<D, MNF_GA_BWD_WAVES, LP>),
                      dim3((unsigned)grid_for_tiles(rows, D == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
                      dim3(MNF_GA_BWD_WAVES * 64), 0, stream, u, g, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld,

@@ -10,6 +10,11 @@
 namespace mnf {
 
 extern thread_local int g_last_hip_error;
+// the kernel family of the process's most recent layer launch (mnf_last_kernel()): a static string set at the launch
+// site -- "*_generic" names are the any-shape kernels, 20-40 x slower than the matrix-core ones at large batches.
+// Process-wide, not per thread: autograd runs the gradient launches on its own thread, and the caller asks from another.
+extern std::atomic<const char*> g_last_kernel;
+inline void tag_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
 int check_launch();
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base);
 bool hidden_ok(int n_hidden, const int* hidden);

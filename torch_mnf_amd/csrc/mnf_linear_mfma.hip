@@ -81,6 +81,7 @@ static int launch(const float* x, const float* image, float* y, int64_t rows, hi
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kLinWaves - 1) / kLinWaves;
   if (blocks > 256 * 8) blocks = 256 * 8;
+  tag_kernel("linear_rows_mfma");
   hipLaunchKernelGGL((linear_rows_mfma_kernel<D>), dim3((unsigned)blocks), dim3(kLinWaves * 64), 0, stream, x,
                      image, y, rows);
   return check_launch();

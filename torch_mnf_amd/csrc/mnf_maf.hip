@@ -317,6 +317,7 @@ int mnf_maf(const float* x, float* y, float* log_det, int accumulate, const floa
     return MNF_ERR_LAUNCH;
   const int64_t blocks = (rows + T - 1) / T;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("maf_generic");
   hipLaunchKernelGGL(maf_fwd_kernel, dim3((unsigned)blocks), dim3((T + 63) / 64 * 64), lds, (hipStream_t)stream, a);
   return check_launch();
 }
@@ -351,6 +352,7 @@ int mnf_maf_bwd(const float* x, const float* y, const float* grad_y, const float
     return MNF_ERR_LAUNCH;
   const int64_t blocks = (rows + T - 1) / T;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("maf_bwd_generic");
   hipLaunchKernelGGL(maf_bwd_kernel, dim3((unsigned)blocks), dim3((T + 63) / 64 * 64), lds, (hipStream_t)stream, a);
   return check_launch();
 }

@@ -295,6 +295,7 @@ static int launch_ml(const float* x, const float* z, const float* eps, float* ou
       [](int dev) { return resident_by_occupancy(mnf_linear_fwd_kernel<YT, RAG>, kMlWaves * 64, dev, 1); });
   const int64_t n_groups = (rows + 16 * kMlWaves - 1) / (16 * kMlWaves);
   const int64_t blocks = n_groups < resident ? n_groups : resident;
+  tag_kernel("mnf_linear_fwd");
   hipLaunchKernelGGL((mnf_linear_fwd_kernel<YT, RAG>), dim3((unsigned)blocks), dim3(kMlWaves * 64), 0, stream, x, z, eps,
                      out, sd_out, simage, flags, rows, n_in, n_out, var_unscale, seed, vec);
   return check_launch();

@@ -807,6 +807,7 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   const int resident_p =
       memo_p.get([](int dev) { return resident_by_occupancy(ml_bwd_prologue_kernel<YT>, 8 * 64, dev, 1); });
   const int64_t blocks_p = n_groups < resident_p ? n_groups : resident_p;
+  tag_kernel("mnf_linear_bwd");
   hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,
                      flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f);
   if (int rc = check_launch()) return rc;

@@ -786,6 +786,7 @@ static int launch_tile(const NtArgs& a, int inverse, hipStream_t stream) {
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU: the sums take the register file
   const size_t lds_bytes = (size_t)Sh::LDS_WORDS * 4;
   static DeviceMemo attr[4];
+  tag_kernel("nsf_bwd_tile");
   for (int st = 0; st < 2; ++st) {
     const NtKernel kernel = inverse ? (st ? NtKernelOf<H, NH, K, true, 1>::get() : NtKernelOf<H, NH, K, true, 0>::get())
                                     : (st ? NtKernelOf<H, NH, K, false, 1>::get() : NtKernelOf<H, NH, K, false, 0>::get());

@@ -179,9 +179,11 @@ constexpr int kNsfWaves = MNF_NSF_WAVES;
 
 // One half-step: params = net(cond); act <- spline(act; params); returns this lane's sum of
 // log-derivatives over its S elements.
+// live: bit g set = this lane's float4 group g exists (a half narrower than H: the dead groups' elements run through the
+// spline like the others -- zero weights, value 0 -- but their log-derivatives must not be counted)
 template <int H, int NH, int K, bool INV>
 __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, int q, const f32x4 (&cond)[H / 16],
-                                               f32x4 (&act)[H / 16], float T) {
+                                               f32x4 (&act)[H / 16], float T, unsigned live = ~0u) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S;
   int a_off = lane * 4, b_off = S_::A_FLOATS + q * 4;
@@ -256,7 +258,7 @@ __device__ __forceinline__ float nsf_half_step(const float* lds_net, int lane, i
     float o, l;
     rqs_regs<K, INV, 4 * NB>(act[s >> 2][s & 3], T, p, o, l);
     act[s >> 2][s & 3] = o;
-    lad_sum += l;
+    lad_sum += ((live >> (s >> 2)) & 1) ? l : 0.f;
   }
   return lad_sum;
 }
@@ -295,7 +297,7 @@ __device__ __forceinline__ f32x4 mfma_h16(const u32x2& a, const u32x2& b, const 
 template <int H, int NH, int K, bool INV>
 __device__ __forceinline__ float nsf_half_step_split(const uint32_t* ops, const float* bias, int lane, int q,
                                                      const f32x4 (&cond)[H / 16], f32x4 (&act)[H / 16], float T,
-                                                     float& mx) {
+                                                     float& mx, unsigned live = ~0u) {
   using S_ = NsfSplitShape<H, NH, K>;
   constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S;
   int a_off = lane * 2, b_off = q * 4;
@@ -387,7 +389,7 @@ __device__ __forceinline__ float nsf_half_step_split(const uint32_t* ops, const 
       float o, l;
       rqs_regs<K, INV, 4 * NB>(a4[0], T, p, o, l);
       a4 = f32x4{a4[1], a4[2], a4[3], o};
-      lad_sum += l;
+      lad_sum += ((live >> g) & 1) ? l : 0.f;
     }
     act[g] = a4;
   }
@@ -399,13 +401,14 @@ template <int G>
 struct HalfStepIO {
   f32x4 act[G];
   float lad;
+  unsigned live;
 };
 template <int H, int NH, int K, bool INV>
 __device__ __attribute__((noinline)) HalfStepIO<H / 16> nsf_half_step_cold(const float* net_f32, int lane, int q,
                                                                           HalfStepIO<H / 16> cond_in,
                                                                           HalfStepIO<H / 16> act_in, float T) {
   HalfStepIO<H / 16> out = act_in;
-  out.lad = nsf_half_step<H, NH, K, INV>(net_f32, lane, q, cond_in.act, out.act, T);
+  out.lad = nsf_half_step<H, NH, K, INV>(net_f32, lane, q, cond_in.act, out.act, T, act_in.live);
   return out;
 }
 
@@ -413,13 +416,13 @@ __device__ __attribute__((noinline)) HalfStepIO<H / 16> nsf_half_step_cold(const
 template <int H, int NH, int K, bool INV>
 __device__ __forceinline__ float nsf_half_step_guarded(const uint32_t* ops, const float* bias, const float* net_f32,
                                                        float wmax, int lane, int q, const f32x4 (&cond)[H / 16],
-                                                       f32x4 (&act)[H / 16], float T) {
+                                                       f32x4 (&act)[H / 16], float T, unsigned live = ~0u) {
   constexpr int G = H / 16;
   f32x4 trial[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) trial[g] = act[g];
   float mx = split_guard_seed(wmax);
-  float lad = nsf_half_step_split<H, NH, K, INV>(ops, bias, lane, q, cond, trial, T, mx);
+  float lad = nsf_half_step_split<H, NH, K, INV>(ops, bias, lane, q, cond, trial, T, mx, live);
   if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {
     HalfStepIO<G> c, a;
 #pragma unroll
@@ -428,6 +431,7 @@ __device__ __forceinline__ float nsf_half_step_guarded(const uint32_t* ops, cons
       a.act[g] = act[g];
     }
     c.lad = a.lad = 0.f;
+    c.live = a.live = live;
     const HalfStepIO<G> r = nsf_half_step_cold<H, NH, K, INV>(net_f32, lane, q, c, a, T);
 #pragma unroll
     for (int g = 0; g < G; ++g) trial[g] = r.act[g];
@@ -475,7 +479,10 @@ __device__ __forceinline__ void affine_rows(const float* aff, int lane, int q, f
 // row-independent log-det constant.  The block's two intermediate tensors are never written.
 // SPLIT: the conditioner on f16 MFMAs in split arithmetic (`simage`), with `image` (fp32, read from global
 // memory) behind it for tiles whose operands leave the f16 range.
-template <int H, int NH, int K, bool INV, int AFF = 0, bool SPLIT = false>
+// RAG (AFF = 0 only): the real half `hr` is narrower than H, in whole float4 groups (dim = 2 hr, a multiple of 8): a lane's
+// groups at or beyond hr are dead -- loaded as zeros from group 0's address, not stored, their log-derivatives not
+// counted; the index tables leave their weights out.
+template <int H, int NH, int K, bool INV, int AFF = 0, bool SPLIT = false, bool RAG = false>
 #ifdef MNF_NSF_WPE
 __global__ void __launch_bounds__(kNsfWaves * 64, MNF_NSF_WPE)
 #else
@@ -486,12 +493,13 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
                 int accumulate,
                 const float* __restrict__ aff_image, float ld_const, const float* __restrict__ scale_shift,
                 float* __restrict__ mid1, float* __restrict__ mid2, float* __restrict__ log_prob,
-                double* __restrict__ log_prob_sum) {
+                double* __restrict__ log_prob_sum, int hr) {
   using S_ = NsfShape<H, NH, K>;
-  constexpr int G = S_::G, dim = 2 * H;
-  static_assert(G >= 1, "");
-  constexpr int AFF_FLOATS = AFF ? dim * dim + dim : 0;
-  constexpr int SS_FLOATS = AFF ? 2 * dim : 0;  // ActNorm's exp(s) and t, for the block's intermediate tensors
+  constexpr int G = S_::G;
+  static_assert(G >= 1 && !(RAG && AFF), "");
+  const int dim = RAG ? 2 * hr : 2 * H, up_off = RAG ? hr : H;  // (compile-time constants without RAG)
+  constexpr int AFF_FLOATS = AFF ? 2 * H * 2 * H + 2 * H : 0;
+  constexpr int SS_FLOATS = AFF ? 2 * 2 * H : 0;  // ActNorm's exp(s) and t, for the block's intermediate tensors
   using SS_ = NsfSplitShape<H, NH, K>;
   constexpr int NET_IMAGE = SPLIT ? SS_::IMAGE_WORDS : S_::IMAGE_FLOATS;  // words of LDS for the conditioner nets
   __shared__ __attribute__((aligned(16))) float lds[NET_IMAGE + AFF_FLOATS + SS_FLOATS];
@@ -515,14 +523,30 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   // split image: [f1 operands][f2 operands][f1 biases][f2 biases][tail: max |weight|]
   const uint32_t* sw = reinterpret_cast<const uint32_t*>(lds);
   const float wmax = SPLIT ? lds[SS_::SPLIT_WORDS + SS_::PLAIN_WORDS] : 0.f;
+  // this lane's float4 groups that exist
+  unsigned live_mask = ~0u;
+  int g_off[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const bool lv = !RAG || 16 * g + 4 * q < hr;
+    if (!lv) live_mask &= ~(1u << g);
+    g_off[g] = lv ? 16 * g + 4 * q : 0;
+  }
   auto half_step = [&](auto inv_tag, int net, const f32x4 (&cond)[G], f32x4 (&act)[G]) -> float {
     constexpr bool kInv = decltype(inv_tag)::value;
+    float lad;
     if constexpr (SPLIT)
-      return nsf_half_step_guarded<H, NH, K, kInv>(sw + net * SS_::SPLIT_WORDS_NET,
-                                                   lds + SS_::SPLIT_WORDS + net * SS_::PLAIN_WORDS_NET,
-                                                   image + net * S_::NET_FLOATS, wmax, lane, q, cond, act, T);
+      lad = nsf_half_step_guarded<H, NH, K, kInv>(sw + net * SS_::SPLIT_WORDS_NET,
+                                                  lds + SS_::SPLIT_WORDS + net * SS_::PLAIN_WORDS_NET,
+                                                  image + net * S_::NET_FLOATS, wmax, lane, q, cond, act, T, live_mask);
     else
-      return nsf_half_step<H, NH, K, kInv>(net ? f2 : f1, lane, q, cond, act, T);
+      lad = nsf_half_step<H, NH, K, kInv>(net ? f2 : f1, lane, q, cond, act, T, live_mask);
+    if constexpr (RAG) {  // (a dead element's spline output is f(0) of an all-zero parameter set: keep it at exactly 0)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (!((live_mask >> g) & 1)) act[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return lad;
   };
 
   double lp_acc = 0.0;
@@ -538,11 +562,11 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
   auto request_tile = [&](int t) {
     const int64_t rw = (int64_t)(t < n_tiles ? t : n_tiles - 1) * 16 + j;
     const int64_t rc = rw < rows ? rw : rows - 1;
-    const float* xr = x + rc * dim + 4 * q;
+    const float* xr = x + rc * dim;
 #pragma unroll
-    for (int g = 0; g < G; ++g) n_lo[g] = *reinterpret_cast<const f32x4*>(xr + 16 * g);
+    for (int g = 0; g < G; ++g) n_lo[g] = *reinterpret_cast<const f32x4*>(xr + g_off[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) n_up[g] = *reinterpret_cast<const f32x4*>(xr + H + 16 * g);
+    for (int g = 0; g < G; ++g) n_up[g] = *reinterpret_cast<const f32x4*>(xr + up_off + g_off[g]);
     n_ld = ld_or_x[rc];
   };
   if (n_tiles > 0) request_tile(tile0);
@@ -550,10 +574,14 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
     const int64_t row = (int64_t)tile * 16 + j;
     const bool live = row < rows;
     const int64_t rowc = live ? row : rows - 1;
-    float* yr = y + rowc * dim + 4 * q;
+    float* yr = y + rowc * dim;
     f32x4 lo[G], up[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) lo[g] = n_lo[g], up[g] = n_up[g];
+    for (int g = 0; g < G; ++g) {
+      const bool lv = (live_mask >> g) & 1;
+      lo[g] = lv ? n_lo[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+      up[g] = lv ? n_up[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float ld_before = n_ld;
     request_tile(tile + tile_step);
     float ld;
@@ -605,9 +633,11 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
       if (mid2) store_actnorm_of(mid2);
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + 16 * g) = lo[g];
+    for (int g = 0; g < G; ++g)
+      if (!RAG || ((live_mask >> g) & 1)) *reinterpret_cast<f32x4*>(yr + g_off[g]) = lo[g];
 #pragma unroll
-    for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(yr + H + 16 * g) = up[g];
+    for (int g = 0; g < G; ++g)
+      if (!RAG || ((live_mask >> g) & 1)) *reinterpret_cast<f32x4*>(yr + up_off + g_off[g]) = up[g];
     if (log_det) {
       ld = sum_over_q(ld) + ld_const;
       if (accumulate) ld += ld_before;
@@ -634,13 +664,14 @@ nsf_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, float* __res
 }
 
 // ---------------------------------------------------------------- host: image index table
+// hr: the real half width (<= H, whole float4 groups): features and elements at or beyond it have no weights
 template <int H, int NH, int K>
-static void build_index(int32_t* idx, const int* widths = nullptr) {
+static void build_index(int32_t* idx, const int* widths = nullptr, int hr = H) {
   using S_ = NsfShape<H, NH, K>;
   constexpr int QH = S_::QH, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
   // real widths of the three hidden layers (<= NH; the other units are structural zeros: LeakyReLU(0) = 0)
   const int w[3] = {widths ? widths[0] : NH, widths ? widths[1] : NH, widths ? widths[2] : NH};
-  int sizes[5] = {H, w[0], w[1], w[2], P * H};
+  int sizes[5] = {hr, w[0], w[1], w[2], P * hr};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -659,7 +690,7 @@ static void build_index(int32_t* idx, const int* widths = nullptr) {
       for (int m = 0; m < NTH; ++m) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = unit_of(m, i);
-          if (u < w[0]) put(lane, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
+          if (u < w[0] && 16 * g + 4 * kq + e < hr) put(lane, net[nn].w_off[0] + u * hr + 16 * g + 4 * kq + e);
         }
         ++n;
       }
@@ -681,7 +712,7 @@ static void build_index(int32_t* idx, const int* widths = nullptr) {
       // accumulator row i = 4 q' + r of tile (s, kb): element 16 (s/4) + 4 q' + (s%4), parameter 4 kb + r
       auto out_of = [&](int kb, int i) {
         const int elem = 16 * (s >> 2) + 4 * (i >> 2) + (s & 3), prm = 4 * kb + (i & 3);
-        return prm < P ? elem * P + prm : -1;
+        return prm < P && elem < hr ? elem * P + prm : -1;
       };
       for (int kb = 0; kb < NB; ++kb, ++bt)
         for (int i = 0; i < 16; ++i)
@@ -700,11 +731,11 @@ static void build_index(int32_t* idx, const int* widths = nullptr) {
 
 // 2 entries per split word (low half, high half), then 1 entry per plain (bias) word -- mnf_pack_gather_split
 template <int H, int NH, int K>
-static void build_split_index(int32_t* idx, const int* widths = nullptr) {
+static void build_split_index(int32_t* idx, const int* widths = nullptr, int hr = H) {
   using S_ = NsfSplitShape<H, NH, K>;
   constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S, P = S_::P;
   const int w[3] = {widths ? widths[0] : NH, widths ? widths[1] : NH, widths ? widths[2] : NH};  // real widths <= NH
-  int sizes[5] = {H, w[0], w[1], w[2], P * H};
+  int sizes[5] = {hr, w[0], w[1], w[2], P * hr};
   NetDesc net[2];
   int64_t off = fill_net(net[0], 5, sizes, 0);
   fill_net(net[1], 5, sizes, off);
@@ -727,7 +758,8 @@ static void build_split_index(int32_t* idx, const int* widths = nullptr) {
         for (int lane = 0; lane < 64; ++lane) {
           const int i = lane & 15, kq = lane >> 4, u = 16 * m + i;
           if (u >= w[0]) continue;
-          for (int e = 0; e < 4; ++e) put(lane, e, net[nn].w_off[0] + u * H + 16 * g + 4 * kq + e);
+          for (int e = 0; e < 4; ++e)
+            if (16 * g + 4 * kq + e < hr) put(lane, e, net[nn].w_off[0] + u * hr + 16 * g + 4 * kq + e);
         }
     for (int l = 1; l <= 2; ++l) {
       for (int m = 0; m < NTH; ++m, ++bt)
@@ -748,7 +780,7 @@ static void build_split_index(int32_t* idx, const int* widths = nullptr) {
       // accumulator row i = 4 q' + r of tile (s, kb): element 16 (s/4) + 4 q' + (s%4), parameter 4 kb + r
       auto out_of = [&](int kb, int i) {
         const int elem = 16 * (s >> 2) + 4 * (i >> 2) + (s & 3), prm = 4 * kb + (i & 3);
-        return prm < P ? elem * P + prm : -1;
+        return prm < P && elem < hr ? elem * P + prm : -1;
       };
       for (int kb = 0; kb < NB; ++kb, ++bt)
         for (int i = 0; i < 16; ++i)
@@ -772,7 +804,7 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
                   const uint32_t* simage, int64_t rows, float T, int inverse, hipStream_t stream,
                   const float* aff = nullptr, float ld_const = 0.f, const float* scale_shift = nullptr,
                   float* mid1 = nullptr, float* mid2 = nullptr, float* log_prob = nullptr,
-                  double* log_prob_sum = nullptr) {
+                  double* log_prob_sum = nullptr, int hr = H) {
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
   auto resident_of = [](auto kernel, int dev) {
@@ -786,10 +818,19 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
              : memo_f32.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>, dev); });
   if (blocks > resident) blocks = resident;
   const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
-#define MNF_NSF_LAUNCH(INVV, AFFV, SPL)                                                                          \
-  hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, INVV, AFFV, SPL>), grid, block, 0, stream, x, y, log_det, image, \
-                     simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2, log_prob, log_prob_sum)
-  if (simage) {
+#define MNF_NSF_LAUNCH_R(INVV, AFFV, SPL, RAGV)                                                                        \
+  hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, INVV, AFFV, SPL, RAGV>), grid, block, 0, stream, x, y, log_det, image, \
+                     simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2, log_prob, log_prob_sum, hr)
+#define MNF_NSF_LAUNCH(INVV, AFFV, SPL) MNF_NSF_LAUNCH_R(INVV, AFFV, SPL, false)
+  tag_kernel(simage ? (aff ? "nsf_block_split" : "nsf_mfma_split") : (aff ? "nsf_block_fp32" : "nsf_mfma_fp32"));
+  if (hr != H) {  // a half narrower than the tile (plain layer only)
+    if (aff) return MNF_ERR_UNSUPPORTED;
+    if (simage) {
+      if (inverse) MNF_NSF_LAUNCH_R(true, 0, true, true); else MNF_NSF_LAUNCH_R(false, 0, true, true);
+    } else {
+      if (inverse) MNF_NSF_LAUNCH_R(true, 0, false, true); else MNF_NSF_LAUNCH_R(false, 0, false, true);
+    }
+  } else if (simage) {
     if (aff) {
       if (inverse) MNF_NSF_LAUNCH(true, 2, true); else MNF_NSF_LAUNCH(false, 1, true);
     } else {
@@ -801,13 +842,14 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
     if (inverse) MNF_NSF_LAUNCH(true, 0, false); else MNF_NSF_LAUNCH(false, 0, false);
   }
 #undef MNF_NSF_LAUNCH
+#undef MNF_NSF_LAUNCH_R
   return check_launch();
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5)
+#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5)
 // ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (the affine image must be one the Glow
-// MFMA kernel supports: dim 32 and 64 are; (32, 16, 5) is not instantiated)
+// MFMA kernel supports: dim 32 and 64 are)
 #define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)
 
 // three hidden layers of at most 16 units: nh = the width the kernels run them at (8 or 16; narrower layers get
@@ -823,6 +865,12 @@ static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
   return nh != 0;
 }
 
+// half width the plain-layer kernels run dim at: 16 or 32, the real half narrower in whole float4 groups (0: none)
+static int nsf_padded_half(int dim) {
+  if (dim < 8 || (dim & 7) || dim > 64) return 0;
+  return dim / 2 <= 16 ? 16 : 32;
+}
+
 int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, const float* image,
                     const void* split_image, int64_t rows, int dim, int K, float tail_bound, int inverse,
                     int n_hidden, const int* hidden, hipStream_t stream) {
@@ -831,10 +879,12 @@ int nsf_mfma_launch(const float* x, float* y, float* log_det, int accumulate, co
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image) |
        reinterpret_cast<uintptr_t>(split_image)) & 15)
     return MNF_ERR_UNSUPPORTED;
+  const int hp = nsf_padded_half(dim);
 #define X(HH, NHH, KK) \
-  if (dim == 2 * HH && nh == NHH && K == KK) \
+  if (hp == HH && nh == NHH && K == KK) \
     return launch<HH, NHH, KK>(x, y, log_det, accumulate, image, static_cast<const uint32_t*>(split_image), rows, \
-                               tail_bound, inverse != 0, stream);
+                               tail_bound, inverse != 0, stream, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr,   \
+                               nullptr, dim / 2);
   MNF_NSF_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;
@@ -888,8 +938,9 @@ int mnf_nsf_cl_split_layout(int dim, int K, int n_hidden, const int* hidden, int
   int nh = 0;
   if (!n_split_words || !n_plain_words || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
+  const int hp = mnf::nsf_padded_half(dim);
 #define X(HH, NHH, KK)                                                   \
-  if (dim == 2 * HH && nh == NHH && K == KK) {                           \
+  if (hp == HH && nh == NHH && K == KK) {                                \
     *n_split_words = mnf::NsfSplitShape<HH, NHH, KK>::SPLIT_WORDS;       \
     *n_plain_words = mnf::NsfSplitShape<HH, NHH, KK>::PLAIN_WORDS;       \
     return MNF_OK;                                                       \
@@ -903,10 +954,11 @@ int mnf_nsf_cl_split_index(int dim, int K, int n_hidden, const int* hidden, int3
   int nh = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
-#define X(HH, NHH, KK)                                     \
-  if (dim == 2 * HH && nh == NHH && K == KK) {             \
-    mnf::build_split_index<HH, NHH, KK>(idx_host, hidden); \
-    return MNF_OK;                                         \
+  const int hp = mnf::nsf_padded_half(dim);
+#define X(HH, NHH, KK)                                              \
+  if (hp == HH && nh == NHH && K == KK) {                           \
+    mnf::build_split_index<HH, NHH, KK>(idx_host, hidden, dim / 2); \
+    return MNF_OK;                                                  \
   }
   MNF_NSF_SHAPES(X)
 #undef X
@@ -916,8 +968,9 @@ int mnf_nsf_cl_split_index(int dim, int K, int n_hidden, const int* hidden, int3
 int64_t mnf_nsf_cl_image_floats(int dim, int K, int n_hidden, const int* hidden) {
   int nh = 0;
   if (!mnf::hidden_ok(n_hidden, hidden) || !mnf::uniform_hidden3(n_hidden, hidden, nh)) return 0;
+  const int hp = mnf::nsf_padded_half(dim);
 #define X(HH, NHH, KK) \
-  if (dim == 2 * HH && nh == NHH && K == KK) return mnf::NsfShape<HH, NHH, KK>::IMAGE_FLOATS;
+  if (hp == HH && nh == NHH && K == KK) return mnf::NsfShape<HH, NHH, KK>::IMAGE_FLOATS;
   MNF_NSF_SHAPES(X)
 #undef X
   return 0;
@@ -927,10 +980,11 @@ int mnf_nsf_cl_image_index(int dim, int K, int n_hidden, const int* hidden, int3
   int nh = 0;
   if (!idx_host || !mnf::hidden_ok(n_hidden, hidden)) return MNF_ERR_INVALID_ARG;
   if (!mnf::uniform_hidden3(n_hidden, hidden, nh)) return MNF_ERR_UNSUPPORTED;
-#define X(HH, NHH, KK)                            \
-  if (dim == 2 * HH && nh == NHH && K == KK) {    \
-    mnf::build_index<HH, NHH, KK>(idx_host, hidden); \
-    return MNF_OK;                                \
+  const int hp = mnf::nsf_padded_half(dim);
+#define X(HH, NHH, KK)                                        \
+  if (hp == HH && nh == NHH && K == KK) {                     \
+    mnf::build_index<HH, NHH, KK>(idx_host, hidden, dim / 2); \
+    return MNF_OK;                                            \
   }
   MNF_NSF_SHAPES(X)
 #undef X

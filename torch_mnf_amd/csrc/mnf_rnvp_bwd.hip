@@ -1073,6 +1073,7 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
   if (phases & 1) {
   if (int rc = zero_word_async(list, stream)) return rc;
+  tag_kernel("rnvp_bwd_mfma");
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), a_lds_bytes, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail,
                      y_in);

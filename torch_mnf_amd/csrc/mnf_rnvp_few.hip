@@ -480,6 +480,7 @@ int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float*
         return few_attr(rnvp_few_fwd_kernel<1>) > 0 && few_attr(rnvp_few_fwd_kernel<2>) > 0 ? 1 : -1;
       }) < 0)
     return MNF_ERR_LAUNCH;
+  tag_kernel("rnvp_few");
   switch (R) {
     case 1: hipLaunchKernelGGL(rnvp_few_fwd_kernel<1>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
     default: hipLaunchKernelGGL(rnvp_few_fwd_kernel<2>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
@@ -515,6 +516,7 @@ int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const 
         return few_attr(rnvp_few_bwd_kernel<1>) > 0 && few_attr(rnvp_few_bwd_kernel<2>) > 0 ? 1 : -1;
       }) < 0)
     return MNF_ERR_LAUNCH;
+  tag_kernel("rnvp_bwd_few");
   switch (R) {
     case 1: hipLaunchKernelGGL(rnvp_few_bwd_kernel<1>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;
     default: hipLaunchKernelGGL(rnvp_few_bwd_kernel<2>, dim3(grid), dim3(kFewThreads), lds, stream, a); break;

@@ -410,6 +410,7 @@ static int launch_rnvp_split_occ(const float* z, const float* mask, float* x, fl
   const int resident0 = mask ? resident_mask : resident_seed;
   const int resident = resident0 < cap ? resident0 : cap;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
+  tag_kernel("rnvp_split");
   if (mask)
     hipLaunchKernelGGL((rnvp_split_kernel<HN, false, RAG, OCC>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream,
                        z, mask, x, log_det, simage, image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
@@ -496,6 +497,7 @@ static int launch_rnvp(const float* z, const float* mask, float* x, float* log_d
       [](int dev) { return resident_by_occupancy(rnvp_mfma_kernel<HN, true, RAG>, kRnvpWaves * 64, dev, 1); });
   const int resident = mask ? resident_mask : resident_seed;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
+  tag_kernel("rnvp_mfma_fp32");
   if (mask)
     hipLaunchKernelGGL((rnvp_mfma_kernel<HN, false, RAG>), dim3((unsigned)blocks), dim3(kRnvpWaves * 64), 0, stream, z,
                        mask, x, log_det, image, rows, dim, accumulate, seed, dm, vec);

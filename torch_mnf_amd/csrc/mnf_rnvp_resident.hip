@@ -520,6 +520,7 @@ static int launch_resident(const float* z, float* x, float* log_det, int accumul
   const int64_t n_groups = (rows + 16 * kResWaves - 1) / (16 * kResWaves);
   const int64_t blocks = n_groups < cus ? n_groups : cus;  // one persistent workgroup per CU
   if ((n_groups + blocks - 1) / (blocks > 0 ? blocks : 1) > 32 * kResColdWords) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("rnvp_resident");
   hipLaunchKernelGGL((rnvp_resident_kernel<HN, G, SAMPLE>), dim3((unsigned)blocks), dim3(kResWaves * 64), lds_bytes,
                      stream, z, x, log_det, simage, image, rows, accumulate, seed, q0_mean, q0_log_var, y_out);
   return check_launch();

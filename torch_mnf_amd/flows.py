@@ -346,6 +346,8 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, rows, f.dim,
             int(bool(f.parity)), int(inverse), *hid, int(f.scale), int(f.shift), _stream())
     _lib.check("mnf_affine_half_bwd", rc)
+    if not f.force_generic:
+        _lib.note_generic("AffineHalfFlow.backward", rows, f"dim={f.dim}, hidden={f.h_sizes}")
     return True
 
 
@@ -403,6 +405,8 @@ class _NsfFn(torch.autograd.Function):
             x.shape[0], module.dim,
             module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
             int(module.force_generic), _stream()))
+        if not module.force_generic:
+            _lib.note_generic("NSF_CL", x.shape[0], f"dim={module.dim}, K={module.K}, hidden={module.h_sizes}")
         ctx.module, ctx.inverse = module, inverse
         # (y too: the tile gradient kernel reads the second net's conditioner input out of it instead of recomputing the
         #  first half-step; the next layer keeps its input alive anyway)
@@ -454,6 +458,8 @@ class _NsfFn(torch.autograd.Function):
             return grad_x, grad_flat, None, None
         _lib.check("mnf_nsf_cl_bwd", lib.mnf_nsf_cl_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
+        if not m.force_generic and _NSF_BWD_KERNEL != "generic":
+            _lib.note_generic("NSF_CL.backward", rows, f"dim={m.dim}, K={m.K}, hidden={m.h_sizes}")
         return grad_x, grad_flat, None, None
 
 
@@ -1048,6 +1054,8 @@ class AffineHalfFlow(_TwoWayFlow):
             _ptr(flat), _ptr(image), _ptr(split), x.shape[0], self.dim, int(bool(self.parity)),
             int(inverse), len(self.h_sizes),
             self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
+        if not self.force_generic:
+            _lib.note_generic("AffineHalfFlow", x.shape[0], f"dim={self.dim}, hidden={self.h_sizes}")
         return y, (None if accum is not None else ld)
 
     def emits_sqnorm(self, device) -> bool:
@@ -1145,6 +1153,8 @@ class NSF_CL(_TwoWayFlow):
             _ptr(split),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
             int(self.force_generic), _stream()))
+        if not self.force_generic:
+            _lib.note_generic("NSF_CL", x.shape[0], f"dim={self.dim}, K={self.K}, hidden={self.h_sizes}")
         return y, (None if accum is not None else ld)
 
 
@@ -1408,6 +1418,8 @@ class RNVP(_HipFlow):
             z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
             int(accum is not None), _ptr(flat), _ptr(image), _ptr(split), z.shape[0], self.dim,
             len(self.h_sizes), self._hid, int(self.force_generic), _stream()))
+        if not self.force_generic:
+            _lib.note_generic("RNVP", z.shape[0], f"dim={self.dim}, hidden={self.h_sizes}")
         return x, (None if accum is not None else ld)
 
     def forward(self, z: Tensor, mask: Tensor | None = None, seed: int | None = None) -> tuple[Tensor, Tensor]:
