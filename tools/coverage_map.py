@@ -33,6 +33,19 @@ def timed(fn, reps=3):
 
 
 def probe(layer, dim, call):
+    """(forward kernel, ns/row, gradient kernel, fwd+bwd ns/row) on the default path, and the same two times with the layer
+    forced onto the any-shape kernels when the default path is not one of them (the cliff AT this shape)."""
+    fast = probe_once(layer, dim, call)
+    gen = (None, None)
+    if "generic" not in fast[0] or "generic" not in fast[2]:
+        layer.force_generic = True
+        g = probe_once(layer, dim, call)
+        layer.force_generic = False
+        gen = (g[1], g[3])
+    return (*fast, *gen)
+
+
+def probe_once(layer, dim, call):
     layer = layer.to(DEV)
     x = torch.randn(ROWS, dim, device=DEV)
 
@@ -59,7 +72,8 @@ def main():
     torch.manual_seed(0)
     print(f"# rows per call: {ROWS}; ns per row = best of 3 launches (HIP events); 'fwd+bwd' = forward with the autograd link, "
           "sum() of both outputs, backward")
-    print("# kernel = torch_mnf_amd.last_kernel() after the call (the gradient pass's name is its last launch's family)")
+    print("# kernel = torch_mnf_amd.last_kernel() after the call; 'generic' = the same call with force_generic (the any-shape "
+          "kernels), x = generic / default")
     rows = []
     for dim in (2, 8, 32, 64, 128, 256, 512):
         for hs in ((24, 24, 24), (16, 16, 16), (32, 32, 32), (64, 64, 64), (24, 24)):
@@ -74,22 +88,25 @@ def main():
         for h in (50, 30, 64):
             f = amd.RNVP(dim, h_sizes=(h,))
             rows.append(("RNVP", f"dim={dim} hidden=({h},)", dim, *probe(f, dim, lambda m, x: m.forward(x, seed=3))))
-    # ns per row per dim, and the factor against the best matrix-core shape of the same layer type
-    best = {}
-    for layer, _, dim, kf, tf, kb, tb in rows:
-        if "generic" not in kf:
-            best[(layer, "f")] = min(best.get((layer, "f"), 1e30), tf / dim)
-        if "generic" not in kb:
-            best[(layer, "b")] = min(best.get((layer, "b"), 1e30), tb / dim)
-    print(f"{'layer':16s} {'shape':32s} {'forward kernel':18s} {'ns/row':>9s} {'x best/dim':>10s}   {'fwd+bwd kernel':20s} "
-          f"{'ns/row':>9s} {'x best/dim':>10s}")
-    for layer, shape, dim, kf, tf, kb, tb in rows:
-        print(f"{layer:16s} {shape:32s} {kf:18s} {tf:9.2f} {tf / dim / best[(layer, 'f')]:10.1f}   {kb:20s} {tb:9.2f} "
-              f"{tb / dim / best[(layer, 'b')]:10.1f}")
-    worst = sorted(((tb / dim / best[(layer, 'b')], layer, shape, kb) for layer, shape, dim, kf, tf, kb, tb in rows), reverse=True)
-    print("\n# the worst cliffs (fwd+bwd ns per row per dim against the layer type's best matrix-core shape):")
-    for fac, layer, shape, kb in worst[:6]:
-        print(f"#   {fac:6.1f} x  {layer} {shape} -> {kb}")
+    print(f"{'layer':15s} {'shape':30s} {'forward kernel':16s} {'ns/row':>8s} {'generic':>8s} {'x':>6s}   {'gradient kernel':20s} "
+          f"{'fwd+bwd':>8s} {'generic':>8s} {'x':>6s}")
+    cliffs = []
+    for layer, shape, dim, kf, tf, kb, tb, gf, gb in rows:
+        xf = f"{gf / tf:6.1f}" if gf else "     -"
+        xb = f"{gb / tb:6.1f}" if gb else "     -"
+        gfs = f"{gf:8.2f}" if gf else "       -"
+        gbs = f"{gb:8.2f}" if gb else "       -"
+        print(f"{layer:15s} {shape:30s} {kf:16s} {tf:8.2f} {gfs} {xf}   {kb:20s} {tb:8.2f} {gbs} {xb}")
+        if gb:
+            cliffs.append((gb / tb, layer, shape, kb))
+    cliffs.sort(reverse=True)
+    print("\n# the largest cliffs (forward + backward: the any-shape kernels against the matrix-core ones AT the same shape):")
+    for fac, layer, shape, kb in cliffs[:6]:
+        print(f"#   {fac:6.1f} x  {layer} {shape}  ({kb})")
+    slow = sorted(((tb, layer, shape) for layer, shape, dim, kf, tf, kb, tb, gf, gb in rows if "generic" in kb), reverse=True)
+    print("# shapes WITHOUT a matrix-core gradient kernel, slowest first (ns per row, forward + backward):")
+    for tb, layer, shape in slow[:8]:
+        print(f"#   {tb:9.1f}  {layer} {shape}")
 
 
 if __name__ == "__main__":

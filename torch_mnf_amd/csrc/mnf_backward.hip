@@ -1062,7 +1062,7 @@ int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, co
   a.R = R;
   const int64_t blocks = list ? 256 : (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
-  tag_kernel("rnvp_bwd_generic");
+  if (!list) tag_kernel("rnvp_bwd_generic");  // (as the matrix-core pass's fix-up it keeps that pass's name)
   hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      stream, a);
   return check_launch();
