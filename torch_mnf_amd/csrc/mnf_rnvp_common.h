@@ -34,19 +34,33 @@ struct RnvpShape {
 // gate = 1 and log gate = 0 there: nothing reaches log_det).  Loads return 0 past the row end, stores skip it;
 // `vec`: dm % 4 == 0 and 16-byte aligned bases keep the 16-byte access, else element by element.
 // (`rowq` = row start + 4 q, the lane's own float4 column inside a 16-dim group; `col` = 16 g; `q4` = 4 q)
+// Ragged rows (RAG: dm is not a multiple of 16): the loads are UNCONDITIONAL -- a piece past the row's end reads the
+// row's first piece instead and is zeroed by a select (round 5: as `if (in range) load` every piece was a load under a
+// branch, behind which hipcc's wait counts fall back to vmcnt(0): at d = 50 a wave spent 55 % of its time waiting).
+// vec: rows and dm multiples of 4 floats (one 16-byte piece); else, dm even (rows 8-byte aligned): two 8-byte pieces;
+// else four dwords.
+typedef float f32x2_row __attribute__((ext_vector_type(2)));
 template <bool RAG>
 __device__ __forceinline__ f32x4 row_load4(const float* rowq, int col, int q4, int dm, bool vec) {
   if (!RAG) return *reinterpret_cast<const f32x4*>(rowq + col);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const float* row0 = rowq - q4;  // the row's first element: always readable
   if (vec) {
-    if (col + q4 < dm) v = *reinterpret_cast<const f32x4*>(rowq + col);
-  } else {
+    const bool ok = col + q4 < dm;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? rowq + col : row0);
+    return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if ((dm & 1) == 0 && (reinterpret_cast<uintptr_t>(row0) & 7) == 0) {
+    const bool ok0 = col + q4 < dm, ok1 = col + q4 + 2 < dm;
+    const f32x2_row a = *reinterpret_cast<const f32x2_row*>(ok0 ? rowq + col : row0);
+    const f32x2_row b = *reinterpret_cast<const f32x2_row*>(ok1 ? rowq + col + 2 : row0);
+    return f32x4{ok0 ? a[0] : 0.f, ok0 ? a[1] : 0.f, ok1 ? b[0] : 0.f, ok1 ? b[1] : 0.f};
+  }
+  f32x4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float e = 0.f;
-      if (col + q4 + r < dm) e = rowq[col + r];
-      v[r] = e;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = col + q4 + r < dm;
+    const float e = *(ok ? rowq + col + r : row0);
+    v[r] = ok ? e : 0.f;
   }
   return v;
 }
@@ -56,6 +70,9 @@ __device__ __forceinline__ void row_store4(float* rowq, int col, int q4, int dm,
     *reinterpret_cast<f32x4*>(rowq + col) = v;
   } else if (vec) {
     if (col + q4 < dm) *reinterpret_cast<f32x4*>(rowq + col) = v;
+  } else if ((dm & 1) == 0 && (reinterpret_cast<uintptr_t>(rowq - q4) & 7) == 0) {
+    if (col + q4 < dm) *reinterpret_cast<f32x2_row*>(rowq + col) = f32x2_row{v[0], v[1]};
+    if (col + q4 + 2 < dm) *reinterpret_cast<f32x2_row*>(rowq + col + 2) = f32x2_row{v[2], v[3]};
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -86,7 +103,9 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
                                                float* __restrict__ x, float* __restrict__ log_det,
                                                const float* __restrict__ image, int64_t rows, int d, int accumulate,
                                                uint64_t seed, const float* zprm = nullptr, int dm_ragged = 0,
-                                               bool vec = true) {
+                                               bool vec = true, bool enable = true) {
+  // enable (wave-uniform): false = this wave's 16 rows take part in the group's staging but store nothing (the narrow
+  // kernel's fix-up: one tile of the group is redone)
   const int dm = RAG ? dm_ragged : d;  // row width in memory
   using S = RnvpShape<HN, WAVES>;
   constexpr int KQ = S::KQ, YT = S::YT, KC = kRnvpChunkK, MC = kRnvpChunkM;
@@ -118,8 +137,8 @@ __device__ __forceinline__ void rnvp_group_f32(float (&lds)[2][RnvpShape<HN>::CH
 
   {
     const int64_t row = (int64_t)grp * (16 * WAVES) + wave * 16 + j;
-    const bool live = row < rows;
-    const int64_t rowc = live ? row : rows - 1;
+    const bool live = row < rows && enable;
+    const int64_t rowc = row < rows ? row : rows - 1;
     const float* zr = z + rowc * dm + 4 * q;
     const float* mr = SEEDED ? nullptr : mask + rowc * dm + 4 * q;
     float* xr = x + rowc * dm + 4 * q;

@@ -59,7 +59,10 @@ constexpr int kRnvpMaxPrologueDim = 1024;  // fused sample_z prologue: mean and 
 
 
 // returns false (block-uniform) when the group has to be recomputed on the fp32 path
-template <int HN, bool SEEDED, bool RAG>
+// RES (round 5): the WHOLE operand image is resident in LDS (lds0; narrow layers: d <= 128 is <= 96 KB) -- no operand
+// staging, no per-chunk barriers.  At d = 50 the streamed form moved 48 KB of operands from L2 through eight barriers
+// for every 25 KB of rows (128 rows per workgroup trip): 123 us per launch at 256,000 rows with nothing saturated.
+template <int HN, bool SEEDED, bool RAG, bool RES = false>
 __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1, int grp, const float* __restrict__ z,
                                                  const float* __restrict__ mask, float* __restrict__ x,
                                                  float* __restrict__ log_det, const uint32_t* __restrict__ simage,
@@ -138,20 +141,34 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
   constexpr int D2 = SEEDED ? 3 : 1;  // GEMM 2: MC groups per set
   uint4 st[S::STAGE_U4];
   auto request_operands = [&](int c, int& n4) {
-    const uint4* src = chunk_src(c < nc ? c : nc - 1, n4);
+    if constexpr (RES) {
+      n4 = 0;
+    } else {
+      const uint4* src = chunk_src(c < nc ? c : nc - 1, n4);
 #pragma unroll
-    for (int i = 0; i < S::STAGE_U4; ++i) {
-      const int k = threadIdx.x + i * (kRnvpWaves * 64);
-      st[i] = src[k < n4 ? k : 0];
+      for (int i = 0; i < S::STAGE_U4; ++i) {
+        const int k = threadIdx.x + i * (kRnvpWaves * 64);
+        st[i] = src[k < n4 ? k : 0];
+      }
     }
   };
   auto hand_over = [&](uint32_t* buf, int n4) {
-    uint4* dst = reinterpret_cast<uint4*>(buf);
+    if constexpr (!RES) {
+      uint4* dst = reinterpret_cast<uint4*>(buf);
 #pragma unroll
-    for (int i = 0; i < S::STAGE_U4; ++i) {
-      const int k = threadIdx.x + i * (kRnvpWaves * 64);
-      if (k < n4) dst[k] = st[i];
+      for (int i = 0; i < S::STAGE_U4; ++i) {
+        const int k = threadIdx.x + i * (kRnvpWaves * 64);
+        if (k < n4) dst[k] = st[i];
+      }
     }
+  };
+  // the LDS words chunk c's operands start at
+  auto chunk_buf = [&](int c) -> const uint32_t* {
+    if constexpr (RES)
+      return c < nc1 ? lds0 + (int64_t)c * KC * S::KS1_WORDS
+                     : lds0 + S::part1_words(d) + (int64_t)(c - nc1) * MC * S::TILE2_WORDS;
+    else
+      return (c & 1) ? lds1 : lds0;
   };
   f32x4 z1[D1][2 * KC], m1[SEEDED ? 1 : D1][2 * KC];
   auto request_rows1 = [&](int c, int u) {
@@ -161,7 +178,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
       if (!SEEDED) m1[u][i] = mask4(row_group(c < nc1 ? c : nc1 - 1, i));
     }
   };
-  __syncthreads();  // the previous group's last chunk is fully consumed
+  if constexpr (!RES) __syncthreads();  // the previous group's last chunk is fully consumed
   {
     int n4;
 #pragma unroll
@@ -169,7 +186,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
     request_operands(0, n4);
     hand_over(lds0, n4);
   }
-  __syncthreads();
+  if constexpr (!RES) __syncthreads();
 
   auto split_mac = [&](const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& mn, f32x4& cr) {
     if (kRnvpAbl == 4 || kRnvpAbl == 6) {
@@ -209,7 +226,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
         int n4_next = 0;
         request_rows1(c + D1, u);
         request_operands(c + 1, n4_next);  // c + 1 == nc1: the first GEMM-2 chunk
-        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const uint32_t* buf = chunk_buf(c);
         const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;  // + 64 * operand
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
@@ -221,7 +238,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
         }
         hand_over((c & 1) ? lds0 : lds1, n4_next);
         // (LDS-only barrier: __syncthreads() would also wait -- vmcnt(0) -- for the row loads requested chunks ahead)
-        if (c < nc1 - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!RES && c < nc1 - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
   }
@@ -269,7 +286,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
           bt[mi] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 4 * q);
           bs[mi] = *reinterpret_cast<const f32x4*>(bias2 + (int64_t)m * 32 + 16 + 4 * q);
         }
-        const uint32_t* buf = (c & 1) ? lds1 : lds0;
+        const uint32_t* buf = chunk_buf(c);
         const f16x8* A8 = reinterpret_cast<const f16x8*>(buf) + lane;
 #pragma unroll
         for (int mi = 0; mi < MC; ++mi) {
@@ -322,7 +339,7 @@ __device__ __forceinline__ bool rnvp_group_split(uint32_t* lds0, uint32_t* lds1,
         }
         request_rows2(c + D2, u);
         hand_over((c & 1) ? lds0 : lds1, n4_next);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS-only, as above: the row stores stay in flight)
+        if (!RES) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS-only, as above: the row stores stay in flight)
       }
     }
   }
@@ -344,13 +361,199 @@ __device__ __attribute__((noinline)) void rnvp_group_f32_cold(float* lds, int gr
                                   log_det, image, rows, d, accumulate, seed, zprm, dm, vec);
 }
 
+// ================================================================================================
+// Narrow layers (d <= 64 after padding: MNFLinear(50, 10)'s flows, BASELINE configs[4]'s second layer): a LATENCY kernel.
+// The streamed kernel above gives a 128-row group to a workgroup and walks it chunk by chunk behind barriers -- built
+// for d = 800, where the operand image does not fit LDS.  At d = 50 the image is 48 KB and a row 200 bytes: there the
+// launch (123-131 us at 256,000 rows, nothing saturated: vector units 0.24, matrix pipe 0.06) was a chain of exposed
+// memory round trips per group with eight waves per CU to hide them.  Here the image is resident in LDS, SIXTEEN waves
+// per CU each own 16-row tiles outright -- no barrier in the tile loop, <= 128 registers: the row is 16 registers, no
+// prefetch rings --, and the latency of one wave's loads is covered by the other fifteen.  A tile whose operands leave
+// the split range is noted in LDS and redone on the fp32 body (rnvp_group_f32, stores enabled for that tile's wave
+// only) after the loop, with the image's LDS as its staging windows.
+// ================================================================================================
+constexpr int kNarrowWaves = 16;
+constexpr int kNarrowMaxTrips = 1024;  // tile-loop trips of a workgroup (one 16-bit cold mask each); more rows: the streamed kernel
+
+template <int HN, bool SEEDED>
+__global__ void __launch_bounds__(kNarrowWaves * 64, 1)
+rnvp_narrow_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
+                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
+                   int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
+                   const float* __restrict__ q0_log_var, int dm, int vec_ok) {
+  using S = RnvpSplitShape<HN>;
+  using F = RnvpShape<HN, kNarrowWaves>;
+  constexpr int YT = S::YT, NKS2 = S::NKS2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t img_lds[];  // the split image; later the fp32 body's windows
+  __shared__ __attribute__((aligned(16))) float zprm_lds[2 * 64];
+  // trip t of the tile loop = the 256-row group blockIdx.x + t gridDim.x, wave w its tile w: bit w of cold[t] = that tile
+  // left the split range
+  __shared__ uint32_t cold[kNarrowMaxTrips];
+  const bool vec = vec_ok != 0;
+  const int G = d / 16;  // <= 4
+  const float* zprm = nullptr;
+  if (q0_mean != nullptr) {  // fused sample_z prologue: z = q0_mean + sqrt(exp(q0_log_var)) eps (mnf_linear.py:59-62)
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      zprm_lds[i] = i < dm ? q0_mean[i] : 0.f;
+      zprm_lds[d + i] = i < dm ? sqrtf(expf(q0_log_var[i])) : 0.f;
+    }
+    zprm = zprm_lds;
+  }
+  for (int i = threadIdx.x; i < kNarrowMaxTrips; i += blockDim.x) cold[i] = 0u;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(simage);
+    uint4* dst = reinterpret_cast<uint4*>(img_lds);
+    for (int i = threadIdx.x; i < (int)(S::split_words(d) / 4); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
+  const bool split_ok = wmax <= kSplitWeightLimit;  // (false: every tile goes to the fp32 body below)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int n_ks1 = (G + 1) / 2;
+  const float* bias2 = reinterpret_cast<const float*>(simage + S::split_words(d));
+  const float* bias_y = bias2 + (int64_t)G * 32;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2 zero2 = u32x2{0u, 0u};
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  int a_off = lane * 4;
+  asm volatile("" : "+v"(a_off));  // keep the operand reads inside the tile loop
+  const f16x8* A1 = reinterpret_cast<const f16x8*>(img_lds + a_off);                        // + 64 * (2 (ks YT + m) + part)
+  const f16x8* A2 = reinterpret_cast<const f16x8*>(img_lds + a_off + S::part1_words(d));    // + 64 * (m TILE2 / 256 + ...)
+
+  const int64_t n_tiles = (rows + 15) >> 4;
+  const int64_t stride = (int64_t)gridDim.x * kNarrowWaves;
+  int trip = 0;
+  for (int64_t tile = (int64_t)blockIdx.x * kNarrowWaves + wave; split_ok && tile < n_tiles; tile += stride, ++trip) {
+    const int64_t row = tile * 16 + j;
+    const bool live = row < rows;
+    const int64_t rowc = live ? row : rows - 1;
+    const float* zr = z + rowc * dm + 4 * q;
+    float* xr = x + rowc * dm + 4 * q;
+    // the row (and the mask when it is an input): G float4 groups per lane, dims 16 g + 4 q .. + 3
+    f32x4 zz[4], mk[4];
+    i32x4 mb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < G) {
+        f32x4 v = row_load4<true>(zr, 16 * g, 4 * q, dm, vec);
+        if (zprm) {
+          const int dd = 16 * g + 4 * q;
+          v = v * *reinterpret_cast<const f32x4*>(zprm + d + dd) + *reinterpret_cast<const f32x4*>(zprm + dd);
+        }
+        zz[g] = v;
+        if (SEEDED) {
+          const int dd = 16 * g + 4 * q;
+          const int32_t w = (int32_t)(rnvp_mask_word(seed, rowc, dd >> 5) >> (dd & 31));
+          mb[g] = i32x4{(int32_t)__builtin_amdgcn_sbfe(w, 0, 1), (int32_t)__builtin_amdgcn_sbfe(w, 1, 1),
+                        (int32_t)__builtin_amdgcn_sbfe(w, 2, 1), (int32_t)__builtin_amdgcn_sbfe(w, 3, 1)};
+        } else {
+          mk[g] = row_load4<true>(mask + rowc * dm + 4 * q, 16 * g, 4 * q, dm, vec);
+        }
+      } else {
+        zz[g] = zero4;
+        mk[g] = zero4;
+        mb[g] = i32x4{0, 0, 0, 0};
+      }
+    }
+    // ---- GEMM 1: y^T = Wn (m z)^T + bn, two 16-dim groups per K = 32 step
+    float mx = 0.f;
+    u32x2 kh[4], kl[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 kept = SEEDED ? __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, zz[g]) & mb[g]) : mk[g] * zz[g];
+      split_tile(kept, kh[g], kl[g], mx);
+    }
+    f32x4 ym[YT], yc[YT];
+#pragma unroll
+    for (int m = 0; m < YT; ++m) {
+      ym[m] = *reinterpret_cast<const f32x4*>(bias_y + m * 16 + 4 * q);
+      yc[m] = zero4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < n_ks1) {
+        const f16x8 bh = pair_operand(kh[2 * ks], kh[2 * ks + 1]), bl = pair_operand(kl[2 * ks], kl[2 * ks + 1]);
+#pragma unroll
+        for (int m = 0; m < YT; ++m)
+          split_mac(A1[64 * (2 * (ks * YT + m))], A1[64 * (2 * (ks * YT + m) + 1)], bh, bl, ym[m], yc[m]);
+      }
+    }
+    u32x2 yh[YT], yl[YT];
+#pragma unroll
+    for (int m = 0; m < YT; ++m) split_tile(yc[m] * kSplitInvScale + ym[m], yh[m], yl[m], mx);
+    if (__builtin_expect(wave_any(!(mx <= kSplitLimit)), 0)) {  // nothing has been stored yet: the fp32 body redoes the tile
+      if (lane == 0) atomicOr(&cold[trip], 1u << wave);
+      continue;
+    }
+    // ---- GEMM 2 + gate, 16 output dims per tile
+    float ld = 0.f, ld2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m < G) {
+        const f16x8* T8 = A2 + 64 * (m * (S::TILE2_WORDS / 256));
+        f32x4 tm = zero4, tc = zero4, sm = zero4, sc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < NKS2; ++ks) {
+          const f16x8 bh = pair_operand(yh[2 * ks], 2 * ks + 1 < YT ? yh[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          const f16x8 bl = pair_operand(yl[2 * ks], 2 * ks + 1 < YT ? yl[2 * ks + 1 < YT ? 2 * ks + 1 : 0] : zero2);
+          split_mac(T8[64 * (2 * ks)], T8[64 * (2 * ks + 1)], bh, bl, tm, tc);
+          split_mac(T8[64 * (2 * (NKS2 + ks))], T8[64 * (2 * (NKS2 + ks) + 1)], bh, bl, sm, sc);
+        }
+        const f32x4 t4 = tc * kSplitInvScale + tm + *reinterpret_cast<const f32x4*>(bias2 + m * 32 + 4 * q);
+        const f32x4 s4 = sc * kSplitInvScale + sm + *reinterpret_cast<const f32x4*>(bias2 + m * 32 + 16 + 4 * q);
+        f32x4 o;
+        if (SEEDED) {
+          // binary mask: x = (1 - gate) t + (m ? z : gate z);  log_det -= (1 - m) ln(1 + e^-s)   (rnvp.py:36-37)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = zz[m][r];
+            const float den = 1.f + __builtin_amdgcn_exp2f(s4[r] * -1.44269504088896341f);
+            const float gate = __builtin_amdgcn_rcpf(den);
+            const int32_t mr_ = mb[m][r];
+            const float zsel = __builtin_bit_cast(float, (mr_ & __builtin_bit_cast(int32_t, v)) |
+                                                             (~mr_ & __builtin_bit_cast(int32_t, v * gate)));
+            o[r] = __builtin_fmaf(-gate, t4[r], t4[r]) + zsel;
+            ld2 += __builtin_bit_cast(float, ~mr_ & __builtin_bit_cast(int32_t, __builtin_amdgcn_logf(den)));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = zz[m][r], mm = mk[m][r];
+            const float gate = __builtin_amdgcn_rcpf(1.f + exp6r(-s4[r]));
+            o[r] = (((1.f - mm) * v) * gate + (1.f - gate) * t4[r]) + mm * v;                 // rnvp.py:37
+            ld += (1.f - mm) * (__builtin_amdgcn_logf(gate) * 0.693147180559945309f);          // :36
+          }
+        }
+        if (live) row_store4<true>(xr, 16 * m, 4 * q, dm, vec, o);
+      }
+    }
+    if (log_det) {
+      ld = sum_over_q(ld - 0.693147180559945309f * ld2);
+      if (live && q == 0) log_det[row] = accumulate ? log_det[row] + ld : ld;
+    }
+  }
+  // ---- tiles that left the split range (or every tile when the weights did): the fp32 body on the trip's 256-row group
+  // with this workgroup's 16 waves, stores enabled for the noted tiles' waves only
+  __syncthreads();
+  float(&win)[2][RnvpShape<HN>::CHUNK_FLOATS] = *reinterpret_cast<float(*)[2][RnvpShape<HN>::CHUNK_FLOATS]>(img_lds);
+  const int n_groups = (int)((rows + 16 * kNarrowWaves - 1) / (16 * kNarrowWaves));
+  int t = 0;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x, ++t) {
+    const uint32_t bits = split_ok ? cold[t] : 0xffffu;  // (block-uniform)
+    if (bits)
+      rnvp_group_f32<HN, SEEDED, true, kNarrowWaves>(win, grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm,
+                                                     dm, vec, ((bits >> wave) & 1u) != 0);
+  }
+}
+
 // OCC = waves per SIMD the register allocation aims at.  4 (<= 128 registers, two 8-wave workgroups per CU, 50-140
 // registers spilled) or 2 (no spills, one workgroup per CU), chosen per launch -- measured at 256,000 rows, seeded mask,
 // us per launch at OCC 4 / 2: ragged rows d = 50: 146 / 123, 96: 118 / 114, 200: 274 / 269, 400: 387 / 397, 799: 1,518 /
 // 1,250; whole 16-dim groups d = 64: 89 / 80, 128: 151 / 140, 256: 254 / 272, 512: 474 / 481, 784: 754 / 734, 800: 714 /
 // 777, 1,024: 919 / 1,471.  (The spills are scratch traffic: at d = 50 the launch moved 241 MB of writes for a 51 MB
 // output, `rocprofv3 --pmc WRITE_SIZE`.)  So: 2 for ragged rows and for d <= 128, else 4.
-template <int HN, bool SEEDED, bool RAG, int OCC>
+template <int HN, bool SEEDED, bool RAG, int OCC, bool RES = false>
 __global__ void __launch_bounds__(kRnvpWaves * 64, OCC)
 rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ x,
                   float* __restrict__ log_det, const uint32_t* __restrict__ simage, const float* __restrict__ image,
@@ -376,12 +579,20 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
   // weights outside the f16 range (flagged by the pack kernel): every group on the fp32 path
   const float wmax = __builtin_bit_cast(float, simage[S::split_words(d) + S::plain_words(d)]);
   const bool split_ok = wmax <= kSplitWeightLimit;
+  extern __shared__ __attribute__((aligned(16))) uint32_t res_lds[];  // RES: the whole split operand image
+  if constexpr (RES) {
+    const uint4* src = reinterpret_cast<const uint4*>(simage);
+    uint4* dst = reinterpret_cast<uint4*>(res_lds);
+    for (int i = threadIdx.x; i < (int)(S::split_words(d) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
   const int n_groups = (int)((rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves));
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    if (split_ok && rnvp_group_split<HN, SEEDED, RAG>(reinterpret_cast<uint32_t*>(lds[0]),
-                                                      reinterpret_cast<uint32_t*>(lds[1]), grp, z, mask, x, log_det,
-                                                      simage, rows, d, accumulate, seed, zprm, dm, vec, y_out))
+    if (split_ok && rnvp_group_split<HN, SEEDED, RAG, RES>(RES ? res_lds : reinterpret_cast<uint32_t*>(lds[0]),
+                                                           reinterpret_cast<uint32_t*>(lds[1]), grp, z, mask, x, log_det,
+                                                           simage, rows, d, accumulate, seed, zprm, dm, vec, y_out))
       continue;
+    if constexpr (RES) __syncthreads();  // (the fp32 body opens with a barrier of its own; kept explicit)
     rnvp_group_f32_cold<HN, SEEDED, RAG>(&lds[0][0], grp, z, mask, x, log_det, image, rows, d, accumulate, seed, zprm,
                                          dm, vec);
     if (y_out) {  // no y from the fp32 body: NaN rows make the gradient pass's launch A flag the group for its fix-up
@@ -392,6 +603,60 @@ rnvp_split_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
       }
     }
   }
+}
+
+// narrow layers (padded d <= 64, no y to keep): the latency kernel
+template <int HN>
+static int launch_rnvp_narrow(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
+                              const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream) {
+  using S = RnvpSplitShape<HN>;
+  const int64_t n_groups = (rows + 16 * kNarrowWaves - 1) / (16 * kNarrowWaves);
+  const int cus = device_cus(current_device());
+  const int64_t blocks = n_groups < cus ? n_groups : cus;
+  if ((n_groups + blocks - 1) / blocks > kNarrowMaxTrips) return MNF_ERR_UNSUPPORTED;
+  const int64_t img_bytes = S::split_words(dim) * 4, win_bytes = 2 * (int64_t)RnvpShape<HN>::CHUNK_FLOATS * 4;
+  const int lds_bytes = (int)(img_bytes > win_bytes ? img_bytes : win_bytes);
+  typedef void (*Kern)(const float*, const float*, float*, float*, const uint32_t*, const float*, int64_t, int, int,
+                       uint64_t, const float*, const float*, int, int);
+  const Kern kern = mask ? static_cast<Kern>(rnvp_narrow_kernel<HN, false>) : static_cast<Kern>(rnvp_narrow_kernel<HN, true>);
+  static DeviceMemo memo[2];
+  const int ok = memo[mask ? 0 : 1].get([&](int) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               64 * 1024) == hipSuccess ? 1 : -1;
+  });
+  if (ok < 0) return MNF_ERR_UNSUPPORTED;
+  tag_kernel("rnvp_narrow");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kNarrowWaves * 64), lds_bytes, stream, z, mask, x, log_det, simage,
+                     image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec);
+  return check_launch();
+}
+
+// narrow layers (padded d <= 128): the operand image resident in LDS, one workgroup per CU
+template <int HN, bool RAG>
+static int launch_rnvp_split_res(const float* z, const float* mask, float* x, float* log_det, int accumulate,
+                                 const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
+                                 const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
+                                 float* y_out) {
+  using S = RnvpSplitShape<HN>;
+  const int64_t n_groups = (rows + 16 * kRnvpWaves - 1) / (16 * kRnvpWaves);
+  const int lds_bytes = (int)S::split_words(dim) * 4;
+  typedef void (*Kern)(const float*, const float*, float*, float*, const uint32_t*, const float*, int64_t, int, int,
+                       uint64_t, const float*, const float*, int, int, float*);
+  const Kern kern = mask ? static_cast<Kern>(rnvp_split_kernel<HN, false, RAG, 2, true>)
+                         : static_cast<Kern>(rnvp_split_kernel<HN, true, RAG, 2, true>);
+  static DeviceMemo memo[2];
+  const int ok = memo[mask ? 0 : 1].get([&](int) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               96 * 1024) == hipSuccess ? 1 : -1;
+  });
+  if (ok < 0) return MNF_ERR_UNSUPPORTED;
+  const int cus = device_cus(current_device());
+  const int64_t blocks = n_groups < cus ? n_groups : cus;
+  tag_kernel("rnvp_split_resident_operands");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kRnvpWaves * 64), lds_bytes, stream, z, mask, x, log_det, simage,
+                     image, rows, dim, accumulate, seed, q0_mean, q0_log_var, dm, vec, y_out);
+  return check_launch();
 }
 
 template <int HN, bool RAG, int OCC>
@@ -427,6 +692,16 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
                              float* y_out = nullptr) {
   // MNF_RNVP_SPLIT_OCC=2|4 forces one register target for rows of whole 16-dim groups (A/B measurements)
   static const int forced = [] { const char* e = getenv("MNF_RNVP_SPLIT_OCC"); return e ? atoi(e) : 0; }();
+  if (dim <= 64 && !forced && !y_out) {
+    const int rc = launch_rnvp_narrow<HN>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
+                                          q0_log_var, dm, vec, stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
+  if (dim <= 128 && !forced) {
+    const int rc = launch_rnvp_split_res<HN, RAG>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
+                                                  q0_log_var, dm, vec, stream, y_out);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
   const bool two = forced == 2 || (forced != 4 && (RAG || dim <= 128));
   if constexpr (RAG) {
     return launch_rnvp_split_occ<HN, true, 2>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
