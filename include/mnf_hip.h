@@ -646,6 +646,18 @@ int mnf_glow_actnorm_inv_logprob(const float* u, const float* M, const float* s,
 int mnf_glow_actnorm_inv_logprob_bwd(const float* u, const float* grad_log_prob, const float* M, const float* s,
                                      const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
                                      float* grad_ld_glow, int64_t rows, int dim, void* stream);
+/* The two gradient launches above with their sums reduced in a FIXED order (MNF_DETERMINISTIC=1 in the Python layer; the
+ * reference's training loop repeats bit for bit under its torch.manual_seed(0), tests/test_flows.py:11): every workgroup
+ * stores its sums as one block of `workspace` (mnf_glow_actnorm_inv_bwd_workspace(rows, dim) floats) and a second kernel
+ * adds the blocks up in block order -- no float atomics.  workspace == NULL: the atomic flush. */
+int64_t mnf_glow_actnorm_inv_bwd_workspace(int64_t rows, int dim);
+int mnf_glow_actnorm_inv_bwd_det(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
+                                 float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
+                                 int64_t rows, int dim, float* workspace, int64_t workspace_floats, void* stream);
+int mnf_glow_actnorm_inv_logprob_bwd_det(const float* u, const float* grad_log_prob, const float* M, const float* s,
+                                         const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
+                                         float* grad_ld_glow, int64_t rows, int dim, float* workspace,
+                                         int64_t workspace_floats, void* stream);
 /* Glow: grad_W (dim, dim) += x^T grad_y   (grad_x is mnf_linear_rows with W^T). */
 int mnf_linear_rows_bwd_weight(const float* x, const float* grad_y, float* grad_W, int64_t rows, int dim,
                                void* stream);

@@ -1,0 +1,69 @@
+"""Are training steps reproducible bit for bit?  For each of the bench's training workloads (c2t: 9 x AffineHalfFlow at
+d = 64; c3t: 3 x [ActNorm, Glow, NSF_CL] at d = 32; c5t: MNFLinear(800, 50)) the same N Adam steps are run twice from
+identical parameters, inputs and seeds; the parameters after each run must be identical (torch.equal).  The reference's
+loop is reproducible under its torch.manual_seed(0) (tests/test_flows.py:11).
+
+usage: python3 tools/soak_determinism_train.py [steps] [rows_c2t rows_c3t rows_c5t]      (MNF_DETERMINISTIC=1: the
+fixed-order reductions everywhere)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+import torch_mnf_amd as amd
+from torch_mnf_amd import synthetic as recipes
+
+dev = torch.device("cuda")
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rows = [int(v) for v in sys.argv[2:5]] if len(sys.argv) > 4 else [1 << 18, 1 << 18, 64000]
+
+
+def run_c2t():
+    model, _ = bench.build_model(64, dev)
+    opt = amd.FusedAdam(amd.FlatParameters(model), lr=1e-3)
+    x = torch.randn(rows[0], 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    return model, opt, (lambda: -model.log_prob(x).mean())
+
+
+def run_c3t():
+    model, _ = bench.build_c3(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x = torch.randn(rows[1], 32, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    return model, opt, (lambda: -model.log_prob(x).mean())
+
+
+def run_c5t():
+    torch.manual_seed(55)
+    layer = amd.MNFLinear(800, 50)
+    for i, f in enumerate(layer.flow_q.flows):
+        f.load_state_dict(recipes.rnvp_params(800 + i, 800, 50))
+    layer = layer.to(dev)
+    opt = amd.FusedAdam(amd.FlatParameters(layer), lr=1e-3)
+    x = torch.rand(rows[2], 800, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    return layer, opt, (lambda: layer.forward(x).pow(2).mean())
+
+
+def trajectory(build):
+    torch.manual_seed(0)  # (the host-drawn seeds of the in-kernel masks / noise)
+    model, opt, loss_fn = build()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = loss_fn()
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    return [p.detach().clone() for p in model.parameters()], float(loss), dt
+
+
+bad_total = 0
+for name, build in (("c2t", run_c2t), ("c3t", run_c3t), ("c5t", run_c5t)):
+    a, la, ta = trajectory(build)
+    b, lb, tb = trajectory(build)
+    bad = sum(int(not torch.equal(p, q)) for p, q in zip(a, b))
+    worst = max(float((p - q).abs().max() / (p.abs().max() + 1e-30)) for p, q in zip(a, b))
+    print(f"{name}: {steps} Adam steps twice: {bad} of {len(a)} parameter tensors differ (worst relative difference {worst:.2e}); "
+          f"final loss {la:.6f} / {lb:.6f}; {min(ta, tb):.3f} ms per step; MNF_DETERMINISTIC={os.environ.get('MNF_DETERMINISTIC', '0')}")
+    bad_total += bad
+sys.exit(1 if bad_total else 0)

@@ -132,6 +132,12 @@ SIGNATURES = {
                                              c_int, c_void_p]),
     "mnf_glow_actnorm_inv_logprob_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_glow_actnorm_inv_bwd_workspace": (c_int64, [c_int64, c_int]),
+    "mnf_glow_actnorm_inv_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mnf_glow_actnorm_inv_logprob_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                                     c_void_p]),
     "mnf_sample_z0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_int64, c_int, c_void_p]),

@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gz, const float* __restrict__ M,
                             const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ gu,
                             float* __restrict__ grad_m, float* __restrict__ grad_s, float* __restrict__ grad_t,
-                            const float* __restrict__ grad_ld, float* __restrict__ grad_ld_out, int64_t rows) {
+                            const float* __restrict__ grad_ld, float* __restrict__ grad_ld_out, int64_t rows,
+                            float* __restrict__ partials) {
   constexpr int G = D / 16, PITCH = GaShape<D>::PITCH;
   __shared__ __attribute__((aligned(16))) float lds_m[D * D], lds_mt[D * D];
   __shared__ __attribute__((aligned(16))) float red[G * G * 256];
@@ -275,18 +276,20 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // column sums: the 16 row lanes of a q group hold the same columns
+  // column sums: the 16 row lanes of a q group hold the same columns -- a fixed-order tree over those lanes, then the
+  // waves add in turn (below): no LDS atomics, a workgroup's sums repeat bit for bit
 #pragma unroll
   for (int m = 0; m < G; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      atomicAdd(red_st + 16 * m + 4 * q + r, sacc[m][r]);
-      atomicAdd(red_st + D + 16 * m + 4 * q + r, tacc[m][r]);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        sacc[m][r] += __shfl_xor(sacc[m][r], off, 64);
+        tacc[m][r] += __shfl_xor(tacc[m][r], off, 64);
+      }
   if (LP) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lacc += __shfl_xor(lacc, m, 64);
-    if (lane == 0) atomicAdd(red_st + 2 * D, lacc);
   }
   for (int w = 0; w < WAVES; ++w) {
     if (wave == w) {
@@ -295,8 +298,30 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
         f32x4* p = reinterpret_cast<f32x4*>(red + tl * 256 + lane * 4);
         *p = w == 0 ? wacc[tl / G][tl % G] : *p + wacc[tl / G][tl % G];
       }
+      if (j == 0) {
+#pragma unroll
+        for (int m = 0; m < G; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            red_st[16 * m + 4 * q + r] += sacc[m][r];
+            red_st[D + 16 * m + 4 * q + r] += tacc[m][r];
+          }
+      }
+      if (LP && lane == 0) red_st[2 * D] += lacc;
     }
     __syncthreads();
+  }
+  if (partials) {
+    // two-stage flush (MNF_DETERMINISTIC=1): this workgroup's sums as one block -- [g_M in destination order | s | t | l] --,
+    // glow_actnorm_reduce_kernel adds the blocks up in a fixed order
+    float* dst = partials + (int64_t)blockIdx.x * (D * D + 2 * D + 1);
+    for (int e = threadIdx.x; e < G * G * 256; e += blockDim.x) {
+      const int tl = e >> 8, l = (e >> 2) & 63, reg = e & 3;
+      const int i = 16 * (tl / G) + 4 * (l >> 4) + reg, jj = 16 * (tl % G) + (l & 15);
+      dst[i * D + jj] = red[e];
+    }
+    if (threadIdx.x < 2 * D + 1) dst[D * D + threadIdx.x] = red_st[threadIdx.x];
+    return;
   }
   for (int e = threadIdx.x; e < G * G * 256; e += blockDim.x) {
     const int tl = e >> 8, l = (e >> 2) & 63, reg = e & 3;
@@ -310,6 +335,38 @@ glow_actnorm_inv_bwd_kernel(const float* __restrict__ u, const float* __restrict
                                           (LP ? red_st[2 * D] : 0.f));
     if (grad_t) atomicAdd(grad_t + threadIdx.x, red_st[D + threadIdx.x]);
     if (LP && grad_ld_out && threadIdx.x == 0) atomicAdd(grad_ld_out, red_st[2 * D]);
+  }
+}
+
+// second stage of the deterministic flush: entry i of every workgroup's block, added up in block order
+__global__ void __launch_bounds__(256) glow_actnorm_reduce_kernel(const float* __restrict__ partials, int n_blocks, int D,
+                                                                  float* __restrict__ grad_m, float* __restrict__ grad_s,
+                                                                  float* __restrict__ grad_t,
+                                                                  const float* __restrict__ grad_ld,
+                                                                  float* __restrict__ grad_ld_out, int lp) {
+  const int n = D * D + 2 * D + 1, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto total = [&](int e) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // (four interleaved chains, each in block order)
+    int b = 0;
+    for (; b + 3 < n_blocks; b += 4) {
+      a0 += partials[(int64_t)(b + 0) * n + e];
+      a1 += partials[(int64_t)(b + 1) * n + e];
+      a2 += partials[(int64_t)(b + 2) * n + e];
+      a3 += partials[(int64_t)(b + 3) * n + e];
+    }
+    for (; b < n_blocks; ++b) a0 += partials[(int64_t)b * n + e];
+    return (a0 + a1) + (a2 + a3);
+  };
+  const float v = total(i);
+  if (i < D * D) {
+    grad_m[i] += v;
+  } else if (i < D * D + D) {
+    if (grad_s) grad_s[i - D * D] += v - (grad_ld ? grad_ld[0] : 0.f) - (lp ? total(n - 1) : 0.f);
+  } else if (i < D * D + 2 * D) {
+    if (grad_t) grad_t[i - D * D - D] += v;
+  } else if (lp && grad_ld_out) {
+    grad_ld_out[0] += v;
   }
 }
 
@@ -345,12 +402,19 @@ int launch_fwd(const float* u, const float* M, const float* s, const float* t, f
 // images held in registers instead of re-read from LDS per tile: 101); d = 64 holds 88 KB of LDS: one workgroup per CU
 template <int D, bool LP>
 int launch_bwd(const float* u, const float* g, const float* M, const float* s, const float* t, float* grad_u, float* grad_m,
-               float* grad_s, float* grad_t, const float* grad_ld, float* grad_ld_out, int64_t rows, hipStream_t stream) {
+               float* grad_s, float* grad_t, const float* grad_ld, float* grad_ld_out, int64_t rows, hipStream_t stream,
+               float* workspace = nullptr, int64_t workspace_floats = 0) {
   tag_kernel("glow_actnorm_inv_bwd");
-  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<D, MNF_GA_BWD_WAVES, LP>),
-                     dim3((unsigned)grid_for_tiles(rows, D == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES)),
+  const int64_t grid = grid_for_tiles(rows, D == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES);
+  constexpr int N = D * D + 2 * D + 1;
+  float* partials = (workspace && workspace_floats >= grid * N) ? workspace : nullptr;
+  hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<D, MNF_GA_BWD_WAVES, LP>), dim3((unsigned)grid),
                      dim3(MNF_GA_BWD_WAVES * 64), 0, stream, u, g, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld,
-                     grad_ld_out, rows);
+                     grad_ld_out, rows, partials);
+  if (int rc = check_launch()) return rc;
+  if (!partials) return MNF_OK;
+  hipLaunchKernelGGL(glow_actnorm_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partials, (int)grid, D, grad_m,
+                     grad_s, grad_t, grad_ld, grad_ld_out, LP ? 1 : 0);
   return check_launch();
 }
 
@@ -391,9 +455,21 @@ int mnf_glow_actnorm_inv_logprob(const float* u, const float* M, const float* s,
                          (launch_fwd<64, true>(u, M, s, t, no_z, ld_glow, no_ld, log_det_rows, log_prob, rows, st)));
 }
 
+int64_t mnf_glow_actnorm_inv_bwd_workspace(int64_t rows, int dim) {
+  if (rows < 0 || !dim_ok(dim)) return 0;
+  return grid_for_tiles(rows, dim == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES) * ((int64_t)dim * dim + 2 * dim + 1);
+}
+
 int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
                              float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
                              int64_t rows, int dim, void* stream) {
+  return mnf_glow_actnorm_inv_bwd_det(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, rows, dim, nullptr, 0,
+                                      stream);
+}
+
+int mnf_glow_actnorm_inv_bwd_det(const float* u, const float* grad_z, const float* M, const float* s, const float* t,
+                                 float* grad_u, float* grad_m, float* grad_s, float* grad_t, const float* grad_ld,
+                                 int64_t rows, int dim, float* workspace, int64_t workspace_floats, void* stream) {
   if (!u || !grad_z || !M || !s || !t || !grad_u || !grad_m || grad_u == u || grad_u == grad_z || rows < 0)
     return MNF_ERR_INVALID_ARG;
   if (!dim_ok(dim) || !aligned16(u, grad_z, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
@@ -401,23 +477,31 @@ int mnf_glow_actnorm_inv_bwd(const float* u, const float* grad_z, const float* M
   hipStream_t st = (hipStream_t)stream;
   float* no_out = nullptr;
   return MNF_GA_DISPATCH(
-      (launch_bwd<16, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)),
-      (launch_bwd<32, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)),
-      (launch_bwd<64, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st)));
+      (launch_bwd<16, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st, workspace, workspace_floats)),
+      (launch_bwd<32, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st, workspace, workspace_floats)),
+      (launch_bwd<64, false>(u, grad_z, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld, no_out, rows, st, workspace, workspace_floats)));
 }
 
 int mnf_glow_actnorm_inv_logprob_bwd(const float* u, const float* grad_log_prob, const float* M, const float* s,
                                      const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
                                      float* grad_ld_glow, int64_t rows, int dim, void* stream) {
+  return mnf_glow_actnorm_inv_logprob_bwd_det(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld_glow, rows,
+                                              dim, nullptr, 0, stream);
+}
+
+int mnf_glow_actnorm_inv_logprob_bwd_det(const float* u, const float* grad_log_prob, const float* M, const float* s,
+                                         const float* t, float* grad_u, float* grad_m, float* grad_s, float* grad_t,
+                                         float* grad_ld_glow, int64_t rows, int dim, float* workspace,
+                                         int64_t workspace_floats, void* stream) {
   if (!u || !grad_log_prob || !M || !s || !t || !grad_u || !grad_m || grad_u == u || rows < 0) return MNF_ERR_INVALID_ARG;
   if (!dim_ok(dim) || !aligned16(u, grad_u, grad_u) || rows >= (int64_t)1 << 31) return MNF_ERR_UNSUPPORTED;
   if (rows == 0) return MNF_OK;
   hipStream_t st = (hipStream_t)stream;
   const float* no_ld = nullptr;
   return MNF_GA_DISPATCH(
-      (launch_bwd<16, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)),
-      (launch_bwd<32, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)),
-      (launch_bwd<64, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st)));
+      (launch_bwd<16, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st, workspace, workspace_floats)),
+      (launch_bwd<32, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st, workspace, workspace_floats)),
+      (launch_bwd<64, true>(u, grad_log_prob, M, s, t, grad_u, grad_m, grad_s, grad_t, no_ld, grad_ld_glow, rows, st, workspace, workspace_floats)));
 }
 
 }  // extern "C"

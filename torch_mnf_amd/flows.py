@@ -644,6 +644,19 @@ def _linear_rows_table(lib, dim: int, device) -> Tensor | None:
 
 _PAIR_FUSION_DIMS = (16, 32, 64)  # mnf_glow_actnorm_inv / _bwd (csrc/mnf_glow_actnorm.hip)
 _NO_PAIR_FUSION_ENV = os.environ.get("MNF_NO_PAIR_FUSION", "0") == "1"
+# MNF_DETERMINISTIC=1: gradient sums through fixed-order two-stage reductions instead of float atomics where a kernel has
+# both (the reference's loop repeats bit for bit under torch.manual_seed(0), tests/test_flows.py:11).  The AffineHalfFlow
+# and NSF_CL gradient kernels always reduce in a fixed order; this switch adds the [Glow, ActNorm] pair's.  (RNVP /
+# MNFLinear gradient launches still add with atomics: INTEGRATION.md.)
+_DETERMINISTIC = os.environ.get("MNF_DETERMINISTIC", "0") == "1"
+
+
+def _pair_bwd_workspace(rows: int, dim: int, device):
+    """Block sums of the pair's gradient launch (deterministic mode), else None."""
+    if not _DETERMINISTIC:
+        return None
+    n = _lib.load().mnf_glow_actnorm_inv_bwd_workspace(rows, dim)
+    return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
 
 
 class _GlowActNormInvFn(torch.autograd.Function):
@@ -677,9 +690,11 @@ class _GlowActNormInvFn(torch.autograd.Function):
         gu = torch.empty_like(u)
         sums = torch.zeros(dim * dim + 2 * dim, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t
         gM, gs, gt = sums[:dim * dim], sums[dim * dim:dim * dim + dim], sums[dim * dim + dim:]
-        _lib.check("mnf_glow_actnorm_inv_bwd", _lib.load().mnf_glow_actnorm_inv_bwd(
+        work = _pair_bwd_workspace(u.shape[0], dim, u.device)
+        _lib.check("mnf_glow_actnorm_inv_bwd", _lib.load().mnf_glow_actnorm_inv_bwd_det(
             u.data_ptr(), gz.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-            gs.data_ptr(), gt.data_ptr(), _ptr(gl), u.shape[0], dim, _stream()))
+            gs.data_ptr(), gt.data_ptr(), _ptr(gl), u.shape[0], dim, _ptr(work), 0 if work is None else work.numel(),
+            _stream()))
         return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape),
                 None if gl is None else gl.reshape(ctx.ld_shape))
 
@@ -2247,9 +2262,11 @@ class _GlowActNormInvLogProbFn(torch.autograd.Function):
         sums = torch.zeros(dim * dim + 2 * dim + 1, dtype=torch.float32, device=u.device)  # grad_M | grad_s | grad_t | grad_ld
         gM, gs = sums[:dim * dim], sums[dim * dim:dim * dim + dim]
         gt, gld = sums[dim * dim + dim:dim * dim + 2 * dim], sums[dim * dim + 2 * dim:]
-        _lib.check("mnf_glow_actnorm_inv_logprob_bwd", _lib.load().mnf_glow_actnorm_inv_logprob_bwd(
+        work = _pair_bwd_workspace(u.shape[0], dim, u.device)
+        _lib.check("mnf_glow_actnorm_inv_logprob_bwd", _lib.load().mnf_glow_actnorm_inv_logprob_bwd_det(
             u.data_ptr(), g.data_ptr(), Mc.data_ptr(), sc.data_ptr(), tc.data_ptr(), gu.data_ptr(), gM.data_ptr(),
-            gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), u.shape[0], dim, _stream()))
+            gs.data_ptr(), gt.data_ptr(), gld.data_ptr(), u.shape[0], dim, _ptr(work), 0 if work is None else work.numel(),
+            _stream()))
         return (gu if ctx.needs_input_grad[0] else None, gM.view(dim, dim), gs.view(sc.shape), gt.view(tc.shape),
                 gld.reshape(ctx.ld_shape), g)
 
