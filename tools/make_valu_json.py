@@ -1,9 +1,12 @@
 """profiles/rN/<workload>_valu_issue.json from the SQ counter passes of tools/profile_bench.sh: how much of the chip's
 vector-instruction issue capacity the dominant kernel used (the C3 spline kernel is VALU / transcendental bound by
 construction).
-usage: make_valu_json.py <gpurun_out/prof_TAG> <workload> <kernel substring> <out.json>"""
+usage: make_valu_json.py <gpurun_out/prof_TAG> <workload> <kernel substring> <out.json> [launches per unit]
+(launches per unit: the substring matches that many kernels whose counters are averaged per dispatch and then summed --
+c3t's gradient pass is two stage kernels per layer)"""
 import csv, glob, json, os, sys
 d, workload, kern, out = sys.argv[1:5]
+mult = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 
 
 def mean_of(sub, counter):
@@ -15,22 +18,31 @@ def mean_of(sub, counter):
     return None
 
 
-def kernel_ns():
+def kernel_ns_mean():
+    """mean over the matching kernels of their average duration (each weighted by its calls)"""
     for f in sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+        tot = calls = 0.0
         for r in csv.DictReader(open(f)):
             if kern in r["Name"]:
-                return float(r["AverageNs"])
+                tot += float(r["AverageNs"]) * float(r["Calls"])
+                calls += float(r["Calls"])
+        if calls:
+            return tot / calls
     return None
 
 
-valu = mean_of("pmc_sq", "SQ_INSTS_VALU")            # wave-level vector instructions, MFMAs included
-mfma = mean_of("pmc_sq2", "SQ_INSTS_MFMA")
-mfma_busy = mean_of("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES")
-gui = mean_of("pmc_sq2", "GRBM_GUI_ACTIVE")          # summed over the 8 XCDs
-wave_cycles = mean_of("pmc_sq", "SQ_WAVE_CYCLES")
-active = mean_of("pmc_sq", "SQ_ACTIVE_INST_ANY")
-active_valu = mean_of("pmc_sq2", "SQ_ACTIVE_INST_VALU")  # quad-cycles the waves spent inside vector instructions
-ns = kernel_ns()
+def scaled(v):
+    return None if v is None else v * mult
+
+
+valu = scaled(mean_of("pmc_sq", "SQ_INSTS_VALU"))            # wave-level vector instructions, MFMAs included
+mfma = scaled(mean_of("pmc_sq2", "SQ_INSTS_MFMA"))
+mfma_busy = scaled(mean_of("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES"))
+gui = scaled(mean_of("pmc_sq2", "GRBM_GUI_ACTIVE"))          # summed over the 8 XCDs
+wave_cycles = scaled(mean_of("pmc_sq", "SQ_WAVE_CYCLES"))
+active = scaled(mean_of("pmc_sq", "SQ_ACTIVE_INST_ANY"))
+active_valu = scaled(mean_of("pmc_sq2", "SQ_ACTIVE_INST_VALU"))  # quad-cycles the waves spent inside vector instructions
+ns = scaled(kernel_ns_mean())
 cycles = gui / 8.0                                     # shader cycles of the dispatch
 simds = 256 * 4
 # MI355X_MICROARCH.md: a SIMD issues one wave64 vector instruction per 2 cycles (32 lanes / cycle); an MFMA
@@ -38,7 +50,7 @@ simds = 256 * 4
 plain = valu - mfma
 issue_cycles = 2.0 * plain + 8.0 * mfma
 json.dump({
-    "kernel": kern, "workload": workload,
+    "kernel": kern, "workload": workload, "launches_per_unit": mult,
     "SQ_INSTS_VALU": valu, "SQ_INSTS_MFMA": mfma, "SQ_VALU_MFMA_BUSY_CYCLES": mfma_busy, "GRBM_GUI_ACTIVE": gui,
     "SQ_WAVE_CYCLES": wave_cycles, "SQ_ACTIVE_INST_ANY": active, "kernel_avg_ns_profiled": ns,
     "effective_clock_GHz": cycles / ns if ns else None,

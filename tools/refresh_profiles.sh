@@ -3,7 +3,7 @@
 # bench JSON lines, rocprofv3 kernel-trace + PMC summaries (every profiler run under `timeout`), PMC traffic files.
 # usage: [ROUND=r4] tools/refresh_profiles.sh [workloads...]   (default: c2 c3 c4 c5 c5b c2t c3t c5t)
 set -u
-ROUND=${ROUND:-r4}
+ROUND=${ROUND:-r5}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -12,7 +12,8 @@ WL=${*:-c2 c3 c4 c5 c5b c2t c3t c5t}
 declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
                   [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
                   [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_shared_kernel<50, true, false" \
-                  [c3t]="nsf_bwd" [c5b]="rnvp_split_kernel<50" )
+                  [c3t]="nsf_bwd_tile_kernel" [c5b]="rnvp_narrow_kernel<50" )
+declare -A MULT=( [c3t]=2 )
 for w in $WL; do
   extra=""; [ "$w" = c2 ] && extra="--no-secondary"
   timeout 400 python bench.py --workload $w $extra > "$OUT/${w}_bench.json" 2> "$OUT/${w}_bench.err"
@@ -31,8 +32,8 @@ for w in $WL; do
     fi )
   python3 tools/summarize_prof.py "$P" > "$OUT/${w}_rocprofv3_summary.txt" 2>&1
   cp "$P"/trace/*/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null || cp "$P"/trace/*kernel_stats.csv "$OUT/${w}_kernel_stats.csv" 2>/dev/null
-  python3 tools/make_traffic_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_pmc_traffic.json" > /dev/null 2>&1
-  python3 tools/make_valu_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" > /dev/null 2>&1
+  python3 tools/make_traffic_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_pmc_traffic.json" ${MULT[$w]:-1} > /dev/null 2>&1
+  python3 tools/make_valu_json.py gpurun_out/prof_${ROUND}_$w $w "${KERN[$w]}" "$OUT/${w}_valu_issue.json" ${MULT[$w]:-1} > /dev/null 2>&1
 done
 ls -la "$OUT"
 for f in "$OUT"/*_bench.json; do echo "$f"; tail -1 "$f" | python3 -c "import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('  ', d['value'], d['unit'], d['ms_per_step'], 'ms', r['bound'], r['frac'], r['avg_kernel_us'], 'us', r.get('traffic'))"; done

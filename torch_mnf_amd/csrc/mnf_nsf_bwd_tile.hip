@@ -562,7 +562,6 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
 #pragma unroll
       for (int g = 0; g < G; ++g) cur[i][g] = g_live[g] ? nx[i][g] : f32x4{0.f, 0.f, 0.f, 0.f};
     const float cur_gl = nx_gl;
-    request_rows(tile + stride);
     const int row = tile * 16 + j;
     const bool live = row < n_rows;
     const float gl = (a.grad_ld && live) ? cur_gl * g_scale : 0.f;
@@ -586,6 +585,10 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
         g_val[g] = cur[3][g] * g_on;
       }
       cold = !half_backward<H, NH, K, INV>(nv, lane, cur[0], cur[1], gl, g_val, g_cond, a.T, wseed, mx_grad);
+      // (the next tile's rows are requested HERE, behind the tile's arithmetic: at the top of the tile the 17 registers
+      //  they land in were live across the whole slot loop and the kernel spilled ~40 registers per tile around it --
+      //  scratch traffic of 230 MB per launch; the other wave of the SIMD covers the latency)
+      request_rows(tile + stride);
       if (!cold && live) {
         float* gr = a.grad_x + (uint32_t)row * dim;
 #pragma unroll
@@ -595,6 +598,9 @@ __device__ __forceinline__ void nsf_bwd_tile_body(const NtArgs& a) {
             *reinterpret_cast<f32x4*>(gr + col_val + g_off[g]) = g_val[g] * g_unscale;
           }
       }
+    }
+    else {
+      request_rows(tile + stride);
     }
     if (ST == 0 && cold && lane == 0) {
       cold_flag[tile] = 1;
