@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do a kernel's cycles go: SQ counter passes over tools/time_rnvp.py (or another script).
-# usage: tools/pmc_sq.sh <tag> [script args...]      env: MNF_LIB_PATH, MNF_RNVP_PAIR ... pass through; SCRIPT=tools/x.py
+# usage: tools/pmc_sq.sh <tag> [script args...]      env: MNF_LIB_PATH, MNF_NSF_BWD_KERNEL ... pass through; SCRIPT=tools/x.py
 TAG=${1:-x}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SCRIPT=${SCRIPT:-tools/time_rnvp.py}
