@@ -315,8 +315,9 @@ def main_c5(args, rank, world, device, dim, rows, desc, n_out: int = 50) -> None
         # register-resident kernel moves exactly that; the streaming kernel (MNF_RNVP_RESIDENT=0) reads z a second
         # time for the gate epilogue: 12d + 8.
         algo_bytes = (8 * dim + 8) * rows
-        # rows held in registers, z read once: the kernel exists for d = 800 (c5b, d = 50, runs the streaming kernel)
+        # rows held in registers, z read once: rnvp_resident_kernel at d = 800, rnvp_narrow_kernel at d <= 64 (c5b)
         resident = SPLIT and os.environ.get("MNF_RNVP_RESIDENT", "1") != "0" and dim == 800
+        narrow = SPLIT and dim <= 64
         if SPLIT:  # memory-path bound (tools ablations: no MFMAs -> same time), priced against HBM
             gbs = algo_bytes / avg_s / 1e9
             traffic, source = pmc_traffic("c5" if resident else "c5b" if dim != 800 else "c5_streaming")
@@ -324,10 +325,13 @@ def main_c5(args, rank, world, device, dim, rows, desc, n_out: int = 50) -> None
                                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                                **physical(traffic, avg_s),
                                "kernel": ("rnvp_resident_kernel<50,50> (rows resident in the register file, z read once)"
-                                          if resident else "rnvp_split_kernel<50,seeded> (z read twice)"),
+                                          if resident else
+                                          "rnvp_narrow_kernel<50,seeded> (16 waves per CU, operand image resident in LDS, "
+                                          "a row tile in registers, z read once)" if narrow else
+                                          "rnvp_split_kernel<50,seeded> (z read twice)"),
                                "avg_kernel_us": avg_s * 1e6,
                                "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(kern_ms),
-                               "bytes_moved_per_launch_by_design": (8 if resident else 12) * dim * rows + 8 * rows,
+                               "bytes_moved_per_launch_by_design": (8 if resident or narrow else 12) * dim * rows + 8 * rows,
                                "fp32_equivalent_tflops": tf}
         else:
             out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -65,7 +65,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 12
+#define MNF_ABI_VERSION 13
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -76,6 +76,13 @@ int mnf_last_hip_error(void);
  * caller can see which side of a shape cliff a layer landed on (shape -> kernel table).  "" before the
  * first launch. */
 const char* mnf_last_kernel(void);
+/* 1 when MNF_DETERMINISTIC is set in the environment (read once per process): the RNVP and MNFLinear gradient launches
+ * (mnf_rnvp_bwd_mfma, mnf_mnf_linear_bwd) then form their parameter sums without float atomics -- one block per row part
+ * in an extension of the caller's workspace (their *_workspace_bytes queries include it), added up in a fixed order -- so
+ * that a training step repeats bit for bit, as the reference's does under torch.manual_seed (tests/test_flows.py:11).
+ * The AffineHalfFlow and NSF_CL gradient launches reduce in a fixed order in every mode; the [Glow, ActNorm] pair has
+ * its own *_det entry points.  Rows that take the fp32 fix-up pass (values beyond the split range) still add atomically. */
+int mnf_deterministic(void);
 /* Number of visible devices whose gcnArchName starts with gfx950 (0 = none / no driver). */
 int mnf_device_count(void);
 
@@ -321,6 +328,13 @@ int mnf_sample_z0_seeded(const float* q0_mean, const float* q0_log_var, uint64_t
 int mnf_sample_z0_seeded_bwd(const float* grad_z0, uint64_t seed, const float* q0_log_var, float* grad_mean,
                              float* grad_log_var, int64_t rows, int dim, void* stream);
 int mnf_sample_z0_noise(uint64_t seed, float* eps, int64_t rows, int dim, void* stream);
+/* mnf_sample_z0_bwd (eps != NULL) / mnf_sample_z0_seeded_bwd (eps == NULL) with the sums over the rows added in a fixed
+ * order: every row block leaves its sums in `workspace` (mnf_sample_z0_bwd_workspace(rows, dim) floats) and a second
+ * launch adds the blocks up in order -- no float atomics, the result repeats bit for bit (MNF_DETERMINISTIC=1). */
+int64_t mnf_sample_z0_bwd_workspace(int64_t rows, int dim);
+int mnf_sample_z0_bwd_det(const float* grad_z0, const float* eps, uint64_t seed, const float* q0_log_var, float* grad_mean,
+                          float* grad_log_var, int64_t rows, int dim, float* workspace, int64_t workspace_floats,
+                          void* stream);
 
 /* ------------------------------------------------------------------ training: one optimizer launch
  * torch.optim.Adam's update (no amsgrad; weight_decay as L2 on the gradient) over ONE flat buffer: param, grad and

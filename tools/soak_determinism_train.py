@@ -57,6 +57,16 @@ def trajectory(build):
     return [p.detach().clone() for p in model.parameters()], float(loss), dt
 
 
+def first_gradients(build):
+    """the gradients of the FIRST step (before any update mixes them): which parameter's sum differs, by name"""
+    torch.manual_seed(0)
+    model, opt, loss_fn = build()
+    opt.zero_grad()
+    loss_fn().backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
 bad_total = 0
 for name, build in (("c2t", run_c2t), ("c3t", run_c3t), ("c5t", run_c5t)):
     a, la, ta = trajectory(build)
@@ -66,4 +76,8 @@ for name, build in (("c2t", run_c2t), ("c3t", run_c3t), ("c5t", run_c5t)):
     print(f"{name}: {steps} Adam steps twice: {bad} of {len(a)} parameter tensors differ (worst relative difference {worst:.2e}); "
           f"final loss {la:.6f} / {lb:.6f}; {min(ta, tb):.3f} ms per step; MNF_DETERMINISTIC={os.environ.get('MNF_DETERMINISTIC', '0')}")
     bad_total += bad
+    ga, gb = first_gradients(build), first_gradients(build)
+    diff = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    if diff:
+        print(f"   first-step gradients that differ between two runs: {', '.join(diff[:12])}{' ...' if len(diff) > 12 else ''}")
 sys.exit(1 if bad_total else 0)

@@ -8,7 +8,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 (The directory is ``torch_mnf_amd``: ``torch-mnf_amd`` is not an importable name.)
 """
 from . import _lib
-from ._lib import MnfHipError, last_kernel
+from ._lib import MnfHipError, deterministic, last_kernel
 from .layers import MNFConv2d, MNFFeedForward, MNFLeNet, MNFLinear
 from .train import FlatParameters, FusedAdam, GraphedStep
 from .flows import (
@@ -34,6 +34,7 @@ from .flows import (
 
 __all__ = [
     "last_kernel",
+    "deterministic",
     "MLP", "MADE", "MaskedLinear", "MAF", "IAF", "ActNormFlow", "AffineConstantFlow", "AffineHalfFlow", "Glow", "NormalizingFlow",
     "NormalizingFlowModel", "NSF_AR", "NSF_CL", "RNVP", "StandardNormal", "FusedSplineBlock", "FusedAffineStack", "rqs", "MNFLinear", "MNFConv2d", "MNFLeNet", "MNFFeedForward", "FlatParameters", "FusedAdam", "GraphedStep", "MnfHipError", "library_path",
 ]

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 12  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 13  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -31,6 +31,7 @@ SIGNATURES = {
     "mnf_error_string": (c_char_p, [c_int]),
     "mnf_last_hip_error": (c_int, []),
     "mnf_last_kernel": (c_char_p, []),
+    "mnf_deterministic": (c_int, []),
     "mnf_device_count": (c_int, []),
     "mnf_affine_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, _intp, c_int, c_int, c_int, c_void_p]),
@@ -143,6 +144,9 @@ SIGNATURES = {
     "mnf_sample_z0_seeded": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_seeded_bwd": (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mnf_sample_z0_noise": (c_int, [c_uint64, c_void_p, c_int64, c_int, c_void_p]),
+    "mnf_sample_z0_bwd_workspace": (c_int64, [c_int64, c_int]),
+    "mnf_sample_z0_bwd_det": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                      c_int64, c_void_p]),
     "mnf_adam_step_graph": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                     c_float, c_void_p, c_void_p]),
     "mnf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
@@ -245,6 +249,12 @@ def last_kernel() -> str:
     """The kernel family the process's most recent layer call ran ("ahf_split_stack", "nsf_bwd_tile", ... or a
     "*_generic" name for the any-shape kernels; "" before the first launch): include/mnf_hip.h mnf_last_kernel."""
     return (load().mnf_last_kernel() or b"").decode()
+
+
+def deterministic() -> bool:
+    """True when the library runs its fixed-order gradient reductions (MNF_DETERMINISTIC=1 in the environment when the
+    process started): include/mnf_hip.h mnf_deterministic."""
+    return bool(load().mnf_deterministic())
 
 
 _WARNED_GENERIC: set = set()

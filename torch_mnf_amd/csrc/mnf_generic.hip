@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "mnf_device.h"
@@ -653,7 +654,8 @@ template <int VEC>
 __global__ void __launch_bounds__(256) sample_z0_bwd_kernel(const float* __restrict__ g, const float* __restrict__ eps,
                                                             const float* __restrict__ log_var,
                                                             float* __restrict__ g_mean, float* __restrict__ g_log_var,
-                                                            int64_t rows, int dim, int atomic, uint64_t seed) {
+                                                            int64_t rows, int dim, int atomic, uint64_t seed,
+                                                            float* __restrict__ blocks) {
   __shared__ float part[2][4][64 * VEC];
   const int j0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
   float sm[VEC], sv[VEC];
@@ -701,7 +703,10 @@ __global__ void __launch_bounds__(256) sample_z0_bwd_kernel(const float* __restr
     const float m = (part[0][0][c] + part[0][1][c]) + (part[0][2][c] + part[0][3][c]);
     float w = (part[1][0][c] + part[1][1][c]) + (part[1][2][c] + part[1][3][c]);
     w *= 0.5f * sqrtf(expf(log_var[j]));
-    if (atomic) {
+    if (blocks) {  // the row block's sums as its own block [mean | log_var]: det_reduce_async adds them in order
+      blocks[(int64_t)blockIdx.y * 2 * dim + j] = m;
+      blocks[(int64_t)blockIdx.y * 2 * dim + dim + j] = w;
+    } else if (atomic) {
       atomicAdd(g_mean + j, m);
       atomicAdd(g_log_var + j, w);
     } else {  // one workgroup per dim block: plain adds, results repeat bit for bit
@@ -795,6 +800,40 @@ int zero_word_async(void* word, hipStream_t stream) {
   return check_launch();
 }
 
+bool deterministic() {
+  static const bool on = [] {
+    const char* e = getenv("MNF_DETERMINISTIC");
+    return e != nullptr && e[0] != '\0' && strcmp(e, "0") != 0;
+  }();
+  return on;
+}
+
+__global__ void __launch_bounds__(256) zero_floats_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+int zero_floats_async(float* p, int64_t n, hipStream_t stream) {
+  if (n <= 0) return MNF_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p, n);
+  return check_launch();
+}
+
+// one thread per parameter, the row parts in order: every run adds the same numbers in the same order
+__global__ void __launch_bounds__(256)
+det_reduce_kernel(const float* __restrict__ part, int n_rows, int64_t stride, int64_t count, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int r = 0; r < n_rows; ++r) s += part[(int64_t)r * stride + i];
+  dst[i] += s;
+}
+int det_reduce_async(const float* part, int n_rows, int64_t stride, int64_t count, float* dst, hipStream_t stream) {
+  if (count <= 0 || n_rows <= 0) return MNF_OK;
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, part, n_rows, stride,
+                     count, dst);
+  return check_launch();
+}
+
 // Fill a NetDesc for MLP(sizes...) whose parameters start at float offset `base` of the flat
 // buffer (weight then bias per Linear, state_dict order).  Returns floats consumed.
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base) {
@@ -848,6 +887,7 @@ const char* mnf_error_string(int code) {
 
 int mnf_last_hip_error(void) { return g_last_hip_error; }
 const char* mnf_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
+int mnf_deterministic(void) { return deterministic() ? 1 : 0; }
 
 int mnf_device_count(void) {
   int n = 0;
@@ -1301,22 +1341,53 @@ int mnf_sample_z0(const float* q0_mean, const float* q0_log_var, const float* ep
   return check_launch();
 }
 
+static void sample_z0_bwd_plan(int64_t rows, int dim, bool vec, int& dim_blocks, int64_t& row_blocks) {
+  const int per_block = vec ? 256 : 64;
+  dim_blocks = (dim + per_block - 1) / per_block;
+  row_blocks = (rows * dim) / (64 * 1024);
+  row_blocks = row_blocks < 1 ? 1 : row_blocks > 2048 / dim_blocks + 1 ? 2048 / dim_blocks + 1 : row_blocks;
+}
+
 static int sample_z0_bwd_launch(const float* grad_z0, const float* eps, uint64_t seed, const float* q0_log_var,
-                                float* grad_mean, float* grad_log_var, int64_t rows, int dim, void* stream) {
+                                float* grad_mean, float* grad_log_var, int64_t rows, int dim, void* stream,
+                                float* blocks = nullptr) {
   if (rows == 0) return MNF_OK;
   // enough workgroups to fill the chip once rows x dim is large; a single row block (no atomics) while it is small
   const bool vec = dim % 4 == 0 && !((reinterpret_cast<uintptr_t>(grad_z0) | reinterpret_cast<uintptr_t>(eps)) & 15);
-  const int per_block = vec ? 256 : 64;
-  const int dim_blocks = (dim + per_block - 1) / per_block;
-  int64_t row_blocks = (rows * dim) / (64 * 1024);
-  row_blocks = row_blocks < 1 ? 1 : row_blocks > 2048 / dim_blocks + 1 ? 2048 / dim_blocks + 1 : row_blocks;
+  int dim_blocks;
+  int64_t row_blocks;
+  sample_z0_bwd_plan(rows, dim, vec, dim_blocks, row_blocks);
+  if (row_blocks == 1) blocks = nullptr;  // (one workgroup per dim block adds in place: nothing to order)
   if (vec)
     hipLaunchKernelGGL(sample_z0_bwd_kernel<4>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
-                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0, seed);
+                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0, seed, blocks);
   else
     hipLaunchKernelGGL(sample_z0_bwd_kernel<1>, dim3(dim_blocks, (unsigned)row_blocks), dim3(64, 4), 0, (hipStream_t)stream,
-                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0, seed);
-  return check_launch();
+                       grad_z0, eps, q0_log_var, grad_mean, grad_log_var, rows, dim, row_blocks > 1 ? 1 : 0, seed, blocks);
+  if (int rc = check_launch()) return rc;
+  if (!blocks) return MNF_OK;
+  if (int rc = det_reduce_async(blocks, (int)row_blocks, 2 * (int64_t)dim, dim, grad_mean, (hipStream_t)stream)) return rc;
+  return det_reduce_async(blocks + dim, (int)row_blocks, 2 * (int64_t)dim, dim, grad_log_var, (hipStream_t)stream);
+}
+
+int64_t mnf_sample_z0_bwd_workspace(int64_t rows, int dim) {
+  if (rows < 1 || dim < 1) return 0;
+  int dim_blocks;
+  int64_t row_blocks;
+  sample_z0_bwd_plan(rows, dim, false, dim_blocks, row_blocks);  // (the scalar plan never has fewer row blocks)
+  int db4;
+  int64_t rb4;
+  sample_z0_bwd_plan(rows, dim, true, db4, rb4);
+  return (row_blocks > rb4 ? row_blocks : rb4) * 2 * dim;
+}
+
+int mnf_sample_z0_bwd_det(const float* grad_z0, const float* eps, uint64_t seed, const float* q0_log_var, float* grad_mean,
+                          float* grad_log_var, int64_t rows, int dim, float* workspace, int64_t workspace_floats,
+                          void* stream) {
+  if (!grad_z0 || !q0_log_var || !grad_mean || !grad_log_var || !workspace || rows < 0 || dim < 1 ||
+      workspace_floats < mnf_sample_z0_bwd_workspace(rows, dim))
+    return MNF_ERR_INVALID_ARG;
+  return sample_z0_bwd_launch(grad_z0, eps, seed, q0_log_var, grad_mean, grad_log_var, rows, dim, stream, workspace);
 }
 
 int mnf_sample_z0_bwd(const float* grad_z0, const float* eps, const float* q0_log_var, float* grad_mean,

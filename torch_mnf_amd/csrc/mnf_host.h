@@ -144,6 +144,29 @@ int rnvp_few_bwd_launch(const float* z, const float* mask, uint64_t seed, const 
 // training step (memory access fault; the same step with these resets as kernels replays cleanly).
 int zero_word_async(void* word, hipStream_t stream);
 
+// MNF_DETERMINISTIC=1 in the environment (read once): the RNVP and MNFLinear gradient launches leave their parameter
+// sums as one block per row part (plain stores into an extension of the caller's workspace, which the *_workspace_bytes
+// queries then include) and det_reduce_async adds the blocks up in a fixed order; the workgroups' waves add into LDS
+// one after the other.  Off: float atomics, sums that differ in their last bits run to run.  mnf_deterministic().
+bool deterministic();
+// n floats := 0 / dst[i] += part[0][i] + part[1][i] + ... (rows in order, row r at part + r * stride), as kernel nodes
+int zero_floats_async(float* p, int64_t n, hipStream_t stream);
+int det_reduce_async(const float* part, int n_rows, int64_t stride, int64_t count, float* dst, hipStream_t stream);
+// the waves of a workgroup add into LDS: atomically, or -- det -- wave 0, then wave 1, ... with plain read-modify-writes
+// (the lanes of one wave must name distinct addresses).  add(op) calls op(float* p, float v) for each of the wave's sums.
+template <int WAVES, typename F>
+__device__ __forceinline__ void lds_wave_add(bool det, int wave, F&& add) {
+  if (!det) {
+    add([](float* p, float v) { atomicAdd(p, v); });
+    return;
+  }
+#pragma unroll 1
+  for (int w = 0; w < WAVES; ++w) {
+    if (wave == w) add([](float* p, float v) { *p += v; });
+    __syncthreads();
+  }
+}
+
 // the generic RNVP gradient kernel (mnf_backward.hip); list != nullptr: only the row groups list[1 .. list[0]] (the
 // fix-up pass of mnf_rnvp_bwd_mfma)
 int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld,

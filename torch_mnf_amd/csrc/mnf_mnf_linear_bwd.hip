@@ -37,6 +37,10 @@ namespace mnf {
 
 constexpr int kMlbGroupRows = 128;  // rows per flag: the forward kernel's 8-wave group
 constexpr int kMlbWaves = 4;        // waves of a slab workgroup
+// MNF_DETERMINISTIC (mnf_host.h): the prologue's workgroups (at most kMlDetBlocks) leave 128 floats each, the slab
+// launch's row parts (at most kMlDetParts) a block of the layer's parameter count each, behind the workspace's tiles
+constexpr int kMlDetBlocks = 1024, kMlDetParts = 64;
+__host__ __device__ inline int64_t ml_params(int n_in, int n_out) { return 2 * (int64_t)n_out * n_in + 2 * n_out; }
 
 template <int YT>
 struct MlBwdShape {
@@ -56,7 +60,7 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
                        uint64_t seed, const float* __restrict__ flat, const int32_t* __restrict__ fwd_flags,
                        uint32_t* __restrict__ side, int32_t* __restrict__ flags, int32_t* __restrict__ list,
                        const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int n_in,
-                       int n_out, float var_unscale, float wmax_limit_ok) {
+                       int n_out, float var_unscale, float wmax_limit_ok, float* __restrict__ det_b) {
   using H = HandoverShape<YT>;
   constexpr int kPitch = 16 * YT + 1;  // (odd: the 16 rows a lane group reads land on 16 different banks)
   __shared__ float stage[8 * 2 * 16 * kPitch];
@@ -159,16 +163,31 @@ ml_bwd_prologue_kernel(const float* __restrict__ gout, const float* __restrict__
           a += __shfl_xor(a, off, 64);
           b += __shfl_xor(b, off, 64);
         }
-        if (j == 0) {
-          atomicAdd(bsum + 16 * m + 4 * q + r, a);
-          atomicAdd(bsum + 64 + 16 * m + 4 * q + r, b);
-        }
+        bm_acc[m][r] = a;
+        bv_acc[m][r] = b;
       }
+    const bool det = det_b != nullptr;  // (the waves add in turn, the workgroup's sums go out as its own block of 128)
+    lds_wave_add<8>(det, wave, [&](auto op) {
+#pragma unroll
+      for (int m = 0; m < YT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j == 0) {
+            op(bsum + 16 * m + 4 * q + r, bm_acc[m][r]);
+            op(bsum + 64 + 16 * m + 4 * q + r, bv_acc[m][r]);
+          }
+    });
     __syncthreads();
     if ((int)threadIdx.x < n_out) {
       const int o = threadIdx.x;
-      if (bsum[o] != 0.f) atomicAdd(grad_flat + bmo + o, bsum[o] * inv);
-      if (bsum[64 + o] != 0.f) atomicAdd(grad_flat + bvo + o, bsum[64 + o] * flat[bvo + o]);
+      const float gm_ = bsum[o] * inv, gv_ = bsum[64 + o] * flat[bvo + o];
+      if (det) {
+        det_b[(int64_t)blockIdx.x * 128 + o] = gm_;
+        det_b[(int64_t)blockIdx.x * 128 + 64 + o] = gv_;
+      } else {
+        if (bsum[o] != 0.f) atomicAdd(grad_flat + bmo + o, gm_);
+        if (bsum[64 + o] != 0.f) atomicAdd(grad_flat + bvo + o, gv_);
+      }
     }
   }
 }
@@ -181,7 +200,7 @@ ml_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ z, flo
                    float* __restrict__ grad_z, float* __restrict__ grad_flat, const float* __restrict__ flat,
                    const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
                    const float* __restrict__ gscale_dev, int64_t rows, int n_in, int n_out, int n_slabs, int row_parts,
-                   int vec2, float var_unscale) {
+                   int vec2, float var_unscale, float* __restrict__ det_part) {
   using S = MlBwdShape<YT>;
   using H = HandoverShape<YT>;
   constexpr int NKS = S::NKS;
@@ -362,24 +381,34 @@ ml_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ z, flo
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * 16 * YT * UP; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
+    lds_wave_add<kMlbWaves>(det_part != nullptr, wave, [&](auto op) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int m = 0; m < YT; ++m)
+        for (int m = 0; m < YT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(red + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWm[dt][m][r]);
-          atomicAdd(red + 16 * YT * UP + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWv[dt][m][r]);
-        }
+          for (int r = 0; r < 4; ++r) {
+            op(red + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWm[dt][m][r]);
+            op(red + 16 * YT * UP + (16 * m + 4 * q + r) * UP + 2 * j + dt, aWv[dt][m][r]);
+          }
+    });
     __syncthreads();
     const int n_dims = min(32, n_in - 32 * slab);
     const int64_t wv = (int64_t)n_out * n_in;
+    float* const out = det_part ? det_part + (int64_t)part * ml_params(n_in, n_out) : grad_flat;
     for (int e = threadIdx.x; e < n_out * 32; e += blockDim.x) {
       const int o = e >> 5, dl = e & 31;
       if (dl < n_dims) {
         const int64_t at = (int64_t)o * n_in + 32 * slab + dl;
-        atomicAdd(grad_flat + at, red[o * UP + dl] * inv_gscale);
-        atomicAdd(grad_flat + wv + at, red[16 * YT * UP + o * UP + dl] * flat[wv + at] * (inv_gscale * var_unscale));
+        const float gm_ = red[o * UP + dl] * inv_gscale;
+        const float gv_ = red[16 * YT * UP + o * UP + dl] * flat[wv + at] * (inv_gscale * var_unscale);
+        if (det_part) {
+          out[at] = gm_;
+          out[wv + at] = gv_;
+        } else {
+          atomicAdd(out + at, gm_);
+          atomicAdd(out + wv + at, gv_);
+        }
       }
     }
   }
@@ -422,7 +451,8 @@ ml_bwd_slab_shared_kernel(const float* __restrict__ x, const float* __restrict__
                           float* __restrict__ grad_z, float* __restrict__ grad_flat, const float* __restrict__ flat,
                           const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side,
                           const int32_t* __restrict__ flags, const float* __restrict__ gscale_dev, int64_t rows, int n_in,
-                          int n_out, int n_slabs, int row_parts, int vec2, float var_unscale) {
+                          int n_out, int n_slabs, int row_parts, int vec2, float var_unscale,
+                          float* __restrict__ det_part) {
   using S = MlBwdShape<YT>;
   using H = HandoverShape<YT>;
   using T = MlSharedShape<YT>;
@@ -686,8 +716,17 @@ ml_bwd_slab_shared_kernel(const float* __restrict__ x, const float* __restrict__
       if (dl < n_dims) {
         const float* rs = red + (dl >> 5) * T::RED_SLAB + o * T::UP + (dl & 31);
         const int64_t at = (int64_t)o * n_in + dim_g + dl;
-        atomicAdd(grad_flat + at, rs[0] * inv_gscale);
-        atomicAdd(grad_flat + wv + at, rs[16 * YT * T::UP] * flat[wv + at] * (inv_gscale * var_unscale));
+        const float gm_ = rs[0] * inv_gscale, gv_ = rs[16 * YT * T::UP] * flat[wv + at] * (inv_gscale * var_unscale);
+        // (two waves per slab added into the zeroed area: either order gives the same number.  det_part: plain stores
+        // into the row part's block, det_reduce_async adds the blocks in a fixed order)
+        if (det_part) {
+          float* const out = det_part + (int64_t)part * ml_params(n_in, n_out);
+          out[at] = gm_;
+          out[wv + at] = gv_;
+        } else {
+          atomicAdd(grad_flat + at, gm_);
+          atomicAdd(grad_flat + wv + at, gv_);
+        }
       }
     }
   }
@@ -785,9 +824,14 @@ static bool mlb_slab_split_forced() {
   return forced;
 }
 
+static int64_t mlb_tiles_end(int64_t rows, int64_t tile_words);
 static int64_t mlb_header_bytes(int64_t rows) {
   const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
   return (((1 + 2 * n_groups) * 4 + 255) & ~(int64_t)255);
+}
+
+static int64_t mlb_tiles_end(int64_t rows, int64_t tile_words) {
+  return (mlb_header_bytes(rows) + ((rows + 15) / 16) * tile_words * 4 + 255) & ~(int64_t)255;
 }
 
 template <int YT, bool RAG>
@@ -806,11 +850,22 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   static DeviceMemo memo_p;
   const int resident_p =
       memo_p.get([](int dev) { return resident_by_occupancy(ml_bwd_prologue_kernel<YT>, 8 * 64, dev, 1); });
-  const int64_t blocks_p = n_groups < resident_p ? n_groups : resident_p;
+  int64_t blocks_p = n_groups < resident_p ? n_groups : resident_p;
+  const bool det = deterministic() && grad_flat != nullptr;
+  float* const det_b =
+      det ? reinterpret_cast<float*>(static_cast<char*>(work) + mlb_tiles_end(rows, HandoverShape<YT>::TILE_WORDS)) : nullptr;
+  float* const det_part = det ? det_b + (int64_t)kMlDetBlocks * 128 : nullptr;
+  const int64_t n_params = ml_params(n_in, n_out), bmo = 2 * (int64_t)n_out * n_in;
+  const int max_l = det ? kMlDetParts / 8 : 32;
+  if (det && blocks_p > kMlDetBlocks) blocks_p = kMlDetBlocks;
   tag_kernel("mnf_linear_bwd");
   hipLaunchKernelGGL((ml_bwd_prologue_kernel<YT>), dim3((unsigned)blocks_p), dim3(8 * 64), 0, stream, gout, sd, eps, seed,
-                     flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f);
+                     flat, fwd_flags, side, flags, list, gscale, grad_flat, rows, n_in, n_out, var_unscale, 1.f, det_b);
   if (int rc = check_launch()) return rc;
+  if (det) {
+    if (int rc = det_reduce_async(det_b, (int)blocks_p, 128, n_out, grad_flat + bmo, stream)) return rc;
+    if (int rc = det_reduce_async(det_b + 64, (int)blocks_p, 128, n_out, grad_flat + bmo + n_out, stream)) return rc;
+  }
   const int n_slabs = (int)S::n_slabs(n_in);
   const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
   int row_parts, grid;
@@ -820,7 +875,7 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
     using T = MlSharedShape<YT>;
     static DeviceMemo memo_s;
     void (*const kernel)(const float*, const float*, float*, float*, float*, const float*, const uint32_t*, const uint32_t*,
-                         const int32_t*, const float*, int64_t, int, int, int, int, int, float) =
+                         const int32_t*, const float*, int64_t, int, int, int, int, int, float, float*) =
         ml_bwd_slab_shared_kernel<YT, RAG>;  // (named out here: a kernel first named inside a lambda gets no host stub)
     const int resident_s = memo_s.get([kernel](int dev) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -833,10 +888,12 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
       return per_cu * device_cus(dev);
     });
     if (resident_s > 0) {
-      plan_slab_launch(n_pairs, 1, (n_slabs + kMlsSlabs - 1) / kMlsSlabs, resident_s, row_parts, grid);
+      plan_slab_launch(n_pairs, 1, (n_slabs + kMlsSlabs - 1) / kMlsSlabs, resident_s, row_parts, grid, max_l);
+      if (det)  // (a row part without pairs writes nothing)
+        if (int rc = zero_floats_async(det_part, row_parts * n_params, stream)) return rc;
       hipLaunchKernelGGL((ml_bwd_slab_shared_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlsWaves * 64), T::LDS_WORDS * 4,
                          stream, x, z, grad_x, grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out,
-                         n_slabs, row_parts, vec2, var_unscale);
+                         n_slabs, row_parts, vec2, var_unscale, det_part);
       if (int rc = check_launch()) return rc;
       launched = true;
     }
@@ -845,12 +902,16 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
     static DeviceMemo memo;
     const int resident = memo.get(
         [](int dev) { return resident_by_occupancy(ml_bwd_slab_kernel<YT, RAG>, kMlbWaves * 64, dev, 2); });
-    plan_slab_launch(n_pairs, kMlbWaves, n_slabs, resident, row_parts, grid);
+    plan_slab_launch(n_pairs, kMlbWaves, n_slabs, resident, row_parts, grid, max_l);
+    if (det)
+      if (int rc = zero_floats_async(det_part, row_parts * n_params, stream)) return rc;
     hipLaunchKernelGGL((ml_bwd_slab_kernel<YT, RAG>), dim3((unsigned)grid), dim3(kMlbWaves * 64), 0, stream, x, z, grad_x,
                        grad_z, grad_flat, flat, bimage, side, flags, gscale, rows, n_in, n_out, n_slabs, row_parts, vec2,
-                       var_unscale);
+                       var_unscale, det_part);
     if (int rc = check_launch()) return rc;
   }
+  if (det)  // the weight blocks of the row parts, in order (the bias sums went out behind the prologue)
+    if (int rc = det_reduce_async(det_part, row_parts, n_params, bmo, grad_flat, stream)) return rc;
   hipLaunchKernelGGL(ml_bwd_fixup_kernel, dim3(256), dim3(256), 0, stream, x, z, gout, sd, eps, seed, grad_x, grad_z,
                      grad_flat, flat, list, rows, n_in, n_out, var_unscale);
   return check_launch();
@@ -870,7 +931,8 @@ int64_t mnf_mnf_linear_bwd_workspace_bytes(int64_t rows, int n_in, int n_out) {
 #define X(YT) if (yt == YT) tile_words = HandoverShape<YT>::TILE_WORDS;
   X(1) X(2) X(3) X(4)
 #undef X
-  return mlb_header_bytes(r) + ((r + 15) / 16) * tile_words * 4;
+  const int64_t det = deterministic() ? ((int64_t)kMlDetBlocks * 128 + kMlDetParts * ml_params(n_in, n_out)) * 4 : 0;
+  return mlb_tiles_end(r, tile_words) + det;
 }
 
 int mnf_mnf_linear_bwd_layout(int n_in, int n_out, int64_t* n_split_words, int64_t* n_plain_words) {

@@ -51,6 +51,10 @@ namespace mnf {
 
 constexpr int kBwdGroupRows = 16 * kRnvpWaves;  // rows per flag (A's 8-wave group)
 constexpr int kBwdBWaves = 4;                   // waves of a B workgroup
+// MNF_DETERMINISTIC (mnf_host.h): launch A's workgroups (at most kDetBlocksA) leave 64 floats each, the slab launches'
+// row parts (at most kDetParts) a block of the layer's parameter count each, behind the tiles of the workspace
+constexpr int kDetBlocksA = 1024, kDetParts = 64;
+__host__ __device__ inline int64_t rnvp_bwd_params(int dm, int hn) { return 3 * (int64_t)dm * hn + hn + 2 * (int64_t)dm; }
 #ifndef MNF_RNVP_BWD_ABL
 #define MNF_RNVP_BWD_ABL 0  // timing experiments only (results are wrong): bit 0 no hand-over loads in B, bit 1 no row
 #endif                      // loads, bit 2 no row-sum MFMAs, bit 3 no grad_z stores, bit 4 no K = units MFMAs
@@ -400,7 +404,8 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
                   const float* __restrict__ gld, const uint32_t* __restrict__ simage, const uint32_t* __restrict__ bimage,
                   uint32_t* __restrict__ side, int32_t* __restrict__ flags, int32_t* __restrict__ list,
                   const float* __restrict__ gscale_dev, float* __restrict__ grad_flat, int64_t rows, int d, int dm_ragged,
-                  int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in) {
+                  int hn, uint64_t seed, int vec_ok, int64_t bimage_tail, const float* __restrict__ y_in,
+                  float* __restrict__ det_bn) {
   using S = RnvpSplitShape<HN>;
   using B [[maybe_unused]] = RnvpBwdShape<HN>;  // (used by the device pass only)
   extern __shared__ __attribute__((aligned(16))) uint32_t a_lds[];  // kBwdRing x RnvpBwdShape::CHUNK_WORDS (101 KB at 64 units)
@@ -441,11 +446,25 @@ rnvp_bwd_a_kernel(const float* __restrict__ z, const float* __restrict__ mask, c
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 8, 64);
-        if (j == 0) atomicAdd(bsum + 16 * m + 4 * q + r, v);
+        bn_acc[m][r] = v;
       }
+    // (det_bn: the waves add in turn and the workgroup's sums go out as its own block of 64, see mnf_host.h)
+    const bool det = det_bn != nullptr;
+    lds_wave_add<kRnvpWaves>(det, (int)(threadIdx.x >> 6), [&](auto op) {
+#pragma unroll
+      for (int m = 0; m < S::YT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j == 0) op(bsum + 16 * m + 4 * q + r, bn_acc[m][r]);
+    });
     __syncthreads();
-    if ((int)threadIdx.x < hn && bsum[threadIdx.x] != 0.f)
-      atomicAdd(grad_flat + (int64_t)hn * dm + threadIdx.x, bsum[threadIdx.x] * (1.f / gscale));
+    if ((int)threadIdx.x < hn) {
+      const float v = bsum[threadIdx.x] * (1.f / gscale);
+      if (det)
+        det_bn[(int64_t)blockIdx.x * 64 + threadIdx.x] = v;
+      else if (v != 0.f)
+        atomicAdd(grad_flat + (int64_t)hn * dm + threadIdx.x, v);
+    }
   }
 }
 
@@ -507,7 +526,8 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
                           const float* __restrict__ gld, float* __restrict__ grad_z, float* __restrict__ grad_flat,
                           const uint32_t* __restrict__ bimage, const uint32_t* __restrict__ side,
                           const int32_t* __restrict__ flags, const float* __restrict__ gscale_dev, int64_t rows, int dm,
-                          int d16, int hn, uint64_t seed, int n_slabs, int row_parts, int vec2) {
+                          int d16, int hn, uint64_t seed, int n_slabs, int row_parts, int vec2,
+                          float* __restrict__ det_part) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   using T = RnvpTsShape<HN>;
@@ -843,16 +863,25 @@ rnvp_bwd_ts_shared_kernel(const float* __restrict__ z, const float* __restrict__
                   bsf = ws + (int64_t)dm * hn;
     const int dim_g = 32 * kTsSlabs * sg;                       // first dim of the group
     const int n_dims = min(32 * kTsSlabs, dm - dim_g);          // dims of this group that exist
+    // (two waves per slab added into the zeroed area: a + b in either order is the same number.  det_part: the item's
+    // sums as plain stores into the row part's block, added up in a fixed order by det_reduce_async)
+    float* const out = det_part ? det_part + (int64_t)part * rnvp_bwd_params(dm, hn) : grad_flat;
+    auto emit = [&](int64_t at, float v) {
+      if (det_part)
+        out[at] = v;
+      else
+        atomicAdd(out + at, v);
+    };
     for (int e = threadIdx.x; e < n_dims * hn; e += blockDim.x) {
       const int dl = e / hn, unit = e - dl * hn;
       const float* rs = red + (dl >> 5) * T::RED_SLAB + (dl & 31) * T::UP + unit;
-      atomicAdd(grad_flat + wt + (int64_t)dim_g * hn + e, rs[0] * inv_gscale);
-      atomicAdd(grad_flat + ws + (int64_t)dim_g * hn + e, rs[32 * T::UP] * inv_gscale);
+      emit(wt + (int64_t)dim_g * hn + e, rs[0] * inv_gscale);
+      emit(ws + (int64_t)dim_g * hn + e, rs[32 * T::UP] * inv_gscale);
     }
     if ((int)threadIdx.x < n_dims) {
       const float* rs = red + (threadIdx.x >> 5) * T::RED_SLAB + 2 * 32 * T::UP + (threadIdx.x & 31);
-      atomicAdd(grad_flat + btf + dim_g + threadIdx.x, rs[0] * inv_gscale);
-      atomicAdd(grad_flat + bsf + dim_g + threadIdx.x, rs[32] * inv_gscale);
+      emit(btf + dim_g + threadIdx.x, rs[0] * inv_gscale);
+      emit(bsf + dim_g + threadIdx.x, rs[32] * inv_gscale);
     }
   }
 }
@@ -865,7 +894,7 @@ __global__ void __launch_bounds__(kBwdBWaves * 64, 4)
 rnvp_bwd_n_kernel(const float* __restrict__ z, const float* __restrict__ mask, float* __restrict__ grad_flat,
                   const uint32_t* __restrict__ side, const int32_t* __restrict__ flags,
                   const float* __restrict__ gscale_dev, int64_t rows, int dm, int hn, uint64_t seed, int n_slabs,
-                  int row_parts, int vec2) {
+                  int row_parts, int vec2, float* __restrict__ det_part) {
   using S = RnvpSplitShape<HN>;
   using B = RnvpBwdShape<HN>;
   constexpr int YT = S::YT;
@@ -961,17 +990,26 @@ rnvp_bwd_n_kernel(const float* __restrict__ z, const float* __restrict__ mask, f
     __syncthreads();
     for (int i = threadIdx.x; i < 16 * YT * 33; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
+    lds_wave_add<kBwdBWaves>(det_part != nullptr, wave, [&](auto op) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int m = 0; m < YT; ++m)
+        for (int m = 0; m < YT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(red + (16 * m + 4 * q + r) * 33 + 2 * j + dt, aWn[dt][m][r]);
+          for (int r = 0; r < 4; ++r) op(red + (16 * m + 4 * q + r) * 33 + 2 * j + dt, aWn[dt][m][r]);
+    });
     __syncthreads();
     const int n_dims = min(32, dm - 32 * slab);
+    float* const out = det_part ? det_part + (int64_t)part * rnvp_bwd_params(dm, hn) : grad_flat;
     for (int e = threadIdx.x; e < hn * 32; e += blockDim.x) {
       const int unit = e >> 5, dl = e & 31;
-      if (dl < n_dims) atomicAdd(grad_flat + (int64_t)unit * dm + 32 * slab + dl, red[unit * 33 + dl] * inv_gscale);
+      if (dl < n_dims) {
+        const float v = red[unit * 33 + dl] * inv_gscale;
+        if (det_part)
+          out[(int64_t)unit * dm + 32 * slab + dl] = v;
+        else
+          atomicAdd(out + (int64_t)unit * dm + 32 * slab + dl, v);
+      }
     }
   }
 }
@@ -1039,8 +1077,13 @@ static int64_t bwd_header_bytes(int64_t rows) {
   return (((1 + 2 * n_groups) * 4 + 255) & ~(int64_t)255);
 }
 template <int HN>
-static int64_t bwd_workspace_bytes(int64_t rows) {
-  return bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4;
+static int64_t bwd_tiles_end(int64_t rows) {
+  return (bwd_header_bytes(rows) + ((rows + 15) / 16) * RnvpBwdShape<HN>::TILE_WORDS * 4 + 255) & ~(int64_t)255;
+}
+template <int HN>
+static int64_t bwd_workspace_bytes(int64_t rows, int dm, int hn) {
+  const int64_t det = deterministic() ? ((int64_t)kDetBlocksA * 64 + kDetParts * rnvp_bwd_params(dm, hn)) * 4 : 0;
+  return bwd_tiles_end<HN>(rows) + det;
 }
 
 // phases: bit 0 launch A, bit 1 B-ts, bit 2 B-n (bit 3, the fp32 fix-up, is the caller's)
@@ -1058,7 +1101,7 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
   constexpr int a_lds_bytes = kBwdRing * B::CHUNK_WORDS * 4;
   void (*const a_kernel)(const float*, const float*, const float*, const float*, const uint32_t*, const uint32_t*, uint32_t*,
                          int32_t*, int32_t*, const float*, float*, int64_t, int, int, int, uint64_t, int, int64_t,
-                         const float*) = rnvp_bwd_a_kernel<HN, SEEDED, RAG>;
+                         const float*, float*) = rnvp_bwd_a_kernel<HN, SEEDED, RAG>;
   const int resident_a = memo_a.get([a_kernel](int dev) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             a_lds_bytes) != hipSuccess)
@@ -1069,22 +1112,30 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     return per_cu * device_cus(dev);
   });
   if (resident_a < 0) return MNF_ERR_UNSUPPORTED;
-  const int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
+  int64_t blocks_a = n_groups < resident_a ? n_groups : resident_a;
+  const bool det = deterministic() && grad_flat != nullptr;
+  float* const det_bn = det ? reinterpret_cast<float*>(static_cast<char*>(work) + bwd_tiles_end<HN>(rows)) : nullptr;
+  float* const det_part = det ? det_bn + (int64_t)kDetBlocksA * 64 : nullptr;
+  const int64_t n_params = rnvp_bwd_params(dm, hn);
+  const int max_l = det ? kDetParts / 8 : 32;
+  if (det && blocks_a > kDetBlocksA) blocks_a = kDetBlocksA;
   const int64_t tail = B::split_words(dm, d16) + B::plain_words(dm);
   if (phases & 1) {
   if (int rc = zero_word_async(list, stream)) return rc;
   tag_kernel("rnvp_bwd_mfma");
   hipLaunchKernelGGL((rnvp_bwd_a_kernel<HN, SEEDED, RAG>), dim3((unsigned)blocks_a), dim3(kRnvpWaves * 64), a_lds_bytes, stream, z,
                      mask, gx, gld, simage, bimage, side, flags, list, gscale, grad_flat, rows, d16, dm, hn, seed, vec4, tail,
-                     y_in);
+                     y_in, det_bn);
   if (int rc = check_launch()) return rc;
+  if (det)
+    if (int rc = det_reduce_async(det_bn, (int)blocks_a, 64, hn, grad_flat + (int64_t)hn * dm, stream)) return rc;
   }
   // B: (row part, slab) work items over a persistent grid.  Row parts come in multiples of 8 (one XCD each, see
   // BwdItems); their number per XCD is chosen so that the XCD's items fill whole rounds of its resident workgroups.
   const int n_slabs = (int)B::n_slabs(dm);
   const int64_t n_pairs = ((rows + 15) / 16 + 1) / 2;
   auto plan = [&](int resident, int& row_parts, int& grid) {
-    plan_slab_launch(n_pairs, kBwdBWaves, n_slabs, resident, row_parts, grid);
+    plan_slab_launch(n_pairs, kBwdBWaves, n_slabs, resident, row_parts, grid, max_l);
   };
   static DeviceMemo memo_n;
   int row_parts, grid;
@@ -1093,8 +1144,8 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     using T = RnvpTsShape<HN>;
     static DeviceMemo memo_s;
     void (*const ts_kernel)(const float*, const float*, const float*, const float*, float*, float*, const uint32_t*,
-                            const uint32_t*, const int32_t*, const float*, int64_t, int, int, int, uint64_t, int, int, int) =
-        rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>;  // (named out here: a kernel first named inside a lambda gets no host stub)
+                            const uint32_t*, const int32_t*, const float*, int64_t, int, int, int, uint64_t, int, int, int,
+                            float*) = rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>;  // (named out here: a kernel first named inside a lambda gets no host stub)
     const int resident_s = memo_s.get([ts_kernel](int dev) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(ts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS_WORDS * 4) != hipSuccess)
@@ -1107,19 +1158,28 @@ static int launch_bwd(const float* z, const float* mask, uint64_t seed, const fl
     });
     if (resident_s < 0) return MNF_ERR_LAUNCH;  // (the LDS request was refused: not an MI355X)
     const int n_slab_groups = (n_slabs + kTsSlabs - 1) / kTsSlabs;
-    plan_slab_launch(n_pairs, 1, n_slab_groups, resident_s, row_parts, grid);
+    plan_slab_launch(n_pairs, 1, n_slab_groups, resident_s, row_parts, grid, max_l);
+    if (det)  // (a row part without pairs writes nothing)
+      if (int rc = zero_floats_async(det_part, row_parts * n_params, stream)) return rc;
     hipLaunchKernelGGL((rnvp_bwd_ts_shared_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kTsWaves * 64),
                        T::LDS_WORDS * 4, stream, z, mask, gx, gld, grad_z, grad_flat, bimage, side, flags, gscale, rows,
-                       dm, d16, hn, seed, n_slabs, row_parts, vec2);
+                       dm, d16, hn, seed, n_slabs, row_parts, vec2, det_part);
     if (int rc = check_launch()) return rc;
+    if (det) {
+      const int64_t wt = (int64_t)hn * dm + hn;
+      if (int rc = det_reduce_async(det_part + wt, row_parts, n_params, n_params - wt, grad_flat + wt, stream)) return rc;
+    }
   }
   if (!grad_flat || !(phases & 4)) return MNF_OK;
   const int resident_n = memo_n.get(
       [](int dev) { return resident_by_occupancy(rnvp_bwd_n_kernel<HN, SEEDED, RAG>, kBwdBWaves * 64, dev, 4); });
   plan(resident_n, row_parts, grid);
+  if (det)
+    if (int rc = zero_floats_async(det_part, row_parts * n_params, stream)) return rc;
   hipLaunchKernelGGL((rnvp_bwd_n_kernel<HN, SEEDED, RAG>), dim3((unsigned)grid), dim3(kBwdBWaves * 64), 0, stream, z,
-                     mask, grad_flat, side, flags, gscale, rows, dm, hn, seed, n_slabs, row_parts, vec2);
-  return check_launch();
+                     mask, grad_flat, side, flags, gscale, rows, dm, hn, seed, n_slabs, row_parts, vec2, det_part);
+  if (int rc = check_launch()) return rc;
+  return det ? det_reduce_async(det_part, row_parts, n_params, (int64_t)hn * dm, grad_flat, stream) : MNF_OK;
 }
 
 }  // namespace mnf
@@ -1130,7 +1190,7 @@ using namespace mnf;
 
 int64_t mnf_rnvp_bwd_mfma_workspace_bytes(int64_t rows, int dim, int n_hidden, const int* hidden) {
   if (rows < 0 || !rnvp_shape_ok(dim, n_hidden, hidden)) return 0;
-#define X(HN) if (rnvp_padded_hidden(n_hidden, hidden) == HN) return bwd_workspace_bytes<HN>(rows < 1 ? 1 : rows);
+#define X(HN) if (rnvp_padded_hidden(n_hidden, hidden) == HN) return bwd_workspace_bytes<HN>(rows < 1 ? 1 : rows, dim, hidden[0]);
   MNF_RNVP_HIDDEN(X)
 #undef X
   return 0;

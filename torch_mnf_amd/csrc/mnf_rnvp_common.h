@@ -383,7 +383,8 @@ struct SlabItems {
 };
 // host: row parts and grid of such a launch.  Row parts come in multiples of 8 (one XCD each); their number per XCD
 // is chosen so that the XCD's items fill whole rounds of its resident workgroups.
-inline void plan_slab_launch(int64_t n_pairs, int waves, int n_slabs, int resident, int& row_parts, int& grid) {
+inline void plan_slab_launch(int64_t n_pairs, int waves, int n_slabs, int resident, int& row_parts, int& grid,
+                             int max_l = 32) {
   const int64_t max_parts = (n_pairs + waves - 1) / waves;  // at least one pair per wave
   if (max_parts < 8) {
     row_parts = (int)(max_parts < 1 ? 1 : max_parts);
@@ -393,7 +394,7 @@ inline void plan_slab_launch(int64_t n_pairs, int waves, int n_slabs, int reside
   const int wgs_xcd = resident / 8 > 0 ? resident / 8 : 1;
   int best_l = 1;
   double best_fill = 0.0;
-  for (int l = 1; l <= 32 && (int64_t)l * 8 <= max_parts; ++l) {
+  for (int l = 1; l <= max_l && (int64_t)l * 8 <= max_parts; ++l) {
     const int items = l * n_slabs, rounds = (items + wgs_xcd - 1) / wgs_xcd;
     const double fill = (double)items / ((double)rounds * wgs_xcd);
     if (fill > best_fill + 0.02) {  // (prefer fewer parts -- fewer flushes -- unless the fill improves by > 2 %)

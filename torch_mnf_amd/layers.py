@@ -150,7 +150,13 @@ class _SampleZ0Fn(torch.autograd.Function):
         dim, home = log_var.numel(), ctx.home
         out = home[0].grad[home[1]:home[1] + home[2]] if home is not None else torch.zeros(2 * dim, device=log_var.device)
         g = grad_z0.contiguous()
-        if eps is None:
+        if _lib.deterministic():  # MNF_DETERMINISTIC=1: the sums over the rows in a fixed order
+            n_ws = _lib.load().mnf_sample_z0_bwd_workspace(g.shape[0], dim)
+            ws = torch.empty(max(int(n_ws), 1), dtype=torch.float32, device=g.device)
+            _lib.check("mnf_sample_z0_bwd_det", _lib.load().mnf_sample_z0_bwd_det(
+                g.data_ptr(), None if eps is None else eps.data_ptr(), ctx.seed, log_var.data_ptr(), out.data_ptr(),
+                out.data_ptr() + 4 * dim, g.shape[0], dim, ws.data_ptr(), ws.numel(), _stream()))
+        elif eps is None:
             _lib.check("mnf_sample_z0_seeded_bwd", _lib.load().mnf_sample_z0_seeded_bwd(
                 g.data_ptr(), ctx.seed, log_var.data_ptr(), out.data_ptr(), out.data_ptr() + 4 * dim, g.shape[0], dim,
                 _stream()))
