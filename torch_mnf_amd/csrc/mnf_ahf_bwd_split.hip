@@ -624,11 +624,24 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     };
     const f16x8 ones8 = __builtin_shufflevector(ones, ones, 0, 1, 2, 3, 4, 5, 6, 7);
     // one weight-gradient tile += delta^T a (all four split products), one bias-gradient tile += delta^T ones
+    // MNF_BS_ABL (timing-only builds, tools/lib_variant.sh; results are wrong): 1 = no weight-gradient phase at all,
+    // 2 = the transposes without the products, 4 = the products without the transposes' conversions feeding them
+#ifndef MNF_BS_ABL
+#define MNF_BS_ABL 0
+#endif
     auto outer = [&](auto t, const f16x8& d_hl, const f16x8& a_hh, const f16x8& a_ll) {
-      acc_outer32<decltype(t)::value>(d_hl, a_hh, a_ll);
+      if (MNF_BS_ABL & 2)
+        asm volatile("" ::"v"(d_hl), "v"(a_hh), "v"(a_ll));
+      else
+        acc_outer32<decltype(t)::value>(d_hl, a_hh, a_ll);
     };
-    auto bias = [&](auto t, const f16x8& d_hl) { acc_bias32<F::DW_TILES + decltype(t)::value>(d_hl, ones8); };
-    {
+    auto bias = [&](auto t, const f16x8& d_hl) {
+      if (MNF_BS_ABL & 2)
+        asm volatile("" ::"v"(d_hl));
+      else
+        acc_bias32<F::DW_TILES + decltype(t)::value>(d_hl, ones8);
+    };
+    if (!(MNF_BS_ABL & 1)) {
       // output layer: delta 4 (2 G tiles) x h3 (NT tiles)
       f16x8 a_hh[NT], a_ll[NT], d_hl[2 * G > NT ? 2 * G : NT];
 #pragma unroll
