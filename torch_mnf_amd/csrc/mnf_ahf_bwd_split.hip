@@ -272,6 +272,123 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     }
     n_gl = gl_or_x[rowc];
   };
+  // ------------------------------------------------------------------ weight gradients: rows on the K axis
+  // The split tiles of a row tile that its weight-gradient products read.  MNF_BS_PIPE: the products of tile i are
+  // issued between the forward stages of tile i + 1 (each block in front of the stage that replaces its activations):
+  // independent matrix work next to the forward pass's vector work, for the one wave of the SIMD.
+#ifndef MNF_BS_PIPE
+#define MNF_BS_PIPE 0
+#endif
+  using std::integral_constant;
+  u32x2 xh[G], xl[G], hh[3][NT], hl[3][NT];
+  u32x2 d4h[2 * G], d4l[2 * G], dh[3][NT], dl_[3][NT];  // dh[2] = delta 3 (pre-activation of h3), dh[0] = delta 1
+  u32x2 pxh[G], pxl[G];
+  auto zero_kept = [&] {
+#pragma unroll
+    for (int g = 0; g < G; ++g) xh[g] = xl[g] = pxh[g] = pxl[g] = zero2;
+#pragma unroll
+    for (int c = 0; c < 2 * G; ++c) d4h[c] = d4l[c] = zero2;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < NT; ++m) hh[l][m] = hl[l][m] = dh[l][m] = dl_[l][m] = zero2;
+  };
+  if (MNF_BS_PIPE) zero_kept();
+  // T(v): the tile with rows along the registers: lane (unit = j, q) holds rows 4 q .. 4 q + 3, head and residual
+  auto transpose = [&](const u32x2& hi, const u32x2& lo, f16x4& th, f16x4& tl) {
+    const f32x4 o = mfma_x16(as_f16x4(hi), ident, zero4);
+    const f32x4 ol = mfma_x16(as_f16x4(lo), ident_lo, zero4);  // (lo 2^-11: the residual itself)
+    th = __builtin_convertvector(o, f16x4);
+    tl = __builtin_convertvector(ol, f16x4);
+  };
+  // a delta tile as the A operand [head | residual] of the K = 32 products, an activation tile as the two B operands
+  // [head | head], [residual | residual]
+  auto delta_op = [&](const u32x2& hi, const u32x2& lo) -> f16x8 {
+    f16x4 th, tl;
+    transpose(hi, lo, th, tl);
+    return __builtin_shufflevector(th, tl, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto act_ops = [&](const u32x2& hi, const u32x2& lo, f16x8& hh_, f16x8& ll_) {
+    f16x4 th, tl;
+    transpose(hi, lo, th, tl);
+    hh_ = __builtin_shufflevector(th, th, 0, 1, 2, 3, 4, 5, 6, 7);
+    ll_ = __builtin_shufflevector(tl, tl, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  const f16x8 ones8 = __builtin_shufflevector(ones, ones, 0, 1, 2, 3, 4, 5, 6, 7);
+  // MNF_BS_ABL (timing-only builds, tools/lib_variant.sh; results are wrong): 1 = no weight-gradient phase at all,
+  // 2 = the transposes without the products
+#ifndef MNF_BS_ABL
+#define MNF_BS_ABL 0
+#endif
+  // one weight-gradient tile += delta^T a (all four split products), one bias-gradient tile += delta^T ones
+  auto outer = [&](auto t, const f16x8& d_hl, const f16x8& a_hh, const f16x8& a_ll) {
+    if (MNF_BS_ABL & 2)
+      asm volatile("" ::"v"(d_hl), "v"(a_hh), "v"(a_ll));
+    else
+      acc_outer32<decltype(t)::value>(d_hl, a_hh, a_ll);
+  };
+  auto bias = [&](auto t, const f16x8& d_hl) {
+    if (MNF_BS_ABL & 2)
+      asm volatile("" ::"v"(d_hl));
+    else
+      acc_bias32<F::DW_TILES + decltype(t)::value>(d_hl, ones8);
+  };
+  // output layer: delta 4 (2 G tiles) x h3 (NT tiles)
+  auto w_out = [&] {
+    if (MNF_BS_ABL & 1) return;
+    f16x8 a_hh[NT], a_ll[NT], d_hl[2 * G];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) act_ops(hh[2][m], hl[2][m], a_hh[m], a_ll[m]);
+#pragma unroll
+    for (int c = 0; c < 2 * G; ++c) d_hl[c] = delta_op(d4h[c], d4l[c]);
+    bs_static_for<2 * G>([&](auto mo_c) {
+      constexpr int mo = decltype(mo_c)::value;
+      bias(integral_constant<int, DB_OUT + mo>{}, d_hl[mo]);
+      bs_static_for<NT>([&](auto mi_c) {
+        constexpr int mi = decltype(mi_c)::value;
+        if constexpr (O::out_used(mo, mi))
+          outer(integral_constant<int, DW_OUT + O::out_rank(mo, mi)>{}, d_hl[mo], a_hh[mi], a_ll[mi]);
+      });
+    });
+  };
+  // hidden layer W_2 (h2 -> h3, l = 2): delta 3 x h2;  W_1 (h1 -> h2, l = 1): delta 2 x h1
+  auto w_hid = [&](auto lc) {
+    if (MNF_BS_ABL & 1) return;
+    constexpr int l = decltype(lc)::value;
+    f16x8 a_hh[NT], a_ll[NT], d_hl[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      d_hl[m] = delta_op(dh[l][m], dl_[l][m]);
+      act_ops(hh[l - 1][m], hl[l - 1][m], a_hh[m], a_ll[m]);
+    }
+    bs_static_for<NT>([&](auto mo_c) {
+      constexpr int mo = decltype(mo_c)::value;
+      bias(integral_constant<int, (l == 2 ? DB_H2 : DB_H1) + mo>{}, d_hl[mo]);
+      bs_static_for<NT>([&](auto mi_c) {
+        constexpr int mi = decltype(mi_c)::value;
+        if constexpr (F::needs(mo, mi))
+          outer(integral_constant<int, (l == 2 ? DW_H2 : DW_H1) + O::hid_rank(mo, mi)>{}, d_hl[mo], a_hh[mi], a_ll[mi]);
+      });
+    });
+  };
+  // layer 1: delta 1 x x0
+  auto w_l1 = [&](const u32x2* xh_, const u32x2* xl_) {
+    if (MNF_BS_ABL & 1) return;
+    f16x8 x_hh[G], x_ll[G], d_hl[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) d_hl[m] = delta_op(dh[0][m], dl_[0][m]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) act_ops(xh_[g], xl_[g], x_hh[g], x_ll[g]);
+    bs_static_for<NT>([&](auto mo_c) {
+      constexpr int mo = decltype(mo_c)::value;
+      bias(integral_constant<int, DB_L1 + mo>{}, d_hl[mo]);
+      bs_static_for<G>([&](auto mi_c) {
+        constexpr int mi = decltype(mi_c)::value;
+        outer(integral_constant<int, DW_L1 + mo * G + mi>{}, d_hl[mo], x_hh[mi], x_ll[mi]);
+      });
+    });
+  };
+
   const int first_tile = (int)blockIdx.x * kBsWaves + wave;
   load_rows(first_tile < n_tiles ? first_tile : 0);
   for (int tile = first_tile; tile < n_tiles; tile += tile_step) {
@@ -334,7 +451,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
         ++op;
       }
     };
-    using std::integral_constant;
     constexpr int N_OUT = [] {
       int n = 0;
       for (int net = 0; net < 2; ++net)
@@ -345,11 +461,11 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     constexpr int N_T4 = B::t4_ops(), N_T1 = B::t1_ops();
 
     // ------------------------------------------------------------------ forward recompute (split_conditioner's order)
-    u32x2 xh[G], xl[G], hh[3][NT], hl[3][NT];
     {
       f16x8 ah[N1], al[N1];
       read_ops(integral_constant<int, N1>{}, ah, al);
       fence();
+      if (MNF_BS_PIPE) w_hid(integral_constant<int, 1>{});  // (the previous tile's delta 2 x h1, before h1 is replaced)
 #pragma unroll
       for (int g = 0; g < G; ++g) split_tile(cnd[g], xh[g], xl[g], mx);
       fence_v();
@@ -383,6 +499,10 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       for (int l = 1; l <= 2; ++l) {
         f16x8* const ahl = ah2;
         f16x8* const all_ = al2;
+        if (MNF_BS_PIPE) {  // the previous tile's delta 3 x h2 before h2 is replaced, delta 4 x h3 before h3 is
+          if (l == 1) w_hid(integral_constant<int, 2>{});
+          else w_out();
+        }
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           mn[m] = B4[4 * (l * NT + m)];
@@ -453,6 +573,7 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     //  overwrites it -- same stream, later)
     f32x4 d4[2 * G];  // [s tiles | t tiles]
     float* const gr = grad_x + rowc * dim + 4 * q;
+    if (MNF_BS_PIPE) w_l1(pxh, pxl);  // (the previous tile's delta 1 x x0, before the delta chain replaces delta 1)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       f32x4 gv;
@@ -475,7 +596,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     }
 
     // ------------------------------------------------------------------ the delta chain through the transposed weights
-    u32x2 d4h[2 * G], d4l[2 * G], dh[3][NT], dl_[3][NT];  // dh[2] = delta 3 (pre-activation of h3), dh[0] = delta 1
     read_ops(integral_constant<int, N_T4>{}, t4h, t4l);  // (not earlier: the delta arithmetic above is where the
     fence();                                               //  register demand peaks)
 #pragma unroll
@@ -599,98 +719,28 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
           }
         }
       }
+      if (MNF_BS_PIPE) zero_kept();  // (this tile adds nothing: its products would run during the next tile)
       continue;
     }
     // ------------------------------------------------------------------ weight gradients: rows on the K axis
-    // T(v): the tile with rows along the registers: lane (unit = j, q) holds rows 4 q .. 4 q + 3, head and residual
-    auto transpose = [&](const u32x2& hi, const u32x2& lo, f16x4& th, f16x4& tl) {
-      const f32x4 o = mfma_x16(as_f16x4(hi), ident, zero4);
-      const f32x4 ol = mfma_x16(as_f16x4(lo), ident_lo, zero4);  // (lo 2^-11: the residual itself)
-      th = __builtin_convertvector(o, f16x4);
-      tl = __builtin_convertvector(ol, f16x4);
-    };
-    // a delta tile as the A operand [head | residual] of the K = 32 products, an activation tile as the two B operands
-    // [head | head], [residual | residual]
-    auto delta_op = [&](const u32x2& hi, const u32x2& lo) -> f16x8 {
-      f16x4 th, tl;
-      transpose(hi, lo, th, tl);
-      return __builtin_shufflevector(th, tl, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    auto act_ops = [&](const u32x2& hi, const u32x2& lo, f16x8& hh_, f16x8& ll_) {
-      f16x4 th, tl;
-      transpose(hi, lo, th, tl);
-      hh_ = __builtin_shufflevector(th, th, 0, 1, 2, 3, 4, 5, 6, 7);
-      ll_ = __builtin_shufflevector(tl, tl, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    const f16x8 ones8 = __builtin_shufflevector(ones, ones, 0, 1, 2, 3, 4, 5, 6, 7);
-    // one weight-gradient tile += delta^T a (all four split products), one bias-gradient tile += delta^T ones
-    // MNF_BS_ABL (timing-only builds, tools/lib_variant.sh; results are wrong): 1 = no weight-gradient phase at all,
-    // 2 = the transposes without the products, 4 = the products without the transposes' conversions feeding them
-#ifndef MNF_BS_ABL
-#define MNF_BS_ABL 0
-#endif
-    auto outer = [&](auto t, const f16x8& d_hl, const f16x8& a_hh, const f16x8& a_ll) {
-      if (MNF_BS_ABL & 2)
-        asm volatile("" ::"v"(d_hl), "v"(a_hh), "v"(a_ll));
-      else
-        acc_outer32<decltype(t)::value>(d_hl, a_hh, a_ll);
-    };
-    auto bias = [&](auto t, const f16x8& d_hl) {
-      if (MNF_BS_ABL & 2)
-        asm volatile("" ::"v"(d_hl));
-      else
-        acc_bias32<F::DW_TILES + decltype(t)::value>(d_hl, ones8);
-    };
-    if (!(MNF_BS_ABL & 1)) {
-      // output layer: delta 4 (2 G tiles) x h3 (NT tiles)
-      f16x8 a_hh[NT], a_ll[NT], d_hl[2 * G > NT ? 2 * G : NT];
+    if (MNF_BS_PIPE) {  // issued between the NEXT tile's forward stages; the conditioning half's split form moves aside
 #pragma unroll
-      for (int m = 0; m < NT; ++m) act_ops(hh[2][m], hl[2][m], a_hh[m], a_ll[m]);
-#pragma unroll
-      for (int c = 0; c < 2 * G; ++c) d_hl[c] = delta_op(d4h[c], d4l[c]);
-      bs_static_for<2 * G>([&](auto mo_c) {
-        constexpr int mo = decltype(mo_c)::value;
-        bias(integral_constant<int, DB_OUT + mo>{}, d_hl[mo]);
-        bs_static_for<NT>([&](auto mi_c) {
-          constexpr int mi = decltype(mi_c)::value;
-          if constexpr (O::out_used(mo, mi))
-            outer(integral_constant<int, DW_OUT + O::out_rank(mo, mi)>{}, d_hl[mo], a_hh[mi], a_ll[mi]);
-        });
-      });
-      // hidden layer W_2 (h2 -> h3): delta 3 x h2;  W_1 (h1 -> h2): delta 2 x h1
-      bs_static_for<2>([&](auto lc) {
-        constexpr int l = 2 - decltype(lc)::value;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-          d_hl[m] = delta_op(dh[l][m], dl_[l][m]);
-          act_ops(hh[l - 1][m], hl[l - 1][m], a_hh[m], a_ll[m]);
-        }
-        bs_static_for<NT>([&](auto mo_c) {
-          constexpr int mo = decltype(mo_c)::value;
-          bias(integral_constant<int, (l == 2 ? DB_H2 : DB_H1) + mo>{}, d_hl[mo]);
-          bs_static_for<NT>([&](auto mi_c) {
-            constexpr int mi = decltype(mi_c)::value;
-            if constexpr (F::needs(mo, mi))
-              outer(integral_constant<int, (l == 2 ? DW_H2 : DW_H1) + O::hid_rank(mo, mi)>{}, d_hl[mo], a_hh[mi],
-                    a_ll[mi]);
-          });
-        });
-      });
-      // layer 1: delta 1 x x0
-      f16x8 x_hh[G], x_ll[G];
-#pragma unroll
-      for (int m = 0; m < NT; ++m) d_hl[m] = delta_op(dh[0][m], dl_[0][m]);
-#pragma unroll
-      for (int g = 0; g < G; ++g) act_ops(xh[g], xl[g], x_hh[g], x_ll[g]);
-      bs_static_for<NT>([&](auto mo_c) {
-        constexpr int mo = decltype(mo_c)::value;
-        bias(integral_constant<int, DB_L1 + mo>{}, d_hl[mo]);
-        bs_static_for<G>([&](auto mi_c) {
-          constexpr int mi = decltype(mi_c)::value;
-          outer(integral_constant<int, DW_L1 + mo * G + mi>{}, d_hl[mo], x_hh[mi], x_ll[mi]);
-        });
-      });
+      for (int g = 0; g < G; ++g) {
+        pxh[g] = xh[g];
+        pxl[g] = xl[g];
+      }
+    } else {
+      w_out();
+      w_hid(integral_constant<int, 2>{});
+      w_hid(integral_constant<int, 1>{});
+      w_l1(xh, xl);
     }
+  }
+  if (MNF_BS_PIPE) {  // the last tile's products
+    w_out();
+    w_hid(integral_constant<int, 2>{});
+    w_hid(integral_constant<int, 1>{});
+    w_l1(pxh, pxl);
   }
 
   // ------------------------------------------------------------------ flush: sum over the waves in LDS, one atomic per parameter
