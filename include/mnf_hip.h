@@ -218,7 +218,7 @@ int mnf_rqs(const float* inputs, const float* W, const float* H, const float* D,
 /* -------------------------------------------------------------- RNVP (masked/gated) */
 /* mask: (rows, dim) floats in {0,1}, supplied by the caller (the reference draws
  * torch.bernoulli per call, rnvp.py:28).  net = MLP(dim, hidden...); t, s = Linear(h_last, dim).
- * MFMA kernels (image / split_image given): one hidden layer of at most 50 units (run at 30 or 50 with structural
+ * MFMA kernels (image / split_image given): one hidden layer of at most 64 units (run at 30, 50 or 64 with structural
  * zeros), any dim >= 49 (dim % 16 != 0: zero-padded operand images, masked row accesses; the padded dims' scale bias
  * is the constant 80 so that they add nothing to log_det); the generic kernel (flat) otherwise. */
 int mnf_rnvp(const float* z, const float* mask, float* x, float* log_det, int accumulate,
@@ -602,7 +602,7 @@ int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* 
                  int64_t rows, int dim, int n_hidden, const int* hidden_host, void* stream);
 /* The same gradients (flows/rnvp.py:25-39 under loss.backward(); what layers/mnf_linear.py:58-64,84 and
  * tests/test_mnf_mnist.py:14-56 train through) on the matrix cores in split arithmetic, for the shapes the split
- * forward kernels cover (one hidden layer of width <= 50, padded dim >= 64).  Two launches: a row-parallel one that
+ * forward kernels cover (one hidden layer of width <= 64, padded dim >= 64).  Two launches: a row-parallel one that
  * recomputes y, forms g_y and hands both over as MFMA operands (1 KB per row in `workspace`), and one in which a
  * workgroup owns 32 dims and a range of rows (grad_z; dWt, dWs, dWn, dbt, dbs as sums over rows in registers); row
  * groups outside the split range are redone by mnf_rnvp_bwd's kernel on those groups only.

@@ -214,7 +214,7 @@ def test_affine_half_index_tables_for_padded_hidden_widths(lib, dim, h_sizes):
 
 
 @pytest.mark.parametrize("dim,hid", [(64, 50), (800, 50), (784, 50), (800, 30), (50, 50), (49, 30), (100, 30), (790, 50),
-                                     (800, 20), (64, 7), (100, 41), (50, 1)])
+                                     (800, 20), (64, 7), (100, 41), (50, 1), (800, 64), (100, 57)])
 def test_rnvp_split_index_covers_every_parameter(lib, dim, hid):
     from torch_mnf_amd._lib import int_array
 

@@ -204,9 +204,9 @@ def test_affine_half_mfma_shape_matrix(amd, O, dim, hid, kernel):
 @pytest.mark.parametrize("kernel", ["split", "fp32"])
 @pytest.mark.parametrize("dim,hid", [(64, 30), (800, 30), (128, 50), (784, 50), (80, 30),
                                      (50, 50), (49, 30), (70, 50), (100, 50), (130, 30), (500, 50), (790, 50),
-                                     (800, 20), (64, 7), (100, 41), (50, 1)])
+                                     (800, 20), (64, 7), (100, 41), (50, 1), (800, 64), (100, 57), (50, 64)])
 def test_rnvp_mfma_shape_matrix(amd, O, dim, hid, kernel):
-    """(dim, hidden width) pairs of the MFMA kernels (a hidden width other than 30 / 50 runs at the next one up with
+    """(dim, hidden width) pairs of the MFMA kernels (a hidden width other than 30 / 50 / 64 runs at the next one up with
     structural-zero units); dim % 16 != 0 (MNFLinear(50, 10)'s flow, MNFFeedForward's
     100 / 500-wide layers) runs the ragged variants: zero-padded operand image, masked row accesses (16-byte
     when dim % 4 == 0, else element by element), padded scale bias such that nothing reaches log_det."""

@@ -245,7 +245,7 @@ def _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask=None, seed=None, generi
 
 
 @pytest.mark.parametrize("dim,hid,rows", [(800, 50, 70), (800, 50, 1000), (50, 50, 129), (64, 30, 33), (784, 50, 300),
-                                          (100, 17, 257), (96, 50, 1), (128, 8, 4099)])
+                                          (100, 17, 257), (96, 50, 1), (128, 8, 4099), (800, 64, 300), (100, 57, 131), (96, 64, 1)])
 @pytest.mark.parametrize("masked", ["explicit", "seeded"])
 def test_rnvp_mfma_gradient_kernels(amd, O, dim, hid, rows, masked):
     """mnf_rnvp_bwd_mfma (row-parallel launch A + dims-slab launch B) against autograd through the oracle in float64

@@ -85,7 +85,7 @@ def main():
                 f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
                 rows.append(("NSF_CL", f"dim={dim} K={K} n_h={n_h}", dim, *probe(f, dim, lambda m, x: m.inverse(x))))
     for dim in (50, 128, 784, 800, 1024, 2048):
-        for h in (50, 30, 64):
+        for h in (50, 30, 64, 100):
             f = amd.RNVP(dim, h_sizes=(h,))
             rows.append(("RNVP", f"dim={dim} hidden=({h},)", dim, *probe(f, dim, lambda m, x: m.forward(x, seed=3))))
     print(f"{'layer':15s} {'shape':30s} {'forward kernel':16s} {'ns/row':>8s} {'generic':>8s} {'x':>6s}   {'gradient kernel':20s} "

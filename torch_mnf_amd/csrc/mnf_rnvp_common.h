@@ -408,12 +408,13 @@ inline void plan_slab_launch(int64_t n_pairs, int waves, int n_slabs, int reside
 }
 
 // ---------------------------------------------------------------- host: shapes and the split image's index table
-// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes) and 30 (RNVP's default); any other width up
-// to 50 runs at the next one up with structural-zero units (rnvp_padded_hidden)
-#define MNF_RNVP_HIDDEN(X) X(50) X(30)
+// hidden widths with an instantiated kernel: 50 (MNFLinear's h_sizes), 30 (RNVP's default) and 64 (the widest the
+// four-tile layout holds); any other width up to 64 runs at the next one up with structural-zero units
+// (rnvp_padded_hidden).  50 and 64 share the split kernels' shape (four 16-unit tiles); the fp32 kernels differ.
+#define MNF_RNVP_HIDDEN(X) X(50) X(30) X(64)
 inline int rnvp_padded_hidden(int n_hidden, const int* hidden) {
   if (n_hidden != 1 || !hidden || hidden[0] < 1) return 0;
-  return hidden[0] <= 30 ? 30 : hidden[0] <= 50 ? 50 : 0;
+  return hidden[0] <= 30 ? 30 : hidden[0] <= 50 ? 50 : hidden[0] <= 64 ? 64 : 0;
 }
 
 

@@ -348,7 +348,7 @@ class MNFLinear(nn.Module):
         self.fuse_prologue = True  # sample_z: form z0 inside the first flow's kernel when that kernel exists
 
     def _fused_prologue_ok(self, flow, eps) -> bool:
-        """The first flow's split MFMA kernel can form z0 in its loads (49 <= d <= 1024, h in {30, 50}).  Inference
+        """The first flow's split MFMA kernel can form z0 in its loads (49 <= d <= 1024, h <= 64).  Inference
         only: when any flow_q layer wants gradients the pass goes through the layers' autograd functions."""
         if self.fuse_prologue is False or (torch.is_grad_enabled()
                                            and any(p.requires_grad for p in self.flow_q.parameters())):
