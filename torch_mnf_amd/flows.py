@@ -44,11 +44,23 @@ _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # 
 # MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
 # the matrix-core RNVP gradient pass from this many rows / dims on (d = 800: 227 vs 252 us at 128 rows, 284 vs 837 us at
-# 2,048; d = 50: the generic kernel stays ahead up to 32,768 rows)
+# 2,048).  Narrower layers (tools/time_rnvp_bwd_small_dim.py, forward + backward, matrix-core vs any-shape kernel): d = 100
+# 326 vs 403 us at 4,096 rows; d = 50 / 64 level at 16,384 rows (471 / 456 vs 390 / 451 us), 457 vs 562 / 659 at 32,768,
+# 719 / 671 vs 2,012 / 3,390 at 262,144
 _RNVP_KEEP_Y_MIN_ROWS = int(os.environ.get("MNF_RNVP_KEEP_Y_MIN_ROWS", "4096"))  # (0 rows of y below: nothing to gain)
 _RNVP_BWD_FEW_GRID_OFF = False  # (tests: the matrix-core / generic gradient kernels at every row count)
 _RNVP_BWD_MFMA_MIN_ROWS = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_ROWS", "64"))
 _RNVP_BWD_MFMA_MIN_DIM = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_DIM", "128"))
+_RNVP_BWD_MFMA_MID_DIM, _RNVP_BWD_MFMA_MID_ROWS, _RNVP_BWD_MFMA_ANY_DIM_ROWS = 96, 4096, 24576
+
+
+def _rnvp_bwd_small(rows: int, dim: int) -> bool:
+    """True where the any-shape RNVP gradient kernel is the faster one (few rows, or a narrow layer at a moderate batch)."""
+    if rows < _RNVP_BWD_MFMA_MIN_ROWS:
+        return True
+    if dim >= _RNVP_BWD_MFMA_MIN_DIM or rows >= _RNVP_BWD_MFMA_ANY_DIM_ROWS:
+        return False
+    return not (dim >= _RNVP_BWD_MFMA_MID_DIM and rows >= _RNVP_BWD_MFMA_MID_ROWS)
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
 # MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
@@ -480,7 +492,7 @@ class _RnvpFn(torch.autograd.Function):
         # gradient pass, whose first launch then skips its own sweep over z
         y, wrote = None, ctypes.c_int(0)
         if (not few and z.shape[0] >= _RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
-                and not _RNVP_BWD_GENERIC_ENV and z.shape[0] >= _RNVP_BWD_MFMA_MIN_ROWS and module.dim >= _RNVP_BWD_MFMA_MIN_DIM):
+                and not _RNVP_BWD_GENERIC_ENV and not _rnvp_bwd_small(z.shape[0], module.dim)):
             per_row = lib.mnf_rnvp_y_floats_per_row(len(module.h_sizes), module._hid)
             if per_row > 0:
                 y = torch.empty(z.shape[0], per_row, dtype=torch.float32, device=z.device)
@@ -523,7 +535,7 @@ class _RnvpFn(torch.autograd.Function):
                     z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
                     flat.data_ptr(), ws.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
                 return grad_z, ret_flat, None, None, None, None
-        small = z.shape[0] < _RNVP_BWD_MFMA_MIN_ROWS or m.dim < _RNVP_BWD_MFMA_MIN_DIM
+        small = _rnvp_bwd_small(z.shape[0], m.dim)
         bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV or small) else m._bwd_image(z.device, flat)
         split = m._split_image(z.device) if bwd is not None else None
         if bwd is not None and split is not None:
