@@ -273,27 +273,12 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     n_gl = gl_or_x[rowc];
   };
   // ------------------------------------------------------------------ weight gradients: rows on the K axis
-  // The split tiles of a row tile that its weight-gradient products read.  MNF_BS_PIPE: the products of tile i are
-  // issued between the forward stages of tile i + 1 (each block in front of the stage that replaces its activations):
-  // independent matrix work next to the forward pass's vector work, for the one wave of the SIMD.
-#ifndef MNF_BS_PIPE
-#define MNF_BS_PIPE 0
-#endif
+  // The split tiles of a row tile that its weight-gradient products read (declared out here for the blocks below).
+  // (Issuing a tile's products one tile later, block by block between the next tile's forward stages -- in registers,
+  // no LDS round trip -- measured 272 us against 266: profiles/r5/ahf_bwd_split_ablation.txt, commit 3bb0743.)
   using std::integral_constant;
   u32x2 xh[G], xl[G], hh[3][NT], hl[3][NT];
   u32x2 d4h[2 * G], d4l[2 * G], dh[3][NT], dl_[3][NT];  // dh[2] = delta 3 (pre-activation of h3), dh[0] = delta 1
-  u32x2 pxh[G], pxl[G];
-  auto zero_kept = [&] {
-#pragma unroll
-    for (int g = 0; g < G; ++g) xh[g] = xl[g] = pxh[g] = pxl[g] = zero2;
-#pragma unroll
-    for (int c = 0; c < 2 * G; ++c) d4h[c] = d4l[c] = zero2;
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < NT; ++m) hh[l][m] = hl[l][m] = dh[l][m] = dl_[l][m] = zero2;
-  };
-  if (MNF_BS_PIPE) zero_kept();
   // T(v): the tile with rows along the registers: lane (unit = j, q) holds rows 4 q .. 4 q + 3, head and residual
   auto transpose = [&](const u32x2& hi, const u32x2& lo, f16x4& th, f16x4& tl) {
     const f32x4 o = mfma_x16(as_f16x4(hi), ident, zero4);
@@ -465,7 +450,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       f16x8 ah[N1], al[N1];
       read_ops(integral_constant<int, N1>{}, ah, al);
       fence();
-      if (MNF_BS_PIPE) w_hid(integral_constant<int, 1>{});  // (the previous tile's delta 2 x h1, before h1 is replaced)
 #pragma unroll
       for (int g = 0; g < G; ++g) split_tile(cnd[g], xh[g], xl[g], mx);
       fence_v();
@@ -499,10 +483,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
       for (int l = 1; l <= 2; ++l) {
         f16x8* const ahl = ah2;
         f16x8* const all_ = al2;
-        if (MNF_BS_PIPE) {  // the previous tile's delta 3 x h2 before h2 is replaced, delta 4 x h3 before h3 is
-          if (l == 1) w_hid(integral_constant<int, 2>{});
-          else w_out();
-        }
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           mn[m] = B4[4 * (l * NT + m)];
@@ -573,7 +553,6 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
     //  overwrites it -- same stream, later)
     f32x4 d4[2 * G];  // [s tiles | t tiles]
     float* const gr = grad_x + rowc * dim + 4 * q;
-    if (MNF_BS_PIPE) w_l1(pxh, pxl);  // (the previous tile's delta 1 x x0, before the delta chain replaces delta 1)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       f32x4 gv;
@@ -719,28 +698,13 @@ ahf_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ grad
           }
         }
       }
-      if (MNF_BS_PIPE) zero_kept();  // (this tile adds nothing: its products would run during the next tile)
       continue;
     }
     // ------------------------------------------------------------------ weight gradients: rows on the K axis
-    if (MNF_BS_PIPE) {  // issued between the NEXT tile's forward stages; the conditioning half's split form moves aside
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        pxh[g] = xh[g];
-        pxl[g] = xl[g];
-      }
-    } else {
-      w_out();
-      w_hid(integral_constant<int, 2>{});
-      w_hid(integral_constant<int, 1>{});
-      w_l1(xh, xl);
-    }
-  }
-  if (MNF_BS_PIPE) {  // the last tile's products
     w_out();
     w_hid(integral_constant<int, 2>{});
     w_hid(integral_constant<int, 1>{});
-    w_l1(pxh, pxl);
+    w_l1(xh, xl);
   }
 
   // ------------------------------------------------------------------ flush: sum over the waves in LDS, one atomic per parameter
