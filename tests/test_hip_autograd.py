@@ -492,6 +492,55 @@ def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
         assert_close(got[k], ref[k], 5e-5, f"tile vs generic {k}")
 
 
+@pytest.mark.parametrize("dim,K,n_h", [(2, 8, 16), (6, 5, 8), (10, 8, 8), (30, 8, 16), (4, 8, 4)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_padded_twin_matches_the_layer(amd, O, dim, K, n_h, inverse, monkeypatch):
+    """Halves that are not whole float4 groups -- dim = 2 is the reference's own NSF_CL shape (tests/test_flows.py:89-99) --
+    run the matrix-core kernels on a padded twin (NSF_CL._run_padded): padded columns sit beyond the tail bound, where the
+    spline is the identity with log-derivative 0, and meet zero weights in the conditioners.  Outputs, log_det and every
+    gradient against the oracle and against the any-shape kernels on the unpadded layer; then a parameter update must
+    reach the twin."""
+    import torch_mnf_amd.flows as fl
+
+    monkeypatch.setattr(fl, "_NSF_PAD_MIN_ROWS", 0)
+    rows = 531
+    sd = recipes.nsf_cl_params(4700 + dim + K, dim, K, n_h)
+    x_cpu = recipes.gaussian(4800 + dim, rows, dim, scale=1.3)
+    x_cpu[0, :] = 5.0      # outside the tail bound: identity
+    x_cpu[1, ::2] = -3.0   # on the bound
+    x_cpu.requires_grad_(True)
+    w_y = recipes.gaussian(4900, rows, dim)
+    w_l = recipes.gaussian(4950, rows, 1)[:, 0]
+    oracle = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse), w_y, w_l), x_cpu, sd)
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    assert f._pad_half() == (dim // 2 + 3) // 4 * 4
+    with torch.no_grad():
+        y_k, ld_k = (f.inverse if inverse else f.forward)(x_cpu.detach().to(DEV))
+        assert amd.last_kernel().startswith("nsf_mfma"), amd.last_kernel()
+        y_o, ld_o = O.nsf_cl(x_cpu.detach(), sd, K, 3.0, inverse)
+    assert y_k.shape == (rows, dim)
+    assert_close(y_k, y_o, 1e-5, f"nsf padded twin d={dim} y")
+    assert_close(ld_k, ld_o, 2e-5, f"nsf padded twin d={dim} log_det")
+    got = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l)
+    assert amd.last_kernel() == "nsf_bwd_tile", amd.last_kernel()
+    ref = nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=True)
+    assert set(got) == set(ref) and all(got[k].shape == ref[k].shape for k in got)
+    oracle.check_all(got, f"nsf padded twin d={dim} K={K} n_h={n_h} inv={inverse}")
+    for k in got:
+        assert_close(got[k], ref[k], 5e-5, f"padded twin vs generic {k}")
+    # an in-place parameter update (an optimizer step) must reach the twin's operand images
+    with torch.no_grad():
+        for q in f.parameters():
+            q.mul_(0.5)
+        sd2 = {k: v.detach().cpu().clone() for k, v in f.state_dict().items()}
+        y2, ld2 = (f.inverse if inverse else f.forward)(x_cpu.detach().to(DEV))
+        y2_o, ld2_o = O.nsf_cl(x_cpu.detach(), sd2, K, 3.0, inverse)
+    assert_close(y2, y2_o, 1e-5, "after the update: y")
+    assert_close(ld2, ld2_o, 2e-5, "after the update: log_det")
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_tile_gradient_kernel_cold_tiles(amd, O, inverse):
     """Rows whose conditioner operands leave the split range (|x| >= 2^13: identity tails for the spline, but the other

@@ -46,3 +46,24 @@ def test_deterministic_switch_is_exported_and_off_by_default():
         assert amd.deterministic() is False
     p = _child(["-c", "import torch_mnf_amd as amd; print(int(amd.deterministic()))"], 300)
     assert p.stdout.strip().endswith("1"), p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,rows,family", [(50, 4096, "rnvp_bwd_generic"), (50, 32768, "rnvp_bwd_mfma"),
+                                              (100, 4096, "rnvp_bwd_mfma"), (100, 1024, "rnvp_bwd_generic"),
+                                              (800, 128, "rnvp_bwd_mfma")])
+def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
+    """Narrow RNVP layers take the matrix-core gradient pass only where it measured faster than the any-shape kernel
+    (flows._rnvp_bwd_small, tools/time_rnvp_bwd_small_dim.py); `last_kernel()` tells which one ran.  Both families are
+    held to the oracle by tests/test_hip_round3.py::test_rnvp_mfma_gradient_kernels."""
+    import torch
+
+    import torch_mnf_amd as amd
+
+    f = amd.RNVP(dim, h_sizes=(50,)).to("cuda")
+    x = torch.randn(rows, dim, device="cuda", requires_grad=True)
+    y, ld = f.forward(x, seed=11)
+    (y.sum() + ld.sum()).backward()
+    torch.cuda.synchronize()
+    assert amd.last_kernel() == family
+    assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in f.parameters())

@@ -40,6 +40,11 @@ _BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
 # 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
 # NSF_CL gradient kernel: "tile" (default: mnf_nsf_bwd_tile.hip where the shape has one) or "generic"
 _NSF_BWD_KERNEL = os.environ.get("MNF_NSF_BWD_KERNEL", "tile")
+# NSF_CL with halves that are not whole float4 groups (dim = 2, 6, 10, ...) runs the matrix-core kernels on a padded twin
+# from this many rows on (NSF_CL._run_padded; tools/time_nsf_padded_twin.py, dim = 2, K = 8, n_h = 16, forward + backward,
+# twin vs any-shape kernels: 690 vs 416 us at 16,384 rows, 705 vs 1,119 at 65,536, 2.07 vs 15.3 ms at 2^20; forward
+# alone 68 vs 54 us, 84 vs 99, 473 vs 1,082)
+_NSF_PAD_MIN_ROWS = int(os.environ.get("MNF_NSF_PAD_MIN_ROWS", "49152"))
 _BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
 # MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
 _RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
@@ -1160,7 +1165,81 @@ class NSF_CL(_TwoWayFlow):
             self.__dict__["_bwd_tile_cache"] = cached
         return cached
 
+    # ---- halves that are not whole float4 groups (dim = 2, 4, 6, 10, ...; the reference's own test shape is dim = 2,
+    # tests/test_flows.py:89-99).  The matrix-core kernels take halves in whole groups of four columns, so such a layer
+    # runs them on a padded TWIN: each half widened to the next multiple of four, the conditioners' first / last layers
+    # zero-padded to match (a padded column meets zero weights; a padded element has no parameters), and the padded
+    # columns of x set beyond the tail bound, where the spline is the identity with log-derivative 0
+    # (spline_flow.py:72-85) -- so y, log_det and every gradient of the real columns and parameters are what the layer
+    # itself would give, and autograd's own pad / slice nodes carry the gradients back.  From _NSF_PAD_MIN_ROWS rows on
+    # (below that the extra pad / slice launches cost more than the any-shape kernels do).
+    def _pad_half(self) -> int:
+        """Padded half width of the twin (0: none -- the halves are whole groups already, or no kernel takes the twin)."""
+        cached = self.__dict__.get("_pad_half_cache")
+        if cached is None:
+            hr = self.dim // 2
+            hp = (hr + 3) // 4 * 4
+            cached = 0
+            if hp != hr and 2 * hp <= 64 and not _narrow_hidden(self.h_sizes) and len(set(self.h_sizes)) == 1:
+                if _lib.load().mnf_nsf_cl_bwd_tile_supported(2 * hp, self.K, len(self.h_sizes), self._hid):
+                    cached = hp
+            self.__dict__["_pad_half_cache"] = cached
+        return cached
+
+    def _padded_params(self, hp: int) -> list[Tensor]:
+        """This layer's parameters in the twin's shapes (differentiable: F.pad nodes)."""
+        hr, P = self.dim // 2, 3 * self.K - 1
+        out = []
+        for net in (self.f1, self.f2):
+            ps = self._net_params([net])
+            for i, prm in enumerate(ps):
+                if i == 0:  # first layer's weight (n_h, hr): zero columns for the padded inputs
+                    prm = torch.nn.functional.pad(prm, (0, hp - hr))
+                elif i == len(ps) - 2:  # last layer's weight ((3K-1) hr, n_h), element-major rows: none for padded elements
+                    prm = torch.nn.functional.pad(prm, (0, 0, 0, P * (hp - hr)))
+                elif i == len(ps) - 1:  # last layer's bias
+                    prm = torch.nn.functional.pad(prm, (0, P * (hp - hr)))
+                out.append(prm)
+        return out
+
+    def _twin(self, device, hp: int) -> "NSF_CL":
+        """The padded layer, its parameters refreshed from this layer's whenever they changed."""
+        twin = self.__dict__.get("_twin_module")
+        if twin is None or twin.f1[0].weight.device != device:
+            twin = NSF_CL(2 * hp, K=self.K, B=self.B, n_h=self.h_sizes[0]).to(device).requires_grad_(False)
+            self.__dict__["_twin_module"] = twin
+            self.__dict__["_twin_key"] = None
+        params = self._packed_params()
+        key = (_flat_gen(self), tuple((q.data_ptr(), q._version) for q in params))
+        if key != self.__dict__.get("_twin_key"):
+            with torch.no_grad():
+                for dst, src in zip(twin._packed_params(), self._padded_params(hp)):
+                    dst.copy_(src)
+            self.__dict__["_twin_key"] = key
+        twin.force_fp32_mfma = self.force_fp32_mfma
+        return twin
+
+    def _run_padded(self, x, inverse, accum, hp: int):
+        hr, rows = self.dim // 2, x.shape[0]
+        twin = self._twin(x.device, hp)
+        fill = x.new_full((rows, hp - hr), 2.0 * float(self.B) + 1.0)  # outside [-B, B]: identity, log-derivative 0
+        wants = accum is None and _wants_grad(self, x)
+        xs = _grad_input(x) if wants else _device_input(x, "input")
+        x_pad = torch.cat([xs[:, :hr], fill, xs[:, hr:], fill], dim=1)
+        if wants:
+            flat_pad = torch.cat([q.reshape(-1) for q in self._padded_params(hp)])
+            y_pad, ld = _NsfFn.apply(x_pad, flat_pad, twin, bool(inverse))
+        else:
+            with torch.no_grad():
+                y_pad, ld = twin._run(x_pad, inverse, accum)
+        return torch.cat([y_pad[:, :hr], y_pad[:, hp:hp + hr]], dim=1), ld
+
     def _run(self, x, inverse, accum):
+        if (isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[1] == self.dim and x.dtype == torch.float32
+                and x.shape[0] >= _NSF_PAD_MIN_ROWS and not self.force_generic):
+            hp = self._pad_half()
+            if hp:
+                return self._run_padded(x, inverse, accum, hp)
         if accum is None and isinstance(x, Tensor) and x.is_cuda and x.shape[0] > 0 and _wants_grad(self, x):
             xg = _grad_input(x)
             if xg.shape[1] != self.dim:
