@@ -51,7 +51,7 @@ def test_deterministic_switch_is_exported_and_off_by_default():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,rows,family", [(50, 4096, "rnvp_bwd_generic"), (50, 32768, "rnvp_bwd_mfma"),
                                               (100, 4096, "rnvp_bwd_mfma"), (100, 1024, "rnvp_bwd_generic"),
-                                              (800, 128, "rnvp_bwd_mfma")])
+                                              (800, 4096, "rnvp_bwd_mfma"), (800, 128, "rnvp_bwd_few")])
 def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
     """Narrow RNVP layers take the matrix-core gradient pass only where it measured faster than the any-shape kernel
     (flows._rnvp_bwd_small, tools/time_rnvp_bwd_small_dim.py); `last_kernel()` tells which one ran.  Both families are
