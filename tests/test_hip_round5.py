@@ -67,3 +67,39 @@ def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
     torch.cuda.synchronize()
     assert amd.last_kernel() == family
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in f.parameters())
+
+
+@pytest.mark.gpu
+def test_padded_nsf_twin_follows_a_fused_optimizer(monkeypatch):
+    """FusedAdam rewrites the flat parameter buffer through its raw pointer (no version bump): the padded twin of an
+    NSF_CL(dim=2) -- the reference's shape, tests/test_flows.py:89-99 -- must pick the new values up (its refresh key
+    includes the buffer's generation).  Three Adam steps with the twin against three with the any-shape kernels."""
+    import torch
+
+    import torch_mnf_amd as amd
+    import torch_mnf_amd.flows as fl
+
+    def train(min_rows):
+        monkeypatch.setattr(fl, "_NSF_PAD_MIN_ROWS", min_rows)
+        torch.manual_seed(5)
+        flows = [amd.NSF_CL(dim=2, K=8, B=3, n_h=16) for _ in range(2)]
+        model = amd.NormalizingFlowModel(amd.StandardNormal(2), flows).to("cuda")
+        opt = amd.FusedAdam(amd.FlatParameters(model), lr=1e-2)
+        x = torch.randn(4096, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = -model.log_prob(x).mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses, [p.detach().clone() for p in model.parameters()], amd.last_kernel()
+
+    l_twin, p_twin, k_twin = train(0)
+    l_any, p_any, k_any = train(1 << 40)
+    assert k_twin == "nsf_bwd_tile" and "generic" in k_any, (k_twin, k_any)
+    assert l_twin[2] < l_twin[0]
+    for a, b in zip(l_twin, l_any):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_twin, l_any)
+    for a, b in zip(p_twin, p_any):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4), float((a - b).abs().max())

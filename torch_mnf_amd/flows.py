@@ -422,7 +422,7 @@ class _NsfFn(torch.autograd.Function):
             x.shape[0], module.dim,
             module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
             int(module.force_generic), _stream()))
-        if not module.force_generic:
+        if not module.force_generic and not module._pad_half():  # (a padded-twin shape is here by choice: few rows)
             _lib.note_generic("NSF_CL", x.shape[0], f"dim={module.dim}, K={module.K}, hidden={module.h_sizes}")
         ctx.module, ctx.inverse = module, inverse
         # (y too: the tile gradient kernel reads the second net's conditioner input out of it instead of recomputing the
@@ -475,7 +475,7 @@ class _NsfFn(torch.autograd.Function):
             return grad_x, grad_flat, None, None
         _lib.check("mnf_nsf_cl_bwd", lib.mnf_nsf_cl_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
-        if not m.force_generic and _NSF_BWD_KERNEL != "generic":
+        if not m.force_generic and _NSF_BWD_KERNEL != "generic" and not m._pad_half():
             _lib.note_generic("NSF_CL.backward", rows, f"dim={m.dim}, K={m.K}, hidden={m.h_sizes}")
         return grad_x, grad_flat, None, None
 
@@ -1259,7 +1259,7 @@ class NSF_CL(_TwoWayFlow):
             _ptr(split),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
             int(self.force_generic), _stream()))
-        if not self.force_generic:
+        if not self.force_generic and not self._pad_half():  # (a padded-twin shape is here by choice: few rows)
             _lib.note_generic("NSF_CL", x.shape[0], f"dim={self.dim}, K={self.K}, hidden={self.h_sizes}")
         return y, (None if accum is not None else ld)
 
