@@ -80,8 +80,8 @@ const char* mnf_last_kernel(void);
  * (mnf_rnvp_bwd_mfma, mnf_mnf_linear_bwd) then form their parameter sums without float atomics -- one block per row part
  * in an extension of the caller's workspace (their *_workspace_bytes queries include it), added up in a fixed order -- so
  * that a training step repeats bit for bit, as the reference's does under torch.manual_seed (tests/test_flows.py:11).
- * The AffineHalfFlow and NSF_CL gradient launches reduce in a fixed order in every mode; the [Glow, ActNorm] pair has
- * its own *_det entry points.  Rows that take the fp32 fix-up pass (values beyond the split range) still add atomically. */
+ * The split AffineHalfFlow and the NSF_CL tile gradient launches reduce in a fixed order in every mode; the [Glow, ActNorm]
+ * pair, the fp32-MFMA AffineHalfFlow kernel and sample_z have *_det entry points of their own.  Rows that take the fp32 fix-up pass (values beyond the split range) still add atomically. */
 int mnf_deterministic(void);
 /* Number of visible devices whose gcnArchName starts with gfx950 (0 = none / no driver). */
 int mnf_device_count(void);
@@ -510,6 +510,14 @@ int mnf_affine_half_bwd_index(int dim, int n_hidden, const int* hidden_host, int
 int mnf_affine_half_bwd_mfma(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                              float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
                              int parity, int inverse, int n_hidden, const int* hidden_host, void* stream);
+/* mnf_affine_half_bwd_mfma with the parameter sums added up in a fixed order (MNF_DETERMINISTIC=1): every workgroup
+ * leaves its sums in `workspace` (mnf_affine_half_bwd_mfma_workspace(rows, ...) floats; 0 = no such kernel) and a second
+ * launch adds the blocks in order -- no float atomics, results repeat bit for bit. */
+int64_t mnf_affine_half_bwd_mfma_workspace(int64_t rows, int dim, int n_hidden, const int* hidden_host);
+int mnf_affine_half_bwd_mfma_det(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                                 float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                                 int parity, int inverse, int n_hidden, const int* hidden_host, float* workspace,
+                                 int64_t workspace_floats, void* stream);
 /* mnf_affine_half_bwd_mfma on the listed 16-row tiles only: tile_list_dev = [count, tile, tile, ...] on the device
  * (at most list_capacity tiles are read; count < 0: every tile); NULL = every tile.  The fix-up pass of
  * mnf_affine_half_bwd_split. */

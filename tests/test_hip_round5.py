@@ -22,7 +22,7 @@ def _child(args, timeout):
 def test_deterministic_mode_training_repeats_bit_for_bit():
     p = _child(["tools/soak_determinism_train.py", "6", "65536", "65536", "32768"], 600)
     lines = [ln for ln in p.stdout.splitlines() if "Adam steps twice" in ln]
-    assert len(lines) == 3, p.stdout + p.stderr
+    assert len(lines) == 4, p.stdout + p.stderr
     for ln in lines:
         assert " 0 of " in ln and "MNF_DETERMINISTIC=1" in ln, ln
     assert p.returncode == 0, p.stdout + p.stderr
@@ -30,10 +30,12 @@ def test_deterministic_mode_training_repeats_bit_for_bit():
 
 @pytest.mark.gpu
 def test_deterministic_mode_gradients_pass_the_default_modes_parity_tests():
-    # the RNVP / MNFLinear / sample_z gradient launches (fixed-order sums through the workspace extension) and the
-    # [Glow, ActNorm] pair against the float64 oracle, in a process that runs them in deterministic mode
-    p = _child(["-m", "pytest", "tests/test_hip_round3.py", "tests/test_hip_round4.py", "-q", "-x", "-m", "gpu", "-p",
-                "no:cacheprovider", "-k", "rnvp or mnf_linear or MNFLinear or glow_actnorm or sample_z"], 1200)
+    # the RNVP / MNFLinear / sample_z gradient launches (fixed-order sums through the workspace extension), the
+    # [Glow, ActNorm] pair and the AffineHalfFlow fp32-MFMA gradient kernel (d = 128, padded halves) against the float64
+    # oracle, in a process that runs them in deterministic mode
+    p = _child(["-m", "pytest", "tests/test_hip_round3.py", "tests/test_hip_round4.py", "tests/test_hip_autograd.py", "-q",
+                "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                "rnvp or mnf_linear or MNFLinear or glow_actnorm or sample_z or fp32_mfma_gradient_kernel"], 1200)
     tail = "\n".join(p.stdout.splitlines()[-15:])
     assert p.returncode == 0, tail + p.stderr[-2000:]
     assert " passed" in tail and "failed" not in tail, tail

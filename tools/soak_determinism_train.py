@@ -1,5 +1,6 @@
 """Are training steps reproducible bit for bit?  For each of the bench's training workloads (c2t: 9 x AffineHalfFlow at
-d = 64; c3t: 3 x [ActNorm, Glow, NSF_CL] at d = 32; c5t: MNFLinear(800, 50)) the same N Adam steps are run twice from
+d = 64; c3t: 3 x [ActNorm, Glow, NSF_CL] at d = 32; c5t: MNFLinear(800, 50)) and for 9 x AffineHalfFlow at d = 256 (c4t:
+the fp32-MFMA gradient kernel) the same N Adam steps are run twice from
 identical parameters, inputs and seeds; the parameters after each run must be identical (torch.equal).  The reference's
 loop is reproducible under its torch.manual_seed(0) (tests/test_flows.py:11).
 
@@ -22,6 +23,14 @@ def run_c2t():
     model, _ = bench.build_model(64, dev)
     opt = amd.FusedAdam(amd.FlatParameters(model), lr=1e-3)
     x = torch.randn(rows[0], 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    return model, opt, (lambda: -model.log_prob(x).mean())
+
+
+def run_c4t():
+    """BASELINE configs[3]'s shape in training: 9 x AffineHalfFlow at d = 256 (the fp32-MFMA gradient kernel)"""
+    model, _ = bench.build_model(256, dev)
+    opt = amd.FusedAdam(amd.FlatParameters(model), lr=1e-3)
+    x = torch.randn(max(rows[0] // 4, 4096), 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
     return model, opt, (lambda: -model.log_prob(x).mean())
 
 
@@ -68,7 +77,7 @@ def first_gradients(build):
 
 
 bad_total = 0
-for name, build in (("c2t", run_c2t), ("c3t", run_c3t), ("c5t", run_c5t)):
+for name, build in (("c2t", run_c2t), ("c4t", run_c4t), ("c3t", run_c3t), ("c5t", run_c5t)):
     a, la, ta = trajectory(build)
     b, lb, tb = trajectory(build)
     bad = sum(int(not torch.equal(p, q)) for p, q in zip(a, b))

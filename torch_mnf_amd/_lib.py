@@ -86,6 +86,9 @@ SIGNATURES = {
     "mnf_affine_half_bwd_index": (c_int, [c_int, c_int, _intp, c_int, c_int, _i32p]),
     "mnf_affine_half_bwd_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_int, c_int, c_int, c_int, _intp, c_void_p]),
+    "mnf_affine_half_bwd_mfma_workspace": (c_int64, [c_int64, c_int, c_int, _intp]),
+    "mnf_affine_half_bwd_mfma_det": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                             c_int, c_int, c_int, c_int, _intp, c_void_p, c_int64, c_void_p]),
     "mnf_affine_half_bwd_mfma_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int64, c_int, c_int, c_int, c_int, _intp, c_void_p, c_int, c_void_p]),
     "mnf_affine_half_bwd_split_layout": (c_int, [c_int, c_int, _intp, c_int, c_int, _i64p, _i64p]),

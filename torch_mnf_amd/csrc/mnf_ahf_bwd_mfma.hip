@@ -41,6 +41,8 @@ __device__ __forceinline__ void tile_rows_on_k(const float* tile, int i, int kq,
 
 // RAG: the coupling half is narrower than the tile (real_h < H: d = 2 ... ): the operand images carry zeros in the padded
 // columns (build_bwd_index), rows are read and written element by element under a column mask.
+constexpr int kBwdBlocksMode = -1;  // list_capacity of a launch whose grad_flat is the per-workgroup block workspace
+
 template <int H, int HID, bool INV, bool RAG>
 __global__ void __launch_bounds__((BwdShape<H, HID>::WAVES * 64), 1)
 ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_y, const float* __restrict__ grad_ld,
@@ -370,6 +372,19 @@ ahf_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ grad_
     }
     __syncthreads();
   }
+  // MNF_DETERMINISTIC (no tile list, list_capacity == kBwdBlocksMode): grad_flat is the workspace -- the workgroup's sums
+  // go there as one block and ahf_bwd_mfma_reduce_kernel adds the blocks in order.  (Signalled through an existing
+  // argument: one more kernel argument sent hipcc's AGPR-copy rewrite pass into a segmentation fault on the <128, 24>
+  // ragged instantiation.)
+  if (!tile_list && list_capacity == kBwdBlocksMode) {
+    float* dst = grad_flat + (int64_t)blockIdx.x * (DW_FLOATS + S::DB_TILES * 16);
+    for (int i = threadIdx.x; i < DW_FLOATS; i += blockDim.x) dst[i] = red[i];
+    for (int i = threadIdx.x; i < S::DB_TILES * 16; i += blockDim.x) {
+      const float* p = red + DW_FLOATS + (i >> 4) * 64 + (i & 15);
+      dst[DW_FLOATS + i] = (p[0] + p[16]) + (p[32] + p[48]);
+    }
+    return;
+  }
   const int32_t* flush_w = index + S::IMAGE_FLOATS;
   const int32_t* flush_b = flush_w + DW_FLOATS;
   for (int i0 = threadIdx.x; i0 < DW_FLOATS; i0 += 4 * blockDim.x) {
@@ -543,10 +558,33 @@ static void build_bwd_index(int32_t* idx, int rh, const int* hs, bool has_s, boo
 // shapes: 16, 24 or 32 hidden-unit slots at tile halves 16, 32 (d <= 64; narrower halves and layers padded), 24 at 64, 128
 #define MNF_AHF_BWD_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(16, 32) X(32, 32) X(128, 24)
 
+// second stage of the deterministic flush: entry i of the flush tables (weights, then biases) += the blocks' entries i, in
+// block order; every parameter appears in exactly one entry
+__global__ void __launch_bounds__(256)
+ahf_bwd_mfma_reduce_kernel(const float* __restrict__ partials, int n_blocks, int red_floats,
+                           const int32_t* __restrict__ flush, float* __restrict__ grad_flat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= red_floats) return;
+  const int32_t dst = flush[i];
+  if (dst < 0) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * red_floats + i];
+  grad_flat[dst] += s;
+}
+
+template <int H, int HID>
+static int64_t bwd_blocks(int64_t rows) {
+  using S = BwdShape<H, HID>;
+  const int cus = device_cus(current_device());
+  const int64_t n_tiles = (rows + 15) / 16, blocks = (n_tiles + S::WAVES - 1) / S::WAVES;
+  return blocks > cus ? cus : blocks;
+}
+
 template <int H, int HID, bool RAG>
 static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x, float* grad_flat,
                       const float* flat, const int32_t* index, int64_t rows, int parity, int inverse,
-                      const int32_t* tile_list, int list_capacity, int real_h, hipStream_t stream) {
+                      const int32_t* tile_list, int list_capacity, int real_h, hipStream_t stream,
+                      float* partials = nullptr) {
   using S = BwdShape<H, HID>;
   constexpr size_t lds_bytes = S::LDS_FLOATS * sizeof(float);
   static DeviceMemo memo;  // per device: CU count once the dynamic-LDS attribute is set there, -1 if it cannot be
@@ -567,10 +605,17 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   if (!tile_list) tag_kernel("ahf_bwd_mfma_fp32");  // (as the split kernel's fix-up pass it keeps that kernel's name)
   if (inverse)
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, true, RAG>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
-                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity, real_h);
+                       grad_x, partials ? partials : grad_flat, flat, index, rows, parity, tile_list,
+                       partials ? kBwdBlocksMode : list_capacity, real_h);
   else
     hipLaunchKernelGGL((ahf_bwd_mfma_kernel<H, HID, false, RAG>), grid, block, lds_bytes, stream, x, grad_y, grad_ld,
-                       grad_x, grad_flat, flat, index, rows, parity, tile_list, list_capacity, real_h);
+                       grad_x, partials ? partials : grad_flat, flat, index, rows, parity, tile_list,
+                       partials ? kBwdBlocksMode : list_capacity, real_h);
+  if (int rc = check_launch()) return rc;
+  if (!partials || !grad_flat) return MNF_OK;
+  constexpr int RED = S::DW_TILES * 256 + S::DB_TILES * 16;
+  hipLaunchKernelGGL(ahf_bwd_mfma_reduce_kernel, dim3((RED + 255) / 256), dim3(256), 0, stream, partials, (int)blocks, RED,
+                     index + S::IMAGE_FLOATS, grad_flat);
   return check_launch();
 }
 
@@ -656,6 +701,52 @@ int mnf_affine_half_bwd_mfma_tiles(const float* x, const float* grad_y, const fl
                   : mnf::launch_bwd<HH, HD, false>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows,      \
                                                    parity != 0, inverse != 0, tile_list, list_capacity, dim / 2,       \
                                                    (hipStream_t)stream);
+  MNF_AHF_BWD_SHAPES(X)
+#undef X
+  return MNF_ERR_UNSUPPORTED;
+}
+
+int64_t mnf_affine_half_bwd_mfma_workspace(int64_t rows, int dim, int n_hidden, const int* hidden) {
+  int hid = 0;
+  if (rows < 1 || dim < 2 || (dim & 1) || !mnf::hidden_ok(n_hidden, hidden) || !mnf::bwd_uniform3(n_hidden, hidden, hid))
+    return 0;
+  const int ph = mnf::bwd_padded_half(dim);
+  if (ph >= 64) hid = hid <= 24 ? 24 : 0;
+#define X(HH, HD) \
+  if (ph == HH && hid == HD) \
+    return mnf::bwd_blocks<HH, HD>(rows) * (mnf::BwdShape<HH, HD>::DW_TILES * 256 + mnf::BwdShape<HH, HD>::DB_TILES * 16);
+  MNF_AHF_BWD_SHAPES(X)
+#undef X
+  return 0;
+}
+
+int mnf_affine_half_bwd_mfma_det(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
+                                 float* grad_flat, const float* flat, const int32_t* index_dev, int64_t rows, int dim,
+                                 int parity, int inverse, int n_hidden, const int* hidden, float* workspace,
+                                 int64_t workspace_floats, void* stream) {
+  int hid = 0;
+  if (!x || !grad_x || !flat || !index_dev || !workspace || rows < 0 || dim < 2 || (dim & 1) ||
+      !mnf::hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (!mnf::bwd_uniform3(n_hidden, hidden, hid)) return MNF_ERR_UNSUPPORTED;
+  const int64_t need = mnf_affine_half_bwd_mfma_workspace(rows, dim, n_hidden, hidden);
+  if (need == 0) return MNF_ERR_UNSUPPORTED;
+  if (workspace_floats < need) return MNF_ERR_INVALID_ARG;
+  const int ph = mnf::bwd_padded_half(dim);
+  if (ph >= 64) hid = hid <= 24 ? 24 : 0;
+  const bool ragged = ph != dim / 2;
+  if (!ragged &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15))
+    return MNF_ERR_UNSUPPORTED;
+#define X(HH, HD)                                                                                                       \
+  if (ph == HH && hid == HD)                                                                                            \
+    return ragged ? mnf::launch_bwd<HH, HD, true>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows,        \
+                                                  parity != 0, inverse != 0, nullptr, 0, dim / 2, (hipStream_t)stream, \
+                                                  workspace)                                                            \
+                  : mnf::launch_bwd<HH, HD, false>(x, grad_y, grad_ld, grad_x, grad_flat, flat, index_dev, rows,       \
+                                                   parity != 0, inverse != 0, nullptr, 0, dim / 2, (hipStream_t)stream,\
+                                                   workspace);
   MNF_AHF_BWD_SHAPES(X)
 #undef X
   return MNF_ERR_UNSUPPORTED;

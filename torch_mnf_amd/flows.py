@@ -355,9 +355,16 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
                 x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
                 f.dim, int(bool(f.parity)), int(inverse), *hid, cold.data_ptr(), cap, _stream())
     if rc == _lib.MNF_ERR_UNSUPPORTED and index is not None:
-        rc = lib.mnf_affine_half_bwd_mfma(
-            x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows, f.dim,
-            int(bool(f.parity)), int(inverse), *hid, _stream())
+        n_ws = lib.mnf_affine_half_bwd_mfma_workspace(rows, f.dim, *hid) if _lib.deterministic() else 0
+        if n_ws > 0:  # MNF_DETERMINISTIC=1: the workgroups' sums as blocks, added in a fixed order
+            ws = torch.empty(n_ws, dtype=torch.float32, device=x_in.device)
+            rc = lib.mnf_affine_half_bwd_mfma_det(
+                x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
+                f.dim, int(bool(f.parity)), int(inverse), *hid, ws.data_ptr(), n_ws, _stream())
+        else:
+            rc = lib.mnf_affine_half_bwd_mfma(
+                x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
+                f.dim, int(bool(f.parity)), int(inverse), *hid, _stream())
     if rc == _lib.MNF_ERR_UNSUPPORTED:  # no MFMA gradient kernel for this shape (e.g. a narrow half)
         rc = lib.mnf_affine_half_bwd(
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, rows, f.dim,
