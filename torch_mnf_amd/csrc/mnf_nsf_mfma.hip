@@ -299,7 +299,7 @@ __device__ __forceinline__ float nsf_half_step_split(const uint32_t* ops, const 
                                                      const f32x4 (&cond)[H / 16], f32x4 (&act)[H / 16], float T,
                                                      float& mx, unsigned live = ~0u) {
   using S_ = NsfSplitShape<H, NH, K>;
-  constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB, SL = S_::S;
+  constexpr int G = S_::G, NTH = S_::NTH, NB = S_::NB;
   int a_off = lane * 2, b_off = q * 4;
   asm volatile("" : "+v"(a_off), "+v"(b_off));  // keep the operand reads inside the tile loop
   const u32x2* A2 = reinterpret_cast<const u32x2*>(ops + a_off);   // + 64 * (2 op + part)

@@ -382,7 +382,6 @@ rnvp_narrow_kernel(const float* __restrict__ z, const float* __restrict__ mask, 
                    int64_t rows, int d, int accumulate, uint64_t seed, const float* __restrict__ q0_mean,
                    const float* __restrict__ q0_log_var, int dm, int vec_ok) {
   using S = RnvpSplitShape<HN>;
-  using F = RnvpShape<HN, kNarrowWaves>;
   constexpr int YT = S::YT, NKS2 = S::NKS2;
   extern __shared__ __attribute__((aligned(16))) uint32_t img_lds[];  // the split image; later the fp32 body's windows
   __shared__ __attribute__((aligned(16))) float zprm_lds[2 * 64];
