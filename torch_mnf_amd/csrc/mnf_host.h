@@ -23,7 +23,7 @@ bool hidden_ok(int n_hidden, const int* hidden);
 // whose half is narrower than its tile runs on the stack kernel's ragged variant: zero operands in the
 // padded columns, element-wise masked row accesses.
 // Hidden width the AffineHalfFlow MFMA kernels run three hidden layers of widths hidden[0..2] at: the smallest of
-// 16 / 24 / 32 that holds the widest one (0: none).  Narrower layers get structural-zero units (zero weights and
+// 16 / 24 / 32 / 64 that holds the widest one (0: none; 64: the single-layer forward kernels at dim = 32 and 64 only).  Narrower layers get structural-zero units (zero weights and
 // bias: LeakyReLU(0) = 0, so they contribute nothing).
 inline int ahf_padded_hidden(int n_hidden, const int* hidden) {
   if (n_hidden != 3 || !hidden) return 0;
@@ -32,7 +32,7 @@ inline int ahf_padded_hidden(int n_hidden, const int* hidden) {
     if (hidden[i] < 1) return 0;
     mx = hidden[i] > mx ? hidden[i] : mx;
   }
-  return mx <= 16 ? 16 : mx <= 24 ? 24 : mx <= 32 ? 32 : 0;
+  return mx <= 16 ? 16 : mx <= 24 ? 24 : mx <= 32 ? 32 : mx <= 64 ? 64 : 0;
 }
 inline int ahf_padded_half(int h) { return h < 1 ? 0 : h <= 16 ? 16 : h <= 32 ? 32 : h <= 64 ? 64 : h <= 128 ? 128 : 0; }
 
