@@ -575,7 +575,7 @@ int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, fl
                    int inverse, int n_hidden, const int* hidden_host, void* stream);
 /* The same gradients with the whole conditioner on the f16 matrix pipe in split arithmetic, a wave per 16-row tile
  * (mnf_nsf_bwd_tile.hip; NSF_CL under loss.backward(): torch_mnf/flows/spline_flow.py:249-285, tests/test_flows.py:89-99):
- * dim a multiple of 8 up to 64, three hidden layers of at most 16 units, K = 5 or 8 -- the shapes
+ * dim a multiple of 8 up to 64, three hidden layers of at most 16 units, K = 5 or 8 (K = 10 up to dim 32) -- the shapes
  * mnf_nsf_cl_bwd_tile_supported() answers 1 for.
  *   y            the layer's OUTPUT for the same x, direction and parameters (mnf_nsf_cl's): the second net's conditioner
  *                input is a column block of it, so the first half-step is not recomputed to get it

@@ -456,7 +456,7 @@ def nsf_grads_dim(amd, sd, dim, K, n_h, inverse, x_cpu, w_y, w_l, generic=False)
 
 
 @pytest.mark.parametrize("dim,K,n_h", [(16, 8, 8), (24, 5, 4), (8, 8, 8), (32, 8, 7), (64, 8, 8), (64, 5, 16), (48, 8, 8),
-                                       (32, 8, 16), (32, 5, 12), (16, 8, 16), (64, 8, 16)])
+                                       (32, 8, 16), (32, 5, 12), (16, 8, 16), (64, 8, 16), (32, 10, 8), (32, 10, 16), (16, 10, 6)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
     """The tile gradient kernel away from d = 32, n_h = 8: halves narrower than its 16- or 32-element tile (whole float4
@@ -492,7 +492,7 @@ def test_nsf_cl_tile_gradient_kernel_dims(amd, O, dim, K, n_h, inverse):
         assert_close(got[k], ref[k], 5e-5, f"tile vs generic {k}")
 
 
-@pytest.mark.parametrize("dim,K,n_h", [(2, 8, 16), (6, 5, 8), (10, 8, 8), (30, 8, 16), (4, 8, 4)])
+@pytest.mark.parametrize("dim,K,n_h", [(2, 8, 16), (6, 5, 8), (10, 8, 8), (30, 8, 16), (4, 8, 4), (2, 10, 8)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_nsf_cl_padded_twin_matches_the_layer(amd, O, dim, K, n_h, inverse, monkeypatch):
     """Halves that are not whole float4 groups -- dim = 2 is the reference's own NSF_CL shape (tests/test_flows.py:89-99) --

@@ -99,8 +99,11 @@ struct NtShape {
   static constexpr int N_BT = (N_BCOLS + 15) / 16;
   static constexpr int TILES = T_B + N_BT;
   static constexpr int RED_FLOATS = TILES * 256;
-  // one wave per SIMD when the sums take more than half of the wave's registers at two
-  static constexpr int WAVES_PER_SIMD = (4 * TILES <= 116) ? 2 : 1;
+  // one wave per SIMD when the sums take more than 112 of the wave's 256 registers at two.  (At 116 -- hidden 16, K = 8,
+  // the reference's test shape -- two waves spilled 88-95 registers per tile: 2.27 ms forward + backward per layer at
+  // 2^20 x 32 against 2.01 with one wave and none; at 112 -- hidden 8, K = 8, 26 spilled -- two waves win, 996 us per
+  // gradient pass against 1,165.)
+  static constexpr int WAVES_PER_SIMD = (4 * TILES <= 112) ? 2 : 1;
   static constexpr int WAVES = 4 * WAVES_PER_SIMD;               // per workgroup (one workgroup per CU)
   static constexpr bool ACC_AG = WAVES_PER_SIMD == 1;            // the sums in accumulator registers / at the top of the vector file
   static constexpr int ACC_BASE = 256 - 4 * TILES;  // (of the accumulator file / of the vector file)
@@ -653,12 +656,14 @@ struct NtKernelOf;
 #define MNF_NT_TOP(BASE) __attribute__((amdgpu_num_vgpr(BASE / 2)))
 MNF_NT_KERNEL4(16, 8, 8, MNF_NT_TOP(144), 144)
 MNF_NT_KERNEL4(16, 8, 5, MNF_NT_TOP(176), 176)
-MNF_NT_KERNEL4(16, 16, 8, MNF_NT_TOP(140), 140)
+MNF_NT_KERNEL4(16, 16, 8, , 140)
 MNF_NT_KERNEL4(16, 16, 5, MNF_NT_TOP(172), 172)
 MNF_NT_KERNEL4(32, 8, 8, , 44)
 MNF_NT_KERNEL4(32, 8, 5, , 108)
 MNF_NT_KERNEL4(32, 16, 8, , 32)
 MNF_NT_KERNEL4(32, 16, 5, , 100)
+MNF_NT_KERNEL4(16, 8, 10, , 112)
+MNF_NT_KERNEL4(16, 16, 10, , 104)
 
 // grad_flat[p] += (sum over the workgroups' blocks, in a fixed order) / scale; nothing when the launch went cold
 __global__ void __launch_bounds__(256) nsf_tile_reduce_kernel(const float* __restrict__ partials, int n_blocks, int n_params,
@@ -810,7 +815,7 @@ static int launch_tile(const NtArgs& a, int inverse, hipStream_t stream) {
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NT_SHAPES(X) X(16, 8, 8) X(16, 8, 5) X(16, 16, 8) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(32, 16, 5)
+#define MNF_NT_SHAPES(X) X(16, 8, 8) X(16, 8, 5) X(16, 16, 8) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10)
 
 struct TileShape {
   int H, NH, K, hr;

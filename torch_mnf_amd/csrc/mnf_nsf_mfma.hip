@@ -847,7 +847,7 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5)
+#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10)
 // ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (the affine image must be one the Glow
 // MFMA kernel supports: dim 32 and 64 are)
 #define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)

@@ -449,7 +449,7 @@ class _NsfFn(torch.autograd.Function):
         rows = x.shape[0]
         args = (rows, m.dim, m.K, float(m.B), int(ctx.inverse), len(m.h_sizes), m._hid)
         # the tile kernel (conditioner on the matrix cores, 16 rows per wave) where it exists -- dim a multiple of 8 up to
-        # 64, hidden width <= 16, K in {5, 8} --, followed by its fp32 fix-up pass over the tiles it handed back; else
+        # 64, hidden width <= 16, K in {5, 8} (10 up to dim 32) --, followed by its fp32 fix-up pass over the tiles it handed back; else
         # the generic kernel
         table = None
         if not (m.force_generic or m.force_fp32_mfma or _FP32_MFMA_ENV or _NSF_BWD_KERNEL == "generic"
