@@ -98,7 +98,7 @@ int mnf_device_count(void);
  * Shapes with operand images (mnf_affine_half_image_floats() > 0): three hidden layers of at most 32 units each
  * (run at 16 / 24 / 32 units with structural zeros), any even dim <= 256 (a half narrower than its 16/32/64/128-
  * column tile is zero-padded in the image and runs the stack kernel's ragged variant with one layer; hidden width 32
- * up to dim 128; hidden widths 33 .. 64 run at 64 units at dim = 32 and dim = 64, one layer per launch), has_scale / has_shift (an absent net is an all-zero operand set: s = 0 or t = 0 exactly).
+ * up to dim 128; hidden widths 33 .. 64 run at 64 units at dim = 32, 64 and 128, one layer per launch), has_scale / has_shift (an absent net is an all-zero operand set: s = 0 or t = 0 exactly).
  * log_det may be NULL (not computed). accumulate != 0: log_det += ld.
  * force_generic != 0 selects the generic kernel (used by tests to compare the kernels). */
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,

@@ -181,7 +181,7 @@ def test_narrow_half_unaligned_view(amd, O):
 
 
 @pytest.mark.parametrize("kernel", ["split", "fp32"])
-@pytest.mark.parametrize("dim,hid", [(32, 16), (64, 16), (32, 32), (64, 32), (128, 32), (32, 24), (128, 24), (64, 64), (32, 64),
+@pytest.mark.parametrize("dim,hid", [(32, 16), (64, 16), (32, 32), (64, 32), (128, 32), (32, 24), (128, 24), (64, 64), (32, 64), (128, 64),
                                      (64, 48)])
 def test_affine_half_mfma_shape_matrix(amd, O, dim, hid, kernel):
     """Every (dim, hidden width) pair with a specialised kernel: MFMA result vs the oracle, and the

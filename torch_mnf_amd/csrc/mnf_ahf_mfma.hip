@@ -428,7 +428,7 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
 
 // (H, HID) pairs with an instantiated kernel
 // reference default hidden width 24 at d = 32..256, plus widths 16 and 32 at the small dims
-#define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24) X(16, 16) X(32, 16) X(16, 32) X(32, 32) X(64, 32) X(16, 64) X(32, 64)
+#define MNF_AHF_SHAPES(X) X(16, 24) X(32, 24) X(64, 24) X(128, 24) X(16, 16) X(32, 16) X(16, 32) X(32, 32) X(64, 32) X(16, 64) X(32, 64) X(64, 64)
 
 // three hidden layers of at most 64 units: hid = the width the kernels run them at (see ahf_padded_hidden)
 static bool uniform_hidden(int n_hidden, const int* hidden, int& hid) {

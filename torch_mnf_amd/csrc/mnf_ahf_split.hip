@@ -584,7 +584,7 @@ static int launch_split_stack(const float* x, float* y, float* mid, float* log_d
 
 // (H, HID) pairs with a split kernel, and those of the stack kernel (hidden width 32 at d <= 64 spills at two tiles
 // per wave and gains nothing over nine single-layer launches: there it only serves narrow halves, see below)
-#define MNF_AHF_SPLIT_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32) X(16, 64) X(32, 64)
+#define MNF_AHF_SPLIT_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32) X(16, 64) X(32, 64) X(64, 64)
 #define MNF_AHF_SPLIT_STACK_SHAPES(X) X(16, 24) X(32, 24) X(16, 16) X(32, 16) X(64, 24) X(128, 24) X(16, 32) X(32, 32) X(64, 32)
 
 // three hidden layers of at most 64 units: hid = the width the kernels run them at (see ahf_padded_hidden)

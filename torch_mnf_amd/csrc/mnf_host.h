@@ -23,7 +23,7 @@ bool hidden_ok(int n_hidden, const int* hidden);
 // whose half is narrower than its tile runs on the stack kernel's ragged variant: zero operands in the
 // padded columns, element-wise masked row accesses.
 // Hidden width the AffineHalfFlow MFMA kernels run three hidden layers of widths hidden[0..2] at: the smallest of
-// 16 / 24 / 32 / 64 that holds the widest one (0: none; 64: the single-layer forward kernels at dim = 32 and 64 only).  Narrower layers get structural-zero units (zero weights and
+// 16 / 24 / 32 / 64 that holds the widest one (0: none; 64: the single-layer forward kernels at dim = 32, 64 and 128 only).  Narrower layers get structural-zero units (zero weights and
 // bias: LeakyReLU(0) = 0, so they contribute nothing).
 inline int ahf_padded_hidden(int n_hidden, const int* hidden) {
   if (n_hidden != 3 || !hidden) return 0;
