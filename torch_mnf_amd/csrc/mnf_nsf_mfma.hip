@@ -847,12 +847,12 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10)
+#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10) X(16, 32, 8) X(16, 32, 5)
 // ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (the affine image must be one the Glow
 // MFMA kernel supports: dim 32 and 64 are)
 #define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)
 
-// three hidden layers of at most 16 units: nh = the width the kernels run them at (8 or 16; narrower layers get
+// three hidden layers of at most 32 units: nh = the width the kernels run them at (8, 16 or -- dim <= 32 -- 32; narrower layers get
 // structural-zero units)
 static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
   if (n_hidden != 3 || !hidden) return false;
@@ -861,7 +861,7 @@ static bool uniform_hidden3(int n_hidden, const int* hidden, int& nh) {
     if (hidden[i] < 1) return false;
     mx = hidden[i] > mx ? hidden[i] : mx;
   }
-  nh = mx <= 8 ? 8 : mx <= 16 ? 16 : 0;
+  nh = mx <= 8 ? 8 : mx <= 16 ? 16 : mx <= 32 ? 32 : 0;
   return nh != 0;
 }
 
