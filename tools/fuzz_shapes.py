@@ -1,7 +1,7 @@
-"""Randomised shape fuzz: runs of 1-4 AffineHalfFlow layers (any even d <= 256, any three hidden widths <= 32, NICE /
-no-shift variants, random row counts, both directions), RNVP layers (49 <= d <= 900, hidden <= 50) and NSF_CL layers
-(d 32 / 64, K 5 / 8, n_h <= 16) on the MFMA
-kernels against the shape-generic kernels.  Not a pytest (minutes of GPU time); exits non-zero on a mismatch."""
+"""Randomised shape fuzz: runs of 1-4 AffineHalfFlow layers (any even d <= 256, any three hidden widths <= 32 -- <= 64
+at d = 32 / 64 / 128 --, NICE / no-shift variants, random row counts, both directions), RNVP layers (49 <= d <= 900,
+hidden <= 64) and NSF_CL layers (any even d <= 64 -- halves that are not whole float4 groups on the padded twin --,
+K 5 / 8 / 10, n_h <= 16, <= 32 up to d = 32) on the MFMA kernels against the shape-generic kernels.  Not a pytest (minutes of GPU time); exits non-zero on a mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -49,17 +49,21 @@ LD_TOL = 5e-5
 
 for case in range(n_cases):
     if rng.random() < 0.15:  # NSF_CL on the MFMA spline kernels: d in {32, 64}, K in {5, 8}, any n_h <= 16
-        dim, K, n_h = int(rng.choice([32, 64])), int(rng.choice([5, 8])), int(rng.integers(1, 17))
-        if dim == 64 and K == 5 and n_h > 8:
-            n_h = 8
+        dim, K = int(rng.integers(1, 33)) * 2, int(rng.choice([5, 8, 10]))
+        n_h = int(rng.integers(4, 33 if dim <= 32 else 17))
+        if K == 10 and dim > 32:
+            K = 8
+        if dim % 8 and n_h > 16:  # (the padded twin exists where the tile gradient kernel does)
+            n_h = 16
         rows, inverse = int(rng.integers(1, 3000)), bool(rng.integers(0, 2))
+        amd.flows._NSF_PAD_MIN_ROWS = 0
         f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
         f.load_state_dict(recipes.nsf_cl_params(int(rng.integers(1 << 30)), dim, K, n_h))
         f.to(dev)
         x = torch.randn(rows, dim, device=dev) * 1.5
         with torch.no_grad():
             y1, l1 = f.inverse(x) if inverse else f.forward(x)
-            mfma += int(f._split_image(torch.device(dev, 0)) is not None)
+            mfma += int("generic" not in amd.last_kernel())
             f.force_generic = True
             y2, l2 = f.inverse(x) if inverse else f.forward(x)
         ok = close(y1, y2, 2e-5) and close(l1, l2, LD_TOL)
@@ -67,6 +71,8 @@ for case in range(n_cases):
     elif rng.random() < 0.75:
         dim = int(rng.integers(1, 129)) * 2
         h = tuple(int(v) for v in rng.integers(1, 33, size=3)) if rng.random() < 0.5 else (24, 24, 24)
+        if dim in (32, 64, 128) and rng.random() < 0.3:
+            h = tuple(int(v) for v in rng.integers(20, 65, size=3))
         if dim > 128 and max(h) > 24 or dim > 128 and max(h) <= 16:
             h = (24, 24, 24)
         kw = {}
@@ -108,7 +114,7 @@ for case in range(n_cases):
                 if ok: print("   ill-conditioned draw, within the split format's error:", desc_of())
         desc = desc_of()
     else:
-        dim, hid, rows = int(rng.integers(49, 901)), int(rng.integers(1, 51)), int(rng.integers(1, 3000))
+        dim, hid, rows = int(rng.integers(49, 901)), int(rng.integers(1, 65)), int(rng.integers(1, 3000))
         f = amd.RNVP(dim, h_sizes=(hid,))
         f.load_state_dict(recipes.rnvp_params(int(rng.integers(1 << 30)), dim, hid))
         f.to(dev)
