@@ -14,6 +14,7 @@
 
 #include "mnf_ahf_shape.h"
 #include "mnf_device.h"
+#include "mnf_generic_gemm.h"
 #include "mnf_host.h"
 
 namespace mnf {
@@ -35,13 +36,7 @@ __device__ __forceinline__ void mlp_forward_keep(const float* __restrict__ flat,
     const float* W = flat + nd.w_off[l];
     const float* b = flat + nd.b_off[l];
     const bool last = l == nd.n_lin - 1;
-    for (int idx = threadIdx.x; idx < R * n_out; idx += blockDim.x) {
-      const int r = idx / n_out, o = idx - r * n_out;
-      float acc = b[o];
-      for (int k = 0; k < n_in; ++k) acc = fmaf(W[(size_t)o * n_in + k], cur[r * ld_cur + k], acc);
-      out[r * n_out + o] = last ? acc : leaky(acc);
-    }
-    __syncthreads();
+    staged_linear(W, b, cur, ld_cur, out, n_out, n_in, n_out, R, !last);  // (mnf_generic_gemm.h; ends with a barrier)
     cur = out;
     ld_cur = n_out;
   }
@@ -80,10 +75,11 @@ __device__ __forceinline__ void mlp_backward(const float* __restrict__ flat, flo
         grad_add(grad_flat + nd.b_off[l] + o, acc, lds_acc);
       }
     }
+    const float* Wk = staged_weights(W, n_in, n_out);  // (lanes along k: conflict-free LDS reads when it fits)
     for (int idx = threadIdx.x; idx < R * n_in; idx += blockDim.x) {
       const int r = idx / n_in, k = idx - r * n_in;
       float acc = 0.f;
-      for (int o = 0; o < n_out; ++o) acc = fmaf(W[(size_t)o * n_in + k], delta[r * n_out + o], acc);
+      for (int o = 0; o < n_out; ++o) acc = fmaf(Wk[(size_t)o * n_in + k], delta[r * n_out + o], acc);
       if (l == 0) {
         g_in[idx] += acc;
       } else {

@@ -17,6 +17,7 @@
 
 #include "mnf_device.h"
 #include "mnf_host.h"
+#include "mnf_generic_gemm.h"
 #include "mnf_split.h"
 
 namespace mnf {
@@ -27,19 +28,12 @@ constexpr int kLdsBudgetFloats = 15 * 1024;  // 60 KiB of dynamic LDS per workgr
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
 // One Linear (+ optional LeakyReLU) over R rows held in LDS.
-// in: [R][ld_in], out: [R][ld_out]; weights (n_out, n_in) row-major in global memory.
+// in: [R][ld_in], out: [R][ld_out]; weights (n_out, n_in) row-major in global memory (mnf_generic_gemm.h: staged
+// through LDS tile by tile in the orientation the dot products read them in).
 __device__ __forceinline__ void block_linear(const float* __restrict__ W, const float* __restrict__ b,
                                              const float* in, int ld_in, float* out, int ld_out,
                                              int n_in, int n_out, int R, bool act) {
-  for (int idx = threadIdx.x; idx < R * n_out; idx += blockDim.x) {
-    const int r = idx / n_out, o = idx - r * n_out;
-    const float* w = W + (size_t)o * n_in;
-    const float* a = in + r * ld_in;
-    float acc = b[o];
-    for (int k = 0; k < n_in; ++k) acc = fmaf(w[k], a[k], acc);
-    out[r * ld_out + o] = act ? leaky(acc) : acc;
-  }
-  __syncthreads();
+  staged_linear(W, b, in, ld_in, out, ld_out, n_in, n_out, R, act);
 }
 
 // Whole MLP.  `in` holds the input [R][ld_in]; bufA/bufB are ping-pong scratch [R][ldw];
