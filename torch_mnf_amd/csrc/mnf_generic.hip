@@ -940,8 +940,15 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
                                    n_hidden, hidden, has_scale, has_shift, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
-  if (y_sqnorm) return MNF_ERR_UNSUPPORTED;  // only the specialised kernel emits |y|^2
-  if ((has_scale || has_shift) && !flat) return MNF_ERR_INVALID_ARG;
+  if ((has_scale || has_shift) && !flat) return y_sqnorm ? MNF_ERR_UNSUPPORTED : MNF_ERR_INVALID_ARG;
+  // any other shape: the run-time-shaped matrix-core kernel (mnf_ahf_rt.hip) from kRtMinRows rows on (force_generic == 2:
+  // at any row count, whatever the shape's specialised kernels -- tests and the coverage map compare the two)
+  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+    const int rc = ahf_rt_launch(x, y, log_det, y_sqnorm, accumulate, flat, rows, dim, parity, inverse, n_hidden, hidden,
+                                 has_scale, has_shift, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
+  if (y_sqnorm) return MNF_ERR_UNSUPPORTED;  // the VALU kernel does not emit |y|^2
 
   AhfArgs a;
   a.x = x; a.y = y; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim;

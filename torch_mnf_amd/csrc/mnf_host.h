@@ -99,6 +99,13 @@ inline int64_t balanced_grid(int64_t n_tiles, int waves_per_block, int resident_
   return best;
 }
 
+// The run-time-shaped matrix-core kernels (mnf_rt.h: any layer count and widths, weights from `flat`) take a call from this
+// many rows on; below, the VALU any-shape kernels of mnf_generic.hip (one workgroup per few rows) have the lower latency.
+constexpr int64_t kRtMinRows = 2048;
+int ahf_rt_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate, const float* flat, int64_t rows,
+                  int dim, int parity, int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                  hipStream_t stream);
+
 // Specialised launchers: return MNF_ERR_UNSUPPORTED when the shape has no MFMA kernel, in
 // which case the caller falls through to the generic kernel.
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
