@@ -99,5 +99,35 @@ if which in ("ahf", "all"):
             line += f"  {amd.last_kernel()} {t * 1e6 / ROWS:.3f} ns/row"
         print(line)
 
+if which in ("nsf", "all"):
+    print("== NSF_CL rt vs oracle")
+    for dim, K, n_h in [(32, 8, 8), (64, 8, 16), (128, 8, 8), (128, 5, 32), (2, 5, 8), (6, 3, 5), (50, 10, 12), (16, 16, 64), (200, 4, 16), (48, 10, 32), (128, 10, 32)]:
+        sd = recipes.nsf_cl_params(21 + dim + K, dim, K, n_h)
+        for rows in (1, 37, 1500):
+            x = recipes.gaussian(5 + dim + rows, rows, dim, scale=1.4)
+            f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+            f.load_state_dict(sd)
+            f.to(DEV)
+            f.force_generic = 2
+            for inverse in (False, True):
+                ry, rld = O.nsf_cl(x, sd, K, 3.0, inverse=inverse)
+                with torch.no_grad():
+                    y, ld = (f.inverse if inverse else f.forward)(x.to(DEV))
+                k = amd.last_kernel()
+                e1, e2 = err(y, ry), err(ld, rld)
+                if max(e1, e2) > 1e-5 or k != "nsf_rt":
+                    check(f"d={dim} K={K} n_h={n_h} rows={rows} inv={inverse} kernel={k} y={e1:.2e} ld", e2)
+    print("== NSF_CL time per row")
+    for dim, K, n_h in [(32, 8, 8), (64, 8, 8), (64, 8, 16), (128, 8, 8), (128, 10, 32), (64, 10, 16), (48, 5, 32), (2, 8, 8)]:
+        f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h).to(DEV)
+        x = torch.randn(ROWS, dim, device=DEV) * 1.4
+        line = f"  d={dim} K={K} n_h={n_h}:"
+        for force in (0, 2, 1):
+            f.force_generic = force
+            with torch.no_grad():
+                t = timed(lambda: f.forward(x), reps=3)
+            line += f"  {amd.last_kernel()} {t * 1e6 / ROWS:.3f} ns/row"
+        print(line)
+
 print("FAILURES:", bad)
 sys.exit(1 if bad else 0)

@@ -1118,6 +1118,13 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const f
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (!flat) return MNF_ERR_INVALID_ARG;
+  // any other shape: the run-time-shaped matrix-core kernel (mnf_nsf_rt.hip; force_generic == 2: at any row count, whatever
+  // the shape's specialised kernels)
+  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+    const int rc = nsf_rt_launch(x, y, log_det, accumulate, flat, rows, dim, K, tail_bound, inverse, n_hidden, hidden,
+                                 (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
   NsfArgs a;
   a.x = x; a.y = y; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim; a.K = K;
   a.inverse = inverse != 0; a.accumulate = accumulate != 0; a.T = tail_bound;

@@ -106,6 +106,9 @@ int ahf_rt_launch(const float* x, float* y, float* log_det, float* ysq, int accu
                   int dim, int parity, int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
                   hipStream_t stream);
 
+int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, const float* flat, int64_t rows, int dim, int K,
+                  float tail_bound, int inverse, int n_hidden, const int* hidden, hipStream_t stream);
+
 // Specialised launchers: return MNF_ERR_UNSUPPORTED when the shape has no MFMA kernel, in
 // which case the caller falls through to the generic kernel.
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,
