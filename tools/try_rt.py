@@ -129,5 +129,47 @@ if which in ("nsf", "all"):
             line += f"  {amd.last_kernel()} {t * 1e6 / ROWS:.3f} ns/row"
         print(line)
 
+if which in ("rnvp", "all"):
+    print("== RNVP rt vs oracle")
+    for dim, hs in [(800, (100,)), (50, (100,)), (128, (30,)), (784, (50, 40)), (50, (17,)), (37, (200,)), (1024, (64, 64)), (130, (130,))]:
+        sd = recipes.mlp_params(np.random.default_rng(31 + dim), "net", (dim, *hs))
+        rng = np.random.default_rng(32 + dim)
+        for name in ("t", "s"):
+            k = 1.0 / np.sqrt(hs[-1])
+            sd[f"{name}.weight"] = torch.from_numpy(rng.uniform(-k, k, size=(dim, hs[-1])).astype(np.float32))
+            sd[f"{name}.bias"] = torch.from_numpy(rng.uniform(-k, k, size=(dim,)).astype(np.float32))
+        for rows in (1, 37, 700):
+            z = recipes.gaussian(5 + dim + rows, rows, dim)
+            mask = recipes.bernoulli_mask(97, rows, dim)
+            f = amd.RNVP(dim, h_sizes=hs)
+            f.load_state_dict(sd)
+            f.to(DEV)
+            f.force_generic = 2
+            ry, rld = O.rnvp(z, sd, mask)
+            with torch.no_grad():
+                y, ld = f.forward(z.to(DEV), mask=mask.to(DEV))
+            k = amd.last_kernel()
+            e1, e2 = err(y, ry), err(ld, rld)
+            if max(e1, e2) > 1e-5 or k != "rnvp_rt":
+                check(f"d={dim} h={hs} rows={rows} kernel={k} x={e1:.2e} ld", e2)
+            m_seed = f.mask_for(77, rows)
+            with torch.no_grad():
+                y, ld = f.forward(z.to(DEV), seed=77)
+            ry, rld = O.rnvp(z, sd, m_seed.cpu())
+            e1, e2 = err(y, ry), err(ld, rld)
+            if max(e1, e2) > 1e-5 or amd.last_kernel() != "rnvp_rt":
+                check(f"d={dim} h={hs} rows={rows} seeded kernel={amd.last_kernel()} x={e1:.2e} ld", e2)
+    print("== RNVP time per row")
+    for dim, hs in [(800, (100,)), (800, (50,)), (50, (100,)), (128, (100,)), (2048, (100,)), (784, (50,)), (50, (50,))]:
+        f = amd.RNVP(dim, h_sizes=hs).to(DEV)
+        x = torch.randn(ROWS, dim, device=DEV)
+        line = f"  d={dim} h={hs}:"
+        for force in (0, 2, 1):
+            f.force_generic = force
+            with torch.no_grad():
+                t = timed(lambda: f.forward(x, seed=5), reps=3)
+            line += f"  {amd.last_kernel()} {t * 1e6 / ROWS:.3f} ns/row"
+        print(line)
+
 print("FAILURES:", bad)
 sys.exit(1 if bad else 0)

@@ -247,7 +247,7 @@ static int ahf_rt_launch_class(AhfRtArgs& a, int64_t n_blocks, int64_t n_bias, h
   // barriers, staging and memory waits); persistent grid = what the occupancy query says is resident
   auto kernel = !a.vec ? ahf_rt_kernel<MT_MAX, NTL, NW, false, false>
                        : resident ? ahf_rt_kernel<MT_MAX, NTL, NW, true, true> : ahf_rt_kernel<MT_MAX, NTL, NW, false, true>;
-  const int nw = NW == 8 && lds <= 79 * 1024 ? 4 : NW;
+  const int nw = NW == 8 && resident && lds <= 79 * 1024 ? 4 : NW;  // (streaming: every wave of the CU shares one conversion of the weights)
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   const int64_t rows_per_block = (int64_t)nw * NTL * 16;

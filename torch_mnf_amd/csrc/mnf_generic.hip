@@ -1238,6 +1238,12 @@ int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, floa
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }
   if (!flat) return MNF_ERR_INVALID_ARG;
+  // any other shape: the run-time-shaped matrix-core kernel (mnf_rnvp_rt.hip; force_generic == 2: at any row count,
+  // whatever the shape's specialised kernels)
+  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+    const int rc = rnvp_rt_launch(z, mask, seed, x, log_det, accumulate, flat, rows, dim, n_hidden, hidden, (hipStream_t)stream);
+    if (rc != MNF_ERR_UNSUPPORTED) return rc;
+  }
   RnvpArgs a;
   a.z = z; a.mask = mask; a.x = x; a.log_det = log_det; a.flat = flat; a.rows = rows; a.dim = dim;
   a.accumulate = accumulate != 0; a.seed = seed;

@@ -109,6 +109,9 @@ int ahf_rt_launch(const float* x, float* y, float* log_det, float* ysq, int accu
 int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, const float* flat, int64_t rows, int dim, int K,
                   float tail_bound, int inverse, int n_hidden, const int* hidden, hipStream_t stream);
 
+int rnvp_rt_launch(const float* z, const float* mask, uint64_t seed, float* x, float* log_det, int accumulate,
+                   const float* flat, int64_t rows, int dim, int n_hidden, const int* hidden, hipStream_t stream);
+
 // Specialised launchers: return MNF_ERR_UNSUPPORTED when the shape has no MFMA kernel, in
 // which case the caller falls through to the generic kernel.
 int ahf_mfma_launch(const float* x, float* y, float* log_det, float* ysq, int accumulate,

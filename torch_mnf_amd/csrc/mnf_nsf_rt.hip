@@ -49,17 +49,16 @@ __device__ __forceinline__ int nsf_tile_of(int tv, int K) {
 
 // Output layer of one conditioner net, walked [slot][valid tile][K-step] from slot s0: block row i = 4 q' + r' is the
 // weight row of (element 16 g + 4 q' + r, position 4 t' + r').
-struct NsfOutFetch {
+struct NsfOutFetch {  // digits (K-step, valid tile, slot - s0)
   const float* W;  // (P H) x n_in
-  int n_in, H, K, KS, TV, s0;
-  __device__ __forceinline__ float operator()(int b, int i, int k) const {
-    const int ks = b % KS, st = b / KS, tv = st % TV, slot = s0 + st / TV;
-    const int g = slot >> 2, r = slot & 3, tp = nsf_tile_of(tv, K);
+  int n_in, H, K, R0, R1, s0;  // R0 = KS, R1 = TV
+  __device__ __forceinline__ void load(int ks, int tv, int sl, int i, int q, f32x4& va, f32x4& vb) const {
+    const int slot = s0 + sl, g = slot >> 2, r = slot & 3, tp = nsf_tile_of(tv, K);
     const int e = 16 * g + 4 * (i >> 2) + r, pos = 4 * tp + (i & 3), c = pos >> 4, kk = pos & 15;
-    const int col = 32 * ks + k;
-    const bool ok = e < H && kk < (c < 2 ? K : K - 1) && col < n_in;
-    const float v = W[ok ? (int64_t)(e * (3 * K - 1) + c * K + kk) * n_in + col : 0];
-    return ok ? v : 0.f;
+    const bool ok = e < H && kk < (c < 2 ? K : K - 1);
+    const int c0 = 32 * ks;
+    const bool aligned = (n_in & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    rt::load_row8(W + (int64_t)(ok ? e * (3 * K - 1) + c * K + kk : 0) * n_in, ok, c0, n_in, aligned, q, va, vb);
   }
 };
 struct NsfOutBias {  // tile t = (slot - s0) * TV + tv
@@ -258,7 +257,7 @@ int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, cons
     return 1;
   });
   auto kernel = !vec ? nsf_rt_kernel<4, NW, false, false> : resident ? nsf_rt_kernel<4, NW, true, true> : nsf_rt_kernel<4, NW, false, true>;
-  const int nw = lds <= 79 * 1024 ? 4 : NW;
+  const int nw = resident && lds <= 79 * 1024 ? 4 : NW;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
   const int64_t rows_per_block = (int64_t)nw * 16;

@@ -83,25 +83,37 @@ __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float,
 // ---------------------------------------------------------------------------------------------------------------------
 // Block b of a chunk: A operand of one (output tile, K-step).  Lane (i, q) of the block holds, in slot e of its 8 halves,
 // the weight of output row i against K index k = (e < 4 ? 4 q + e : 16 + 4 q + (e - 4)) of the step -- the order in
-// which two accumulator tiles form a B operand (pair_operand, mnf_split.h).  fetch(b, i, k) returns that weight (0 for
-// padding); every weight is multiplied by `wdown` (a power of two) first.
+// which two accumulator tiles form a B operand (pair_operand, mnf_split.h).  A wave converts whole blocks (block index =
+// a mixed-radix number with digits (d0, d1, d2), d0 fastest, radices fetch.R0, fetch.R1: kept as counters, no division);
+// fetch.load(d0, d1, d2, i, q, lo4, hi4) returns the lane's eight weights (0 for padding); every weight is multiplied by
+// `wdown` (a power of two) first.
 template <typename Fetch>
 __device__ __forceinline__ void stage_blocks(uint32_t* dst, int n_blocks, const Fetch& fetch, float wdown) {
-  for (int u = threadIdx.x; u < n_blocks * 64; u += blockDim.x) {
-    const int b = u >> 6, lane = u & 63, i = lane & 15, q = lane >> 4;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = fetch(b, i, 4 * q + e) * wdown;
-      v[4 + e] = fetch(b, i, 16 + 4 * q + e) * wdown;
-    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, i = lane & 15, q = lane >> 4;
+  // a wave converts a contiguous range of blocks: the digits are set once and then counted up
+  const int per = (n_blocks + nw - 1) / nw, b0 = wave * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  int d0 = b0 % fetch.R0, rest = b0 / fetch.R0, d1 = rest % fetch.R1, d2 = rest / fetch.R1;
+  for (int b = b0; b < b1; ++b) {
+    f32x4 va, vb;
+    fetch.load(d0, d1, d2, i, q, va, vb);
+    va *= wdown;
+    vb *= wdown;
     uint32_t hi[4], lo[4];
     float unused = 0.f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) split_pair(v[2 * p], v[2 * p + 1], hi[p], lo[p], unused);
+    split_pair(va[0], va[1], hi[0], lo[0], unused);
+    split_pair(va[2], va[3], hi[1], lo[1], unused);
+    split_pair(vb[0], vb[1], hi[2], lo[2], unused);
+    split_pair(vb[2], vb[3], hi[3], lo[3], unused);
     u32x4v* d = reinterpret_cast<u32x4v*>(dst + b * kBlockWords);
     d[lane] = u32x4v{hi[0], hi[1], hi[2], hi[3]};
     d[64 + lane] = u32x4v{lo[0], lo[1], lo[2], lo[3]};
+    if (++d0 == fetch.R0) {
+      d0 = 0;
+      if (++d1 == fetch.R1) {
+        d1 = 0;
+        ++d2;
+      }
+    }
   }
 }
 
@@ -111,31 +123,52 @@ __device__ __forceinline__ void stage_bias(float* dst, int n_tiles, const Bias& 
   for (int u = threadIdx.x; u < n_tiles * 16; u += blockDim.x) dst[u] = bias(u >> 4, u & 15);
 }
 
-// A dense Linear W (n_out x n_in, row-major): block b of a chunk that starts at K-step ks0 and walks [K-step][tile]
-// (K-major stages: the first layer and the hidden layers)
+// the eight weights of lane (i, q) out of row `row` (n_cols wide, valid when row_ok) of a row-major matrix: columns
+// c0 + 4 q + e and c0 + 16 + 4 q + e, zeros beyond n_cols.  aligned: every row starts 16-byte aligned and n_cols % 4 == 0
+// (two dwordx4 per lane), else element by element.  No load sits under a divergent branch.
+__device__ __forceinline__ void load_row8(const float* __restrict__ row, bool row_ok, int c0, int n_cols, bool aligned, int q,
+                                          f32x4& va, f32x4& vb) {
+  const int ca = c0 + 4 * q, cb = ca + 16;
+  if (aligned) {  // (uniform)
+    const bool oka = row_ok && ca < n_cols, okb = row_ok && cb < n_cols;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + (oka ? ca : 0));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(row + (okb ? cb : 0));
+    va = oka ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+    vb = okb ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool oka = row_ok && ca + e < n_cols, okb = row_ok && cb + e < n_cols;
+    const float xa = row[oka ? ca + e : 0], xb = row[okb ? cb + e : 0];
+    va[e] = oka ? xa : 0.f;
+    vb[e] = okb ? xb : 0.f;
+  }
+}
+
+// A dense Linear W (n_out x n_in, row-major) walked [K-step][tile] from K-step ks0 (K-major stages: the first layer and
+// the hidden layers): digits (tile, K-step - ks0)
 struct DenseKMajor {
   const float* W;
-  int n_in, n_out, MT, ks0;
-  __device__ __forceinline__ float operator()(int b, int i, int k) const {
-    const int ks = ks0 + b / MT, m = b - (b / MT) * MT;
-    const int o = 16 * m + i, c = 32 * ks + k;
-    const bool ok = o < n_out && c < n_in;
-    const float v = W[ok ? (size_t)o * n_in + c : 0];
-    return ok ? v : 0.f;
+  int n_in, n_out, R0, ks0;  // R0 = MT
+  static constexpr int R1 = 1 << 30;
+  __device__ __forceinline__ void load(int m, int ksl, int, int i, int q, f32x4& va, f32x4& vb) const {
+    const int o = 16 * m + i, c0 = 32 * (ks0 + ksl);
+    const bool aligned = (n_in & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    load_row8(W + (int64_t)(o < n_out ? o : 0) * n_in, o < n_out, c0, n_in, aligned, q, va, vb);
   }
 };
-// the same matrix walked [tile][K-step] from output tile m0 (M-major stages: the output layer), `heads` matrices of one
-// shape interleaved per tile: block = ((m - m0) * heads + head) * KS + ks, head h at W + h * head_stride
+// the same matrix walked [tile][head][K-step] from output tile m0 (M-major stages: the output layer), `heads` matrices of
+// one shape interleaved per tile, head h at W + h * head_stride: digits (K-step, head, tile - m0)
 struct DenseMMajor {
   const float* W;
-  int n_in, n_out, KS, m0, heads;
+  int n_in, n_out, R0, m0, R1;  // R0 = KS, R1 = heads
   int64_t head_stride;
-  __device__ __forceinline__ float operator()(int b, int i, int k) const {
-    const int ks = b % KS, mh = b / KS, head = mh % heads, m = m0 + mh / heads;
-    const int o = 16 * m + i, c = 32 * ks + k;
-    const bool ok = o < n_out && c < n_in;
-    const float v = W[ok ? head * head_stride + (int64_t)o * n_in + c : 0];
-    return ok ? v : 0.f;
+  __device__ __forceinline__ void load(int ks, int head, int ml, int i, int q, f32x4& va, f32x4& vb) const {
+    const int o = 16 * (m0 + ml) + i, c0 = 32 * ks;
+    const float* Wh = W + head * head_stride;
+    const bool aligned = (n_in & 3) == 0 && (reinterpret_cast<uintptr_t>(Wh) & 15) == 0;
+    load_row8(Wh + (int64_t)(o < n_out ? o : 0) * n_in, o < n_out, c0, n_in, aligned, q, va, vb);
   }
 };
 struct DenseBias {
