@@ -1,0 +1,241 @@
+"""Round 6: the run-time-shaped matrix-core kernels (csrc/mnf_rt.h: any layer count and widths, weights converted from
+the plain parameter vector inside the kernel) against the CPU oracle, through the C ABI (mnf_affine_half / mnf_nsf_cl /
+mnf_rnvp_seeded with force_generic = 2, and by default for the shapes without a per-shape kernel)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from helpers import RTOL, assert_close, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch_mnf_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch_mnf_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import flow_oracle
+
+    return flow_oracle
+
+
+def cuda(a):
+    return a.to(DEV)
+
+
+def rt(f):
+    f.force_generic = 2  # include/mnf_hip.h: the run-time-shaped kernel whatever the shape's specialised kernels
+    return f.to(DEV)
+
+
+# ------------------------------------------------------------------ AffineHalfFlow (reference: affine_half_flow.py:28-66)
+AHF_SHAPES = [
+    (64, (24, 24), {}), (64, (24, 24, 24), {}), (64, (64, 64, 64), {}), (32, (24, 24), {}), (2, (24, 24), {}),
+    (8, (16, 16, 16), {}), (50, (17, 30), {}), (6, (5, 9), {}), (128, (100,), {}), (256, (32, 32, 32), {}),
+    (256, (200, 130, 40, 7), {}), (512, (24, 24, 24), {}), (512, (64, 64, 64), {}), (1024, (32, 32), {}),
+    (64, (24, 24), {"scale": False}), (64, (24, 24), {"shift": False}), (40, (256,), {}),
+]
+
+
+@pytest.mark.parametrize("dim,hs,kw", AHF_SHAPES, ids=lambda v: str(v).replace(" ", ""))
+def test_affine_half_rt_shape_matrix(amd, O, dim, hs, kw):
+    """Any h_sizes length >= 1, hidden widths 4..256, any even dim, NICE / no-shift variants: the run-time-shaped kernel
+    against the oracle, both parities and directions, row counts with partial tiles, one row."""
+    sd = recipes.affine_half_params(11 + dim, dim, h_sizes=hs, s_last_gain=3.0, **kw)
+    for rows in (1, 37, 1000):
+        x = recipes.gaussian(5 + dim + rows, rows, dim)
+        for parity in (False, True):
+            f = amd.AffineHalfFlow(dim, parity=parity, h_sizes=hs, **kw)
+            f.load_state_dict(sd)
+            rt(f)
+            for inverse in (False, True):
+                ref_y, ref_ld = O.affine_half(x, sd, parity, inverse, **kw)
+                with torch.no_grad():
+                    y, ld = f.forward(cuda(x), inverse=inverse)
+                assert amd.last_kernel() == "ahf_rt"
+                what = f"ahf_rt d={dim} h={hs} {kw} rows={rows} par={parity} inv={inverse}"
+                assert_parity(y, ref_y.numpy(), None, what + " y")
+                if rows > 1:  # (one row: max |log_det| is the one value itself, a sum that may nearly cancel)
+                    assert_parity(ld, ref_ld.numpy(), None, what + " ld")
+                else:
+                    assert abs(float(ld[0]) - float(ref_ld[0])) <= 1e-5 * max(1.0, float(ref_ld.abs().max()))
+
+
+def test_affine_half_rt_is_the_default_without_a_specialised_kernel(amd, O):
+    """From 2,048 rows on, a shape without a per-shape kernel lands on the run-time-shaped one by itself (no warning about
+    an any-shape kernel); below, and for hidden layers narrower than 4 units, the VALU kernel keeps the call."""
+    import warnings
+
+    dim, hs = 64, (24, 24)
+    sd = recipes.affine_half_params(3, dim, h_sizes=hs)
+    f = amd.AffineHalfFlow(dim, parity=False, h_sizes=hs)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    x = recipes.gaussian(4, 5000, dim)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            y, ld = f.forward(cuda(x))
+    assert amd.last_kernel() == "ahf_rt"
+    ref_y, ref_ld = O.affine_half(x, sd, False, False)
+    assert_close(y, ref_y, RTOL, "y")
+    assert_close(ld, ref_ld, RTOL, "ld")
+    with torch.no_grad():
+        f.forward(cuda(x[:100]))
+    assert amd.last_kernel() == "ahf_generic"
+    g = amd.AffineHalfFlow(dim, parity=False, h_sizes=(2, 24)).to(DEV)
+    with torch.no_grad():
+        g.forward(cuda(x))
+    assert amd.last_kernel() == "ahf_generic"
+
+
+@pytest.mark.parametrize("case", ["big_rows", "big_weights", "tiny_first_layer", "inf_row"])
+def test_affine_half_rt_range(amd, O, case):
+    """The run-time-shaped kernel has no fp32 fix-up path: rows beyond the split range are scaled by a power of two
+    before the split, weights are staged scaled to the top of f16's range -- results must not depend on either range."""
+    dim, hs = 64, (24, 24)
+    sd = recipes.affine_half_params(3, dim, h_sizes=hs)
+    x = recipes.gaussian(4, 500, dim)
+    if case == "big_rows":
+        x = x.clone()
+        x[::7] *= 3.0e5
+        sd = {k: (v * 1e-5 if k.endswith("0.weight") else v) for k, v in sd.items()}
+    elif case == "big_weights":
+        sd = {k: (v * 3000 if k.endswith("2.weight") else (v / 3000 if k.endswith("4.weight") else v)) for k, v in sd.items()}
+    elif case == "tiny_first_layer":
+        x = x * 1.0e4
+        sd = {k: (v * 1e-4 if k.endswith("0.weight") else v) for k, v in sd.items()}
+    elif case == "inf_row":
+        x = x.clone()
+        x[3, 1] = float("inf")
+    f = amd.AffineHalfFlow(dim, parity=False, h_sizes=hs)
+    f.load_state_dict(sd)
+    rt(f)
+    ref_y, ref_ld = O.affine_half(x, sd, False, False)
+    with torch.no_grad():
+        y, ld = f.forward(cuda(x))
+    assert amd.last_kernel() == "ahf_rt"
+    if case == "inf_row":
+        # a row holding a non-finite conditioner input comes out non-finite (the reference: inf or NaN, here NaN) and
+        # does not touch its 15 tile neighbours
+        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        keep[3] = False
+        assert not bool(torch.isfinite(y.cpu()[3, dim // 2:]).any()) and not bool(torch.isfinite(ld.cpu()[3]))
+        assert not bool(torch.isfinite(ref_y[3, dim // 2:]).any())
+        assert_close(y.cpu()[keep], ref_y[keep], RTOL, "y (other rows)")
+        assert_close(ld.cpu()[keep], ref_ld[keep], RTOL, "ld (other rows)")
+        return
+    assert_close(y, ref_y, RTOL, f"{case} y")
+    assert_close(ld, ref_ld, RTOL, f"{case} ld")
+
+
+# ------------------------------------------------------------------ NSF_CL (reference: spline_flow.py:241-285)
+NSF_SHAPES = [(32, 8, 8), (64, 8, 16), (128, 8, 8), (128, 5, 32), (2, 5, 8), (6, 3, 5), (50, 10, 12), (16, 16, 64),
+              (200, 4, 16), (48, 10, 32), (128, 10, 32), (64, 2, 8), (24, 13, 20)]
+
+
+@pytest.mark.parametrize("dim,K,n_h", NSF_SHAPES)
+def test_nsf_cl_rt_shape_matrix(amd, O, dim, K, n_h):
+    """Any dim, K = 2..16, n_h = 4..64: the run-time-shaped kernel against the oracle, both directions, on the parity
+    rule's float64 budget (a spline element a few ulps from a knot moves by more than 1e-5 between two correct fp32
+    evaluations: helpers.assert_parity)."""
+    sd = recipes.nsf_cl_params(21 + dim + K, dim, K, n_h)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    rt(f)
+    for rows in (37, 1500):
+        x = recipes.gaussian(5 + dim + rows, rows, dim, scale=1.4)
+        for inverse in (False, True):
+            ref_y, ref_ld = O.nsf_cl(x, sd, K, 3.0, inverse)
+            y64, ld64 = O.nsf_cl(x.double(), sd64, K, 3.0, inverse)
+            with torch.no_grad():
+                y, ld = (f.inverse if inverse else f.forward)(cuda(x))
+            assert amd.last_kernel() == "nsf_rt"
+            what = f"nsf_rt ({dim},{K},{n_h}) rows={rows} inv={inverse}"
+            assert_parity(y, ref_y.numpy(), y64.numpy(), what + " y")
+            assert_parity(ld, ref_ld.numpy(), ld64.numpy(), what + " ld")
+
+
+def test_nsf_cl_rt_round_trip_and_default(amd):
+    """d = 128 has no per-shape kernel: the default path is the run-time-shaped one, and inverse(forward(x)) = x with
+    cancelling log-dets at 2^18 rows."""
+    dim, K, n_h, rows = 128, 8, 8, 1 << 18
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(recipes.nsf_cl_params(77, dim, K, n_h))
+    f.to(DEV)
+    x = torch.randn(rows, dim, device=DEV) * 1.3
+    with torch.no_grad():
+        y, ld = f.forward(x)
+        assert amd.last_kernel() == "nsf_rt"
+        xb, ldb = f.inverse(y)
+    assert float((xb - x).abs().max()) <= 2e-5 * float(x.abs().max())
+    assert float((ld + ldb).abs().max()) <= 2e-5 * float(ld.abs().max())
+
+
+# ------------------------------------------------------------------ RNVP (reference: rnvp.py:19-39)
+def _rnvp_sd(seed, dim, hs):
+    rng = np.random.default_rng(seed)
+    sd = recipes.mlp_params(rng, "net", (dim, *hs), gain=1.5)
+    k = 1.5 / np.sqrt(hs[-1])
+    for name in ("t", "s"):
+        sd[f"{name}.weight"] = torch.from_numpy(rng.uniform(-k, k, size=(dim, hs[-1])).astype(np.float32))
+        sd[f"{name}.bias"] = torch.from_numpy(rng.uniform(-k, k, size=(dim,)).astype(np.float32))
+    return sd
+
+
+RNVP_SHAPES = [(800, (100,)), (50, (100,)), (128, (30,)), (784, (50, 40)), (50, (17,)), (37, (200,)), (1024, (64, 64)),
+               (130, (130,)), (800, (50,)), (2048, (100,)), (64, (7, 9, 11))]
+
+
+@pytest.mark.parametrize("dim,hs", RNVP_SHAPES, ids=lambda v: str(v).replace(" ", ""))
+def test_rnvp_rt_shape_matrix(amd, O, dim, hs):
+    """Any number of conditioner layers of widths 4..256, any dim: explicit mask and the in-kernel mask (the bits
+    mnf_rnvp_mask materialises), row counts with partial tiles, one row."""
+    sd = _rnvp_sd(31 + dim, dim, hs)
+    f = amd.RNVP(dim, h_sizes=hs)
+    f.load_state_dict(sd)
+    rt(f)
+    for rows in (1, 37, 700):
+        z = recipes.gaussian(5 + dim + rows, rows, dim)
+        mask = recipes.bernoulli_mask(97, rows, dim)
+        ref_x, ref_ld = O.rnvp(z, sd, mask)
+        with torch.no_grad():
+            x, ld = f.forward(cuda(z), mask=cuda(mask))
+        assert amd.last_kernel() == "rnvp_rt"
+        assert_parity(x, ref_x.numpy(), None, f"rnvp_rt d={dim} h={hs} rows={rows} x")
+        assert_parity(ld, ref_ld.numpy(), None, f"rnvp_rt d={dim} h={hs} rows={rows} ld")
+        m_seed = f.mask_for(77, rows)
+        with torch.no_grad():
+            x, ld = f.forward(cuda(z), seed=77)
+        assert amd.last_kernel() == "rnvp_rt"
+        ref_x, ref_ld = O.rnvp(z, sd, m_seed.cpu())
+        assert_parity(x, ref_x.numpy(), None, f"rnvp_rt d={dim} h={hs} rows={rows} x (seeded)")
+        assert_parity(ld, ref_ld.numpy(), None, f"rnvp_rt d={dim} h={hs} rows={rows} ld (seeded)")
+
+
+def test_rnvp_rt_is_the_default_for_wide_hidden_layers(amd, O):
+    dim, hs, rows = 800, (100,), 4096
+    sd = _rnvp_sd(5, dim, hs)
+    f = amd.RNVP(dim, h_sizes=hs)
+    f.load_state_dict(sd)
+    f.to(DEV)
+    z = recipes.gaussian(6, rows, dim)
+    mask = recipes.bernoulli_mask(7, rows, dim)
+    with torch.no_grad():
+        x, ld = f.forward(cuda(z), mask=cuda(mask))
+    assert amd.last_kernel() == "rnvp_rt"
+    ref_x, ref_ld = O.rnvp(z, sd, mask)
+    assert_close(x, ref_x, RTOL, "x")
+    assert_close(ld, ref_ld, RTOL, "ld")
