@@ -100,3 +100,54 @@ def test_bench_spawns_its_ranks_as_child_processes():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert out.stderr.count("needs an MI355X") >= 1 and "local_rank" in out.stderr, out.stderr[-1500:]
+
+
+def _actnorm_worker(rank, world, port, rows, dim, out):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch_mnf_amd as amd
+    from torch_mnf_amd.dist import shard_bounds
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    x = 1.7 * recipes.gaussian(123, rows, dim) + 0.4
+    lo, hi = shard_bounds(rows, world, rank)  # uneven shards (rows is odd)
+    torch.manual_seed(7)  # the same random s, t on every rank (replicated parameters)
+    f = amd.ActNormFlow(dim)
+    f._maybe_init(x[lo:hi])  # the data-dependent initialisation proper: plain tensor ops, runs on the CPU shards
+    out.put((rank, f.s.detach().clone(), f.t.detach().clone(), f.data_dep_init_done))
+    dist.destroy_process_group()
+
+
+def test_actnorm_data_dependent_init_is_rank_consistent():
+    """ActNormFlow initialises s, t from its first batch (affine_constant_flow.py:42-50).  With that batch sharded over
+    two ranks (uneven shards) every rank must get the GLOBAL batch's statistics: bit-equal across ranks, and equal to
+    what one process computes from the concatenated batch."""
+    import torch_mnf_amd as amd
+
+    rows, dim, world = 1001, 12, 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_actnorm_worker, args=(r, world, port, rows, dim, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((out.get(timeout=120) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, t0, d0), (_, s1, t1, d1) = got
+    assert d0 and d1
+    assert torch.equal(s0, s1) and torch.equal(t0, t1), "the replicas' parameters differ"
+    x = 1.7 * recipes.gaussian(123, rows, dim) + 0.4
+    torch.manual_seed(7)
+    ref = amd.ActNormFlow(dim)
+    ref._maybe_init(x)  # single process, whole batch: the reference's formulas as they stand
+    assert float((s0 - ref.s.detach()).abs().max()) <= 1e-6 and float((t0 - ref.t.detach()).abs().max()) <= 1e-6
+    # and NOT the local statistics (which is what an unsynchronised init would give)
+    local = amd.ActNormFlow(dim)
+    local._maybe_init(x[:501])
+    assert float((s0 - local.s.detach()).abs().max()) > 1e-4

@@ -33,47 +33,27 @@ def timed(fn, reps=3):
 
 
 def probe(layer, dim, call):
-    """(forward kernel, ns/row, gradient kernel, fwd+bwd ns/row) on the default path, and the same two times with the layer
-    forced onto the any-shape kernels when the default path is not one of them (the cliff AT this shape)."""
+    """Default path: (forward kernel, ns/row, gradient kernel, fwd+bwd ns/row); then the same two times with the layer
+    forced onto the run-time-shaped matrix-core kernels (force_generic = 2; None where the default path is already one
+    of them) and onto the VALU any-shape kernels (force_generic = 1)."""
     fast = probe_once(layer, dim, call)
-    gen = (None, None)
-    if "generic" not in fast[0] or "generic" not in fast[2]:
-        layer.force_generic = True
+    rt = (None, None)
+    if not (fast[0].endswith("_rt") and fast[2].endswith("_rt")):
+        layer.force_generic = 2
         g = probe_once(layer, dim, call)
-        layer.force_generic = False
-        gen = (g[1], g[3])
-    return (*fast, *gen)
-
-
-def probe_once(layer, dim, call):
-    layer = layer.to(DEV)
-    x = torch.randn(ROWS, dim, device=DEV)
-
-    def fwd():
-        with torch.no_grad():
-            call(layer, x)
-
-    t_f = timed(fwd)
-    k_f = amd.last_kernel()
-    xg = x.clone().requires_grad_(True)
-    k_b = [None]
-
-    def both():
-        layer.zero_grad()
-        y, ld = call(layer, xg)
-        (y.sum() + ld.sum()).backward()
-        k_b[0] = amd.last_kernel()
-
-    t_b = timed(both)
-    return k_f, t_f, k_b[0], t_b
+        rt = (g[1] if g[0].endswith("_rt") else None, g[3] if g[2].endswith("_rt") else None)
+    layer.force_generic = 1
+    g = probe_once(layer, dim, call)
+    layer.force_generic = False
+    return (*fast, *rt, g[1], g[3])
 
 
 def main():
     torch.manual_seed(0)
     print(f"# rows per call: {ROWS}; ns per row = best of 3 launches (HIP events); 'fwd+bwd' = forward with the autograd link, "
           "sum() of both outputs, backward")
-    print("# kernel = torch_mnf_amd.last_kernel() after the call; 'generic' = the same call with force_generic (the any-shape "
-          "kernels), x = generic / default")
+    print("# kernel = torch_mnf_amd.last_kernel() after the call; rt = the same call forced onto the run-time-shaped matrix-core "
+          "kernels (force_generic = 2), rt/x = rt / default; valu = forced onto the VALU any-shape kernels (force_generic = 1)")
     rows = []
     for dim in (2, 8, 32, 64, 128, 256, 512):
         for hs in ((24, 24, 24), (16, 16, 16), (32, 32, 32), (64, 64, 64), (24, 24)):
@@ -88,25 +68,33 @@ def main():
         for h in (50, 30, 64, 100):
             f = amd.RNVP(dim, h_sizes=(h,))
             rows.append(("RNVP", f"dim={dim} hidden=({h},)", dim, *probe(f, dim, lambda m, x: m.forward(x, seed=3))))
-    print(f"{'layer':15s} {'shape':30s} {'forward kernel':16s} {'ns/row':>8s} {'generic':>8s} {'x':>6s}   {'gradient kernel':20s} "
-          f"{'fwd+bwd':>8s} {'generic':>8s} {'x':>6s}")
-    cliffs = []
-    for layer, shape, dim, kf, tf, kb, tb, gf, gb in rows:
-        xf = f"{gf / tf:6.1f}" if gf else "     -"
-        xb = f"{gb / tb:6.1f}" if gb else "     -"
-        gfs = f"{gf:8.2f}" if gf else "       -"
-        gbs = f"{gb:8.2f}" if gb else "       -"
-        print(f"{layer:15s} {shape:30s} {kf:16s} {tf:8.2f} {gfs} {xf}   {kb:20s} {tb:8.2f} {gbs} {xb}")
-        if gb:
-            cliffs.append((gb / tb, layer, shape, kb))
-    cliffs.sort(reverse=True)
-    print("\n# the largest cliffs (forward + backward: the any-shape kernels against the matrix-core ones AT the same shape):")
-    for fac, layer, shape, kb in cliffs[:6]:
-        print(f"#   {fac:6.1f} x  {layer} {shape}  ({kb})")
-    slow = sorted(((tb, layer, shape) for layer, shape, dim, kf, tf, kb, tb, gf, gb in rows if "generic" in kb), reverse=True)
-    print("# shapes WITHOUT a matrix-core gradient kernel, slowest first (ns per row, forward + backward):")
-    for tb, layer, shape in slow[:8]:
-        print(f"#   {tb:9.1f}  {layer} {shape}")
+    print(f"{'layer':15s} {'shape':30s} {'forward kernel':28s} {'ns/row':>8s} {'rt':>8s} {'rt/x':>5s} {'valu':>8s}   "
+          f"{'gradient kernel':20s} {'fwd+bwd':>8s} {'rt':>8s} {'rt/x':>5s} {'valu':>8s}")
+
+    def num(v, w=8):
+        return f"{v:{w}.2f}" if v else " " * (w - 1) + "-"
+
+    worst_f, worst_b, generic = [], [], []
+    for layer, shape, dim, kf, tf, kb, tb, rf, rb, gf, gb in rows:
+        xf = rf / tf if rf else None
+        xb = rb / tb if rb else None
+        print(f"{layer:15s} {shape:30s} {kf:28s} {tf:8.2f} {num(rf)} {num(xf, 5)} {num(gf)}   {kb:20s} {tb:8.2f} {num(rb)} "
+              f"{num(xb, 5)} {num(gb)}")
+        if xf:
+            worst_f.append((xf, layer, shape, kf))
+        if xb:
+            worst_b.append((xb, layer, shape, kb))
+        if "generic" in kf or "generic" in kb:
+            generic.append((tb, layer, shape, kf, kb))
+    for name, lst in (("forward", worst_f), ("forward + backward", worst_b)):
+        lst.sort(reverse=True)
+        print(f"\n# {name}: run-time-shaped / specialised at the same shape, worst first:")
+        for fac, layer, shape, k in lst[:6]:
+            print(f"#   {fac:5.2f} x  {layer} {shape}  ({k})")
+    generic.sort(reverse=True)
+    print(f"\n# shapes whose default path still has a VALU any-shape (*_generic) kernel: {len(generic)}")
+    for tb, layer, shape, kf, kb in generic[:12]:
+        print(f"#   {tb:9.1f} ns/row fwd+bwd  {layer} {shape}  ({kf} / {kb})")
 
 
 if __name__ == "__main__":

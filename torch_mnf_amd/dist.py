@@ -95,3 +95,25 @@ def sharded_mean_log_prob_async(
     """The same with the reduction left in flight: call ``.result()`` when the mean is needed (e.g. after
     enqueueing the next batch), so the 16-byte all-reduce's latency is hidden behind the next evaluation."""
     return reduce_sum_count(log_prob_sum_fn(x_local), x_local.shape[0], group, async_op=True)
+
+
+def global_column_mean(x_local: torch.Tensor, group=None) -> torch.Tensor:
+    """Column means of the batch whose rows are sharded over the group's ranks: one all-reduce of the float64 vector
+    [count, column sums].  Identical on every rank (an all-reduce hands every rank the same bits)."""
+    buf = torch.cat([torch.tensor([float(x_local.shape[0])], dtype=torch.float64, device=x_local.device),
+                     x_local.double().sum(dim=0)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[1:] / buf[0]
+
+
+def global_column_std(x_local: torch.Tensor, group=None) -> torch.Tensor:
+    """Unbiased column standard deviations (torch.std's default, what ActNormFlow's data-dependent initialisation uses:
+    flows/affine_constant_flow.py:45) of the batch sharded over the group's ranks: the global mean first, then one
+    all-reduce of [count, sum (x - mean)^2] in float64 (two passes: no cancellation)."""
+    mean = global_column_mean(x_local, group)
+    buf = torch.cat([torch.tensor([float(x_local.shape[0])], dtype=torch.float64, device=x_local.device),
+                     ((x_local.double() - mean) ** 2).sum(dim=0)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return torch.sqrt(buf[1:] / (buf[0] - 1.0))

@@ -29,6 +29,7 @@ from torch import Tensor, nn
 import os
 
 from . import _lib
+from . import dist as _dist
 from ._lib import MnfHipError
 
 # MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
@@ -148,6 +149,13 @@ class MADE(nn.Sequential):
             masks[-1] = np.concatenate([masks[-1]] * (self.n_out // self.n_in), axis=1)
         for layer, mask in zip([m for m in self if isinstance(m, MaskedLinear)], masks):
             layer.set_mask(mask)
+
+
+def _dist_world() -> int:
+    """Ranks of the default ``torch.distributed`` group (1: not initialised)."""
+    import torch.distributed as td
+
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
 
 
 def _require_mlp(*nets: nn.Module) -> None:
@@ -1717,12 +1725,25 @@ class ActNormFlow(AffineConstantFlow):
         return super().inverse(x)
 
     def _maybe_init(self, x: Tensor) -> None:
+        """The reference initialises from "the very first batch" (affine_constant_flow.py:42-50).  When that batch is
+        sharded over the ranks of a ``torch.distributed`` group (rows shard, parameters are replicated),
+        the statistics are those of the GLOBAL batch: three all-reduces of float64 column sums -- (count, sum x), then
+        sum (x - mean)^2, then sum x e^s -- so that every rank ends up with the same ``s`` and ``t``, bit for bit, and
+        the same values a single process would get from the concatenated batch (up to fp32 rounding of its own sums).
+        Local statistics would make the replicas' parameters diverge silently."""
         if self.data_dep_init_done is False:
             with torch.no_grad():  # one-off, cross-row statistics: plain device ops
+                sharded = _dist_world() > 1
                 if not bool((self.s.squeeze() == 0).all()):
-                    self.s.data = x.std(dim=0, keepdim=True).log().detach()
+                    if sharded:
+                        self.s.data = _dist.global_column_std(x).log().to(self.s.dtype).reshape(1, -1)
+                    else:
+                        self.s.data = x.std(dim=0, keepdim=True).log().detach()
                 if not bool((self.t.squeeze() == 0).all()):
-                    self.t.data = (x * self.s.exp()).mean(dim=0, keepdim=True).detach()
+                    if sharded:
+                        self.t.data = _dist.global_column_mean(x * self.s.exp()).to(self.t.dtype).reshape(1, -1)
+                    else:
+                        self.t.data = (x * self.s.exp()).mean(dim=0, keepdim=True).detach()
             self.data_dep_init_done = True
 
     def _run(self, x, inverse, accum):
