@@ -65,7 +65,7 @@ extern "C" {
 
 /* Bumped whenever an entry point's signature or meaning changes; mnf_abi_version() returns the value the
  * library was built with, so a binding can refuse a stale build. */
-#define MNF_ABI_VERSION 13
+#define MNF_ABI_VERSION 14
 int mnf_abi_version(void);
 const char* mnf_error_string(int code);
 /* hipError_t of the last failed launch on the calling thread (0 if none). */
@@ -100,7 +100,10 @@ int mnf_device_count(void);
  * column tile is zero-padded in the image and runs the stack kernel's ragged variant with one layer; hidden width 32
  * up to dim 128; hidden widths 33 .. 64 run at 64 units at dim = 32, 64 and 128, one layer per launch), has_scale / has_shift (an absent net is an all-zero operand set: s = 0 or t = 0 exactly).
  * log_det may be NULL (not computed). accumulate != 0: log_det += ld.
- * force_generic != 0 selects the generic kernel (used by tests to compare the kernels). */
+ * force_generic == 1 selects the VALU any-shape kernel, == 2 the run-time-shaped matrix-core kernel (mnf_ahf_rt.hip:
+ * any h_sizes of length >= 1 with widths 4 .. 256, any even dim; weights converted from `flat` inside the kernel) whatever
+ * the shape's specialised kernels (tests and tools/coverage_map.py compare the three).  With force_generic == 0 a shape
+ * without a specialised kernel runs the run-time-shaped one from 2,048 rows on and the VALU one below. */
 int mnf_affine_half(const float* x, float* y, float* log_det, int accumulate,
                     const float* flat, const float* image, const void* split_image,
                     int64_t rows, int dim, int parity, int inverse,
@@ -570,6 +573,18 @@ int mnf_affine_half_bwd_split_lp(const float* x, const float* lp_grad, float* gy
                                  int parity, int inverse, int n_hidden, const int* hidden_host,
                                  const float* grad_scale_dev, int32_t* cold_list, int cold_capacity, float* workspace,
                                  int64_t workspace_floats, void* stream);
+/* The same gradients for ANY conditioner shape on the f16 matrix pipe (mnf_ahf_bwd_rt.hip: run-time layer count and
+ * widths, weights read from `flat`; no operand image, no index table): 1 .. 4 hidden layers of widths 4 .. 64, any even dim.
+ * What the per-shape kernels above have no instantiation for runs here instead of on mnf_affine_half_bwd's VALU kernel.
+ *   y               the layer's OUTPUT for the same x, direction and parameters (needed in the inverse direction with a
+ *                   scale net: g_s = -grad_y y - grad_ld; may be NULL otherwise)
+ *   grad_scale_dev  device float, a power of two that brings the cotangents near 1 (mnf_affine_half_grad_scale)
+ * grad_x is written, grad_flat (layout of `flat`) is ADDED to with float atomics, one flush per block of 16 .. 128 rows (or
+ * NULL: grad_x only).  MNF_ERR_UNSUPPORTED: shape outside these limits, or MNF_DETERMINISTIC is set (atomic sums). */
+int mnf_affine_half_bwd_rt(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x,
+                           float* grad_flat, const float* flat, const float* grad_scale_dev, int64_t rows, int dim,
+                           int parity, int inverse, int n_hidden, const int* hidden_host, int has_scale, int has_shift,
+                           void* stream);
 int mnf_nsf_cl_bwd(const float* x, const float* grad_y, const float* grad_ld, float* grad_x,
                    float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                    int inverse, int n_hidden, const int* hidden_host, void* stream);

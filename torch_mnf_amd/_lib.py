@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNF_LIB_PATH") or os.path.join(_HERE, "libmnf_hip.so")  # override: A/B builds
 
-ABI_VERSION = 13  # include/mnf_hip.h MNF_ABI_VERSION
+ABI_VERSION = 14  # include/mnf_hip.h MNF_ABI_VERSION
 MNF_OK = 0
 MNF_ERR_INVALID_ARG = -1
 MNF_ERR_UNSUPPORTED = -2
@@ -101,6 +101,8 @@ SIGNATURES = {
     "mnf_affine_half_bwd_split_lp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int64, c_int, c_int, c_int, c_int, _intp, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int64, c_void_p]),
+    "mnf_affine_half_bwd_rt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_nsf_cl_bwd_tile_supported": (c_int, [c_int, c_int, c_int, _intp]),

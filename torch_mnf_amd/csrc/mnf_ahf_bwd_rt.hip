@@ -1,0 +1,430 @@
+// Gradients of AffineHalfFlow.forward / .inverse (torch_mnf/flows/affine_half_flow.py:44-66 under loss.backward(); the
+// reference trains through these layers: tests/test_flows.py:14-31) for ANY conditioner shape on the f16 matrix pipe:
+// run-time layer count and widths (mnf_rt.h, mnf_rt_bwd.h), weights read from the plain `flat` parameter vector.  Takes
+// the calls the per-shape gradient kernels (mnf_ahf_bwd_split.hip, mnf_ahf_bwd_mfma.hip: three hidden layers of at most
+// 32 units) have no instantiation for: 1 .. 4 hidden layers of widths 4 .. 64, any even dim.
+//
+// A workgroup owns a block of 16 NW rows, a wave one tile of it.  Per net (s, then t): the forward recompute keeps every
+// hidden vector (turned, in the LDS exchange area) and the row scales; the output layer is walked two 16-column tiles at
+// a time -- s or t of the tiles, the cotangents g_s / g_t from grad_y, grad_ld (and y: the inverse direction's g_s = -g y
+// - g_ld needs no second net), grad_x of the transformed half, the first step of the delta chain W_out^T g and the
+// tiles' dW_out products --, then the hidden layers backwards (delta chain in registers, dW per layer through the
+// exchange area), then grad_x of the conditioning half and dW of the first layer input tile by input tile.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "mnf_host.h"
+#include "mnf_rt_bwd.h"
+
+namespace mnf {
+
+struct AhfBwdRtArgs {
+  const float* x;
+  const float* y;  // the layer's output for the same x (inverse direction only)
+  const float* grad_y;
+  const float* grad_ld;
+  float* grad_x;
+  float* grad_flat;
+  const float* flat;
+  const float* gscale_dev;  // power of two that brings the cotangents near 1
+  int64_t rows;
+  int dim, parity, inverse, has_scale, has_shift;
+  int n_params, vec, dbg;
+  int cb, bt, block_words, bias_words;  // weight stream (mnf_rt.h Source<false>)
+  int ht_tiles, dt_tiles, ct_tiles;     // exchange tiles: hidden vectors of one net | one layer's deltas | a chunk
+  NetDesc s_net, t_net;
+};
+
+constexpr float kLog2eB = 1.4426950408889634f;
+
+template <int MT_MAX>
+__device__ __forceinline__ uint32_t pack_signs(const rt::Hidden<MT_MAX, 1>& h) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t half = (h.hi[0][m][r >> 1] >> (16 * (r & 1))) & 0xffffu;
+      bits |= (half != 0u && (half & 0x8000u) == 0u) ? 1u << (4 * m + r) : 0u;  // LeakyReLU keeps the sign
+    }
+  return bits;
+}
+
+// (main + corr 2^-11) * scale, times the LeakyReLU derivative of the hidden vector whose sign bits are `bits`
+template <int MT_MAX>
+__device__ __forceinline__ void chain_result(const rt::Acc<MT_MAX, 1>& acc, float scale, uint32_t bits, f32x4 (&dv)[MT_MAX]) {
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) {
+    const f32x4 p = (acc.corr[0][m] * kSplitInvScale + acc.main[0][m]) * scale;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dv[m][r] = p[r] * ((bits >> (4 * m + r)) & 1u ? 1.f : kLeakySlope);
+  }
+}
+
+// a split hidden vector back to fp32: (head + residual 2^-11) * the row's scale
+__device__ __forceinline__ float half_of(uint32_t word, int hi) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? word >> 16 : word & 0xffffu));
+}
+template <int MT_MAX>
+__device__ __forceinline__ void unsplit(const rt::Hidden<MT_MAX, 1>& h, f32x4 (&v)[MT_MAX]) {
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) {
+    const u32x2 wh = h.hi[0][m], wl = h.lo[0][m];
+    v[m][0] = (half_of(wl[0], 0) * kSplitInvScale + half_of(wh[0], 0)) * h.up[0];
+    v[m][1] = (half_of(wl[0], 1) * kSplitInvScale + half_of(wh[0], 1)) * h.up[0];
+    v[m][2] = (half_of(wl[1], 0) * kSplitInvScale + half_of(wh[1], 0)) * h.up[0];
+    v[m][3] = (half_of(wl[1], 1) * kSplitInvScale + half_of(wh[1], 1)) * h.up[0];
+  }
+}
+
+// fp32 tiles -> split tiles with the row's power-of-two scale (the B operands of the next chain product)
+template <int MT_MAX>
+__device__ __forceinline__ void split_rows(const f32x4 (&v)[MT_MAX], rt::Hidden<MT_MAX, 1>& h) {
+  using namespace rt;
+  float fm = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fm = __builtin_fmaxf(fm, finite_abs(v[m][r]));
+  const int e = down_exponent(max_over_q(fm), 13);
+  const float down = pow2f(-e);
+  h.up[0] = pow2f(e);
+  float unused = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) split_tile(v[m] * down, h.hi[0][m], h.lo[0][m], unused);
+}
+
+// first exchange tile of hidden vector H_i (i >= 1) of net nd
+__host__ __device__ inline int exH_tile_of(const NetDesc& nd, int i) {
+  int t = 0;
+  for (int k = 1; k < i; ++k) t += (nd.sizes[k] + 15) >> 4;
+  return t;
+}
+
+template <int MT_MAX, bool VEC>
+__global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
+  using namespace rt;
+  extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4, nw = blockDim.x >> 6;
+  // LDS: [scratch 16][scales: sA 8, sC 8, sH (layers + 1) x 8][weights][bias][exchange: HT | DT | CT][meta: per wave sign bits]
+  float* scratch = reinterpret_cast<float*>(rt_lds);
+  float* sA = scratch + 16;   // scale of the wave-tile's delta tiles
+  float* sC = scratch + 24;   // scale of the wave-tile's chunk tiles (cotangents / x0)
+  float* sH = scratch + 32;   // [hidden vector i][wave]: scale of the wave-tile's copy of H_i
+  uint32_t* blocks = rt_lds + 32 + 8 * (kMaxBwdLayers + 2);
+  float* bias = reinterpret_cast<float*>(blocks + a.block_words);
+  Exchange exH{reinterpret_cast<uint16_t*>(bias + a.bias_words), 16 * nw};
+  Exchange exD{exH.base + (size_t)a.ht_tiles * exH.tile_halves(), 16 * nw};
+  Exchange exC{exD.base + (size_t)a.dt_tiles * exH.tile_halves(), 16 * nw};
+  uint32_t* meta_bits = reinterpret_cast<uint32_t*>(exC.base + (size_t)a.ct_tiles * exH.tile_halves()) + wave * ((kMaxBwdLayers + 1) * 64);
+
+  const float wmax = block_weight_max(a.flat, a.n_params, scratch);
+  const int we = weight_exponent(wmax);
+  const float wup = pow2f(we);
+  Source<false> src{blocks, bias, a.cb, a.bt, 0, 0, 0, pow2f(-we), 0};
+  const float gs = *a.gscale_dev, inv_gs = 1.f / gs;
+  const f16x4 ident = identity_operand(j, q);
+  const int H = a.dim / 2;
+  const int cond_off = a.parity ? H : 0, act_off = a.parity ? 0 : H;
+  const int n_nets = (a.has_scale ? 1 : 0) + (a.has_shift ? 1 : 0);
+  const int64_t n_blocks = (a.rows + 16 * nw - 1) / (16 * nw);
+
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int64_t r = blk * (16 * nw) + 16 * wave + j;
+    const bool live = r < a.rows;
+    const int64_t rc = live ? r : a.rows - 1;
+    const float* xrow = a.x + rc * a.dim;
+    const float* yrow = a.y ? a.y + rc * a.dim : xrow;
+    const float* gyrow = a.grad_y ? a.grad_y + rc * a.dim : xrow;
+    float* gxrow = a.grad_x + rc * a.dim;
+    const float gl = a.grad_ld && live ? a.grad_ld[rc] : 0.f;
+    const float rowmask = live ? 1.f : 0.f;  // rows past the end add nothing to the parameter sums
+    Hidden<MT_MAX, 1> hs_last;  // the s-net's last hidden vector: the t pass needs e^{+-s}
+
+#pragma unroll 1
+    for (int pass = 0; pass < n_nets; ++pass) {
+      const bool is_s = a.has_scale && pass == 0;
+      const NetDesc& nd = is_s ? a.s_net : a.t_net;
+      const int n_hid = nd.n_lin - 1, L = n_hid;
+      float* gflat = a.grad_flat;
+      // ---- forward recompute: every hidden vector goes, turned, into the exchange area; sign bits and row scales into LDS
+      Hidden<MT_MAX, 1> h;
+      {
+        auto load_x = [&](int, int ks, f32x4& xa, f32x4& xb) {
+          const int c0 = 32 * ks + 4 * q;
+          xa = load4(xrow + cond_off, c0, H, VEC);
+          xb = load4(xrow + cond_off, c0 + 16, H, VEC);
+        };
+        auto use_x = [&](int, int, const f32x4&, const f32x4&) {};
+        int tile0 = 0;
+        auto hook = [&](int i, const Hidden<MT_MAX, 1>& hh) {
+          const int MT = tiles16(nd.sizes[i]);
+          f32x4 hv[MT_MAX];  // the vector's true values (head + residual, times the row's scale)
+          unsplit<MT_MAX>(hh, hv);
+          const float sc = exchange_store<MT_MAX>(hv, MT, exH, tile0, 16 * wave, lane, ident);
+          if (lane == 0) sH[i * 8 + wave] = sc;
+          tile0 += MT;
+          meta_bits[i * 64 + lane] = pack_signs<MT_MAX>(hh);
+        };
+        net_to_hidden<MT_MAX, 1, false>(src, a.flat, nd, n_hid, -1, wup, lane, q, load_x, use_x, h, hook);
+      }
+      // ---- output layer, two 16-column tiles (one K-step of the chain) per chunk
+      const int MTh = tiles16(nd.sizes[L]), KSh = steps32(16 * MTh), M = tiles16(H);
+      const bool need_s = !is_s && a.has_scale;  // the t pass recomputes s from the s-net's last hidden vector
+      const int KSs = need_s ? steps32(16 * tiles16(a.s_net.sizes[L])) : 0;
+      const int ht_last = exH_tile_of(nd, L);
+      Acc<MT_MAX, 1> accd;
+      accd.zero();
+      float downd = 1.f;  // the row's running scale of the chain's first product (as in net_to_hidden)
+      for (int m0 = 0; m0 < M; m0 += 2) {
+        const int mo = M - m0 < 2 ? M - m0 : 2;
+        uint32_t* buf = src.cur_blocks();
+        float* bbuf = src.cur_bias();
+        stage_blocks(buf, mo * KSh, DenseMMajor{a.flat + nd.w_off[L], nd.sizes[L], H, KSh, m0, 1, 0}, src.wdown);
+        stage_bias(bbuf, mo, DenseBias{a.flat + nd.b_off[L], H, m0});
+        if (need_s) {
+          stage_blocks(buf + mo * KSh * kBlockWords, mo * KSs,
+                       DenseMMajor{a.flat + a.s_net.w_off[L], a.s_net.sizes[L], H, KSs, m0, 1, 0}, src.wdown);
+          stage_bias(bbuf + 16 * mo, mo, DenseBias{a.flat + a.s_net.b_off[L], H, m0});
+        }
+        const uint32_t* bufT = buf + mo * (KSh + KSs) * kBlockWords;
+        stage_blocks(const_cast<uint32_t*>(bufT), MTh, DenseTKMajor{a.flat + nd.w_off[L], nd.sizes[L], H, MTh, m0 >> 1},
+                     src.wdown);
+        src.commit();
+        f32x4 g2[2];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) {
+          g2[ml] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ml < mo) {
+            const int col = 16 * (m0 + ml) + 4 * q;
+            f32x4 o[1], sv[1];
+            out_tile<MT_MAX, 1>(buf, ml * KSh, KSh, bbuf + 16 * ml, lane, q, h, wup, o);
+            sv[0] = is_s ? o[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (need_s) out_tile<MT_MAX, 1>(buf + mo * KSh * kBlockWords, ml * KSs, KSs, bbuf + 16 * (mo + ml), lane, q, hs_last, wup, sv);
+            const f32x4 x1 = load4(xrow + act_off, col, H, VEC);
+            const f32x4 gy1 = a.grad_y ? load4(gyrow + act_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 y1 = a.inverse && is_s ? load4(yrow + act_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 gx1;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              // forward: y = e^s v + t      g_v = g e^s     g_s = g e^s v + g_ld     g_t = g
+              // inverse: y = (v - t) e^-s   g_v = g e^-s    g_s = -g y - g_ld        g_t = -g e^-s
+              const float ex = __builtin_amdgcn_exp2f((a.inverse ? -sv[0][e4] : sv[0][e4]) * kLog2eB);
+              gx1[e4] = gy1[e4] * ex;
+              float g;
+              if (is_s) g = a.inverse ? -gy1[e4] * y1[e4] - gl : gy1[e4] * ex * x1[e4] + gl;
+              else g = a.inverse ? -gy1[e4] * ex : gy1[e4];
+              g2[ml][e4] = col + e4 < H ? g * gs * rowmask : 0.f;
+            }
+            if (pass == 0) store4(gxrow + act_off, col, H, VEC, live, gx1);
+          }
+        }
+        // the chain's first step: accd += W_out^T-blocks x [g tile 0 | g tile 1]
+        {
+          f16x8 bh[1], bl[1];
+          float mx = 0.f;
+          split_kstep(g2[0], g2[1], downd, bh[0], bl[0], mx);
+          if (__builtin_expect(wave_any(!(mx < kSplitLimit)), 0)) {
+            float fm = 0.f;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) fm = __builtin_fmaxf(fm, __builtin_fmaxf(finite_abs(g2[0][e4]), finite_abs(g2[1][e4])));
+            const float want = pow2f(-down_exponent(max_over_q(fm), 13));
+            if (want < downd) {
+              const float f = want / downd;
+#pragma unroll
+              for (int m = 0; m < MT_MAX; ++m) {
+                accd.main[0][m] *= f;
+                accd.corr[0][m] *= f;
+              }
+              downd = want;
+            }
+            float unused = 0.f;
+            split_kstep(g2[0], g2[1], downd, bh[0], bl[0], unused);
+          }
+          mac_kstep<MT_MAX, 1>(bufT, 0, MTh, lane, bh, bl, accd.main, accd.corr);
+        }
+        // dW_out, db_out of the two tiles: cotangents (times the hidden vector's row scale) x last hidden vector
+        if (gflat) {
+          f32x4 cv[MT_MAX];
+#pragma unroll
+          for (int m = 0; m < MT_MAX; ++m) cv[m] = m < 2 ? g2[m < 2 ? m : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+          const float sc = exchange_store<MT_MAX>(cv, mo, exC, 0, 16 * wave, lane, ident);
+          if (lane == 0) sC[wave] = sc;
+          lds_barrier();
+          dw_phase(exC, 0, mo, exH, ht_last, MTh, sC, sH + L * 8, nw, inv_gs, gflat + nd.w_off[L], gflat + nd.b_off[L], H, nd.sizes[L], m0, 0);
+        }
+      }
+      if (is_s) hs_last = h;
+      // ---- hidden layers backwards: dv = the cotangent of H_i's pre-activation (in units of gs)
+      f32x4 dv[MT_MAX];
+      chain_result<MT_MAX>(accd, wup / downd, meta_bits[n_hid * 64 + lane], dv);
+#pragma unroll 1
+      for (int i = n_hid; i >= 2; --i) {
+        const int MTi = tiles16(nd.sizes[i]), MTp = tiles16(nd.sizes[i - 1]);
+        if (gflat) {
+          lds_barrier();  // (the previous phase's readers are done with the delta tiles)
+          const float sc = exchange_store<MT_MAX>(dv, MTi, exD, 0, 16 * wave, lane, ident);
+          if (lane == 0) sA[wave] = sc;
+          lds_barrier();
+          dw_phase(exD, 0, MTi, exH, exH_tile_of(nd, i - 1), MTp, sA, sH + (i - 1) * 8, nw, inv_gs, gflat + nd.w_off[i - 1],
+                   gflat + nd.b_off[i - 1], nd.sizes[i], nd.sizes[i - 1], 0, 0);
+        }
+        // delta_{i-1} = (W_{i-1}^T delta_i) * act'(H_{i-1}): K = the units of H_i, output tiles = those of H_{i-1}
+        Hidden<MT_MAX, 1> hd;
+        split_rows<MT_MAX>(dv, hd);
+        const int KS = steps32(16 * MTi);
+        int KC = src.cb / MTp;
+        if (KC < 1) KC = 1;
+        Acc<MT_MAX, 1> acc;
+        acc.zero();
+        const uint32_t* bufT = nullptr;
+        int next_start = 0, chunk_start = 0;
+#pragma unroll
+        for (int ks = 0; ks < MT_MAX / 2; ++ks)
+          if (ks < KS) {
+            if (ks == next_start) {
+              const int kc = KS - ks < KC ? KS - ks : KC;
+              uint32_t* b = src.cur_blocks();
+              stage_blocks(b, kc * MTp, DenseTKMajor{a.flat + nd.w_off[i - 1], nd.sizes[i - 1], nd.sizes[i], MTp, ks}, src.wdown);
+              src.commit();
+              bufT = b;
+              chunk_start = ks;
+              next_start = ks + kc;
+            }
+            f16x8 bh[1], bl[1];
+            hidden_operand<MT_MAX, 1>(hd, ks, bh, bl);
+            mac_kstep<MT_MAX, 1>(bufT, (ks - chunk_start) * MTp, MTp, lane, bh, bl, acc.main, acc.corr);
+          }
+        chain_result<MT_MAX>(acc, wup * hd.up[0], meta_bits[(i - 1) * 64 + lane], dv);
+      }
+      // ---- first layer: dv = delta_1.  grad_x of the conditioning half and dW_0, input tile by input tile
+      {
+        const int MT1 = tiles16(nd.sizes[1]), KS1 = steps32(16 * MT1), MI = tiles16(H);
+        if (gflat) {
+          lds_barrier();
+          const float sc = exchange_store<MT_MAX>(dv, MT1, exD, 0, 16 * wave, lane, ident);
+          if (lane == 0) sA[wave] = sc;
+        }
+        Hidden<MT_MAX, 1> hd;
+        split_rows<MT_MAX>(dv, hd);
+        int CI = src.cb / KS1;
+        if (CI > a.ct_tiles) CI = a.ct_tiles;
+        if (CI > MT_MAX) CI = MT_MAX;
+        if (CI < 1) CI = 1;
+        for (int mi0 = 0; mi0 < MI; mi0 += CI) {
+          const int ci = MI - mi0 < CI ? MI - mi0 : CI;
+          uint32_t* buf = src.cur_blocks();
+          float* bbuf = src.cur_bias();
+          stage_blocks(buf, ci * KS1, DenseTMMajor{a.flat + nd.w_off[0], H, nd.sizes[1], KS1, mi0}, src.wdown);
+          stage_bias(bbuf, 1, NoBias{});
+          src.commit();
+          f32x4 xv[MT_MAX];
+#pragma unroll
+          for (int ml = 0; ml < MT_MAX; ++ml) {
+            xv[ml] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ml < ci) {
+              const int col = 16 * (mi0 + ml) + 4 * q;
+              f32x4 gx[1];
+              out_tile<MT_MAX, 1>(buf, ml * KS1, KS1, bbuf, lane, q, hd, wup, gx);
+              const f32x4 base = pass == 0 ? (a.grad_y ? load4(gyrow + cond_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f})
+                                           : load4(gxrow + cond_off, col, H, VEC);
+              store4(gxrow + cond_off, col, H, VEC, live, base + gx[0] * inv_gs);
+              xv[ml] = load4(xrow + cond_off, col, H, VEC);
+            }
+          }
+          if (gflat) {
+            const float sc = exchange_store<MT_MAX>(xv, ci, exC, 0, 16 * wave, lane, ident);
+            if (lane == 0) sC[wave] = sc;
+            lds_barrier();
+            dw_phase(exD, 0, MT1, exC, 0, ci, sA, sC, nw, inv_gs, gflat + nd.w_off[0], mi0 == 0 ? gflat + nd.b_off[0] : nullptr,
+                     nd.sizes[1], H, 0, mi0);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mnf
+
+using namespace mnf;
+
+extern "C" int mnf_affine_half_bwd_rt(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x,
+                                      float* grad_flat, const float* flat, const float* grad_scale_dev, int64_t rows, int dim,
+                                      int parity, int inverse, int n_hidden, const int* hidden, int has_scale, int has_shift,
+                                      void* stream) {
+  if (!x || !grad_x || !flat || !grad_scale_dev || rows < 0 || dim < 2 || (dim & 1) || !hidden_ok(n_hidden, hidden))
+    return MNF_ERR_INVALID_ARG;
+  if (rows == 0) return MNF_OK;
+  if (n_hidden < 1 || n_hidden > rt::kMaxBwdLayers || (!has_scale && !has_shift) || (inverse && has_scale && !y) ||
+      deterministic() || rows * dim >= (1ll << 40))
+    return MNF_ERR_UNSUPPORTED;
+  AhfBwdRtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.grad_y = grad_y; a.grad_ld = grad_ld; a.grad_x = grad_x; a.grad_flat = grad_flat; a.flat = flat;
+  a.gscale_dev = grad_scale_dev; a.rows = rows; a.dim = dim; a.parity = parity != 0; a.inverse = inverse != 0;
+  a.has_scale = has_scale != 0; a.has_shift = has_shift != 0;
+  const int H = dim / 2;
+  int sizes[MNF_MAX_LINEAR + 1];
+  sizes[0] = H;
+  int mn = 1 << 30, mxh = 0, ht = 0, dt = 0;
+  for (int i = 0; i < n_hidden; ++i) {
+    sizes[1 + i] = hidden[i];
+    mn = hidden[i] < mn ? hidden[i] : mn;
+    mxh = hidden[i] > mxh ? hidden[i] : mxh;
+    ht += (hidden[i] + 15) / 16;
+    dt = (hidden[i] + 15) / 16 > dt ? (hidden[i] + 15) / 16 : dt;
+  }
+  sizes[n_hidden + 1] = H;
+  if (mn < 4 || mxh > 64) return MNF_ERR_UNSUPPORTED;
+  int64_t off = 0;
+  if (has_scale) off += fill_net(a.s_net, n_hidden + 2, sizes, off);
+  if (has_shift) off += fill_net(a.t_net, n_hidden + 2, sizes, off);
+  if (!has_scale) a.s_net = a.t_net;
+  if (!has_shift) a.t_net = a.s_net;
+  if (off >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;
+  a.n_params = (int)off;
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vec = dim % 8 == 0 && aligned(x) && aligned(grad_x) && (!y || aligned(y)) && (!grad_y || aligned(grad_y));
+  constexpr int MT_MAX = 4;
+  a.dbg = getenv("MNF_RT_DBG") ? atoi(getenv("MNF_RT_DBG")) : 0;
+  a.cb = 12;
+  a.bt = 8;
+  a.block_words = 2 * a.cb * rt::kBlockWords;
+  a.bias_words = 2 * a.bt * 16;
+  a.ht_tiles = ht;
+  a.dt_tiles = dt;
+  const int KS1 = (16 * ((hidden[0] + 15) / 16) + 31) / 32;
+  int ci = a.cb / KS1;
+  ci = ci > MT_MAX ? MT_MAX : ci;
+  a.ct_tiles = ci < 2 ? 2 : ci;
+  // the largest workgroup (rows per block = 16 waves) whose exchange area fits next to the weight stream
+  int nw = 8;
+  size_t lds = 0;
+  for (; nw >= 1; nw >>= 1) {
+    const size_t tile_bytes = (size_t)2 * 16 * (16 * nw + rt::kExPad) * 2;
+    lds = (size_t)4 * (32 + 8 * (rt::kMaxBwdLayers + 2)) + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 + (size_t)(a.ht_tiles + a.dt_tiles + a.ct_tiles) * tile_bytes +
+          (size_t)nw * (rt::kMaxBwdLayers + 1) * 64 * 4;
+    if (lds <= 160 * 1024) break;
+  }
+  if (nw < 1) return MNF_ERR_UNSUPPORTED;
+  auto kernel = a.vec ? ahf_bwd_rt_kernel<MT_MAX, true> : ahf_bwd_rt_kernel<MT_MAX, false>;
+  static DeviceMemo attr;
+  attr.get([&](int) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_rt_kernel<MT_MAX, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_rt_kernel<MT_MAX, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return 1;
+  });
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  const int64_t need = (rows + 16 * nw - 1) / (16 * nw);
+  int64_t grid = (int64_t)per_cu * device_cus(current_device());
+  if (grid > need) grid = need;
+  tag_kernel("ahf_bwd_rt");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(nw * 64), lds, (hipStream_t)stream, a);
+  return check_launch();
+}

@@ -35,6 +35,12 @@ constexpr int kRing = 1;          // K-steps / output tiles a wave's row reads r
 
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also drains the wave's outstanding global
+// stores and atomics (its release fence is s_waitcnt vmcnt(0)): a wave would sit out the ~1-3 k cycles of its last row
+// stores or gradient atomics at every chunk boundary.  Nothing in these kernels hands data to another wave through
+// global memory, so the LDS counter is all that has to reach zero.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weight range: max |w| over the finite entries of the parameter vector, by every workgroup for itself (the vector is
 // L2-resident; a pass costs microseconds), and the power of two that brings it to <= kSplitWeightLimit
@@ -87,33 +93,49 @@ __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float,
 // a mixed-radix number with digits (d0, d1, d2), d0 fastest, radices fetch.R0, fetch.R1: kept as counters, no division);
 // fetch.load(d0, d1, d2, i, q, lo4, hi4) returns the lane's eight weights (0 for padding); every weight is multiplied by
 // `wdown` (a power of two) first.
+__device__ __forceinline__ void convert_block(uint32_t* dst, int lane, f32x4 va, f32x4 vb, float wdown) {
+  va *= wdown;
+  vb *= wdown;
+  uint32_t hi[4], lo[4];
+  float unused = 0.f;
+  split_pair(va[0], va[1], hi[0], lo[0], unused);
+  split_pair(va[2], va[3], hi[1], lo[1], unused);
+  split_pair(vb[0], vb[1], hi[2], lo[2], unused);
+  split_pair(vb[2], vb[3], hi[3], lo[3], unused);
+  u32x4v* d = reinterpret_cast<u32x4v*>(dst);
+  d[lane] = u32x4v{hi[0], hi[1], hi[2], hi[3]};
+  d[64 + lane] = u32x4v{lo[0], lo[1], lo[2], lo[3]};
+}
+
 template <typename Fetch>
 __device__ __forceinline__ void stage_blocks(uint32_t* dst, int n_blocks, const Fetch& fetch, float wdown) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, i = lane & 15, q = lane >> 4;
-  // a wave converts a contiguous range of blocks: the digits are set once and then counted up
+  // a wave converts a contiguous range of blocks: the digits are set once and then counted up; two blocks per trip, both
+  // blocks' loads ahead of the arithmetic (a block's eight weights are L2 reads: their latency is the cost of this loop)
   const int per = (n_blocks + nw - 1) / nw, b0 = wave * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
   int d0 = b0 % fetch.R0, rest = b0 / fetch.R0, d1 = rest % fetch.R1, d2 = rest / fetch.R1;
-  for (int b = b0; b < b1; ++b) {
-    f32x4 va, vb;
-    fetch.load(d0, d1, d2, i, q, va, vb);
-    va *= wdown;
-    vb *= wdown;
-    uint32_t hi[4], lo[4];
-    float unused = 0.f;
-    split_pair(va[0], va[1], hi[0], lo[0], unused);
-    split_pair(va[2], va[3], hi[1], lo[1], unused);
-    split_pair(vb[0], vb[1], hi[2], lo[2], unused);
-    split_pair(vb[2], vb[3], hi[3], lo[3], unused);
-    u32x4v* d = reinterpret_cast<u32x4v*>(dst + b * kBlockWords);
-    d[lane] = u32x4v{hi[0], hi[1], hi[2], hi[3]};
-    d[64 + lane] = u32x4v{lo[0], lo[1], lo[2], lo[3]};
-    if (++d0 == fetch.R0) {
-      d0 = 0;
-      if (++d1 == fetch.R1) {
-        d1 = 0;
-        ++d2;
+  auto advance = [&](int& e0, int& e1, int& e2) {
+    if (++e0 == fetch.R0) {
+      e0 = 0;
+      if (++e1 == fetch.R1) {
+        e1 = 0;
+        ++e2;
       }
     }
+  };
+  for (int b = b0; b < b1; b += 2) {
+    const bool two = b + 1 < b1;  // (uniform)
+    int e0 = d0, e1 = d1, e2 = d2;
+    if (two) advance(e0, e1, e2);
+    f32x4 va, vb, wa, wb;
+    fetch.load(d0, d1, d2, i, q, va, vb);
+    fetch.load(e0, e1, e2, i, q, wa, wb);  // (the last odd block: the same block again, not stored)
+    convert_block(dst + b * kBlockWords, lane, va, vb, wdown);
+    if (two) convert_block(dst + (b + 1) * kBlockWords, lane, wa, wb, wdown);
+    d0 = e0;
+    d1 = e1;
+    d2 = e2;
+    advance(d0, d1, d2);
   }
 }
 
@@ -210,6 +232,14 @@ struct Source {
   float wdown;
   int dbg;
 
+  // streaming mode, chunks built from several parts: stage into cur_blocks() / cur_bias(), then commit()
+  __device__ __forceinline__ uint32_t* cur_blocks() const { return blocks + cur * cb * kBlockWords; }
+  __device__ __forceinline__ float* cur_bias() const { return bias + cur * bt * 16; }
+  __device__ __forceinline__ void commit() {
+    lds_barrier();
+    cur ^= 1;
+  }
+
   // PREFILL (resident mode's first pass): stage to the absolute position, no barrier, nothing is computed
   template <bool PREFILL, typename Fetch, typename Bias>
   __device__ __forceinline__ Chunk chunk(int n_blocks, const Fetch& fetch, int n_bias, const Bias& bias_fn) {
@@ -230,7 +260,7 @@ struct Source {
       float* b = bias + cur * bt * 16;
       if (!(dbg & 1)) stage_blocks(a, n_blocks, fetch, wdown);
       stage_bias(b, n_bias, bias_fn);
-      __syncthreads();  // (the other buffer is free once every wave is here: see the header comment)
+      lds_barrier();  // (the other buffer is free once every wave is here: see the header comment)
       cur ^= 1;
       c.A = a;
       c.bias = b;
@@ -373,14 +403,20 @@ __device__ __forceinline__ void hidden_operand(const Hidden<MT_MAX, NTL>& h, int
 //   load_x(t, ks, a, b): the fp32 input of row tile t for K-step ks: a = columns 32 ks + 4 q + r, b = 32 ks + 16 + 4 q + r
 //   (zeros beyond the input width); a pure read -- it is issued one K-step ahead, past the end the last step again.
 //   use_x(t, ks, a, b): called once per K-step when its data is consumed (the caller's side effects: copies, sums).
+//   hook(i, h): called with every finished hidden vector H_i, i = 1 .. n_hid (the gradient kernels keep them).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tiles16(int n) { return (n + 15) >> 4; }
 __device__ __forceinline__ int steps32(int n) { return (n + 31) >> 5; }
 
-template <int MT_MAX, int NTL, bool PREFILL, typename Src, typename LoadX, typename UseX>
+struct NoLayerHook {
+  template <typename H>
+  __device__ __forceinline__ void operator()(int, const H&) const {}
+};
+
+template <int MT_MAX, int NTL, bool PREFILL, typename Src, typename LoadX, typename UseX, typename Hook = NoLayerHook>
 __device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict__ flat, const NetDesc& nd, int n_hid,
                                               int no_act_layer, float wup, int lane, int q, const LoadX& load_x,
-                                              const UseX& use_x, Hidden<MT_MAX, NTL>& h) {
+                                              const UseX& use_x, Hidden<MT_MAX, NTL>& h, const Hook& hook = Hook()) {
   constexpr int KS_MAX = MT_MAX / 2;
   Acc<MT_MAX, NTL> acc;
   // ---- layer 0: K-streamed
@@ -462,6 +498,7 @@ __device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict_
 #pragma unroll
       for (int t = 0; t < NTL; ++t) scale[t] = wup / down[t];
       finish_layer<MT_MAX, NTL>(acc, c.bias, MT, q, scale, no_act_layer != 0, h);
+      hook(1, h);
     }
   }
   // ---- hidden -> hidden layers
@@ -495,6 +532,7 @@ __device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict_
 #pragma unroll
       for (int t = 0; t < NTL; ++t) scale[t] = wup * h.up[t];
       finish_layer<MT_MAX, NTL>(acc, c.bias, MT, q, scale, l != no_act_layer, h);
+      hook(l + 1, h);
     }
   }
 }

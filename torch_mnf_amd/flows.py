@@ -28,6 +28,7 @@ from torch import Tensor, nn
 
 import os
 
+from . import _dispatch
 from . import _lib
 from . import dist as _dist
 from ._lib import MnfHipError
@@ -313,7 +314,8 @@ def _bwd_split_workspace(lib, f, rows: int, device) -> Tensor | None:
 
 
 def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr, flat_ptr, bwd_image_ptr, scale, cold,
-                        inverse: bool, work: Tensor | None = None, lp_scratch: Tensor | None = None) -> bool:
+                        inverse: bool, work: Tensor | None = None, lp_scratch: Tensor | None = None,
+                        y_out: Tensor | None = None) -> bool:
     """Gradients of ONE AffineHalfFlow layer: the split-MFMA kernel (+ its fp32 fix-up pass over the tiles it handed
     back), else the fp32-MFMA kernel, else the generic one.  grad_x is written, the flat gradient added to.
 
@@ -373,7 +375,14 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
             rc = lib.mnf_affine_half_bwd_mfma(
                 x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
                 f.dim, int(bool(f.parity)), int(inverse), *hid, _stream())
-    if rc == _lib.MNF_ERR_UNSUPPORTED:  # no MFMA gradient kernel for this shape (e.g. a narrow half)
+    if rc == _lib.MNF_ERR_UNSUPPORTED and flat_ptr is not None and f.force_generic != 1 \
+            and (rows >= _dispatch.RT_MIN_ROWS or f.force_generic == 2) and (y_out is not None or not inverse or not f.scale):
+        # no per-shape gradient kernel: the run-time-shaped matrix-core one (any 1..4 hidden layers of widths 4..64)
+        sc = scale if scale is not None else _grad_scale(gy, gl, rows, f.dim, x_in.device)
+        rc = lib.mnf_affine_half_bwd_rt(
+            x_in.data_ptr(), _ptr(y_out), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, sc.data_ptr(), rows,
+            f.dim, int(bool(f.parity)), int(inverse), *hid, int(f.scale), int(f.shift), _stream())
+    if rc == _lib.MNF_ERR_UNSUPPORTED:  # no matrix-core gradient kernel for this shape at all
         rc = lib.mnf_affine_half_bwd(
             x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, rows, f.dim,
             int(bool(f.parity)), int(inverse), *hid, int(f.scale), int(f.shift), _stream())
@@ -399,12 +408,14 @@ class _AffineHalfFn(torch.autograd.Function):
             int(bool(module.parity)), int(inverse), len(module.h_sizes), module._hid, int(module.scale),
             int(module.shift), int(module.force_generic), _stream()))
         ctx.module, ctx.inverse = module, inverse
-        ctx.save_for_backward(x, flat if flat is not None else x.new_empty(0))
+        # (y too: the run-time-shaped gradient kernel forms the inverse direction's g_s = -grad_y y - grad_ld from it; the
+        #  next layer keeps its input alive anyway)
+        ctx.save_for_backward(x, flat if flat is not None else x.new_empty(0), y)
         return y, ld
 
     @staticmethod
     def backward(ctx, grad_y, grad_ld):
-        x, flat = ctx.saved_tensors
+        x, flat, y_out = ctx.saved_tensors
         m = ctx.module
         gy = None if grad_y is None else grad_y.contiguous()
         gl = None if grad_ld is None else grad_ld.contiguous()
@@ -419,7 +430,7 @@ class _AffineHalfFn(torch.autograd.Function):
             cold = torch.zeros((x.shape[0] + 15) // 16 + 1, dtype=torch.int32, device=x.device)
             work = _bwd_split_workspace(_lib.load(), m, x.shape[0], x.device)
         _ahf_layer_backward(_lib.load(), m, x, gy, gl, grad_x, _ptr(grad_flat) if has else None,
-                            _ptr(flat) if has else None, _ptr(bwd), scale, cold, ctx.inverse, work)
+                            _ptr(flat) if has else None, _ptr(bwd), scale, cold, ctx.inverse, work, y_out=y_out)
         return grad_x, (grad_flat if flat.numel() else None), None, None
 
 
