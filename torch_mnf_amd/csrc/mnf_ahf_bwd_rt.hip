@@ -39,70 +39,6 @@ struct AhfBwdRtArgs {
 
 constexpr float kLog2eB = 1.4426950408889634f;
 
-template <int MT_MAX>
-__device__ __forceinline__ uint32_t pack_signs(const rt::Hidden<MT_MAX, 1>& h) {
-  uint32_t bits = 0;
-#pragma unroll
-  for (int m = 0; m < MT_MAX; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t half = (h.hi[0][m][r >> 1] >> (16 * (r & 1))) & 0xffffu;
-      bits |= (half != 0u && (half & 0x8000u) == 0u) ? 1u << (4 * m + r) : 0u;  // LeakyReLU keeps the sign
-    }
-  return bits;
-}
-
-// (main + corr 2^-11) * scale, times the LeakyReLU derivative of the hidden vector whose sign bits are `bits`
-template <int MT_MAX>
-__device__ __forceinline__ void chain_result(const rt::Acc<MT_MAX, 1>& acc, float scale, uint32_t bits, f32x4 (&dv)[MT_MAX]) {
-#pragma unroll
-  for (int m = 0; m < MT_MAX; ++m) {
-    const f32x4 p = (acc.corr[0][m] * kSplitInvScale + acc.main[0][m]) * scale;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dv[m][r] = p[r] * ((bits >> (4 * m + r)) & 1u ? 1.f : kLeakySlope);
-  }
-}
-
-// a split hidden vector back to fp32: (head + residual 2^-11) * the row's scale
-__device__ __forceinline__ float half_of(uint32_t word, int hi) {
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? word >> 16 : word & 0xffffu));
-}
-template <int MT_MAX>
-__device__ __forceinline__ void unsplit(const rt::Hidden<MT_MAX, 1>& h, f32x4 (&v)[MT_MAX]) {
-#pragma unroll
-  for (int m = 0; m < MT_MAX; ++m) {
-    const u32x2 wh = h.hi[0][m], wl = h.lo[0][m];
-    v[m][0] = (half_of(wl[0], 0) * kSplitInvScale + half_of(wh[0], 0)) * h.up[0];
-    v[m][1] = (half_of(wl[0], 1) * kSplitInvScale + half_of(wh[0], 1)) * h.up[0];
-    v[m][2] = (half_of(wl[1], 0) * kSplitInvScale + half_of(wh[1], 0)) * h.up[0];
-    v[m][3] = (half_of(wl[1], 1) * kSplitInvScale + half_of(wh[1], 1)) * h.up[0];
-  }
-}
-
-// fp32 tiles -> split tiles with the row's power-of-two scale (the B operands of the next chain product)
-template <int MT_MAX>
-__device__ __forceinline__ void split_rows(const f32x4 (&v)[MT_MAX], rt::Hidden<MT_MAX, 1>& h) {
-  using namespace rt;
-  float fm = 0.f;
-#pragma unroll
-  for (int m = 0; m < MT_MAX; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) fm = __builtin_fmaxf(fm, finite_abs(v[m][r]));
-  const int e = down_exponent(max_over_q(fm), 13);
-  const float down = pow2f(-e);
-  h.up[0] = pow2f(e);
-  float unused = 0.f;
-#pragma unroll
-  for (int m = 0; m < MT_MAX; ++m) split_tile(v[m] * down, h.hi[0][m], h.lo[0][m], unused);
-}
-
-// first exchange tile of hidden vector H_i (i >= 1) of net nd
-__host__ __device__ inline int exH_tile_of(const NetDesc& nd, int i) {
-  int t = 0;
-  for (int k = 1; k < i; ++k) t += (nd.sizes[k] + 15) >> 4;
-  return t;
-}
-
 template <int MT_MAX, bool VEC>
 __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
   using namespace rt;
@@ -110,22 +46,20 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4, nw = blockDim.x >> 6;
   // LDS: [scratch 16][scales: sA 8, sC 8, sH (layers + 1) x 8][weights][bias][exchange: HT | DT | CT][meta: per wave sign bits]
   float* scratch = reinterpret_cast<float*>(rt_lds);
-  float* sA = scratch + 16;   // scale of the wave-tile's delta tiles
-  float* sC = scratch + 24;   // scale of the wave-tile's chunk tiles (cotangents / x0)
-  float* sH = scratch + 32;   // [hidden vector i][wave]: scale of the wave-tile's copy of H_i
-  uint32_t* blocks = rt_lds + 32 + 8 * (kMaxBwdLayers + 2);
+  uint32_t* blocks = rt_lds + kBwdHeadWords;
   float* bias = reinterpret_cast<float*>(blocks + a.block_words);
-  Exchange exH{reinterpret_cast<uint16_t*>(bias + a.bias_words), 16 * nw};
-  Exchange exD{exH.base + (size_t)a.ht_tiles * exH.tile_halves(), 16 * nw};
-  Exchange exC{exD.base + (size_t)a.dt_tiles * exH.tile_halves(), 16 * nw};
-  uint32_t* meta_bits = reinterpret_cast<uint32_t*>(exC.base + (size_t)a.ct_tiles * exH.tile_halves()) + wave * ((kMaxBwdLayers + 1) * 64);
+  const BwdLds lds = bwd_lds(rt_lds, bias + a.bias_words, a.ht_tiles, a.dt_tiles, a.ct_tiles);
+  float* const sC = lds.sC;
+  float* const sH = lds.sH;
+  const Exchange& exH = lds.exH;
+  const Exchange& exC = lds.exC;
+  const f16x4& ident = lds.ident;
 
   const float wmax = block_weight_max(a.flat, a.n_params, scratch);
   const int we = weight_exponent(wmax);
   const float wup = pow2f(we);
   Source<false> src{blocks, bias, a.cb, a.bt, 0, 0, 0, pow2f(-we), 0};
   const float gs = *a.gscale_dev, inv_gs = 1.f / gs;
-  const f16x4 ident = identity_operand(j, q);
   const int H = a.dim / 2;
   const int cond_off = a.parity ? H : 0, act_off = a.parity ? 0 : H;
   const int n_nets = (a.has_scale ? 1 : 0) + (a.has_shift ? 1 : 0);
@@ -149,7 +83,7 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
       const NetDesc& nd = is_s ? a.s_net : a.t_net;
       const int n_hid = nd.n_lin - 1, L = n_hid;
       float* gflat = a.grad_flat;
-      // ---- forward recompute: every hidden vector goes, turned, into the exchange area; sign bits and row scales into LDS
+      // ---- forward recompute: every hidden vector goes, turned, into the exchange area; its sign bits into LDS
       Hidden<MT_MAX, 1> h;
       {
         auto load_x = [&](int, int ks, f32x4& xa, f32x4& xb) {
@@ -157,18 +91,7 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
           xa = load4(xrow + cond_off, c0, H, VEC);
           xb = load4(xrow + cond_off, c0 + 16, H, VEC);
         };
-        auto use_x = [&](int, int, const f32x4&, const f32x4&) {};
-        int tile0 = 0;
-        auto hook = [&](int i, const Hidden<MT_MAX, 1>& hh) {
-          const int MT = tiles16(nd.sizes[i]);
-          f32x4 hv[MT_MAX];  // the vector's true values (head + residual, times the row's scale)
-          unsplit<MT_MAX>(hh, hv);
-          const float sc = exchange_store<MT_MAX>(hv, MT, exH, tile0, 16 * wave, lane, ident);
-          if (lane == 0) sH[i * 8 + wave] = sc;
-          tile0 += MT;
-          meta_bits[i * 64 + lane] = pack_signs<MT_MAX>(hh);
-        };
-        net_to_hidden<MT_MAX, 1, false>(src, a.flat, nd, n_hid, -1, wup, lane, q, load_x, use_x, h, hook);
+        forward_keep<MT_MAX>(src, a.flat, nd, n_hid, -1, wup, lds, load_x, h);
       }
       // ---- output layer, two 16-column tiles (one K-step of the chain) per chunk
       const int MTh = tiles16(nd.sizes[L]), KSh = steps32(16 * MTh), M = tiles16(H);
@@ -257,92 +180,17 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
         }
       }
       if (is_s) hs_last = h;
-      // ---- hidden layers backwards: dv = the cotangent of H_i's pre-activation (in units of gs)
+      // ---- hidden layers backwards, then grad_x of the conditioning half and dW_0 (mnf_rt_bwd.h)
       f32x4 dv[MT_MAX];
-      chain_result<MT_MAX>(accd, wup / downd, meta_bits[n_hid * 64 + lane], dv);
-#pragma unroll 1
-      for (int i = n_hid; i >= 2; --i) {
-        const int MTi = tiles16(nd.sizes[i]), MTp = tiles16(nd.sizes[i - 1]);
-        if (gflat) {
-          lds_barrier();  // (the previous phase's readers are done with the delta tiles)
-          const float sc = exchange_store<MT_MAX>(dv, MTi, exD, 0, 16 * wave, lane, ident);
-          if (lane == 0) sA[wave] = sc;
-          lds_barrier();
-          dw_phase(exD, 0, MTi, exH, exH_tile_of(nd, i - 1), MTp, sA, sH + (i - 1) * 8, nw, inv_gs, gflat + nd.w_off[i - 1],
-                   gflat + nd.b_off[i - 1], nd.sizes[i], nd.sizes[i - 1], 0, 0);
-        }
-        // delta_{i-1} = (W_{i-1}^T delta_i) * act'(H_{i-1}): K = the units of H_i, output tiles = those of H_{i-1}
-        Hidden<MT_MAX, 1> hd;
-        split_rows<MT_MAX>(dv, hd);
-        const int KS = steps32(16 * MTi);
-        int KC = src.cb / MTp;
-        if (KC < 1) KC = 1;
-        Acc<MT_MAX, 1> acc;
-        acc.zero();
-        const uint32_t* bufT = nullptr;
-        int next_start = 0, chunk_start = 0;
-#pragma unroll
-        for (int ks = 0; ks < MT_MAX / 2; ++ks)
-          if (ks < KS) {
-            if (ks == next_start) {
-              const int kc = KS - ks < KC ? KS - ks : KC;
-              uint32_t* b = src.cur_blocks();
-              stage_blocks(b, kc * MTp, DenseTKMajor{a.flat + nd.w_off[i - 1], nd.sizes[i - 1], nd.sizes[i], MTp, ks}, src.wdown);
-              src.commit();
-              bufT = b;
-              chunk_start = ks;
-              next_start = ks + kc;
-            }
-            f16x8 bh[1], bl[1];
-            hidden_operand<MT_MAX, 1>(hd, ks, bh, bl);
-            mac_kstep<MT_MAX, 1>(bufT, (ks - chunk_start) * MTp, MTp, lane, bh, bl, acc.main, acc.corr);
-          }
-        chain_result<MT_MAX>(acc, wup * hd.up[0], meta_bits[(i - 1) * 64 + lane], dv);
-      }
-      // ---- first layer: dv = delta_1.  grad_x of the conditioning half and dW_0, input tile by input tile
-      {
-        const int MT1 = tiles16(nd.sizes[1]), KS1 = steps32(16 * MT1), MI = tiles16(H);
-        if (gflat) {
-          lds_barrier();
-          const float sc = exchange_store<MT_MAX>(dv, MT1, exD, 0, 16 * wave, lane, ident);
-          if (lane == 0) sA[wave] = sc;
-        }
-        Hidden<MT_MAX, 1> hd;
-        split_rows<MT_MAX>(dv, hd);
-        int CI = src.cb / KS1;
-        if (CI > a.ct_tiles) CI = a.ct_tiles;
-        if (CI > MT_MAX) CI = MT_MAX;
-        if (CI < 1) CI = 1;
-        for (int mi0 = 0; mi0 < MI; mi0 += CI) {
-          const int ci = MI - mi0 < CI ? MI - mi0 : CI;
-          uint32_t* buf = src.cur_blocks();
-          float* bbuf = src.cur_bias();
-          stage_blocks(buf, ci * KS1, DenseTMMajor{a.flat + nd.w_off[0], H, nd.sizes[1], KS1, mi0}, src.wdown);
-          stage_bias(bbuf, 1, NoBias{});
-          src.commit();
-          f32x4 xv[MT_MAX];
-#pragma unroll
-          for (int ml = 0; ml < MT_MAX; ++ml) {
-            xv[ml] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ml < ci) {
-              const int col = 16 * (mi0 + ml) + 4 * q;
-              f32x4 gx[1];
-              out_tile<MT_MAX, 1>(buf, ml * KS1, KS1, bbuf, lane, q, hd, wup, gx);
-              const f32x4 base = pass == 0 ? (a.grad_y ? load4(gyrow + cond_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f})
-                                           : load4(gxrow + cond_off, col, H, VEC);
-              store4(gxrow + cond_off, col, H, VEC, live, base + gx[0] * inv_gs);
-              xv[ml] = load4(xrow + cond_off, col, H, VEC);
-            }
-          }
-          if (gflat) {
-            const float sc = exchange_store<MT_MAX>(xv, ci, exC, 0, 16 * wave, lane, ident);
-            if (lane == 0) sC[wave] = sc;
-            lds_barrier();
-            dw_phase(exD, 0, MT1, exC, 0, ci, sA, sC, nw, inv_gs, gflat + nd.w_off[0], mi0 == 0 ? gflat + nd.b_off[0] : nullptr,
-                     nd.sizes[1], H, 0, mi0);
-          }
-        }
-      }
+      chain_result<MT_MAX>(accd, wup / downd, lds.meta_bits[n_hid * 64 + lane], dv);
+      auto load_in = [&](int mi) { return load4(xrow + cond_off, 16 * mi + 4 * q, H, VEC); };
+      auto add_gx = [&](int mi, const f32x4& g) {
+        const int col = 16 * mi + 4 * q;
+        const f32x4 base = pass == 0 ? (a.grad_y ? load4(gyrow + cond_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f})
+                                     : load4(gxrow + cond_off, col, H, VEC);
+        store4(gxrow + cond_off, col, H, VEC, live, base + g);
+      };
+      backward_tail<MT_MAX>(src, a.flat, gflat, nd, n_hid, -1, dv, lds, wup, inv_gs, H, load_in, add_gx);
     }
   }
 }
@@ -405,7 +253,7 @@ extern "C" int mnf_affine_half_bwd_rt(const float* x, const float* y, const floa
   size_t lds = 0;
   for (; nw >= 1; nw >>= 1) {
     const size_t tile_bytes = (size_t)2 * 16 * (16 * nw + rt::kExPad) * 2;
-    lds = (size_t)4 * (32 + 8 * (rt::kMaxBwdLayers + 2)) + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 + (size_t)(a.ht_tiles + a.dt_tiles + a.ct_tiles) * tile_bytes +
+    lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 + (size_t)(a.ht_tiles + a.dt_tiles + a.ct_tiles) * tile_bytes +
           (size_t)nw * (rt::kMaxBwdLayers + 1) * 64 * 4;
     if (lds <= 160 * 1024) break;
   }

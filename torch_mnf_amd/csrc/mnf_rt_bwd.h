@@ -199,5 +199,216 @@ __device__ __forceinline__ void leaky_gate(const Hidden<MT_MAX, 1>& h, f32x4 (&g
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// what the layers' gradient kernels share
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT_MAX>
+__device__ __forceinline__ uint32_t pack_signs(const Hidden<MT_MAX, 1>& h) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t half = (h.hi[0][m][r >> 1] >> (16 * (r & 1))) & 0xffffu;
+      bits |= (half != 0u && (half & 0x8000u) == 0u) ? 1u << (4 * m + r) : 0u;  // LeakyReLU keeps the sign
+    }
+  return bits;
+}
+
+// (main + corr 2^-11) * scale, times the LeakyReLU derivative of the hidden vector whose sign bits are `bits`
+template <int MT_MAX>
+__device__ __forceinline__ void chain_result(const Acc<MT_MAX, 1>& acc, float scale, uint32_t bits, f32x4 (&dv)[MT_MAX]) {
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) {
+    const f32x4 p = (acc.corr[0][m] * kSplitInvScale + acc.main[0][m]) * scale;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dv[m][r] = p[r] * ((bits >> (4 * m + r)) & 1u ? 1.f : kLeakySlope);
+  }
+}
+
+// a split hidden vector back to fp32: (head + residual 2^-11) * the row's scale
+__device__ __forceinline__ float half_of(uint32_t word, int hi) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? word >> 16 : word & 0xffffu));
+}
+template <int MT_MAX>
+__device__ __forceinline__ void unsplit(const Hidden<MT_MAX, 1>& h, f32x4 (&v)[MT_MAX]) {
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) {
+    const u32x2 wh = h.hi[0][m], wl = h.lo[0][m];
+    v[m][0] = (half_of(wl[0], 0) * kSplitInvScale + half_of(wh[0], 0)) * h.up[0];
+    v[m][1] = (half_of(wl[0], 1) * kSplitInvScale + half_of(wh[0], 1)) * h.up[0];
+    v[m][2] = (half_of(wl[1], 0) * kSplitInvScale + half_of(wh[1], 0)) * h.up[0];
+    v[m][3] = (half_of(wl[1], 1) * kSplitInvScale + half_of(wh[1], 1)) * h.up[0];
+  }
+}
+
+// fp32 tiles -> split tiles with the row's power-of-two scale (the B operands of the next chain product)
+template <int MT_MAX>
+__device__ __forceinline__ void split_rows(const f32x4 (&v)[MT_MAX], Hidden<MT_MAX, 1>& h) {
+  float fm = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fm = __builtin_fmaxf(fm, finite_abs(v[m][r]));
+  const int e = down_exponent(max_over_q(fm), 13);
+  const float down = pow2f(-e);
+  h.up[0] = pow2f(e);
+  float unused = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT_MAX; ++m) split_tile(v[m] * down, h.hi[0][m], h.lo[0][m], unused);
+}
+
+// first exchange tile of hidden vector H_i (i >= 1) of net nd
+__host__ __device__ inline int exH_tile_of(const NetDesc& nd, int i) {
+  int t = 0;
+  for (int k = 1; k < i; ++k) t += (nd.sizes[k] + 15) >> 4;
+  return t;
+}
+
+
+constexpr int kBwdHeadWords = 32 + 8 * (kMaxBwdLayers + 2);  // scratch 16 | sA 8 | sC 8 | sH (layers + 1) x 8 | spare
+
+struct BwdLds {
+  float *sA, *sC, *sH;   // power-of-two scales of the wave-tiles' exchange copies: deltas | chunk tiles | hidden vector i
+  Exchange exH, exD, exC;  // hidden vectors of one net | one layer's deltas | a chunk's cotangent / input tiles
+  uint32_t* meta_bits;   // this wave's [hidden vector i][lane] sign bits
+  int ct_tiles;
+  int nw, wave, lane, q;
+  f16x4 ident;
+};
+__device__ __forceinline__ BwdLds bwd_lds(uint32_t* lds0, float* after_weights, int ht_tiles, int dt_tiles, int ct_tiles) {
+  BwdLds L;
+  float* scratch = reinterpret_cast<float*>(lds0);
+  L.sA = scratch + 16;
+  L.sC = scratch + 24;
+  L.sH = scratch + 32;
+  L.nw = blockDim.x >> 6;
+  L.wave = threadIdx.x >> 6;
+  L.lane = threadIdx.x & 63;
+  L.q = L.lane >> 4;
+  L.exH = Exchange{reinterpret_cast<uint16_t*>(after_weights), 16 * L.nw};
+  L.exD = Exchange{L.exH.base + (size_t)ht_tiles * L.exH.tile_halves(), 16 * L.nw};
+  L.exC = Exchange{L.exD.base + (size_t)dt_tiles * L.exH.tile_halves(), 16 * L.nw};
+  L.meta_bits = reinterpret_cast<uint32_t*>(L.exC.base + (size_t)ct_tiles * L.exH.tile_halves()) + L.wave * ((kMaxBwdLayers + 1) * 64);
+  L.ct_tiles = ct_tiles;
+  L.ident = identity_operand(L.lane & 15, L.q);
+  return L;
+}
+// bytes of LDS behind the weight stream for a workgroup of nw waves
+inline size_t bwd_lds_bytes(int nw, int ht_tiles, int dt_tiles, int ct_tiles) {
+  const size_t tile_bytes = (size_t)2 * 16 * (16 * nw + kExPad) * 2;
+  return (size_t)(ht_tiles + dt_tiles + ct_tiles) * tile_bytes + (size_t)nw * (kMaxBwdLayers + 1) * 64 * 4;
+}
+
+// The forward recompute of one conditioner net that KEEPS every hidden vector: its true values turned into the exchange
+// area (tiles from exH tile 0 on, with the wave-tile's scale in sH[i][wave]) and its sign bits (the LeakyReLU derivative).
+template <int MT_MAX, typename Src, typename LoadX>
+__device__ __forceinline__ void forward_keep(Src& src, const float* __restrict__ flat, const NetDesc& nd, int n_hid,
+                                             int no_act_layer, float wup, const BwdLds& L, const LoadX& load_x,
+                                             Hidden<MT_MAX, 1>& h) {
+  auto use_x = [&](int, int, const f32x4&, const f32x4&) {};
+  int tile0 = 0;
+  auto hook = [&](int i, const Hidden<MT_MAX, 1>& hh) {
+    const int MT = tiles16(nd.sizes[i]);
+    f32x4 hv[MT_MAX];  // the vector's true values (head + residual, times the row's scale)
+    unsplit<MT_MAX>(hh, hv);
+    const float sc = exchange_store<MT_MAX>(hv, MT, L.exH, tile0, 16 * L.wave, L.lane, L.ident);
+    if (L.lane == 0) L.sH[i * 8 + L.wave] = sc;
+    tile0 += MT;
+    L.meta_bits[i * 64 + L.lane] = pack_signs<MT_MAX>(hh);
+  };
+  net_to_hidden<MT_MAX, 1, false>(src, flat, nd, n_hid, no_act_layer, wup, L.lane, L.q, load_x, use_x, h, hook);
+}
+
+// From dv = the cotangent of H_n's pre-activation (n = n_hid; in units of the gradient scale) down to the net's input:
+// per hidden layer dW_{i-1}, db_{i-1} through the exchange area and the chain step  delta_{i-1} = (W_{i-1}^T delta_i) *
+// act'(H_{i-1});  then the first layer input tile by input tile: add_in(mi, W_0^T delta_1 of the tile's 16 columns, times
+// inv_gs) and dW_0 += delta_1 (x) load_in(mi).  n_in0 = the first layer's input width.  The hidden vector whose index is
+// no_act_hidden has no activation (derivative 1).
+template <int MT_MAX, typename Src, typename LoadIn, typename AddIn>
+__device__ __forceinline__ void backward_tail(Src& src, const float* __restrict__ flat, float* gflat, const NetDesc& nd,
+                                              int n_hid, int no_act_hidden, f32x4 (&dv)[MT_MAX], const BwdLds& L, float wup,
+                                              float inv_gs, int n_in0, const LoadIn& load_in, const AddIn& add_in) {
+  const int lane = L.lane, wave = L.wave, q = L.q, nw = L.nw;
+#pragma unroll 1
+  for (int i = n_hid; i >= 2; --i) {
+    const int MTi = tiles16(nd.sizes[i]), MTp = tiles16(nd.sizes[i - 1]);
+    if (gflat) {
+      lds_barrier();  // (the previous phase's readers are done with the delta tiles)
+      const float sc = exchange_store<MT_MAX>(dv, MTi, L.exD, 0, 16 * wave, lane, L.ident);
+      if (lane == 0) L.sA[wave] = sc;
+      lds_barrier();
+      dw_phase(L.exD, 0, MTi, L.exH, exH_tile_of(nd, i - 1), MTp, L.sA, L.sH + (i - 1) * 8, nw, inv_gs, gflat + nd.w_off[i - 1],
+               gflat + nd.b_off[i - 1], nd.sizes[i], nd.sizes[i - 1], 0, 0);
+    }
+    // delta_{i-1} = (W_{i-1}^T delta_i) * act'(H_{i-1}): K = the units of H_i, output tiles = those of H_{i-1}
+    Hidden<MT_MAX, 1> hd;
+    split_rows<MT_MAX>(dv, hd);
+    const int KS = steps32(16 * MTi);
+    int KC = src.cb / MTp;
+    if (KC < 1) KC = 1;
+    Acc<MT_MAX, 1> acc;
+    acc.zero();
+    const uint32_t* bufT = nullptr;
+    int next_start = 0, chunk_start = 0;
+#pragma unroll
+    for (int ks = 0; ks < MT_MAX / 2; ++ks)
+      if (ks < KS) {
+        if (ks == next_start) {
+          const int kc = KS - ks < KC ? KS - ks : KC;
+          uint32_t* b = src.cur_blocks();
+          stage_blocks(b, kc * MTp, DenseTKMajor{flat + nd.w_off[i - 1], nd.sizes[i - 1], nd.sizes[i], MTp, ks}, src.wdown);
+          src.commit();
+          bufT = b;
+          chunk_start = ks;
+          next_start = ks + kc;
+        }
+        f16x8 bh[1], bl[1];
+        hidden_operand<MT_MAX, 1>(hd, ks, bh, bl);
+        mac_kstep<MT_MAX, 1>(bufT, (ks - chunk_start) * MTp, MTp, lane, bh, bl, acc.main, acc.corr);
+      }
+    chain_result<MT_MAX>(acc, wup * hd.up[0], i - 1 == no_act_hidden ? 0xffffffffu : L.meta_bits[(i - 1) * 64 + lane], dv);
+  }
+  // ---- first layer: dv = delta_1
+  const int MT1 = tiles16(nd.sizes[1]), KS1 = steps32(16 * MT1), MI = tiles16(n_in0);
+  if (gflat) {
+    lds_barrier();
+    const float sc = exchange_store<MT_MAX>(dv, MT1, L.exD, 0, 16 * wave, lane, L.ident);
+    if (lane == 0) L.sA[wave] = sc;
+  }
+  Hidden<MT_MAX, 1> hd;
+  split_rows<MT_MAX>(dv, hd);
+  int CI = src.cb / KS1;
+  if (CI > L.ct_tiles) CI = L.ct_tiles;
+  if (CI > MT_MAX) CI = MT_MAX;
+  if (CI < 1) CI = 1;
+  for (int mi0 = 0; mi0 < MI; mi0 += CI) {
+    const int ci = MI - mi0 < CI ? MI - mi0 : CI;
+    uint32_t* buf = src.cur_blocks();
+    float* bbuf = src.cur_bias();
+    stage_blocks(buf, ci * KS1, DenseTMMajor{flat + nd.w_off[0], n_in0, nd.sizes[1], KS1, mi0}, src.wdown);
+    stage_bias(bbuf, 1, NoBias{});
+    src.commit();
+    f32x4 xv[MT_MAX];
+#pragma unroll
+    for (int ml = 0; ml < MT_MAX; ++ml) {
+      xv[ml] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ml < ci) {
+        f32x4 gx[1];
+        out_tile<MT_MAX, 1>(buf, ml * KS1, KS1, bbuf, lane, q, hd, wup, gx);
+        add_in(mi0 + ml, gx[0] * inv_gs);
+        xv[ml] = load_in(mi0 + ml);
+      }
+    }
+    if (gflat) {
+      const float sc = exchange_store<MT_MAX>(xv, ci, L.exC, 0, 16 * wave, lane, L.ident);
+      if (lane == 0) L.sC[wave] = sc;
+      lds_barrier();
+      dw_phase(L.exD, 0, MT1, L.exC, 0, ci, L.sA, L.sC, nw, inv_gs, gflat + nd.w_off[0], mi0 == 0 ? gflat + nd.b_off[0] : nullptr,
+               nd.sizes[1], n_in0, 0, mi0);
+    }
+  }
+}
+
 }  // namespace rt
 }  // namespace mnf
