@@ -657,6 +657,14 @@ int mnf_rnvp_bwd_mfma_phases(const float* z, const float* mask, uint64_t seed, c
                              const void* split_image, const void* bwd_image, const float* grad_scale_dev,
                              void* workspace, int64_t workspace_bytes, int64_t rows, int dim, int n_hidden,
                              const int* hidden_host, int phases, const float* y, void* stream);
+/* mnf_rnvp_bwd for ANY conditioner shape on the f16 matrix pipe (mnf_rnvp_bwd_rt.hip: run-time layer count and widths,
+ * weights read from `flat`; no operand image, no workspace): net = MLP(dim, h_1 .. h_n) with 1 .. 4 layers of widths
+ * 4 .. 128, any dim.  grad_scale_dev: device float, a power of two that brings the cotangents near 1
+ * (mnf_affine_half_grad_scale).  grad_z is written, grad_flat ADDED to with float atomics, one flush per block of 16 .. 128
+ * rows (or NULL).  MNF_ERR_UNSUPPORTED: shape outside these limits, or MNF_DETERMINISTIC is set (atomic sums). */
+int mnf_rnvp_bwd_rt(const float* z, const float* mask, uint64_t seed, const float* grad_x, const float* grad_ld, float* grad_z,
+                    float* grad_flat, const float* flat, const float* grad_scale_dev, int64_t rows, int dim, int n_hidden,
+                    const int* hidden_host, void* stream);
 /* AffineConstantFlow: grad_x = grad_y * exp(+-s); grad_s, grad_t (dim,) are ADDED to. */
 int mnf_affine_const_bwd(const float* x, const float* y, const float* grad_y, const float* s,
                          float* grad_x, float* grad_s, float* grad_t, int64_t rows, int dim,

@@ -79,5 +79,59 @@ if which in ("ahf", "all"):
             line += f"  {kb[0]} {t * 1e6 / ROWS:.3f} ns/row"
         print(line)
 
+def rnvp_sd(seed, dim, hs):
+    rng = np.random.default_rng(seed)
+    sd = recipes.mlp_params(rng, "net", (dim, *hs), gain=1.5)
+    k = 1.5 / np.sqrt(hs[-1])
+    for name in ("t", "s"):
+        sd[f"{name}.weight"] = torch.from_numpy(rng.uniform(-k, k, size=(dim, hs[-1])).astype(np.float32))
+        sd[f"{name}.bias"] = torch.from_numpy(rng.uniform(-k, k, size=(dim,)).astype(np.float32))
+    return sd
+
+
+if which in ("rnvp", "all"):
+    print("== RNVP gradients, rt kernel vs float64 oracle")
+    for dim, hs in [(800, (100,)), (50, (100,)), (128, (30,)), (784, (50, 40)), (50, (17,)), (37, (120,)), (256, (64, 64)), (64, (7, 9, 11))]:
+        for rows in (300, 2100):
+            for seeded in (False, True):
+                sd = rnvp_sd(41 + dim, dim, hs)
+                z_cpu = recipes.gaussian(42 + dim, rows, dim)
+                w_y, w_l = recipes.gaussian(43, rows, dim), recipes.gaussian(44, rows, 1)[:, 0]
+                f = amd.RNVP(dim, h_sizes=hs)
+                f.load_state_dict(sd); f.to(DEV); f.force_generic = 2
+                mask = f.mask_for(77, rows).cpu() if seeded else recipes.bernoulli_mask(97, rows, dim)
+                fn = lambda x, p: O.rnvp(x, p, mask.to(x.dtype))
+                g32, g64 = oracle_grads(fn, z_cpu, sd, w_y, w_l, torch.float32), oracle_grads(fn, z_cpu, sd, w_y, w_l, torch.float64)
+                z = z_cpu.to(DEV).requires_grad_(True)
+                xg, ldg = f.forward(z, seed=77) if seeded else f.forward(z, mask=mask.to(DEV))
+                ((xg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+                k = amd.last_kernel()
+                got = {"x": z.grad, **{n: q.grad for n, q in f.named_parameters()}}
+                worst, wkey = 0.0, ""
+                for key in got:
+                    budget = 1e-5 + 2 * nerr(g32[key], g64[key])
+                    e = nerr(got[key], g64[key]) / budget
+                    if e > worst: worst, wkey = e, key
+                flag = "" if worst <= 1.0 and k == "rnvp_bwd_rt" else "   <-- FAIL"
+                if flag: bad += 1
+                if flag or (rows == 2100 and not seeded):
+                    print(f"  d={dim} h={hs} rows={rows} seeded={seeded}: kernel={k} worst {worst:.2f} of budget ({wkey}){flag}")
+    print("== RNVP fwd+bwd time per row")
+    for dim, hs in [(800, (100,)), (800, (50,)), (50, (100,)), (128, (100,)), (2048, (100,)), (784, (50,))]:
+        f = amd.RNVP(dim, h_sizes=hs).to(DEV)
+        x = torch.randn(ROWS, dim, device=DEV).requires_grad_(True)
+        line = f"  d={dim} h={hs}:"
+        for force in (0, 2, 1):
+            f.force_generic = force
+            kb = [None]
+            def both():
+                f.zero_grad()
+                y, ld = f.forward(x, seed=3)
+                (y.sum() + ld.sum()).backward()
+                kb[0] = amd.last_kernel()
+            t = timed(both, reps=2)
+            line += f"  {kb[0]} {t * 1e6 / ROWS:.3f} ns/row"
+        print(line)
+
 print("FAILURES:", bad)
 sys.exit(1 if bad else 0)

@@ -116,6 +116,8 @@ SIGNATURES = {
                                           c_int, c_float, c_int, c_int, _intp, c_void_p, c_int, c_void_p]),
     "mnf_rnvp_bwd": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int64, c_int, c_int, _intp, c_void_p]),
+    "mnf_rnvp_bwd_rt": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_int, c_int, _intp, c_void_p]),
     "mnf_rnvp_bwd_mfma_workspace_bytes": (c_int64, [c_int64, c_int, c_int, _intp]),
     "mnf_rnvp_bwd_mfma_layout": (c_int, [c_int, c_int, _intp, _i64p, _i64p]),
     "mnf_rnvp_bwd_mfma_index": (c_int, [c_int, c_int, _intp, _i32p]),

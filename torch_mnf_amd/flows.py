@@ -594,6 +594,15 @@ class _RnvpFn(torch.autograd.Function):
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_rnvp_bwd_mfma", rc)
                 return grad_z, ret_flat, None, None, None, None
+        if m.force_generic != 1 and not _RNVP_BWD_GENERIC_ENV and (z.shape[0] >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+            # no per-shape gradient kernel: the run-time-shaped matrix-core one (1..4 conditioner layers of widths 4..128)
+            scale = _grad_scale(gx, gl, z.shape[0], m.dim, z.device)
+            rc = lib.mnf_rnvp_bwd_rt(
+                z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
+                flat.data_ptr(), scale.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_rnvp_bwd_rt", rc)
+                return grad_z, ret_flat, None, None, None, None
         _lib.check("mnf_rnvp_bwd", lib.mnf_rnvp_bwd(
             z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
             flat.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
