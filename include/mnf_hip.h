@@ -619,6 +619,14 @@ int mnf_nsf_cl_bwd_tile_fixup(const float* x, const float* grad_y, const float* 
                               float* grad_flat, const float* flat, int64_t rows, int dim, int K, float tail_bound,
                               int inverse, int n_hidden, const int* hidden_host, const int32_t* cold,
                               int cold_capacity, void* stream);
+/* mnf_nsf_cl_bwd for ANY dim, K = 2 .. 16 and 1 .. 4 hidden layers of widths 4 .. 64 on the f16 matrix pipe
+ * (mnf_nsf_bwd_rt.hip: run-time shapes, weights read from `flat`; no operand image, no workspace).  y = the layer's OUTPUT
+ * for the same x, direction and parameters; grad_scale_dev as for mnf_nsf_cl_bwd_tile.  grad_x is written, grad_flat ADDED
+ * to with float atomics, one flush per block of 16 .. 128 rows and slot (or NULL).  MNF_ERR_UNSUPPORTED: shape outside these
+ * limits, or MNF_DETERMINISTIC is set (atomic sums). */
+int mnf_nsf_cl_bwd_rt(const float* x, const float* y, const float* grad_y, const float* grad_ld, float* grad_x,
+                      float* grad_flat, const float* flat, const float* grad_scale_dev, int64_t rows, int dim, int K,
+                      float tail_bound, int inverse, int n_hidden, const int* hidden_host, void* stream);
 /* mask == NULL: the mask of the seeded forward call is regenerated from `seed`. */
 int mnf_rnvp_bwd(const float* z, const float* mask, uint64_t seed, const float* grad_x,
                  const float* grad_ld, float* grad_z, float* grad_flat, const float* flat,

@@ -79,6 +79,50 @@ if which in ("ahf", "all"):
             line += f"  {kb[0]} {t * 1e6 / ROWS:.3f} ns/row"
         print(line)
 
+if which in ("nsf", "all"):
+    print("== NSF_CL gradients, rt kernel vs float64 oracle")
+    for dim, K, n_h in [(32, 8, 8), (64, 8, 16), (128, 8, 8), (48, 5, 32), (2, 5, 8), (6, 3, 5), (50, 10, 12), (16, 16, 16), (64, 10, 32), (24, 13, 20)]:
+        for rows in (300, 2100):
+            for inverse in (False, True):
+                sd = recipes.nsf_cl_params(51 + dim + K, dim, K, n_h)
+                x_cpu = recipes.gaussian(52 + dim, rows, dim, scale=1.4)
+                w_y, w_l = recipes.gaussian(53, rows, dim), recipes.gaussian(54, rows, 1)[:, 0]
+                fn = lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse)
+                g32, g64 = oracle_grads(fn, x_cpu, sd, w_y, w_l, torch.float32), oracle_grads(fn, x_cpu, sd, w_y, w_l, torch.float64)
+                f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+                f.load_state_dict(sd); f.to(DEV); f.force_generic = 2
+                x = x_cpu.to(DEV).requires_grad_(True)
+                yg, ldg = (f.inverse if inverse else f.forward)(x)
+                ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+                k = amd.last_kernel()
+                got = {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+                worst, wkey = 0.0, ""
+                for key in got:
+                    budget = 1e-5 + 2 * nerr(g32[key], g64[key])
+                    e = nerr(got[key], g64[key]) / budget
+                    if e > worst: worst, wkey = e, key
+                flag = "" if worst <= 1.0 and k == "nsf_bwd_rt" else "   <-- FAIL"
+                if flag: bad += 1
+                if flag or rows == 2100:
+                    print(f"  d={dim} K={K} n_h={n_h} rows={rows} inv={inverse}: kernel={k} worst {worst:.2f} of budget ({wkey}){flag}")
+    print("== NSF_CL fwd+bwd time per row")
+    for dim, K, n_h in [(32, 8, 8), (64, 8, 16), (128, 8, 8), (64, 8, 32), (128, 10, 32), (48, 10, 16)]:
+        f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h).to(DEV)
+        x = (torch.randn(ROWS, dim, device=DEV) * 1.4).requires_grad_(True)
+        line = f"  d={dim} K={K} n_h={n_h}:"
+        for force in (0, 2, 1):
+            f.force_generic = force
+            kb = [None]
+            def both():
+                f.zero_grad()
+                y, ld = f.forward(x)
+                (y.sum() + ld.sum()).backward()
+                kb[0] = amd.last_kernel()
+            t = timed(both, reps=2)
+            line += f"  {kb[0]} {t * 1e6 / ROWS:.3f} ns/row"
+        print(line)
+
+
 def rnvp_sd(seed, dim, hs):
     rng = np.random.default_rng(seed)
     sd = recipes.mlp_params(rng, "net", (dim, *hs), gain=1.5)

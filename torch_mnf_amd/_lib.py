@@ -105,6 +105,8 @@ SIGNATURES = {
                                        c_int64, c_int, c_int, c_int, c_int, _intp, c_int, c_int, c_void_p]),
     "mnf_nsf_cl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_int, c_int, _intp, c_void_p]),
+    "mnf_nsf_cl_bwd_rt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_int, c_float, c_int, c_int, _intp, c_void_p]),
     "mnf_nsf_cl_bwd_tile_supported": (c_int, [c_int, c_int, c_int, _intp]),
     "mnf_nsf_cl_bwd_tile_layout": (c_int, [c_int, c_int, c_int, _intp, _i64p, _i64p, _i64p]),
     "mnf_nsf_cl_bwd_tile_index": (c_int, [c_int, c_int, c_int, _intp, _i32p, _i32p]),

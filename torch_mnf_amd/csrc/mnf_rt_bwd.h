@@ -90,10 +90,19 @@ __device__ __forceinline__ float exchange_store(const f32x4 (&v)[MT_MAX], int MT
 // wave-tiles w of sa[w] sb[w] (A tile m)^T-product (B tile n), A = the delta tiles at exchange tile a0 .. a0 + MA - 1, B
 // = the input tiles at b0 .. b0 + MB - 1; bias: db[16 (m0 + m) + i] += the row sums of A (gb != nullptr).  The (m, n)
 // pairs are dealt out over the workgroup's waves.  gW: the layer's weight gradient (n_out x n_in, row-major).
-__device__ __forceinline__ void dw_phase(const Exchange& exa, int a0, int MA, const Exchange& exb, int b0, int MB,
-                                         const float* sa, const float* sb,
-                                         int nw, float out_scale, float* __restrict__ gW, float* __restrict__ gb, int n_out,
-                                         int n_in, int m0, int n0) {
+// rows of the weight matrix behind delta tile m: unit i' of tile m <-> row rows(m, i') (< 0: padding)
+struct ContigRows {
+  int m0, n_out;
+  __device__ __forceinline__ int operator()(int m, int u) const {
+    const int o = 16 * (m0 + m) + u;
+    return o < n_out ? o : -1;
+  }
+};
+template <typename RowMap>
+__device__ __forceinline__ void dw_phase_rows(const Exchange& exa, int a0, int MA, const Exchange& exb, int b0, int MB,
+                                              const float* sa, const float* sb, int nw, float out_scale,
+                                              float* __restrict__ gW, float* __restrict__ gb, const RowMap& rows, int n_in,
+                                              int n0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int us = exa.unit_stride();
   f16x4 ones;
@@ -145,12 +154,17 @@ __device__ __forceinline__ void dw_phase(const Exchange& exa, int a0, int MA, co
     const int k = 16 * (n0 + n) + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int o = 16 * (m0 + m) + 4 * q + r;
-      if (o < n_out && k < n_in) atomicAdd(gW + (size_t)o * n_in + k, acc[r] * out_scale);
-      if (gb && n == 0 && i == 0 && o < n_out) atomicAdd(gb + o, bacc[r] * out_scale);
+      const int o = rows(m, 4 * q + r);
+      if (o >= 0 && k < n_in) atomicAdd(gW + (size_t)o * n_in + k, acc[r] * out_scale);
+      if (gb && n == 0 && i == 0 && o >= 0) atomicAdd(gb + o, bacc[r] * out_scale);
     }
     n += nw;
   }
+}
+__device__ __forceinline__ void dw_phase(const Exchange& exa, int a0, int MA, const Exchange& exb, int b0, int MB,
+                                         const float* sa, const float* sb, int nw, float out_scale, float* __restrict__ gW,
+                                         float* __restrict__ gb, int n_out, int n_in, int m0, int n0) {
+  dw_phase_rows(exa, a0, MA, exb, b0, MB, sa, sb, nw, out_scale, gW, gb, ContigRows{m0, n_out}, n_in, n0);
 }
 
 // W^T of a dense Linear W (n_out x n_in) as A blocks: block row i = INPUT unit 16 mi + i, K index = OUTPUT unit.

@@ -489,16 +489,27 @@ class _NsfFn(torch.autograd.Function):
             work = torch.empty(n_work, dtype=torch.float32, device=x.device)
             if marks is not None:
                 marks[0].record()
-            _lib.check("mnf_nsf_cl_bwd_tile", lib.mnf_nsf_cl_bwd_tile(
+            rc = lib.mnf_nsf_cl_bwd_tile(
                 x.data_ptr(), y_out.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(),
-                image.data_ptr(), flush.data_ptr(), *args, scale.data_ptr(), cold.data_ptr(), cap, work.data_ptr(), n_work, _stream()))
-            if marks is not None:
-                marks[1].record()
-                bwd_kernel_events.append(marks)
-            _lib.check("mnf_nsf_cl_bwd_tile_fixup", lib.mnf_nsf_cl_bwd_tile_fixup(
-                x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
-                cold.data_ptr(), cap, _stream()))
-            return grad_x, grad_flat, None, None
+                image.data_ptr(), flush.data_ptr(), *args, scale.data_ptr(), cold.data_ptr(), cap, work.data_ptr(), n_work, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:  # (unsupported: e.g. a view at an odd storage offset -- the kernels below take it)
+                _lib.check("mnf_nsf_cl_bwd_tile", rc)
+                if marks is not None:
+                    marks[1].record()
+                    bwd_kernel_events.append(marks)
+                _lib.check("mnf_nsf_cl_bwd_tile_fixup", lib.mnf_nsf_cl_bwd_tile_fixup(
+                    x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
+                    cold.data_ptr(), cap, _stream()))
+                return grad_x, grad_flat, None, None
+        if m.force_generic != 1 and _NSF_BWD_KERNEL != "generic" and (rows >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+            # no per-shape gradient kernel: the run-time-shaped matrix-core one (any dim, K <= 16, hidden widths 4..64)
+            scale = _grad_scale(gy, gl, rows, m.dim, x.device)
+            rc = lib.mnf_nsf_cl_bwd_rt(
+                x.data_ptr(), y_out.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(),
+                scale.data_ptr(), *args, _stream())
+            if rc != _lib.MNF_ERR_UNSUPPORTED:
+                _lib.check("mnf_nsf_cl_bwd_rt", rc)
+                return grad_x, grad_flat, None, None
         _lib.check("mnf_nsf_cl_bwd", lib.mnf_nsf_cl_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
         if not m.force_generic and _NSF_BWD_KERNEL != "generic" and not m._pad_half():
