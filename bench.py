@@ -541,12 +541,12 @@ def main_train(args, rank, world, device, dim, rows, desc) -> None:
         loss_cpu = -(ld + O.std_normal_log_prob(zs[-1])).mean()
         loss_cpu.backward()
         fresh, _ = build_model(dim, device)
-        floor, amd_flows._BWD_SPLIT_MIN_ROWS = amd_flows._BWD_SPLIT_MIN_ROWS, 0
+        floor, amd_flows._dispatch.BWD_SPLIT_MIN_ROWS = amd_flows._dispatch.BWD_SPLIT_MIN_ROWS, 0
         try:
             loss_gpu = -fresh.log_prob(x[:n].contiguous()).mean()
             loss_gpu.backward()
         finally:
-            amd_flows._BWD_SPLIT_MIN_ROWS = floor
+            amd_flows._dispatch.BWD_SPLIT_MIN_ROWS = floor
         worst = 0.0
         for sp, f in zip(specs, fresh.flows):
             for name, prm in f.named_parameters():

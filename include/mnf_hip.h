@@ -251,8 +251,7 @@ int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, floa
  * wave sums, no operand image.
  *   mnf_rnvp_seeded   a workgroup per two rows: up to MNF_RNVP_FEW_FWD_ROWS rows with an explicit mask (the reference's
  *                     batch of 128 rows of 800 dims: 103 -> 35 us), up to 64 with the in-kernel mask (the register-
- *                     resident kernels are as fast from ~100 rows); one row of 800 dims: 86 -> 22 us.  The
- *                     environment variable MNF_RNVP_FEW_FWD_ROWS overrides both limits
+ *                     resident kernels are as fast from ~100 rows); one row of 800 dims: 86 -> 22 us
  *   mnf_rnvp_bwd      up to MNF_RNVP_FEW_ROWS rows -- what the MNF layers' kl_div runs (one row per call,
  *                     mnf_linear.py:67/84, mnf_conv.py:90-101/127): ONE workgroup owns every parameter gradient, no
  *                     atomics (one row of 800 dims: 150 -> 49 us)

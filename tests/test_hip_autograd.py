@@ -138,11 +138,11 @@ def ahf_grads(amd, sd, dim, h_sizes, parity, inverse, x_cpu, w_y, w_l, mode):
     assert (f._bwd_split_ok() and bool(f._bwd_split_index(torch.device(DEV, 0)))) == (mode == "split")
     x = x_cpu.detach().to(DEV).requires_grad_(True)
     yg, ldg = f.forward(x, inverse=inverse)
-    floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, 0  # (small batches default to the fp32 kernel)
+    floor, amd._dispatch.BWD_SPLIT_MIN_ROWS = amd._dispatch.BWD_SPLIT_MIN_ROWS, 0  # (small batches default to the fp32 kernel)
     try:
         ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
     finally:
-        amd.flows._BWD_SPLIT_MIN_ROWS = floor
+        amd._dispatch.BWD_SPLIT_MIN_ROWS = floor
     return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
 
 
@@ -253,13 +253,13 @@ def test_split_gradient_kernel_seeded_fuzz(amd, O, seed):
     f.to(DEV)
     x = x_cpu.detach().to(DEV).requires_grad_(True)
     yg, ldg = f.forward(x, inverse=inverse)
-    floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, 0
+    floor, amd._dispatch.BWD_SPLIT_MIN_ROWS = amd._dispatch.BWD_SPLIT_MIN_ROWS, 0
     try:
         terms = ([(yg * w_y.to(DEV)).sum()] if which != "ld_only" else []) + \
                 ([(ldg * w_l.to(DEV)).sum()] if which != "y_only" else [])
         sum(terms).backward()
     finally:
-        amd.flows._BWD_SPLIT_MIN_ROWS = floor
+        amd._dispatch.BWD_SPLIT_MIN_ROWS = floor
     what = f"d={dim} hid={hid} rows={rows} parity={parity} inverse={inverse} x*{x_scale} w*{w_scale} g*{g_scale} {which}"
     # (rows < 49,152 never reach the split kernel in production: the few-row draws are here for the ragged tiles)
     ref.check_all({"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}, what,
@@ -502,7 +502,7 @@ def test_nsf_cl_padded_twin_matches_the_layer(amd, O, dim, K, n_h, inverse, monk
     reach the twin."""
     import torch_mnf_amd.flows as fl
 
-    monkeypatch.setattr(fl, "_NSF_PAD_MIN_ROWS", 0)
+    monkeypatch.setattr(fl._dispatch, "NSF_PAD_MIN_ROWS", 0)
     rows = 531
     sd = recipes.nsf_cl_params(4700 + dim + K, dim, K, n_h)
     x_cpu = recipes.gaussian(4800 + dim, rows, dim, scale=1.3)
@@ -755,13 +755,13 @@ def test_affine_run_backward_on_the_split_gradient_kernel(amd, O, flat_home):
             f = amd.AffineHalfFlow(dim, parity=bool(i % 2)); f.load_state_dict(sd); flows.append(f)
         model = amd.NormalizingFlowModel(amd.StandardNormal(dim), flows).to(DEV)
         flat = amd.FlatParameters(model) if flat_home else None
-        floor, amd.flows._BWD_SPLIT_MIN_ROWS = amd.flows._BWD_SPLIT_MIN_ROWS, min_rows
+        floor, amd._dispatch.BWD_SPLIT_MIN_ROWS = amd._dispatch.BWD_SPLIT_MIN_ROWS, min_rows
         try:
             if flat is not None:
                 flat.zero_grad()
             (-model.log_prob(x_cpu.to(DEV)).mean()).backward()
         finally:
-            amd.flows._BWD_SPLIT_MIN_ROWS = floor
+            amd._dispatch.BWD_SPLIT_MIN_ROWS = floor
         return [{n: q.grad.clone() for n, q in f.named_parameters()} for f in flows]
 
     split, fp32 = gpu_grads(0), gpu_grads(1 << 30)

@@ -112,11 +112,11 @@ def test_few_rows_gradient_grid_vs_float64_oracle(amd, O, dim, hid, rows, masked
     _, again = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, *kw)
     for k in got:
         assert torch.equal(got[k], again[k]), k
-    fl._RNVP_BWD_FEW_GRID_OFF = True
+    fl._dispatch.RNVP_BWD_FEW_GRID_OFF = True
     try:
         _, streaming = _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, *kw)
     finally:
-        fl._RNVP_BWD_FEW_GRID_OFF = False
+        fl._dispatch.RNVP_BWD_FEW_GRID_OFF = False
     for k in got:
         assert_close(got[k], streaming[k], 2e-5, f"grid vs streaming gradient kernels: {k}")
     # a second backward pass adds to the first (FlatParameters home: in place)

@@ -223,9 +223,9 @@ def _mfma_gradient_path_at_every_size(monkeypatch):
     exercise the matrix-core kernels at every size."""
     import torch_mnf_amd.flows as fl
 
-    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_ROWS", 0)
-    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_DIM", 0)
-    monkeypatch.setattr(fl, "_RNVP_BWD_FEW_GRID_OFF", True)  # (batches of <= 512 rows otherwise take mnf_rnvp_bwd_few)
+    monkeypatch.setattr(fl._dispatch, "RNVP_BWD_MFMA_MIN_ROWS", 0)
+    monkeypatch.setattr(fl._dispatch, "RNVP_BWD_MFMA_MIN_DIM", 0)
+    monkeypatch.setattr(fl._dispatch, "RNVP_BWD_FEW_GRID_OFF", True)  # (batches of <= 512 rows otherwise take mnf_rnvp_bwd_few)
 
 
 def _rnvp_gpu_grads(amd, sd, dim, hid, z, w_x, w_l, mask=None, seed=None, generic=False):
@@ -558,7 +558,7 @@ def test_rnvp_gradient_pass_with_the_forward_pass_y_streaming_kernels(amd, O, di
     same gradients as with launch A's own first sweep, and the float64 oracle on a slice."""
     import torch_mnf_amd.flows as fl
 
-    monkeypatch.setattr(fl, "_RNVP_BWD_MFMA_MIN_DIM", 0)
+    monkeypatch.setattr(fl._dispatch, "RNVP_BWD_MFMA_MIN_DIM", 0)
     sd = recipes.rnvp_params(8200 + dim, dim, hid)
     z = recipes.gaussian(8201 + dim, rows, dim)
     z[7] *= 3.0e4  # one group through the fp32 bodies
@@ -569,7 +569,7 @@ def test_rnvp_gradient_pass_with_the_forward_pass_y_streaming_kernels(amd, O, di
     mask = recipes.bernoulli_mask(8204 + dim, rows, dim) if masked == "explicit" else probe.mask_for(seed, rows).cpu()
 
     def run(keep):
-        monkeypatch.setattr(fl, "_RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
+        monkeypatch.setattr(fl._dispatch, "RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
         f = amd.RNVP(dim, h_sizes=(hid,))
         f.load_state_dict(sd)
         f.to(DEV)
@@ -611,7 +611,7 @@ def test_rnvp_gradient_pass_with_the_forward_pass_y(amd, O, case, monkeypatch):
     seed = 99
 
     def run(keep):
-        monkeypatch.setattr(fl, "_RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
+        monkeypatch.setattr(fl._dispatch, "RNVP_KEEP_Y_MIN_ROWS", 4096 if keep else 1 << 60)
         f = amd.RNVP(dim, h_sizes=(hid,))
         f.load_state_dict(sd)
         f.to(DEV)

@@ -239,7 +239,7 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows, n_layers, x
     then reads the grad_y rows the split kernel left in its scratch buffer."""
     dim = 64
     flows_mod = amd.flows
-    floor, flows_mod._BWD_SPLIT_MIN_ROWS = flows_mod._BWD_SPLIT_MIN_ROWS, 0
+    floor, flows_mod._dispatch.BWD_SPLIT_MIN_ROWS = flows_mod._dispatch.BWD_SPLIT_MIN_ROWS, 0
     try:
         results = {}
         for fused in (True, False):
@@ -251,12 +251,12 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows, n_layers, x
             model = amd.NormalizingFlowModel(amd.StandardNormal(dim), layers).to(DEV)
             x = (recipes.gaussian(77, rows, dim) * x_scale).to(DEV).requires_grad_(True)
             w = recipes.gaussian(78, rows, 1)[:, 0].to(DEV)  # a row-dependent cotangent, not just 1 / rows
-            env, flows_mod._NO_FUSED_LOGPROB_ENV = flows_mod._NO_FUSED_LOGPROB_ENV, not fused
+            env, flows_mod._dispatch.NO_FUSED_LOGPROB = flows_mod._dispatch.NO_FUSED_LOGPROB, not fused
             try:
                 lp = model.log_prob(x)
                 (-(lp * w).mean()).backward()
             finally:
-                flows_mod._NO_FUSED_LOGPROB_ENV = env
+                flows_mod._dispatch.NO_FUSED_LOGPROB = env
             results[fused] = (lp.detach(), x.grad, {n: p.grad for n, p in model.named_parameters()})
         assert bool(torch.isfinite(results[False][0]).all()) and bool(torch.isfinite(results[False][1]).all())
         assert float((results[True][0] - results[False][0]).abs().max()) <= 2e-5 * float(results[False][0].abs().max())
@@ -264,7 +264,7 @@ def test_log_prob_training_node_matches_the_unfused_route(amd, rows, n_layers, x
         for n, g in results[False][2].items():
             assert normwise_err(results[True][2][n].cpu().numpy(), g.cpu().numpy()) <= 5e-6, n
     finally:
-        flows_mod._BWD_SPLIT_MIN_ROWS = floor
+        flows_mod._dispatch.BWD_SPLIT_MIN_ROWS = floor
 
 
 # ------------------------------------------------------------------------ Glow.inverse + ActNormFlow.inverse, fused

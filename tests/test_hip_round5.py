@@ -51,12 +51,13 @@ def test_deterministic_switch_is_exported_and_off_by_default():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,rows,family", [(50, 4096, "rnvp_bwd_generic"), (50, 32768, "rnvp_bwd_mfma"),
+@pytest.mark.parametrize("dim,rows,family", [(50, 4096, "rnvp_bwd_rt"), (50, 1024, "rnvp_bwd_generic"), (50, 32768, "rnvp_bwd_mfma"),
                                               (100, 4096, "rnvp_bwd_mfma"), (100, 1024, "rnvp_bwd_generic"),
                                               (800, 4096, "rnvp_bwd_mfma"), (800, 128, "rnvp_bwd_few")])
 def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
-    """Narrow RNVP layers take the matrix-core gradient pass only where it measured faster than the any-shape kernel
-    (flows._rnvp_bwd_small, tools/time_rnvp_bwd_small_dim.py); `last_kernel()` tells which one ran.  Both families are
+    """Narrow RNVP layers take the per-shape matrix-core gradient pass only where it measured faster than the one-launch
+    kernels (_dispatch.rnvp_bwd_small): below, the run-time-shaped kernel from 2,048 rows on (_dispatch.RT_MIN_ROWS), the
+    VALU kernel under that; `last_kernel()` tells which one ran.  Both families are
     held to the oracle by tests/test_hip_round3.py::test_rnvp_mfma_gradient_kernels."""
     import torch
 
@@ -82,7 +83,7 @@ def test_padded_nsf_twin_follows_a_fused_optimizer(monkeypatch):
     import torch_mnf_amd.flows as fl
 
     def train(min_rows):
-        monkeypatch.setattr(fl, "_NSF_PAD_MIN_ROWS", min_rows)
+        monkeypatch.setattr(fl._dispatch, "NSF_PAD_MIN_ROWS", min_rows)
         torch.manual_seed(5)
         flows = [amd.NSF_CL(dim=2, K=8, B=3, n_h=16) for _ in range(2)]
         model = amd.NormalizingFlowModel(amd.StandardNormal(2), flows).to("cuda")

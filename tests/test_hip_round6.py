@@ -239,3 +239,98 @@ def test_rnvp_rt_is_the_default_for_wide_hidden_layers(amd, O):
     ref_x, ref_ld = O.rnvp(z, sd, mask)
     assert_close(x, ref_x, RTOL, "x")
     assert_close(ld, ref_ld, RTOL, "ld")
+
+
+# ------------------------------------------------------------------ gradients (the reference trains through all three:
+# tests/test_flows.py:14-99, tests/test_mnf_mnist.py:14-56): the run-time-shaped gradient kernels against the FLOAT64 oracle
+from test_hip_autograd import OracleGrads, cot_loss  # noqa: E402  (the audited gradient budget: GBASE + float64 head-room)
+
+
+def _backward(f, x_cpu, call, w_y, w_l):
+    x = x_cpu.detach().to(DEV).requires_grad_(True)
+    yg, ldg = call(f, x)
+    ((yg * w_y.to(DEV)).sum() + (ldg * w_l.to(DEV)).sum()).backward()
+    return {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+
+
+AHF_BWD_SHAPES = [(64, (24, 24), {}), (64, (64, 64, 64), {}), (10, (16, 40), {}), (2, (24, 24), {}), (512, (24, 24, 24), {}),
+                  (64, (24,), {}), (64, (20, 30, 40, 50), {}), (64, (24, 24), {"scale": False}), (64, (24, 24), {"shift": False}),
+                  (256, (64, 64, 64), {})]
+
+
+@pytest.mark.parametrize("dim,hs,kw", AHF_BWD_SHAPES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_half_rt_gradients(amd, O, dim, hs, kw, inverse):
+    """1..4 hidden layers of widths 4..64, any even dim, NICE / no-shift variants, both directions and parities; a row
+    count with a partial tile and one spanning several row blocks."""
+    for rows, parity in ((300, True), (2100, False)):
+        sd = recipes.affine_half_params(31 + dim, dim, h_sizes=hs, s_last_gain=2.0, **kw)
+        # (seed 232: with test_hip_autograd's 32 + dim, row 211 of the dim = 64, (24, 24) case has a second-layer
+        #  pre-activation of 1.4e-8 -- on the LeakyReLU kink, where two fp32-accurate evaluations may take different slopes)
+        x_cpu = recipes.gaussian(232 + dim, rows, dim)
+        w_y, w_l = recipes.gaussian(33, rows, dim), recipes.gaussian(34, rows, 1)[:, 0]
+        ref = OracleGrads(cot_loss(lambda x, p: O.affine_half(x, p, parity, inverse, **kw), w_y, w_l), x_cpu, sd)
+        f = amd.AffineHalfFlow(dim, parity, h_sizes=hs, **kw)
+        f.load_state_dict(sd)
+        rt(f)
+        got = _backward(f, x_cpu, lambda m, x: m.forward(x, inverse=inverse), w_y, w_l)
+        assert amd.last_kernel() == "ahf_bwd_rt"
+        ref.check_all(got, f"ahf_bwd_rt d={dim} h={hs} {kw} rows={rows} inv={inverse}")
+
+
+NSF_BWD_SHAPES = [(32, 8, 8), (64, 8, 16), (128, 8, 8), (48, 5, 32), (2, 5, 8), (6, 3, 5), (50, 10, 12), (16, 16, 16), (64, 10, 32)]
+
+
+@pytest.mark.parametrize("dim,K,n_h", NSF_BWD_SHAPES)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_nsf_cl_rt_gradients(amd, O, dim, K, n_h, inverse):
+    rows = 700
+    sd = recipes.nsf_cl_params(51 + dim + K, dim, K, n_h)
+    x_cpu = recipes.gaussian(52 + dim, rows, dim, scale=1.4)
+    w_y, w_l = recipes.gaussian(53, rows, dim), recipes.gaussian(54, rows, 1)[:, 0]
+    ref = OracleGrads(cot_loss(lambda x, p: O.nsf_cl(x, p, K, 3.0, inverse), w_y, w_l), x_cpu, sd)
+    f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
+    f.load_state_dict(sd)
+    rt(f)
+    got = _backward(f, x_cpu, lambda m, x: (m.inverse if inverse else m.forward)(x), w_y, w_l)
+    assert amd.last_kernel() == "nsf_bwd_rt"
+    ref.check_all(got, f"nsf_bwd_rt ({dim},{K},{n_h}) inv={inverse}")
+
+
+RNVP_BWD_SHAPES = [(800, (100,)), (50, (100,)), (128, (30,)), (784, (50, 40)), (50, (17,)), (37, (120,)), (256, (64, 64)),
+                   (64, (7, 9, 11))]
+
+
+@pytest.mark.parametrize("dim,hs", RNVP_BWD_SHAPES, ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("seeded", [False, True])
+def test_rnvp_rt_gradients(amd, O, dim, hs, seeded):
+    rows = 700
+    sd = _rnvp_sd(41 + dim, dim, hs)
+    z_cpu = recipes.gaussian(42 + dim, rows, dim)
+    w_y, w_l = recipes.gaussian(43, rows, dim), recipes.gaussian(44, rows, 1)[:, 0]
+    f = amd.RNVP(dim, h_sizes=hs)
+    f.load_state_dict(sd)
+    rt(f)
+    mask = f.mask_for(77, rows).cpu() if seeded else recipes.bernoulli_mask(97, rows, dim)
+    ref = OracleGrads(cot_loss(lambda x, p: O.rnvp(x, p, mask.to(x.dtype)), w_y, w_l), z_cpu, sd)
+    got = _backward(f, z_cpu, (lambda m, z: m.forward(z, seed=77)) if seeded else (lambda m, z: m.forward(z, mask=mask.to(DEV))),
+                    w_y, w_l)
+    assert amd.last_kernel() == "rnvp_bwd_rt"
+    ref.check_all(got, f"rnvp_bwd_rt d={dim} h={hs} seeded={seeded}")
+
+
+def test_rt_gradients_are_the_default_without_a_specialised_kernel(amd):
+    """From 2,048 rows on the autograd path lands on the run-time-shaped gradient kernels by itself for shapes without a
+    per-shape one; below, on the VALU kernels."""
+    cases = [(amd.AffineHalfFlow(64, False, h_sizes=(64, 64, 64)), 64, lambda m, x: m.forward(x), "ahf_bwd_rt", "ahf_bwd_generic"),
+             (amd.NSF_CL(128, K=8, B=3, n_h=8), 128, lambda m, x: m.forward(x), "nsf_bwd_rt", "nsf_bwd_generic"),
+             (amd.RNVP(128, h_sizes=(100,)), 128, lambda m, x: m.forward(x, seed=3), "rnvp_bwd_rt", "rnvp_bwd_generic")]
+    for f, dim, call, fast, slow in cases:
+        f.to(DEV)
+        for rows, want in ((4096, fast), (200, slow)):
+            x = torch.randn(rows, dim, device=DEV, requires_grad=True)
+            f.zero_grad()
+            y, ld = call(f, x)
+            (y.sum() + ld.sum()).backward()
+            assert amd.last_kernel() == want, (type(f).__name__, rows, amd.last_kernel())
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in f.parameters())

@@ -56,7 +56,7 @@ for case in range(n_cases):
         if dim % 8 and n_h > 16:  # (the padded twin exists where the tile gradient kernel does)
             n_h = 16
         rows, inverse = int(rng.integers(1, 3000)), bool(rng.integers(0, 2))
-        amd.flows._NSF_PAD_MIN_ROWS = 0
+        amd._dispatch.NSF_PAD_MIN_ROWS = 0
         f = amd.NSF_CL(dim, K=K, B=3, n_h=n_h)
         f.load_state_dict(recipes.nsf_cl_params(int(rng.integers(1 << 30)), dim, K, n_h))
         f.to(dev)

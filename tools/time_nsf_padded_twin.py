@@ -1,6 +1,6 @@
 """NSF_CL at dims whose halves are not whole float4 groups (the reference's dim = 2): the padded twin on the matrix-core
 kernels against the any-shape kernels, forward (no_grad) and forward + backward, over row counts -- where
-flows._NSF_PAD_MIN_ROWS comes from.  usage: python3 tools/time_nsf_padded_twin.py [dim K n_h]"""
+_dispatch.NSF_PAD_MIN_ROWS comes from.  usage: python3 tools/time_nsf_padded_twin.py [dim K n_h]"""
 import os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +28,7 @@ for rows in (1024, 4096, 8192, 16384, 65536, 262144, 1 << 20):
     xg = x.clone().requires_grad_(True)
     out = []
     for min_rows in (0, 1 << 40):
-        fl._NSF_PAD_MIN_ROWS = min_rows
+        fl._dispatch.NSF_PAD_MIN_ROWS = min_rows
 
         def fwd():
             with torch.no_grad():

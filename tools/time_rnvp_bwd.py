@@ -23,7 +23,7 @@ def step():
 
 
 for generic in (False, True):
-    amd.flows._RNVP_BWD_GENERIC_ENV = generic
+    amd._dispatch.RNVP_BWD_GENERIC = generic
     if generic and rows > 70000:
         continue
     for _ in range(3):

@@ -20,7 +20,7 @@ for dim in (800, 50, 20):
             x, ld = f.forward(z, mask=mask, seed=None if explicit else 5)
             res = []
             for off in (False, True):
-                fl._RNVP_BWD_FEW_GRID_OFF = off
+                fl._dispatch.RNVP_BWD_FEW_GRID_OFF = off
                 for _ in range(3):
                     torch.autograd.grad((x, ld), (z, *f.parameters()), (gx, gl), retain_graph=True)
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,5 +1,5 @@
 """RNVP forward + backward at narrow dims (50 / 64 / 100) over row counts: which gradient kernel family is faster where
-(torch_mnf_amd.flows._rnvp_bwd_small's thresholds).  usage: [MNF_RNVP_BWD_MFMA_MIN_DIM=49] python3 tools/time_rnvp_bwd_small_dim.py"""
+(torch_mnf_amd._dispatch.rnvp_bwd_small's thresholds).  usage: [MNF_RNVP_BWD_MFMA_MIN_DIM=49] python3 tools/time_rnvp_bwd_small_dim.py"""
 import sys, os, torch, warnings
 sys.path.insert(0, os.getcwd())
 import torch_mnf_amd as amd

@@ -15,8 +15,8 @@ for dim in (800, 50):
         gl = torch.randn(rows, device=dev)
         res = {}
         for name, generic in (("mfma", False), ("generic", True)):
-            amd.flows._RNVP_BWD_GENERIC_ENV = generic
-            amd.flows._RNVP_BWD_MFMA_MIN_ROWS = 0; amd.flows._RNVP_BWD_MFMA_MIN_DIM = 0
+            amd._dispatch.RNVP_BWD_GENERIC = generic
+            amd._dispatch.RNVP_BWD_MFMA_MIN_ROWS = 0; amd._dispatch.RNVP_BWD_MFMA_MIN_DIM = 0
             x, ld = f.forward(z, seed=5)
             for _ in range(3):
                 torch.autograd.grad((x, ld), (z, *f.parameters()), (gx, gl), retain_graph=True)

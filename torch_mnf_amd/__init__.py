@@ -7,7 +7,7 @@ not touch the GPU; the library is loaded on first use and its absence is an erro
 
 (The directory is ``torch_mnf_amd``: ``torch-mnf_amd`` is not an importable name.)
 """
-from . import _lib
+from . import _dispatch, _lib
 from ._lib import MnfHipError, deterministic, last_kernel
 from .layers import MNFConv2d, MNFFeedForward, MNFLeNet, MNFLinear
 from .train import FlatParameters, FusedAdam, GraphedStep

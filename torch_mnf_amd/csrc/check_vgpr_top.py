@@ -1,5 +1,5 @@
-"""Build gate for mnf_ahf_bwd_net.hip: its kernels keep their weight-gradient sums in hand-assigned VECTOR registers at the
-top of the file, v[BASE] .. v255, which `amdgpu_num_vgpr(BASE / 2)` reserves (the compiler allocates below BASE only).
+"""Build gate for mnf_nsf_bwd_tile.hip (two-waves-per-SIMD shapes): its kernels keep their weight-gradient sums in hand-assigned
+VECTOR registers at the top of the file, v[BASE] .. v255, which `amdgpu_num_vgpr(BASE / 2)` reserves (the compiler allocates below BASE only).
 
 This script reads the device assembly and fails when, in a kernel named on the command line, an instruction OUTSIDE an
 inline-asm block names a vector register at or above that kernel's BASE, when the kernel's register count is not 256

@@ -12,7 +12,6 @@
 // exchange area), then grad_x of the conditioning half and dW of the first layer input tile by input tile.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "mnf_host.h"
@@ -31,7 +30,7 @@ struct AhfBwdRtArgs {
   const float* gscale_dev;  // power of two that brings the cotangents near 1
   int64_t rows;
   int dim, parity, inverse, has_scale, has_shift;
-  int n_params, vec, dbg;
+  int n_params, vec;
   int cb, bt, block_words, bias_words;  // weight stream (mnf_rt.h Source<false>)
   int ht_tiles, dt_tiles, ct_tiles;     // exchange tiles: hidden vectors of one net | one layer's deltas | a chunk
   NetDesc s_net, t_net;
@@ -237,7 +236,6 @@ extern "C" int mnf_affine_half_bwd_rt(const float* x, const float* y, const floa
   auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec = dim % 8 == 0 && aligned(x) && aligned(grad_x) && (!y || aligned(y)) && (!grad_y || aligned(grad_y));
   constexpr int MT_MAX = 4;
-  a.dbg = getenv("MNF_RT_DBG") ? atoi(getenv("MNF_RT_DBG")) : 0;
   a.cb = 12;
   a.bt = 8;
   a.block_words = 2 * a.cb * rt::kBlockWords;

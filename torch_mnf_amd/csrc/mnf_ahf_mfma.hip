@@ -401,10 +401,10 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
   });
   const int cus = device_cus(current_device());
   blocks = balanced_grid(n_tiles, kAhfWaves, resident, cus);
-  // Non-temporal loads/stores (MNF_AHF_NT=1) are an experiment switch, off by default: in the
+  // Non-temporal loads/stores are a compile-time experiment switch, off: in the
   // isolated microbench they gain 5 % at d = 64, but inside the 9-layer pass (each layer re-reads
   // what the previous one just wrote) they are neutral at d = 64 and cost 13 % at d = 256.
-  static const bool nt = [] { const char* e = getenv("MNF_AHF_NT"); return e && e[0] == '1'; }();
+  constexpr bool nt = false;  // (rebuild with true for the A/B)
   constexpr int kNt = 14;  // loads + stores non-temporal (see the ABL list above the kernel)
   const dim3 grid((unsigned)blocks), block(kAhfWaves * 64);
   tag_kernel("ahf_mfma_fp32");

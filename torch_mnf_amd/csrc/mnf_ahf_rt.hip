@@ -9,7 +9,6 @@
 // tile by tile: s and t of 16 columns, the affine transform of those columns, the row's log|det J| in registers.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "mnf_host.h"
@@ -26,7 +25,6 @@ struct AhfRtArgs {
   int64_t rows;
   int dim, parity, inverse, accumulate, has_scale, has_shift;
   int n_params;
-  int dbg;
   int vec;                   // rows and halves are 16-byte aligned: dwordx4 row accesses
   int cb, bt;                // LDS plan (mnf_rt.h Source)
   int block_words, bias_words;
@@ -181,7 +179,7 @@ __global__ void __launch_bounds__(NW * 64) ahf_rt_kernel(AhfRtArgs a) {
   const float wmax = rt::block_weight_max(a.flat, a.n_params, scratch);
   const int e = rt::weight_exponent(wmax);  // weights are staged as w 2^-e: the largest one just below 2^15
   const float wup = rt::pow2f(e);
-  rt::Source<RESIDENT> src{blocks, bias, a.cb, a.bt, 0, 0, 0, rt::pow2f(-e), a.dbg};
+  rt::Source<RESIDENT> src{blocks, bias, a.cb, a.bt, 0, 0, 0, rt::pow2f(-e), 0};
   if (RESIDENT) {
     ahf_rt_block<MT_MAX, NTL, VEC, true>(a, src, wup, 0);
     __syncthreads();
@@ -285,7 +283,6 @@ int ahf_rt_launch(const float* x, float* y, float* log_det, float* ysq, int accu
   if (!has_shift) a.t_net = a.s_net;
   if (off >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;
   a.n_params = (int)off;
-  a.dbg = getenv("MNF_RT_DBG") ? atoi(getenv("MNF_RT_DBG")) : 0;
   a.vec = dim % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
   int64_t n_blocks, n_bias;
   int max_hidden;

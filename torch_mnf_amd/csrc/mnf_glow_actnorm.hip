@@ -407,7 +407,8 @@ int launch_bwd(const float* u, const float* g, const float* M, const float* s, c
   tag_kernel("glow_actnorm_inv_bwd");
   const int64_t grid = grid_for_tiles(rows, D == 64 ? 1 : MNF_GA_BWD_PER_CU, MNF_GA_BWD_WAVES);
   constexpr int N = D * D + 2 * D + 1;
-  float* partials = (workspace && workspace_floats >= grid * N) ? workspace : nullptr;
+  if (workspace && workspace_floats < grid * N) return MNF_ERR_INVALID_ARG;  // (not: a silent fall-back to the atomic flush)
+  float* partials = workspace;
   hipLaunchKernelGGL((glow_actnorm_inv_bwd_kernel<D, MNF_GA_BWD_WAVES, LP>), dim3((unsigned)grid),
                      dim3(MNF_GA_BWD_WAVES * 64), 0, stream, u, g, M, s, t, grad_u, grad_m, grad_s, grad_t, grad_ld,
                      grad_ld_out, rows, partials);

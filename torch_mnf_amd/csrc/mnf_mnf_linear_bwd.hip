@@ -814,15 +814,9 @@ static void build_mlb_index(int n_in, int n_out, int32_t* idx) {
 
 static int mlb_tiles(int n_out) { return n_out < 1 || n_out > 64 ? 0 : (n_out + 15) / 16; }
 
-// MNF_MNF_LINEAR_BWD_SLAB=split in the environment: the slab launch on the one-slab-per-workgroup kernel (the round-3
-// kernel, kept for same-box A/B runs and as the fallback when the shared kernel's LDS request is refused)
-static bool mlb_slab_split_forced() {
-  static const bool forced = [] {
-    const char* v = getenv("MNF_MNF_LINEAR_BWD_SLAB");
-    return v != nullptr && strcmp(v, "split") == 0;
-  }();
-  return forced;
-}
+// the slab launch on the one-slab-per-workgroup kernel (round 3) is kept as the fallback when the shared kernel's LDS
+// request is refused (return true here for a same-box A/B of the two)
+static bool mlb_slab_split_forced() { return false; }
 
 static int64_t mlb_tiles_end(int64_t rows, int64_t tile_words);
 static int64_t mlb_header_bytes(int64_t rows) {

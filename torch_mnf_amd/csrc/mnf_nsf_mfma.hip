@@ -685,8 +685,6 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
   const int64_t n_tiles = (rows + 15) / 16;
   int64_t blocks = (n_tiles + kNsfWaves - 1) / kNsfWaves;
   auto resident_of = [](auto kernel, int dev) {
-    if (const char* e = getenv("MNF_NSF_BLOCKS_PER_CU"))  // experiment switch
-      if (atoi(e) > 0) return atoi(e) * device_cus(dev);
     return resident_by_occupancy(kernel, kNsfWaves * 64, dev, 2);
   };
   static DeviceMemo memo_f32, memo_split;

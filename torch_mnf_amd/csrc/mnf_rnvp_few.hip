@@ -449,14 +449,9 @@ bool rnvp_few_ok(int64_t rows, int dim, int n_hidden, const int* hidden) {
 // forward: a workgroup per two rows.  With an explicit mask tensor up to MNF_RNVP_FEW_FWD_ROWS rows (the streaming
 // kernel for explicit masks takes 103 us at 128 rows of 800 dims, this one 35 up to 512 rows); with the in-kernel mask
 // the register-resident kernels take over at ~100 rows (31 us at 128): up to 64 rows.  (tools/time_rnvp_fwd_rows.py;
-// the environment variable MNF_RNVP_FEW_FWD_ROWS overrides both limits.)
+// include/mnf_hip.h MNF_RNVP_FEW_FWD_ROWS.)
 bool rnvp_few_fwd_ok(int64_t rows, int dim, int n_hidden, const int* hidden, bool explicit_mask) {
-  static const int64_t forced = [] {
-    const char* e = getenv("MNF_RNVP_FEW_FWD_ROWS");
-    const long v = e ? atol(e) : 0;
-    return (int64_t)(v > 0 ? v : 0);
-  }();
-  const int64_t max_rows = forced ? forced : explicit_mask ? kFewFwdRows : kFewFwdRowsSeeded;
+  const int64_t max_rows = explicit_mask ? kFewFwdRows : kFewFwdRowsSeeded;
   return few_shape_ok(rows, max_rows, dim, n_hidden, hidden);
 }
 
@@ -490,14 +485,9 @@ int rnvp_few_fwd_launch(const float* z, const float* mask, uint64_t seed, float*
 
 static inline int64_t few_n_par(int dim, int hid) { return 3 * (int64_t)hid * dim + hid + 2 * (int64_t)dim; }
 
-// gradients as a grid: up to MNF_RNVP_FEW_BWD_ROWS rows (environment variable of that name overrides)
+// gradients as a grid: up to MNF_RNVP_FEW_BWD_ROWS rows (include/mnf_hip.h)
 bool rnvp_few_bwd_grid_ok(int64_t rows, int dim, int n_hidden, const int* hidden) {
-  static const int64_t max_rows = [] {
-    const char* e = getenv("MNF_RNVP_FEW_BWD_ROWS");
-    const long v = e ? atol(e) : 0;
-    return (int64_t)(v > 0 ? v : kFewBwdRows);
-  }();
-  return rows > kFewRows && few_shape_ok(rows, max_rows, dim, n_hidden, hidden);
+  return rows > kFewRows && few_shape_ok(rows, kFewBwdRows, dim, n_hidden, hidden);
 }
 
 // partial == nullptr: one workgroup (rows <= 2) adding to grad_flat; else a workgroup per two rows writing its copy

@@ -669,10 +669,7 @@ static int launch_rnvp_split_occ(const float* z, const float* mask, float* x, fl
       [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, false, RAG, OCC>, kRnvpWaves * 64, dev, 1); });
   const int resident_seed = memo_seed.get(
       [](int dev) { return resident_by_occupancy(rnvp_split_kernel<HN, true, RAG, OCC>, kRnvpWaves * 64, dev, 1); });
-  // experiment switch: MNF_RNVP_BLOCKS_PER_CU=n caps the persistent grid at n workgroups per CU
-  static const int cap = [] { const char* e = getenv("MNF_RNVP_BLOCKS_PER_CU"); return e ? atoi(e) * 256 : 1 << 30; }();
-  const int resident0 = mask ? resident_mask : resident_seed;
-  const int resident = resident0 < cap ? resident0 : cap;
+  const int resident = mask ? resident_mask : resident_seed;
   const int64_t blocks = n_groups < resident ? n_groups : resident;
   tag_kernel("rnvp_split");
   if (mask)
@@ -689,8 +686,7 @@ static int launch_rnvp_split(const float* z, const float* mask, float* x, float*
                              const uint32_t* simage, const float* image, int64_t rows, int dim, uint64_t seed,
                              const float* q0_mean, const float* q0_log_var, int dm, int vec, hipStream_t stream,
                              float* y_out = nullptr) {
-  // MNF_RNVP_SPLIT_OCC=2|4 forces one register target for rows of whole 16-dim groups (A/B measurements)
-  static const int forced = [] { const char* e = getenv("MNF_RNVP_SPLIT_OCC"); return e ? atoi(e) : 0; }();
+  constexpr int forced = 0;  // (2 | 4: one register target for rows of whole 16-dim groups, for A/B measurements)
   if (dim <= 64 && !forced && !y_out) {
     const int rc = launch_rnvp_narrow<HN>(z, mask, x, log_det, accumulate, simage, image, rows, dim, seed, q0_mean,
                                           q0_log_var, dm, vec, stream);

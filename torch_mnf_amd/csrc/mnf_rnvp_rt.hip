@@ -9,7 +9,6 @@
 // walked 16 output dims at a time: shift and scale of the tile, the gate, x, the row's log|det J| in registers.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "mnf_host.h"

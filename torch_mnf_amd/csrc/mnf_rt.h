@@ -230,7 +230,7 @@ struct Source {
   int cb, bt, cur;
   int slot, btile;    // running position in the resident image
   float wdown;
-  int dbg;
+  int spare;
 
   // streaming mode, chunks built from several parts: stage into cur_blocks() / cur_bias(), then commit()
   __device__ __forceinline__ uint32_t* cur_blocks() const { return blocks + cur * cb * kBlockWords; }
@@ -258,7 +258,7 @@ struct Source {
     } else {
       uint32_t* a = blocks + cur * cb * kBlockWords;
       float* b = bias + cur * bt * 16;
-      if (!(dbg & 1)) stage_blocks(a, n_blocks, fetch, wdown);
+      stage_blocks(a, n_blocks, fetch, wdown);
       stage_bias(b, n_bias, bias_fn);
       lds_barrier();  // (the other buffer is free once every wave is here: see the header comment)
       cur ^= 1;

@@ -35,43 +35,9 @@ from ._lib import MnfHipError
 
 # MNF_FP32_MFMA=1: run the fp32 MFMA kernels instead of the split (f16 hi + lo) ones, for A/B measurements
 _FP32_MFMA_ENV = os.environ.get("MNF_FP32_MFMA", "0") == "1"
-# MNF_BWD_FP32=1: AffineHalfFlow gradients on the fp32-MFMA kernel instead of the split one, for A/B measurements
-_BWD_FP32_ENV = os.environ.get("MNF_BWD_FP32", "0") == "1"
-# ... and below this many rows anyway: the split kernel needs three small launches more per backward pass (gradient
-# scale, operand repack, fix-up list) and only pays them back from ~32k rows on (4,096 rows: 0.84 vs 0.65 ms per
-# 9-layer training step; 65,536: 0.89 vs 0.95; 2^20: 4.7 vs 6.5)
-# NSF_CL gradient kernel: "tile" (default: mnf_nsf_bwd_tile.hip where the shape has one) or "generic"
-_NSF_BWD_KERNEL = os.environ.get("MNF_NSF_BWD_KERNEL", "tile")
-# NSF_CL with halves that are not whole float4 groups (dim = 2, 6, 10, ...) runs the matrix-core kernels on a padded twin
-# from this many rows on (NSF_CL._run_padded; tools/time_nsf_padded_twin.py, dim = 2, K = 8, n_h = 16, forward + backward,
-# twin vs any-shape kernels: 690 vs 416 us at 16,384 rows, 705 vs 1,119 at 65,536, 2.07 vs 15.3 ms at 2^20; forward
-# alone 68 vs 54 us, 84 vs 99, 473 vs 1,082)
-_NSF_PAD_MIN_ROWS = int(os.environ.get("MNF_NSF_PAD_MIN_ROWS", "49152"))
-_BWD_SPLIT_MIN_ROWS = int(os.environ.get("MNF_BWD_SPLIT_MIN_ROWS", "49152"))  # (crossover measured: fp32 0.65 vs 0.72 ms per step at 32,768 rows, 0.75 vs 0.73 at 65,536)
-# MNF_RNVP_BWD_GENERIC=1: RNVP gradients on the generic kernel instead of the matrix-core pair, for A/B measurements
-_RNVP_BWD_GENERIC_ENV = os.environ.get("MNF_RNVP_BWD_GENERIC", "0") == "1"
-# the matrix-core RNVP gradient pass from this many rows / dims on (d = 800: 227 vs 252 us at 128 rows, 284 vs 837 us at
-# 2,048).  Narrower layers (tools/time_rnvp_bwd_small_dim.py, forward + backward, matrix-core vs any-shape kernel): d = 100
-# 326 vs 403 us at 4,096 rows; d = 50 / 64 level at 16,384 rows (471 / 456 vs 390 / 451 us), 457 vs 562 / 659 at 32,768,
-# 719 / 671 vs 2,012 / 3,390 at 262,144
-_RNVP_KEEP_Y_MIN_ROWS = int(os.environ.get("MNF_RNVP_KEEP_Y_MIN_ROWS", "4096"))  # (0 rows of y below: nothing to gain)
-_RNVP_BWD_FEW_GRID_OFF = False  # (tests: the matrix-core / generic gradient kernels at every row count)
-_RNVP_BWD_MFMA_MIN_ROWS = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_ROWS", "64"))
-_RNVP_BWD_MFMA_MIN_DIM = int(os.environ.get("MNF_RNVP_BWD_MFMA_MIN_DIM", "128"))
-_RNVP_BWD_MFMA_MID_DIM, _RNVP_BWD_MFMA_MID_ROWS, _RNVP_BWD_MFMA_ANY_DIM_ROWS = 96, 4096, 24576
-
-
-def _rnvp_bwd_small(rows: int, dim: int) -> bool:
-    """True where the any-shape RNVP gradient kernel is the faster one (few rows, or a narrow layer at a moderate batch)."""
-    if rows < _RNVP_BWD_MFMA_MIN_ROWS:
-        return True
-    if dim >= _RNVP_BWD_MFMA_MIN_DIM or rows >= _RNVP_BWD_MFMA_ANY_DIM_ROWS:
-        return False
-    return not (dim >= _RNVP_BWD_MFMA_MID_DIM and rows >= _RNVP_BWD_MFMA_MID_ROWS)
+# (every shape / row-count threshold of this module lives in _dispatch.py)
 # MNF_NO_RUN_FUSION=1: NormalizingFlow launches every layer separately (per-layer measurements)
 _NO_RUN_FUSION_ENV = os.environ.get("MNF_NO_RUN_FUSION", "0") == "1"
-# MNF_NO_FUSED_LOGPROB=1: A/B switch -- the log-prob epilogue stays its own kernel after an affine run
-_NO_FUSED_LOGPROB_ENV = os.environ.get("MNF_NO_FUSED_LOGPROB", "") not in ("", "0")
 
 __all__ = [
     "MLP", "AffineHalfFlow", "NSF_CL", "NSF_AR", "RNVP", "AffineConstantFlow", "ActNormFlow", "Glow",
@@ -423,7 +389,7 @@ class _AffineHalfFn(torch.autograd.Function):
         grad_flat = torch.zeros_like(flat)
         has = flat.numel() > 0
         bwd = (m._bwd_split_image(x.device, flat)
-               if has and not m.force_generic and x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None)
+               if has and not m.force_generic and x.shape[0] >= _dispatch.BWD_SPLIT_MIN_ROWS else None)
         scale = cold = work = None
         if bwd is not None:
             scale = _grad_scale(gy, gl, x.shape[0], m.dim, x.device)
@@ -471,7 +437,7 @@ class _NsfFn(torch.autograd.Function):
         # 64, hidden width <= 16, K in {5, 8} (10 up to dim 32) --, followed by its fp32 fix-up pass over the tiles it handed back; else
         # the generic kernel
         table = None
-        if not (m.force_generic or m.force_fp32_mfma or _FP32_MFMA_ENV or _NSF_BWD_KERNEL == "generic"
+        if not (m.force_generic or m.force_fp32_mfma or _FP32_MFMA_ENV or _dispatch.NSF_BWD_KERNEL == "generic"
                 or rows * m.dim >= (1 << 31)):
             table = m._bwd_tile_tables(x.device)
         marks = None
@@ -501,7 +467,7 @@ class _NsfFn(torch.autograd.Function):
                     x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
                     cold.data_ptr(), cap, _stream()))
                 return grad_x, grad_flat, None, None
-        if m.force_generic != 1 and _NSF_BWD_KERNEL != "generic" and (rows >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+        if m.force_generic != 1 and _dispatch.NSF_BWD_KERNEL != "generic" and (rows >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
             # no per-shape gradient kernel: the run-time-shaped matrix-core one (any dim, K <= 16, hidden widths 4..64)
             scale = _grad_scale(gy, gl, rows, m.dim, x.device)
             rc = lib.mnf_nsf_cl_bwd_rt(
@@ -512,7 +478,7 @@ class _NsfFn(torch.autograd.Function):
                 return grad_x, grad_flat, None, None
         _lib.check("mnf_nsf_cl_bwd", lib.mnf_nsf_cl_bwd(
             x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args, _stream()))
-        if not m.force_generic and _NSF_BWD_KERNEL != "generic" and not m._pad_half():
+        if not m.force_generic and _dispatch.NSF_BWD_KERNEL != "generic" and not m._pad_half():
             _lib.note_generic("NSF_CL.backward", rows, f"dim={m.dim}, K={m.K}, hidden={m.h_sizes}")
         return grad_x, grad_flat, None, None
 
@@ -533,8 +499,8 @@ class _RnvpFn(torch.autograd.Function):
         # a large batch: the split forward kernels can keep y = net(mask * z) (64 floats per row) for the matrix-core
         # gradient pass, whose first launch then skips its own sweep over z
         y, wrote = None, ctypes.c_int(0)
-        if (not few and z.shape[0] >= _RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
-                and not _RNVP_BWD_GENERIC_ENV and not _rnvp_bwd_small(z.shape[0], module.dim)):
+        if (not few and z.shape[0] >= _dispatch.RNVP_KEEP_Y_MIN_ROWS and not module.force_generic
+                and not _dispatch.RNVP_BWD_GENERIC and not _dispatch.rnvp_bwd_small(z.shape[0], module.dim)):
             per_row = lib.mnf_rnvp_y_floats_per_row(len(module.h_sizes), module._hid)
             if per_row > 0:
                 y = torch.empty(z.shape[0], per_row, dtype=torch.float32, device=z.device)
@@ -569,7 +535,7 @@ class _RnvpFn(torch.autograd.Function):
         #  launches, the first a single workgroup's sweep over all dims: tools/time_rnvp_small.py)
         # a batch of a few hundred rows (the reference trains at 128): the latency kernel as a grid, a workgroup per
         # two rows writing its own copy of the parameter gradients, then one reduction launch
-        if not (m.force_generic or _RNVP_BWD_GENERIC_ENV or _RNVP_BWD_FEW_GRID_OFF):
+        if not (m.force_generic or _dispatch.RNVP_BWD_GENERIC or _dispatch.RNVP_BWD_FEW_GRID_OFF):
             n_ws = lib.mnf_rnvp_bwd_few_workspace_floats(z.shape[0], m.dim, len(m.h_sizes), m._hid)
             if n_ws > 0:
                 ws = torch.empty(n_ws, dtype=torch.float32, device=z.device)
@@ -577,8 +543,8 @@ class _RnvpFn(torch.autograd.Function):
                     z.data_ptr(), _ptr(ctx.mask), ctx.seed, _ptr(gx), _ptr(gl), grad_z.data_ptr(), grad_flat.data_ptr(),
                     flat.data_ptr(), ws.data_ptr(), z.shape[0], m.dim, len(m.h_sizes), m._hid, _stream()))
                 return grad_z, ret_flat, None, None, None, None
-        small = _rnvp_bwd_small(z.shape[0], m.dim)
-        bwd = None if (m.force_generic or _RNVP_BWD_GENERIC_ENV or small) else m._bwd_image(z.device, flat)
+        small = _dispatch.rnvp_bwd_small(z.shape[0], m.dim)
+        bwd = None if (m.force_generic or _dispatch.RNVP_BWD_GENERIC or small) else m._bwd_image(z.device, flat)
         split = m._split_image(z.device) if bwd is not None else None
         if bwd is not None and split is not None:
             rows = z.shape[0]
@@ -605,7 +571,7 @@ class _RnvpFn(torch.autograd.Function):
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_rnvp_bwd_mfma", rc)
                 return grad_z, ret_flat, None, None, None, None
-        if m.force_generic != 1 and not _RNVP_BWD_GENERIC_ENV and (z.shape[0] >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+        if m.force_generic != 1 and not _dispatch.RNVP_BWD_GENERIC and (z.shape[0] >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
             # no per-shape gradient kernel: the run-time-shaped matrix-core one (1..4 conditioner layers of widths 4..128)
             scale = _grad_scale(gx, gl, z.shape[0], m.dim, z.device)
             rc = lib.mnf_rnvp_bwd_rt(
@@ -707,16 +673,18 @@ def _linear_rows_table(lib, dim: int, device) -> Tensor | None:
 
 _PAIR_FUSION_DIMS = (16, 32, 64)  # mnf_glow_actnorm_inv / _bwd (csrc/mnf_glow_actnorm.hip)
 _NO_PAIR_FUSION_ENV = os.environ.get("MNF_NO_PAIR_FUSION", "0") == "1"
-# MNF_DETERMINISTIC=1: gradient sums through fixed-order two-stage reductions instead of float atomics where a kernel has
-# both (the reference's loop repeats bit for bit under torch.manual_seed(0), tests/test_flows.py:11).  The AffineHalfFlow
-# and NSF_CL gradient kernels always reduce in a fixed order; this switch adds the [Glow, ActNorm] pair's.  (RNVP /
-# MNFLinear gradient launches still add with atomics: INTEGRATION.md.)
-_DETERMINISTIC = os.environ.get("MNF_DETERMINISTIC", "0") == "1"
+# MNF_DETERMINISTIC=1 (read once by the LIBRARY: _lib.deterministic() is the one source of truth): gradient sums through
+# fixed-order two-stage reductions instead of float atomics where a kernel has both (the reference's loop repeats bit for
+# bit under torch.manual_seed(0), tests/test_flows.py:11).  The per-shape AffineHalfFlow and NSF_CL gradient kernels
+# reduce in a fixed order in every mode; the switch adds the RNVP, MNFLinear, sample_z and [Glow, ActNorm] launches, and
+# keeps shapes without a per-shape kernel off the run-time-shaped gradient kernels (atomic flushes).  What still adds
+# atomically then: rows that take an fp32 fix-up pass (operands beyond the split range) and the VALU any-shape gradient
+# kernels.
 
 
 def _pair_bwd_workspace(rows: int, dim: int, device):
     """Block sums of the pair's gradient launch (deterministic mode), else None."""
-    if not _DETERMINISTIC:
+    if not _lib.deterministic():
         return None
     n = _lib.load().mnf_glow_actnorm_inv_bwd_workspace(rows, dim)
     return torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
@@ -844,7 +812,7 @@ class _AffineRunFn(torch.autograd.Function):
         g = grads[n - 1]
         # split gradient kernel: every layer's backward image from one launch, one gradient scale for the run (the
         # magnitude changes by e^s per layer: far inside the split range), one fix-up list per layer
-        bwd = run.bwd_images(x.device, flat) if x.shape[0] >= _BWD_SPLIT_MIN_ROWS else None
+        bwd = run.bwd_images(x.device, flat) if x.shape[0] >= _dispatch.BWD_SPLIT_MIN_ROWS else None
         scale = cold = work = None
         if bwd is not None:
             first = next((t for t in reversed(grads[:n]) if t is not None), None)
@@ -1064,7 +1032,7 @@ class AffineHalfFlow(_TwoWayFlow):
         return cached
 
     def _bwd_split_ok(self) -> bool:
-        return not (self.force_fp32_mfma or _FP32_MFMA_ENV or _BWD_FP32_ENV or self.force_generic or not self._split_ok)
+        return not (self.force_fp32_mfma or _FP32_MFMA_ENV or _dispatch.BWD_FP32 or self.force_generic or not self._split_ok)
 
     def _bwd_split_image(self, device, flat: Tensor) -> Tensor | None:
         """The split gradient kernel's operand image for the parameters in ``flat`` (packed per call: the weights
@@ -1217,7 +1185,7 @@ class NSF_CL(_TwoWayFlow):
     # zero-padded to match (a padded column meets zero weights; a padded element has no parameters), and the padded
     # columns of x set beyond the tail bound, where the spline is the identity with log-derivative 0
     # (spline_flow.py:72-85) -- so y, log_det and every gradient of the real columns and parameters are what the layer
-    # itself would give, and autograd's own pad / slice nodes carry the gradients back.  From _NSF_PAD_MIN_ROWS rows on
+    # itself would give, and autograd's own pad / slice nodes carry the gradients back.  From _dispatch.NSF_PAD_MIN_ROWS rows on
     # (below that the extra pad / slice launches cost more than the any-shape kernels do).
     def _pad_half(self) -> int:
         """Padded half width of the twin (0: none -- the halves are whole groups already, or no kernel takes the twin)."""
@@ -1282,7 +1250,7 @@ class NSF_CL(_TwoWayFlow):
 
     def _run(self, x, inverse, accum):
         if (isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.shape[1] == self.dim and x.dtype == torch.float32
-                and x.shape[0] >= _NSF_PAD_MIN_ROWS and not self.force_generic):
+                and x.shape[0] >= _dispatch.NSF_PAD_MIN_ROWS and not self.force_generic):
             hp = self._pad_half()
             if hp:
                 return self._run_padded(x, inverse, accum, hp)
@@ -2249,7 +2217,10 @@ class _AffineRun:
     def launch_grad(self, x: Tensor, inverse: bool, with_lp: bool = False):
         """(outputs in application order, log_det) with the autograd link; None when the shape has no kernels.
         ``with_lp``: log p under a standard-normal base instead, as ONE tensor (see _AffineRunFn.forward)."""
-        if with_lp and getattr(self, "_lp_unsupported", None) == (x.shape[1], x.device):
+        # (a refusal of the fused log-prob form is remembered per CALL shape: it can depend on the row count and on the
+        #  batch's alignment, not only on the layer -- one misaligned batch must not send every later call the slow way)
+        lp_key = (x.shape[0], x.shape[1], x.device, x.data_ptr() % 16)
+        if with_lp and lp_key in getattr(self, "_lp_unsupported", ()):
             return None
         self._home_now = self.flat_home()
         if self._home_now is not None:
@@ -2264,7 +2235,11 @@ class _AffineRun:
             if err.code != _lib.MNF_ERR_UNSUPPORTED:
                 raise
             if with_lp:  # (only the epilogue may be missing: the caller takes the unfused route -- and does not ask
-                self._lp_unsupported = (x.shape[1], x.device)  # again: the refusal comes AFTER a whole stack launch)
+                refused = set(getattr(self, "_lp_unsupported", ()))  # again: the refusal comes AFTER a whole stack launch)
+                if len(refused) > 64:
+                    refused.clear()
+                refused.add(lp_key)
+                self._lp_unsupported = refused
                 return None
             self._unsupported = True
             return None
@@ -2294,7 +2269,7 @@ class _AffineRun:
                 f0.dim, int(inverse), len(f0.h_sizes), f0._hid, _stream())
 
         self.logprob_fused = (logprob is not None and splits is not None and not self._no_fused_logprob
-                              and not _NO_FUSED_LOGPROB_ENV)
+                              and not _dispatch.NO_FUSED_LOGPROB)
         rc = go(logprob[0], logprob[1], None) if self.logprob_fused else go(None, None, sqnorm)
         if rc == _lib.MNF_ERR_UNSUPPORTED and self.logprob_fused:  # shape runs on the fp32 stack kernel: no epilogue
             self._no_fused_logprob, self.logprob_fused = True, False
@@ -2561,8 +2536,8 @@ class NormalizingFlow(nn.Module):
                 else:
                     sq = None
                     outs = run.launch(x, inverse, log_det, True, keep=True,
-                                      logprob=want_logprob if (last and not _NO_FUSED_LOGPROB_ENV) else None)
-                    if outs is not None and last and want_logprob is not None and not _NO_FUSED_LOGPROB_ENV:
+                                      logprob=want_logprob if (last and not _dispatch.NO_FUSED_LOGPROB) else None)
+                    if outs is not None and last and want_logprob is not None and not _dispatch.NO_FUSED_LOGPROB:
                         self._logprob_done = True
                 if outs is not None:
                     self._last_sqnorm = sq
@@ -2573,7 +2548,7 @@ class NormalizingFlow(nn.Module):
             if (outs is None and last_only and inverse and i + 1 < n and type(flow) is Glow
                     and type(order[i + 1]) is ActNormFlow and _pair_fusable(flow, order[i + 1], x)):
                 # Glow.inverse + ActNormFlow.inverse of a training pass: one launch each way (csrc/mnf_glow_actnorm.hip)
-                if (lp_tail and i + 2 == n and not _NO_FUSED_LOGPROB_ENV and isinstance(log_det, Tensor)
+                if (lp_tail and i + 2 == n and not _dispatch.NO_FUSED_LOGPROB and isinstance(log_det, Tensor)
                         and log_det.shape == (x.shape[0],) and log_det.dtype == torch.float32):
                     self._lp_node = _glow_actnorm_inverse(flow, order[i + 1], x, log_det)
                     x = None
@@ -2719,9 +2694,9 @@ class NormalizingFlowModel(NormalizingFlow):
         base the epilogue kernel also produces the fp64 sum over rows."""
         std = isinstance(self.base, StandardNormal)
         lp = total = None
-        if (std and torch.is_grad_enabled() and not _NO_FUSED_LOGPROB_ENV and not _NO_RUN_FUSION_ENV
+        if (std and torch.is_grad_enabled() and not _dispatch.NO_FUSED_LOGPROB and not _NO_RUN_FUSION_ENV
                 and self.fuse_affine_runs and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2
-                and x.shape[0] >= _BWD_SPLIT_MIN_ROWS and x.dtype == torch.float32 and self.layer_events is None):
+                and x.shape[0] >= _dispatch.BWD_SPLIT_MIN_ROWS and x.dtype == torch.float32 and self.layer_events is None):
             # training, the whole model ONE run of AffineHalfFlow layers: one autograd node from x to log p -- the
             # stack kernel's epilogue writes log p, the gradient kernel of the last layer forms -z g itself
             runs = self._affine_runs()
