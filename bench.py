@@ -163,6 +163,30 @@ def apply_valu_convention(r: dict, workload: str, avg_kernel_s: float) -> None:
                                  "the same SIMD cycles (how long the vector units were occupied, profiled run)"})
 
 
+def apply_transcendental_floor(r: dict, workload: str, rows: int, ms_per_step: float) -> None:
+    """The floor no instruction diet of the plain arithmetic can go below: the transcendental wave-instructions of a step
+    (v_exp / v_log / v_rcp / v_sqrt per spline element, counted from the kernels' device assembly by
+    tools/transcendental_count.py and committed as profiles/rN/<workload>_transcendentals.json) at the guide's issue cost
+    of 8 cycles each on 1,024 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost')."""
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()),
+                    key=lambda d: -int(d[1:])) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    for rd in rounds:
+        path = os.path.join(ROOT, "profiles", rd, f"{workload}_transcendentals.json")
+        try:
+            with open(path) as fh:
+                t = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        wave_instr = t["per_element_per_step_layer"] * t["elements_per_row"] * t["layers_per_step"] * rows / 64.0
+        floor_ms = wave_instr * t["cycles_per_transcendental"] / 1024.0 / 2.4e9 * 1e3
+        r.update({"transcendental_floor_ms": floor_ms, "frac_of_transcendental_floor": floor_ms / ms_per_step,
+                  "transcendentals_per_element": t["per_element_per_step_layer"],
+                  "plain_valu_per_element": t.get("valu_per_element"),
+                  "transcendental_source": f"profiles/{rd}/{workload}_transcendentals.json ({t.get('what', '')}); floor = count x "
+                                           "elements x rows / 64 lanes x 8 cycles / 1,024 SIMDs / 2.4 GHz, against ms_per_step"})
+        return
+
+
 def physical(traffic, avg_kernel_s: float) -> dict:
     """The HBM fraction by bytes that actually cross the interface (PMC), next to the SURVEY 8(d) algorithmic one."""
     if not traffic:
@@ -829,6 +853,7 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
                      "launches_timed": len(kern_ms), "launches_per_step": 3},
     }
     apply_valu_convention(out["roofline"], "c3t", avg_s)
+    apply_transcendental_floor(out["roofline"], "c3t", rows, out["ms_per_step"])
     if not args.no_cpu_baseline:
         from oracle import flow_oracle as O
 
@@ -1229,6 +1254,7 @@ def main() -> None:
             # ~2,300 vector instructions per 16 rows per layer): the roofline it is priced against is the vector
             # ISSUE rate; the HBM figures stay in the object under their own names.
             apply_valu_convention(out["roofline"], "c3", avg_kernel_s)
+            apply_transcendental_floor(out["roofline"], "c3", rows, out["ms_per_step"])
         if world == 1 and not args.no_cpu_baseline:
             info, cpu_mean, n = cpu_baseline(layers, dim, x)
             with torch.no_grad():

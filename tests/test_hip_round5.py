@@ -76,7 +76,7 @@ def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
 def test_padded_nsf_twin_follows_a_fused_optimizer(monkeypatch):
     """FusedAdam rewrites the flat parameter buffer through its raw pointer (no version bump): the padded twin of an
     NSF_CL(dim=2) -- the reference's shape, tests/test_flows.py:89-99 -- must pick the new values up (its refresh key
-    includes the buffer's generation).  Three Adam steps with the twin against three with the any-shape kernels."""
+    includes the buffer's generation).  Three Adam steps with the twin against three with the run-time-shaped kernels."""
     import torch
 
     import torch_mnf_amd as amd
@@ -100,7 +100,7 @@ def test_padded_nsf_twin_follows_a_fused_optimizer(monkeypatch):
 
     l_twin, p_twin, k_twin = train(0)
     l_any, p_any, k_any = train(1 << 40)
-    assert k_twin == "nsf_bwd_tile" and "generic" in k_any, (k_twin, k_any)
+    assert k_twin == "nsf_bwd_tile" and k_any == "nsf_bwd_rt", (k_twin, k_any)
     assert l_twin[2] < l_twin[0]
     for a, b in zip(l_twin, l_any):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_twin, l_any)

@@ -2,7 +2,7 @@
 on (torch_mnf_amd.last_kernel()) and what a row costs there, forward (no_grad) and forward + backward, over the shapes a
 user of the reference might pick.  The specialised kernels are narrow templates; this table is where their edges are.
 
-usage: python3 tools/coverage_map.py [rows] > profiles/r5/coverage_map.txt"""
+usage: python3 tools/coverage_map.py [rows] > profiles/r6/coverage_map.txt"""
 import os
 import sys
 import warnings
@@ -30,6 +30,27 @@ def timed(fn, reps=3):
         torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b))
     return best * 1e6 / ROWS  # ns per row
+
+
+def probe_once(layer, dim, call):
+    """(forward kernel, ns/row, gradient kernel, fwd+bwd ns/row) of one layer in its current force_generic state."""
+    layer.to(DEV)
+    x = torch.randn(ROWS, dim, device=DEV)
+    with torch.no_grad():
+        tf = timed(lambda: call(layer, x))
+    kf = amd.last_kernel()
+    xg = x.clone().requires_grad_(True)
+
+    def train():
+        xg.grad = None
+        y, ld = call(layer, xg)
+        (y.sum() + ld.sum()).backward()
+
+    tb = timed(train)
+    kb = amd.last_kernel()
+    for p in layer.parameters():
+        p.grad = None
+    return kf, tf, kb, tb
 
 
 def probe(layer, dim, call):
