@@ -47,8 +47,9 @@ def test_built_assembly_passes_the_gate():
     # the NSF_CL tile gradient kernel keeps its sums in hand-assigned registers: the Makefile's limits, checked here too
     tile = os.path.join(CSRC, "mnf_nsf_bwd_tile.gfx950.s")
     if os.path.exists(tile):
-        import check_vgpr_top
-
+        spec_top = importlib.util.spec_from_file_location("check_vgpr_top", os.path.join(CSRC, "check_vgpr_top.py"))
+        check_vgpr_top = importlib.util.module_from_spec(spec_top)
+        spec_top.loader.exec_module(check_vgpr_top)
         assert check_vgpr_top.main(tile, 100, {"kernel_16_8_8": 144, "kernel_16_8_5": 176, "kernel_16_16_5": 172}) == 0
         assert check_agpr.main(tile, 0, {"kernel_32_8_8": 44, "kernel_32_8_5": 108, "kernel_32_16_8": 32, "kernel_32_16_5": 100,
                                          "kernel_16_8_10": 112, "kernel_16_16_10": 104, "kernel_16_16_8": 140}) == 0

@@ -142,7 +142,7 @@ def test_affine_half_rt_range(amd, O, case):
 
 # ------------------------------------------------------------------ NSF_CL (reference: spline_flow.py:241-285)
 NSF_SHAPES = [(32, 8, 8), (64, 8, 16), (128, 8, 8), (128, 5, 32), (2, 5, 8), (6, 3, 5), (50, 10, 12), (16, 16, 64),
-              (200, 4, 16), (48, 10, 32), (128, 10, 32), (64, 2, 8), (24, 13, 20)]
+              (200, 4, 16), (48, 10, 32), (128, 10, 32), (64, 2, 8), (24, 13, 20), (32, 8, 32), (32, 5, 32), (16, 8, 24)]
 
 
 @pytest.mark.parametrize("dim,K,n_h", NSF_SHAPES)

@@ -601,6 +601,11 @@ static int launch_bwd(const float* x, const float* grad_y, const float* grad_ld,
   if (blocks > cus) blocks = cus;  // one persistent workgroup per CU (LDS bound)
   // (a fix-up pass gets the full grid too: the list is usually empty and every workgroup returns at once, but it may
   //  also name every tile)
+  // MNF_DETERMINISTIC: the list in ascending order and ONE workgroup -- its waves take the tiles in list order and add up
+  // in wave order (mnf_host.h det_sort_ids_async)
+  if (tile_list && !partials && deterministic() &&
+      det_sort_ids_async(const_cast<int32_t*>(tile_list) + 1, tile_list, list_capacity, n_tiles, stream) == MNF_OK)
+    blocks = 1;
   const dim3 grid((unsigned)blocks), block(S::WAVES * 64);
   if (!tile_list) tag_kernel("ahf_bwd_mfma_fp32");  // (as the split kernel's fix-up pass it keeps that kernel's name)
   if (inverse)

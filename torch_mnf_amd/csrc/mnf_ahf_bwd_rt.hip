@@ -38,9 +38,10 @@ struct AhfBwdRtArgs {
 
 constexpr float kLog2eB = 1.4426950408889634f;
 
-template <int MT_MAX, bool VEC>
+template <int MT_MAX>
 __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform) rows are 16-byte aligned: dwordx4 row accesses
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4, nw = blockDim.x >> 6;
   // LDS: [scratch 16][scales: sA 8, sC 8, sH (layers + 1) x 8][weights][bias][exchange: HT | DT | CT][meta: per wave sign bits]
@@ -256,13 +257,11 @@ extern "C" int mnf_affine_half_bwd_rt(const float* x, const float* y, const floa
     if (lds <= 160 * 1024) break;
   }
   if (nw < 1) return MNF_ERR_UNSUPPORTED;
-  auto kernel = a.vec ? ahf_bwd_rt_kernel<MT_MAX, true> : ahf_bwd_rt_kernel<MT_MAX, false>;
+  auto kernel = ahf_bwd_rt_kernel<MT_MAX>;
   static DeviceMemo attr;
   attr.get([&](int) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_rt_kernel<MT_MAX, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_rt_kernel<MT_MAX, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ahf_bwd_rt_kernel<MT_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     return 1;
   });
   int per_cu = 0;

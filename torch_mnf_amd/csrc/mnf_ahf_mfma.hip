@@ -408,7 +408,7 @@ static int launch(const float* x, float* y, float* log_det, float* ysq, int accu
   constexpr int kNt = 14;  // loads + stores non-temporal (see the ABL list above the kernel)
   const dim3 grid((unsigned)blocks), block(kAhfWaves * 64);
   tag_kernel("ahf_mfma_fp32");
-  if (nt) {
+  if constexpr (nt) {
     if (inverse)
       hipLaunchKernelGGL((ahf_mfma_kernel<H, HID, true, kPrefetch, kNt>), grid, block, 0, stream, x, y, log_det,
                          ysq, image, rows, parity, accumulate);

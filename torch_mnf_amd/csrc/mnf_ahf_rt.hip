@@ -33,13 +33,13 @@ struct AhfRtArgs {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int MT_MAX, int NTL, bool VEC, bool PREFILL, typename Src>
+template <int MT_MAX, int NTL, int VEC, bool PREFILL, typename Src>  // VEC: 0 / 1, or 2 = a.vec
 __device__ __forceinline__ void ahf_rt_block(const AhfRtArgs& a, Src& src, float wup, int64_t row0) {
   using namespace rt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.dim / 2;
   const int cond_off = a.parity ? H : 0, act_off = a.parity ? 0 : H;
-  constexpr bool vec = VEC;
+  const bool vec = VEC == 2 ? a.vec != 0 : VEC == 1;
   const float* xrow[NTL];
   float* yrow[NTL];
   bool live[NTL];
@@ -170,7 +170,7 @@ __device__ __forceinline__ void ahf_rt_block(const AhfRtArgs& a, Src& src, float
   }
 }
 
-template <int MT_MAX, int NTL, int NW, bool RESIDENT, bool VEC>
+template <int MT_MAX, int NTL, int NW, bool RESIDENT, int VEC>
 __global__ void __launch_bounds__(NW * 64) ahf_rt_kernel(AhfRtArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   float* scratch = reinterpret_cast<float*>(rt_lds);
@@ -220,8 +220,12 @@ template <int MT_MAX, int NTL, int NW>
 static int ahf_rt_launch_class(AhfRtArgs& a, int64_t n_blocks, int64_t n_bias, hipStream_t stream) {
   constexpr int kResidentBytes = 158 * 1024, kStreamBlocks = 16, kStreamBias = 16;
   const int64_t resident_bytes = n_blocks * 2048 + n_bias * 64;
-  // (rows that are not 16-byte aligned have the streaming kernel only: small or odd shapes, one variant less)
-  const bool resident = resident_bytes <= kResidentBytes && a.vec;
+  // Rows that are not 16-byte aligned (dim not a multiple of 8, a view at an odd offset) have the resident variant only,
+  // except in the widest class, whose streaming kernel takes the alignment at run time (a branch around every row access:
+  // 15-20 % on the memory-bound shapes) and serves every width: ahf_rt_launch sends such a call there.
+  const bool resident = resident_bytes <= kResidentBytes;
+  constexpr int kStreamVec = MT_MAX == 16 ? 2 : 1;
+  if (!resident && !a.vec && kStreamVec != 2) return MNF_ERR_UNSUPPORTED;
   if (resident) {
     a.cb = (int)n_blocks;
     a.bt = (int)n_bias;
@@ -236,15 +240,15 @@ static int ahf_rt_launch_class(AhfRtArgs& a, int64_t n_blocks, int64_t n_bias, h
   const size_t lds = 64 + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4;
   static DeviceMemo attr;
   attr.get([&](int) {
-    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, true, true>);
-    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, false, true>);
-    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, false, false>);
+    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, true, 1>);
+    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, false, kStreamVec>);
+    rt_allow_big_lds(ahf_rt_kernel<MT_MAX, NTL, NW, true, 0>);
     return 1;
   });
   // workgroups of NW waves -- of 4 when the LDS footprint lets a CU hold two or more of them (they overlap each other's
   // barriers, staging and memory waits); persistent grid = what the occupancy query says is resident
-  auto kernel = !a.vec ? ahf_rt_kernel<MT_MAX, NTL, NW, false, false>
-                       : resident ? ahf_rt_kernel<MT_MAX, NTL, NW, true, true> : ahf_rt_kernel<MT_MAX, NTL, NW, false, true>;
+  auto kernel = !resident ? ahf_rt_kernel<MT_MAX, NTL, NW, false, kStreamVec>
+                          : a.vec ? ahf_rt_kernel<MT_MAX, NTL, NW, true, 1> : ahf_rt_kernel<MT_MAX, NTL, NW, true, 0>;
   const int nw = NW == 8 && resident && lds <= 79 * 1024 ? 4 : NW;  // (streaming: every wave of the CU shares one conversion of the weights)
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -289,10 +293,12 @@ int ahf_rt_launch(const float* x, float* y, float* log_det, float* ysq, int accu
   const int heads = (has_scale ? 1 : 0) + (has_shift ? 1 : 0);
   ahf_rt_plan(a.s_net, H, heads, n_blocks, n_bias, max_hidden);
   tag_kernel("ahf_rt");
-  if (max_hidden <= 64) return ahf_rt_launch_class<4, 1, 8>(a, n_blocks, n_bias, stream);
-  if (max_hidden <= 128) return ahf_rt_launch_class<8, 1, 8>(a, n_blocks, n_bias, stream);
-  if (max_hidden <= 256) return ahf_rt_launch_class<16, 1, 4>(a, n_blocks, n_bias, stream);
-  return MNF_ERR_UNSUPPORTED;
+  if (max_hidden > 256) return MNF_ERR_UNSUPPORTED;
+  int rc = MNF_ERR_UNSUPPORTED;
+  if (max_hidden <= 64) rc = ahf_rt_launch_class<4, 1, 8>(a, n_blocks, n_bias, stream);
+  else if (max_hidden <= 128) rc = ahf_rt_launch_class<8, 1, 8>(a, n_blocks, n_bias, stream);
+  if (rc == MNF_ERR_UNSUPPORTED) rc = ahf_rt_launch_class<16, 1, 4>(a, n_blocks, n_bias, stream);
+  return rc;
 }
 
 }  // namespace mnf

@@ -990,6 +990,11 @@ static int nsf_cl_bwd_launch(const float* x, const float* grad_y, const float* g
     blocks = ((rows + 15) / 16) * (16 / R);
     const int64_t cap = 8 * (int64_t)device_cus(current_device());
     if (blocks > cap) blocks = cap;
+    // MNF_DETERMINISTIC: the list in ascending order and ONE workgroup -- a parameter's additions then follow the list
+    // (mnf_host.h det_sort_ids_async; a slot of the sums is always visited by the same thread)
+    if (deterministic() && det_sort_ids_async(const_cast<int32_t*>(cold) + 2, cold, cold_capacity, (rows + 15) / 16,
+                                              (hipStream_t)stream) == MNF_OK)
+      blocks = 1;
   }
   a.R = R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
@@ -1056,8 +1061,12 @@ int rnvp_bwd_generic_launch(const float* z, const float* mask, uint64_t seed, co
     R = r2;
   }
   a.R = R;
-  const int64_t blocks = list ? 256 : (rows + R - 1) / R;
+  int64_t blocks = list ? 256 : (rows + R - 1) / R;
   if (blocks > 0x7fffffff) return MNF_ERR_UNSUPPORTED;
+  if (list && deterministic()) {  // the groups in ascending order, one workgroup: mnf_host.h det_sort_ids_async
+    const int64_t n_groups = (rows + rows_per_group - 1) / rows_per_group;
+    if (det_sort_ids_async(const_cast<int32_t*>(list) + 1, list, (int)n_groups, n_groups, stream) == MNF_OK) blocks = 1;
+  }
   if (!list) tag_kernel("rnvp_bwd_generic");  // (as the matrix-core pass's fix-up it keeps that pass's name)
   hipLaunchKernelGGL(rnvp_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), (size_t)R * per_row * sizeof(float),
                      stream, a);

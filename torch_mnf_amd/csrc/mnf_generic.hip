@@ -828,6 +828,66 @@ int det_reduce_async(const float* part, int n_rows, int64_t stride, int64_t coun
   return check_launch();
 }
 
+// det_sort_ids_async: ONE workgroup; a bit per possible id in LDS (ids are distinct), then the set bits written back in
+// ascending order.
+constexpr int kDetSortThreads = 1024;
+constexpr int64_t kDetSortMaxIds = 64 * 1024 * 8;  // 64 KB of bits
+__global__ void __launch_bounds__(kDetSortThreads)
+det_sort_ids_kernel(int32_t* __restrict__ ids, const int32_t* __restrict__ count, int capacity, int n_words) {
+  extern __shared__ uint32_t sort_bits[];
+  __shared__ int chunk_sum[kDetSortThreads];
+  int n = count[0];
+  if (n > capacity) n = capacity;
+  if (n < 2) return;  // (negative: the "every item" marker of the tile lists)
+  for (int i = threadIdx.x; i < n_words; i += blockDim.x) sort_bits[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t id = (uint32_t)ids[i];
+    if ((int)(id >> 5) < n_words) atomicOr(&sort_bits[id >> 5], 1u << (id & 31));
+  }
+  __syncthreads();
+  // thread t owns the words [t * per, (t + 1) * per): its ids land behind those of the threads before it
+  const int per = (n_words + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int w0 = threadIdx.x * per, w1 = w0 + per < n_words ? w0 + per : n_words;
+  int mine = 0;
+  for (int w = w0; w < w1; ++w) mine += __popc(sort_bits[w]);
+  chunk_sum[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < (int)blockDim.x; ++t) {
+      const int c = chunk_sum[t];
+      chunk_sum[t] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  int at = chunk_sum[threadIdx.x];
+  for (int w = w0; w < w1; ++w) {
+    uint32_t bits = sort_bits[w];
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      ids[at++] = w * 32 + b;
+    }
+  }
+}
+
+int det_sort_ids_async(int32_t* ids, const int32_t* count, int capacity, int64_t n_items, hipStream_t stream) {
+  if (capacity < 2 || n_items < 2) return MNF_OK;
+  if (n_items > kDetSortMaxIds) return MNF_ERR_UNSUPPORTED;
+  const int n_words = (int)((n_items + 31) / 32);
+  static DeviceMemo attr;
+  attr.get([&](int) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(det_sort_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              64 * 1024);
+    return 1;
+  });
+  hipLaunchKernelGGL(det_sort_ids_kernel, dim3(1), dim3(kDetSortThreads), (size_t)n_words * 4, stream, ids, count, capacity,
+                     n_words);
+  return check_launch();
+}
+
 // Fill a NetDesc for MLP(sizes...) whose parameters start at float offset `base` of the flat
 // buffer (weight then bias per Linear, state_dict order).  Returns floats consumed.
 int64_t fill_net(NetDesc& nd, int n_sizes, const int* sizes, int64_t base) {
@@ -942,8 +1002,10 @@ int mnf_affine_half_sq(const float* x, float* y, float* log_det, float* y_sqnorm
   }
   if ((has_scale || has_shift) && !flat) return y_sqnorm ? MNF_ERR_UNSUPPORTED : MNF_ERR_INVALID_ARG;
   // any other shape: the run-time-shaped matrix-core kernel (mnf_ahf_rt.hip) from kRtMinRows rows on (force_generic == 2:
-  // at any row count, whatever the shape's specialised kernels -- tests and the coverage map compare the two)
-  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+  // at any row count, whatever the shape's specialised kernels -- tests and the coverage map compare the two).  An fp32
+  // request -- the fp32 operand image without the split one -- does not take it: its arithmetic is split-f16; the VALU
+  // kernel below is fp32.
+  if (force_generic == 2 || (!force_generic && !(image && !split_image) && rows >= kRtMinRows)) {
     const int rc = ahf_rt_launch(x, y, log_det, y_sqnorm, accumulate, flat, rows, dim, parity, inverse, n_hidden, hidden,
                                  has_scale, has_shift, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
@@ -1120,7 +1182,7 @@ int mnf_nsf_cl(const float* x, float* y, float* log_det, int accumulate, const f
   if (!flat) return MNF_ERR_INVALID_ARG;
   // any other shape: the run-time-shaped matrix-core kernel (mnf_nsf_rt.hip; force_generic == 2: at any row count, whatever
   // the shape's specialised kernels)
-  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+  if (force_generic == 2 || (!force_generic && !(image && !split_image) && rows >= kRtMinRows)) {
     const int rc = nsf_rt_launch(x, y, log_det, accumulate, flat, rows, dim, K, tail_bound, inverse, n_hidden, hidden,
                                  (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
@@ -1240,7 +1302,7 @@ int mnf_rnvp_seeded_train(const float* z, const float* mask, uint64_t seed, floa
   if (!flat) return MNF_ERR_INVALID_ARG;
   // any other shape: the run-time-shaped matrix-core kernel (mnf_rnvp_rt.hip; force_generic == 2: at any row count,
   // whatever the shape's specialised kernels)
-  if (force_generic == 2 || (!force_generic && rows >= kRtMinRows)) {
+  if (force_generic == 2 || (!force_generic && !(image && !split_image) && rows >= kRtMinRows)) {
     const int rc = rnvp_rt_launch(z, mask, seed, x, log_det, accumulate, flat, rows, dim, n_hidden, hidden, (hipStream_t)stream);
     if (rc != MNF_ERR_UNSUPPORTED) return rc;
   }

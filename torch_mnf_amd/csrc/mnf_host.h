@@ -165,6 +165,13 @@ bool deterministic();
 // n floats := 0 / dst[i] += part[0][i] + part[1][i] + ... (rows in order, row r at part + r * stride), as kernel nodes
 int zero_floats_async(float* p, int64_t n, hipStream_t stream);
 int det_reduce_async(const float* part, int n_rows, int64_t stride, int64_t count, float* dst, hipStream_t stream);
+// The fp32 fix-up passes under MNF_DETERMINISTIC: the matrix-core gradient launches hand back the tiles / row groups
+// whose operands left the split range as a LIST filled through an atomic counter -- the same ids every run, in any order.
+// det_sort_ids_async sorts ids[0 .. min(*count, capacity)) (distinct values in [0, n_items)) ascending, in place, as a
+// kernel node; the fix-up pass then runs as ONE workgroup, whose additions to a parameter's sum follow the list: the same
+// sums bit for bit every run (slow, but these rows are the exception).  MNF_ERR_UNSUPPORTED beyond 524,288 possible ids
+// (8.4 M rows of 16-row tiles): the caller then runs the pass as it does without the switch.
+int det_sort_ids_async(int32_t* ids, const int32_t* count, int capacity, int64_t n_items, hipStream_t stream);
 // the waves of a workgroup add into LDS: atomically, or -- det -- wave 0, then wave 1, ... with plain read-modify-writes
 // (the lanes of one wave must name distinct addresses).  add(op) calls op(float* p, float v) for each of the wave's sums.
 template <int WAVES, typename F>

@@ -906,8 +906,13 @@ static int launch_mlb(const float* x, const float* z, const float* gout, const f
   }
   if (det)  // the weight blocks of the row parts, in order (the bias sums went out behind the prologue)
     if (int rc = det_reduce_async(det_part, row_parts, n_params, bmo, grad_flat, stream)) return rc;
-  hipLaunchKernelGGL(ml_bwd_fixup_kernel, dim3(256), dim3(256), 0, stream, x, z, gout, sd, eps, seed, grad_x, grad_z,
-                     grad_flat, flat, list, rows, n_in, n_out, var_unscale);
+  int fix_blocks = 256;
+  if (deterministic()) {  // the groups in ascending order, one workgroup: mnf_host.h det_sort_ids_async
+    const int64_t n_groups = (rows + kMlbGroupRows - 1) / kMlbGroupRows;
+    if (det_sort_ids_async(list + 1, list, (int)n_groups, n_groups, stream) == MNF_OK) fix_blocks = 1;
+  }
+  hipLaunchKernelGGL(ml_bwd_fixup_kernel, dim3((unsigned)fix_blocks), dim3(256), 0, stream, x, z, gout, sd, eps, seed, grad_x,
+                     grad_z, grad_flat, flat, list, rows, n_in, n_out, var_unscale);
   return check_launch();
 }
 

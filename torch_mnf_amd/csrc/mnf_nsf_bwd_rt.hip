@@ -99,12 +99,13 @@ struct NsfbOutTFetch {
 };
 
 // The slots of one half-step for a compile-time K: parameters, spline derivative, chain start, dW_out.
-template <int MT_MAX, int K, bool VEC, typename Src>
+template <int MT_MAX, int K, typename Src>
 __device__ __forceinline__ void nsf_bwd_slots(const NsfBwdRtArgs& a, Src& src, const NetDesc& nd, const rt::BwdLds& lds, float wup,
                                               float gs, float inv_gs, const rt::Hidden<MT_MAX, 1>& h, const float* xrow,
                                               const float* gorow, float* gxrow, int act_off, bool live, float gl,
                                               rt::Acc<MT_MAX, 1>& accd, float& downd) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform)
   constexpr int NW_ = (K + 3) / 4, ND_ = (K - 1 + 3) / 4, TV = 2 * NW_ + ND_, KSO = (TV + 1) / 2;
   const int lane = lds.lane, q = lds.q, wave = lds.wave, nw = lds.nw;
   const int H = a.dim / 2, L = nd.n_lin - 1;
@@ -194,9 +195,10 @@ __device__ __forceinline__ void nsf_bwd_slots(const NsfBwdRtArgs& a, Src& src, c
   }
 }
 
-template <int MT_MAX, bool VEC>
+template <int MT_MAX>
 __global__ void __launch_bounds__(256) nsf_bwd_rt_kernel(NsfBwdRtArgs a) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform) rows and halves are 16-byte aligned: dwordx4 row accesses
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4, nw = blockDim.x >> 6;
   float* scratch = reinterpret_cast<float*>(rt_lds);
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(256) nsf_bwd_rt_kernel(NsfBwdRtArgs a) {
       float downd = 1.f;
       switch (a.K) {  // (uniform)
 #define MNF_NSF_BWD_CASE(KK) \
-  case KK: nsf_bwd_slots<MT_MAX, KK, VEC>(a, src, nd, lds, wup, gs, inv_gs, h, xrow, gorow, gxrow, act_off, live, gl, accd, downd); break;
+  case KK: nsf_bwd_slots<MT_MAX, KK>(a, src, nd, lds, wup, gs, inv_gs, h, xrow, gorow, gxrow, act_off, live, gl, accd, downd); break;
         MNF_NSF_BWD_CASE(2) MNF_NSF_BWD_CASE(3) MNF_NSF_BWD_CASE(4) MNF_NSF_BWD_CASE(5) MNF_NSF_BWD_CASE(6) MNF_NSF_BWD_CASE(7)
         MNF_NSF_BWD_CASE(8) MNF_NSF_BWD_CASE(9) MNF_NSF_BWD_CASE(10) MNF_NSF_BWD_CASE(11) MNF_NSF_BWD_CASE(12)
         MNF_NSF_BWD_CASE(13) MNF_NSF_BWD_CASE(14) MNF_NSF_BWD_CASE(15) MNF_NSF_BWD_CASE(16)
@@ -318,13 +320,11 @@ extern "C" int mnf_nsf_cl_bwd_rt(const float* x, const float* y, const float* gr
     if (lds <= 160 * 1024) break;
   }
   if (nw < 1) return MNF_ERR_UNSUPPORTED;
-  auto kernel = a.vec ? nsf_bwd_rt_kernel<MT_MAX, true> : nsf_bwd_rt_kernel<MT_MAX, false>;
+  auto kernel = nsf_bwd_rt_kernel<MT_MAX>;
   static DeviceMemo attr;
   attr.get([&](int) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nsf_bwd_rt_kernel<MT_MAX, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nsf_bwd_rt_kernel<MT_MAX, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nsf_bwd_rt_kernel<MT_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     return 1;
   });
   int per_cu = 0;

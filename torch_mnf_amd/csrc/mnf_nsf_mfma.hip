@@ -687,33 +687,34 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
   auto resident_of = [](auto kernel, int dev) {
     return resident_by_occupancy(kernel, kNsfWaves * 64, dev, 2);
   };
+  // The fp32-MFMA variants (no split image: force_fp32_mfma / MNF_FP32_MFMA=1) exist for the K = 8 shapes of full width
+  // only; an fp32 request at another shape is MNF_ERR_UNSUPPORTED here and runs the VALU kernel (fp32 too) -- the
+  // run-time-shaped kernels are split arithmetic and do not take it (mnf_generic.hip).
+  // (nor for the fused [ActNorm, Glow, NSF_CL] block: the three layers then run one after the other)
+  constexpr bool kHasFp32 = K == 8 && NH <= 16;
+  if (!simage && (!kHasFp32 || hr != H || aff)) return MNF_ERR_UNSUPPORTED;
   static DeviceMemo memo_f32, memo_split;
-  const int resident =
-      simage ? memo_split.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, true>, dev); })
-             : memo_f32.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>, dev); });
+  int resident = 0;
+  if (simage) resident = memo_split.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, true>, dev); });
+  else if constexpr (kHasFp32)
+    resident = memo_f32.get([&](int dev) { return resident_of(nsf_mfma_kernel<H, NH, K, true, 2, false>, dev); });
   if (blocks > resident) blocks = resident;
   const dim3 grid((unsigned)blocks), block(kNsfWaves * 64);
 #define MNF_NSF_LAUNCH_R(INVV, AFFV, SPL, RAGV)                                                                        \
   hipLaunchKernelGGL((nsf_mfma_kernel<H, NH, K, INVV, AFFV, SPL, RAGV>), grid, block, 0, stream, x, y, log_det, image, \
                      simage, rows, T, accumulate, aff, ld_const, scale_shift, mid1, mid2, log_prob, log_prob_sum, hr)
 #define MNF_NSF_LAUNCH(INVV, AFFV, SPL) MNF_NSF_LAUNCH_R(INVV, AFFV, SPL, false)
-  tag_kernel(simage ? (aff ? "nsf_block_split" : "nsf_mfma_split") : (aff ? "nsf_block_fp32" : "nsf_mfma_fp32"));
+  tag_kernel(simage ? (aff ? "nsf_block_split" : "nsf_mfma_split") : "nsf_mfma_fp32");
   if (hr != H) {  // a half narrower than the tile (plain layer only)
     if (aff) return MNF_ERR_UNSUPPORTED;
-    if (simage) {
-      if (inverse) MNF_NSF_LAUNCH_R(true, 0, true, true); else MNF_NSF_LAUNCH_R(false, 0, true, true);
-    } else {
-      if (inverse) MNF_NSF_LAUNCH_R(true, 0, false, true); else MNF_NSF_LAUNCH_R(false, 0, false, true);
-    }
+    if (inverse) MNF_NSF_LAUNCH_R(true, 0, true, true); else MNF_NSF_LAUNCH_R(false, 0, true, true);
   } else if (simage) {
     if (aff) {
       if (inverse) MNF_NSF_LAUNCH(true, 2, true); else MNF_NSF_LAUNCH(false, 1, true);
     } else {
       if (inverse) MNF_NSF_LAUNCH(true, 0, true); else MNF_NSF_LAUNCH(false, 0, true);
     }
-  } else if (aff) {  // fused [ActNorm, Glow, NSF_CL] block
-    if (inverse) MNF_NSF_LAUNCH(true, 2, false); else MNF_NSF_LAUNCH(false, 1, false);
-  } else {
+  } else if constexpr (kHasFp32) {
     if (inverse) MNF_NSF_LAUNCH(true, 0, false); else MNF_NSF_LAUNCH(false, 0, false);
   }
 #undef MNF_NSF_LAUNCH
@@ -722,7 +723,9 @@ static int launch(const float* x, float* y, float* log_det, int accumulate, cons
 }
 
 // (H, NH, K) triples with an instantiated kernel
-#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10) X(16, 32, 8) X(16, 32, 5)
+// (three hidden layers of 32 units at dim <= 32 had kernels here until round 6: the run-time-shaped kernel of mnf_nsf_rt.hip
+// runs those within 1.1-1.2x of them, profiles/r6/coverage_map.txt)
+#define MNF_NSF_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8) X(16, 16, 5) X(32, 16, 5) X(16, 8, 10) X(16, 16, 10)
 // ... and those that also have the fused [ActNorm, Glow, NSF_CL] variants (the affine image must be one the Glow
 // MFMA kernel supports: dim 32 and 64 are)
 #define MNF_NSF_FUSED_SHAPES(X) X(16, 8, 8) X(16, 16, 8) X(16, 8, 5) X(16, 16, 5) X(32, 8, 8) X(32, 8, 5) X(32, 16, 8)

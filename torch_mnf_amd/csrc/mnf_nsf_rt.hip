@@ -29,7 +29,7 @@ struct NsfRtArgs {
   int64_t rows;
   int dim, K, inverse, accumulate;
   float T;
-  int n_params;
+  int n_params, vec;  // vec: rows and halves are 16-byte aligned (dwordx4 row accesses)
   int cb, bt;  // LDS plan (mnf_rt.h Source)
   int block_words, bias_words;
   NetDesc f1, f2;
@@ -76,11 +76,12 @@ struct NsfOutBias {  // tile t = (slot - s0) * TV + tv
 
 // The output layer and the spline of one half-step for a compile-time K (the tiles of a slot and the positions of its
 // parameters are then static: the slot's LDS reads and products are scheduled together); `inv` is run-time.
-template <int MT_MAX, int K, bool VEC, bool PREFILL, typename Src>
+template <int MT_MAX, int K, bool PREFILL, typename Src>
 __device__ __forceinline__ float nsf_rt_slots(const NsfRtArgs& a, Src& src, const NetDesc& nd, float wup,
                                               const rt::Hidden<MT_MAX, 1>& h, const float* xrow, float* yrow, int act_off,
                                               bool live, bool inv) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform)
   constexpr int NW_ = (K + 3) / 4, ND_ = (K - 1 + 3) / 4, TV = 2 * NW_ + ND_;  // tiles of widths / heights, derivatives
   const int lane = threadIdx.x & 63, q = lane >> 4;
   const int H = a.dim / 2;
@@ -128,9 +129,10 @@ __device__ __forceinline__ float nsf_rt_slots(const NsfRtArgs& a, Src& src, cons
   return lad_sum;
 }
 
-template <int MT_MAX, bool VEC, bool PREFILL, typename Src>
+template <int MT_MAX, bool PREFILL, typename Src>
 __device__ __forceinline__ void nsf_rt_block(const NsfRtArgs& a, Src& src, float wup, int64_t row0) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.dim / 2;
   const int64_t r = row0 + (int64_t)wave * 16 + j;
@@ -157,7 +159,7 @@ __device__ __forceinline__ void nsf_rt_block(const NsfRtArgs& a, Src& src, float
     net_to_hidden<MT_MAX, 1, PREFILL>(src, a.flat, nd, nd.n_lin - 1, -1, wup, lane, q, load_x, use_x, h);
     switch (a.K) {  // (uniform)
 #define MNF_NSF_RT_CASE(KK) \
-  case KK: lad += nsf_rt_slots<MT_MAX, KK, VEC, PREFILL>(a, src, nd, wup, h, xrow, yrow, act_off, live, a.inverse != 0); break;
+  case KK: lad += nsf_rt_slots<MT_MAX, KK, PREFILL>(a, src, nd, wup, h, xrow, yrow, act_off, live, a.inverse != 0); break;
       MNF_NSF_RT_CASE(2) MNF_NSF_RT_CASE(3) MNF_NSF_RT_CASE(4) MNF_NSF_RT_CASE(5) MNF_NSF_RT_CASE(6) MNF_NSF_RT_CASE(7)
       MNF_NSF_RT_CASE(8) MNF_NSF_RT_CASE(9) MNF_NSF_RT_CASE(10) MNF_NSF_RT_CASE(11) MNF_NSF_RT_CASE(12) MNF_NSF_RT_CASE(13)
       MNF_NSF_RT_CASE(14) MNF_NSF_RT_CASE(15) MNF_NSF_RT_CASE(16)
@@ -170,7 +172,7 @@ __device__ __forceinline__ void nsf_rt_block(const NsfRtArgs& a, Src& src, float
   if (q == 0 && live && a.log_det) a.log_det[r] = a.accumulate ? a.log_det[r] + total : total;
 }
 
-template <int MT_MAX, int NW, bool RESIDENT, bool VEC>
+template <int MT_MAX, int NW, bool RESIDENT>
 __global__ void __launch_bounds__(NW * 64) nsf_rt_kernel(NsfRtArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   float* scratch = reinterpret_cast<float*>(rt_lds);
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64) nsf_rt_kernel(NsfRtArgs a) {
   const float wup = rt::pow2f(e);
   rt::Source<RESIDENT> src{blocks, bias, a.cb, a.bt, 0, 0, 0, rt::pow2f(-e), 0};
   if (RESIDENT) {
-    nsf_rt_block<MT_MAX, VEC, true>(a, src, wup, 0);
+    nsf_rt_block<MT_MAX, true>(a, src, wup, 0);
     __syncthreads();
   }
   const int64_t rows_per_block = (int64_t)(blockDim.x >> 6) * 16;
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(NW * 64) nsf_rt_kernel(NsfRtArgs a) {
   for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
     src.slot = 0;
     src.btile = 0;
-    nsf_rt_block<MT_MAX, VEC, false>(a, src, wup, b * rows_per_block);
+    nsf_rt_block<MT_MAX, false>(a, src, wup, b * rows_per_block);
   }
 }
 
@@ -220,7 +222,7 @@ int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, cons
   int64_t off = fill_net(a.f1, n_hidden + 2, sizes, 0);
   off += fill_net(a.f2, n_hidden + 2, sizes, off);
   a.n_params = (int)off;
-  const bool vec = dim % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  a.vec = dim % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
   // the resident image: both nets, blocks and bias tiles
   int64_t n_blocks = 0, n_bias = 0;
   for (int l = 0; l < n_hidden; ++l) {
@@ -234,7 +236,7 @@ int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, cons
   n_blocks *= 2;
   n_bias *= 2;
   constexpr int kResidentBytes = 150 * 1024, kStreamBlocks = 24, kStreamBias = 24;
-  const bool resident = vec && n_blocks * 2048 + n_bias * 64 <= kResidentBytes;
+  const bool resident = n_blocks * 2048 + n_bias * 64 <= kResidentBytes;
   if (resident) {
     a.cb = (int)n_blocks;
     a.bt = (int)n_bias;
@@ -251,12 +253,11 @@ int nsf_rt_launch(const float* x, float* y, float* log_det, int accumulate, cons
   constexpr int NW = 8;
   static DeviceMemo attr;
   attr.get([&](int) {
-    nsf_rt_allow_big_lds(nsf_rt_kernel<4, NW, true, true>);
-    nsf_rt_allow_big_lds(nsf_rt_kernel<4, NW, false, true>);
-    nsf_rt_allow_big_lds(nsf_rt_kernel<4, NW, false, false>);
+    nsf_rt_allow_big_lds(nsf_rt_kernel<4, NW, true>);
+    nsf_rt_allow_big_lds(nsf_rt_kernel<4, NW, false>);
     return 1;
   });
-  auto kernel = !vec ? nsf_rt_kernel<4, NW, false, false> : resident ? nsf_rt_kernel<4, NW, true, true> : nsf_rt_kernel<4, NW, false, true>;
+  auto kernel = resident ? nsf_rt_kernel<4, NW, true> : nsf_rt_kernel<4, NW, false>;
   const int nw = resident && lds <= 79 * 1024 ? 4 : NW;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;

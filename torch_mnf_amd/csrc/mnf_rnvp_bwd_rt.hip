@@ -45,9 +45,10 @@ __device__ __forceinline__ f32x4 bwd_mask_bits4(uint32_t word, int first_bit) {
   return m;
 }
 
-template <int MT_MAX, bool VEC>
+template <int MT_MAX>
 __global__ void __launch_bounds__(MT_MAX <= 4 ? 512 : 256) rnvp_bwd_rt_kernel(RnvpBwdRtArgs a) {
   using namespace rt;
+  const bool VEC = a.vec != 0;  // (uniform) rows are 16-byte aligned: dwordx4 row accesses
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4, nw = blockDim.x >> 6;
   float* scratch = reinterpret_cast<float*>(rt_lds);
@@ -194,13 +195,11 @@ static int rnvp_bwd_rt_launch_class(RnvpBwdRtArgs& a, int max_nw, hipStream_t st
     if (lds <= 160 * 1024) break;
   }
   if (nw < 1) return MNF_ERR_UNSUPPORTED;
-  auto kernel = a.vec ? rnvp_bwd_rt_kernel<MT_MAX, true> : rnvp_bwd_rt_kernel<MT_MAX, false>;
+  auto kernel = rnvp_bwd_rt_kernel<MT_MAX>;
   static DeviceMemo attr;
   attr.get([&](int) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnvp_bwd_rt_kernel<MT_MAX, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnvp_bwd_rt_kernel<MT_MAX, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnvp_bwd_rt_kernel<MT_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     return 1;
   });
   int per_cu = 0;

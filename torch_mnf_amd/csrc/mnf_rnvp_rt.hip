@@ -26,7 +26,7 @@ struct RnvpRtArgs {
   int64_t rows;
   uint64_t seed;
   int dim, accumulate;
-  int n_params;
+  int n_params, vec;  // vec: rows are 16-byte aligned (dwordx4 row accesses)
   int t_w, t_b, s_w, s_b;  // float offsets of the heads
   int cb, bt;
   int block_words, bias_words;
@@ -40,9 +40,10 @@ __device__ __forceinline__ f32x4 mask_bits4(uint32_t word, int first_bit) {
   return m;
 }
 
-template <int MT_MAX, bool VEC, bool PREFILL, typename Src>
+template <int MT_MAX, int VECM, bool PREFILL, typename Src>  // VECM: 0 / 1, or 2 = a.vec
 __device__ __forceinline__ void rnvp_rt_block(const RnvpRtArgs& a, Src& src, float wup, int64_t row0) {
   using namespace rt;
+  const bool VEC = VECM == 2 ? a.vec != 0 : VECM == 1;
   constexpr int NTL = 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int d = a.dim;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void rnvp_rt_block(const RnvpRtArgs& a, Src& src, flo
   if (q == 0 && live && a.log_det) a.log_det[r] = a.accumulate ? a.log_det[r] + total : total;
 }
 
-template <int MT_MAX, int NW, bool RESIDENT, bool VEC>
+template <int MT_MAX, int NW, bool RESIDENT, int VEC>
 __global__ void __launch_bounds__(NW * 64) rnvp_rt_kernel(RnvpRtArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
   float* scratch = reinterpret_cast<float*>(rt_lds);
@@ -152,9 +153,14 @@ static void rnvp_rt_allow_big_lds(K kernel) {
 }
 
 template <int MT_MAX, int NW>
-static int rnvp_rt_launch_class(RnvpRtArgs& a, int64_t n_blocks, int64_t n_bias, bool vec, int cb_stream, hipStream_t stream) {
+static int rnvp_rt_launch_class(RnvpRtArgs& a, int64_t n_blocks, int64_t n_bias, int cb_stream, hipStream_t stream) {
   constexpr int kResidentBytes = 150 * 1024;
-  const bool resident = vec && n_blocks * 2048 + n_bias * 64 <= kResidentBytes;
+  // Rows that are not 16-byte aligned (dim not a multiple of 4, a view at an odd offset) have the resident variant only,
+  // except in the widest class, whose streaming kernel takes the alignment at run time (a branch around every row access:
+  // 15-20 % on the memory-bound shapes) and serves every width: rnvp_rt_launch sends such a call there.
+  const bool resident = n_blocks * 2048 + n_bias * 64 <= kResidentBytes;
+  constexpr int kStreamVec = MT_MAX == 16 ? 2 : 1;
+  if (!resident && !a.vec && kStreamVec != 2) return MNF_ERR_UNSUPPORTED;
   if (resident) {
     a.cb = (int)n_blocks;
     a.bt = (int)n_bias;
@@ -169,13 +175,13 @@ static int rnvp_rt_launch_class(RnvpRtArgs& a, int64_t n_blocks, int64_t n_bias,
   const size_t lds = 64 + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4;
   static DeviceMemo attr;
   attr.get([&](int) {
-    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, true, true>);
-    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, false, true>);
-    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, false, false>);
+    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, true, 1>);
+    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, false, kStreamVec>);
+    rnvp_rt_allow_big_lds(rnvp_rt_kernel<MT_MAX, NW, true, 0>);
     return 1;
   });
-  auto kernel = !vec ? rnvp_rt_kernel<MT_MAX, NW, false, false>
-                     : resident ? rnvp_rt_kernel<MT_MAX, NW, true, true> : rnvp_rt_kernel<MT_MAX, NW, false, true>;
+  auto kernel = !resident ? rnvp_rt_kernel<MT_MAX, NW, false, kStreamVec>
+                          : a.vec ? rnvp_rt_kernel<MT_MAX, NW, true, 1> : rnvp_rt_kernel<MT_MAX, NW, true, 0>;
   const int nw = NW == 8 && resident && lds <= 79 * 1024 ? 4 : NW;  // (streaming: every wave of the CU shares one conversion of the weights)
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, nw * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -212,7 +218,7 @@ int rnvp_rt_launch(const float* z, const float* mask, uint64_t seed, float* x, f
   a.s_b = (int)off; off += dim;
   if (off >= (1ll << 31)) return MNF_ERR_UNSUPPORTED;
   a.n_params = (int)off;
-  const bool vec = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+  a.vec = dim % 4 == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                    (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
   int64_t n_blocks = 0, n_bias = 0;
   for (int l = 0; l < n_hidden; ++l) {
@@ -224,9 +230,11 @@ int rnvp_rt_launch(const float* z, const float* mask, uint64_t seed, float* x, f
   n_blocks += 2ll * KS * M;
   n_bias += 2ll * M;
   tag_kernel("rnvp_rt");
-  if (mxh <= 64) return rnvp_rt_launch_class<4, 8>(a, n_blocks, n_bias, vec, 16, stream);
-  if (mxh <= 128) return rnvp_rt_launch_class<8, 8>(a, n_blocks, n_bias, vec, 16, stream);
-  return rnvp_rt_launch_class<16, 4>(a, n_blocks, n_bias, vec, 16, stream);
+  int rc = MNF_ERR_UNSUPPORTED;
+  if (mxh <= 64) rc = rnvp_rt_launch_class<4, 8>(a, n_blocks, n_bias, 16, stream);
+  else if (mxh <= 128) rc = rnvp_rt_launch_class<8, 8>(a, n_blocks, n_bias, 16, stream);
+  if (rc == MNF_ERR_UNSUPPORTED) rc = rnvp_rt_launch_class<16, 4>(a, n_blocks, n_bias, 16, stream);
+  return rc;
 }
 
 }  // namespace mnf

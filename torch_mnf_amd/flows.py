@@ -342,7 +342,7 @@ def _ahf_layer_backward(lib, f, x_in: Tensor, gy, gl, gx: Tensor, grad_flat_ptr,
                 x_in.data_ptr(), _ptr(gy), _ptr(gl), gx.data_ptr(), grad_flat_ptr, flat_ptr, index.data_ptr(), rows,
                 f.dim, int(bool(f.parity)), int(inverse), *hid, _stream())
     if rc == _lib.MNF_ERR_UNSUPPORTED and flat_ptr is not None and f.force_generic != 1 \
-            and (rows >= _dispatch.RT_MIN_ROWS or f.force_generic == 2) and (y_out is not None or not inverse or not f.scale):
+            and (f.force_generic == 2 or (rows >= _dispatch.RT_MIN_ROWS and not f._fp32_request())) and (y_out is not None or not inverse or not f.scale):
         # no per-shape gradient kernel: the run-time-shaped matrix-core one (any 1..4 hidden layers of widths 4..64)
         sc = scale if scale is not None else _grad_scale(gy, gl, rows, f.dim, x_in.device)
         rc = lib.mnf_affine_half_bwd_rt(
@@ -372,7 +372,7 @@ class _AffineHalfFn(torch.autograd.Function):
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), _ptr(module._split_image(x.device)),
             x.shape[0], module.dim,
             int(bool(module.parity)), int(inverse), len(module.h_sizes), module._hid, int(module.scale),
-            int(module.shift), int(module.force_generic), _stream()))
+            int(module.shift), module._force_code(image), _stream()))
         ctx.module, ctx.inverse = module, inverse
         # (y too: the run-time-shaped gradient kernel forms the inverse direction's g_s = -grad_y y - grad_ld from it; the
         #  next layer keeps its input alive anyway)
@@ -413,7 +413,7 @@ class _NsfFn(torch.autograd.Function):
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image), _ptr(module._split_image(x.device)),
             x.shape[0], module.dim,
             module.K, float(module.B), int(inverse), len(module.h_sizes), module._hid,
-            int(module.force_generic), _stream()))
+            module._force_code(image), _stream()))
         if not module.force_generic and not module._pad_half():  # (a padded-twin shape is here by choice: few rows)
             _lib.note_generic("NSF_CL", x.shape[0], f"dim={module.dim}, K={module.K}, hidden={module.h_sizes}")
         ctx.module, ctx.inverse = module, inverse
@@ -467,7 +467,8 @@ class _NsfFn(torch.autograd.Function):
                     x.data_ptr(), _ptr(gy), _ptr(gl), grad_x.data_ptr(), grad_flat.data_ptr(), flat.data_ptr(), *args,
                     cold.data_ptr(), cap, _stream()))
                 return grad_x, grad_flat, None, None
-        if m.force_generic != 1 and _dispatch.NSF_BWD_KERNEL != "generic" and (rows >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+        if m.force_generic != 1 and _dispatch.NSF_BWD_KERNEL != "generic" and (
+                m.force_generic == 2 or (rows >= _dispatch.RT_MIN_ROWS and not m._fp32_request())):
             # no per-shape gradient kernel: the run-time-shaped matrix-core one (any dim, K <= 16, hidden widths 4..64)
             scale = _grad_scale(gy, gl, rows, m.dim, x.device)
             rc = lib.mnf_nsf_cl_bwd_rt(
@@ -507,7 +508,8 @@ class _RnvpFn(torch.autograd.Function):
         _lib.check("mnf_rnvp_seeded_train", lib.mnf_rnvp_seeded_train(
             z.data_ptr(), _ptr(mask), seed, x.data_ptr(), ld.data_ptr(), 0, _ptr(flat), _ptr(image),
             None if few else _ptr(module._split_image(z.device)), z.shape[0],
-            module.dim, len(module.h_sizes), module._hid, int(module.force_generic), _ptr(y), ctypes.byref(wrote),
+            module.dim, len(module.h_sizes), module._hid,
+            int(module.force_generic) if few else module._force_code(image), _ptr(y), ctypes.byref(wrote),
             _stream()))
         ctx.module, ctx.seed, ctx.mask = module, seed, mask
         ctx.kept_y = y if wrote.value else None
@@ -571,7 +573,8 @@ class _RnvpFn(torch.autograd.Function):
             if rc != _lib.MNF_ERR_UNSUPPORTED:
                 _lib.check("mnf_rnvp_bwd_mfma", rc)
                 return grad_z, ret_flat, None, None, None, None
-        if m.force_generic != 1 and not _dispatch.RNVP_BWD_GENERIC and (z.shape[0] >= _dispatch.RT_MIN_ROWS or m.force_generic == 2):
+        if m.force_generic != 1 and not _dispatch.RNVP_BWD_GENERIC and (
+                m.force_generic == 2 or (z.shape[0] >= _dispatch.RT_MIN_ROWS and not m._fp32_request())):
             # no per-shape gradient kernel: the run-time-shaped matrix-core one (1..4 conditioner layers of widths 4..128)
             scale = _grad_scale(gx, gl, z.shape[0], m.dim, z.device)
             rc = lib.mnf_rnvp_bwd_rt(
@@ -856,6 +859,18 @@ class _HipFlow(nn.Module):
         # that a product sum has too few terms to average the split format's 2^-22 per product out, see _narrow_hidden)
         self._split_ok = True
 
+    def _fp32_request(self) -> bool:
+        """force_fp32_mfma / MNF_FP32_MFMA=1: no split-f16 arithmetic for this layer."""
+        return bool(self.force_fp32_mfma or _FP32_MFMA_ENV)
+
+    def _force_code(self, image: Tensor | None) -> int:
+        """`force_generic` as the C entries take it (0: dispatch, 1: VALU kernel, 2: run-time-shaped kernel).  An fp32
+        request on a shape without operand image -- no per-shape kernel, so no fp32 matrix-core one -- runs the VALU
+        kernel, which is fp32 too: the run-time-shaped kernels are split arithmetic (with an image and no fp32 kernel
+        for the shape the C entry does the same by itself: csrc/mnf_generic.hip)."""
+        fg = int(self.force_generic)
+        return 1 if not fg and image is None and self._fp32_request() else fg
+
     def invalidate(self) -> None:
         """Drop the packed operand images; the next call repacks them from the parameters.
 
@@ -1099,7 +1114,7 @@ class AffineHalfFlow(_TwoWayFlow):
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), _ptr(sqnorm), int(accum is not None and not overwrite),
             _ptr(flat), _ptr(image), _ptr(split), x.shape[0], self.dim, int(bool(self.parity)),
             int(inverse), len(self.h_sizes),
-            self._hid, int(self.scale), int(self.shift), int(self.force_generic), _stream()))
+            self._hid, int(self.scale), int(self.shift), self._force_code(image), _stream()))
         if not self.force_generic:
             _lib.note_generic("AffineHalfFlow", x.shape[0], f"dim={self.dim}, hidden={self.h_sizes}")
         return y, (None if accum is not None else ld)
@@ -1272,7 +1287,7 @@ class NSF_CL(_TwoWayFlow):
             x.data_ptr(), y.data_ptr(), ld.data_ptr(), int(accum is not None), _ptr(flat), _ptr(image),
             _ptr(split),
             x.shape[0], self.dim, self.K, float(self.B), int(inverse), len(self.h_sizes), self._hid,
-            int(self.force_generic), _stream()))
+            self._force_code(image), _stream()))
         if not self.force_generic and not self._pad_half():  # (a padded-twin shape is here by choice: few rows)
             _lib.note_generic("NSF_CL", x.shape[0], f"dim={self.dim}, K={self.K}, hidden={self.h_sizes}")
         return y, (None if accum is not None else ld)
@@ -1516,7 +1531,8 @@ class RNVP(_HipFlow):
             home = _flat_home_of(self, params)
             flat_g = _home_stand_in(self, z.device) if home is not None else torch.cat([p.reshape(-1) for p in params])
             return _RnvpFn.apply(_grad_input(zin), flat_g, self, mask, int(seed or 0) & 0xFFFFFFFFFFFFFFFF, home)
-        if prologue is None and self._few(z.shape[0], mask is not None):
+        few = prologue is None and self._few(z.shape[0], mask is not None)
+        if few:
             flat, image, split = self._packed(z.device, images=False)[0], None, None
         else:
             flat, image, split = self._packed3(z.device)
@@ -1537,7 +1553,7 @@ class RNVP(_HipFlow):
         _lib.check("mnf_rnvp_seeded", _lib.load().mnf_rnvp_seeded(
             z.data_ptr(), _ptr(mask), int(seed or 0) & 0xFFFFFFFFFFFFFFFF, x.data_ptr(), ld.data_ptr(),
             int(accum is not None), _ptr(flat), _ptr(image), _ptr(split), z.shape[0], self.dim,
-            len(self.h_sizes), self._hid, int(self.force_generic), _stream()))
+            len(self.h_sizes), self._hid, int(self.force_generic) if few else self._force_code(image), _stream()))
         if not self.force_generic:
             _lib.note_generic("RNVP", z.shape[0], f"dim={self.dim}, hidden={self.h_sizes}")
         return x, (None if accum is not None else ld)
@@ -2005,7 +2021,8 @@ class _SplineBlockRun:
             buf[0].data_ptr() if keep else None, buf[1].data_ptr() if keep else None,
             _ptr(logprob[0]) if logprob else None, _ptr(logprob[1]) if logprob else None, x.shape[0], self.dim, nsf.K, float(nsf.B), int(inverse), len(nsf.h_sizes), nsf._hid, _stream())
         if rc == _lib.MNF_ERR_UNSUPPORTED:
-            self._unsupported = True
+            # (an fp32 request has no fused kernel at any shape; it is a per-call choice, not a property of the shape)
+            self._unsupported = not nsf._fp32_request()
             return None
         _lib.check("mnf_nsf_cl_fused", rc)
         return list(buf.unbind(0))
