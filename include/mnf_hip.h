@@ -81,7 +81,13 @@ const char* mnf_last_kernel(void);
  * in an extension of the caller's workspace (their *_workspace_bytes queries include it), added up in a fixed order -- so
  * that a training step repeats bit for bit, as the reference's does under torch.manual_seed (tests/test_flows.py:11).
  * The split AffineHalfFlow and the NSF_CL tile gradient launches reduce in a fixed order in every mode; the [Glow, ActNorm]
- * pair, the fp32-MFMA AffineHalfFlow kernel and sample_z have *_det entry points of their own.  Rows that take the fp32 fix-up pass (values beyond the split range) still add atomically. */
+ * pair, the fp32-MFMA AffineHalfFlow kernel and sample_z have *_det entry points of their own.  The fp32 fix-up passes
+ * (tiles / row groups whose values left the split range, handed back as a list in any order) then sort their list on the
+ * device -- in place, also where this header passes it as const -- and run as ONE workgroup, so that their sums follow
+ * the list (slow; such rows are the exception).  tools/soak_determinism_train.py: 0 differing tensors with a tenth of
+ * the rows forced onto those passes.  The run-time-shaped gradient kernels (mnf_*_bwd_rt) return MNF_ERR_UNSUPPORTED
+ * under the switch: their shapes then take the VALU gradient kernels, which add atomically across workgroups -- the
+ * switch covers the shapes with per-shape gradient kernels (the reference's configurations), not every shape. */
 int mnf_deterministic(void);
 /* Number of visible devices whose gcnArchName starts with gfx950 (0 = none / no driver). */
 int mnf_device_count(void);
