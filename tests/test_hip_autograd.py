@@ -429,7 +429,7 @@ def test_nsf_cl_row_gradient_kernel_many_rows(amd, inverse, nsf_rows_kernel):
     does not depend on where the row sits) and the parameter gradients must be 70 times the single batch's.
     (A large random batch cannot be compared kernel against kernel: among ~10^6 hidden units some pre-activation
     lands within rounding of the LeakyReLU kink and the two kernels legitimately take different one-sided
-    derivatives -- tools/nsf_grad_outliers.py shows such rows.)"""
+    derivatives -- tests/tool_nsf_grad_outliers.py shows such rows.)"""
     rows, copies, K, n_h = 1003, 70, 8, 8
     sd = recipes.nsf_cl_params(391, 32, K, n_h)
     x_cpu = recipes.gaussian(392, rows, 32, scale=1.3)
