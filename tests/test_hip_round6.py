@@ -334,3 +334,40 @@ def test_rt_gradients_are_the_default_without_a_specialised_kernel(amd):
             (y.sum() + ld.sum()).backward()
             assert amd.last_kernel() == want, (type(f).__name__, rows, amd.last_kernel())
             assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in f.parameters())
+
+
+@pytest.mark.parametrize("layer", ["ahf", "nsf", "nsf_rt", "rnvp"])
+def test_gradients_of_a_view_at_an_odd_storage_offset(amd, O, layer):
+    """Rows that are not 16-byte aligned (a contiguous view one float into its buffer): the per-shape gradient kernels refuse
+    such a launch (MNF_ERR_UNSUPPORTED) and the call must land on a kernel that takes it -- the run-time-shaped one, whose
+    row accesses then go element by element -- with the same gradients (advisor, round 5: the NSF_CL tile kernel's refusal
+    used to surface as an exception in backward after a forward pass that had quietly fallen back)."""
+    rows = 2500
+    if layer == "ahf":
+        dim, sd = 64, recipes.affine_half_params(71, 64)
+        f = amd.AffineHalfFlow(dim, False)
+        ref_fn, call = (lambda x, p: O.affine_half(x, p, False, False)), (lambda m, x: m.forward(x))
+    elif layer in ("nsf", "nsf_rt"):
+        dim, n_h = 32, (8 if layer == "nsf" else 40)
+        sd = recipes.nsf_cl_params(72, dim, 8, n_h)
+        f = amd.NSF_CL(dim, K=8, B=3, n_h=n_h)
+        ref_fn, call = (lambda x, p: O.nsf_cl(x, p, 8, 3.0, False)), (lambda m, x: m.forward(x))
+    else:
+        dim, sd = 128, _rnvp_sd(73, 128, (50,))
+        f = amd.RNVP(dim, h_sizes=(50,))
+        mask = recipes.bernoulli_mask(74, rows, dim)
+        ref_fn, call = (lambda x, p: O.rnvp(x, p, mask.to(x.dtype))), (lambda m, x: m.forward(x, mask=mask.to(DEV)))
+    f.load_state_dict(sd)
+    f.to(DEV)
+    x_cpu = recipes.gaussian(75 + dim, rows, dim)
+    w_y, w_l = recipes.gaussian(76, rows, dim), recipes.gaussian(77, rows, 1)[:, 0]
+    ref = OracleGrads(cot_loss(ref_fn, w_y, w_l), x_cpu, sd)
+    buf = torch.zeros(rows * dim + 1, device=DEV)
+    x = buf[1:].view(rows, dim)
+    x.copy_(x_cpu.to(DEV))
+    assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+    x.requires_grad_(True)
+    y, ld = call(f, x)
+    ((y * w_y.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
+    got = {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
+    ref.check_all(got, f"{layer} at an odd storage offset ({amd.last_kernel()})")

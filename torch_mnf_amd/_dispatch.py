@@ -18,7 +18,7 @@ MNF_NO_RUN_FUSION and MNF_NO_PAIR_FUSION (layer-by-layer passes, for per-layer m
 |                          | any             | the fp32-MFMA kernel's shapes                     | ahf_bwd_mfma_fp32              |
 |                          | >= RT_MIN_ROWS  | 1..4 hidden layers of widths 4..64, any d         | ahf_bwd_rt                     |
 |                          | else            | anything                                          | ahf_bwd_generic                |
-| NSF_CL fwd               | any             | d % 8 == 0 up to 64, n_h <= 16 (32 fwd), K 5/8/10 | nsf_mfma_split                 |
+| NSF_CL fwd               | any             | d % 8 == 0 up to 64, n_h <= 16, K 5/8 (10: d<=32) | nsf_mfma_split                 |
 |                          | >= NSF_PAD_MIN_ROWS | other d <= 64 (zero-padded twin layer)        | nsf_mfma_split                 |
 |                          | >= RT_MIN_ROWS  | any d, K 2..16, hidden widths 4..64               | nsf_rt                         |
 |                          | else            | anything                                          | nsf_generic                    |
@@ -33,6 +33,12 @@ MNF_NO_RUN_FUSION and MNF_NO_PAIR_FUSION (layer-by-layer passes, for per-layer m
 |                          | not rnvp_bwd_small() | one hidden layer <= 64, padded d >= 64       | rnvp_bwd_mfma                  |
 |                          | >= RT_MIN_ROWS  | 1..4 layers of widths 4..128, any d               | rnvp_bwd_rt                    |
 |                          | else            | anything                                          | rnvp_bwd_generic               |
+
+Two requests override the shape: an fp32 request (layer.force_fp32_mfma / MNF_FP32_MFMA=1) never lands on the *_rt
+kernels, whose arithmetic is split-f16 -- it takes the fp32 matrix-core kernel where the shape has one (AffineHalfFlow and
+RNVP: wherever a split kernel exists; NSF_CL: the K = 8 shapes, plain layer only), else the VALU kernel; and under
+MNF_DETERMINISTIC=1 the *_bwd_rt kernels (atomic sums) refuse, so their shapes take the VALU gradient kernels.
+layer.force_generic = 1 / 2 forces the VALU / the run-time-shaped kernels (tests, tools/coverage_map.py).
 """
 
 # The run-time-shaped matrix-core kernels (csrc/mnf_rt.h: any layer count and widths) take a call without a per-shape
