@@ -230,7 +230,8 @@ def test_flat_parameter_home_receives_the_gradients_in_place(amd, golden, kind):
 
 def test_mnf_lenet_trains_on_a_synthetic_ten_class_problem(amd):
     """The reference's tests/test_mnf_mnist.py without the download: MNFLeNet, Adam, batches of 32, loss =
-    nll + 1e-3 kl_div, until the batch accuracy passes 0.95; validation accuracy > 0.8 ("just make sure it trains").
+    nll + 1e-3 kl_div, until the batch accuracy passes 0.95 (three batches in a row); validation accuracy > 0.8 ("just make
+    sure it trains").
     The images are ten fixed random 28 x 28 patterns plus noise."""
     torch.manual_seed(0)
     gen = torch.Generator(device=DEV).manual_seed(11)
@@ -243,6 +244,7 @@ def test_mnf_lenet_trains_on_a_synthetic_ten_class_problem(amd):
     model = amd.MNFLeNet().to(DEV)
     assert [type(m).__name__ for m in model][:4] == ["MNFConv2d", "ReLU", "MaxPool2d", "MNFConv2d"]
     adam = torch.optim.Adam(model.parameters())
+    good = 0
     for _ in range(400):
         x, y = batch(32)
         adam.zero_grad()
@@ -250,7 +252,11 @@ def test_mnf_lenet_trains_on_a_synthetic_ten_class_problem(amd):
         loss = torch.nn.functional.nll_loss(preds, y) + model.kl_div() * 1e-3
         loss.backward()
         adam.step()
-        if float((y == preds.argmax(1)).float().mean()) > 0.95:
+        # (the reference stops at the FIRST batch above 0.95: with 32 rows per batch a lucky one ends the training early,
+        #  and the gradient sums' atomics make which batch that is differ run to run -- one run in six then ended below the
+        #  0.8 bar; three batches in a row say the same thing about the model without the coin toss)
+        good = good + 1 if float((y == preds.argmax(1)).float().mean()) > 0.95 else 0
+        if good == 3:
             break
     x_val, y_val = batch(500)
     with torch.no_grad():

@@ -365,7 +365,9 @@ def test_spline_block_training_pass_with_the_fused_pair_matches_layer_by_layer(a
         if n.endswith(".s"):
             # ActNorm's s right after its data-dependent initialisation: +1 from log_det and -(1 - 1/rows) from the rows
             # cancel to 1/rows, so the budget is the fp32 error of the O(1) terms, not of their difference
-            assert float((results[True][2][n] - g).abs().max()) <= 2e-6, n
+            # (4e-6: both passes add these sums with float atomics in whatever order the workgroups finish; 25 repeats of the
+            #  8,192-row case gave up to 2.06e-6 between two runs' orders)
+            assert float((results[True][2][n] - g).abs().max()) <= 4e-6, n
         else:
             assert _err(results[True][2][n], g) <= 2e-5, n
 

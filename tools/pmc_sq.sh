@@ -1,9 +1,9 @@
 #!/bin/bash
-# Where do a kernel's cycles go: SQ counter passes over tools/time_rnvp.py (or another script).
+# Where do a kernel's cycles go: SQ counter passes over tools/time_rt.py (or another script).
 # usage: tools/pmc_sq.sh <tag> [script args...]      env: MNF_LIB_PATH, MNF_NSF_BWD_KERNEL ... pass through; SCRIPT=tools/x.py
 TAG=${1:-x}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-SCRIPT=${SCRIPT:-tools/time_rnvp.py}
+SCRIPT=${SCRIPT:-tools/time_rt.py}
 OUT=$REPO/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 case "$MNF_LIB_PATH" in ""|/*) ;; *) export MNF_LIB_PATH=$REPO/$MNF_LIB_PATH;; esac
