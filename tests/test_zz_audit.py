@@ -2,7 +2,7 @@
 ``helpers.PARITY_LOG`` (assert_parity: outputs against the reference / oracle with float64 head-room) and
 ``helpers.GRAD_LOG`` (gradients against the float64 oracle, optimiser equivalence) -- with a hard rule: a NON-stress
 comparison may use at most 80 % of its budget.  The table goes to stdout (pytest -s) and to
-``gpurun_out/r5/parity_budget.txt`` (copied to profiles/r5/)."""
+``gpurun_out/r6/parity_budget.txt`` (copied to profiles/r6/)."""
 import os
 
 import pytest
@@ -43,7 +43,7 @@ def test_zz_every_non_stress_comparison_uses_at_most_80_percent_of_its_budget():
         lines.append(f"worst non-stress {k}: {100 * r['used']:.0f} % -- {r['what'][:100]}")
     report = "\n".join(lines)
     print("\n" + report)
-    out_dir = os.path.join(ROOT, "gpurun_out", "r5")
+    out_dir = os.path.join(ROOT, "gpurun_out", "r6")
     try:
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "parity_budget.txt"), "w") as fh:
