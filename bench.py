@@ -910,7 +910,8 @@ SECONDARY = (("c3", "c3", {}), ("c4", "c4", {}), ("c5", "c5", {}), ("c5b", "c5b"
 def secondary_lines(args) -> dict:
     """The other configurations, driver-observable: after the headline's timed region (and outside it) each of them
     runs as a CHILD process -- `bench.py --workload X --steps 20 --warmup 3 --no-cpu-baseline` -- and its line is
-    condensed to {ms_per_step, value, unit, kernel, avg_kernel_us, bound, frac, traffic, frac_physical} (+ latency_us
+    condensed to {ms_per_step, value, unit, kernel, avg_kernel_us, bound, frac, traffic, frac_physical} (+ the transcendental
+    floor of c3 / c3t, + latency_us
     for c1).  (A child process, never an exec: this process has initialised the GPU.)  A workload that fails or
     overruns its time limit is reported as such."""
     import subprocess
@@ -934,6 +935,9 @@ def secondary_lines(args) -> dict:
                         "kernel": (r.get("kernel") or "")[:80], "avg_kernel_us": r.get("avg_kernel_us"),
                         "bound": r.get("bound"), "frac": r.get("frac"), "traffic": r.get("traffic"),
                         "frac_physical": r.get("frac_physical"), "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("transcendental_floor_ms", "frac_of_transcendental_floor"):  # (c3, c3t: the vector-issue-bound ones)
+                if k in r:
+                    out[key][k] = r[k]
             if "latency_us" in d:
                 out[key]["latency_us"] = {k: v for k, v in d["latency_us"].items() if k != "note"}
             if extra_env:

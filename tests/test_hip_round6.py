@@ -371,3 +371,55 @@ def test_gradients_of_a_view_at_an_odd_storage_offset(amd, O, layer):
     ((y * w_y.to(DEV)).sum() + (ld * w_l.to(DEV)).sum()).backward()
     got = {"x": x.grad, **{n: q.grad for n, q in f.named_parameters()}}
     ref.check_all(got, f"{layer} at an odd storage offset ({amd.last_kernel()})")
+
+
+def test_graphed_training_step_of_a_model_on_the_run_time_shaped_kernels(amd):
+    """A model none of whose coupling layers has a per-shape kernel -- two-layer conditioners, K = 6, 100 RNVP hidden units --
+    trained with FlatParameters + FusedAdam at 4,096 rows: every layer's forward and gradient launch is a run-time-shaped
+    kernel (no operand image to repack after the optimiser step: they read the flat buffer), the parameter gradients land in
+    the flat gradient buffer, and the step replays from one hipGraph (GraphedStep) with the losses and parameters of the
+    eager loop."""
+    dim, rows = 16, 4096
+
+    def build():
+        torch.manual_seed(31)
+        layers = [amd.AffineHalfFlow(dim, parity=False, h_sizes=(20, 20)), amd.NSF_CL(dim, K=6, B=3, n_h=24),
+                  amd.AffineHalfFlow(dim, parity=True, h_sizes=(40,)), amd.AffineHalfFlow(dim, parity=False, h_sizes=(12, 16, 12, 8))]
+        model = amd.NormalizingFlowModel(amd.StandardNormal(dim), layers).to(DEV)
+        return model, amd.FusedAdam(amd.FlatParameters(model), lr=1e-3, capturable=True)
+
+    batches = [recipes.gaussian(400 + i, rows, dim).to(DEV) for i in range(8)]
+    model_e, opt_e = build()
+    losses_e, kernels = [], set()
+    for x in [batches[0]] * 3 + batches[1:]:
+        opt_e.zero_grad()
+        loss = -model_e.log_prob(x).mean()
+        kernels.add(amd.last_kernel())
+        loss.backward()
+        kernels.add(amd.last_kernel())
+        opt_e.step()
+        losses_e.append(float(loss.detach()))
+    del loss
+    assert kernels <= {"ahf_rt", "ahf_bwd_rt", "nsf_rt", "nsf_bwd_rt"}, kernels
+    assert losses_e[-1] < losses_e[0]
+    model_g, opt_g = build()
+    step = amd.GraphedStep(opt_g, lambda x: -model_g.log_prob(x).mean(), batches[0])
+    losses_g = [float(step(x)) for x in batches[1:]]
+    for a, b in zip(losses_e[3:], losses_g):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (a, b)
+    assert_close(opt_g.flat.data, opt_e.flat.data, 2e-3, "parameters after 10 steps")
+    # and a wide RNVP (100 hidden units) as MNFLinear's flows would use it, trained the same way
+    torch.manual_seed(32)
+    f = amd.RNVP(64, h_sizes=(100,)).to(DEV)
+    opt = amd.FusedAdam(amd.FlatParameters(f), lr=1e-3)
+    z = recipes.gaussian(500, rows, 64).to(DEV)
+    first = None
+    for _ in range(5):
+        opt.zero_grad()
+        x, ld = f.forward(z, seed=9)
+        loss = (x.pow(2).mean() - ld.mean())
+        loss.backward()
+        assert amd.last_kernel() == "rnvp_bwd_rt"
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+    assert float(loss.detach()) < first
