@@ -70,6 +70,8 @@ def test_rnvp_gradient_kernel_choice_by_shape(dim, rows, family):
     y, ld = f.forward(x, seed=11)
     (y.sum() + ld.sum()).backward()
     torch.cuda.synchronize()
+    if amd.deterministic():  # (the run-time-shaped gradient kernels add atomically and refuse under the switch)
+        family = family.replace("_bwd_rt", "_bwd_generic")
     assert amd.last_kernel() == family
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in f.parameters())
 
@@ -102,7 +104,7 @@ def test_padded_nsf_twin_follows_a_fused_optimizer(monkeypatch):
 
     l_twin, p_twin, k_twin = train(0)
     l_any, p_any, k_any = train(1 << 40)
-    assert k_twin == "nsf_bwd_tile" and k_any == "nsf_bwd_rt", (k_twin, k_any)
+    assert k_twin == "nsf_bwd_tile" and k_any == ("nsf_bwd_generic" if amd.deterministic() else "nsf_bwd_rt"), (k_twin, k_any)
     assert l_twin[2] < l_twin[0]
     for a, b in zip(l_twin, l_any):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (l_twin, l_any)
