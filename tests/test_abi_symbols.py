@@ -302,3 +302,39 @@ def test_cached_parameter_walk_matches_module_parameters():
                                                    list(r.net.parameters()) + list(r.t.parameters()) + list(r.s.parameters())]
     n = amd.NSF_CL(4, K=5, n_h=8)
     assert [id(p) for p in n._packed_params()] == [id(p) for p in list(n.f1.parameters()) + list(n.f2.parameters())]
+
+
+def test_dispatch_table_agrees_with_the_measured_coverage_map():
+    """torch_mnf_amd/_dispatch.py is the one place the kernel-selection policy is written down: its tier() (the table as a
+    function: the library's host-side shape queries + the row-count constants) must name, for every shape of the
+    committed coverage map (profiles/r6/coverage_map.txt: what torch_mnf_amd.last_kernel() reported on the GPU at 262,144
+    rows), the tier of the kernel that actually ran -- forward and gradient direction.  No GPU needed."""
+    import re
+
+    from torch_mnf_amd import _dispatch
+
+    path = os.path.join(ROOT, "profiles", "r6", "coverage_map.txt")
+    rows, checked = 262144, 0
+    for line in open(path):
+        m = re.match(r"(AffineHalfFlow|NSF_CL|RNVP)\s+(dim=.*?)\s{2,}(\w+)\s+[\d.]+.*?\s{3}(\w+)\s+[\d.]+", line)
+        if not m:
+            continue
+        layer, shape, k_fwd, k_bwd = m.groups()
+        dim = int(re.search(r"dim=(\d+)", shape).group(1))
+        if layer == "NSF_CL":
+            K, n_h = int(re.search(r"K=(\d+)", shape).group(1)), int(re.search(r"n_h=(\d+)", shape).group(1))
+            kind, hidden = "nsf", (n_h,) * 3
+        else:
+            K = None
+            hidden = tuple(int(v) for v in re.search(r"hidden=\(([^)]*)\)", shape).group(1).replace(" ", "").split(",") if v)
+            kind = "ahf" if layer == "AffineHalfFlow" else "rnvp"
+        for direction, kernel in (("fwd", k_fwd), ("bwd", k_bwd)):
+            want = _dispatch.tier_of_kernel(kernel)
+            got = _dispatch.tier(kind, direction, rows, dim, hidden, K)
+            assert got == want, f"{layer} {shape} {direction}: the map ran '{kernel}' ({want}), the table says {got}"
+            checked += 1
+    assert checked == 2 * 131, checked
+    # below the run-time-shaped kernels' row floor everything without a per-shape kernel is on the VALU kernels
+    assert _dispatch.tier("ahf", "fwd", 100, 64, (24, 24)) == "valu" and _dispatch.tier("ahf", "fwd", 4096, 64, (24, 24)) == "rt"
+    assert _dispatch.tier("rnvp", "bwd", 128, 800, (50,)) == "per-shape" and _dispatch.tier("rnvp", "bwd", 4096, 50, (50,)) == "rt"
+    assert _dispatch.tier("nsf", "fwd", 4096, 2, (16,) * 3, 8) == "rt" and _dispatch.tier("nsf", "fwd", 1 << 16, 2, (16,) * 3, 8) == "per-shape"

@@ -1,5 +1,5 @@
 """Time per row of the run-time-shaped kernels (force_generic = 2), forward and forward + backward, for a few shapes.
-usage: python3 tools/time_rt.py [rows]"""
+usage: python3 tools/time_rt.py [rows] [only the cases whose name contains this]"""
 import os
 import sys
 
@@ -9,6 +9,7 @@ import torch
 import torch_mnf_amd as amd
 
 ROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 DEV = "cuda"
 
 
@@ -33,12 +34,15 @@ CASES = [
     ("ahf d=512 (24,24,24)", lambda: amd.AffineHalfFlow(512, False, h_sizes=(24, 24, 24)), 512, lambda m, x: m.inverse(x)),
     ("ahf d=512 (64,64,64)", lambda: amd.AffineHalfFlow(512, False, h_sizes=(64, 64, 64)), 512, lambda m, x: m.inverse(x)),
     ("nsf d=32 K=8 n_h=16", lambda: amd.NSF_CL(32, K=8, B=3, n_h=16), 32, lambda m, x: m.inverse(x)),
+    ("nsf d=32 K=8 n_h=32", lambda: amd.NSF_CL(32, K=8, B=3, n_h=32), 32, lambda m, x: m.inverse(x)),
     ("nsf d=128 K=8 n_h=8", lambda: amd.NSF_CL(128, K=8, B=3, n_h=8), 128, lambda m, x: m.inverse(x)),
     ("rnvp d=800 h=50", lambda: amd.RNVP(800, h_sizes=(50,)), 800, lambda m, x: m.forward(x, seed=3)),
     ("rnvp d=800 h=100", lambda: amd.RNVP(800, h_sizes=(100,)), 800, lambda m, x: m.forward(x, seed=3)),
     ("rnvp d=2048 h=100", lambda: amd.RNVP(2048, h_sizes=(100,)), 2048, lambda m, x: m.forward(x, seed=3)),
 ]
 for name, make, dim, call in CASES:
+    if ONLY not in name:
+        continue
     layer = make().to(DEV)
     layer.force_generic = 2
     x = torch.randn(ROWS, dim, device=DEV)

@@ -79,3 +79,50 @@ def rnvp_bwd_small(rows: int, dim: int) -> bool:
     if dim >= RNVP_BWD_MFMA_MIN_DIM or rows >= RNVP_BWD_MFMA_ANY_DIM_ROWS:
         return False
     return not (dim >= RNVP_BWD_MFMA_MID_DIM and rows >= RNVP_BWD_MFMA_MID_ROWS)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The table above as a function: which TIER a call lands on ("per-shape", "rt" = run-time-shaped, "valu").  The shape
+# questions go to the library's own host-side queries (no GPU needed); the row-count questions are the constants above.
+# tests/test_abi_symbols.py checks it against every row of the committed coverage map (profiles/r6/coverage_map.txt):
+# the table, this function and the measured map cannot drift apart unnoticed.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rt_range(kind: str, direction: str, hidden, K) -> bool:
+    if not hidden or min(hidden) < 4:
+        return False
+    if kind == "ahf":
+        return max(hidden) <= (256 if direction == "fwd" else 64) and (direction == "fwd" or len(hidden) <= 4)
+    if kind == "nsf":
+        return max(hidden) <= 64 and K is not None and 2 <= K <= 16 and (direction == "fwd" or len(hidden) <= 4)
+    return max(hidden) <= (256 if direction == "fwd" else 128) and (direction == "fwd" or len(hidden) <= 4)
+
+
+def tier(kind: str, direction: str, rows: int, dim: int, hidden, K: int | None = None, scale: bool = True,
+         shift: bool = True) -> str:
+    """Tier of one layer call in default mode (no force_generic, no fp32 request, no MNF_DETERMINISTIC): kind "ahf" |
+    "nsf" | "rnvp", direction "fwd" | "bwd", hidden = the conditioner's hidden widths (NSF_CL: (n_h,) * 3)."""
+    from . import _lib
+    lib, hid, n = _lib.load(), _lib.int_array(list(hidden)), len(hidden)
+    if kind == "ahf":
+        if direction == "fwd":
+            per_shape = lib.mnf_affine_half_image_floats(dim, n, hid, int(scale), int(shift)) > 0
+        else:  # the fp32-MFMA gradient kernel's shapes contain the split kernel's
+            per_shape = lib.mnf_affine_half_bwd_index_ints(dim, n, hid, int(scale), int(shift)) > 0
+    elif kind == "nsf":
+        tile = bool(lib.mnf_nsf_cl_bwd_tile_supported(dim, K, n, hid))
+        per_shape = lib.mnf_nsf_cl_image_floats(dim, K, n, hid) > 0 if direction == "fwd" else tile
+        hp = (dim // 2 + 3) // 4 * 4
+        if not per_shape and hp != dim // 2 and 2 * hp <= 64 and len(set(hidden)) == 1 and rows >= NSF_PAD_MIN_ROWS:
+            per_shape = bool(lib.mnf_nsf_cl_bwd_tile_supported(2 * hp, K, n, hid))  # the zero-padded twin layer
+    else:
+        per_shape = lib.mnf_rnvp_image_floats(dim, n, hid) > 0
+        if direction == "bwd":
+            per_shape = per_shape and not rnvp_bwd_small(rows, dim)
+    if per_shape:
+        return "per-shape"
+    return "rt" if rows >= RT_MIN_ROWS and _rt_range(kind, direction, hidden, K) else "valu"
+
+
+def tier_of_kernel(name: str) -> str:
+    """The tier a kernel family name (torch_mnf_amd.last_kernel()) belongs to."""
+    return "valu" if "generic" in name else "rt" if name.endswith("_rt") else "per-shape"
