@@ -75,7 +75,6 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
     float* gxrow = a.grad_x + rc * a.dim;
     const float gl = a.grad_ld && live ? a.grad_ld[rc] : 0.f;
     const float rowmask = live ? 1.f : 0.f;  // rows past the end add nothing to the parameter sums
-    Hidden<MT_MAX, 1> hs_last;  // the s-net's last hidden vector: the t pass needs e^{+-s}
 
 #pragma unroll 1
     for (int pass = 0; pass < n_nets; ++pass) {
@@ -95,8 +94,9 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
       }
       // ---- output layer, two 16-column tiles (one K-step of the chain) per chunk
       const int MTh = tiles16(nd.sizes[L]), KSh = steps32(16 * MTh), M = tiles16(H);
-      const bool need_s = !is_s && a.has_scale;  // the t pass recomputes s from the s-net's last hidden vector
-      const int KSs = need_s ? steps32(16 * tiles16(a.s_net.sizes[L])) : 0;
+      // (the t pass behind an s pass needs e^{-s} in the inverse direction only, and only as g e^{-s}: that is the
+      //  value-half cotangent the s pass stored in grad_x -- read back by the lane that wrote it, program order)
+      const bool after_s = !is_s && a.has_scale;
       const int ht_last = exH_tile_of(nd, L);
       Acc<MT_MAX, 1> accd;
       accd.zero();
@@ -107,12 +107,7 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
         float* bbuf = src.cur_bias();
         stage_blocks(buf, mo * KSh, DenseMMajor{a.flat + nd.w_off[L], nd.sizes[L], H, KSh, m0, 1, 0}, src.wdown);
         stage_bias(bbuf, mo, DenseBias{a.flat + nd.b_off[L], H, m0});
-        if (need_s) {
-          stage_blocks(buf + mo * KSh * kBlockWords, mo * KSs,
-                       DenseMMajor{a.flat + a.s_net.w_off[L], a.s_net.sizes[L], H, KSs, m0, 1, 0}, src.wdown);
-          stage_bias(bbuf + 16 * mo, mo, DenseBias{a.flat + a.s_net.b_off[L], H, m0});
-        }
-        const uint32_t* bufT = buf + mo * (KSh + KSs) * kBlockWords;
+        const uint32_t* bufT = buf + mo * KSh * kBlockWords;
         stage_blocks(const_cast<uint32_t*>(bufT), MTh, DenseTKMajor{a.flat + nd.w_off[L], nd.sizes[L], H, MTh, m0 >> 1},
                      src.wdown);
         src.commit();
@@ -125,10 +120,10 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
             f32x4 o[1], sv[1];
             out_tile<MT_MAX, 1>(buf, ml * KSh, KSh, bbuf + 16 * ml, lane, q, h, wup, o);
             sv[0] = is_s ? o[0] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (need_s) out_tile<MT_MAX, 1>(buf + mo * KSh * kBlockWords, ml * KSs, KSs, bbuf + 16 * (mo + ml), lane, q, hs_last, wup, sv);
             const f32x4 x1 = load4(xrow + act_off, col, H, VEC);
             const f32x4 gy1 = a.grad_y ? load4(gyrow + act_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f};
             const f32x4 y1 = a.inverse && is_s ? load4(yrow + act_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 gxs = a.inverse && after_s ? load4(gxrow + act_off, col, H, VEC) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 gx1;
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
@@ -138,7 +133,8 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
               gx1[e4] = gy1[e4] * ex;
               float g;
               if (is_s) g = a.inverse ? -gy1[e4] * y1[e4] - gl : gy1[e4] * ex * x1[e4] + gl;
-              else g = a.inverse ? -gy1[e4] * ex : gy1[e4];
+              else if (after_s) g = a.inverse ? -gxs[e4] : gy1[e4];
+              else g = a.inverse ? -gy1[e4] * ex : gy1[e4];  // (no scale net: ex = 1)
               g2[ml][e4] = col + e4 < H ? g * gs * rowmask : 0.f;
             }
             if (pass == 0) store4(gxrow + act_off, col, H, VEC, live, gx1);
@@ -179,7 +175,6 @@ __global__ void __launch_bounds__(512) ahf_bwd_rt_kernel(AhfBwdRtArgs a) {
           dw_phase(exC, 0, mo, exH, ht_last, MTh, sC, sH + L * 8, nw, inv_gs, gflat + nd.w_off[L], gflat + nd.b_off[L], H, nd.sizes[L], m0, 0);
         }
       }
-      if (is_s) hs_last = h;
       // ---- hidden layers backwards, then grad_x of the conditioning half and dW_0 (mnf_rt_bwd.h)
       f32x4 dv[MT_MAX];
       chain_result<MT_MAX>(accd, wup / downd, lds.meta_bits[n_hid * 64 + lane], dv);
@@ -237,25 +232,37 @@ extern "C" int mnf_affine_half_bwd_rt(const float* x, const float* y, const floa
   auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec = dim % 8 == 0 && aligned(x) && aligned(grad_x) && (!y || aligned(y)) && (!grad_y || aligned(grad_y));
   constexpr int MT_MAX = 4;
-  a.cb = 12;
   a.bt = 8;
-  a.block_words = 2 * a.cb * rt::kBlockWords;
   a.bias_words = 2 * a.bt * 16;
   a.ht_tiles = ht;
-  a.dt_tiles = dt;
+  a.dt_tiles = 0;  // (the deltas reuse the hidden vectors' tiles: mnf_rt_bwd.h backward_tail)
+  (void)dt;
   const int KS1 = (16 * ((hidden[0] + 15) / 16) + 31) / 32;
-  int ci = a.cb / KS1;
-  ci = ci > MT_MAX ? MT_MAX : ci;
-  a.ct_tiles = ci < 2 ? 2 : ci;
-  // the largest workgroup (rows per block = 16 waves) whose exchange area fits next to the weight stream
+  // The LDS plan.  Rows per workgroup first (16 per wave, any wave count: the per-row-block cost is what this kernel is
+  // bound by), then the roomier of two weight-stream sizes (12 blocks per buffer: fewer chunks; 8: the largest chunk
+  // there is -- two output tiles' forward blocks and the transposed blocks of their K-step at 64 hidden units), then as
+  // many first-layer input tiles per chunk as fit (the output-layer chunks need two).
   int nw = 8;
   size_t lds = 0;
-  for (; nw >= 1; nw >>= 1) {
+  bool fits = false;
+  for (; nw >= 1; --nw) {
     const size_t tile_bytes = (size_t)2 * 16 * (16 * nw + rt::kExPad) * 2;
-    lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 + (size_t)(a.ht_tiles + a.dt_tiles + a.ct_tiles) * tile_bytes +
-          (size_t)nw * (rt::kMaxBwdLayers + 1) * 64 * 4;
-    if (lds <= 160 * 1024) break;
+    for (int cb = 12; cb >= 8 && !fits; cb -= 4) {
+      int ci = cb / KS1;
+      ci = ci > MT_MAX ? MT_MAX : ci < 2 ? 2 : ci;
+      for (int ct = ci; ct >= 2 && !fits; ct = ct > 2 ? 2 : 0) {
+        lds = (size_t)4 * rt::kBwdHeadWords + (size_t)2 * cb * rt::kBlockWords * 4 + (size_t)a.bias_words * 4 +
+              (size_t)(a.ht_tiles + a.dt_tiles + ct) * tile_bytes + (size_t)nw * (rt::kMaxBwdLayers + 1) * 64 * 4;
+        if (lds <= 160 * 1024) {
+          a.cb = cb;
+          a.ct_tiles = ct;
+          fits = true;
+        }
+      }
+    }
+    if (fits) break;
   }
+  a.block_words = 2 * a.cb * rt::kBlockWords;
   if (nw < 1) return MNF_ERR_UNSUPPORTED;
   auto kernel = ahf_bwd_rt_kernel<MT_MAX>;
   static DeviceMemo attr;

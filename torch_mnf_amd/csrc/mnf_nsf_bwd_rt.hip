@@ -310,11 +310,12 @@ extern "C" int mnf_nsf_cl_bwd_rt(const float* x, const float* y, const float* gr
   a.block_words = 2 * a.cb * rt::kBlockWords;
   a.bias_words = 2 * a.bt * 16;
   a.ht_tiles = ht;
-  a.dt_tiles = dt;
+  a.dt_tiles = 0;  // (the deltas reuse the hidden vectors' tiles: mnf_rt_bwd.h backward_tail)
+  (void)dt;
   a.ct_tiles = TV > MT_MAX ? TV : MT_MAX;
   int nw = 4;  // (the spline derivative at K up to 16 wants a wave's full register file: one wave per SIMD)
   size_t lds = 0;
-  for (; nw >= 1; nw >>= 1) {
+  for (; nw >= 1; --nw) {  // (any wave count: 6 or 7 waves where 8 do not fit)
     lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 +
           rt::bwd_lds_bytes(nw, a.ht_tiles, a.dt_tiles, a.ct_tiles);
     if (lds <= 160 * 1024) break;

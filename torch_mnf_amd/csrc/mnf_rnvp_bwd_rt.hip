@@ -187,12 +187,22 @@ __global__ void __launch_bounds__(MT_MAX <= 4 ? 512 : 256) rnvp_bwd_rt_kernel(Rn
 
 template <int MT_MAX>
 static int rnvp_bwd_rt_launch_class(RnvpBwdRtArgs& a, int max_nw, hipStream_t stream) {
+  // rows per workgroup first (any wave count), then as many first-layer input tiles per chunk as still fit (a.ct_tiles on
+  // entry; the output-layer chunks need four: [t0 t1 s0 s1])
   int nw = max_nw;
   size_t lds = 0;
-  for (; nw >= 1; nw >>= 1) {
-    lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 +
-          rt::bwd_lds_bytes(nw, a.ht_tiles, a.dt_tiles, a.ct_tiles);
-    if (lds <= 160 * 1024) break;
+  bool fits = false;
+  const int ct_wish = a.ct_tiles;
+  for (; nw >= 1; --nw) {
+    for (int ct = ct_wish; ct >= 4 && !fits; ct = ct > 4 ? 4 : 0) {
+      lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 +
+            rt::bwd_lds_bytes(nw, a.ht_tiles, a.dt_tiles, ct);
+      if (lds <= 160 * 1024) {
+        a.ct_tiles = ct;
+        fits = true;
+      }
+    }
+    if (fits) break;
   }
   if (nw < 1) return MNF_ERR_UNSUPPORTED;
   auto kernel = rnvp_bwd_rt_kernel<MT_MAX>;
@@ -258,11 +268,12 @@ extern "C" int mnf_rnvp_bwd_rt(const float* z, const float* mask, uint64_t seed,
   a.block_words = 2 * a.cb * rt::kBlockWords;
   a.bias_words = 2 * a.bt * 16;
   a.ht_tiles = ht;
-  a.dt_tiles = dt;
+  a.dt_tiles = 0;  // (the deltas reuse the hidden vectors' tiles: mnf_rt_bwd.h backward_tail)
+  (void)dt;
   const int KS1 = (16 * MT1 + 31) / 32;
   int ci = a.cb / KS1;
   ci = ci > MT_MAX ? MT_MAX : ci;
-  a.ct_tiles = ci < 4 ? 4 : ci;
+  a.ct_tiles = ci < 4 ? 4 : ci;  // (the wish: rnvp_bwd_rt_launch_class settles for four where that buys a larger workgroup)
   if (MT_MAX == 4) return rnvp_bwd_rt_launch_class<4>(a, 8, (hipStream_t)stream);
   return rnvp_bwd_rt_launch_class<8>(a, 4, (hipStream_t)stream);
 }

@@ -284,7 +284,7 @@ constexpr int kBwdHeadWords = 32 + 8 * (kMaxBwdLayers + 2);  // scratch 16 | sA 
 
 struct BwdLds {
   float *sA, *sC, *sH;   // power-of-two scales of the wave-tiles' exchange copies: deltas | chunk tiles | hidden vector i
-  Exchange exH, exD, exC;  // hidden vectors of one net | one layer's deltas | a chunk's cotangent / input tiles
+  Exchange exH, exC;  // hidden vectors of one net (a layer's deltas take the place of its dead hidden vector) | a chunk's cotangent / input tiles
   uint32_t* meta_bits;   // this wave's [hidden vector i][lane] sign bits
   int ct_tiles;
   int nw, wave, lane, q;
@@ -301,8 +301,7 @@ __device__ __forceinline__ BwdLds bwd_lds(uint32_t* lds0, float* after_weights, 
   L.lane = threadIdx.x & 63;
   L.q = L.lane >> 4;
   L.exH = Exchange{reinterpret_cast<uint16_t*>(after_weights), 16 * L.nw};
-  L.exD = Exchange{L.exH.base + (size_t)ht_tiles * L.exH.tile_halves(), 16 * L.nw};
-  L.exC = Exchange{L.exD.base + (size_t)dt_tiles * L.exH.tile_halves(), 16 * L.nw};
+  L.exC = Exchange{L.exH.base + (size_t)(ht_tiles + dt_tiles) * L.exH.tile_halves(), 16 * L.nw};
   L.meta_bits = reinterpret_cast<uint32_t*>(L.exC.base + (size_t)ct_tiles * L.exH.tile_halves()) + L.wave * ((kMaxBwdLayers + 1) * 64);
   L.ct_tiles = ct_tiles;
   L.ident = identity_operand(L.lane & 15, L.q);
@@ -348,11 +347,15 @@ __device__ __forceinline__ void backward_tail(Src& src, const float* __restrict_
   for (int i = n_hid; i >= 2; --i) {
     const int MTi = tiles16(nd.sizes[i]), MTp = tiles16(nd.sizes[i - 1]);
     if (gflat) {
-      lds_barrier();  // (the previous phase's readers are done with the delta tiles)
-      const float sc = exchange_store<MT_MAX>(dv, MTi, L.exD, 0, 16 * wave, lane, L.ident);
+      // delta_i goes into the exchange tiles of H_i: that vector's last reader was the previous phase (dW_{i+1}, or the
+      // caller's output-layer phase for i = n_hid), which every wave has left behind this barrier -- no tiles of their own
+      // for the deltas, so that more rows fit a workgroup (the per-row-block cost is what these kernels are bound by)
+      lds_barrier();
+      const Exchange exD{L.exH.tile(exH_tile_of(nd, i)), L.exH.R};
+      const float sc = exchange_store<MT_MAX>(dv, MTi, exD, 0, 16 * wave, lane, L.ident);
       if (lane == 0) L.sA[wave] = sc;
       lds_barrier();
-      dw_phase(L.exD, 0, MTi, L.exH, exH_tile_of(nd, i - 1), MTp, L.sA, L.sH + (i - 1) * 8, nw, inv_gs, gflat + nd.w_off[i - 1],
+      dw_phase(exD, 0, MTi, L.exH, exH_tile_of(nd, i - 1), MTp, L.sA, L.sH + (i - 1) * 8, nw, inv_gs, gflat + nd.w_off[i - 1],
                gflat + nd.b_off[i - 1], nd.sizes[i], nd.sizes[i - 1], 0, 0);
     }
     // delta_{i-1} = (W_{i-1}^T delta_i) * act'(H_{i-1}): K = the units of H_i, output tiles = those of H_{i-1}
@@ -385,9 +388,10 @@ __device__ __forceinline__ void backward_tail(Src& src, const float* __restrict_
   }
   // ---- first layer: dv = delta_1
   const int MT1 = tiles16(nd.sizes[1]), KS1 = steps32(16 * MT1), MI = tiles16(n_in0);
+  const Exchange exD1{L.exH.tile(exH_tile_of(nd, 1)), L.exH.R};  // (delta_1 in H_1's tiles, as above)
   if (gflat) {
     lds_barrier();
-    const float sc = exchange_store<MT_MAX>(dv, MT1, L.exD, 0, 16 * wave, lane, L.ident);
+    const float sc = exchange_store<MT_MAX>(dv, MT1, exD1, 0, 16 * wave, lane, L.ident);
     if (lane == 0) L.sA[wave] = sc;
   }
   Hidden<MT_MAX, 1> hd;
@@ -418,7 +422,7 @@ __device__ __forceinline__ void backward_tail(Src& src, const float* __restrict_
       const float sc = exchange_store<MT_MAX>(xv, ci, L.exC, 0, 16 * wave, lane, L.ident);
       if (lane == 0) L.sC[wave] = sc;
       lds_barrier();
-      dw_phase(L.exD, 0, MT1, L.exC, 0, ci, L.sA, L.sC, nw, inv_gs, gflat + nd.w_off[0], mi0 == 0 ? gflat + nd.b_off[0] : nullptr,
+      dw_phase(exD1, 0, MT1, L.exC, 0, ci, L.sA, L.sC, nw, inv_gs, gflat + nd.w_off[0], mi0 == 0 ? gflat + nd.b_off[0] : nullptr,
                nd.sizes[1], n_in0, 0, mi0);
     }
   }
