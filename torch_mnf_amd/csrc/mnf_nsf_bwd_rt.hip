@@ -196,7 +196,7 @@ __device__ __forceinline__ void nsf_bwd_slots(const NsfBwdRtArgs& a, Src& src, c
 }
 
 template <int MT_MAX>
-__global__ void __launch_bounds__(256) nsf_bwd_rt_kernel(NsfBwdRtArgs a) {
+__global__ void __launch_bounds__(512) nsf_bwd_rt_kernel(NsfBwdRtArgs a) {
   using namespace rt;
   const bool VEC = a.vec != 0;  // (uniform) rows and halves are 16-byte aligned: dwordx4 row accesses
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
@@ -313,7 +313,7 @@ extern "C" int mnf_nsf_cl_bwd_rt(const float* x, const float* y, const float* gr
   a.dt_tiles = 0;  // (the deltas reuse the hidden vectors' tiles: mnf_rt_bwd.h backward_tail)
   (void)dt;
   a.ct_tiles = TV > MT_MAX ? TV : MT_MAX;
-  int nw = 4;  // (the spline derivative at K up to 16 wants a wave's full register file: one wave per SIMD)
+  int nw = 8;
   size_t lds = 0;
   for (; nw >= 1; --nw) {  // (any wave count: 6 or 7 waves where 8 do not fit)
     lds = (size_t)4 * rt::kBwdHeadWords + (size_t)a.block_words * 4 + (size_t)a.bias_words * 4 +

@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x4 bwd_mask_bits4(uint32_t word, int first_bit) {
 }
 
 template <int MT_MAX>
-__global__ void __launch_bounds__(MT_MAX <= 4 ? 512 : 256) rnvp_bwd_rt_kernel(RnvpBwdRtArgs a) {
+__global__ void __launch_bounds__(512) rnvp_bwd_rt_kernel(RnvpBwdRtArgs a) {
   using namespace rt;
   const bool VEC = a.vec != 0;  // (uniform) rows are 16-byte aligned: dwordx4 row accesses
   extern __shared__ __attribute__((aligned(16))) uint32_t rt_lds[];
@@ -275,5 +275,5 @@ extern "C" int mnf_rnvp_bwd_rt(const float* z, const float* mask, uint64_t seed,
   ci = ci > MT_MAX ? MT_MAX : ci;
   a.ct_tiles = ci < 4 ? 4 : ci;  // (the wish: rnvp_bwd_rt_launch_class settles for four where that buys a larger workgroup)
   if (MT_MAX == 4) return rnvp_bwd_rt_launch_class<4>(a, 8, (hipStream_t)stream);
-  return rnvp_bwd_rt_launch_class<8>(a, 4, (hipStream_t)stream);
+  return rnvp_bwd_rt_launch_class<8>(a, 8, (hipStream_t)stream);
 }
