@@ -60,26 +60,45 @@ __device__ __forceinline__ void ahf_rt_block(const AhfRtArgs& a, Src& src, float
   Hidden<MT_MAX, NTL> hs, ht;
   // the conditioning half: B operands of the first layer; the first net's pass also copies it to y (:50, :60-61)
   const int n_nets = (a.has_scale ? 1 : 0) + (a.has_shift ? 1 : 0);
-#pragma unroll 1
-  for (int net = 0; net < n_nets; ++net) {
-    const bool copy = net == 0;
-    auto load_x = [&](int t, int ks, f32x4& xa, f32x4& xb) {
-      const int c0 = 32 * ks + 4 * q;
-      xa = load4(xrow[t] + cond_off, c0, H, vec);
-      xb = load4(xrow[t] + cond_off, c0 + 16, H, vec);
-    };
+  auto load_x = [&](int t, int ks, f32x4& xa, f32x4& xb) {
+    const int c0 = 32 * ks + 4 * q;
+    xa = load4(xrow[t] + cond_off, c0, H, vec);
+    xb = load4(xrow[t] + cond_off, c0 + 16, H, vec);
+  };
+  if (MT_MAX == 4 && n_nets == 2) {
+    // both nets' first layers in ONE pass over the conditioning half (it is loaded, copied to y and split once; at wide
+    // dims the input side is most of the layer), then each net's hidden layers
     auto use_x = [&](int t, int ks, const f32x4& xa, const f32x4& xb) {
       const int c0 = 32 * ks + 4 * q;
-      store4(yrow[t] + cond_off, c0, H, vec, live[t] && copy, xa);
-      store4(yrow[t] + cond_off, c0 + 16, H, vec, live[t] && copy, xb);
-      const float ss = xa[0] * xa[0] + xa[1] * xa[1] + xa[2] * xa[2] + xa[3] * xa[3] + xb[0] * xb[0] + xb[1] * xb[1] +
-                       xb[2] * xb[2] + xb[3] * xb[3];
-      sq[t] += copy ? ss : 0.f;
+      store4(yrow[t] + cond_off, c0, H, vec, live[t], xa);
+      store4(yrow[t] + cond_off, c0 + 16, H, vec, live[t], xb);
+      sq[t] += xa[0] * xa[0] + xa[1] * xa[1] + xa[2] * xa[2] + xa[3] * xa[3] + xb[0] * xb[0] + xb[1] * xb[1] + xb[2] * xb[2] +
+               xb[3] * xb[3];
     };
-    // (s_net, t_net are both filled: an absent net is a copy of the other one; net 0 = the first PRESENT net)
-    if (net == 1) hs = ht;  // (both nets present: the s-net's vector moves over, the t-net's takes its place)
-    net_to_hidden<MT_MAX, NTL, PREFILL>(src, a.flat, net == 0 && a.has_scale ? a.s_net : a.t_net, n_hid, -1, wup, lane, q,
-                                        load_x, use_x, ht);
+    const NetDesc* const nds[2] = {&a.s_net, &a.t_net};
+    Hidden<MT_MAX, NTL> h2[2];
+    first_layer<MT_MAX, NTL, PREFILL, 2>(src, a.flat, nds, n_hid != 0, wup, lane, q, load_x, use_x, h2);
+    hs = h2[0];
+    ht = h2[1];
+    hidden_layers<MT_MAX, NTL, PREFILL>(src, a.flat, a.s_net, n_hid, -1, wup, lane, q, hs);
+    hidden_layers<MT_MAX, NTL, PREFILL>(src, a.flat, a.t_net, n_hid, -1, wup, lane, q, ht);
+  } else {
+#pragma unroll 1
+    for (int net = 0; net < n_nets; ++net) {
+      const bool copy = net == 0;
+      auto use_x = [&](int t, int ks, const f32x4& xa, const f32x4& xb) {
+        const int c0 = 32 * ks + 4 * q;
+        store4(yrow[t] + cond_off, c0, H, vec, live[t] && copy, xa);
+        store4(yrow[t] + cond_off, c0 + 16, H, vec, live[t] && copy, xb);
+        const float ss = xa[0] * xa[0] + xa[1] * xa[1] + xa[2] * xa[2] + xa[3] * xa[3] + xb[0] * xb[0] + xb[1] * xb[1] +
+                         xb[2] * xb[2] + xb[3] * xb[3];
+        sq[t] += copy ? ss : 0.f;
+      };
+      // (s_net, t_net are both filled: an absent net is a copy of the other one; net 0 = the first PRESENT net)
+      if (net == 1) hs = ht;  // (both nets present: the s-net's vector moves over, the t-net's takes its place)
+      net_to_hidden<MT_MAX, NTL, PREFILL>(src, a.flat, net == 0 && a.has_scale ? a.s_net : a.t_net, n_hid, -1, wup, lane, q,
+                                          load_x, use_x, ht);
+    }
   }
   const bool both = n_nets == 2;  // else the one present net's vector is in ht
 

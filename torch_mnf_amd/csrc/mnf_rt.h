@@ -413,95 +413,148 @@ struct NoLayerHook {
   __device__ __forceinline__ void operator()(int, const H&) const {}
 };
 
-template <int MT_MAX, int NTL, bool PREFILL, typename Src, typename LoadX, typename UseX, typename Hook = NoLayerHook>
-__device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict__ flat, const NetDesc& nd, int n_hid,
-                                              int no_act_layer, float wup, int lane, int q, const LoadX& load_x,
-                                              const UseX& use_x, Hidden<MT_MAX, NTL>& h, const Hook& hook = Hook()) {
-  constexpr int KS_MAX = MT_MAX / 2;
-  Acc<MT_MAX, NTL> acc;
-  // ---- layer 0: K-streamed
-  {
-    const int n_in = nd.sizes[0], n_out = nd.sizes[1];
-    const int KS = steps32(n_in), MT = tiles16(n_out);
-    int KC = src.cb / MT;  // K-steps per chunk
-    if (KC < 1) KC = 1;
-    if (Src::resident) KC = KS;
-    if (!PREFILL) acc.zero();
-    float down[NTL];  // the rows' running scale (a power of two <= 1)
+// NN nets of ONE shape reading the same input (AffineHalfFlow's s- and t-net): a chunk holds, per K-step, the MT blocks of
+// net 0, then those of net 1: digits (tile + MT * net, K-step - ks0); bias tiles likewise.
+template <int NN>
+struct DenseKMajorN {
+  const float* W[NN];
+  int n_in, n_out, MT, R0, ks0;  // R0 = NN * MT
+  static constexpr int R1 = 1 << 30;
+  __device__ __forceinline__ void load(int mm, int ksl, int, int i, int q, f32x4& va, f32x4& vb) const {
+    const int net = mm >= MT ? 1 : 0, m = mm - net * MT;  // (NN <= 2)
+    const float* Wn = W[NN > 1 ? net : 0];
+    const int o = 16 * m + i, c0 = 32 * (ks0 + ksl);
+    const bool aligned = (n_in & 3) == 0 && (reinterpret_cast<uintptr_t>(Wn) & 15) == 0;
+    load_row8(Wn + (int64_t)(o < n_out ? o : 0) * n_in, o < n_out, c0, n_in, aligned, q, va, vb);
+  }
+};
+template <int NN>
+struct DenseBiasN {
+  const float* b[NN];
+  int n_out, MT;
+  __device__ __forceinline__ float operator()(int t, int u) const {
+    const int net = t >= MT ? 1 : 0, o = 16 * (t - net * MT) + u;
+    const float v = b[NN > 1 ? net : 0][o < n_out ? o : 0];
+    return o < n_out ? v : 0.f;
+  }
+};
+
+// Layer 0 of NN nets of one shape over the same input, K-streamed: the input is loaded and split ONCE per K-step and
+// multiplied into every net's accumulators (NN = 2: AffineHalfFlow's s- and t-net at hidden widths <= 64 -- the input
+// side of a wide layer is most of its forward pass).  h[n] = H_1 of net n.
+template <int MT_MAX, int NTL, bool PREFILL, int NN, typename Src, typename LoadX, typename UseX, typename Hook = NoLayerHook>
+__device__ __forceinline__ void first_layer(Src& src, const float* __restrict__ flat, const NetDesc* const (&nds)[NN], bool act,
+                                            float wup, int lane, int q, const LoadX& load_x, const UseX& use_x,
+                                            Hidden<MT_MAX, NTL> (&h)[NN], const Hook& hook = Hook()) {
+  Acc<MT_MAX, NTL> acc[NN];
+  const NetDesc& nd = *nds[0];
+  const int n_in = nd.sizes[0], n_out = nd.sizes[1];
+  const int KS = steps32(n_in), MT = tiles16(n_out);
+  int KC = src.cb / (NN * MT);  // K-steps per chunk
+  if (KC < 1) KC = 1;
+  if (Src::resident) KC = KS;
+  if (!PREFILL) {
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) down[t] = 1.f;
-    // the input runs kRing K-steps ahead of the arithmetic in a register ring (a wave's 16 rows are 2 KB per K-step: a
-    // CU needs tens of KB in flight to cover HBM latency); past the end the last step is read again and dropped
-    f32x4 ra[kRing][NTL], rb[kRing][NTL];
-    if (!PREFILL) {
+    for (int n = 0; n < NN; ++n) acc[n].zero();
+  }
+  float down[NTL];  // the rows' running scale (a power of two <= 1)
 #pragma unroll
-      for (int u = 0; u < kRing; ++u)
+  for (int t = 0; t < NTL; ++t) down[t] = 1.f;
+  // the input runs kRing K-steps ahead of the arithmetic in a register ring (a wave's 16 rows are 2 KB per K-step: a
+  // CU needs tens of KB in flight to cover HBM latency); past the end the last step is read again and dropped
+  f32x4 ra[kRing][NTL], rb[kRing][NTL];
+  if (!PREFILL) {
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) load_x(t, u < KS ? u : KS - 1, ra[u][t], rb[u][t]);
-    }
-    Chunk c{nullptr, nullptr};
-    int next_start = 0, chunk_start = 0;
-    for (int ks_base = 0; ks_base < KS; ks_base += kRing) {
+    for (int u = 0; u < kRing; ++u)
 #pragma unroll
-      for (int u = 0; u < kRing; ++u) {
-        const int ks = ks_base + u;
-        if (ks < KS) {
-          if (ks == next_start) {  // (uniform) a new chunk of A blocks starts at this K-step
-            const int kc = KS - ks < KC ? KS - ks : KC;
-            c = src.template chunk<PREFILL>(kc * MT, DenseKMajor{flat + nd.w_off[0], n_in, n_out, MT, ks}, ks + kc == KS ? MT : 0,
-                                            DenseBias{flat + nd.b_off[0], n_out, 0});
-            chunk_start = ks;
-            next_start = ks + kc;
+      for (int t = 0; t < NTL; ++t) load_x(t, u < KS ? u : KS - 1, ra[u][t], rb[u][t]);
+  }
+  DenseKMajorN<NN> fetch;
+  DenseBiasN<NN> bias_fn;
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    fetch.W[n] = flat + nds[n]->w_off[0];
+    bias_fn.b[n] = flat + nds[n]->b_off[0];
+  }
+  fetch.n_in = n_in; fetch.n_out = n_out; fetch.MT = MT; fetch.R0 = NN * MT;
+  bias_fn.n_out = n_out; bias_fn.MT = MT;
+  Chunk c{nullptr, nullptr};
+  int next_start = 0, chunk_start = 0;
+  for (int ks_base = 0; ks_base < KS; ks_base += kRing) {
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) {
+      const int ks = ks_base + u;
+      if (ks < KS) {
+        if (ks == next_start) {  // (uniform) a new chunk of A blocks starts at this K-step
+          const int kc = KS - ks < KC ? KS - ks : KC;
+          fetch.ks0 = ks;
+          c = src.template chunk<PREFILL>(kc * NN * MT, fetch, ks + kc == KS ? NN * MT : 0, bias_fn);
+          chunk_start = ks;
+          next_start = ks + kc;
+        }
+        if (!PREFILL) {
+          f16x8 bh[NTL], bl[NTL];
+          f32x4 xa[NTL], xb[NTL];
+          float mx = 0.f;
+          const int ks_ahead = ks + kRing < KS ? ks + kRing : KS - 1;
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) {
+            xa[t] = ra[u][t];
+            xb[t] = rb[u][t];
+            load_x(t, ks_ahead, ra[u][t], rb[u][t]);
+            use_x(t, ks, xa[t], xb[t]);
+            split_kstep(xa[t], xb[t], down[t], bh[t], bl[t], mx);
           }
-          if (!PREFILL) {
-            f16x8 bh[NTL], bl[NTL];
-            f32x4 xa[NTL], xb[NTL];
-            float mx = 0.f;
-            const int ks_ahead = ks + kRing < KS ? ks + kRing : KS - 1;
+          if (__builtin_expect(wave_any(!(mx < kSplitLimit)), 0)) {
+            // rare: a row at or beyond the split range (or non-finite).  The row's accumulators and every later K-step
+            // of it move to a smaller power-of-two scale (exact); finish_layer multiplies the layer's result back
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
-              xa[t] = ra[u][t];
-              xb[t] = rb[u][t];
-              load_x(t, ks_ahead, ra[u][t], rb[u][t]);
-              use_x(t, ks, xa[t], xb[t]);
-              split_kstep(xa[t], xb[t], down[t], bh[t], bl[t], mx);
-            }
-            if (__builtin_expect(wave_any(!(mx < kSplitLimit)), 0)) {
-              // rare: a row at or beyond the split range (or non-finite).  The row's accumulators and every later K-step
-              // of it move to a smaller power-of-two scale (exact); finish_layer multiplies the layer's result back
+              float fm = 0.f;
 #pragma unroll
-              for (int t = 0; t < NTL; ++t) {
-                float fm = 0.f;
+              for (int r = 0; r < 4; ++r) fm = __builtin_fmaxf(fm, __builtin_fmaxf(finite_abs(xa[t][r]), finite_abs(xb[t][r])));
+              const float want = pow2f(-down_exponent(max_over_q(fm), 13));
+              if (want < down[t]) {
+                const float f = want / down[t];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) fm = __builtin_fmaxf(fm, __builtin_fmaxf(finite_abs(xa[t][r]), finite_abs(xb[t][r])));
-                const float want = pow2f(-down_exponent(max_over_q(fm), 13));
-                if (want < down[t]) {
-                  const float f = want / down[t];
+                for (int n = 0; n < NN; ++n)
 #pragma unroll
                   for (int m = 0; m < MT_MAX; ++m) {
-                    acc.main[t][m] *= f;
-                    acc.corr[t][m] *= f;
+                    acc[n].main[t][m] *= f;
+                    acc[n].corr[t][m] *= f;
                   }
-                  down[t] = want;
-                }
-                float unused = 0.f;
-                split_kstep(xa[t], xb[t], down[t], bh[t], bl[t], unused);
+                down[t] = want;
               }
+              float unused = 0.f;
+              split_kstep(xa[t], xb[t], down[t], bh[t], bl[t], unused);
             }
-            mac_kstep<MT_MAX, NTL>(c.A, (ks - chunk_start) * MT, MT, lane, bh, bl, acc.main, acc.corr);
           }
+#pragma unroll
+          for (int n = 0; n < NN; ++n)
+            mac_kstep<MT_MAX, NTL>(c.A, ((ks - chunk_start) * NN + n) * MT, MT, lane, bh, bl, acc[n].main, acc[n].corr);
         }
       }
     }
-    if (!PREFILL) {
-      float scale[NTL];
+  }
+  if (!PREFILL) {
+    float scale[NTL];
 #pragma unroll
-      for (int t = 0; t < NTL; ++t) scale[t] = wup / down[t];
-      finish_layer<MT_MAX, NTL>(acc, c.bias, MT, q, scale, no_act_layer != 0, h);
-      hook(1, h);
+    for (int t = 0; t < NTL; ++t) scale[t] = wup / down[t];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      finish_layer<MT_MAX, NTL>(acc[n], c.bias + 16 * n * MT, MT, q, scale, act, h[n]);
+      if (n == 0) hook(1, h[0]);
     }
   }
-  // ---- hidden -> hidden layers
+}
+
+// The hidden -> hidden layers 1 .. n_hid - 1 of one net in registers, from h = H_1 to h = H_{n_hid}.
+template <int MT_MAX, int NTL, bool PREFILL, typename Src, typename Hook = NoLayerHook>
+__device__ __forceinline__ void hidden_layers(Src& src, const float* __restrict__ flat, const NetDesc& nd, int n_hid,
+                                              int no_act_layer, float wup, int lane, int q, Hidden<MT_MAX, NTL>& h,
+                                              const Hook& hook = Hook()) {
+  constexpr int KS_MAX = MT_MAX / 2;
+  Acc<MT_MAX, NTL> acc;
   for (int l = 1; l < n_hid; ++l) {
     const int n_in = nd.sizes[l], n_out = nd.sizes[l + 1];
     const int KS = steps32(16 * tiles16(n_in)), MT = tiles16(n_out);
@@ -535,6 +588,17 @@ __device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict_
       hook(l + 1, h);
     }
   }
+}
+
+template <int MT_MAX, int NTL, bool PREFILL, typename Src, typename LoadX, typename UseX, typename Hook = NoLayerHook>
+__device__ __forceinline__ void net_to_hidden(Src& src, const float* __restrict__ flat, const NetDesc& nd, int n_hid,
+                                              int no_act_layer, float wup, int lane, int q, const LoadX& load_x,
+                                              const UseX& use_x, Hidden<MT_MAX, NTL>& h, const Hook& hook = Hook()) {
+  const NetDesc* const nds[1] = {&nd};
+  Hidden<MT_MAX, NTL> h1[1];
+  first_layer<MT_MAX, NTL, PREFILL, 1>(src, flat, nds, no_act_layer != 0, wup, lane, q, load_x, use_x, h1, hook);
+  h = h1[0];
+  hidden_layers<MT_MAX, NTL, PREFILL>(src, flat, nd, n_hid, no_act_layer, wup, lane, q, h, hook);
 }
 
 // One output tile from a last-hidden vector: the KS blocks at A + b0, bias tile `bias16` (16 floats), scale as in
