@@ -53,3 +53,17 @@ def test_built_assembly_passes_the_gate():
         assert check_vgpr_top.main(tile, 100, {"kernel_16_8_8": 144, "kernel_16_8_5": 176, "kernel_16_16_5": 172}) == 0
         assert check_agpr.main(tile, 0, {"kernel_32_8_8": 44, "kernel_32_8_5": 108, "kernel_32_16_8": 32, "kernel_32_16_5": 100,
                                          "kernel_16_8_10": 112, "kernel_16_16_10": 104, "kernel_16_16_8": 140}) == 0
+
+
+def test_library_size_stays_under_its_budget():
+    """The per-shape kernels are templates, and every instantiation is code in the library: round 5 ended at 11.7 MB, and
+    round 6 -- which added the six run-time-shaped kernels -- was asked to stay there (it pruned instantiations the new
+    kernels cover instead).  A build that grows past the budget should be a decision, not an accident."""
+    import torch_mnf_amd
+
+    path = torch_mnf_amd.library_path()
+    if not os.path.exists(path):
+        import pytest
+
+        pytest.skip("library not built")
+    assert os.path.getsize(path) <= 11_700_000, os.path.getsize(path)
