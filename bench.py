@@ -35,6 +35,9 @@ WORKLOADS = {
     "c4": (256, 1 << 19, "9xAffineHalfFlow d=256 batch=2^19/GPU inverse+log_prob (BASELINE configs[3]: 2^22 rows over "
                          "8 GPUs = this shard per GPU; at --gpus 8 the line IS configs[3])"),
     "c3": (32, 1 << 20, "3x[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob (BASELINE configs[2])"),
+    "c6": (512, 1 << 18, "9xAffineHalfFlow d=512 batch=2^18 inverse+log_prob: a shape without per-shape kernel (they end "
+                         "at d = 256), one launch per layer on the run-time-shaped matrix-core kernel (round 6: the "
+                         "any-shape path; round 5 ran this on the VALU kernel at 18 ns per row and layer)"),
     "c2f": (64, 1 << 20, "FusedAffineStack(9xAffineHalfFlow) d=64 batch=2^20 inverse+log_prob (opt-in whole-stack "
                          "fusion: no intermediates; reported separately from c2)"),
     "c3f": (32, 1 << 20, "3xFusedSplineBlock[ActNorm,Glow,NSF_CL] d=32 K=8 n_h=8 batch=2^20 inverse+log_prob "
@@ -902,7 +905,7 @@ def main_train_c3(args, rank, world, device, dim, rows, desc) -> None:
 
 
 # (key in `secondary`, workload, extra environment)
-SECONDARY = (("c3", "c3", {}), ("c4", "c4", {}), ("c5", "c5", {}), ("c5b", "c5b", {}), ("c1", "c1", {}),
+SECONDARY = (("c3", "c3", {}), ("c4", "c4", {}), ("c5", "c5", {}), ("c5b", "c5b", {}), ("c6", "c6", {}), ("c1", "c1", {}),
              ("c2_fp32", "c2", {"MNF_FP32_MFMA": "1"}),  # the headline on the strict fp32-MFMA stack kernel
              ("c2t", "c2t", {}), ("c3t", "c3t", {}), ("c5t", "c5t", {}), ("lenet", "lenet", {}))
 
@@ -1237,7 +1240,9 @@ def main() -> None:
                            if args.workload == "c3f" else f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<32,24,inverse> (9 layers per launch)"
                            if args.workload == "c2f" else
                            f"{AHF_KERNEL.replace('_kernel', '_stack_kernel')}<{dim // 2},24,inverse> ({span_dom} layers per launch, "
-                           "every intermediate written)" if span_dom > 1 else f"{AHF_KERNEL}<{dim // 2},24,inverse>"),
+                           "every intermediate written)" if span_dom > 1 else
+                           "ahf_rt_kernel<4,1,8,resident> (run-time-shaped: csrc/mnf_ahf_rt.hip; one layer per launch)"
+                           if args.workload == "c6" else f"{AHF_KERNEL}<{dim // 2},24,inverse>"),
                 "avg_kernel_us": avg_kernel_s * 1e6,
                 "median_kernel_us": kern_sorted[len(kern_sorted) // 2] * 1e3,
                 "min_kernel_us": kern_sorted[0] * 1e3,

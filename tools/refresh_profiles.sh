@@ -1,18 +1,18 @@
 #!/bin/bash
 # Regenerates a round's evidence on the GPU box into gpurun_out/$ROUND/ (copy what is to be judged into profiles/$ROUND/):
 # bench JSON lines, rocprofv3 kernel-trace + PMC summaries (every profiler run under `timeout`), PMC traffic files.
-# usage: [ROUND=r4] tools/refresh_profiles.sh [workloads...]   (default: c2 c3 c4 c5 c5b c2t c3t c5t)
+# usage: [ROUND=r4] tools/refresh_profiles.sh [workloads...]   (default: c2 c3 c4 c5 c5b c6 c2t c3t c5t)
 set -u
 ROUND=${ROUND:-r5}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd "$REPO"
-WL=${*:-c2 c3 c4 c5 c5b c2t c3t c5t}
+WL=${*:-c2 c3 c4 c5 c5b c6 c2t c3t c5t}
 declare -A KERN=( [c2]="ahf_split_stack_kernel<32, 24, true" [c4]="ahf_split_stack_kernel<128, 24, true" \
                   [c3]="nsf_mfma_kernel<16, 8, 8, true, 2, true" [c5]="rnvp_resident_kernel<50, 50, false" \
                   [c2t]="ahf_bwd_split_kernel<32, 24, true" [c5t]="rnvp_bwd_ts_shared_kernel<50, true, false" \
-                  [c3t]="nsf_bwd_tile_kernel" [c5b]="rnvp_narrow_kernel<50" )
+                  [c3t]="nsf_bwd_tile_kernel" [c5b]="rnvp_narrow_kernel<50" [c6]="ahf_rt_kernel<4, 1, 8, true, 1>" )
 declare -A MULT=( [c3t]=2 )
 for w in $WL; do
   extra=""; [ "$w" = c2 ] && extra="--no-secondary"
