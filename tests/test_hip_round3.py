@@ -526,13 +526,14 @@ def test_bench_lenet_training_step_line(amd):
 
 
 def test_bench_default_line_carries_the_other_configurations(amd):
-    """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c2t, c3t, c5t and the MNF-LeNet step as `secondary`
+    """The default (driver-run) invocation attaches 20-step runs of c3, c4, c5, c5b, c6, c2t, c3t, c5t and the MNF-LeNet step as `secondary`
     (only c2 used to be driver-observable), the per-step median / min and a one-thread CPU
     figure."""
     line = _run_bench("--steps", "5", "--warmup", "2", "--prime-ms", "5", "--no-cpu-baseline")
     assert line["config"]["workload"].startswith("9xAffineHalfFlow d=64")
     sec = line["secondary"]
-    assert set(sec) == {"c3", "c4", "c5", "c5b", "c1", "c2_fp32", "c2t", "c3t", "c5t", "lenet"}
+    assert set(sec) == {"c3", "c4", "c5", "c5b", "c6", "c1", "c2_fp32", "c2t", "c3t", "c5t", "lenet"}
+    assert "ahf_rt" in sec["c6"]["kernel"]  # (round 6: a shape without per-shape kernel, on the run-time-shaped one)
     for w, d in sec.items():
         assert "error" not in d, (w, d)
         assert d["ms_per_step"] > 0 and (w == "c1" or d["bound"] in ("hbm", "valu", "mfma")), (w, d)
