@@ -7,7 +7,8 @@ the gradients -- with the layer forced onto them (force_generic = 2) against the
 referee (autograd through the oracle's formulas in float64 on the CPU): neither result may be more than twice as far from
 it as the other, or 5e-5.  A disagreement that one or two rows carry alone -- a pre-activation within fp32 rounding of a
 LeakyReLU kink, where two correct evaluations take different derivatives; about one draw in a hundred -- is confirmed
-by repeating the case without those rows' cotangents.  Not a pytest (minutes of GPU time; the file name keeps it out of the collection)
+by repeating the case without those rows' cotangents.  (Split arithmetic carries ~22 bits per product against fp32's 24,
+so of two correct kernels the run-time-shaped one is the one on the other side of the kink three times out of four.)  Not a pytest (minutes of GPU time; the file name keeps it out of the collection)
 but test infrastructure -- it lives here because it uses oracle/ as the referee, which only tests may.  Exits non-zero on
 a mismatch.
 
